@@ -1,0 +1,211 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into, imported by or called from the product path.
+//
+// ref_shim_me.cpp: drives the REAL reference motion search (VTM 9.3 EncoderLib/InterSearch.cpp, compiled in
+// place by oracle/Makefile.ref) on caller-supplied sample planes, so that the C restatement in
+// oracle/vtm_oracle.c (vo_tz_search / vo_full_search / vo_frac_search) and the HIP search kernels can be
+// pinned against the reference's own decisions:
+//   InterSearch::xTZSearch             EncoderLib/InterSearch.cpp:3640-3976
+//   InterSearch::xSetSearchRange       :3496-3563
+//   InterSearch::xPatternSearch        :3566-3608
+//   InterSearch::xPatternSearchFracDIF :4284-4339 (+ xExtDIFUpSamplingH/Q :5840-6051, xPatternRefinement :707-761)
+// Nothing here is reference source: it builds the minimum object graph those members read
+// (SPS/PPS picture size, CodingUnit/PredictionUnit position, EncCfg switches, RdCost lambda/predictor)
+// and calls them (compiled with -fno-access-control: they are protected members).
+#include "CommonLib/CommonDef.h"
+#include "CommonLib/Unit.h"
+#include "CommonLib/Slice.h"
+#include "CommonLib/CodingStructure.h"
+#include "CommonLib/RdCost.h"
+#include "CommonLib/Mv.h"
+#include "EncoderLib/EncCfg.h"
+#include "EncoderLib/InterSearch.h"
+
+#include <cstdint>
+#include <cstring>
+
+namespace
+{
+struct MeRig
+{
+  SPS             sps;
+  PPS             pps;
+  Slice           slice;
+  CUCache         cuCache;
+  PUCache         puCache;
+  TUCache         tuCache;
+  CodingStructure cs;
+  CodingUnit      cu;
+  PredictionUnit  pu;
+  EncCfg          cfg;
+  RdCost          rd;
+  InterSearch     is;
+  BlkUniMvInfo    uniMv[16];
+
+  MeRig() : cs( cuCache, puCache, tuCache )
+  {
+    clipMv = clipMvInPic;   // what EncLib installs when there are no sub-pictures (EncLib.cpp)
+    cs.sps   = &sps;
+    cs.pps   = &pps;
+    cs.slice = &slice;
+    cu.cs    = &cs;
+    cu.slice = &slice;
+    pu.cs    = &cs;
+    pu.cu    = &cu;
+    cu.imv   = 0;
+    pps.m_numSubPics = 1;
+    pps.m_subPics.resize( 1 );
+    pps.m_subPics[0].setTreatedAsPicFlag( false );
+    pps.setWrapAroundEnabledFlag( false );
+    sps.setWrapAroundEnabledFlag( false );
+    cfg.setMCTSEncConstraint( false );
+    cfg.setUseHashME( false );
+    cfg.setUseHADME( true );
+    cfg.setFastMEAssumingSmootherMVEnabled( true );
+    cfg.setClipForBiPredMeEnabled( false );
+    slice.setDisableSATDForRD( false );
+    is.m_pcEncCfg      = &cfg;
+    is.m_pcRdCost      = &rd;
+    is.m_useCompositeRef = false;
+    is.m_skipFracME    = false;
+    is.m_currChromaFormat = CHROMA_420;
+    is.m_uniMvList        = uniMv;
+    is.m_uniMvListMaxSize = 15;
+    is.m_uniMvListSize    = 0;
+    is.m_uniMvListIdx     = 0;
+    is.m_currRefPicList   = REF_PIC_LIST_0;
+    is.m_currRefPicIndex  = 0;
+    is.m_if.initInterpolationFilter( true );
+    // m_filteredBlock / m_filteredBlockTmp as InterPrediction::init allocates them (InterPrediction.cpp:150-176)
+    const int extW = MAX_CU_SIZE + 16, extH = MAX_CU_SIZE + 1 + 16;
+    for( int i = 0; i < 4; i++ )
+    {
+      is.m_filteredBlockTmp[i][0] = ( Pel * ) xMalloc( Pel, ( extW + 4 ) * ( extH + 7 + 4 ) );
+      for( int j = 0; j < 4; j++ ) is.m_filteredBlock[i][j][0] = ( Pel * ) xMalloc( Pel, extW * extH );
+    }
+  }
+};
+
+MeRig *g_rig = nullptr;
+
+struct MeCtxC   // must match vo_me_ctx_t (oracle/vtm_oracle.h)
+{
+  const int16_t *org; int orgStride; const int16_t *ref; int refStride; int w, h, subShift, bitDepth; unsigned imvShift;
+  struct { double motionLambda; int predHor, predVer, costScale; } mv;   // vo_mvcost_t (nested: keeps its tail padding)
+  int picW, picH, puX, puY, ctuSize;
+};
+struct TzJobC   // vo_tz_job_t
+{
+  int mvHor, mvVer, searchRange, extendedSettings, fastSettings, firstSearchStop, hasInt, intHor, intVer, numExtra; int extra[16][2];
+};
+struct MeResC { int mvX, mvY; uint64_t cost, dist, nEval; };
+struct FracResC { int halfX, halfY, qterX, qterY; uint64_t costHalf, cost, candHalf[9], candQuarter[9]; };
+
+void setup( MeRig &r, const MeCtxC &c, InterSearch::IntTZSearchStruct &st, CPelBuf &pattern )
+{
+  r.sps.setMaxCUWidth( c.ctuSize );
+  r.sps.setMaxCUHeight( c.ctuSize );
+  r.pps.setPicWidthInLumaSamples( c.picW );
+  r.pps.setPicHeightInLumaSamples( c.picH );
+  const UnitArea ua( CHROMA_420, Area( c.puX, c.puY, c.w, c.h ) );
+  r.cu.UnitArea::operator=( ua );
+  r.pu.UnitArea::operator=( ua );
+  r.cu.chromaFormat = CHROMA_420;
+  r.pu.chromaFormat = CHROMA_420;
+  r.rd.m_motionLambda = c.mv.motionLambda;
+  r.rd.setPredictor( Mv( c.mv.predHor, c.mv.predVer ) );
+  r.rd.setCostScale( c.mv.costScale );
+  r.is.m_lumaClpRng.min = 0;
+  r.is.m_lumaClpRng.max = ( 1 << c.bitDepth ) - 1;
+  r.is.m_lumaClpRng.bd  = c.bitDepth;
+  r.is.m_lumaClpRng.n   = 0;
+  pattern               = CPelBuf( c.org, c.orgStride, c.w, c.h );
+  st.pcPatternKey = &pattern;
+  st.iRefStride   = c.refStride;
+  st.piRefY       = c.ref;
+  st.imvShift     = c.imvShift;
+  st.useAltHpelIf = false;
+  st.inCtuSearch  = false;
+  st.zeroMV       = false;
+  // subShiftMode: 2 reproduces the CTC FEN=1 rule; we pass the mode that yields c.subShift for this block
+  st.subShiftMode = c.subShift ? ( ( c.h > 8 && c.w <= 64 ) ? 2 : 3 ) : 0;
+}
+}   // namespace
+
+extern "C"
+{
+
+void ref_tz_search( const MeCtxC *c, const TzJobC *job, MeResC *res )
+{
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  InterSearch::IntTZSearchStruct st;
+  CPelBuf pattern;
+  setup( r, *c, st, pattern );
+  r.cfg.setFastMEAssumingSmootherMVEnabled( job->firstSearchStop != 0 );
+  r.is.m_iSearchRange = job->searchRange;
+  r.is.m_uniMvListSize = job->numExtra;
+  r.is.m_uniMvListIdx  = job->numExtra % 15;
+  // candidate i is read from slot (idx - 1 - i) mod max (InterSearch.cpp:3728)
+  for( int i = 0; i < job->numExtra; i++ )
+  {
+    const int slot = ( r.is.m_uniMvListIdx - 1 - i + 15 ) % 15;
+    r.uniMv[slot].uniMvs[0][0] = Mv( job->extra[i][0], job->extra[i][1] );
+  }
+  Mv         rcMv( job->mvHor, job->mvVer );
+  Mv         intPred( job->intHor, job->intVer );
+  Distortion sad = 0;
+  r.is.xTZSearch( r.pu, REF_PIC_LIST_0, 0, st, rcMv, sad, job->hasInt ? &intPred : nullptr, job->extendedSettings != 0, job->fastSettings != 0 );
+  res->mvX   = rcMv.hor;
+  res->mvY   = rcMv.ver;
+  res->cost  = st.uiBestSad;
+  res->dist  = sad;
+  res->nEval = 0;
+  r.is.m_uniMvListSize = 0;
+}
+
+void ref_set_search_range( const MeCtxC *c, int predHor, int predVer, int range, int out[4] )
+{
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  InterSearch::IntTZSearchStruct st;
+  CPelBuf pattern;
+  setup( r, *c, st, pattern );
+  InterSearch::SearchRange sr;
+  r.is.xSetSearchRange( r.pu, Mv( predHor, predVer ), range, sr, st );
+  out[0] = sr.left; out[1] = sr.right; out[2] = sr.top; out[3] = sr.bottom;
+}
+
+void ref_full_search( const MeCtxC *c, const int range[4], MeResC *res )
+{
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  InterSearch::IntTZSearchStruct st;
+  CPelBuf pattern;
+  setup( r, *c, st, pattern );
+  st.searchRange.left = range[0]; st.searchRange.right = range[1]; st.searchRange.top = range[2]; st.searchRange.bottom = range[3];
+  Mv         mv;
+  Distortion sad = 0;
+  r.is.xPatternSearch( st, mv, sad );
+  res->mvX = mv.hor; res->mvY = mv.ver; res->cost = st.uiBestSad; res->dist = sad; res->nEval = 0;
+}
+
+void ref_frac_search( const MeCtxC *c, int intX, int intY, int useHad, int useAltHpelIf, FracResC *res )
+{
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  InterSearch::IntTZSearchStruct st;
+  CPelBuf pattern;
+  setup( r, *c, st, pattern );
+  st.useAltHpelIf = useAltHpelIf != 0;
+  r.cfg.setUseHADME( useHad != 0 );
+  Mv         mvInt( intX, intY ), mvHalf, mvQter;
+  Distortion cost = 0;
+  r.is.xPatternSearchFracDIF( r.pu, REF_PIC_LIST_0, 0, st, mvInt, mvHalf, mvQter, cost );
+  res->halfX = mvHalf.hor; res->halfY = mvHalf.ver; res->qterX = mvQter.hor; res->qterY = mvQter.ver;
+  res->cost  = cost; res->costHalf = 0;
+  memset( res->candHalf, 0, sizeof( res->candHalf ) );
+  memset( res->candQuarter, 0, sizeof( res->candQuarter ) );
+  r.cfg.setUseHADME( true );
+}
+
+}   // extern "C"

@@ -1,0 +1,1137 @@
+/*
+ * vtm_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the VTM 9.3 inter motion-estimation + transform/quant hot path
+ * (SURVEY.md section 8a).  It is the *checker* for the HIP kernels: only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path (vtm_amd/, libvtmhip.so) never does.
+ *
+ * Parity status: PINNED.  Every function below is compared against the real reference compiled from
+ * /root/reference by oracle/Makefile.ref (oracle/_ref/libvtmref.so, tests/test_oracle_vs_ref.py) and
+ * against the golden vectors that tests/golden/gen_golden.py recorded from that build.
+ *
+ * Each function cites the reference file:line whose arithmetic it restates.  Paths are relative to
+ * /root/reference/source/Lib.  Types: Pel = int16_t, TCoeff = int32_t, Distortion = uint64_t
+ * (CommonLib/TypeDef.h:259-270, high-bit-depth OFF).
+ */
+#include "vtm_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define VO_MAX_TB 64
+
+static inline int vo_abs( int v ) { return v < 0 ? -v : v; }
+static inline int vo_clip3( int lo, int hi, int v ) { return v < lo ? lo : ( v > hi ? hi : v ); }
+static inline int vo_floor_log2( unsigned v )
+{
+  int r = -1;
+  while( v ) { v >>= 1; r++; }
+  return r;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K1  SAD   CommonLib/RdCost.cpp:493-528 (generic), :530-1003 (width-specialised, same arithmetic),
+ *           SIMD x86/RdCostX86.h:210-301.  Rows are visited with step 1<<subShift, the sum is shifted
+ *           back left; DISTORTION_PRECISION_ADJUSTMENT is 0 (TypeDef.h:228-233).  The scalar early
+ *           exit (:516-519) is not restated: the SIMD path never takes it and callers compare with '<'.
+ * ------------------------------------------------------------------------------------------------ */
+uint64_t vo_sad( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h, int subShift )
+{
+  const int step = 1 << subShift;
+  uint64_t  sum  = 0;
+  for( int y = 0; y < h; y += step )
+  {
+    const int16_t *o = org + ( ptrdiff_t ) y * orgStride;
+    const int16_t *c = cur + ( ptrdiff_t ) y * curStride;
+    for( int x = 0; x < w; x++ )
+    {
+      sum += ( uint64_t ) vo_abs( ( int ) o[x] - ( int ) c[x] );
+    }
+  }
+  return sum << subShift;
+}
+
+/* RdCost::setDistParam subShift rule, CommonLib/RdCost.cpp:289-323 */
+int vo_subshift_for_mode( int w, int h, int subShiftMode )
+{
+  if( subShiftMode == 1 )
+  {
+    if( h > 32 && ( h & 15 ) == 0 ) return 4;
+    if( h > 16 && ( h & 7 ) == 0 ) return 3;
+    if( h > 8 && ( h & 3 ) == 0 ) return 2;
+    if( ( h & 1 ) == 0 ) return 1;
+    return 0;
+  }
+  if( subShiftMode == 2 ) return ( h > 8 && w <= 64 ) ? 1 : 0;
+  if( subShiftMode == 3 ) return ( h > 8 ) ? 1 : 0;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K4  SSE   CommonLib/RdCost.cpp:1783-1814: per-addend (d*d) >> 0 in 32-bit, 64-bit sum.
+ * ------------------------------------------------------------------------------------------------ */
+uint64_t vo_sse( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h )
+{
+  uint64_t sum = 0;
+  for( int y = 0; y < h; y++ )
+  {
+    for( int x = 0; x < w; x++ )
+    {
+      const int32_t d = ( int32_t ) org[( ptrdiff_t ) y * orgStride + x] - ( int32_t ) cur[( ptrdiff_t ) y * curStride + x];
+      sum += ( uint64_t )( uint32_t )( d * d );
+    }
+  }
+  return sum;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K2  SATD  CommonLib/RdCost.cpp:2140-2934.
+ *   One tile = 2-D Walsh-Hadamard of (org - cur); t = sum|coef| - |dc| + (|dc| >> 2)
+ *   (JVET_R0164_MEAN_SCALED_SATD, TypeDef.h:62); per-tile normalisation:
+ *     2x2: t (only the dc term is >>2, :2154-2162)   4x4: (t+1)>>1 (:2258-2262)   8x8: (t+2)>>2 (:2359-2363)
+ *     16x8 / 8x16: (int)(t / sqrt(16.0*8) * 2) (:2513,2654)    8x4 / 4x8: (int)(t / sqrt(4.0*8) * 2) (:2731,2814)
+ *   Tile selection: xGetHADs :2819-2934.
+ *   The butterfly order is free: only the multiset of |coef| and coef[0][0] = sum(diff) matter.
+ * ------------------------------------------------------------------------------------------------ */
+static int vo_had_tile_abs_sum( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int tw, int th )
+{
+  int32_t m[16 * 16];
+  for( int y = 0; y < th; y++ )
+    for( int x = 0; x < tw; x++ )
+      m[y * tw + x] = ( int32_t ) org[( ptrdiff_t ) y * orgStride + x] - ( int32_t ) cur[( ptrdiff_t ) y * curStride + x];
+
+  /* in-place WHT along x, then along y (natural/Hadamard order, dc at [0]) */
+  for( int y = 0; y < th; y++ )
+    for( int len = 1; len < tw; len <<= 1 )
+      for( int i = 0; i < tw; i += len << 1 )
+        for( int j = i; j < i + len; j++ )
+        {
+          const int32_t a = m[y * tw + j], b = m[y * tw + j + len];
+          m[y * tw + j]       = a + b;
+          m[y * tw + j + len] = a - b;
+        }
+  for( int x = 0; x < tw; x++ )
+    for( int len = 1; len < th; len <<= 1 )
+      for( int i = 0; i < th; i += len << 1 )
+        for( int j = i; j < i + len; j++ )
+        {
+          const int32_t a = m[j * tw + x], b = m[( j + len ) * tw + x];
+          m[j * tw + x]           = a + b;
+          m[( j + len ) * tw + x] = a - b;
+        }
+  int t = 0;
+  for( int i = 0; i < tw * th; i++ ) t += vo_abs( m[i] );
+  const int dc = vo_abs( m[0] );
+  return t - dc + ( dc >> 2 );
+}
+
+static uint64_t vo_had_tile( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int tw, int th )
+{
+  const int t = vo_had_tile_abs_sum( org, orgStride, cur, curStride, tw, th );
+  if( tw == 2 && th == 2 ) return ( uint64_t ) t;
+  if( tw == 4 && th == 4 ) return ( uint64_t )( ( t + 1 ) >> 1 );
+  if( tw == 8 && th == 8 ) return ( uint64_t )( ( t + 2 ) >> 2 );
+  if( tw * th == 128 ) return ( uint64_t )( int ) ( t / sqrt( 16.0 * 8 ) * 2 );
+  /* 8x4, 4x8 */
+  return ( uint64_t )( int ) ( t / sqrt( 4.0 * 8 ) * 2 );
+}
+
+/* Tile shape chosen by xGetHADs (RdCost.cpp:2837-2931).  Returns 0 and sets *tw,*th; -1 = "Invalid size". */
+int vo_satd_tile_shape( int w, int h, int *tw, int *th )
+{
+  if( w > h && ( h & 7 ) == 0 && ( w & 15 ) == 0 ) { *tw = 16; *th = 8; }
+  else if( w < h && ( w & 7 ) == 0 && ( h & 15 ) == 0 ) { *tw = 8; *th = 16; }
+  else if( w > h && ( h & 3 ) == 0 && ( w & 7 ) == 0 ) { *tw = 8; *th = 4; }
+  else if( w < h && ( w & 3 ) == 0 && ( h & 7 ) == 0 ) { *tw = 4; *th = 8; }
+  else if( ( h % 8 == 0 ) && ( w % 8 == 0 ) ) { *tw = 8; *th = 8; }
+  else if( ( h % 4 == 0 ) && ( w % 4 == 0 ) ) { *tw = 4; *th = 4; }
+  else if( ( h % 2 == 0 ) && ( w % 2 == 0 ) ) { *tw = 2; *th = 2; }
+  else return -1;
+  return 0;
+}
+
+uint64_t vo_satd( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h )
+{
+  int tw, th;
+  if( vo_satd_tile_shape( w, h, &tw, &th ) ) return UINT64_MAX;
+  uint64_t sum = 0;
+  for( int y = 0; y < h; y += th )
+    for( int x = 0; x < w; x += tw )
+      sum += vo_had_tile( org + ( ptrdiff_t ) y * orgStride + x, orgStride, cur + ( ptrdiff_t ) y * curStride + x, curStride, tw, th );
+  return sum;
+}
+
+/* SATD 8x8 block grid x (2r+1)^2 displacements: the SURVEY.md 8(d) micro-benchmark, same output layout as
+ * ref_satd8_grid / vtmhip_satd8_grid. */
+void vo_satd8_grid( const int16_t *org, int orgStride, const int16_t *ref, int refStride, int w, int h, int r, uint64_t *out )
+{
+  const int bw = w / 8, bh = h / 8, nd = 2 * r + 1;
+  for( int by = 0; by < bh; by++ )
+    for( int bx = 0; bx < bw; bx++ )
+    {
+      const int16_t *o  = org + ( ptrdiff_t ) by * 8 * orgStride + bx * 8;
+      const int16_t *c  = ref + ( ptrdiff_t ) by * 8 * refStride + bx * 8;
+      uint64_t      *po = out + ( size_t )( by * bw + bx ) * nd * nd;
+      for( int dy = -r; dy <= r; dy++ )
+        for( int dx = -r; dx <= r; dx++ )
+          *po++ = vo_had_tile( o, orgStride, c + ( ptrdiff_t ) dy * refStride + dx, refStride, 8, 8 );
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * MV rate  CommonLib/RdCost.h:301-315.  bits(v): exp-Golomb length of the signed value; the loop
+ * form strips MAX_CU_DEPTH(7) bits at a time while temp > MAX_CU_SIZE(128).
+ * cost = (uint64)(motionLambda * bits), fp64 multiply then truncation.
+ * ------------------------------------------------------------------------------------------------ */
+static unsigned vo_eg_bits( int v )
+{
+  unsigned len = 1;
+  unsigned t   = ( v <= 0 ) ? ( ( unsigned ) ( -v ) << 1 ) + 1 : ( unsigned ) ( v << 1 );
+  while( t > 128 )
+  {
+    len += 14;
+    t >>= 7;
+  }
+  return len + ( ( unsigned ) vo_floor_log2( t ) << 1 );
+}
+
+unsigned vo_mv_bits( const vo_mvcost_t *mc, int x, int y, unsigned imvShift )
+{
+  return vo_eg_bits( ( ( x << mc->costScale ) - mc->predHor ) >> imvShift ) + vo_eg_bits( ( ( y << mc->costScale ) - mc->predVer ) >> imvShift );
+}
+
+uint64_t vo_mv_cost( const vo_mvcost_t *mc, int x, int y, unsigned imvShift )
+{
+  return ( uint64_t ) ( mc->motionLambda * vo_mv_bits( mc, x, y, imvShift ) );
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K7/K8 Interpolation  CommonLib/InterpolationFilter.cpp:398-525 (copy), :548-651 (FIR),
+ *       tap tables :57-330 (H.266 8.5.6.3 tables 27/28 constants), dispatch :749-891.
+ * ------------------------------------------------------------------------------------------------ */
+#define VO_IF_PREC 14
+#define VO_IF_OFFS ( 1 << ( VO_IF_PREC - 1 ) )
+#define VO_IF_FILTER_PREC 6
+
+/* H.266 luma 1/16-sample 8-tap filter (InterpolationFilter.cpp:77-95) */
+const int16_t vo_luma_filter[16][8] = {
+  { 0, 0, 0, 64, 0, 0, 0, 0 },       { 0, 1, -3, 63, 4, -2, 1, 0 },     { -1, 2, -5, 62, 8, -3, 1, 0 },    { -1, 3, -8, 60, 13, -4, 1, 0 },
+  { -1, 4, -10, 58, 17, -5, 1, 0 },  { -1, 4, -11, 52, 26, -8, 3, -1 }, { -1, 3, -9, 47, 31, -10, 4, -1 }, { -1, 4, -11, 45, 34, -10, 4, -1 },
+  { -1, 4, -11, 40, 40, -11, 4, -1 },{ -1, 4, -10, 34, 45, -11, 4, -1 },{ -1, 4, -10, 31, 47, -9, 3, -1 }, { -1, 3, -8, 26, 52, -11, 4, -1 },
+  { 0, 1, -5, 17, 58, -10, 4, -1 },  { 0, 1, -4, 13, 60, -8, 3, -1 },   { 0, 1, -3, 8, 62, -5, 2, -1 },    { 0, 1, -2, 4, 63, -3, 1, 0 } };
+
+/* 6-tap variant used for 4x4 (affine sub-)blocks (InterpolationFilter.cpp:57-75) */
+const int16_t vo_luma_filter_4x4[16][8] = {
+  { 0, 0, 0, 64, 0, 0, 0, 0 },      { 0, 1, -3, 63, 4, -2, 1, 0 },    { 0, 1, -5, 62, 8, -3, 1, 0 },    { 0, 2, -8, 60, 13, -4, 1, 0 },
+  { 0, 3, -10, 58, 17, -5, 1, 0 },  { 0, 3, -11, 52, 26, -8, 2, 0 },  { 0, 2, -9, 47, 31, -10, 3, 0 },  { 0, 3, -11, 45, 34, -10, 3, 0 },
+  { 0, 3, -11, 40, 40, -11, 3, 0 }, { 0, 3, -10, 34, 45, -11, 3, 0 }, { 0, 3, -10, 31, 47, -9, 2, 0 },  { 0, 2, -8, 26, 52, -11, 3, 0 },
+  { 0, 1, -5, 17, 58, -10, 3, 0 },  { 0, 1, -4, 13, 60, -8, 2, 0 },   { 0, 1, -3, 8, 62, -5, 1, 0 },    { 0, 1, -2, 4, 63, -3, 1, 0 } };
+
+const int16_t vo_luma_alt_hpel[8] = { 0, 3, 9, 20, 20, 9, 3, 0 };   /* InterpolationFilter.cpp:181 */
+
+/* H.266 chroma 1/32-sample 4-tap filter (InterpolationFilter.cpp:182-216) */
+const int16_t vo_chroma_filter[32][4] = {
+  { 0, 64, 0, 0 },    { -1, 63, 2, 0 },   { -2, 62, 4, 0 },   { -2, 60, 7, -1 },  { -2, 58, 10, -2 }, { -3, 57, 12, -2 }, { -4, 56, 14, -2 }, { -4, 55, 15, -2 },
+  { -4, 54, 16, -2 }, { -5, 53, 18, -2 }, { -6, 52, 20, -2 }, { -6, 49, 24, -3 }, { -6, 46, 28, -4 }, { -5, 44, 29, -4 }, { -4, 42, 30, -4 }, { -4, 39, 33, -4 },
+  { -4, 36, 36, -4 }, { -4, 33, 39, -4 }, { -4, 30, 42, -4 }, { -4, 29, 44, -5 }, { -4, 28, 46, -6 }, { -3, 24, 49, -6 }, { -2, 20, 52, -6 }, { -2, 18, 53, -5 },
+  { -2, 16, 54, -4 }, { -2, 15, 55, -4 }, { -2, 14, 56, -4 }, { -2, 12, 57, -3 }, { -2, 10, 58, -2 }, { -1, 7, 60, -2 },  { 0, 4, 62, -2 },   { 0, 2, 63, -1 } };
+
+/* bilinear, 4-bit precision: { 16 - f, f } (InterpolationFilter.cpp:312-330); DMVR / BDOF only */
+static void vo_bilinear_prec4( int frac, int16_t c[2] ) { c[0] = ( int16_t )( 16 - frac ); c[1] = ( int16_t ) frac; }
+
+void vo_if_copy( int isFirst, int isLast, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int w, int h, int bitDepth, int clipMin,
+                 int clipMax, int biMCForDMVR )
+{
+  const int headRoom = ( VO_IF_PREC - bitDepth ) > 2 ? ( VO_IF_PREC - bitDepth ) : 2;   /* IF_INTERNAL_FRAC_BITS, InterpolationFilter.h:54 */
+  for( int y = 0; y < h; y++, src += srcStride, dst += dstStride )
+  {
+    for( int x = 0; x < w; x++ )
+    {
+      const int s = src[x];
+      if( isFirst == isLast )
+      {
+        dst[x] = ( int16_t ) s;
+      }
+      else if( biMCForDMVR )
+      {
+        /* both directions identical: :417-447 and :470-500 (IF_INTERNAL_PREC_BILINEAR = 10) */
+        if( bitDepth > 10 )
+        {
+          const int sh = bitDepth - 10;
+          dst[x]       = ( int16_t )( ( s + ( 1 << ( sh - 1 ) ) ) >> sh );
+        }
+        else
+        {
+          dst[x] = ( int16_t )( s << ( 10 - bitDepth ) );
+        }
+      }
+      else if( isFirst )
+      {
+        const int16_t v = ( int16_t )( s << headRoom );   /* Pel val = leftShift_round(src, shift) */
+        dst[x]          = ( int16_t )( v - ( int16_t ) VO_IF_OFFS );
+      }
+      else
+      {
+        const int16_t v = ( int16_t )( ( s + VO_IF_OFFS + ( 1 << ( headRoom - 1 ) ) ) >> headRoom );
+        dst[x]          = ( int16_t ) vo_clip3( clipMin, clipMax, v );
+      }
+    }
+  }
+}
+
+void vo_if_filter( int vertical, int taps, int isFirst, int isLast, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int w, int h,
+                   const int16_t *coeff, int bitDepth, int clipMin, int clipMax, int biMCForDMVR )
+{
+  const int cStride  = vertical ? srcStride : 1;
+  const int headRoom = ( VO_IF_PREC - bitDepth ) > 2 ? ( VO_IF_PREC - bitDepth ) : 2;
+  int       shift    = VO_IF_FILTER_PREC;
+  int       offset;
+  src -= ( taps / 2 - 1 ) * cStride;
+  if( isLast )
+  {
+    shift += isFirst ? 0 : headRoom;
+    offset = 1 << ( shift - 1 );
+    offset += isFirst ? 0 : ( VO_IF_OFFS << VO_IF_FILTER_PREC );
+  }
+  else
+  {
+    shift -= isFirst ? headRoom : 0;
+    offset = isFirst ? -( VO_IF_OFFS << shift ) : 0;
+  }
+  if( biMCForDMVR )
+  {
+    shift  = isFirst ? 4 - ( 10 - bitDepth ) : 4;   /* IF_FILTER_PREC_BILINEAR - (IF_INTERNAL_PREC_BILINEAR - bd) */
+    offset = 1 << ( shift - 1 );
+  }
+  for( int y = 0; y < h; y++, src += srcStride, dst += dstStride )
+  {
+    for( int x = 0; x < w; x++ )
+    {
+      int sum = 0;
+      for( int k = 0; k < taps; k++ ) sum += ( int ) src[x + k * cStride] * ( int ) coeff[k];
+      int16_t val = ( int16_t )( ( sum + offset ) >> shift );   /* truncation to Pel happens before the clip (:645) */
+      if( isLast ) val = ( int16_t ) vo_clip3( clipMin, clipMax, val );
+      dst[x] = val;
+    }
+  }
+}
+
+/* public filterHor (InterpolationFilter.cpp:749-812): isFirst is implicitly true */
+void vo_if_hor( int compID, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int w, int h, int frac, int isLast, int bitDepth,
+                int nFilterIdx, int biMCForDMVR, int useAltHpelIf )
+{
+  const int clipMax = ( 1 << bitDepth ) - 1;
+  int16_t   bil[2];
+  if( frac == 0 && nFilterIdx < 2 )
+  {
+    vo_if_copy( 1, isLast, src, srcStride, dst, dstStride, w, h, bitDepth, 0, clipMax, biMCForDMVR );
+    return;
+  }
+  const int16_t *c;
+  int            taps = 8;
+  if( compID == 0 )
+  {
+    if( nFilterIdx == 1 ) { vo_bilinear_prec4( frac, bil ); c = bil; taps = 2; }
+    else if( nFilterIdx == 2 ) c = vo_luma_filter_4x4[frac];
+    else if( frac == 8 && useAltHpelIf ) c = vo_luma_alt_hpel;
+    else if( ( w == 4 && h == 4 ) || ( w == 4 && h == 4 + 8 - 1 ) ) c = vo_luma_filter_4x4[frac];
+    else c = vo_luma_filter[frac];
+  }
+  else
+  {
+    c    = vo_chroma_filter[frac];   /* 4:2:0: frac << (1 - csx) with csx = 1 */
+    taps = 4;
+  }
+  vo_if_filter( 0, taps, 1, isLast, src, srcStride, dst, dstStride, w, h, c, bitDepth, 0, clipMax, biMCForDMVR );
+}
+
+/* public filterVer (InterpolationFilter.cpp:832-891) */
+void vo_if_ver( int compID, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int w, int h, int frac, int isFirst, int isLast,
+                int bitDepth, int nFilterIdx, int biMCForDMVR, int useAltHpelIf )
+{
+  const int clipMax = ( 1 << bitDepth ) - 1;
+  int16_t   bil[2];
+  if( frac == 0 && nFilterIdx < 2 )
+  {
+    vo_if_copy( isFirst, isLast, src, srcStride, dst, dstStride, w, h, bitDepth, 0, clipMax, biMCForDMVR );
+    return;
+  }
+  const int16_t *c;
+  int            taps = 8;
+  if( compID == 0 )
+  {
+    if( nFilterIdx == 1 ) { vo_bilinear_prec4( frac, bil ); c = bil; taps = 2; }
+    else if( nFilterIdx == 2 ) c = vo_luma_filter_4x4[frac];
+    else if( frac == 8 && useAltHpelIf ) c = vo_luma_alt_hpel;
+    else if( w == 4 && h == 4 ) c = vo_luma_filter_4x4[frac];
+    else c = vo_luma_filter[frac];
+  }
+  else
+  {
+    c    = vo_chroma_filter[frac];
+    taps = 4;
+  }
+  vo_if_filter( 1, taps, isFirst, isLast, src, srcStride, dst, dstStride, w, h, c, bitDepth, 0, clipMax, biMCForDMVR );
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K9 Transforms.  Core matrices = H.266 8.7.4 transMatrix constants (CommonLib/RomTr.cpp:432-..., 6-bit set,
+ * Rom.h:79-84,115-130).  We do not carry the tables: DCT-2 is generated from the 63 distinct magnitudes
+ * c[j] ~ 64*sqrt(2)*cos(j*pi/128) of the 64-point matrix (smaller sizes are its row-subsampled top-left
+ * corners), DST-7 from the first row of each size (entries are +-row0[fold((2k+1)(n+1) mod (2N+1))]),
+ * DCT-8[k][n] = (-1)^k * DST-7[k][N-1-n].  tests/test_oracle_vs_ref.py checks all 14 matrices against
+ * g_trCore*.  The reference's "fast" butterflies (TrQuant_EMT.cpp:51-1860) are exact refactorings of the
+ * plain matrix product (no intermediate rounding), so the product below is bit-identical.
+ * ------------------------------------------------------------------------------------------------ */
+static const int8_t vo_dct2_mag[64] = { 0, /* j = 1..63 */
+  91, 90, 90, 90, 90, 90, 90, 89, 88, 88, 87, 87, 86, 85, 84, 83, 83, 82, 81, 80, 79, 78, 77, 75, 73, 73, 71, 70, 69, 67, 65, 64,
+  62, 61, 59, 57, 56, 54, 52, 50, 48, 46, 44, 43, 41, 38, 37, 36, 33, 31, 28, 25, 24, 22, 20, 18, 15, 13, 11, 9,  7,  4,  2 };
+
+static const int8_t vo_dst7_row0_4[4]   = { 29, 55, 74, 84 };
+static const int8_t vo_dst7_row0_8[8]   = { 17, 32, 46, 60, 71, 78, 85, 86 };
+static const int8_t vo_dst7_row0_16[16] = { 8, 17, 25, 33, 40, 48, 55, 62, 68, 73, 77, 81, 85, 87, 88, 88 };
+static const int8_t vo_dst7_row0_32[32] = { 4,  9,  13, 17, 21, 26, 30, 34, 38, 42, 46, 50, 53, 56, 60, 63,
+                                            66, 68, 72, 74, 77, 78, 80, 82, 84, 85, 86, 87, 88, 89, 90, 90 };
+
+int vo_tr_matrix( int type, int n, int16_t *out )
+{
+  if( type == VO_DCT2 )
+  {
+    if( n != 2 && n != 4 && n != 8 && n != 16 && n != 32 && n != 64 ) return -1;
+    const int s = 64 / n;
+    for( int k = 0; k < n; k++ )
+      for( int x = 0; x < n; x++ )
+      {
+        if( k == 0 ) { out[x] = 64; continue; }
+        int j    = ( ( k * s ) * ( 2 * x + 1 ) ) % 256;   /* angle in units of pi/128 */
+        int sign = 1;
+        if( j > 128 ) j = 256 - j;
+        if( j > 64 ) { j = 128 - j; sign = -1; }
+        out[k * n + x] = ( int16_t )( sign * vo_dct2_mag[j] );
+      }
+    return 0;
+  }
+  const int8_t *row0 = n == 4 ? vo_dst7_row0_4 : n == 8 ? vo_dst7_row0_8 : n == 16 ? vo_dst7_row0_16 : n == 32 ? vo_dst7_row0_32 : NULL;
+  if( !row0 || ( type != VO_DST7 && type != VO_DCT8 ) ) return -1;
+  const int p = 2 * n + 1;
+  for( int k = 0; k < n; k++ )
+    for( int x = 0; x < n; x++ )
+    {
+      int m    = ( ( 2 * k + 1 ) * ( x + 1 ) ) % ( 2 * p );   /* sin(pi*m/p) */
+      int sign = 1;
+      if( m > p ) { m = 2 * p - m; sign = -1; }
+      if( m > n ) m = p - m;
+      const int v = m == 0 ? 0 : sign * row0[m - 1];
+      if( type == VO_DST7 ) out[k * n + x] = ( int16_t ) v;
+      else out[k * n + ( n - 1 - x )] = ( int16_t )( ( k & 1 ) ? -v : v );
+    }
+  return 0;
+}
+
+static const int16_t *vo_matrix( int type, int n )
+{
+  static int16_t cache[3][7][64 * 64];
+  static int     have[3][7];
+  const int      li = vo_floor_log2( ( unsigned ) n );
+  if( !have[type][li] )
+  {
+    if( vo_tr_matrix( type, n, cache[type][li] ) ) return NULL;
+    have[type][li] = 1;
+  }
+  return cache[type][li];
+}
+
+/* FwdTrans signature (CommonLib/TrQuant.h:53): dst[k*line + j] = (sum_n M[k][n]*src[j*N+n] + rnd) >> shift for
+ * j < line-skip1, k < N-skip2; zero elsewhere (_fastForwardMM TrQuant_EMT.cpp:274-323).  int32 wrap-around. */
+int vo_fwd_trans( int type, int n, const int32_t *src, int32_t *dst, int shift, int line, int skip1, int skip2 )
+{
+  const int16_t *m = vo_matrix( type, n );
+  if( !m ) return -1;
+  const uint32_t rnd    = shift > 0 ? 1u << ( shift - 1 ) : 0;
+  const int      rl     = line - skip1;
+  const int      cutoff = n - skip2;
+  for( int k = 0; k < n; k++ )
+    for( int j = 0; j < line; j++ )
+    {
+      if( j >= rl || k >= cutoff ) { dst[k * line + j] = 0; continue; }
+      uint32_t sum = 0;
+      for( int x = 0; x < n; x++ ) sum += ( uint32_t )( ( int32_t ) m[k * n + x] ) * ( uint32_t ) src[j * n + x];
+      dst[k * line + j] = ( int32_t )( sum + rnd ) >> shift;
+    }
+  return 0;
+}
+
+/* InvTrans signature (TrQuant.h:54): dst[i*N + j] = clip((sum_{k<N-skip2} src[k*line+i]*M[k][j] + rnd) >> shift),
+ * rows i >= line-skip1 zero (_fastInverseMM TrQuant_EMT.cpp:235-271). */
+int vo_inv_trans( int type, int n, const int32_t *src, int32_t *dst, int shift, int line, int skip1, int skip2, int clipMin, int clipMax )
+{
+  const int16_t *m = vo_matrix( type, n );
+  if( !m ) return -1;
+  const uint32_t rnd    = 1u << ( shift - 1 );
+  const int      rl     = line - skip1;
+  const int      cutoff = n - skip2;
+  for( int i = 0; i < line; i++ )
+    for( int j = 0; j < n; j++ )
+    {
+      if( i >= rl ) { dst[i * n + j] = 0; continue; }
+      uint32_t sum = 0;
+      for( int k = 0; k < cutoff; k++ ) sum += ( uint32_t ) src[k * line + i] * ( uint32_t )( ( int32_t ) m[k * n + j] );
+      dst[i * n + j] = vo_clip3( clipMin, clipMax, ( int32_t )( sum + rnd ) >> shift );
+    }
+  return 0;
+}
+
+static int vo_skip( int type, int n ) { return ( type != VO_DCT2 && n == 32 ) ? 16 : ( n > 32 ? n - 32 : 0 ); }
+
+/* TrQuant::xT (CommonLib/TrQuant.cpp:776-851), 2-D and the W==1 / H==1 1-D cases; maxLog2TrDynamicRange = 15,
+ * TRANSFORM_MATRIX_SHIFT = 6, COM16_C806_TRANS_PREC = 0.  No LFNST (out of scope). */
+int vo_fwd_2d( const int16_t *resi, int stride, int w, int h, int bitDepth, int typeHor, int typeVer, int32_t *coef )
+{
+  int32_t   block[VO_MAX_TB * VO_MAX_TB], tmp[VO_MAX_TB * VO_MAX_TB];
+  const int skipW = vo_skip( typeHor, w ), skipH = vo_skip( typeVer, h );
+  if( w > VO_MAX_TB || h > VO_MAX_TB ) return -1;
+  for( int y = 0; y < h; y++ )
+    for( int x = 0; x < w; x++ ) block[y * w + x] = resi[( ptrdiff_t ) y * stride + x];
+  if( w > 1 && h > 1 )
+  {
+    const int s1 = vo_floor_log2( w ) + bitDepth + 6 - 15;
+    const int s2 = vo_floor_log2( h ) + 6;
+    if( vo_fwd_trans( typeHor, w, block, tmp, s1, h, 0, skipW ) ) return -1;
+    if( vo_fwd_trans( typeVer, h, tmp, coef, s2, w, skipW, skipH ) ) return -1;
+  }
+  else if( h == 1 )
+  {
+    if( vo_fwd_trans( typeHor, w, block, coef, vo_floor_log2( w ) + bitDepth + 6 - 15, 1, 0, skipW ) ) return -1;
+  }
+  else
+  {
+    if( vo_fwd_trans( typeVer, h, block, coef, vo_floor_log2( h ) + bitDepth + 6 - 15, 1, 0, skipH ) ) return -1;
+  }
+  return 0;
+}
+
+/* TrQuant::xIT (TrQuant.cpp:853-923) */
+int vo_inv_2d( const int32_t *coef, int w, int h, int bitDepth, int typeHor, int typeVer, int16_t *resi, int stride )
+{
+  int32_t   block[VO_MAX_TB * VO_MAX_TB], tmp[VO_MAX_TB * VO_MAX_TB];
+  const int skipW = vo_skip( typeHor, w ), skipH = vo_skip( typeVer, h );
+  const int cmin = -( 1 << 15 ), cmax = ( 1 << 15 ) - 1;
+  if( w > VO_MAX_TB || h > VO_MAX_TB ) return -1;
+  if( w > 1 && h > 1 )
+  {
+    const int s1 = 6 + 1;
+    const int s2 = ( 6 + 15 - 1 ) - bitDepth;
+    if( vo_inv_trans( typeVer, h, coef, tmp, s1, w, skipW, skipH, cmin, cmax ) ) return -1;
+    if( vo_inv_trans( typeHor, w, tmp, block, s2, h, 0, skipW, cmin, cmax ) ) return -1;
+  }
+  else if( w == 1 )
+  {
+    if( vo_inv_trans( typeVer, h, coef, block, ( 6 + 15 - 1 ) - bitDepth + 1, 1, 0, skipH, cmin, cmax ) ) return -1;
+  }
+  else
+  {
+    if( vo_inv_trans( typeHor, w, coef, block, ( 6 + 15 - 1 ) - bitDepth + 1, 1, 0, skipW, cmin, cmax ) ) return -1;
+  }
+  for( int y = 0; y < h; y++ )
+    for( int x = 0; x < w; x++ ) resi[( ptrdiff_t ) y * stride + x] = ( int16_t ) block[y * w + x];
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K10 Scalar quant / dequant, flat scaling list.  CommonLib/Quant.cpp:955-1038 (quant), :357-482 (dequant),
+ * scales CommonLib/Rom.cpp:463-473, getTransformShift ChromaFormat.h:111-114,
+ * TU::needsBlockSizeTrafoScale = (log2W + log2H) odd.  Sign-bit hiding is not restated (SBH needs the scan).
+ * ------------------------------------------------------------------------------------------------ */
+static const int vo_quant_scales[2][6]     = { { 26214, 23302, 20560, 18396, 16384, 14564 }, { 18396, 16384, 14564, 13107, 11651, 10280 } };
+static const int vo_inv_quant_scales[2][6] = { { 40, 45, 51, 57, 64, 72 }, { 57, 64, 72, 80, 90, 102 } };
+
+void vo_quant( const int32_t *coef, int w, int h, int bitDepth, int qpPer, int qpRem, int isIRAP, int isTS, int32_t *qcoef, int32_t *deltaU,
+               int32_t *absSum )
+{
+  const int lw = vo_floor_log2( w ), lh = vo_floor_log2( h );
+  const int needSqrt = ( ( lw + lh ) & 1 ) && !isTS;   /* TU::needsBlockSizeTrafoScale: not for transform skip */
+  const int scale    = vo_quant_scales[needSqrt][qpRem];
+  const int trShift  = 15 - bitDepth - ( ( lw + lh ) >> 1 ) + ( needSqrt ? -1 : 0 );
+  const int qBits    = 14 + qpPer + ( isTS ? 0 : trShift );
+  const int64_t add  = ( int64_t )( isIRAP ? 171 : 85 ) << ( qBits - 9 );
+  const int qBits8   = qBits - 8;
+  int32_t   sum      = 0;
+  for( int i = 0; i < w * h; i++ )
+  {
+    const int32_t c   = coef[i];
+    const int64_t t   = ( int64_t ) vo_abs( c ) * scale;
+    const int32_t mag = ( int32_t )( ( t + add ) >> qBits );
+    if( deltaU ) deltaU[i] = ( int32_t )( ( t - ( ( int64_t ) mag << qBits ) ) >> qBits8 );
+    sum += mag;
+    qcoef[i] = vo_clip3( -32768, 32767, c < 0 ? -mag : mag );
+  }
+  *absSum = sum;
+}
+
+void vo_dequant( const int32_t *qcoef, int w, int h, int bitDepth, int qpPer, int qpRem, int isTS, int32_t *coef )
+{
+  const int lw = vo_floor_log2( w ), lh = vo_floor_log2( h );
+  const int needSqrt   = ( ( lw + lh ) & 1 ) && !isTS;
+  const int trShift    = 15 - bitDepth - ( ( lw + lh ) >> 1 ) + ( needSqrt ? -1 : 0 );
+  const int rightShift = 6 - ( ( isTS ? 0 : trShift ) + qpPer );
+  const int scale      = vo_inv_quant_scales[needSqrt][qpRem];
+  int       inBits     = 32 + rightShift - 7;
+  if( inBits > 16 ) inBits = 16;
+  const int32_t inMin = -( 1 << ( inBits - 1 ) ), inMax = ( 1 << ( inBits - 1 ) ) - 1;
+  for( int i = 0; i < w * h; i++ )
+  {
+    const int32_t q = vo_clip3( inMin, inMax, qcoef[i] );
+    int32_t       v;
+    if( rightShift > 0 ) v = ( int32_t )( ( uint32_t )( q * scale ) + ( 1u << ( rightShift - 1 ) ) ) >> rightShift;
+    else v = ( int32_t )( ( uint32_t )( q * scale ) << ( -rightShift ) );
+    coef[i] = vo_clip3( -32768, 32767, v );
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K12 PelBufferOps used by bi-pred ME.
+ *   removeHighFreq (CommonLib/Buffer.h:475-520 / Buffer.cpp removeHighFreq, call InterSearch.cpp:3320-3326):
+ *     org = 2*org - pred, no clip (ClipForBiPredMEEnabled = 0), BCW default.
+ *   addAvg (Buffer.cpp:467-507): dst = clip((a + b + offset) >> shift), shift = headRoom + 1,
+ *     offset = (1 << (shift-1)) + 2*IF_INTERNAL_OFFS.
+ * ------------------------------------------------------------------------------------------------ */
+void vo_remove_high_freq( int16_t *org, int orgStride, const int16_t *pred, int predStride, int w, int h )
+{
+  for( int y = 0; y < h; y++ )
+    for( int x = 0; x < w; x++ )
+      org[( ptrdiff_t ) y * orgStride + x] = ( int16_t )( 2 * org[( ptrdiff_t ) y * orgStride + x] - pred[( ptrdiff_t ) y * predStride + x] );
+}
+
+void vo_add_avg( const int16_t *a, int aStride, const int16_t *b, int bStride, int16_t *dst, int dstStride, int w, int h, int bitDepth )
+{
+  const int headRoom = ( VO_IF_PREC - bitDepth ) > 2 ? ( VO_IF_PREC - bitDepth ) : 2;
+  const int shift    = headRoom + 1;
+  const int offset   = ( 1 << ( shift - 1 ) ) + 2 * VO_IF_OFFS;
+  for( int y = 0; y < h; y++ )
+    for( int x = 0; x < w; x++ )
+      dst[( ptrdiff_t ) y * dstStride + x] =
+        ( int16_t ) vo_clip3( 0, ( 1 << bitDepth ) - 1, ( a[( ptrdiff_t ) y * aStride + x] + b[( ptrdiff_t ) y * bStride + x] + offset ) >> shift );
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K11 Affine gradient  CommonLib/AffineGradientSearch.cpp:62-170.
+ * ------------------------------------------------------------------------------------------------ */
+void vo_sobel( int vertical, const int16_t *p, int ps, int32_t *d, int ds, int w, int h )
+{
+  for( int j = 1; j < h - 1; j++ )
+    for( int k = 1; k < w - 1; k++ )
+    {
+      const int16_t *c = p + ( ptrdiff_t ) j * ps + k;
+      d[j * ds + k]    = vertical ? ( c[ps - 1] - c[-ps - 1] + ( c[ps] << 1 ) - ( c[-ps] << 1 ) + c[ps + 1] - c[-ps + 1] )
+                                  : ( c[1 - ps] - c[-1 - ps] + ( c[1] << 1 ) - ( c[-1] << 1 ) + c[1 + ps] - c[-1 + ps] );
+    }
+  /* border replication; the end state is order-independent: edges copy the adjacent interior sample,
+   * corners copy the diagonal interior sample (:77-92, :111-126) */
+  for( int j = 1; j < h - 1; j++ )
+  {
+    d[j * ds]         = d[j * ds + 1];
+    d[j * ds + w - 1] = d[j * ds + w - 2];
+  }
+  for( int k = 1; k < w - 1; k++ )
+  {
+    d[k]                  = d[ds + k];
+    d[( h - 1 ) * ds + k] = d[( h - 2 ) * ds + k];
+  }
+  d[0]                      = d[ds + 1];
+  d[w - 1]                  = d[ds + w - 2];
+  d[( h - 1 ) * ds]         = d[( h - 2 ) * ds + 1];
+  d[( h - 1 ) * ds + w - 1] = d[( h - 2 ) * ds + w - 2];
+}
+
+void vo_equal_coeff( const int16_t *resi, int rs, const int32_t *gx, const int32_t *gy, int ds, int64_t eq[7][7], int w, int h, int b6Param )
+{
+  const int np = b6Param ? 6 : 4;
+  for( int j = 0; j < h; j++ )
+  {
+    const int cy = ( ( j >> 2 ) << 2 ) + 2;
+    for( int k = 0; k < w; k++ )
+    {
+      const int cx = ( ( k >> 2 ) << 2 ) + 2;
+      const int x = gx[j * ds + k], y = gy[j * ds + k];
+      int       c[6];
+      if( !b6Param ) { c[0] = x; c[1] = cx * x + cy * y; c[2] = y; c[3] = cy * x - cx * y; }
+      else { c[0] = x; c[1] = cx * x; c[2] = y; c[3] = cx * y; c[4] = cy * x; c[5] = cy * y; }
+      for( int col = 0; col < np; col++ )
+      {
+        for( int row = 0; row < np; row++ ) eq[col + 1][row] += ( int64_t ) c[col] * c[row];
+        eq[col + 1][np] += ( ( int64_t ) c[col] * resi[( ptrdiff_t ) j * rs + k] ) << 3;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Integer motion search  EncoderLib/InterSearch.cpp.
+ *   clipMv            CommonLib/Mv.cpp:56-74 (no wrap-around, no sub-pictures -- CTC)
+ *   xClipMv           InterSearch.cpp:7735-7764 (identical arithmetic under the same conditions)
+ *   xSetSearchRange   :3496-3563        xTZSearchHelp :330-419 (subShiftMode != 1 branch)
+ *   xTZ2PointSearch   :422-447          xTZ8PointDiamondSearch :504-705
+ *   xTZSearch         :3640-3976        xPatternSearch :3566-3608
+ * Structure here: every round first *generates* its ordered candidate list, then evaluates it, then
+ * replays the accept rule in list order -- the same three steps the HIP kernel runs (evaluation in parallel).
+ * The accept rule "sad < best, then sad + cost < best" equals "sad + cost < best" because cost >= 0.
+ * ------------------------------------------------------------------------------------------------ */
+static void vo_clip_mv( int *hor, int *ver, const vo_me_ctx_t *c )
+{
+  const int horMax = ( c->picW + 8 - c->puX - 1 ) << 4;
+  const int horMin = ( -c->ctuSize - 8 - c->puX + 1 ) << 4;
+  const int verMax = ( c->picH + 8 - c->puY - 1 ) << 4;
+  const int verMin = ( -c->ctuSize - 8 - c->puY + 1 ) << 4;
+  *hor = *hor < horMin ? horMin : ( *hor > horMax ? horMax : *hor );
+  *ver = *ver < verMin ? verMin : ( *ver > verMax ? verMax : *ver );
+}
+
+static inline int vo_div_pow2( int v, int i ) { return ( v + ( 1 << ( i - 1 ) ) - ( v >= 0 ) ) >> i; }          /* Mv::divideByPowerOf2 Mv.h:128 */
+static inline int vo_prec_down( int v, int rs ) { const int o = 1 << ( rs - 1 ); return v >= 0 ? ( v + o - 1 ) >> rs : ( v + o ) >> rs; } /* Mv.h:183-197 */
+
+void vo_set_search_range( const vo_me_ctx_t *c, int predHor, int predVer, int range, vo_range_t *sr )
+{
+  vo_clip_mv( &predHor, &predVer, c );
+  int l = predHor - ( range << 4 ), t = predVer - ( range << 4 );
+  int r = predHor + ( range << 4 ), b = predVer + ( range << 4 );
+  vo_clip_mv( &l, &t, c );
+  vo_clip_mv( &r, &b, c );
+  sr->left   = vo_div_pow2( l, 4 );
+  sr->top    = vo_div_pow2( t, 4 );
+  sr->right  = vo_div_pow2( r, 4 );
+  sr->bottom = vo_div_pow2( b, 4 );
+}
+
+typedef struct
+{
+  const vo_me_ctx_t *c;
+  vo_range_t         sr;
+  uint64_t           bestSad;
+  int                bestX, bestY;
+  unsigned           bestDist, bestRound;
+  int                pointNr;
+  uint64_t           nEval;
+} vo_tz_t;
+
+typedef struct { int x, y, nr, dist; } vo_pt_t;
+
+static uint64_t vo_me_sad( const vo_me_ctx_t *c, int x, int y )
+{
+  return vo_sad( c->org, c->orgStride, c->ref + ( ptrdiff_t ) y * c->refStride + x, c->refStride, c->w, c->h, c->subShift );
+}
+
+static void vo_tz_check( vo_tz_t *s, const vo_pt_t *p )
+{
+  const uint64_t cost = vo_me_sad( s->c, p->x, p->y ) + vo_mv_cost( &s->c->mv, p->x, p->y, s->c->imvShift );
+  s->nEval++;
+  if( cost < s->bestSad )
+  {
+    s->bestSad   = cost;
+    s->bestX     = p->x;
+    s->bestY     = p->y;
+    s->bestDist  = ( unsigned ) p->dist;
+    s->bestRound = 0;
+    s->pointNr   = p->nr;
+  }
+}
+
+#define VO_PUSH( X, Y, NR, D ) do { pts[n].x = ( X ); pts[n].y = ( Y ); pts[n].nr = ( NR ); pts[n].dist = ( D ); n++; } while( 0 )
+
+/* ordered candidate list of one diamond round; at most 16 points */
+static int vo_diamond_points( const vo_range_t *sr, int sx, int sy, int d, int cornersAtDist1, vo_pt_t *pts )
+{
+  int       n = 0;
+  const int top = sy - d, bot = sy + d, left = sx - d, right = sx + d;
+  if( d == 1 )
+  {
+    if( top >= sr->top )
+    {
+      if( cornersAtDist1 && left >= sr->left ) VO_PUSH( left, top, 1, d );
+      VO_PUSH( sx, top, 2, d );
+      if( cornersAtDist1 && right <= sr->right ) VO_PUSH( right, top, 3, d );
+    }
+    if( left >= sr->left ) VO_PUSH( left, sy, 4, d );
+    if( right <= sr->right ) VO_PUSH( right, sy, 5, d );
+    if( bot <= sr->bottom )
+    {
+      if( cornersAtDist1 && left >= sr->left ) VO_PUSH( left, bot, 6, d );
+      VO_PUSH( sx, bot, 7, d );
+      if( cornersAtDist1 && right <= sr->right ) VO_PUSH( right, bot, 8, d );
+    }
+  }
+  else if( d <= 8 )
+  {
+    const int h2 = d >> 1, top2 = sy - h2, bot2 = sy + h2, left2 = sx - h2, right2 = sx + h2;
+    if( top >= sr->top && left >= sr->left && right <= sr->right && bot <= sr->bottom )
+    {
+      VO_PUSH( sx, top, 2, d );
+      VO_PUSH( left2, top2, 1, h2 );
+      VO_PUSH( right2, top2, 3, h2 );
+      VO_PUSH( left, sy, 4, d );
+      VO_PUSH( right, sy, 5, d );
+      VO_PUSH( left2, bot2, 6, h2 );
+      VO_PUSH( right2, bot2, 8, h2 );
+      VO_PUSH( sx, bot, 7, d );
+    }
+    else
+    {
+      if( top >= sr->top ) VO_PUSH( sx, top, 2, d );
+      if( top2 >= sr->top )
+      {
+        if( left2 >= sr->left ) VO_PUSH( left2, top2, 1, h2 );
+        if( right2 <= sr->right ) VO_PUSH( right2, top2, 3, h2 );
+      }
+      if( left >= sr->left ) VO_PUSH( left, sy, 4, d );
+      if( right <= sr->right ) VO_PUSH( right, sy, 5, d );
+      if( bot2 <= sr->bottom )
+      {
+        if( left2 >= sr->left ) VO_PUSH( left2, bot2, 6, h2 );
+        if( right2 <= sr->right ) VO_PUSH( right2, bot2, 8, h2 );
+      }
+      if( bot <= sr->bottom ) VO_PUSH( sx, bot, 7, d );
+    }
+  }
+  else
+  {
+    const int q      = d >> 2;
+    const int inside = top >= sr->top && left >= sr->left && right <= sr->right && bot <= sr->bottom;
+    if( inside || top >= sr->top ) VO_PUSH( sx, top, 0, d );
+    if( inside || left >= sr->left ) VO_PUSH( left, sy, 0, d );
+    if( inside || right <= sr->right ) VO_PUSH( right, sy, 0, d );
+    if( inside || bot <= sr->bottom ) VO_PUSH( sx, bot, 0, d );
+    for( int i = 1; i < 4; i++ )
+    {
+      const int yt = top + q * i, yb = bot - q * i, xl = sx - q * i, xr = sx + q * i;
+      if( inside || yt >= sr->top )
+      {
+        if( inside || xl >= sr->left ) VO_PUSH( xl, yt, 0, d );
+        if( inside || xr <= sr->right ) VO_PUSH( xr, yt, 0, d );
+      }
+      if( inside || yb <= sr->bottom )
+      {
+        if( inside || xl >= sr->left ) VO_PUSH( xl, yb, 0, d );
+        if( inside || xr <= sr->right ) VO_PUSH( xr, yb, 0, d );
+      }
+    }
+  }
+  return n;
+}
+
+static void vo_tz_diamond( vo_tz_t *s, int sx, int sy, int d, int cornersAtDist1 )
+{
+  vo_pt_t   pts[16];
+  const int n = vo_diamond_points( &s->sr, sx, sy, d, cornersAtDist1, pts );
+  s->bestRound += 1;
+  for( int i = 0; i < n; i++ ) vo_tz_check( s, &pts[i] );
+}
+
+static void vo_tz_two_point( vo_tz_t *s )
+{
+  /* untested neighbours of the best point, indexed by the point number 1..8 of the dist-1 round (:426-446) */
+  static const int xo[2][9] = { { 0, -1, -1, 0, -1, +1, -1, -1, +1 }, { 0, 0, +1, +1, -1, +1, 0, +1, 0 } };
+  static const int yo[2][9] = { { 0, 0, -1, -1, +1, -1, 0, +1, 0 }, { 0, -1, -1, 0, -1, +1, +1, +1, +1 } };
+  const int        nr = s->pointNr;
+  vo_pt_t          p[2];
+  for( int i = 0; i < 2; i++ ) { p[i].x = s->bestX + xo[i][nr]; p[i].y = s->bestY + yo[i][nr]; p[i].nr = 0; p[i].dist = 2; }
+  for( int i = 0; i < 2; i++ )
+    if( p[i].x >= s->sr.left && p[i].x <= s->sr.right && p[i].y >= s->sr.top && p[i].y <= s->sr.bottom ) vo_tz_check( s, &p[i] );
+}
+
+void vo_tz_search( const vo_me_ctx_t *c, const vo_tz_job_t *job, vo_me_result_t *res )
+{
+  vo_tz_t s;
+  memset( &s, 0, sizeof( s ) );
+  s.c       = c;
+  s.bestSad = UINT64_MAX;
+
+  const int ext = job->extendedSettings, fast = job->fastSettings;
+  const int iRaster            = fast ? 8 : 5;
+  const int testZeroVector     = !fast;
+  const int firstSearchRounds  = 3;
+  const int starRounds         = 2;
+  const int searchRange        = job->searchRange;
+
+  /* start vector: clip, internal(1/16) -> quarter with Mv::changePrecision, then divideByPowerOf2(2) (:3686-3687) */
+  int mx = job->mvHor, my = job->mvVer;
+  vo_clip_mv( &mx, &my, c );
+  mx = vo_div_pow2( vo_prec_down( mx, 2 ), 2 );
+  my = vo_div_pow2( vo_prec_down( my, 2 ), 2 );
+
+  vo_pt_t p = { mx, my, 0, 0 };
+  vo_tz_check( &s, &p );
+  if( testZeroVector && ( mx != 0 || my != 0 ) && ( s.bestX != 0 || s.bestY != 0 ) )
+  {
+    vo_pt_t z = { 0, 0, 0, 0 };
+    vo_tz_check( &s, &z );
+  }
+  if( job->hasIntMv2Nx2NPred )
+  {
+    int ix = job->intMv2Nx2NPredHor << 4, iy = job->intMv2Nx2NPredVer << 4;   /* INT -> INTERNAL */
+    vo_clip_mv( &ix, &iy, c );
+    ix = vo_div_pow2( vo_prec_down( ix, 2 ), 2 );
+    iy = vo_div_pow2( vo_prec_down( iy, 2 ), 2 );
+    if( ( mx != ix || my != iy ) && ( ix != s.bestX || iy != s.bestY ) )
+    {
+      vo_pt_t q = { ix, iy, 0, 0 };
+      vo_tz_check( &s, &q );
+    }
+  }
+  /* m_uniMvList candidates, already de-duplicated by the caller as :3730-3746 does; these do not touch
+   * bestDistance / bestRound / pointNr (:3754-3761), which are all still 0 here anyway. */
+  for( int i = 0; i < job->numExtraStart; i++ )
+  {
+    int ex = job->extraStart[i][0], ey = job->extraStart[i][1];
+    vo_clip_mv( &ex, &ey, c );
+    ex = vo_prec_down( ex, 4 );
+    ey = vo_prec_down( ey, 4 );
+    const uint64_t cost = vo_me_sad( c, ex, ey ) + vo_mv_cost( &c->mv, ex, ey, c->imvShift );
+    s.nEval++;
+    if( cost < s.bestSad ) { s.bestSad = cost; s.bestX = ex; s.bestY = ey; }
+  }
+
+  vo_set_search_range( c, s.bestX << 4, s.bestY << 4, searchRange >> ( fast ? 1 : 0 ), &s.sr );
+
+  int       startX = s.bestX, startY = s.bestY;
+  const int bestCandidateZero = ( s.bestX == 0 && s.bestY == 0 );
+
+  for( int d = 1; d <= searchRange; d *= 2 )
+  {
+    vo_tz_diamond( &s, startX, startY, d, ext );
+    if( job->firstSearchStop && s.bestRound >= ( unsigned ) firstSearchRounds ) break;
+  }
+
+  if( ext && !bestCandidateZero )   /* bNewZeroNeighbourhoodTest branch (:3861-3873) */
+  {
+    for( int d = 1; d <= ( searchRange >> 1 ); d *= 2 ) vo_tz_diamond( &s, 0, 0, d, 0 );
+  }
+
+  if( s.bestDist == 1 )
+  {
+    s.bestDist = 0;
+    vo_tz_two_point( &s );
+  }
+
+  if( ext )   /* bUseAdaptiveRaster (:3883-3903) */
+  {
+    int        win = iRaster;
+    vo_range_t lsr = s.sr;
+    if( !( ( int ) s.bestDist >= iRaster ) )
+    {
+      win++;
+      lsr.left /= 2; lsr.right /= 2; lsr.top /= 2; lsr.bottom /= 2;
+    }
+    s.bestDist = ( unsigned ) win;
+    for( int y = lsr.top; y <= lsr.bottom; y += win )
+      for( int x = lsr.left; x <= lsr.right; x += win )
+      {
+        vo_pt_t q = { x, y, 0, win };
+        vo_tz_check( &s, &q );
+      }
+  }
+  else if( ( int ) s.bestDist >= iRaster )
+  {
+    s.bestDist = ( unsigned ) iRaster;
+    for( int y = s.sr.top; y <= s.sr.bottom; y += iRaster )
+      for( int x = s.sr.left; x <= s.sr.right; x += iRaster )
+      {
+        vo_pt_t q = { x, y, 0, iRaster };
+        vo_tz_check( &s, &q );
+      }
+  }
+
+  /* star refinement (:3937-3971) */
+  while( s.bestDist > 0 )
+  {
+    startX     = s.bestX;
+    startY     = s.bestY;
+    s.bestDist = 0;
+    s.pointNr  = 0;
+    for( int d = 1; d < searchRange + 1; d *= 2 )
+    {
+      vo_tz_diamond( &s, startX, startY, d, ext );
+      if( fast && s.bestRound >= ( unsigned ) starRounds ) break;
+    }
+    if( s.bestDist == 1 )
+    {
+      s.bestDist = 0;
+      if( s.pointNr != 0 ) vo_tz_two_point( &s );
+    }
+  }
+
+  res->mvX   = s.bestX;
+  res->mvY   = s.bestY;
+  res->cost  = s.bestSad;
+  res->dist  = s.bestSad - vo_mv_cost( &c->mv, s.bestX, s.bestY, c->imvShift );
+  res->nEval = s.nEval;
+}
+
+/* xPatternSearch (:3566-3608): exhaustive raster over the range, first strict minimum */
+void vo_full_search( const vo_me_ctx_t *c, const vo_range_t *sr, vo_me_result_t *res )
+{
+  uint64_t best = UINT64_MAX;
+  int      bx = 0, by = 0;
+  uint64_t n  = 0;
+  for( int y = sr->top; y <= sr->bottom; y++ )
+    for( int x = sr->left; x <= sr->right; x++ )
+    {
+      const uint64_t cost = vo_me_sad( c, x, y ) + vo_mv_cost( &c->mv, x, y, c->imvShift );
+      n++;
+      if( cost < best ) { best = cost; bx = x; by = y; }
+    }
+  res->mvX   = bx;
+  res->mvY   = by;
+  res->cost  = best;
+  res->dist  = best - vo_mv_cost( &c->mv, bx, by, c->imvShift );
+  res->nEval = n;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Fractional motion search  xPatternSearchFracDIF :4284-4339, xExtDIFUpSamplingH :5840-5889,
+ * xExtDIFUpSamplingQ :5895-6051, xPatternRefinement :707-761 (tables s_acMvRefineH/Q :60-85).
+ * The plane buffers mirror m_filteredBlockTmp[4] / m_filteredBlock[4][4]; strides are W+1 as in the reference.
+ * ------------------------------------------------------------------------------------------------ */
+#define VO_FB_STRIDE ( 128 + 1 )
+#define VO_FB_ROWS ( 128 + 8 + 1 )
+typedef struct
+{
+  int16_t tmp[4][VO_FB_STRIDE * VO_FB_ROWS];
+  int16_t blk[4][4][VO_FB_STRIDE * VO_FB_ROWS];
+} vo_fb_t;
+
+static const int8_t vo_refine_h[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { 1, -1 }, { -1, 1 }, { 1, 1 } };
+static const int8_t vo_refine_q[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { 1, 1 } };
+
+static void vo_upsample_h( vo_fb_t *fb, const int16_t *pat, int ps, int w, int h, int bd, int altHpel )
+{
+  const int      is = w + 1, dsd = w + 1;
+  const int16_t *src = pat - 4 * ps - 1;
+  vo_if_hor( 0, src, ps, fb->tmp[0], is, w + 1, h + 8, 0 << 2, 0, bd, 0, 0, altHpel );
+  vo_if_hor( 0, src, ps, fb->tmp[2], is, w + 1, h + 8, 2 << 2, 0, bd, 0, 0, altHpel );
+  vo_if_ver( 0, fb->tmp[0] + 4 * is + 1, is, fb->blk[0][0], dsd, w, h, 0 << 2, 0, 1, bd, 0, 0, altHpel );
+  vo_if_ver( 0, fb->tmp[0] + 3 * is + 1, is, fb->blk[2][0], dsd, w, h + 1, 2 << 2, 0, 1, bd, 0, 0, altHpel );
+  vo_if_ver( 0, fb->tmp[2] + 4 * is, is, fb->blk[0][2], dsd, w + 1, h, 0 << 2, 0, 1, bd, 0, 0, altHpel );
+  vo_if_ver( 0, fb->tmp[2] + 3 * is, is, fb->blk[2][2], dsd, w + 1, h + 1, 2 << 2, 0, 1, bd, 0, 0, altHpel );
+}
+
+static void vo_upsample_q( vo_fb_t *fb, const int16_t *pat, int ps, int w, int h, int bd, int halfHor, int halfVer )
+{
+  const int      is = w + 1, dsd = w + 1;
+  const int      extH = ( halfVer == 0 ) ? h + 8 : h + 7;
+  const int16_t *src;
+  int16_t       *ip;
+
+  src = pat - 4 * ps - 1;
+  if( halfVer > 0 ) src += ps;
+  if( halfHor >= 0 ) src += 1;
+  vo_if_hor( 0, src, ps, fb->tmp[1], is, w, extH, 1 << 2, 0, bd, 0, 0, 0 );
+
+  src = pat - 4 * ps - 1;
+  if( halfVer > 0 ) src += ps;
+  if( halfHor > 0 ) src += 1;
+  vo_if_hor( 0, src, ps, fb->tmp[3], is, w, extH, 3 << 2, 0, bd, 0, 0, 0 );
+
+  ip = fb->tmp[1] + 3 * is;                                   /* @1,1 */
+  if( halfVer == 0 ) ip += is;
+  vo_if_ver( 0, ip, is, fb->blk[1][1], dsd, w, h, 1 << 2, 0, 1, bd, 0, 0, 0 );
+  ip = fb->tmp[1] + 3 * is;                                   /* @3,1 */
+  vo_if_ver( 0, ip, is, fb->blk[3][1], dsd, w, h, 3 << 2, 0, 1, bd, 0, 0, 0 );
+
+  if( halfVer != 0 )
+  {
+    vo_if_ver( 0, fb->tmp[1] + 3 * is, is, fb->blk[2][1], dsd, w, h, 2 << 2, 0, 1, bd, 0, 0, 0 );   /* @2,1 */
+    vo_if_ver( 0, fb->tmp[3] + 3 * is, is, fb->blk[2][3], dsd, w, h, 2 << 2, 0, 1, bd, 0, 0, 0 );   /* @2,3 */
+  }
+  else
+  {
+    vo_if_ver( 0, fb->tmp[1] + 4 * is, is, fb->blk[0][1], dsd, w, h, 0 << 2, 0, 1, bd, 0, 0, 0 );   /* @0,1 */
+    vo_if_ver( 0, fb->tmp[3] + 4 * is, is, fb->blk[0][3], dsd, w, h, 0 << 2, 0, 1, bd, 0, 0, 0 );   /* @0,3 */
+  }
+
+  if( halfHor != 0 )
+  {
+    ip = fb->tmp[2] + 3 * is;                                 /* @1,2 */
+    if( halfHor > 0 ) ip += 1;
+    if( halfVer >= 0 ) ip += is;
+    vo_if_ver( 0, ip, is, fb->blk[1][2], dsd, w, h, 1 << 2, 0, 1, bd, 0, 0, 0 );
+    ip = fb->tmp[2] + 3 * is;                                 /* @3,2 */
+    if( halfHor > 0 ) ip += 1;
+    if( halfVer > 0 ) ip += is;
+    vo_if_ver( 0, ip, is, fb->blk[3][2], dsd, w, h, 3 << 2, 0, 1, bd, 0, 0, 0 );
+  }
+  else
+  {
+    ip = fb->tmp[0] + 3 * is + 1;                             /* @1,0 */
+    if( halfVer >= 0 ) ip += is;
+    vo_if_ver( 0, ip, is, fb->blk[1][0], dsd, w, h, 1 << 2, 0, 1, bd, 0, 0, 0 );
+    ip = fb->tmp[0] + 3 * is + 1;                             /* @3,0 */
+    if( halfVer > 0 ) ip += is;
+    vo_if_ver( 0, ip, is, fb->blk[3][0], dsd, w, h, 3 << 2, 0, 1, bd, 0, 0, 0 );
+  }
+
+  ip = fb->tmp[3] + 3 * is;                                   /* @1,3 */
+  if( halfVer == 0 ) ip += is;
+  vo_if_ver( 0, ip, is, fb->blk[1][3], dsd, w, h, 1 << 2, 0, 1, bd, 0, 0, 0 );
+  vo_if_ver( 0, fb->tmp[3] + 3 * is, is, fb->blk[3][3], dsd, w, h, 3 << 2, 0, 1, bd, 0, 0, 0 );     /* @3,3 */
+}
+
+static uint64_t vo_pattern_refinement( const vo_me_ctx_t *c, const vo_mvcost_t *mc, vo_fb_t *fb, int baseHor, int baseVer, int frac, int *mvHor,
+                                       int *mvVer, int useHad, uint64_t cand[9] )
+{
+  const int     rs = c->w + 1;
+  const int8_t( *tab )[2] = frac == 2 ? vo_refine_h : vo_refine_q;
+  uint64_t best = UINT64_MAX;
+  int      bi   = 0;
+  for( int i = 0; i < 9; i++ )
+  {
+    const int      hv = ( tab[i][0] + baseHor ) * frac, vv = ( tab[i][1] + baseVer ) * frac;
+    const int16_t *p  = fb->blk[vv & 3][hv & 3];
+    if( hv == 2 && ( vv & 1 ) == 0 ) p += 1;
+    if( ( hv & 1 ) == 0 && vv == 2 ) p += rs;
+    const int tx = tab[i][0] + *mvHor, ty = tab[i][1] + *mvVer;
+    uint64_t  d  = useHad ? vo_satd( c->org, c->orgStride, p, rs, c->w, c->h ) : vo_sad( c->org, c->orgStride, p, rs, c->w, c->h, 0 );
+    d += vo_mv_cost( mc, tx, ty, 0 );
+    if( cand ) cand[i] = d;
+    if( d < best ) { best = d; bi = i; }
+  }
+  *mvHor = tab[bi][0];
+  *mvVer = tab[bi][1];
+  return best;
+}
+
+/* imv == IMV_OFF path of xPatternSearchFracDIF; intX/intY = integer MV from the integer search. */
+void vo_frac_search( const vo_me_ctx_t *c, int intX, int intY, int useHad, int useAltHpelIf, vo_frac_result_t *res )
+{
+  vo_fb_t       *fb  = ( vo_fb_t * ) malloc( sizeof( vo_fb_t ) );
+  const int16_t *pat = c->ref + ( ptrdiff_t ) intY * c->refStride + intX;
+  vo_mvcost_t    mc  = c->mv;
+
+  mc.costScale = 1;
+  vo_upsample_h( fb, pat, c->refStride, c->w, c->h, c->bitDepth, useAltHpelIf );
+  int hx = intX << 1, hy = intY << 1;
+  res->costHalf = vo_pattern_refinement( c, &mc, fb, 0, 0, 2, &hx, &hy, useHad, res->candHalf );
+  res->halfX    = hx;
+  res->halfY    = hy;
+
+  mc.costScale = 0;
+  vo_upsample_q( fb, pat, c->refStride, c->w, c->h, c->bitDepth, hx, hy );
+  int qx = ( ( intX << 1 ) + hx ) << 1, qy = ( ( intY << 1 ) + hy ) << 1;
+  res->cost = vo_pattern_refinement( c, &mc, fb, hx << 1, hy << 1, 1, &qx, &qy, useHad, res->candQuarter );
+  res->qterX = qx;
+  res->qterY = qy;
+  free( fb );
+}
+
+/* Direct 2-D separable luma interpolation at quarter-sample offset (qx,qy) from `pat`: what each
+ * fractional candidate's block is, independent of the plane bookkeeping above (used to cross-check the
+ * fused HIP interp+SATD kernel). */
+void vo_interp_qpel( const int16_t *pat, int ps, int w, int h, int bitDepth, int qx, int qy, int16_t *dst, int ds )
+{
+  int16_t        tmp[( 128 + 8 ) * 128];
+  const int      fx = qx & 3, fy = qy & 3, cmax = ( 1 << bitDepth ) - 1;
+  const int16_t *src = pat + ( ptrdiff_t )( ( qy >> 2 ) - 3 ) * ps + ( qx >> 2 );
+  if( fx == 0 ) vo_if_copy( 1, 0, src, ps, tmp, w, w, h + 7, bitDepth, 0, cmax, 0 );
+  else vo_if_filter( 0, 8, 1, 0, src, ps, tmp, w, w, h + 7, vo_luma_filter[fx << 2], bitDepth, 0, cmax, 0 );
+  if( fy == 0 ) vo_if_copy( 0, 1, tmp + 3 * w, w, dst, ds, w, h, bitDepth, 0, cmax, 0 );
+  else vo_if_filter( 1, 8, 0, 1, tmp + 3 * w, w, dst, ds, w, h, vo_luma_filter[fy << 2], bitDepth, 0, cmax, 0 );
+}

@@ -1,0 +1,109 @@
+/* vtm_oracle.h -- TEST INFRASTRUCTURE ONLY (see vtm_oracle.c). */
+#ifndef VTM_ORACLE_H
+#define VTM_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { VO_DCT2 = 0, VO_DCT8 = 1, VO_DST7 = 2 };   /* TransType, CommonLib/TypeDef.h */
+
+typedef struct
+{
+  double motionLambda;   /* RdCost::m_motionLambda = sqrt(lambda) */
+  int    predHor, predVer;   /* RdCost::m_mvPredictor (quarter-sample units) */
+  int    costScale;          /* RdCost::m_iCostScale: 2 integer, 1 half, 0 quarter */
+} vo_mvcost_t;
+
+typedef struct { int left, right, top, bottom; } vo_range_t;   /* SearchRange, EncoderLib/InterSearch.h */
+
+/* Everything xTZSearchHelp / xPatternSearch / xPatternSearchFracDIF read for one PU x one reference picture */
+typedef struct
+{
+  const int16_t *org;   /* pcPatternKey */
+  int            orgStride;
+  const int16_t *ref;   /* piRefY: reference luma plane at the PU position (MV 0,0) */
+  int            refStride;
+  int            w, h;
+  int            subShift;   /* DistParam::subShift after setDistParam(subShiftMode) */
+  int            bitDepth;
+  unsigned       imvShift;
+  vo_mvcost_t    mv;
+  int            picW, picH, puX, puY, ctuSize;   /* for clipMv / xClipMv */
+} vo_me_ctx_t;
+
+typedef struct
+{
+  int mvHor, mvVer;   /* rcMv on entry (internal 1/16 precision) */
+  int searchRange;    /* m_iSearchRange */
+  int extendedSettings, fastSettings, firstSearchStop;
+  int hasIntMv2Nx2NPred, intMv2Nx2NPredHor, intMv2Nx2NPredVer;   /* integer precision */
+  int numExtraStart;
+  int extraStart[16][2];   /* m_uniMvList candidates after de-duplication, internal precision */
+} vo_tz_job_t;
+
+typedef struct
+{
+  int      mvX, mvY;   /* integer MV */
+  uint64_t cost;       /* uiBestSad (distortion + MV rate) */
+  uint64_t dist;       /* ruiSAD */
+  uint64_t nEval;      /* number of distFunc evaluations (statistics only) */
+} vo_me_result_t;
+
+typedef struct
+{
+  int      halfX, halfY;   /* rcMvHalf in {-1,0,1} */
+  int      qterX, qterY;   /* rcMvQter in {-1,0,1} */
+  uint64_t costHalf, cost;
+  uint64_t candHalf[9], candQuarter[9];
+} vo_frac_result_t;
+
+uint64_t vo_sad( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h, int subShift );
+uint64_t vo_sse( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h );
+uint64_t vo_satd( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h );
+int      vo_satd_tile_shape( int w, int h, int *tw, int *th );
+int      vo_subshift_for_mode( int w, int h, int subShiftMode );
+void     vo_satd8_grid( const int16_t *org, int orgStride, const int16_t *ref, int refStride, int w, int h, int r, uint64_t *out );
+unsigned vo_mv_bits( const vo_mvcost_t *mc, int x, int y, unsigned imvShift );
+uint64_t vo_mv_cost( const vo_mvcost_t *mc, int x, int y, unsigned imvShift );
+
+extern const int16_t vo_luma_filter[16][8];
+extern const int16_t vo_luma_filter_4x4[16][8];
+extern const int16_t vo_luma_alt_hpel[8];
+extern const int16_t vo_chroma_filter[32][4];
+
+void vo_if_copy( int isFirst, int isLast, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int w, int h, int bitDepth, int clipMin,
+                 int clipMax, int biMCForDMVR );
+void vo_if_filter( int vertical, int taps, int isFirst, int isLast, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int w, int h,
+                   const int16_t *coeff, int bitDepth, int clipMin, int clipMax, int biMCForDMVR );
+void vo_if_hor( int compID, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int w, int h, int frac, int isLast, int bitDepth,
+                int nFilterIdx, int biMCForDMVR, int useAltHpelIf );
+void vo_if_ver( int compID, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int w, int h, int frac, int isFirst, int isLast,
+                int bitDepth, int nFilterIdx, int biMCForDMVR, int useAltHpelIf );
+void vo_interp_qpel( const int16_t *pat, int ps, int w, int h, int bitDepth, int qx, int qy, int16_t *dst, int ds );
+
+int vo_tr_matrix( int type, int n, int16_t *out );
+int vo_fwd_trans( int type, int n, const int32_t *src, int32_t *dst, int shift, int line, int skip1, int skip2 );
+int vo_inv_trans( int type, int n, const int32_t *src, int32_t *dst, int shift, int line, int skip1, int skip2, int clipMin, int clipMax );
+int vo_fwd_2d( const int16_t *resi, int stride, int w, int h, int bitDepth, int typeHor, int typeVer, int32_t *coef );
+int vo_inv_2d( const int32_t *coef, int w, int h, int bitDepth, int typeHor, int typeVer, int16_t *resi, int stride );
+void vo_quant( const int32_t *coef, int w, int h, int bitDepth, int qpPer, int qpRem, int isIRAP, int isTS, int32_t *qcoef, int32_t *deltaU,
+               int32_t *absSum );
+void vo_dequant( const int32_t *qcoef, int w, int h, int bitDepth, int qpPer, int qpRem, int isTS, int32_t *coef );
+
+void vo_remove_high_freq( int16_t *org, int orgStride, const int16_t *pred, int predStride, int w, int h );
+void vo_add_avg( const int16_t *a, int aStride, const int16_t *b, int bStride, int16_t *dst, int dstStride, int w, int h, int bitDepth );
+void vo_sobel( int vertical, const int16_t *p, int ps, int32_t *d, int ds, int w, int h );
+void vo_equal_coeff( const int16_t *resi, int rs, const int32_t *gx, const int32_t *gy, int ds, int64_t eq[7][7], int w, int h, int b6Param );
+
+void vo_set_search_range( const vo_me_ctx_t *c, int predHor, int predVer, int range, vo_range_t *sr );
+void vo_tz_search( const vo_me_ctx_t *c, const vo_tz_job_t *job, vo_me_result_t *res );
+void vo_full_search( const vo_me_ctx_t *c, const vo_range_t *sr, vo_me_result_t *res );
+void vo_frac_search( const vo_me_ctx_t *c, int intX, int intY, int useHad, int useAltHpelIf, vo_frac_result_t *res );
+
+#ifdef __cplusplus
+}
+#endif
+#endif
