@@ -1,0 +1,161 @@
+/*
+ * vtmhip.h -- C ABI of libvtmhip.so: MI355X (gfx950) implementation of the VTM 9.3 inter motion-estimation +
+ * transform/quantisation hot path.  Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * Two layers:
+ *   (1) POINTER-SURFACE calls (host pointers in, host results out): one entry point per slot of the reference's
+ *       function-pointer dispatch surface, same argument meaning, so a `initRdCostHIP()`-style installer can
+ *       trampoline into them.  They stage the operands to the device, run the SAME kernels as
+ *       layer 2 with a batch of one and copy the result back: correct drop-ins, not fast ones (a launch costs more
+ *       than the whole CPU call, SURVEY.md section 7 hard part 1).
+ *   (2) BATCHED DEVICE calls (`*_dev`): operands already resident in HBM (device pointers), many jobs per launch,
+ *       asynchronous on the context's stream.  This is the product path; the hooks B1..B10 of SURVEY.md Appendix B
+ *       feed it.
+ *
+ * Reference interfaces replaced (paths relative to /root/reference/source/Lib):
+ *   DistParam::distFunc / RdCost::m_afpDistortFunc[DF_SAD*|DF_HAD*|DF_SSE*]   CommonLib/RdCost.h:60,67-105,113; RdCost.cpp:125-217
+ *   RdCost::getCostOfVectorWithPredictor                                       CommonLib/RdCost.h:301-315
+ *   InterSearch::xTZSearch / xPatternSearch / xPatternSearchFracDIF            EncoderLib/InterSearch.cpp:3640-3976, 3566-3608, 4284-4339
+ *   InterpolationFilter::m_filterHor/m_filterVer/m_filterCopy                  CommonLib/InterpolationFilter.h:93-96
+ *   fastFwdTrans / fastInvTrans, TrQuant::xT / xIT                             CommonLib/TrQuant.cpp:69-81, 776-923
+ *   Quant::quant / Quant::dequant (flat scaling list)                          CommonLib/Quant.cpp:955-1038, 357-482
+ *   AffineGradientSearch::m_HorizontalSobelFilter/m_VerticalSobelFilter/m_EqualCoeffComputer  CommonLib/AffineGradientSearch.h:50-54
+ *   PelBufferOps::removeHighFreq / addAvg                                      CommonLib/Buffer.h:64-81
+ *
+ * Types: Pel = int16_t, TCoeff = int32_t, Distortion = uint64_t (CommonLib/TypeDef.h:259-270).
+ * Every function returns VTMHIP_OK (0) or a negative VTMHIP_E_* code and never throws; a C++ trampoline turns a
+ * non-zero status into the reference's THROW (TypeDef.h:1065-1081).
+ */
+#ifndef VTMHIP_H
+#define VTMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VTMHIP_ABI_VERSION 1
+
+enum
+{
+  VTMHIP_OK            = 0,
+  VTMHIP_E_INVALID     = -1,   /* bad argument (the reference would THROW "Unsupported size" / CHECK) */
+  VTMHIP_E_NODEVICE    = -2,   /* no HIP device / device index out of range */
+  VTMHIP_E_HIP         = -3,   /* a HIP runtime call failed; see vtmhip_last_error() */
+  VTMHIP_E_NOMEM       = -4,
+  VTMHIP_E_UNSUPPORTED = -5    /* caller must keep its CPU path (applyWeight, useMR, step != 1, explicit scaling lists, ...) */
+};
+
+enum { VTMHIP_DIST_SAD = 0, VTMHIP_DIST_SATD = 1, VTMHIP_DIST_SSE = 2 };
+enum { VTMHIP_DCT2 = 0, VTMHIP_DCT8 = 1, VTMHIP_DST7 = 2 };   /* TransType, CommonLib/TypeDef.h */
+
+typedef struct vtmhip_ctx vtmhip_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------------------ */
+int         vtmhip_abi_version( void );
+int         vtmhip_struct_size( int which );   /* sizeof() of the job/result structs below, in declaration order (0 = vtmhip_dist_job ...): lets a foreign-language binding verify its layout */
+int         vtmhip_device_count( int *count );
+int         vtmhip_create( int device, vtmhip_ctx **ctx );              /* one context per encoder stack / per rank */
+int         vtmhip_destroy( vtmhip_ctx *ctx );
+int         vtmhip_set_stream( vtmhip_ctx *ctx, void *hipStream );     /* NULL = the context's own stream */
+int         vtmhip_sync( vtmhip_ctx *ctx );                            /* waits for the context's stream */
+const char *vtmhip_last_error( vtmhip_ctx *ctx );
+const char *vtmhip_status_string( int status );
+
+/* device memory helpers for hosts without their own allocator (the C++ encoder); torch hosts pass data_ptr() */
+int vtmhip_dev_alloc( vtmhip_ctx *ctx, size_t bytes, void **devPtr );
+int vtmhip_dev_free( vtmhip_ctx *ctx, void *devPtr );
+int vtmhip_h2d( vtmhip_ctx *ctx, void *dev, const void *host, size_t bytes );   /* asynchronous on the stream */
+int vtmhip_d2h( vtmhip_ctx *ctx, void *host, const void *dev, size_t bytes );   /* synchronises before returning */
+/* stream timing with HIP events (bench.py uses this around the timed region) */
+int vtmhip_timer_start( vtmhip_ctx *ctx );
+int vtmhip_timer_stop_ms( vtmhip_ctx *ctx, float *ms );   /* synchronises */
+
+/* ================================================================================================================
+ * (1) POINTER-SURFACE CALLS -- host pointers
+ * ============================================================================================================== */
+
+/* DistParam::distFunc for DF_SAD* / DF_HAD* / DF_SSE* (RdCost.cpp:493-1003, 2819-2934, 1783-2133).
+ * org/cur: top-left sample of the W x H blocks, strides in samples.  subShift as DistParam::subShift (SAD only).
+ * Any int16 sample values are accepted (bi-pred ME passes 2*org - pred).
+ * The reference guards (applyWeight, useMR, step != 1) stay in the trampoline: fall back to the scalar function. */
+int vtmhip_xGetSAD( vtmhip_ctx *ctx, const int16_t *org, int orgStride, const int16_t *cur, int curStride, int width, int height, int subShift,
+                    uint64_t *dist );
+int vtmhip_xGetHADs( vtmhip_ctx *ctx, const int16_t *org, int orgStride, const int16_t *cur, int curStride, int width, int height,
+                     uint64_t *dist );
+int vtmhip_xGetSSE( vtmhip_ctx *ctx, const int16_t *org, int orgStride, const int16_t *cur, int curStride, int width, int height,
+                    uint64_t *dist );
+
+/* ================================================================================================================
+ * (2) BATCHED DEVICE CALLS -- device pointers, asynchronous on the context's stream
+ * ============================================================================================================== */
+
+/* One distortion evaluation: org block at orgBase + orgOff, candidate block at curBase + curOff (offsets in samples). */
+typedef struct
+{
+  int64_t orgOff;
+  int64_t curOff;
+  int32_t orgStride;
+  int32_t curStride;
+  int16_t width;
+  int16_t height;
+  int16_t subShift;   /* SAD only */
+  int16_t kind;       /* VTMHIP_DIST_* */
+} vtmhip_dist_job;
+
+/* n independent distFunc evaluations (hooks B1-B7, B10).  d_jobs and d_dist are device arrays of n entries. */
+int vtmhip_dist_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_curBase, const vtmhip_dist_job *d_jobs, int n,
+                           uint64_t *d_dist );
+
+/* SATD 8x8 block-grid micro-benchmark: every 8-aligned 8x8 block of the W x H org picture against the
+ * reference picture displaced by (dx,dy) in [-r,r]^2.  d_ref must carry >= r samples of valid margin on every side.
+ * d_dist[(by*(W/8)+bx)*(2r+1)^2 + (dy+r)*(2r+1) + (dx+r)], 32-bit (an 8x8 SATD of int16 samples fits). */
+int vtmhip_satd8_grid_dev( vtmhip_ctx *ctx, const int16_t *d_org, int orgStride, const int16_t *d_ref, int refStride, int width, int height,
+                           int r, uint32_t *d_dist );
+
+/* ---- integer motion search ----------------------------------------------------------------------------------- */
+typedef struct
+{
+  int32_t picW, picH;   /* pps.getPicWidth/HeightInLumaSamples: clipMv / xClipMv limits */
+  int32_t ctuSize;      /* sps.getMaxCUWidth() */
+  int32_t bitDepth;
+} vtmhip_pic_params;
+
+/* One (PU, reference picture) integer search = one call of InterSearch::xTZSearch. */
+typedef struct
+{
+  int64_t orgOff;       /* sample offset of the PU's top-left in the original plane (pcPatternKey)         */
+  int64_t refOff;       /* sample offset of the SAME position (MV 0,0) in the reference plane (piRefY)      */
+  int32_t orgStride, refStride;
+  int16_t puX, puY;     /* luma position of the PU in the picture                                          */
+  int16_t width, height;
+  int16_t subShift;     /* DistParam::subShift after setDistParam(subShiftMode) (RdCost.cpp:289-323)       */
+  int16_t imvShift;
+  int32_t predHor, predVer;     /* RdCost::setPredictor, quarter-sample units                              */
+  double  motionLambda;         /* RdCost::m_motionLambda                                                  */
+  int32_t mvHor, mvVer;         /* rcMv on entry (internal 1/16 precision)                                 */
+  int32_t searchRange;          /* m_iSearchRange                                                          */
+  uint8_t extendedSettings, fastSettings, firstSearchStop, hasIntMv2Nx2NPred;
+  int32_t intMv2Nx2NPredHor, intMv2Nx2NPredVer;
+  int32_t numExtraStart;        /* m_uniMvList candidates, de-duplicated by the caller (InterSearch.cpp:3728-3746) */
+  int32_t extraStart[15][2];    /* internal precision */
+} vtmhip_tz_job;
+
+typedef struct
+{
+  int32_t  mvX, mvY;   /* integer MV (rcMv on return) */
+  uint32_t nEval;      /* distFunc evaluations performed (statistics; the reference does not return it) */
+  uint32_t reserved;
+  uint64_t cost;       /* cStruct.uiBestSad: distortion + MV rate */
+  uint64_t dist;       /* ruiSAD */
+} vtmhip_me_result;
+
+int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                const vtmhip_tz_job *d_jobs, int n, vtmhip_me_result *d_results );
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTMHIP_H */

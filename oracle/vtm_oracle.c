@@ -79,7 +79,7 @@ uint64_t vo_sse( const int16_t *org, int orgStride, const int16_t *cur, int curS
     for( int x = 0; x < w; x++ )
     {
       const int32_t d = ( int32_t ) org[( ptrdiff_t ) y * orgStride + x] - ( int32_t ) cur[( ptrdiff_t ) y * curStride + x];
-      sum += ( uint64_t )( uint32_t )( d * d );
+      sum += ( uint64_t )( ( uint32_t ) d * ( uint32_t ) d );   /* |d| > 46340 overflows the reference's int product (UB there); we define it as 32-bit wrap */
     }
   }
   return sum;

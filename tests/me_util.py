@@ -1,0 +1,104 @@
+"""Shared helpers for the motion-search tests: builds the same randomized jobs for the oracle (vo_*), the reference
+shim (ref_*) and the HIP kernels."""
+import ctypes as C
+
+import numpy as np
+
+import oracle_lib as ol
+from vtm_amd import synth
+from vtm_amd.lib import TzJob as HipTzJob
+
+PU_W = [8, 16, 32, 64, 128, 4, 16, 8, 32, 64, 12, 24, 48]
+PU_H = [8, 16, 32, 64, 128, 8, 4, 16]
+
+
+class Scene:
+    """Two frames of the synthetic clip: `cur` (original) and the border-extended reference plane."""
+
+    def __init__(self, w=416, h=240, hard=True, t_ref=0, t_cur=2, margin=160):
+        fr = (synth.gen_frames_hard if hard else synth.gen_frames)(w, h, t_cur + 1)
+        self.W, self.H = w, h
+        self.cur = np.ascontiguousarray(fr[t_cur])
+        self.ref_buf, self.ref_off, self.ref_stride = synth.extend_plane(fr[t_ref], margin)
+        self.margin = margin
+
+
+def random_tz_jobs(scene, n, seed=5, ranges=(64, 96, 192, 384, 8), allow_ext=True):
+    rng = np.random.default_rng(seed)
+    jobs = []
+    trial = 0
+    while len(jobs) < n:
+        trial += 1
+        w = int(rng.choice(PU_W))
+        h = int(rng.choice(PU_H))
+        if w > scene.W or h > scene.H:
+            continue
+        x = int(rng.integers(0, (scene.W - w) // 4 + 1)) * 4
+        y = int(rng.integers(0, (scene.H - h) // 4 + 1)) * 4
+        j = dict(w=w, h=h, x=x, y=y, subShift=1 if (h > 8 and w <= 64) else 0,
+                 lam=float(rng.uniform(1, 40)), predHor=int(rng.integers(-64, 64)), predVer=int(rng.integers(-64, 64)),
+                 mvHor=int(rng.integers(-40 * 16, 40 * 16)), mvVer=int(rng.integers(-30 * 16, 30 * 16)),
+                 searchRange=int(rng.choice(ranges)),
+                 ext=int(allow_ext and trial % 5 == 0), fast=int(trial % 11 == 0), firstStop=int(trial % 3 != 0),
+                 hasInt=int(trial % 4 == 0), intHor=int(rng.integers(-20, 20)), intVer=int(rng.integers(-20, 20)),
+                 extra=[(int(rng.integers(-30 * 16, 30 * 16)), int(rng.integers(-30 * 16, 30 * 16)))
+                        for _ in range(int(rng.integers(0, 6)))])
+        if trial % 7 == 0:
+            j["mvHor"] = j["mvVer"] = 0
+        jobs.append(j)
+    return jobs
+
+
+def oracle_ctx(scene, j, org_block):
+    c = ol.MeCtx()
+    c.org = org_block.ctypes.data
+    c.orgStride = org_block.shape[1]
+    c.ref = scene.ref_buf.ctypes.data + 2 * (scene.ref_off + j["y"] * scene.ref_stride + j["x"])
+    c.refStride = scene.ref_stride
+    c.w, c.h, c.subShift, c.bitDepth, c.imvShift = j["w"], j["h"], j["subShift"], 10, 0
+    c.mv = ol.MvCost(j["lam"], j["predHor"], j["predVer"], 2)
+    c.picW, c.picH, c.puX, c.puY, c.ctuSize = scene.W, scene.H, j["x"], j["y"], 128
+    return c
+
+
+def oracle_tz_job(j):
+    t = ol.TzJob()
+    t.mvHor, t.mvVer, t.searchRange = j["mvHor"], j["mvVer"], j["searchRange"]
+    t.extendedSettings, t.fastSettings, t.firstSearchStop = j["ext"], j["fast"], j["firstStop"]
+    t.hasIntMv2Nx2NPred, t.intMv2Nx2NPredHor, t.intMv2Nx2NPredVer = j["hasInt"], j["intHor"], j["intVer"]
+    t.numExtraStart = len(j["extra"])
+    for i, (a, b) in enumerate(j["extra"]):
+        t.extraStart[i][0], t.extraStart[i][1] = a, b
+    return t
+
+
+def hip_tz_jobs(scene, jobs, cur_stride):
+    arr = (HipTzJob * len(jobs))()
+    for k, j in enumerate(jobs):
+        t = arr[k]
+        t.orgOff = j["y"] * cur_stride + j["x"]
+        t.refOff = scene.ref_off + j["y"] * scene.ref_stride + j["x"]
+        t.orgStride, t.refStride = cur_stride, scene.ref_stride
+        t.puX, t.puY, t.width, t.height = j["x"], j["y"], j["w"], j["h"]
+        t.subShift, t.imvShift = j["subShift"], 0
+        t.predHor, t.predVer, t.motionLambda = j["predHor"], j["predVer"], j["lam"]
+        t.mvHor, t.mvVer, t.searchRange = j["mvHor"], j["mvVer"], j["searchRange"]
+        t.extendedSettings, t.fastSettings, t.firstSearchStop = j["ext"], j["fast"], j["firstStop"]
+        t.hasIntMv2Nx2NPred, t.intMv2Nx2NPredHor, t.intMv2Nx2NPredVer = j["hasInt"], j["intHor"], j["intVer"]
+        t.numExtraStart = len(j["extra"])
+        for i, (a, b) in enumerate(j["extra"]):
+            t.extraStart[i][0], t.extraStart[i][1] = a, b
+    return arr
+
+
+def run_oracle_tz(scene, jobs):
+    L = ol.oracle()
+    out = []
+    for j in jobs:
+        org = np.ascontiguousarray(scene.cur[j["y"]:j["y"] + j["h"], j["x"]:j["x"] + j["w"]])
+        c = oracle_ctx(scene, j, org)
+        t = oracle_tz_job(j)
+        r = ol.MeResult()
+        L.vo_tz_search(C.byref(c), C.byref(t), C.byref(r))
+        out.append((r.mvX, r.mvY, r.cost, r.dist, r.nEval))
+    return out

@@ -1,0 +1,158 @@
+// ctx.hip -- context management, memory helpers and stream timing of the C ABI (include/vtmhip.h).
+#include "ctx.hpp"
+
+extern "C"
+{
+
+int vtmhip_abi_version( void ) { return VTMHIP_ABI_VERSION; }
+
+int vtmhip_struct_size( int which )
+{
+  switch( which )
+  {
+  case 0: return ( int ) sizeof( vtmhip_dist_job );
+  case 1: return ( int ) sizeof( vtmhip_tz_job );
+  case 2: return ( int ) sizeof( vtmhip_me_result );
+  case 3: return ( int ) sizeof( vtmhip_pic_params );
+  default: return -1;
+  }
+}
+
+const char *vtmhip_status_string( int status )
+{
+  switch( status )
+  {
+  case VTMHIP_OK: return "ok";
+  case VTMHIP_E_INVALID: return "invalid argument";
+  case VTMHIP_E_NODEVICE: return "no such HIP device";
+  case VTMHIP_E_HIP: return "HIP runtime error";
+  case VTMHIP_E_NOMEM: return "out of memory";
+  case VTMHIP_E_UNSUPPORTED: return "unsupported on the device path (keep the CPU function)";
+  default: return "unknown status";
+  }
+}
+
+int vtmhip_device_count( int *count )
+{
+  if( !count ) return VTMHIP_E_INVALID;
+  int n = 0;
+  if( hipGetDeviceCount( &n ) != hipSuccess ) n = 0;
+  *count = n;
+  return VTMHIP_OK;
+}
+
+int vtmhip_create( int device, vtmhip_ctx **out )
+{
+  if( !out ) return VTMHIP_E_INVALID;
+  *out  = nullptr;
+  int n = 0;
+  if( hipGetDeviceCount( &n ) != hipSuccess || n <= 0 || device < 0 || device >= n ) return VTMHIP_E_NODEVICE;
+  vtmhip_ctx *ctx = new( std::nothrow ) vtmhip_ctx();
+  if( !ctx ) return VTMHIP_E_NOMEM;
+  ctx->device = device;
+  if( hipSetDevice( device ) != hipSuccess || hipStreamCreateWithFlags( &ctx->ownStream, hipStreamNonBlocking ) != hipSuccess ||
+      hipEventCreate( &ctx->evStart ) != hipSuccess || hipEventCreate( &ctx->evStop ) != hipSuccess )
+  {
+    delete ctx;
+    return VTMHIP_E_HIP;
+  }
+  hipDeviceProp_t prop;
+  if( hipGetDeviceProperties( &prop, device ) == hipSuccess ) ctx->numCUs = prop.multiProcessorCount;
+  ctx->stream = ctx->ownStream;
+  *out        = ctx;
+  return VTMHIP_OK;
+}
+
+int vtmhip_destroy( vtmhip_ctx *ctx )
+{
+  if( !ctx ) return VTMHIP_OK;
+  ( void ) hipSetDevice( ctx->device );
+  ( void ) hipStreamSynchronize( ctx->stream );
+  if( ctx->scratch ) ( void ) hipFree( ctx->scratch );
+  if( ctx->pinned ) ( void ) hipHostFree( ctx->pinned );
+  if( ctx->evStart ) ( void ) hipEventDestroy( ctx->evStart );
+  if( ctx->evStop ) ( void ) hipEventDestroy( ctx->evStop );
+  if( ctx->ownStream ) ( void ) hipStreamDestroy( ctx->ownStream );
+  delete ctx;
+  return VTMHIP_OK;
+}
+
+int vtmhip_set_stream( vtmhip_ctx *ctx, void *hipStream )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  ctx->stream = hipStream ? ( hipStream_t ) hipStream : ctx->ownStream;
+  return VTMHIP_OK;
+}
+
+int vtmhip_sync( vtmhip_ctx *ctx )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  return VTMHIP_OK;
+}
+
+const char *vtmhip_last_error( vtmhip_ctx *ctx ) { return ctx ? ctx->lastError.c_str() : "null context"; }
+
+int vtmhip_dev_alloc( vtmhip_ctx *ctx, size_t bytes, void **devPtr )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, devPtr != nullptr, "devPtr" );
+  VTMHIP_HIP( ctx, hipSetDevice( ctx->device ) );
+  VTMHIP_HIP( ctx, hipMalloc( devPtr, bytes ? bytes : 1 ) );
+  return VTMHIP_OK;
+}
+
+int vtmhip_dev_free( vtmhip_ctx *ctx, void *devPtr )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  if( devPtr ) VTMHIP_HIP( ctx, hipFree( devPtr ) );
+  return VTMHIP_OK;
+}
+
+int vtmhip_h2d( vtmhip_ctx *ctx, void *dev, const void *host, size_t bytes )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( dev, host, bytes, hipMemcpyHostToDevice, ctx->stream ) );
+  return VTMHIP_OK;
+}
+
+int vtmhip_d2h( vtmhip_ctx *ctx, void *host, const void *dev, size_t bytes )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream ) );
+  VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  return VTMHIP_OK;
+}
+
+int vtmhip_timer_start( vtmhip_ctx *ctx )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_HIP( ctx, hipEventRecord( ctx->evStart, ctx->stream ) );
+  return VTMHIP_OK;
+}
+
+int vtmhip_timer_stop_ms( vtmhip_ctx *ctx, float *ms )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, ms != nullptr, "ms" );
+  VTMHIP_HIP( ctx, hipEventRecord( ctx->evStop, ctx->stream ) );
+  VTMHIP_HIP( ctx, hipEventSynchronize( ctx->evStop ) );
+  VTMHIP_HIP( ctx, hipEventElapsedTime( ms, ctx->evStart, ctx->evStop ) );
+  return VTMHIP_OK;
+}
+
+}   // extern "C"
+
+int vtmhip_internal_scratch( vtmhip_ctx *ctx, size_t bytes )
+{
+  if( bytes <= ctx->scratchSize ) return VTMHIP_OK;
+  size_t want = ( bytes + ( 1u << 20 ) - 1 ) & ~( size_t )( ( 1u << 20 ) - 1 );
+  VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  if( ctx->scratch ) VTMHIP_HIP( ctx, hipFree( ctx->scratch ) );
+  if( ctx->pinned ) VTMHIP_HIP( ctx, hipHostFree( ctx->pinned ) );
+  ctx->scratch = nullptr; ctx->pinned = nullptr; ctx->scratchSize = 0; ctx->pinnedSize = 0;
+  VTMHIP_HIP( ctx, hipMalloc( &ctx->scratch, want ) );
+  VTMHIP_HIP( ctx, hipHostMalloc( &ctx->pinned, want ) );
+  ctx->scratchSize = ctx->pinnedSize = want;
+  return VTMHIP_OK;
+}

@@ -1,0 +1,67 @@
+// ctx.hpp -- context object and small host/device helpers shared by the libvtmhip.so translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/vtmhip.h"
+
+struct vtmhip_ctx
+{
+  int         device      = 0;
+  hipStream_t ownStream   = nullptr;
+  hipStream_t stream      = nullptr;   // the stream every launch goes to (own or caller-supplied)
+  hipEvent_t  evStart     = nullptr;
+  hipEvent_t  evStop      = nullptr;
+  void       *scratch     = nullptr;   // staging area for the pointer-surface (host pointer) calls
+  size_t      scratchSize = 0;
+  void       *pinned      = nullptr;   // pinned host mirror of the staging area
+  size_t      pinnedSize  = 0;
+  int         numCUs      = 256;
+  std::string lastError;
+};
+
+#define VTMHIP_CHECK_CTX( ctx ) \
+  do { if( !( ctx ) ) return VTMHIP_E_INVALID; } while( 0 )
+
+#define VTMHIP_HIP( ctx, call )                                                                        \
+  do {                                                                                                 \
+    hipError_t e_ = ( call );                                                                          \
+    if( e_ != hipSuccess )                                                                             \
+    {                                                                                                  \
+      ( ctx )->lastError = std::string( #call ) + ": " + hipGetErrorString( e_ );                      \
+      return VTMHIP_E_HIP;                                                                             \
+    }                                                                                                  \
+  } while( 0 )
+
+#define VTMHIP_REQUIRE( ctx, cond, msg )                   \
+  do {                                                     \
+    if( !( cond ) )                                        \
+    {                                                      \
+      ( ctx )->lastError = std::string( "invalid argument: " ) + ( msg ); \
+      return VTMHIP_E_INVALID;                             \
+    }                                                      \
+  } while( 0 )
+
+// launch-error check after a kernel launch (asynchronous errors surface at the next sync)
+#define VTMHIP_LAUNCHED( ctx ) VTMHIP_HIP( ctx, hipGetLastError() )
+
+int vtmhip_internal_scratch( vtmhip_ctx *ctx, size_t bytes );   // grows ctx->scratch / ctx->pinned
+
+// ---- device helpers -------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_reduce_add( int v )
+{
+#pragma unroll
+  for( int o = 32; o > 0; o >>= 1 ) v += __shfl_xor( v, o, 64 );
+  return v;
+}
+
+__device__ __forceinline__ unsigned long long wave_reduce_add_u64( unsigned long long v )
+{
+#pragma unroll
+  for( int o = 32; o > 0; o >>= 1 ) v += __shfl_xor( v, o, 64 );
+  return v;
+}

@@ -1,0 +1,296 @@
+// dist.hip -- distortion kernels: SAD / SATD (Hadamard) / SSE.
+//
+// Replaces RdCost::m_afpDistortFunc[DF_SAD*|DF_HAD*|DF_SSE*] (reference CommonLib/RdCost.cpp:493-1003, 2140-2934,
+// 1783-2133; x86 versions CommonLib/x86/RdCostX86.h).  Integer results are bit-exact with the reference for any
+// int16 input (diffs are formed in 32-bit; the rectangular-tile SATD normalisation is done in fp64 exactly as
+// RdCost.cpp:2513,2654,2731,2814 does).
+//
+// Kernels (wave = 64 lanes, gfx950):
+//   dist_batch_kernel   one wave per (org block, candidate block) job, arbitrary W x H -- hooks B1-B7/B10.
+//   satd8_grid_kernel   8x8 SATD of every aligned 8x8 block x (2r+1)^2 displacements: the reference tile of a
+//                       workgroup is staged ONCE in LDS with coalesced 16-byte loads and re-used by all displacements
+//                       (HBM traffic ~ one read of each picture; the kernel is integer-VALU bound).
+#include "ctx.hpp"
+
+namespace
+{
+
+// ---- Hadamard building blocks (32-bit, order-free: only sum|coef| and coef[0] matter) ----------
+template<int N, int STRIDE>
+__device__ __forceinline__ void wht1d( int *m )
+{
+#pragma unroll
+  for( int len = 1; len < N; len <<= 1 )
+  {
+#pragma unroll
+    for( int i = 0; i < N; i += len << 1 )
+    {
+#pragma unroll
+      for( int j = i; j < i + len; j++ )
+      {
+        const int a = m[j * STRIDE], b = m[( j + len ) * STRIDE];
+        m[j * STRIDE]           = a + b;
+        m[( j + len ) * STRIDE] = a - b;
+      }
+    }
+  }
+}
+
+// m[] holds the TW x TH differences (row-major) on entry.  Returns the per-tile SATD with the reference's
+// mean-scaled dc (JVET_R0164) and per-shape normalisation.
+template<int TW, int TH>
+__device__ __forceinline__ unsigned had_finish( int *m )
+{
+#pragma unroll
+  for( int y = 0; y < TH; y++ ) wht1d<TW, 1>( m + y * TW );
+#pragma unroll
+  for( int x = 0; x < TW; x++ ) wht1d<TH, TW>( m + x );
+  int t = 0;
+#pragma unroll
+  for( int i = 0; i < TW * TH; i++ ) t += abs( m[i] );
+  const int dc = abs( m[0] );
+  t            = t - dc + ( dc >> 2 );
+  if( TW == 2 && TH == 2 ) return ( unsigned ) t;
+  if( TW == 4 && TH == 4 ) return ( unsigned ) ( ( t + 1 ) >> 1 );
+  if( TW == 8 && TH == 8 ) return ( unsigned ) ( ( t + 2 ) >> 2 );
+  if( TW * TH == 128 ) return ( unsigned ) ( int ) ( ( double ) t / 11.313708498984761 * 2.0 );   // sqrt(16.0*8)
+  return ( unsigned ) ( int ) ( ( double ) t / 5.656854249492381 * 2.0 );                        // sqrt(4.0*8)
+}
+
+template<int TW, int TH>
+__device__ __forceinline__ unsigned had_tile( const int16_t *o, int os, const int16_t *c, int cs )
+{
+  int m[TW * TH];
+#pragma unroll
+  for( int y = 0; y < TH; y++ )
+  {
+#pragma unroll
+    for( int x = 0; x < TW; x++ ) m[y * TW + x] = ( int ) o[y * os + x] - ( int ) c[y * cs + x];
+  }
+  return had_finish<TW, TH>( m );
+}
+
+// ---- general batch: one wave per job ------------------------------------------------------------------------------
+__global__ __launch_bounds__( 256 ) void dist_batch_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ curBase,
+                                                           const vtmhip_dist_job *__restrict__ jobs, int n, unsigned long long *__restrict__ out )
+{
+  const int lane = threadIdx.x & 63;
+  const int job  = blockIdx.x * ( blockDim.x >> 6 ) + ( threadIdx.x >> 6 );
+  if( job >= n ) return;   // whole wave leaves together
+  const vtmhip_dist_job j   = jobs[job];
+  const int16_t        *org = orgBase + j.orgOff;
+  const int16_t        *cur = curBase + j.curOff;
+  const int             w = j.width, h = j.height, os = j.orgStride, cs = j.curStride;
+  unsigned long long    acc = 0;
+
+  if( j.kind == VTMHIP_DIST_SAD )
+  {
+    // rows y = 0, step, 2*step ...; work items = (row, 4-sample segment)
+    const int ss = j.subShift, rows = ( h + ( 1 << ss ) - 1 ) >> ss, segs = w >> 2;
+    unsigned  s = 0;
+    for( int it = lane; it < rows * segs; it += 64 )
+    {
+      const int      r = it / segs, x = ( it - r * segs ) << 2;
+      const int16_t *o = org + ( long ) ( r << ss ) * os + x;
+      const int16_t *c = cur + ( long ) ( r << ss ) * cs + x;
+#pragma unroll
+      for( int k = 0; k < 4; k++ ) s += ( unsigned ) abs( ( int ) o[k] - ( int ) c[k] );
+    }
+    acc = ( unsigned long long ) s << ss;   // per-lane partial (W*H*65535 < 2^32 for W,H <= 128 needs care: 128*128*65535 = 2^30)
+  }
+  else if( j.kind == VTMHIP_DIST_SSE )
+  {
+    const int segs = w >> 2;
+    for( int it = lane; it < h * segs; it += 64 )
+    {
+      const int      r = it / segs, x = ( it - r * segs ) << 2;
+      const int16_t *o = org + ( long ) r * os + x;
+      const int16_t *c = cur + ( long ) r * cs + x;
+#pragma unroll
+      for( int k = 0; k < 4; k++ )
+      {
+        const int d = ( int ) o[k] - ( int ) c[k];
+        acc += ( unsigned long long ) ( ( unsigned ) d * ( unsigned ) d );   // per-addend 32-bit product as RdCost.cpp:1783-1814
+      }
+    }
+  }
+  else   // SATD: tile shape by the rules of xGetHADs (RdCost.cpp:2837-2931); one tile per lane
+  {
+    int tw, th;
+    if( w > h && ( h & 7 ) == 0 && ( w & 15 ) == 0 ) { tw = 16; th = 8; }
+    else if( w < h && ( w & 7 ) == 0 && ( h & 15 ) == 0 ) { tw = 8; th = 16; }
+    else if( w > h && ( h & 3 ) == 0 && ( w & 7 ) == 0 ) { tw = 8; th = 4; }
+    else if( w < h && ( w & 3 ) == 0 && ( h & 7 ) == 0 ) { tw = 4; th = 8; }
+    else if( ( h & 7 ) == 0 && ( w & 7 ) == 0 ) { tw = 8; th = 8; }
+    else if( ( h & 3 ) == 0 && ( w & 3 ) == 0 ) { tw = 4; th = 4; }
+    else { tw = 2; th = 2; }
+    const int tx = w / tw, ty = h / th;
+    for( int it = lane; it < tx * ty; it += 64 )
+    {
+      const int      y = ( it / tx ) * th, x = ( it % tx ) * tw;
+      const int16_t *o = org + ( long ) y * os + x;
+      const int16_t *c = cur + ( long ) y * cs + x;
+      unsigned       v;
+      if( tw == 16 ) v = had_tile<16, 8>( o, os, c, cs );
+      else if( th == 16 ) v = had_tile<8, 16>( o, os, c, cs );
+      else if( tw == 8 && th == 4 ) v = had_tile<8, 4>( o, os, c, cs );
+      else if( tw == 4 && th == 8 ) v = had_tile<4, 8>( o, os, c, cs );
+      else if( tw == 8 ) v = had_tile<8, 8>( o, os, c, cs );
+      else if( tw == 4 ) v = had_tile<4, 4>( o, os, c, cs );
+      else v = had_tile<2, 2>( o, os, c, cs );
+      acc += v;
+    }
+  }
+  acc = wave_reduce_add_u64( acc );
+  if( lane == 0 ) out[job] = acc;
+}
+
+// ---- SATD 8x8 grid ---------------------------------------------------------------------------------------------------
+// Workgroup = 256 threads = TBX x TBY org blocks; LDS holds the org tile and the reference tile (+r halo).
+constexpr int GRID_TBX = 8, GRID_TBY = 4;
+
+__global__ __launch_bounds__( 256 ) void satd8_grid_kernel( const int16_t *__restrict__ org, int orgStride, const int16_t *__restrict__ ref,
+                                                           int refStride, int bw, int bh, int r, unsigned *__restrict__ out )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];
+  const int nd = 2 * r + 1, nd2 = nd * nd;
+  const int refW = GRID_TBX * 8 + 2 * r, refH = GRID_TBY * 8 + 2 * r;
+  const int refLd = ( refW + 7 ) & ~7;   // keep rows 16-byte aligned
+  int16_t  *sOrg = lds;                                   // [TBY*8][TBX*8]
+  int16_t  *sRef = lds + GRID_TBY * 8 * GRID_TBX * 8;     // [refH][refLd]
+  const int bx0 = blockIdx.x * GRID_TBX, by0 = blockIdx.y * GRID_TBY;
+
+  // stage org tile: 32 rows x 64 samples = 256 x 16-byte vectors, one per thread (coalesced 128-byte rows)
+  {
+    const int row = threadIdx.x >> 3, seg = threadIdx.x & 7;
+    const int gy = by0 * 8 + row, gx = bx0 * 8 + seg * 8;
+    int4      v  = make_int4( 0, 0, 0, 0 );
+    if( gy < bh * 8 && gx < bw * 8 ) v = *reinterpret_cast<const int4 *>( org + ( long ) gy * orgStride + gx );
+    *reinterpret_cast<int4 *>( sOrg + row * 64 + seg * 8 ) = v;
+  }
+  // stage reference tile: refH rows x refW samples starting at (bx0*8 - r, by0*8 - r); 2-byte granularity on the
+  // global side (the halo start is not 16-byte aligned), dword stores on the LDS side
+  const int needW = min( GRID_TBX, bw - bx0 ) * 8 + 2 * r, needH = min( GRID_TBY, bh - by0 ) * 8 + 2 * r;   // never read past the last block's halo
+  for( int i = threadIdx.x; i < refH * ( refLd >> 1 ); i += 256 )
+  {
+    const int      row = i / ( refLd >> 1 ), c2 = ( i - row * ( refLd >> 1 ) ) << 1;
+    const int16_t *p   = ref + ( long ) ( by0 * 8 - r + row ) * refStride + ( bx0 * 8 - r + c2 );
+    int16_t        a = 0, b = 0;
+    if( row < needH && c2 < needW ) a = p[0];
+    if( row < needH && c2 + 1 < needW ) b = p[1];
+    *reinterpret_cast<unsigned *>( sRef + row * refLd + c2 ) = ( unsigned ) ( unsigned short ) a | ( ( unsigned ) ( unsigned short ) b << 16 );
+  }
+  __syncthreads();
+
+  const int pairs = GRID_TBX * GRID_TBY * nd2;
+  for( int p = threadIdx.x; p < pairs; p += 256 )
+  {
+    const int b = p / nd2, d = p - b * nd2;
+    const int lby = b / GRID_TBX, lbx = b - lby * GRID_TBX;
+    const int dy = d / nd, dx = d - dy * nd;   // 0..2r
+    if( bx0 + lbx >= bw || by0 + lby >= bh ) continue;
+    const int16_t *o = sOrg + lby * 8 * 64 + lbx * 8;
+    const int16_t *c = sRef + ( lby * 8 + dy ) * refLd + lbx * 8 + dx;
+    int            m[64];
+#pragma unroll
+    for( int y = 0; y < 8; y++ )
+    {
+#pragma unroll
+      for( int x = 0; x < 8; x++ ) m[y * 8 + x] = ( int ) o[y * 64 + x] - ( int ) c[y * refLd + x];
+    }
+    out[( ( long ) ( by0 + lby ) * bw + ( bx0 + lbx ) ) * nd2 + d] = had_finish<8, 8>( m );
+  }
+}
+
+int check_dist_args( vtmhip_ctx *ctx, int w, int h, int subShift, int kind )
+{
+  VTMHIP_REQUIRE( ctx, w >= 4 && h >= 4 && w <= 128 && h <= 128 && ( w & 3 ) == 0, "block size must be 4..128, width a multiple of 4" );
+  VTMHIP_REQUIRE( ctx, kind != VTMHIP_DIST_SATD || ( h & 1 ) == 0, "SATD needs even height" );
+  VTMHIP_REQUIRE( ctx, subShift >= 0 && subShift <= 4 && ( kind == VTMHIP_DIST_SAD || subShift == 0 ), "subShift" );
+  return VTMHIP_OK;
+}
+
+// pointer-surface helper: stage both blocks compactly (stride = width) and run a batch of one
+int dist_single( vtmhip_ctx *ctx, int kind, const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h, int subShift,
+                 uint64_t *dist )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, org && cur && dist, "null pointer" );
+  int st = check_dist_args( ctx, w, h, subShift, kind );
+  if( st ) return st;
+  const size_t blk = ( size_t ) w * h * sizeof( int16_t );
+  const size_t jobOff = ( 2 * blk + 63 ) & ~( size_t ) 63, outOff = jobOff + 64;
+  st = vtmhip_internal_scratch( ctx, outOff + 64 );
+  if( st ) return st;
+  char *hp = ( char * ) ctx->pinned, *dp = ( char * ) ctx->scratch;
+  for( int y = 0; y < h; y++ )
+  {
+    memcpy( hp + ( size_t ) y * w * 2, org + ( ptrdiff_t ) y * orgStride, ( size_t ) w * 2 );
+    memcpy( hp + blk + ( size_t ) y * w * 2, cur + ( ptrdiff_t ) y * curStride, ( size_t ) w * 2 );
+  }
+  vtmhip_dist_job j;
+  j.orgOff = 0; j.curOff = ( int64_t ) w * h; j.orgStride = w; j.curStride = w;
+  j.width = ( int16_t ) w; j.height = ( int16_t ) h; j.subShift = ( int16_t ) subShift; j.kind = ( int16_t ) kind;
+  memcpy( hp + jobOff, &j, sizeof( j ) );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( dp, hp, outOff, hipMemcpyHostToDevice, ctx->stream ) );
+  hipLaunchKernelGGL( dist_batch_kernel, dim3( 1 ), dim3( 256 ), 0, ctx->stream, ( const int16_t * ) dp, ( const int16_t * ) dp,
+                      ( const vtmhip_dist_job * ) ( dp + jobOff ), 1, ( unsigned long long * ) ( dp + outOff ) );
+  VTMHIP_LAUNCHED( ctx );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( hp + outOff, dp + outOff, 8, hipMemcpyDeviceToHost, ctx->stream ) );
+  VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  memcpy( dist, hp + outOff, 8 );
+  return VTMHIP_OK;
+}
+
+}   // namespace
+
+extern "C"
+{
+
+int vtmhip_xGetSAD( vtmhip_ctx *ctx, const int16_t *org, int orgStride, const int16_t *cur, int curStride, int width, int height, int subShift,
+                    uint64_t *dist )
+{
+  return dist_single( ctx, VTMHIP_DIST_SAD, org, orgStride, cur, curStride, width, height, subShift, dist );
+}
+
+int vtmhip_xGetHADs( vtmhip_ctx *ctx, const int16_t *org, int orgStride, const int16_t *cur, int curStride, int width, int height, uint64_t *dist )
+{
+  return dist_single( ctx, VTMHIP_DIST_SATD, org, orgStride, cur, curStride, width, height, 0, dist );
+}
+
+int vtmhip_xGetSSE( vtmhip_ctx *ctx, const int16_t *org, int orgStride, const int16_t *cur, int curStride, int width, int height, uint64_t *dist )
+{
+  return dist_single( ctx, VTMHIP_DIST_SSE, org, orgStride, cur, curStride, width, height, 0, dist );
+}
+
+int vtmhip_dist_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_curBase, const vtmhip_dist_job *d_jobs, int n,
+                           uint64_t *d_dist )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_orgBase && d_curBase && d_jobs && d_dist, "null pointer" );
+  const int wavesPerBlock = 4;
+  hipLaunchKernelGGL( dist_batch_kernel, dim3( ( n + wavesPerBlock - 1 ) / wavesPerBlock ), dim3( 64 * wavesPerBlock ), 0, ctx->stream,
+                      d_orgBase, d_curBase, d_jobs, n, ( unsigned long long * ) d_dist );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_satd8_grid_dev( vtmhip_ctx *ctx, const int16_t *d_org, int orgStride, const int16_t *d_ref, int refStride, int width, int height, int r,
+                           uint32_t *d_dist )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, d_org && d_ref && d_dist, "null pointer" );
+  VTMHIP_REQUIRE( ctx, width >= 8 && height >= 8 && r >= 0 && r <= 16, "size / range" );
+  VTMHIP_REQUIRE( ctx, ( orgStride & 7 ) == 0 && ( ( ( uintptr_t ) d_org ) & 15 ) == 0, "org plane must be 16-byte aligned with a stride multiple of 8" );
+  const int    bw = width / 8, bh = height / 8;
+  const int    refW = GRID_TBX * 8 + 2 * r, refH = GRID_TBY * 8 + 2 * r, refLd = ( refW + 7 ) & ~7;
+  const size_t lds = ( size_t ) ( GRID_TBY * 8 * GRID_TBX * 8 + refH * refLd ) * sizeof( int16_t );
+  dim3         grid( ( bw + GRID_TBX - 1 ) / GRID_TBX, ( bh + GRID_TBY - 1 ) / GRID_TBY );
+  hipLaunchKernelGGL( satd8_grid_kernel, grid, dim3( 256 ), lds, ctx->stream, d_org, orgStride, d_ref, refStride, bw, bh, r, d_dist );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+}   // extern "C"

@@ -1,0 +1,132 @@
+"""Thin Python host layer over the C ABI: context, device buffers and the batched calls.
+
+Plumbing only -- every computation happens in libvtmhip.so.  numpy arrays go in/out through
+vtmhip_dev_alloc / vtmhip_h2d / vtmhip_d2h; torch users pass `tensor.data_ptr()` wherever a device pointer is
+expected and `torch.cuda.current_stream().cuda_stream` to `Context.set_stream`."""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .lib import DistJob, MeResult, PicParams, TzJob, VtmHipError   # noqa: F401  (re-exported)
+
+
+class DevBuf:
+    """A device allocation owned by a Context (freed with the context or explicitly)."""
+
+    def __init__(self, ctx, nbytes, dtype=np.uint8, shape=None):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        self.dtype = np.dtype(dtype)
+        self.shape = shape
+        p = C.c_void_p()
+        ctx._check(ctx.L.vtmhip_dev_alloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+        ctx._bufs.append(self)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._keep.append(arr)   # the copy is asynchronous: keep the source alive until the next sync
+        self.ctx._check(self.ctx.L.vtmhip_h2d(self.ctx.h, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def to_host(self, dtype=None, shape=None):
+        dtype = np.dtype(dtype or self.dtype)
+        out = np.empty(self.nbytes // dtype.itemsize, dtype=dtype)
+        self.ctx._check(self.ctx.L.vtmhip_d2h(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes))
+        self.ctx._keep.clear()
+        shape = shape or self.shape
+        return out.reshape(shape) if shape is not None else out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.L.vtmhip_dev_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """One per process / GPU (reference analogue: one RdCost/InterSearch stack, EncLib.cpp:110-122)."""
+
+    def __init__(self, device=0):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        st = self.L.vtmhip_create(device, C.byref(h))
+        if st != _lib.OK:
+            raise VtmHipError(st, self.L.vtmhip_status_string(st).decode())
+        self.h = h
+        self._bufs = []
+        self._keep = []
+
+    def _check(self, st):
+        if st != _lib.OK:
+            raise VtmHipError(st, self.L.vtmhip_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            for b in self._bufs:
+                b.free()
+            self.L.vtmhip_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream_ptr):
+        self._check(self.L.vtmhip_set_stream(self.h, stream_ptr))
+
+    def sync(self):
+        self._check(self.L.vtmhip_sync(self.h))
+        self._keep.clear()
+
+    def alloc(self, nbytes, dtype=np.uint8, shape=None):
+        return DevBuf(self, nbytes, dtype, shape)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DevBuf(self, max(arr.nbytes, 1), arr.dtype, arr.shape).upload(arr)
+
+    def timer_start(self):
+        self._check(self.L.vtmhip_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_float()
+        self._check(self.L.vtmhip_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    # ---- pointer-surface calls (host arrays) ------------------------------------------------------------------
+    def xGetSAD(self, org, org_stride, cur, cur_stride, w, h, sub_shift=0, org_off=0, cur_off=0):
+        d = C.c_uint64()
+        self._check(self.L.vtmhip_xGetSAD(self.h, org.ctypes.data + 2 * org_off, org_stride, cur.ctypes.data + 2 * cur_off,
+                                          cur_stride, w, h, sub_shift, C.byref(d)))
+        return d.value
+
+    def xGetHADs(self, org, org_stride, cur, cur_stride, w, h, org_off=0, cur_off=0):
+        d = C.c_uint64()
+        self._check(self.L.vtmhip_xGetHADs(self.h, org.ctypes.data + 2 * org_off, org_stride, cur.ctypes.data + 2 * cur_off,
+                                           cur_stride, w, h, C.byref(d)))
+        return d.value
+
+    def xGetSSE(self, org, org_stride, cur, cur_stride, w, h, org_off=0, cur_off=0):
+        d = C.c_uint64()
+        self._check(self.L.vtmhip_xGetSSE(self.h, org.ctypes.data + 2 * org_off, org_stride, cur.ctypes.data + 2 * cur_off,
+                                          cur_stride, w, h, C.byref(d)))
+        return d.value
+
+    # ---- batched device calls (device pointers: DevBuf.ptr or tensor.data_ptr()) ---------------------------------
+    def dist_batch(self, d_org, d_cur, d_jobs, n, d_out):
+        self._check(self.L.vtmhip_dist_batch_dev(self.h, d_org, d_cur, d_jobs, n, d_out))
+
+    def satd8_grid(self, d_org, org_stride, d_ref, ref_stride, w, h, r, d_out):
+        self._check(self.L.vtmhip_satd8_grid_dev(self.h, d_org, org_stride, d_ref, ref_stride, w, h, r, d_out))
+
+    def tz_search_batch(self, pic, d_org, d_ref, d_jobs, n, d_results):
+        self._check(self.L.vtmhip_tz_search_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, d_results))
+
+
+def struct_array_to_numpy(arr):
+    """ctypes array of Structures -> uint8 numpy view (for upload)."""
+    return np.frombuffer(arr, dtype=np.uint8)

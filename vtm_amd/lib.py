@@ -1,0 +1,102 @@
+"""ctypes binding of the C ABI in include/vtmhip.h (libvtmhip.so, built in-tree by vtm_amd.build).
+
+The library is the product: if it is missing this module raises -- there is no CPU fallback."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvtmhip.so")
+
+OK, E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+DIST_SAD, DIST_SATD, DIST_SSE = 0, 1, 2
+DCT2, DCT8, DST7 = 0, 1, 2
+
+
+class DistJob(C.Structure):
+    _fields_ = [("orgOff", C.c_int64), ("curOff", C.c_int64), ("orgStride", C.c_int32), ("curStride", C.c_int32),
+                ("width", C.c_int16), ("height", C.c_int16), ("subShift", C.c_int16), ("kind", C.c_int16)]
+
+
+class PicParams(C.Structure):
+    _fields_ = [("picW", C.c_int32), ("picH", C.c_int32), ("ctuSize", C.c_int32), ("bitDepth", C.c_int32)]
+
+
+class TzJob(C.Structure):
+    _fields_ = [("orgOff", C.c_int64), ("refOff", C.c_int64), ("orgStride", C.c_int32), ("refStride", C.c_int32),
+                ("puX", C.c_int16), ("puY", C.c_int16), ("width", C.c_int16), ("height", C.c_int16),
+                ("subShift", C.c_int16), ("imvShift", C.c_int16), ("predHor", C.c_int32), ("predVer", C.c_int32),
+                ("motionLambda", C.c_double), ("mvHor", C.c_int32), ("mvVer", C.c_int32), ("searchRange", C.c_int32),
+                ("extendedSettings", C.c_uint8), ("fastSettings", C.c_uint8), ("firstSearchStop", C.c_uint8),
+                ("hasIntMv2Nx2NPred", C.c_uint8), ("intMv2Nx2NPredHor", C.c_int32), ("intMv2Nx2NPredVer", C.c_int32),
+                ("numExtraStart", C.c_int32), ("extraStart", (C.c_int32 * 2) * 15)]
+
+
+class MeResult(C.Structure):
+    _fields_ = [("mvX", C.c_int32), ("mvY", C.c_int32), ("nEval", C.c_uint32), ("reserved", C.c_uint32),
+                ("cost", C.c_uint64), ("dist", C.c_uint64)]
+
+
+_STRUCTS = [DistJob, TzJob, MeResult, PicParams]   # order of vtmhip_struct_size(which)
+
+# every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
+_PROTOS = {
+    "vtmhip_abi_version": (C.c_int, []),
+    "vtmhip_struct_size": (C.c_int, [C.c_int]),
+    "vtmhip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "vtmhip_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "vtmhip_destroy": (C.c_int, [C.c_void_p]),
+    "vtmhip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vtmhip_sync": (C.c_int, [C.c_void_p]),
+    "vtmhip_last_error": (C.c_char_p, [C.c_void_p]),
+    "vtmhip_status_string": (C.c_char_p, [C.c_int]),
+    "vtmhip_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "vtmhip_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vtmhip_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "vtmhip_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "vtmhip_timer_start": (C.c_int, [C.c_void_p]),
+    "vtmhip_timer_stop_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "vtmhip_xGetSAD": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(C.c_uint64)]),
+    "vtmhip_xGetHADs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(C.c_uint64)]),
+    "vtmhip_xGetSSE": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(C.c_uint64)]),
+    "vtmhip_dist_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vtmhip_satd8_grid_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p]),
+    "vtmhip_tz_search_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+class VtmHipError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        super().__init__("libvtmhip status %d%s" % (status, (": " + detail) if detail else ""))
+
+
+def load():
+    """Loads libvtmhip.so, declares prototypes and checks the struct layouts against the library's sizeof()."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libvtmhip.so is missing (%s): build it with `python -m vtm_amd.build` -- the HIP "
+                          "extension is the product, there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    for i, s in enumerate(_STRUCTS):
+        if lib.vtmhip_struct_size(i) != C.sizeof(s):
+            raise ImportError("ABI mismatch: %s is %d bytes in Python, %d in libvtmhip.so"
+                              % (s.__name__, C.sizeof(s), lib.vtmhip_struct_size(i)))
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_PROTOS)
