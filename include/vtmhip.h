@@ -59,7 +59,8 @@ int         vtmhip_struct_size( int which );   /* sizeof() of the job/result str
 int         vtmhip_device_count( int *count );
 int         vtmhip_create( int device, vtmhip_ctx **ctx );              /* one context per encoder stack / per rank */
 int         vtmhip_destroy( vtmhip_ctx *ctx );
-int         vtmhip_set_stream( vtmhip_ctx *ctx, void *hipStream );     /* NULL = the context's own stream */
+int         vtmhip_set_stream( vtmhip_ctx *ctx, void *hipStream );     /* launch on the caller's hipStream_t; NULL = HIP's default stream (torch's default) */
+int         vtmhip_use_own_stream( vtmhip_ctx *ctx );                  /* back to the non-blocking stream the context created (the initial state) */
 int         vtmhip_sync( vtmhip_ctx *ctx );                            /* waits for the context's stream */
 const char *vtmhip_last_error( vtmhip_ctx *ctx );
 const char *vtmhip_status_string( int status );

@@ -80,7 +80,14 @@ int vtmhip_destroy( vtmhip_ctx *ctx )
 int vtmhip_set_stream( vtmhip_ctx *ctx, void *hipStream )
 {
   VTMHIP_CHECK_CTX( ctx );
-  ctx->stream = hipStream ? ( hipStream_t ) hipStream : ctx->ownStream;
+  ctx->stream = ( hipStream_t ) hipStream;   // NULL is HIP's default (null) stream, e.g. torch's default stream
+  return VTMHIP_OK;
+}
+
+int vtmhip_use_own_stream( vtmhip_ctx *ctx )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  ctx->stream = ctx->ownStream;
   return VTMHIP_OK;
 }
 

@@ -78,6 +78,9 @@ class Context:
     def set_stream(self, stream_ptr):
         self._check(self.L.vtmhip_set_stream(self.h, stream_ptr))
 
+    def use_own_stream(self):
+        self._check(self.L.vtmhip_use_own_stream(self.h))
+
     def sync(self):
         self._check(self.L.vtmhip_sync(self.h))
         self._keep.clear()

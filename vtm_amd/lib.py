@@ -46,6 +46,7 @@ _PROTOS = {
     "vtmhip_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "vtmhip_destroy": (C.c_int, [C.c_void_p]),
     "vtmhip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vtmhip_use_own_stream": (C.c_int, [C.c_void_p]),
     "vtmhip_sync": (C.c_int, [C.c_void_p]),
     "vtmhip_last_error": (C.c_char_p, [C.c_void_p]),
     "vtmhip_status_string": (C.c_char_p, [C.c_int]),
