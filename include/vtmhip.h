@@ -89,6 +89,18 @@ int vtmhip_xGetHADs( vtmhip_ctx *ctx, const int16_t *org, int orgStride, const i
 int vtmhip_xGetSSE( vtmhip_ctx *ctx, const int16_t *org, int orgStride, const int16_t *cur, int curStride, int width, int height,
                     uint64_t *dist );
 
+
+/* InterpolationFilter::m_filterHor / m_filterVer [tapIdx][isFirst][isLast] and m_filterCopy[isFirst][isLast]
+ * (InterpolationFilter.h:93-95; filter<> InterpolationFilter.cpp:548-651, filterCopy<> :398-525).  `src` points at the
+ * OUTPUT-aligned sample, as in the reference: the callee reads (taps/2 - 1) samples before it along the filter direction.
+ * taps: 8, 4 or 2; coeff: `taps` filter taps; clipMin/clipMax/bitDepth: ClpRng::min/max/bd. */
+int vtmhip_filterHor( vtmhip_ctx *ctx, int taps, int isFirst, int isLast, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int width,
+                      int height, const int16_t *coeff, int bitDepth, int clipMin, int clipMax, int biMCForDMVR );
+int vtmhip_filterVer( vtmhip_ctx *ctx, int taps, int isFirst, int isLast, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int width,
+                      int height, const int16_t *coeff, int bitDepth, int clipMin, int clipMax, int biMCForDMVR );
+int vtmhip_filterCopy( vtmhip_ctx *ctx, int isFirst, int isLast, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int width, int height,
+                       int bitDepth, int clipMin, int clipMax, int biMCForDMVR );
+
 /* ================================================================================================================
  * (2) BATCHED DEVICE CALLS -- device pointers, asynchronous on the context's stream
  * ============================================================================================================== */
@@ -155,6 +167,49 @@ typedef struct
 
 int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
                                 const vtmhip_tz_job *d_jobs, int n, vtmhip_me_result *d_results );
+
+
+/* ---- interpolation ----------------------------------------------------------------------------------------------- */
+typedef struct
+{
+  int64_t srcOff, dstOff;   /* samples; srcOff addresses the output-aligned sample */
+  int32_t srcStride, dstStride;
+  int16_t width, height;
+  uint8_t vertical, taps /* 8, 4, 2; 0 = filterCopy */, isFirst, isLast;
+  int16_t coeff[8];
+  int16_t clipMin, clipMax;
+  uint8_t bitDepth, biMCForDMVR, pad0, pad1;
+} vtmhip_if_job;
+
+/* n filter / copy passes, one workgroup each (hook B6 plane generation, motion compensation) */
+int vtmhip_if_batch_dev( vtmhip_ctx *ctx, const int16_t *d_srcBase, int16_t *d_dstBase, const vtmhip_if_job *d_jobs, int n );
+
+/* ---- fractional motion search: one InterSearch::xPatternSearchFracDIF per job (hook B6) ------------------------------ */
+typedef struct
+{
+  int64_t orgOff, refOff;   /* as vtmhip_tz_job: PU top-left in the original plane / same position (MV 0,0) in the reference plane */
+  int32_t orgStride, refStride;
+  int16_t width, height;    /* not 4x4 (no 4x4 inter PU exists; the reference switches tap tables there, InterpolationFilter.cpp:786-789) */
+  int16_t intX, intY;       /* rcMvInt: result of the integer search */
+  int32_t predHor, predVer; /* RdCost::setPredictor, quarter-sample units */
+  double  motionLambda;
+  uint8_t useHad;           /* HadamardME && !DisableSATDForRD: SATD, else SAD */
+  uint8_t useAltHpelIf;     /* cu.imv == IMV_HPEL */
+  uint8_t imvShift;         /* 0: half + quarter refinement; 1 (IMV_HPEL): half only */
+  uint8_t bitDepth;
+  int32_t pad;
+} vtmhip_frac_job;
+
+typedef struct
+{
+  int16_t  halfX, halfY;   /* rcMvHalf in {-1,0,1}^2 */
+  int16_t  qterX, qterY;   /* rcMvQter in {-1,0,1}^2; final MV (quarter units) = (int << 2) + (half << 1) + qter */
+  uint64_t cost;           /* ruiCost */
+} vtmhip_frac_result;
+
+/* maxWidth/maxHeight: upper bounds of the job sizes in this batch (they size the per-workgroup LDS window) */
+int vtmhip_frac_search_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_frac_job *d_jobs, int n,
+                                  int maxWidth, int maxHeight, vtmhip_frac_result *d_results );
 
 #ifdef __cplusplus
 }

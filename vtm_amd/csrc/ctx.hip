@@ -14,6 +14,9 @@ int vtmhip_struct_size( int which )
   case 1: return ( int ) sizeof( vtmhip_tz_job );
   case 2: return ( int ) sizeof( vtmhip_me_result );
   case 3: return ( int ) sizeof( vtmhip_pic_params );
+  case 4: return ( int ) sizeof( vtmhip_if_job );
+  case 5: return ( int ) sizeof( vtmhip_frac_job );
+  case 6: return ( int ) sizeof( vtmhip_frac_result );
   default: return -1;
   }
 }

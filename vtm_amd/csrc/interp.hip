@@ -1,0 +1,419 @@
+// interp.hip -- sub-sample interpolation (8-tap luma / 4-tap chroma / 2-tap bilinear / copy) and the fused
+// fractional motion search (interpolate -> SATD -> first-strict-minimum) of one PU.
+//
+// Reference: CommonLib/InterpolationFilter.cpp filter<> :548-651, filterCopy<> :398-525, tap tables :57-330;
+// EncoderLib/InterSearch.cpp xPatternSearchFracDIF :4284-4339, xExtDIFUpSamplingH/Q :5840-6051,
+// xPatternRefinement :707-761 (s_acMvRefineH/Q :60-85).
+//
+// Arithmetic (bit-exact): val = (int16)((sum_k src[.]*c[k] + offset) >> shift), clip only when isLast
+// (the int16 truncation precedes the clip, InterpolationFilter.cpp:645-650).
+//
+// Fractional search: the reference builds 4 + 10 shifted planes (m_filteredBlock[v][h]) and indexes them with pointer
+// nudges; every candidate block is nothing but the separable interpolation of the reference picture at
+// (intMv*4 + q) quarter samples: H pass (first, !last) on rows -3..H+3, V pass (!first, last).  Integer phases go
+// through the same FIR with taps {0,0,0,64,0,0,0,0}, which is arithmetically identical to filterCopy.
+// One wave per PU: window -> LDS once, 3 H passes per round (one per horizontal phase), 9 V passes + SATDs.
+#include "ctx.hpp"
+
+namespace
+{
+
+__constant__ int16_t c_lumaFilter[16][8] = {
+  { 0, 0, 0, 64, 0, 0, 0, 0 },       { 0, 1, -3, 63, 4, -2, 1, 0 },     { -1, 2, -5, 62, 8, -3, 1, 0 },    { -1, 3, -8, 60, 13, -4, 1, 0 },
+  { -1, 4, -10, 58, 17, -5, 1, 0 },  { -1, 4, -11, 52, 26, -8, 3, -1 }, { -1, 3, -9, 47, 31, -10, 4, -1 }, { -1, 4, -11, 45, 34, -10, 4, -1 },
+  { -1, 4, -11, 40, 40, -11, 4, -1 },{ -1, 4, -10, 34, 45, -11, 4, -1 },{ -1, 4, -10, 31, 47, -9, 3, -1 }, { -1, 3, -8, 26, 52, -11, 4, -1 },
+  { 0, 1, -5, 17, 58, -10, 4, -1 },  { 0, 1, -4, 13, 60, -8, 3, -1 },   { 0, 1, -3, 8, 62, -5, 2, -1 },    { 0, 1, -2, 4, 63, -3, 1, 0 } };
+__constant__ int16_t c_lumaAltHpel[8] = { 0, 3, 9, 20, 20, 9, 3, 0 };
+
+struct IfParams { int shift, offset, clip, cmin, cmax; };
+
+// shift / offset rules of InterpolationFilter::filter (:577-614)
+__device__ __forceinline__ IfParams if_params( int isFirst, int isLast, int bitDepth, int clipMin, int clipMax, int biMC )
+{
+  IfParams  p;
+  const int headRoom = max( 2, 14 - bitDepth );
+  int       shift    = 6, offset;
+  if( isLast )
+  {
+    shift += isFirst ? 0 : headRoom;
+    offset = 1 << ( shift - 1 );
+    offset += isFirst ? 0 : ( 8192 << 6 );
+  }
+  else
+  {
+    shift -= isFirst ? headRoom : 0;
+    offset = isFirst ? -( 8192 << shift ) : 0;
+  }
+  if( biMC )
+  {
+    shift  = isFirst ? 4 - ( 10 - bitDepth ) : 4;
+    offset = 1 << ( shift - 1 );
+  }
+  p.shift = shift; p.offset = offset; p.clip = isLast; p.cmin = clipMin; p.cmax = clipMax;
+  return p;
+}
+
+__device__ __forceinline__ int16_t if_finish( int sum, const IfParams &p )
+{
+  int16_t v = ( int16_t ) ( ( sum + p.offset ) >> p.shift );
+  if( p.clip ) v = ( int16_t ) min( p.cmax, max( p.cmin, ( int ) v ) );
+  return v;
+}
+
+// ---- generic batched filter: one workgroup per job, one thread per output sample -------------------------------------
+__global__ __launch_bounds__( 256 ) void if_batch_kernel( const int16_t *__restrict__ srcBase, int16_t *__restrict__ dstBase,
+                                                         const vtmhip_if_job *__restrict__ jobs )
+{
+  const vtmhip_if_job j   = jobs[blockIdx.x];
+  const int16_t      *src = srcBase + j.srcOff;
+  int16_t            *dst = dstBase + j.dstOff;
+  const int           w = j.width, h = j.height, taps = j.taps;
+  if( taps == 0 )   // filterCopy<isFirst,isLast> (:398-525)
+  {
+    const int headRoom = max( 2, 14 - ( int ) j.bitDepth );
+    for( int i = threadIdx.x; i < w * h; i += blockDim.x )
+    {
+      const int y = i / w, x = i - y * w;
+      const int s = src[( long ) y * j.srcStride + x];
+      int16_t   v;
+      if( j.isFirst == j.isLast ) v = ( int16_t ) s;
+      else if( j.biMCForDMVR )
+      {
+        if( j.bitDepth > 10 ) { const int sh = j.bitDepth - 10; v = ( int16_t ) ( ( s + ( 1 << ( sh - 1 ) ) ) >> sh ); }
+        else v = ( int16_t ) ( s << ( 10 - j.bitDepth ) );
+      }
+      else if( j.isFirst ) v = ( int16_t ) ( ( int16_t ) ( s << headRoom ) - ( int16_t ) 8192 );
+      else
+      {
+        const int16_t t = ( int16_t ) ( ( s + 8192 + ( 1 << ( headRoom - 1 ) ) ) >> headRoom );
+        v               = ( int16_t ) min( ( int ) j.clipMax, max( ( int ) j.clipMin, ( int ) t ) );
+      }
+      dst[( long ) y * j.dstStride + x] = v;
+    }
+    return;
+  }
+  const IfParams p       = if_params( j.isFirst, j.isLast, j.bitDepth, j.clipMin, j.clipMax, j.biMCForDMVR );
+  const long     cStride = j.vertical ? j.srcStride : 1;
+  src -= ( taps / 2 - 1 ) * cStride;
+  for( int i = threadIdx.x; i < w * h; i += blockDim.x )
+  {
+    const int      y = i / w, x = i - y * w;
+    const int16_t *s = src + ( long ) y * j.srcStride + x;
+    int            sum = 0;
+    for( int k = 0; k < taps; k++ ) sum += ( int ) s[k * cStride] * ( int ) j.coeff[k];
+    dst[( long ) y * j.dstStride + x] = if_finish( sum, p );
+  }
+}
+
+// ---- Hadamard tiles on LDS / global operands (same arithmetic as dist.hip) ---------------------------------------------
+template<int N, int STRIDE>
+__device__ __forceinline__ void wht1d( int *m )
+{
+#pragma unroll
+  for( int len = 1; len < N; len <<= 1 )
+  {
+#pragma unroll
+    for( int i = 0; i < N; i += len << 1 )
+    {
+#pragma unroll
+      for( int j = i; j < i + len; j++ )
+      {
+        const int a = m[j * STRIDE], b = m[( j + len ) * STRIDE];
+        m[j * STRIDE]           = a + b;
+        m[( j + len ) * STRIDE] = a - b;
+      }
+    }
+  }
+}
+
+template<int TW, int TH>
+__device__ __forceinline__ unsigned had_tile( const int16_t *o, int os, const int16_t *c, int cs )
+{
+  int m[TW * TH];
+#pragma unroll
+  for( int y = 0; y < TH; y++ )
+  {
+#pragma unroll
+    for( int x = 0; x < TW; x++ ) m[y * TW + x] = ( int ) o[y * os + x] - ( int ) c[y * cs + x];
+  }
+#pragma unroll
+  for( int y = 0; y < TH; y++ ) wht1d<TW, 1>( m + y * TW );
+#pragma unroll
+  for( int x = 0; x < TW; x++ ) wht1d<TH, TW>( m + x );
+  int t = 0;
+#pragma unroll
+  for( int i = 0; i < TW * TH; i++ ) t += abs( m[i] );
+  const int dc = abs( m[0] );
+  t            = t - dc + ( dc >> 2 );
+  if( TW == 2 && TH == 2 ) return ( unsigned ) t;
+  if( TW == 4 && TH == 4 ) return ( unsigned ) ( ( t + 1 ) >> 1 );
+  if( TW == 8 && TH == 8 ) return ( unsigned ) ( ( t + 2 ) >> 2 );
+  if( TW * TH == 128 ) return ( unsigned ) ( int ) ( ( double ) t / 11.313708498984761 * 2.0 );
+  return ( unsigned ) ( int ) ( ( double ) t / 5.656854249492381 * 2.0 );
+}
+
+// distortion of the W x H block: org from global memory, candidate block in LDS (stride W); whole wave, result uniform
+__device__ __forceinline__ unsigned long long block_dist( const int16_t *org, int os, const int16_t *pred, int w, int h, bool useHad, int lane )
+{
+  unsigned long long acc = 0;
+  if( !useHad )
+  {
+    unsigned s = 0;
+    for( int i = lane; i < w * h; i += 64 )
+    {
+      const int y = i / w, x = i - y * w;
+      s += ( unsigned ) abs( ( int ) org[( long ) y * os + x] - ( int ) pred[y * w + x] );
+    }
+    acc = s;
+  }
+  else
+  {
+    int tw, th;   // xGetHADs tile rules (RdCost.cpp:2837-2931)
+    if( w > h && ( h & 7 ) == 0 && ( w & 15 ) == 0 ) { tw = 16; th = 8; }
+    else if( w < h && ( w & 7 ) == 0 && ( h & 15 ) == 0 ) { tw = 8; th = 16; }
+    else if( w > h && ( h & 3 ) == 0 && ( w & 7 ) == 0 ) { tw = 8; th = 4; }
+    else if( w < h && ( w & 3 ) == 0 && ( h & 7 ) == 0 ) { tw = 4; th = 8; }
+    else if( ( h & 7 ) == 0 && ( w & 7 ) == 0 ) { tw = 8; th = 8; }
+    else if( ( h & 3 ) == 0 && ( w & 3 ) == 0 ) { tw = 4; th = 4; }
+    else { tw = 2; th = 2; }
+    const int tx = w / tw, ty = h / th;
+    for( int it = lane; it < tx * ty; it += 64 )
+    {
+      const int      y = ( it / tx ) * th, x = ( it % tx ) * tw;
+      const int16_t *o = org + ( long ) y * os + x;
+      const int16_t *c = pred + y * w + x;
+      unsigned       v;
+      if( tw == 16 ) v = had_tile<16, 8>( o, os, c, w );
+      else if( th == 16 ) v = had_tile<8, 16>( o, os, c, w );
+      else if( tw == 8 && th == 4 ) v = had_tile<8, 4>( o, os, c, w );
+      else if( tw == 4 && th == 8 ) v = had_tile<4, 8>( o, os, c, w );
+      else if( tw == 8 ) v = had_tile<8, 8>( o, os, c, w );
+      else if( tw == 4 ) v = had_tile<4, 4>( o, os, c, w );
+      else v = had_tile<2, 2>( o, os, c, w );
+      acc += v;
+    }
+  }
+  return wave_reduce_add_u64( acc );
+}
+
+__device__ __forceinline__ int floor_log2_u( unsigned v ) { return 31 - __clz( ( int ) v ); }
+__device__ __forceinline__ unsigned eg_bits( int v )
+{
+  unsigned len = 1;
+  unsigned t   = ( v <= 0 ) ? ( ( unsigned ) ( -v ) << 1 ) + 1 : ( unsigned ) ( v << 1 );
+  while( t > 128 ) { len += 14; t >>= 7; }
+  return len + ( ( unsigned ) floor_log2_u( t ) << 1 );
+}
+// getCostOfVectorWithPredictor( x, y, 0 ) with m_iCostScale = costScale (RdCost.h:314-315)
+__device__ __forceinline__ unsigned long long mv_cost( double lambda, int predHor, int predVer, int costScale, int x, int y )
+{
+  const unsigned bits = eg_bits( ( x << costScale ) - predHor ) + eg_bits( ( y << costScale ) - predVer );
+  return ( unsigned long long ) ( lambda * ( double ) bits );
+}
+
+__constant__ int8_t c_refineH[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { 1, -1 }, { -1, 1 }, { 1, 1 } };
+__constant__ int8_t c_refineQ[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { 1, 1 } };
+
+// One refinement round (xPatternRefinement :707-761).  (cx, cy): round centre in quarter samples relative to the
+// integer vector; step: 2 (half) or 1 (quarter).  Returns the best table index; cost[] gets the 9 costs.
+__device__ int refine_round( const vtmhip_frac_job &j, const int16_t *org, const int16_t *win, int winLd, int16_t *tmp, int16_t *pred, int cx,
+                             int cy, int step, int costScale, int mvBaseX, int mvBaseY, bool altHpel, unsigned long long *bestCost, int lane )
+{
+  const int w = j.width, h = j.height;
+  const int8_t( *tab )[2] = step == 2 ? c_refineH : c_refineQ;
+  const IfParams pH = if_params( 1, 0, j.bitDepth, 0, ( 1 << j.bitDepth ) - 1, 0 );
+  const IfParams pV = if_params( 0, 1, j.bitDepth, 0, ( 1 << j.bitDepth ) - 1, 0 );
+  unsigned long long cost[9];
+#pragma unroll
+  for( int i = 0; i < 9; i++ ) cost[i] = ~0ull;
+
+  for( int dx = -1; dx <= 1; dx++ )
+  {
+    const int      qx = cx + dx * step, ix = qx >> 2, fx = qx & 3;
+    const int16_t *cH = ( altHpel && fx == 2 ) ? c_lumaAltHpel : c_lumaFilter[fx << 2];
+    int            ch[8];
+#pragma unroll
+    for( int k = 0; k < 8; k++ ) ch[k] = cH[k];
+    // H pass (first, !last): tmp[r][x], r = 0..h+7 <-> picture rows -4..h+3 (window rows r), columns x + ix (+4 in the window)
+    for( int i = lane; i < ( h + 8 ) * w; i += 64 )
+    {
+      const int      r = i / w, x = i - r * w;
+      const int16_t *s = win + r * winLd + ( x + ix + 4 - 3 );
+      int            sum = 0;
+#pragma unroll
+      for( int k = 0; k < 8; k++ ) sum += ( int ) s[k] * ch[k];
+      tmp[i] = if_finish( sum, pH );
+    }
+    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+    __builtin_amdgcn_wave_barrier();
+    for( int dy = -1; dy <= 1; dy++ )
+    {
+      const int      qy = cy + dy * step, iy = qy >> 2, fy = qy & 3;
+      const int16_t *cV = ( altHpel && fy == 2 ) ? c_lumaAltHpel : c_lumaFilter[fy << 2];
+      int            cv[8];
+#pragma unroll
+      for( int k = 0; k < 8; k++ ) cv[k] = cV[k];
+      // V pass (!first, last): output row y uses tmp rows (y + iy + 4 - 3) .. +7
+      for( int i = lane; i < h * w; i += 64 )
+      {
+        const int      y = i / w, x = i - y * w;
+        const int16_t *s = tmp + ( y + iy + 1 ) * w + x;
+        int            sum = 0;
+#pragma unroll
+        for( int k = 0; k < 8; k++ ) sum += ( int ) s[k * w] * cv[k];
+        pred[i] = if_finish( sum, pV );
+      }
+      __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+      __builtin_amdgcn_wave_barrier();
+      unsigned long long d = block_dist( org, j.orgStride, pred, w, h, j.useHad != 0, lane );
+      d += mv_cost( j.motionLambda, j.predHor, j.predVer, costScale, mvBaseX + dx, mvBaseY + dy );
+#pragma unroll
+      for( int i = 0; i < 9; i++ )
+        if( tab[i][0] == dx && tab[i][1] == dy ) cost[i] = d;
+      __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  unsigned long long best = ~0ull;
+  int                bi   = 0;
+#pragma unroll
+  for( int i = 0; i < 9; i++ )
+    if( cost[i] < best ) { best = cost[i]; bi = i; }   // first strict minimum in table order
+  *bestCost = best;
+  return bi;
+}
+
+__global__ __launch_bounds__( 64 ) void frac_search_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+                                                           const vtmhip_frac_job *__restrict__ jobs, vtmhip_frac_result *__restrict__ results,
+                                                           int maxW, int maxH )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];
+  const int             lane = threadIdx.x;
+  const vtmhip_frac_job j    = jobs[blockIdx.x];
+  const int             w = j.width, h = j.height;
+  const int             winLd = w + 8;
+  int16_t              *win  = lds;                                   // [(h+8)][w+8]: picture rows/cols -4 .. +3 around the block
+  int16_t              *tmp  = win + ( maxH + 8 ) * ( maxW + 8 );     // [(h+8)][w]
+  int16_t              *pred = tmp + ( maxH + 8 ) * maxW;             // [h][w]
+  const int16_t        *org  = orgBase + j.orgOff;
+  const int16_t        *ref  = refBase + j.refOff + ( long ) j.intY * j.refStride + j.intX;   // cPatternRoi (:4298-4299)
+
+  for( int i = lane; i < ( h + 8 ) * winLd; i += 64 )
+  {
+    const int r = i / winLd, c = i - r * winLd;
+    win[i]      = ref[( long ) ( r - 4 ) * j.refStride + ( c - 4 )];
+  }
+  __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+  __builtin_amdgcn_wave_barrier();
+
+  vtmhip_frac_result res;
+  res.halfX = res.halfY = res.qterX = res.qterY = 0;
+  unsigned long long cost = 0;
+  const bool         altHpel = j.useAltHpelIf != 0;
+
+  // half-sample refinement: setCostScale(1), rcMvHalf = rcMvInt << 1 (:4320-4325)
+  int bi    = refine_round( j, org, win, winLd, tmp, pred, 0, 0, 2, 1, j.intX << 1, j.intY << 1, altHpel, &cost, lane );
+  res.halfX = c_refineH[bi][0];
+  res.halfY = c_refineH[bi][1];
+  if( j.imvShift == 0 )
+  {
+    // quarter-sample refinement: setCostScale(0), rcMvQter = ((rcMvInt << 1) + rcMvHalf) << 1 (:4328-4337)
+    const int bx = ( ( j.intX << 1 ) + res.halfX ) << 1, by = ( ( j.intY << 1 ) + res.halfY ) << 1;
+    bi        = refine_round( j, org, win, winLd, tmp, pred, res.halfX * 2, res.halfY * 2, 1, 0, bx, by, false, &cost, lane );
+    res.qterX = c_refineQ[bi][0];
+    res.qterY = c_refineQ[bi][1];
+  }
+  res.cost = cost;
+  if( lane == 0 ) results[blockIdx.x] = res;
+}
+
+size_t frac_lds_bytes( int maxW, int maxH ) { return ( size_t ) ( ( maxH + 8 ) * ( maxW + 8 ) + ( maxH + 8 ) * maxW + maxH * maxW ) * sizeof( int16_t ); }
+
+int if_single( vtmhip_ctx *ctx, int vertical, int taps, int isFirst, int isLast, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int w,
+               int h, const int16_t *coeff, int bitDepth, int clipMin, int clipMax, int biMC )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, src && dst && ( taps == 0 || coeff ), "null pointer" );
+  VTMHIP_REQUIRE( ctx, w >= 1 && h >= 1 && w <= 256 && h <= 256, "block size" );
+  VTMHIP_REQUIRE( ctx, taps == 0 || taps == 2 || taps == 4 || taps == 8, "taps must be 8, 4, 2 or 0 (copy)" );
+  VTMHIP_REQUIRE( ctx, bitDepth >= 8 && bitDepth <= 14, "bitDepth" );
+  // stage the source region the filter touches: (taps/2 - 1) samples before, taps/2 after, along the filter direction
+  const int before = taps ? taps / 2 - 1 : 0, after = taps ? taps / 2 : 0;
+  const int sw = w + ( vertical ? 0 : before + after ), sh = h + ( vertical ? before + after : 0 );
+  const size_t srcBytes = ( size_t ) sw * sh * 2, dstBytes = ( size_t ) w * h * 2;
+  const size_t dstOffB = ( srcBytes + 63 ) & ~( size_t ) 63, jobOffB = ( dstOffB + dstBytes + 63 ) & ~( size_t ) 63;
+  int st = vtmhip_internal_scratch( ctx, jobOffB + sizeof( vtmhip_if_job ) );
+  if( st ) return st;
+  char          *hp = ( char * ) ctx->pinned, *dp = ( char * ) ctx->scratch;
+  const int16_t *s0 = src - ( vertical ? ( ptrdiff_t ) before * srcStride : before );
+  for( int y = 0; y < sh; y++ ) memcpy( hp + ( size_t ) y * sw * 2, s0 + ( ptrdiff_t ) y * srcStride, ( size_t ) sw * 2 );
+  vtmhip_if_job j;
+  memset( &j, 0, sizeof( j ) );
+  j.srcOff = vertical ? ( int64_t ) before * sw : before;
+  j.dstOff = 0; j.srcStride = sw; j.dstStride = w; j.width = ( int16_t ) w; j.height = ( int16_t ) h;
+  j.vertical = ( uint8_t ) vertical; j.taps = ( uint8_t ) taps; j.isFirst = ( uint8_t ) isFirst; j.isLast = ( uint8_t ) isLast;
+  for( int k = 0; k < taps; k++ ) j.coeff[k] = coeff[k];
+  j.clipMin = ( int16_t ) clipMin; j.clipMax = ( int16_t ) clipMax; j.bitDepth = ( uint8_t ) bitDepth; j.biMCForDMVR = ( uint8_t ) biMC;
+  memcpy( hp + jobOffB, &j, sizeof( j ) );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( dp, hp, srcBytes, hipMemcpyHostToDevice, ctx->stream ) );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( dp + jobOffB, hp + jobOffB, sizeof( j ), hipMemcpyHostToDevice, ctx->stream ) );
+  hipLaunchKernelGGL( if_batch_kernel, dim3( 1 ), dim3( 256 ), 0, ctx->stream, ( const int16_t * ) dp, ( int16_t * ) ( dp + dstOffB ),
+                      ( const vtmhip_if_job * ) ( dp + jobOffB ) );
+  VTMHIP_LAUNCHED( ctx );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( hp + dstOffB, dp + dstOffB, dstBytes, hipMemcpyDeviceToHost, ctx->stream ) );
+  VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  for( int y = 0; y < h; y++ ) memcpy( dst + ( ptrdiff_t ) y * dstStride, hp + dstOffB + ( size_t ) y * w * 2, ( size_t ) w * 2 );
+  return VTMHIP_OK;
+}
+
+}   // namespace
+
+extern "C"
+{
+
+int vtmhip_filterHor( vtmhip_ctx *ctx, int taps, int isFirst, int isLast, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int width,
+                      int height, const int16_t *coeff, int bitDepth, int clipMin, int clipMax, int biMCForDMVR )
+{
+  return if_single( ctx, 0, taps, isFirst, isLast, src, srcStride, dst, dstStride, width, height, coeff, bitDepth, clipMin, clipMax, biMCForDMVR );
+}
+
+int vtmhip_filterVer( vtmhip_ctx *ctx, int taps, int isFirst, int isLast, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int width,
+                      int height, const int16_t *coeff, int bitDepth, int clipMin, int clipMax, int biMCForDMVR )
+{
+  return if_single( ctx, 1, taps, isFirst, isLast, src, srcStride, dst, dstStride, width, height, coeff, bitDepth, clipMin, clipMax, biMCForDMVR );
+}
+
+int vtmhip_filterCopy( vtmhip_ctx *ctx, int isFirst, int isLast, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int width, int height,
+                       int bitDepth, int clipMin, int clipMax, int biMCForDMVR )
+{
+  return if_single( ctx, 0, 0, isFirst, isLast, src, srcStride, dst, dstStride, width, height, nullptr, bitDepth, clipMin, clipMax, biMCForDMVR );
+}
+
+int vtmhip_if_batch_dev( vtmhip_ctx *ctx, const int16_t *d_srcBase, int16_t *d_dstBase, const vtmhip_if_job *d_jobs, int n )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_srcBase && d_dstBase && d_jobs, "null pointer" );
+  hipLaunchKernelGGL( if_batch_kernel, dim3( n ), dim3( 256 ), 0, ctx->stream, d_srcBase, d_dstBase, d_jobs );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_frac_search_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_frac_job *d_jobs, int n,
+                                  int maxWidth, int maxHeight, vtmhip_frac_result *d_results )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_orgBase && d_refBase && d_jobs && d_results, "null pointer" );
+  VTMHIP_REQUIRE( ctx, maxWidth >= 4 && maxWidth <= 128 && maxHeight >= 4 && maxHeight <= 128, "maxWidth / maxHeight" );
+  const size_t lds = frac_lds_bytes( maxWidth, maxHeight );
+  if( lds > 64 * 1024 )
+    VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( frac_search_kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
+  hipLaunchKernelGGL( frac_search_kernel, dim3( n ), dim3( 64 ), lds, ctx->stream, d_orgBase, d_refBase, d_jobs, d_results, maxWidth, maxHeight );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+}   // extern "C"

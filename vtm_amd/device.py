@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _lib
-from .lib import DistJob, MeResult, PicParams, TzJob, VtmHipError   # noqa: F401  (re-exported)
+from .lib import DistJob, FracJob, FracResult, IfJob, MeResult, PicParams, TzJob, VtmHipError   # noqa: F401  (re-exported)
 
 
 class DevBuf:
@@ -119,12 +119,35 @@ class Context:
                                           cur_stride, w, h, C.byref(d)))
         return d.value
 
+    def filter(self, vertical, taps, is_first, is_last, src, src_off, src_stride, w, h, coeff, bit_depth=10, clip=None, bimc=0):
+        """m_filterHor/m_filterVer[taps][isFirst][isLast] on a host array; returns the h x w int16 block."""
+        clip = clip or (0, (1 << bit_depth) - 1)
+        dst = np.zeros((h, w), np.int16)
+        co = np.ascontiguousarray(coeff, dtype=np.int16)
+        fn = self.L.vtmhip_filterVer if vertical else self.L.vtmhip_filterHor
+        self._check(fn(self.h, taps, is_first, is_last, src.ctypes.data + 2 * src_off, src_stride, dst.ctypes.data, w, w, h,
+                       co.ctypes.data, bit_depth, clip[0], clip[1], bimc))
+        return dst
+
+    def filter_copy(self, is_first, is_last, src, src_off, src_stride, w, h, bit_depth=10, clip=None, bimc=0):
+        clip = clip or (0, (1 << bit_depth) - 1)
+        dst = np.zeros((h, w), np.int16)
+        self._check(self.L.vtmhip_filterCopy(self.h, is_first, is_last, src.ctypes.data + 2 * src_off, src_stride, dst.ctypes.data,
+                                             w, w, h, bit_depth, clip[0], clip[1], bimc))
+        return dst
+
     # ---- batched device calls (device pointers: DevBuf.ptr or tensor.data_ptr()) ---------------------------------
     def dist_batch(self, d_org, d_cur, d_jobs, n, d_out):
         self._check(self.L.vtmhip_dist_batch_dev(self.h, d_org, d_cur, d_jobs, n, d_out))
 
     def satd8_grid(self, d_org, org_stride, d_ref, ref_stride, w, h, r, d_out):
         self._check(self.L.vtmhip_satd8_grid_dev(self.h, d_org, org_stride, d_ref, ref_stride, w, h, r, d_out))
+
+    def if_batch(self, d_src, d_dst, d_jobs, n):
+        self._check(self.L.vtmhip_if_batch_dev(self.h, d_src, d_dst, d_jobs, n))
+
+    def frac_search_batch(self, d_org, d_ref, d_jobs, n, max_w, max_h, d_results):
+        self._check(self.L.vtmhip_frac_search_batch_dev(self.h, d_org, d_ref, d_jobs, n, max_w, max_h, d_results))
 
     def tz_search_batch(self, pic, d_org, d_ref, d_jobs, n, d_results):
         self._check(self.L.vtmhip_tz_search_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, d_results))

@@ -36,7 +36,27 @@ class MeResult(C.Structure):
                 ("cost", C.c_uint64), ("dist", C.c_uint64)]
 
 
-_STRUCTS = [DistJob, TzJob, MeResult, PicParams]   # order of vtmhip_struct_size(which)
+class IfJob(C.Structure):
+    _fields_ = [("srcOff", C.c_int64), ("dstOff", C.c_int64), ("srcStride", C.c_int32), ("dstStride", C.c_int32),
+                ("width", C.c_int16), ("height", C.c_int16), ("vertical", C.c_uint8), ("taps", C.c_uint8),
+                ("isFirst", C.c_uint8), ("isLast", C.c_uint8), ("coeff", C.c_int16 * 8), ("clipMin", C.c_int16),
+                ("clipMax", C.c_int16), ("bitDepth", C.c_uint8), ("biMCForDMVR", C.c_uint8), ("pad0", C.c_uint8),
+                ("pad1", C.c_uint8)]
+
+
+class FracJob(C.Structure):
+    _fields_ = [("orgOff", C.c_int64), ("refOff", C.c_int64), ("orgStride", C.c_int32), ("refStride", C.c_int32),
+                ("width", C.c_int16), ("height", C.c_int16), ("intX", C.c_int16), ("intY", C.c_int16),
+                ("predHor", C.c_int32), ("predVer", C.c_int32), ("motionLambda", C.c_double), ("useHad", C.c_uint8),
+                ("useAltHpelIf", C.c_uint8), ("imvShift", C.c_uint8), ("bitDepth", C.c_uint8), ("pad", C.c_int32)]
+
+
+class FracResult(C.Structure):
+    _fields_ = [("halfX", C.c_int16), ("halfY", C.c_int16), ("qterX", C.c_int16), ("qterY", C.c_int16),
+                ("cost", C.c_uint64)]
+
+
+_STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
 _PROTOS = {
@@ -62,6 +82,15 @@ _PROTOS = {
                                   C.POINTER(C.c_uint64)]),
     "vtmhip_xGetSSE": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_uint64)]),
+    "vtmhip_filterHor": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vtmhip_filterVer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vtmhip_filterCopy": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vtmhip_if_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "vtmhip_frac_search_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                               C.c_void_p]),
     "vtmhip_dist_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vtmhip_satd8_grid_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),
