@@ -101,6 +101,17 @@ int vtmhip_filterVer( vtmhip_ctx *ctx, int taps, int isFirst, int isLast, const 
 int vtmhip_filterCopy( vtmhip_ctx *ctx, int isFirst, int isLast, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int width, int height,
                        int bitDepth, int clipMin, int clipMax, int biMCForDMVR );
 
+/* fastFwdTrans[type][log2(n)-1] / fastInvTrans[type][log2(n)-1] (TrQuant.cpp:69-81; typedefs TrQuant.h:53-54): 1-D transform of `line`
+ * rows, TRANSPOSED output dst[k*line + j] (forward) / dst[i*n + j] (inverse), zero-out through skipLine / skipLine2.
+ * (type, n) pairs whose table slot is nullptr in the reference return VTMHIP_E_INVALID. */
+int vtmhip_fastFwdTrans( vtmhip_ctx *ctx, int type, int n, const int32_t *src, int32_t *dst, int shift, int line, int skipLine, int skipLine2 );
+int vtmhip_fastInvTrans( vtmhip_ctx *ctx, int type, int n, const int32_t *src, int32_t *dst, int shift, int line, int skipLine, int skipLine2,
+                         int32_t outputMinimum, int32_t outputMaximum );
+/* n x n forward core matrix g_trCore<type>P<n>[TRANSFORM_FORWARD] (Rom.h:115-130), row-major int16; host-only helper */
+int vtmhip_tr_matrix_host( int type, int n, int16_t *out );
+/* MTS candidate pre-selection thresholds of TrQuant::transformNxN( tu, compID, cQP, &trModes, maxCand ) (TrQuant.cpp:950-1019); host-only */
+int vtmhip_mts_select( const int32_t *sumAbs, int numCand, int width, int height, int maxCand, uint8_t *test );
+
 /* ================================================================================================================
  * (2) BATCHED DEVICE CALLS -- device pointers, asynchronous on the context's stream
  * ============================================================================================================== */
@@ -210,6 +221,39 @@ typedef struct
 /* maxWidth/maxHeight: upper bounds of the job sizes in this batch (they size the per-workgroup LDS window) */
 int vtmhip_frac_search_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_frac_job *d_jobs, int n,
                                   int maxWidth, int maxHeight, vtmhip_frac_result *d_results );
+
+/* ---- transform / quantisation: one TU per job --------------------------------------------------------------------- */
+typedef struct
+{
+  int64_t srcOff, dstOff;   /* xT: residual samples -> coefficients; xIT: coefficients -> residual samples (offsets in elements) */
+  int32_t srcStride;        /* xT: residual stride (CS resi stride); coefficients are always W x H contiguous */
+  int32_t dstStride;        /* xIT: residual stride */
+  int16_t width, height;    /* 1..64 (MAX_TB_SIZEY) */
+  uint8_t typeHor, typeVer; /* VTMHIP_DCT2 / DCT8 / DST7 as TrQuant::getTrTypes chose them */
+  uint8_t bitDepth, pad;
+} vtmhip_tr_job;
+
+/* TrQuant::xT (TrQuant.cpp:776-851) for n TUs.  d_sumAbs (may be NULL): sum |coef| per TU (MTS pre-selection, :986-990). */
+int vtmhip_xT_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, int32_t *d_coefBase, const vtmhip_tr_job *d_jobs, int n, int maxWidth,
+                         int maxHeight, int32_t *d_sumAbs );
+/* TrQuant::xIT (TrQuant.cpp:853-923) */
+int vtmhip_xIT_batch_dev( vtmhip_ctx *ctx, const int32_t *d_coefBase, int16_t *d_resiBase, const vtmhip_tr_job *d_jobs, int n, int maxWidth,
+                          int maxHeight );
+
+typedef struct
+{
+  int64_t srcOff, dstOff;   /* W x H contiguous TCoeff blocks */
+  int16_t width, height;
+  int16_t qpPer, qpRem;     /* QpParam::per / rem (Quant.cpp:65-104) */
+  uint8_t bitDepth, isIRAP, isTransformSkip, pad;
+  int32_t pad2;
+} vtmhip_quant_job;
+
+/* Quant::quant, flat scaling list, no sign-bit hiding (Quant.cpp:955-1038): levels, optional deltaU, absSum per TU */
+int vtmhip_quant_batch_dev( vtmhip_ctx *ctx, const int32_t *d_coefBase, int32_t *d_qBase, int32_t *d_deltaUBase, const vtmhip_quant_job *d_jobs, int n,
+                            int32_t *d_absSum );
+/* Quant::dequant, flat scaling list (Quant.cpp:357-482) */
+int vtmhip_dequant_batch_dev( vtmhip_ctx *ctx, const int32_t *d_qBase, int32_t *d_coefBase, const vtmhip_quant_job *d_jobs, int n );
 
 #ifdef __cplusplus
 }

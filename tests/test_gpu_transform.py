@@ -1,0 +1,178 @@
+"""GPU parity: 1-D transform pointer surface, batched xT / xIT, scalar quant / dequant vs the CPU oracle.  Bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from vtm_amd.lib import QuantJob, TrJob
+
+pytestmark = pytest.mark.gpu
+
+DCT2, DCT8, DST7 = 0, 1, 2
+
+
+def _skip(t, n):
+    return 16 if (t != DCT2 and n == 32) else (n - 32 if n > 32 else 0)
+
+
+def _legal_types(n):
+    return (DCT2, DCT8, DST7) if 4 <= n <= 32 else (DCT2,)
+
+
+def test_fast_trans_pointer_surface_matches_oracle(ctx):
+    L = ol.oracle()
+    rng = np.random.default_rng(31)
+    for n in (2, 4, 8, 16, 32, 64):
+        for t in _legal_types(n):
+            for line in (1, 2, 4, 8, 16, 32, 64):
+                sk1s = {0} | ({16} if line == 32 else set()) | ({32} if line == 64 else set())
+                for sk1 in sk1s:
+                    for sk2 in {0, _skip(t, n)}:
+                        for amp, shift in ((512, 1), (32767, 7), (1 << 20, 10)):   # the last one wraps in 32 bits, like the reference
+                            src = rng.integers(-amp, amp, line * n).astype(np.int32)
+                            exp = np.zeros(line * n, np.int32)
+                            assert L.vo_fwd_trans(t, n, ol.P(src), ol.P(exp), shift, line, sk1, sk2) == 0
+                            got = ctx.fastFwdTrans(t, n, src, shift, line, sk1, sk2)
+                            assert np.array_equal(got, exp), ("fwd", t, n, line, sk1, sk2, amp)
+                            assert L.vo_inv_trans(t, n, ol.P(src), ol.P(exp), shift, line, sk1, sk2, -32768, 32767) == 0
+                            got = ctx.fastInvTrans(t, n, src, shift, line, sk1, sk2)
+                            assert np.array_equal(got, exp), ("inv", t, n, line, sk1, sk2, amp)
+
+
+def test_null_table_slots_are_rejected(ctx):
+    from vtm_amd.lib import VtmHipError
+    z = np.zeros(64 * 64, np.int32)
+    for (t, n) in ((DST7, 2), (DCT8, 64), (DST7, 64), (DCT8, 2), (DCT2, 128), (DCT2, 3)):
+        with pytest.raises(VtmHipError):
+            ctx.fastFwdTrans(t, n, z, 1, 1, 0, 0)
+
+
+def _tu_list():
+    tus = []
+    for w in (1, 2, 4, 8, 16, 32, 64):
+        for h in (1, 2, 4, 8, 16, 32, 64):
+            if w == 1 and h == 1:
+                continue
+            for th in _legal_types(w) if w > 1 else (DCT2,):
+                for tv in _legal_types(h) if h > 1 else (DCT2,):
+                    tus.append((w, h, th, tv))
+    return tus
+
+
+@pytest.mark.parametrize("bd", [10, 8])
+def test_xT_xIT_batch_matches_oracle(ctx, bd):
+    L = ol.oracle()
+    rng = np.random.default_rng(32 + bd)
+    tus = _tu_list() * 2
+    n = len(tus)
+    stride = 80
+    resi = np.zeros((n * 64, stride), np.int16)
+    jobs = (TrJob * n)()
+    exp_coef = np.zeros((n, 64 * 64), np.int32)
+    amp = 1 << bd
+    for k, (w, h, th, tv) in enumerate(tus):
+        blk = rng.integers(-amp + 1, amp, (h, w)).astype(np.int16)
+        if k % 7 == 0:
+            blk[:] = amp - 1 if k % 14 == 0 else -(amp - 1)   # dc extremes
+        resi[k * 64:k * 64 + h, 3:3 + w] = blk
+        j = jobs[k]
+        j.srcOff, j.dstOff, j.srcStride, j.dstStride = k * 64 * stride + 3, k * 4096, stride, stride
+        j.width, j.height, j.typeHor, j.typeVer, j.bitDepth = w, h, th, tv, bd
+        e = np.zeros(w * h, np.int32)
+        assert L.vo_fwd_2d(C.c_void_p(resi.ctypes.data + 2 * j.srcOff), stride, w, h, bd, th, tv, ol.P(e)) == 0
+        exp_coef[k, :w * h] = e
+    d_resi = ctx.to_device(resi)
+    d_coef = ctx.to_device(np.zeros((n, 4096), np.int32))
+    d_jobs = ctx.to_device(np.frombuffer(jobs, np.uint8))
+    d_sum = ctx.alloc(4 * n, np.int32)
+    ctx.xT_batch(d_resi.ptr, d_coef.ptr, d_jobs.ptr, n, 64, 64, d_sum.ptr)
+    got = d_coef.to_host().reshape(n, 4096)
+    sums = d_sum.to_host()
+    for k, (w, h, th, tv) in enumerate(tus):
+        assert np.array_equal(got[k, :w * h], exp_coef[k, :w * h]), ("xT", w, h, th, tv)
+        assert sums[k] == np.abs(exp_coef[k, :w * h].astype(np.int64)).sum(), ("sumAbs", w, h)
+
+    # inverse of (perturbed) coefficients: coefficient range as dequant produces it (16-bit clipped)
+    coefs = np.zeros((n, 4096), np.int32)
+    exp_resi = np.zeros((n * 64, stride), np.int16)
+    for k, (w, h, th, tv) in enumerate(tus):
+        c = (exp_coef[k, :w * h] // 3) * 3
+        c2 = c.reshape(h, w).copy()
+        sw, sh = _skip(th, w), _skip(tv, h)
+        if sw:
+            c2[:, w - sw:] = 0
+        if sh:
+            c2[h - sh:, :] = 0
+        coefs[k, :w * h] = c2.reshape(-1)
+        jobs[k].srcOff, jobs[k].dstOff = k * 4096, k * 64 * stride + 5
+        e = np.zeros((h, stride), np.int16)
+        assert L.vo_inv_2d(ol.P(np.ascontiguousarray(coefs[k, :w * h])), w, h, bd, th, tv, ol.P(e), stride) == 0
+        exp_resi[k * 64:k * 64 + h, 5:5 + w] = e[:, :w]
+    d_coef2 = ctx.to_device(coefs)
+    d_out = ctx.to_device(np.zeros((n * 64, stride), np.int16))
+    d_jobs2 = ctx.to_device(np.frombuffer(jobs, np.uint8))
+    ctx.xIT_batch(d_coef2.ptr, d_out.ptr, d_jobs2.ptr, n, 64, 64)
+    got_r = d_out.to_host().reshape(n * 64, stride)
+    assert np.array_equal(got_r, exp_resi)
+
+
+def test_transform_roundtrip_property(ctx):
+    """Size-independent property: xIT(xT(r)) reproduces r within +-6 (integer-transform rounding; the plain-C oracle
+    shows at most 5 at 32x32) for every DCT2 size up to 32, where nothing is zeroed out."""
+    rng = np.random.default_rng(5)
+    sizes = [(w, h) for w in (4, 8, 16, 32) for h in (4, 8, 16, 32)]
+    n = len(sizes)
+    resi = np.zeros((n * 32, 32), np.int16)
+    jobs = (TrJob * n)()
+    for k, (w, h) in enumerate(sizes):
+        resi[k * 32:k * 32 + h, :w] = rng.integers(-300, 300, (h, w))
+        j = jobs[k]
+        j.srcOff, j.dstOff, j.srcStride, j.dstStride, j.width, j.height, j.bitDepth = k * 1024, k * 1024, 32, 32, w, h, 10
+    d_resi = ctx.to_device(resi)
+    d_coef = ctx.alloc(4 * n * 1024, np.int32)
+    d_jobs = ctx.to_device(np.frombuffer(jobs, np.uint8))
+    d_back = ctx.to_device(np.zeros((n * 32, 32), np.int16))
+    ctx.xT_batch(d_resi.ptr, d_coef.ptr, d_jobs.ptr, n, 32, 32, None)
+    ctx.xIT_batch(d_coef.ptr, d_back.ptr, d_jobs.ptr, n, 32, 32)
+    back = d_back.to_host().reshape(n * 32, 32)
+    assert np.abs(back.astype(int) - resi).max() <= 6
+
+
+def test_quant_dequant_batch_matches_oracle(ctx):
+    L = ol.oracle()
+    rng = np.random.default_rng(41)
+    cases = [(w, h, qp, irap, ts) for w in (4, 8, 16, 32, 64) for h in (4, 8, 16, 32, 64) for qp in (22, 27, 32, 37, 51)
+             for irap in (0, 1) for ts in (0, 1) if not (ts and max(w, h) > 32)]
+    n = len(cases)
+    coef = np.zeros((n, 4096), np.int32)
+    jobs = (QuantJob * n)()
+    exp_q, exp_du, exp_dq = (np.zeros((n, 4096), np.int32) for _ in range(3))
+    exp_sum = np.zeros(n, np.int32)
+    for k, (w, h, qp, irap, ts) in enumerate(cases):
+        c = rng.integers(-32768, 32768, w * h).astype(np.int32)
+        c[rng.random(w * h) < 0.5] //= 64
+        coef[k, :w * h] = c
+        base_qp = qp + 12   # 10-bit: qpBdOffset 12 (Quant.cpp:65-104)
+        j = jobs[k]
+        j.srcOff, j.dstOff, j.width, j.height, j.qpPer, j.qpRem = k * 4096, k * 4096, w, h, base_qp // 6, base_qp % 6
+        j.bitDepth, j.isIRAP, j.isTransformSkip = 10, irap, ts
+        s = C.c_int32()
+        L.vo_quant(ol.P(np.ascontiguousarray(c)), w, h, 10, j.qpPer, j.qpRem, irap, ts, ol.P(exp_q[k]), ol.P(exp_du[k]), C.byref(s))
+        exp_sum[k] = s.value
+        L.vo_dequant(ol.P(exp_q[k]), w, h, 10, j.qpPer, j.qpRem, ts, ol.P(exp_dq[k]))
+    d_coef = ctx.to_device(coef)
+    d_q = ctx.to_device(np.zeros((n, 4096), np.int32))
+    d_du = ctx.to_device(np.zeros((n, 4096), np.int32))
+    d_dq = ctx.to_device(np.zeros((n, 4096), np.int32))
+    d_jobs = ctx.to_device(np.frombuffer(jobs, np.uint8))
+    d_sum = ctx.alloc(4 * n, np.int32)
+    ctx.quant_batch(d_coef.ptr, d_q.ptr, d_du.ptr, d_jobs.ptr, n, d_sum.ptr)
+    ctx.dequant_batch(d_q.ptr, d_dq.ptr, d_jobs.ptr, n)
+    q, du, dq = (d.to_host().reshape(n, 4096) for d in (d_q, d_du, d_dq))
+    sm = d_sum.to_host()
+    for k, (w, h, qp, irap, ts) in enumerate(cases):
+        assert np.array_equal(q[k, :w * h], exp_q[k, :w * h]), ("q", cases[k])
+        assert np.array_equal(du[k, :w * h], exp_du[k, :w * h]), ("deltaU", cases[k])
+        assert np.array_equal(dq[k, :w * h], exp_dq[k, :w * h]), ("dequant", cases[k])
+        assert sm[k] == exp_sum[k], ("absSum", cases[k])

@@ -17,6 +17,8 @@ int vtmhip_struct_size( int which )
   case 4: return ( int ) sizeof( vtmhip_if_job );
   case 5: return ( int ) sizeof( vtmhip_frac_job );
   case 6: return ( int ) sizeof( vtmhip_frac_result );
+  case 7: return ( int ) sizeof( vtmhip_tr_job );
+  case 8: return ( int ) sizeof( vtmhip_quant_job );
   default: return -1;
   }
 }

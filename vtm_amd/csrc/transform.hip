@@ -1,0 +1,469 @@
+// transform.hip -- separable DCT-2 / DST-7 / DCT-8 (2..64 points), scalar quantisation / dequantisation.
+//
+// Reference: CommonLib/TrQuant.cpp xT :776-851, xIT :853-923, tables fastFwdTrans/fastInvTrans :69-81;
+// CommonLib/TrQuant_EMT.cpp (the "fast" butterflies are exact refactorings of the matrix product
+// _fastForwardMM :274-323 / _fastInverseMM :235-271 -- no intermediate rounding -- so a plain 32-bit integer
+// matrix product is bit-identical, wrap-around included); core matrices CommonLib/RomTr.cpp (H.266 8.7.4.2
+// transMatrix constants, regenerated procedurally in tr_tables.hpp); Quant::quant CommonLib/Quant.cpp:955-1038,
+// Quant::dequant :357-482 (flat scaling list), scales CommonLib/Rom.cpp:463-473.
+//
+// One workgroup per transform unit.  The residual block, the intermediate (transposed) block and the transposed core
+// matrix live in LDS; lane l of a wave produces output frequency k = l (matrix columns are contiguous in LDS, the data
+// row is a broadcast), so LDS reads are conflict-free.
+#include "ctx.hpp"
+#include "tr_tables.hpp"
+
+#include <vector>
+
+namespace
+{
+
+struct TrTables { const int16_t *m[3][7]; };   // [type][log2 N] -> device pointer to the N x N forward matrix (row-major)
+
+int16_t *g_dTables[16] = {};   // per-device table buffer
+TrTables g_tabs[16];
+
+int ensure_tables( vtmhip_ctx *ctx )
+{
+  const int d = ctx->device & 15;
+  if( g_dTables[d] ) return VTMHIP_OK;
+  std::vector<int16_t> host;
+  size_t               offs[3][7];
+  for( int t = 0; t < 3; t++ )
+    for( int l = 0; l < 7; l++ )
+    {
+      offs[t][l] = ( size_t ) -1;
+      const int n = 1 << l;
+      std::vector<int16_t> m( ( size_t ) n * n );
+      if( n >= 2 && vtmhip_tr_matrix( t, n, m.data() ) == 0 )
+      {
+        offs[t][l] = host.size();
+        host.insert( host.end(), m.begin(), m.end() );
+      }
+    }
+  int16_t *dbuf = nullptr;
+  VTMHIP_HIP( ctx, hipMalloc( ( void ** ) &dbuf, host.size() * sizeof( int16_t ) ) );
+  VTMHIP_HIP( ctx, hipMemcpy( dbuf, host.data(), host.size() * sizeof( int16_t ), hipMemcpyHostToDevice ) );
+  for( int t = 0; t < 3; t++ )
+    for( int l = 0; l < 7; l++ ) g_tabs[d].m[t][l] = offs[t][l] == ( size_t ) -1 ? nullptr : dbuf + offs[t][l];
+  g_dTables[d] = dbuf;
+  return VTMHIP_OK;
+}
+
+__device__ __forceinline__ int ilog2( int v ) { return 31 - __clz( v ); }
+__device__ __forceinline__ int tr_skip( int type, int n ) { return ( type != VTMHIP_DCT2 && n == 32 ) ? 16 : ( n > 32 ? n - 32 : 0 ); }
+
+// sMT[n * N + k] = M[k][n]
+__device__ __forceinline__ void load_matrix_T( const int16_t *__restrict__ m, int N, int16_t *sMT )
+{
+  for( int i = threadIdx.x; i < N * N; i += blockDim.x )
+  {
+    const int k = i / N, n = i - k * N;
+    sMT[n * N + k] = m[i];
+  }
+}
+
+// dst[k * dstLd + j] = (sum_n M[k][n] * src[j * srcLd + n] + rnd) >> shift   for j < lines, k < kEff; zero for kEff <= k < N
+__device__ __forceinline__ void fwd_pass( const int *src, int srcLd, int *dst, int dstLd, const int16_t *sMT, int N, int lines, int kEff, int shift )
+{
+  const int rnd = shift > 0 ? 1 << ( shift - 1 ) : 0;
+  for( int o = threadIdx.x; o < lines * N; o += blockDim.x )
+  {
+    const int j = o / N, k = o - j * N;
+    int       v = 0;
+    if( k < kEff )
+    {
+      unsigned sum = 0;
+      for( int n = 0; n < N; n++ ) sum += ( unsigned ) src[j * srcLd + n] * ( unsigned ) ( int ) sMT[n * N + k];
+      v = ( int ) ( sum + ( unsigned ) rnd ) >> shift;
+    }
+    dst[k * dstLd + j] = v;
+  }
+}
+
+// dst[i * dstLd + j] = clip((sum_{k<cut} src[k * srcLd + i] * M[k][j] + rnd) >> shift)   for i < lines; M[k][j] = sMT[j * N + k]... we need
+// M row-major here: sM[k * N + j]
+__device__ __forceinline__ void inv_pass( const int *src, int srcLd, int *dst, int dstLd, const int16_t *sM, int N, int lines, int linesEff, int cut,
+                                          int shift, int cmin, int cmax )
+{
+  const unsigned rnd = 1u << ( shift - 1 );
+  for( int o = threadIdx.x; o < lines * N; o += blockDim.x )
+  {
+    const int i = o / N, j = o - i * N;
+    int       v = 0;
+    if( i < linesEff )
+    {
+      unsigned sum = 0;
+      for( int k = 0; k < cut; k++ ) sum += ( unsigned ) src[k * srcLd + i] * ( unsigned ) ( int ) sM[k * N + j];
+      v = min( cmax, max( cmin, ( int ) ( sum + rnd ) >> shift ) );
+    }
+    dst[i * dstLd + j] = v;
+  }
+}
+
+constexpr int TB = 64;   // MAX_TB_SIZEY
+
+__global__ __launch_bounds__( 256 ) void xT_kernel( const int16_t *__restrict__ resiBase, int *__restrict__ coefBase,
+                                                   const vtmhip_tr_job *__restrict__ jobs, TrTables tabs, int *__restrict__ sumAbsOut )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int ldsw[];
+  const vtmhip_tr_job j = jobs[blockIdx.x];
+  const int           w = j.width, h = j.height, bd = j.bitDepth;
+  int                *blk = ldsw;                    // [h][w]
+  int                *tmp = blk + w * h;             // [w][h+1]
+  int16_t            *sMT = ( int16_t * ) ( tmp + w * ( h + 1 ) );
+  const int16_t      *resi = resiBase + j.srcOff;
+  int                *coef = coefBase + j.dstOff;
+  for( int i = threadIdx.x; i < w * h; i += blockDim.x )
+  {
+    const int y = i / w, x = i - y * w;
+    blk[i]      = resi[( long ) y * j.srcStride + x];
+  }
+  const int skipW = tr_skip( j.typeHor, w ), skipH = tr_skip( j.typeVer, h );
+  int       sumAbs = 0;
+  if( w > 1 && h > 1 )
+  {
+    const int s1 = ilog2( w ) + bd + 6 - 15, s2 = ilog2( h ) + 6;
+    load_matrix_T( tabs.m[j.typeHor][ilog2( w )], w, sMT );
+    __syncthreads();
+    fwd_pass( blk, w, tmp, h + 1, sMT, w, h, w - skipW, s1 );   // tmp[k][y]
+    __syncthreads();
+    load_matrix_T( tabs.m[j.typeVer][ilog2( h )], h, sMT );
+    __syncthreads();
+    // second pass straight to global: coef[k2 * w + j2], zero where j2 >= w - skipW or k2 >= h - skipH
+    const int rnd = 1 << ( s2 - 1 ), kEff = h - skipH, jEff = w - skipW;
+    for( int o = threadIdx.x; o < w * h; o += blockDim.x )
+    {
+      const int j2 = o / h, k2 = o - j2 * h;
+      int       v  = 0;
+      if( j2 < jEff && k2 < kEff )
+      {
+        unsigned sum = 0;
+        for( int n = 0; n < h; n++ ) sum += ( unsigned ) tmp[j2 * ( h + 1 ) + n] * ( unsigned ) ( int ) sMT[n * h + k2];
+        v = ( int ) ( sum + ( unsigned ) rnd ) >> s2;
+      }
+      coef[k2 * w + j2] = v;
+      sumAbs += abs( v );
+    }
+  }
+  else
+  {
+    // 1-D cases (W == 1 or H == 1, TrQuant.cpp:836-850)
+    const int n = h == 1 ? w : h, type = h == 1 ? j.typeHor : j.typeVer, skip = h == 1 ? skipW : skipH;
+    const int s = ilog2( n ) + bd + 6 - 15;
+    load_matrix_T( tabs.m[type][ilog2( n )], n, sMT );
+    __syncthreads();
+    fwd_pass( blk, n, tmp, 1, sMT, n, 1, n - skip, s );
+    __syncthreads();
+    for( int i = threadIdx.x; i < n; i += blockDim.x ) { coef[i] = tmp[i]; sumAbs += abs( tmp[i] ); }
+  }
+  if( sumAbsOut )
+  {
+    // sum |coef| of the block (MTS candidate pre-selection, TrQuant.cpp:986-990); block-wide reduction through LDS
+    __syncthreads();
+    sumAbs = wave_reduce_add( sumAbs );
+    if( ( threadIdx.x & 63 ) == 0 ) blk[threadIdx.x >> 6] = sumAbs;
+    __syncthreads();
+    if( threadIdx.x == 0 )
+    {
+      int t = 0;
+      for( int k = 0; k < ( int ) ( blockDim.x >> 6 ); k++ ) t += blk[k];
+      sumAbsOut[blockIdx.x] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__( 256 ) void xIT_kernel( const int *__restrict__ coefBase, int16_t *__restrict__ resiBase,
+                                                    const vtmhip_tr_job *__restrict__ jobs, TrTables tabs )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int ldsw[];
+  const vtmhip_tr_job j = jobs[blockIdx.x];
+  const int           w = j.width, h = j.height, bd = j.bitDepth;
+  int                *blk = ldsw;                  // coefficients [h][w]
+  int                *tmp = blk + w * h;           // [w][h]
+  int16_t            *sM  = ( int16_t * ) ( tmp + w * h );
+  const int          *coef = coefBase + j.srcOff;
+  int16_t            *resi = resiBase + j.dstOff;
+  const int           cmin = -32768, cmax = 32767;
+  for( int i = threadIdx.x; i < w * h; i += blockDim.x ) blk[i] = coef[i];
+  const int skipW = tr_skip( j.typeHor, w ), skipH = tr_skip( j.typeVer, h );
+  if( w > 1 && h > 1 )
+  {
+    const int s1 = 7, s2 = 20 - bd;
+    {
+      const int16_t *m = tabs.m[j.typeVer][ilog2( h )];
+      for( int i = threadIdx.x; i < h * h; i += blockDim.x ) sM[i] = m[i];
+    }
+    __syncthreads();
+    inv_pass( blk, w, tmp, h, sM, h, w, w - skipW, h - skipH, s1, cmin, cmax );   // tmp[i (x-frequency)][y]
+    __syncthreads();
+    {
+      const int16_t *m = tabs.m[j.typeHor][ilog2( w )];
+      for( int i = threadIdx.x; i < w * w; i += blockDim.x ) sM[i] = m[i];
+    }
+    __syncthreads();
+    const unsigned rnd = 1u << ( s2 - 1 );
+    const int      cut = w - skipW;
+    for( int o = threadIdx.x; o < w * h; o += blockDim.x )
+    {
+      const int y = o / w, x = o - y * w;
+      unsigned  sum = 0;
+      for( int k = 0; k < cut; k++ ) sum += ( unsigned ) tmp[k * h + y] * ( unsigned ) ( int ) sM[k * w + x];
+      const int v = min( cmax, max( cmin, ( int ) ( sum + rnd ) >> s2 ) );
+      resi[( long ) y * j.dstStride + x] = ( int16_t ) v;
+    }
+  }
+  else
+  {
+    const int n = w == 1 ? h : w, type = w == 1 ? j.typeVer : j.typeHor, skip = w == 1 ? skipH : skipW;
+    const int s = 20 - bd + 1;
+    const int16_t *m = tabs.m[type][ilog2( n )];
+    for( int i = threadIdx.x; i < n * n; i += blockDim.x ) sM[i] = m[i];
+    __syncthreads();
+    inv_pass( blk, 1, tmp, n, sM, n, 1, 1, n - skip, s, cmin, cmax );
+    __syncthreads();
+    for( int i = threadIdx.x; i < n; i += blockDim.x )
+    {
+      if( w == 1 ) resi[( long ) i * j.dstStride] = ( int16_t ) tmp[i];
+      else resi[i] = ( int16_t ) tmp[i];
+    }
+  }
+}
+
+// 1-D pointer-surface kernels (FwdTrans / InvTrans signatures, arbitrary int32 input)
+__global__ __launch_bounds__( 256 ) void fwd1d_kernel( const int *__restrict__ src, int *__restrict__ dst, const int16_t *__restrict__ m, int N, int shift,
+                                                      int line, int skip1, int skip2 )
+{
+  const int      rl = line - skip1, cut = N - skip2;
+  const unsigned rnd = shift > 0 ? 1u << ( shift - 1 ) : 0;
+  for( int o = blockIdx.x * blockDim.x + threadIdx.x; o < N * line; o += gridDim.x * blockDim.x )
+  {
+    const int k = o / line, j = o - k * line;
+    int       v = 0;
+    if( j < rl && k < cut )
+    {
+      unsigned sum = 0;
+      for( int n = 0; n < N; n++ ) sum += ( unsigned ) src[j * N + n] * ( unsigned ) ( int ) m[k * N + n];
+      v = ( int ) ( sum + rnd ) >> shift;
+    }
+    dst[o] = v;
+  }
+}
+
+__global__ __launch_bounds__( 256 ) void inv1d_kernel( const int *__restrict__ src, int *__restrict__ dst, const int16_t *__restrict__ m, int N, int shift,
+                                                      int line, int skip1, int skip2, int cmin, int cmax )
+{
+  const int      rl = line - skip1, cut = N - skip2;
+  const unsigned rnd = 1u << ( shift - 1 );
+  for( int o = blockIdx.x * blockDim.x + threadIdx.x; o < N * line; o += gridDim.x * blockDim.x )
+  {
+    const int i = o / N, jj = o - i * N;
+    int       v = 0;
+    if( i < rl )
+    {
+      unsigned sum = 0;
+      for( int k = 0; k < cut; k++ ) sum += ( unsigned ) src[k * line + i] * ( unsigned ) ( int ) m[k * N + jj];
+      v = min( cmax, max( cmin, ( int ) ( sum + rnd ) >> shift ) );
+    }
+    dst[o] = v;
+  }
+}
+
+// ---- scalar quantisation (flat scaling list) -----------------------------------------------------------------------------
+__constant__ int c_quantScales[2][6]    = { { 26214, 23302, 20560, 18396, 16384, 14564 }, { 18396, 16384, 14564, 13107, 11651, 10280 } };
+__constant__ int c_invQuantScales[2][6] = { { 40, 45, 51, 57, 64, 72 }, { 57, 64, 72, 80, 90, 102 } };
+
+__global__ __launch_bounds__( 256 ) void quant_kernel( const int *__restrict__ coefBase, int *__restrict__ qBase, int *__restrict__ deltaUBase,
+                                                      const vtmhip_quant_job *__restrict__ jobs, int *__restrict__ absSumOut )
+{
+  __shared__ int            sRed[4];
+  const vtmhip_quant_job j  = jobs[blockIdx.x];
+  const int              w = j.width, h = j.height, lw = ilog2( w ), lh = ilog2( h );
+  const int              needSqrt = ( ( lw + lh ) & 1 ) && !j.isTransformSkip;
+  const int              scale    = c_quantScales[needSqrt][j.qpRem];
+  const int              trShift  = 15 - j.bitDepth - ( ( lw + lh ) >> 1 ) + ( needSqrt ? -1 : 0 );
+  const int              qBits    = 14 + j.qpPer + ( j.isTransformSkip ? 0 : trShift );
+  const long long        add      = ( long long ) ( j.isIRAP ? 171 : 85 ) << ( qBits - 9 );
+  const int             *coef     = coefBase + j.srcOff;
+  int                   *q        = qBase + j.dstOff;
+  int                    sum      = 0;
+  for( int i = threadIdx.x; i < w * h; i += blockDim.x )
+  {
+    const int       c   = coef[i];
+    const long long t   = ( long long ) abs( c ) * scale;
+    const int       mag = ( int ) ( ( t + add ) >> qBits );
+    if( deltaUBase ) deltaUBase[j.dstOff + i] = ( int ) ( ( t - ( ( long long ) mag << qBits ) ) >> ( qBits - 8 ) );
+    sum += mag;
+    q[i] = min( 32767, max( -32768, c < 0 ? -mag : mag ) );
+  }
+  sum = wave_reduce_add( sum );
+  if( ( threadIdx.x & 63 ) == 0 ) sRed[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if( threadIdx.x == 0 ) absSumOut[blockIdx.x] = sRed[0] + sRed[1] + sRed[2] + sRed[3];
+}
+
+__global__ __launch_bounds__( 256 ) void dequant_kernel( const int *__restrict__ qBase, int *__restrict__ coefBase,
+                                                        const vtmhip_quant_job *__restrict__ jobs )
+{
+  const vtmhip_quant_job j = jobs[blockIdx.x];
+  const int              w = j.width, h = j.height, lw = ilog2( w ), lh = ilog2( h );
+  const int              needSqrt   = ( ( lw + lh ) & 1 ) && !j.isTransformSkip;
+  const int              trShift    = 15 - j.bitDepth - ( ( lw + lh ) >> 1 ) + ( needSqrt ? -1 : 0 );
+  const int              rightShift = 6 - ( ( j.isTransformSkip ? 0 : trShift ) + j.qpPer );
+  const int              scale      = c_invQuantScales[needSqrt][j.qpRem];
+  const int              inBits     = min( 16, 32 + rightShift - 7 );
+  const int              inMin = -( 1 << ( inBits - 1 ) ), inMax = ( 1 << ( inBits - 1 ) ) - 1;
+  const int             *q    = qBase + j.srcOff;
+  int                   *coef = coefBase + j.dstOff;
+  for( int i = threadIdx.x; i < w * h; i += blockDim.x )
+  {
+    const int qq = min( inMax, max( inMin, q[i] ) );
+    int       v;
+    if( rightShift > 0 ) v = ( int ) ( ( unsigned ) ( qq * scale ) + ( 1u << ( rightShift - 1 ) ) ) >> rightShift;
+    else v = ( int ) ( ( unsigned ) ( qq * scale ) << ( -rightShift ) );
+    coef[i] = min( 32767, max( -32768, v ) );
+  }
+}
+
+bool pow2( int v ) { return v > 0 && ( v & ( v - 1 ) ) == 0; }
+int  hlog2( int v ) { int r = 0; while( ( 1 << r ) < v ) r++; return r; }
+
+}   // namespace
+
+extern "C"
+{
+
+int vtmhip_tr_matrix_host( int type, int n, int16_t *out ) { return vtmhip_tr_matrix( type, n, out ) ? VTMHIP_E_INVALID : VTMHIP_OK; }
+
+int vtmhip_fastFwdTrans( vtmhip_ctx *ctx, int type, int n, const int32_t *src, int32_t *dst, int shift, int line, int skipLine, int skipLine2 )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, src && dst, "null pointer" );
+  VTMHIP_REQUIRE( ctx, type >= 0 && type < 3 && pow2( n ) && n >= 2 && n <= 64 && ( type == VTMHIP_DCT2 || ( n >= 4 && n <= 32 ) ),
+                  "no such transform (fastFwdTrans slot is nullptr)" );
+  VTMHIP_REQUIRE( ctx, line >= 1 && line <= 64 && shift >= 0 && shift < 32 && skipLine >= 0 && skipLine <= line && skipLine2 >= 0 && skipLine2 <= n, "shape" );
+  int st = ensure_tables( ctx );
+  if( st ) return st;
+  const size_t bytes = ( size_t ) n * line * 4;
+  st = vtmhip_internal_scratch( ctx, 2 * bytes + 128 );
+  if( st ) return st;
+  char *hp = ( char * ) ctx->pinned, *dp = ( char * ) ctx->scratch;
+  const size_t dOff = ( bytes + 63 ) & ~( size_t ) 63;
+  memcpy( hp, src, bytes );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( dp, hp, bytes, hipMemcpyHostToDevice, ctx->stream ) );
+  hipLaunchKernelGGL( fwd1d_kernel, dim3( ( n * line + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, ( const int * ) dp, ( int * ) ( dp + dOff ),
+                      g_tabs[ctx->device & 15].m[type][hlog2( n )], n, shift, line, skipLine, skipLine2 );
+  VTMHIP_LAUNCHED( ctx );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( hp + dOff, dp + dOff, bytes, hipMemcpyDeviceToHost, ctx->stream ) );
+  VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  memcpy( dst, hp + dOff, bytes );
+  return VTMHIP_OK;
+}
+
+int vtmhip_fastInvTrans( vtmhip_ctx *ctx, int type, int n, const int32_t *src, int32_t *dst, int shift, int line, int skipLine, int skipLine2,
+                         int32_t outputMinimum, int32_t outputMaximum )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, src && dst, "null pointer" );
+  VTMHIP_REQUIRE( ctx, type >= 0 && type < 3 && pow2( n ) && n >= 2 && n <= 64 && ( type == VTMHIP_DCT2 || ( n >= 4 && n <= 32 ) ),
+                  "no such transform (fastInvTrans slot is nullptr)" );
+  VTMHIP_REQUIRE( ctx, line >= 1 && line <= 64 && shift >= 1 && shift < 32 && skipLine >= 0 && skipLine <= line && skipLine2 >= 0 && skipLine2 <= n, "shape" );
+  int st = ensure_tables( ctx );
+  if( st ) return st;
+  const size_t bytes = ( size_t ) n * line * 4;
+  st = vtmhip_internal_scratch( ctx, 2 * bytes + 128 );
+  if( st ) return st;
+  char *hp = ( char * ) ctx->pinned, *dp = ( char * ) ctx->scratch;
+  const size_t dOff = ( bytes + 63 ) & ~( size_t ) 63;
+  memcpy( hp, src, bytes );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( dp, hp, bytes, hipMemcpyHostToDevice, ctx->stream ) );
+  hipLaunchKernelGGL( inv1d_kernel, dim3( ( n * line + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, ( const int * ) dp, ( int * ) ( dp + dOff ),
+                      g_tabs[ctx->device & 15].m[type][hlog2( n )], n, shift, line, skipLine, skipLine2, outputMinimum, outputMaximum );
+  VTMHIP_LAUNCHED( ctx );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( hp + dOff, dp + dOff, bytes, hipMemcpyDeviceToHost, ctx->stream ) );
+  VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  memcpy( dst, hp + dOff, bytes );
+  return VTMHIP_OK;
+}
+
+int vtmhip_xT_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, int32_t *d_coefBase, const vtmhip_tr_job *d_jobs, int n, int maxWidth,
+                         int maxHeight, int32_t *d_sumAbs )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_resiBase && d_coefBase && d_jobs, "null pointer" );
+  VTMHIP_REQUIRE( ctx, maxWidth >= 1 && maxWidth <= TB && maxHeight >= 1 && maxHeight <= TB, "maxWidth / maxHeight (max transform size 64)" );
+  int st = ensure_tables( ctx );
+  if( st ) return st;
+  const int    mx  = maxWidth > maxHeight ? maxWidth : maxHeight;
+  const size_t lds = ( size_t ) ( maxWidth * maxHeight + maxWidth * ( maxHeight + 1 ) ) * 4 + ( size_t ) mx * mx * 2 + 16;
+  hipLaunchKernelGGL( xT_kernel, dim3( n ), dim3( 256 ), lds, ctx->stream, d_resiBase, d_coefBase, d_jobs, g_tabs[ctx->device & 15], d_sumAbs );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_xIT_batch_dev( vtmhip_ctx *ctx, const int32_t *d_coefBase, int16_t *d_resiBase, const vtmhip_tr_job *d_jobs, int n, int maxWidth,
+                          int maxHeight )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_resiBase && d_coefBase && d_jobs, "null pointer" );
+  VTMHIP_REQUIRE( ctx, maxWidth >= 1 && maxWidth <= TB && maxHeight >= 1 && maxHeight <= TB, "maxWidth / maxHeight (max transform size 64)" );
+  int st = ensure_tables( ctx );
+  if( st ) return st;
+  const int    mx  = maxWidth > maxHeight ? maxWidth : maxHeight;
+  const size_t lds = ( size_t ) ( 2 * maxWidth * maxHeight ) * 4 + ( size_t ) mx * mx * 2 + 16;
+  hipLaunchKernelGGL( xIT_kernel, dim3( n ), dim3( 256 ), lds, ctx->stream, d_coefBase, d_resiBase, d_jobs, g_tabs[ctx->device & 15] );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_quant_batch_dev( vtmhip_ctx *ctx, const int32_t *d_coefBase, int32_t *d_qBase, int32_t *d_deltaUBase, const vtmhip_quant_job *d_jobs, int n,
+                            int32_t *d_absSum )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_coefBase && d_qBase && d_jobs && d_absSum, "null pointer" );
+  hipLaunchKernelGGL( quant_kernel, dim3( n ), dim3( 256 ), 0, ctx->stream, d_coefBase, d_qBase, d_deltaUBase, d_jobs, d_absSum );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_dequant_batch_dev( vtmhip_ctx *ctx, const int32_t *d_qBase, int32_t *d_coefBase, const vtmhip_quant_job *d_jobs, int n )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_coefBase && d_qBase && d_jobs, "null pointer" );
+  hipLaunchKernelGGL( dequant_kernel, dim3( n ), dim3( 256 ), 0, ctx->stream, d_qBase, d_coefBase, d_jobs );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+// MTS candidate pre-selection thresholds (TrQuant::transformNxN( ..., trModes, maxCand ), TrQuant.cpp:950-1019): host arithmetic (fp64).
+// sumAbs[i]: sum |coef| of candidate i in trModes order, as vtmhip_xT_batch_dev returns it (a transform-skip candidate already scaled by
+// the caller, :992-1001).  The reference compares the candidate at LIST POSITION 1 against the unscaled threshold (:1012).
+// test[i] = 1 when the candidate survives.
+int vtmhip_mts_select( const int32_t *sumAbs, int numCand, int width, int height, int maxCand, uint8_t *test )
+{
+  if( !sumAbs || !test || numCand < 1 || width < 1 || height < 1 ) return VTMHIP_E_INVALID;
+  static const double facBB[] = { 1.2, 1.3, 1.3, 1.4, 1.5 };
+  const int    mx  = width > height ? width : height;
+  int          lg  = 0;
+  while( ( 2 << lg ) <= mx ) lg++;
+  const int    fi  = lg - 2 > 0 ? ( lg - 2 > 4 ? 4 : lg - 2 ) : 0;
+  const double thr = facBB[fi] * sumAbs[0], thrTS = sumAbs[0];
+  int          numTests = 0;
+  for( int i = 0; i < numCand; i++ )
+  {
+    const bool t = sumAbs[i] <= ( i == 1 ? thrTS : thr ) && numTests <= maxCand;
+    test[i]      = t;
+    numTests += t;
+  }
+  return VTMHIP_OK;
+}
+
+}   // extern "C"

@@ -8,7 +8,8 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _lib
-from .lib import DistJob, FracJob, FracResult, IfJob, MeResult, PicParams, TzJob, VtmHipError   # noqa: F401  (re-exported)
+from .lib import (DistJob, FracJob, FracResult, IfJob, MeResult, PicParams, QuantJob, TrJob, TzJob,   # noqa: F401
+                  VtmHipError)
 
 
 class DevBuf:
@@ -136,6 +137,18 @@ class Context:
                                              w, w, h, bit_depth, clip[0], clip[1], bimc))
         return dst
 
+    def fastFwdTrans(self, ttype, n, src, shift, line, skip1, skip2):
+        src = np.ascontiguousarray(src, dtype=np.int32)
+        dst = np.zeros(n * line, np.int32)
+        self._check(self.L.vtmhip_fastFwdTrans(self.h, ttype, n, src.ctypes.data, dst.ctypes.data, shift, line, skip1, skip2))
+        return dst
+
+    def fastInvTrans(self, ttype, n, src, shift, line, skip1, skip2, cmin=-32768, cmax=32767):
+        src = np.ascontiguousarray(src, dtype=np.int32)
+        dst = np.zeros(n * line, np.int32)
+        self._check(self.L.vtmhip_fastInvTrans(self.h, ttype, n, src.ctypes.data, dst.ctypes.data, shift, line, skip1, skip2, cmin, cmax))
+        return dst
+
     # ---- batched device calls (device pointers: DevBuf.ptr or tensor.data_ptr()) ---------------------------------
     def dist_batch(self, d_org, d_cur, d_jobs, n, d_out):
         self._check(self.L.vtmhip_dist_batch_dev(self.h, d_org, d_cur, d_jobs, n, d_out))
@@ -148,6 +161,18 @@ class Context:
 
     def frac_search_batch(self, d_org, d_ref, d_jobs, n, max_w, max_h, d_results):
         self._check(self.L.vtmhip_frac_search_batch_dev(self.h, d_org, d_ref, d_jobs, n, max_w, max_h, d_results))
+
+    def xT_batch(self, d_resi, d_coef, d_jobs, n, max_w, max_h, d_sum_abs=None):
+        self._check(self.L.vtmhip_xT_batch_dev(self.h, d_resi, d_coef, d_jobs, n, max_w, max_h, d_sum_abs))
+
+    def xIT_batch(self, d_coef, d_resi, d_jobs, n, max_w, max_h):
+        self._check(self.L.vtmhip_xIT_batch_dev(self.h, d_coef, d_resi, d_jobs, n, max_w, max_h))
+
+    def quant_batch(self, d_coef, d_q, d_delta_u, d_jobs, n, d_abs_sum):
+        self._check(self.L.vtmhip_quant_batch_dev(self.h, d_coef, d_q, d_delta_u, d_jobs, n, d_abs_sum))
+
+    def dequant_batch(self, d_q, d_coef, d_jobs, n):
+        self._check(self.L.vtmhip_dequant_batch_dev(self.h, d_q, d_coef, d_jobs, n))
 
     def tz_search_batch(self, pic, d_org, d_ref, d_jobs, n, d_results):
         self._check(self.L.vtmhip_tz_search_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, d_results))

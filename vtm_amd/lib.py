@@ -56,7 +56,19 @@ class FracResult(C.Structure):
                 ("cost", C.c_uint64)]
 
 
-_STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult]   # order of vtmhip_struct_size(which)
+class TrJob(C.Structure):
+    _fields_ = [("srcOff", C.c_int64), ("dstOff", C.c_int64), ("srcStride", C.c_int32), ("dstStride", C.c_int32),
+                ("width", C.c_int16), ("height", C.c_int16), ("typeHor", C.c_uint8), ("typeVer", C.c_uint8),
+                ("bitDepth", C.c_uint8), ("pad", C.c_uint8)]
+
+
+class QuantJob(C.Structure):
+    _fields_ = [("srcOff", C.c_int64), ("dstOff", C.c_int64), ("width", C.c_int16), ("height", C.c_int16),
+                ("qpPer", C.c_int16), ("qpRem", C.c_int16), ("bitDepth", C.c_uint8), ("isIRAP", C.c_uint8),
+                ("isTransformSkip", C.c_uint8), ("pad", C.c_uint8), ("pad2", C.c_int32)]
+
+
+_STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
 _PROTOS = {
@@ -91,6 +103,15 @@ _PROTOS = {
     "vtmhip_if_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "vtmhip_frac_search_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                C.c_void_p]),
+    "vtmhip_fastFwdTrans": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vtmhip_fastInvTrans": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int32, C.c_int32]),
+    "vtmhip_tr_matrix_host": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
+    "vtmhip_mts_select": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vtmhip_xT_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vtmhip_xIT_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "vtmhip_quant_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vtmhip_dequant_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "vtmhip_dist_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vtmhip_satd8_grid_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),
