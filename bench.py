@@ -125,7 +125,7 @@ def main():
 
     def step(k=None):
         if world > 1:
-            dist.broadcast(dpb, src=0)   # reconstructed reference pictures -> every GPU (xGMI)
+            dist.broadcast(dpb.view(torch.uint8), src=0)   # reconstructed reference pictures -> every GPU (xGMI); bytes: int16 is not a collective dtype
         if k is not None:
             tz_ev[k][0].record()
         fme.run(cur.data_ptr(), dpb.data_ptr())

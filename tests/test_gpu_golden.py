@@ -1,0 +1,61 @@
+"""GPU: the HIP kernels against the golden vectors recorded from the real reference (tests/golden/*.npz)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import me_util
+from vtm_amd.lib import FracJob, FracResult, MeResult, PicParams
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_dist_golden(ctx):
+    z = np.load(os.path.join(G, "dist.npz"))
+    org, cur, st = z["org"], z["cur"], z["starts"]
+    for (bi, w, h, kind, ss), e in zip(z["meta"], z["exp"]):
+        o = np.ascontiguousarray(org[st[bi]:st[bi + 1]])
+        c = np.ascontiguousarray(cur[st[bi]:st[bi + 1]])
+        w, h = int(w), int(h)
+        got = (ctx.xGetSAD(o, w, c, w, w, h, int(ss)) if kind == 0 else ctx.xGetHADs(o, w, c, w, w, h) if kind == 1 else ctx.xGetSSE(o, w, c, w, w, h))
+        assert got == int(e), (w, h, kind, ss)
+
+
+def test_transform_golden(ctx):
+    z = np.load(os.path.join(G, "transform.npz"))
+    src, dst = z["src"], z["dst"]
+    for (t, n, line, a, b, shift, inv, o0) in z["meta"]:
+        s = src[o0:o0 + n * line]
+        got = (ctx.fastInvTrans if inv else ctx.fastFwdTrans)(int(t), int(n), s, int(shift), int(line), int(a), int(b))
+        assert np.array_equal(got, dst[o0:o0 + n * line]), (t, n, line, a, b, shift, inv)
+
+
+def test_motion_search_golden(ctx):
+    z = np.load(os.path.join(G, "me.npz"))
+    scene = me_util.Scene(416, 240, hard=True)
+    jobs = [json.loads(s) for s in z["tz_jobs"]]
+    arr = me_util.hip_tz_jobs(scene, jobs, scene.W)
+    d_cur, d_ref = ctx.to_device(scene.cur), ctx.to_device(scene.ref_buf)
+    d_jobs = ctx.to_device(np.frombuffer(arr, np.uint8))
+    d_res = ctx.alloc(len(jobs) * 32)
+    ctx.tz_search_batch(PicParams(scene.W, scene.H, 128, 10), d_cur.ptr, d_ref.ptr, d_jobs.ptr, len(jobs), d_res.ptr)
+    res = (MeResult * len(jobs)).from_buffer_copy(d_res.to_host(np.uint8).tobytes())
+    got = np.array([(r.mvX, r.mvY, r.cost, r.dist) for r in res], np.int64)
+    assert np.array_equal(got, z["tz_res"])
+
+    fj = z["frac_jobs"]
+    farr = (FracJob * len(fj))()
+    for k, (w, h, x, y, lam, ph, pv, ix, iy, had) in enumerate(fj):
+        t = farr[k]
+        t.orgOff, t.refOff = int(y) * scene.W + int(x), scene.ref_off + int(y) * scene.ref_stride + int(x)
+        t.orgStride, t.refStride, t.width, t.height = scene.W, scene.ref_stride, int(w), int(h)
+        t.intX, t.intY, t.predHor, t.predVer, t.motionLambda = int(ix), int(iy), int(ph), int(pv), float(lam)
+        t.useHad, t.useAltHpelIf, t.imvShift, t.bitDepth = int(had), 0, 0, 10
+    d_fj = ctx.to_device(np.frombuffer(farr, np.uint8))
+    d_fr = ctx.alloc(16 * len(fj))
+    ctx.frac_search_batch(d_cur.ptr, d_ref.ptr, d_fj.ptr, len(fj), 128, 128, d_fr.ptr)
+    fres = (FracResult * len(fj)).from_buffer_copy(d_fr.to_host(np.uint8).tobytes())
+    gotf = np.array([(r.halfX, r.halfY, r.qterX, r.qterY, r.cost) for r in fres], np.int64)
+    assert np.array_equal(gotf, z["frac_res"])

@@ -1,0 +1,67 @@
+"""CPU: host-side logic of the frame pipeline (job tables, quadtree parents, CTU-row ownership) and the 2-rank
+sharding path on the gloo backend."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from vtm_amd import pipeline, synth
+from vtm_amd.lib import TzJob
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_subshift_rule_matches_oracle(oracle):
+    for w in (4, 8, 12, 16, 24, 32, 48, 64, 128):
+        for h in (4, 8, 16, 32, 64, 128):
+            assert pipeline.subshift_mode2(w, h) == oracle.vo_subshift_for_mode(w, h, 2)
+
+
+def test_quadtree_levels_cover_picture_and_parents_enclose_children():
+    lv = pipeline.quadtree_levels(416, 240)
+    assert [l[0] for l in lv] == [128, 64, 32, 16, 8]
+    for (s, xs, ys, parent), (ps, pxs, pys, _) in zip(lv[1:], lv[:-1]):
+        ok = parent >= 0
+        assert ((xs[ok] // ps * ps == pxs[parent[ok]]) & (ys[ok] // ps * ps == pys[parent[ok]])).all()
+        # children without a parent only exist where the coarser block would cross the picture edge
+        assert (((xs[~ok] // ps * ps + ps > 416) | (ys[~ok] // ps * ps + ps > 240))).all()
+    s, xs, ys, _ = lv[-1]
+    assert xs.size == (416 // 8) * (240 // 8)
+
+
+def test_row_filter_partitions_the_picture():
+    all_lv = pipeline.quadtree_levels(3840, 2160, sizes=(64,))
+    parts = [pipeline.quadtree_levels(3840, 2160, sizes=(64,), row_filter=lambda r, k=k: r % 4 == k) for k in range(4)]
+    assert sum(p[0][1].size for p in parts) == all_lv[0][1].size
+    seen = set()
+    for p in parts:
+        for x, y in zip(p[0][1], p[0][2]):
+            assert (x, y) not in seen
+            seen.add((x, y))
+
+
+def test_tz_job_table_layout():
+    xs, ys = np.array([0, 64]), np.array([128, 128])
+    a = pipeline.build_tz_jobs(64, xs, ys, 3840, 1000, 4160, 96, 8.0)
+    raw = a.view(np.uint8).reshape(2, -1)
+    j = TzJob.from_buffer_copy(raw[1].tobytes())
+    assert (j.orgOff, j.refOff, j.puX, j.puY, j.width, j.height) == (128 * 3840 + 64, 1000 + 128 * 4160 + 64, 64, 128, 64, 64)
+    assert (j.subShift, j.searchRange, j.motionLambda, j.firstSearchStop) == (1, 96, 8.0, 1)
+
+
+def test_extend_plane_replicates_border():
+    p = np.arange(12, dtype=np.int16).reshape(3, 4)
+    buf, off, stride = synth.extend_plane(p, margin=5, align=8)
+    ext = buf.reshape(-1, stride)
+    assert ext[5, 5] == 0 and ext[0, 0] == 0 and ext[7, 8] == 11 and ext[12, 13] == 11 and buf[off + 1 * stride + 2] == 6
+
+
+def test_two_rank_gloo_sharding():
+    """world_size 2 on CPU/gloo: rank 0 broadcasts the reference planes, each rank builds the job table of its own CTU
+    rows, and the union over ranks is the single-rank table."""
+    script = os.path.join(ROOT, "tests", "gloo_worker.py")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29517", script], capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "GLOO_OK" in out.stdout

@@ -1,0 +1,110 @@
+"""CPU: the plain-C oracle against the golden vectors recorded from the real reference (tests/golden/gen_golden.py).
+This is what pins the oracle on machines where the reference itself is not available."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+import me_util
+import oracle_lib as ol
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_dist_golden(oracle):
+    z = np.load(os.path.join(G, "dist.npz"))
+    org, cur, st = z["org"], z["cur"], z["starts"]
+    for (bi, w, h, kind, ss), e in zip(z["meta"], z["exp"]):
+        o = np.ascontiguousarray(org[st[bi]:st[bi + 1]]).reshape(h, w)
+        c = np.ascontiguousarray(cur[st[bi]:st[bi + 1]]).reshape(h, w)
+        assert ol.o_dist(int(kind), o, c, int(w), int(h), int(ss)) == int(e), (w, h, kind, ss)
+
+
+def test_mvcost_golden(oracle):
+    rows = np.load(os.path.join(G, "mvcost.npz"))["rows"]
+    for lam, ph, pv, cs, x, y, imv, e in rows:
+        mc = ol.MvCost(lam, int(ph), int(pv), int(cs))
+        assert oracle.vo_mv_cost(C.byref(mc), int(x), int(y), int(imv)) == int(e)
+
+
+def test_interp_golden(oracle):
+    z = np.load(os.path.join(G, "interp.npz"))
+    src10, src14, out = z["src10"], z["src14"], z["out"]
+    ss, off = 160, 8 * 160 + 8
+    for (w, h, comp, frac, vertical, isFirst, isLast, alt, o0) in z["meta"]:
+        src = src10 if isFirst else src14
+        d = np.zeros((h, w), np.int16)
+        if vertical:
+            oracle.vo_if_ver(int(comp), C.c_void_p(src.ctypes.data + 2 * off), ss, ol.P(d), int(w), int(w), int(h), int(frac), int(isFirst),
+                             int(isLast), 10, 0, 0, int(alt))
+        else:
+            oracle.vo_if_hor(int(comp), C.c_void_p(src.ctypes.data + 2 * off), ss, ol.P(d), int(w), int(w), int(h), int(frac), int(isLast), 10,
+                             0, 0, int(alt))
+        assert np.array_equal(d.reshape(-1), out[o0:o0 + w * h]), (w, h, comp, frac, vertical, isFirst, isLast, alt)
+
+
+def test_transform_golden(oracle):
+    z = np.load(os.path.join(G, "transform.npz"))
+    for t in range(3):
+        for n in (2, 4, 8, 16, 32, 64):
+            m = np.zeros((n, n), np.int16)
+            r = oracle.vo_tr_matrix(t, n, ol.P(m))
+            key = "m_%d_%d" % (t, n)
+            assert (r == 0) == (key in z.files)
+            if r == 0:
+                assert np.array_equal(m, z[key]), key
+    src, dst = z["src"], z["dst"]
+    for (t, n, line, a, b, shift, inv, o0) in z["meta"]:
+        s = np.ascontiguousarray(src[o0:o0 + n * line])
+        d = np.zeros(n * line, np.int32)
+        if inv:
+            oracle.vo_inv_trans(int(t), int(n), ol.P(s), ol.P(d), int(shift), int(line), int(a), int(b), -32768, 32767)
+        else:
+            oracle.vo_fwd_trans(int(t), int(n), ol.P(s), ol.P(d), int(shift), int(line), int(a), int(b))
+        assert np.array_equal(d, dst[o0:o0 + n * line]), (t, n, line, a, b, shift, inv)
+
+
+def test_motion_search_golden(oracle):
+    z = np.load(os.path.join(G, "me.npz"))
+    scene = me_util.Scene(416, 240, hard=True)
+    jobs = [json.loads(s) for s in z["tz_jobs"]]
+    got = me_util.run_oracle_tz(scene, jobs)
+    for g, e in zip(got, z["tz_res"]):
+        assert g[:4] == tuple(int(v) for v in e)
+    for fj, fr, fu in zip(z["frac_jobs"], z["frac_res"], z["full_res"]):
+        w, h, x, y, lam, ph, pv, ix, iy, had = fj
+        j = dict(w=int(w), h=int(h), x=int(x), y=int(y), subShift=0, lam=float(lam), predHor=int(ph), predVer=int(pv))
+        org = np.ascontiguousarray(scene.cur[j["y"]:j["y"] + j["h"], j["x"]:j["x"] + j["w"]])
+        c = me_util.oracle_ctx(scene, j, org)
+        r = ol.FracResult()
+        oracle.vo_frac_search(C.byref(c), int(ix), int(iy), int(had), 0, C.byref(r))
+        assert (r.halfX, r.halfY, r.qterX, r.qterY, r.cost) == tuple(int(v) for v in fr)
+        sr = ol.Range()
+        oracle.vo_set_search_range(C.byref(c), int(ix) * 16, int(iy) * 16, 4, C.byref(sr))
+        assert (sr.left, sr.right, sr.top, sr.bottom) == tuple(int(v) for v in fu[:4])
+        c.subShift = 1 if (j["h"] > 8 and j["w"] <= 64) else 0
+        m = ol.MeResult()
+        oracle.vo_full_search(C.byref(c), C.byref(sr), C.byref(m))
+        assert (m.mvX, m.mvY, m.cost, m.dist) == tuple(int(v) for v in fu[4:])
+
+
+def test_misc_golden(oracle):
+    z = np.load(os.path.join(G, "misc.npz"))
+    for k in range(int(z["count"][0])):
+        pred, resi = z["pred_%d" % k], z["resi_%d" % k]
+        h, w = pred.shape
+        for vertical, key in ((0, "gx_%d"), (1, "gy_%d")):
+            g = np.zeros((h, w), np.int32)
+            oracle.vo_sobel(vertical, ol.P(pred), w, ol.P(g), w, w, h)
+            assert np.array_equal(g, z[key % k])
+        for six in (0, 1):
+            eq = np.zeros((7, 7), np.int64)
+            oracle.vo_equal_coeff(ol.P(resi), w, ol.P(z["gx_%d" % k]), ol.P(z["gy_%d" % k]), w, ol.P(eq), w, h, six)
+            assert np.array_equal(eq, z["eq_%d_%d" % (k, six)])
+        o = z["org_%d" % k].copy()
+        oracle.vo_remove_high_freq(ol.P(o), w, ol.P(pred), w, w, h)
+        assert np.array_equal(o, z["rhf_%d" % k])
+        av = np.zeros((h, w), np.int16)
+        oracle.vo_add_avg(ol.P(z["a14_%d" % k]), w, ol.P(z["b14_%d" % k]), w, ol.P(av), w, w, h, 10)
+        assert np.array_equal(av, z["avg_%d" % k])

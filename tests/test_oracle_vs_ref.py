@@ -1,0 +1,157 @@
+"""CPU, dev container only: the plain-C oracle against the REAL reference (oracle/_ref/libvtmref.so, built from
+/root/reference by oracle/Makefile.ref) on randomized sweeps -- wider than the committed golden fixtures.
+Skipped where the reference build is absent (e.g. a fresh checkout on the GPU box before `make -f oracle/Makefile.ref`)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import me_util
+import oracle_lib as ol
+
+pytestmark = pytest.mark.ref
+
+
+def test_distortion_sweep(oracle, reflib):
+    rng = np.random.default_rng(101)
+    for w in (4, 8, 12, 16, 24, 32, 48, 64, 128):
+        for h in (4, 8, 16, 32, 64, 128):
+            for _ in range(2):
+                org = ol.i16(rng.integers(-1023, 2047, (h, w + 7)))
+                cur = ol.i16(rng.integers(0, 1024, (h, w + 3)))
+                for ss in (0, 1):
+                    assert ol.o_dist(0, org, cur, w, h, ss) == ol.r_dist(0, 1, org, cur, w, h, 10, ss) == ol.r_dist(0, 0, org, cur, w, h, 10, ss)
+                assert ol.o_dist(1, org, cur, w, h) == ol.r_dist(1, 1, org, cur, w, h) == ol.r_dist(1, 0, org, cur, w, h)
+                assert ol.o_dist(2, org, cur, w, h) == ol.r_dist(2, 0, org, cur, w, h)
+            for mode in (0, 1, 2, 3):
+                assert oracle.vo_subshift_for_mode(w, h, mode) == reflib.ref_subshift_for_mode(w, h, mode)
+
+
+def test_satd8_grid_matches_reference_distfunc(oracle, reflib):
+    scene = me_util.Scene(128, 64, hard=True, margin=16)
+    nb, r = (128 // 8) * (64 // 8), 4
+    a, b = np.zeros(nb * 81, np.uint64), np.zeros(nb * 81, np.uint64)
+    refp = C.c_void_p(scene.ref_buf.ctypes.data + 2 * scene.ref_off)
+    oracle.vo_satd8_grid(ol.P(scene.cur), 128, refp, scene.ref_stride, 128, 64, r, ol.P(a))
+    reflib.ref_satd8_grid(1, ol.P(scene.cur), 128, refp, scene.ref_stride, 128, 64, r, 10, ol.P(b))
+    assert np.array_equal(a, b)
+
+
+def test_tap_tables_and_matrices(oracle, reflib):
+    for which, name, nf, nt in ((0, "vo_luma_filter", 16, 8), (1, "vo_luma_filter_4x4", 16, 8), (2, "vo_chroma_filter", 32, 4)):
+        tab = np.array((C.c_int16 * (nf * nt)).in_dll(oracle, name)).reshape(nf, nt)
+        for f in range(nf):
+            o = np.zeros(8, np.int16)
+            reflib.ref_if_taps(which, f, ol.P(o))
+            assert np.array_equal(o[:nt], tab[f])
+    alt = np.zeros(8, np.int16)
+    reflib.ref_if_taps(4, 0, ol.P(alt))
+    assert np.array_equal(alt, np.array((C.c_int16 * 8).in_dll(oracle, "vo_luma_alt_hpel")))
+    for t in range(3):
+        for n in (2, 4, 8, 16, 32, 64):
+            a, b = np.zeros((n, n), np.int16), np.zeros((n, n), np.int16)
+            ra, rb = oracle.vo_tr_matrix(t, n, ol.P(a)), reflib.ref_tr_matrix(t, n, 0, ol.P(b))
+            assert (ra == 0) == (rb == 0)
+            if ra == 0:
+                assert np.array_equal(a, b)
+                reflib.ref_tr_matrix(t, n, 1, ol.P(b))   # the "inverse" table is the same matrix; the inverse transform indexes it transposed
+                assert np.array_equal(a, b)
+
+
+def test_interpolation_sweep(oracle, reflib):
+    rng = np.random.default_rng(102)
+    for (w, h) in ((4, 4), (4, 11), (4, 8), (8, 8), (16, 16), (17, 24), (5, 12), (64, 72), (12, 16)):
+        for bd in (8, 10):
+            src = ol.i16(rng.integers(0, 1 << bd, (h + 16, w + 16)))
+            src14 = ol.i16(rng.integers(-8192, 8191, (h + 16, w + 16)))
+            ss = w + 16
+            off = 8 * ss + 8
+            for comp, nfr in ((0, 16), (1, 32)):
+                for frac in range(nfr):
+                    for isLast in (0, 1):
+                        d = [np.zeros((h, w + 5), np.int16) for _ in range(3)]
+                        oracle.vo_if_hor(comp, C.c_void_p(src.ctypes.data + 2 * off), ss, ol.P(d[0]), w + 5, w, h, frac, isLast, bd, 0, 0, 0)
+                        for simd in (0, 1):
+                            reflib.ref_if_hor(simd, comp, C.c_void_p(src.ctypes.data + 2 * off), ss, ol.P(d[1 + simd]), w + 5, w, h, frac, isLast,
+                                              bd, 0, 0, 0)
+                        assert np.array_equal(d[0], d[1]) and np.array_equal(d[0], d[2]), ("hor", w, h, bd, comp, frac, isLast)
+                        for isFirst in (0, 1):
+                            s = src if isFirst else src14
+                            oracle.vo_if_ver(comp, C.c_void_p(s.ctypes.data + 2 * off), ss, ol.P(d[0]), w + 5, w, h, frac, isFirst, isLast, bd, 0,
+                                             0, 0)
+                            for simd in (0, 1):
+                                reflib.ref_if_ver(simd, comp, C.c_void_p(s.ctypes.data + 2 * off), ss, ol.P(d[1 + simd]), w + 5, w, h, frac,
+                                                  isFirst, isLast, bd, 0, 0, 0)
+                            assert np.array_equal(d[0], d[1]) and np.array_equal(d[0], d[2]), ("ver", w, h, bd, comp, frac, isFirst, isLast)
+
+
+def test_transform_1d_sweep(oracle, reflib):
+    """All table slots with the skip combinations xT / xIT can produce; amplitudes up to 2^20 wrap in 32 bits on both sides.
+    (Other skip values are not comparable: the small DCT-2 butterflies ignore iSkipLine2, TrQuant_EMT.cpp:51-232.)"""
+    rng = np.random.default_rng(103)
+    for t in range(3):
+        for n in (2, 4, 8, 16, 32, 64):
+            si = int(np.log2(n)) - 1
+            sk2s = {0, 16 if (t != 0 and n == 32) else (n - 32 if n > 32 else 0)}
+            for line in (1, 2, 4, 8, 16, 32, 64):
+                for sk1 in {0} | ({16} if line == 32 else set()) | ({32} if line == 64 else set()):
+                    for sk2 in sk2s:
+                        for amp, shift in ((512, 1), (32767, 7), (1 << 20, 12)):
+                            src = rng.integers(-amp, amp, line * n).astype(np.int32)
+                            d1, d2 = np.full(line * n, -7, np.int32), np.full(line * n, -7, np.int32)
+                            ra = oracle.vo_fwd_trans(t, n, ol.P(src), ol.P(d1), shift, line, sk1, sk2)
+                            rb = reflib.ref_fwd_trans(t, si, ol.P(src), ol.P(d2), shift, line, sk1, sk2)
+                            assert ra == rb and (ra != 0 or np.array_equal(d1, d2)), ("fwd", t, n, line, sk1, sk2)
+                            s2 = src.reshape(n, line).copy()
+                            if sk2:
+                                s2[n - sk2:, :] = 0
+                            if sk1:
+                                s2[:, line - sk1:] = 0
+                            ra = oracle.vo_inv_trans(t, n, ol.P(s2), ol.P(d1), shift, line, sk1, sk2, -32768, 32767)
+                            rb = reflib.ref_inv_trans(t, si, ol.P(s2), ol.P(d2), shift, line, sk1, sk2, -32768, 32767)
+                            assert ra == rb and (ra != 0 or np.array_equal(d1, d2)), ("inv", t, n, line, sk1, sk2)
+
+
+@pytest.mark.parametrize("hard", [True, False])
+def test_tz_search_equals_reference_xTZSearch(oracle, reflib, hard):
+    scene = me_util.Scene(416, 240, hard=hard)
+    jobs = me_util.random_tz_jobs(scene, 600, seed=201 + hard)
+    exp = []
+    for j in jobs:
+        org = np.ascontiguousarray(scene.cur[j["y"]:j["y"] + j["h"], j["x"]:j["x"] + j["w"]])
+        c, t, r = me_util.oracle_ctx(scene, j, org), me_util.oracle_tz_job(j), ol.MeResult()
+        reflib.ref_tz_search(C.byref(c), C.byref(t), C.byref(r))
+        exp.append((r.mvX, r.mvY, r.cost, r.dist))
+    got = [g[:4] for g in me_util.run_oracle_tz(scene, jobs)]
+    assert got == exp
+
+
+def test_frac_and_full_search_equal_reference(oracle, reflib):
+    scene = me_util.Scene(416, 240, hard=True)
+    rng = np.random.default_rng(203)
+    for trial in range(250):
+        w = int(rng.choice([8, 16, 32, 64, 128, 4, 16, 8, 32, 64]))
+        h = int(rng.choice([8, 16, 32, 64, 128, 8, 4, 16]))
+        if w == 4 and h == 4:
+            continue
+        x = int(rng.integers(0, (416 - w) // 4 + 1)) * 4
+        y = int(rng.integers(0, (240 - h) // 4 + 1)) * 4
+        org = np.ascontiguousarray(scene.cur[y:y + h, x:x + w])
+        if trial % 3 == 0:   # bi-pred ME target
+            org = (2 * org.astype(np.int32) - rng.integers(0, 1024, org.shape)).astype(np.int16)
+        j = dict(w=w, h=h, x=x, y=y, subShift=0, lam=float(rng.uniform(1, 40)), predHor=int(rng.integers(-64, 64)), predVer=int(rng.integers(-64, 64)))
+        c = me_util.oracle_ctx(scene, j, org)
+        ix, iy, had = int(rng.integers(-12, 12)), int(rng.integers(-12, 12)), int(trial % 4 != 0)
+        a, b = ol.FracResult(), ol.FracResult()
+        oracle.vo_frac_search(C.byref(c), ix, iy, had, 0, C.byref(a))
+        reflib.ref_frac_search(C.byref(c), ix, iy, had, 0, C.byref(b))
+        assert (a.halfX, a.halfY, a.qterX, a.qterY, a.cost) == (b.halfX, b.halfY, b.qterX, b.qterY, b.cost)
+        sr, out = ol.Range(), (C.c_int * 4)()
+        oracle.vo_set_search_range(C.byref(c), ix * 16, iy * 16, 4, C.byref(sr))
+        reflib.ref_set_search_range(C.byref(c), ix * 16, iy * 16, 4, out)
+        assert list(out) == [sr.left, sr.right, sr.top, sr.bottom]
+        c.subShift = 1 if (h > 8 and w <= 64) else 0
+        m, r = ol.MeResult(), ol.MeResult()
+        oracle.vo_full_search(C.byref(c), C.byref(sr), C.byref(m))
+        reflib.ref_full_search(C.byref(c), out, C.byref(r))
+        assert (m.mvX, m.mvY, m.cost, m.dist) == (r.mvX, r.mvY, r.cost, r.dist)

@@ -70,5 +70,5 @@ def extend_plane(plane, margin=160, align=64):
     h, w = plane.shape
     stride = padded_stride(w, margin, align)
     ext = np.pad(plane, ((margin, margin), (margin, stride - w - margin)), mode="edge")
-    buf = np.ascontiguousarray(ext, dtype=np.int16)
+    buf = np.ascontiguousarray(ext, dtype=np.int16).reshape(-1)
     return buf, margin * stride + margin, stride
