@@ -145,6 +145,7 @@ typedef struct
   int32_t picW, picH;   /* pps.getPicWidth/HeightInLumaSamples: clipMv / xClipMv limits */
   int32_t ctuSize;      /* sps.getMaxCUWidth() */
   int32_t bitDepth;
+  int32_t wavesPerJob;  /* tuning hint for this batch: 0/1 = one wave per search; 2, 4, 8, 16 = waves that split each candidate list (large PUs) */
 } vtmhip_pic_params;
 
 /* One (PU, reference picture) integer search = one call of InterSearch::xTZSearch. */
@@ -156,7 +157,8 @@ typedef struct
   int16_t puX, puY;     /* luma position of the PU in the picture                                          */
   int16_t width, height;
   int16_t subShift;     /* DistParam::subShift after setDistParam(subShiftMode) (RdCost.cpp:289-323)       */
-  int16_t imvShift;
+  uint8_t imvShift;
+  uint8_t signedSamples;   /* 0: every org/ref sample is >= 0 (uni-pred ME on pictures); 1: full int16 range (2*org - pred targets) */
   int32_t predHor, predVer;     /* RdCost::setPredictor, quarter-sample units                              */
   double  motionLambda;         /* RdCost::m_motionLambda                                                  */
   int32_t mvHor, mvVer;         /* rcMv on entry (internal 1/16 precision)                                 */

@@ -80,7 +80,7 @@ def hip_tz_jobs(scene, jobs, cur_stride):
         t.refOff = scene.ref_off + j["y"] * scene.ref_stride + j["x"]
         t.orgStride, t.refStride = cur_stride, scene.ref_stride
         t.puX, t.puY, t.width, t.height = j["x"], j["y"], j["w"], j["h"]
-        t.subShift, t.imvShift = j["subShift"], 0
+        t.subShift, t.imvShift, t.signedSamples = j["subShift"], 0, j.get("signed", 0)
         t.predHor, t.predVer, t.motionLambda = j["predHor"], j["predVer"], j["lam"]
         t.mvHor, t.mvVer, t.searchRange = j["mvHor"], j["mvVer"], j["searchRange"]
         t.extendedSettings, t.fastSettings, t.firstSearchStop = j["ext"], j["fast"], j["firstStop"]

@@ -9,12 +9,12 @@ from vtm_amd.lib import MeResult, PicParams
 pytestmark = pytest.mark.gpu
 
 
-def _run_hip(ctx, scene, jobs):
+def _run_hip(ctx, scene, jobs, wpj=0):
     arr = me_util.hip_tz_jobs(scene, jobs, scene.W)
     d_cur, d_ref = ctx.to_device(scene.cur), ctx.to_device(scene.ref_buf)
     d_jobs = ctx.to_device(np.frombuffer(arr, np.uint8))
     d_res = ctx.alloc(len(jobs) * 32)
-    pic = PicParams(scene.W, scene.H, 128, 10)
+    pic = PicParams(scene.W, scene.H, 128, 10, wpj)
     ctx.tz_search_batch(pic, d_cur.ptr, d_ref.ptr, d_jobs.ptr, len(jobs), d_res.ptr)
     raw = d_res.to_host(np.uint8)
     res = (MeResult * len(jobs)).from_buffer_copy(raw.tobytes())
@@ -42,5 +42,31 @@ def test_tz_search_picture_border_and_tiny_range(ctx):
             j["mvHor"], j["mvVer"] = (-1) ** k * 3000, (-1) ** (k // 2) * 2500
     exp = me_util.run_oracle_tz(scene, jobs)
     got = _run_hip(ctx, scene, jobs)
+    bad = [k for k in range(len(jobs)) if got[k] != exp[k]]
+    assert not bad, [(jobs[k], got[k], exp[k]) for k in bad[:5]]
+
+
+def test_tz_search_signed_samples(ctx):
+    """Full int16 range targets (2*org - pred of bi-pred ME) through the sign-biased v_sad_u16 path."""
+    scene = me_util.Scene(416, 240, hard=True)
+    rng = np.random.default_rng(17)
+    scene.cur = np.ascontiguousarray((2 * scene.cur.astype(np.int32) - rng.integers(0, 1024, scene.cur.shape)).astype(np.int16))
+    assert scene.cur.min() < 0
+    jobs = me_util.random_tz_jobs(scene, 500, seed=18)
+    for j in jobs:
+        j["signed"] = 1
+    exp = me_util.run_oracle_tz(scene, jobs)
+    got = _run_hip(ctx, scene, jobs)
+    bad = [k for k in range(len(jobs)) if got[k] != exp[k]]
+    assert not bad, [(jobs[k], got[k], exp[k]) for k in bad[:5]]
+
+
+@pytest.mark.parametrize("wpj", [2, 4, 8, 16])
+def test_tz_search_multi_wave_jobs(ctx, wpj):
+    """wavesPerJob > 1: the waves of a workgroup split every candidate list; results must not change."""
+    scene = me_util.Scene(416, 240, hard=True)
+    jobs = me_util.random_tz_jobs(scene, 400, seed=30 + wpj)
+    exp = me_util.run_oracle_tz(scene, jobs)
+    got = _run_hip(ctx, scene, jobs, wpj)
     bad = [k for k in range(len(jobs)) if got[k] != exp[k]]
     assert not bad, [(jobs[k], got[k], exp[k]) for k in bad[:5]]

@@ -27,9 +27,24 @@ struct MeJob   // wave-uniform view of one vtmhip_tz_job
   int            predHor, predVer, costScale;
   double         lambda;
   int            horMin, horMax, verMin, verMax;   // clipMv limits (internal 1/16 precision)
+  // cooperative SAD decomposition: a candidate = `items` segments of `seg` samples (rows stepped by 1 << ss);
+  // `lpc` lanes (power of two) share one candidate, 64 / lpc candidates are evaluated at a time
+  int            seg, segsPerRow, items, lpc;
+  int            lpcShift, sprShift;   // log2(lpc); log2(segsPerRow) or -1 when it is not a power of two (widths 12, 24, 48)
+  bool           narrow;               // lambda * 126 < 2^31: distortion + MV rate fits 32 bits -> packed (cost, index) keys
+  unsigned       bias;   // 0x80008000 when samples may be negative (v_sad_u16 is unsigned), else 0
 };
 
 __device__ __forceinline__ int floor_log2_u( unsigned v ) { return 31 - __clz( ( int ) v ); }
+
+// wave-uniform values: tell the compiler (SGPRs, scalar branches instead of exec-mask control flow)
+__device__ __forceinline__ int uni( int v ) { return __builtin_amdgcn_readfirstlane( v ); }
+__device__ __forceinline__ unsigned uni( unsigned v ) { return ( unsigned ) __builtin_amdgcn_readfirstlane( ( int ) v ); }
+__device__ __forceinline__ unsigned long long uni( unsigned long long v )
+{
+  const unsigned lo = uni( ( unsigned ) v ), hi = uni( ( unsigned ) ( v >> 32 ) );
+  return ( ( unsigned long long ) hi << 32 ) | lo;
+}
 
 __device__ __forceinline__ unsigned eg_bits( int v )
 {
@@ -42,7 +57,8 @@ __device__ __forceinline__ unsigned eg_bits( int v )
 __device__ __forceinline__ unsigned long long mv_cost( const MeJob &j, int x, int y )
 {
   const unsigned bits = eg_bits( ( ( x << j.costScale ) - j.predHor ) >> j.imvShift ) + eg_bits( ( ( y << j.costScale ) - j.predVer ) >> j.imvShift );
-  return ( unsigned long long ) ( j.lambda * ( double ) bits );   // fp64 multiply, truncation (RdCost.h:314)
+  const double   c    = j.lambda * ( double ) bits;   // fp64 multiply, truncation (RdCost.h:314)
+  return j.narrow ? ( unsigned long long ) ( unsigned ) c : ( unsigned long long ) c;   // bits <= 126: c < 2^31 when narrow
 }
 
 __device__ __forceinline__ void clip_mv( const MeJob &j, int &hor, int &ver )
@@ -64,48 +80,43 @@ __device__ __forceinline__ Range search_range( const MeJob &j, int predHor, int 
   return sr;
 }
 
-// 8 consecutive samples from a 2-byte aligned address (gfx950 global memory handles the misalignment in hardware)
-struct __attribute__( ( packed, aligned( 2 ) ) ) Pel8 { int16_t v[8]; };
-struct __attribute__( ( packed, aligned( 2 ) ) ) Pel4 { int16_t v[4]; };
+// 8 / 4 consecutive samples from a 2-byte aligned address (gfx950 global memory handles the misalignment in hardware)
+struct __attribute__( ( packed, aligned( 2 ) ) ) Pel8 { unsigned v[4]; };
+struct __attribute__( ( packed, aligned( 2 ) ) ) Pel4 { unsigned v[2]; };
 
-// full SAD of one candidate by ONE lane (rows stepped by 1 << ss, result shifted back) -- RdCost.cpp:493-528
-__device__ __forceinline__ unsigned sad_lane( const MeJob &j, int cx, int cy )
+// |a.lo - b.lo| + |a.hi - b.hi| + acc on unsigned 16-bit halves: one VALU instruction per two samples.
+// Signed samples are made unsigned by flipping the sign bits of both operands (bias), which leaves |a - b| unchanged.
+__device__ __forceinline__ unsigned sad2( unsigned a, unsigned b, unsigned acc ) { return __builtin_amdgcn_sad_u16( a, b, acc ); }
+
+// partial SAD of candidate (cx, cy) over the items sub, sub + lpc, ... (RdCost.cpp:493-528 arithmetic)
+__device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy, int sub )
 {
-  const int16_t *o    = j.org;
-  const int16_t *c    = j.ref + ( long ) cy * j.refStride + cx;
-  const int      step = 1 << j.ss;
-  unsigned       s    = 0;
-  if( ( j.w & 7 ) == 0 )
+  const int16_t *c0 = j.ref + ( long ) cy * j.refStride + cx;
+  const long     os = ( long ) j.orgStride << j.ss, cs = ( long ) j.refStride << j.ss;
+  unsigned       s = 0;
+  if( j.seg == 8 )
   {
-    for( int y = 0; y < j.h; y += step )
+    for( int it = sub; it < j.items; it += j.lpc )
     {
-      for( int x = 0; x < j.w; x += 8 )
-      {
-        const Pel8 a = *reinterpret_cast<const Pel8 *>( o + x );
-        const Pel8 b = *reinterpret_cast<const Pel8 *>( c + x );
+      const int  r = j.sprShift >= 0 ? it >> j.sprShift : it / j.segsPerRow, x = ( it - r * j.segsPerRow ) << 3;
+      const Pel8 a = *reinterpret_cast<const Pel8 *>( j.org + r * os + x );
+      const Pel8 b = *reinterpret_cast<const Pel8 *>( c0 + r * cs + x );
 #pragma unroll
-        for( int k = 0; k < 8; k++ ) s += ( unsigned ) abs( ( int ) a.v[k] - ( int ) b.v[k] );
-      }
-      o += ( long ) j.orgStride * step;
-      c += ( long ) j.refStride * step;
+      for( int k = 0; k < 4; k++ ) s = sad2( a.v[k] ^ j.bias, b.v[k] ^ j.bias, s );
     }
   }
   else
   {
-    for( int y = 0; y < j.h; y += step )
+    for( int it = sub; it < j.items; it += j.lpc )
     {
-      for( int x = 0; x < j.w; x += 4 )
-      {
-        const Pel4 a = *reinterpret_cast<const Pel4 *>( o + x );
-        const Pel4 b = *reinterpret_cast<const Pel4 *>( c + x );
+      const int  r = j.sprShift >= 0 ? it >> j.sprShift : it / j.segsPerRow, x = ( it - r * j.segsPerRow ) << 2;
+      const Pel4 a = *reinterpret_cast<const Pel4 *>( j.org + r * os + x );
+      const Pel4 b = *reinterpret_cast<const Pel4 *>( c0 + r * cs + x );
 #pragma unroll
-        for( int k = 0; k < 4; k++ ) s += ( unsigned ) abs( ( int ) a.v[k] - ( int ) b.v[k] );
-      }
-      o += ( long ) j.orgStride * step;
-      c += ( long ) j.refStride * step;
+      for( int k = 0; k < 2; k++ ) s = sad2( a.v[k] ^ j.bias, b.v[k] ^ j.bias, s );
     }
   }
-  return s << j.ss;
+  return s;
 }
 
 // lexicographic (cost, index) minimum over the wave
@@ -128,42 +139,148 @@ struct TzState
   unsigned           bestDist, bestRound, nEval;
 };
 
-// evaluate the n (<= 64) candidates whose (x, y, nr, dist) sit in pts[] and replay the accept rule
-__device__ __forceinline__ void tz_round( const MeJob &j, TzState &s, const int4 *pts, int n, int lane, bool touchMeta )
+// The lanes that run one job: WPJ waves (WPJ = 1: one wave, four independent jobs per workgroup; WPJ > 1: the whole
+// workgroup is one job and the waves split every candidate list).  All waves carry identical search state.
+struct Coop
 {
-  unsigned long long cost = ~0ull;
-  unsigned           idx  = 0xffffffffu;
-  // pts[] was written by lane 0 of this wave: DS operations of one wave execute in order; the fence keeps the
-  // compiler from moving the reads above the writes
-  __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
-  __builtin_amdgcn_wave_barrier();
-  if( lane < n )
+  int                 lane, wave, wpj;
+  bool                leader;    // the single thread that writes the candidate list
+  unsigned long long *redCost;   // [wpj] cross-wave arg-min exchange (LDS)
+  unsigned           *redIdx;
+};
+
+template<int WPJ>
+__device__ __forceinline__ void job_sync()
+{
+  if( WPJ == 1 )
   {
-    const int4 p = pts[lane];
-    cost         = ( unsigned long long ) sad_lane( j, p.x, p.y ) + mv_cost( j, p.x, p.y );
-    idx          = ( unsigned ) lane;
+    // DS operations of one wave execute in order; the fence keeps the compiler from reordering across it
+    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+    __builtin_amdgcn_wave_barrier();
   }
-  wave_argmin( cost, idx );
+  else
+  {
+    __syncthreads();
+  }
+}
+
+// Evaluates `total` candidates, 64 / lpc at a time, and returns the lexicographic (cost, index) minimum (wave-uniform).
+// RASTER: candidate k = grid point (k % nx, k / nx) of the raster; otherwise pts[k].
+template<bool RASTER, int WPJ>
+__device__ __forceinline__ void eval_candidates( const MeJob &j, const int4 *pts, int total, int rLeft, int rTop, int nx, int stepXY, const Coop &co,
+                                                 unsigned long long &bestCost, unsigned &bestIdx )
+{
+  const int lane = co.lane;
+  const int lpc = j.lpc, cpw = 64 >> j.lpcShift;
+  const int grp = lane >> j.lpcShift, sub = lane & ( lpc - 1 );
+  bestCost = ~0ull;
+  bestIdx  = 0xffffffffu;
+  for( int base = co.wave * cpw; base < total; base += cpw * WPJ )
+  {
+    const int k = base + grp;
+    unsigned  s = 0;
+    int       x = 0, y = 0;
+    if( k < total )
+    {
+      if( RASTER )
+      {
+        const int ry = k / nx, rx = k - ry * nx;
+        x = rLeft + rx * stepXY;
+        y = rTop + ry * stepXY;
+      }
+      else
+      {
+        const int4 p = pts[k];
+        x = p.x;
+        y = p.y;
+      }
+      s = sad_partial( j, x, y, sub );
+    }
+    // sum over the lpc lanes of the group (butterfly: every lane of the group ends with the total)
+#pragma unroll
+    for( int o = 32; o > 0; o >>= 1 )
+      if( o < lpc ) s += __shfl_xor( s, o, 64 );
+    if( k < total )
+    {
+      const unsigned long long c = ( ( unsigned long long ) s << j.ss ) + mv_cost( j, x, y );
+      if( c < bestCost ) { bestCost = c; bestIdx = ( unsigned ) k; }   // k increases: keeps the earliest index per lane
+    }
+  }
+  if( j.narrow )
+  {
+    // cost < 2^32: one 64-bit key (cost << 32 | index) orders lexicographically
+    unsigned long long key = ( bestCost << 32 ) | bestIdx;
+    if( bestIdx == 0xffffffffu ) key = ~0ull;
+#pragma unroll
+    for( int o = 32; o > 0; o >>= 1 )
+    {
+      const unsigned long long ok = __shfl_xor( key, o, 64 );
+      key = ok < key ? ok : key;
+    }
+    if( WPJ > 1 )
+    {
+      if( lane == 0 ) co.redCost[co.wave] = key;
+      __syncthreads();
+#pragma unroll
+      for( int w = 0; w < WPJ; w++ )
+      {
+        const unsigned long long ok = co.redCost[w];
+        key = ok < key ? ok : key;
+      }
+      __syncthreads();
+    }
+    key      = uni( key );
+    bestCost = key == ~0ull ? ~0ull : key >> 32;
+    bestIdx  = ( unsigned ) key;
+    return;
+  }
+  wave_argmin( bestCost, bestIdx );
+  if( WPJ > 1 )
+  {
+    if( lane == 0 ) { co.redCost[co.wave] = bestCost; co.redIdx[co.wave] = bestIdx; }
+    __syncthreads();
+#pragma unroll
+    for( int w = 0; w < WPJ; w++ )
+    {
+      const unsigned long long oc = co.redCost[w];
+      const unsigned           oi = co.redIdx[w];
+      if( oc < bestCost || ( oc == bestCost && oi < bestIdx ) ) { bestCost = oc; bestIdx = oi; }
+    }
+    __syncthreads();
+  }
+  bestCost = uni( bestCost );
+  bestIdx  = uni( bestIdx );
+}
+
+// evaluate the n (<= 16) candidates whose (x, y, nr, dist) sit in pts[] and replay the accept rule
+template<int WPJ>
+__device__ __forceinline__ void tz_round( const MeJob &j, TzState &s, const int4 *pts, int n, const Coop &co, bool touchMeta )
+{
+  job_sync<WPJ>();   // pts[] was written by the job's leader thread
+  unsigned long long cost;
+  unsigned           idx;
+  eval_candidates<false, WPJ>( j, pts, n, 0, 0, 1, 1, co, cost, idx );
   s.nEval += ( unsigned ) n;
   if( n > 0 && cost < s.bestSad )
   {
     const int4 p = pts[idx];
     s.bestSad    = cost;
-    s.bestX      = p.x;
-    s.bestY      = p.y;
+    s.bestX      = uni( p.x );
+    s.bestY      = uni( p.y );
     if( touchMeta )
     {
-      s.bestDist  = ( unsigned ) p.w;
+      s.bestDist  = ( unsigned ) uni( p.w );
       s.bestRound = 0;
-      s.pointNr   = p.z;
+      s.pointNr   = uni( p.z );
     }
   }
+  job_sync<WPJ>();   // everyone has read pts[] before the next round overwrites it
 }
 
-#define PUSH( X, Y, NR, D ) do { if( lane == 0 ) pts[n] = make_int4( ( X ), ( Y ), ( NR ), ( D ) ); n++; } while( 0 )
+#define PUSH( X, Y, NR, D ) do { if( co.leader ) pts[n] = make_int4( ( X ), ( Y ), ( NR ), ( D ) ); n++; } while( 0 )
 
 // ordered candidate list of one diamond round (xTZ8PointDiamondSearch :504-705); returns the count (<= 16)
-__device__ int diamond_points( const Range &sr, int sx, int sy, int d, bool corners, int4 *pts, int lane )
+__device__ int diamond_points( const Range &sr, int sx, int sy, int d, bool corners, int4 *pts, const Coop &co )
 {
   int       n = 0;
   const int top = sy - d, bot = sy + d, left = sx - d, right = sx + d;
@@ -242,14 +359,16 @@ __device__ int diamond_points( const Range &sr, int sx, int sy, int d, bool corn
   return n;
 }
 
-__device__ __forceinline__ void tz_diamond( const MeJob &j, TzState &s, int sx, int sy, int d, bool corners, int4 *pts, int lane )
+template<int WPJ>
+__device__ __forceinline__ void tz_diamond( const MeJob &j, TzState &s, int sx, int sy, int d, bool corners, int4 *pts, const Coop &co )
 {
-  const int n = diamond_points( s.sr, sx, sy, d, corners, pts, lane );
+  const int n = diamond_points( s.sr, sx, sy, d, corners, pts, co );
   s.bestRound += 1;
-  tz_round( j, s, pts, n, lane, true );
+  tz_round<WPJ>( j, s, pts, n, co, true );
 }
 
-__device__ __forceinline__ void tz_two_point( const MeJob &j, TzState &s, int4 *pts, int lane )
+template<int WPJ>
+__device__ __forceinline__ void tz_two_point( const MeJob &j, TzState &s, int4 *pts, const Coop &co )
 {
   // untested neighbours of the best point, by the point number of the dist-1 round (xTZ2PointSearch :426-446);
   // packed as 2-bit fields (value + 1) per point number 0..8
@@ -263,26 +382,19 @@ __device__ __forceinline__ void tz_two_point( const MeJob &j, TzState &s, int4 *
   int       n  = 0;
   if( x1 >= s.sr.left && x1 <= s.sr.right && y1 >= s.sr.top && y1 <= s.sr.bottom ) PUSH( x1, y1, 0, 2 );
   if( x2 >= s.sr.left && x2 <= s.sr.right && y2 >= s.sr.top && y2 <= s.sr.bottom ) PUSH( x2, y2, 0, 2 );
-  tz_round( j, s, pts, n, lane, true );
+  tz_round<WPJ>( j, s, pts, n, co, true );
 }
 
-// raster scan (xTZSearch :3888-3899 / adaptive :3883-3903): candidate k = (row k / nx, column k % nx), one per lane,
-// 64 at a time; per-lane running minimum keeps the earliest index, the wave arg-min the earliest lane.
-__device__ __forceinline__ void tz_raster( const MeJob &j, TzState &s, const Range &r, int stepXY, int lane )
+// raster scan (xTZSearch :3888-3899 / adaptive :3883-3903): candidate k = (row k / nx, column k % nx) in row-major order
+template<int WPJ>
+__device__ __forceinline__ void tz_raster( const MeJob &j, TzState &s, const Range &r, int stepXY, const Coop &co )
 {
   const int nx = r.right >= r.left ? ( r.right - r.left ) / stepXY + 1 : 0;
   const int ny = r.bottom >= r.top ? ( r.bottom - r.top ) / stepXY + 1 : 0;
   const int total = nx * ny;
-  unsigned long long cost = ~0ull;
-  unsigned           idx  = 0xffffffffu;
-  for( int k = lane; k < total; k += 64 )
-  {
-    const int                ry = k / nx, rx = k - ry * nx;
-    const int                x = r.left + rx * stepXY, y = r.top + ry * stepXY;
-    const unsigned long long c = ( unsigned long long ) sad_lane( j, x, y ) + mv_cost( j, x, y );
-    if( c < cost ) { cost = c; idx = ( unsigned ) k; }
-  }
-  wave_argmin( cost, idx );
+  unsigned long long cost;
+  unsigned           idx;
+  eval_candidates<true, WPJ>( j, nullptr, total, r.left, r.top, nx > 0 ? nx : 1, stepXY, co, cost, idx );
   s.nEval += ( unsigned ) total;
   if( total > 0 && cost < s.bestSad )
   {
@@ -296,18 +408,25 @@ __device__ __forceinline__ void tz_raster( const MeJob &j, TzState &s, const Ran
   }
 }
 
-constexpr int TZ_WAVES = 4;
-
-__global__ __launch_bounds__( 64 * TZ_WAVES ) void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase,
-                                                                    const int16_t *__restrict__ refBase, const vtmhip_tz_job *__restrict__ jobs, int numJobs,
-                                                                    vtmhip_me_result *__restrict__ results )
+// WPJ = 1: 256 threads = 4 independent jobs.  WPJ > 1: 64 * WPJ threads = 1 job.
+template<int WPJ>
+__global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase,
+                                                                                const int16_t *__restrict__ refBase,
+                                                                                const vtmhip_tz_job *__restrict__ jobs, int numJobs,
+                                                                                vtmhip_me_result *__restrict__ results )
 {
-  __shared__ int4 sPts[TZ_WAVES][16];
-  const int       lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int       jobIdx = blockIdx.x * TZ_WAVES + wave;
-  if( jobIdx >= numJobs ) return;
+  constexpr int JOBS_PER_BLOCK = WPJ == 1 ? 4 : 1;
+  __shared__ int4               sPts[JOBS_PER_BLOCK][16];   // 15 m_uniMvList candidates / 16 diamond points at most
+  __shared__ unsigned long long sRedCost[WPJ];
+  __shared__ unsigned           sRedIdx[WPJ];
+  const int lane = threadIdx.x & 63, wv = uni( ( int ) ( threadIdx.x >> 6 ) );
+  const int jobIdx = WPJ == 1 ? blockIdx.x * 4 + wv : blockIdx.x;
+  if( jobIdx >= numJobs ) return;   // WPJ == 1: whole waves leave; WPJ > 1: never true (grid = numJobs)
   const vtmhip_tz_job *jp  = jobs + jobIdx;
-  int4                *pts = sPts[wave];
+  int4                *pts = sPts[WPJ == 1 ? wv : 0];
+  Coop                 co;
+  co.lane = lane; co.wave = WPJ == 1 ? 0 : wv; co.wpj = WPJ; co.leader = ( lane == 0 && co.wave == 0 );
+  co.redCost = sRedCost; co.redIdx = sRedIdx;
 
   MeJob j;
   j.org       = orgBase + jp->orgOff;
@@ -326,6 +445,15 @@ __global__ __launch_bounds__( 64 * TZ_WAVES ) void tz_search_kernel( vtmhip_pic_
   j.horMin    = ( -pic.ctuSize - 8 - jp->puX + 1 ) << 4;
   j.verMax    = ( pic.picH + 8 - jp->puY - 1 ) << 4;
   j.verMin    = ( -pic.ctuSize - 8 - jp->puY + 1 ) << 4;
+  j.seg        = ( j.w & 7 ) == 0 ? 8 : 4;
+  j.segsPerRow = j.w / j.seg;
+  j.items      = j.segsPerRow * ( ( j.h + ( 1 << j.ss ) - 1 ) >> j.ss );
+  j.lpc        = 1;
+  while( j.lpc < 64 && ( j.lpc << 1 ) <= j.items ) j.lpc <<= 1;
+  j.bias       = jp->signedSamples ? 0x80008000u : 0u;
+  j.lpcShift   = floor_log2_u( ( unsigned ) j.lpc );
+  j.sprShift   = ( j.segsPerRow & ( j.segsPerRow - 1 ) ) == 0 ? floor_log2_u( ( unsigned ) j.segsPerRow ) : -1;
+  j.narrow     = j.lambda >= 0.0 && j.lambda * 126.0 < 2147483648.0;
 
   const bool ext = jp->extendedSettings != 0, fast = jp->fastSettings != 0, firstStop = jp->firstSearchStop != 0;
   const int  iRaster = fast ? 8 : 5, searchRange = jp->searchRange;
@@ -339,21 +467,48 @@ __global__ __launch_bounds__( 64 * TZ_WAVES ) void tz_search_kernel( vtmhip_pic_
   clip_mv( j, mx, my );
   mx = div_pow2( prec_down( mx, 2 ), 2 );
   my = div_pow2( prec_down( my, 2 ), 2 );
-  int n0 = 0;
+  if( !jp->hasIntMv2Nx2NPred )
   {
+    // Start candidates in ONE round: rcMv is always accepted first (best = max), so the zero-vector test condition
+    // (:3696-3704) is known up front, and the m_uniMvList candidates (:3725-3762) use the same strict-minimum rule
+    // with dist = pointNr = 0 like the start vector.
     int n = 0;
     PUSH( mx, my, 0, 0 );
-    n0 = n;
+    if( !fast && ( mx != 0 || my != 0 ) ) PUSH( 0, 0, 0, 0 );
+    const int ne = min( jp->numExtraStart, 14 );
+    for( int i = 0; i < ne; i++ )
+    {
+      int ex = jp->extraStart[i][0], ey = jp->extraStart[i][1];
+      clip_mv( j, ex, ey );
+      PUSH( prec_down( ex, 4 ), prec_down( ey, 4 ), 0, 0 );
+    }
+    tz_round<WPJ>( j, s, pts, n, co, true );
+    if( jp->numExtraStart > 14 )   // 15th candidate: the list holds 16 points
+    {
+      int m = 0;
+      {
+        int n = 0;
+        int ex = jp->extraStart[14][0], ey = jp->extraStart[14][1];
+        clip_mv( j, ex, ey );
+        PUSH( prec_down( ex, 4 ), prec_down( ey, 4 ), 0, 0 );
+        m = n;
+      }
+      tz_round<WPJ>( j, s, pts, m, co, false );
+    }
   }
-  tz_round( j, s, pts, n0, lane, true );
-  if( !fast && ( mx != 0 || my != 0 ) && ( s.bestX != 0 || s.bestY != 0 ) )
+  else
   {
-    int n = 0;
-    PUSH( 0, 0, 0, 0 );
-    tz_round( j, s, pts, n, lane, true );
-  }
-  if( jp->hasIntMv2Nx2NPred )
-  {
+    {
+      int n = 0;
+      PUSH( mx, my, 0, 0 );
+      tz_round<WPJ>( j, s, pts, n, co, true );
+    }
+    if( !fast && ( mx != 0 || my != 0 ) && ( s.bestX != 0 || s.bestY != 0 ) )
+    {
+      int n = 0;
+      PUSH( 0, 0, 0, 0 );
+      tz_round<WPJ>( j, s, pts, n, co, true );
+    }
     int ix = jp->intMv2Nx2NPredHor << 4, iy = jp->intMv2Nx2NPredVer << 4;
     clip_mv( j, ix, iy );
     ix = div_pow2( prec_down( ix, 2 ), 2 );
@@ -362,10 +517,8 @@ __global__ __launch_bounds__( 64 * TZ_WAVES ) void tz_search_kernel( vtmhip_pic_
     {
       int n = 0;
       PUSH( ix, iy, 0, 0 );
-      tz_round( j, s, pts, n, lane, true );
+      tz_round<WPJ>( j, s, pts, n, co, true );
     }
-  }
-  {
     // m_uniMvList start candidates (:3725-3762): one parallel round, same first-strict-minimum semantics
     int       n  = 0;
     const int ne = min( jp->numExtraStart, 15 );
@@ -375,7 +528,7 @@ __global__ __launch_bounds__( 64 * TZ_WAVES ) void tz_search_kernel( vtmhip_pic_
       clip_mv( j, ex, ey );
       PUSH( prec_down( ex, 4 ), prec_down( ey, 4 ), 0, 0 );
     }
-    tz_round( j, s, pts, n, lane, false );
+    tz_round<WPJ>( j, s, pts, n, co, false );
   }
 
   s.sr = search_range( j, s.bestX << 4, s.bestY << 4, searchRange >> ( fast ? 1 : 0 ) );
@@ -385,17 +538,17 @@ __global__ __launch_bounds__( 64 * TZ_WAVES ) void tz_search_kernel( vtmhip_pic_
 
   for( int d = 1; d <= searchRange; d *= 2 )
   {
-    tz_diamond( j, s, startX, startY, d, ext, pts, lane );
+    tz_diamond<WPJ>( j, s, startX, startY, d, ext, pts, co );
     if( firstStop && s.bestRound >= 3 ) break;
   }
   if( ext && !bestCandidateZero )
   {
-    for( int d = 1; d <= ( searchRange >> 1 ); d *= 2 ) tz_diamond( j, s, 0, 0, d, false, pts, lane );
+    for( int d = 1; d <= ( searchRange >> 1 ); d *= 2 ) tz_diamond<WPJ>( j, s, 0, 0, d, false, pts, co );
   }
   if( s.bestDist == 1 )
   {
     s.bestDist = 0;
-    tz_two_point( j, s, pts, lane );
+    tz_two_point<WPJ>( j, s, pts, co );
   }
   if( ext )
   {
@@ -407,12 +560,12 @@ __global__ __launch_bounds__( 64 * TZ_WAVES ) void tz_search_kernel( vtmhip_pic_
       lsr.left /= 2; lsr.right /= 2; lsr.top /= 2; lsr.bottom /= 2;
     }
     s.bestDist = ( unsigned ) win;
-    tz_raster( j, s, lsr, win, lane );
+    tz_raster<WPJ>( j, s, lsr, win, co );
   }
   else if( ( int ) s.bestDist >= iRaster )
   {
     s.bestDist = ( unsigned ) iRaster;
-    tz_raster( j, s, s.sr, iRaster, lane );
+    tz_raster<WPJ>( j, s, s.sr, iRaster, co );
   }
   // star refinement (:3937-3971)
   while( s.bestDist > 0 )
@@ -423,17 +576,17 @@ __global__ __launch_bounds__( 64 * TZ_WAVES ) void tz_search_kernel( vtmhip_pic_
     s.pointNr  = 0;
     for( int d = 1; d < searchRange + 1; d *= 2 )
     {
-      tz_diamond( j, s, startX, startY, d, ext, pts, lane );
+      tz_diamond<WPJ>( j, s, startX, startY, d, ext, pts, co );
       if( fast && s.bestRound >= 2 ) break;
     }
     if( s.bestDist == 1 )
     {
       s.bestDist = 0;
-      if( s.pointNr != 0 ) tz_two_point( j, s, pts, lane );
+      if( s.pointNr != 0 ) tz_two_point<WPJ>( j, s, pts, co );
     }
   }
 
-  if( lane == 0 )
+  if( co.leader )
   {
     vtmhip_me_result r;
     r.mvX = s.bestX; r.mvY = s.bestY; r.nEval = s.nEval; r.reserved = 0;
@@ -453,8 +606,21 @@ extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_par
   if( n == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, d_orgBase && d_refBase && d_jobs && d_results, "null pointer" );
   VTMHIP_REQUIRE( ctx, pic->picW > 0 && pic->picH > 0 && pic->ctuSize > 0, "picture parameters" );
-  hipLaunchKernelGGL( tz_search_kernel, dim3( ( n + TZ_WAVES - 1 ) / TZ_WAVES ), dim3( 64 * TZ_WAVES ), 0, ctx->stream, *pic, d_orgBase, d_refBase,
-                      d_jobs, n, d_results );
+  // wavesPerJob: tuning hint for the whole batch (0 / 1: a wave per search -- small blocks, short candidate lists;
+  // 2..16: that many waves split every candidate list -- large blocks, raster scans)
+  const int wpj = pic->wavesPerJob;
+  VTMHIP_REQUIRE( ctx, wpj == 0 || wpj == 1 || wpj == 2 || wpj == 4 || wpj == 8 || wpj == 16, "wavesPerJob must be 0, 1, 2, 4, 8 or 16" );
+#define VTMHIP_TZ_LAUNCH( W, GRID ) \
+  hipLaunchKernelGGL( tz_search_kernel<W>, dim3( GRID ), dim3( W == 1 ? 256 : 64 * W ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, d_results )
+  switch( wpj )
+  {
+  case 2: VTMHIP_TZ_LAUNCH( 2, n ); break;
+  case 4: VTMHIP_TZ_LAUNCH( 4, n ); break;
+  case 8: VTMHIP_TZ_LAUNCH( 8, n ); break;
+  case 16: VTMHIP_TZ_LAUNCH( 16, n ); break;
+  default: VTMHIP_TZ_LAUNCH( 1, ( n + 3 ) / 4 ); break;
+  }
+#undef VTMHIP_TZ_LAUNCH
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

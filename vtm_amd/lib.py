@@ -18,13 +18,14 @@ class DistJob(C.Structure):
 
 
 class PicParams(C.Structure):
-    _fields_ = [("picW", C.c_int32), ("picH", C.c_int32), ("ctuSize", C.c_int32), ("bitDepth", C.c_int32)]
+    _fields_ = [("picW", C.c_int32), ("picH", C.c_int32), ("ctuSize", C.c_int32), ("bitDepth", C.c_int32),
+                ("wavesPerJob", C.c_int32)]
 
 
 class TzJob(C.Structure):
     _fields_ = [("orgOff", C.c_int64), ("refOff", C.c_int64), ("orgStride", C.c_int32), ("refStride", C.c_int32),
                 ("puX", C.c_int16), ("puY", C.c_int16), ("width", C.c_int16), ("height", C.c_int16),
-                ("subShift", C.c_int16), ("imvShift", C.c_int16), ("predHor", C.c_int32), ("predVer", C.c_int32),
+                ("subShift", C.c_int16), ("imvShift", C.c_uint8), ("signedSamples", C.c_uint8), ("predHor", C.c_int32), ("predVer", C.c_int32),
                 ("motionLambda", C.c_double), ("mvHor", C.c_int32), ("mvVer", C.c_int32), ("searchRange", C.c_int32),
                 ("extendedSettings", C.c_uint8), ("fastSettings", C.c_uint8), ("firstSearchStop", C.c_uint8),
                 ("hasIntMv2Nx2NPred", C.c_uint8), ("intMv2Nx2NPredHor", C.c_int32), ("intMv2Nx2NPredVer", C.c_int32),

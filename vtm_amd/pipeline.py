@@ -22,6 +22,9 @@ assert TzJob.predHor.offset == 4 * _J_PRED_HOR and TzJob.mvHor.offset == 4 * _J_
 assert C.sizeof(TzJob) % 4 == 0 and C.sizeof(MeResult) == 32
 
 
+WAVES_PER_JOB = {128: 4, 64: 4, 32: 4, 16: 2, 8: 1}   # vtmhip_pic_params.wavesPerJob per PU size (measured)
+
+
 def subshift_mode2(w, h):
     """RdCost::setDistParam subShiftMode 2 (FEN=1 / FastSearch, RdCost.cpp:311-317)."""
     return 1 if (h > 8 and w <= 64) else 0
@@ -70,10 +73,13 @@ class FrameME:
     torch tensors: `org` int16 [H*orgStride], `dpb` int16 (all reference planes, border-extended, back to back)."""
 
     def __init__(self, ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda=8.0,
-                 sizes=(128, 64, 32, 16, 8), row_filter=None):
+                 sizes=(128, 64, 32, 16, 8), row_filter=None, waves_per_job=None):
         """refs: [(ref_off, ref_stride)] sample offsets of each reference plane's (0,0) inside `dpb`."""
         self.ctx, self.torch, self.device = ctx, torch, device
-        self.pic = PicParams(pic_w, pic_h, 128, 10)
+        self.pic_w, self.pic_h = pic_w, pic_h
+        # waves that share one search: big PUs have long SADs and (at the top level, which has no predictor) raster scans
+        self.wpj = dict(WAVES_PER_JOB)
+        self.wpj.update(waves_per_job or {})
         self.levels = []
         self.n_jobs = 0
         self.alg_bytes_per_eval = []
@@ -90,7 +96,7 @@ class FrameME:
             if parent is not None:
                 npar = self.levels[-1]["n"] // nref
                 par = np.concatenate([np.where(parent >= 0, parent + r * npar, -1) for r in range(nref)])
-            lvl = dict(size=s, n=n,
+            lvl = dict(size=s, n=n, pic=PicParams(pic_w, pic_h, 128, 10, self.wpj.get(s, 1)),
                        jobs=torch.from_numpy(jobs.view(np.uint8).reshape(n, TZ_DT.itemsize).copy()).to(device),
                        res=torch.zeros((n, 8), dtype=torch.int32, device=device),
                        parent=None if par is None else torch.from_numpy(par).to(device))
@@ -112,7 +118,7 @@ class FrameME:
                 j32[:, _J_MV_VER] = mvy << 4
                 j32[:, _J_PRED_HOR] = mvx << 2    # MV predictor, quarter-sample units
                 j32[:, _J_PRED_VER] = mvy << 2
-            self.ctx.tz_search_batch(self.pic, org_ptr, dpb_ptr, lvl["jobs"].data_ptr(), lvl["n"], lvl["res"].data_ptr())
+            self.ctx.tz_search_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["jobs"].data_ptr(), lvl["n"], lvl["res"].data_ptr())
 
     def stats(self):
         """(total candidate evaluations, algorithmic bytes = sum over jobs of nEval * 4*W*H >> subShift)."""
