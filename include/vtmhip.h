@@ -182,6 +182,57 @@ int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, c
                                 const vtmhip_tz_job *d_jobs, int n, vtmhip_me_result *d_results );
 
 
+/* One exhaustive search = xSetSearchRange + xPatternSearch (InterSearch.cpp:3496-3608): every integer position of the
+ * clipped window around `center`, first strict minimum in raster order (hook B5, the +-BipredSearchRange refinement). */
+typedef struct
+{
+  int64_t orgOff, refOff;
+  int32_t orgStride, refStride;
+  int16_t puX, puY, width, height;
+  int16_t subShift;
+  uint8_t imvShift;
+  uint8_t signedSamples;        /* 1 for the bi-pred target 2*org - pred */
+  int32_t predHor, predVer;     /* quarter-sample units */
+  double  motionLambda;
+  int32_t centerHor, centerVer; /* bestInitMv, internal 1/16 precision */
+  int32_t searchRange;          /* iSrchRng (BipredSearchRange = 4) */
+  int32_t pad;
+} vtmhip_full_job;
+
+int vtmhip_full_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                  const vtmhip_full_job *d_jobs, int n, vtmhip_me_result *d_results );
+
+/* ---- motion compensation / bi-pred buffer ops ------------------------------------------------------------------------ */
+typedef struct
+{
+  int64_t refOff, dstOff;       /* refOff: block position with MV (0,0) in the reference plane */
+  int32_t refStride, dstStride;
+  int16_t width, height;
+  int32_t mvHor, mvVer;         /* internal 1/16 precision */
+  uint8_t bi;                   /* 0: rounded + clipped samples (uni-pred); 1: 14-bit intermediates for addAvg */
+  uint8_t bitDepth, useAltHpelIf, pad;
+} vtmhip_mc_job;
+
+/* InterPrediction::xPredInterBlk, luma, no BDOF/DMVR/RPR/wrap-around (InterPrediction.cpp:660-815) */
+int vtmhip_mc_luma_batch_dev( vtmhip_ctx *ctx, const int16_t *d_refBase, int16_t *d_dstBase, const vtmhip_mc_job *d_jobs, int n, int maxWidth,
+                              int maxHeight );
+
+typedef struct
+{
+  int64_t aOff, bOff, dstOff;
+  int32_t aStride, bStride, dstStride;
+  int16_t width, height;
+  uint8_t bitDepth, pad0, pad1, pad2;
+  int32_t pad3;
+} vtmhip_pelop_job;
+
+/* PelBuf::removeHighFreq (Buffer.cpp:475-520; bi-pred ME target, InterSearch.cpp:3320-3326): dst = 2*org - pred, unclipped */
+int vtmhip_remove_high_freq_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_predBase, int16_t *d_dstBase,
+                                       const vtmhip_pelop_job *d_jobs, int n );
+/* PelBuf::addAvg (Buffer.cpp:467-507): dst = clip((src0 + src1 + offset) >> shift) on 14-bit intermediates */
+int vtmhip_add_avg_batch_dev( vtmhip_ctx *ctx, const int16_t *d_src0Base, const int16_t *d_src1Base, int16_t *d_dstBase,
+                              const vtmhip_pelop_job *d_jobs, int n );
+
 /* ---- interpolation ----------------------------------------------------------------------------------------------- */
 typedef struct
 {

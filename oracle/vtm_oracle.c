@@ -1135,3 +1135,30 @@ void vo_interp_qpel( const int16_t *pat, int ps, int w, int h, int bitDepth, int
   if( fy == 0 ) vo_if_copy( 0, 1, tmp + 3 * w, w, dst, ds, w, h, bitDepth, 0, cmax, 0 );
   else vo_if_filter( 1, 8, 0, 1, tmp + 3 * w, w, dst, ds, w, h, vo_luma_filter[fy << 2], bitDepth, 0, cmax, 0 );
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Luma motion compensation of one block, InterPrediction::xPredInterBlk (CommonLib/InterPrediction.cpp:660-815)
+ * without BDOF / DMVR / RPR / wrap-around: mv in internal 1/16 precision, bi = 0 -> rounded + clipped samples
+ * (rndRes), bi = 1 -> 14-bit intermediates for addAvg.  `ref` points at the block position with MV (0,0).
+ * (Composition of the pinned filterHor / filterVer; the composition itself is restated from the lines cited.)
+ * ------------------------------------------------------------------------------------------------ */
+void vo_mc_luma( const int16_t *ref, int refStride, int w, int h, int mvHor, int mvVer, int bi, int bitDepth, int useAltHpelIf, int16_t *dst,
+                 int dstStride )
+{
+  const int      xFrac = mvHor & 15, yFrac = mvVer & 15, rndRes = !bi;
+  const int16_t *src   = ref + ( ptrdiff_t )( mvVer >> 4 ) * refStride + ( mvHor >> 4 );
+  if( yFrac == 0 )
+  {
+    vo_if_hor( 0, src, refStride, dst, dstStride, w, h, xFrac, rndRes, bitDepth, 0, 0, useAltHpelIf );
+  }
+  else if( xFrac == 0 )
+  {
+    vo_if_ver( 0, src, refStride, dst, dstStride, w, h, yFrac, 1, rndRes, bitDepth, 0, 0, useAltHpelIf );
+  }
+  else
+  {
+    int16_t tmp[128 * ( 128 + 7 )];
+    vo_if_hor( 0, src - 3 * refStride, refStride, tmp, w, w, h + 7, xFrac, 0, bitDepth, 0, 0, useAltHpelIf );
+    vo_if_ver( 0, tmp + 3 * w, w, dst, dstStride, w, h, yFrac, 0, rndRes, bitDepth, 0, 0, useAltHpelIf );
+  }
+}

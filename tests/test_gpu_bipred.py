@@ -1,0 +1,114 @@
+"""GPU parity: luma motion compensation, removeHighFreq / addAvg and the exhaustive (bi-pred refinement) search vs the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import me_util
+import oracle_lib as ol
+from vtm_amd.lib import FullJob, McJob, MeResult, PelOpJob, PicParams
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_mc_luma_matches_oracle(ctx):
+    L = ol.oracle()
+    scene = me_util.Scene(416, 240, hard=True)
+    rng = np.random.default_rng(51)
+    n = 600
+    jobs = (McJob * n)()
+    dst_stride = 136
+    exp = np.zeros((n * 128, dst_stride), np.int16)
+    meta = []
+    for k in range(n):
+        w = int(rng.choice([4, 8, 16, 32, 64, 128, 8, 16]))
+        h = int(rng.choice([4, 8, 16, 32, 64, 128, 8, 16]))
+        x = int(rng.integers(0, (416 - w) // 4 + 1)) * 4
+        y = int(rng.integers(0, (240 - h) // 4 + 1)) * 4
+        mvh, mvv = int(rng.integers(-40 * 16, 40 * 16)), int(rng.integers(-30 * 16, 30 * 16))
+        if k % 5 == 0:
+            mvh &= ~15
+        if k % 7 == 0:
+            mvv &= ~15
+        if k % 11 == 0:
+            mvh, mvv = (mvh & ~15) | 8, (mvv & ~15) | 8
+        bi, alt = k % 3 == 0, k % 13 == 0
+        j = jobs[k]
+        j.refOff = scene.ref_off + y * scene.ref_stride + x
+        j.dstOff, j.refStride, j.dstStride, j.width, j.height = k * 128 * dst_stride, scene.ref_stride, dst_stride, w, h
+        j.mvHor, j.mvVer, j.bi, j.bitDepth, j.useAltHpelIf = mvh, mvv, bi, 10, alt
+        e = np.zeros((h, dst_stride), np.int16)
+        L.vo_mc_luma(C.c_void_p(scene.ref_buf.ctypes.data + 2 * j.refOff), scene.ref_stride, w, h, mvh, mvv, int(bi), 10, int(alt), ol.P(e), dst_stride)
+        exp[k * 128:k * 128 + h, :w] = e[:, :w]
+        meta.append((w, h, mvh, mvv, bi, alt))
+    d_ref = ctx.to_device(scene.ref_buf)
+    d_dst = ctx.to_device(np.zeros((n * 128, dst_stride), np.int16))
+    d_jobs = ctx.to_device(np.frombuffer(jobs, np.uint8))
+    ctx.mc_luma_batch(d_ref.ptr, d_dst.ptr, d_jobs.ptr, n, 128, 128)
+    got = d_dst.to_host().reshape(n * 128, dst_stride)
+    for k, (w, h, *_rest) in enumerate(meta):
+        assert np.array_equal(got[k * 128:k * 128 + h, :w], exp[k * 128:k * 128 + h, :w]), (k, meta[k])
+
+
+def test_pel_ops_match_reference_golden(ctx):
+    z = np.load(os.path.join(G, "misc.npz"))
+    for k in range(int(z["count"][0])):
+        org, pred, a14, b14 = z["org_%d" % k], z["pred_%d" % k], z["a14_%d" % k], z["b14_%d" % k]
+        h, w = org.shape
+        jobs = (PelOpJob * 1)()
+        j = jobs[0]
+        j.aOff = j.bOff = j.dstOff = 0
+        j.aStride = j.bStride = j.dstStride = w
+        j.width, j.height, j.bitDepth = w, h, 10
+        d_jobs = ctx.to_device(np.frombuffer(jobs, np.uint8))
+        d_a, d_b, d_o = ctx.to_device(org), ctx.to_device(pred), ctx.to_device(np.zeros((h, w), np.int16))
+        ctx.remove_high_freq_batch(d_a.ptr, d_b.ptr, d_o.ptr, d_jobs.ptr, 1)
+        assert np.array_equal(d_o.to_host(), z["rhf_%d" % k])
+        d_a, d_b = ctx.to_device(a14), ctx.to_device(b14)
+        ctx.add_avg_batch(d_a.ptr, d_b.ptr, d_o.ptr, d_jobs.ptr, 1)
+        assert np.array_equal(d_o.to_host(), z["avg_%d" % k])
+
+
+def test_full_search_matches_oracle(ctx):
+    """xSetSearchRange + xPatternSearch around the current vector on the unclipped bi-pred target 2*org - pred."""
+    L = ol.oracle()
+    scene = me_util.Scene(416, 240, hard=True)
+    rng = np.random.default_rng(61)
+    tgt = np.ascontiguousarray((2 * scene.cur.astype(np.int32) - rng.integers(0, 1024, scene.cur.shape)).astype(np.int16))
+    n = 500
+    jobs = (FullJob * n)()
+    exp = []
+    for k in range(n):
+        w = int(rng.choice([4, 8, 16, 32, 64, 128, 8, 16, 12, 24]))
+        h = int(rng.choice([4, 8, 16, 32, 64, 128, 8, 16]))
+        x = int(rng.integers(0, (416 - w) // 4 + 1)) * 4
+        y = int(rng.integers(0, (240 - h) // 4 + 1)) * 4
+        if k % 6 == 0:
+            x, y = (0 if k % 12 == 0 else 416 - w), (0 if k % 4 == 0 else 240 - h)
+        ch, cv = int(rng.integers(-3000, 3000)), int(rng.integers(-2500, 2500))
+        sr = int(rng.choice([4, 4, 4, 2, 7]))
+        jd = dict(w=w, h=h, x=x, y=y, subShift=1 if (h > 8 and w <= 64) else 0, lam=float(rng.uniform(1, 40)),
+                  predHor=int(rng.integers(-64, 64)), predVer=int(rng.integers(-64, 64)))
+        org = np.ascontiguousarray(tgt[y:y + h, x:x + w])
+        c = me_util.oracle_ctx(scene, jd, org)
+        rg = ol.Range()
+        L.vo_set_search_range(C.byref(c), ch, cv, sr, C.byref(rg))
+        r = ol.MeResult()
+        L.vo_full_search(C.byref(c), C.byref(rg), C.byref(r))
+        exp.append((r.mvX, r.mvY, r.cost, r.dist, r.nEval))
+        j = jobs[k]
+        j.orgOff, j.refOff = y * 416 + x, scene.ref_off + y * scene.ref_stride + x
+        j.orgStride, j.refStride, j.puX, j.puY, j.width, j.height = 416, scene.ref_stride, x, y, w, h
+        j.subShift, j.imvShift, j.signedSamples = jd["subShift"], 0, 1
+        j.predHor, j.predVer, j.motionLambda = jd["predHor"], jd["predVer"], jd["lam"]
+        j.centerHor, j.centerVer, j.searchRange = ch, cv, sr
+    d_org, d_ref = ctx.to_device(tgt), ctx.to_device(scene.ref_buf)
+    d_jobs = ctx.to_device(np.frombuffer(jobs, np.uint8))
+    d_res = ctx.alloc(32 * n)
+    ctx.full_search_batch(PicParams(416, 240, 128, 10, 0), d_org.ptr, d_ref.ptr, d_jobs.ptr, n, d_res.ptr)
+    res = (MeResult * n).from_buffer_copy(d_res.to_host(np.uint8).tobytes())
+    got = [(r.mvX, r.mvY, r.cost, r.dist, r.nEval) for r in res]
+    bad = [k for k in range(n) if got[k] != exp[k]]
+    assert not bad, [(got[k], exp[k]) for k in bad[:5]]

@@ -19,6 +19,9 @@ int vtmhip_struct_size( int which )
   case 6: return ( int ) sizeof( vtmhip_frac_result );
   case 7: return ( int ) sizeof( vtmhip_tr_job );
   case 8: return ( int ) sizeof( vtmhip_quant_job );
+  case 9: return ( int ) sizeof( vtmhip_full_job );
+  case 10: return ( int ) sizeof( vtmhip_mc_job );
+  case 11: return ( int ) sizeof( vtmhip_pelop_job );
   default: return -1;
   }
 }

@@ -596,6 +596,58 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel(
   }
 }
 
+
+// ---- exhaustive search (InterSearch::xPatternSearch :3566-3608 after xSetSearchRange :3496-3563): the bi-predictive
+// refinement of xMotionEstimation (:3385-3440, +-BipredSearchRange around the current vector).  One wave per job.
+__global__ __launch_bounds__( 256 ) void full_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+                                                            const vtmhip_full_job *__restrict__ jobs, int numJobs, vtmhip_me_result *__restrict__ results )
+{
+  const int lane = threadIdx.x & 63, wv = uni( ( int ) ( threadIdx.x >> 6 ) );
+  const int jobIdx = blockIdx.x * 4 + wv;
+  if( jobIdx >= numJobs ) return;
+  const vtmhip_full_job *jp = jobs + jobIdx;
+  Coop                   co;
+  co.lane = lane; co.wave = 0; co.wpj = 1; co.leader = lane == 0; co.redCost = nullptr; co.redIdx = nullptr;
+  MeJob j;
+  j.org = orgBase + jp->orgOff; j.ref = refBase + jp->refOff;
+  j.orgStride = jp->orgStride; j.refStride = jp->refStride;
+  j.w = jp->width; j.h = jp->height; j.ss = jp->subShift; j.imvShift = jp->imvShift;
+  j.predHor = jp->predHor; j.predVer = jp->predVer; j.costScale = 2; j.lambda = jp->motionLambda;
+  j.horMax = ( pic.picW + 8 - jp->puX - 1 ) << 4;
+  j.horMin = ( -pic.ctuSize - 8 - jp->puX + 1 ) << 4;
+  j.verMax = ( pic.picH + 8 - jp->puY - 1 ) << 4;
+  j.verMin = ( -pic.ctuSize - 8 - jp->puY + 1 ) << 4;
+  j.seg        = ( j.w & 7 ) == 0 ? 8 : 4;
+  j.segsPerRow = j.w / j.seg;
+  j.items      = j.segsPerRow * ( ( j.h + ( 1 << j.ss ) - 1 ) >> j.ss );
+  j.lpc        = 1;
+  while( j.lpc < 64 && ( j.lpc << 1 ) <= j.items ) j.lpc <<= 1;
+  j.bias       = jp->signedSamples ? 0x80008000u : 0u;
+  j.lpcShift   = floor_log2_u( ( unsigned ) j.lpc );
+  j.sprShift   = ( j.segsPerRow & ( j.segsPerRow - 1 ) ) == 0 ? floor_log2_u( ( unsigned ) j.segsPerRow ) : -1;
+  j.narrow     = j.lambda >= 0.0 && j.lambda * 126.0 < 2147483648.0;
+
+  const Range sr = search_range( j, jp->centerHor, jp->centerVer, jp->searchRange );
+  const int   nx = sr.right >= sr.left ? sr.right - sr.left + 1 : 0, ny = sr.bottom >= sr.top ? sr.bottom - sr.top + 1 : 0;
+  unsigned long long cost;
+  unsigned           idx;
+  eval_candidates<true, 1>( j, nullptr, nx * ny, sr.left, sr.top, nx > 0 ? nx : 1, 1, co, cost, idx );
+  if( lane == 0 )
+  {
+    vtmhip_me_result r;
+    r.mvX = 0; r.mvY = 0; r.nEval = ( unsigned ) ( nx * ny ); r.reserved = 0; r.cost = ~0ull; r.dist = ~0ull;
+    if( nx * ny > 0 )
+    {
+      const int ry = ( int ) idx / nx, rx = ( int ) idx - ry * nx;
+      r.mvX  = sr.left + rx;
+      r.mvY  = sr.top + ry;
+      r.cost = cost;
+      r.dist = cost - mv_cost( j, r.mvX, r.mvY );
+    }
+    results[jobIdx] = r;
+  }
+}
+
 }   // namespace
 
 extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
@@ -621,6 +673,20 @@ extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_par
   default: VTMHIP_TZ_LAUNCH( 1, ( n + 3 ) / 4 ); break;
   }
 #undef VTMHIP_TZ_LAUNCH
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+
+extern "C" int vtmhip_full_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                             const vtmhip_full_job *d_jobs, int n, vtmhip_me_result *d_results )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, pic && n >= 0, "pic / n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_orgBase && d_refBase && d_jobs && d_results, "null pointer" );
+  VTMHIP_REQUIRE( ctx, pic->picW > 0 && pic->picH > 0 && pic->ctuSize > 0, "picture parameters" );
+  hipLaunchKernelGGL( full_search_kernel, dim3( ( n + 3 ) / 4 ), dim3( 256 ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, d_results );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

@@ -8,8 +8,8 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _lib
-from .lib import (DistJob, FracJob, FracResult, IfJob, MeResult, PicParams, QuantJob, TrJob, TzJob,   # noqa: F401
-                  VtmHipError)
+from .lib import (DistJob, FracJob, FracResult, FullJob, IfJob, McJob, MeResult, PelOpJob, PicParams, QuantJob,   # noqa: F401
+                  TrJob, TzJob, VtmHipError)
 
 
 class DevBuf:
@@ -173,6 +173,18 @@ class Context:
 
     def dequant_batch(self, d_q, d_coef, d_jobs, n):
         self._check(self.L.vtmhip_dequant_batch_dev(self.h, d_q, d_coef, d_jobs, n))
+
+    def full_search_batch(self, pic, d_org, d_ref, d_jobs, n, d_results):
+        self._check(self.L.vtmhip_full_search_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, d_results))
+
+    def mc_luma_batch(self, d_ref, d_dst, d_jobs, n, max_w, max_h):
+        self._check(self.L.vtmhip_mc_luma_batch_dev(self.h, d_ref, d_dst, d_jobs, n, max_w, max_h))
+
+    def remove_high_freq_batch(self, d_org, d_pred, d_dst, d_jobs, n):
+        self._check(self.L.vtmhip_remove_high_freq_batch_dev(self.h, d_org, d_pred, d_dst, d_jobs, n))
+
+    def add_avg_batch(self, d_a, d_b, d_dst, d_jobs, n):
+        self._check(self.L.vtmhip_add_avg_batch_dev(self.h, d_a, d_b, d_dst, d_jobs, n))
 
     def tz_search_batch(self, pic, d_org, d_ref, d_jobs, n, d_results):
         self._check(self.L.vtmhip_tz_search_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, d_results))

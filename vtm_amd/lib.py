@@ -69,7 +69,27 @@ class QuantJob(C.Structure):
                 ("isTransformSkip", C.c_uint8), ("pad", C.c_uint8), ("pad2", C.c_int32)]
 
 
-_STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob]   # order of vtmhip_struct_size(which)
+class FullJob(C.Structure):
+    _fields_ = [("orgOff", C.c_int64), ("refOff", C.c_int64), ("orgStride", C.c_int32), ("refStride", C.c_int32),
+                ("puX", C.c_int16), ("puY", C.c_int16), ("width", C.c_int16), ("height", C.c_int16),
+                ("subShift", C.c_int16), ("imvShift", C.c_uint8), ("signedSamples", C.c_uint8), ("predHor", C.c_int32),
+                ("predVer", C.c_int32), ("motionLambda", C.c_double), ("centerHor", C.c_int32), ("centerVer", C.c_int32),
+                ("searchRange", C.c_int32), ("pad", C.c_int32)]
+
+
+class McJob(C.Structure):
+    _fields_ = [("refOff", C.c_int64), ("dstOff", C.c_int64), ("refStride", C.c_int32), ("dstStride", C.c_int32),
+                ("width", C.c_int16), ("height", C.c_int16), ("mvHor", C.c_int32), ("mvVer", C.c_int32), ("bi", C.c_uint8),
+                ("bitDepth", C.c_uint8), ("useAltHpelIf", C.c_uint8), ("pad", C.c_uint8)]
+
+
+class PelOpJob(C.Structure):
+    _fields_ = [("aOff", C.c_int64), ("bOff", C.c_int64), ("dstOff", C.c_int64), ("aStride", C.c_int32),
+                ("bStride", C.c_int32), ("dstStride", C.c_int32), ("width", C.c_int16), ("height", C.c_int16),
+                ("bitDepth", C.c_uint8), ("pad0", C.c_uint8), ("pad1", C.c_uint8), ("pad2", C.c_uint8), ("pad3", C.c_int32)]
+
+
+_STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
 _PROTOS = {
@@ -113,6 +133,11 @@ _PROTOS = {
     "vtmhip_xIT_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "vtmhip_quant_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vtmhip_dequant_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "vtmhip_full_search_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_void_p]),
+    "vtmhip_mc_luma_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "vtmhip_remove_high_freq_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "vtmhip_add_avg_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "vtmhip_dist_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vtmhip_satd8_grid_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),
