@@ -229,6 +229,8 @@ typedef struct
 /* PelBuf::removeHighFreq (Buffer.cpp:475-520; bi-pred ME target, InterSearch.cpp:3320-3326): dst = 2*org - pred, unclipped */
 int vtmhip_remove_high_freq_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_predBase, int16_t *d_dstBase,
                                        const vtmhip_pelop_job *d_jobs, int n );
+/* PelBuf::subtract (residual = org - pred; CodingStructure resi buffer, InterSearch.cpp:7260-7262) */
+int vtmhip_subtract_batch_dev( vtmhip_ctx *ctx, const int16_t *d_aBase, const int16_t *d_bBase, int16_t *d_dstBase, const vtmhip_pelop_job *d_jobs, int n );
 /* PelBuf::addAvg (Buffer.cpp:467-507): dst = clip((src0 + src1 + offset) >> shift) on 14-bit intermediates */
 int vtmhip_add_avg_batch_dev( vtmhip_ctx *ctx, const int16_t *d_src0Base, const int16_t *d_src1Base, int16_t *d_dstBase,
                               const vtmhip_pelop_job *d_jobs, int n );

@@ -133,6 +133,7 @@ __global__ __launch_bounds__( 256 ) void pelop_kernel( const int16_t *__restrict
     const int av = a[( long ) y * j.aStride + x], bv = b[( long ) y * j.bStride + x];
     int       v;
     if( op == 0 ) v = ( int16_t ) ( 2 * av - bv );                        // removeHighFreq
+    else if( op == 2 ) v = ( int16_t ) ( av - bv );                        // subtract (residual = org - pred, Buffer.cpp AreaBuf::subtract)
     else v = min( cmax, max( 0, ( av + bv + offset ) >> shift ) );         // addAvg
     d[( long ) y * j.dstStride + x] = ( int16_t ) v;
   }
@@ -165,6 +166,17 @@ int vtmhip_remove_high_freq_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase
   if( n == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, d_orgBase && d_predBase && d_dstBase && d_jobs, "null pointer" );
   hipLaunchKernelGGL( pelop_kernel, dim3( n ), dim3( 256 ), 0, ctx->stream, d_orgBase, d_predBase, d_dstBase, d_jobs, 0 );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_subtract_batch_dev( vtmhip_ctx *ctx, const int16_t *d_aBase, const int16_t *d_bBase, int16_t *d_dstBase, const vtmhip_pelop_job *d_jobs, int n )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_aBase && d_bBase && d_dstBase && d_jobs, "null pointer" );
+  hipLaunchKernelGGL( pelop_kernel, dim3( n ), dim3( 256 ), 0, ctx->stream, d_aBase, d_bBase, d_dstBase, d_jobs, 2 );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

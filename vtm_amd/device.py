@@ -183,6 +183,9 @@ class Context:
     def remove_high_freq_batch(self, d_org, d_pred, d_dst, d_jobs, n):
         self._check(self.L.vtmhip_remove_high_freq_batch_dev(self.h, d_org, d_pred, d_dst, d_jobs, n))
 
+    def subtract_batch(self, d_a, d_b, d_dst, d_jobs, n):
+        self._check(self.L.vtmhip_subtract_batch_dev(self.h, d_a, d_b, d_dst, d_jobs, n))
+
     def add_avg_batch(self, d_a, d_b, d_dst, d_jobs, n):
         self._check(self.L.vtmhip_add_avg_batch_dev(self.h, d_a, d_b, d_dst, d_jobs, n))
 

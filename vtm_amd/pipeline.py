@@ -131,3 +131,257 @@ class FrameME:
 
     def results_numpy(self):
         return [lvl["res"].cpu().numpy().view(RES_DT).reshape(-1) for lvl in self.levels]
+
+
+# ======================================================================================================================
+# Full hot path of one inter picture: integer ME -> fractional ME -> bi-predictive refinement -> residual coding.
+# ======================================================================================================================
+from .lib import DistJob, FracJob, FracResult, FullJob, McJob, PelOpJob, QuantJob, TrJob   # noqa: E402
+
+FRAC_DT, FRACRES_DT, MC_DT, FULL_DT = np.dtype(FracJob), np.dtype(FracResult), np.dtype(McJob), np.dtype(FullJob)
+PEL_DT, TR_DT, Q_DT, DIST_DT = np.dtype(PelOpJob), np.dtype(TrJob), np.dtype(QuantJob), np.dtype(DistJob)
+
+# (typeHor, typeVer) of mtsIdx 0, 2, 3, 4, 5 (TrQuant::getTrTypes, TrQuant.cpp:695-772): DCT2 = 0, DCT8 = 1, DST7 = 2
+MTS_CANDS = ((0, 0), (2, 2), (1, 2), (2, 1), (1, 1))
+
+
+class _Tab:
+    """A job table in HBM: uint8 [n, itemsize] torch tensor with typed column views for on-device patching."""
+
+    def __init__(self, torch, device, arr):
+        self.n = arr.size
+        self.t = torch.from_numpy(arr.view(np.uint8).reshape(arr.size, arr.dtype.itemsize).copy()).to(device)
+        self.dt = arr.dtype
+        self.torch = torch
+
+    def col(self, field):
+        off = self.dt.fields[field][1]
+        kind = self.dt.fields[field][0]
+        tt = {np.dtype(np.int64): self.torch.int64, np.dtype(np.int32): self.torch.int32, np.dtype(np.int16): self.torch.int16}[kind]
+        assert off % kind.itemsize == 0
+        return self.t.view(tt)[:, off // kind.itemsize]
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+
+class FrameHotPath(FrameME):
+    """All stages for one picture with two reference pictures (list 0 / list 1), level by level:
+
+      tz      InterSearch::xTZSearch per (PU, list)                                   (InterSearch.cpp:3640-3976)
+      frac    xPatternSearchFracDIF per (PU, list): half + quarter refinement, SATD     (:4284-4339)
+      bi      FEN bi-pred iteration (:2531-2680): refine the list with the LARGER uni cost: motion-compensate the other
+              list, org' = 2*org - pred (removeHighFreq), +-4 exhaustive search (xPatternSearch), fractional search on org'
+      resi    final prediction (bi via addAvg when cheaper, else best uni) -> residual -> per TU (<= 64x64):
+              xT (DCT2 + 4 MTS candidates up to 32x32, with sum|coef| for the pre-selection) -> Quant::quant -> dequant -> xIT -> SSE
+    Mode decision between the candidates, CABAC bit estimation and DepQuant stay on the host (out of scope, SURVEY.md 8a);
+    every MTS candidate is taken through the whole chain (the reference prunes with the sum|coef| threshold).
+    """
+
+    def __init__(self, ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda=8.0, qp=32, **kw):
+        assert len(refs) == 2
+        super().__init__(ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda, **kw)
+        self.refs, self.org_stride, self.lam = refs, org_stride, motion_lambda
+        base_qp = qp + 12   # 10-bit: qpBdOffset = 12 (Quant.cpp:65-104)
+        self.qp_per, self.qp_rem = base_qp // 6, base_qp % 6
+        T, dev = torch, device
+        max_samples = 0
+        for lvl in self.levels:
+            s, npu = lvl["size"], lvl["n"] // 2
+            jobs = lvl["jobs"].cpu().numpy().view(TZ_DT).reshape(-1)
+            xs, ys = jobs["puX"][:npu].astype(np.int64), jobs["puY"][:npu].astype(np.int64)
+            blk = np.arange(npu, dtype=np.int64) * s * s
+            lvl["npu"] = npu
+            lvl["ref_base"] = T.tensor([r[0] for r in refs], dtype=T.int64, device=dev)
+            lvl["pos_off"] = [T.from_numpy(ys * r[1] + xs).to(dev) for r in refs]   # block offset inside each reference plane
+            ref_strides = [r[1] for r in refs]
+            assert ref_strides[0] == ref_strides[1]
+            rs = ref_strides[0]
+
+            fj = np.zeros(2 * npu, FRAC_DT)
+            fj["orgOff"], fj["refOff"] = jobs["orgOff"], jobs["refOff"]
+            fj["orgStride"], fj["refStride"], fj["width"], fj["height"] = org_stride, rs, s, s
+            fj["motionLambda"], fj["useHad"], fj["bitDepth"] = motion_lambda, 1, 10
+            lvl["frac"] = _Tab(T, dev, fj)
+            lvl["frac_res"] = T.zeros((2 * npu, 16), dtype=T.uint8, device=dev)
+
+            mj = np.zeros(npu, MC_DT)
+            mj["dstOff"], mj["refStride"], mj["dstStride"], mj["width"], mj["height"], mj["bitDepth"] = blk, rs, s, s, s, 10
+            lvl["mc_other"] = _Tab(T, dev, mj)
+
+            pj = np.zeros(npu, PEL_DT)
+            pj["aOff"], pj["aStride"] = ys * org_stride + xs, org_stride
+            pj["bOff"], pj["bStride"], pj["dstOff"], pj["dstStride"] = blk, s, blk, s
+            pj["width"], pj["height"], pj["bitDepth"] = s, s, 10
+            lvl["rhf"] = _Tab(T, dev, pj)
+            lvl["sub"] = _Tab(T, dev, pj.copy())   # bOff is patched to the chosen prediction
+            aj = np.zeros(npu, PEL_DT)
+            aj["aOff"], aj["bOff"], aj["dstOff"] = blk, blk, blk
+            aj["aStride"], aj["bStride"], aj["dstStride"], aj["width"], aj["height"], aj["bitDepth"] = s, s, s, s, s, 10
+            lvl["avg"] = _Tab(T, dev, aj)
+
+            uj = np.zeros(npu, FULL_DT)
+            uj["orgOff"], uj["orgStride"], uj["refStride"] = blk, s, rs
+            uj["puX"], uj["puY"], uj["width"], uj["height"] = xs, ys, s, s
+            uj["subShift"], uj["signedSamples"], uj["motionLambda"], uj["searchRange"] = subshift_mode2(s, s), 1, motion_lambda, 4
+            lvl["full"] = _Tab(T, dev, uj)
+            lvl["full_res"] = T.zeros((npu, 8), dtype=T.int32, device=dev)
+
+            bj = np.zeros(npu, FRAC_DT)
+            bj["orgOff"], bj["orgStride"], bj["refStride"], bj["width"], bj["height"] = blk, s, rs, s, s
+            bj["motionLambda"], bj["useHad"], bj["bitDepth"] = motion_lambda, 1, 10
+            lvl["frac_bi"] = _Tab(T, dev, bj)
+            lvl["frac_bi_res"] = T.zeros((npu, 16), dtype=T.uint8, device=dev)
+
+            for name, bi in (("mc_uni", 0), ("mc_b0", 1), ("mc_b1", 1)):
+                m2 = mj.copy()
+                m2["bi"] = bi
+                lvl[name] = _Tab(T, dev, m2)
+
+            # transform units: the PU itself up to 64x64, four 64x64 quadrants of a 128x128 PU (MaxTbSize 64)
+            ts = min(s, 64)
+            q = s // ts
+            tu_src, tu_stride = [], s
+            for qy in range(q):
+                for qx in range(q):
+                    tu_src.append(blk + qy * ts * s + qx * ts)
+            tu_src = np.stack(tu_src, 1).reshape(-1)                     # [npu * q*q]
+            ntu = tu_src.size
+            cands = MTS_CANDS if ts <= 32 else MTS_CANDS[:1]
+            nc = len(cands)
+            tj = np.zeros(ntu * nc, TR_DT)
+            coef_off = np.arange(ntu * nc, dtype=np.int64) * ts * ts
+            tj["srcOff"] = np.tile(tu_src, nc)
+            tj["dstOff"], tj["srcStride"], tj["dstStride"], tj["width"], tj["height"], tj["bitDepth"] = coef_off, tu_stride, ts, ts, ts, 10
+            tj["typeHor"] = np.repeat([c[0] for c in cands], ntu)
+            tj["typeVer"] = np.repeat([c[1] for c in cands], ntu)
+            lvl["xt"] = _Tab(T, dev, tj)
+            ij = tj.copy()
+            ij["srcOff"], ij["dstOff"] = coef_off, coef_off              # dequantised coefficients -> reconstructed residual (contiguous per TU)
+            lvl["xit"] = _Tab(T, dev, ij)
+            qj = np.zeros(ntu * nc, Q_DT)
+            qj["srcOff"], qj["dstOff"], qj["width"], qj["height"] = coef_off, coef_off, ts, ts
+            qj["qpPer"], qj["qpRem"], qj["bitDepth"] = self.qp_per, self.qp_rem, 10
+            lvl["quant"] = _Tab(T, dev, qj)
+            dj = np.zeros(ntu * nc, DIST_DT)
+            dj["orgOff"], dj["curOff"], dj["orgStride"], dj["curStride"] = np.tile(tu_src, nc), coef_off, tu_stride, ts
+            dj["width"], dj["height"], dj["kind"] = ts, ts, _lib.DIST_SSE
+            lvl["sse"] = _Tab(T, dev, dj)
+            lvl["ntu"], lvl["nc"], lvl["ts"] = ntu, nc, ts
+            lvl["sum_abs"] = T.zeros(ntu * nc, dtype=T.int32, device=dev)
+            lvl["abs_sum"] = T.zeros(ntu * nc, dtype=T.int32, device=dev)
+            lvl["sse_out"] = T.zeros(ntu * nc, dtype=T.int64, device=dev)
+            lvl["blk_off"] = T.from_numpy(blk).to(dev)
+            max_samples = max(max_samples, npu * s * s * nc)
+        npx = max(l["npu"] * l["size"] ** 2 for l in self.levels)
+        mk = lambda: T.zeros(npx, dtype=T.int16, device=dev)   # noqa: E731
+        self.buf = dict(pred_other=mk(), org_bi=mk(), pred_uni=mk(), p0=mk(), p1=mk(), pred_bi=mk(), resi=mk())
+        # one arena for the two selectable predictions so a job can address either with an offset
+        self.pred_sel = T.zeros(2 * npx, dtype=T.int16, device=dev)
+        self.npx = npx
+        self.coef = T.zeros(max_samples, dtype=T.int32, device=dev)
+        self.qcoef = T.zeros(max_samples, dtype=T.int32, device=dev)
+        self.dqcoef = T.zeros(max_samples, dtype=T.int32, device=dev)
+        self.rec_resi = T.zeros(max_samples, dtype=T.int16, device=dev)
+        self.out = []
+
+    # ---- per-level stages ---------------------------------------------------------------------------------------------
+    def _level(self, i, org_ptr, dpb_ptr):
+        T, ctx, lvl = self.torch, self.ctx, self.levels[i]
+        s, npu = lvl["size"], lvl["npu"]
+        # (1) integer ME (parent predictors patched as in FrameME.run)
+        if lvl["parent"] is not None:
+            j32 = lvl["jobs"].view(T.int32)
+            pres = self.levels[i - 1]["res"]
+            p = lvl["parent"].clamp(min=0)
+            has = lvl["parent"] >= 0
+            mvx = T.where(has, pres[p, 0], T.zeros_like(pres[p, 0]))
+            mvy = T.where(has, pres[p, 1], T.zeros_like(pres[p, 1]))
+            j32[:, _J_MV_HOR], j32[:, _J_MV_VER] = mvx << 4, mvy << 4
+            j32[:, _J_PRED_HOR], j32[:, _J_PRED_VER] = mvx << 2, mvy << 2
+        ctx.tz_search_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["jobs"].data_ptr(), lvl["n"], lvl["res"].data_ptr())
+        tz = lvl["res"]
+        j32 = lvl["jobs"].view(T.int32)
+        pred_h, pred_v = j32[:, _J_PRED_HOR], j32[:, _J_PRED_VER]
+
+        # (2) fractional ME per (PU, list)
+        fr = lvl["frac"]
+        fr.col("intX").copy_(tz[:, 0].to(T.int16))
+        fr.col("intY").copy_(tz[:, 1].to(T.int16))
+        fr.col("predHor").copy_(pred_h)
+        fr.col("predVer").copy_(pred_v)
+        ctx.frac_search_batch(org_ptr, dpb_ptr, fr.ptr, 2 * npu, s, s, lvl["frac_res"].data_ptr())
+        fres16 = lvl["frac_res"].view(T.int16)
+        cost_uni = lvl["frac_res"].view(T.int64)[:, 1]
+        mvq_x = (tz[:, 0] << 2) + (fres16[:, 0].to(T.int32) << 1) + fres16[:, 2].to(T.int32)   # quarter-sample units
+        mvq_y = (tz[:, 1] << 2) + (fres16[:, 1].to(T.int32) << 1) + fres16[:, 3].to(T.int32)
+
+        # (3) bi-pred refinement of the list with the larger uni cost (FASTINTERSEARCH_MODE1: one iteration, :2544-2556)
+        c0, c1 = cost_uni[:npu], cost_uni[npu:]
+        rl = (c0 <= c1).to(T.int64)                    # list to refine
+        ol_ = 1 - rl                                    # the other list supplies the fixed prediction
+        idx = T.arange(npu, device=self.device)
+        sel = lambda a, l: a[l * npu + idx]            # noqa: E731
+        pos = T.stack(lvl["pos_off"])                  # [2, npu]
+        ref_off = lambda l: lvl["ref_base"][l] + pos[l, idx]   # noqa: E731
+        mo = lvl["mc_other"]
+        mo.col("refOff").copy_(ref_off(ol_))
+        mo.col("mvHor").copy_(sel(mvq_x, ol_) << 2)
+        mo.col("mvVer").copy_(sel(mvq_y, ol_) << 2)
+        ctx.mc_luma_batch(dpb_ptr, self.buf["pred_other"].data_ptr(), mo.ptr, npu, s, s)
+        ctx.remove_high_freq_batch(org_ptr, self.buf["pred_other"].data_ptr(), self.buf["org_bi"].data_ptr(), lvl["rhf"].ptr, npu)
+        fu = lvl["full"]
+        fu.col("refOff").copy_(ref_off(rl))
+        fu.col("predHor").copy_(sel(pred_h, rl))
+        fu.col("predVer").copy_(sel(pred_v, rl))
+        fu.col("centerHor").copy_(sel(mvq_x, rl) << 2)
+        fu.col("centerVer").copy_(sel(mvq_y, rl) << 2)
+        ctx.full_search_batch(lvl["pic"], self.buf["org_bi"].data_ptr(), dpb_ptr, fu.ptr, npu, lvl["full_res"].data_ptr())
+        fb = lvl["frac_bi"]
+        fb.col("refOff").copy_(ref_off(rl))
+        fb.col("intX").copy_(lvl["full_res"][:, 0].to(T.int16))
+        fb.col("intY").copy_(lvl["full_res"][:, 1].to(T.int16))
+        fb.col("predHor").copy_(sel(pred_h, rl))
+        fb.col("predVer").copy_(sel(pred_v, rl))
+        ctx.frac_search_batch(self.buf["org_bi"].data_ptr(), dpb_ptr, fb.ptr, npu, s, s, lvl["frac_bi_res"].data_ptr())
+        b16 = lvl["frac_bi_res"].view(T.int16)
+        cost_bi = lvl["frac_bi_res"].view(T.int64)[:, 1] >> 1   # the reference re-weights by 0.5 plus rate terms (:3483); mode decision is host work
+        bi_x = (lvl["full_res"][:, 0] << 2) + (b16[:, 0].to(T.int32) << 1) + b16[:, 2].to(T.int32)
+        bi_y = (lvl["full_res"][:, 1] << 2) + (b16[:, 1].to(T.int32) << 1) + b16[:, 3].to(T.int32)
+
+        # (4) final prediction: best uni list, and the bi-prediction (addAvg of the two 14-bit MC outputs)
+        best_l = (c1 < c0).to(T.int64)
+        mu = lvl["mc_uni"]
+        mu.col("refOff").copy_(ref_off(best_l))
+        mu.col("mvHor").copy_(sel(mvq_x, best_l) << 2)
+        mu.col("mvVer").copy_(sel(mvq_y, best_l) << 2)
+        uni_ptr = self.pred_sel.data_ptr()
+        bi_ptr = uni_ptr + 2 * self.npx
+        ctx.mc_luma_batch(dpb_ptr, uni_ptr, mu.ptr, npu, s, s)
+        mvx_l = [T.where(rl == l, bi_x, mvq_x[l * npu:(l + 1) * npu]) for l in (0, 1)]   # refined list takes the bi vector
+        mvy_l = [T.where(rl == l, bi_y, mvq_y[l * npu:(l + 1) * npu]) for l in (0, 1)]
+        for l, name, bufname in ((0, "mc_b0", "p0"), (1, "mc_b1", "p1")):
+            mb = lvl[name]
+            mb.col("refOff").copy_(lvl["ref_base"][l] + pos[l])
+            mb.col("mvHor").copy_(mvx_l[l] << 2)
+            mb.col("mvVer").copy_(mvy_l[l] << 2)
+            ctx.mc_luma_batch(dpb_ptr, self.buf[bufname].data_ptr(), mb.ptr, npu, s, s)
+        ctx.add_avg_batch(self.buf["p0"].data_ptr(), self.buf["p1"].data_ptr(), bi_ptr, lvl["avg"].ptr, npu)
+        use_bi = cost_bi < T.minimum(c0, c1)
+        sb = lvl["sub"]
+        sb.col("bOff").copy_(lvl["blk_off"] + use_bi.to(T.int64) * self.npx)
+        ctx.subtract_batch(org_ptr, uni_ptr, self.buf["resi"].data_ptr(), sb.ptr, npu)
+
+        # (5) residual coding per TU and transform candidate
+        nt, ts = lvl["ntu"] * lvl["nc"], lvl["ts"]
+        ctx.xT_batch(self.buf["resi"].data_ptr(), self.coef.data_ptr(), lvl["xt"].ptr, nt, ts, ts, lvl["sum_abs"].data_ptr())
+        ctx.quant_batch(self.coef.data_ptr(), self.qcoef.data_ptr(), None, lvl["quant"].ptr, nt, lvl["abs_sum"].data_ptr())
+        ctx.dequant_batch(self.qcoef.data_ptr(), self.dqcoef.data_ptr(), lvl["quant"].ptr, nt)
+        ctx.xIT_batch(self.dqcoef.data_ptr(), self.rec_resi.data_ptr(), lvl["xit"].ptr, nt, ts, ts)
+        ctx.dist_batch(self.buf["resi"].data_ptr(), self.rec_resi.data_ptr(), lvl["sse"].ptr, nt, lvl["sse_out"].data_ptr())
+        lvl["out"] = dict(mvq_x=mvq_x, mvq_y=mvq_y, cost_uni=cost_uni, rl=rl, bi_x=bi_x, bi_y=bi_y, cost_bi=cost_bi, use_bi=use_bi)
+
+    def run(self, org_ptr, dpb_ptr):
+        for i in range(len(self.levels)):
+            self._level(i, org_ptr, dpb_ptr)
