@@ -3,9 +3,13 @@
 
 One STEP = one pass of the implemented hot-path stages over ONE 3840x2160 10-bit inter picture of the
 random-access configuration (synthetic YUV, SURVEY.md 8d generator):
-  stage "tz"   integer TZ search (InterSearch::xTZSearch) for every square PU of the quadtree levels 128..8
-               against 2 reference pictures (L0/L1 at |dPOC| = 2 -> ASR search range 96), SAD with the FEN
-               sub-sampling rule; level L+1 starts from / predicts with the level-L vector of the enclosing block.
+  tz         integer TZ search (InterSearch::xTZSearch) for every square PU of the quadtree levels 128..8 against
+             2 reference pictures (L0/L1 at |dPOC| = 2 -> ASR search range 96), SAD with the FEN sub-sampling rule;
+             level L+1 starts from / predicts with the level-L vector of the enclosing block
+  frac       half + quarter sample refinement (xPatternSearchFracDIF, SATD) per (PU, list)
+  bi_search  FEN bi-pred iteration: MC of the other list, 2*org - pred, +-4 exhaustive search, fractional refinement
+  mc         final prediction (best uni list; bi via two 14-bit MCs + addAvg) and residual
+  resi       per TU (<= 64x64) and transform candidate (DCT2 + 4 MTS up to 32x32): xT, Quant::quant, dequant, xIT, SSE
 Inputs (original picture, border-extended reference planes, job tables) are resident in HBM before the timed region.
 With --gpus N each rank owns the 17 CTU rows of its own picture (N pictures in flight, weak scaling); the reference
 planes are re-broadcast from rank 0 over RCCL inside every step (the reconstructed-picture exchange of SURVEY.md 8e).
@@ -38,49 +42,48 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(fme, cur_np, ref_np, refs, W, H, budget_s):
-    """Times the SAME TZ jobs (with the predictors the device run used) on the host, on a bounded sample.
-    kind "reference": the real VTM 9.3 xTZSearch (x86 SIMD distFunc) from oracle/_ref/libvtmref.so when it travelled
-    with the repo; otherwise kind "port": the plain-C oracle.  Also cross-checks the sampled results against the GPU's."""
+def cpu_baseline(hp, cur_np, dpb_np, refs, W, H, lam, qp, budget_s):
+    """Runs the SAME chain (tests/cpu_chain.py) for a bounded random sample of PUs of every level on one host core and
+    extrapolates to the picture.  kind "reference": the real VTM 9.3 xTZSearch / xPatternSearchFracDIF / xPatternSearch /
+    filterHor / filterVer / fastFwdTrans / fastInvTrans / distFunc (x86 SIMD) from oracle/_ref/libvtmref.so when it
+    travelled with the repo (quant/dequant: oracle port); otherwise kind "port": the plain-C oracle throughout.
+    Every sampled PU is also compared with the GPU result."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_chain
     import oracle_lib as ol
-    from vtm_amd.pipeline import RES_DT, TZ_DT
-    use_ref = ol.have_ref()
-    try:
-        L = ol.ref() if use_ref else ol.oracle()
-    except OSError:
-        use_ref, L = False, ol.oracle()
-    fn = L.ref_tz_search if use_ref else L.vo_tz_search
-    jobs = np.concatenate([lvl["jobs"].cpu().numpy().view(TZ_DT).reshape(-1) for lvl in fme.levels])
-    res = np.concatenate([lvl["res"].cpu().numpy().view(RES_DT).reshape(-1) for lvl in fme.levels])
-    n = jobs.size
+    R = None
+    if ol.have_ref():
+        try:
+            R = ol.ref()
+        except OSError:
+            R = None
+    snaps = cpu_chain.snapshot(hp)
     rng = np.random.default_rng(7)
-    order = rng.permutation(n)
-    done, mism, t0 = 0, 0, time.perf_counter()
-    cur_base, ref_base = cur_np.ctypes.data, ref_np.ctypes.data
-    for k in order:
-        j = jobs[k]
-        c = ol.MeCtx()
-        c.org, c.orgStride = cur_base + 2 * int(j["orgOff"]), int(j["orgStride"])
-        c.ref, c.refStride = ref_base + 2 * int(j["refOff"]), int(j["refStride"])
-        c.w, c.h, c.subShift, c.bitDepth, c.imvShift = int(j["width"]), int(j["height"]), int(j["subShift"]), 10, 0
-        c.mv = ol.MvCost(float(j["motionLambda"]), int(j["predHor"]), int(j["predVer"]), 2)
-        c.picW, c.picH, c.puX, c.puY, c.ctuSize = W, H, int(j["puX"]), int(j["puY"]), 128
-        t = ol.TzJob()
-        t.mvHor, t.mvVer, t.searchRange, t.firstSearchStop = int(j["mvHor"]), int(j["mvVer"]), int(j["searchRange"]), 1
-        r = ol.MeResult()
-        fn(C.byref(c), C.byref(t), C.byref(r))
-        g = res[k]
-        if (r.mvX, r.mvY, r.cost, r.dist) != (int(g["mvX"]), int(g["mvY"]), int(g["cost"]), int(g["dist"])):
-            mism += 1
-        done += 1
-        if done % 64 == 0 and time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": done / dt / n, "unit": "pictures/s", "cores": 1, "kind": "reference" if use_ref else "port",
-            "sample": "%d of %d TZ-search jobs of the same picture (uniform random sample, %.1f s); %d mismatches vs GPU"
-                      % (done, n, dt, mism),
-            "jobs_per_s": done / dt, "mismatches_vs_gpu": mism}
+    total_s, done, mism, detail = 0.0, 0, 0, []
+    per_level = budget_s / len(snaps)
+    for lvl in snaps:
+        s, npu, jobs = lvl["size"], lvl["npu"], lvl["jobs_np"]
+        order = rng.permutation(npu)
+        t_lvl, n_lvl = 0.0, 0
+        for i in order:
+            t0 = time.perf_counter()
+            out = cpu_chain.run_pu(cur_np, dpb_np.ctypes.data, refs[0][1], W, H, s, int(jobs["puX"][i]), int(jobs["puY"][i]),
+                                   (jobs[i], jobs[npu + i]), lam, (qp + 12) // 6, (qp + 12) % 6, ref=R)
+            t_lvl += time.perf_counter() - t0
+            n_lvl += 1
+            try:
+                cpu_chain.compare_with_device(lvl, int(i), out)
+            except AssertionError:
+                mism += 1
+            if t_lvl > per_level and n_lvl >= 4:
+                break
+        total_s += t_lvl / n_lvl * npu
+        done += n_lvl
+        detail.append("%dx%d:%d" % (s, s, n_lvl))
+    return {"value": 1.0 / total_s, "unit": "pictures/s", "cores": 1, "kind": "reference" if R is not None else "port",
+            "sample": "%d PUs (%s) of the same picture through the whole chain, per-level time extrapolated to all %d PUs; %d mismatches vs GPU"
+                      % (done, " ".join(detail), sum(l["npu"] for l in snaps), mism),
+            "seconds_per_picture": total_s, "mismatches_vs_gpu": mism}
 
 
 def main():
@@ -89,7 +92,7 @@ def main():
     import torch.distributed as dist
     from vtm_amd import synth
     from vtm_amd.device import Context
-    from vtm_amd.pipeline import FrameME
+    from vtm_amd.pipeline import FrameHotPath
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -119,18 +122,13 @@ def main():
     ctx = Context(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     sr = 96   # Clip3(MinSearchWindow 96, 384, (384*|dPOC| + 8)/16) for |dPOC| = 2 (EncSlice.cpp:1127)
-    fme = FrameME(ctx, torch, dev, W, H, W, refs, [sr, sr], motion_lambda=8.0)
-
-    tz_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    lam, qp = 8.0, 32
+    fme = FrameHotPath(ctx, torch, dev, W, H, W, refs, [sr, sr], motion_lambda=lam, qp=qp)
 
     def step(k=None):
         if world > 1:
             dist.broadcast(dpb.view(torch.uint8), src=0)   # reconstructed reference pictures -> every GPU (xGMI); bytes: int16 is not a collective dtype
-        if k is not None:
-            tz_ev[k][0].record()
         fme.run(cur.data_ptr(), dpb.data_ptr())
-        if k is not None:
-            tz_ev[k][1].record()
 
     for _ in range(a.warmup):
         step()
@@ -151,8 +149,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    evals, alg_bytes = fme.stats()
-    tz_ms = sum(s.elapsed_time(e) for s, e in tz_ev) / a.steps   # includes the (tiny) predictor gathers between levels
+    # per-stage kernel time: a separate, event-instrumented pass after the timed region (events between the launches of one step)
+    stage_acc = {}
+    for _ in range(3):
+        fme.run(cur.data_ptr(), dpb.data_ptr(), timing=True)
+        torch.cuda.synchronize()
+        for k2, v in fme.stage_ms().items():
+            stage_acc[k2] = stage_acc.get(k2, 0.0) + v / 3
+    evals = fme.stats()[0]
+    alg = fme.alg_bytes()
+    stages = {k2: {"ms": stage_acc[k2], "alg_GBps": alg[k2] / stage_acc[k2] / 1e6} for k2 in stage_acc}
+    dom = max(stage_acc, key=stage_acc.get)
+    dom_kernel = {"tz": "tz_search_kernel", "frac": "frac_search_kernel", "bi_search": "mc_luma + pelop + full_search + frac_search kernels",
+                  "mc": "mc_luma_kernel + pelop_kernel", "resi": "xT + quant + dequant + xIT + dist_batch kernels"}[dom]
 
     # ---- SATD 8x8 grid micro-benchmark (extra key; outside the timed steps) --------------------------------------
     nb = (W // 8) * (H // 8)
@@ -173,24 +182,26 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "hot-path pictures/sec (3840x2160 randomaccess QP32; stages: integer TZ-search SAD; not a full encode) + SATD Gblocks/s",
+            "metric": "hot-path pictures/sec (3840x2160 randomaccess QP32; stages: TZ integer ME, fractional ME, bi-pred refinement, MC, residual xT/quant/xIT/SSE; not a full encode) + SATD Gblocks/s",
             "value": world * a.steps / dt, "unit": "pictures/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16 samples, int32 accumulation (fp64 MV-rate multiply)", "data": "synthetic",
             "config": {"workload": "%dx%d 10-bit, encoder_randomaccess_vtm.cfg operating point (QP32, SR 96 via ASR, FEN subsampling): "
-                                   "TZ search of quadtree PUs 128..8 x 2 refs = %d searches/picture" % (W, H, fme.n_jobs),
-                       "stages": ["tz_search"], "pictures_in_flight": world, "parallelism": "ctu-rows: 1 picture (17 CTU rows) per GPU"},
+                                   "quadtree PUs 128..8 x 2 refs = %d integer searches + %d fractional + %d bi-pred refinements/picture, %d TU x transform-candidate chains"
+                                   % (W, H, fme.n_jobs, fme.n_jobs, fme.n_jobs // 2, sum(l["ntu"] * l["nc"] for l in fme.levels)),
+                       "stages": ["tz_search", "frac_search", "bi_search", "mc", "resi"], "pictures_in_flight": world, "parallelism": "ctu-rows: 1 picture (17 CTU rows) per GPU"},
             "satd_gblocks_per_s": float(satd_g.item()),
             "tz_candidates_per_picture": evals,
-            "roofline": {"bound": "hbm", "kernel": "tz_search_kernel", "achieved": alg_bytes / tz_ms / 1e6, "peak": 8000.0, "unit": "GB/s",
-                         "frac": alg_bytes / tz_ms / 1e6 / 8000.0, "traffic": None,
-                         "note": "algorithmic bytes = sum over searches of nEval * (4*W*H >> subShift); %d launches/step, %.3f ms/step"
-                                 % (len(fme.levels), tz_ms)},
+            "stages": stages,
+            "roofline": {"bound": "hbm", "kernel": dom_kernel, "stage": dom, "achieved": stages[dom]["alg_GBps"], "peak": 8000.0, "unit": "GB/s",
+                         "frac": stages[dom]["alg_GBps"] / 8000.0, "traffic": None,
+                         "note": "dominant stage of the step; algorithmic bytes per DESIGN.md section 5; %.3f ms of %.3f ms/step (sum of stages)"
+                                 % (stage_acc[dom], sum(stage_acc.values()))},
             "satd_roofline": {"bound": "hbm", "kernel": "satd8_grid_kernel", "achieved": nb * 81 * 256 / satd_ms / 1e6, "peak": 8000.0,
                               "unit": "GB/s", "frac": nb * 81 * 256 / satd_ms / 1e6 / 8000.0, "ms": satd_ms},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fme, cur_np, dpb_np, refs, W, H, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(fme, cur_np, dpb_np, refs, W, H, lam, qp, a.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -285,6 +285,36 @@ class FrameHotPath(FrameME):
         self.dqcoef = T.zeros(max_samples, dtype=T.int32, device=dev)
         self.rec_resi = T.zeros(max_samples, dtype=T.int16, device=dev)
         self.out = []
+        self._marks = None
+
+    # ---- stage timing (HIP events on the launch stream; only when run(..., timing=True)) ----------------------------------
+    def _mark(self, name):
+        if self._marks is not None:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._marks.append((name, e))
+
+    def stage_ms(self):
+        """{stage: milliseconds} of the last timed run (call after a synchronize)."""
+        acc = {}
+        for (n0, e0), (n1, e1) in zip(self._marks[:-1], self._marks[1:]):
+            acc[n1] = acc.get(n1, 0.0) + e0.elapsed_time(e1)
+        acc.pop("start", None)
+        return acc
+
+    def alg_bytes(self):
+        """Algorithmic bytes per stage of one picture (SURVEY.md 8d figures; formulas in DESIGN.md section 5)."""
+        b = dict(tz=0, frac=0, bi_search=0, mc=0, resi=0)
+        b["tz"] = self.stats()[1]
+        for lvl in self.levels:
+            s, npu, nt, ts = lvl["size"], lvl["npu"], lvl["ntu"] * lvl["nc"], lvl["ts"]
+            frac_job = 24 * (s + 8) * s + 144 * s * s           # 6 H + 18 V filter passes (4 B / output sample) + 18 SATDs (4 B / sample)
+            b["frac"] += 2 * npu * frac_job
+            ss = subshift_mode2(s, s)
+            b["bi_search"] += npu * (4 * ((2 * s + 7) * s) + 6 * s * s + 81 * (4 * s * s >> ss) + frac_job)   # MC + removeHighFreq + 81 SADs + frac
+            b["mc"] += npu * (3 * 4 * ((2 * s + 7) * s) + 2 * 6 * s * s)                                       # 3 MC + addAvg + subtract
+            b["resi"] += nt * ts * ts * (6 + 8 + 8 + 6 + 4)                                                    # xT, quant, dequant, xIT, SSE
+        return b
 
     # ---- per-level stages ---------------------------------------------------------------------------------------------
     def _level(self, i, org_ptr, dpb_ptr):
@@ -301,6 +331,7 @@ class FrameHotPath(FrameME):
             j32[:, _J_MV_HOR], j32[:, _J_MV_VER] = mvx << 4, mvy << 4
             j32[:, _J_PRED_HOR], j32[:, _J_PRED_VER] = mvx << 2, mvy << 2
         ctx.tz_search_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["jobs"].data_ptr(), lvl["n"], lvl["res"].data_ptr())
+        self._mark("tz")
         tz = lvl["res"]
         j32 = lvl["jobs"].view(T.int32)
         pred_h, pred_v = j32[:, _J_PRED_HOR], j32[:, _J_PRED_VER]
@@ -312,6 +343,7 @@ class FrameHotPath(FrameME):
         fr.col("predHor").copy_(pred_h)
         fr.col("predVer").copy_(pred_v)
         ctx.frac_search_batch(org_ptr, dpb_ptr, fr.ptr, 2 * npu, s, s, lvl["frac_res"].data_ptr())
+        self._mark("frac")
         fres16 = lvl["frac_res"].view(T.int16)
         cost_uni = lvl["frac_res"].view(T.int64)[:, 1]
         mvq_x = (tz[:, 0] << 2) + (fres16[:, 0].to(T.int32) << 1) + fres16[:, 2].to(T.int32)   # quarter-sample units
@@ -345,6 +377,7 @@ class FrameHotPath(FrameME):
         fb.col("predHor").copy_(sel(pred_h, rl))
         fb.col("predVer").copy_(sel(pred_v, rl))
         ctx.frac_search_batch(self.buf["org_bi"].data_ptr(), dpb_ptr, fb.ptr, npu, s, s, lvl["frac_bi_res"].data_ptr())
+        self._mark("bi_search")
         b16 = lvl["frac_bi_res"].view(T.int16)
         cost_bi = lvl["frac_bi_res"].view(T.int64)[:, 1] >> 1   # the reference re-weights by 0.5 plus rate terms (:3483); mode decision is host work
         bi_x = (lvl["full_res"][:, 0] << 2) + (b16[:, 0].to(T.int32) << 1) + b16[:, 2].to(T.int32)
@@ -372,6 +405,7 @@ class FrameHotPath(FrameME):
         sb = lvl["sub"]
         sb.col("bOff").copy_(lvl["blk_off"] + use_bi.to(T.int64) * self.npx)
         ctx.subtract_batch(org_ptr, uni_ptr, self.buf["resi"].data_ptr(), sb.ptr, npu)
+        self._mark("mc")
 
         # (5) residual coding per TU and transform candidate
         nt, ts = lvl["ntu"] * lvl["nc"], lvl["ts"]
@@ -380,8 +414,11 @@ class FrameHotPath(FrameME):
         ctx.dequant_batch(self.qcoef.data_ptr(), self.dqcoef.data_ptr(), lvl["quant"].ptr, nt)
         ctx.xIT_batch(self.dqcoef.data_ptr(), self.rec_resi.data_ptr(), lvl["xit"].ptr, nt, ts, ts)
         ctx.dist_batch(self.buf["resi"].data_ptr(), self.rec_resi.data_ptr(), lvl["sse"].ptr, nt, lvl["sse_out"].data_ptr())
+        self._mark("resi")
         lvl["out"] = dict(mvq_x=mvq_x, mvq_y=mvq_y, cost_uni=cost_uni, rl=rl, bi_x=bi_x, bi_y=bi_y, cost_bi=cost_bi, use_bi=use_bi)
 
-    def run(self, org_ptr, dpb_ptr):
+    def run(self, org_ptr, dpb_ptr, timing=False):
+        self._marks = [] if timing else None
+        self._mark("start")
         for i in range(len(self.levels)):
             self._level(i, org_ptr, dpb_ptr)
