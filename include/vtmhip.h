@@ -273,9 +273,12 @@ typedef struct
   uint64_t cost;           /* ruiCost */
 } vtmhip_frac_result;
 
-/* maxWidth/maxHeight: upper bounds of the job sizes in this batch (they size the per-workgroup LDS window) */
+/* maxWidth/maxHeight: upper bounds of the job sizes in this batch (they size the per-workgroup LDS window).
+ * uniformSquare != 0: the caller guarantees that EVERY job is exactly maxWidth x maxHeight with maxWidth == maxHeight in
+ * {8,16,32,64,128} and that all jobs share imvShift; the library then uses the tiled kernel (one lane per
+ * (PU, candidate, 8x8 tile)); 0 = any mix of sizes (one wave per PU). */
 int vtmhip_frac_search_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_frac_job *d_jobs, int n,
-                                  int maxWidth, int maxHeight, vtmhip_frac_result *d_results );
+                                  int maxWidth, int maxHeight, int uniformSquare, vtmhip_frac_result *d_results );
 
 /* ---- transform / quantisation: one TU per job --------------------------------------------------------------------- */
 typedef struct

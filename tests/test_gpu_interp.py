@@ -155,3 +155,42 @@ def test_frac_search_half_pel_only_alt_filter(ctx):
     res = (FracResult * len(jobs)).from_buffer_copy(d_res.to_host(np.uint8).tobytes())
     got = [(r.halfX, r.halfY, r.cost) for r in res]
     assert got == exp
+
+
+@pytest.mark.parametrize("size", [8, 16, 32, 64, 128])
+@pytest.mark.parametrize("use_had,signed", [(1, 0), (0, 0), (1, 1)])
+def test_frac_search_tiled_square_path(ctx, size, use_had, signed):
+    """uniformSquare fast path (one lane per (PU, candidate, 8x8 tile)) vs the oracle, incl. the signed bi-pred target."""
+    L = ol.oracle()
+    scene = me_util.Scene(416, 240, hard=True)
+    rng = np.random.default_rng(100 + size)
+    cur = scene.cur
+    if signed:
+        cur = np.ascontiguousarray((2 * cur.astype(np.int32) - rng.integers(0, 1024, cur.shape)).astype(np.int16))
+    n = {8: 300, 16: 150, 32: 60, 64: 24, 128: 6}[size]
+    arr = (FracJob * n)()
+    exp = []
+    for k in range(n):
+        x = int(rng.integers(0, (416 - size) // 4 + 1)) * 4
+        y = int(rng.integers(0, (240 - size) // 4 + 1)) * 4
+        j = dict(w=size, h=size, x=x, y=y, subShift=0, lam=float(rng.uniform(1, 40)), predHor=int(rng.integers(-64, 64)),
+                 predVer=int(rng.integers(-64, 64)))
+        ix, iy = int(rng.integers(-12, 12)), int(rng.integers(-12, 12))
+        org = np.ascontiguousarray(cur[y:y + size, x:x + size])
+        c = me_util.oracle_ctx(scene, j, org)
+        fr = ol.FracResult()
+        L.vo_frac_search(C.byref(c), ix, iy, use_had, 0, C.byref(fr))
+        exp.append((fr.halfX, fr.halfY, fr.qterX, fr.qterY, fr.cost))
+        t = arr[k]
+        t.orgOff, t.refOff = y * 416 + x, scene.ref_off + y * scene.ref_stride + x
+        t.orgStride, t.refStride, t.width, t.height = 416, scene.ref_stride, size, size
+        t.intX, t.intY, t.predHor, t.predVer, t.motionLambda = ix, iy, j["predHor"], j["predVer"], j["lam"]
+        t.useHad, t.useAltHpelIf, t.imvShift, t.bitDepth = use_had, 0, 0, 10
+    d_cur, d_ref = ctx.to_device(cur), ctx.to_device(scene.ref_buf)
+    d_jobs = ctx.to_device(np.frombuffer(arr, np.uint8))
+    d_res = ctx.alloc(16 * n)
+    ctx.frac_search_batch(d_cur.ptr, d_ref.ptr, d_jobs.ptr, n, size, size, d_res.ptr, uniform_square=True)
+    res = (FracResult * n).from_buffer_copy(d_res.to_host(np.uint8).tobytes())
+    got = [(r.halfX, r.halfY, r.qterX, r.qterY, r.cost) for r in res]
+    bad = [k for k in range(n) if got[k] != exp[k]]
+    assert not bad, [(got[k], exp[k]) for k in bad[:5]]

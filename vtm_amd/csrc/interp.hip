@@ -25,6 +25,8 @@ __constant__ int16_t c_lumaFilter[16][8] = {
   { 0, 1, -5, 17, 58, -10, 4, -1 },  { 0, 1, -4, 13, 60, -8, 3, -1 },   { 0, 1, -3, 8, 62, -5, 2, -1 },    { 0, 1, -2, 4, 63, -3, 1, 0 } };
 __constant__ int16_t c_lumaAltHpel[8] = { 0, 3, 9, 20, 20, 9, 3, 0 };
 
+struct __attribute__( ( packed, aligned( 2 ) ) ) Pel8u { unsigned v[4]; };   // 8 samples from a 2-byte aligned address
+
 struct IfParams { int shift, offset, clip, cmin, cmax; };
 
 // shift / offset rules of InterpolationFilter::filter (:577-614)
@@ -327,6 +329,189 @@ __global__ __launch_bounds__( 64 ) void frac_search_kernel( const int16_t *__res
   if( lane == 0 ) results[blockIdx.x] = res;
 }
 
+
+// =====================================================================================================================
+// Tiled fractional search for square PUs (S = 8, 16, 32, 64, 128): the fast path.
+//
+// The generic kernel above gives a whole wave to one PU and its SATD phase keeps one lane per 8x8 tile busy -- one lane
+// of 64 for an 8x8 PU.  Here a workgroup takes JPW PUs and every lane owns one (PU, candidate, 8x8 tile) ITEM:
+//   phase H   3 horizontal passes per PU (one per horizontal quarter position of the round) -> LDS planes [(S+8)][S]
+//   phase V   per item: 15 plane rows (16-byte LDS reads) -> 8x8 vertical FIR in registers (64 accumulators) ->
+//             round/clip -> difference to the original tile -> 8x8 Hadamard in registers -> LDS atomic add into cost[PU][cand]
+//   select    one lane per PU: + MV rate, first strict minimum in the reference's table order (xPatternRefinement :707-761)
+// The fractional search has no data-dependent control flow (2 rounds x 9 candidates), so PUs batch perfectly.
+// =====================================================================================================================
+template<int S>
+struct FracSq
+{
+  static constexpr int TILES = ( S / 8 ) * ( S / 8 );
+  static constexpr int ITEMS = 9 * TILES;                       // per PU per round
+  static constexpr int BLOCK = S == 32 ? 192 : 256;
+  static constexpr int JPW   = ITEMS >= BLOCK ? 1 : BLOCK / ITEMS;   // S = 8: 28, 16: 7, 32: 1 (144 of 192 lanes), 64 / 128: 1
+  static constexpr int WLD   = S + 8;                           // window stride
+  static constexpr int WIN   = ( S + 8 ) * WLD;                 // window samples per PU
+  static constexpr int PLANE = ( S + 8 ) * S;                   // one H-pass plane
+  static constexpr int PERJOB = ( ( WIN + 3 * PLANE ) + 7 ) & ~7;   // samples, keeps every plane 16-byte aligned
+  static constexpr size_t LDS = ( size_t ) JPW * PERJOB * sizeof( int16_t ) + ( size_t ) JPW * 16 * sizeof( unsigned );
+};
+
+template<int S>
+__global__ __launch_bounds__( FracSq<S>::BLOCK ) void frac_search_sq_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+                                                                            const vtmhip_frac_job *__restrict__ jobs, int numJobs,
+                                                                            vtmhip_frac_result *__restrict__ results )
+{
+  using C = FracSq<S>;
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];
+  unsigned *sCost = reinterpret_cast<unsigned *>( lds + C::JPW * C::PERJOB );   // [JPW][16]: 9 candidate distortions (+ scratch)
+  __shared__ int sCentre[C::JPW][2];                                            // half-sample winner per PU (round 2 centre)
+  const int tid = threadIdx.x;
+  const int job0 = blockIdx.x * C::JPW;
+  const int nj = min( C::JPW, numJobs - job0 );
+
+  // ---- windows: rows/cols -4 .. S+3 around the integer vector ------------------------------------------------------------
+  for( int i = tid; i < nj * C::WIN; i += C::BLOCK )
+  {
+    const int               jl = i / C::WIN, r = ( i - jl * C::WIN ) / C::WLD, c = i - jl * C::WIN - r * C::WLD;
+    const vtmhip_frac_job &j  = jobs[job0 + jl];
+    const int16_t         *ref = refBase + j.refOff + ( long ) j.intY * j.refStride + j.intX;
+    lds[jl * C::PERJOB + r * C::WLD + c] = ref[( long ) ( r - 4 ) * j.refStride + ( c - 4 )];
+  }
+  for( int i = tid; i < C::JPW * 2; i += C::BLOCK ) sCentre[i >> 1][i & 1] = 0;
+  __syncthreads();
+
+  for( int round = 0; round < 2; round++ )
+  {
+    const int step = round == 0 ? 2 : 1;
+    if( round == 1 && jobs[job0].imvShift != 0 ) break;   // IMV_HPEL: half-sample refinement only (uniform per batch, checked on the host side)
+    // ---- phase H: plane p (dx = p - 1) of PU jl: (first, !last) 8-tap FIR of window rows 0..S+7 ----------------------------
+    for( int i = tid; i < nj * 3 * C::PLANE; i += C::BLOCK )
+    {
+      const int jl = i / ( 3 * C::PLANE ), rem = i - jl * 3 * C::PLANE;
+      const int p = rem / C::PLANE, o = rem - p * C::PLANE, r = o / S, x = o - r * S;
+      const vtmhip_frac_job &j = jobs[job0 + jl];
+      const int qx = sCentre[jl][0] + ( p - 1 ) * step, ix = qx >> 2, fx = qx & 3;
+      const int16_t *cH = ( round == 0 && j.useAltHpelIf && fx == 2 ) ? c_lumaAltHpel : c_lumaFilter[fx << 2];
+      const IfParams pH = if_params( 1, 0, j.bitDepth, 0, ( 1 << j.bitDepth ) - 1, 0 );
+      const int16_t *w = lds + jl * C::PERJOB + r * C::WLD + ( x + ix + 1 );
+      int sum = 0;
+#pragma unroll
+      for( int k = 0; k < 8; k++ ) sum += ( int ) w[k] * ( int ) cH[k];
+      lds[jl * C::PERJOB + C::WIN + p * C::PLANE + o] = if_finish( sum, pH );
+    }
+    for( int i = tid; i < C::JPW * 16; i += C::BLOCK ) sCost[i] = 0;
+    __syncthreads();
+
+    // ---- phase V: one (PU, candidate, tile) item per lane ------------------------------------------------------------------
+    for( int it = tid; it < nj * C::ITEMS; it += C::BLOCK )
+    {
+      const int jl = it / C::ITEMS, rem = it - jl * C::ITEMS, cand = rem / C::TILES, tile = rem - cand * C::TILES;
+      const vtmhip_frac_job &j = jobs[job0 + jl];
+      const int8_t( *tab )[2] = round == 0 ? c_refineH : c_refineQ;
+      const int dx = tab[cand][0], dy = tab[cand][1];
+      const int qy = sCentre[jl][1] + dy * step, iy = qy >> 2, fy = qy & 3;
+      const int16_t *cV = ( round == 0 && j.useAltHpelIf && fy == 2 ) ? c_lumaAltHpel : c_lumaFilter[fy << 2];
+      int cv[8];
+#pragma unroll
+      for( int k = 0; k < 8; k++ ) cv[k] = cV[k];
+      const int      ty = tile / ( S / 8 ), tx = tile - ty * ( S / 8 );
+      const int16_t *pl = lds + jl * C::PERJOB + C::WIN + ( dx + 1 ) * C::PLANE + ( ty * 8 + iy + 1 ) * S + tx * 8;
+      int acc[64];
+#pragma unroll
+      for( int i = 0; i < 64; i++ ) acc[i] = 0;
+#pragma unroll
+      for( int r = 0; r < 15; r++ )
+      {
+        const int4 raw = *reinterpret_cast<const int4 *>( pl + r * S );   // 8 samples of plane row r
+        int        v[8];
+        v[0] = ( int ) ( short ) raw.x; v[1] = raw.x >> 16; v[2] = ( int ) ( short ) raw.y; v[3] = raw.y >> 16;
+        v[4] = ( int ) ( short ) raw.z; v[5] = raw.z >> 16; v[6] = ( int ) ( short ) raw.w; v[7] = raw.w >> 16;
+#pragma unroll
+        for( int y = 0; y < 8; y++ )
+        {
+          if( r - y >= 0 && r - y < 8 )
+          {
+#pragma unroll
+            for( int x = 0; x < 8; x++ ) acc[y * 8 + x] += v[x] * cv[r - y];
+          }
+        }
+      }
+      const IfParams pV  = if_params( 0, 1, j.bitDepth, 0, ( 1 << j.bitDepth ) - 1, 0 );
+      const int16_t *org = orgBase + j.orgOff + ( long ) ( ty * 8 ) * j.orgStride + tx * 8;
+      unsigned       d;
+      if( j.useHad )
+      {
+#pragma unroll
+        for( int y = 0; y < 8; y++ )
+        {
+          const Pel8u o = *reinterpret_cast<const Pel8u *>( org + ( long ) y * j.orgStride );
+#pragma unroll
+          for( int x = 0; x < 8; x++ )
+          {
+            const int ov   = ( x & 1 ) ? ( int ) o.v[x >> 1] >> 16 : ( int ) ( short ) o.v[x >> 1];
+            acc[y * 8 + x] = ov - ( int ) if_finish( acc[y * 8 + x], pV );
+          }
+        }
+#pragma unroll
+        for( int y = 0; y < 8; y++ ) wht1d<8, 1>( acc + y * 8 );
+#pragma unroll
+        for( int x = 0; x < 8; x++ ) wht1d<8, 8>( acc + x );
+        int t = 0;
+#pragma unroll
+        for( int i = 0; i < 64; i++ ) t += abs( acc[i] );
+        const int dc = abs( acc[0] );
+        d            = ( unsigned ) ( ( t - dc + ( dc >> 2 ) + 2 ) >> 2 );
+      }
+      else
+      {
+        unsigned t = 0;
+#pragma unroll
+        for( int y = 0; y < 8; y++ )
+        {
+          const Pel8u o = *reinterpret_cast<const Pel8u *>( org + ( long ) y * j.orgStride );
+#pragma unroll
+          for( int x = 0; x < 8; x++ )
+          {
+            const int ov = ( x & 1 ) ? ( int ) o.v[x >> 1] >> 16 : ( int ) ( short ) o.v[x >> 1];
+            t += ( unsigned ) abs( ov - ( int ) if_finish( acc[y * 8 + x], pV ) );
+          }
+        }
+        d = t;
+      }
+      atomicAdd( &sCost[jl * 16 + cand], d );
+    }
+    __syncthreads();
+
+    // ---- select: first strict minimum of distortion + MV rate in table order ------------------------------------------------
+    if( tid < nj )
+    {
+      const vtmhip_frac_job &j = jobs[job0 + tid];
+      const int8_t( *tab )[2] = round == 0 ? c_refineH : c_refineQ;
+      const int costScale = round == 0 ? 1 : 0;
+      const int bx = round == 0 ? ( j.intX << 1 ) : ( ( ( j.intX << 1 ) + ( sCentre[tid][0] >> 1 ) ) << 1 );
+      const int by = round == 0 ? ( j.intY << 1 ) : ( ( ( j.intY << 1 ) + ( sCentre[tid][1] >> 1 ) ) << 1 );
+      unsigned long long best = ~0ull;
+      int                bi   = 0;
+      for( int i = 0; i < 9; i++ )
+      {
+        const unsigned long long c = ( unsigned long long ) sCost[tid * 16 + i] + mv_cost( j.motionLambda, j.predHor, j.predVer, costScale, bx + tab[i][0], by + tab[i][1] );
+        if( c < best ) { best = c; bi = i; }
+      }
+      vtmhip_frac_result *res = results + job0 + tid;
+      if( round == 0 )
+      {
+        res->halfX = tab[bi][0]; res->halfY = tab[bi][1]; res->qterX = 0; res->qterY = 0; res->cost = best;
+        sCentre[tid][0] = tab[bi][0] * 2;   // quarter-sample units
+        sCentre[tid][1] = tab[bi][1] * 2;
+      }
+      else
+      {
+        res->qterX = tab[bi][0]; res->qterY = tab[bi][1]; res->cost = best;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 size_t frac_lds_bytes( int maxW, int maxH ) { return ( size_t ) ( ( maxH + 8 ) * ( maxW + 8 ) + ( maxH + 8 ) * maxW + maxH * maxW ) * sizeof( int16_t ); }
 
 int if_single( vtmhip_ctx *ctx, int vertical, int taps, int isFirst, int isLast, const int16_t *src, int srcStride, int16_t *dst, int dstStride, int w,
@@ -366,6 +551,18 @@ int if_single( vtmhip_ctx *ctx, int vertical, int taps, int isFirst, int isLast,
   return VTMHIP_OK;
 }
 
+template<int S>
+int launch_frac_sq( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_frac_job *d_jobs, int n, vtmhip_frac_result *d_results )
+{
+  using C = FracSq<S>;
+  if( C::LDS > 64 * 1024 )
+    VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( frac_search_sq_kernel<S> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) C::LDS ) );
+  hipLaunchKernelGGL( frac_search_sq_kernel<S>, dim3( ( n + C::JPW - 1 ) / C::JPW ), dim3( C::BLOCK ), C::LDS, ctx->stream, d_orgBase, d_refBase, d_jobs, n,
+                      d_results );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
 }   // namespace
 
 extern "C"
@@ -401,13 +598,27 @@ int vtmhip_if_batch_dev( vtmhip_ctx *ctx, const int16_t *d_srcBase, int16_t *d_d
 }
 
 int vtmhip_frac_search_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_frac_job *d_jobs, int n,
-                                  int maxWidth, int maxHeight, vtmhip_frac_result *d_results )
+                                  int maxWidth, int maxHeight, int uniformSquare, vtmhip_frac_result *d_results )
 {
   VTMHIP_CHECK_CTX( ctx );
   VTMHIP_REQUIRE( ctx, n >= 0, "n" );
   if( n == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, d_orgBase && d_refBase && d_jobs && d_results, "null pointer" );
   VTMHIP_REQUIRE( ctx, maxWidth >= 4 && maxWidth <= 128 && maxHeight >= 4 && maxHeight <= 128, "maxWidth / maxHeight" );
+  if( uniformSquare )
+  {
+    // caller's promise: every job is exactly maxWidth x maxHeight, square, and all jobs share imvShift -> tiled fast path
+    VTMHIP_REQUIRE( ctx, maxWidth == maxHeight, "uniformSquare needs maxWidth == maxHeight" );
+    switch( maxWidth )
+    {
+    case 8: return launch_frac_sq<8>( ctx, d_orgBase, d_refBase, d_jobs, n, d_results );
+    case 16: return launch_frac_sq<16>( ctx, d_orgBase, d_refBase, d_jobs, n, d_results );
+    case 32: return launch_frac_sq<32>( ctx, d_orgBase, d_refBase, d_jobs, n, d_results );
+    case 64: return launch_frac_sq<64>( ctx, d_orgBase, d_refBase, d_jobs, n, d_results );
+    case 128: return launch_frac_sq<128>( ctx, d_orgBase, d_refBase, d_jobs, n, d_results );
+    default: break;   // other sizes: generic kernel below
+    }
+  }
   const size_t lds = frac_lds_bytes( maxWidth, maxHeight );
   if( lds > 64 * 1024 )
     VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( frac_search_kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );

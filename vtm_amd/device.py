@@ -159,8 +159,8 @@ class Context:
     def if_batch(self, d_src, d_dst, d_jobs, n):
         self._check(self.L.vtmhip_if_batch_dev(self.h, d_src, d_dst, d_jobs, n))
 
-    def frac_search_batch(self, d_org, d_ref, d_jobs, n, max_w, max_h, d_results):
-        self._check(self.L.vtmhip_frac_search_batch_dev(self.h, d_org, d_ref, d_jobs, n, max_w, max_h, d_results))
+    def frac_search_batch(self, d_org, d_ref, d_jobs, n, max_w, max_h, d_results, uniform_square=False):
+        self._check(self.L.vtmhip_frac_search_batch_dev(self.h, d_org, d_ref, d_jobs, n, max_w, max_h, int(uniform_square), d_results))
 
     def xT_batch(self, d_resi, d_coef, d_jobs, n, max_w, max_h, d_sum_abs=None):
         self._check(self.L.vtmhip_xT_batch_dev(self.h, d_resi, d_coef, d_jobs, n, max_w, max_h, d_sum_abs))

@@ -123,7 +123,7 @@ _PROTOS = {
                                     C.c_int, C.c_int, C.c_int, C.c_int]),
     "vtmhip_if_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "vtmhip_frac_search_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                               C.c_void_p]),
+                                               C.c_int, C.c_void_p]),
     "vtmhip_fastFwdTrans": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vtmhip_fastInvTrans": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int32, C.c_int32]),
@@ -155,6 +155,23 @@ class VtmHipError(RuntimeError):
         super().__init__("libvtmhip status %d%s" % (status, (": " + detail) if detail else ""))
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm ships its own libamdhip64.so.  Two HIP runtimes in one process cannot both own the GPU (whichever
+    initialises second sees no device), and streams / device pointers are only interchangeable inside ONE runtime.
+    So when a PyTorch installation is present we map ITS runtime first (without importing torch); libvtmhip.so then
+    binds to that already-loaded soname, whatever the later import order is."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass   # no torch: the system runtime libvtmhip.so was linked against is used
+
+
 def load():
     """Loads libvtmhip.so, declares prototypes and checks the struct layouts against the library's sizeof()."""
     global _lib
@@ -163,6 +180,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libvtmhip.so is missing (%s): build it with `python -m vtm_amd.build` -- the HIP "
                           "extension is the product, there is no CPU fallback" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)

@@ -342,7 +342,7 @@ class FrameHotPath(FrameME):
         fr.col("intY").copy_(tz[:, 1].to(T.int16))
         fr.col("predHor").copy_(pred_h)
         fr.col("predVer").copy_(pred_v)
-        ctx.frac_search_batch(org_ptr, dpb_ptr, fr.ptr, 2 * npu, s, s, lvl["frac_res"].data_ptr())
+        ctx.frac_search_batch(org_ptr, dpb_ptr, fr.ptr, 2 * npu, s, s, lvl["frac_res"].data_ptr(), uniform_square=True)
         self._mark("frac")
         fres16 = lvl["frac_res"].view(T.int16)
         cost_uni = lvl["frac_res"].view(T.int64)[:, 1]
@@ -376,7 +376,7 @@ class FrameHotPath(FrameME):
         fb.col("intY").copy_(lvl["full_res"][:, 1].to(T.int16))
         fb.col("predHor").copy_(sel(pred_h, rl))
         fb.col("predVer").copy_(sel(pred_v, rl))
-        ctx.frac_search_batch(self.buf["org_bi"].data_ptr(), dpb_ptr, fb.ptr, npu, s, s, lvl["frac_bi_res"].data_ptr())
+        ctx.frac_search_batch(self.buf["org_bi"].data_ptr(), dpb_ptr, fb.ptr, npu, s, s, lvl["frac_bi_res"].data_ptr(), uniform_square=True)
         self._mark("bi_search")
         b16 = lvl["frac_bi_res"].view(T.int16)
         cost_bi = lvl["frac_bi_res"].view(T.int64)[:, 1] >> 1   # the reference re-weights by 0.5 plus rate terms (:3483); mode decision is host work
