@@ -313,6 +313,31 @@ int vtmhip_quant_batch_dev( vtmhip_ctx *ctx, const int32_t *d_coefBase, int32_t 
 /* Quant::dequant, flat scaling list (Quant.cpp:357-482) */
 int vtmhip_dequant_batch_dev( vtmhip_ctx *ctx, const int32_t *d_qBase, int32_t *d_coefBase, const vtmhip_quant_job *d_jobs, int n );
 
+/* ---- fused residual-coding chain: hooks B8 + B9 in one launch -------------------------------------------------------------
+ * per TU and transform candidate: TrQuant::xT -> Quant::quant -> Quant::dequant -> TrQuant::xIT -> SSE(residual, reconstruction)
+ * (xEstimateInterResidualQT, InterSearch.cpp:6637-6733, minus the CABAC bit estimate between quant and dequant).  2-D TUs only. */
+typedef struct
+{
+  int64_t resiOff;          /* residual samples (int16) */
+  int64_t outOff;           /* W x H contiguous block inside d_levelsBase / d_recBase (when those are given) */
+  int32_t resiStride;
+  int16_t width, height;    /* 2..64 */
+  int16_t qpPer, qpRem;
+  uint8_t typeHor, typeVer, bitDepth, isIRAP;
+  int32_t pad;
+} vtmhip_tu_job;
+
+typedef struct
+{
+  uint64_t sse;             /* getDistPart( DF_SSE ) of residual vs reconstructed residual */
+  int32_t  sumAbs;          /* sum |coef| after xT (MTS pre-selection cost, TrQuant.cpp:986-990) */
+  int32_t  absSum;          /* uiAbsSum of Quant::quant (cbf = absSum > 0) */
+} vtmhip_tu_result;
+
+/* d_levelsBase (quantised levels for the host's CABAC estimate) and d_recBase (reconstructed residual) may be NULL */
+int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int maxWidth, int maxHeight,
+                               int32_t *d_levelsBase, int16_t *d_recBase, vtmhip_tu_result *d_results );
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,7 +71,8 @@ def test_pel_ops_match_reference_golden(ctx):
         assert np.array_equal(d_o.to_host(), z["avg_%d" % k])
 
 
-def test_full_search_matches_oracle(ctx):
+@pytest.mark.parametrize("wpj", [0, 2, 4, 8, 16])
+def test_full_search_matches_oracle(ctx, wpj):
     """xSetSearchRange + xPatternSearch around the current vector on the unclipped bi-pred target 2*org - pred."""
     L = ol.oracle()
     scene = me_util.Scene(416, 240, hard=True)
@@ -107,7 +108,7 @@ def test_full_search_matches_oracle(ctx):
     d_org, d_ref = ctx.to_device(tgt), ctx.to_device(scene.ref_buf)
     d_jobs = ctx.to_device(np.frombuffer(jobs, np.uint8))
     d_res = ctx.alloc(32 * n)
-    ctx.full_search_batch(PicParams(416, 240, 128, 10, 0), d_org.ptr, d_ref.ptr, d_jobs.ptr, n, d_res.ptr)
+    ctx.full_search_batch(PicParams(416, 240, 128, 10, wpj), d_org.ptr, d_ref.ptr, d_jobs.ptr, n, d_res.ptr)
     res = (MeResult * n).from_buffer_copy(d_res.to_host(np.uint8).tobytes())
     got = [(r.mvX, r.mvY, r.cost, r.dist, r.nEval) for r in res]
     bad = [k for k in range(n) if got[k] != exp[k]]

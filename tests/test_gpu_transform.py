@@ -176,3 +176,61 @@ def test_quant_dequant_batch_matches_oracle(ctx):
         assert np.array_equal(du[k, :w * h], exp_du[k, :w * h]), ("deltaU", cases[k])
         assert np.array_equal(dq[k, :w * h], exp_dq[k, :w * h]), ("dequant", cases[k])
         assert sm[k] == exp_sum[k], ("absSum", cases[k])
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_tu_chain_matches_oracle(ctx, big):
+    """Fused xT -> quant -> dequant -> xIT -> SSE (one launch) vs the oracle's separate steps; all 2-D sizes and type pairs."""
+    from vtm_amd.lib import TuJob, TuResult
+    L = ol.oracle()
+    rng = np.random.default_rng(77 + big)
+    tus = [t for t in _tu_list() if t[0] > 1 and t[1] > 1 and ((t[0] * t[1] > 256) == big)]
+    n = len(tus)
+    stride = 72
+    resi = np.zeros((n * 64, stride), np.int16)
+    jobs = (TuJob * n)()
+    exp, exp_lv, exp_rec = [], np.zeros((n, 4096), np.int32), np.zeros((n, 4096), np.int16)
+    for k, (w, h, th, tv) in enumerate(tus):
+        amp = int(rng.choice([8, 60, 400, 1023]))
+        blk = rng.integers(-amp, amp + 1, (h, w)).astype(np.int16)
+        resi[k * 64:k * 64 + h, 4:4 + w] = blk
+        qp = int(rng.choice([22, 27, 32, 37])) + 12
+        irap = int(rng.integers(0, 2))
+        j = jobs[k]
+        j.resiOff, j.outOff, j.resiStride, j.width, j.height = k * 64 * stride + 4, k * 4096, stride, w, h
+        j.qpPer, j.qpRem, j.typeHor, j.typeVer, j.bitDepth, j.isIRAP = qp // 6, qp % 6, th, tv, 10, irap
+        coef, qc, dq = np.zeros(w * h, np.int32), np.zeros(w * h, np.int32), np.zeros(w * h, np.int32)
+        blk_c = np.ascontiguousarray(blk)
+        assert L.vo_fwd_2d(ol.P(blk_c), w, w, h, 10, th, tv, ol.P(coef)) == 0
+        s = C.c_int32()
+        L.vo_quant(ol.P(coef), w, h, 10, j.qpPer, j.qpRem, irap, 0, ol.P(qc), None, C.byref(s))
+        L.vo_dequant(ol.P(qc), w, h, 10, j.qpPer, j.qpRem, 0, ol.P(dq))
+        rec = np.zeros((h, w), np.int16)
+        assert L.vo_inv_2d(ol.P(dq), w, h, 10, th, tv, ol.P(rec), w) == 0
+        exp.append((ol.o_dist(2, blk_c, rec, w, h), int(np.abs(coef.astype(np.int64)).sum()), s.value))
+        exp_lv[k, :w * h], exp_rec[k, :w * h] = qc, rec.reshape(-1)
+    d_resi = ctx.to_device(resi)
+    d_jobs = ctx.to_device(np.frombuffer(jobs, np.uint8))
+    d_res = ctx.alloc(16 * n)
+    d_lv, d_rec = ctx.to_device(np.zeros((n, 4096), np.int32)), ctx.to_device(np.zeros((n, 4096), np.int16))
+    if big:
+        ctx.tu_chain_batch(d_resi.ptr, d_jobs.ptr, n, 64, 64, d_res.ptr, d_lv.ptr, d_rec.ptr)
+    else:
+        # w*h <= 256 covers shapes from 64x4 to 4x64; one launch per shape (maxWidth x maxHeight sizes the LDS and picks 64 threads per TU)
+        acc = np.zeros((n, 16), np.uint8)
+        for shape in sorted({(t[0], t[1]) for t in tus}):
+            idx = [k for k, t in enumerate(tus) if (t[0], t[1]) == shape]
+            sub = (TuJob * len(idx))()
+            for i, k in enumerate(idx):
+                C.memmove(C.byref(sub[i]), C.byref(jobs[k]), C.sizeof(TuJob))
+            d_sub = ctx.to_device(np.frombuffer(sub, np.uint8))
+            d_r = ctx.alloc(16 * len(idx))
+            ctx.tu_chain_batch(d_resi.ptr, d_sub.ptr, len(idx), shape[0], shape[1], d_r.ptr, d_lv.ptr, d_rec.ptr)
+            acc[idx] = d_r.to_host(np.uint8).reshape(len(idx), 16)
+        d_res = ctx.to_device(acc)
+    res = (TuResult * n).from_buffer_copy(d_res.to_host(np.uint8).tobytes())
+    got = [(r.sse, r.sumAbs, r.absSum) for r in res]
+    lv, rc = d_lv.to_host().reshape(n, 4096), d_rec.to_host().reshape(n, 4096)
+    for k, (w, h, th, tv) in enumerate(tus):
+        assert got[k] == exp[k], (tus[k], got[k], exp[k])
+        assert np.array_equal(lv[k, :w * h], exp_lv[k, :w * h]) and np.array_equal(rc[k, :w * h], exp_rec[k, :w * h]), tus[k]

@@ -22,6 +22,8 @@ int vtmhip_struct_size( int which )
   case 9: return ( int ) sizeof( vtmhip_full_job );
   case 10: return ( int ) sizeof( vtmhip_mc_job );
   case 11: return ( int ) sizeof( vtmhip_pelop_job );
+  case 12: return ( int ) sizeof( vtmhip_tu_job );
+  case 13: return ( int ) sizeof( vtmhip_tu_result );
   default: return -1;
   }
 }

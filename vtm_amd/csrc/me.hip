@@ -599,15 +599,20 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel(
 
 // ---- exhaustive search (InterSearch::xPatternSearch :3566-3608 after xSetSearchRange :3496-3563): the bi-predictive
 // refinement of xMotionEstimation (:3385-3440, +-BipredSearchRange around the current vector).  One wave per job.
-__global__ __launch_bounds__( 256 ) void full_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
-                                                            const vtmhip_full_job *__restrict__ jobs, int numJobs, vtmhip_me_result *__restrict__ results )
+template<int WPJ>
+__global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void full_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase,
+                                                                                  const int16_t *__restrict__ refBase,
+                                                                                  const vtmhip_full_job *__restrict__ jobs, int numJobs,
+                                                                                  vtmhip_me_result *__restrict__ results )
 {
+  __shared__ unsigned long long sRedCost[WPJ];
+  __shared__ unsigned           sRedIdx[WPJ];
   const int lane = threadIdx.x & 63, wv = uni( ( int ) ( threadIdx.x >> 6 ) );
-  const int jobIdx = blockIdx.x * 4 + wv;
+  const int jobIdx = WPJ == 1 ? blockIdx.x * 4 + wv : blockIdx.x;
   if( jobIdx >= numJobs ) return;
   const vtmhip_full_job *jp = jobs + jobIdx;
   Coop                   co;
-  co.lane = lane; co.wave = 0; co.wpj = 1; co.leader = lane == 0; co.redCost = nullptr; co.redIdx = nullptr;
+  co.lane = lane; co.wave = WPJ == 1 ? 0 : wv; co.wpj = WPJ; co.leader = ( lane == 0 && co.wave == 0 ); co.redCost = sRedCost; co.redIdx = sRedIdx;
   MeJob j;
   j.org = orgBase + jp->orgOff; j.ref = refBase + jp->refOff;
   j.orgStride = jp->orgStride; j.refStride = jp->refStride;
@@ -631,8 +636,8 @@ __global__ __launch_bounds__( 256 ) void full_search_kernel( vtmhip_pic_params p
   const int   nx = sr.right >= sr.left ? sr.right - sr.left + 1 : 0, ny = sr.bottom >= sr.top ? sr.bottom - sr.top + 1 : 0;
   unsigned long long cost;
   unsigned           idx;
-  eval_candidates<true, 1>( j, nullptr, nx * ny, sr.left, sr.top, nx > 0 ? nx : 1, 1, co, cost, idx );
-  if( lane == 0 )
+  eval_candidates<true, WPJ>( j, nullptr, nx * ny, sr.left, sr.top, nx > 0 ? nx : 1, 1, co, cost, idx );
+  if( co.leader )
   {
     vtmhip_me_result r;
     r.mvX = 0; r.mvY = 0; r.nEval = ( unsigned ) ( nx * ny ); r.reserved = 0; r.cost = ~0ull; r.dist = ~0ull;
@@ -686,7 +691,19 @@ extern "C" int vtmhip_full_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_p
   if( n == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, d_orgBase && d_refBase && d_jobs && d_results, "null pointer" );
   VTMHIP_REQUIRE( ctx, pic->picW > 0 && pic->picH > 0 && pic->ctuSize > 0, "picture parameters" );
-  hipLaunchKernelGGL( full_search_kernel, dim3( ( n + 3 ) / 4 ), dim3( 256 ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, d_results );
+  const int wpj = pic->wavesPerJob;
+  VTMHIP_REQUIRE( ctx, wpj == 0 || wpj == 1 || wpj == 2 || wpj == 4 || wpj == 8 || wpj == 16, "wavesPerJob must be 0, 1, 2, 4, 8 or 16" );
+#define VTMHIP_FS_LAUNCH( W, GRID ) \
+  hipLaunchKernelGGL( full_search_kernel<W>, dim3( GRID ), dim3( W == 1 ? 256 : 64 * W ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, d_results )
+  switch( wpj )
+  {
+  case 2: VTMHIP_FS_LAUNCH( 2, n ); break;
+  case 4: VTMHIP_FS_LAUNCH( 4, n ); break;
+  case 8: VTMHIP_FS_LAUNCH( 8, n ); break;
+  case 16: VTMHIP_FS_LAUNCH( 16, n ); break;
+  default: VTMHIP_FS_LAUNCH( 1, ( n + 3 ) / 4 ); break;
+  }
+#undef VTMHIP_FS_LAUNCH
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

@@ -325,6 +325,185 @@ __global__ __launch_bounds__( 256 ) void dequant_kernel( const int *__restrict__
   }
 }
 
+
+// ---- fused residual-coding chain of one TU: xT -> Quant::quant -> Quant::dequant -> xIT -> SSE(residual, reconstructed residual) ----
+// = transformNxN + invTransformNxN + getDistPart( DF_SSE ) of xEstimateInterResidualQT (EncoderLib/InterSearch.cpp:6637-6733) without the
+// CABAC bit estimate in between (host).  Everything stays in LDS; TPT threads per TU (64: four independent TUs per workgroup, wave-level
+// synchronisation only; 256: one TU per workgroup).
+template<int TPT>
+__device__ __forceinline__ void tu_sync()
+{
+  if( TPT == 64 ) { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
+  else __syncthreads();
+}
+
+template<int TPT>
+__global__ __launch_bounds__( 256 ) void tu_chain_kernel( const int16_t *__restrict__ resiBase, const vtmhip_tu_job *__restrict__ jobs, int numJobs,
+                                                         TrTables tabs, int *__restrict__ levelsBase, int16_t *__restrict__ recBase,
+                                                         vtmhip_tu_result *__restrict__ results, int maxW, int maxH )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int ldsw[];
+  __shared__ long long sRed[4][3];
+  constexpr int TUS = 256 / TPT;
+  const int     sub = TPT == 64 ? ( int ) ( threadIdx.x >> 6 ) : 0, t = TPT == 64 ? ( int ) ( threadIdx.x & 63 ) : ( int ) threadIdx.x;
+  const int     jobIdx = blockIdx.x * TUS + sub;
+  if( jobIdx >= numJobs ) return;   // TPT == 64: whole waves leave; TPT == 256: grid == numJobs
+  const vtmhip_tu_job j = jobs[jobIdx];
+  const int           w = j.width, h = j.height, bd = j.bitDepth;
+  const int           mx = maxW > maxH ? maxW : maxH;
+  const int           perTu = maxW * maxH + maxW * ( maxH + 1 ) + ( ( mx * mx + 1 ) >> 1 ) + ( ( maxW * maxH + 1 ) >> 1 );   // ints
+  int                *blk = ldsw + sub * perTu;            // [h][w] residual -> coefficients -> dequantised coefficients
+  int                *tmp = blk + maxW * maxH;             // [w][h+1] / [w][h]
+  int16_t            *sM  = ( int16_t * ) ( tmp + maxW * ( maxH + 1 ) );
+  int16_t            *sR  = sM + ( ( mx * mx + 1 ) & ~1 );   // residual copy for the SSE
+  const int16_t      *resi = resiBase + j.resiOff;
+  for( int i = t; i < w * h; i += TPT )
+  {
+    const int y = i / w, x = i - y * w;
+    const int16_t v = resi[( long ) y * j.resiStride + x];
+    blk[i] = v;
+    sR[i]  = v;
+  }
+  const int skipW = tr_skip( j.typeHor, w ), skipH = tr_skip( j.typeVer, h );
+  const int lw = ilog2( w ), lh = ilog2( h );
+  long long sumAbs = 0, absSum = 0, sse = 0;
+
+  // ---- forward: TrQuant::xT ----------------------------------------------------------------------------------------------------
+  {
+    const int s1 = lw + bd + 6 - 15, s2 = lh + 6;
+    const int16_t *m = tabs.m[j.typeHor][lw];
+    for( int i = t; i < w * w; i += TPT ) { const int k = i / w, n = i - k * w; sM[n * w + k] = m[i]; }
+    tu_sync<TPT>();
+    {
+      const int rnd = s1 > 0 ? 1 << ( s1 - 1 ) : 0, kEff = w - skipW;
+      for( int o = t; o < h * w; o += TPT )
+      {
+        const int jj = o / w, k = o - jj * w;
+        int       v  = 0;
+        if( k < kEff )
+        {
+          unsigned sum = 0;
+          for( int n = 0; n < w; n++ ) sum += ( unsigned ) blk[jj * w + n] * ( unsigned ) ( int ) sM[n * w + k];
+          v = ( int ) ( sum + ( unsigned ) rnd ) >> s1;
+        }
+        tmp[k * ( h + 1 ) + jj] = v;
+      }
+    }
+    tu_sync<TPT>();
+    m = tabs.m[j.typeVer][lh];
+    for( int i = t; i < h * h; i += TPT ) { const int k = i / h, n = i - k * h; sM[n * h + k] = m[i]; }
+    tu_sync<TPT>();
+    {
+      const int rnd = 1 << ( s2 - 1 ), kEff = h - skipH, jEff = w - skipW;
+      for( int o = t; o < w * h; o += TPT )
+      {
+        const int j2 = o / h, k2 = o - j2 * h;
+        int       v  = 0;
+        if( j2 < jEff && k2 < kEff )
+        {
+          unsigned sum = 0;
+          for( int n = 0; n < h; n++ ) sum += ( unsigned ) tmp[j2 * ( h + 1 ) + n] * ( unsigned ) ( int ) sM[n * h + k2];
+          v = ( int ) ( sum + ( unsigned ) rnd ) >> s2;
+        }
+        blk[k2 * w + j2] = v;
+        sumAbs += abs( v );
+      }
+    }
+    tu_sync<TPT>();
+  }
+  // ---- Quant::quant + Quant::dequant (flat scaling list), in place ------------------------------------------------------------
+  {
+    const int       needSqrt = ( lw + lh ) & 1;
+    const int       trShift  = 15 - bd - ( ( lw + lh ) >> 1 ) + ( needSqrt ? -1 : 0 );
+    const int       qBits    = 14 + j.qpPer + trShift;
+    const long long add      = ( long long ) ( j.isIRAP ? 171 : 85 ) << ( qBits - 9 );
+    const int       scale    = c_quantScales[needSqrt][j.qpRem], iscale = c_invQuantScales[needSqrt][j.qpRem];
+    const int       rightShift = 6 - ( trShift + j.qpPer );
+    const int       inBits   = min( 16, 32 + rightShift - 7 );
+    const int       inMin = -( 1 << ( inBits - 1 ) ), inMax = ( 1 << ( inBits - 1 ) ) - 1;
+    int            *levels   = levelsBase ? levelsBase + j.outOff : nullptr;
+    for( int i = t; i < w * h; i += TPT )
+    {
+      const int       c   = blk[i];
+      const long long tt  = ( long long ) abs( c ) * scale;
+      const int       mag = ( int ) ( ( tt + add ) >> qBits );
+      absSum += mag;
+      const int q = min( 32767, max( -32768, c < 0 ? -mag : mag ) );
+      if( levels ) levels[i] = q;
+      const int qq = min( inMax, max( inMin, q ) );
+      int       v;
+      if( rightShift > 0 ) v = ( int ) ( ( unsigned ) ( qq * iscale ) + ( 1u << ( rightShift - 1 ) ) ) >> rightShift;
+      else v = ( int ) ( ( unsigned ) ( qq * iscale ) << ( -rightShift ) );
+      blk[i] = min( 32767, max( -32768, v ) );
+    }
+    tu_sync<TPT>();
+  }
+  // ---- inverse: TrQuant::xIT, then SSE against the residual ------------------------------------------------------------------
+  {
+    const int s1 = 7, s2 = 20 - bd;
+    const int16_t *m = tabs.m[j.typeVer][lh];
+    for( int i = t; i < h * h; i += TPT ) sM[i] = m[i];
+    tu_sync<TPT>();
+    {
+      const unsigned rnd = 1u << ( s1 - 1 );
+      const int      linesEff = w - skipW, cut = h - skipH;
+      for( int o = t; o < w * h; o += TPT )
+      {
+        const int i = o / h, jj = o - i * h;
+        int       v = 0;
+        if( i < linesEff )
+        {
+          unsigned sum = 0;
+          for( int k = 0; k < cut; k++ ) sum += ( unsigned ) blk[k * w + i] * ( unsigned ) ( int ) sM[k * h + jj];
+          v = min( 32767, max( -32768, ( int ) ( sum + rnd ) >> s1 ) );
+        }
+        tmp[i * h + jj] = v;
+      }
+    }
+    tu_sync<TPT>();
+    m = tabs.m[j.typeHor][lw];
+    for( int i = t; i < w * w; i += TPT ) sM[i] = m[i];
+    tu_sync<TPT>();
+    {
+      const unsigned rnd = 1u << ( s2 - 1 );
+      const int      cut = w - skipW;
+      int16_t       *rec = recBase ? recBase + j.outOff : nullptr;
+      for( int o = t; o < w * h; o += TPT )
+      {
+        const int y = o / w, x = o - y * w;
+        unsigned  sum = 0;
+        for( int k = 0; k < cut; k++ ) sum += ( unsigned ) tmp[k * h + y] * ( unsigned ) ( int ) sM[k * w + x];
+        const int v = min( 32767, max( -32768, ( int ) ( sum + rnd ) >> s2 ) );
+        if( rec ) rec[o] = ( int16_t ) v;
+        const int d = ( int ) sR[o] - ( int ) ( int16_t ) v;
+        sse += ( long long ) ( unsigned long long ) ( ( unsigned ) d * ( unsigned ) d );
+      }
+    }
+  }
+  // ---- reduce the three sums over the TU's threads ------------------------------------------------------------------------------
+  sumAbs = ( long long ) wave_reduce_add_u64( ( unsigned long long ) sumAbs );
+  absSum = ( long long ) wave_reduce_add_u64( ( unsigned long long ) absSum );
+  sse    = ( long long ) wave_reduce_add_u64( ( unsigned long long ) sse );
+  if( TPT == 64 )
+  {
+    if( t == 0 ) { vtmhip_tu_result r; r.sse = ( uint64_t ) sse; r.sumAbs = ( int32_t ) sumAbs; r.absSum = ( int32_t ) absSum; results[jobIdx] = r; }
+  }
+  else
+  {
+    __syncthreads();
+    if( ( threadIdx.x & 63 ) == 0 ) { sRed[threadIdx.x >> 6][0] = sumAbs; sRed[threadIdx.x >> 6][1] = absSum; sRed[threadIdx.x >> 6][2] = sse; }
+    __syncthreads();
+    if( threadIdx.x == 0 )
+    {
+      vtmhip_tu_result r;
+      r.sumAbs = ( int32_t ) ( sRed[0][0] + sRed[1][0] + sRed[2][0] + sRed[3][0] );
+      r.absSum = ( int32_t ) ( sRed[0][1] + sRed[1][1] + sRed[2][1] + sRed[3][1] );
+      r.sse    = ( uint64_t ) ( sRed[0][2] + sRed[1][2] + sRed[2][2] + sRed[3][2] );
+      results[jobIdx] = r;
+    }
+  }
+}
+
 bool pow2( int v ) { return v > 0 && ( v & ( v - 1 ) ) == 0; }
 int  hlog2( int v ) { int r = 0; while( ( 1 << r ) < v ) r++; return r; }
 
@@ -439,6 +618,32 @@ int vtmhip_dequant_batch_dev( vtmhip_ctx *ctx, const int32_t *d_qBase, int32_t *
   if( n == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, d_coefBase && d_qBase && d_jobs, "null pointer" );
   hipLaunchKernelGGL( dequant_kernel, dim3( n ), dim3( 256 ), 0, ctx->stream, d_qBase, d_coefBase, d_jobs );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int maxWidth, int maxHeight,
+                               int32_t *d_levelsBase, int16_t *d_recBase, vtmhip_tu_result *d_results )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_resiBase && d_jobs && d_results, "null pointer" );
+  VTMHIP_REQUIRE( ctx, maxWidth >= 2 && maxWidth <= TB && maxHeight >= 2 && maxHeight <= TB, "maxWidth / maxHeight: 2..64 (2-D transforms)" );
+  int st = ensure_tables( ctx );
+  if( st ) return st;
+  const int    mx    = maxWidth > maxHeight ? maxWidth : maxHeight;
+  const size_t perTu = ( size_t ) maxWidth * maxHeight + ( size_t ) maxWidth * ( maxHeight + 1 ) + ( ( mx * mx + 1 ) >> 1 ) + ( ( maxWidth * maxHeight + 1 ) >> 1 );
+  if( maxWidth * maxHeight <= 256 )
+  {
+    hipLaunchKernelGGL( tu_chain_kernel<64>, dim3( ( n + 3 ) / 4 ), dim3( 256 ), 4 * perTu * sizeof( int ), ctx->stream, d_resiBase, d_jobs, n,
+                        g_tabs[ctx->device & 15], d_levelsBase, d_recBase, d_results, maxWidth, maxHeight );
+  }
+  else
+  {
+    hipLaunchKernelGGL( tu_chain_kernel<256>, dim3( n ), dim3( 256 ), perTu * sizeof( int ), ctx->stream, d_resiBase, d_jobs, n,
+                        g_tabs[ctx->device & 15], d_levelsBase, d_recBase, d_results, maxWidth, maxHeight );
+  }
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

@@ -9,7 +9,7 @@ import numpy as np
 
 from . import lib as _lib
 from .lib import (DistJob, FracJob, FracResult, FullJob, IfJob, McJob, MeResult, PelOpJob, PicParams, QuantJob,   # noqa: F401
-                  TrJob, TzJob, VtmHipError)
+                  TrJob, TuJob, TuResult, TzJob, VtmHipError)
 
 
 class DevBuf:
@@ -188,6 +188,9 @@ class Context:
 
     def add_avg_batch(self, d_a, d_b, d_dst, d_jobs, n):
         self._check(self.L.vtmhip_add_avg_batch_dev(self.h, d_a, d_b, d_dst, d_jobs, n))
+
+    def tu_chain_batch(self, d_resi, d_jobs, n, max_w, max_h, d_results, d_levels=None, d_rec=None):
+        self._check(self.L.vtmhip_tu_chain_batch_dev(self.h, d_resi, d_jobs, n, max_w, max_h, d_levels, d_rec, d_results))
 
     def tz_search_batch(self, pic, d_org, d_ref, d_jobs, n, d_results):
         self._check(self.L.vtmhip_tz_search_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, d_results))

@@ -89,7 +89,18 @@ class PelOpJob(C.Structure):
                 ("bitDepth", C.c_uint8), ("pad0", C.c_uint8), ("pad1", C.c_uint8), ("pad2", C.c_uint8), ("pad3", C.c_int32)]
 
 
-_STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob]   # order of vtmhip_struct_size(which)
+class TuJob(C.Structure):
+    _fields_ = [("resiOff", C.c_int64), ("outOff", C.c_int64), ("resiStride", C.c_int32), ("width", C.c_int16),
+                ("height", C.c_int16), ("qpPer", C.c_int16), ("qpRem", C.c_int16), ("typeHor", C.c_uint8),
+                ("typeVer", C.c_uint8), ("bitDepth", C.c_uint8), ("isIRAP", C.c_uint8), ("pad", C.c_int32)]
+
+
+class TuResult(C.Structure):
+    _fields_ = [("sse", C.c_uint64), ("sumAbs", C.c_int32), ("absSum", C.c_int32)]
+
+
+_STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob,
+            TuJob, TuResult]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
 _PROTOS = {
@@ -139,6 +150,8 @@ _PROTOS = {
     "vtmhip_remove_high_freq_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "vtmhip_subtract_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "vtmhip_add_avg_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "vtmhip_tu_chain_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]),
     "vtmhip_dist_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vtmhip_satd8_grid_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),

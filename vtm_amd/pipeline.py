@@ -25,6 +25,9 @@ assert C.sizeof(TzJob) % 4 == 0 and C.sizeof(MeResult) == 32
 WAVES_PER_JOB = {128: 4, 64: 4, 32: 4, 16: 2, 8: 1}   # vtmhip_pic_params.wavesPerJob per PU size (measured)
 
 
+FULL_WAVES_PER_JOB = {128: 16, 64: 8, 32: 4, 16: 1, 8: 1}   # 81-point exhaustive search: one candidate at a time per wave for big PUs
+
+
 def subshift_mode2(w, h):
     """RdCost::setDistParam subShiftMode 2 (FEN=1 / FastSearch, RdCost.cpp:311-317)."""
     return 1 if (h > 8 and w <= 64) else 0
@@ -136,10 +139,11 @@ class FrameME:
 # ======================================================================================================================
 # Full hot path of one inter picture: integer ME -> fractional ME -> bi-predictive refinement -> residual coding.
 # ======================================================================================================================
-from .lib import DistJob, FracJob, FracResult, FullJob, McJob, PelOpJob, QuantJob, TrJob   # noqa: E402
+from .lib import DistJob, FracJob, FracResult, FullJob, McJob, PelOpJob, QuantJob, TrJob, TuJob   # noqa: E402
 
 FRAC_DT, FRACRES_DT, MC_DT, FULL_DT = np.dtype(FracJob), np.dtype(FracResult), np.dtype(McJob), np.dtype(FullJob)
 PEL_DT, TR_DT, Q_DT, DIST_DT = np.dtype(PelOpJob), np.dtype(TrJob), np.dtype(QuantJob), np.dtype(DistJob)
+TU_DT = np.dtype(TuJob)
 
 # (typeHor, typeVer) of mtsIdx 0, 2, 3, 4, 5 (TrQuant::getTrTypes, TrQuant.cpp:695-772): DCT2 = 0, DCT8 = 1, DST7 = 2
 MTS_CANDS = ((0, 0), (2, 2), (1, 2), (2, 1), (1, 1))
@@ -179,8 +183,9 @@ class FrameHotPath(FrameME):
     every MTS candidate is taken through the whole chain (the reference prunes with the sum|coef| threshold).
     """
 
-    def __init__(self, ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda=8.0, qp=32, **kw):
+    def __init__(self, ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda=8.0, qp=32, fused_tu=True, **kw):
         assert len(refs) == 2
+        self.fused_tu = fused_tu
         super().__init__(ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda, **kw)
         self.refs, self.org_stride, self.lam = refs, org_stride, motion_lambda
         base_qp = qp + 12   # 10-bit: qpBdOffset = 12 (Quant.cpp:65-104)
@@ -193,6 +198,7 @@ class FrameHotPath(FrameME):
             xs, ys = jobs["puX"][:npu].astype(np.int64), jobs["puY"][:npu].astype(np.int64)
             blk = np.arange(npu, dtype=np.int64) * s * s
             lvl["npu"] = npu
+            lvl["pic_full"] = PicParams(pic_w, pic_h, 128, 10, FULL_WAVES_PER_JOB.get(s, 1))
             lvl["ref_base"] = T.tensor([r[0] for r in refs], dtype=T.int64, device=dev)
             lvl["pos_off"] = [T.from_numpy(ys * r[1] + xs).to(dev) for r in refs]   # block offset inside each reference plane
             ref_strides = [r[1] for r in refs]
@@ -268,6 +274,12 @@ class FrameHotPath(FrameME):
             dj["orgOff"], dj["curOff"], dj["orgStride"], dj["curStride"] = np.tile(tu_src, nc), coef_off, tu_stride, ts
             dj["width"], dj["height"], dj["kind"] = ts, ts, _lib.DIST_SSE
             lvl["sse"] = _Tab(T, dev, dj)
+            uj2 = np.zeros(ntu * nc, TU_DT)
+            uj2["resiOff"], uj2["outOff"], uj2["resiStride"], uj2["width"], uj2["height"] = np.tile(tu_src, nc), coef_off, tu_stride, ts, ts
+            uj2["qpPer"], uj2["qpRem"], uj2["bitDepth"] = self.qp_per, self.qp_rem, 10
+            uj2["typeHor"], uj2["typeVer"] = tj["typeHor"], tj["typeVer"]
+            lvl["tu"] = _Tab(T, dev, uj2)
+            lvl["tu_res"] = T.zeros((ntu * nc, 2), dtype=T.int64, device=dev)   # vtmhip_tu_result: {sse u64, sumAbs i32, absSum i32}
             lvl["ntu"], lvl["nc"], lvl["ts"] = ntu, nc, ts
             lvl["sum_abs"] = T.zeros(ntu * nc, dtype=T.int32, device=dev)
             lvl["abs_sum"] = T.zeros(ntu * nc, dtype=T.int32, device=dev)
@@ -369,7 +381,7 @@ class FrameHotPath(FrameME):
         fu.col("predVer").copy_(sel(pred_v, rl))
         fu.col("centerHor").copy_(sel(mvq_x, rl) << 2)
         fu.col("centerVer").copy_(sel(mvq_y, rl) << 2)
-        ctx.full_search_batch(lvl["pic"], self.buf["org_bi"].data_ptr(), dpb_ptr, fu.ptr, npu, lvl["full_res"].data_ptr())
+        ctx.full_search_batch(lvl["pic_full"], self.buf["org_bi"].data_ptr(), dpb_ptr, fu.ptr, npu, lvl["full_res"].data_ptr())
         fb = lvl["frac_bi"]
         fb.col("refOff").copy_(ref_off(rl))
         fb.col("intX").copy_(lvl["full_res"][:, 0].to(T.int16))
@@ -409,11 +421,17 @@ class FrameHotPath(FrameME):
 
         # (5) residual coding per TU and transform candidate
         nt, ts = lvl["ntu"] * lvl["nc"], lvl["ts"]
-        ctx.xT_batch(self.buf["resi"].data_ptr(), self.coef.data_ptr(), lvl["xt"].ptr, nt, ts, ts, lvl["sum_abs"].data_ptr())
-        ctx.quant_batch(self.coef.data_ptr(), self.qcoef.data_ptr(), None, lvl["quant"].ptr, nt, lvl["abs_sum"].data_ptr())
-        ctx.dequant_batch(self.qcoef.data_ptr(), self.dqcoef.data_ptr(), lvl["quant"].ptr, nt)
-        ctx.xIT_batch(self.dqcoef.data_ptr(), self.rec_resi.data_ptr(), lvl["xit"].ptr, nt, ts, ts)
-        ctx.dist_batch(self.buf["resi"].data_ptr(), self.rec_resi.data_ptr(), lvl["sse"].ptr, nt, lvl["sse_out"].data_ptr())
+        if self.fused_tu:
+            # levels go to the host for the CABAC estimate in the real encoder; the bench keeps them in HBM
+            ctx.tu_chain_batch(self.buf["resi"].data_ptr(), lvl["tu"].ptr, nt, ts, ts, lvl["tu_res"].data_ptr(), self.qcoef.data_ptr(), None)
+            r32 = lvl["tu_res"].view(T.int32)
+            lvl["sse_out"], lvl["sum_abs"], lvl["abs_sum"] = lvl["tu_res"][:, 0], r32[:, 2], r32[:, 3]
+        else:
+            ctx.xT_batch(self.buf["resi"].data_ptr(), self.coef.data_ptr(), lvl["xt"].ptr, nt, ts, ts, lvl["sum_abs"].data_ptr())
+            ctx.quant_batch(self.coef.data_ptr(), self.qcoef.data_ptr(), None, lvl["quant"].ptr, nt, lvl["abs_sum"].data_ptr())
+            ctx.dequant_batch(self.qcoef.data_ptr(), self.dqcoef.data_ptr(), lvl["quant"].ptr, nt)
+            ctx.xIT_batch(self.dqcoef.data_ptr(), self.rec_resi.data_ptr(), lvl["xit"].ptr, nt, ts, ts)
+            ctx.dist_batch(self.buf["resi"].data_ptr(), self.rec_resi.data_ptr(), lvl["sse"].ptr, nt, lvl["sse_out"].data_ptr())
         self._mark("resi")
         lvl["out"] = dict(mvq_x=mvq_x, mvq_y=mvq_y, cost_uni=cost_uni, rl=rl, bi_x=bi_x, bi_y=bi_y, cost_bi=cost_bi, use_bi=use_bi)
 
