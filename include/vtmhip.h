@@ -338,6 +338,26 @@ typedef struct
 int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int maxWidth, int maxHeight,
                                int32_t *d_levelsBase, int16_t *d_recBase, vtmhip_tu_result *d_results );
 
+/* ---- affine ME gradients: AffineGradientSearch::m_HorizontalSobelFilter / m_VerticalSobelFilter / m_EqualCoeffComputer -----------
+ * (AffineGradientSearch.h:50-54, AffineGradientSearch.cpp:62-170; caller xAffineMotionEstimation, InterSearch.cpp:5340-5775) */
+typedef struct
+{
+  int64_t predOff;      /* prediction block (int16) */
+  int64_t resiOff;      /* error block org - pred (int16) */
+  int64_t derivHOff;    /* horizontal derivative plane (int32) inside d_derivBase */
+  int64_t derivVOff;    /* vertical derivative plane */
+  int32_t predStride, resiStride, derivStride;
+  int16_t width, height;   /* >= 16 in the reference (affine CUs) */
+  uint8_t sixParam;     /* b6Param */
+  uint8_t pad[7];
+} vtmhip_affine_job;
+
+/* both Sobel planes of n blocks (interior 3x3 Sobel, border samples replicated as the reference does) */
+int vtmhip_affine_sobel_batch_dev( vtmhip_ctx *ctx, const int16_t *d_predBase, int32_t *d_derivBase, const vtmhip_affine_job *d_jobs, int n );
+/* d_equalCoeff: n x [7][7] int64, ACCUMULATED into (the reference zeroes pEqualCoeff before the call); rows 1..np, columns 0..np are written */
+int vtmhip_affine_equal_coeff_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const int32_t *d_derivBase, const vtmhip_affine_job *d_jobs, int n,
+                                         int64_t *d_equalCoeff );
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,3 +113,29 @@ def test_full_search_matches_oracle(ctx, wpj):
     got = [(r.mvX, r.mvY, r.cost, r.dist, r.nEval) for r in res]
     bad = [k for k in range(n) if got[k] != exp[k]]
     assert not bad, [(got[k], exp[k]) for k in bad[:5]]
+
+
+def test_affine_gradient_matches_reference_golden(ctx):
+    """Sobel planes and 4-/6-parameter normal equations vs vectors recorded from AffineGradientSearch (scalar == AVX2)."""
+    from vtm_amd.lib import AffineJob
+    z = np.load(os.path.join(G, "misc.npz"))
+    for k in range(int(z["count"][0])):
+        pred, resi = z["pred_%d" % k], z["resi_%d" % k]
+        h, w = pred.shape
+        for six in (0, 1):
+            jobs = (AffineJob * 2)()   # two identical jobs: exercises the batch indexing
+            for q in range(2):
+                j = jobs[q]
+                j.predOff, j.resiOff, j.derivHOff, j.derivVOff = 0, 0, q * 2 * w * h, q * 2 * w * h + w * h
+                j.predStride, j.resiStride, j.derivStride, j.width, j.height, j.sixParam = w, w, w, w, h, six
+            d_pred, d_resi = ctx.to_device(pred), ctx.to_device(resi)
+            d_der = ctx.to_device(np.zeros(4 * w * h, np.int32))
+            d_eq = ctx.to_device(np.zeros((2, 7, 7), np.int64))
+            d_jobs = ctx.to_device(np.frombuffer(jobs, np.uint8))
+            ctx.affine_sobel_batch(d_pred.ptr, d_der.ptr, d_jobs.ptr, 2)
+            ctx.affine_equal_coeff_batch(d_resi.ptr, d_der.ptr, d_jobs.ptr, 2, d_eq.ptr)
+            der = d_der.to_host().reshape(4, h, w)
+            eq = d_eq.to_host().reshape(2, 7, 7)
+            for q in range(2):
+                assert np.array_equal(der[2 * q], z["gx_%d" % k]) and np.array_equal(der[2 * q + 1], z["gy_%d" % k]), (k, six, q)
+                assert np.array_equal(eq[q], z["eq_%d_%d" % (k, six)]), (k, six, q)

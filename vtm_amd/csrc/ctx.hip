@@ -24,6 +24,7 @@ int vtmhip_struct_size( int which )
   case 11: return ( int ) sizeof( vtmhip_pelop_job );
   case 12: return ( int ) sizeof( vtmhip_tu_job );
   case 13: return ( int ) sizeof( vtmhip_tu_result );
+  case 14: return ( int ) sizeof( vtmhip_affine_job );
   default: return -1;
   }
 }

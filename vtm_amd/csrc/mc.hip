@@ -194,3 +194,114 @@ int vtmhip_add_avg_batch_dev( vtmhip_ctx *ctx, const int16_t *d_src0Base, const 
 }
 
 }   // extern "C"
+
+// =====================================================================================================================
+// Affine motion estimation gradients (reference CommonLib/AffineGradientSearch.cpp:62-170; callers
+// EncoderLib/InterSearch.cpp xAffineMotionEstimation :5340-5775): 3x3 Sobel derivatives with border replication and the
+// normal-equation accumulation of the 4- / 6-parameter model (int64 sums; the fp64 Gaussian solve stays on the host).
+// =====================================================================================================================
+namespace
+{
+
+__global__ __launch_bounds__( 256 ) void sobel_kernel( const int16_t *__restrict__ predBase, int *__restrict__ derivBase,
+                                                      const vtmhip_affine_job *__restrict__ jobs, int vertical )
+{
+  const vtmhip_affine_job j = jobs[blockIdx.x];
+  const int16_t          *p = predBase + j.predOff;
+  int                    *d = derivBase + ( vertical ? j.derivVOff : j.derivHOff );
+  const int               w = j.width, h = j.height, ps = j.predStride, ds = j.derivStride;
+  for( int i = threadIdx.x; i < w * h; i += blockDim.x )
+  {
+    const int y = i / w, x = i - y * w;
+    // border samples take the value of the nearest interior position (corners: the diagonal neighbour), :77-92 / :111-126
+    const int yc = min( h - 2, max( 1, y ) ), xc = min( w - 2, max( 1, x ) );
+    const int16_t *c = p + ( long ) yc * ps + xc;
+    const int v = vertical ? ( c[ps - 1] - c[-ps - 1] + ( c[ps] << 1 ) - ( c[-ps] << 1 ) + c[ps + 1] - c[-ps + 1] )
+                           : ( c[1 - ps] - c[-1 - ps] + ( c[1] << 1 ) - ( c[-1] << 1 ) + c[1 + ps] - c[-1 + ps] );
+    d[( long ) y * ds + x] = v;
+  }
+}
+
+__global__ __launch_bounds__( 256 ) void equal_coeff_kernel( const int16_t *__restrict__ resiBase, const int *__restrict__ derivBase,
+                                                            const vtmhip_affine_job *__restrict__ jobs, long long *__restrict__ eqBase )
+{
+  __shared__ long long     sAcc[4][42];
+  const vtmhip_affine_job j = jobs[blockIdx.x];
+  const int16_t           *r  = resiBase + j.resiOff;
+  const int               *gx = derivBase + j.derivHOff, *gy = derivBase + j.derivVOff;
+  const int                w = j.width, h = j.height, np = j.sixParam ? 6 : 4;
+  long long                acc[42];   // [col][row 0..np] flattened with stride 7: col * 7 + row
+#pragma unroll
+  for( int i = 0; i < 42; i++ ) acc[i] = 0;
+  for( int i = threadIdx.x; i < w * h; i += blockDim.x )
+  {
+    const int y = i / w, x = i - y * w;
+    const int cy = ( ( y >> 2 ) << 2 ) + 2, cx = ( ( x >> 2 ) << 2 ) + 2;
+    const int a = gx[( long ) y * j.derivStride + x], b = gy[( long ) y * j.derivStride + x];
+    const int e = r[( long ) y * j.resiStride + x];
+    int       c[6];
+    if( !j.sixParam ) { c[0] = a; c[1] = cx * a + cy * b; c[2] = b; c[3] = cy * a - cx * b; c[4] = 0; c[5] = 0; }
+    else { c[0] = a; c[1] = cx * a; c[2] = b; c[3] = cx * b; c[4] = cy * a; c[5] = cy * b; }
+#pragma unroll
+    for( int col = 0; col < 6; col++ )
+    {
+      if( col < np )
+      {
+#pragma unroll
+        for( int row = 0; row < 6; row++ )
+          if( row < np ) acc[col * 7 + row] += ( long long ) c[col] * c[row];
+        acc[col * 7 + 6] += ( ( long long ) c[col] * e ) << 3;   // slot 6 holds the right-hand side (written to column np below)
+      }
+    }
+  }
+#pragma unroll
+  for( int i = 0; i < 42; i++ ) acc[i] = ( long long ) wave_reduce_add_u64( ( unsigned long long ) acc[i] );
+  if( ( threadIdx.x & 63 ) == 0 )
+  {
+#pragma unroll
+    for( int i = 0; i < 42; i++ ) sAcc[threadIdx.x >> 6][i] = acc[i];
+  }
+  __syncthreads();
+  if( threadIdx.x < 42 )
+  {
+    const int       col = threadIdx.x / 7, row = threadIdx.x % 7;
+    const long long v   = sAcc[0][threadIdx.x] + sAcc[1][threadIdx.x] + sAcc[2][threadIdx.x] + sAcc[3][threadIdx.x];
+    long long      *eq  = eqBase + ( long ) blockIdx.x * 49;   // pEqualCoeff[7][7]; row 0 is unused by the reference
+    if( col < np )
+    {
+      if( row < np ) eq[( col + 1 ) * 7 + row] += v;
+      else if( row == 6 ) eq[( col + 1 ) * 7 + np] += v;
+    }
+  }
+}
+
+}   // namespace
+
+extern "C"
+{
+
+int vtmhip_affine_sobel_batch_dev( vtmhip_ctx *ctx, const int16_t *d_predBase, int32_t *d_derivBase, const vtmhip_affine_job *d_jobs, int n )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_predBase && d_derivBase && d_jobs, "null pointer" );
+  hipLaunchKernelGGL( sobel_kernel, dim3( n ), dim3( 256 ), 0, ctx->stream, d_predBase, d_derivBase, d_jobs, 0 );
+  hipLaunchKernelGGL( sobel_kernel, dim3( n ), dim3( 256 ), 0, ctx->stream, d_predBase, d_derivBase, d_jobs, 1 );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_affine_equal_coeff_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const int32_t *d_derivBase, const vtmhip_affine_job *d_jobs, int n,
+                                         int64_t *d_equalCoeff )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_resiBase && d_derivBase && d_jobs && d_equalCoeff, "null pointer" );
+  hipLaunchKernelGGL( equal_coeff_kernel, dim3( n ), dim3( 256 ), 0, ctx->stream, d_resiBase, d_derivBase, d_jobs, ( long long * ) d_equalCoeff );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+}   // extern "C"

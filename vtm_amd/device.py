@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _lib
-from .lib import (DistJob, FracJob, FracResult, FullJob, IfJob, McJob, MeResult, PelOpJob, PicParams, QuantJob,   # noqa: F401
+from .lib import (AffineJob, DistJob, FracJob, FracResult, FullJob, IfJob, McJob, MeResult, PelOpJob, PicParams, QuantJob,   # noqa: F401
                   TrJob, TuJob, TuResult, TzJob, VtmHipError)
 
 
@@ -191,6 +191,12 @@ class Context:
 
     def tu_chain_batch(self, d_resi, d_jobs, n, max_w, max_h, d_results, d_levels=None, d_rec=None):
         self._check(self.L.vtmhip_tu_chain_batch_dev(self.h, d_resi, d_jobs, n, max_w, max_h, d_levels, d_rec, d_results))
+
+    def affine_sobel_batch(self, d_pred, d_deriv, d_jobs, n):
+        self._check(self.L.vtmhip_affine_sobel_batch_dev(self.h, d_pred, d_deriv, d_jobs, n))
+
+    def affine_equal_coeff_batch(self, d_resi, d_deriv, d_jobs, n, d_eq):
+        self._check(self.L.vtmhip_affine_equal_coeff_batch_dev(self.h, d_resi, d_deriv, d_jobs, n, d_eq))
 
     def tz_search_batch(self, pic, d_org, d_ref, d_jobs, n, d_results):
         self._check(self.L.vtmhip_tz_search_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, d_results))

@@ -99,8 +99,14 @@ class TuResult(C.Structure):
     _fields_ = [("sse", C.c_uint64), ("sumAbs", C.c_int32), ("absSum", C.c_int32)]
 
 
+class AffineJob(C.Structure):
+    _fields_ = [("predOff", C.c_int64), ("resiOff", C.c_int64), ("derivHOff", C.c_int64), ("derivVOff", C.c_int64),
+                ("predStride", C.c_int32), ("resiStride", C.c_int32), ("derivStride", C.c_int32), ("width", C.c_int16),
+                ("height", C.c_int16), ("sixParam", C.c_uint8), ("pad", C.c_uint8 * 7)]
+
+
 _STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob,
-            TuJob, TuResult]   # order of vtmhip_struct_size(which)
+            TuJob, TuResult, AffineJob]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
 _PROTOS = {
@@ -152,6 +158,8 @@ _PROTOS = {
     "vtmhip_add_avg_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "vtmhip_tu_chain_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_void_p]),
+    "vtmhip_affine_sobel_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "vtmhip_affine_equal_coeff_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vtmhip_dist_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vtmhip_satd8_grid_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),
