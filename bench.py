@@ -160,8 +160,19 @@ def main():
     alg = fme.alg_bytes()
     stages = {k2: {"ms": stage_acc[k2], "alg_GBps": alg[k2] / stage_acc[k2] / 1e6} for k2 in stage_acc}
     dom = max(stage_acc, key=stage_acc.get)
-    dom_kernel = {"tz": "tz_search_kernel", "frac": "frac_search_kernel", "bi_search": "mc_luma + pelop + full_search + frac_search kernels",
-                  "mc": "mc_luma_kernel + pelop_kernel", "resi": "xT + quant + dequant + xIT + dist_batch kernels"}[dom]
+    dom_kernel = {"tz": "tz_search_kernel", "frac": "frac_search_sq_kernel", "full": "full_search_kernel", "mc": "mc_luma_kernel",
+                  "pelop": "pelop_kernel", "tu": "tu_chain_kernel"}[dom]
+    launches = {"tz": 1, "frac": 2, "full": 1, "mc": 4, "pelop": 3, "tu": 1}[dom] * len(fme.levels)
+    # HBM-side traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
+    # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null when the file is absent
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic_per_launch_KB.json")))
+        tot = sum((2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 * v.get("launches_per_step", 1) for k2, v in pmc.items()
+                  if k2.startswith(dom_kernel))
+        traffic = tot / launches if tot else None
+    except Exception:
+        pass
 
     # ---- SATD 8x8 grid micro-benchmark (extra key; outside the timed steps) --------------------------------------
     nb = (W // 8) * (H // 8)
@@ -189,14 +200,17 @@ def main():
             "config": {"workload": "%dx%d 10-bit, encoder_randomaccess_vtm.cfg operating point (QP32, SR 96 via ASR, FEN subsampling): "
                                    "quadtree PUs 128..8 x 2 refs = %d integer searches + %d fractional + %d bi-pred refinements/picture, %d TU x transform-candidate chains"
                                    % (W, H, fme.n_jobs, fme.n_jobs, fme.n_jobs // 2, sum(l["ntu"] * l["nc"] for l in fme.levels)),
-                       "stages": ["tz_search", "frac_search", "bi_search", "mc", "resi"], "pictures_in_flight": world, "parallelism": "ctu-rows: 1 picture (17 CTU rows) per GPU"},
+                       "stages": ["tz_search", "frac_search", "bi-pred refinement (mc + removeHighFreq + full_search + frac_search)", "final mc/addAvg/residual",
+                                  "tu_chain (xT, quant, dequant, xIT, SSE)"], "pictures_in_flight": world, "parallelism": "ctu-rows: 1 picture (17 CTU rows) per GPU"},
             "satd_gblocks_per_s": float(satd_g.item()),
             "tz_candidates_per_picture": evals,
             "stages": stages,
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "stage": dom, "achieved": stages[dom]["alg_GBps"], "peak": 8000.0, "unit": "GB/s",
-                         "frac": stages[dom]["alg_GBps"] / 8000.0, "traffic": None,
-                         "note": "dominant stage of the step; algorithmic bytes per DESIGN.md section 5; %.3f ms of %.3f ms/step (sum of stages)"
-                                 % (stage_acc[dom], sum(stage_acc.values()))},
+                         "frac": stages[dom]["alg_GBps"] / 8000.0, "traffic": traffic, "launches_per_step": launches,
+                         "achieved_per_launch_bytes": alg[dom] / launches, "ms_per_launch": stage_acc[dom] / launches,
+                         "note": "dominant kernel family of the step by time; achieved = algorithmic bytes (DESIGN.md section 5) / kernel time, both per "
+                                 "launch averaged over its %d launches/step; %.3f ms of %.3f ms/step; traffic = HBM-side bytes per launch from the "
+                                 "committed PMC passes (profiles/)" % (launches, stage_acc[dom], sum(stage_acc.values()))},
             "satd_roofline": {"bound": "hbm", "kernel": "satd8_grid_kernel", "achieved": nb * 81 * 256 / satd_ms / 1e6, "peak": 8000.0,
                               "unit": "GB/s", "frac": nb * 81 * 256 / satd_ms / 1e6 / 8000.0, "ms": satd_ms},
         }

@@ -356,7 +356,7 @@ struct FracSq
 };
 
 template<int S>
-__global__ __launch_bounds__( FracSq<S>::BLOCK ) void frac_search_sq_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+__global__ __launch_bounds__( FracSq<S>::BLOCK, 4 ) void frac_search_sq_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
                                                                             const vtmhip_frac_job *__restrict__ jobs, int numJobs,
                                                                             vtmhip_frac_result *__restrict__ results )
 {
@@ -368,13 +368,17 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK ) void frac_search_sq_kernel( con
   const int job0 = blockIdx.x * C::JPW;
   const int nj = min( C::JPW, numJobs - job0 );
 
-  // ---- windows: rows/cols -4 .. S+3 around the integer vector ------------------------------------------------------------
-  for( int i = tid; i < nj * C::WIN; i += C::BLOCK )
+  // ---- windows: rows/cols -4 .. S+3 around the integer vector; 8 samples (16 bytes) per thread and step ----------------------
   {
-    const int               jl = i / C::WIN, r = ( i - jl * C::WIN ) / C::WLD, c = i - jl * C::WIN - r * C::WLD;
-    const vtmhip_frac_job &j  = jobs[job0 + jl];
-    const int16_t         *ref = refBase + j.refOff + ( long ) j.intY * j.refStride + j.intX;
-    lds[jl * C::PERJOB + r * C::WLD + c] = ref[( long ) ( r - 4 ) * j.refStride + ( c - 4 )];
+    constexpr int CH = C::WLD / 8;   // 16-byte chunks per window row
+    for( int i = tid; i < nj * ( S + 8 ) * CH; i += C::BLOCK )
+    {
+      const int               jl = i / ( ( S + 8 ) * CH ), rem = i - jl * ( S + 8 ) * CH, r = rem / CH, c = ( rem - r * CH ) * 8;
+      const vtmhip_frac_job &j  = jobs[job0 + jl];
+      const int16_t         *ref = refBase + j.refOff + ( long ) ( j.intY + r - 4 ) * j.refStride + ( j.intX + c - 4 );
+      const Pel8u            v   = *reinterpret_cast<const Pel8u *>( ref );
+      *reinterpret_cast<int4 *>( lds + jl * C::PERJOB + r * C::WLD + c ) = make_int4( ( int ) v.v[0], ( int ) v.v[1], ( int ) v.v[2], ( int ) v.v[3] );
+    }
   }
   for( int i = tid; i < C::JPW * 2; i += C::BLOCK ) sCentre[i >> 1][i & 1] = 0;
   __syncthreads();
@@ -383,20 +387,43 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK ) void frac_search_sq_kernel( con
   {
     const int step = round == 0 ? 2 : 1;
     if( round == 1 && jobs[job0].imvShift != 0 ) break;   // IMV_HPEL: half-sample refinement only (uniform per batch, checked on the host side)
-    // ---- phase H: plane p (dx = p - 1) of PU jl: (first, !last) 8-tap FIR of window rows 0..S+7 ----------------------------
-    for( int i = tid; i < nj * 3 * C::PLANE; i += C::BLOCK )
+    // ---- phase H: plane p (dx = p - 1) of PU jl: (first, !last) 8-tap FIR of window rows 0..S+7; 8 outputs per thread and step ----
     {
-      const int jl = i / ( 3 * C::PLANE ), rem = i - jl * 3 * C::PLANE;
-      const int p = rem / C::PLANE, o = rem - p * C::PLANE, r = o / S, x = o - r * S;
-      const vtmhip_frac_job &j = jobs[job0 + jl];
-      const int qx = sCentre[jl][0] + ( p - 1 ) * step, ix = qx >> 2, fx = qx & 3;
-      const int16_t *cH = ( round == 0 && j.useAltHpelIf && fx == 2 ) ? c_lumaAltHpel : c_lumaFilter[fx << 2];
-      const IfParams pH = if_params( 1, 0, j.bitDepth, 0, ( 1 << j.bitDepth ) - 1, 0 );
-      const int16_t *w = lds + jl * C::PERJOB + r * C::WLD + ( x + ix + 1 );
-      int sum = 0;
+      constexpr int CH = S / 8;
+      for( int i = tid; i < nj * 3 * ( S + 8 ) * CH; i += C::BLOCK )
+      {
+        const int jl = i / ( 3 * ( S + 8 ) * CH ), rem = i - jl * 3 * ( S + 8 ) * CH;
+        const int p = rem / ( ( S + 8 ) * CH ), o = rem - p * ( S + 8 ) * CH, r = o / CH, x0 = ( o - r * CH ) * 8;
+        const vtmhip_frac_job &j = jobs[job0 + jl];
+        const int qx = sCentre[jl][0] + ( p - 1 ) * step, ix = qx >> 2, fx = qx & 3;
+        const int16_t *cH = ( round == 0 && j.useAltHpelIf && fx == 2 ) ? c_lumaAltHpel : c_lumaFilter[fx << 2];
+        int ch[8];
 #pragma unroll
-      for( int k = 0; k < 8; k++ ) sum += ( int ) w[k] * ( int ) cH[k];
-      lds[jl * C::PERJOB + C::WIN + p * C::PLANE + o] = if_finish( sum, pH );
+        for( int k = 0; k < 8; k++ ) ch[k] = cH[k];
+        const IfParams pH = if_params( 1, 0, j.bitDepth, 0, ( 1 << j.bitDepth ) - 1, 0 );
+        // output x0+i needs window columns x0 + ix + 1 + i + (0..7): 16 samples from the 16-byte aligned column x0, shifted by ix + 1 in {0, 1}
+        const int4 *w4 = reinterpret_cast<const int4 *>( lds + jl * C::PERJOB + r * C::WLD + x0 );
+        const int4  a = w4[0], b = w4[1];
+        unsigned    d[8] = { ( unsigned ) a.x, ( unsigned ) a.y, ( unsigned ) a.z, ( unsigned ) a.w, ( unsigned ) b.x, ( unsigned ) b.y, ( unsigned ) b.z, ( unsigned ) b.w };
+        const unsigned sh = ( unsigned ) ( ix + 1 ) << 4;   // 0 or 16 bits
+#pragma unroll
+        for( int m = 0; m < 7; m++ ) d[m] = __builtin_amdgcn_alignbit( d[m + 1], d[m], sh );
+        d[7] = d[7] >> sh;
+        int v[16];
+#pragma unroll
+        for( int m = 0; m < 8; m++ ) { v[2 * m] = ( int ) ( short ) d[m]; v[2 * m + 1] = ( int ) d[m] >> 16; }
+        unsigned outw[4];
+#pragma unroll
+        for( int q = 0; q < 8; q++ )
+        {
+          int sum = 0;
+#pragma unroll
+          for( int k = 0; k < 8; k++ ) sum += v[q + k] * ch[k];
+          const unsigned hv = ( unsigned ) ( unsigned short ) if_finish( sum, pH );
+          if( q & 1 ) outw[q >> 1] |= hv << 16; else outw[q >> 1] = hv;
+        }
+        *reinterpret_cast<int4 *>( lds + jl * C::PERJOB + C::WIN + p * C::PLANE + r * S + x0 ) = make_int4( ( int ) outw[0], ( int ) outw[1], ( int ) outw[2], ( int ) outw[3] );
+      }
     }
     for( int i = tid; i < C::JPW * 16; i += C::BLOCK ) sCost[i] = 0;
     __syncthreads();
@@ -415,9 +442,10 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK ) void frac_search_sq_kernel( con
       for( int k = 0; k < 8; k++ ) cv[k] = cV[k];
       const int      ty = tile / ( S / 8 ), tx = tile - ty * ( S / 8 );
       const int16_t *pl = lds + jl * C::PERJOB + C::WIN + ( dx + 1 ) * C::PLANE + ( ty * 8 + iy + 1 ) * S + tx * 8;
+      const IfParams pV = if_params( 0, 1, j.bitDepth, 0, ( 1 << j.bitDepth ) - 1, 0 );
       int acc[64];
 #pragma unroll
-      for( int i = 0; i < 64; i++ ) acc[i] = 0;
+      for( int i = 0; i < 64; i++ ) acc[i] = pV.offset;
 #pragma unroll
       for( int r = 0; r < 15; r++ )
       {
@@ -434,8 +462,9 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK ) void frac_search_sq_kernel( con
             for( int x = 0; x < 8; x++ ) acc[y * 8 + x] += v[x] * cv[r - y];
           }
         }
+        __builtin_amdgcn_sched_barrier( 0 );   // keep the 15 row loads from being hoisted together (register pressure -> occupancy)
       }
-      const IfParams pV  = if_params( 0, 1, j.bitDepth, 0, ( 1 << j.bitDepth ) - 1, 0 );
+      // |sum of taps| <= 112 and |plane sample| <= 32768: (acc >> shift) fits 16 bits, so the reference's Pel truncation is the identity here
       const int16_t *org = orgBase + j.orgOff + ( long ) ( ty * 8 ) * j.orgStride + tx * 8;
       unsigned       d;
       if( j.useHad )
@@ -448,7 +477,7 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK ) void frac_search_sq_kernel( con
           for( int x = 0; x < 8; x++ )
           {
             const int ov   = ( x & 1 ) ? ( int ) o.v[x >> 1] >> 16 : ( int ) ( short ) o.v[x >> 1];
-            acc[y * 8 + x] = ov - ( int ) if_finish( acc[y * 8 + x], pV );
+            acc[y * 8 + x] = ov - min( pV.cmax, max( 0, acc[y * 8 + x] >> pV.shift ) );
           }
         }
 #pragma unroll
@@ -472,7 +501,7 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK ) void frac_search_sq_kernel( con
           for( int x = 0; x < 8; x++ )
           {
             const int ov = ( x & 1 ) ? ( int ) o.v[x >> 1] >> 16 : ( int ) ( short ) o.v[x >> 1];
-            t += ( unsigned ) abs( ov - ( int ) if_finish( acc[y * 8 + x], pV ) );
+            t += ( unsigned ) abs( ov - min( pV.cmax, max( 0, acc[y * 8 + x] >> pV.shift ) ) );
           }
         }
         d = t;

@@ -315,17 +315,21 @@ class FrameHotPath(FrameME):
         return acc
 
     def alg_bytes(self):
-        """Algorithmic bytes per stage of one picture (SURVEY.md 8d figures; formulas in DESIGN.md section 5)."""
-        b = dict(tz=0, frac=0, bi_search=0, mc=0, resi=0)
-        b["tz"] = self.stats()[1]
+        """Algorithmic bytes per kernel family for one picture (SURVEY.md 8d per-unit figures):
+        tz    sum over searches of nEval * (4*W*H >> subShift)                       [SAD: 4*W*H >> subShift per candidate]
+        frac  per search: 6 H + 18 V filter passes (4 B per output sample) + 18 SATDs (256 B per 8x8 tile = 4 B per sample)
+        full  81 candidates * (4*W*H >> subShift)
+        mc    4 B per output sample of every filter pass (H pass on H+7 rows, V pass)
+        pelop 6 B per sample (two 2-byte reads, one 2-byte write)
+        tu    per sample: xT 6 + quant 8 + dequant 8 + xIT 6 + SSE 4 = 32 B"""
+        b = dict(tz=self.stats()[1], frac=0, full=0, mc=0, pelop=0, tu=0)
         for lvl in self.levels:
             s, npu, nt, ts = lvl["size"], lvl["npu"], lvl["ntu"] * lvl["nc"], lvl["ts"]
-            frac_job = 24 * (s + 8) * s + 144 * s * s           # 6 H + 18 V filter passes (4 B / output sample) + 18 SATDs (4 B / sample)
-            b["frac"] += 2 * npu * frac_job
-            ss = subshift_mode2(s, s)
-            b["bi_search"] += npu * (4 * ((2 * s + 7) * s) + 6 * s * s + 81 * (4 * s * s >> ss) + frac_job)   # MC + removeHighFreq + 81 SADs + frac
-            b["mc"] += npu * (3 * 4 * ((2 * s + 7) * s) + 2 * 6 * s * s)                                       # 3 MC + addAvg + subtract
-            b["resi"] += nt * ts * ts * (6 + 8 + 8 + 6 + 4)                                                    # xT, quant, dequant, xIT, SSE
+            b["frac"] += 3 * npu * (24 * (s + 8) * s + 144 * s * s)
+            b["full"] += npu * 81 * (4 * s * s >> subshift_mode2(s, s))
+            b["mc"] += 4 * npu * 4 * ((2 * s + 7) * s)
+            b["pelop"] += 3 * npu * 6 * s * s
+            b["tu"] += nt * ts * ts * 32
         return b
 
     # ---- per-level stages ---------------------------------------------------------------------------------------------
@@ -374,7 +378,9 @@ class FrameHotPath(FrameME):
         mo.col("mvHor").copy_(sel(mvq_x, ol_) << 2)
         mo.col("mvVer").copy_(sel(mvq_y, ol_) << 2)
         ctx.mc_luma_batch(dpb_ptr, self.buf["pred_other"].data_ptr(), mo.ptr, npu, s, s)
+        self._mark("mc")
         ctx.remove_high_freq_batch(org_ptr, self.buf["pred_other"].data_ptr(), self.buf["org_bi"].data_ptr(), lvl["rhf"].ptr, npu)
+        self._mark("pelop")
         fu = lvl["full"]
         fu.col("refOff").copy_(ref_off(rl))
         fu.col("predHor").copy_(sel(pred_h, rl))
@@ -382,6 +388,7 @@ class FrameHotPath(FrameME):
         fu.col("centerHor").copy_(sel(mvq_x, rl) << 2)
         fu.col("centerVer").copy_(sel(mvq_y, rl) << 2)
         ctx.full_search_batch(lvl["pic_full"], self.buf["org_bi"].data_ptr(), dpb_ptr, fu.ptr, npu, lvl["full_res"].data_ptr())
+        self._mark("full")
         fb = lvl["frac_bi"]
         fb.col("refOff").copy_(ref_off(rl))
         fb.col("intX").copy_(lvl["full_res"][:, 0].to(T.int16))
@@ -389,7 +396,7 @@ class FrameHotPath(FrameME):
         fb.col("predHor").copy_(sel(pred_h, rl))
         fb.col("predVer").copy_(sel(pred_v, rl))
         ctx.frac_search_batch(self.buf["org_bi"].data_ptr(), dpb_ptr, fb.ptr, npu, s, s, lvl["frac_bi_res"].data_ptr(), uniform_square=True)
-        self._mark("bi_search")
+        self._mark("frac")
         b16 = lvl["frac_bi_res"].view(T.int16)
         cost_bi = lvl["frac_bi_res"].view(T.int64)[:, 1] >> 1   # the reference re-weights by 0.5 plus rate terms (:3483); mode decision is host work
         bi_x = (lvl["full_res"][:, 0] << 2) + (b16[:, 0].to(T.int32) << 1) + b16[:, 2].to(T.int32)
@@ -412,12 +419,13 @@ class FrameHotPath(FrameME):
             mb.col("mvHor").copy_(mvx_l[l] << 2)
             mb.col("mvVer").copy_(mvy_l[l] << 2)
             ctx.mc_luma_batch(dpb_ptr, self.buf[bufname].data_ptr(), mb.ptr, npu, s, s)
+        self._mark("mc")
         ctx.add_avg_batch(self.buf["p0"].data_ptr(), self.buf["p1"].data_ptr(), bi_ptr, lvl["avg"].ptr, npu)
         use_bi = cost_bi < T.minimum(c0, c1)
         sb = lvl["sub"]
         sb.col("bOff").copy_(lvl["blk_off"] + use_bi.to(T.int64) * self.npx)
         ctx.subtract_batch(org_ptr, uni_ptr, self.buf["resi"].data_ptr(), sb.ptr, npu)
-        self._mark("mc")
+        self._mark("pelop")
 
         # (5) residual coding per TU and transform candidate
         nt, ts = lvl["ntu"] * lvl["nc"], lvl["ts"]
@@ -432,7 +440,7 @@ class FrameHotPath(FrameME):
             ctx.dequant_batch(self.qcoef.data_ptr(), self.dqcoef.data_ptr(), lvl["quant"].ptr, nt)
             ctx.xIT_batch(self.dqcoef.data_ptr(), self.rec_resi.data_ptr(), lvl["xit"].ptr, nt, ts, ts)
             ctx.dist_batch(self.buf["resi"].data_ptr(), self.rec_resi.data_ptr(), lvl["sse"].ptr, nt, lvl["sse_out"].data_ptr())
-        self._mark("resi")
+        self._mark("tu")
         lvl["out"] = dict(mvq_x=mvq_x, mvq_y=mvq_y, cost_uni=cost_uni, rl=rl, bi_x=bi_x, bi_y=bi_y, cost_bi=cost_bi, use_bi=use_bi)
 
     def run(self, org_ptr, dpb_ptr, timing=False):
