@@ -334,9 +334,10 @@ typedef struct
   int32_t  absSum;          /* uiAbsSum of Quant::quant (cbf = absSum > 0) */
 } vtmhip_tu_result;
 
-/* d_levelsBase (quantised levels for the host's CABAC estimate) and d_recBase (reconstructed residual) may be NULL */
+/* d_levelsBase (quantised levels for the host's CABAC estimate) and d_recBase (reconstructed residual) may be NULL.
+ * uniformSize != 0: the caller guarantees every TU is exactly maxWidth x maxHeight (both >= 8) -> register-blocked kernel. */
 int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int maxWidth, int maxHeight,
-                               int32_t *d_levelsBase, int16_t *d_recBase, vtmhip_tu_result *d_results );
+                               int uniformSize, int32_t *d_levelsBase, int16_t *d_recBase, vtmhip_tu_result *d_results );
 
 /* ---- affine ME gradients: AffineGradientSearch::m_HorizontalSobelFilter / m_VerticalSobelFilter / m_EqualCoeffComputer -----------
  * (AffineGradientSearch.h:50-54, AffineGradientSearch.cpp:62-170; caller xAffineMotionEstimation, InterSearch.cpp:5340-5775) */

@@ -178,8 +178,8 @@ def test_quant_dequant_batch_matches_oracle(ctx):
         assert sm[k] == exp_sum[k], ("absSum", cases[k])
 
 
-@pytest.mark.parametrize("big", [False, True])
-def test_tu_chain_matches_oracle(ctx, big):
+@pytest.mark.parametrize("big,uniform", [(False, False), (True, False), (False, True), (True, True)])
+def test_tu_chain_matches_oracle(ctx, big, uniform):
     """Fused xT -> quant -> dequant -> xIT -> SSE (one launch) vs the oracle's separate steps; all 2-D sizes and type pairs."""
     from vtm_amd.lib import TuJob, TuResult
     L = ol.oracle()
@@ -213,7 +213,7 @@ def test_tu_chain_matches_oracle(ctx, big):
     d_jobs = ctx.to_device(np.frombuffer(jobs, np.uint8))
     d_res = ctx.alloc(16 * n)
     d_lv, d_rec = ctx.to_device(np.zeros((n, 4096), np.int32)), ctx.to_device(np.zeros((n, 4096), np.int16))
-    if big:
+    if big and not uniform:
         ctx.tu_chain_batch(d_resi.ptr, d_jobs.ptr, n, 64, 64, d_res.ptr, d_lv.ptr, d_rec.ptr)
     else:
         # w*h <= 256 covers shapes from 64x4 to 4x64; one launch per shape (maxWidth x maxHeight sizes the LDS and picks 64 threads per TU)
@@ -225,7 +225,7 @@ def test_tu_chain_matches_oracle(ctx, big):
                 C.memmove(C.byref(sub[i]), C.byref(jobs[k]), C.sizeof(TuJob))
             d_sub = ctx.to_device(np.frombuffer(sub, np.uint8))
             d_r = ctx.alloc(16 * len(idx))
-            ctx.tu_chain_batch(d_resi.ptr, d_sub.ptr, len(idx), shape[0], shape[1], d_r.ptr, d_lv.ptr, d_rec.ptr)
+            ctx.tu_chain_batch(d_resi.ptr, d_sub.ptr, len(idx), shape[0], shape[1], d_r.ptr, d_lv.ptr, d_rec.ptr, uniform=uniform)
             acc[idx] = d_r.to_host(np.uint8).reshape(len(idx), 16)
         d_res = ctx.to_device(acc)
     res = (TuResult * n).from_buffer_copy(d_res.to_host(np.uint8).tobytes())

@@ -504,6 +504,205 @@ __global__ __launch_bounds__( 256 ) void tu_chain_kernel( const int16_t *__restr
   }
 }
 
+
+// ---- register-blocked fast path of the fused chain for batches of ONE TU size (W, H >= 8) --------------------------------------
+// Every pass is out[r][c] = sum_n A(r, n) * B[n][c] with B = the core matrix in the orientation that makes B[n][c .. c+7]
+// contiguous (forward: transposed, inverse: plain).  A lane owns 8 consecutive outputs of one row: per inner step it needs ONE
+// 32-bit LDS read of A and ONE 128-bit LDS read of B for 8 multiply-adds (the simple kernel above needs two LDS reads per
+// multiply-add and is LDS-issue bound).  LPT lanes share one TU; 256 / LPT TUs per workgroup; matrices staged once per workgroup.
+//
+// 24-bit multiplies are exact here: every B entry is a matrix coefficient (|m| <= 91) and every A value is bounded by 2^23 --
+// residuals / clipped coefficients are 16-bit and the first forward pass of 16-bit input stays below (sum|m| * 32768) >> shift1
+// < 2^23 for every size and bit depth >= 8.  v_mad_i32_i24 issues at full rate, v_mul_lo_u32 at a quarter of it.
+template<int LPT>
+__device__ __forceinline__ void tuq_sync()
+{
+  if( LPT <= 64 ) { __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier(); }
+  else __syncthreads();
+}
+
+// rows x cols outputs (cols multiple of 8); rEff / cEff: outputs beyond them are zero (zero-out); inner: summation length
+template<int LPT, bool CLIP>
+__device__ __forceinline__ void tuq_pass( const int *A, int aRowStride, int aColStride, const int16_t *B, int ldb, int inner, int rows, int cols,
+                                          int rEff, int cEff, int *out, int oRowStride, int oColStride, int shift, int t, long long *sumAbs )
+{
+  const int cb = cols >> 3, rnd = shift > 0 ? 1 << ( shift - 1 ) : 0;
+  for( int it = t; it < rows * cb; it += LPT )
+  {
+    const int r = it / cb, c0 = ( it - r * cb ) << 3;
+    int       acc[8];
+#pragma unroll
+    for( int i = 0; i < 8; i++ ) acc[i] = rnd;
+    if( r < rEff && c0 < cEff )
+    {
+      const int *a = A + r * aRowStride;
+      for( int n = 0; n < inner; n++ )
+      {
+        const int  av = a[n * aColStride];
+        const int4 bv = *reinterpret_cast<const int4 *>( B + n * ldb + c0 );
+        acc[0] += __mul24( av, ( int ) ( short ) bv.x ); acc[1] += __mul24( av, bv.x >> 16 );
+        acc[2] += __mul24( av, ( int ) ( short ) bv.y ); acc[3] += __mul24( av, bv.y >> 16 );
+        acc[4] += __mul24( av, ( int ) ( short ) bv.z ); acc[5] += __mul24( av, bv.z >> 16 );
+        acc[6] += __mul24( av, ( int ) ( short ) bv.w ); acc[7] += __mul24( av, bv.w >> 16 );
+      }
+    }
+#pragma unroll
+    for( int i = 0; i < 8; i++ )
+    {
+      int v = ( r < rEff && c0 + i < cEff ) ? acc[i] >> shift : 0;
+      if( CLIP ) v = min( 32767, max( -32768, v ) );
+      out[r * oRowStride + ( c0 + i ) * oColStride] = v;
+      if( sumAbs ) *sumAbs += abs( v );
+    }
+  }
+}
+
+template<int LPT>
+__global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__restrict__ resiBase, const vtmhip_tu_job *__restrict__ jobs, int numJobs,
+                                                             TrTables tabs, int *__restrict__ levelsBase, int16_t *__restrict__ recBase,
+                                                             vtmhip_tu_result *__restrict__ results, int w, int h )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int ldsw[];
+  __shared__ long long sRed[4][3];
+  constexpr int TUS = 256 / LPT;
+  const int     sub = threadIdx.x / LPT, t = threadIdx.x - sub * LPT;
+  const int     perTu = w * h + w * ( h + 1 ) + ( ( w * h + 1 ) >> 1 );   // ints: blk, tmp, residual copy
+  int16_t      *sMat = ( int16_t * ) ( ldsw + TUS * perTu );              // [dim][type][orientation][N*N]
+  const int     lw = ilog2( w ), lh = ilog2( h );
+  for( int ty = 0; ty < 3; ty++ )
+  {
+    const int16_t *mw = tabs.m[ty][lw], *mh = tabs.m[ty][lh];
+    if( mw )
+      for( int i = threadIdx.x; i < w * w; i += 256 )
+      {
+        const int k = i / w, n = i - k * w;
+        sMat[( ty * 2 + 0 ) * w * w + i]         = mw[i];
+        sMat[( ty * 2 + 1 ) * w * w + n * w + k] = mw[i];
+      }
+    if( mh )
+      for( int i = threadIdx.x; i < h * h; i += 256 )
+      {
+        const int k = i / h, n = i - k * h;
+        sMat[6 * w * w + ( ty * 2 + 0 ) * h * h + i]         = mh[i];
+        sMat[6 * w * w + ( ty * 2 + 1 ) * h * h + n * h + k] = mh[i];
+      }
+  }
+  __syncthreads();
+  const int  jobIdx = blockIdx.x * TUS + sub;
+  const bool live   = jobIdx < numJobs;   // LPT <= 64: dead groups are whole waves or idle lane groups that only meet at the barriers
+  vtmhip_tu_job j;
+  if( live ) j = jobs[jobIdx];
+  else { j = jobs[numJobs - 1]; }
+  const int      bd = j.bitDepth;
+  int           *blk = ldsw + sub * perTu, *tmp = blk + w * h;
+  int16_t       *sR  = ( int16_t * ) ( tmp + w * ( h + 1 ) );
+  const int16_t *mW = sMat + ( j.typeHor * 2 ) * w * w, *mH = sMat + 6 * w * w + ( j.typeVer * 2 ) * h * h;
+  const int16_t *resi = resiBase + j.resiOff;
+  for( int i = t; i < w * h; i += LPT )
+  {
+    const int y = i / w, x = i - y * w;
+    const int16_t v = resi[( long ) y * j.resiStride + x];
+    blk[i] = v;
+    sR[i]  = v;
+  }
+  const int skipW = tr_skip( j.typeHor, w ), skipH = tr_skip( j.typeVer, h );
+  long long sumAbs = 0, absSum = 0, sse = 0;
+  tuq_sync<LPT>();
+  // forward (TrQuant::xT): tmp[k][y] = sum_n blk[y][n] * MT_hor[n][k];  blk[k2][j2] = sum_n tmp[j2][n] * MT_ver[n][k2]
+  tuq_pass<LPT, false>( blk, w, 1, mW + w * w, w, w, h, w, h, w - skipW, tmp, 1, h + 1, lw + bd + 6 - 15, t, nullptr );
+  tuq_sync<LPT>();
+  tuq_pass<LPT, false>( tmp, h + 1, 1, mH + h * h, h, h, w, h, w - skipW, h - skipH, blk, 1, w, lh + 6, t, &sumAbs );
+  tuq_sync<LPT>();
+  // Quant::quant + Quant::dequant (flat scaling list), in place
+  {
+    const int       needSqrt = ( lw + lh ) & 1;
+    const int       trShift  = 15 - bd - ( ( lw + lh ) >> 1 ) + ( needSqrt ? -1 : 0 );
+    const int       qBits    = 14 + j.qpPer + trShift;
+    const long long add      = ( long long ) ( j.isIRAP ? 171 : 85 ) << ( qBits - 9 );
+    const int       scale    = c_quantScales[needSqrt][j.qpRem], iscale = c_invQuantScales[needSqrt][j.qpRem];
+    const int       rightShift = 6 - ( trShift + j.qpPer );
+    const int       inBits   = min( 16, 32 + rightShift - 7 );
+    const int       inMin = -( 1 << ( inBits - 1 ) ), inMax = ( 1 << ( inBits - 1 ) ) - 1;
+    int            *levels   = ( levelsBase && live ) ? levelsBase + j.outOff : nullptr;
+    for( int i = t; i < w * h; i += LPT )
+    {
+      const int       c   = blk[i];
+      const long long tt  = ( long long ) abs( c ) * scale;
+      const int       mag = ( int ) ( ( tt + add ) >> qBits );
+      absSum += mag;
+      const int q = min( 32767, max( -32768, c < 0 ? -mag : mag ) );
+      if( levels ) levels[i] = q;
+      const int qq = min( inMax, max( inMin, q ) );
+      int       v;
+      if( rightShift > 0 ) v = ( int ) ( ( unsigned ) ( qq * iscale ) + ( 1u << ( rightShift - 1 ) ) ) >> rightShift;
+      else v = ( int ) ( ( unsigned ) ( qq * iscale ) << ( -rightShift ) );
+      blk[i] = min( 32767, max( -32768, v ) );
+    }
+  }
+  tuq_sync<LPT>();
+  // inverse (TrQuant::xIT): tmp[i][y] = clip( sum_k blk[k][i] * M_ver[k][y] );  rec[y][x] = clip( sum_k tmp[k][y] * M_hor[k][x] )
+  tuq_pass<LPT, true>( blk, 1, w, mH, h, h - skipH, w, h, w - skipW, h, tmp, h, 1, 7, t, nullptr );
+  tuq_sync<LPT>();
+  tuq_pass<LPT, true>( tmp, 1, h, mW, w, w - skipW, h, w, h, w, blk, w, 1, 20 - bd, t, nullptr );
+  tuq_sync<LPT>();
+  {
+    int16_t *rec = ( recBase && live ) ? recBase + j.outOff : nullptr;
+    for( int i = t; i < w * h; i += LPT )
+    {
+      const int v = blk[i];
+      if( rec ) rec[i] = ( int16_t ) v;
+      const int d = ( int ) sR[i] - v;
+      sse += ( long long ) ( unsigned long long ) ( ( unsigned ) d * ( unsigned ) d );
+    }
+  }
+  // reduce the three sums over the LPT lanes of the TU
+  if( LPT <= 64 )
+  {
+#pragma unroll
+    for( int o = 32; o > 0; o >>= 1 )
+      if( o < LPT )
+      {
+        sumAbs += __shfl_xor( sumAbs, o, 64 );
+        absSum += __shfl_xor( absSum, o, 64 );
+        sse += __shfl_xor( sse, o, 64 );
+      }
+    if( t == 0 && live ) { vtmhip_tu_result r; r.sse = ( uint64_t ) sse; r.sumAbs = ( int32_t ) sumAbs; r.absSum = ( int32_t ) absSum; results[jobIdx] = r; }
+  }
+  else
+  {
+    sumAbs = ( long long ) wave_reduce_add_u64( ( unsigned long long ) sumAbs );
+    absSum = ( long long ) wave_reduce_add_u64( ( unsigned long long ) absSum );
+    sse    = ( long long ) wave_reduce_add_u64( ( unsigned long long ) sse );
+    __syncthreads();
+    if( ( threadIdx.x & 63 ) == 0 ) { sRed[threadIdx.x >> 6][0] = sumAbs; sRed[threadIdx.x >> 6][1] = absSum; sRed[threadIdx.x >> 6][2] = sse; }
+    __syncthreads();
+    constexpr int WPT = LPT / 64;   // waves per TU
+    if( t == 0 && live )
+    {
+      vtmhip_tu_result r;
+      long long a0 = 0, a1 = 0, a2 = 0;
+      for( int k = 0; k < WPT; k++ ) { a0 += sRed[sub * WPT + k][0]; a1 += sRed[sub * WPT + k][1]; a2 += sRed[sub * WPT + k][2]; }
+      r.sumAbs = ( int32_t ) a0; r.absSum = ( int32_t ) a1; r.sse = ( uint64_t ) a2;
+      results[jobIdx] = r;
+    }
+  }
+}
+
+template<int LPT>
+int launch_tu_uni( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int w, int h, int32_t *d_levelsBase, int16_t *d_recBase,
+                   vtmhip_tu_result *d_results, const TrTables &tabs )
+{
+  constexpr int TUS   = 256 / LPT;
+  const size_t  perTu = ( size_t ) w * h + ( size_t ) w * ( h + 1 ) + ( ( w * h + 1 ) >> 1 );
+  const size_t  lds   = TUS * perTu * sizeof( int ) + ( size_t ) 6 * ( w * w + h * h ) * sizeof( int16_t );
+  if( lds > 64 * 1024 )
+    VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( tu_chain_uni_kernel<LPT> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
+  hipLaunchKernelGGL( tu_chain_uni_kernel<LPT>, dim3( ( n + TUS - 1 ) / TUS ), dim3( 256 ), lds, ctx->stream, d_resiBase, d_jobs, n, tabs, d_levelsBase, d_recBase,
+                      d_results, w, h );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
 bool pow2( int v ) { return v > 0 && ( v & ( v - 1 ) ) == 0; }
 int  hlog2( int v ) { int r = 0; while( ( 1 << r ) < v ) r++; return r; }
 
@@ -623,7 +822,7 @@ int vtmhip_dequant_batch_dev( vtmhip_ctx *ctx, const int32_t *d_qBase, int32_t *
 }
 
 int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int maxWidth, int maxHeight,
-                               int32_t *d_levelsBase, int16_t *d_recBase, vtmhip_tu_result *d_results )
+                               int uniformSize, int32_t *d_levelsBase, int16_t *d_recBase, vtmhip_tu_result *d_results )
 {
   VTMHIP_CHECK_CTX( ctx );
   VTMHIP_REQUIRE( ctx, n >= 0, "n" );
@@ -632,6 +831,18 @@ int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const
   VTMHIP_REQUIRE( ctx, maxWidth >= 2 && maxWidth <= TB && maxHeight >= 2 && maxHeight <= TB, "maxWidth / maxHeight: 2..64 (2-D transforms)" );
   int st = ensure_tables( ctx );
   if( st ) return st;
+  if( uniformSize && maxWidth >= 8 && maxHeight >= 8 )
+  {
+    // caller's promise: every TU is exactly maxWidth x maxHeight -> register-blocked kernel, LPT lanes per TU
+    const int      items = maxWidth * maxHeight / 8;
+    const TrTables &tb   = g_tabs[ctx->device & 15];
+    if( items <= 8 ) return launch_tu_uni<8>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
+    if( items <= 16 ) return launch_tu_uni<16>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
+    if( items <= 32 ) return launch_tu_uni<32>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
+    if( items <= 64 ) return launch_tu_uni<64>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
+    if( items <= 128 ) return launch_tu_uni<128>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
+    return launch_tu_uni<256>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
+  }
   const int    mx    = maxWidth > maxHeight ? maxWidth : maxHeight;
   const size_t perTu = ( size_t ) maxWidth * maxHeight + ( size_t ) maxWidth * ( maxHeight + 1 ) + ( ( mx * mx + 1 ) >> 1 ) + ( ( maxWidth * maxHeight + 1 ) >> 1 );
   if( maxWidth * maxHeight <= 256 )

@@ -189,8 +189,8 @@ class Context:
     def add_avg_batch(self, d_a, d_b, d_dst, d_jobs, n):
         self._check(self.L.vtmhip_add_avg_batch_dev(self.h, d_a, d_b, d_dst, d_jobs, n))
 
-    def tu_chain_batch(self, d_resi, d_jobs, n, max_w, max_h, d_results, d_levels=None, d_rec=None):
-        self._check(self.L.vtmhip_tu_chain_batch_dev(self.h, d_resi, d_jobs, n, max_w, max_h, d_levels, d_rec, d_results))
+    def tu_chain_batch(self, d_resi, d_jobs, n, max_w, max_h, d_results, d_levels=None, d_rec=None, uniform=False):
+        self._check(self.L.vtmhip_tu_chain_batch_dev(self.h, d_resi, d_jobs, n, max_w, max_h, int(uniform), d_levels, d_rec, d_results))
 
     def affine_sobel_batch(self, d_pred, d_deriv, d_jobs, n):
         self._check(self.L.vtmhip_affine_sobel_batch_dev(self.h, d_pred, d_deriv, d_jobs, n))

@@ -431,7 +431,7 @@ class FrameHotPath(FrameME):
         nt, ts = lvl["ntu"] * lvl["nc"], lvl["ts"]
         if self.fused_tu:
             # levels go to the host for the CABAC estimate in the real encoder; the bench keeps them in HBM
-            ctx.tu_chain_batch(self.buf["resi"].data_ptr(), lvl["tu"].ptr, nt, ts, ts, lvl["tu_res"].data_ptr(), self.qcoef.data_ptr(), None)
+            ctx.tu_chain_batch(self.buf["resi"].data_ptr(), lvl["tu"].ptr, nt, ts, ts, lvl["tu_res"].data_ptr(), self.qcoef.data_ptr(), None, uniform=True)
             r32 = lvl["tu_res"].view(T.int32)
             lvl["sse_out"], lvl["sum_abs"], lvl["abs_sum"] = lvl["tu_res"][:, 0], r32[:, 2], r32[:, 3]
         else:
