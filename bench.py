@@ -158,8 +158,8 @@ def main():
             stage_acc[k2] = stage_acc.get(k2, 0.0) + v / 3
     evals = fme.stats()[0]
     alg = fme.alg_bytes()
-    stages = {k2: {"ms": stage_acc[k2], "alg_GBps": alg[k2] / stage_acc[k2] / 1e6} for k2 in stage_acc}
-    dom = max(stage_acc, key=stage_acc.get)
+    stages = {k2: ({"ms": stage_acc[k2], "alg_GBps": alg[k2] / stage_acc[k2] / 1e6} if k2 in alg else {"ms": stage_acc[k2]}) for k2 in stage_acc}
+    dom = max((k2 for k2 in stage_acc if k2 in alg), key=stage_acc.get)
     dom_kernel = {"tz": "tz_search_kernel", "frac": "frac_search_sq_kernel", "full": "full_search_kernel", "mc": "mc_luma_kernel",
                   "pelop": "pelop_kernel", "tu": "tu_chain_kernel"}[dom]
     launches = {"tz": 1, "frac": 2, "full": 1, "mc": 4, "pelop": 3, "tu": 1}[dom] * len(fme.levels)

@@ -171,132 +171,153 @@ class _Tab:
 
 
 class FrameHotPath(FrameME):
-    """All stages for one picture with two reference pictures (list 0 / list 1), level by level:
+    """All stages for one picture with two reference pictures (list 0 / list 1):
 
-      tz      InterSearch::xTZSearch per (PU, list)                                   (InterSearch.cpp:3640-3976)
-      frac    xPatternSearchFracDIF per (PU, list): half + quarter refinement, SATD     (:4284-4339)
+      tz      InterSearch::xTZSearch per (PU, list), level by level (children start from the parent's vector)   (InterSearch.cpp:3640-3976)
+      frac    xPatternSearchFracDIF per (PU, list): half + quarter refinement, SATD                               (:4284-4339)
       bi      FEN bi-pred iteration (:2531-2680): refine the list with the LARGER uni cost: motion-compensate the other
               list, org' = 2*org - pred (removeHighFreq), +-4 exhaustive search (xPatternSearch), fractional search on org'
-      resi    final prediction (bi via addAvg when cheaper, else best uni) -> residual -> per TU (<= 64x64):
-              xT (DCT2 + 4 MTS candidates up to 32x32, with sum|coef| for the pre-selection) -> Quant::quant -> dequant -> xIT -> SSE
+      resi    final prediction (bi via addAvg when cheaper, else best uni) -> residual -> per TU (<= 64x64) and transform
+              candidate (DCT2 + 4 MTS candidates up to 32x32): xT -> Quant::quant -> dequant -> xIT -> SSE (one fused launch per level)
     Mode decision between the candidates, CABAC bit estimation and DepQuant stay on the host (out of scope, SURVEY.md 8a);
     every MTS candidate is taken through the whole chain (the reference prunes with the sum|coef| threshold).
+
+    STAGE-MAJOR execution: the integer search runs level by level (parent -> child dependence); every later stage is one
+    launch per level over job tables that are concatenated across levels, so the on-device bookkeeping between stages
+    (list choice, vector arithmetic, job patching -- a few dozen tiny tensor ops) happens once per picture, not per level.
     """
 
     def __init__(self, ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda=8.0, qp=32, fused_tu=True, **kw):
-        assert len(refs) == 2
-        self.fused_tu = fused_tu
+        assert len(refs) == 2 and refs[0][1] == refs[1][1]
         super().__init__(ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda, **kw)
+        self.fused_tu = fused_tu
         self.refs, self.org_stride, self.lam = refs, org_stride, motion_lambda
         base_qp = qp + 12   # 10-bit: qpBdOffset = 12 (Quant.cpp:65-104)
         self.qp_per, self.qp_rem = base_qp // 6, base_qp % 6
-        T, dev = torch, device
-        max_samples = 0
+        T, dev, rs = torch, device, refs[0][1]
+
+        # ---- concatenate the per-level TZ tables so that every later stage sees one table ----------------------------------
+        NP = sum(l["n"] // 2 for l in self.levels)
+        self.NP = NP
+        self.tz_jobs_all = T.cat([l["jobs"] for l in self.levels])            # [2*NP, 208] rows: per level [list0 PUs | list1 PUs]
+        self.tz_res_all = T.zeros((2 * NP, 8), dtype=T.int32, device=dev)
+        row0, row1, pos, blk, sizes = [], [], [], [], []
+        pb, sb = 0, 0
         for lvl in self.levels:
             s, npu = lvl["size"], lvl["n"] // 2
-            jobs = lvl["jobs"].cpu().numpy().view(TZ_DT).reshape(-1)
-            xs, ys = jobs["puX"][:npu].astype(np.int64), jobs["puY"][:npu].astype(np.int64)
-            blk = np.arange(npu, dtype=np.int64) * s * s
-            lvl["npu"] = npu
+            lvl["npu"], lvl["pb"], lvl["sb"] = npu, pb, sb
+            lvl["jobs"] = self.tz_jobs_all[2 * pb:2 * pb + 2 * npu]           # views: launches and parent patching act on the big table
+            lvl["res"] = self.tz_res_all[2 * pb:2 * pb + 2 * npu]
             lvl["pic_full"] = PicParams(pic_w, pic_h, 128, 10, FULL_WAVES_PER_JOB.get(s, 1))
-            lvl["ref_base"] = T.tensor([r[0] for r in refs], dtype=T.int64, device=dev)
-            lvl["pos_off"] = [T.from_numpy(ys * r[1] + xs).to(dev) for r in refs]   # block offset inside each reference plane
-            ref_strides = [r[1] for r in refs]
-            assert ref_strides[0] == ref_strides[1]
-            rs = ref_strides[0]
+            jn = lvl["jobs"].cpu().numpy().view(TZ_DT).reshape(-1)
+            xs, ys = jn["puX"][:npu].astype(np.int64), jn["puY"][:npu].astype(np.int64)
+            lvl["xs"], lvl["ys"] = xs, ys
+            row0.append(2 * pb + np.arange(npu))
+            row1.append(2 * pb + npu + np.arange(npu))
+            pos.append(ys * rs + xs)
+            blk.append(sb + np.arange(npu, dtype=np.int64) * s * s)
+            sizes.append(np.full(npu, s))
+            pb += npu
+            sb += npu * s * s
+        self.NS = sb                                                            # samples of one full-coverage buffer (all levels)
+        row0, row1, pos, blk, sizes = (np.concatenate(a) for a in (row0, row1, pos, blk, sizes))
+        xs_all = np.concatenate([l["xs"] for l in self.levels])
+        ys_all = np.concatenate([l["ys"] for l in self.levels])
+        self.row0, self.row1 = T.from_numpy(row0).to(dev), T.from_numpy(row1).to(dev)
+        self.pos, self.blk_off = T.from_numpy(pos).to(dev), T.from_numpy(blk).to(dev)
+        self.ref_base = T.tensor([r[0] for r in refs], dtype=T.int64, device=dev)
+        tzj = self.tz_jobs_all.cpu().numpy().view(TZ_DT).reshape(-1)
 
-            fj = np.zeros(2 * npu, FRAC_DT)
-            fj["orgOff"], fj["refOff"] = jobs["orgOff"], jobs["refOff"]
-            fj["orgStride"], fj["refStride"], fj["width"], fj["height"] = org_stride, rs, s, s
-            fj["motionLambda"], fj["useHad"], fj["bitDepth"] = motion_lambda, 1, 10
-            lvl["frac"] = _Tab(T, dev, fj)
-            lvl["frac_res"] = T.zeros((2 * npu, 16), dtype=T.uint8, device=dev)
+        fj = np.zeros(2 * NP, FRAC_DT)
+        fj["orgOff"], fj["refOff"] = tzj["orgOff"], tzj["refOff"]
+        fj["orgStride"], fj["refStride"], fj["width"], fj["height"] = org_stride, rs, tzj["width"], tzj["height"]
+        fj["motionLambda"], fj["useHad"], fj["bitDepth"] = motion_lambda, 1, 10
+        self.frac = _Tab(T, dev, fj)
+        self.frac_res = T.zeros((2 * NP, 16), dtype=T.uint8, device=dev)
 
-            mj = np.zeros(npu, MC_DT)
-            mj["dstOff"], mj["refStride"], mj["dstStride"], mj["width"], mj["height"], mj["bitDepth"] = blk, rs, s, s, s, 10
-            lvl["mc_other"] = _Tab(T, dev, mj)
+        mj = np.zeros(NP, MC_DT)
+        mj["dstOff"], mj["refStride"], mj["dstStride"], mj["width"], mj["height"], mj["bitDepth"] = blk, rs, sizes, sizes, sizes, 10
+        self.mc_other = _Tab(T, dev, mj)
+        self.mc_tabs = {}
+        for name, bi in (("mc_uni", 0), ("mc_b0", 1), ("mc_b1", 1)):
+            m2 = mj.copy()
+            m2["bi"] = bi
+            self.mc_tabs[name] = _Tab(T, dev, m2)
+        pj = np.zeros(NP, PEL_DT)
+        pj["aOff"], pj["aStride"] = ys_all * org_stride + xs_all, org_stride
+        pj["bOff"], pj["bStride"], pj["dstOff"], pj["dstStride"] = blk, sizes, blk, sizes
+        pj["width"], pj["height"], pj["bitDepth"] = sizes, sizes, 10
+        self.rhf = _Tab(T, dev, pj)
+        self.sub = _Tab(T, dev, pj.copy())      # bOff is patched to the chosen prediction
+        aj = np.zeros(NP, PEL_DT)
+        aj["aOff"], aj["bOff"], aj["dstOff"] = blk, blk, blk
+        aj["aStride"], aj["bStride"], aj["dstStride"], aj["width"], aj["height"], aj["bitDepth"] = sizes, sizes, sizes, sizes, sizes, 10
+        self.avg = _Tab(T, dev, aj)
+        uj = np.zeros(NP, FULL_DT)
+        uj["orgOff"], uj["orgStride"], uj["refStride"] = blk, sizes, rs
+        uj["puX"], uj["puY"], uj["width"], uj["height"] = xs_all, ys_all, sizes, sizes
+        uj["subShift"] = np.where((sizes > 8) & (sizes <= 64), 1, 0)
+        uj["signedSamples"], uj["motionLambda"], uj["searchRange"] = 1, motion_lambda, 4
+        self.full = _Tab(T, dev, uj)
+        self.full_res = T.zeros((NP, 8), dtype=T.int32, device=dev)
+        bj = np.zeros(NP, FRAC_DT)
+        bj["orgOff"], bj["orgStride"], bj["refStride"], bj["width"], bj["height"] = blk, sizes, rs, sizes, sizes
+        bj["motionLambda"], bj["useHad"], bj["bitDepth"] = motion_lambda, 1, 10
+        self.frac_bi = _Tab(T, dev, bj)
+        self.frac_bi_res = T.zeros((NP, 16), dtype=T.uint8, device=dev)
 
-            pj = np.zeros(npu, PEL_DT)
-            pj["aOff"], pj["aStride"] = ys * org_stride + xs, org_stride
-            pj["bOff"], pj["bStride"], pj["dstOff"], pj["dstStride"] = blk, s, blk, s
-            pj["width"], pj["height"], pj["bitDepth"] = s, s, 10
-            lvl["rhf"] = _Tab(T, dev, pj)
-            lvl["sub"] = _Tab(T, dev, pj.copy())   # bOff is patched to the chosen prediction
-            aj = np.zeros(npu, PEL_DT)
-            aj["aOff"], aj["bOff"], aj["dstOff"] = blk, blk, blk
-            aj["aStride"], aj["bStride"], aj["dstStride"], aj["width"], aj["height"], aj["bitDepth"] = s, s, s, s, s, 10
-            lvl["avg"] = _Tab(T, dev, aj)
-
-            uj = np.zeros(npu, FULL_DT)
-            uj["orgOff"], uj["orgStride"], uj["refStride"] = blk, s, rs
-            uj["puX"], uj["puY"], uj["width"], uj["height"] = xs, ys, s, s
-            uj["subShift"], uj["signedSamples"], uj["motionLambda"], uj["searchRange"] = subshift_mode2(s, s), 1, motion_lambda, 4
-            lvl["full"] = _Tab(T, dev, uj)
-            lvl["full_res"] = T.zeros((npu, 8), dtype=T.int32, device=dev)
-
-            bj = np.zeros(npu, FRAC_DT)
-            bj["orgOff"], bj["orgStride"], bj["refStride"], bj["width"], bj["height"] = blk, s, rs, s, s
-            bj["motionLambda"], bj["useHad"], bj["bitDepth"] = motion_lambda, 1, 10
-            lvl["frac_bi"] = _Tab(T, dev, bj)
-            lvl["frac_bi_res"] = T.zeros((npu, 16), dtype=T.uint8, device=dev)
-
-            for name, bi in (("mc_uni", 0), ("mc_b0", 1), ("mc_b1", 1)):
-                m2 = mj.copy()
-                m2["bi"] = bi
-                lvl[name] = _Tab(T, dev, m2)
-
-            # transform units: the PU itself up to 64x64, four 64x64 quadrants of a 128x128 PU (MaxTbSize 64)
+        # ---- transform units: the PU itself up to 64x64, four 64x64 quadrants of a 128x128 PU (MaxTbSize 64) ---------------
+        tu_tabs, legacy, tb, max_coef = [], [], 0, 0
+        for lvl in self.levels:
+            s, npu = lvl["size"], lvl["npu"]
             ts = min(s, 64)
             q = s // ts
-            tu_src, tu_stride = [], s
-            for qy in range(q):
-                for qx in range(q):
-                    tu_src.append(blk + qy * ts * s + qx * ts)
-            tu_src = np.stack(tu_src, 1).reshape(-1)                     # [npu * q*q]
+            blk_l = lvl["sb"] + np.arange(npu, dtype=np.int64) * s * s
+            tu_src = np.stack([blk_l + qy * ts * s + qx * ts for qy in range(q) for qx in range(q)], 1).reshape(-1)
             ntu = tu_src.size
             cands = MTS_CANDS if ts <= 32 else MTS_CANDS[:1]
             nc = len(cands)
-            tj = np.zeros(ntu * nc, TR_DT)
-            coef_off = np.arange(ntu * nc, dtype=np.int64) * ts * ts
-            tj["srcOff"] = np.tile(tu_src, nc)
-            tj["dstOff"], tj["srcStride"], tj["dstStride"], tj["width"], tj["height"], tj["bitDepth"] = coef_off, tu_stride, ts, ts, ts, 10
-            tj["typeHor"] = np.repeat([c[0] for c in cands], ntu)
-            tj["typeVer"] = np.repeat([c[1] for c in cands], ntu)
-            lvl["xt"] = _Tab(T, dev, tj)
-            ij = tj.copy()
-            ij["srcOff"], ij["dstOff"] = coef_off, coef_off              # dequantised coefficients -> reconstructed residual (contiguous per TU)
-            lvl["xit"] = _Tab(T, dev, ij)
-            qj = np.zeros(ntu * nc, Q_DT)
-            qj["srcOff"], qj["dstOff"], qj["width"], qj["height"] = coef_off, coef_off, ts, ts
-            qj["qpPer"], qj["qpRem"], qj["bitDepth"] = self.qp_per, self.qp_rem, 10
-            lvl["quant"] = _Tab(T, dev, qj)
-            dj = np.zeros(ntu * nc, DIST_DT)
-            dj["orgOff"], dj["curOff"], dj["orgStride"], dj["curStride"] = np.tile(tu_src, nc), coef_off, tu_stride, ts
-            dj["width"], dj["height"], dj["kind"] = ts, ts, _lib.DIST_SSE
-            lvl["sse"] = _Tab(T, dev, dj)
+            coef_off = np.arange(ntu * nc, dtype=np.int64) * ts * ts        # per-level arena (levels run one after the other)
             uj2 = np.zeros(ntu * nc, TU_DT)
-            uj2["resiOff"], uj2["outOff"], uj2["resiStride"], uj2["width"], uj2["height"] = np.tile(tu_src, nc), coef_off, tu_stride, ts, ts
+            uj2["resiOff"], uj2["outOff"], uj2["resiStride"], uj2["width"], uj2["height"] = np.tile(tu_src, nc), coef_off, s, ts, ts
             uj2["qpPer"], uj2["qpRem"], uj2["bitDepth"] = self.qp_per, self.qp_rem, 10
-            uj2["typeHor"], uj2["typeVer"] = tj["typeHor"], tj["typeVer"]
-            lvl["tu"] = _Tab(T, dev, uj2)
-            lvl["tu_res"] = T.zeros((ntu * nc, 2), dtype=T.int64, device=dev)   # vtmhip_tu_result: {sse u64, sumAbs i32, absSum i32}
-            lvl["ntu"], lvl["nc"], lvl["ts"] = ntu, nc, ts
-            lvl["sum_abs"] = T.zeros(ntu * nc, dtype=T.int32, device=dev)
-            lvl["abs_sum"] = T.zeros(ntu * nc, dtype=T.int32, device=dev)
-            lvl["sse_out"] = T.zeros(ntu * nc, dtype=T.int64, device=dev)
-            lvl["blk_off"] = T.from_numpy(blk).to(dev)
-            max_samples = max(max_samples, npu * s * s * nc)
-        npx = max(l["npu"] * l["size"] ** 2 for l in self.levels)
-        mk = lambda: T.zeros(npx, dtype=T.int16, device=dev)   # noqa: E731
-        self.buf = dict(pred_other=mk(), org_bi=mk(), pred_uni=mk(), p0=mk(), p1=mk(), pred_bi=mk(), resi=mk())
-        # one arena for the two selectable predictions so a job can address either with an offset
-        self.pred_sel = T.zeros(2 * npx, dtype=T.int16, device=dev)
-        self.npx = npx
-        self.coef = T.zeros(max_samples, dtype=T.int32, device=dev)
-        self.qcoef = T.zeros(max_samples, dtype=T.int32, device=dev)
-        self.dqcoef = T.zeros(max_samples, dtype=T.int32, device=dev)
-        self.rec_resi = T.zeros(max_samples, dtype=T.int16, device=dev)
-        self.out = []
+            uj2["typeHor"] = np.repeat([c[0] for c in cands], ntu)
+            uj2["typeVer"] = np.repeat([c[1] for c in cands], ntu)
+            tu_tabs.append(uj2)
+            lvl["ntu"], lvl["nc"], lvl["ts"], lvl["tb"] = ntu, nc, ts, tb
+            tb += ntu * nc
+            max_coef = max(max_coef, ntu * nc * ts * ts)
+            if not fused_tu:   # the five separate kernels (kept for A/B and as the non-fused parity path)
+                tj = np.zeros(ntu * nc, TR_DT)
+                tj["srcOff"], tj["dstOff"], tj["srcStride"], tj["dstStride"] = np.tile(tu_src, nc), coef_off, s, ts
+                tj["width"], tj["height"], tj["bitDepth"], tj["typeHor"], tj["typeVer"] = ts, ts, 10, uj2["typeHor"], uj2["typeVer"]
+                ij = tj.copy()
+                ij["srcOff"] = coef_off
+                qj = np.zeros(ntu * nc, Q_DT)
+                qj["srcOff"], qj["dstOff"], qj["width"], qj["height"] = coef_off, coef_off, ts, ts
+                qj["qpPer"], qj["qpRem"], qj["bitDepth"] = self.qp_per, self.qp_rem, 10
+                dj = np.zeros(ntu * nc, DIST_DT)
+                dj["orgOff"], dj["curOff"], dj["orgStride"], dj["curStride"] = np.tile(tu_src, nc), coef_off, s, ts
+                dj["width"], dj["height"], dj["kind"] = ts, ts, _lib.DIST_SSE
+                lvl["xt"], lvl["xit"], lvl["quant"], lvl["sse"] = (_Tab(T, dev, x) for x in (tj, ij, qj, dj))
+        self.tu = _Tab(T, dev, np.concatenate(tu_tabs))
+        self.tu_res = T.zeros((tb, 2), dtype=T.int64, device=dev)   # vtmhip_tu_result {sse u64, sumAbs i32, absSum i32}
+        for lvl in self.levels:
+            n_l = lvl["ntu"] * lvl["nc"]
+            r = self.tu_res[lvl["tb"]:lvl["tb"] + n_l]
+            lvl["sse_out"], lvl["sum_abs"], lvl["abs_sum"] = r[:, 0], r.view(T.int32)[:, 2], r.view(T.int32)[:, 3]
+            if not fused_tu:
+                lvl["sum_abs"] = T.zeros(n_l, dtype=T.int32, device=dev)
+                lvl["abs_sum"] = T.zeros(n_l, dtype=T.int32, device=dev)
+                lvl["sse_out"] = T.zeros(n_l, dtype=T.int64, device=dev)
+        mk = lambda n: T.zeros(n, dtype=T.int16, device=dev)   # noqa: E731
+        self.buf = dict(pred_other=mk(sb), org_bi=mk(sb), p0=mk(sb), p1=mk(sb), resi=mk(sb))
+        self.pred_sel = mk(2 * sb)     # [uni prediction | bi prediction]: a residual job addresses either with an offset
+        self.qcoef = T.zeros(max_coef, dtype=T.int32, device=dev)
+        if not fused_tu:
+            self.coef = T.zeros(max_coef, dtype=T.int32, device=dev)
+            self.dqcoef = T.zeros(max_coef, dtype=T.int32, device=dev)
+            self.rec_resi = T.zeros(max_coef, dtype=T.int16, device=dev)
         self._marks = None
 
     # ---- stage timing (HIP events on the launch stream; only when run(..., timing=True)) ----------------------------------
@@ -307,7 +328,7 @@ class FrameHotPath(FrameME):
             self._marks.append((name, e))
 
     def stage_ms(self):
-        """{stage: milliseconds} of the last timed run (call after a synchronize)."""
+        """{stage: milliseconds} of the last timed run (call after a synchronize); 'glue' = on-device bookkeeping between stages."""
         acc = {}
         for (n0, e0), (n1, e1) in zip(self._marks[:-1], self._marks[1:]):
             acc[n1] = acc.get(n1, 0.0) + e0.elapsed_time(e1)
@@ -332,119 +353,130 @@ class FrameHotPath(FrameME):
             b["tu"] += nt * ts * ts * 32
         return b
 
-    # ---- per-level stages ---------------------------------------------------------------------------------------------
-    def _level(self, i, org_ptr, dpb_ptr):
-        T, ctx, lvl = self.torch, self.ctx, self.levels[i]
-        s, npu = lvl["size"], lvl["npu"]
-        # (1) integer ME (parent predictors patched as in FrameME.run)
-        if lvl["parent"] is not None:
-            j32 = lvl["jobs"].view(T.int32)
-            pres = self.levels[i - 1]["res"]
-            p = lvl["parent"].clamp(min=0)
-            has = lvl["parent"] >= 0
-            mvx = T.where(has, pres[p, 0], T.zeros_like(pres[p, 0]))
-            mvy = T.where(has, pres[p, 1], T.zeros_like(pres[p, 1]))
-            j32[:, _J_MV_HOR], j32[:, _J_MV_VER] = mvx << 4, mvy << 4
-            j32[:, _J_PRED_HOR], j32[:, _J_PRED_VER] = mvx << 2, mvy << 2
-        ctx.tz_search_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["jobs"].data_ptr(), lvl["n"], lvl["res"].data_ptr())
+    def _per_level(self, fn):
+        for lvl in self.levels:
+            fn(lvl, lvl["pb"], lvl["npu"], lvl["size"])
+
+    def run(self, org_ptr, dpb_ptr, timing=False):
+        T, ctx, NP = self.torch, self.ctx, self.NP
+        self._marks = [] if timing else None
+        self._mark("start")
+        # (1) integer ME, coarse to fine
+        for i, lvl in enumerate(self.levels):
+            if lvl["parent"] is not None:
+                j32 = lvl["jobs"].view(T.int32)
+                pres = self.levels[i - 1]["res"]
+                p = lvl["parent"].clamp(min=0)
+                has = lvl["parent"] >= 0
+                mvx = T.where(has, pres[p, 0], T.zeros_like(pres[p, 0]))
+                mvy = T.where(has, pres[p, 1], T.zeros_like(pres[p, 1]))
+                j32[:, _J_MV_HOR], j32[:, _J_MV_VER] = mvx << 4, mvy << 4
+                j32[:, _J_PRED_HOR], j32[:, _J_PRED_VER] = mvx << 2, mvy << 2
+            ctx.tz_search_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["jobs"].data_ptr(), lvl["n"], lvl["res"].data_ptr())
         self._mark("tz")
-        tz = lvl["res"]
-        j32 = lvl["jobs"].view(T.int32)
+        tz = self.tz_res_all
+        j32 = self.tz_jobs_all.view(T.int32)
         pred_h, pred_v = j32[:, _J_PRED_HOR], j32[:, _J_PRED_VER]
 
         # (2) fractional ME per (PU, list)
-        fr = lvl["frac"]
+        fr = self.frac
         fr.col("intX").copy_(tz[:, 0].to(T.int16))
         fr.col("intY").copy_(tz[:, 1].to(T.int16))
         fr.col("predHor").copy_(pred_h)
         fr.col("predVer").copy_(pred_v)
-        ctx.frac_search_batch(org_ptr, dpb_ptr, fr.ptr, 2 * npu, s, s, lvl["frac_res"].data_ptr(), uniform_square=True)
+        self._mark("glue")
+        self._per_level(lambda l, pb, n, s: ctx.frac_search_batch(org_ptr, dpb_ptr, fr.ptr + 2 * pb * FRAC_DT.itemsize, 2 * n, s, s,
+                                                                  self.frac_res.data_ptr() + 2 * pb * 16, uniform_square=True))
         self._mark("frac")
-        fres16 = lvl["frac_res"].view(T.int16)
-        cost_uni = lvl["frac_res"].view(T.int64)[:, 1]
+        fres16 = self.frac_res.view(T.int16)
+        cost_uni = self.frac_res.view(T.int64)[:, 1]
         mvq_x = (tz[:, 0] << 2) + (fres16[:, 0].to(T.int32) << 1) + fres16[:, 2].to(T.int32)   # quarter-sample units
         mvq_y = (tz[:, 1] << 2) + (fres16[:, 1].to(T.int32) << 1) + fres16[:, 3].to(T.int32)
 
         # (3) bi-pred refinement of the list with the larger uni cost (FASTINTERSEARCH_MODE1: one iteration, :2544-2556)
-        c0, c1 = cost_uni[:npu], cost_uni[npu:]
-        rl = (c0 <= c1).to(T.int64)                    # list to refine
-        ol_ = 1 - rl                                    # the other list supplies the fixed prediction
-        idx = T.arange(npu, device=self.device)
-        sel = lambda a, l: a[l * npu + idx]            # noqa: E731
-        pos = T.stack(lvl["pos_off"])                  # [2, npu]
-        ref_off = lambda l: lvl["ref_base"][l] + pos[l, idx]   # noqa: E731
-        mo = lvl["mc_other"]
-        mo.col("refOff").copy_(ref_off(ol_))
-        mo.col("mvHor").copy_(sel(mvq_x, ol_) << 2)
-        mo.col("mvVer").copy_(sel(mvq_y, ol_) << 2)
-        ctx.mc_luma_batch(dpb_ptr, self.buf["pred_other"].data_ptr(), mo.ptr, npu, s, s)
+        c0, c1 = cost_uni[self.row0], cost_uni[self.row1]
+        rl = c0 <= c1                                                    # True: refine list 1
+        row_r, row_o = T.where(rl, self.row1, self.row0), T.where(rl, self.row0, self.row1)
+        off_r = T.where(rl, self.ref_base[1], self.ref_base[0]) + self.pos
+        off_o = T.where(rl, self.ref_base[0], self.ref_base[1]) + self.pos
+        mo = self.mc_other
+        mo.col("refOff").copy_(off_o)
+        mo.col("mvHor").copy_(mvq_x[row_o] << 2)
+        mo.col("mvVer").copy_(mvq_y[row_o] << 2)
+        fu = self.full
+        fu.col("refOff").copy_(off_r)
+        fu.col("predHor").copy_(pred_h[row_r])
+        fu.col("predVer").copy_(pred_v[row_r])
+        fu.col("centerHor").copy_(mvq_x[row_r] << 2)
+        fu.col("centerVer").copy_(mvq_y[row_r] << 2)
+        fb = self.frac_bi
+        fb.col("refOff").copy_(off_r)
+        fb.col("predHor").copy_(pred_h[row_r])
+        fb.col("predVer").copy_(pred_v[row_r])
+        self._mark("glue")
+        self._per_level(lambda l, pb, n, s: ctx.mc_luma_batch(dpb_ptr, self.buf["pred_other"].data_ptr(), mo.ptr + pb * MC_DT.itemsize, n, s, s))
         self._mark("mc")
-        ctx.remove_high_freq_batch(org_ptr, self.buf["pred_other"].data_ptr(), self.buf["org_bi"].data_ptr(), lvl["rhf"].ptr, npu)
+        self._per_level(lambda l, pb, n, s: ctx.remove_high_freq_batch(org_ptr, self.buf["pred_other"].data_ptr(), self.buf["org_bi"].data_ptr(),
+                                                                       self.rhf.ptr + pb * PEL_DT.itemsize, n))
         self._mark("pelop")
-        fu = lvl["full"]
-        fu.col("refOff").copy_(ref_off(rl))
-        fu.col("predHor").copy_(sel(pred_h, rl))
-        fu.col("predVer").copy_(sel(pred_v, rl))
-        fu.col("centerHor").copy_(sel(mvq_x, rl) << 2)
-        fu.col("centerVer").copy_(sel(mvq_y, rl) << 2)
-        ctx.full_search_batch(lvl["pic_full"], self.buf["org_bi"].data_ptr(), dpb_ptr, fu.ptr, npu, lvl["full_res"].data_ptr())
+        self._per_level(lambda l, pb, n, s: ctx.full_search_batch(l["pic_full"], self.buf["org_bi"].data_ptr(), dpb_ptr, fu.ptr + pb * FULL_DT.itemsize, n,
+                                                                  self.full_res.data_ptr() + pb * 32))
         self._mark("full")
-        fb = lvl["frac_bi"]
-        fb.col("refOff").copy_(ref_off(rl))
-        fb.col("intX").copy_(lvl["full_res"][:, 0].to(T.int16))
-        fb.col("intY").copy_(lvl["full_res"][:, 1].to(T.int16))
-        fb.col("predHor").copy_(sel(pred_h, rl))
-        fb.col("predVer").copy_(sel(pred_v, rl))
-        ctx.frac_search_batch(self.buf["org_bi"].data_ptr(), dpb_ptr, fb.ptr, npu, s, s, lvl["frac_bi_res"].data_ptr(), uniform_square=True)
+        fb.col("intX").copy_(self.full_res[:, 0].to(T.int16))
+        fb.col("intY").copy_(self.full_res[:, 1].to(T.int16))
+        self._mark("glue")
+        self._per_level(lambda l, pb, n, s: ctx.frac_search_batch(self.buf["org_bi"].data_ptr(), dpb_ptr, fb.ptr + pb * FRAC_DT.itemsize, n, s, s,
+                                                                  self.frac_bi_res.data_ptr() + pb * 16, uniform_square=True))
         self._mark("frac")
-        b16 = lvl["frac_bi_res"].view(T.int16)
-        cost_bi = lvl["frac_bi_res"].view(T.int64)[:, 1] >> 1   # the reference re-weights by 0.5 plus rate terms (:3483); mode decision is host work
-        bi_x = (lvl["full_res"][:, 0] << 2) + (b16[:, 0].to(T.int32) << 1) + b16[:, 2].to(T.int32)
-        bi_y = (lvl["full_res"][:, 1] << 2) + (b16[:, 1].to(T.int32) << 1) + b16[:, 3].to(T.int32)
+        b16 = self.frac_bi_res.view(T.int16)
+        cost_bi = self.frac_bi_res.view(T.int64)[:, 1] >> 1   # the reference re-weights by 0.5 plus rate terms (:3483); mode decision is host work
+        bi_x = (self.full_res[:, 0] << 2) + (b16[:, 0].to(T.int32) << 1) + b16[:, 2].to(T.int32)
+        bi_y = (self.full_res[:, 1] << 2) + (b16[:, 1].to(T.int32) << 1) + b16[:, 3].to(T.int32)
 
-        # (4) final prediction: best uni list, and the bi-prediction (addAvg of the two 14-bit MC outputs)
-        best_l = (c1 < c0).to(T.int64)
-        mu = lvl["mc_uni"]
-        mu.col("refOff").copy_(ref_off(best_l))
-        mu.col("mvHor").copy_(sel(mvq_x, best_l) << 2)
-        mu.col("mvVer").copy_(sel(mvq_y, best_l) << 2)
-        uni_ptr = self.pred_sel.data_ptr()
-        bi_ptr = uni_ptr + 2 * self.npx
-        ctx.mc_luma_batch(dpb_ptr, uni_ptr, mu.ptr, npu, s, s)
-        mvx_l = [T.where(rl == l, bi_x, mvq_x[l * npu:(l + 1) * npu]) for l in (0, 1)]   # refined list takes the bi vector
-        mvy_l = [T.where(rl == l, bi_y, mvq_y[l * npu:(l + 1) * npu]) for l in (0, 1)]
-        for l, name, bufname in ((0, "mc_b0", "p0"), (1, "mc_b1", "p1")):
-            mb = lvl[name]
-            mb.col("refOff").copy_(lvl["ref_base"][l] + pos[l])
-            mb.col("mvHor").copy_(mvx_l[l] << 2)
-            mb.col("mvVer").copy_(mvy_l[l] << 2)
-            ctx.mc_luma_batch(dpb_ptr, self.buf[bufname].data_ptr(), mb.ptr, npu, s, s)
-        self._mark("mc")
-        ctx.add_avg_batch(self.buf["p0"].data_ptr(), self.buf["p1"].data_ptr(), bi_ptr, lvl["avg"].ptr, npu)
+        # (4) final prediction: best uni list, and the bi-prediction (addAvg of the two 14-bit MC outputs); residual of the cheaper one
+        best1 = c1 < c0
+        row_b = T.where(best1, self.row1, self.row0)
+        mu = self.mc_tabs["mc_uni"]
+        mu.col("refOff").copy_(T.where(best1, self.ref_base[1], self.ref_base[0]) + self.pos)
+        mu.col("mvHor").copy_(mvq_x[row_b] << 2)
+        mu.col("mvVer").copy_(mvq_y[row_b] << 2)
+        for l, name, rw in ((0, "mc_b0", self.row0), (1, "mc_b1", self.row1)):
+            refined = rl if l == 1 else ~rl                                  # the refined list takes the bi vector
+            mb = self.mc_tabs[name]
+            mb.col("refOff").copy_(self.ref_base[l] + self.pos)
+            mb.col("mvHor").copy_(T.where(refined, bi_x, mvq_x[rw]) << 2)
+            mb.col("mvVer").copy_(T.where(refined, bi_y, mvq_y[rw]) << 2)
         use_bi = cost_bi < T.minimum(c0, c1)
-        sb = lvl["sub"]
-        sb.col("bOff").copy_(lvl["blk_off"] + use_bi.to(T.int64) * self.npx)
-        ctx.subtract_batch(org_ptr, uni_ptr, self.buf["resi"].data_ptr(), sb.ptr, npu)
+        self.sub.col("bOff").copy_(self.blk_off + use_bi.to(T.int64) * self.NS)
+        self._mark("glue")
+        uni_ptr = self.pred_sel.data_ptr()
+        bi_ptr = uni_ptr + 2 * self.NS
+        self._per_level(lambda l, pb, n, s: ctx.mc_luma_batch(dpb_ptr, uni_ptr, mu.ptr + pb * MC_DT.itemsize, n, s, s))
+        self._per_level(lambda l, pb, n, s: ctx.mc_luma_batch(dpb_ptr, self.buf["p0"].data_ptr(), self.mc_tabs["mc_b0"].ptr + pb * MC_DT.itemsize, n, s, s))
+        self._per_level(lambda l, pb, n, s: ctx.mc_luma_batch(dpb_ptr, self.buf["p1"].data_ptr(), self.mc_tabs["mc_b1"].ptr + pb * MC_DT.itemsize, n, s, s))
+        self._mark("mc")
+        self._per_level(lambda l, pb, n, s: ctx.add_avg_batch(self.buf["p0"].data_ptr(), self.buf["p1"].data_ptr(), bi_ptr,
+                                                              self.avg.ptr + pb * PEL_DT.itemsize, n))
+        self._per_level(lambda l, pb, n, s: ctx.subtract_batch(org_ptr, uni_ptr, self.buf["resi"].data_ptr(), self.sub.ptr + pb * PEL_DT.itemsize, n))
         self._mark("pelop")
 
         # (5) residual coding per TU and transform candidate
-        nt, ts = lvl["ntu"] * lvl["nc"], lvl["ts"]
-        if self.fused_tu:
-            # levels go to the host for the CABAC estimate in the real encoder; the bench keeps them in HBM
-            ctx.tu_chain_batch(self.buf["resi"].data_ptr(), lvl["tu"].ptr, nt, ts, ts, lvl["tu_res"].data_ptr(), self.qcoef.data_ptr(), None, uniform=True)
-            r32 = lvl["tu_res"].view(T.int32)
-            lvl["sse_out"], lvl["sum_abs"], lvl["abs_sum"] = lvl["tu_res"][:, 0], r32[:, 2], r32[:, 3]
-        else:
-            ctx.xT_batch(self.buf["resi"].data_ptr(), self.coef.data_ptr(), lvl["xt"].ptr, nt, ts, ts, lvl["sum_abs"].data_ptr())
-            ctx.quant_batch(self.coef.data_ptr(), self.qcoef.data_ptr(), None, lvl["quant"].ptr, nt, lvl["abs_sum"].data_ptr())
-            ctx.dequant_batch(self.qcoef.data_ptr(), self.dqcoef.data_ptr(), lvl["quant"].ptr, nt)
-            ctx.xIT_batch(self.dqcoef.data_ptr(), self.rec_resi.data_ptr(), lvl["xit"].ptr, nt, ts, ts)
-            ctx.dist_batch(self.buf["resi"].data_ptr(), self.rec_resi.data_ptr(), lvl["sse"].ptr, nt, lvl["sse_out"].data_ptr())
+        for lvl in self.levels:
+            nt, ts = lvl["ntu"] * lvl["nc"], lvl["ts"]
+            if self.fused_tu:
+                # levels go to the host for the CABAC estimate in the real encoder; the bench keeps them in HBM
+                ctx.tu_chain_batch(self.buf["resi"].data_ptr(), self.tu.ptr + lvl["tb"] * TU_DT.itemsize, nt, ts, ts,
+                                   self.tu_res.data_ptr() + lvl["tb"] * 16, self.qcoef.data_ptr(), None, uniform=True)
+            else:
+                ctx.xT_batch(self.buf["resi"].data_ptr(), self.coef.data_ptr(), lvl["xt"].ptr, nt, ts, ts, lvl["sum_abs"].data_ptr())
+                ctx.quant_batch(self.coef.data_ptr(), self.qcoef.data_ptr(), None, lvl["quant"].ptr, nt, lvl["abs_sum"].data_ptr())
+                ctx.dequant_batch(self.qcoef.data_ptr(), self.dqcoef.data_ptr(), lvl["quant"].ptr, nt)
+                ctx.xIT_batch(self.dqcoef.data_ptr(), self.rec_resi.data_ptr(), lvl["xit"].ptr, nt, ts, ts)
+                ctx.dist_batch(self.buf["resi"].data_ptr(), self.rec_resi.data_ptr(), lvl["sse"].ptr, nt, lvl["sse_out"].data_ptr())
         self._mark("tu")
-        lvl["out"] = dict(mvq_x=mvq_x, mvq_y=mvq_y, cost_uni=cost_uni, rl=rl, bi_x=bi_x, bi_y=bi_y, cost_bi=cost_bi, use_bi=use_bi)
-
-    def run(self, org_ptr, dpb_ptr, timing=False):
-        self._marks = [] if timing else None
-        self._mark("start")
-        for i in range(len(self.levels)):
-            self._level(i, org_ptr, dpb_ptr)
+        # per-level views of every decision (what tests/cpu_chain.py and a host encoder read back)
+        for lvl in self.levels:
+            pb, n = lvl["pb"], lvl["npu"]
+            sl2, sl = slice(2 * pb, 2 * pb + 2 * n), slice(pb, pb + n)
+            lvl["out"] = dict(mvq_x=mvq_x[sl2], mvq_y=mvq_y[sl2], cost_uni=cost_uni[sl2], rl=rl[sl].to(T.int64), bi_x=bi_x[sl], bi_y=bi_y[sl],
+                              cost_bi=cost_bi[sl], use_bi=use_bi[sl])
