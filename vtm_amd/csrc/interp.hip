@@ -347,6 +347,7 @@ struct FracSq
   static constexpr int TILES = ( S / 8 ) * ( S / 8 );
   static constexpr int ITEMS = 9 * TILES;                       // per PU per round
   static constexpr int BLOCK = S == 32 ? 192 : 256;
+  static constexpr int MINW  = ( S == 32 || S == 64 ) ? 3 : 4;   // waves per SIMD the register budget is sized for (32 / 64 spill at 128 VGPRs)
   static constexpr int JPW   = ITEMS >= BLOCK ? 1 : BLOCK / ITEMS;   // S = 8: 28, 16: 7, 32: 1 (144 of 192 lanes), 64 / 128: 1
   static constexpr int WLD   = S + 8;                           // window stride
   static constexpr int WIN   = ( S + 8 ) * WLD;                 // window samples per PU
@@ -356,7 +357,7 @@ struct FracSq
 };
 
 template<int S>
-__global__ __launch_bounds__( FracSq<S>::BLOCK, 4 ) void frac_search_sq_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+__global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_search_sq_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
                                                                             const vtmhip_frac_job *__restrict__ jobs, int numJobs,
                                                                             vtmhip_frac_result *__restrict__ results )
 {
@@ -383,6 +384,7 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, 4 ) void frac_search_sq_kernel( 
   for( int i = tid; i < C::JPW * 2; i += C::BLOCK ) sCentre[i >> 1][i & 1] = 0;
   __syncthreads();
 
+#pragma unroll 1
   for( int round = 0; round < 2; round++ )
   {
     const int step = round == 0 ? 2 : 1;
@@ -429,6 +431,7 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, 4 ) void frac_search_sq_kernel( 
     __syncthreads();
 
     // ---- phase V: one (PU, candidate, tile) item per lane ------------------------------------------------------------------
+#pragma unroll 1
     for( int it = tid; it < nj * C::ITEMS; it += C::BLOCK )
     {
       const int jl = it / C::ITEMS, rem = it - jl * C::ITEMS, cand = rem / C::TILES, tile = rem - cand * C::TILES;
