@@ -209,3 +209,53 @@ void ref_frac_search( const MeCtxC *c, int intX, int intY, int useHad, int useAl
 }
 
 }   // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Scalar quantisation through the REAL Quant::quant / Quant::dequant (CommonLib/Quant.cpp:955-1038, 357-482): a TransformUnit
+// with just the fields those members read (block size, mtsIdx, cu->qp / predMode, SPS bit depth, slice NAL type for
+// isIRAP, no sign-bit hiding, no explicit scaling lists).
+// ------------------------------------------------------------------------------------------------------------------
+#include "CommonLib/Quant.h"
+#include "CommonLib/Rom.h"
+#include "CommonLib/Contexts.h"
+
+extern "C" int ref_quant_dequant( const int32_t *coef, int w, int h, int bitDepth, int qp, int isIRAP, int32_t *qcoef, int32_t *absSum, int32_t *dqcoef )
+{
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  static bool   romInit = false;
+  static Quant *quant   = nullptr;
+  if( !romInit ) { initROM(); romInit = true; }
+  if( !quant ) { quant = new Quant( nullptr ); quant->init( 64, false, false, false ); }
+  r.sps.setBitDepth( CHANNEL_TYPE_LUMA, bitDepth );
+  r.sps.setBitDepth( CHANNEL_TYPE_CHROMA, bitDepth );
+  r.sps.setQpBDOffset( CHANNEL_TYPE_LUMA, 6 * ( bitDepth - 8 ) );
+  r.sps.setQpBDOffset( CHANNEL_TYPE_CHROMA, 6 * ( bitDepth - 8 ) );
+  r.sps.setInternalMinusInputBitDepth( CHANNEL_TYPE_LUMA, 0 );
+  r.slice.setNalUnitType( isIRAP ? NAL_UNIT_CODED_SLICE_IDR_W_RADL : NAL_UNIT_CODED_SLICE_TRAIL );
+  r.slice.setSignDataHidingEnabledFlag( false );
+  r.slice.setExplicitScalingListUsed( false );
+  r.slice.setSPS( &r.sps );
+  static TransformUnit *tu = nullptr;
+  if( !tu ) tu = new TransformUnit( UnitArea( CHROMA_400, Area( 0, 0, w, h ) ) );
+  tu->UnitArea::operator=( UnitArea( CHROMA_400, Area( 0, 0, w, h ) ) );
+  tu->cs = &r.cs;
+  tu->cu = &r.cu;
+  tu->chromaFormat = CHROMA_400;
+  tu->mtsIdx[0]    = MTS_DCT2_DCT2;
+  tu->noResidual   = false;
+  r.cu.qp = qp; r.cu.predMode = MODE_INTER; r.cu.lfnstIdx = 0; r.cu.colorTransform = false; r.cu.bdpcmMode = 0; r.cu.bdpcmModeChroma = 0;
+  r.cu.chromaQpAdj = 0; r.cu.treeType = TREE_D; r.cu.modeType = MODE_TYPE_ALL;
+  static TCoeff levels[64 * 64];
+  tu->m_coeffs[0] = levels;
+  const QpParam cQP( *tu, COMPONENT_Y );
+  CCoeffBuf src( coef, w, w, h );
+  TCoeff    sum = 0;
+  Ctx       ctx;
+  quant->quant( *tu, COMPONENT_Y, src, sum, cQP, ctx );
+  memcpy( qcoef, levels, sizeof( TCoeff ) * w * h );
+  *absSum = sum;
+  CoeffBuf dst( dqcoef, w, w, h );
+  quant->dequant( *tu, dst, COMPONENT_Y, cQP );
+  return 0;
+}

@@ -542,6 +542,7 @@ int vo_inv_2d( const int32_t *coef, int w, int h, int bitDepth, int typeHor, int
  * K10 Scalar quant / dequant, flat scaling list.  CommonLib/Quant.cpp:955-1038 (quant), :357-482 (dequant),
  * scales CommonLib/Rom.cpp:463-473, getTransformShift ChromaFormat.h:111-114,
  * TU::needsBlockSizeTrafoScale = (log2W + log2H) odd.  Sign-bit hiding is not restated (SBH needs the scan).
+ * Pinned against the real Quant::quant / Quant::dequant through oracle/ref_shim_me.cpp:ref_quant_dequant.
  * ------------------------------------------------------------------------------------------------ */
 static const int vo_quant_scales[2][6]     = { { 26214, 23302, 20560, 18396, 16384, 14564 }, { 18396, 16384, 14564, 13107, 11651, 10280 } };
 static const int vo_inv_quant_scales[2][6] = { { 40, 45, 51, 57, 64, 72 }, { 57, 64, 72, 80, 90, 102 } };
@@ -559,6 +560,9 @@ void vo_quant( const int32_t *coef, int w, int h, int bitDepth, int qpPer, int q
   int32_t   sum      = 0;
   for( int i = 0; i < w * h; i++ )
   {
+    /* the coefficient scan of blocks wider/taller than 32 only covers the 32x32 zero-out region (g_scanOrder is built for
+     * min(32, W) x min(32, H), Rom.cpp initROM): positions outside are never visited and keep level 0 (memset :1004) */
+    if( ( i % w ) >= 32 || ( i / w ) >= 32 ) { qcoef[i] = 0; if( deltaU ) deltaU[i] = 0; continue; }
     const int32_t c   = coef[i];
     const int64_t t   = ( int64_t ) vo_abs( c ) * scale;
     const int32_t mag = ( int32_t )( ( t + add ) >> qBits );

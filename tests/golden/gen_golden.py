@@ -216,6 +216,32 @@ def gen_misc():
     print("misc:", k, "cases")
 
 
+def gen_quant():
+    """Quant::quant / Quant::dequant (flat scaling list) through the TransformUnit rig of oracle/ref_shim_me.cpp."""
+    meta, coefs, qs, dqs, sums = [], [], [], [], []
+    for w in (4, 8, 16, 32, 64):
+        for h in (4, 8, 16, 32, 64):
+            for qp in (22, 32, 37, 51):
+                for irap in (0, 1):
+                    c = rng.integers(-32768, 32768, w * h).astype(np.int32)
+                    c[rng.random(w * h) < 0.6] //= 128
+                    # blocks wider / taller than 32: the transform zeroes everything outside the top-left 32x32 (TrQuant.cpp:790-805) and
+                    # Quant::quant walks a scan table that only covers that region (its loop bound is the full area, so it reads past the
+                    # table for such blocks -- harmless there because those coefficients are zero).  Golden inputs respect the zero-out.
+                    c2 = c.reshape(h, w)
+                    c2[32:, :] = 0
+                    c2[:, 32:] = 0
+                    q, d, s = np.zeros(w * h, np.int32), np.zeros(w * h, np.int32), C.c_int32()
+                    R.ref_quant_dequant(ol.P(c), w, h, 10, qp, irap, ol.P(q), C.byref(s), ol.P(d))
+                    meta.append((w, h, qp, irap, sum(a.size for a in coefs), s.value))
+                    coefs.append(c)
+                    qs.append(q)
+                    dqs.append(d)
+    np.savez_compressed(os.path.join(HERE, "quant.npz"), meta=np.array(meta, np.int64), coef=np.concatenate(coefs), q=np.concatenate(qs),
+                        dq=np.concatenate(dqs))
+    print("quant:", len(meta), "cases")
+
+
 if __name__ == "__main__":
     gen_dist()
     gen_mvcost()
@@ -223,3 +249,4 @@ if __name__ == "__main__":
     gen_tr()
     gen_me()
     gen_misc()
+    gen_quant()

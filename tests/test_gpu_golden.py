@@ -59,3 +59,24 @@ def test_motion_search_golden(ctx):
     fres = (FracResult * len(fj)).from_buffer_copy(d_fr.to_host(np.uint8).tobytes())
     gotf = np.array([(r.halfX, r.halfY, r.qterX, r.qterY, r.cost) for r in fres], np.int64)
     assert np.array_equal(gotf, z["frac_res"])
+
+
+def test_quant_golden(ctx):
+    """Quant::quant / dequant kernels vs vectors recorded from the real Quant (incl. 64-wide blocks: only the 32x32 region is scanned)."""
+    from vtm_amd.lib import QuantJob
+    z = np.load(os.path.join(G, "quant.npz"))
+    meta = z["meta"]
+    n = len(meta)
+    jobs = (QuantJob * n)()
+    for k, (w, h, qp, irap, o0, asum) in enumerate(meta):
+        bq = int(qp) + 12
+        j = jobs[k]
+        j.srcOff, j.dstOff, j.width, j.height, j.qpPer, j.qpRem, j.bitDepth, j.isIRAP = int(o0), int(o0), int(w), int(h), bq // 6, bq % 6, 10, int(irap)
+    d_c = ctx.to_device(z["coef"])
+    d_q, d_dq = ctx.to_device(np.zeros_like(z["q"])), ctx.to_device(np.zeros_like(z["dq"]))
+    d_jobs = ctx.to_device(np.frombuffer(jobs, np.uint8))
+    d_sum = ctx.alloc(4 * n, np.int32)
+    ctx.quant_batch(d_c.ptr, d_q.ptr, None, d_jobs.ptr, n, d_sum.ptr)
+    ctx.dequant_batch(d_q.ptr, d_dq.ptr, d_jobs.ptr, n)
+    assert np.array_equal(d_q.to_host(), z["q"]) and np.array_equal(d_dq.to_host(), z["dq"])
+    assert np.array_equal(d_sum.to_host().astype(np.int64), meta[:, 5])

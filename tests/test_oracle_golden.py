@@ -108,3 +108,15 @@ def test_misc_golden(oracle):
         av = np.zeros((h, w), np.int16)
         oracle.vo_add_avg(ol.P(z["a14_%d" % k]), w, ol.P(z["b14_%d" % k]), w, ol.P(av), w, w, h, 10)
         assert np.array_equal(av, z["avg_%d" % k])
+
+
+def test_quant_golden(oracle):
+    z = np.load(os.path.join(G, "quant.npz"))
+    for (w, h, qp, irap, o0, asum) in z["meta"]:
+        n = int(w * h)
+        c = np.ascontiguousarray(z["coef"][o0:o0 + n])
+        q, d, s = np.zeros(n, np.int32), np.zeros(n, np.int32), C.c_int32()
+        bq = int(qp) + 12
+        oracle.vo_quant(ol.P(c), int(w), int(h), 10, bq // 6, bq % 6, int(irap), 0, ol.P(q), None, C.byref(s))
+        oracle.vo_dequant(ol.P(q), int(w), int(h), 10, bq // 6, bq % 6, 0, ol.P(d))
+        assert np.array_equal(q, z["q"][o0:o0 + n]) and np.array_equal(d, z["dq"][o0:o0 + n]) and s.value == asum, (w, h, qp, irap)

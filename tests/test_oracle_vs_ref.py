@@ -155,3 +155,24 @@ def test_frac_and_full_search_equal_reference(oracle, reflib):
         oracle.vo_full_search(C.byref(c), C.byref(sr), C.byref(m))
         reflib.ref_full_search(C.byref(c), out, C.byref(r))
         assert (m.mvX, m.mvY, m.cost, m.dist) == (r.mvX, r.mvY, r.cost, r.dist)
+
+
+def test_quant_dequant_equal_reference(oracle, reflib):
+    """The real Quant::quant / Quant::dequant (flat scaling list, no SBH) through a minimal TransformUnit rig."""
+    rng = np.random.default_rng(204)
+    for w in (4, 8, 16, 32, 64):
+        for h in (4, 8, 16, 32, 64):
+            for qp in (22, 27, 32, 37, 45, 51):
+                for irap in (0, 1):
+                    c = rng.integers(-32768, 32768, w * h).astype(np.int32)
+                    c[rng.random(w * h) < 0.5] //= 64
+                    c2 = c.reshape(h, w)   # inputs respect the transform's zero-out (the reference's scan loop reads past its table otherwise)
+                    c2[32:, :] = 0
+                    c2[:, 32:] = 0
+                    q1, d1, q2, d2 = (np.zeros(w * h, np.int32) for _ in range(4))
+                    s1, s2 = C.c_int32(), C.c_int32()
+                    reflib.ref_quant_dequant(ol.P(c), w, h, 10, qp, irap, ol.P(q1), C.byref(s1), ol.P(d1))
+                    bq = qp + 12
+                    oracle.vo_quant(ol.P(c), w, h, 10, bq // 6, bq % 6, irap, 0, ol.P(q2), None, C.byref(s2))
+                    oracle.vo_dequant(ol.P(q2), w, h, 10, bq // 6, bq % 6, 0, ol.P(d2))
+                    assert np.array_equal(q1, q2) and np.array_equal(d1, d2) and s1.value == s2.value, (w, h, qp, irap)

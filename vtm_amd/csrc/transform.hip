@@ -289,6 +289,8 @@ __global__ __launch_bounds__( 256 ) void quant_kernel( const int *__restrict__ c
   int                    sum      = 0;
   for( int i = threadIdx.x; i < w * h; i += blockDim.x )
   {
+    // the reference's scan covers only the 32x32 zero-out region of larger blocks: positions outside keep level 0 (Quant.cpp:1004-1008)
+    if( ( i % w ) >= 32 || ( i / w ) >= 32 ) { q[i] = 0; if( deltaUBase ) deltaUBase[j.dstOff + i] = 0; continue; }
     const int       c   = coef[i];
     const long long t   = ( long long ) abs( c ) * scale;
     const int       mag = ( int ) ( ( t + add ) >> qBits );
