@@ -1,3 +1,4 @@
+# GPU box: parity tests + a short bench line.  usage: gpurun -- 'bash scripts/gpu_check.sh'
 set -e
 cd $GRAFT_REPO_ROOT
 python -m pytest tests -m gpu -q -x > gpurun_out/pl.txt 2>&1 || (grep -n "^E " gpurun_out/pl.txt | head -20; tail -5 gpurun_out/pl.txt; exit 1)

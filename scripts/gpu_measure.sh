@@ -1,3 +1,5 @@
+# GPU box: full bench line + rocprofv3 kernel trace + PMC passes.  usage: gpurun -- "bash scripts/gpu_measure.sh <tag>", then
+# python3 scripts/summarize_profiles.py <tag> here to condense gpurun_out/ into profiles/.
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
