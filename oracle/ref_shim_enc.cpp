@@ -1,0 +1,301 @@
+// TEST INFRASTRUCTURE ONLY -- encoder-level drop-in check.
+//
+// Runs the REAL reference encoder (EncApp / EncLib of VTM 9.3, compiled in place into oracle/_ref/libvtmref.so) and, when a
+// libvtmhip.so path is given, installs trampolines into the reference's own dispatch surface exactly where INTEGRATION.md
+// section 2 says a maintainer would:
+//   RdCost::m_afpDistortFunc[DF_SAD*, DF_HAD*, DF_SSE*]              (RdCost.h:113, RdCost.cpp:125-217)
+//   InterpolationFilter::m_filterHor / m_filterVer / m_filterCopy    (InterpolationFilter.h:93-95) of EncLib's InterSearch
+//   fastFwdTrans / fastInvTrans                                      (TrQuant.cpp:69-81)
+// A hooked call is routed to the device through the C ABI of include/vtmhip.h; its result is what the encoder continues with
+// (replace mode), and it is also compared with the reference's own function on the same arguments.  Only every `stride`-th
+// call per table slot goes to the device (the first `head` calls of each slot always do) so that a small encode stays within
+// a test's time budget; all other calls run the reference function untouched.
+//
+// The driver below follows the call order of the reference's own main() (App/EncoderApp/encmain.cpp:120-320):
+// initROM, EncApp::create, parseCfg, createLib, { encodePrep, encode } until eos, destroyLib, destroy, destroyROM.
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <utility>
+#include <vector>
+
+#include "EncoderLib/EncLibCommon.h"
+#include "EncApp.h"
+#include "CommonLib/RdCost.h"
+#include "CommonLib/TrQuant.h"
+#include "CommonLib/TrQuant_EMT.h"
+#include "CommonLib/InterpolationFilter.h"
+#include "CommonLib/Rom.h"
+#include "EncoderLib/EncLib.h"
+
+#include "../include/vtmhip.h"
+
+extern FwdTrans *fastFwdTrans[NUM_TRANS_TYPE][g_numTransformMatrixSizes];
+extern InvTrans *fastInvTrans[NUM_TRANS_TYPE][g_numTransformMatrixSizes];
+
+extern "C" {
+struct RefEncStats
+{
+  uint64_t calls[3];      // dist / interpolation / transform calls that went through a trampoline
+  uint64_t device[3];     // ... of which were executed on the device
+  uint64_t mismatch[3];   // device result != reference result
+  uint64_t errors;        // non-zero vtmhip status
+  int32_t  firstMismatch[8];
+  char     firstError[160]; // vtmhip_last_error() of the first failed call
+};
+}
+
+namespace
+{
+struct Api
+{
+  void *so = nullptr;
+  decltype( &vtmhip_create )       create;
+  decltype( &vtmhip_destroy )      destroy;
+  decltype( &vtmhip_last_error )   last_error;
+  decltype( &vtmhip_xGetSAD )      sad;
+  decltype( &vtmhip_xGetHADs )     had;
+  decltype( &vtmhip_xGetSSE )      sse;
+  decltype( &vtmhip_filterHor )    fhor;
+  decltype( &vtmhip_filterVer )    fver;
+  decltype( &vtmhip_filterCopy )   fcopy;
+  decltype( &vtmhip_fastFwdTrans ) fwd;
+  decltype( &vtmhip_fastInvTrans ) inv;
+} A;
+
+vtmhip_ctx  *g_ctx = nullptr;
+RefEncStats *g_st  = nullptr;
+uint64_t     g_stride = 1, g_head = 0;
+unsigned     g_mask = 7;
+bool         g_countOnly = false;   // familyMask bit 3: trampolines installed, nothing sent to the device (call census on a CPU-only box)
+
+template<class F> bool sym( F &f, const char *name ) { f = (F) dlsym( A.so, name ); return f != nullptr; }
+
+inline bool sampled( uint64_t &ctr )
+{
+  const uint64_t n = ctr++;
+  if( g_countOnly ) return false;
+  return n < g_head || ( n % g_stride ) == 0;
+}
+inline void note_error()
+{
+  if( g_st->errors++ == 0 ) { strncpy( g_st->firstError, A.last_error( g_ctx ), sizeof( g_st->firstError ) - 1 ); }
+}
+inline void note_mismatch( int family, int a, int b, int c, int d, long long ref, long long dev )
+{
+  if( g_st->mismatch[0] + g_st->mismatch[1] + g_st->mismatch[2] == 0 )
+  {
+    const int32_t v[8] = { family, a, b, c, d, (int32_t) ref, (int32_t) dev, 0 };
+    memcpy( g_st->firstMismatch, v, sizeof( v ) );
+  }
+  g_st->mismatch[family]++;
+}
+
+// ---- distortion ------------------------------------------------------------------------------------------------------------
+FpDistFunc g_distOrig[DF_TOTAL_FUNCTIONS];
+uint64_t   g_distCtr[DF_TOTAL_FUNCTIONS];
+
+template<int IDX> Distortion distTramp( const DistParam &p )
+{
+  constexpr int kind = ( IDX >= DF_HAD && IDX <= DF_HAD16N ) ? 1 : ( IDX >= DF_SSE && IDX <= DF_SSE16N ) ? 2 : 0;
+  g_st->calls[0]++;
+  // same guards as the x86 table entries (x86/RdCostX86.h:213,344,2157) -- what the device path does not cover stays on the host
+  if( p.applyWeight || p.useMR || p.step != 1 || p.mask != nullptr || p.bitDepth > 12 || ( kind != 0 && p.subShift != 0 ) || !sampled( g_distCtr[IDX] ) )
+  {
+    return g_distOrig[IDX]( p );
+  }
+  const Distortion ref = g_distOrig[IDX]( p );
+  uint64_t dev = 0;
+  const int w = p.org.width, h = p.org.height;
+  const int st = kind == 0 ? A.sad( g_ctx, p.org.buf, p.org.stride, p.cur.buf, p.cur.stride, w, h, p.subShift, &dev )
+               : kind == 1 ? A.had( g_ctx, p.org.buf, p.org.stride, p.cur.buf, p.cur.stride, w, h, &dev )
+                           : A.sse( g_ctx, p.org.buf, p.org.stride, p.cur.buf, p.cur.stride, w, h, &dev );
+  if( st != VTMHIP_OK ) { note_error(); return ref; }
+  g_st->device[0]++;
+  // the scalar SAD may stop early once it exceeds maximumDistortionForEarlyExit (RdCost.cpp:516-519); callers only compare '<'
+  const bool early = ref > p.maximumDistortionForEarlyExit && dev >= ref;
+  if( dev != ref && !early ) note_mismatch( 0, IDX, w, h, p.subShift, (long long) ref, (long long) dev );
+  return early ? ref : Distortion( dev );
+}
+template<int... I> void installDist( std::integer_sequence<int, I...> )
+{
+  static const FpDistFunc t[] = { distTramp<I>... };
+  for( int i = 0; i < DF_TOTAL_FUNCTIONS; i++ )
+  {
+    g_distOrig[i] = RdCost::m_afpDistortFunc[i];
+    const bool hook = ( i >= DF_SSE && i <= DF_SSE16N ) || ( i >= DF_SAD && i <= DF_SAD16N ) || ( i >= DF_HAD && i <= DF_HAD16N ) || ( i >= DF_SAD12 && i <= DF_SAD48 );
+    if( hook && ( g_mask & 1 ) ) RdCost::m_afpDistortFunc[i] = t[i];
+  }
+}
+void restoreDist() { for( int i = 0; i < DF_TOTAL_FUNCTIONS; i++ ) if( g_distOrig[i] ) RdCost::m_afpDistortFunc[i] = g_distOrig[i]; }
+
+// ---- interpolation ---------------------------------------------------------------------------------------------------------
+typedef void ( *IfFn )( const ClpRng &, Pel const *, int, Pel *, int, int, int, TFilterCoeff const *, bool );
+typedef void ( *IfCopyFn )( const ClpRng &, Pel const *, int, Pel *, int, int, int, bool );
+IfFn     g_ifOrig[2][3][2][2];
+IfCopyFn g_ifCopyOrig[2][2];
+uint64_t g_ifCtr[2][3][2][2], g_ifCopyCtr[2][2];
+std::vector<Pel> g_ifTmp;
+
+inline void compare_block( int family, int a, int b, const Pel *ref, int rs, const Pel *dev, int ds, int w, int h )
+{
+  for( int y = 0; y < h; y++ )
+    for( int x = 0; x < w; x++ )
+      if( ref[y * rs + x] != dev[y * ds + x] ) { note_mismatch( family, a, b, x, y, ref[y * rs + x], dev[y * ds + x] ); return; }
+}
+template<int VER, int TI, int FIRST, int LAST>
+void ifTramp( const ClpRng &c, Pel const *src, int ss, Pel *dst, int ds, int w, int h, TFilterCoeff const *coeff, bool biMC )
+{
+  g_st->calls[1]++;
+  g_ifOrig[VER][TI][FIRST][LAST]( c, src, ss, dst, ds, w, h, coeff, biMC );
+  if( !sampled( g_ifCtr[VER][TI][FIRST][LAST] ) ) return;
+  constexpr int taps = TI == 0 ? 8 : TI == 1 ? 4 : 2;
+  g_ifTmp.resize( size_t( w ) * h );
+  const int st = ( VER ? A.fver : A.fhor )( g_ctx, taps, FIRST, LAST, src, ss, g_ifTmp.data(), w, w, h, coeff, c.bd, c.min, c.max, biMC );
+  if( st != VTMHIP_OK ) { note_error(); return; }
+  g_st->device[1]++;
+  compare_block( 1, VER * 100 + TI * 10 + FIRST * 2 + LAST, w * 1000 + h, dst, ds, g_ifTmp.data(), w, w, h );
+  for( int y = 0; y < h; y++ ) memcpy( dst + y * ds, g_ifTmp.data() + y * w, sizeof( Pel ) * w );   // the encoder continues with the device output
+}
+template<int FIRST, int LAST>
+void ifCopyTramp( const ClpRng &c, Pel const *src, int ss, Pel *dst, int ds, int w, int h, bool biMC )
+{
+  g_st->calls[1]++;
+  g_ifCopyOrig[FIRST][LAST]( c, src, ss, dst, ds, w, h, biMC );
+  if( !sampled( g_ifCopyCtr[FIRST][LAST] ) ) return;
+  g_ifTmp.resize( size_t( w ) * h );
+  const int st = A.fcopy( g_ctx, FIRST, LAST, src, ss, g_ifTmp.data(), w, w, h, c.bd, c.min, c.max, biMC );
+  if( st != VTMHIP_OK ) { note_error(); return; }
+  g_st->device[1]++;
+  compare_block( 1, 900 + FIRST * 2 + LAST, w * 1000 + h, dst, ds, g_ifTmp.data(), w, w, h );
+  for( int y = 0; y < h; y++ ) memcpy( dst + y * ds, g_ifTmp.data() + y * w, sizeof( Pel ) * w );
+}
+template<int VER, int TI> void installIfSlot( InterpolationFilter &f )
+{
+  auto &tab = VER ? f.m_filterVer : f.m_filterHor;
+  g_ifOrig[VER][TI][0][0] = tab[TI][0][0]; tab[TI][0][0] = ifTramp<VER, TI, 0, 0>;
+  g_ifOrig[VER][TI][0][1] = tab[TI][0][1]; tab[TI][0][1] = ifTramp<VER, TI, 0, 1>;
+  g_ifOrig[VER][TI][1][0] = tab[TI][1][0]; tab[TI][1][0] = ifTramp<VER, TI, 1, 0>;
+  g_ifOrig[VER][TI][1][1] = tab[TI][1][1]; tab[TI][1][1] = ifTramp<VER, TI, 1, 1>;
+}
+void installIf( InterpolationFilter &f )
+{
+  installIfSlot<0, 0>( f ); installIfSlot<0, 1>( f ); installIfSlot<0, 2>( f );
+  installIfSlot<1, 0>( f ); installIfSlot<1, 1>( f ); installIfSlot<1, 2>( f );
+  g_ifCopyOrig[0][0] = f.m_filterCopy[0][0]; f.m_filterCopy[0][0] = ifCopyTramp<0, 0>;
+  g_ifCopyOrig[0][1] = f.m_filterCopy[0][1]; f.m_filterCopy[0][1] = ifCopyTramp<0, 1>;
+  g_ifCopyOrig[1][0] = f.m_filterCopy[1][0]; f.m_filterCopy[1][0] = ifCopyTramp<1, 0>;
+  g_ifCopyOrig[1][1] = f.m_filterCopy[1][1]; f.m_filterCopy[1][1] = ifCopyTramp<1, 1>;
+}
+
+// ---- transforms ------------------------------------------------------------------------------------------------------------
+FwdTrans *g_fwdOrig[NUM_TRANS_TYPE][g_numTransformMatrixSizes];
+InvTrans *g_invOrig[NUM_TRANS_TYPE][g_numTransformMatrixSizes];
+uint64_t  g_trCtr[2][NUM_TRANS_TYPE][g_numTransformMatrixSizes];
+std::vector<TCoeff> g_trTmp;
+
+template<int T, int L> void fwdTramp( const TCoeff *src, TCoeff *dst, int shift, int line, int skip1, int skip2 )
+{
+  g_st->calls[2]++;
+  g_fwdOrig[T][L]( src, dst, shift, line, skip1, skip2 );
+  if( !sampled( g_trCtr[0][T][L] ) ) return;
+  constexpr int n = 2 << L;
+  g_trTmp.assign( size_t( n ) * line, 0 );
+  if( A.fwd( g_ctx, T, n, src, g_trTmp.data(), shift, line, skip1, skip2 ) != VTMHIP_OK ) { note_error(); return; }
+  g_st->device[2]++;
+  // rows [n - skip2, n) of the transposed output are left to the caller's zero-out in some of the reference's butterflies; compare
+  // (and hand on) what the reference function defines: coefficient rows k < n - skip2, columns j < line - skip1
+  const int rows = n - skip2, cols = line - skip1;
+  for( int k = 0; k < rows; k++ )
+    for( int j = 0; j < cols; j++ )
+      if( dst[k * line + j] != g_trTmp[k * line + j] ) { note_mismatch( 2, T, n, line, k * line + j, dst[k * line + j], g_trTmp[k * line + j] ); k = rows; break; }
+  for( int k = 0; k < rows; k++ ) memcpy( dst + k * line, g_trTmp.data() + k * line, sizeof( TCoeff ) * cols );
+}
+template<int T, int L> void invTramp( const TCoeff *src, TCoeff *dst, int shift, int line, int skip1, int skip2, const TCoeff lo, const TCoeff hi )
+{
+  g_st->calls[2]++;
+  g_invOrig[T][L]( src, dst, shift, line, skip1, skip2, lo, hi );
+  if( !sampled( g_trCtr[1][T][L] ) ) return;
+  constexpr int n = 2 << L;
+  g_trTmp.assign( size_t( n ) * line, 0 );
+  if( A.inv( g_ctx, T, n, src, g_trTmp.data(), shift, line, skip1, skip2, lo, hi ) != VTMHIP_OK ) { note_error(); return; }
+  g_st->device[2]++;
+  const int rows = line - skip1;                               // output rows i < line - skip1, n samples each
+  for( int i = 0; i < rows * n; i++ )
+    if( dst[i] != g_trTmp[i] ) { note_mismatch( 2, 10 + T, n, line, i, dst[i], g_trTmp[i] ); break; }
+  memcpy( dst, g_trTmp.data(), sizeof( TCoeff ) * rows * n );
+}
+template<int T, int L> void installTrSlot()
+{
+  g_fwdOrig[T][L] = fastFwdTrans[T][L]; if( fastFwdTrans[T][L] ) fastFwdTrans[T][L] = fwdTramp<T, L>;
+  g_invOrig[T][L] = fastInvTrans[T][L]; if( fastInvTrans[T][L] ) fastInvTrans[T][L] = invTramp<T, L>;
+}
+template<int T> void installTrType() { installTrSlot<T, 0>(); installTrSlot<T, 1>(); installTrSlot<T, 2>(); installTrSlot<T, 3>(); installTrSlot<T, 4>(); installTrSlot<T, 5>(); }
+void installTr() { installTrType<DCT2>(); installTrType<DCT8>(); installTrType<DST7>(); }
+void restoreTr()
+{
+  for( int t = 0; t < NUM_TRANS_TYPE; t++ )
+    for( int l = 0; l < g_numTransformMatrixSizes; l++ )
+    {
+      if( g_fwdOrig[t][l] ) fastFwdTrans[t][l] = g_fwdOrig[t][l];
+      if( g_invOrig[t][l] ) fastInvTrans[t][l] = g_invOrig[t][l];
+    }
+}
+}   // namespace
+
+extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsigned familyMask, uint64_t stride, uint64_t head, RefEncStats *stats )
+{
+  memset( stats, 0, sizeof( *stats ) );
+  g_st = stats; g_stride = stride ? stride : 1; g_head = head; g_mask = familyMask; g_countOnly = ( familyMask & 8 ) != 0;
+  memset( g_distCtr, 0, sizeof( g_distCtr ) ); memset( g_ifCtr, 0, sizeof( g_ifCtr ) ); memset( g_ifCopyCtr, 0, sizeof( g_ifCopyCtr ) ); memset( g_trCtr, 0, sizeof( g_trCtr ) );
+  memset( g_distOrig, 0, sizeof( g_distOrig ) ); memset( g_fwdOrig, 0, sizeof( g_fwdOrig ) ); memset( g_invOrig, 0, sizeof( g_invOrig ) );
+  if( vtmhipPath && !g_countOnly )
+  {
+    A.so = dlopen( vtmhipPath, RTLD_NOW | RTLD_GLOBAL );
+    if( !A.so ) { fprintf( stderr, "ref_encode: %s\n", dlerror() ); return -10; }
+    const bool ok = sym( A.create, "vtmhip_create" ) && sym( A.destroy, "vtmhip_destroy" ) && sym( A.last_error, "vtmhip_last_error" ) && sym( A.sad, "vtmhip_xGetSAD" )
+                 && sym( A.had, "vtmhip_xGetHADs" ) && sym( A.sse, "vtmhip_xGetSSE" ) && sym( A.fhor, "vtmhip_filterHor" ) && sym( A.fver, "vtmhip_filterVer" )
+                 && sym( A.fcopy, "vtmhip_filterCopy" ) && sym( A.fwd, "vtmhip_fastFwdTrans" ) && sym( A.inv, "vtmhip_fastInvTrans" );
+    if( !ok ) { fprintf( stderr, "ref_encode: libvtmhip.so lacks a pointer-surface symbol\n" ); return -11; }
+    const int st = A.create( 0, &g_ctx );
+    if( st != VTMHIP_OK ) { fprintf( stderr, "ref_encode: vtmhip_create failed (%d) -- no CPU fallback\n", st ); return -12; }
+  }
+
+  int rc = 0;
+  std::fstream bitstream;
+  EncLibCommon common;
+  initROM();
+  TComHash::initBlockSizeToIndex();
+  EncApp *app = new EncApp( bitstream, &common );
+  app->create();
+  try
+  {
+    if( !app->parseCfg( argc, argv ) ) { rc = 1; }
+    else
+    {
+      app->createLib( 0 );
+      if( g_ctx || g_countOnly )
+      {
+        installDist( std::make_integer_sequence<int, DF_TOTAL_FUNCTIONS>() );
+        if( g_mask & 2 ) installIf( app->m_cEncLib.m_cInterSearch.m_if );
+        if( g_mask & 4 ) installTr();
+      }
+      bool eos = false;
+      while( !eos )
+      {
+        while( app->encodePrep( eos ) ) {}
+        while( app->encode() ) {}
+      }
+      app->destroyLib();
+    }
+  }
+  catch( Exception &e ) { fprintf( stderr, "ref_encode: %s\n", e.what() ); rc = 2; }
+  if( g_ctx || g_countOnly ) { restoreDist(); restoreTr(); }
+  app->destroy();
+  delete app;
+  destroyROM();
+  if( g_ctx ) { A.destroy( g_ctx ); g_ctx = nullptr; }
+  fflush( stdout );
+  return rc;
+}

@@ -11,6 +11,7 @@ from vtm_amd.lib import DistJob
 pytestmark = pytest.mark.gpu
 
 SIZES = [(w, h) for w in (4, 8, 12, 16, 24, 32, 48, 64, 128) for h in (4, 8, 16, 32, 64, 128)]
+SIZES += [(2, 2), (2, 4), (2, 8), (2, 32), (6, 4), (4, 2), (8, 2), (16, 2), (64, 2), (10, 6)]   # chroma / odd shapes the scalar reference accepts
 
 
 def test_pointer_surface_matches_oracle(ctx):
@@ -19,7 +20,7 @@ def test_pointer_surface_matches_oracle(ctx):
         org = ol.i16(rng.integers(-1023, 2047, (h, w + 7)))   # bi-pred ME target range
         cur = ol.i16(rng.integers(0, 1024, (h, w + 3)))
         for ss in (0, 1, 2):
-            if h >> ss < 1:
+            if h >> ss < 1 or h % (1 << ss):
                 continue
             assert ctx.xGetSAD(org, w + 7, cur, w + 3, w, h, ss) == ol.o_dist(0, org, cur, w, h, ss), (w, h, ss)
         assert ctx.xGetHADs(org, w + 7, cur, w + 3, w, h) == ol.o_dist(1, org, cur, w, h), (w, h)
@@ -44,7 +45,9 @@ def test_invalid_arguments_return_status(ctx):
     from vtm_amd.lib import VtmHipError
     a = np.zeros((8, 8), np.int16)
     with pytest.raises(VtmHipError):
-        ctx.xGetSAD(a, 8, a, 8, 6, 8)        # width not a multiple of 4 (the reference THROWs "Unsupported size")
+        ctx.xGetSAD(a, 8, a, 8, 0, 8)
+    with pytest.raises(VtmHipError):
+        ctx.xGetHADs(a, 8, a, 8, 5, 8)       # odd size: the reference THROWs "Invalid size" (RdCost.cpp:2925-2931)
     with pytest.raises(VtmHipError):
         ctx.xGetHADs(a, 8, a, 8, 256, 8)
 

@@ -25,6 +25,13 @@ def test_distortion_sweep(oracle, reflib):
                 assert ol.o_dist(2, org, cur, w, h) == ol.r_dist(2, 0, org, cur, w, h)
             for mode in (0, 1, 2, 3):
                 assert oracle.vo_subshift_for_mode(w, h, mode) == reflib.ref_subshift_for_mode(w, h, mode)
+    # chroma / small shapes (2-wide blocks, 2x2 Hadamard tiles) as the encoder's own calls have them
+    for (w, h) in ((2, 2), (2, 4), (2, 8), (2, 32), (4, 2), (8, 2), (16, 2), (64, 2)):
+        org = ol.i16(rng.integers(0, 1024, (h, w + 7)))
+        cur = ol.i16(rng.integers(0, 1024, (h, w + 3)))
+        assert ol.o_dist(0, org, cur, w, h, 0) == ol.r_dist(0, 1, org, cur, w, h, 10, 0)
+        assert ol.o_dist(1, org, cur, w, h) == ol.r_dist(1, 1, org, cur, w, h)
+        assert ol.o_dist(2, org, cur, w, h) == ol.r_dist(2, 1, org, cur, w, h)
 
 
 def test_satd8_grid_matches_reference_distfunc(oracle, reflib):

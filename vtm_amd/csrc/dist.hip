@@ -85,32 +85,55 @@ __global__ __launch_bounds__( 256 ) void dist_batch_kernel( const int16_t *__res
 
   if( j.kind == VTMHIP_DIST_SAD )
   {
-    // rows y = 0, step, 2*step ...; work items = (row, 4-sample segment)
+    // rows y = 0, step, 2*step ...; work items = (row, 4-sample segment), or single samples for widths like 2 / 6 (chroma)
     const int ss = j.subShift, rows = ( h + ( 1 << ss ) - 1 ) >> ss, segs = w >> 2;
     unsigned  s = 0;
-    for( int it = lane; it < rows * segs; it += 64 )
+    if( ( w & 3 ) == 0 )
     {
-      const int      r = it / segs, x = ( it - r * segs ) << 2;
-      const int16_t *o = org + ( long ) ( r << ss ) * os + x;
-      const int16_t *c = cur + ( long ) ( r << ss ) * cs + x;
+      for( int it = lane; it < rows * segs; it += 64 )
+      {
+        const int      r = it / segs, x = ( it - r * segs ) << 2;
+        const int16_t *o = org + ( long ) ( r << ss ) * os + x;
+        const int16_t *c = cur + ( long ) ( r << ss ) * cs + x;
 #pragma unroll
-      for( int k = 0; k < 4; k++ ) s += ( unsigned ) abs( ( int ) o[k] - ( int ) c[k] );
+        for( int k = 0; k < 4; k++ ) s += ( unsigned ) abs( ( int ) o[k] - ( int ) c[k] );
+      }
+    }
+    else
+    {
+      for( int it = lane; it < rows * w; it += 64 )
+      {
+        const int r = it / w, x = it - r * w;
+        s += ( unsigned ) abs( ( int ) org[( long ) ( r << ss ) * os + x] - ( int ) cur[( long ) ( r << ss ) * cs + x] );
+      }
     }
     acc = ( unsigned long long ) s << ss;   // per-lane partial (W*H*65535 < 2^32 for W,H <= 128 needs care: 128*128*65535 = 2^30)
   }
   else if( j.kind == VTMHIP_DIST_SSE )
   {
     const int segs = w >> 2;
-    for( int it = lane; it < h * segs; it += 64 )
+    if( ( w & 3 ) == 0 )
     {
-      const int      r = it / segs, x = ( it - r * segs ) << 2;
-      const int16_t *o = org + ( long ) r * os + x;
-      const int16_t *c = cur + ( long ) r * cs + x;
-#pragma unroll
-      for( int k = 0; k < 4; k++ )
+      for( int it = lane; it < h * segs; it += 64 )
       {
-        const int d = ( int ) o[k] - ( int ) c[k];
-        acc += ( unsigned long long ) ( ( unsigned ) d * ( unsigned ) d );   // per-addend 32-bit product as RdCost.cpp:1783-1814
+        const int      r = it / segs, x = ( it - r * segs ) << 2;
+        const int16_t *o = org + ( long ) r * os + x;
+        const int16_t *c = cur + ( long ) r * cs + x;
+#pragma unroll
+        for( int k = 0; k < 4; k++ )
+        {
+          const int d = ( int ) o[k] - ( int ) c[k];
+          acc += ( unsigned long long ) ( ( unsigned ) d * ( unsigned ) d );   // per-addend 32-bit product as RdCost.cpp:1783-1814
+        }
+      }
+    }
+    else
+    {
+      for( int it = lane; it < h * w; it += 64 )
+      {
+        const int r = it / w, x = it - r * w;
+        const int d = ( int ) org[( long ) r * os + x] - ( int ) cur[( long ) r * cs + x];
+        acc += ( unsigned long long ) ( ( unsigned ) d * ( unsigned ) d );
       }
     }
   }
@@ -204,8 +227,9 @@ __global__ __launch_bounds__( 256 ) void satd8_grid_kernel( const int16_t *__res
 
 int check_dist_args( vtmhip_ctx *ctx, int w, int h, int subShift, int kind )
 {
-  VTMHIP_REQUIRE( ctx, w >= 4 && h >= 4 && w <= 128 && h <= 128 && ( w & 3 ) == 0, "block size must be 4..128, width a multiple of 4" );
-  VTMHIP_REQUIRE( ctx, kind != VTMHIP_DIST_SATD || ( h & 1 ) == 0, "SATD needs even height" );
+  VTMHIP_REQUIRE( ctx, w >= 1 && h >= 1 && w <= 128 && h <= 128, "block size must be 1..128" );
+  VTMHIP_REQUIRE( ctx, kind != VTMHIP_DIST_SATD || ( ( ( w | h ) & 1 ) == 0 ), "SATD needs even width and height (RdCost.cpp:2925-2931: \"Invalid size\")" );
+  VTMHIP_REQUIRE( ctx, ( h & ( ( 1 << subShift ) - 1 ) ) == 0 || subShift == 0, "height must be a multiple of the row step" );
   VTMHIP_REQUIRE( ctx, subShift >= 0 && subShift <= 4 && ( kind == VTMHIP_DIST_SAD || subShift == 0 ), "subShift" );
   return VTMHIP_OK;
 }
