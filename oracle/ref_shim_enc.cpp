@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <algorithm>
 #include <utility>
 #include <vector>
 
@@ -37,9 +38,9 @@ extern InvTrans *fastInvTrans[NUM_TRANS_TYPE][g_numTransformMatrixSizes];
 extern "C" {
 struct RefEncStats
 {
-  uint64_t calls[3];      // dist / interpolation / transform calls that went through a trampoline
-  uint64_t device[3];     // ... of which were executed on the device
-  uint64_t mismatch[3];   // device result != reference result
+  uint64_t calls[4];      // dist / interpolation / transform / (buffer ops + affine gradients) calls through a trampoline
+  uint64_t device[4];     // ... of which were executed on the device
+  uint64_t mismatch[4];   // device result != reference result
   uint64_t errors;        // non-zero vtmhip status
   int32_t  firstMismatch[8];
   char     firstError[160]; // vtmhip_last_error() of the first failed call
@@ -62,6 +63,14 @@ struct Api
   decltype( &vtmhip_filterCopy )   fcopy;
   decltype( &vtmhip_fastFwdTrans ) fwd;
   decltype( &vtmhip_fastInvTrans ) inv;
+  decltype( &vtmhip_dev_alloc )    dalloc;
+  decltype( &vtmhip_dev_free )     dfree;
+  decltype( &vtmhip_h2d )          h2d;
+  decltype( &vtmhip_d2h )          d2h;
+  decltype( &vtmhip_add_avg_batch_dev )            addAvg;
+  decltype( &vtmhip_remove_high_freq_batch_dev )   rhf;
+  decltype( &vtmhip_affine_sobel_batch_dev )       sobel;
+  decltype( &vtmhip_affine_equal_coeff_batch_dev ) eqc;
 } A;
 
 vtmhip_ctx  *g_ctx = nullptr;
@@ -84,7 +93,7 @@ inline void note_error()
 }
 inline void note_mismatch( int family, int a, int b, int c, int d, long long ref, long long dev )
 {
-  if( g_st->mismatch[0] + g_st->mismatch[1] + g_st->mismatch[2] == 0 )
+  if( g_st->mismatch[0] + g_st->mismatch[1] + g_st->mismatch[2] + g_st->mismatch[3] == 0 )
   {
     const int32_t v[8] = { family, a, b, c, d, (int32_t) ref, (int32_t) dev, 0 };
     memcpy( g_st->firstMismatch, v, sizeof( v ) );
@@ -242,13 +251,134 @@ void restoreTr()
       if( g_invOrig[t][l] ) fastInvTrans[t][l] = g_invOrig[t][l];
     }
 }
+// ---- buffer ops (g_pelBufOP.addAvg4/8, removeHighFreq4/8: Buffer.h:64-81) and affine gradients (AffineGradientSearch.h:50-54) -----------
+// These have no host-pointer entry in the C ABI: the trampolines drive the batched device calls with a batch of one over device
+// buffers of the context (vtmhip_dev_alloc / h2d / d2h), which is what hook B5 / the affine hook of INTEGRATION.md section 3 do.
+constexpr int AUX_MAX = 128 * 128;
+int16_t *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;
+int32_t *d_deriv = nullptr;
+int64_t *d_eq = nullptr;
+void    *d_job = nullptr;
+std::vector<Pel> g_auxA, g_auxB, g_auxC;
+uint64_t g_auxCtr[8];
+decltype( PelBufferOps::addAvg4 )         g_addAvgOrig[2];
+decltype( PelBufferOps::removeHighFreq4 ) g_rhfOrig[2];
+decltype( AffineGradientSearch::m_HorizontalSobelFilter ) g_sobelOrig[2];
+decltype( AffineGradientSearch::m_EqualCoeffComputer )    g_eqOrig;
+AffineGradientSearch *g_affine = nullptr;
+
+bool auxAlloc()
+{
+  return A.dalloc( g_ctx, AUX_MAX * 2, (void **) &d_a ) == VTMHIP_OK && A.dalloc( g_ctx, AUX_MAX * 2, (void **) &d_b ) == VTMHIP_OK
+      && A.dalloc( g_ctx, AUX_MAX * 2, (void **) &d_c ) == VTMHIP_OK && A.dalloc( g_ctx, AUX_MAX * 8, (void **) &d_deriv ) == VTMHIP_OK
+      && A.dalloc( g_ctx, 49 * 8, (void **) &d_eq ) == VTMHIP_OK && A.dalloc( g_ctx, 256, &d_job ) == VTMHIP_OK;
+}
+void pack( std::vector<Pel> &v, const Pel *src, int stride, int w, int h )
+{
+  v.resize( size_t( w ) * h );
+  for( int y = 0; y < h; y++ ) memcpy( v.data() + size_t( y ) * w, src + ptrdiff_t( y ) * stride, sizeof( Pel ) * w );
+}
+// dst = op( a, b ) for one w x h block, compact strides on the device
+bool pelopOnDevice( int op, const Pel *a, int as, const Pel *b, int bs, int w, int h, int bd )
+{
+  pack( g_auxA, a, as, w, h ); pack( g_auxB, b, bs, w, h );
+  vtmhip_pelop_job j; memset( &j, 0, sizeof( j ) );
+  j.aStride = j.bStride = j.dstStride = w; j.width = (int16_t) w; j.height = (int16_t) h; j.bitDepth = (uint8_t) bd;
+  g_auxC.assign( size_t( w ) * h, 0 );
+  bool ok = A.h2d( g_ctx, d_a, g_auxA.data(), g_auxA.size() * 2 ) == VTMHIP_OK && A.h2d( g_ctx, d_b, g_auxB.data(), g_auxB.size() * 2 ) == VTMHIP_OK
+         && A.h2d( g_ctx, d_job, &j, sizeof( j ) ) == VTMHIP_OK;
+  ok = ok && ( op ? A.addAvg( g_ctx, d_a, d_b, d_c, (const vtmhip_pelop_job *) d_job, 1 ) : A.rhf( g_ctx, d_a, d_b, d_c, (const vtmhip_pelop_job *) d_job, 1 ) ) == VTMHIP_OK;
+  return ok && A.d2h( g_ctx, g_auxC.data(), d_c, g_auxC.size() * 2 ) == VTMHIP_OK;
+}
+template<int V> void addAvgTramp( const Pel *s0, int s0s, const Pel *s1, int s1s, Pel *dst, int ds, int w, int h, int shift, int offset, const ClpRng &c )
+{
+  g_st->calls[3]++;
+  g_addAvgOrig[V]( s0, s0s, s1, s1s, dst, ds, w, h, shift, offset, c );
+  const int headRoom = std::max( 2, 14 - c.bd );
+  // the device op derives shift / offset / clip range from the bit depth (PelBuf::addAvg, Buffer.cpp:467-507); anything else stays on the host
+  if( w * h > AUX_MAX || shift != headRoom + 1 || offset != ( 1 << ( shift - 1 ) ) + 2 * IF_INTERNAL_OFFS || c.min != 0 || c.max != ( 1 << c.bd ) - 1 || !sampled( g_auxCtr[V] ) ) return;
+  if( !pelopOnDevice( 1, s0, s0s, s1, s1s, w, h, c.bd ) ) { note_error(); return; }
+  g_st->device[3]++;
+  compare_block( 3, V, w * 1000 + h, dst, ds, g_auxC.data(), w, w, h );
+  for( int y = 0; y < h; y++ ) memcpy( dst + ptrdiff_t( y ) * ds, g_auxC.data() + size_t( y ) * w, sizeof( Pel ) * w );
+}
+template<int V> void rhfTramp( Pel *s0, int s0s, const Pel *s1, int s1s, int w, int h )
+{
+  g_st->calls[3]++;
+  if( w * h > AUX_MAX || !sampled( g_auxCtr[2 + V] ) ) { g_rhfOrig[V]( s0, s0s, s1, s1s, w, h ); return; }
+  const bool ok = pelopOnDevice( 0, s0, s0s, s1, s1s, w, h, 10 );      // in-place op: run the device first, on the untouched input
+  g_rhfOrig[V]( s0, s0s, s1, s1s, w, h );
+  if( !ok ) { note_error(); return; }
+  g_st->device[3]++;
+  compare_block( 3, 2 + V, w * 1000 + h, s0, s0s, g_auxC.data(), w, w, h );
+  for( int y = 0; y < h; y++ ) memcpy( s0 + ptrdiff_t( y ) * s0s, g_auxC.data() + size_t( y ) * w, sizeof( Pel ) * w );
+}
+template<int V> void sobelTramp( Pel *const pred, const int ps, int *const deriv, const int ds, const int w, const int h )
+{
+  g_st->calls[3]++;
+  g_sobelOrig[V]( pred, ps, deriv, ds, w, h );
+  if( w * h > AUX_MAX || !sampled( g_auxCtr[4 + V] ) ) return;
+  pack( g_auxA, pred, ps, w, h );
+  vtmhip_affine_job j; memset( &j, 0, sizeof( j ) );
+  j.derivHOff = 0; j.derivVOff = AUX_MAX; j.predStride = w; j.resiStride = w; j.derivStride = w; j.width = (int16_t) w; j.height = (int16_t) h;
+  std::vector<int> out( size_t( w ) * h );
+  const bool ok = A.h2d( g_ctx, d_a, g_auxA.data(), g_auxA.size() * 2 ) == VTMHIP_OK && A.h2d( g_ctx, d_job, &j, sizeof( j ) ) == VTMHIP_OK
+               && A.sobel( g_ctx, d_a, d_deriv, (const vtmhip_affine_job *) d_job, 1 ) == VTMHIP_OK
+               && A.d2h( g_ctx, out.data(), d_deriv + ( V ? AUX_MAX : 0 ), out.size() * 4 ) == VTMHIP_OK;
+  if( !ok ) { note_error(); return; }
+  g_st->device[3]++;
+  for( int y = 0; y < h; y++ )
+    for( int x = 0; x < w; x++ )
+      if( deriv[y * ds + x] != out[y * w + x] ) { note_mismatch( 3, 4 + V, w * 1000 + h, x, y, deriv[y * ds + x], out[y * w + x] ); y = h; break; }
+  for( int y = 0; y < h; y++ ) memcpy( deriv + ptrdiff_t( y ) * ds, out.data() + size_t( y ) * w, sizeof( int ) * w );
+}
+void eqTramp( Pel *resi, int rs, int **ppDeriv, int ds, int64_t ( *eq )[7], int w, int h, bool b6 )
+{
+  g_st->calls[3]++;
+  int64_t before[7][7]; memcpy( before, eq, sizeof( before ) );
+  g_eqOrig( resi, rs, ppDeriv, ds, eq, w, h, b6 );
+  if( w * h > AUX_MAX || ds != w || !sampled( g_auxCtr[6] ) ) return;
+  pack( g_auxA, resi, rs, w, h );
+  vtmhip_affine_job j; memset( &j, 0, sizeof( j ) );
+  j.derivHOff = 0; j.derivVOff = AUX_MAX; j.predStride = w; j.resiStride = w; j.derivStride = w; j.width = (int16_t) w; j.height = (int16_t) h; j.sixParam = b6;
+  int64_t dev[7][7];
+  const bool ok = A.h2d( g_ctx, d_a, g_auxA.data(), g_auxA.size() * 2 ) == VTMHIP_OK && A.h2d( g_ctx, d_job, &j, sizeof( j ) ) == VTMHIP_OK
+               && A.h2d( g_ctx, d_deriv, ppDeriv[0], size_t( w ) * h * 4 ) == VTMHIP_OK && A.h2d( g_ctx, d_deriv + AUX_MAX, ppDeriv[1], size_t( w ) * h * 4 ) == VTMHIP_OK
+               && A.h2d( g_ctx, d_eq, before, sizeof( before ) ) == VTMHIP_OK          // the device call accumulates, like the reference
+               && A.eqc( g_ctx, d_a, d_deriv, (const vtmhip_affine_job *) d_job, 1, d_eq ) == VTMHIP_OK && A.d2h( g_ctx, dev, d_eq, sizeof( dev ) ) == VTMHIP_OK;
+  if( !ok ) { note_error(); return; }
+  g_st->device[3]++;
+  const int np = b6 ? 6 : 4;
+  for( int r = 1; r <= np; r++ )
+    for( int c = 0; c <= np; c++ )
+      if( dev[r][c] != eq[r][c] ) { note_mismatch( 3, 6, w * 1000 + h, r, c, (long long) eq[r][c], (long long) dev[r][c] ); r = np + 1; break; }
+  for( int r = 1; r <= np; r++ ) memcpy( &eq[r][0], &dev[r][0], sizeof( int64_t ) * ( np + 1 ) );
+}
+void installAux( AffineGradientSearch &ag )
+{
+  g_addAvgOrig[0] = g_pelBufOP.addAvg4; g_pelBufOP.addAvg4 = addAvgTramp<0>;
+  g_addAvgOrig[1] = g_pelBufOP.addAvg8; g_pelBufOP.addAvg8 = addAvgTramp<1>;
+  g_rhfOrig[0] = g_pelBufOP.removeHighFreq4; g_pelBufOP.removeHighFreq4 = rhfTramp<0>;
+  g_rhfOrig[1] = g_pelBufOP.removeHighFreq8; g_pelBufOP.removeHighFreq8 = rhfTramp<1>;
+  g_affine = &ag;
+  g_sobelOrig[0] = ag.m_HorizontalSobelFilter; ag.m_HorizontalSobelFilter = sobelTramp<0>;
+  g_sobelOrig[1] = ag.m_VerticalSobelFilter;   ag.m_VerticalSobelFilter = sobelTramp<1>;
+  g_eqOrig = ag.m_EqualCoeffComputer; ag.m_EqualCoeffComputer = eqTramp;
+}
+void restoreAux()
+{
+  if( !g_affine ) return;
+  g_pelBufOP.addAvg4 = g_addAvgOrig[0]; g_pelBufOP.addAvg8 = g_addAvgOrig[1];
+  g_pelBufOP.removeHighFreq4 = g_rhfOrig[0]; g_pelBufOP.removeHighFreq8 = g_rhfOrig[1];
+  g_affine = nullptr;
+}
 }   // namespace
 
 extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsigned familyMask, uint64_t stride, uint64_t head, RefEncStats *stats )
 {
   memset( stats, 0, sizeof( *stats ) );
   g_st = stats; g_stride = stride ? stride : 1; g_head = head; g_mask = familyMask; g_countOnly = ( familyMask & 8 ) != 0;
-  memset( g_distCtr, 0, sizeof( g_distCtr ) ); memset( g_ifCtr, 0, sizeof( g_ifCtr ) ); memset( g_ifCopyCtr, 0, sizeof( g_ifCopyCtr ) ); memset( g_trCtr, 0, sizeof( g_trCtr ) );
+  memset( g_distCtr, 0, sizeof( g_distCtr ) ); memset( g_ifCtr, 0, sizeof( g_ifCtr ) ); memset( g_ifCopyCtr, 0, sizeof( g_ifCopyCtr ) ); memset( g_trCtr, 0, sizeof( g_trCtr ) ); memset( g_auxCtr, 0, sizeof( g_auxCtr ) );
   memset( g_distOrig, 0, sizeof( g_distOrig ) ); memset( g_fwdOrig, 0, sizeof( g_fwdOrig ) ); memset( g_invOrig, 0, sizeof( g_invOrig ) );
   if( vtmhipPath && !g_countOnly )
   {
@@ -256,7 +386,10 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
     if( !A.so ) { fprintf( stderr, "ref_encode: %s\n", dlerror() ); return -10; }
     const bool ok = sym( A.create, "vtmhip_create" ) && sym( A.destroy, "vtmhip_destroy" ) && sym( A.last_error, "vtmhip_last_error" ) && sym( A.sad, "vtmhip_xGetSAD" )
                  && sym( A.had, "vtmhip_xGetHADs" ) && sym( A.sse, "vtmhip_xGetSSE" ) && sym( A.fhor, "vtmhip_filterHor" ) && sym( A.fver, "vtmhip_filterVer" )
-                 && sym( A.fcopy, "vtmhip_filterCopy" ) && sym( A.fwd, "vtmhip_fastFwdTrans" ) && sym( A.inv, "vtmhip_fastInvTrans" );
+                 && sym( A.fcopy, "vtmhip_filterCopy" ) && sym( A.fwd, "vtmhip_fastFwdTrans" ) && sym( A.inv, "vtmhip_fastInvTrans" )
+                 && sym( A.dalloc, "vtmhip_dev_alloc" ) && sym( A.dfree, "vtmhip_dev_free" ) && sym( A.h2d, "vtmhip_h2d" ) && sym( A.d2h, "vtmhip_d2h" )
+                 && sym( A.addAvg, "vtmhip_add_avg_batch_dev" ) && sym( A.rhf, "vtmhip_remove_high_freq_batch_dev" )
+                 && sym( A.sobel, "vtmhip_affine_sobel_batch_dev" ) && sym( A.eqc, "vtmhip_affine_equal_coeff_batch_dev" );
     if( !ok ) { fprintf( stderr, "ref_encode: libvtmhip.so lacks a pointer-surface symbol\n" ); return -11; }
     const int st = A.create( 0, &g_ctx );
     if( st != VTMHIP_OK ) { fprintf( stderr, "ref_encode: vtmhip_create failed (%d) -- no CPU fallback\n", st ); return -12; }
@@ -280,6 +413,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
         installDist( std::make_integer_sequence<int, DF_TOTAL_FUNCTIONS>() );
         if( g_mask & 2 ) installIf( app->m_cEncLib.m_cInterSearch.m_if );
         if( g_mask & 4 ) installTr();
+        if( ( g_mask & 16 ) && ( g_countOnly || auxAlloc() ) ) installAux( (AffineGradientSearch &) app->m_cEncLib.m_cInterSearch );   // private base: C-style cast
       }
       bool eos = false;
       while( !eos )
@@ -287,11 +421,12 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
         while( app->encodePrep( eos ) ) {}
         while( app->encode() ) {}
       }
+      restoreAux();      // InterSearch dies with the library
       app->destroyLib();
     }
   }
   catch( Exception &e ) { fprintf( stderr, "ref_encode: %s\n", e.what() ); rc = 2; }
-  if( g_ctx || g_countOnly ) { restoreDist(); restoreTr(); }
+  if( g_ctx || g_countOnly ) { restoreDist(); restoreTr(); restoreAux(); }
   app->destroy();
   delete app;
   destroyROM();

@@ -16,7 +16,7 @@ CFG = os.path.join(ROOT, "tests", "data", "enc_ra_gop4.cfg")
 
 
 class Stats(C.Structure):
-    _fields_ = [("calls", C.c_uint64 * 3), ("device", C.c_uint64 * 3), ("mismatch", C.c_uint64 * 3), ("errors", C.c_uint64),
+    _fields_ = [("calls", C.c_uint64 * 4), ("device", C.c_uint64 * 4), ("mismatch", C.c_uint64 * 4), ("errors", C.c_uint64),
                 ("firstMismatch", C.c_int32 * 8), ("firstError", C.c_char * 160)]
 
 
@@ -44,7 +44,7 @@ def _child(argv_json):
     os.write(2, ("\nDROPIN_RESULT " + json.dumps(out) + "\n").encode())
 
 
-def encode(yuv, w, h, frames, qp, out_prefix, hip=False, mask=7, stride=1, head=0, extra=(), timeout=1500):
+def encode(yuv, w, h, frames, qp, out_prefix, hip=False, mask=23, stride=1, head=0, extra=(), timeout=1500):
     """Returns (stats dict, md5 of the bitstream, md5 of the reconstruction)."""
     bits, rec = out_prefix + ".bin", out_prefix + "_rec.yuv"
     args = ["-c", CFG, "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-f", str(frames), "-q", str(qp), "-b", bits, "-o", rec,
