@@ -259,3 +259,98 @@ extern "C" int ref_quant_dequant( const int32_t *coef, int w, int h, int bitDept
   quant->dequant( *tu, dst, COMPONENT_Y, cQP );
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The whole InterSearch::xMotionEstimation (InterSearch.cpp:3299-3494, with xPatternSearchIntRefine :4172-4282 for the
+// integer / 4-sample AMVR modes) on caller-supplied planes: a Picture whose reconstruction buffer aliases the caller's
+// reference plane is installed as slice reference (list 0, index 0); the other list's prediction goes through
+// m_tmpPredStorage[1] exactly as predInterSearch leaves it for the bi-pred iteration.
+// ------------------------------------------------------------------------------------------------------------------
+#include "CommonLib/Picture.h"
+#include "vtm_oracle.h"
+
+extern "C" void ref_motion_estimation( const vo_mest_cfg_t *cfg, const vo_mest_job_t *j, vo_mest_result_t *res )
+{
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  static Picture *pic = nullptr;
+  static bool     storage = false;
+  if( !pic ) pic = new Picture();
+  if( !storage )
+  {
+    const UnitArea lcu( CHROMA_400, Area( 0, 0, MAX_CU_SIZE, MAX_CU_SIZE ) );
+    r.is.m_tmpStorageLCU.create( lcu );
+    r.is.m_tmpPredStorage[0].create( lcu );
+    r.is.m_tmpPredStorage[1].create( lcu );
+    storage = true;
+  }
+  r.sps.setMaxCUWidth( j->ctuSize );
+  r.sps.setMaxCUHeight( j->ctuSize );
+  r.sps.setUseBcw( false );
+  r.pps.setPicWidthInLumaSamples( j->picW );
+  r.pps.setPicHeightInLumaSamples( j->picH );
+  r.pps.setUseWP( false );
+  r.pps.setWPBiPred( false );
+  r.slice.setPPS( &r.pps );
+  r.slice.setSPS( &r.sps );
+  r.slice.setSliceType( B_SLICE );
+  const UnitArea ua( CHROMA_400, Area( j->puX, j->puY, j->w, j->h ) );
+  r.cu.UnitArea::operator=( ua );
+  r.pu.UnitArea::operator=( ua );
+  r.cu.chromaFormat = CHROMA_400;
+  r.pu.chromaFormat = CHROMA_400;
+  r.cu.imv    = j->imv;
+  r.cu.BcwIdx = BCW_DEFAULT;
+  r.rd.m_motionLambda = j->motionLambda;
+  ClpRng clp; clp.min = 0; clp.max = ( 1 << j->bitDepth ) - 1; clp.bd = j->bitDepth; clp.n = 0;
+  r.slice.m_clpRngs.comp[COMPONENT_Y] = clp;
+  // reference picture: reconstruction buffer = the caller's plane, picture origin at (0,0)
+  Pel *origin = const_cast<Pel *>( j->ref ) - ( ptrdiff_t ) j->puY * j->refStride - j->puX;
+  pic->chromaFormat = CHROMA_400;
+  pic->m_bufs[PIC_RECONSTRUCTION].createFromBuf( PelUnitBuf( CHROMA_400, PelBuf( origin, j->refStride, j->picW, j->picH ) ) );
+  r.slice.m_apcRefPicList[REF_PIC_LIST_0][0] = pic;
+  // encoder switches
+  r.cfg.setUseHADME( cfg->useHadME != 0 );
+  r.cfg.setFastInterSearchMode( cfg->fastInterSearchMode13 ? FASTINTERSEARCH_MODE1 : FASTINTERSEARCH_DISABLED );
+  r.cfg.setRestrictMESampling( false );
+  r.cfg.setMotionEstimationSearchMethod( cfg->extendedSettings ? MESEARCH_DIAMOND_ENHANCED : MESEARCH_DIAMOND );
+  r.cfg.setFastMEAssumingSmootherMVEnabled( cfg->firstSearchStop != 0 );
+  r.is.m_motionEstimationSearchMethod = cfg->extendedSettings ? MESEARCH_DIAMOND_ENHANCED : MESEARCH_DIAMOND;
+  r.is.m_bipredSearchRange            = cfg->bipredSearchRange;
+  r.is.m_aaiAdaptSR[0][0]             = j->searchRange;
+  r.is.m_modeCtrl                     = nullptr;
+  r.is.m_uniMvListSize = j->numExtraStart;
+  r.is.m_uniMvListIdx  = j->numExtraStart % 15;
+  for( int i = 0; i < j->numExtraStart; i++ )
+  {
+    const int slot = ( r.is.m_uniMvListIdx - 1 - i + 15 ) % 15;
+    r.uniMv[slot].uniMvs[0][0] = Mv( j->extraStart[i][0], j->extraStart[i][1] );
+  }
+  for( int i = 0; i < 2; i++ ) r.is.m_auiMVPIdxCost[i][AMVP_MAX_NUM_CANDS] = j->mvpIdxBits[i];
+  AMVPInfo amvp;
+  amvp.numCand = j->numAmvpCand;
+  for( int i = 0; i < 2; i++ ) amvp.mvCand[i] = Mv( j->amvpCand[i][0], j->amvpCand[i][1] );
+  if( j->bi )
+  {
+    PelBuf other = r.is.m_tmpPredStorage[1].getBuf( UnitAreaRelative( r.cu, r.pu ) ).Y();
+    for( int y = 0; y < j->h; y++ ) memcpy( other.buf + ( ptrdiff_t ) y * other.stride, j->otherPred + ( ptrdiff_t ) y * j->otherStride, sizeof( Pel ) * j->w );
+  }
+  PelUnitBuf origBuf( CHROMA_400, PelBuf( const_cast<Pel *>( j->org ), j->orgStride, j->w, j->h ) );
+  Mv         mvPred( j->mvPredHor, j->mvPredVer ), mv( j->mvHor, j->mvVer );
+  int        mvpIdx = j->mvpIdx;
+  uint32_t   bits   = j->bits;
+  Distortion cost   = std::numeric_limits<Distortion>::max();
+  r.is.xMotionEstimation( r.pu, origBuf, REF_PIC_LIST_0, mvPred, 0, mv, mvpIdx, bits, cost, amvp, j->bi != 0 );
+  res->mvHor = mv.hor; res->mvVer = mv.ver; res->mvPredHor = mvPred.hor; res->mvPredVer = mvPred.ver; res->mvpIdx = mvpIdx;
+  res->bits = bits; res->cost = cost;
+  res->intX = r.is.m_integerMv2Nx2N[0][0].hor; res->intY = r.is.m_integerMv2Nx2N[0][0].ver; res->intDist = 0;
+  // leave the rig as the other shims expect it
+  r.is.m_uniMvListSize = 0;
+  r.cu.imv = 0;
+  r.cfg.setUseHADME( true );
+  r.cfg.setFastMEAssumingSmootherMVEnabled( true );
+  r.cu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+  r.pu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+  r.cu.chromaFormat = CHROMA_420;
+  r.pu.chromaFormat = CHROMA_420;
+}

@@ -1103,7 +1103,8 @@ static uint64_t vo_pattern_refinement( const vo_me_ctx_t *c, const vo_mvcost_t *
   return best;
 }
 
-/* imv == IMV_OFF path of xPatternSearchFracDIF; intX/intY = integer MV from the integer search. */
+/* xPatternSearchFracDIF for cu.imv == 0 (c->imvShift 0: half + quarter) and IMV_HPEL (c->imvShift 1: half only, :4322);
+ * intX/intY = integer MV from the integer search. */
 void vo_frac_search( const vo_me_ctx_t *c, int intX, int intY, int useHad, int useAltHpelIf, vo_frac_result_t *res )
 {
   vo_fb_t       *fb  = ( vo_fb_t * ) malloc( sizeof( vo_fb_t ) );
@@ -1116,6 +1117,14 @@ void vo_frac_search( const vo_me_ctx_t *c, int intX, int intY, int useHad, int u
   res->costHalf = vo_pattern_refinement( c, &mc, fb, 0, 0, 2, &hx, &hy, useHad, res->candHalf );
   res->halfX    = hx;
   res->halfY    = hy;
+  if( c->imvShift != 0 )
+  {
+    res->cost  = res->costHalf;
+    res->qterX = res->qterY = 0;
+    memset( res->candQuarter, 0, sizeof( res->candQuarter ) );
+    free( fb );
+    return;
+  }
 
   mc.costScale = 0;
   vo_upsample_q( fb, pat, c->refStride, c->w, c->h, c->bitDepth, hx, hy );
@@ -1165,4 +1174,152 @@ void vo_mc_luma( const int16_t *ref, int refStride, int w, int h, int mvHor, int
     vo_if_hor( 0, src - 3 * refStride, refStride, tmp, w, w, h + 7, xFrac, 0, bitDepth, 0, 0, useAltHpelIf );
     vo_if_ver( 0, tmp + 3 * w, w, dst, dstStride, w, h, yFrac, 0, rndRes, bitDepth, 0, 0, useAltHpelIf );
   }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * InterSearch::xMotionEstimation (EncoderLib/InterSearch.cpp:3299-3494) for one (PU, list, refIdx), without BCW,
+ * weighted prediction, MCTS, composite references and the block-MV cache (none is on in the CTC), with
+ * xPatternSearchIntRefine (:4172-4282) for the integer / 4-sample AMVR modes.  Composition of the pinned stages
+ * above; the composition itself (start candidates of the bi-pred search :3384-3425, final rate re-weighting
+ * :3478-3484, AMVR refinement) is restated from the lines cited and pinned through ref_motion_estimation().
+ * ------------------------------------------------------------------------------------------------ */
+static void vo_to_amvr( int *v, int imv )   /* Mv::changeTransPrecInternal2Amvr: INTERNAL(6) -> {QUARTER 4, INT 2, 4PEL 0, HALF 3} */
+{
+  static const int rs[4] = { 2, 4, 6, 3 };
+  *v = vo_prec_down( *v, rs[imv] );
+}
+static int vo_amvr_shift( int imv ) { static const int rs[4] = { 2, 4, 6, 3 }; return rs[imv]; }
+
+void vo_motion_estimation( const vo_mest_cfg_t *cfg, const vo_mest_job_t *j, vo_mest_result_t *res )
+{
+  const int      w = j->w, h = j->h;
+  int16_t       *tmp = NULL;
+  const int16_t *pat = j->org;
+  int            ps  = j->orgStride;
+  double         fWeight = 1.0;
+  if( j->bi )
+  {
+    tmp = ( int16_t * ) malloc( sizeof( int16_t ) * w * h );
+    for( int y = 0; y < h; y++ ) memcpy( tmp + y * w, j->org + ( ptrdiff_t ) y * j->orgStride, sizeof( int16_t ) * w );
+    vo_remove_high_freq( tmp, w, j->otherPred, j->otherStride, w, h );
+    pat = tmp; ps = w; fWeight = 0.5;
+  }
+  vo_me_ctx_t c;
+  memset( &c, 0, sizeof( c ) );
+  c.org = pat; c.orgStride = ps; c.ref = j->ref; c.refStride = j->refStride; c.w = w; c.h = h;
+  c.bitDepth = j->bitDepth; c.imvShift = j->imv == 3 ? 1u : ( unsigned ) j->imv << 1;
+  c.picW = j->picW; c.picH = j->picH; c.puX = j->puX; c.puY = j->puY; c.ctuSize = j->ctuSize;
+  c.mv.motionLambda = j->motionLambda;
+  c.mv.predHor = vo_prec_down( j->mvPredHor, 2 );      /* predQuarter */
+  c.mv.predVer = vo_prec_down( j->mvPredVer, 2 );
+  c.mv.costScale = 2;
+
+  /* m_uniMvList candidates, newest first, de-duplicated against the earlier ones (:3391-3403 and :3728-3746) */
+  int ex[16][2], nex = 0;
+  for( int i = 0; i < j->numExtraStart; i++ )
+  {
+    int k = 0;
+    for( ; k < i; k++ ) if( j->extraStart[k][0] == j->extraStart[i][0] && j->extraStart[k][1] == j->extraStart[i][1] ) break;
+    if( k < i ) continue;
+    ex[nex][0] = j->extraStart[i][0]; ex[nex][1] = j->extraStart[i][1]; nex++;
+  }
+
+  vo_me_result_t ir;
+  if( j->bi )
+  {
+    c.subShift = vo_subshift_for_mode( w, h, cfg->fastInterSearchMode13 ? 2 : 0 );
+    int bestH = j->mvHor, bestV = j->mvVer;
+    int th = bestH, tv = bestV;
+    vo_clip_mv( &th, &tv, &c );
+    th = vo_prec_down( th, 4 ); tv = vo_prec_down( tv, 4 );
+    uint64_t best = vo_me_sad( &c, th, tv ) + vo_mv_cost( &c.mv, th, tv, c.imvShift );
+    for( int i = 0; i < nex; i++ )
+    {
+      th = ex[i][0]; tv = ex[i][1];
+      vo_clip_mv( &th, &tv, &c );
+      th = vo_prec_down( th, 4 ); tv = vo_prec_down( tv, 4 );
+      const uint64_t sad = vo_me_sad( &c, th, tv ) + vo_mv_cost( &c.mv, th, tv, c.imvShift );
+      if( sad < best ) { best = sad; bestH = ex[i][0]; bestV = ex[i][1]; }
+    }
+    vo_range_t sr;
+    vo_set_search_range( &c, bestH, bestV, cfg->bipredSearchRange, &sr );
+    vo_full_search( &c, &sr, &ir );
+  }
+  else
+  {
+    c.subShift = vo_subshift_for_mode( w, h, cfg->fastInterSearchMode13 ? 2 : 0 );
+    vo_tz_job_t t;
+    memset( &t, 0, sizeof( t ) );
+    t.mvHor = j->mvPredHor; t.mvVer = j->mvPredVer; t.searchRange = j->searchRange;
+    t.extendedSettings = cfg->extendedSettings; t.fastSettings = 0; t.firstSearchStop = cfg->firstSearchStop;
+    t.numExtraStart = nex;
+    memcpy( t.extraStart, ex, sizeof( int ) * 2 * nex );
+    vo_tz_search( &c, &t, &ir );
+  }
+  res->intX = ir.mvX; res->intY = ir.mvY; res->intDist = ir.dist;
+
+  unsigned bits = j->bits;
+  if( j->imv == 0 || j->imv == 3 )
+  {
+    vo_frac_result_t fr;
+    c.subShift = 0;
+    vo_frac_search( &c, ir.mvX, ir.mvY, cfg->useHadME, j->imv == 3, &fr );
+    const int qx = ( ir.mvX << 2 ) + ( fr.halfX << 1 ) + fr.qterX, qy = ( ir.mvY << 2 ) + ( fr.halfY << 1 ) + fr.qterY;
+    c.mv.costScale = 0;
+    const unsigned mvBits = vo_mv_bits( &c.mv, qx, qy, c.imvShift );
+    bits += mvBits;
+    const uint64_t costMvBits = ( uint64_t )( j->motionLambda * mvBits ), costBits = ( uint64_t )( j->motionLambda * bits );
+    res->cost      = ( uint64_t )( floor( fWeight * ( ( double ) fr.cost - ( double ) costMvBits ) ) + ( double ) costBits );
+    res->mvHor     = qx << 2;
+    res->mvVer     = qy << 2;
+    res->mvPredHor = j->mvPredHor; res->mvPredVer = j->mvPredVer; res->mvpIdx = j->mvpIdx; res->bits = bits;
+  }
+  else
+  {
+    static const int testPos[9][2] = { { 0, 0 }, { -1, -1 }, { -1, 0 }, { -1, 1 }, { 0, -1 }, { 0, 1 }, { 1, -1 }, { 1, 0 }, { 1, 1 } };
+    const int  sh = vo_amvr_shift( j->imv );
+    const int  rcH = ir.mvX << 4, rcV = ir.mvY << 4;
+    bits -= j->mvpIdxBits[j->mvpIdx];
+    int base[2][2];
+    for( int i = 0; i < 2; i++ )
+    {
+      base[i][0] = rcH - j->amvpCand[i][0]; base[i][1] = rcV - j->amvpCand[i][1];
+      for( int k = 0; k < 2; k++ ) { vo_to_amvr( &base[i][k], j->imv ); base[i][k] <<= sh; }   /* roundTransPrecInternal2Amvr */
+    }
+    uint64_t bestDist = UINT64_MAX, satd = 0;
+    int      bestH = rcH, bestV = rcV, bestBits = 0, bestIdx = j->mvpIdx;
+    for( int pos = 0; pos < 9; pos++ )
+    {
+      int test[2][2] = { { 0, 0 }, { 0, 0 } };
+      for( int i = 0; i < j->numAmvpCand; i++ )
+      {
+        test[i][0] = ( testPos[pos][0] << sh ) + base[i][0] + j->amvpCand[i][0];
+        test[i][1] = ( testPos[pos][1] << sh ) + base[i][1] + j->amvpCand[i][1];
+        uint64_t dist;
+        if( i == 0 || test[0][0] != test[1][0] || test[0][1] != test[1][1] )
+        {
+          int th = test[i][0], tv = test[i][1];
+          vo_clip_mv( &th, &tv, &c );
+          const int16_t *cur = j->ref + ( ptrdiff_t )( tv >> 4 ) * j->refStride + ( th >> 4 );
+          const uint64_t d   = cfg->useHadME ? vo_satd( pat, ps, cur, j->refStride, w, h ) : vo_sad( pat, ps, cur, j->refStride, w, h, 0 );
+          dist = satd = ( uint64_t )( ( double ) d * fWeight );
+        }
+        else dist = satd;
+        int mvBits = ( int ) j->mvpIdxBits[i];
+        int ph = j->amvpCand[i][0], pv = j->amvpCand[i][1], mh = test[i][0], mv = test[i][1];
+        vo_to_amvr( &ph, j->imv ); vo_to_amvr( &pv, j->imv ); vo_to_amvr( &mh, j->imv ); vo_to_amvr( &mv, j->imv );
+        vo_mvcost_t mc = c.mv;
+        mc.predHor = ph; mc.predVer = pv; mc.costScale = 0;
+        mvBits += ( int ) vo_mv_bits( &mc, mh, mv, 0 );
+        dist += ( uint64_t )( j->motionLambda * ( unsigned ) mvBits );
+        if( dist < bestDist ) { bestDist = dist; bestH = test[i][0]; bestV = test[i][1]; bestIdx = i; bestBits = mvBits; }
+      }
+    }
+    res->mvHor = bestH; res->mvVer = bestV; res->mvpIdx = bestIdx;
+    res->mvPredHor = j->amvpCand[bestIdx][0]; res->mvPredVer = j->amvpCand[bestIdx][1];
+    bits += ( unsigned ) bestBits;
+    res->bits = bits;
+    res->cost = bestDist - ( uint64_t )( j->motionLambda * ( unsigned ) bestBits ) + ( uint64_t )( j->motionLambda * bits );
+  }
+  free( tmp );
 }

@@ -105,6 +105,45 @@ void vo_tz_search( const vo_me_ctx_t *c, const vo_tz_job_t *job, vo_me_result_t 
 void vo_full_search( const vo_me_ctx_t *c, const vo_range_t *sr, vo_me_result_t *res );
 void vo_frac_search( const vo_me_ctx_t *c, int intX, int intY, int useHad, int useAltHpelIf, vo_frac_result_t *res );
 
+/* InterSearch::xMotionEstimation: encoder switches shared by a batch, one (PU, list, refIdx) job, its outputs */
+typedef struct
+{
+  int bipredSearchRange;       /* m_bipredSearchRange (cfg BipredSearchRange, 4) */
+  int useHadME;                /* HadamardME && !slice.getDisableSATDForRD() */
+  int fastInterSearchMode13;   /* FEN 1 or 3: setDistParam subShiftMode 2, else 0 */
+  int extendedSettings;        /* MESEARCH_DIAMOND_ENHANCED */
+  int firstSearchStop;         /* FastMEAssumingSmootherMVEnabled */
+} vo_mest_cfg_t;
+
+typedef struct
+{
+  const int16_t *org;  int orgStride;        /* origBuf.Y() */
+  const int16_t *ref;  int refStride;        /* reconstructed reference luma at the PU position */
+  const int16_t *otherPred; int otherStride; /* bi: prediction from the other list (m_tmpPredStorage[1 - list]) */
+  int w, h, puX, puY, picW, picH, ctuSize, bitDepth;
+  int bi, imv, mvpIdx, numAmvpCand;          /* bBi, cu.imv (0 off, 1 integer, 2 four-sample, 3 half), riMVPIdx, amvpInfo.numCand */
+  int mvPredHor, mvPredVer;                  /* rcMvPred, internal 1/16 precision */
+  int mvHor, mvVer;                          /* rcMv on entry (bi: start vector) */
+  int amvpCand[2][2];                        /* amvpInfo.mvCand */
+  unsigned mvpIdxBits[2];                    /* m_auiMVPIdxCost[i][AMVP_MAX_NUM_CANDS] */
+  unsigned bits;                             /* ruiBits on entry */
+  int searchRange;                           /* m_aaiAdaptSR[list][refIdx] */
+  double motionLambda;
+  int numExtraStart;                         /* m_uniMvListSize */
+  int extraStart[16][2];                     /* m_uniMvList entries for (list, refIdx), newest first, NOT de-duplicated */
+} vo_mest_job_t;
+
+typedef struct
+{
+  int      mvHor, mvVer, mvPredHor, mvPredVer, mvpIdx;   /* rcMv, rcMvPred, riMVPIdx on return */
+  unsigned bits;                                         /* ruiBits */
+  uint64_t cost;                                         /* ruiCost */
+  int      intX, intY;                                   /* integer-stage vector */
+  uint64_t intDist;                                      /* ruiCost after the integer stage (distortion without the vector rate) */
+} vo_mest_result_t;
+
+void vo_motion_estimation( const vo_mest_cfg_t *cfg, const vo_mest_job_t *job, vo_mest_result_t *res );
+
 #ifdef __cplusplus
 }
 #endif

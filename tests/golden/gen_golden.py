@@ -242,7 +242,31 @@ def gen_quant():
     print("quant:", len(meta), "cases")
 
 
+def gen_mest():
+    """InterSearch::xMotionEstimation through the rig of oracle/ref_shim_me.cpp (ref_motion_estimation): jobs as JSON (the clip is
+    re-synthesised from its seed), results = rcMv, rcMvPred, riMVPIdx, ruiBits, ruiCost."""
+    import json
+    scene = me_util.Scene(416, 240, hard=True)
+    jobs, res, cfgs = [], [], []
+    for ci, cfgv in enumerate(((4, 1, 1, 0, 1), (4, 0, 1, 0, 0), (4, 1, 0, 1, 1))):
+        cfg = ol.MestCfg(*cfgv)
+        for j in me_util.random_mest_jobs(scene, 90, seed=900 + ci):
+            keep = []
+            t = me_util.oracle_mest_job(scene, j, keep)
+            r = ol.MestResult()
+            R.ref_motion_estimation(C.byref(cfg), C.byref(t), C.byref(r))
+            jobs.append(json.dumps(j))
+            cfgs.append(cfgv)
+            res.append(r.key())
+    np.savez_compressed(os.path.join(HERE, "mest.npz"), jobs=np.array(jobs), cfg=np.array(cfgs, np.int32), res=np.array(res, np.int64))
+    print("mest:", len(jobs), "jobs")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:   # regenerate selected fixtures only: gen_golden.py mest quant ...
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+        sys.exit(0)
     gen_dist()
     gen_mvcost()
     gen_if()
@@ -250,3 +274,4 @@ if __name__ == "__main__":
     gen_me()
     gen_misc()
     gen_quant()
+    gen_mest()

@@ -102,3 +102,82 @@ def run_oracle_tz(scene, jobs):
         L.vo_tz_search(C.byref(c), C.byref(t), C.byref(r))
         out.append((r.mvX, r.mvY, r.cost, r.dist, r.nEval))
     return out
+
+
+# ---- whole xMotionEstimation jobs ---------------------------------------------------------------------------------
+AMVR_SHIFT = {0: 2, 1: 4, 2: 6, 3: 3}   # cu.imv -> right shift from internal precision (Mv::m_amvrPrecision)
+
+
+def _round_amvr(v, imv):
+    """Mv::roundTransPrecInternal2Amvr on one component."""
+    rs = AMVR_SHIFT[imv]
+    o = 1 << (rs - 1)
+    return (((v + o - 1) >> rs) if v >= 0 else ((v + o) >> rs)) << rs
+
+
+def random_mest_jobs(scene, n, seed=17, sizes=None):
+    """(PU, list, refIdx) jobs of InterSearch::xMotionEstimation: uni / bi, every cu.imv mode, AMVP candidates rounded to the AMVR
+    precision as the encoder's AMVP lists are, m_uniMvList entries with duplicates."""
+    rng = np.random.default_rng(seed)
+    jobs = []
+    t = 0
+    while len(jobs) < n:
+        t += 1
+        w = int(rng.choice(sizes[0] if sizes else PU_W))
+        h = int(rng.choice(sizes[1] if sizes else PU_H))
+        if w > scene.W or h > scene.H or (w == 4 and h == 4):
+            continue
+        x = int(rng.integers(0, (scene.W - w) // 4 + 1)) * 4
+        y = int(rng.integers(0, (scene.H - h) // 4 + 1)) * 4
+        imv = int(rng.choice([0, 0, 0, 1, 2, 3]))
+        cands = [[_round_amvr(int(rng.integers(-24 * 16, 24 * 16)), imv), _round_amvr(int(rng.integers(-16 * 16, 16 * 16)), imv)] for _ in range(2)]
+        if t % 9 == 0:
+            cands[1] = list(cands[0])
+        idx = int(rng.integers(0, 2))
+        ncand = 2 if t % 6 else 1
+        if ncand == 1:
+            idx = 0
+        extra = [(int(rng.integers(-30 * 16, 30 * 16)), int(rng.integers(-30 * 16, 30 * 16))) for _ in range(int(rng.integers(0, 7)))]
+        if len(extra) > 2 and t % 2:
+            extra.append(extra[0])   # duplicates exercise the de-duplication loop
+        jobs.append(dict(w=w, h=h, x=x, y=y, bi=int(t % 3 == 0), imv=imv, mvpIdx=idx, numCand=ncand, cands=cands,
+                         mvPred=tuple(cands[idx]), mv=(int(rng.integers(-30, 30)) * 16 + int(rng.integers(0, 16)), int(rng.integers(-20, 20)) * 16 + int(rng.integers(0, 16))),
+                         idxBits=(int(rng.integers(1, 3)), int(rng.integers(1, 3))), bits=int(rng.integers(3, 12)),
+                         searchRange=int(rng.choice([64, 96, 192, 8])), lam=float(rng.uniform(1, 40)), extra=extra,
+                         other_seed=int(rng.integers(0, 1 << 30))))
+    return jobs
+
+
+def other_pred(scene, j):
+    """Prediction 'from the other list' for the bi-pred target: the co-located reference block displaced a little plus noise."""
+    rng = np.random.default_rng(j["other_seed"])
+    dx, dy = int(rng.integers(-3, 4)), int(rng.integers(-3, 4))
+    m = scene.margin
+    plane = scene.ref_buf.reshape(-1, scene.ref_stride)
+    blk = plane[m + j["y"] + dy:m + j["y"] + dy + j["h"], m + j["x"] + dx:m + j["x"] + dx + j["w"]].astype(np.int32)
+    return np.ascontiguousarray(np.clip(blk + rng.integers(-6, 7, blk.shape), 0, 1023).astype(np.int16))
+
+
+def oracle_mest_job(scene, j, keep):
+    """ctypes job for vo_motion_estimation / ref_motion_estimation; `keep` collects the arrays the pointers refer to."""
+    t = ol.MestJob()
+    t.org = scene.cur.ctypes.data + 2 * (j["y"] * scene.W + j["x"])
+    t.orgStride = scene.W
+    t.ref = scene.ref_buf.ctypes.data + 2 * (scene.ref_off + j["y"] * scene.ref_stride + j["x"])
+    t.refStride = scene.ref_stride
+    if j["bi"]:
+        o = other_pred(scene, j)
+        keep.append(o)
+        t.otherPred, t.otherStride = o.ctypes.data, j["w"]
+    t.w, t.h, t.puX, t.puY, t.picW, t.picH, t.ctuSize, t.bitDepth = j["w"], j["h"], j["x"], j["y"], scene.W, scene.H, 128, 10
+    t.bi, t.imv, t.mvpIdx, t.numAmvpCand = j["bi"], j["imv"], j["mvpIdx"], j["numCand"]
+    t.mvPredHor, t.mvPredVer = j["mvPred"]
+    t.mvHor, t.mvVer = j["mv"]
+    for i in range(2):
+        t.amvpCand[i][0], t.amvpCand[i][1] = j["cands"][i]
+        t.mvpIdxBits[i] = j["idxBits"][i]
+    t.bits, t.searchRange, t.motionLambda = j["bits"], j["searchRange"], j["lam"]
+    t.numExtraStart = len(j["extra"])
+    for i, (a, b) in enumerate(j["extra"]):
+        t.extraStart[i][0], t.extraStart[i][1] = a, b
+    return t

@@ -60,6 +60,28 @@ class FracResult(C.Structure):
                 ("candQuarter", C.c_uint64 * 9)]
 
 
+class MestCfg(C.Structure):
+    _fields_ = [("bipredSearchRange", C.c_int), ("useHadME", C.c_int), ("fastInterSearchMode13", C.c_int), ("extendedSettings", C.c_int),
+                ("firstSearchStop", C.c_int)]
+
+
+class MestJob(C.Structure):
+    _fields_ = [("org", C.c_void_p), ("orgStride", C.c_int), ("ref", C.c_void_p), ("refStride", C.c_int), ("otherPred", C.c_void_p),
+                ("otherStride", C.c_int), ("w", C.c_int), ("h", C.c_int), ("puX", C.c_int), ("puY", C.c_int), ("picW", C.c_int),
+                ("picH", C.c_int), ("ctuSize", C.c_int), ("bitDepth", C.c_int), ("bi", C.c_int), ("imv", C.c_int), ("mvpIdx", C.c_int),
+                ("numAmvpCand", C.c_int), ("mvPredHor", C.c_int), ("mvPredVer", C.c_int), ("mvHor", C.c_int), ("mvVer", C.c_int),
+                ("amvpCand", (C.c_int * 2) * 2), ("mvpIdxBits", C.c_uint * 2), ("bits", C.c_uint), ("searchRange", C.c_int),
+                ("motionLambda", C.c_double), ("numExtraStart", C.c_int), ("extraStart", (C.c_int * 2) * 16)]
+
+
+class MestResult(C.Structure):
+    _fields_ = [("mvHor", C.c_int), ("mvVer", C.c_int), ("mvPredHor", C.c_int), ("mvPredVer", C.c_int), ("mvpIdx", C.c_int),
+                ("bits", C.c_uint), ("cost", C.c_uint64), ("intX", C.c_int), ("intY", C.c_int), ("intDist", C.c_uint64)]
+
+    def key(self):
+        return (self.mvHor, self.mvVer, self.mvPredHor, self.mvPredVer, self.mvpIdx, self.bits, self.cost)
+
+
 _oracle = None
 _ref = None
 

@@ -120,3 +120,17 @@ def test_quant_golden(oracle):
         oracle.vo_quant(ol.P(c), int(w), int(h), 10, bq // 6, bq % 6, int(irap), 0, ol.P(q), None, C.byref(s))
         oracle.vo_dequant(ol.P(q), int(w), int(h), 10, bq // 6, bq % 6, 0, ol.P(d))
         assert np.array_equal(q, z["q"][o0:o0 + n]) and np.array_equal(d, z["dq"][o0:o0 + n]) and s.value == asum, (w, h, qp, irap)
+
+
+def test_motion_estimation_golden(oracle):
+    """xMotionEstimation results recorded from the real member function (tests/golden/gen_golden.py gen_mest)."""
+    z = np.load(os.path.join(G, "mest.npz"))
+    scene = me_util.Scene(416, 240, hard=True)
+    for js, cfgv, exp in zip(z["jobs"], z["cfg"], z["res"]):
+        j = json.loads(str(js))
+        keep = []
+        t = me_util.oracle_mest_job(scene, j, keep)
+        cfg = ol.MestCfg(*[int(v) for v in cfgv])
+        r = ol.MestResult()
+        oracle.vo_motion_estimation(C.byref(cfg), C.byref(t), C.byref(r))
+        assert r.key() == tuple(int(v) for v in exp), j

@@ -183,3 +183,24 @@ def test_quant_dequant_equal_reference(oracle, reflib):
                     oracle.vo_quant(ol.P(c), w, h, 10, bq // 6, bq % 6, irap, 0, ol.P(q2), None, C.byref(s2))
                     oracle.vo_dequant(ol.P(q2), w, h, 10, bq // 6, bq % 6, 0, ol.P(d2))
                     assert np.array_equal(q1, q2) and np.array_equal(d1, d2) and s1.value == s2.value, (w, h, qp, irap)
+
+
+@pytest.mark.parametrize("use_had,fen,ext,first_stop", [(1, 1, 0, 1), (0, 1, 0, 0), (1, 0, 1, 1)])
+def test_motion_estimation_equals_reference_xMotionEstimation(oracle, reflib, use_had, fen, ext, first_stop):
+    """Whole InterSearch::xMotionEstimation (uni TZ / bi exhaustive, fractional refinement or AMVR integer refinement, final rate
+    re-weighting) on a rig around the real member function vs the oracle's composition."""
+    scene = me_util.Scene(416, 240, hard=True)
+    cfg = ol.MestCfg(4, use_had, fen, ext, first_stop)
+    jobs = me_util.random_mest_jobs(scene, 160, seed=300 + use_had * 4 + fen * 2 + ext)
+    seen = set()
+    for j in jobs:
+        keep = []
+        t = me_util.oracle_mest_job(scene, j, keep)
+        a, b = ol.MestResult(), ol.MestResult()
+        oracle.vo_motion_estimation(C.byref(cfg), C.byref(t), C.byref(a))
+        reflib.ref_motion_estimation(C.byref(cfg), C.byref(t), C.byref(b))
+        assert a.key() == b.key(), (j, a.key(), b.key())
+        if not j["bi"]:
+            assert (a.intX, a.intY) == (b.intX, b.intY)
+        seen.add((j["bi"], j["imv"]))
+    assert len(seen) == 8   # uni / bi x the four AMVR modes
