@@ -202,6 +202,59 @@ typedef struct
 int vtmhip_full_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
                                   const vtmhip_full_job *d_jobs, int n, vtmhip_me_result *d_results );
 
+/* ---- whole motion estimation of one (PU, list, refIdx): InterSearch::xMotionEstimation -------------------------------------
+ * (InterSearch.cpp:3299-3494; AMVR integer refinement xPatternSearchIntRefine :4172-4282).  One call runs, for n jobs:
+ *   bi:  pattern = 2*org - otherPred (removeHighFreq :3320-3326), best start among rcMv and the m_uniMvList entries (:3377-3420),
+ *        xSetSearchRange + xPatternSearch over +-bipredSearchRange;        uni: xTZSearch from rcMvPred (:3440-3446)
+ *   cu.imv 0 / IMV_HPEL: xPatternSearchFracDIF and the rate re-weighting of :3478-3484
+ *   cu.imv 1 / 2:        xPatternSearchIntRefine over 9 positions x the AMVP candidates
+ * as a fixed sequence of launches on the context's stream (no host synchronisation).  Not covered (the trampoline keeps the host
+ * path): BCW weights, weighted prediction, MCTS, composite references, the block-MV cache (xReadBufferedUniMv / CacheBlkInfoCtrl). */
+typedef struct
+{
+  int32_t bipredSearchRange;       /* m_bipredSearchRange */
+  uint8_t useHadME;                /* HadamardME && !slice.getDisableSATDForRD() */
+  uint8_t fastInterSearchMode13;   /* FEN mode 1 or 3: setDistParam subShiftMode 2 (RdCost.cpp:289-323); else 0 */
+  uint8_t extendedSettings;        /* MESEARCH_DIAMOND_ENHANCED */
+  uint8_t firstSearchStop;         /* FastMEAssumingSmootherMVEnabled */
+  int32_t uniformImv;              /* -1: jobs mix cu.imv values; 0..3: every job of the batch has this cu.imv (lets whole stages be skipped) */
+  int32_t uniformSquare;           /* != 0: every job is maxWidth x maxWidth (tiled fractional kernel when uniformImv is 0 or 3) */
+} vtmhip_me_cfg;
+
+typedef struct
+{
+  int64_t  orgOff, refOff;          /* PU top-left in the original plane / the same position (MV 0,0) in the reference plane */
+  int64_t  otherPredOff;            /* bi: block of the other list's prediction inside d_otherPredBase (m_tmpPredStorage[1 - list]) */
+  int32_t  orgStride, refStride, otherPredStride;
+  int16_t  puX, puY, width, height;
+  uint8_t  bi, imv, mvpIdx, numAmvpCand;   /* bBi, cu.imv (0 quarter, 1 integer, 2 four-sample, 3 half), riMVPIdx, amvpInfo.numCand */
+  int32_t  mvPredHor, mvPredVer;    /* rcMvPred, internal 1/16 precision */
+  int32_t  mvHor, mvVer;            /* rcMv on entry (start of the bi-pred search) */
+  int32_t  amvpCand[2][2];          /* amvpInfo.mvCand */
+  uint32_t mvpIdxBits[2];           /* m_auiMVPIdxCost[i][AMVP_MAX_NUM_CANDS] */
+  uint32_t bits;                    /* ruiBits on entry */
+  int32_t  searchRange;             /* m_aaiAdaptSR[list][refIdx] */
+  double   motionLambda;
+  int32_t  numExtraStart;           /* m_uniMvListSize */
+  int32_t  extraStart[15][2];       /* uniMvs[list][refIdx] of the m_uniMvList entries, newest first, duplicates allowed */
+  int32_t  pad;
+} vtmhip_me_job;
+
+typedef struct
+{
+  int32_t  mvHor, mvVer;            /* rcMv, internal precision */
+  int32_t  mvPredHor, mvPredVer;    /* rcMvPred (changes only in the AMVR integer refinement) */
+  int32_t  mvpIdx;                  /* riMVPIdx */
+  uint32_t bits;                    /* ruiBits */
+  uint64_t cost;                    /* ruiCost */
+  int32_t  intX, intY;              /* integer-stage vector (m_integerMv2Nx2N for uni searches) */
+  uint64_t intDist;                 /* distortion of the integer stage without the vector rate (the D_ME trace value MECostFPel) */
+} vtmhip_me_out;
+
+int vtmhip_xMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg *cfg, const int16_t *d_orgBase,
+                                        const int16_t *d_refBase, const int16_t *d_otherPredBase, const vtmhip_me_job *d_jobs, int n,
+                                        int maxWidth, int maxHeight, vtmhip_me_out *d_results );
+
 /* ---- motion compensation / bi-pred buffer ops ------------------------------------------------------------------------ */
 typedef struct
 {

@@ -1,0 +1,112 @@
+"""GPU parity: vtmhip_xMotionEstimation_batch_dev (whole InterSearch::xMotionEstimation per job) vs the oracle composition and vs
+the golden vectors recorded from the real member function.  Bit-exact: vectors, predictor choice, bits, cost."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import me_util
+import oracle_lib as ol
+from vtm_amd.lib import MeCfg, MeJob, MeOut, PicParams
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def hip_jobs(scene, jobs, others):
+    """others: flat int16 array holding every bi job's other-list prediction; returns the ctypes job array."""
+    arr = (MeJob * len(jobs))()
+    off = 0
+    for k, j in enumerate(jobs):
+        t = arr[k]
+        t.orgOff = j["y"] * scene.W + j["x"]
+        t.refOff = scene.ref_off + j["y"] * scene.ref_stride + j["x"]
+        t.orgStride, t.refStride = scene.W, scene.ref_stride
+        if j["bi"]:
+            o = me_util.other_pred(scene, j)
+            others[off:off + o.size] = o.reshape(-1)
+            t.otherPredOff, t.otherPredStride = off, j["w"]
+            off += o.size
+        t.puX, t.puY, t.width, t.height = j["x"], j["y"], j["w"], j["h"]
+        t.bi, t.imv, t.mvpIdx, t.numAmvpCand = j["bi"], j["imv"], j["mvpIdx"], j["numCand"]
+        t.mvPredHor, t.mvPredVer = j["mvPred"]
+        t.mvHor, t.mvVer = j["mv"]
+        for i in range(2):
+            t.amvpCand[i][0], t.amvpCand[i][1] = j["cands"][i]
+            t.mvpIdxBits[i] = j["idxBits"][i]
+        t.bits, t.searchRange, t.motionLambda = j["bits"], j["searchRange"], j["lam"]
+        t.numExtraStart = len(j["extra"])
+        for i, (a, b) in enumerate(j["extra"]):
+            t.extraStart[i][0], t.extraStart[i][1] = a, b
+    return arr
+
+
+def run_device(ctx, scene, jobs, cfgv, uniform_imv=-1, uniform_square=0, max_wh=(128, 128)):
+    others = np.zeros(max(1, sum(j["w"] * j["h"] for j in jobs if j["bi"])), np.int16)
+    arr = hip_jobs(scene, jobs, others)
+    cfg = MeCfg(cfgv[0], cfgv[1], cfgv[2], cfgv[3], cfgv[4], uniform_imv, uniform_square)
+    pic = PicParams(scene.W, scene.H, 128, 10, 0)
+    d_cur, d_ref, d_oth = ctx.to_device(scene.cur), ctx.to_device(scene.ref_buf), ctx.to_device(others)
+    d_jobs = ctx.to_device(np.frombuffer(arr, np.uint8))
+    d_res = ctx.alloc(C.sizeof(MeOut) * len(jobs))
+    ctx.motion_estimation_batch(pic, cfg, d_cur.ptr, d_ref.ptr, d_oth.ptr, d_jobs.ptr, len(jobs), max_wh[0], max_wh[1], d_res.ptr)
+    res = (MeOut * len(jobs)).from_buffer_copy(d_res.to_host(np.uint8).tobytes())
+    return [(r.mvHor, r.mvVer, r.mvPredHor, r.mvPredVer, r.mvpIdx, r.bits, r.cost) for r in res], res
+
+
+def test_matches_golden_from_reference(ctx):
+    z = np.load(os.path.join(G, "mest.npz"))
+    scene = me_util.Scene(416, 240, hard=True)
+    jobs = [json.loads(str(s)) for s in z["jobs"]]
+    cfgs = [tuple(int(v) for v in c) for c in z["cfg"]]
+    exp = [tuple(int(v) for v in e) for e in z["res"]]
+    for cfgv in sorted(set(cfgs)):
+        idx = [i for i, c in enumerate(cfgs) if c == cfgv]
+        got, _ = run_device(ctx, scene, [jobs[i] for i in idx], cfgv)
+        for g, i in zip(got, idx):
+            assert g == exp[i], (jobs[i], g, exp[i])
+
+
+@pytest.mark.parametrize("cfgv", [(4, 1, 1, 0, 1), (4, 0, 0, 1, 0), (8, 1, 1, 1, 1)])
+def test_matches_oracle_mixed_batch(ctx, cfgv):
+    L = ol.oracle()
+    scene = me_util.Scene(416, 240, hard=True)
+    jobs = me_util.random_mest_jobs(scene, 400, seed=40 + cfgv[0] + cfgv[1])
+    cfg = ol.MestCfg(*cfgv)
+    exp, exp_int = [], []
+    for j in jobs:
+        keep = []
+        t = me_util.oracle_mest_job(scene, j, keep)
+        r = ol.MestResult()
+        L.vo_motion_estimation(C.byref(cfg), C.byref(t), C.byref(r))
+        exp.append(r.key())
+        exp_int.append((r.intX, r.intY, r.intDist))
+    got, res = run_device(ctx, scene, jobs, cfgv)
+    for k, (g, e) in enumerate(zip(got, exp)):
+        assert g == e, (jobs[k], g, e)
+    assert [(r.intX, r.intY, r.intDist) for r in res] == exp_int
+
+
+@pytest.mark.parametrize("size,imv", [(8, 0), (16, 0), (32, 3), (64, 0), (16, 1), (32, 2)])
+def test_uniform_batches_use_fast_paths(ctx, size, imv):
+    """uniformSquare + uniformImv: tiled fractional kernel / skipped stages; same results as the oracle."""
+    L = ol.oracle()
+    scene = me_util.Scene(416, 240, hard=True)
+    jobs = me_util.random_mest_jobs(scene, 200, seed=70 + size + imv, sizes=([size], [size]))
+    for j in jobs:
+        j["imv"] = imv
+        j["cands"] = [[me_util._round_amvr(v, imv) for v in c] for c in j["cands"]]
+        j["mvPred"] = tuple(j["cands"][j["mvpIdx"]])
+    cfgv = (4, 1, 1, 0, 1)
+    cfg = ol.MestCfg(*cfgv)
+    exp = []
+    for j in jobs:
+        keep = []
+        t = me_util.oracle_mest_job(scene, j, keep)
+        r = ol.MestResult()
+        L.vo_motion_estimation(C.byref(cfg), C.byref(t), C.byref(r))
+        exp.append(r.key())
+    got, _ = run_device(ctx, scene, jobs, cfgv, uniform_imv=imv, uniform_square=1, max_wh=(size, size))
+    assert got == exp

@@ -25,6 +25,9 @@ int vtmhip_struct_size( int which )
   case 12: return ( int ) sizeof( vtmhip_tu_job );
   case 13: return ( int ) sizeof( vtmhip_tu_result );
   case 14: return ( int ) sizeof( vtmhip_affine_job );
+  case 15: return ( int ) sizeof( vtmhip_me_cfg );
+  case 16: return ( int ) sizeof( vtmhip_me_job );
+  case 17: return ( int ) sizeof( vtmhip_me_out );
   default: return -1;
   }
 }
@@ -80,6 +83,7 @@ int vtmhip_destroy( vtmhip_ctx *ctx )
   ( void ) hipSetDevice( ctx->device );
   ( void ) hipStreamSynchronize( ctx->stream );
   if( ctx->scratch ) ( void ) hipFree( ctx->scratch );
+  if( ctx->work ) ( void ) hipFree( ctx->work );
   if( ctx->pinned ) ( void ) hipHostFree( ctx->pinned );
   if( ctx->evStart ) ( void ) hipEventDestroy( ctx->evStart );
   if( ctx->evStop ) ( void ) hipEventDestroy( ctx->evStop );
@@ -172,5 +176,23 @@ int vtmhip_internal_scratch( vtmhip_ctx *ctx, size_t bytes )
   VTMHIP_HIP( ctx, hipMalloc( &ctx->scratch, want ) );
   VTMHIP_HIP( ctx, hipHostMalloc( &ctx->pinned, want ) );
   ctx->scratchSize = ctx->pinnedSize = want;
+  return VTMHIP_OK;
+}
+
+int vtmhip_internal_workspace( vtmhip_ctx *ctx, size_t bytes )
+{
+  if( bytes <= ctx->workSize ) return VTMHIP_OK;
+  const size_t want = ( bytes + ( 1u << 20 ) - 1 ) & ~( size_t )( ( 1u << 20 ) - 1 );
+  VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );   // earlier launches may still use the old block
+  if( ctx->work ) VTMHIP_HIP( ctx, hipFree( ctx->work ) );
+  ctx->work = nullptr; ctx->workSize = 0;
+  if( hipMalloc( &ctx->work, want ) != hipSuccess )
+  {
+    ( void ) hipGetLastError();
+    ctx->work = nullptr;
+    ctx->lastError = "out of device memory for the call's workspace";
+    return VTMHIP_E_NOMEM;
+  }
+  ctx->workSize = want;
   return VTMHIP_OK;
 }

@@ -20,6 +20,8 @@ struct vtmhip_ctx
   size_t      scratchSize = 0;
   void       *pinned      = nullptr;   // pinned host mirror of the staging area
   size_t      pinnedSize  = 0;
+  void       *work        = nullptr;   // device workspace of the multi-stage calls (vtmhip_xMotionEstimation_batch_dev)
+  size_t      workSize    = 0;
   int         numCUs      = 256;
   std::string lastError;
 };
@@ -50,6 +52,7 @@ struct vtmhip_ctx
 #define VTMHIP_LAUNCHED( ctx ) VTMHIP_HIP( ctx, hipGetLastError() )
 
 int vtmhip_internal_scratch( vtmhip_ctx *ctx, size_t bytes );   // grows ctx->scratch / ctx->pinned
+int vtmhip_internal_workspace( vtmhip_ctx *ctx, size_t bytes ); // grows ctx->work (device only)
 
 // ---- device helpers -------------------------------------------------------------------------------------------
 __device__ __forceinline__ int wave_reduce_add( int v )

@@ -82,6 +82,7 @@ __global__ __launch_bounds__( 256 ) void dist_batch_kernel( const int16_t *__res
   const int16_t        *cur = curBase + j.curOff;
   const int             w = j.width, h = j.height, os = j.orgStride, cs = j.curStride;
   unsigned long long    acc = 0;
+  if( w == 0 ) return;   // empty slot of a multi-stage call: nothing read, nothing written
 
   if( j.kind == VTMHIP_DIST_SAD )
   {

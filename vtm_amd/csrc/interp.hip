@@ -293,6 +293,7 @@ __global__ __launch_bounds__( 64 ) void frac_search_kernel( const int16_t *__res
   const int             lane = threadIdx.x;
   const vtmhip_frac_job j    = jobs[blockIdx.x];
   const int             w = j.width, h = j.height;
+  if( w == 0 ) return;   // empty slot of a multi-stage call
   const int             winLd = w + 8;
   int16_t              *win  = lds;                                   // [(h+8)][w+8]: picture rows/cols -4 .. +3 around the block
   int16_t              *tmp  = win + ( maxH + 8 ) * ( maxW + 8 );     // [(h+8)][w]

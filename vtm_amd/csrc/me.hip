@@ -423,6 +423,7 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel(
   const int jobIdx = WPJ == 1 ? blockIdx.x * 4 + wv : blockIdx.x;
   if( jobIdx >= numJobs ) return;   // WPJ == 1: whole waves leave; WPJ > 1: never true (grid = numJobs)
   const vtmhip_tz_job *jp  = jobs + jobIdx;
+  if( uni( ( int ) jp->width ) == 0 ) return;   // empty slot of a multi-stage call (job handled by another stage); uniform per wave / per block
   int4                *pts = sPts[WPJ == 1 ? wv : 0];
   Coop                 co;
   co.lane = lane; co.wave = WPJ == 1 ? 0 : wv; co.wpj = WPJ; co.leader = ( lane == 0 && co.wave == 0 );
@@ -611,6 +612,7 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void full_search_kerne
   const int jobIdx = WPJ == 1 ? blockIdx.x * 4 + wv : blockIdx.x;
   if( jobIdx >= numJobs ) return;
   const vtmhip_full_job *jp = jobs + jobIdx;
+  if( uni( ( int ) jp->width ) == 0 ) return;   // empty slot (see tz_search_kernel)
   Coop                   co;
   co.lane = lane; co.wave = WPJ == 1 ? 0 : wv; co.wpj = WPJ; co.leader = ( lane == 0 && co.wave == 0 ); co.redCost = sRedCost; co.redIdx = sRedIdx;
   MeJob j;

@@ -1,0 +1,342 @@
+// mest.hip -- InterSearch::xMotionEstimation as one batched call (reference EncoderLib/InterSearch.cpp:3299-3494, with
+// xPatternSearchIntRefine :4172-4282).  The heavy stages are the library's own search kernels (me.hip, interp.hip, dist.hip);
+// this file is the device-side bookkeeping between them -- one thread per job builds the next stage's job table from the
+// previous stage's results, so the whole function is a fixed sequence of launches on one stream with no host round trip:
+//
+//   pattern   copy of the PU's original block (uni) or 2*org - otherPred (bi, removeHighFreq :3320-3326) into a compact slot
+//   prepare   tz job (uni) / start-candidate SAD jobs (bi: rcMv + de-duplicated m_uniMvList entries, :3377-3420)
+//   [dist]    start-candidate SADs            -> bi_start: best start, exhaustive-search job (xSetSearchRange + xPatternSearch)
+//   tz / full integer search
+//   mid       fractional job (cu.imv 0 / HPEL) or the 9 x numCand SATD jobs of the AMVR refinement (cu.imv 1 / 2)
+//   frac / [dist]
+//   final     rate re-weighting (:3478-3484) or the AMVR selection loop (:4208-4262), fp64 exactly as the reference
+#include "ctx.hpp"
+
+namespace
+{
+
+constexpr int REFINE_SLOTS = 18;   // 9 positions x 2 AMVP candidates
+
+__device__ __forceinline__ int floor_log2_u( unsigned v ) { return 31 - __clz( ( int ) v ); }
+// RdCost::xGetExpGolombNumberOfBits (RdCost.h:301-313)
+__device__ __forceinline__ unsigned eg_bits( int v )
+{
+  unsigned len = 1;
+  unsigned t   = v <= 0 ? ( ( unsigned ) ( -v ) << 1 ) + 1 : ( unsigned ) ( v << 1 );
+  while( t > 128 ) { len += 14; t >>= 7; }
+  return len + ( ( unsigned ) floor_log2_u( t ) << 1 );
+}
+__device__ __forceinline__ unsigned mv_bits( int x, int y, int predHor, int predVer, int costScale, unsigned imvShift )
+{
+  return eg_bits( ( ( x << costScale ) - predHor ) >> imvShift ) + eg_bits( ( ( y << costScale ) - predVer ) >> imvShift );
+}
+__device__ __forceinline__ unsigned long long rate( double lambda, unsigned bits ) { return ( unsigned long long ) ( lambda * bits ); }   // RdCost::getCost
+__device__ __forceinline__ int prec_down( int v, int rs ) { const int o = 1 << ( rs - 1 ); return v >= 0 ? ( v + o - 1 ) >> rs : ( v + o ) >> rs; }   // Mv::changePrecision
+__device__ __forceinline__ int amvr_shift( int imv ) { return imv == 0 ? 2 : imv == 1 ? 4 : imv == 2 ? 6 : 3; }   // Mv::m_amvrPrecision vs INTERNAL
+__device__ __forceinline__ void clip_mv( const vtmhip_pic_params &pic, const vtmhip_me_job &j, int &hor, int &ver )   // clipMvInPic
+{
+  const int horMax = ( pic.picW + 8 - j.puX - 1 ) << 4, horMin = ( -pic.ctuSize - 8 - j.puX + 1 ) << 4;
+  const int verMax = ( pic.picH + 8 - j.puY - 1 ) << 4, verMin = ( -pic.ctuSize - 8 - j.puY + 1 ) << 4;
+  hor = min( horMax, max( horMin, hor ) );
+  ver = min( verMax, max( verMin, ver ) );
+}
+__device__ __forceinline__ int sub_shift( const vtmhip_me_cfg &cfg, int w, int h ) { return cfg.fastInterSearchMode13 && h > 8 && w <= 64 ? 1 : 0; }   // RdCost.cpp:289-323, mode 2
+__device__ __forceinline__ unsigned imv_shift( int imv ) { return imv == 3 ? 1u : ( unsigned ) imv << 1; }
+
+// m_uniMvList entries, newest first, each kept only if no earlier entry equals it (:3391-3403, :3728-3746)
+__device__ __forceinline__ int dedup( const vtmhip_me_job &j, int ex[15][2] )
+{
+  int n = 0;
+  const int m = min( 15, max( 0, j.numExtraStart ) );
+  for( int i = 0; i < m; i++ )
+  {
+    int k = 0;
+    for( ; k < i; k++ ) if( j.extraStart[k][0] == j.extraStart[i][0] && j.extraStart[k][1] == j.extraStart[i][1] ) break;
+    if( k < i ) continue;
+    ex[n][0] = j.extraStart[i][0]; ex[n][1] = j.extraStart[i][1]; n++;
+  }
+  return n;
+}
+
+struct Work
+{
+  int16_t            *pattern;   // n slots of slotSamples
+  vtmhip_tz_job      *tz;
+  vtmhip_full_job    *full;
+  vtmhip_me_result   *ires;
+  vtmhip_frac_job    *frac;
+  vtmhip_frac_result *fres;
+  vtmhip_dist_job    *dist;      // n x REFINE_SLOTS (the start candidates use the first START_SLOTS of each row)
+  unsigned long long *dout;
+  long                slotSamples;
+};
+
+// one workgroup per job: the search pattern in a compact slot (stride = width)
+__global__ __launch_bounds__( 256 ) void mest_pattern_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ otherBase,
+                                                             const vtmhip_me_job *__restrict__ jobs, Work wk )
+{
+  const vtmhip_me_job &j = jobs[blockIdx.x];
+  const int16_t *o = orgBase + j.orgOff;
+  int16_t       *d = wk.pattern + ( long ) blockIdx.x * wk.slotSamples;
+  const int      w = j.width, h = j.height;
+  if( j.bi )
+  {
+    const int16_t *p = otherBase + j.otherPredOff;
+    for( int i = threadIdx.x; i < w * h; i += 256 )
+    {
+      const int y = i / w, x = i - y * w;
+      d[i] = ( int16_t ) ( 2 * o[( long ) y * j.orgStride + x] - p[( long ) y * j.otherPredStride + x] );   // removeHighFreq, unclipped (Buffer.h:475-520)
+    }
+  }
+  else
+  {
+    for( int i = threadIdx.x; i < w * h; i += 256 )
+    {
+      const int y = i / w, x = i - y * w;
+      d[i] = o[( long ) y * j.orgStride + x];
+    }
+  }
+}
+
+__device__ __forceinline__ void sad_job( vtmhip_dist_job &d, long slot, const vtmhip_me_job &j, int intX, int intY, int ss, int kind )
+{
+  d.orgOff = slot; d.curOff = j.refOff + ( long ) intY * j.refStride + intX;
+  d.orgStride = j.width; d.curStride = j.refStride; d.width = j.width; d.height = j.height; d.subShift = ( int16_t ) ss; d.kind = ( int16_t ) kind;
+}
+
+__global__ __launch_bounds__( 256 ) void mest_prepare_kernel( vtmhip_pic_params pic, vtmhip_me_cfg cfg, const vtmhip_me_job *__restrict__ jobs, int n, Work wk )
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if( i >= n ) return;
+  const vtmhip_me_job &j = jobs[i];
+  const long     slot = ( long ) i * wk.slotSamples;
+  const int      ss   = sub_shift( cfg, j.width, j.height );
+  const unsigned is   = imv_shift( j.imv );
+  int ex[15][2];
+  const int nex = dedup( j, ex );
+  vtmhip_tz_job   &t = wk.tz[i];
+  vtmhip_full_job &f = wk.full[i];
+  vtmhip_dist_job *d = wk.dist + ( long ) i * REFINE_SLOTS;
+  for( int k = 0; k < REFINE_SLOTS; k++ ) d[k].width = 0;
+  if( !j.bi )
+  {
+    f.width = 0;
+    t.orgOff = slot; t.refOff = j.refOff; t.orgStride = j.width; t.refStride = j.refStride;
+    t.puX = j.puX; t.puY = j.puY; t.width = j.width; t.height = j.height; t.subShift = ( int16_t ) ss; t.imvShift = ( uint8_t ) is; t.signedSamples = 0;
+    t.predHor = prec_down( j.mvPredHor, 2 ); t.predVer = prec_down( j.mvPredVer, 2 ); t.motionLambda = j.motionLambda;
+    t.mvHor = j.mvPredHor; t.mvVer = j.mvPredVer;                      // rcMv = rcMvPred (:3441)
+    t.searchRange = j.searchRange;
+    t.extendedSettings = cfg.extendedSettings; t.fastSettings = 0; t.firstSearchStop = cfg.firstSearchStop; t.hasIntMv2Nx2NPred = 0;
+    t.intMv2Nx2NPredHor = t.intMv2Nx2NPredVer = 0;
+    t.numExtraStart = nex;
+    for( int k = 0; k < nex; k++ ) { t.extraStart[k][0] = ex[k][0]; t.extraStart[k][1] = ex[k][1]; }
+  }
+  else
+  {
+    t.width = 0;
+    f.width = 0;   // filled by mest_bi_start_kernel
+    for( int k = 0; k <= nex; k++ )
+    {
+      int th = k == 0 ? j.mvHor : ex[k - 1][0], tv = k == 0 ? j.mvVer : ex[k - 1][1];
+      clip_mv( pic, j, th, tv );
+      sad_job( d[k], slot, j, prec_down( th, 4 ), prec_down( tv, 4 ), ss, VTMHIP_DIST_SAD );
+    }
+  }
+}
+
+__global__ __launch_bounds__( 256 ) void mest_bi_start_kernel( vtmhip_pic_params pic, vtmhip_me_cfg cfg, const vtmhip_me_job *__restrict__ jobs, int n, Work wk )
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if( i >= n ) return;
+  const vtmhip_me_job &j = jobs[i];
+  if( !j.bi ) return;
+  const unsigned is = imv_shift( j.imv );
+  const int      ph = prec_down( j.mvPredHor, 2 ), pv = prec_down( j.mvPredVer, 2 );
+  int ex[15][2];
+  const int nex = dedup( j, ex );
+  unsigned long long best = 0;
+  int                bestH = j.mvHor, bestV = j.mvVer;
+  for( int k = 0; k <= nex; k++ )
+  {
+    int th = k == 0 ? j.mvHor : ex[k - 1][0], tv = k == 0 ? j.mvVer : ex[k - 1][1];
+    clip_mv( pic, j, th, tv );
+    th = prec_down( th, 4 ); tv = prec_down( tv, 4 );
+    const unsigned long long c = wk.dout[( long ) i * REFINE_SLOTS + k] + rate( j.motionLambda, mv_bits( th, tv, ph, pv, 2, is ) );
+    if( k == 0 || c < best ) { best = c; if( k ) { bestH = ex[k - 1][0]; bestV = ex[k - 1][1]; } }
+  }
+  vtmhip_full_job &f = wk.full[i];
+  f.orgOff = ( long ) i * wk.slotSamples; f.refOff = j.refOff; f.orgStride = j.width; f.refStride = j.refStride;
+  f.puX = j.puX; f.puY = j.puY; f.width = j.width; f.height = j.height; f.subShift = ( int16_t ) sub_shift( cfg, j.width, j.height );
+  f.imvShift = ( uint8_t ) is; f.signedSamples = 1;
+  f.predHor = ph; f.predVer = pv; f.motionLambda = j.motionLambda; f.centerHor = bestH; f.centerVer = bestV; f.searchRange = cfg.bipredSearchRange; f.pad = 0;
+}
+
+// test vector of the AMVR refinement: position `pos`, AMVP candidate c (:4208-4215)
+__device__ __forceinline__ void refine_test_mv( const vtmhip_me_job &j, int intX, int intY, int pos, int c, int &th, int &tv )
+{
+  const int px = pos == 0 ? 0 : ( pos <= 3 ? -1 : pos <= 5 ? 0 : 1 );
+  const int py = pos == 0 ? 0 : ( pos <= 3 ? pos - 2 : pos == 4 ? -1 : pos == 5 ? 1 : pos - 7 );
+  const int sh = amvr_shift( j.imv );
+  const int bh = prec_down( ( intX << 4 ) - j.amvpCand[c][0], sh ) << sh;   // cBaseMvd, roundTransPrecInternal2Amvr
+  const int bv = prec_down( ( intY << 4 ) - j.amvpCand[c][1], sh ) << sh;
+  th = ( px << sh ) + bh + j.amvpCand[c][0];
+  tv = ( py << sh ) + bv + j.amvpCand[c][1];
+}
+
+__global__ __launch_bounds__( 256 ) void mest_mid_kernel( vtmhip_pic_params pic, vtmhip_me_cfg cfg, const vtmhip_me_job *__restrict__ jobs, int n, Work wk )
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if( i >= n ) return;
+  const vtmhip_me_job   &j = jobs[i];
+  const vtmhip_me_result r = wk.ires[i];
+  const long             slot = ( long ) i * wk.slotSamples;
+  vtmhip_frac_job       &q = wk.frac[i];
+  vtmhip_dist_job       *d = wk.dist + ( long ) i * REFINE_SLOTS;
+  for( int k = 0; k < REFINE_SLOTS; k++ ) d[k].width = 0;
+  if( j.imv == 0 || j.imv == 3 )
+  {
+    q.orgOff = slot; q.refOff = j.refOff; q.orgStride = j.width; q.refStride = j.refStride; q.width = j.width; q.height = j.height;
+    q.intX = ( int16_t ) r.mvX; q.intY = ( int16_t ) r.mvY;
+    q.predHor = prec_down( j.mvPredHor, 2 ); q.predVer = prec_down( j.mvPredVer, 2 ); q.motionLambda = j.motionLambda;
+    q.useHad = cfg.useHadME; q.useAltHpelIf = j.imv == 3; q.imvShift = j.imv == 3; q.bitDepth = ( uint8_t ) pic.bitDepth; q.pad = 0;
+  }
+  else
+  {
+    q.width = 0;
+    for( int pos = 0; pos < 9; pos++ )
+      for( int c = 0; c < j.numAmvpCand && c < 2; c++ )
+      {
+        int th, tv;
+        refine_test_mv( j, r.mvX, r.mvY, pos, c, th, tv );
+        clip_mv( pic, j, th, tv );
+        sad_job( d[pos * 2 + c], slot, j, th >> 4, tv >> 4, 0, cfg.useHadME ? VTMHIP_DIST_SATD : VTMHIP_DIST_SAD );
+      }
+  }
+}
+
+__global__ __launch_bounds__( 256 ) void mest_final_kernel( vtmhip_me_cfg cfg, const vtmhip_me_job *__restrict__ jobs, int n, Work wk, vtmhip_me_out *__restrict__ out )
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if( i >= n ) return;
+  const vtmhip_me_job   &j = jobs[i];
+  const vtmhip_me_result r = wk.ires[i];
+  const double           fWeight = j.bi ? 0.5 : 1.0;    // xGetMEDistortionWeight with BCW_DEFAULT (:7666-7676)
+  const double           lam = j.motionLambda;
+  vtmhip_me_out o;
+  o.intX = r.mvX; o.intY = r.mvY; o.intDist = r.dist;
+  unsigned bits = j.bits;
+  if( j.imv == 0 || j.imv == 3 )
+  {
+    const vtmhip_frac_result f = wk.fres[i];
+    const int qx = ( r.mvX << 2 ) + ( f.halfX << 1 ) + f.qterX, qy = ( r.mvY << 2 ) + ( f.halfY << 1 ) + f.qterY;
+    const unsigned mvBits = mv_bits( qx, qy, prec_down( j.mvPredHor, 2 ), prec_down( j.mvPredVer, 2 ), 0, imv_shift( j.imv ) );
+    bits += mvBits;
+    o.cost = ( unsigned long long ) ( floor( fWeight * ( ( double ) f.cost - ( double ) rate( lam, mvBits ) ) ) + ( double ) rate( lam, bits ) );   // :3483
+    o.mvHor = qx << 2; o.mvVer = qy << 2; o.mvPredHor = j.mvPredHor; o.mvPredVer = j.mvPredVer; o.mvpIdx = j.mvpIdx; o.bits = bits;
+  }
+  else
+  {
+    const int sh = amvr_shift( j.imv );
+    bits -= j.mvpIdxBits[j.mvpIdx & 1];
+    unsigned long long bestDist = ~0ull, satd = 0;
+    int                bestH = r.mvX << 4, bestV = r.mvY << 4, bestBits = 0, bestIdx = j.mvpIdx;
+    for( int pos = 0; pos < 9; pos++ )
+    {
+      int t0h = 0, t0v = 0;
+      for( int c = 0; c < j.numAmvpCand && c < 2; c++ )
+      {
+        int th, tv;
+        refine_test_mv( j, r.mvX, r.mvY, pos, c, th, tv );
+        if( c == 0 ) { t0h = th; t0v = tv; }
+        unsigned long long dist;
+        if( c == 0 || th != t0h || tv != t0v ) dist = satd = ( unsigned long long ) ( ( double ) wk.dout[( long ) i * REFINE_SLOTS + pos * 2 + c] * fWeight );
+        else dist = satd;
+        const int mvBits = ( int ) j.mvpIdxBits[c]
+                         + ( int ) mv_bits( prec_down( th, sh ), prec_down( tv, sh ), prec_down( j.amvpCand[c][0], sh ), prec_down( j.amvpCand[c][1], sh ), 0, 0 );
+        dist += rate( lam, ( unsigned ) mvBits );
+        if( dist < bestDist ) { bestDist = dist; bestH = th; bestV = tv; bestIdx = c; bestBits = mvBits; }
+      }
+    }
+    o.mvHor = bestH; o.mvVer = bestV; o.mvpIdx = bestIdx; o.mvPredHor = j.amvpCand[bestIdx][0]; o.mvPredVer = j.amvpCand[bestIdx][1];
+    bits += ( unsigned ) bestBits;
+    o.bits = bits;
+    o.cost = bestDist - rate( lam, ( unsigned ) bestBits ) + rate( lam, bits );
+  }
+  out[i] = o;
+}
+
+size_t align_up( size_t v ) { return ( v + 255 ) & ~( size_t ) 255; }
+
+}   // namespace
+
+extern "C" int vtmhip_xMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg *cfg, const int16_t *d_orgBase,
+                                                   const int16_t *d_refBase, const int16_t *d_otherPredBase, const vtmhip_me_job *d_jobs, int n,
+                                                   int maxWidth, int maxHeight, vtmhip_me_out *d_results )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, pic && cfg && d_orgBase && d_refBase && d_jobs && d_results, "null pointer" );
+  VTMHIP_REQUIRE( ctx, maxWidth >= 4 && maxWidth <= 128 && maxHeight >= 4 && maxHeight <= 128, "maxWidth / maxHeight" );
+  VTMHIP_REQUIRE( ctx, cfg->uniformImv >= -1 && cfg->uniformImv <= 3, "uniformImv" );
+  VTMHIP_REQUIRE( ctx, cfg->bipredSearchRange >= 0 && cfg->bipredSearchRange <= 64, "bipredSearchRange" );
+  VTMHIP_REQUIRE( ctx, !cfg->uniformSquare || maxWidth == maxHeight, "uniformSquare needs maxWidth == maxHeight" );
+
+  // workspace layout
+  Work   wk;
+  size_t off = 0;
+  const size_t slotSamples = ( size_t ) maxWidth * maxHeight;
+  const size_t oPattern = off; off = align_up( off + ( size_t ) n * slotSamples * sizeof( int16_t ) );
+  const size_t oTz      = off; off = align_up( off + ( size_t ) n * sizeof( vtmhip_tz_job ) );
+  const size_t oFull    = off; off = align_up( off + ( size_t ) n * sizeof( vtmhip_full_job ) );
+  const size_t oIres    = off; off = align_up( off + ( size_t ) n * sizeof( vtmhip_me_result ) );
+  const size_t oFrac    = off; off = align_up( off + ( size_t ) n * sizeof( vtmhip_frac_job ) );
+  const size_t oFres    = off; off = align_up( off + ( size_t ) n * sizeof( vtmhip_frac_result ) );
+  const size_t oDist    = off; off = align_up( off + ( size_t ) n * REFINE_SLOTS * sizeof( vtmhip_dist_job ) );
+  const size_t oDout    = off; off = align_up( off + ( size_t ) n * REFINE_SLOTS * sizeof( unsigned long long ) );
+  int st = vtmhip_internal_workspace( ctx, off );
+  if( st ) return st;
+  char *base = ( char * ) ctx->work;
+  wk.pattern = ( int16_t * ) ( base + oPattern ); wk.tz = ( vtmhip_tz_job * ) ( base + oTz ); wk.full = ( vtmhip_full_job * ) ( base + oFull );
+  wk.ires = ( vtmhip_me_result * ) ( base + oIres ); wk.frac = ( vtmhip_frac_job * ) ( base + oFrac ); wk.fres = ( vtmhip_frac_result * ) ( base + oFres );
+  wk.dist = ( vtmhip_dist_job * ) ( base + oDist ); wk.dout = ( unsigned long long * ) ( base + oDout ); wk.slotSamples = ( long ) slotSamples;
+
+  const dim3 perJob( ( n + 255 ) / 256 ), tpb( 256 );
+  const int  big = maxWidth > maxHeight ? maxWidth : maxHeight;
+  vtmhip_pic_params pTz = *pic, pFull = *pic;
+  if( pic->wavesPerJob == 0 )   // tuning defaults by block size (waves that share one search)
+  {
+    pTz.wavesPerJob   = big > 16 ? 4 : big > 8 ? 2 : 1;
+    pFull.wavesPerJob = big > 64 ? 16 : big > 32 ? 8 : big > 16 ? 4 : 1;
+  }
+
+  hipLaunchKernelGGL( mest_pattern_kernel, dim3( n ), tpb, 0, ctx->stream, d_orgBase, d_otherPredBase ? d_otherPredBase : d_orgBase, d_jobs, wk );
+  hipLaunchKernelGGL( mest_prepare_kernel, perJob, tpb, 0, ctx->stream, *pic, *cfg, d_jobs, n, wk );
+  VTMHIP_LAUNCHED( ctx );
+  // bi-pred: start candidates -> best start -> exhaustive search
+  st = vtmhip_dist_batch_dev( ctx, wk.pattern, d_refBase, wk.dist, n * REFINE_SLOTS, ( uint64_t * ) wk.dout );
+  if( st ) return st;
+  hipLaunchKernelGGL( mest_bi_start_kernel, perJob, tpb, 0, ctx->stream, *pic, *cfg, d_jobs, n, wk );
+  VTMHIP_LAUNCHED( ctx );
+  st = vtmhip_full_search_batch_dev( ctx, &pFull, wk.pattern, d_refBase, wk.full, n, wk.ires );
+  if( st ) return st;
+  // uni: TZ search
+  st = vtmhip_tz_search_batch_dev( ctx, &pTz, wk.pattern, d_refBase, wk.tz, n, wk.ires );
+  if( st ) return st;
+  hipLaunchKernelGGL( mest_mid_kernel, perJob, tpb, 0, ctx->stream, *pic, *cfg, d_jobs, n, wk );
+  VTMHIP_LAUNCHED( ctx );
+  const int uimv = cfg->uniformImv;
+  if( uimv == -1 || uimv == 0 || uimv == 3 )
+  {
+    st = vtmhip_frac_search_batch_dev( ctx, wk.pattern, d_refBase, wk.frac, n, maxWidth, maxHeight, cfg->uniformSquare && uimv != -1, wk.fres );
+    if( st ) return st;
+  }
+  if( uimv == -1 || uimv == 1 || uimv == 2 )
+  {
+    st = vtmhip_dist_batch_dev( ctx, wk.pattern, d_refBase, wk.dist, n * REFINE_SLOTS, ( uint64_t * ) wk.dout );
+    if( st ) return st;
+  }
+  hipLaunchKernelGGL( mest_final_kernel, perJob, tpb, 0, ctx->stream, *cfg, d_jobs, n, wk, d_results );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}

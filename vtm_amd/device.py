@@ -177,6 +177,11 @@ class Context:
     def full_search_batch(self, pic, d_org, d_ref, d_jobs, n, d_results):
         self._check(self.L.vtmhip_full_search_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, d_results))
 
+    def motion_estimation_batch(self, pic, cfg, d_org, d_ref, d_other, d_jobs, n, max_w, max_h, d_results):
+        """InterSearch::xMotionEstimation for n (PU, list, refIdx) jobs (vtmhip_xMotionEstimation_batch_dev)."""
+        self._check(self.L.vtmhip_xMotionEstimation_batch_dev(self.h, C.byref(pic), C.byref(cfg), d_org, d_ref, d_other, d_jobs, n,
+                                                              max_w, max_h, d_results))
+
     def mc_luma_batch(self, d_ref, d_dst, d_jobs, n, max_w, max_h):
         self._check(self.L.vtmhip_mc_luma_batch_dev(self.h, d_ref, d_dst, d_jobs, n, max_w, max_h))
 

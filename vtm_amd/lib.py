@@ -105,8 +105,29 @@ class AffineJob(C.Structure):
                 ("height", C.c_int16), ("sixParam", C.c_uint8), ("pad", C.c_uint8 * 7)]
 
 
+class MeCfg(C.Structure):
+    _fields_ = [("bipredSearchRange", C.c_int32), ("useHadME", C.c_uint8), ("fastInterSearchMode13", C.c_uint8),
+                ("extendedSettings", C.c_uint8), ("firstSearchStop", C.c_uint8), ("uniformImv", C.c_int32), ("uniformSquare", C.c_int32)]
+
+
+class MeJob(C.Structure):
+    _fields_ = [("orgOff", C.c_int64), ("refOff", C.c_int64), ("otherPredOff", C.c_int64), ("orgStride", C.c_int32),
+                ("refStride", C.c_int32), ("otherPredStride", C.c_int32), ("puX", C.c_int16), ("puY", C.c_int16),
+                ("width", C.c_int16), ("height", C.c_int16), ("bi", C.c_uint8), ("imv", C.c_uint8), ("mvpIdx", C.c_uint8),
+                ("numAmvpCand", C.c_uint8), ("mvPredHor", C.c_int32), ("mvPredVer", C.c_int32), ("mvHor", C.c_int32),
+                ("mvVer", C.c_int32), ("amvpCand", (C.c_int32 * 2) * 2), ("mvpIdxBits", C.c_uint32 * 2), ("bits", C.c_uint32),
+                ("searchRange", C.c_int32), ("motionLambda", C.c_double), ("numExtraStart", C.c_int32),
+                ("extraStart", (C.c_int32 * 2) * 15), ("pad", C.c_int32)]
+
+
+class MeOut(C.Structure):
+    _fields_ = [("mvHor", C.c_int32), ("mvVer", C.c_int32), ("mvPredHor", C.c_int32), ("mvPredVer", C.c_int32),
+                ("mvpIdx", C.c_int32), ("bits", C.c_uint32), ("cost", C.c_uint64), ("intX", C.c_int32), ("intY", C.c_int32),
+                ("intDist", C.c_uint64)]
+
+
 _STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob,
-            TuJob, TuResult, AffineJob]   # order of vtmhip_struct_size(which)
+            TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
 _PROTOS = {
@@ -163,6 +184,8 @@ _PROTOS = {
     "vtmhip_dist_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vtmhip_satd8_grid_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),
+    "vtmhip_xMotionEstimation_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.POINTER(MeCfg), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vtmhip_tz_search_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_void_p]),
 }
