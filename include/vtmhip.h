@@ -263,10 +263,16 @@ typedef struct
   int16_t width, height;
   int32_t mvHor, mvVer;         /* internal 1/16 precision */
   uint8_t bi;                   /* 0: rounded + clipped samples (uni-pred); 1: 14-bit intermediates for addAvg */
-  uint8_t bitDepth, useAltHpelIf, pad;
+  uint8_t bitDepth, useAltHpelIf;
+  uint8_t chroma;               /* 0: luma plane, 8-tap, width/height/offsets in luma samples; 1: a 4:2:0 chroma plane, 4-tap at 1/32 phase --
+                                   width/height/refOff/dstOff in samples of THAT plane, the vector still in luma 1/16 units */
 } vtmhip_mc_job;
 
-/* InterPrediction::xPredInterBlk, luma, no BDOF/DMVR/RPR/wrap-around (InterPrediction.cpp:660-815) */
+/* InterPrediction::xPredInterBlk without BDOF/DMVR/RPR/wrap-around (InterPrediction.cpp:660-815), luma and 4:2:0 chroma blocks mixed
+ * freely in one batch (vtmhip_mc_job::chroma); maxWidth/maxHeight bound the block sizes of the batch (2..128). */
+int vtmhip_mc_batch_dev( vtmhip_ctx *ctx, const int16_t *d_refBase, int16_t *d_dstBase, const vtmhip_mc_job *d_jobs, int n, int maxWidth,
+                         int maxHeight );
+/* the same call under its first name (luma-only callers) */
 int vtmhip_mc_luma_batch_dev( vtmhip_ctx *ctx, const int16_t *d_refBase, int16_t *d_dstBase, const vtmhip_mc_job *d_jobs, int n, int maxWidth,
                               int maxHeight );
 

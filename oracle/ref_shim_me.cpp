@@ -354,3 +354,42 @@ extern "C" void ref_motion_estimation( const vo_mest_cfg_t *cfg, const vo_mest_j
   r.cu.chromaFormat = CHROMA_420;
   r.pu.chromaFormat = CHROMA_420;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// InterPrediction::xPredInterBlk (CommonLib/InterPrediction.cpp:660-815) for one component of one PU: the three planes of a
+// 4:2:0 reference picture alias the caller's buffers (plane origin pointers), the prediction goes to the caller's block.
+// comp 0 luma, 1 Cb, 2 Cr.  w, h: LUMA size of the PU; mv in internal 1/16 luma units.
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" void ref_pred_inter_blk( int comp, const int16_t *planeY, int strideY, const int16_t *planeC, int strideC, int picW, int picH, int puX, int puY,
+                                    int w, int h, int mvHor, int mvVer, int bi, int bitDepth, int imv, int16_t *dst, int dstStride )
+{
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  static Picture *pic = nullptr;
+  if( !pic )
+  {
+    pic = new Picture();
+    for( int c = 1; c < 3; c++ ) r.is.m_filteredBlockTmp[0][c] = ( Pel * ) xMalloc( Pel, ( MAX_CU_SIZE + 16 + 4 ) * ( MAX_CU_SIZE + 1 + 16 + 7 + 4 ) );
+  }
+  r.pps.setPicWidthInLumaSamples( picW );
+  r.pps.setPicHeightInLumaSamples( picH );
+  const UnitArea ua( CHROMA_420, Area( puX, puY, w, h ) );
+  r.cu.UnitArea::operator=( ua );
+  r.pu.UnitArea::operator=( ua );
+  r.cu.chromaFormat = CHROMA_420;
+  r.pu.chromaFormat = CHROMA_420;
+  r.cu.imv = imv;
+  pic->chromaFormat = CHROMA_420;
+  pic->unscaledPic  = pic;
+  Pel *py = const_cast<Pel *>( planeY ), *pc = const_cast<Pel *>( planeC );
+  pic->m_bufs[PIC_RECONSTRUCTION].createFromBuf(
+    PelUnitBuf( CHROMA_420, PelBuf( py, strideY, picW, picH ), PelBuf( pc, strideC, picW / 2, picH / 2 ), PelBuf( pc, strideC, picW / 2, picH / 2 ) ) );
+  ClpRng clp; clp.min = 0; clp.max = ( 1 << bitDepth ) - 1; clp.bd = bitDepth; clp.n = 0;
+  const int  cw = comp ? w / 2 : w, ch = comp ? h / 2 : h;
+  PelBuf     d( dst, dstStride, cw, ch );
+  PelUnitBuf dstPic( CHROMA_420, comp == 0 ? d : PelBuf(), comp == 1 ? d : PelBuf(), comp == 2 ? d : PelBuf() );
+  r.is.xPredInterBlk( ComponentID( comp ), r.pu, pic, Mv( mvHor, mvVer ), dstPic, bi != 0, clp, false, false );
+  r.cu.imv = 0;
+  r.cu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+  r.pu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+}

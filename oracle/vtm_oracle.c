@@ -1176,6 +1176,29 @@ void vo_mc_luma( const int16_t *ref, int refStride, int w, int h, int mvHor, int
   }
 }
 
+/* xPredInterBlk for luma (comp 0) or a 4:2:0 chroma plane (comp 1 / 2): the vector stays in luma 1/16 units, so the chroma phase
+ * has 5 bits (1/32 sample) and the 4-tap chroma filter applies (InterPrediction.cpp:675-676, 693-694, 766-785).
+ * `ref` points at the block position with MV (0,0) in THAT plane; w, h in samples of that plane. */
+void vo_mc_block( int comp, const int16_t *ref, int refStride, int w, int h, int mvHor, int mvVer, int bi, int bitDepth, int useAltHpelIf,
+                  int16_t *dst, int dstStride )
+{
+  if( comp == 0 )
+  {
+    vo_mc_luma( ref, refStride, w, h, mvHor, mvVer, bi, bitDepth, useAltHpelIf, dst, dstStride );
+    return;
+  }
+  const int      xFrac = mvHor & 31, yFrac = mvVer & 31, rndRes = !bi;
+  const int16_t *src   = ref + ( ptrdiff_t )( mvVer >> 5 ) * refStride + ( mvHor >> 5 );
+  if( yFrac == 0 ) vo_if_hor( comp, src, refStride, dst, dstStride, w, h, xFrac, rndRes, bitDepth, 0, 0, useAltHpelIf );
+  else if( xFrac == 0 ) vo_if_ver( comp, src, refStride, dst, dstStride, w, h, yFrac, 1, rndRes, bitDepth, 0, 0, useAltHpelIf );
+  else
+  {
+    int16_t tmp[64 * ( 64 + 3 )];
+    vo_if_hor( comp, src - refStride, refStride, tmp, w, w, h + 3, xFrac, 0, bitDepth, 0, 0, useAltHpelIf );
+    vo_if_ver( comp, tmp + w, w, dst, dstStride, w, h, yFrac, 0, rndRes, bitDepth, 0, 0, useAltHpelIf );
+  }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * InterSearch::xMotionEstimation (EncoderLib/InterSearch.cpp:3299-3494) for one (PU, list, refIdx), without BCW,
  * weighted prediction, MCTS, composite references and the block-MV cache (none is on in the CTC), with

@@ -84,6 +84,8 @@ void vo_if_ver( int compID, const int16_t *src, int srcStride, int16_t *dst, int
                 int bitDepth, int nFilterIdx, int biMCForDMVR, int useAltHpelIf );
 void vo_mc_luma( const int16_t *ref, int refStride, int w, int h, int mvHor, int mvVer, int bi, int bitDepth, int useAltHpelIf, int16_t *dst,
                  int dstStride );
+void vo_mc_block( int comp, const int16_t *ref, int refStride, int w, int h, int mvHor, int mvVer, int bi, int bitDepth, int useAltHpelIf,
+                  int16_t *dst, int dstStride );
 void vo_interp_qpel( const int16_t *pat, int ps, int w, int h, int bitDepth, int qx, int qy, int16_t *dst, int ds );
 
 int vo_tr_matrix( int type, int n, int16_t *out );

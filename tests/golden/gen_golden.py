@@ -262,6 +262,41 @@ def gen_mest():
     print("mest:", len(jobs), "jobs")
 
 
+def gen_mc():
+    """InterPrediction::xPredInterBlk through ref_pred_inter_blk (oracle/ref_shim_me.cpp): luma and 4:2:0 chroma blocks of the synthetic
+    clip (re-synthesised from its seed), rows = (comp, x, y, w, h, mvHor, mvVer, bi, imv), outputs concatenated."""
+    from vtm_amd import synth
+    W, H, m = 416, 240, 64
+    y, u, v = synth.gen_frames(W, H, 1, chroma=True)[0]
+    yb, yo, ys = synth.extend_plane(y, m)
+    ub, uo, us = synth.extend_plane(u, m // 2)
+    g = np.random.default_rng(555)
+    meta, outs = [], []
+    t = 0
+    while len(meta) < 240:
+        t += 1
+        w, h = int(g.choice([4, 8, 16, 32, 64, 128])), int(g.choice([4, 8, 16, 32, 64, 128]))
+        if w == 4 and h == 4:
+            continue
+        x, yy = int(g.integers(0, (W - w) // 4 + 1)) * 4, int(g.integers(0, (H - h) // 4 + 1)) * 4
+        mvh, mvv = int(g.integers(-20 * 16, 20 * 16)), int(g.integers(-20 * 16, 20 * 16))
+        if t % 5 == 0:
+            mvh &= ~15
+        if t % 7 == 0:
+            mvv &= ~15
+        if t % 11 == 0:
+            mvh = (mvh & ~15) | 8
+        bi, imv, comp = t % 2, 3 if t % 3 == 0 else 0, (0, 1, 2)[t % 3]
+        cw, ch = (w // 2, h // 2) if comp else (w, h)
+        out = np.zeros((ch, cw), np.int16)
+        R.ref_pred_inter_blk(comp, C.c_void_p(yb.ctypes.data + 2 * yo), ys, C.c_void_p(ub.ctypes.data + 2 * uo), us, W, H, x, yy, w, h, mvh, mvv,
+                             bi, 10, imv, ol.P(out), cw)
+        meta.append((comp, x, yy, w, h, mvh, mvv, bi, imv))
+        outs.append(out.reshape(-1))
+    np.savez_compressed(os.path.join(HERE, "mc.npz"), meta=np.array(meta, np.int32), out=np.concatenate(outs))
+    print("mc:", len(meta), "blocks")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected fixtures only: gen_golden.py mest quant ...
         for name in sys.argv[1:]:
@@ -275,3 +310,4 @@ if __name__ == "__main__":
     gen_misc()
     gen_quant()
     gen_mest()
+    gen_mc()

@@ -80,3 +80,32 @@ def test_quant_golden(ctx):
     ctx.dequant_batch(d_q.ptr, d_dq.ptr, d_jobs.ptr, n)
     assert np.array_equal(d_q.to_host(), z["q"]) and np.array_equal(d_dq.to_host(), z["dq"])
     assert np.array_equal(d_sum.to_host().astype(np.int64), meta[:, 5])
+
+
+def test_mc_luma_chroma_golden(ctx):
+    """vtmhip_mc_batch_dev (luma + 4:2:0 chroma jobs in one batch) vs xPredInterBlk outputs recorded from the real reference."""
+    from vtm_amd import synth
+    from vtm_amd.lib import McJob
+    z = np.load(os.path.join(G, "mc.npz"))
+    W, H, m = 416, 240, 64
+    y, u, v = synth.gen_frames(W, H, 1, chroma=True)[0]
+    yb, yo, ys = synth.extend_plane(y, m)
+    ub, uo, us = synth.extend_plane(u, m // 2)
+    planes = np.concatenate([yb, ub])          # one device buffer: luma plane, then the chroma plane
+    meta = z["meta"].tolist()
+    arr = (McJob * len(meta))()
+    pos = 0
+    for k, (comp, x, yy, w, h, mvh, mvv, bi, imv) in enumerate(meta):
+        cw, ch = (w // 2, h // 2) if comp else (w, h)
+        t = arr[k]
+        t.refOff = (yb.size + uo + (yy // 2) * us + x // 2) if comp else (yo + yy * ys + x)
+        t.refStride = us if comp else ys
+        t.dstOff, t.dstStride, t.width, t.height = pos, cw, cw, ch
+        t.mvHor, t.mvVer, t.bi, t.bitDepth, t.useAltHpelIf, t.chroma = mvh, mvv, bi, 10, int(imv == 3), int(comp != 0)
+        pos += cw * ch
+    d_ref = ctx.to_device(planes)
+    d_jobs = ctx.to_device(np.frombuffer(arr, np.uint8))
+    d_dst = ctx.alloc(2 * pos)
+    ctx.mc_batch(d_ref.ptr, d_dst.ptr, d_jobs.ptr, len(meta), 128, 128)
+    got = d_dst.to_host(np.int16)
+    assert np.array_equal(got, z["out"])

@@ -134,3 +134,27 @@ def test_motion_estimation_golden(oracle):
         r = ol.MestResult()
         oracle.vo_motion_estimation(C.byref(cfg), C.byref(t), C.byref(r))
         assert r.key() == tuple(int(v) for v in exp), j
+
+
+def _mc_planes():
+    from vtm_amd import synth
+    W, H, m = 416, 240, 64
+    y, u, v = synth.gen_frames(W, H, 1, chroma=True)[0]
+    return synth.extend_plane(y, m), synth.extend_plane(u, m // 2)
+
+
+def test_mc_golden(oracle):
+    """xPredInterBlk outputs recorded from the real member function (gen_golden.py gen_mc): luma and 4:2:0 chroma."""
+    z = np.load(os.path.join(G, "mc.npz"))
+    (yb, yo, ys), (ub, uo, us) = _mc_planes()
+    pos = 0
+    for comp, x, y, w, h, mvh, mvv, bi, imv in z["meta"].tolist():
+        cw, ch = (w // 2, h // 2) if comp else (w, h)
+        a = np.zeros((ch, cw), np.int16)
+        if comp:
+            refp, st = ub.ctypes.data + 2 * (uo + (y // 2) * us + x // 2), us
+        else:
+            refp, st = yb.ctypes.data + 2 * (yo + y * ys + x), ys
+        oracle.vo_mc_block(comp, C.c_void_p(refp), st, cw, ch, mvh, mvv, bi, 10, int(imv == 3), ol.P(a), cw)
+        assert np.array_equal(a.reshape(-1), z["out"][pos:pos + cw * ch]), (comp, x, y, w, h, mvh, mvv, bi, imv)
+        pos += cw * ch

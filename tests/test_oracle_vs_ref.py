@@ -204,3 +204,40 @@ def test_motion_estimation_equals_reference_xMotionEstimation(oracle, reflib, us
             assert (a.intX, a.intY) == (b.intX, b.intY)
         seen.add((j["bi"], j["imv"]))
     assert len(seen) == 8   # uni / bi x the four AMVR modes
+
+
+def test_pred_inter_blk_luma_and_chroma(oracle, reflib):
+    """InterPrediction::xPredInterBlk on a rig (real member function, Picture aliasing our planes) vs vo_mc_block: luma 8-tap / chroma
+    4-tap at 1/32 phase, uni (rounded, clipped) and bi (14-bit intermediates), alternative half-sample filter."""
+    from vtm_amd import synth
+    W, H, m = 416, 240, 64
+    y, u, v = synth.gen_frames(W, H, 1, chroma=True)[0]
+    yb, yo, ys = synth.extend_plane(y, m)
+    ub, uo, us = synth.extend_plane(u, m // 2)
+    rng = np.random.default_rng(77)
+    for t in range(500):
+        w = int(rng.choice([4, 8, 16, 32, 64, 128]))
+        h = int(rng.choice([4, 8, 16, 32, 64, 128]))
+        if w > W or h > H or (w == 4 and h == 4):
+            continue
+        x = int(rng.integers(0, (W - w) // 4 + 1)) * 4
+        yy = int(rng.integers(0, (H - h) // 4 + 1)) * 4
+        mvh, mvv = int(rng.integers(-20 * 16, 20 * 16)), int(rng.integers(-20 * 16, 20 * 16))
+        if t % 5 == 0:
+            mvh &= ~15
+        if t % 7 == 0:
+            mvv &= ~15
+        if t % 11 == 0:
+            mvh = (mvh & ~15) | 8
+        bi, imv, comp = int(t % 2), 3 if t % 3 == 0 else 0, int(t % 3 != 1) and (1 + t % 2) or 0
+        cw, ch = (w // 2, h // 2) if comp else (w, h)
+        a, b = np.zeros((ch, cw), np.int16), np.zeros((ch, cw), np.int16)
+        if comp:
+            refp = ub.ctypes.data + 2 * (uo + (yy // 2) * us + x // 2)
+            oracle.vo_mc_block(comp, C.c_void_p(refp), us, cw, ch, mvh, mvv, bi, 10, int(imv == 3), ol.P(a), cw)
+        else:
+            refp = yb.ctypes.data + 2 * (yo + yy * ys + x)
+            oracle.vo_mc_block(0, C.c_void_p(refp), ys, cw, ch, mvh, mvv, bi, 10, int(imv == 3), ol.P(a), cw)
+        reflib.ref_pred_inter_blk(comp, C.c_void_p(yb.ctypes.data + 2 * yo), ys, C.c_void_p(ub.ctypes.data + 2 * uo), us, W, H, x, yy, w, h, mvh, mvv,
+                                  bi, 10, imv, ol.P(b), cw)
+        assert np.array_equal(a, b), (t, comp, w, h, mvh, mvv, bi, imv)

@@ -1,6 +1,6 @@
-// mc.hip -- luma motion compensation of whole blocks and the two PelBufferOps of bi-predictive ME.
+// mc.hip -- motion compensation of whole blocks (luma 8-tap, 4:2:0 chroma 4-tap) and the two PelBufferOps of bi-predictive ME.
 //
-// Reference: CommonLib/InterPrediction.cpp xPredInterBlk :660-815 (luma, no BDOF/DMVR/RPR/wrap-around):
+// Reference: CommonLib/InterPrediction.cpp xPredInterBlk :660-815 (no BDOF/DMVR/RPR/wrap-around):
 //   yFrac == 0 -> filterHor(isLast = rndRes); xFrac == 0 -> filterVer(first, isLast = rndRes);
 //   else filterHor(first, !last) on rows -3..H+3 then filterVer(!first, isLast = rndRes);   rndRes = !bi.
 // CommonLib/Buffer.cpp removeHighFreq :475-520 (org = 2*org - pred, unclipped: ClipForBiPredMEEnabled = 0),
@@ -51,16 +51,24 @@ __device__ __forceinline__ const int16_t *luma_taps( int frac, int w, int h, int
   return c_lumaFilterMc[frac];
 }
 
-__global__ __launch_bounds__( 64 ) void mc_luma_kernel( const int16_t *__restrict__ refBase, int16_t *__restrict__ dstBase,
-                                                       const vtmhip_mc_job *__restrict__ jobs, int maxW, int maxH )
+// H.266 table 28 (chroma 4-tap filter, 1/32 sample phases), InterpolationFilter.cpp:132-166
+__constant__ int16_t c_chromaFilterMc[32][4] = {
+  { 0, 64, 0, 0 },    { -1, 63, 2, 0 },   { -2, 62, 4, 0 },   { -2, 60, 7, -1 },  { -2, 58, 10, -2 }, { -3, 57, 12, -2 }, { -4, 56, 14, -2 }, { -4, 55, 15, -2 },
+  { -4, 54, 16, -2 }, { -5, 53, 18, -2 }, { -6, 52, 20, -2 }, { -6, 49, 24, -3 }, { -6, 46, 28, -4 }, { -5, 44, 29, -4 }, { -4, 42, 30, -4 }, { -4, 39, 33, -4 },
+  { -4, 36, 36, -4 }, { -4, 33, 39, -4 }, { -4, 30, 42, -4 }, { -4, 29, 44, -5 }, { -4, 28, 46, -6 }, { -3, 24, 49, -6 }, { -2, 20, 52, -6 }, { -2, 18, 53, -5 },
+  { -2, 16, 54, -4 }, { -2, 15, 55, -4 }, { -2, 14, 56, -4 }, { -2, 12, 57, -3 }, { -2, 10, 58, -2 }, { -1, 7, 60, -2 },  { 0, 4, 62, -2 },   { 0, 2, 63, -1 } };
+
+// One block, one wave.  NT = 8: luma (phase = 4 fraction bits); NT = 4: a 4:2:0 chroma plane (the vector stays in luma 1/16 units, so
+// the phase has 5 bits; InterPrediction.cpp:675-676).  lds holds the (h + NT - 1) x w horizontal-pass intermediates.
+template<int NT>
+__device__ __forceinline__ void mc_block( const vtmhip_mc_job &j, const int16_t *__restrict__ refBase, int16_t *__restrict__ dstBase, int16_t *lds, int lane )
 {
-  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];   // [(h+7)][w] H-pass intermediates
-  const vtmhip_mc_job j    = jobs[blockIdx.x];
-  const int           lane = threadIdx.x, w = j.width, h = j.height, bd = j.bitDepth;
-  const int           xFrac = j.mvHor & 15, yFrac = j.mvVer & 15, rnd = !j.bi;
-  const bool          alt = j.useAltHpelIf != 0;
-  const int16_t      *src = refBase + j.refOff + ( long ) ( j.mvVer >> 4 ) * j.refStride + ( j.mvHor >> 4 );
-  int16_t            *dst = dstBase + j.dstOff;
+  constexpr int FB = NT == 8 ? 4 : 5, HALO = NT / 2 - 1;
+  const int     w = j.width, h = j.height, bd = j.bitDepth;
+  const int     xFrac = j.mvHor & ( ( 1 << FB ) - 1 ), yFrac = j.mvVer & ( ( 1 << FB ) - 1 ), rnd = !j.bi;
+  const bool    alt = j.useAltHpelIf != 0;
+  const int16_t *src = refBase + j.refOff + ( long ) ( j.mvVer >> FB ) * j.refStride + ( j.mvHor >> FB );
+  int16_t       *dst = dstBase + j.dstOff;
   if( yFrac == 0 )
   {
     if( xFrac == 0 && rnd )   // filterCopy<true,true>: plain copy
@@ -69,40 +77,40 @@ __global__ __launch_bounds__( 64 ) void mc_luma_kernel( const int16_t *__restric
       return;
     }
     const Fir      f = fir_params( 1, rnd, bd );
-    const int16_t *c = luma_taps( xFrac, w, h, h, alt );
+    const int16_t *c = NT == 8 ? luma_taps( xFrac, w, h, h, alt ) : c_chromaFilterMc[xFrac];
     for( int i = lane; i < w * h; i += 64 )
     {
       const int y = i / w, x = i - y * w;
       int       sum = 0;
 #pragma unroll
-      for( int k = 0; k < 8; k++ ) sum += ( int ) src[( long ) y * j.refStride + x + k - 3] * ( int ) c[k];
+      for( int k = 0; k < NT; k++ ) sum += ( int ) src[( long ) y * j.refStride + x + k - HALO] * ( int ) c[k];
       dst[( long ) y * j.dstStride + x] = fir_out( sum, f );
     }
   }
   else if( xFrac == 0 )
   {
     const Fir      f = fir_params( 1, rnd, bd );
-    const int16_t *c = luma_taps( yFrac, w, h, h, alt );
+    const int16_t *c = NT == 8 ? luma_taps( yFrac, w, h, h, alt ) : c_chromaFilterMc[yFrac];
     for( int i = lane; i < w * h; i += 64 )
     {
       const int y = i / w, x = i - y * w;
       int       sum = 0;
 #pragma unroll
-      for( int k = 0; k < 8; k++ ) sum += ( int ) src[( long ) ( y + k - 3 ) * j.refStride + x] * ( int ) c[k];
+      for( int k = 0; k < NT; k++ ) sum += ( int ) src[( long ) ( y + k - HALO ) * j.refStride + x] * ( int ) c[k];
       dst[( long ) y * j.dstStride + x] = fir_out( sum, f );
     }
   }
   else
   {
     const Fir      fh = fir_params( 1, 0, bd ), fv = fir_params( 0, rnd, bd );
-    const int16_t *ch = luma_taps( xFrac, w, h, h + 7 == 11 ? 4 : -1, alt );   // the H pass sees a W x (H+7) block: 4 x 11 takes the 4x4 taps
-    const int16_t *cv = luma_taps( yFrac, w, h, h, alt );
-    for( int i = lane; i < w * ( h + 7 ); i += 64 )
+    const int16_t *ch = NT == 8 ? luma_taps( xFrac, w, h, h + 7 == 11 ? 4 : -1, alt ) : c_chromaFilterMc[xFrac];   // luma H pass sees W x (H+7): 4 x 11 takes the 4x4 taps
+    const int16_t *cv = NT == 8 ? luma_taps( yFrac, w, h, h, alt ) : c_chromaFilterMc[yFrac];
+    for( int i = lane; i < w * ( h + NT - 1 ); i += 64 )
     {
       const int r = i / w, x = i - r * w;
       int       sum = 0;
 #pragma unroll
-      for( int k = 0; k < 8; k++ ) sum += ( int ) src[( long ) ( r - 3 ) * j.refStride + x + k - 3] * ( int ) ch[k];
+      for( int k = 0; k < NT; k++ ) sum += ( int ) src[( long ) ( r - HALO ) * j.refStride + x + k - HALO] * ( int ) ch[k];
       lds[i] = fir_out( sum, fh );
     }
     __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
@@ -112,10 +120,19 @@ __global__ __launch_bounds__( 64 ) void mc_luma_kernel( const int16_t *__restric
       const int y = i / w, x = i - y * w;
       int       sum = 0;
 #pragma unroll
-      for( int k = 0; k < 8; k++ ) sum += ( int ) lds[( y + k ) * w + x] * ( int ) cv[k];
+      for( int k = 0; k < NT; k++ ) sum += ( int ) lds[( y + k ) * w + x] * ( int ) cv[k];
       dst[( long ) y * j.dstStride + x] = fir_out( sum, fv );
     }
   }
+}
+
+__global__ __launch_bounds__( 64 ) void mc_kernel( const int16_t *__restrict__ refBase, int16_t *__restrict__ dstBase,
+                                                  const vtmhip_mc_job *__restrict__ jobs, int maxW, int maxH )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];   // [(h+7)][w] H-pass intermediates
+  const vtmhip_mc_job j = jobs[blockIdx.x];
+  if( j.chroma ) mc_block<4>( j, refBase, dstBase, lds, ( int ) threadIdx.x );
+  else mc_block<8>( j, refBase, dstBase, lds, ( int ) threadIdx.x );
 }
 
 __global__ __launch_bounds__( 256 ) void pelop_kernel( const int16_t *__restrict__ aBase, const int16_t *__restrict__ bBase, int16_t *__restrict__ dstBase,
@@ -147,13 +164,18 @@ extern "C"
 int vtmhip_mc_luma_batch_dev( vtmhip_ctx *ctx, const int16_t *d_refBase, int16_t *d_dstBase, const vtmhip_mc_job *d_jobs, int n, int maxWidth,
                               int maxHeight )
 {
+  return vtmhip_mc_batch_dev( ctx, d_refBase, d_dstBase, d_jobs, n, maxWidth, maxHeight );
+}
+
+int vtmhip_mc_batch_dev( vtmhip_ctx *ctx, const int16_t *d_refBase, int16_t *d_dstBase, const vtmhip_mc_job *d_jobs, int n, int maxWidth, int maxHeight )
+{
   VTMHIP_CHECK_CTX( ctx );
   VTMHIP_REQUIRE( ctx, n >= 0, "n" );
   if( n == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, d_refBase && d_dstBase && d_jobs, "null pointer" );
-  VTMHIP_REQUIRE( ctx, maxWidth >= 4 && maxWidth <= 128 && maxHeight >= 4 && maxHeight <= 128, "maxWidth / maxHeight" );
+  VTMHIP_REQUIRE( ctx, maxWidth >= 2 && maxWidth <= 128 && maxHeight >= 2 && maxHeight <= 128, "maxWidth / maxHeight" );
   const size_t lds = ( size_t ) maxWidth * ( maxHeight + 7 ) * sizeof( int16_t );
-  hipLaunchKernelGGL( mc_luma_kernel, dim3( n ), dim3( 64 ), lds, ctx->stream, d_refBase, d_dstBase, d_jobs, maxWidth, maxHeight );
+  hipLaunchKernelGGL( mc_kernel, dim3( n ), dim3( 64 ), lds, ctx->stream, d_refBase, d_dstBase, d_jobs, maxWidth, maxHeight );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

@@ -119,6 +119,15 @@ __device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy,
   return s;
 }
 
+// XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2), so block b takes
+// the work item at position (b % 8) * (n / 8) + b / 8 (bijective for any n): the workgroups running on one XCD at any moment
+// then hold NEIGHBOURING jobs of the table (PUs in raster order), whose search windows overlap and stay in that XCD's 4 MiB L2.
+__device__ __forceinline__ int xcd_order( int b, int n )
+{
+  const int q = n >> 3, r = n & 7, xcd = b & 7;
+  return ( xcd < r ? xcd * ( q + 1 ) : r * ( q + 1 ) + ( xcd - r ) * q ) + ( b >> 3 );
+}
+
 // lexicographic (cost, index) minimum over the wave
 __device__ __forceinline__ void wave_argmin( unsigned long long &cost, unsigned &idx )
 {
@@ -385,6 +394,67 @@ __device__ __forceinline__ void tz_two_point( const MeJob &j, TzState &s, int4 *
   tz_round<WPJ>( j, s, pts, n, co, true );
 }
 
+// Raster scan when a whole wave shares one candidate (lpc == 64, 8-sample segments, power-of-two row length): the lane's IPL
+// original segments stay in registers for the whole scan (they are the same for every candidate) and only the reference
+// segments are fetched per candidate, which halves the vector-memory traffic of the scan.  Candidate order and the
+// (cost, index) minimum are those of eval_candidates<true, WPJ>.
+template<int IPL, int WPJ>
+__device__ __forceinline__ void raster_resident_org( const MeJob &j, int total, int rLeft, int rTop, int nx, int stepXY, const Coop &co,
+                                                     unsigned long long &bestCost, unsigned &bestIdx )
+{
+  const int lane = co.lane;
+  const long os = ( long ) j.orgStride << j.ss, cs = ( long ) j.refStride << j.ss;
+  Pel8 o[IPL];
+  int  off[IPL];
+#pragma unroll
+  for( int m = 0; m < IPL; m++ )
+  {
+    const int it = lane + 64 * m, r = it >> j.sprShift, x = ( it - ( r << j.sprShift ) ) << 3;
+    o[m] = *reinterpret_cast<const Pel8 *>( j.org + r * os + x );
+#pragma unroll
+    for( int k = 0; k < 4; k++ ) o[m].v[k] ^= j.bias;
+    off[m] = ( int ) ( r * cs + x );
+  }
+  bestCost = ~0ull;
+  bestIdx  = 0xffffffffu;
+  int ry = co.wave / nx, rx = co.wave - ry * nx;          // candidate k = wave, wave + WPJ, ...
+  for( int k = co.wave; k < total; k += WPJ )
+  {
+    const int      x = rLeft + rx * stepXY, y = rTop + ry * stepXY;
+    const int16_t *c0 = j.ref + ( long ) y * j.refStride + x;
+    unsigned       s = 0;
+#pragma unroll
+    for( int m = 0; m < IPL; m++ )
+    {
+      const Pel8 b = *reinterpret_cast<const Pel8 *>( c0 + off[m] );
+#pragma unroll
+      for( int q = 0; q < 4; q++ ) s = sad2( o[m].v[q], b.v[q] ^ j.bias, s );
+    }
+#pragma unroll
+    for( int sh = 32; sh > 0; sh >>= 1 ) s += __shfl_xor( s, sh, 64 );
+    const unsigned long long c = ( ( unsigned long long ) uni( s ) << j.ss ) + mv_cost( j, x, y );
+    if( c < bestCost ) { bestCost = c; bestIdx = ( unsigned ) k; }
+    rx += WPJ;
+    while( rx >= nx ) { rx -= nx; ry++; }
+  }
+  // wave-uniform (cost, index); merge across the job's waves
+  if( WPJ > 1 )
+  {
+    if( lane == 0 ) { co.redCost[co.wave] = bestCost; co.redIdx[co.wave] = bestIdx; }
+    __syncthreads();
+#pragma unroll
+    for( int w = 0; w < WPJ; w++ )
+    {
+      const unsigned long long oc = co.redCost[w];
+      const unsigned           oi = co.redIdx[w];
+      if( oc < bestCost || ( oc == bestCost && oi < bestIdx ) ) { bestCost = oc; bestIdx = oi; }
+    }
+    __syncthreads();
+  }
+  bestCost = uni( bestCost );
+  bestIdx  = uni( bestIdx );
+}
+
 // raster scan (xTZSearch :3888-3899 / adaptive :3883-3903): candidate k = (row k / nx, column k % nx) in row-major order
 template<int WPJ>
 __device__ __forceinline__ void tz_raster( const MeJob &j, TzState &s, const Range &r, int stepXY, const Coop &co )
@@ -394,7 +464,14 @@ __device__ __forceinline__ void tz_raster( const MeJob &j, TzState &s, const Ran
   const int total = nx * ny;
   unsigned long long cost;
   unsigned           idx;
-  eval_candidates<true, WPJ>( j, nullptr, total, r.left, r.top, nx > 0 ? nx : 1, stepXY, co, cost, idx );
+  // register-resident original (raster_resident_org): the 16-segment variant costs ~110 VGPRs, so it is only built into the
+  // kernels meant for the largest blocks (8 / 16 waves per job); smaller variants keep the small-block kernels at full occupancy
+  const int  ipl  = j.items >> 6;
+  const bool fits = total > 0 && j.lpc == 64 && j.seg == 8 && j.sprShift >= 0 && ( j.items & 63 ) == 0;
+  if( WPJ >= 8 && fits && ipl == 16 ) raster_resident_org<16, WPJ>( j, total, r.left, r.top, nx, stepXY, co, cost, idx );
+  else if( WPJ >= 4 && fits && ipl == 4 ) raster_resident_org<4, WPJ>( j, total, r.left, r.top, nx, stepXY, co, cost, idx );
+  else if( WPJ >= 2 && fits && ipl == 1 ) raster_resident_org<1, WPJ>( j, total, r.left, r.top, nx, stepXY, co, cost, idx );
+  else eval_candidates<true, WPJ>( j, nullptr, total, r.left, r.top, nx > 0 ? nx : 1, stepXY, co, cost, idx );
   s.nEval += ( unsigned ) total;
   if( total > 0 && cost < s.bestSad )
   {
@@ -420,7 +497,8 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel(
   __shared__ unsigned long long sRedCost[WPJ];
   __shared__ unsigned           sRedIdx[WPJ];
   const int lane = threadIdx.x & 63, wv = uni( ( int ) ( threadIdx.x >> 6 ) );
-  const int jobIdx = WPJ == 1 ? blockIdx.x * 4 + wv : blockIdx.x;
+  const int blk    = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x );
+  const int jobIdx = WPJ == 1 ? blk * 4 + wv : blk;
   if( jobIdx >= numJobs ) return;   // WPJ == 1: whole waves leave; WPJ > 1: never true (grid = numJobs)
   const vtmhip_tz_job *jp  = jobs + jobIdx;
   if( uni( ( int ) jp->width ) == 0 ) return;   // empty slot of a multi-stage call (job handled by another stage); uniform per wave / per block
@@ -609,7 +687,8 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void full_search_kerne
   __shared__ unsigned long long sRedCost[WPJ];
   __shared__ unsigned           sRedIdx[WPJ];
   const int lane = threadIdx.x & 63, wv = uni( ( int ) ( threadIdx.x >> 6 ) );
-  const int jobIdx = WPJ == 1 ? blockIdx.x * 4 + wv : blockIdx.x;
+  const int blk    = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x );
+  const int jobIdx = WPJ == 1 ? blk * 4 + wv : blk;
   if( jobIdx >= numJobs ) return;
   const vtmhip_full_job *jp = jobs + jobIdx;
   if( uni( ( int ) jp->width ) == 0 ) return;   // empty slot (see tz_search_kernel)

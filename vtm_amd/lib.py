@@ -80,7 +80,7 @@ class FullJob(C.Structure):
 class McJob(C.Structure):
     _fields_ = [("refOff", C.c_int64), ("dstOff", C.c_int64), ("refStride", C.c_int32), ("dstStride", C.c_int32),
                 ("width", C.c_int16), ("height", C.c_int16), ("mvHor", C.c_int32), ("mvVer", C.c_int32), ("bi", C.c_uint8),
-                ("bitDepth", C.c_uint8), ("useAltHpelIf", C.c_uint8), ("pad", C.c_uint8)]
+                ("bitDepth", C.c_uint8), ("useAltHpelIf", C.c_uint8), ("chroma", C.c_uint8)]
 
 
 class PelOpJob(C.Structure):
@@ -173,6 +173,7 @@ _PROTOS = {
     "vtmhip_dequant_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "vtmhip_full_search_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                C.c_void_p]),
+    "vtmhip_mc_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "vtmhip_mc_luma_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "vtmhip_remove_high_freq_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "vtmhip_subtract_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

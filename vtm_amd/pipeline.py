@@ -9,6 +9,8 @@ device memory, streams and the tiny gather that forms the child predictors.
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import lib as _lib
@@ -83,6 +85,9 @@ class FrameME:
         # waves that share one search: big PUs have long SADs and (at the top level, which has no predictor) raster scans
         self.wpj = dict(WAVES_PER_JOB)
         self.wpj.update(waves_per_job or {})
+        for kv in filter(None, os.environ.get("VTM_AMD_TZ_WPJ", "").split(",")):   # tuning knob, e.g. VTM_AMD_TZ_WPJ=128:8,64:4
+            k, v = kv.split(":")
+            self.wpj[int(k)] = int(v)
         self.levels = []
         self.n_jobs = 0
         self.alg_bytes_per_eval = []
