@@ -160,9 +160,9 @@ def main():
     alg = fme.alg_bytes()
     stages = {k2: ({"ms": stage_acc[k2], "alg_GBps": alg[k2] / stage_acc[k2] / 1e6} if k2 in alg else {"ms": stage_acc[k2]}) for k2 in stage_acc}
     dom = max((k2 for k2 in stage_acc if k2 in alg), key=stage_acc.get)
-    dom_kernel = {"tz": "tz_search_kernel", "frac": "frac_search_sq_kernel", "full": "full_search_kernel", "mc": "mc_luma_kernel",
-                  "pelop": "pelop_kernel", "tu": "tu_chain_kernel"}[dom]
-    launches = {"tz": 1, "frac": 2, "full": 1, "mc": 4, "pelop": 3, "tu": 1}[dom] * len(fme.levels)
+    dom_kernel = {"tz": "tz_search_kernel", "frac": "frac_search_sq_kernel", "full": "full_search_kernel", "mc": "motion_comp_kernel",
+                  "tu": "tu_chain"}[dom]
+    launches = {"tz": 1, "frac": 2, "full": 1, "mc": 2, "tu": 1}[dom] * len(fme.levels)
     # HBM-side traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null when the file is absent
     traffic = None

@@ -276,6 +276,26 @@ int vtmhip_mc_batch_dev( vtmhip_ctx *ctx, const int16_t *d_refBase, int16_t *d_d
 int vtmhip_mc_luma_batch_dev( vtmhip_ctx *ctx, const int16_t *d_refBase, int16_t *d_dstBase, const vtmhip_mc_job *d_jobs, int n, int maxWidth,
                               int maxHeight );
 
+/* InterPrediction::motionCompensation for one PU and one plane (InterPrediction.cpp:445-660: xPredInterUni, or xPredInterBi with the
+ * default-weight xWeightedAverage = PelBuf::addAvg :1354-1435), with the consumer of the prediction optionally fused in. */
+typedef struct
+{
+  int64_t orgOff;               /* block in the original plane (epilogue 1 / 2) */
+  int64_t refOff[2];            /* block position with MV (0,0) in the list-0 / list-1 reference plane (both inside d_refBase) */
+  int64_t predOff, outOff;      /* prediction block inside d_predBase, epilogue output inside d_outBase */
+  int32_t orgStride, refStride[2], predStride, outStride;
+  int32_t mv[2][2];             /* [list][hor, ver], internal 1/16 luma precision */
+  int16_t width, height;
+  uint8_t mode;                 /* 0: uni-prediction from list 0, 1: from list 1, 2: bi-prediction (two 14-bit predictions, addAvg) */
+  uint8_t epilogue;             /* 0: none; 1: out = org - pred (residual, InterSearch.cpp:7260-7262); 2: out = 2*org - pred (removeHighFreq) */
+  uint8_t bitDepth, useAltHpelIf, chroma, pad0;
+  int16_t pad1;
+} vtmhip_pred_job;
+
+/* d_predBase and d_outBase may each be NULL (that output is skipped); d_orgBase is needed when d_outBase is given. */
+int vtmhip_motion_compensation_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, int16_t *d_predBase, int16_t *d_outBase,
+                                          const vtmhip_pred_job *d_jobs, int n, int maxWidth, int maxHeight );
+
 typedef struct
 {
   int64_t aOff, bOff, dstOff;

@@ -139,3 +139,81 @@ def test_affine_gradient_matches_reference_golden(ctx):
             for q in range(2):
                 assert np.array_equal(der[2 * q], z["gx_%d" % k]) and np.array_equal(der[2 * q + 1], z["gy_%d" % k]), (k, six, q)
                 assert np.array_equal(eq[q], z["eq_%d_%d" % (k, six)]), (k, six, q)
+
+
+def test_motion_compensation_fused_matches_oracle(ctx):
+    """vtmhip_motion_compensation_batch_dev: uni / bi (two 14-bit predictions + addAvg) for luma and 4:2:0 chroma blocks, prediction
+    output plus the fused residual (org - pred) or removeHighFreq (2*org - pred) epilogue, against the oracle composition
+    vo_mc_block -> vo_add_avg -> subtract."""
+    from vtm_amd import synth
+    from vtm_amd.lib import PredJob
+    L = ol.oracle()
+    W, H, m = 416, 240, 64
+    fr = synth.gen_frames(W, H, 3, chroma=True)
+    (yb0, yo, ys), (ub0, uo, us) = synth.extend_plane(fr[0][0], m), synth.extend_plane(fr[0][1], m // 2)
+    (yb1, _, _), (ub1, _, _) = synth.extend_plane(fr[1][0], m), synth.extend_plane(fr[1][1], m // 2)
+    org_y, org_u = np.ascontiguousarray(fr[2][0]), np.ascontiguousarray(fr[2][1])
+    # device layout: [Y ref0 | Y ref1 | U ref0 | U ref1], originals [Y | U]
+    refs = np.concatenate([yb0, yb1, ub0, ub1])
+    base = {(0, 0): 0, (0, 1): yb0.size, (1, 0): 2 * yb0.size, (1, 1): 2 * yb0.size + ub0.size}
+    planes = {(0, 0): yb0, (0, 1): yb1, (1, 0): ub0, (1, 1): ub1}
+    orgs = np.concatenate([org_y.reshape(-1), org_u.reshape(-1)])
+    rng = np.random.default_rng(91)
+    n = 500
+    jobs = (PredJob * n)()
+    exp_pred, exp_out, meta = [], [], []
+    pos = 0
+    for k in range(n):
+        w, h = int(rng.choice([4, 8, 16, 32, 64, 128])), int(rng.choice([4, 8, 16, 32, 64, 128]))
+        x, y = int(rng.integers(0, (W - w) // 4 + 1)) * 4, int(rng.integers(0, (H - h) // 4 + 1)) * 4
+        chroma, mode, epi, alt = int(k % 3 == 1), int(k % 4 if k % 4 < 3 else 2), int(k % 3), int(k % 7 == 0)
+        if w == 4 and h == 4 and not chroma:
+            w = 8
+        cw, ch, cx, cy = (w // 2, h // 2, x // 2, y // 2) if chroma else (w, h, x, y)
+        st, o0 = (us, uo) if chroma else (ys, yo)
+        mv = [[int(rng.integers(-20 * 16, 20 * 16)), int(rng.integers(-20 * 16, 20 * 16))] for _ in range(2)]
+        if k % 5 == 0:
+            mv[0][0] &= ~15
+        if k % 9 == 0:
+            mv[1][1] &= ~31
+        j = jobs[k]
+        j.orgOff = (org_y.size + cy * (W // 2) + cx) if chroma else (cy * W + cx)
+        j.orgStride = W // 2 if chroma else W
+        for l in (0, 1):
+            j.refOff[l] = base[(chroma, l)] + o0 + cy * st + cx
+            j.refStride[l] = st
+            j.mv[l][0], j.mv[l][1] = mv[l]
+        j.predOff = j.outOff = pos
+        j.predStride = j.outStride = cw
+        j.width, j.height, j.mode, j.epilogue, j.bitDepth, j.useAltHpelIf, j.chroma = cw, ch, mode, epi, 10, alt, chroma
+        p = [np.zeros((ch, cw), np.int16), np.zeros((ch, cw), np.int16)]
+        for l in ((0, 1) if mode == 2 else (mode,)):
+            pl = planes[(chroma, l)]
+            refp = pl.ctypes.data + 2 * (o0 + cy * st + cx)
+            L.vo_mc_block(1 if chroma else 0, C.c_void_p(refp), st, cw, ch, mv[l][0], mv[l][1], int(mode == 2), 10, alt, ol.P(p[l]), cw)
+        if mode == 2:
+            pred = np.zeros((ch, cw), np.int16)
+            L.vo_add_avg(ol.P(p[0]), cw, ol.P(p[1]), cw, ol.P(pred), cw, cw, ch, 10)
+        else:
+            pred = p[mode]
+        ob = (org_u if chroma else org_y)[cy:cy + ch, cx:cx + cw].astype(np.int32)
+        out = (ob - pred) if epi == 1 else (2 * ob - pred) if epi == 2 else np.zeros_like(ob)
+        exp_pred.append(pred.reshape(-1))
+        exp_out.append(out.astype(np.int16).reshape(-1))
+        meta.append((cw, ch, chroma, mode, epi))
+        pos += cw * ch
+    d_org, d_ref = ctx.to_device(orgs), ctx.to_device(refs)
+    d_jobs = ctx.to_device(np.frombuffer(jobs, np.uint8))
+    d_pred, d_out = ctx.to_device(np.zeros(pos, np.int16)), ctx.to_device(np.zeros(pos, np.int16))
+    ctx.motion_compensation_batch(d_org.ptr, d_ref.ptr, d_pred.ptr, d_out.ptr, d_jobs.ptr, n, 128, 128)
+    gp, go = d_pred.to_host(np.int16), d_out.to_host(np.int16)
+    at = 0
+    for k, (cw, ch, chroma, mode, epi) in enumerate(meta):
+        sl = slice(at, at + cw * ch)
+        assert np.array_equal(gp[sl], exp_pred[k]), ("pred", k, meta[k])
+        assert np.array_equal(go[sl], exp_out[k]), ("out", k, meta[k])
+        at += cw * ch
+    # prediction-only and epilogue-only calls
+    d_out2 = ctx.to_device(np.zeros(pos, np.int16))
+    ctx.motion_compensation_batch(d_org.ptr, d_ref.ptr, None, d_out2.ptr, d_jobs.ptr, n, 128, 128)
+    assert np.array_equal(d_out2.to_host(np.int16), go)

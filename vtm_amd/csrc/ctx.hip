@@ -28,6 +28,7 @@ int vtmhip_struct_size( int which )
   case 15: return ( int ) sizeof( vtmhip_me_cfg );
   case 16: return ( int ) sizeof( vtmhip_me_job );
   case 17: return ( int ) sizeof( vtmhip_me_out );
+  case 18: return ( int ) sizeof( vtmhip_pred_job );
   default: return -1;
   }
 }

@@ -60,44 +60,55 @@ __constant__ int16_t c_chromaFilterMc[32][4] = {
 
 // One block, one wave.  NT = 8: luma (phase = 4 fraction bits); NT = 4: a 4:2:0 chroma plane (the vector stays in luma 1/16 units, so
 // the phase has 5 bits; InterPrediction.cpp:675-676).  lds holds the (h + NT - 1) x w horizontal-pass intermediates.
-template<int NT>
-__device__ __forceinline__ void mc_block( const vtmhip_mc_job &j, const int16_t *__restrict__ refBase, int16_t *__restrict__ dstBase, int16_t *lds, int lane )
+// `out( y, x, v )` receives every output sample (store to HBM, keep in LDS, or a fused epilogue).
+template<int THREADS>
+__device__ __forceinline__ void block_sync()
+{
+  if( THREADS == 64 )
+  {
+    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
+    __builtin_amdgcn_wave_barrier();
+  }
+  else __syncthreads();
+}
+
+template<int NT, int THREADS, class Out>
+__device__ __forceinline__ void mc_block( const vtmhip_mc_job &j, const int16_t *__restrict__ refBase, int16_t *lds, int lane, Out out )
 {
   constexpr int FB = NT == 8 ? 4 : 5, HALO = NT / 2 - 1;
   const int     w = j.width, h = j.height, bd = j.bitDepth;
   const int     xFrac = j.mvHor & ( ( 1 << FB ) - 1 ), yFrac = j.mvVer & ( ( 1 << FB ) - 1 ), rnd = !j.bi;
   const bool    alt = j.useAltHpelIf != 0;
   const int16_t *src = refBase + j.refOff + ( long ) ( j.mvVer >> FB ) * j.refStride + ( j.mvHor >> FB );
-  int16_t       *dst = dstBase + j.dstOff;
   if( yFrac == 0 )
   {
     if( xFrac == 0 && rnd )   // filterCopy<true,true>: plain copy
     {
-      for( int i = lane; i < w * h; i += 64 ) { const int y = i / w, x = i - y * w; dst[( long ) y * j.dstStride + x] = src[( long ) y * j.refStride + x]; }
+      for( int i = lane; i < w * h; i += THREADS ) { const int y = i / w, x = i - y * w; out( y, x, src[( long ) y * j.refStride + x] ); }
       return;
     }
     const Fir      f = fir_params( 1, rnd, bd );
     const int16_t *c = NT == 8 ? luma_taps( xFrac, w, h, h, alt ) : c_chromaFilterMc[xFrac];
-    for( int i = lane; i < w * h; i += 64 )
+    for( int i = lane; i < w * h; i += THREADS )
     {
       const int y = i / w, x = i - y * w;
       int       sum = 0;
 #pragma unroll
       for( int k = 0; k < NT; k++ ) sum += ( int ) src[( long ) y * j.refStride + x + k - HALO] * ( int ) c[k];
-      dst[( long ) y * j.dstStride + x] = fir_out( sum, f );
+      out( y, x, fir_out( sum, f ) );
     }
   }
   else if( xFrac == 0 )
   {
     const Fir      f = fir_params( 1, rnd, bd );
     const int16_t *c = NT == 8 ? luma_taps( yFrac, w, h, h, alt ) : c_chromaFilterMc[yFrac];
-    for( int i = lane; i < w * h; i += 64 )
+    for( int i = lane; i < w * h; i += THREADS )
     {
       const int y = i / w, x = i - y * w;
       int       sum = 0;
 #pragma unroll
       for( int k = 0; k < NT; k++ ) sum += ( int ) src[( long ) ( y + k - HALO ) * j.refStride + x] * ( int ) c[k];
-      dst[( long ) y * j.dstStride + x] = fir_out( sum, f );
+      out( y, x, fir_out( sum, f ) );
     }
   }
   else
@@ -105,7 +116,7 @@ __device__ __forceinline__ void mc_block( const vtmhip_mc_job &j, const int16_t 
     const Fir      fh = fir_params( 1, 0, bd ), fv = fir_params( 0, rnd, bd );
     const int16_t *ch = NT == 8 ? luma_taps( xFrac, w, h, h + 7 == 11 ? 4 : -1, alt ) : c_chromaFilterMc[xFrac];   // luma H pass sees W x (H+7): 4 x 11 takes the 4x4 taps
     const int16_t *cv = NT == 8 ? luma_taps( yFrac, w, h, h, alt ) : c_chromaFilterMc[yFrac];
-    for( int i = lane; i < w * ( h + NT - 1 ); i += 64 )
+    for( int i = lane; i < w * ( h + NT - 1 ); i += THREADS )
     {
       const int r = i / w, x = i - r * w;
       int       sum = 0;
@@ -113,26 +124,97 @@ __device__ __forceinline__ void mc_block( const vtmhip_mc_job &j, const int16_t 
       for( int k = 0; k < NT; k++ ) sum += ( int ) src[( long ) ( r - HALO ) * j.refStride + x + k - HALO] * ( int ) ch[k];
       lds[i] = fir_out( sum, fh );
     }
-    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
-    __builtin_amdgcn_wave_barrier();
-    for( int i = lane; i < w * h; i += 64 )
+    block_sync<THREADS>();
+    for( int i = lane; i < w * h; i += THREADS )
     {
       const int y = i / w, x = i - y * w;
       int       sum = 0;
 #pragma unroll
       for( int k = 0; k < NT; k++ ) sum += ( int ) lds[( y + k ) * w + x] * ( int ) cv[k];
-      dst[( long ) y * j.dstStride + x] = fir_out( sum, fv );
+      out( y, x, fir_out( sum, fv ) );
     }
   }
 }
+
+struct StoreGlobal
+{
+  int16_t *dst; int stride;
+  __device__ __forceinline__ void operator()( int y, int x, int16_t v ) const { dst[( long ) y * stride + x] = v; }
+};
 
 __global__ __launch_bounds__( 64 ) void mc_kernel( const int16_t *__restrict__ refBase, int16_t *__restrict__ dstBase,
                                                   const vtmhip_mc_job *__restrict__ jobs, int maxW, int maxH )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];   // [(h+7)][w] H-pass intermediates
   const vtmhip_mc_job j = jobs[blockIdx.x];
-  if( j.chroma ) mc_block<4>( j, refBase, dstBase, lds, ( int ) threadIdx.x );
-  else mc_block<8>( j, refBase, dstBase, lds, ( int ) threadIdx.x );
+  const StoreGlobal   st{ dstBase + j.dstOff, j.dstStride };
+  if( j.chroma ) mc_block<4, 64>( j, refBase, lds, ( int ) threadIdx.x, st );
+  else mc_block<8, 64>( j, refBase, lds, ( int ) threadIdx.x, st );
+}
+
+// ---- InterPrediction::motionCompensation for one PU and one plane: xPredInterUni (:445-520) or xPredInterBi + xWeightedAverage
+// (:527-660, 1354-1435; default weights -> PelBuf::addAvg) with the consumer of the prediction fused in: the residual
+// org - pred (CodingStructure resi buffer, InterSearch.cpp:7260-7262) or the bi-pred ME target 2*org - pred (removeHighFreq). ----------
+struct StoreLds
+{
+  int16_t *p; int w;
+  __device__ __forceinline__ void operator()( int y, int x, int16_t v ) const { p[y * w + x] = v; }
+};
+struct Epilogue
+{
+  const int16_t *org; int orgStride; int16_t *pred; int predStride; int16_t *out; int outStride; int mode;
+  __device__ __forceinline__ void operator()( int y, int x, int16_t v ) const
+  {
+    if( pred ) pred[( long ) y * predStride + x] = v;
+    if( mode == 1 ) out[( long ) y * outStride + x] = ( int16_t ) ( org[( long ) y * orgStride + x] - v );
+    else if( mode == 2 ) out[( long ) y * outStride + x] = ( int16_t ) ( 2 * org[( long ) y * orgStride + x] - v );
+  }
+};
+struct AvgThen
+{
+  const int16_t *p0; int w; int shift, offset, cmax; Epilogue ep;
+  __device__ __forceinline__ void operator()( int y, int x, int16_t v ) const
+  {
+    ep( y, x, ( int16_t ) min( cmax, max( 0, ( ( int ) p0[y * w + x] + ( int ) v + offset ) >> shift ) ) );   // addAvg (Buffer.cpp:467-507)
+  }
+};
+
+template<int THREADS>
+__global__ __launch_bounds__( THREADS ) void motion_comp_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase, int16_t *__restrict__ predBase,
+                                                           int16_t *__restrict__ outBase, const vtmhip_pred_job *__restrict__ jobs, int maxW, int maxH )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];
+  int16_t              *tmp = lds;                             // [(h+7)][w] H-pass intermediates
+  int16_t              *p0  = lds + maxW * ( maxH + 7 );       // [h][w] list-0 prediction of a bi-predicted block (14-bit)
+  const vtmhip_pred_job j    = jobs[blockIdx.x];
+  const int             lane = threadIdx.x;
+  Epilogue ep;
+  ep.org = orgBase ? orgBase + j.orgOff : nullptr; ep.orgStride = j.orgStride;
+  ep.pred = predBase ? predBase + j.predOff : nullptr; ep.predStride = j.predStride;
+  ep.out = outBase ? outBase + j.outOff : nullptr; ep.outStride = j.outStride;
+  ep.mode = ( outBase && orgBase ) ? j.epilogue : 0;
+  vtmhip_mc_job m;
+  m.width = j.width; m.height = j.height; m.bitDepth = j.bitDepth; m.useAltHpelIf = j.useAltHpelIf; m.chroma = j.chroma;
+  m.dstOff = 0; m.dstStride = 0;
+  if( j.mode != 2 )
+  {
+    const int l = j.mode;
+    m.refOff = j.refOff[l]; m.refStride = j.refStride[l]; m.mvHor = j.mv[l][0]; m.mvVer = j.mv[l][1]; m.bi = 0;
+    if( j.chroma ) mc_block<4, THREADS>( m, refBase, tmp, lane, ep );
+    else mc_block<8, THREADS>( m, refBase, tmp, lane, ep );
+    return;
+  }
+  m.bi = 1;
+  m.refOff = j.refOff[0]; m.refStride = j.refStride[0]; m.mvHor = j.mv[0][0]; m.mvVer = j.mv[0][1];
+  const StoreLds s0{ p0, j.width };
+  if( j.chroma ) mc_block<4, THREADS>( m, refBase, tmp, lane, s0 );
+  else mc_block<8, THREADS>( m, refBase, tmp, lane, s0 );
+  block_sync<THREADS>();   // p0 complete, tmp free again
+  const int headRoom = max( 2, 14 - ( int ) j.bitDepth ), shift = headRoom + 1;
+  const AvgThen av{ p0, j.width, shift, ( 1 << ( shift - 1 ) ) + 2 * 8192, ( 1 << j.bitDepth ) - 1, ep };
+  m.refOff = j.refOff[1]; m.refStride = j.refStride[1]; m.mvHor = j.mv[1][0]; m.mvVer = j.mv[1][1];
+  if( j.chroma ) mc_block<4, THREADS>( m, refBase, tmp, lane, av );
+  else mc_block<8, THREADS>( m, refBase, tmp, lane, av );
 }
 
 __global__ __launch_bounds__( 256 ) void pelop_kernel( const int16_t *__restrict__ aBase, const int16_t *__restrict__ bBase, int16_t *__restrict__ dstBase,
@@ -176,6 +258,29 @@ int vtmhip_mc_batch_dev( vtmhip_ctx *ctx, const int16_t *d_refBase, int16_t *d_d
   VTMHIP_REQUIRE( ctx, maxWidth >= 2 && maxWidth <= 128 && maxHeight >= 2 && maxHeight <= 128, "maxWidth / maxHeight" );
   const size_t lds = ( size_t ) maxWidth * ( maxHeight + 7 ) * sizeof( int16_t );
   hipLaunchKernelGGL( mc_kernel, dim3( n ), dim3( 64 ), lds, ctx->stream, d_refBase, d_dstBase, d_jobs, maxWidth, maxHeight );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_motion_compensation_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, int16_t *d_predBase, int16_t *d_outBase,
+                                          const vtmhip_pred_job *d_jobs, int n, int maxWidth, int maxHeight )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_refBase && d_jobs && ( d_predBase || d_outBase ), "null pointer" );
+  VTMHIP_REQUIRE( ctx, !d_outBase || d_orgBase, "an epilogue output needs the original plane" );
+  VTMHIP_REQUIRE( ctx, maxWidth >= 2 && maxWidth <= 128 && maxHeight >= 2 && maxHeight <= 128, "maxWidth / maxHeight" );
+  const size_t lds = ( ( size_t ) maxWidth * ( maxHeight + 7 ) + ( size_t ) maxWidth * maxHeight ) * sizeof( int16_t );
+  // one wave per block up to 16x16 samples, four waves above (the samples of a block are independent; only the H -> V hand-over syncs)
+  if( maxWidth * maxHeight > 256 )
+  {
+    if( lds > 64 * 1024 )
+      VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( motion_comp_kernel<256> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
+    hipLaunchKernelGGL( motion_comp_kernel<256>, dim3( n ), dim3( 256 ), lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, maxWidth, maxHeight );
+  }
+  else
+    hipLaunchKernelGGL( motion_comp_kernel<64>, dim3( n ), dim3( 64 ), lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, maxWidth, maxHeight );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

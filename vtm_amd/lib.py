@@ -126,8 +126,15 @@ class MeOut(C.Structure):
                 ("intDist", C.c_uint64)]
 
 
+class PredJob(C.Structure):
+    _fields_ = [("orgOff", C.c_int64), ("refOff", C.c_int64 * 2), ("predOff", C.c_int64), ("outOff", C.c_int64), ("orgStride", C.c_int32),
+                ("refStride", C.c_int32 * 2), ("predStride", C.c_int32), ("outStride", C.c_int32), ("mv", (C.c_int32 * 2) * 2),
+                ("width", C.c_int16), ("height", C.c_int16), ("mode", C.c_uint8), ("epilogue", C.c_uint8), ("bitDepth", C.c_uint8),
+                ("useAltHpelIf", C.c_uint8), ("chroma", C.c_uint8), ("pad0", C.c_uint8), ("pad1", C.c_int16)]
+
+
 _STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob,
-            TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut]   # order of vtmhip_struct_size(which)
+            TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut, PredJob]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
 _PROTOS = {
@@ -173,6 +180,8 @@ _PROTOS = {
     "vtmhip_dequant_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "vtmhip_full_search_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                C.c_void_p]),
+    "vtmhip_motion_compensation_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                       C.c_int]),
     "vtmhip_mc_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "vtmhip_mc_luma_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "vtmhip_remove_high_freq_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

@@ -144,11 +144,12 @@ class FrameME:
 # ======================================================================================================================
 # Full hot path of one inter picture: integer ME -> fractional ME -> bi-predictive refinement -> residual coding.
 # ======================================================================================================================
-from .lib import DistJob, FracJob, FracResult, FullJob, McJob, PelOpJob, QuantJob, TrJob, TuJob   # noqa: E402
+from .lib import DistJob, FracJob, FracResult, FullJob, McJob, PelOpJob, PredJob, QuantJob, TrJob, TuJob   # noqa: E402
 
 FRAC_DT, FRACRES_DT, MC_DT, FULL_DT = np.dtype(FracJob), np.dtype(FracResult), np.dtype(McJob), np.dtype(FullJob)
 PEL_DT, TR_DT, Q_DT, DIST_DT = np.dtype(PelOpJob), np.dtype(TrJob), np.dtype(QuantJob), np.dtype(DistJob)
 TU_DT = np.dtype(TuJob)
+PRED_DT = np.dtype(PredJob)
 
 # (typeHor, typeVer) of mtsIdx 0, 2, 3, 4, 5 (TrQuant::getTrTypes, TrQuant.cpp:695-772): DCT2 = 0, DCT8 = 1, DST7 = 2
 MTS_CANDS = ((0, 0), (2, 2), (1, 2), (2, 1), (1, 1))
@@ -166,7 +167,18 @@ class _Tab:
     def col(self, field):
         off = self.dt.fields[field][1]
         kind = self.dt.fields[field][0]
-        tt = {np.dtype(np.int64): self.torch.int64, np.dtype(np.int32): self.torch.int32, np.dtype(np.int16): self.torch.int16}[kind]
+        return self._view(kind, off)
+
+    def col2(self, field, k):
+        """k-th scalar of an array field (row-major), e.g. col2("mv", 2 * list + component)."""
+        kind, off = self.dt.fields[field][0], self.dt.fields[field][1]
+        while kind.subdtype is not None:      # nested C arrays arrive as nested sub-array dtypes
+            kind = kind.subdtype[0]
+        return self._view(kind, off + k * kind.itemsize)
+
+    def _view(self, kind, off):
+        tt = {np.dtype(np.int64): self.torch.int64, np.dtype(np.int32): self.torch.int32, np.dtype(np.int16): self.torch.int16,
+              np.dtype(np.uint8): self.torch.uint8}[kind]
         assert off % kind.itemsize == 0
         return self.t.view(tt)[:, off // kind.itemsize]
 
@@ -240,24 +252,20 @@ class FrameHotPath(FrameME):
         self.frac = _Tab(T, dev, fj)
         self.frac_res = T.zeros((2 * NP, 16), dtype=T.uint8, device=dev)
 
-        mj = np.zeros(NP, MC_DT)
-        mj["dstOff"], mj["refStride"], mj["dstStride"], mj["width"], mj["height"], mj["bitDepth"] = blk, rs, sizes, sizes, sizes, 10
-        self.mc_other = _Tab(T, dev, mj)
-        self.mc_tabs = {}
-        for name, bi in (("mc_uni", 0), ("mc_b0", 1), ("mc_b1", 1)):
-            m2 = mj.copy()
-            m2["bi"] = bi
-            self.mc_tabs[name] = _Tab(T, dev, m2)
-        pj = np.zeros(NP, PEL_DT)
-        pj["aOff"], pj["aStride"] = ys_all * org_stride + xs_all, org_stride
-        pj["bOff"], pj["bStride"], pj["dstOff"], pj["dstStride"] = blk, sizes, blk, sizes
-        pj["width"], pj["height"], pj["bitDepth"] = sizes, sizes, 10
-        self.rhf = _Tab(T, dev, pj)
-        self.sub = _Tab(T, dev, pj.copy())      # bOff is patched to the chosen prediction
-        aj = np.zeros(NP, PEL_DT)
-        aj["aOff"], aj["bOff"], aj["dstOff"] = blk, blk, blk
-        aj["aStride"], aj["bStride"], aj["dstStride"], aj["width"], aj["height"], aj["bitDepth"] = sizes, sizes, sizes, sizes, sizes, 10
-        self.avg = _Tab(T, dev, aj)
+        # motion compensation with the consumer fused in (vtmhip_motion_compensation_batch_dev):
+        #   pred_other  other list's uni prediction -> bi-pred ME target 2*org - pred        (xMotionEstimation bBi branch, :3316-3329)
+        #   pred_final  chosen uni / bi (addAvg) prediction -> prediction + residual org - pred
+        qj0 = np.zeros(NP, PRED_DT)
+        qj0["orgOff"], qj0["orgStride"] = ys_all * org_stride + xs_all, org_stride
+        qj0["refStride"] = rs
+        qj0["predOff"], qj0["outOff"], qj0["predStride"], qj0["outStride"] = blk, blk, sizes, sizes
+        qj0["width"], qj0["height"], qj0["bitDepth"] = sizes, sizes, 10
+        qo = qj0.copy()
+        qo["epilogue"] = 2
+        self.pred_other = _Tab(T, dev, qo)
+        qf = qj0.copy()
+        qf["epilogue"] = 1
+        self.pred_final = _Tab(T, dev, qf)
         uj = np.zeros(NP, FULL_DT)
         uj["orgOff"], uj["orgStride"], uj["refStride"] = blk, sizes, rs
         uj["puX"], uj["puY"], uj["width"], uj["height"] = xs_all, ys_all, sizes, sizes
@@ -316,8 +324,7 @@ class FrameHotPath(FrameME):
                 lvl["abs_sum"] = T.zeros(n_l, dtype=T.int32, device=dev)
                 lvl["sse_out"] = T.zeros(n_l, dtype=T.int64, device=dev)
         mk = lambda n: T.zeros(n, dtype=T.int16, device=dev)   # noqa: E731
-        self.buf = dict(pred_other=mk(sb), org_bi=mk(sb), p0=mk(sb), p1=mk(sb), resi=mk(sb))
-        self.pred_sel = mk(2 * sb)     # [uni prediction | bi prediction]: a residual job addresses either with an offset
+        self.buf = dict(org_bi=mk(sb), pred=mk(sb), resi=mk(sb))
         self.qcoef = T.zeros(max_coef, dtype=T.int32, device=dev)
         if not fused_tu:
             self.coef = T.zeros(max_coef, dtype=T.int32, device=dev)
@@ -345,16 +352,17 @@ class FrameHotPath(FrameME):
         tz    sum over searches of nEval * (4*W*H >> subShift)                       [SAD: 4*W*H >> subShift per candidate]
         frac  per search: 6 H + 18 V filter passes (4 B per output sample) + 18 SATDs (256 B per 8x8 tile = 4 B per sample)
         full  81 candidates * (4*W*H >> subShift)
-        mc    4 B per output sample of every filter pass (H pass on H+7 rows, V pass)
-        pelop 6 B per sample (two 2-byte reads, one 2-byte write)
+        mc    4 B per output sample of every filter pass (H pass on H+7 rows, V pass) of the predictions formed (other-list uni, final
+              uni or bi) + 6 B per sample of each fused epilogue (org read, prediction / target / residual written)
         tu    per sample: xT 6 + quant 8 + dequant 8 + xIT 6 + SSE 4 = 32 B"""
-        b = dict(tz=self.stats()[1], frac=0, full=0, mc=0, pelop=0, tu=0)
+        b = dict(tz=self.stats()[1], frac=0, full=0, mc=0, tu=0)
+        nbi = int(self._use_bi.sum().item()) if getattr(self, "_use_bi", None) is not None else 0
+        frac_bi = nbi / max(1, self.NP)
         for lvl in self.levels:
             s, npu, nt, ts = lvl["size"], lvl["npu"], lvl["ntu"] * lvl["nc"], lvl["ts"]
             b["frac"] += 3 * npu * (24 * (s + 8) * s + 144 * s * s)
             b["full"] += npu * 81 * (4 * s * s >> subshift_mode2(s, s))
-            b["mc"] += 4 * npu * 4 * ((2 * s + 7) * s)
-            b["pelop"] += 3 * npu * 6 * s * s
+            b["mc"] += int(npu * (2 + frac_bi) * 4 * ((2 * s + 7) * s)) + 2 * npu * 6 * s * s
             b["tu"] += nt * ts * ts * 32
         return b
 
@@ -404,10 +412,12 @@ class FrameHotPath(FrameME):
         row_r, row_o = T.where(rl, self.row1, self.row0), T.where(rl, self.row0, self.row1)
         off_r = T.where(rl, self.ref_base[1], self.ref_base[0]) + self.pos
         off_o = T.where(rl, self.ref_base[0], self.ref_base[1]) + self.pos
-        mo = self.mc_other
-        mo.col("refOff").copy_(off_o)
-        mo.col("mvHor").copy_(mvq_x[row_o] << 2)
-        mo.col("mvVer").copy_(mvq_y[row_o] << 2)
+        po = self.pred_other
+        po.col("mode").copy_((~rl).to(T.uint8))                              # the OTHER list: 0 when list 1 is refined
+        for l in (0, 1):
+            po.col2("refOff", l).copy_(self.ref_base[l] + self.pos)
+            po.col2("mv", 2 * l).copy_(mvq_x[self.row1 if l else self.row0] << 2)
+            po.col2("mv", 2 * l + 1).copy_(mvq_y[self.row1 if l else self.row0] << 2)
         fu = self.full
         fu.col("refOff").copy_(off_r)
         fu.col("predHor").copy_(pred_h[row_r])
@@ -419,11 +429,9 @@ class FrameHotPath(FrameME):
         fb.col("predHor").copy_(pred_h[row_r])
         fb.col("predVer").copy_(pred_v[row_r])
         self._mark("glue")
-        self._per_level(lambda l, pb, n, s: ctx.mc_luma_batch(dpb_ptr, self.buf["pred_other"].data_ptr(), mo.ptr + pb * MC_DT.itemsize, n, s, s))
+        self._per_level(lambda l, pb, n, s: ctx.motion_compensation_batch(org_ptr, dpb_ptr, None, self.buf["org_bi"].data_ptr(),
+                                                                          po.ptr + pb * PRED_DT.itemsize, n, s, s))
         self._mark("mc")
-        self._per_level(lambda l, pb, n, s: ctx.remove_high_freq_batch(org_ptr, self.buf["pred_other"].data_ptr(), self.buf["org_bi"].data_ptr(),
-                                                                       self.rhf.ptr + pb * PEL_DT.itemsize, n))
-        self._mark("pelop")
         self._per_level(lambda l, pb, n, s: ctx.full_search_batch(l["pic_full"], self.buf["org_bi"].data_ptr(), dpb_ptr, fu.ptr + pb * FULL_DT.itemsize, n,
                                                                   self.full_res.data_ptr() + pb * 32))
         self._mark("full")
@@ -438,32 +446,21 @@ class FrameHotPath(FrameME):
         bi_x = (self.full_res[:, 0] << 2) + (b16[:, 0].to(T.int32) << 1) + b16[:, 2].to(T.int32)
         bi_y = (self.full_res[:, 1] << 2) + (b16[:, 1].to(T.int32) << 1) + b16[:, 3].to(T.int32)
 
-        # (4) final prediction: best uni list, and the bi-prediction (addAvg of the two 14-bit MC outputs); residual of the cheaper one
+        # (4) final prediction and residual: bi-prediction (addAvg of the two 14-bit predictions) when cheaper, else the best uni list
         best1 = c1 < c0
-        row_b = T.where(best1, self.row1, self.row0)
-        mu = self.mc_tabs["mc_uni"]
-        mu.col("refOff").copy_(T.where(best1, self.ref_base[1], self.ref_base[0]) + self.pos)
-        mu.col("mvHor").copy_(mvq_x[row_b] << 2)
-        mu.col("mvVer").copy_(mvq_y[row_b] << 2)
-        for l, name, rw in ((0, "mc_b0", self.row0), (1, "mc_b1", self.row1)):
-            refined = rl if l == 1 else ~rl                                  # the refined list takes the bi vector
-            mb = self.mc_tabs[name]
-            mb.col("refOff").copy_(self.ref_base[l] + self.pos)
-            mb.col("mvHor").copy_(T.where(refined, bi_x, mvq_x[rw]) << 2)
-            mb.col("mvVer").copy_(T.where(refined, bi_y, mvq_y[rw]) << 2)
         use_bi = cost_bi < T.minimum(c0, c1)
-        self.sub.col("bOff").copy_(self.blk_off + use_bi.to(T.int64) * self.NS)
+        self._use_bi = use_bi
+        pf = self.pred_final
+        pf.col("mode").copy_(T.where(use_bi, T.full_like(best1, 2, dtype=T.uint8), best1.to(T.uint8)))
+        for l, rw in ((0, self.row0), (1, self.row1)):
+            refined = (rl if l == 1 else ~rl) & use_bi                       # in a bi-predicted PU the refined list takes the bi vector
+            pf.col2("refOff", l).copy_(self.ref_base[l] + self.pos)
+            pf.col2("mv", 2 * l).copy_(T.where(refined, bi_x, mvq_x[rw]) << 2)
+            pf.col2("mv", 2 * l + 1).copy_(T.where(refined, bi_y, mvq_y[rw]) << 2)
         self._mark("glue")
-        uni_ptr = self.pred_sel.data_ptr()
-        bi_ptr = uni_ptr + 2 * self.NS
-        self._per_level(lambda l, pb, n, s: ctx.mc_luma_batch(dpb_ptr, uni_ptr, mu.ptr + pb * MC_DT.itemsize, n, s, s))
-        self._per_level(lambda l, pb, n, s: ctx.mc_luma_batch(dpb_ptr, self.buf["p0"].data_ptr(), self.mc_tabs["mc_b0"].ptr + pb * MC_DT.itemsize, n, s, s))
-        self._per_level(lambda l, pb, n, s: ctx.mc_luma_batch(dpb_ptr, self.buf["p1"].data_ptr(), self.mc_tabs["mc_b1"].ptr + pb * MC_DT.itemsize, n, s, s))
+        self._per_level(lambda l, pb, n, s: ctx.motion_compensation_batch(org_ptr, dpb_ptr, self.buf["pred"].data_ptr(), self.buf["resi"].data_ptr(),
+                                                                          pf.ptr + pb * PRED_DT.itemsize, n, s, s))
         self._mark("mc")
-        self._per_level(lambda l, pb, n, s: ctx.add_avg_batch(self.buf["p0"].data_ptr(), self.buf["p1"].data_ptr(), bi_ptr,
-                                                              self.avg.ptr + pb * PEL_DT.itemsize, n))
-        self._per_level(lambda l, pb, n, s: ctx.subtract_batch(org_ptr, uni_ptr, self.buf["resi"].data_ptr(), self.sub.ptr + pb * PEL_DT.itemsize, n))
-        self._mark("pelop")
 
         # (5) residual coding per TU and transform candidate
         for lvl in self.levels:
