@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel of a step eagerly instead of replaying one captured hipGraph")
     return ap.parse_args()
 
 
@@ -125,10 +126,31 @@ def main():
     lam, qp = 8.0, 32
     fme = FrameHotPath(ctx, torch, dev, W, H, W, refs, [sr, sr], motion_lambda=lam, qp=qp)
 
+    # The ~150 launches of one picture (search kernels + the small on-device bookkeeping ops between them) are captured ONCE into a
+    # hipGraph and replayed per step: same kernels, same order, same buffers -- only the launch path changes.
+    graph = None
+    if not a.no_graph and world == 1:   # with RCCL initialised its watchdog thread may touch the runtime during a capture: eager there
+        try:
+            fme.run(cur.data_ptr(), dpb.data_ptr())          # allocations / lazy initialisation happen outside the capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                fme.run(cur.data_ptr(), dpb.data_ptr())
+            graph = g
+        except Exception as e:   # capture unsupported on this runtime: eager launches (identical work)
+            sys.stderr.write("hipGraph capture failed (%r); launching eagerly\n" % (e,))
+            graph = None
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+
     def step(k=None):
         if world > 1:
             dist.broadcast(dpb.view(torch.uint8), src=0)   # reconstructed reference pictures -> every GPU (xGMI); bytes: int16 is not a collective dtype
-        fme.run(cur.data_ptr(), dpb.data_ptr())
+        if graph is not None:
+            graph.replay()
+        else:
+            fme.run(cur.data_ptr(), dpb.data_ptr())
 
     for _ in range(a.warmup):
         step()
@@ -200,8 +222,9 @@ def main():
             "config": {"workload": "%dx%d 10-bit, encoder_randomaccess_vtm.cfg operating point (QP32, SR 96 via ASR, FEN subsampling): "
                                    "quadtree PUs 128..8 x 2 refs = %d integer searches + %d fractional + %d bi-pred refinements/picture, %d TU x transform-candidate chains"
                                    % (W, H, fme.n_jobs, fme.n_jobs, fme.n_jobs // 2, sum(l["ntu"] * l["nc"] for l in fme.levels)),
-                       "stages": ["tz_search", "frac_search", "bi-pred refinement (mc + removeHighFreq + full_search + frac_search)", "final mc/addAvg/residual",
-                                  "tu_chain (xT, quant, dequant, xIT, SSE)"], "pictures_in_flight": world, "parallelism": "ctu-rows: 1 picture (17 CTU rows) per GPU"},
+                       "stages": ["tz_search", "frac_search", "bi-pred refinement (mc+removeHighFreq fused, full_search, frac_search)", "final uni/bi prediction + residual (fused)",
+                                  "tu_chain (xT, quant, dequant, xIT, SSE)"], "launch": "hipGraph replay" if graph is not None else "eager",
+                       "pictures_in_flight": world, "parallelism": "ctu-rows: 1 picture (17 CTU rows) per GPU"},
             "satd_gblocks_per_s": float(satd_g.item()),
             "tz_candidates_per_picture": evals,
             "stages": stages,
