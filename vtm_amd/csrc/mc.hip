@@ -136,10 +136,165 @@ __device__ __forceinline__ void mc_block( const vtmhip_mc_job &j, const int16_t 
   }
 }
 
+
+// ---- 8 outputs per lane (blocks whose width is a multiple of 8): 16-byte loads / stores, each input sample fetched once per lane --------
+struct __attribute__( ( packed, aligned( 2 ) ) ) Pel8u { unsigned v[4]; };   // 8 samples at a 2-byte aligned address (global memory)
+
+__device__ __forceinline__ void unpack8( const unsigned u[4], int a[8] )
+{
+#pragma unroll
+  for( int k = 0; k < 4; k++ ) { a[2 * k] = ( int ) ( short ) ( u[k] & 0xffffu ); a[2 * k + 1] = ( int ) u[k] >> 16; }
+}
+__device__ __forceinline__ uint4 pack8( const int v[8] )
+{
+  uint4 u;
+  u.x = ( ( unsigned ) v[0] & 0xffffu ) | ( ( unsigned ) v[1] << 16 ); u.y = ( ( unsigned ) v[2] & 0xffffu ) | ( ( unsigned ) v[3] << 16 );
+  u.z = ( ( unsigned ) v[4] & 0xffffu ) | ( ( unsigned ) v[5] << 16 ); u.w = ( ( unsigned ) v[6] & 0xffffu ) | ( ( unsigned ) v[7] << 16 );
+  return u;
+}
+__device__ __forceinline__ void load8g( const int16_t *p, int a[8] )    // global, 2-byte aligned
+{
+  const Pel8u t = *reinterpret_cast<const Pel8u *>( p );
+  unpack8( t.v, a );
+}
+__device__ __forceinline__ void store8g( int16_t *p, const int v[8] )
+{
+  const uint4 u = pack8( v );
+  Pel8u       t;
+  t.v[0] = u.x; t.v[1] = u.y; t.v[2] = u.z; t.v[3] = u.w;
+  *reinterpret_cast<Pel8u *>( p ) = t;
+}
+__device__ __forceinline__ void load8s( const int16_t *p, int a[8] )    // LDS, 16-byte aligned
+{
+  const uint4    u = *reinterpret_cast<const uint4 *>( p );
+  const unsigned t[4] = { u.x, u.y, u.z, u.w };
+  unpack8( t, a );
+}
+__device__ __forceinline__ void load16( const int16_t *p, int a[16] )
+{
+  load8g( p, a );
+  load8g( p + 8, a + 8 );
+}
+
+// `out.vec( y, x0, v )` receives 8 horizontally adjacent output samples.
+template<int NT, int THREADS, class Out>
+__device__ __forceinline__ void mc_block_vec( const vtmhip_mc_job &j, const int16_t *__restrict__ refBase, int16_t *lds, int lane, Out out )
+{
+  constexpr int FB = NT == 8 ? 4 : 5, HALO = NT / 2 - 1;
+  const int     w = j.width, h = j.height, bd = j.bitDepth, segs = w >> 3;
+  const int     xFrac = j.mvHor & ( ( 1 << FB ) - 1 ), yFrac = j.mvVer & ( ( 1 << FB ) - 1 ), rnd = !j.bi;
+  const bool    alt = j.useAltHpelIf != 0;
+  const int16_t *src = refBase + j.refOff + ( long ) ( j.mvVer >> FB ) * j.refStride + ( j.mvHor >> FB );
+  if( yFrac == 0 && xFrac == 0 && rnd )   // filterCopy<true,true>: plain copy
+  {
+    for( int i = lane; i < segs * h; i += THREADS )
+    {
+      const int   y = i / segs, x0 = ( i - y * segs ) << 3;
+      int a[8];
+      load8g( src + ( long ) y * j.refStride + x0, a );
+      out.vec( y, x0, a );
+    }
+    return;
+  }
+  if( yFrac == 0 )   // horizontal only (phase 0 of a bi prediction runs the {0,0,0,64,..} taps = filterCopy<first,!last> arithmetic)
+  {
+    const Fir      f = fir_params( 1, rnd, bd );
+    const int16_t *c = NT == 8 ? luma_taps( xFrac, w, h, h, alt ) : c_chromaFilterMc[xFrac];
+    int            cc[NT];
+#pragma unroll
+    for( int t = 0; t < NT; t++ ) cc[t] = c[t];
+    for( int i = lane; i < segs * h; i += THREADS )
+    {
+      const int y = i / segs, x0 = ( i - y * segs ) << 3;
+      int       a[16];
+      load16( src + ( long ) y * j.refStride + x0 - HALO, a );
+      int v[8];
+#pragma unroll
+      for( int k = 0; k < 8; k++ )
+      {
+        int sum = 0;
+#pragma unroll
+        for( int t = 0; t < NT; t++ ) sum += a[k + t] * cc[t];
+        v[k] = fir_out( sum, f );
+      }
+      out.vec( y, x0, v );
+    }
+    return;
+  }
+  const bool     twoPass = xFrac != 0;
+  const int16_t *cvp = NT == 8 ? luma_taps( yFrac, w, h, h, alt ) : c_chromaFilterMc[yFrac];
+  int            cv[NT];
+#pragma unroll
+  for( int t = 0; t < NT; t++ ) cv[t] = cvp[t];
+  if( twoPass )
+  {
+    const Fir      fh = fir_params( 1, 0, bd );
+    const int16_t *chp = NT == 8 ? luma_taps( xFrac, w, h, h + 7 == 11 ? 4 : -1, alt ) : c_chromaFilterMc[xFrac];
+    int            ch[NT];
+#pragma unroll
+    for( int t = 0; t < NT; t++ ) ch[t] = chp[t];
+    for( int i = lane; i < segs * ( h + NT - 1 ); i += THREADS )
+    {
+      const int r = i / segs, x0 = ( i - r * segs ) << 3;
+      int       a[16];
+      load16( src + ( long ) ( r - HALO ) * j.refStride + x0 - HALO, a );
+      int v[8];
+#pragma unroll
+      for( int k = 0; k < 8; k++ )
+      {
+        int sum = 0;
+#pragma unroll
+        for( int t = 0; t < NT; t++ ) sum += a[k + t] * ch[t];
+        v[k] = fir_out( sum, fh );
+      }
+      *reinterpret_cast<uint4 *>( lds + r * w + x0 ) = pack8( v );   // rows of w = 8n samples: 16-byte aligned
+    }
+    block_sync<THREADS>();
+  }
+  const Fir fv = fir_params( twoPass ? 0 : 1, rnd, bd );
+  for( int i = lane; i < segs * h; i += THREADS )
+  {
+    const int y = i / segs, x0 = ( i - y * segs ) << 3;
+    int       sum[8];
+#pragma unroll
+    for( int k = 0; k < 8; k++ ) sum[k] = 0;
+#pragma unroll
+    for( int t = 0; t < NT; t++ )
+    {
+      int row[8];
+      if( twoPass ) load8s( lds + ( y + t ) * w + x0, row );
+      else load8g( src + ( long ) ( y + t - HALO ) * j.refStride + x0, row );
+#pragma unroll
+      for( int k = 0; k < 8; k++ ) sum[k] += row[k] * cv[t];
+    }
+    int v[8];
+#pragma unroll
+    for( int k = 0; k < 8; k++ ) v[k] = fir_out( sum[k], fv );
+    out.vec( y, x0, v );
+  }
+}
+
+// luma / chroma, 8-outputs-per-lane path for widths that are multiples of 8, sample-per-lane path otherwise (4-wide luma, small chroma)
+template<int THREADS, class Out>
+__device__ __forceinline__ void mc_any( const vtmhip_mc_job &j, const int16_t *__restrict__ refBase, int16_t *lds, int lane, Out out )
+{
+  if( ( j.width & 7 ) == 0 )
+  {
+    if( j.chroma ) mc_block_vec<4, THREADS>( j, refBase, lds, lane, out );
+    else mc_block_vec<8, THREADS>( j, refBase, lds, lane, out );
+  }
+  else
+  {
+    if( j.chroma ) mc_block<4, THREADS>( j, refBase, lds, lane, out );
+    else mc_block<8, THREADS>( j, refBase, lds, lane, out );
+  }
+}
+
 struct StoreGlobal
 {
   int16_t *dst; int stride;
   __device__ __forceinline__ void operator()( int y, int x, int16_t v ) const { dst[( long ) y * stride + x] = v; }
+  __device__ __forceinline__ void vec( int y, int x0, const int v[8] ) const { store8g( dst + ( long ) y * stride + x0, v ); }
 };
 
 __global__ __launch_bounds__( 64 ) void mc_kernel( const int16_t *__restrict__ refBase, int16_t *__restrict__ dstBase,
@@ -148,8 +303,7 @@ __global__ __launch_bounds__( 64 ) void mc_kernel( const int16_t *__restrict__ r
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];   // [(h+7)][w] H-pass intermediates
   const vtmhip_mc_job j = jobs[blockIdx.x];
   const StoreGlobal   st{ dstBase + j.dstOff, j.dstStride };
-  if( j.chroma ) mc_block<4, 64>( j, refBase, lds, ( int ) threadIdx.x, st );
-  else mc_block<8, 64>( j, refBase, lds, ( int ) threadIdx.x, st );
+  mc_any<64>( j, refBase, lds, ( int ) threadIdx.x, st );
 }
 
 // ---- InterPrediction::motionCompensation for one PU and one plane: xPredInterUni (:445-520) or xPredInterBi + xWeightedAverage
@@ -159,6 +313,7 @@ struct StoreLds
 {
   int16_t *p; int w;
   __device__ __forceinline__ void operator()( int y, int x, int16_t v ) const { p[y * w + x] = v; }
+  __device__ __forceinline__ void vec( int y, int x0, const int v[8] ) const { *reinterpret_cast<uint4 *>( p + y * w + x0 ) = pack8( v ); }
 };
 struct Epilogue
 {
@@ -169,6 +324,18 @@ struct Epilogue
     if( mode == 1 ) out[( long ) y * outStride + x] = ( int16_t ) ( org[( long ) y * orgStride + x] - v );
     else if( mode == 2 ) out[( long ) y * outStride + x] = ( int16_t ) ( 2 * org[( long ) y * orgStride + x] - v );
   }
+  __device__ __forceinline__ void vec( int y, int x0, const int v[8] ) const
+  {
+    if( pred ) store8g( pred + ( long ) y * predStride + x0, v );
+    if( mode )
+    {
+      int o[8], r[8];
+      load8g( org + ( long ) y * orgStride + x0, o );
+#pragma unroll
+      for( int k = 0; k < 8; k++ ) r[k] = ( mode == 1 ? o[k] : 2 * o[k] ) - v[k];
+      store8g( out + ( long ) y * outStride + x0, r );
+    }
+  }
 };
 struct AvgThen
 {
@@ -176,6 +343,14 @@ struct AvgThen
   __device__ __forceinline__ void operator()( int y, int x, int16_t v ) const
   {
     ep( y, x, ( int16_t ) min( cmax, max( 0, ( ( int ) p0[y * w + x] + ( int ) v + offset ) >> shift ) ) );   // addAvg (Buffer.cpp:467-507)
+  }
+  __device__ __forceinline__ void vec( int y, int x0, const int v[8] ) const
+  {
+    int a[8], r[8];
+    load8s( p0 + y * w + x0, a );
+#pragma unroll
+    for( int k = 0; k < 8; k++ ) r[k] = min( cmax, max( 0, ( a[k] + v[k] + offset ) >> shift ) );
+    ep.vec( y, x0, r );
   }
 };
 
@@ -199,22 +374,20 @@ __global__ __launch_bounds__( THREADS ) void motion_comp_kernel( const int16_t *
   if( j.mode != 2 )
   {
     const int l = j.mode;
-    m.refOff = j.refOff[l]; m.refStride = j.refStride[l]; m.mvHor = j.mv[l][0]; m.mvVer = j.mv[l][1]; m.bi = 0;
-    if( j.chroma ) mc_block<4, THREADS>( m, refBase, tmp, lane, ep );
-    else mc_block<8, THREADS>( m, refBase, tmp, lane, ep );
+    m.refOff = l ? j.refOff[1] : j.refOff[0]; m.refStride = l ? j.refStride[1] : j.refStride[0];   // (no dynamic indexing: keeps the job in registers)
+    m.mvHor = l ? j.mv[1][0] : j.mv[0][0]; m.mvVer = l ? j.mv[1][1] : j.mv[0][1]; m.bi = 0;
+    mc_any<THREADS>( m, refBase, tmp, lane, ep );
     return;
   }
   m.bi = 1;
   m.refOff = j.refOff[0]; m.refStride = j.refStride[0]; m.mvHor = j.mv[0][0]; m.mvVer = j.mv[0][1];
   const StoreLds s0{ p0, j.width };
-  if( j.chroma ) mc_block<4, THREADS>( m, refBase, tmp, lane, s0 );
-  else mc_block<8, THREADS>( m, refBase, tmp, lane, s0 );
+  mc_any<THREADS>( m, refBase, tmp, lane, s0 );
   block_sync<THREADS>();   // p0 complete, tmp free again
   const int headRoom = max( 2, 14 - ( int ) j.bitDepth ), shift = headRoom + 1;
   const AvgThen av{ p0, j.width, shift, ( 1 << ( shift - 1 ) ) + 2 * 8192, ( 1 << j.bitDepth ) - 1, ep };
   m.refOff = j.refOff[1]; m.refStride = j.refStride[1]; m.mvHor = j.mv[1][0]; m.mvVer = j.mv[1][1];
-  if( j.chroma ) mc_block<4, THREADS>( m, refBase, tmp, lane, av );
-  else mc_block<8, THREADS>( m, refBase, tmp, lane, av );
+  mc_any<THREADS>( m, refBase, tmp, lane, av );
 }
 
 __global__ __launch_bounds__( 256 ) void pelop_kernel( const int16_t *__restrict__ aBase, const int16_t *__restrict__ bBase, int16_t *__restrict__ dstBase,
