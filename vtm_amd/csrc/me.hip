@@ -33,6 +33,11 @@ struct MeJob   // wave-uniform view of one vtmhip_tz_job
   int            lpcShift, sprShift;   // log2(lpc); log2(segsPerRow) or -1 when it is not a power of two (widths 12, 24, 48)
   bool           narrow;               // lambda * 126 < 2^31: distortion + MV rate fits 32 bits -> packed (cost, index) keys
   unsigned       bias;   // 0x80008000 when samples may be negative (v_sad_u16 is unsigned), else 0
+  // items == lpc (blocks up to 32x32 with row sub-sampling): every lane owns ONE segment of the original block for the whole
+  // search, so it is loaded once (per-lane data, already XORed with bias) instead of once per candidate
+  bool           orgResident;
+  unsigned       orgSeg[4];
+  int            resOff;   // r * (refStride << ss) + x of that segment
 };
 
 __device__ __forceinline__ int floor_log2_u( unsigned v ) { return 31 - __clz( ( int ) v ); }
@@ -94,6 +99,22 @@ __device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy,
   const int16_t *c0 = j.ref + ( long ) cy * j.refStride + cx;
   const long     os = ( long ) j.orgStride << j.ss, cs = ( long ) j.refStride << j.ss;
   unsigned       s = 0;
+  if( j.orgResident )
+  {
+    if( j.seg == 8 )
+    {
+      const Pel8 b = *reinterpret_cast<const Pel8 *>( c0 + j.resOff );
+#pragma unroll
+      for( int k = 0; k < 4; k++ ) s = sad2( j.orgSeg[k], b.v[k] ^ j.bias, s );
+    }
+    else
+    {
+      const Pel4 b = *reinterpret_cast<const Pel4 *>( c0 + j.resOff );
+#pragma unroll
+      for( int k = 0; k < 2; k++ ) s = sad2( j.orgSeg[k], b.v[k] ^ j.bias, s );
+    }
+    return s;
+  }
   if( j.seg == 8 )
   {
     for( int it = sub; it < j.items; it += j.lpc )
@@ -534,6 +555,28 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel(
   j.sprShift   = ( j.segsPerRow & ( j.segsPerRow - 1 ) ) == 0 ? floor_log2_u( ( unsigned ) j.segsPerRow ) : -1;
   j.narrow     = j.lambda >= 0.0 && j.lambda * 126.0 < 2147483648.0;
 
+  j.orgResident = j.items == j.lpc;
+  j.resOff      = 0;
+  j.orgSeg[0] = j.orgSeg[1] = j.orgSeg[2] = j.orgSeg[3] = 0;
+  if( j.orgResident )
+  {
+    const int  sub = lane & ( j.lpc - 1 );
+    const int  r = j.sprShift >= 0 ? sub >> j.sprShift : sub / j.segsPerRow, x = ( sub - r * j.segsPerRow ) * j.seg;
+    const long os = ( long ) j.orgStride << j.ss;
+    if( j.seg == 8 )
+    {
+      const Pel8 a = *reinterpret_cast<const Pel8 *>( j.org + r * os + x );
+#pragma unroll
+      for( int k = 0; k < 4; k++ ) j.orgSeg[k] = a.v[k] ^ j.bias;
+    }
+    else
+    {
+      const Pel4 a = *reinterpret_cast<const Pel4 *>( j.org + r * os + x );
+      j.orgSeg[0] = a.v[0] ^ j.bias; j.orgSeg[1] = a.v[1] ^ j.bias;
+    }
+    j.resOff = ( int ) ( r * ( ( long ) j.refStride << j.ss ) + x );
+  }
+
   const bool ext = jp->extendedSettings != 0, fast = jp->fastSettings != 0, firstStop = jp->firstSearchStop != 0;
   const int  iRaster = fast ? 8 : 5, searchRange = jp->searchRange;
 
@@ -712,6 +755,28 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void full_search_kerne
   j.lpcShift   = floor_log2_u( ( unsigned ) j.lpc );
   j.sprShift   = ( j.segsPerRow & ( j.segsPerRow - 1 ) ) == 0 ? floor_log2_u( ( unsigned ) j.segsPerRow ) : -1;
   j.narrow     = j.lambda >= 0.0 && j.lambda * 126.0 < 2147483648.0;
+
+  j.orgResident = j.items == j.lpc;
+  j.resOff      = 0;
+  j.orgSeg[0] = j.orgSeg[1] = j.orgSeg[2] = j.orgSeg[3] = 0;
+  if( j.orgResident )
+  {
+    const int  sub = lane & ( j.lpc - 1 );
+    const int  r = j.sprShift >= 0 ? sub >> j.sprShift : sub / j.segsPerRow, x = ( sub - r * j.segsPerRow ) * j.seg;
+    const long os = ( long ) j.orgStride << j.ss;
+    if( j.seg == 8 )
+    {
+      const Pel8 a = *reinterpret_cast<const Pel8 *>( j.org + r * os + x );
+#pragma unroll
+      for( int k = 0; k < 4; k++ ) j.orgSeg[k] = a.v[k] ^ j.bias;
+    }
+    else
+    {
+      const Pel4 a = *reinterpret_cast<const Pel4 *>( j.org + r * os + x );
+      j.orgSeg[0] = a.v[0] ^ j.bias; j.orgSeg[1] = a.v[1] ^ j.bias;
+    }
+    j.resOff = ( int ) ( r * ( ( long ) j.refStride << j.ss ) + x );
+  }
 
   const Range sr = search_range( j, jp->centerHor, jp->centerVer, jp->searchRange );
   const int   nx = sr.right >= sr.left ? sr.right - sr.left + 1 : 0, ny = sr.bottom >= sr.top ? sr.bottom - sr.top + 1 : 0;
