@@ -485,11 +485,11 @@ __device__ __forceinline__ void tz_raster( const MeJob &j, TzState &s, const Ran
   const int total = nx * ny;
   unsigned long long cost;
   unsigned           idx;
-  // register-resident original (raster_resident_org): the 16-segment variant costs ~110 VGPRs, so it is only built into the
-  // kernels meant for the largest blocks (8 / 16 waves per job); smaller variants keep the small-block kernels at full occupancy
+  // register-resident original (raster_resident_org) for 1 and 4 segments per lane (32x32 / 64x64 with row sub-sampling); the
+  // 16-segment case (128x128) costs ~110 VGPRs and measured slower than the generic path at the occupancy that leaves
   const int  ipl  = j.items >> 6;
   const bool fits = total > 0 && j.lpc == 64 && j.seg == 8 && j.sprShift >= 0 && ( j.items & 63 ) == 0;
-  if( WPJ >= 8 && fits && ipl == 16 ) raster_resident_org<16, WPJ>( j, total, r.left, r.top, nx, stepXY, co, cost, idx );
+  if( false ) {}
   else if( WPJ >= 4 && fits && ipl == 4 ) raster_resident_org<4, WPJ>( j, total, r.left, r.top, nx, stepXY, co, cost, idx );
   else if( WPJ >= 2 && fits && ipl == 1 ) raster_resident_org<1, WPJ>( j, total, r.left, r.top, nx, stepXY, co, cost, idx );
   else eval_candidates<true, WPJ>( j, nullptr, total, r.left, r.top, nx > 0 ? nx : 1, stepXY, co, cost, idx );
