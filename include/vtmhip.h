@@ -201,6 +201,11 @@ typedef struct
 
 int vtmhip_full_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
                                   const vtmhip_full_job *d_jobs, int n, vtmhip_me_result *d_results );
+/* Same searches, same results, for a batch the caller promises to be uniform: EVERY job is size x size with searchRange <= 4
+ * (the bi-pred refinement of one quadtree level).  size 8 / 16 / 32 / 64: one lane per candidate over an LDS-resident window; any other size
+ * forwards to vtmhip_full_search_batch_dev.  The reference plane must be readable 7 samples beyond the search window's right edge. */
+int vtmhip_full_search_square_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                         const vtmhip_full_job *d_jobs, int n, int size, vtmhip_me_result *d_results );
 
 /* ---- whole motion estimation of one (PU, list, refIdx): InterSearch::xMotionEstimation -------------------------------------
  * (InterSearch.cpp:3299-3494; AMVR integer refinement xPatternSearchIntRefine :4172-4282).  One call runs, for n jobs:

@@ -217,3 +217,50 @@ def test_motion_compensation_fused_matches_oracle(ctx):
     d_out2 = ctx.to_device(np.zeros(pos, np.int16))
     ctx.motion_compensation_batch(d_org.ptr, d_ref.ptr, None, d_out2.ptr, d_jobs.ptr, n, 128, 128)
     assert np.array_equal(d_out2.to_host(np.int16), go)
+
+
+@pytest.mark.parametrize("size", [8, 16, 32, 64])
+def test_full_search_square_kernel_matches_oracle(ctx, size):
+    """vtmhip_full_search_square_batch_dev (one lane per candidate over an LDS window): uniform S x S jobs, +-4 and smaller / clipped
+    ranges, picture-corner positions, signed bi-pred targets and plain pictures."""
+    L = ol.oracle()
+    scene = me_util.Scene(416, 240, hard=True)
+    rng = np.random.default_rng(62 + size)
+    tgt = np.ascontiguousarray((2 * scene.cur.astype(np.int32) - rng.integers(0, 1024, scene.cur.shape)).astype(np.int16))
+    for signed, plane in ((1, tgt), (0, scene.cur)):
+        n = 700 if size <= 16 else 250
+        jobs = (FullJob * n)()
+        exp = []
+        for k in range(n):
+            w = h = size
+            x = int(rng.integers(0, (416 - w) // 4 + 1)) * 4
+            y = int(rng.integers(0, (240 - h) // 4 + 1)) * 4
+            if k % 6 == 0:
+                x, y = (0 if k % 12 == 0 else 416 - w), (0 if k % 4 == 0 else 240 - h)
+            ch, cv = int(rng.integers(-3000, 3000)), int(rng.integers(-2500, 2500))
+            if k % 9 == 0:
+                ch, cv = -5000, 4000      # far outside: the clipped window collapses
+            sr = int(rng.choice([4, 4, 4, 2, 1, 0, 3]))
+            jd = dict(w=w, h=h, x=x, y=y, subShift=1 if (h > 8 and w <= 64) else 0, lam=float(rng.uniform(1, 40)),
+                      predHor=int(rng.integers(-64, 64)), predVer=int(rng.integers(-64, 64)))
+            org = np.ascontiguousarray(plane[y:y + h, x:x + w])
+            c = me_util.oracle_ctx(scene, jd, org)
+            rg = ol.Range()
+            L.vo_set_search_range(C.byref(c), ch, cv, sr, C.byref(rg))
+            r = ol.MeResult()
+            L.vo_full_search(C.byref(c), C.byref(rg), C.byref(r))
+            exp.append((r.mvX, r.mvY, r.cost, r.dist, r.nEval))
+            j = jobs[k]
+            j.orgOff, j.refOff = y * 416 + x, scene.ref_off + y * scene.ref_stride + x
+            j.orgStride, j.refStride, j.puX, j.puY, j.width, j.height = 416, scene.ref_stride, x, y, w, h
+            j.subShift, j.imvShift, j.signedSamples = jd["subShift"], 0, signed
+            j.predHor, j.predVer, j.motionLambda = jd["predHor"], jd["predVer"], jd["lam"]
+            j.centerHor, j.centerVer, j.searchRange = ch, cv, sr
+        d_org, d_ref = ctx.to_device(plane), ctx.to_device(scene.ref_buf)
+        d_jobs = ctx.to_device(np.frombuffer(jobs, np.uint8))
+        d_res = ctx.alloc(32 * n)
+        ctx.full_search_batch(PicParams(416, 240, 128, 10, 0), d_org.ptr, d_ref.ptr, d_jobs.ptr, n, d_res.ptr, square=size)
+        res = (MeResult * n).from_buffer_copy(d_res.to_host(np.uint8).tobytes())
+        got = [(r.mvX, r.mvY, r.cost, r.dist, r.nEval) for r in res]
+        bad = [k for k in range(n) if got[k] != exp[k]]
+        assert not bad, (signed, [(got[k], exp[k]) for k in bad[:5]])

@@ -799,6 +799,144 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void full_search_kerne
   }
 }
 
+// ---- exhaustive search of small square blocks (8x8, 16x16), +-4: one LANE per candidate -------------------------------------
+// The cooperative kernel above spends a wave-step (8 or 4 candidates) on ~110 instructions; here the (S+8)^2 reference window and
+// the original block of every job of the workgroup are staged in LDS once and each lane owns one of the <= 81 candidates: S*S/2
+// v_sad_u16 over dword LDS reads (odd columns through v_alignbit), then the MV rate and an LDS arg-min per job.
+template<int S> struct FullSq
+{
+  static constexpr int JPB     = S == 8 ? 12 : S == 16 ? 6 : S == 32 ? 3 : 1;   // jobs per workgroup
+  static constexpr int THREADS = S <= 32 ? 256 : 128;                           // 81 candidates per job
+};
+
+template<int S>
+__global__ __launch_bounds__( FullSq<S>::THREADS ) void full_search_sq_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+                                                               const vtmhip_full_job *__restrict__ jobs, int numJobs, vtmhip_me_result *__restrict__ results )
+{
+  constexpr int JPB = FullSq<S>::JPB, THREADS = FullSq<S>::THREADS, WLD = S + 8, WD = WLD / 2 + 1, MAXC = 81;
+  __shared__ unsigned           sWin[JPB][WLD][WD];     // reference window, two samples per dword, one spare dword per row
+  __shared__ unsigned           sOrg[JPB][S][S / 2];
+  __shared__ int                sRange[JPB][4];          // left, top, nx, ny
+  __shared__ unsigned long long sBest[JPB];
+  __shared__ unsigned           sIdx[JPB];
+  const int tid  = threadIdx.x;
+  const int job0 = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x ) * JPB;
+  const int nj   = min( JPB, numJobs - job0 );
+  if( nj <= 0 ) return;
+
+  MeJob j;   // per-lane view of job `jl` (set below); only the fields mv_cost / search_range read
+  auto  view = [&]( const vtmhip_full_job &q ) {
+    j.ss = q.subShift; j.imvShift = q.imvShift; j.predHor = q.predHor; j.predVer = q.predVer; j.costScale = 2; j.lambda = q.motionLambda;
+    j.horMax = ( pic.picW + 8 - q.puX - 1 ) << 4; j.horMin = ( -pic.ctuSize - 8 - q.puX + 1 ) << 4;
+    j.verMax = ( pic.picH + 8 - q.puY - 1 ) << 4; j.verMin = ( -pic.ctuSize - 8 - q.puY + 1 ) << 4;
+    j.narrow = j.lambda >= 0.0 && j.lambda * 126.0 < 2147483648.0;
+  };
+  if( tid < nj )
+  {
+    const vtmhip_full_job &q = jobs[job0 + tid];
+    view( q );
+    const Range sr = search_range( j, q.centerHor, q.centerVer, q.searchRange );
+    sRange[tid][0] = sr.left; sRange[tid][1] = sr.top;
+    int nx = sr.right >= sr.left ? sr.right - sr.left + 1 : 0, ny = sr.bottom >= sr.top ? sr.bottom - sr.top + 1 : 0;
+    if( nx > 9 || ny > 9 || q.width != S || q.height != S ) nx = ny = 0;   // the caller's promise is broken: no candidates, cost stays ~0 (never touch memory outside the window)
+    sRange[tid][2] = nx;
+    sRange[tid][3] = ny;
+    sBest[tid] = ~0ull; sIdx[tid] = 0xffffffffu;
+  }
+  __syncthreads();
+  // stage windows (rows top .. top + ny + S - 2, columns left .. left + nx + S - 2) and original blocks, two samples per thread and step
+  for( int i = tid; i < nj * WLD * ( WLD / 2 ); i += THREADS )
+  {
+    const int jl = i / ( WLD * ( WLD / 2 ) ), rem = i - jl * ( WLD * ( WLD / 2 ) ), r = rem / ( WLD / 2 ), c2 = ( rem - r * ( WLD / 2 ) ) * 2;
+    const int nx = sRange[jl][2], ny = sRange[jl][3];
+    unsigned  v = 0;
+    if( r < ny + S - 1 && c2 < nx + S - 1 )
+    {
+      const vtmhip_full_job &q = jobs[job0 + jl];
+      const int16_t *p = refBase + q.refOff + ( long ) ( sRange[jl][1] + r ) * q.refStride + ( sRange[jl][0] + c2 );
+      const unsigned lo = ( unsigned short ) p[0], hi = c2 + 1 < nx + S - 1 ? ( unsigned short ) p[1] : 0u;
+      v = ( lo | ( hi << 16 ) ) ^ ( q.signedSamples ? 0x80008000u : 0u );
+    }
+    sWin[jl][r][c2 >> 1] = v;
+  }
+  for( int i = tid; i < nj * WLD; i += THREADS ) sWin[i / WLD][i % WLD][WD - 1] = 0;
+  for( int i = tid; i < nj * S * ( S / 2 ); i += THREADS )
+  {
+    const int jl = i / ( S * ( S / 2 ) ), rem = i - jl * ( S * ( S / 2 ) ), r = rem / ( S / 2 ), c2 = ( rem - r * ( S / 2 ) ) * 2;
+    const vtmhip_full_job &q = jobs[job0 + jl];
+    const int16_t *p = orgBase + q.orgOff + ( long ) r * q.orgStride + c2;
+    sOrg[jl][r][c2 >> 1] = ( ( unsigned ) ( unsigned short ) p[0] | ( ( unsigned ) ( unsigned short ) p[1] << 16 ) ) ^ ( q.signedSamples ? 0x80008000u : 0u );
+  }
+  __syncthreads();
+
+  // one candidate per lane; two passes over the arg-min: cost first, then the smallest index among equal costs (raster order = the
+  // reference's first strict minimum)
+  unsigned long long myCost[( JPB * MAXC + THREADS - 1 ) / THREADS];
+#pragma unroll
+  for( int pass = 0; pass < ( JPB * MAXC + THREADS - 1 ) / THREADS; pass++ )
+  {
+    const int it = tid + pass * THREADS;
+    myCost[pass] = ~0ull;
+    if( it < nj * MAXC )
+    {
+      const int jl = it / MAXC, k = it - jl * MAXC;
+      const int nx = sRange[jl][2], ny = sRange[jl][3];
+      if( k < nx * ny )
+      {
+        const vtmhip_full_job &q = jobs[job0 + jl];
+        view( q );
+        const int cy = k / nx, cx = k - cy * nx;
+        const unsigned sh = ( unsigned ) ( cx & 1 ) << 4;
+        unsigned       s = 0;
+        const int      step = 1 << j.ss;
+#pragma unroll 2
+        for( int r = 0; r < S; r += step )
+        {
+          const unsigned *w = &sWin[jl][cy + r][cx >> 1];
+          const unsigned *o = &sOrg[jl][r][0];
+          unsigned        d[S / 2 + 1];
+#pragma unroll
+          for( int m = 0; m <= S / 2; m++ ) d[m] = w[m];
+#pragma unroll
+          for( int m = 0; m < S / 2; m++ ) s = sad2( o[m], __builtin_amdgcn_alignbit( d[m + 1], d[m], sh ), s );
+        }
+        const int x = sRange[jl][0] + cx, y = sRange[jl][1] + cy;
+        myCost[pass] = ( ( unsigned long long ) s << j.ss ) + mv_cost( j, x, y );
+        atomicMin( &sBest[jl], myCost[pass] );
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for( int pass = 0; pass < ( JPB * MAXC + THREADS - 1 ) / THREADS; pass++ )
+  {
+    const int it = tid + pass * THREADS;
+    if( it < nj * MAXC )
+    {
+      const int jl = it / MAXC, k = it - jl * MAXC;
+      if( myCost[pass] == sBest[jl] ) atomicMin( &sIdx[jl], ( unsigned ) k );
+    }
+  }
+  __syncthreads();
+  if( tid < nj )
+  {
+    const vtmhip_full_job &q = jobs[job0 + tid];
+    view( q );
+    const int nx = sRange[tid][2], ny = sRange[tid][3];
+    vtmhip_me_result r;
+    r.mvX = 0; r.mvY = 0; r.nEval = ( unsigned ) ( nx * ny ); r.reserved = 0; r.cost = ~0ull; r.dist = ~0ull;
+    if( nx * ny > 0 )
+    {
+      const int idx = ( int ) sIdx[tid], ry = idx / nx, rx = idx - ry * nx;
+      r.mvX  = sRange[tid][0] + rx;
+      r.mvY  = sRange[tid][1] + ry;
+      r.cost = sBest[tid];
+      r.dist = r.cost - mv_cost( j, r.mvX, r.mvY );
+    }
+    results[job0 + tid] = r;
+  }
+}
+
 }   // namespace
 
 extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
@@ -850,6 +988,31 @@ extern "C" int vtmhip_full_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_p
   default: VTMHIP_FS_LAUNCH( 1, ( n + 3 ) / 4 ); break;
   }
 #undef VTMHIP_FS_LAUNCH
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+
+extern "C" int vtmhip_full_search_square_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                                    const vtmhip_full_job *d_jobs, int n, int size, vtmhip_me_result *d_results )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  if( size != 8 && size != 16 && size != 32 && size != 64 ) return vtmhip_full_search_batch_dev( ctx, pic, d_orgBase, d_refBase, d_jobs, n, d_results );
+  VTMHIP_REQUIRE( ctx, pic && n >= 0, "pic / n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_orgBase && d_refBase && d_jobs && d_results, "null pointer" );
+  VTMHIP_REQUIRE( ctx, pic->picW > 0 && pic->picH > 0 && pic->ctuSize > 0, "picture parameters" );
+#define VTMHIP_FSQ_LAUNCH( SZ ) \
+  hipLaunchKernelGGL( full_search_sq_kernel<SZ>, dim3( ( n + FullSq<SZ>::JPB - 1 ) / FullSq<SZ>::JPB ), dim3( FullSq<SZ>::THREADS ), 0, ctx->stream, *pic, d_orgBase, \
+                      d_refBase, d_jobs, n, d_results )
+  switch( size )
+  {
+  case 8: VTMHIP_FSQ_LAUNCH( 8 ); break;
+  case 16: VTMHIP_FSQ_LAUNCH( 16 ); break;
+  case 32: VTMHIP_FSQ_LAUNCH( 32 ); break;
+  default: VTMHIP_FSQ_LAUNCH( 64 ); break;
+  }
+#undef VTMHIP_FSQ_LAUNCH
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

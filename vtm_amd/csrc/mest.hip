@@ -318,6 +318,8 @@ extern "C" int vtmhip_xMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip
   if( st ) return st;
   hipLaunchKernelGGL( mest_bi_start_kernel, perJob, tpb, 0, ctx->stream, *pic, *cfg, d_jobs, n, wk );
   VTMHIP_LAUNCHED( ctx );
+  // (the lane-per-candidate kernel needs every slot to be a real size x size job: uniform square batches of bi jobs only -- here slots of
+  //  uni jobs are empty, so the cooperative kernel, which skips them, is used)
   st = vtmhip_full_search_batch_dev( ctx, &pFull, wk.pattern, d_refBase, wk.full, n, wk.ires );
   if( st ) return st;
   // uni: TZ search

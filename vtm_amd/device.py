@@ -174,8 +174,12 @@ class Context:
     def dequant_batch(self, d_q, d_coef, d_jobs, n):
         self._check(self.L.vtmhip_dequant_batch_dev(self.h, d_q, d_coef, d_jobs, n))
 
-    def full_search_batch(self, pic, d_org, d_ref, d_jobs, n, d_results):
-        self._check(self.L.vtmhip_full_search_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, d_results))
+    def full_search_batch(self, pic, d_org, d_ref, d_jobs, n, d_results, square=0):
+        """square = S: the caller promises S x S jobs with searchRange <= 4 (lane-per-candidate kernel for S = 8 / 16)."""
+        if square:
+            self._check(self.L.vtmhip_full_search_square_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, square, d_results))
+        else:
+            self._check(self.L.vtmhip_full_search_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, d_results))
 
     def motion_estimation_batch(self, pic, cfg, d_org, d_ref, d_other, d_jobs, n, max_w, max_h, d_results):
         """InterSearch::xMotionEstimation for n (PU, list, refIdx) jobs (vtmhip_xMotionEstimation_batch_dev)."""

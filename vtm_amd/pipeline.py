@@ -433,7 +433,7 @@ class FrameHotPath(FrameME):
                                                                           po.ptr + pb * PRED_DT.itemsize, n, s, s))
         self._mark("mc")
         self._per_level(lambda l, pb, n, s: ctx.full_search_batch(l["pic_full"], self.buf["org_bi"].data_ptr(), dpb_ptr, fu.ptr + pb * FULL_DT.itemsize, n,
-                                                                  self.full_res.data_ptr() + pb * 32))
+                                                                  self.full_res.data_ptr() + pb * 32, square=s if s <= 64 else 0))
         self._mark("full")
         fb.col("intX").copy_(self.full_res[:, 0].to(T.int16))
         fb.col("intY").copy_(self.full_res[:, 1].to(T.int16))
