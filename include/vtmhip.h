@@ -443,6 +443,45 @@ int vtmhip_affine_sobel_batch_dev( vtmhip_ctx *ctx, const int16_t *d_predBase, i
 int vtmhip_affine_equal_coeff_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const int32_t *d_derivBase, const vtmhip_affine_job *d_jobs, int n,
                                          int64_t *d_equalCoeff );
 
+/* ================================================================================================================
+ * (3) FRAME-LEVEL CHAINING -- the next stage's job table from the previous stage's results, on the device
+ * ==============================================================================================================
+ * A level-order driver (vtm_amd/pipeline.py) keeps every job table in HBM; these helpers patch them with one
+ * thread per job so that no decision returns to the host between the stages of a picture.  The decisions are those of
+ * InterSearch::predInterSearch at the FEN operating point (InterSearch.cpp:2531-2680). */
+
+/* children of a quadtree level start from / predict with their parent's integer vector (parentIdx < 0: zero vector) */
+int vtmhip_frame_child_start( vtmhip_ctx *ctx, vtmhip_tz_job *d_childJobs, int n, const int32_t *d_parentIdx, const vtmhip_me_result *d_parentRes );
+/* fractional jobs take rcMvInt from the integer results and the predictor from the integer jobs (same order, n entries) */
+int vtmhip_frame_frac_jobs( vtmhip_ctx *ctx, vtmhip_frac_job *d_fracJobs, const vtmhip_tz_job *d_tzJobs, const vtmhip_me_result *d_tzRes, int n );
+
+typedef struct
+{
+  int32_t numPU;                        /* PUs of the picture (all levels); every PU has one row per list in the 2*numPU-row tables */
+  int32_t pad;
+  const vtmhip_tz_job      *tz;         /* [2*numPU] integer jobs   */
+  const vtmhip_me_result   *tzRes;      /* [2*numPU] their results  */
+  const vtmhip_frac_result *fracRes;    /* [2*numPU] uni fractional results */
+  const int32_t            *row0, *row1;/* [numPU] row of the PU's list-0 / list-1 search */
+  const int64_t            *pos;        /* [numPU] y * refStride + x */
+  int64_t                   refBase[2]; /* sample offset of the list-0 / list-1 reference plane origin */
+  vtmhip_pred_job          *predOther;  /* [numPU] stage 0 out: prediction of the other list -> 2*org - pred */
+  vtmhip_full_job          *full;       /* [numPU] stage 0 out: exhaustive refinement around the refined list's vector */
+  vtmhip_frac_job          *fracBi;     /* [numPU] stage 0 / 1 out */
+  const vtmhip_me_result   *fullRes;    /* [numPU] */
+  const vtmhip_frac_result *fracBiRes;  /* [numPU] */
+  vtmhip_pred_job          *predFinal;  /* [numPU] stage 2 out: chosen uni / bi prediction */
+  int32_t                  *mvq;        /* [2*numPU][2] uni vectors, quarter-sample units (stage 0 out) */
+  int32_t                  *refineList; /* [numPU] 1: list 1 is refined (stage 0 out) */
+  int32_t                  *biMv;       /* [numPU][2] refined vector, quarter-sample units (stage 2 out) */
+  int64_t                  *costBi;     /* [numPU] (stage 2 out) */
+  int32_t                  *useBi;      /* [numPU] (stage 2 out) */
+} vtmhip_frame_tabs;
+
+/* stage 0: after the uni fractional searches -> predOther / full / fracBi;  1: after the exhaustive refinement -> fracBi.intX/Y;
+ * 2: after the bi fractional search -> predFinal (mode, vectors), biMv, costBi, useBi */
+int vtmhip_frame_stage( vtmhip_ctx *ctx, const vtmhip_frame_tabs *tabs, int stage );
+
 #ifdef __cplusplus
 }
 #endif

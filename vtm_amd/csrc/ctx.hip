@@ -29,6 +29,7 @@ int vtmhip_struct_size( int which )
   case 16: return ( int ) sizeof( vtmhip_me_job );
   case 17: return ( int ) sizeof( vtmhip_me_out );
   case 18: return ( int ) sizeof( vtmhip_pred_job );
+  case 19: return ( int ) sizeof( vtmhip_frame_tabs );
   default: return -1;
   }
 }

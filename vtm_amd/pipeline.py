@@ -107,25 +107,17 @@ class FrameME:
             lvl = dict(size=s, n=n, pic=PicParams(pic_w, pic_h, 128, 10, self.wpj.get(s, 1)),
                        jobs=torch.from_numpy(jobs.view(np.uint8).reshape(n, TZ_DT.itemsize).copy()).to(device),
                        res=torch.zeros((n, 8), dtype=torch.int32, device=device),
-                       parent=None if par is None else torch.from_numpy(par).to(device))
+                       parent=None if par is None else torch.from_numpy(par).to(device),
+                       parent32=None if par is None else torch.from_numpy(par.astype(np.int32)).to(device))
             self.levels.append(lvl)
             self.n_jobs += n
             self.alg_bytes_per_eval.append(4 * s * s >> subshift_mode2(s, s))
 
     def run(self, org_ptr, dpb_ptr):
         """Launches every level (coarse to fine) on the context's stream; no host synchronisation."""
-        torch = self.torch
         for i, lvl in enumerate(self.levels):
-            if lvl["parent"] is not None:
-                j32 = lvl["jobs"].view(torch.int32)
-                pres = self.levels[i - 1]["res"]
-                p = lvl["parent"].clamp(min=0)
-                mvx = torch.where(lvl["parent"] >= 0, pres[p, 0], torch.zeros_like(pres[p, 0]))
-                mvy = torch.where(lvl["parent"] >= 0, pres[p, 1], torch.zeros_like(pres[p, 1]))
-                j32[:, _J_MV_HOR] = mvx << 4      # start vector, internal 1/16 precision
-                j32[:, _J_MV_VER] = mvy << 4
-                j32[:, _J_PRED_HOR] = mvx << 2    # MV predictor, quarter-sample units
-                j32[:, _J_PRED_VER] = mvy << 2
+            if lvl["parent"] is not None:   # start vector and MV predictor = the parent's integer vector (device-side patch)
+                self.ctx.frame_child_start(lvl["jobs"].data_ptr(), lvl["n"], lvl["parent32"].data_ptr(), self.levels[i - 1]["res"].data_ptr())
             self.ctx.tz_search_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["jobs"].data_ptr(), lvl["n"], lvl["res"].data_ptr())
 
     def stats(self):
@@ -144,7 +136,7 @@ class FrameME:
 # ======================================================================================================================
 # Full hot path of one inter picture: integer ME -> fractional ME -> bi-predictive refinement -> residual coding.
 # ======================================================================================================================
-from .lib import DistJob, FracJob, FracResult, FullJob, McJob, PelOpJob, PredJob, QuantJob, TrJob, TuJob   # noqa: E402
+from .lib import DistJob, FracJob, FracResult, FrameTabs, FullJob, McJob, PelOpJob, PredJob, QuantJob, TrJob, TuJob   # noqa: E402
 
 FRAC_DT, FRACRES_DT, MC_DT, FULL_DT = np.dtype(FracJob), np.dtype(FracResult), np.dtype(McJob), np.dtype(FullJob)
 PEL_DT, TR_DT, Q_DT, DIST_DT = np.dtype(PelOpJob), np.dtype(TrJob), np.dtype(QuantJob), np.dtype(DistJob)
@@ -279,6 +271,27 @@ class FrameHotPath(FrameME):
         self.frac_bi = _Tab(T, dev, bj)
         self.frac_bi_res = T.zeros((NP, 16), dtype=T.uint8, device=dev)
 
+        # ---- device-side chaining (vtmhip_frame_*): static columns once, decisions in HBM -----------------------------------
+        for tab in (self.pred_other, self.pred_final):
+            for l in (0, 1):
+                tab.col2("refOff", l).copy_(self.ref_base[l] + self.pos)
+        self.row0_32, self.row1_32 = self.row0.to(T.int32), self.row1.to(T.int32)
+        self.mvq = T.zeros((2 * NP, 2), dtype=T.int32, device=dev)
+        self.refine = T.zeros(NP, dtype=T.int32, device=dev)
+        self.bi_mv = T.zeros((NP, 2), dtype=T.int32, device=dev)
+        self.cost_bi = T.zeros(NP, dtype=T.int64, device=dev)
+        self.use_bi = T.zeros(NP, dtype=T.int32, device=dev)
+        ft = FrameTabs()
+        ft.numPU = NP
+        ft.tz, ft.tzRes, ft.fracRes = self.tz_jobs_all.data_ptr(), self.tz_res_all.data_ptr(), self.frac_res.data_ptr()
+        ft.row0, ft.row1, ft.pos = self.row0_32.data_ptr(), self.row1_32.data_ptr(), self.pos.data_ptr()
+        ft.refBase[0], ft.refBase[1] = int(refs[0][0]), int(refs[1][0])
+        ft.predOther, ft.full, ft.fracBi = self.pred_other.ptr, self.full.ptr, self.frac_bi.ptr
+        ft.fullRes, ft.fracBiRes, ft.predFinal = self.full_res.data_ptr(), self.frac_bi_res.data_ptr(), self.pred_final.ptr
+        ft.mvq, ft.refineList, ft.biMv = self.mvq.data_ptr(), self.refine.data_ptr(), self.bi_mv.data_ptr()
+        ft.costBi, ft.useBi = self.cost_bi.data_ptr(), self.use_bi.data_ptr()
+        self.frame_tabs = ft
+
         # ---- transform units: the PU itself up to 64x64, four 64x64 quadrants of a 128x128 PU (MaxTbSize 64) ---------------
         tu_tabs, legacy, tb, max_coef = [], [], 0, 0
         for lvl in self.levels:
@@ -374,60 +387,25 @@ class FrameHotPath(FrameME):
         T, ctx, NP = self.torch, self.ctx, self.NP
         self._marks = [] if timing else None
         self._mark("start")
-        # (1) integer ME, coarse to fine
+        # (1) integer ME, coarse to fine: children start from / predict with the parent's vector
         for i, lvl in enumerate(self.levels):
             if lvl["parent"] is not None:
-                j32 = lvl["jobs"].view(T.int32)
-                pres = self.levels[i - 1]["res"]
-                p = lvl["parent"].clamp(min=0)
-                has = lvl["parent"] >= 0
-                mvx = T.where(has, pres[p, 0], T.zeros_like(pres[p, 0]))
-                mvy = T.where(has, pres[p, 1], T.zeros_like(pres[p, 1]))
-                j32[:, _J_MV_HOR], j32[:, _J_MV_VER] = mvx << 4, mvy << 4
-                j32[:, _J_PRED_HOR], j32[:, _J_PRED_VER] = mvx << 2, mvy << 2
+                ctx.frame_child_start(lvl["jobs"].data_ptr(), lvl["n"], lvl["parent32"].data_ptr(), self.levels[i - 1]["res"].data_ptr())
             ctx.tz_search_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["jobs"].data_ptr(), lvl["n"], lvl["res"].data_ptr())
         self._mark("tz")
-        tz = self.tz_res_all
-        j32 = self.tz_jobs_all.view(T.int32)
-        pred_h, pred_v = j32[:, _J_PRED_HOR], j32[:, _J_PRED_VER]
 
         # (2) fractional ME per (PU, list)
-        fr = self.frac
-        fr.col("intX").copy_(tz[:, 0].to(T.int16))
-        fr.col("intY").copy_(tz[:, 1].to(T.int16))
-        fr.col("predHor").copy_(pred_h)
-        fr.col("predVer").copy_(pred_v)
+        fr, ft = self.frac, self.frame_tabs
+        ctx.frame_frac_jobs(fr.ptr, self.tz_jobs_all.data_ptr(), self.tz_res_all.data_ptr(), 2 * NP)
         self._mark("glue")
         self._per_level(lambda l, pb, n, s: ctx.frac_search_batch(org_ptr, dpb_ptr, fr.ptr + 2 * pb * FRAC_DT.itemsize, 2 * n, s, s,
                                                                   self.frac_res.data_ptr() + 2 * pb * 16, uniform_square=True))
         self._mark("frac")
-        fres16 = self.frac_res.view(T.int16)
-        cost_uni = self.frac_res.view(T.int64)[:, 1]
-        mvq_x = (tz[:, 0] << 2) + (fres16[:, 0].to(T.int32) << 1) + fres16[:, 2].to(T.int32)   # quarter-sample units
-        mvq_y = (tz[:, 1] << 2) + (fres16[:, 1].to(T.int32) << 1) + fres16[:, 3].to(T.int32)
 
-        # (3) bi-pred refinement of the list with the larger uni cost (FASTINTERSEARCH_MODE1: one iteration, :2544-2556)
-        c0, c1 = cost_uni[self.row0], cost_uni[self.row1]
-        rl = c0 <= c1                                                    # True: refine list 1
-        row_r, row_o = T.where(rl, self.row1, self.row0), T.where(rl, self.row0, self.row1)
-        off_r = T.where(rl, self.ref_base[1], self.ref_base[0]) + self.pos
-        off_o = T.where(rl, self.ref_base[0], self.ref_base[1]) + self.pos
-        po = self.pred_other
-        po.col("mode").copy_((~rl).to(T.uint8))                              # the OTHER list: 0 when list 1 is refined
-        for l in (0, 1):
-            po.col2("refOff", l).copy_(self.ref_base[l] + self.pos)
-            po.col2("mv", 2 * l).copy_(mvq_x[self.row1 if l else self.row0] << 2)
-            po.col2("mv", 2 * l + 1).copy_(mvq_y[self.row1 if l else self.row0] << 2)
-        fu = self.full
-        fu.col("refOff").copy_(off_r)
-        fu.col("predHor").copy_(pred_h[row_r])
-        fu.col("predVer").copy_(pred_v[row_r])
-        fu.col("centerHor").copy_(mvq_x[row_r] << 2)
-        fu.col("centerVer").copy_(mvq_y[row_r] << 2)
-        fb = self.frac_bi
-        fb.col("refOff").copy_(off_r)
-        fb.col("predHor").copy_(pred_h[row_r])
-        fb.col("predVer").copy_(pred_v[row_r])
+        # (3) bi-pred refinement of the list with the larger uni cost (FASTINTERSEARCH_MODE1: one iteration, :2544-2556):
+        #     prediction of the other list fused with 2*org - pred, +-4 exhaustive search, fractional search on the new target
+        po, fu, fb = self.pred_other, self.full, self.frac_bi
+        ctx.frame_stage(ft, 0)
         self._mark("glue")
         self._per_level(lambda l, pb, n, s: ctx.motion_compensation_batch(org_ptr, dpb_ptr, None, self.buf["org_bi"].data_ptr(),
                                                                           po.ptr + pb * PRED_DT.itemsize, n, s, s))
@@ -435,32 +413,23 @@ class FrameHotPath(FrameME):
         self._per_level(lambda l, pb, n, s: ctx.full_search_batch(l["pic_full"], self.buf["org_bi"].data_ptr(), dpb_ptr, fu.ptr + pb * FULL_DT.itemsize, n,
                                                                   self.full_res.data_ptr() + pb * 32, square=s if s <= 64 else 0))
         self._mark("full")
-        fb.col("intX").copy_(self.full_res[:, 0].to(T.int16))
-        fb.col("intY").copy_(self.full_res[:, 1].to(T.int16))
+        ctx.frame_stage(ft, 1)
         self._mark("glue")
         self._per_level(lambda l, pb, n, s: ctx.frac_search_batch(self.buf["org_bi"].data_ptr(), dpb_ptr, fb.ptr + pb * FRAC_DT.itemsize, n, s, s,
                                                                   self.frac_bi_res.data_ptr() + pb * 16, uniform_square=True))
         self._mark("frac")
-        b16 = self.frac_bi_res.view(T.int16)
-        cost_bi = self.frac_bi_res.view(T.int64)[:, 1] >> 1   # the reference re-weights by 0.5 plus rate terms (:3483); mode decision is host work
-        bi_x = (self.full_res[:, 0] << 2) + (b16[:, 0].to(T.int32) << 1) + b16[:, 2].to(T.int32)
-        bi_y = (self.full_res[:, 1] << 2) + (b16[:, 1].to(T.int32) << 1) + b16[:, 3].to(T.int32)
 
         # (4) final prediction and residual: bi-prediction (addAvg of the two 14-bit predictions) when cheaper, else the best uni list
-        best1 = c1 < c0
-        use_bi = cost_bi < T.minimum(c0, c1)
-        self._use_bi = use_bi
         pf = self.pred_final
-        pf.col("mode").copy_(T.where(use_bi, T.full_like(best1, 2, dtype=T.uint8), best1.to(T.uint8)))
-        for l, rw in ((0, self.row0), (1, self.row1)):
-            refined = (rl if l == 1 else ~rl) & use_bi                       # in a bi-predicted PU the refined list takes the bi vector
-            pf.col2("refOff", l).copy_(self.ref_base[l] + self.pos)
-            pf.col2("mv", 2 * l).copy_(T.where(refined, bi_x, mvq_x[rw]) << 2)
-            pf.col2("mv", 2 * l + 1).copy_(T.where(refined, bi_y, mvq_y[rw]) << 2)
+        ctx.frame_stage(ft, 2)
+        self._use_bi = self.use_bi
         self._mark("glue")
         self._per_level(lambda l, pb, n, s: ctx.motion_compensation_batch(org_ptr, dpb_ptr, self.buf["pred"].data_ptr(), self.buf["resi"].data_ptr(),
                                                                           pf.ptr + pb * PRED_DT.itemsize, n, s, s))
         self._mark("mc")
+        cost_uni = self.frac_res.view(T.int64)[:, 1]
+        mvq_x, mvq_y, rl = self.mvq[:, 0], self.mvq[:, 1], self.refine
+        bi_x, bi_y, cost_bi, use_bi = self.bi_mv[:, 0], self.bi_mv[:, 1], self.cost_bi, self.use_bi
 
         # (5) residual coding per TU and transform candidate
         for lvl in self.levels:
@@ -480,5 +449,5 @@ class FrameHotPath(FrameME):
         for lvl in self.levels:
             pb, n = lvl["pb"], lvl["npu"]
             sl2, sl = slice(2 * pb, 2 * pb + 2 * n), slice(pb, pb + n)
-            lvl["out"] = dict(mvq_x=mvq_x[sl2], mvq_y=mvq_y[sl2], cost_uni=cost_uni[sl2], rl=rl[sl].to(T.int64), bi_x=bi_x[sl], bi_y=bi_y[sl],
+            lvl["out"] = dict(mvq_x=mvq_x[sl2], mvq_y=mvq_y[sl2], cost_uni=cost_uni[sl2], rl=rl[sl], bi_x=bi_x[sl], bi_y=bi_y[sl],
                               cost_bi=cost_bi[sl], use_bi=use_bi[sl])
