@@ -366,6 +366,7 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];
   unsigned *sCost = reinterpret_cast<unsigned *>( lds + C::JPW * C::PERJOB );   // [JPW][16]: 9 candidate distortions (+ scratch)
   __shared__ int sCentre[C::JPW][2];                                            // half-sample winner per PU (round 2 centre)
+  __shared__ unsigned sKeep[C::JPW];                                            // its distortion = candidate 0 of round 2 (same samples)
   const int tid = threadIdx.x;
   const int job0 = blockIdx.x * C::JPW;
   const int nj = min( C::JPW, numJobs - job0 );
@@ -428,14 +429,16 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
         *reinterpret_cast<int4 *>( lds + jl * C::PERJOB + C::WIN + p * C::PLANE + r * S + x0 ) = make_int4( ( int ) outw[0], ( int ) outw[1], ( int ) outw[2], ( int ) outw[3] );
       }
     }
-    for( int i = tid; i < C::JPW * 16; i += C::BLOCK ) sCost[i] = 0;
+    // round 2: candidate 0 is the half-sample winner itself -- the block round 1 already measured -- so only 8 candidates are formed
+    for( int i = tid; i < C::JPW * 16; i += C::BLOCK ) sCost[i] = ( round == 1 && ( i & 15 ) == 0 ) ? sKeep[i >> 4] : 0u;
     __syncthreads();
 
     // ---- phase V: one (PU, candidate, tile) item per lane ------------------------------------------------------------------
+    const int items = round == 0 ? C::ITEMS : C::ITEMS - C::TILES, cand0 = round;
 #pragma unroll 1
-    for( int it = tid; it < nj * C::ITEMS; it += C::BLOCK )
+    for( int it = tid; it < nj * items; it += C::BLOCK )
     {
-      const int jl = it / C::ITEMS, rem = it - jl * C::ITEMS, cand = rem / C::TILES, tile = rem - cand * C::TILES;
+      const int jl = it / items, rem = it - jl * items, cand = cand0 + rem / C::TILES, tile = rem - ( cand - cand0 ) * C::TILES;
       const vtmhip_frac_job &j = jobs[job0 + jl];
       const int8_t( *tab )[2] = round == 0 ? c_refineH : c_refineQ;
       const int dx = tab[cand][0], dy = tab[cand][1];
@@ -535,6 +538,7 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
         res->halfX = tab[bi][0]; res->halfY = tab[bi][1]; res->qterX = 0; res->qterY = 0; res->cost = best;
         sCentre[tid][0] = tab[bi][0] * 2;   // quarter-sample units
         sCentre[tid][1] = tab[bi][1] * 2;
+        sKeep[tid]      = sCost[tid * 16 + bi];
       }
       else
       {
