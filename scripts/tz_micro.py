@@ -19,9 +19,7 @@ ctx = Context(0)
 scene = me_util.Scene(1920, 1080, hard=True)
 d_cur, d_ref = ctx.to_device(scene.cur), ctx.to_device(scene.ref_buf)
 for size, wpj, n in ((8, 1, 60000), (16, 2, 30000), (32, 4, 12000), (64, 4, 4000)):
-    me_util.PU_W[:] = [size]
-    me_util.PU_H[:] = [size]
-    jobs = me_util.random_tz_jobs(scene, n, seed=size, ranges=(96,), allow_ext=False)
+    jobs = me_util.random_tz_jobs(scene, n, seed=size, ranges=(96,), allow_ext=False, sizes=([size], [size]))
     for j in jobs:
         j["fast"] = 0
         j["hasInt"] = 0

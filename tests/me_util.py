@@ -23,14 +23,14 @@ class Scene:
         self.margin = margin
 
 
-def random_tz_jobs(scene, n, seed=5, ranges=(64, 96, 192, 384, 8), allow_ext=True):
+def random_tz_jobs(scene, n, seed=5, ranges=(64, 96, 192, 384, 8), allow_ext=True, sizes=None):
     rng = np.random.default_rng(seed)
     jobs = []
     trial = 0
     while len(jobs) < n:
         trial += 1
-        w = int(rng.choice(PU_W))
-        h = int(rng.choice(PU_H))
+        w = int(rng.choice(sizes[0] if sizes else PU_W))
+        h = int(rng.choice(sizes[1] if sizes else PU_H))
         if w > scene.W or h > scene.H:
             continue
         x = int(rng.integers(0, (scene.W - w) // 4 + 1)) * 4
