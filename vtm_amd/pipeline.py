@@ -291,6 +291,18 @@ class FrameHotPath(FrameME):
         ft.mvq, ft.refineList, ft.biMv = self.mvq.data_ptr(), self.refine.data_ptr(), self.bi_mv.data_ptr()
         ft.costBi, ft.useBi = self.cost_bi.data_ptr(), self.use_bi.data_ptr()
         self.frame_tabs = ft
+        # per-level views of the same table set (the per-PU arrays advanced to the level's first PU): each level's chain of stages can then
+        # run on its own stream as soon as that level's integer search is done
+        for lvl in self.levels:
+            pb, n = lvl["pb"], lvl["npu"]
+            lt = FrameTabs()
+            C.memmove(C.byref(lt), C.byref(ft), C.sizeof(FrameTabs))
+            lt.numPU = n
+            for name, isz in (("row0", 4), ("row1", 4), ("pos", 8), ("predOther", PRED_DT.itemsize), ("full", FULL_DT.itemsize), ("fracBi", FRAC_DT.itemsize),
+                              ("fullRes", 32), ("fracBiRes", 16), ("predFinal", PRED_DT.itemsize), ("refineList", 4), ("biMv", 8), ("costBi", 8), ("useBi", 4)):
+                setattr(lt, name, getattr(ft, name) + pb * isz)
+            lvl["ftabs"] = lt
+        self.side_streams = [T.cuda.Stream(device=dev) for _ in range(int(os.environ.get("VTM_AMD_SIDE_STREAMS", "3")))] if dev.type == "cuda" else []
 
         # ---- transform units: the PU itself up to 64x64, four 64x64 quadrants of a 128x128 PU (MaxTbSize 64) ---------------
         tu_tabs, legacy, tb, max_coef = [], [], 0, 0
@@ -338,7 +350,12 @@ class FrameHotPath(FrameME):
                 lvl["sse_out"] = T.zeros(n_l, dtype=T.int64, device=dev)
         mk = lambda n: T.zeros(n, dtype=T.int16, device=dev)   # noqa: E731
         self.buf = dict(org_bi=mk(sb), pred=mk(sb), resi=mk(sb))
-        self.qcoef = T.zeros(max_coef, dtype=T.int32, device=dev)
+        # quantised levels: one arena per level (the levels' chains may run concurrently)
+        qoff = 0
+        for lvl in self.levels:
+            lvl["qoff"] = qoff
+            qoff += lvl["ntu"] * lvl["nc"] * lvl["ts"] * lvl["ts"]
+        self.qcoef = T.zeros(qoff, dtype=T.int32, device=dev)
         if not fused_tu:
             self.coef = T.zeros(max_coef, dtype=T.int32, device=dev)
             self.dqcoef = T.zeros(max_coef, dtype=T.int32, device=dev)
@@ -383,8 +400,64 @@ class FrameHotPath(FrameME):
         for lvl in self.levels:
             fn(lvl, lvl["pb"], lvl["npu"], lvl["size"])
 
+    def _level_chain(self, lvl, org_ptr, dpb_ptr):
+        """Stages (2)-(5) of ONE quadtree level, in order, on the context's current stream."""
+        ctx, pb, n, s, lt = self.ctx, lvl["pb"], lvl["npu"], lvl["size"], lvl["ftabs"]
+        fr, po, fu, fb, pf = self.frac, self.pred_other, self.full, self.frac_bi, self.pred_final
+        ctx.frame_frac_jobs(fr.ptr + 2 * pb * FRAC_DT.itemsize, self.tz_jobs_all.data_ptr() + 2 * pb * TZ_DT.itemsize, self.tz_res_all.data_ptr() + 2 * pb * 32, 2 * n)
+        ctx.frac_search_batch(org_ptr, dpb_ptr, fr.ptr + 2 * pb * FRAC_DT.itemsize, 2 * n, s, s, self.frac_res.data_ptr() + 2 * pb * 16, uniform_square=True)
+        ctx.frame_stage(lt, 0)
+        ctx.motion_compensation_batch(org_ptr, dpb_ptr, None, self.buf["org_bi"].data_ptr(), po.ptr + pb * PRED_DT.itemsize, n, s, s)
+        ctx.full_search_batch(lvl["pic_full"], self.buf["org_bi"].data_ptr(), dpb_ptr, fu.ptr + pb * FULL_DT.itemsize, n, self.full_res.data_ptr() + pb * 32,
+                              square=s if s <= 64 else 0)
+        ctx.frame_stage(lt, 1)
+        ctx.frac_search_batch(self.buf["org_bi"].data_ptr(), dpb_ptr, fb.ptr + pb * FRAC_DT.itemsize, n, s, s, self.frac_bi_res.data_ptr() + pb * 16, uniform_square=True)
+        ctx.frame_stage(lt, 2)
+        ctx.motion_compensation_batch(org_ptr, dpb_ptr, self.buf["pred"].data_ptr(), self.buf["resi"].data_ptr(), pf.ptr + pb * PRED_DT.itemsize, n, s, s)
+        nt, ts = lvl["ntu"] * lvl["nc"], lvl["ts"]
+        ctx.tu_chain_batch(self.buf["resi"].data_ptr(), self.tu.ptr + lvl["tb"] * TU_DT.itemsize, nt, ts, ts, self.tu_res.data_ptr() + lvl["tb"] * 16,
+                           self.qcoef.data_ptr() + 4 * lvl["qoff"], None, uniform=True)
+
+    def _run_overlapped(self, org_ptr, dpb_ptr):
+        """Level-major order over several streams: the integer searches stay one dependent chain (child <- parent) on the caller's stream;
+        every level's remaining stages start as soon as ITS integer search is done, on a side stream, so the low-parallelism launches of
+        the large blocks (960 searches of 128x128) share the chip with the other levels' work.  Same launches, same tables, same results
+        as the stage-major order."""
+        T, ctx = self.torch, self.ctx
+        main = T.cuda.current_stream()
+        for i, lvl in enumerate(self.levels):
+            if lvl["parent"] is not None:
+                ctx.frame_child_start(lvl["jobs"].data_ptr(), lvl["n"], lvl["parent32"].data_ptr(), self.levels[i - 1]["res"].data_ptr())
+            ctx.tz_search_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["jobs"].data_ptr(), lvl["n"], lvl["res"].data_ptr())
+            ev = T.cuda.Event()
+            ev.record(main)
+            st = self.side_streams[i % len(self.side_streams)]
+            st.wait_event(ev)
+            ctx.set_stream(st.cuda_stream)
+            self._level_chain(lvl, org_ptr, dpb_ptr)
+            ctx.set_stream(main.cuda_stream)
+        for st in self.side_streams:
+            main.wait_stream(st)
+        self._use_bi = self.use_bi
+        self._publish()
+
+    def _publish(self):
+        """per-level views of every decision (what tests/cpu_chain.py and a host encoder read back)"""
+        T = self.torch
+        cost_uni = self.frac_res.view(T.int64)[:, 1]
+        for lvl in self.levels:
+            pb, n = lvl["pb"], lvl["npu"]
+            sl2, sl = slice(2 * pb, 2 * pb + 2 * n), slice(pb, pb + n)
+            lvl["out"] = dict(mvq_x=self.mvq[sl2, 0], mvq_y=self.mvq[sl2, 1], cost_uni=cost_uni[sl2], rl=self.refine[sl], bi_x=self.bi_mv[sl, 0],
+                              bi_y=self.bi_mv[sl, 1], cost_bi=self.cost_bi[sl], use_bi=self.use_bi[sl])
+
     def run(self, org_ptr, dpb_ptr, timing=False):
+        """timing=True (or no side streams / VTM_AMD_OVERLAP=0): stage-major order on one stream with an event after every stage;
+        otherwise the overlapped level-major order."""
         T, ctx, NP = self.torch, self.ctx, self.NP
+        if not timing and self.fused_tu and self.side_streams and os.environ.get("VTM_AMD_OVERLAP", "1") != "0":
+            self._marks = None
+            return self._run_overlapped(org_ptr, dpb_ptr)
         self._marks = [] if timing else None
         self._mark("start")
         # (1) integer ME, coarse to fine: children start from / predict with the parent's vector
@@ -427,17 +500,13 @@ class FrameHotPath(FrameME):
         self._per_level(lambda l, pb, n, s: ctx.motion_compensation_batch(org_ptr, dpb_ptr, self.buf["pred"].data_ptr(), self.buf["resi"].data_ptr(),
                                                                           pf.ptr + pb * PRED_DT.itemsize, n, s, s))
         self._mark("mc")
-        cost_uni = self.frac_res.view(T.int64)[:, 1]
-        mvq_x, mvq_y, rl = self.mvq[:, 0], self.mvq[:, 1], self.refine
-        bi_x, bi_y, cost_bi, use_bi = self.bi_mv[:, 0], self.bi_mv[:, 1], self.cost_bi, self.use_bi
-
         # (5) residual coding per TU and transform candidate
         for lvl in self.levels:
             nt, ts = lvl["ntu"] * lvl["nc"], lvl["ts"]
             if self.fused_tu:
                 # levels go to the host for the CABAC estimate in the real encoder; the bench keeps them in HBM
                 ctx.tu_chain_batch(self.buf["resi"].data_ptr(), self.tu.ptr + lvl["tb"] * TU_DT.itemsize, nt, ts, ts,
-                                   self.tu_res.data_ptr() + lvl["tb"] * 16, self.qcoef.data_ptr(), None, uniform=True)
+                                   self.tu_res.data_ptr() + lvl["tb"] * 16, self.qcoef.data_ptr() + 4 * lvl["qoff"], None, uniform=True)
             else:
                 ctx.xT_batch(self.buf["resi"].data_ptr(), self.coef.data_ptr(), lvl["xt"].ptr, nt, ts, ts, lvl["sum_abs"].data_ptr())
                 ctx.quant_batch(self.coef.data_ptr(), self.qcoef.data_ptr(), None, lvl["quant"].ptr, nt, lvl["abs_sum"].data_ptr())
@@ -445,9 +514,4 @@ class FrameHotPath(FrameME):
                 ctx.xIT_batch(self.dqcoef.data_ptr(), self.rec_resi.data_ptr(), lvl["xit"].ptr, nt, ts, ts)
                 ctx.dist_batch(self.buf["resi"].data_ptr(), self.rec_resi.data_ptr(), lvl["sse"].ptr, nt, lvl["sse_out"].data_ptr())
         self._mark("tu")
-        # per-level views of every decision (what tests/cpu_chain.py and a host encoder read back)
-        for lvl in self.levels:
-            pb, n = lvl["pb"], lvl["npu"]
-            sl2, sl = slice(2 * pb, 2 * pb + 2 * n), slice(pb, pb + n)
-            lvl["out"] = dict(mvq_x=mvq_x[sl2], mvq_y=mvq_y[sl2], cost_uni=cost_uni[sl2], rl=rl[sl], bi_x=bi_x[sl], bi_y=bi_y[sl],
-                              cost_bi=cost_bi[sl], use_bi=use_bi[sl])
+        self._publish()
