@@ -35,6 +35,7 @@ struct MeJob   // wave-uniform view of one vtmhip_tz_job
   unsigned       bias;   // 0x80008000 when samples may be negative (v_sad_u16 is unsigned), else 0
   // items == lpc (blocks up to 32x32 with row sub-sampling): every lane owns ONE segment of the original block for the whole
   // search, so it is loaded once (per-lane data, already XORed with bias) instead of once per candidate
+  const int16_t *orgLds;   // != nullptr: the (row sub-sampled, bias-XORed) original block staged in LDS, row length w (multi-wave jobs)
   bool           orgResident;
   unsigned       orgSeg[4];
   int            resOff;   // r * (refStride << ss) + x of that segment
@@ -115,7 +116,19 @@ __device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy,
     }
     return s;
   }
-  if( j.seg == 8 )
+  if( j.seg == 8 && j.orgLds )
+  {
+    // items are 16-byte aligned in the LDS copy (w is a multiple of 8): one ds_read_b128 per item instead of a second vector-memory load
+    for( int it = sub; it < j.items; it += j.lpc )
+    {
+      const int   r = j.sprShift >= 0 ? it >> j.sprShift : it / j.segsPerRow, x = ( it - r * j.segsPerRow ) << 3;
+      const uint4 a = *reinterpret_cast<const uint4 *>( j.orgLds + ( it << 3 ) );
+      const Pel8  b = *reinterpret_cast<const Pel8 *>( c0 + r * cs + x );
+      s = sad2( a.x, b.v[0] ^ j.bias, s ); s = sad2( a.y, b.v[1] ^ j.bias, s );
+      s = sad2( a.z, b.v[2] ^ j.bias, s ); s = sad2( a.w, b.v[3] ^ j.bias, s );
+    }
+  }
+  else if( j.seg == 8 )
   {
     for( int it = sub; it < j.items; it += j.lpc )
     {
@@ -149,6 +162,25 @@ __device__ __forceinline__ int xcd_order( int b, int n )
   return ( xcd < r ? xcd * ( q + 1 ) : r * ( q + 1 ) + ( xcd - r ) * q ) + ( b >> 3 );
 }
 
+// Multi-wave jobs (large blocks): the original block -- read again for EVERY candidate -- is staged once in LDS, item-major
+// (item it = 8 samples at sLds[it * 8]), already XORed with the sign bias; candidates then fetch only the reference through the vector
+// memory path and the original through the LDS port.  Blocks that do not fit (or 4-sample segments) keep the global path.
+template<int WPJ, int CAP>
+__device__ __forceinline__ void stage_org( MeJob &j, int16_t *sLds, int tid )
+{
+  j.orgLds = nullptr;
+  if( WPJ < 4 || j.seg != 8 || j.items * 8 > CAP ) return;
+  const long os = ( long ) j.orgStride << j.ss;
+  for( int it = tid; it < j.items; it += 64 * WPJ )
+  {
+    const int  r = j.sprShift >= 0 ? it >> j.sprShift : it / j.segsPerRow, x = ( it - r * j.segsPerRow ) << 3;
+    const Pel8 a = *reinterpret_cast<const Pel8 *>( j.org + r * os + x );
+    *reinterpret_cast<uint4 *>( sLds + ( it << 3 ) ) = make_uint4( a.v[0] ^ j.bias, a.v[1] ^ j.bias, a.v[2] ^ j.bias, a.v[3] ^ j.bias );
+  }
+  __syncthreads();
+  j.orgLds = sLds;
+}
+
 // lexicographic (cost, index) minimum over the wave
 __device__ __forceinline__ void wave_argmin( unsigned long long &cost, unsigned &idx )
 {
@@ -160,6 +192,8 @@ __device__ __forceinline__ void wave_argmin( unsigned long long &cost, unsigned 
     if( oc < cost || ( oc == cost && oi < idx ) ) { cost = oc; idx = oi; }
   }
 }
+
+constexpr int ORG_LDS_CAP = 128 * 128;   // samples of the LDS copy of the original block (multi-wave kernels)
 
 struct TzState
 {
@@ -517,6 +551,7 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel(
   __shared__ int4               sPts[JOBS_PER_BLOCK][16];   // 15 m_uniMvList candidates / 16 diamond points at most
   __shared__ unsigned long long sRedCost[WPJ];
   __shared__ unsigned           sRedIdx[WPJ];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sOrgLds[WPJ >= 4 ? ORG_LDS_CAP : 8];
   const int lane = threadIdx.x & 63, wv = uni( ( int ) ( threadIdx.x >> 6 ) );
   const int blk    = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x );
   const int jobIdx = WPJ == 1 ? blk * 4 + wv : blk;
@@ -576,6 +611,7 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel(
     }
     j.resOff = ( int ) ( r * ( ( long ) j.refStride << j.ss ) + x );
   }
+  stage_org<WPJ, ORG_LDS_CAP>( j, sOrgLds, ( int ) threadIdx.x );
 
   const bool ext = jp->extendedSettings != 0, fast = jp->fastSettings != 0, firstStop = jp->firstSearchStop != 0;
   const int  iRaster = fast ? 8 : 5, searchRange = jp->searchRange;
@@ -729,6 +765,7 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void full_search_kerne
 {
   __shared__ unsigned long long sRedCost[WPJ];
   __shared__ unsigned           sRedIdx[WPJ];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sOrgLds[WPJ >= 4 ? ORG_LDS_CAP : 8];
   const int lane = threadIdx.x & 63, wv = uni( ( int ) ( threadIdx.x >> 6 ) );
   const int blk    = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x );
   const int jobIdx = WPJ == 1 ? blk * 4 + wv : blk;
@@ -777,6 +814,7 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void full_search_kerne
     }
     j.resOff = ( int ) ( r * ( ( long ) j.refStride << j.ss ) + x );
   }
+  stage_org<WPJ, ORG_LDS_CAP>( j, sOrgLds, ( int ) threadIdx.x );
 
   const Range sr = search_range( j, jp->centerHor, jp->centerVer, jp->searchRange );
   const int   nx = sr.right >= sr.left ? sr.right - sr.left + 1 : 0, ny = sr.bottom >= sr.top ? sr.bottom - sr.top + 1 : 0;

@@ -24,7 +24,7 @@ assert TzJob.predHor.offset == 4 * _J_PRED_HOR and TzJob.mvHor.offset == 4 * _J_
 assert C.sizeof(TzJob) % 4 == 0 and C.sizeof(MeResult) == 32
 
 
-WAVES_PER_JOB = {128: 4, 64: 4, 32: 4, 16: 2, 8: 1}   # vtmhip_pic_params.wavesPerJob per PU size (measured)
+WAVES_PER_JOB = {128: 8, 64: 2, 32: 1, 16: 1, 8: 1}   # vtmhip_pic_params.wavesPerJob per PU size: measured with the levels' chains overlapping
 
 
 FULL_WAVES_PER_JOB = {128: 16, 64: 8, 32: 4, 16: 1, 8: 1}   # 81-point exhaustive search: one candidate at a time per wave for big PUs
@@ -302,7 +302,7 @@ class FrameHotPath(FrameME):
                               ("fullRes", 32), ("fracBiRes", 16), ("predFinal", PRED_DT.itemsize), ("refineList", 4), ("biMv", 8), ("costBi", 8), ("useBi", 4)):
                 setattr(lt, name, getattr(ft, name) + pb * isz)
             lvl["ftabs"] = lt
-        self.side_streams = [T.cuda.Stream(device=dev) for _ in range(int(os.environ.get("VTM_AMD_SIDE_STREAMS", "3")))] if dev.type == "cuda" else []
+        self.side_streams = [T.cuda.Stream(device=dev) for _ in range(int(os.environ.get("VTM_AMD_SIDE_STREAMS", "5")))] if dev.type == "cuda" else []
 
         # ---- transform units: the PU itself up to 64x64, four 64x64 quadrants of a 128x128 PU (MaxTbSize 64) ---------------
         tu_tabs, legacy, tb, max_coef = [], [], 0, 0
