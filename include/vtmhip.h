@@ -88,6 +88,11 @@ int vtmhip_xGetHADs( vtmhip_ctx *ctx, const int16_t *org, int orgStride, const i
                      uint64_t *dist );
 int vtmhip_xGetSSE( vtmhip_ctx *ctx, const int16_t *org, int orgStride, const int16_t *cur, int curStride, int width, int height,
                     uint64_t *dist );
+/* DistParam::distFunc for DF_SAD_WITH_MASK (RdCost::xGetSADwMask, RdCost.cpp:3513-3549; set up by the mask overload of setDistParam :3488-3511;
+ * GEO merge estimation EncCu.cpp:2930-2960): sum |org - cur| * mask, the mask walked with stepX (+1 / -1) per sample and
+ * maskStride * (1 << subShift) + maskStride2 per row, as the scalar reference does. */
+int vtmhip_xGetSADwMask( vtmhip_ctx *ctx, const int16_t *org, int orgStride, const int16_t *cur, int curStride, int width, int height, int subShift,
+                         const int16_t *mask, int maskStride, int stepX, int maskStride2, uint64_t *dist );
 
 
 /* InterpolationFilter::m_filterHor / m_filterVer [tapIdx][isFirst][isLast] and m_filterCopy[isFirst][isLast]
@@ -132,6 +137,17 @@ typedef struct
 /* n independent distFunc evaluations (hooks B1-B7, B10).  d_jobs and d_dist are device arrays of n entries. */
 int vtmhip_dist_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_curBase, const vtmhip_dist_job *d_jobs, int n,
                            uint64_t *d_dist );
+
+typedef struct
+{
+  int64_t orgOff, curOff, maskOff;   /* maskOff: first mask sample (DistParam::mask) inside d_maskBase */
+  int32_t orgStride, curStride, maskStride, maskStride2;
+  int16_t width, height, subShift, stepX;
+} vtmhip_masked_sad_job;
+
+/* n masked SADs (DF_SAD_WITH_MASK), e.g. every (GEO split, merge candidate) pair of a CU in one launch */
+int vtmhip_masked_sad_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_curBase, const int16_t *d_maskBase,
+                                 const vtmhip_masked_sad_job *d_jobs, int n, uint64_t *d_dist );
 
 /* SATD 8x8 block-grid micro-benchmark: every 8-aligned 8x8 block of the W x H org picture against the
  * reference picture displaced by (dx,dy) in [-r,r]^2.  d_ref must carry >= r samples of valid margin on every side.

@@ -85,6 +85,18 @@ uint64_t ref_dist( int kind, int simd, const int16_t *org, int orgStride, const 
   return dp.distFunc( dp );
 }
 
+// RdCost::xGetSADwMask through the mask overload of setDistParam (RdCost.cpp:3488-3511); simd 1: the table entry (x86), 0: the scalar member
+uint64_t ref_sad_mask( int simd, const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h, int bitDepth, const int16_t *mask,
+                       int maskStride, int stepX, int maskStride2 )
+{
+  ensureInit();
+  DistParam dp;
+  CPelBuf   o( org, orgStride, w, h );
+  g_rd->setDistParam( dp, o, cur, curStride, mask, maskStride, stepX, maskStride2, bitDepth, COMPONENT_Y );
+  if( !simd ) dp.distFunc = RdCost::xGetSADwMask;
+  return dp.distFunc( dp );
+}
+
 // subShift as chosen by RdCost::setDistParam( ..., subShiftMode, ... ) (RdCost.cpp:238-324)
 int ref_subshift_for_mode( int w, int h, int subShiftMode )
 {

@@ -3,7 +3,7 @@
 // Runs the REAL reference encoder (EncApp / EncLib of VTM 9.3, compiled in place into oracle/_ref/libvtmref.so) and, when a
 // libvtmhip.so path is given, installs trampolines into the reference's own dispatch surface exactly where INTEGRATION.md
 // section 2 says a maintainer would:
-//   RdCost::m_afpDistortFunc[DF_SAD*, DF_HAD*, DF_SSE*]              (RdCost.h:113, RdCost.cpp:125-217)
+//   RdCost::m_afpDistortFunc[DF_SAD*, DF_HAD*, DF_SSE*, DF_SAD_WITH_MASK]  (RdCost.h:113, RdCost.cpp:125-217)
 //   InterpolationFilter::m_filterHor / m_filterVer / m_filterCopy    (InterpolationFilter.h:93-95) of EncLib's InterSearch
 //   fastFwdTrans / fastInvTrans                                      (TrQuant.cpp:69-81)
 // A hooked call is routed to the device through the C ABI of include/vtmhip.h; its result is what the encoder continues with
@@ -58,6 +58,7 @@ struct Api
   decltype( &vtmhip_xGetSAD )      sad;
   decltype( &vtmhip_xGetHADs )     had;
   decltype( &vtmhip_xGetSSE )      sse;
+  decltype( &vtmhip_xGetSADwMask ) sadmask;
   decltype( &vtmhip_filterHor )    fhor;
   decltype( &vtmhip_filterVer )    fver;
   decltype( &vtmhip_filterCopy )   fcopy;
@@ -107,10 +108,11 @@ uint64_t   g_distCtr[DF_TOTAL_FUNCTIONS];
 
 template<int IDX> Distortion distTramp( const DistParam &p )
 {
-  constexpr int kind = ( IDX >= DF_HAD && IDX <= DF_HAD16N ) ? 1 : ( IDX >= DF_SSE && IDX <= DF_SSE16N ) ? 2 : 0;
+  constexpr int kind = ( IDX >= DF_HAD && IDX <= DF_HAD16N ) ? 1 : ( IDX >= DF_SSE && IDX <= DF_SSE16N ) ? 2 : IDX == DF_SAD_WITH_MASK ? 3 : 0;
   g_st->calls[0]++;
-  // same guards as the x86 table entries (x86/RdCostX86.h:213,344,2157) -- what the device path does not cover stays on the host
-  if( p.applyWeight || p.useMR || p.step != 1 || p.mask != nullptr || p.bitDepth > 12 || ( kind != 0 && p.subShift != 0 ) || !sampled( g_distCtr[IDX] ) )
+  // same guards as the x86 table entries (x86/RdCostX86.h:213,344,2065,2157) -- what the device path does not cover stays on the host
+  if( p.applyWeight || p.useMR || p.step != 1 || ( ( p.mask != nullptr ) != ( kind == 3 ) ) || p.bitDepth > 12 || ( ( kind == 1 || kind == 2 ) && p.subShift != 0 )
+      || ( kind == 3 && p.stepX != 1 && p.stepX != -1 ) || !sampled( g_distCtr[IDX] ) )
   {
     return g_distOrig[IDX]( p );
   }
@@ -119,7 +121,8 @@ template<int IDX> Distortion distTramp( const DistParam &p )
   const int w = p.org.width, h = p.org.height;
   const int st = kind == 0 ? A.sad( g_ctx, p.org.buf, p.org.stride, p.cur.buf, p.cur.stride, w, h, p.subShift, &dev )
                : kind == 1 ? A.had( g_ctx, p.org.buf, p.org.stride, p.cur.buf, p.cur.stride, w, h, &dev )
-                           : A.sse( g_ctx, p.org.buf, p.org.stride, p.cur.buf, p.cur.stride, w, h, &dev );
+               : kind == 2 ? A.sse( g_ctx, p.org.buf, p.org.stride, p.cur.buf, p.cur.stride, w, h, &dev )
+                           : A.sadmask( g_ctx, p.org.buf, p.org.stride, p.cur.buf, p.cur.stride, w, h, p.subShift, p.mask, p.maskStride, p.stepX, p.maskStride2, &dev );
   if( st != VTMHIP_OK ) { note_error(); return ref; }
   g_st->device[0]++;
   // the scalar SAD may stop early once it exceeds maximumDistortionForEarlyExit (RdCost.cpp:516-519); callers only compare '<'
@@ -133,7 +136,7 @@ template<int... I> void installDist( std::integer_sequence<int, I...> )
   for( int i = 0; i < DF_TOTAL_FUNCTIONS; i++ )
   {
     g_distOrig[i] = RdCost::m_afpDistortFunc[i];
-    const bool hook = ( i >= DF_SSE && i <= DF_SSE16N ) || ( i >= DF_SAD && i <= DF_SAD16N ) || ( i >= DF_HAD && i <= DF_HAD16N ) || ( i >= DF_SAD12 && i <= DF_SAD48 );
+    const bool hook = ( i >= DF_SSE && i <= DF_SSE16N ) || ( i >= DF_SAD && i <= DF_SAD16N ) || ( i >= DF_HAD && i <= DF_HAD16N ) || ( i >= DF_SAD12 && i <= DF_SAD48 ) || i == DF_SAD_WITH_MASK;
     if( hook && ( g_mask & 1 ) ) RdCost::m_afpDistortFunc[i] = t[i];
   }
 }
@@ -385,7 +388,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
     A.so = dlopen( vtmhipPath, RTLD_NOW | RTLD_GLOBAL );
     if( !A.so ) { fprintf( stderr, "ref_encode: %s\n", dlerror() ); return -10; }
     const bool ok = sym( A.create, "vtmhip_create" ) && sym( A.destroy, "vtmhip_destroy" ) && sym( A.last_error, "vtmhip_last_error" ) && sym( A.sad, "vtmhip_xGetSAD" )
-                 && sym( A.had, "vtmhip_xGetHADs" ) && sym( A.sse, "vtmhip_xGetSSE" ) && sym( A.fhor, "vtmhip_filterHor" ) && sym( A.fver, "vtmhip_filterVer" )
+                 && sym( A.had, "vtmhip_xGetHADs" ) && sym( A.sse, "vtmhip_xGetSSE" ) && sym( A.sadmask, "vtmhip_xGetSADwMask" ) && sym( A.fhor, "vtmhip_filterHor" ) && sym( A.fver, "vtmhip_filterVer" )
                  && sym( A.fcopy, "vtmhip_filterCopy" ) && sym( A.fwd, "vtmhip_fastFwdTrans" ) && sym( A.inv, "vtmhip_fastInvTrans" )
                  && sym( A.dalloc, "vtmhip_dev_alloc" ) && sym( A.dfree, "vtmhip_dev_free" ) && sym( A.h2d, "vtmhip_h2d" ) && sym( A.d2h, "vtmhip_d2h" )
                  && sym( A.addAvg, "vtmhip_add_avg_batch_dev" ) && sym( A.rhf, "vtmhip_remove_high_freq_batch_dev" )

@@ -52,6 +52,27 @@ uint64_t vo_sad( const int16_t *org, int orgStride, const int16_t *cur, int curS
   return sum << subShift;
 }
 
+/* RdCost::xGetSADwMask (CommonLib/RdCost.cpp:3513-3549; GEO merge estimation, EncCu.cpp:2930-2960): |org - cur| weighted by a mask that is
+ * walked with a per-sample step (+1 / -1) and two per-row strides.  The x86 version (x86/RdCostX86.h:2065-2152) addresses the mask
+ * as row * maskStride (+ a reversed load for stepX == -1); both agree for the callers' maskStride2 == -stepX * width. */
+uint64_t vo_sad_mask( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h, int subShift, const int16_t *mask,
+                      int maskStride, int stepX, int maskStride2 )
+{
+  const int step = 1 << subShift;
+  uint64_t  sum  = 0;
+  for( int y = 0; y < h; y += step )
+  {
+    for( int x = 0; x < w; x++ )
+    {
+      sum += ( uint64_t )( int64_t )( vo_abs( ( int ) org[( ptrdiff_t ) y * orgStride + x] - ( int ) cur[( ptrdiff_t ) y * curStride + x] ) * ( int ) *mask );
+      mask += stepX;
+    }
+    mask += maskStride * step;
+    mask += maskStride2;
+  }
+  return sum << subShift;
+}
+
 /* RdCost::setDistParam subShift rule, CommonLib/RdCost.cpp:289-323 */
 int vo_subshift_for_mode( int w, int h, int subShiftMode )
 {

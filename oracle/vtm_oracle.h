@@ -61,6 +61,8 @@ typedef struct
 } vo_frac_result_t;
 
 uint64_t vo_sad( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h, int subShift );
+uint64_t vo_sad_mask( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h, int subShift, const int16_t *mask,
+                      int maskStride, int stepX, int maskStride2 );
 uint64_t vo_sse( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h );
 uint64_t vo_satd( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h );
 int      vo_satd_tile_shape( int w, int h, int *tw, int *th );

@@ -99,3 +99,40 @@ def test_satd8_grid_matches_oracle(ctx, size, r):
     ctx.satd8_grid(d_cur.ptr, W8, d_ref.ptr + 2 * off, stride, W, H, r, d_out.ptr)
     got = d_out.to_host().astype(np.uint64)
     assert np.array_equal(got, exp), np.nonzero(got != exp)[0][:10]
+
+
+def test_masked_sad_pointer_surface_and_batch(ctx):
+    """DF_SAD_WITH_MASK (GEO merge estimation): pointer surface and batched call vs the oracle; mask walked forwards / backwards in x and y."""
+    from vtm_amd.lib import MaskedSadJob
+    L = ol.oracle()
+    L.vo_sad_mask.restype = C.c_uint64
+    rng = np.random.default_rng(405)
+    M = 112
+    plane = ol.i16(rng.integers(0, 9, (M, M))).reshape(-1)
+    n = 400
+    jobs = (MaskedSadJob * n)()
+    orgs, curs, exp = [], [], []
+    pos = 0
+    for k in range(n):
+        w, h = int(rng.choice([4, 8, 16, 32, 64, 128 if k % 50 == 0 else 8])), int(rng.choice([4, 8, 16, 32, 64]))
+        w = min(w, 64)
+        org, cur = ol.i16(rng.integers(-1023, 2047, (h, w))), ol.i16(rng.integers(0, 1024, (h, w)))
+        sx, rd = (1 if k % 3 else -1), (1 if k % 2 else -1)
+        x0 = int(rng.integers(0, M - w)) + (w - 1 if sx < 0 else 0)
+        y0 = int(rng.integers(0, M - h)) + (h - 1 if rd < 0 else 0)
+        off, ms, ms2, ss = y0 * M + x0, rd * M, -sx * w, (1 if (k % 5 == 0 and h >= 8) else 0)
+        e = L.vo_sad_mask(ol.P(org), w, ol.P(cur), w, w, h, ss, C.c_void_p(plane.ctypes.data + 2 * off), ms, sx, ms2)
+        exp.append(e)
+        if k < 60:
+            assert ctx.xGetSADwMask(org, w, cur, w, w, h, plane, off, ms, sx, ms2, ss) == e, (k, w, h, sx, rd, ss)
+        j = jobs[k]
+        j.orgOff = j.curOff = pos
+        j.maskOff, j.orgStride, j.curStride, j.maskStride, j.maskStride2 = off, w, w, ms, ms2
+        j.width, j.height, j.subShift, j.stepX = w, h, ss, sx
+        orgs.append(org.reshape(-1)); curs.append(cur.reshape(-1))
+        pos += w * h
+    d_org, d_cur, d_mask = ctx.to_device(np.concatenate(orgs)), ctx.to_device(np.concatenate(curs)), ctx.to_device(plane)
+    d_jobs = ctx.to_device(np.frombuffer(jobs, np.uint8))
+    d_out = ctx.alloc(8 * n)
+    ctx.masked_sad_batch(d_org.ptr, d_cur.ptr, d_mask.ptr, d_jobs.ptr, n, d_out.ptr)
+    assert list(d_out.to_host(np.uint64)) == exp

@@ -241,3 +241,32 @@ def test_pred_inter_blk_luma_and_chroma(oracle, reflib):
         reflib.ref_pred_inter_blk(comp, C.c_void_p(yb.ctypes.data + 2 * yo), ys, C.c_void_p(ub.ctypes.data + 2 * uo), us, W, H, x, yy, w, h, mvh, mvv,
                                   bi, 10, imv, ol.P(b), cw)
         assert np.array_equal(a, b), (t, comp, w, h, mvh, mvv, bi, imv)
+
+
+def _masked_cases(rng, n):
+    """(org, cur, w, h, mask array, mask_off, maskStride, stepX, maskStride2) in the caller's convention of EncCu.cpp:2930-2960:
+    a 112x112 weight plane, rows walked with +-maskStride, columns with stepX, maskStride2 = -stepX * width."""
+    M = 112
+    plane = ol.i16(rng.integers(0, 9, (M, M)))
+    out = []
+    for k in range(n):
+        w, h = int(rng.choice([8, 16, 32, 64])), int(rng.choice([8, 16, 32, 64]))
+        org, cur = ol.i16(rng.integers(0, 1024, (h, w + 5))), ol.i16(rng.integers(0, 1024, (h, w + 3)))
+        step_x = 1 if k % 3 else -1
+        row_dir = 1 if k % 2 else -1
+        x0 = int(rng.integers(0, M - w)) + (w - 1 if step_x < 0 else 0)
+        y0 = int(rng.integers(0, M - h)) + (h - 1 if row_dir < 0 else 0)
+        out.append((org, cur, w, h, plane.reshape(-1), y0 * M + x0, row_dir * M, step_x, -step_x * w))
+    return out
+
+
+def test_masked_sad_equals_reference(oracle, reflib):
+    oracle.vo_sad_mask.restype = C.c_uint64
+    reflib.ref_sad_mask.restype = C.c_uint64
+    rng = np.random.default_rng(404)
+    for org, cur, w, h, mask, off, ms, sx, ms2 in _masked_cases(rng, 300):
+        mp = C.c_void_p(mask.ctypes.data + 2 * off)
+        a = oracle.vo_sad_mask(ol.P(org), org.shape[1], ol.P(cur), cur.shape[1], w, h, 0, mp, ms, sx, ms2)
+        b = reflib.ref_sad_mask(1, ol.P(org), org.shape[1], ol.P(cur), cur.shape[1], w, h, 10, mp, ms, sx, ms2)
+        c = reflib.ref_sad_mask(0, ol.P(org), org.shape[1], ol.P(cur), cur.shape[1], w, h, 10, mp, ms, sx, ms2)
+        assert a == b == c, (w, h, ms, sx, ms2)

@@ -226,6 +226,28 @@ __global__ __launch_bounds__( 256 ) void satd8_grid_kernel( const int16_t *__res
   }
 }
 
+// ---- masked SAD (GEO merge estimation): one wave per job ---------------------------------------------------------------------------
+__global__ __launch_bounds__( 256 ) void sad_mask_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ curBase, const int16_t *__restrict__ maskBase,
+                                                         const vtmhip_masked_sad_job *__restrict__ jobs, int n, unsigned long long *__restrict__ out )
+{
+  const int lane = threadIdx.x & 63;
+  const int job  = blockIdx.x * ( blockDim.x >> 6 ) + ( threadIdx.x >> 6 );
+  if( job >= n ) return;
+  const vtmhip_masked_sad_job j = jobs[job];
+  const int16_t *org = orgBase + j.orgOff, *cur = curBase + j.curOff, *mask = maskBase + j.maskOff;
+  const int  w = j.width, ss = j.subShift, rows = j.height >> ss;
+  const long rowStep = ( long ) w * j.stepX + ( ( long ) j.maskStride << ss ) + j.maskStride2;   // mask pointer advance per (sub-sampled) row
+  unsigned long long acc = 0;
+  for( int it = lane; it < rows * w; it += 64 )
+  {
+    const int r = it / w, x = it - r * w;
+    const int d = abs( ( int ) org[( long ) ( r << ss ) * j.orgStride + x] - ( int ) cur[( long ) ( r << ss ) * j.curStride + x] );
+    acc += ( unsigned long long ) ( long long ) ( d * ( int ) mask[r * rowStep + ( long ) x * j.stepX] );
+  }
+  acc = wave_reduce_add_u64( acc );
+  if( lane == 0 ) out[job] = acc << ss;
+}
+
 int check_dist_args( vtmhip_ctx *ctx, int w, int h, int subShift, int kind )
 {
   VTMHIP_REQUIRE( ctx, w >= 1 && h >= 1 && w <= 128 && h <= 128, "block size must be 1..128" );
@@ -319,3 +341,59 @@ int vtmhip_satd8_grid_dev( vtmhip_ctx *ctx, const int16_t *d_org, int orgStride,
 }
 
 }   // extern "C"
+
+
+extern "C" int vtmhip_masked_sad_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_curBase, const int16_t *d_maskBase,
+                                            const vtmhip_masked_sad_job *d_jobs, int n, uint64_t *d_dist )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_orgBase && d_curBase && d_maskBase && d_jobs && d_dist, "null pointer" );
+  hipLaunchKernelGGL( sad_mask_kernel, dim3( ( n + 3 ) / 4 ), dim3( 256 ), 0, ctx->stream, d_orgBase, d_curBase, d_maskBase, d_jobs, n, ( unsigned long long * ) d_dist );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+extern "C" int vtmhip_xGetSADwMask( vtmhip_ctx *ctx, const int16_t *org, int orgStride, const int16_t *cur, int curStride, int width, int height, int subShift,
+                                    const int16_t *mask, int maskStride, int stepX, int maskStride2, uint64_t *dist )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, org && cur && mask && dist, "null pointer" );
+  VTMHIP_REQUIRE( ctx, width >= 1 && height >= 1 && width <= 128 && height <= 128, "block size must be 1..128" );
+  VTMHIP_REQUIRE( ctx, subShift >= 0 && subShift <= 4 && ( height & ( ( 1 << subShift ) - 1 ) ) == 0, "subShift" );
+  VTMHIP_REQUIRE( ctx, stepX == 1 || stepX == -1, "stepX must be +1 or -1" );
+  // span of the mask the walk touches: offsets i * rowStep + x * stepX over the corners
+  const int  rows = height >> subShift;
+  const long rowStep = ( long ) width * stepX + ( long ) maskStride * ( 1 << subShift ) + maskStride2;
+  long lo = 0, hi = 0;
+  const long corners[4] = { 0, ( long ) ( width - 1 ) * stepX, ( long ) ( rows - 1 ) * rowStep, ( long ) ( rows - 1 ) * rowStep + ( long ) ( width - 1 ) * stepX };
+  for( long c : corners ) { lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
+  const size_t maskN = ( size_t ) ( hi - lo + 1 );
+  VTMHIP_REQUIRE( ctx, maskN <= ( size_t ) 1 << 22, "mask walk spans more than 4 M samples" );
+  const size_t blk = ( size_t ) width * height * sizeof( int16_t );
+  const size_t maskOff = ( 2 * blk + 63 ) & ~( size_t ) 63, jobOff = ( maskOff + maskN * 2 + 63 ) & ~( size_t ) 63, outOff = jobOff + 64;
+  int st = vtmhip_internal_scratch( ctx, outOff + 64 );
+  if( st ) return st;
+  char *hp = ( char * ) ctx->pinned, *dp = ( char * ) ctx->scratch;
+  for( int y = 0; y < height; y++ )
+  {
+    memcpy( hp + ( size_t ) y * width * 2, org + ( ptrdiff_t ) y * orgStride, ( size_t ) width * 2 );
+    memcpy( hp + blk + ( size_t ) y * width * 2, cur + ( ptrdiff_t ) y * curStride, ( size_t ) width * 2 );
+  }
+  memcpy( hp + maskOff, mask + lo, maskN * 2 );
+  vtmhip_masked_sad_job j;
+  memset( &j, 0, sizeof( j ) );
+  j.orgOff = 0; j.curOff = ( int64_t ) width * height; j.maskOff = ( int64_t ) ( maskOff / 2 ) - lo;
+  j.orgStride = width; j.curStride = width; j.maskStride = maskStride; j.maskStride2 = maskStride2;
+  j.width = ( int16_t ) width; j.height = ( int16_t ) height; j.subShift = ( int16_t ) subShift; j.stepX = ( int16_t ) stepX;
+  memcpy( hp + jobOff, &j, sizeof( j ) );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( dp, hp, outOff, hipMemcpyHostToDevice, ctx->stream ) );
+  hipLaunchKernelGGL( sad_mask_kernel, dim3( 1 ), dim3( 256 ), 0, ctx->stream, ( const int16_t * ) dp, ( const int16_t * ) dp, ( const int16_t * ) dp,
+                      ( const vtmhip_masked_sad_job * ) ( dp + jobOff ), 1, ( unsigned long long * ) ( dp + outOff ) );
+  VTMHIP_LAUNCHED( ctx );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( hp + outOff, dp + outOff, 8, hipMemcpyDeviceToHost, ctx->stream ) );
+  VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  memcpy( dist, hp + outOff, 8 );
+  return VTMHIP_OK;
+}

@@ -120,6 +120,16 @@ class Context:
                                           cur_stride, w, h, C.byref(d)))
         return d.value
 
+    def xGetSADwMask(self, org, org_stride, cur, cur_stride, w, h, mask, mask_off, mask_stride, step_x, mask_stride2, sub_shift=0):
+        """DF_SAD_WITH_MASK on host arrays; `mask` is a 1-D int16 array, mask_off the index of DistParam::mask inside it."""
+        d = C.c_uint64()
+        self._check(self.L.vtmhip_xGetSADwMask(self.h, org.ctypes.data, org_stride, cur.ctypes.data, cur_stride, w, h, sub_shift,
+                                               mask.ctypes.data + 2 * mask_off, mask_stride, step_x, mask_stride2, C.byref(d)))
+        return d.value
+
+    def masked_sad_batch(self, d_org, d_cur, d_mask, d_jobs, n, d_dist):
+        self._check(self.L.vtmhip_masked_sad_batch_dev(self.h, d_org, d_cur, d_mask, d_jobs, n, d_dist))
+
     def filter(self, vertical, taps, is_first, is_last, src, src_off, src_stride, w, h, coeff, bit_depth=10, clip=None, bimc=0):
         """m_filterHor/m_filterVer[taps][isFirst][isLast] on a host array; returns the h x w int16 block."""
         clip = clip or (0, (1 << bit_depth) - 1)

@@ -140,8 +140,14 @@ class FrameTabs(C.Structure):
                 ("refineList", C.c_void_p), ("biMv", C.c_void_p), ("costBi", C.c_void_p), ("useBi", C.c_void_p)]
 
 
+class MaskedSadJob(C.Structure):
+    _fields_ = [("orgOff", C.c_int64), ("curOff", C.c_int64), ("maskOff", C.c_int64), ("orgStride", C.c_int32), ("curStride", C.c_int32),
+                ("maskStride", C.c_int32), ("maskStride2", C.c_int32), ("width", C.c_int16), ("height", C.c_int16), ("subShift", C.c_int16),
+                ("stepX", C.c_int16)]
+
+
 _STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob,
-            TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut, PredJob, FrameTabs]   # order of vtmhip_struct_size(which)
+            TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut, PredJob, FrameTabs, MaskedSadJob]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
 _PROTOS = {
@@ -165,6 +171,9 @@ _PROTOS = {
                                  C.POINTER(C.c_uint64)]),
     "vtmhip_xGetHADs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(C.c_uint64)]),
+    "vtmhip_xGetSADwMask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_int, C.POINTER(C.c_uint64)]),
+    "vtmhip_masked_sad_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vtmhip_xGetSSE": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_uint64)]),
     "vtmhip_filterHor": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
