@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="stage-major order on one stream (no overlap of the levels' chains): clean per-kernel times for profiling")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of a step eagerly instead of replaying one captured hipGraph")
     return ap.parse_args()
 
@@ -95,6 +96,8 @@ def main():
     from vtm_amd.device import Context
     from vtm_amd.pipeline import FrameHotPath
 
+    if a.serial:
+        os.environ["VTM_AMD_OVERLAP"] = "0"
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -224,6 +227,7 @@ def main():
                                    % (W, H, fme.n_jobs, fme.n_jobs, fme.n_jobs // 2, sum(l["ntu"] * l["nc"] for l in fme.levels)),
                        "stages": ["tz_search", "frac_search", "bi-pred refinement (mc+removeHighFreq fused, full_search, frac_search)", "final uni/bi prediction + residual (fused)",
                                   "tu_chain (xT, quant, dequant, xIT, SSE)"], "launch": "hipGraph replay" if graph is not None else "eager",
+                       "order": "stage-major, one stream" if a.serial else "level-major over 5 side streams (each level's stages start when its integer search is done)",
                        "pictures_in_flight": world, "parallelism": "ctu-rows: 1 picture (17 CTU rows) per GPU"},
             "satd_gblocks_per_s": float(satd_g.item()),
             "tz_candidates_per_picture": evals,
@@ -232,8 +236,9 @@ def main():
                          "frac": stages[dom]["alg_GBps"] / 8000.0, "traffic": traffic, "launches_per_step": launches,
                          "achieved_per_launch_bytes": alg[dom] / launches, "ms_per_launch": stage_acc[dom] / launches,
                          "note": "dominant kernel family of the step by time; achieved = algorithmic bytes (DESIGN.md section 5) / kernel time, both per "
-                                 "launch averaged over its %d launches/step; %.3f ms of %.3f ms/step; traffic = HBM-side bytes per launch from the "
-                                 "committed PMC passes (profiles/)" % (launches, stage_acc[dom], sum(stage_acc.values()))},
+                                 "launch averaged over its %d launches/step, timed in the stage-major pass (one stream, no overlap between the levels' chains): "
+                                 "%.3f ms of %.3f ms there; traffic = HBM-side bytes per launch from the committed PMC passes (profiles/)"
+                                 % (launches, stage_acc[dom], sum(stage_acc.values()))},
             "satd_roofline": {"bound": "hbm", "kernel": "satd8_grid_kernel", "achieved": nb * 81 * 256 / satd_ms / 1e6, "peak": 8000.0,
                               "unit": "GB/s", "frac": nb * 81 * 256 / satd_ms / 1e6 / 8000.0, "ms": satd_ms},
         }
