@@ -348,7 +348,7 @@ struct FracSq
   static constexpr int TILES = ( S / 8 ) * ( S / 8 );
   static constexpr int ITEMS = 9 * TILES;                       // per PU per round
   static constexpr int BLOCK = S == 32 ? 192 : 256;
-  static constexpr int MINW  = ( S == 32 || S == 64 ) ? 3 : 4;   // waves per SIMD the register budget is sized for (32 / 64 spill at 128 VGPRs)
+  static constexpr int MINW  = 4;                                // waves per SIMD the register budget is sized for (128 VGPRs; the dot-product V pass fits every size)
   static constexpr int JPW   = ITEMS >= BLOCK ? 1 : BLOCK / ITEMS;   // S = 8: 28, 16: 7, 32: 1 (144 of 192 lanes), 64 / 128: 1
   static constexpr int WLD   = S + 8;                           // window stride
   static constexpr int WIN   = ( S + 8 ) * WLD;                 // window samples per PU
@@ -450,26 +450,44 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
       const int      ty = tile / ( S / 8 ), tx = tile - ty * ( S / 8 );
       const int16_t *pl = lds + jl * C::PERJOB + C::WIN + ( dx + 1 ) * C::PLANE + ( ty * 8 + iy + 1 ) * S + tx * 8;
       const IfParams pV = if_params( 0, 1, j.bitDepth, 0, ( 1 << j.bitDepth ) - 1, 0 );
+      // Vertical FIR with v_dot2c_i32_i16: rows r and r + 1 are interleaved column-wise (two v_perm per dword pair), so one instruction
+      // applies two taps: output row y takes the row pairs (y, y+1), (y+2, y+3), (y+4, y+5), (y+6, y+7) with the tap pairs
+      // (c0,c1) .. (c6,c7) -- 256 dot products instead of 512 multiply-adds, and no 16-bit unpacking.
+      typedef short v2s __attribute__( ( ext_vector_type( 2 ) ) );
+      v2s cpk[4];
+#pragma unroll
+      for( int m = 0; m < 4; m++ ) { cpk[m].x = ( short ) cv[2 * m]; cpk[m].y = ( short ) cv[2 * m + 1]; }
       int acc[64];
 #pragma unroll
       for( int i = 0; i < 64; i++ ) acc[i] = pV.offset;
+      int4 prev = *reinterpret_cast<const int4 *>( pl );
 #pragma unroll
-      for( int r = 0; r < 15; r++ )
+      for( int r = 1; r < 15; r++ )
       {
-        const int4 raw = *reinterpret_cast<const int4 *>( pl + r * S );   // 8 samples of plane row r
-        int        v[8];
-        v[0] = ( int ) ( short ) raw.x; v[1] = raw.x >> 16; v[2] = ( int ) ( short ) raw.y; v[3] = raw.y >> 16;
-        v[4] = ( int ) ( short ) raw.z; v[5] = raw.z >> 16; v[6] = ( int ) ( short ) raw.w; v[7] = raw.w >> 16;
+        const int4     cur = *reinterpret_cast<const int4 *>( pl + r * S );   // 8 samples of plane row r
+        const unsigned pw[4] = { ( unsigned ) prev.x, ( unsigned ) prev.y, ( unsigned ) prev.z, ( unsigned ) prev.w };
+        const unsigned cw[4] = { ( unsigned ) cur.x, ( unsigned ) cur.y, ( unsigned ) cur.z, ( unsigned ) cur.w };
+        v2s pr[8];   // column x: (row r-1, row r)
 #pragma unroll
-        for( int y = 0; y < 8; y++ )
+        for( int k = 0; k < 4; k++ )
         {
-          if( r - y >= 0 && r - y < 8 )
+          const unsigned lo = __builtin_amdgcn_perm( cw[k], pw[k], 0x05040100u ), hi = __builtin_amdgcn_perm( cw[k], pw[k], 0x07060302u );
+          __builtin_memcpy( &pr[2 * k], &lo, 4 );
+          __builtin_memcpy( &pr[2 * k + 1], &hi, 4 );
+        }
+        const int q = r - 1;   // the pair (q, q+1)
+#pragma unroll
+        for( int m = 0; m < 4; m++ )
+        {
+          const int y = q - 2 * m;
+          if( y >= 0 && y < 8 )
           {
 #pragma unroll
-            for( int x = 0; x < 8; x++ ) acc[y * 8 + x] += v[x] * cv[r - y];
+            for( int x = 0; x < 8; x++ ) acc[y * 8 + x] = __builtin_amdgcn_sdot2( pr[x], cpk[m], acc[y * 8 + x], false );
           }
         }
-        __builtin_amdgcn_sched_barrier( 0 );   // keep the 15 row loads from being hoisted together (register pressure -> occupancy)
+        prev = cur;
+        __builtin_amdgcn_sched_barrier( 0 );   // keep the row loads from being hoisted together (register pressure -> occupancy)
       }
       // |sum of taps| <= 112 and |plane sample| <= 32768: (acc >> shift) fits 16 bits, so the reference's Pel truncation is the identity here
       const int16_t *org = orgBase + j.orgOff + ( long ) ( ty * 8 ) * j.orgStride + tx * 8;
