@@ -559,6 +559,50 @@ __device__ __forceinline__ void tuq_pass( const int *A, int aRowStride, int aCol
   }
 }
 
+// The same product when every A value fits 16 bits (residuals; dequantised coefficients and the first inverse pass are clipped to
+// 16 bits): v_dot2c_i32_i16 takes two summation steps per instruction.  A: int16, the summation index contiguous (rows of
+// aRowStride samples, even); Bp: the matrix with rows n, n + 1 interleaved per column -- Bp[(n >> 1) * cols + c] = (B[n][c], B[n+1][c]).
+template<int LPT, bool CLIP, class OutT>
+__device__ __forceinline__ void tuq_pass16( const int16_t *A, int aRowStride, const unsigned *Bp, int inner, int rows, int cols, int rEff, int cEff, OutT *out,
+                                            int oRowStride, int oColStride, int shift, int t )
+{
+  typedef short v2s __attribute__( ( ext_vector_type( 2 ) ) );
+  const int cb = cols >> 3, rnd = shift > 0 ? 1 << ( shift - 1 ) : 0;
+  for( int it = t; it < rows * cb; it += LPT )
+  {
+    const int r = it / cb, c0 = ( it - r * cb ) << 3;
+    int       acc[8];
+#pragma unroll
+    for( int i = 0; i < 8; i++ ) acc[i] = rnd;
+    if( r < rEff && c0 < cEff )
+    {
+      const unsigned *a = reinterpret_cast<const unsigned *>( A + r * aRowStride );
+      for( int n2 = 0; n2 < ( inner >> 1 ); n2++ )
+      {
+        const unsigned av = a[n2];
+        const uint4    b0 = *reinterpret_cast<const uint4 *>( Bp + n2 * cols + c0 ), b1 = *reinterpret_cast<const uint4 *>( Bp + n2 * cols + c0 + 4 );
+        const unsigned bw[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+        v2s va;
+        __builtin_memcpy( &va, &av, 4 );
+#pragma unroll
+        for( int i = 0; i < 8; i++ )
+        {
+          v2s vb;
+          __builtin_memcpy( &vb, &bw[i], 4 );
+          acc[i] = __builtin_amdgcn_sdot2( va, vb, acc[i], false );
+        }
+      }
+    }
+#pragma unroll
+    for( int i = 0; i < 8; i++ )
+    {
+      int v = ( r < rEff && c0 + i < cEff ) ? acc[i] >> shift : 0;
+      if( CLIP ) v = min( 32767, max( -32768, v ) );
+      out[r * oRowStride + ( c0 + i ) * oColStride] = ( OutT ) v;
+    }
+  }
+}
+
 template<int LPT>
 __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__restrict__ resiBase, const vtmhip_tu_job *__restrict__ jobs, int numJobs,
                                                              TrTables tabs, int *__restrict__ levelsBase, int16_t *__restrict__ recBase,
@@ -574,19 +618,21 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
   for( int ty = 0; ty < 3; ty++ )
   {
     const int16_t *mw = tabs.m[ty][lw], *mh = tabs.m[ty][lh];
+    // width:  slot 0 = M_W with rows k, k+1 interleaved (second inverse pass), slot 1 = M_W^T with rows n, n+1 interleaved (first forward pass)
+    // height: slot 0 = M_H with rows k, k+1 interleaved (first inverse pass),   slot 1 = M_H^T plain (second forward pass: 32-bit input)
     if( mw )
       for( int i = threadIdx.x; i < w * w; i += 256 )
       {
         const int k = i / w, n = i - k * w;
-        sMat[( ty * 2 + 0 ) * w * w + i]         = mw[i];
-        sMat[( ty * 2 + 1 ) * w * w + n * w + k] = mw[i];
+        sMat[( ty * 2 + 0 ) * w * w + ( ( k >> 1 ) * w + n ) * 2 + ( k & 1 )] = mw[i];   // (M[k][n], M[k+1][n]) at pair-row k >> 1, column n
+        sMat[( ty * 2 + 1 ) * w * w + ( ( n >> 1 ) * w + k ) * 2 + ( n & 1 )] = mw[i];   // (M[k][n], M[k][n+1]) at pair-row n >> 1, column k
       }
     if( mh )
       for( int i = threadIdx.x; i < h * h; i += 256 )
       {
         const int k = i / h, n = i - k * h;
-        sMat[6 * w * w + ( ty * 2 + 0 ) * h * h + i]         = mh[i];
-        sMat[6 * w * w + ( ty * 2 + 1 ) * h * h + n * h + k] = mh[i];
+        sMat[6 * w * w + ( ty * 2 + 0 ) * h * h + ( ( k >> 1 ) * h + n ) * 2 + ( k & 1 )] = mh[i];
+        sMat[6 * w * w + ( ty * 2 + 1 ) * h * h + n * h + k]                              = mh[i];
       }
   }
   __syncthreads();
@@ -603,15 +649,16 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
   for( int i = t; i < w * h; i += LPT )
   {
     const int y = i / w, x = i - y * w;
-    const int16_t v = resi[( long ) y * j.resiStride + x];
-    blk[i] = v;
-    sR[i]  = v;
+    sR[i] = resi[( long ) y * j.resiStride + x];
   }
+  int16_t *dq16 = reinterpret_cast<int16_t *>( tmp );   // dequantised coefficients [k][k2] (after the second forward pass has consumed tmp)
+  int16_t *t16  = reinterpret_cast<int16_t *>( blk );   // first inverse pass output [y][i] (after quantisation has consumed blk)
+  int     *rec32 = tmp;                                  // reconstructed residual [y][x]
   const int skipW = tr_skip( j.typeHor, w ), skipH = tr_skip( j.typeVer, h );
   long long sumAbs = 0, absSum = 0, sse = 0;
   tuq_sync<LPT>();
   // forward (TrQuant::xT): tmp[k][y] = sum_n blk[y][n] * MT_hor[n][k];  blk[k2][j2] = sum_n tmp[j2][n] * MT_ver[n][k2]
-  tuq_pass<LPT, false>( blk, w, 1, mW + w * w, w, w, h, w, h, w - skipW, tmp, 1, h + 1, lw + bd + 6 - 15, t, nullptr );
+  tuq_pass16<LPT, false>( sR, w, reinterpret_cast<const unsigned *>( mW + w * w ), w, h, w, h, w - skipW, tmp, 1, h + 1, lw + bd + 6 - 15, t );
   tuq_sync<LPT>();
   tuq_pass<LPT, false>( tmp, h + 1, 1, mH + h * h, h, h, w, h, w - skipW, h - skipH, blk, 1, w, lh + 6, t, &sumAbs );
   tuq_sync<LPT>();
@@ -638,20 +685,20 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
       int       v;
       if( rightShift > 0 ) v = ( int ) ( ( unsigned ) ( qq * iscale ) + ( 1u << ( rightShift - 1 ) ) ) >> rightShift;
       else v = ( int ) ( ( unsigned ) ( qq * iscale ) << ( -rightShift ) );
-      blk[i] = min( 32767, max( -32768, v ) );
+      dq16[( i % w ) * h + i / w] = ( int16_t ) min( 32767, max( -32768, v ) );   // transposed: the vertical index contiguous
     }
   }
   tuq_sync<LPT>();
   // inverse (TrQuant::xIT): tmp[i][y] = clip( sum_k blk[k][i] * M_ver[k][y] );  rec[y][x] = clip( sum_k tmp[k][y] * M_hor[k][x] )
-  tuq_pass<LPT, true>( blk, 1, w, mH, h, h - skipH, w, h, w - skipW, h, tmp, h, 1, 7, t, nullptr );
+  tuq_pass16<LPT, true>( dq16, h, reinterpret_cast<const unsigned *>( mH ), h - skipH, w, h, w - skipW, h, t16, 1, w, 7, t );
   tuq_sync<LPT>();
-  tuq_pass<LPT, true>( tmp, 1, h, mW, w, w - skipW, h, w, h, w, blk, w, 1, 20 - bd, t, nullptr );
+  tuq_pass16<LPT, true>( t16, w, reinterpret_cast<const unsigned *>( mW ), w - skipW, h, w, h, w, rec32, w, 1, 20 - bd, t );
   tuq_sync<LPT>();
   {
     int16_t *rec = ( recBase && live ) ? recBase + j.outOff : nullptr;
     for( int i = t; i < w * h; i += LPT )
     {
-      const int v = blk[i];
+      const int v = rec32[i];
       if( rec ) rec[i] = ( int16_t ) v;
       const int d = ( int ) sR[i] - v;
       sse += ( long long ) ( unsigned long long ) ( ( unsigned ) d * ( unsigned ) d );
