@@ -528,34 +528,36 @@ template<int LPT, bool CLIP>
 __device__ __forceinline__ void tuq_pass( const int *A, int aRowStride, int aColStride, const int16_t *B, int ldb, int inner, int rows, int cols,
                                           int rEff, int cEff, int *out, int oRowStride, int oColStride, int shift, int t, long long *sumAbs )
 {
+  // one lane: a 2 x 8 block of outputs (rows r, r + 1): the 16-byte matrix read of a summation step feeds 16 multiply-adds
   const int cb = cols >> 3, rnd = shift > 0 ? 1 << ( shift - 1 ) : 0;
-  for( int it = t; it < rows * cb; it += LPT )
+  for( int it = t; it < ( rows >> 1 ) * cb; it += LPT )
   {
-    const int r = it / cb, c0 = ( it - r * cb ) << 3;
-    int       acc[8];
+    const int r = ( it / cb ) << 1, c0 = ( it - ( it / cb ) * cb ) << 3;
+    int       acc[2][8];
 #pragma unroll
-    for( int i = 0; i < 8; i++ ) acc[i] = rnd;
+    for( int i = 0; i < 8; i++ ) acc[0][i] = acc[1][i] = rnd;
     if( r < rEff && c0 < cEff )
     {
-      const int *a = A + r * aRowStride;
+      const int *a0 = A + r * aRowStride, *a1 = a0 + aRowStride;
       for( int n = 0; n < inner; n++ )
       {
-        const int  av = a[n * aColStride];
+        const int  av0 = a0[n * aColStride], av1 = a1[n * aColStride];
         const int4 bv = *reinterpret_cast<const int4 *>( B + n * ldb + c0 );
-        acc[0] += __mul24( av, ( int ) ( short ) bv.x ); acc[1] += __mul24( av, bv.x >> 16 );
-        acc[2] += __mul24( av, ( int ) ( short ) bv.y ); acc[3] += __mul24( av, bv.y >> 16 );
-        acc[4] += __mul24( av, ( int ) ( short ) bv.z ); acc[5] += __mul24( av, bv.z >> 16 );
-        acc[6] += __mul24( av, ( int ) ( short ) bv.w ); acc[7] += __mul24( av, bv.w >> 16 );
+        const int  b[8] = { ( int ) ( short ) bv.x, bv.x >> 16, ( int ) ( short ) bv.y, bv.y >> 16, ( int ) ( short ) bv.z, bv.z >> 16, ( int ) ( short ) bv.w, bv.w >> 16 };
+#pragma unroll
+        for( int i = 0; i < 8; i++ ) { acc[0][i] += __mul24( av0, b[i] ); acc[1][i] += __mul24( av1, b[i] ); }
       }
     }
 #pragma unroll
-    for( int i = 0; i < 8; i++ )
-    {
-      int v = ( r < rEff && c0 + i < cEff ) ? acc[i] >> shift : 0;
-      if( CLIP ) v = min( 32767, max( -32768, v ) );
-      out[r * oRowStride + ( c0 + i ) * oColStride] = v;
-      if( sumAbs ) *sumAbs += abs( v );
-    }
+    for( int q = 0; q < 2; q++ )
+#pragma unroll
+      for( int i = 0; i < 8; i++ )
+      {
+        int v = ( r + q < rEff && c0 + i < cEff ) ? acc[q][i] >> shift : 0;
+        if( CLIP ) v = min( 32767, max( -32768, v ) );
+        out[( r + q ) * oRowStride + ( c0 + i ) * oColStride] = v;
+        if( sumAbs ) *sumAbs += abs( v );
+      }
   }
 }
 
@@ -568,38 +570,42 @@ __device__ __forceinline__ void tuq_pass16( const int16_t *A, int aRowStride, co
 {
   typedef short v2s __attribute__( ( ext_vector_type( 2 ) ) );
   const int cb = cols >> 3, rnd = shift > 0 ? 1 << ( shift - 1 ) : 0;
-  for( int it = t; it < rows * cb; it += LPT )
+  for( int it = t; it < ( rows >> 1 ) * cb; it += LPT )   // a 2 x 8 block of outputs per lane
   {
-    const int r = it / cb, c0 = ( it - r * cb ) << 3;
-    int       acc[8];
+    const int r = ( it / cb ) << 1, c0 = ( it - ( it / cb ) * cb ) << 3;
+    int       acc[2][8];
 #pragma unroll
-    for( int i = 0; i < 8; i++ ) acc[i] = rnd;
+    for( int i = 0; i < 8; i++ ) acc[0][i] = acc[1][i] = rnd;
     if( r < rEff && c0 < cEff )
     {
-      const unsigned *a = reinterpret_cast<const unsigned *>( A + r * aRowStride );
+      const unsigned *a0 = reinterpret_cast<const unsigned *>( A + r * aRowStride ), *a1 = reinterpret_cast<const unsigned *>( A + ( r + 1 ) * aRowStride );
       for( int n2 = 0; n2 < ( inner >> 1 ); n2++ )
       {
-        const unsigned av = a[n2];
+        const unsigned av0 = a0[n2], av1 = a1[n2];
         const uint4    b0 = *reinterpret_cast<const uint4 *>( Bp + n2 * cols + c0 ), b1 = *reinterpret_cast<const uint4 *>( Bp + n2 * cols + c0 + 4 );
         const unsigned bw[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
-        v2s va;
-        __builtin_memcpy( &va, &av, 4 );
+        v2s va0, va1;
+        __builtin_memcpy( &va0, &av0, 4 );
+        __builtin_memcpy( &va1, &av1, 4 );
 #pragma unroll
         for( int i = 0; i < 8; i++ )
         {
           v2s vb;
           __builtin_memcpy( &vb, &bw[i], 4 );
-          acc[i] = __builtin_amdgcn_sdot2( va, vb, acc[i], false );
+          acc[0][i] = __builtin_amdgcn_sdot2( va0, vb, acc[0][i], false );
+          acc[1][i] = __builtin_amdgcn_sdot2( va1, vb, acc[1][i], false );
         }
       }
     }
 #pragma unroll
-    for( int i = 0; i < 8; i++ )
-    {
-      int v = ( r < rEff && c0 + i < cEff ) ? acc[i] >> shift : 0;
-      if( CLIP ) v = min( 32767, max( -32768, v ) );
-      out[r * oRowStride + ( c0 + i ) * oColStride] = ( OutT ) v;
-    }
+    for( int q = 0; q < 2; q++ )
+#pragma unroll
+      for( int i = 0; i < 8; i++ )
+      {
+        int v = ( r + q < rEff && c0 + i < cEff ) ? acc[q][i] >> shift : 0;
+        if( CLIP ) v = min( 32767, max( -32768, v ) );
+        out[( r + q ) * oRowStride + ( c0 + i ) * oColStride] = ( OutT ) v;
+      }
   }
 }
 
@@ -883,8 +889,9 @@ int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const
   if( uniformSize && maxWidth >= 8 && maxHeight >= 8 )
   {
     // caller's promise: every TU is exactly maxWidth x maxHeight -> register-blocked kernel, LPT lanes per TU
-    const int      items = maxWidth * maxHeight / 8;
+    const int      items = maxWidth * maxHeight / 16;   // one lane = 2 x 8 outputs of a transform pass
     const TrTables &tb   = g_tabs[ctx->device & 15];
+    if( items <= 4 ) return launch_tu_uni<4>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
     if( items <= 8 ) return launch_tu_uni<8>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
     if( items <= 16 ) return launch_tu_uni<16>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
     if( items <= 32 ) return launch_tu_uni<32>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
