@@ -413,16 +413,27 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
 #pragma unroll
         for( int m = 0; m < 7; m++ ) d[m] = __builtin_amdgcn_alignbit( d[m + 1], d[m], sh );
         d[7] = d[7] >> sh;
-        int v[16];
+        // 8 outputs with v_dot2c_i32_i16: d[m] = (v[2m], v[2m+1]) serves the even outputs, e[m] = (v[2m+1], v[2m+2]) the odd ones
+        typedef short v2s __attribute__( ( ext_vector_type( 2 ) ) );
+        unsigned e[7];
 #pragma unroll
-        for( int m = 0; m < 8; m++ ) { v[2 * m] = ( int ) ( short ) d[m]; v[2 * m + 1] = ( int ) d[m] >> 16; }
+        for( int m = 0; m < 7; m++ ) e[m] = __builtin_amdgcn_alignbit( d[m + 1], d[m], 16 );
+        v2s cpk[4];
+#pragma unroll
+        for( int m = 0; m < 4; m++ ) { cpk[m].x = ( short ) ch[2 * m]; cpk[m].y = ( short ) ch[2 * m + 1]; }
         unsigned outw[4];
 #pragma unroll
         for( int q = 0; q < 8; q++ )
         {
           int sum = 0;
 #pragma unroll
-          for( int k = 0; k < 8; k++ ) sum += v[q + k] * ch[k];
+          for( int m = 0; m < 4; m++ )
+          {
+            const unsigned pw = ( q & 1 ) ? e[( q >> 1 ) + m] : d[( q >> 1 ) + m];
+            v2s pv;
+            __builtin_memcpy( &pv, &pw, 4 );
+            sum = __builtin_amdgcn_sdot2( pv, cpk[m], sum, false );
+          }
           const unsigned hv = ( unsigned ) ( unsigned short ) if_finish( sum, pH );
           if( q & 1 ) outw[q >> 1] |= hv << 16; else outw[q >> 1] = hv;
         }
