@@ -3,7 +3,7 @@ set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc_insts
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d gpurun_out/pmc_insts -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-graph > gpurun_out/pmc_insts/stdout.json 2> gpurun_out/pmc_insts/stderr.txt || (tail -20 gpurun_out/pmc_insts/stderr.txt; exit 1)
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d gpurun_out/pmc_insts -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_insts/stdout.json 2> gpurun_out/pmc_insts/stderr.txt || (tail -20 gpurun_out/pmc_insts/stderr.txt; exit 1)
 python3 - <<'PY'
 import csv, collections, re
 acc = collections.OrderedDict()
