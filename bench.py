@@ -166,27 +166,21 @@ def main():
     # not a collective dtype).  Double-buffered: the planes of step k + 1 travel on RCCL's stream while step k computes on the planes that
     # arrived before (the asynchronous collective starts after the launches already queued on the compute stream, i.e. after the step that
     # last read its target buffer); a step's compute waits -- on the stream -- for its own planes.
-    dpbs = [dpb, dpb.clone()] if use_dist else [dpb]
-    state = {"n": 0, "pending": None}
+    from vtm_amd.exchange import PlaneExchange
+    xchg = PlaneExchange([dpb, dpb.clone()], src=0) if use_dist else None
 
     def step(k=None):
-        if use_dist:
-            i = state["n"] & 1
-            if state["pending"] is None:
-                state["pending"] = dist.broadcast(dpbs[i].view(torch.uint8), src=0, async_op=True)
-            state["pending"].wait()
-            state["pending"] = dist.broadcast(dpbs[1 - i].view(torch.uint8), src=0, async_op=True)
-            state["n"] += 1
-            fme.run(cur.data_ptr(), dpbs[i].data_ptr())
+        if xchg is not None:
+            planes = xchg.next()
+            fme.run(cur.data_ptr(), planes.data_ptr())
         elif graph is not None:
             graph.replay()
         else:
             fme.run(cur.data_ptr(), dpb.data_ptr())
 
     def drain():
-        if use_dist and state["pending"] is not None:
-            state["pending"].wait()
-            state["pending"] = None
+        if xchg is not None:
+            xchg.drain()
 
     for _ in range(a.warmup):
         step()

@@ -1,0 +1,36 @@
+"""Worker of tests/test_host_logic.py::test_two_rank_plane_exchange (torch.distributed.run, gloo, CPU): the double-buffered reference-plane
+broadcast of bench.py --gpus N.  Rank 0 'reconstructs' a new picture before every transfer; every rank must see picture k in step k."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vtm_amd.exchange import PlaneExchange   # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    bufs = [torch.full((70001,), -1, dtype=torch.int16), torch.full((70001,), -1, dtype=torch.int16)]
+    sent = []
+    x = PlaneExchange(bufs, src=0, produce=lambda b, k: (b.fill_(100 + k), sent.append(k)))
+    seen = []
+    for k in range(7):
+        planes = x.next()
+        assert planes.data_ptr() == bufs[k & 1].data_ptr()
+        assert bool((planes == 100 + k).all()), (rank, k, int(planes[0]))   # picture k, complete, in step k
+        seen.append(int(planes[12345]))
+    x.drain()
+    assert seen == [100 + k for k in range(7)]
+    if rank == 0:
+        assert sent == list(range(8))   # one transfer ahead
+    dist.barrier()
+    if rank == 0:
+        print("EXCHANGE_OK")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,3 +65,13 @@ def test_two_rank_gloo_sharding():
                           "--master-port", "29517", script], capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "GLOO_OK" in out.stdout
+
+
+def test_two_rank_plane_exchange():
+    """world_size 2 on CPU/gloo: the double-buffered asynchronous reference-plane broadcast bench.py uses for N > 1 (vtm_amd/exchange.py):
+    every rank computes step k on picture k while picture k + 1 is already travelling."""
+    script = os.path.join(ROOT, "tests", "gloo_exchange_worker.py")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29519", script], capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "EXCHANGE_OK" in out.stdout
