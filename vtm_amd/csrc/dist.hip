@@ -16,11 +16,11 @@ namespace
 {
 
 // ---- Hadamard building blocks (32-bit, order-free: only sum|coef| and coef[0] matter) ----------
-template<int N, int STRIDE>
-__device__ __forceinline__ void wht1d( int *m )
+template<int N, int STRIDE, bool LAST = true>
+__device__ __forceinline__ void wht1d( int *m )   // LAST = false: every butterfly level but the last (len = N / 2)
 {
 #pragma unroll
-  for( int len = 1; len < N; len <<= 1 )
+  for( int len = 1; len < ( LAST ? N : N / 2 ); len <<= 1 )
   {
 #pragma unroll
     for( int i = 0; i < N; i += len << 1 )
@@ -44,11 +44,13 @@ __device__ __forceinline__ unsigned had_finish( int *m )
 #pragma unroll
   for( int y = 0; y < TH; y++ ) wht1d<TW, 1>( m + y * TW );
 #pragma unroll
-  for( int x = 0; x < TW; x++ ) wht1d<TH, TW>( m + x );
+  for( int x = 0; x < TW; x++ ) wht1d<TH, TW, false>( m + x );
+  // last butterfly level + |.| + sum in one: |a + b| + |a - b| = 2 max(|a|, |b|) for the pair (row j, row j + TH/2) of a column
   int t = 0;
 #pragma unroll
-  for( int i = 0; i < TW * TH; i++ ) t += abs( m[i] );
-  const int dc = abs( m[0] );
+  for( int i = 0; i < TW * TH / 2; i++ ) t += max( abs( m[i] ), abs( m[i + TW * TH / 2] ) );
+  t <<= 1;
+  const int dc = abs( m[0] + m[TW * TH / 2] );
   t            = t - dc + ( dc >> 2 );
   if( TW == 2 && TH == 2 ) return ( unsigned ) t;
   if( TW == 4 && TH == 4 ) return ( unsigned ) ( ( t + 1 ) >> 1 );

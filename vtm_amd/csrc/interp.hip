@@ -108,11 +108,11 @@ __global__ __launch_bounds__( 256 ) void if_batch_kernel( const int16_t *__restr
 }
 
 // ---- Hadamard tiles on LDS / global operands (same arithmetic as dist.hip) ---------------------------------------------
-template<int N, int STRIDE>
-__device__ __forceinline__ void wht1d( int *m )
+template<int N, int STRIDE, bool LAST = true>
+__device__ __forceinline__ void wht1d( int *m )   // LAST = false: every butterfly level but the last (len = N / 2)
 {
 #pragma unroll
-  for( int len = 1; len < N; len <<= 1 )
+  for( int len = 1; len < ( LAST ? N : N / 2 ); len <<= 1 )
   {
 #pragma unroll
     for( int i = 0; i < N; i += len << 1 )
@@ -141,11 +141,13 @@ __device__ __forceinline__ unsigned had_tile( const int16_t *o, int os, const in
 #pragma unroll
   for( int y = 0; y < TH; y++ ) wht1d<TW, 1>( m + y * TW );
 #pragma unroll
-  for( int x = 0; x < TW; x++ ) wht1d<TH, TW>( m + x );
+  for( int x = 0; x < TW; x++ ) wht1d<TH, TW, false>( m + x );
+  // last butterfly level + |.| + sum in one: |a + b| + |a - b| = 2 max(|a|, |b|) for the pair (row j, row j + TH/2) of a column
   int t = 0;
 #pragma unroll
-  for( int i = 0; i < TW * TH; i++ ) t += abs( m[i] );
-  const int dc = abs( m[0] );
+  for( int i = 0; i < TW * TH / 2; i++ ) t += max( abs( m[i] ), abs( m[i + TW * TH / 2] ) );
+  t <<= 1;
+  const int dc = abs( m[0] + m[TW * TH / 2] );
   t            = t - dc + ( dc >> 2 );
   if( TW == 2 && TH == 2 ) return ( unsigned ) t;
   if( TW == 4 && TH == 4 ) return ( unsigned ) ( ( t + 1 ) >> 1 );
@@ -519,11 +521,12 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
 #pragma unroll
         for( int y = 0; y < 8; y++ ) wht1d<8, 1>( acc + y * 8 );
 #pragma unroll
-        for( int x = 0; x < 8; x++ ) wht1d<8, 8>( acc + x );
-        int t = 0;
+        for( int x = 0; x < 8; x++ ) wht1d<8, 8, false>( acc + x );
+        int t = 0;   // last level + |.| + sum: |a + b| + |a - b| = 2 max(|a|, |b|)
 #pragma unroll
-        for( int i = 0; i < 64; i++ ) t += abs( acc[i] );
-        const int dc = abs( acc[0] );
+        for( int i = 0; i < 32; i++ ) t += max( abs( acc[i] ), abs( acc[i + 32] ) );
+        t <<= 1;
+        const int dc = abs( acc[0] + acc[32] );
         d            = ( unsigned ) ( ( t - dc + ( dc >> 2 ) + 2 ) >> 2 );
       }
       else
