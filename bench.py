@@ -18,7 +18,6 @@ Prints ONE JSON line (rank 0).  `value` = pictures/s of the stages listed in con
 Extra keys: satd_gblocks_per_s (SURVEY.md 8d SATD-8x8 grid micro-benchmark, 81 displacements), roofline, cpu_baseline.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys

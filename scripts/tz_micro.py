@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """TZ search micro-benchmark on HARD jobs (random start vectors / predictors on the noisy clip: the star refinement and the raster
 scan run often, unlike the well-predicted searches of bench.py).  usage (GPU box): python3 scripts/tz_micro.py"""
-import ctypes as C
 import os
 import sys
 import time
