@@ -149,6 +149,12 @@ typedef struct
 int vtmhip_masked_sad_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_curBase, const int16_t *d_maskBase,
                                  const vtmhip_masked_sad_job *d_jobs, int n, uint64_t *d_dist );
 
+/* The same distortions for a batch the caller promises to be uniform: EVERY job is width x height of one `kind` (and subShift for SAD); the jobs'
+ * own width / height / kind / subShift fields are ignored.  Small blocks then share a wave (an 8x8 SATD is one Hadamard tile = one lane): the form
+ * hooks B7 / B10 use for the merge / AMVP candidates of one CU size. */
+int vtmhip_dist_uniform_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_curBase, const vtmhip_dist_job *d_jobs, int n,
+                                   int kind, int width, int height, int subShift, uint64_t *d_dist );
+
 /* SATD 8x8 block-grid micro-benchmark: every 8-aligned 8x8 block of the W x H org picture against the
  * reference picture displaced by (dx,dy) in [-r,r]^2.  d_ref must carry >= r samples of valid margin on every side.
  * d_dist[(by*(W/8)+bx)*(2r+1)^2 + (dy+r)*(2r+1) + (dx+r)], 32-bit (an 8x8 SATD of int16 samples fits). */

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks of SURVEY.md section 8d on one MI355X (inputs resident in HBM, HIP-event timing on the context's stream):
+
+  SATD-8x8   every 8-aligned 8x8 block of frame t x 81 displacements against frame t-1                 (vtmhip_satd8_grid_dev)
+  SAD/SATD-PU PU sizes {8x8 .. 128x128, 16x8, 8x16, 32x8, 64x16}, candidate positions of a +-8 neighbourhood (vtmhip_dist_uniform_batch_dev)
+  IF         half + quarter sample planes (one H pass first/!last, one V pass !first/last) of all 16x16 blocks (vtmhip_if_batch_dev)
+  TR         forward 2-D transform of 4096 random residual blocks per (type, W, H), and the fused xT/quant/dequant/xIT/SSE chain
+             for the square sizes                                                                       (vtmhip_xT_batch_dev, vtmhip_tu_chain_batch_dev)
+
+Prints one JSON object per line: algorithmic bytes (SURVEY.md 8d per-unit figures) / time against the 8 TB/s HBM peak.
+usage (GPU box): python3 scripts/microbench.py [--width 3840 --height 2160] > gpurun_out/microbench.json"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from vtm_amd import synth   # noqa: E402
+from vtm_amd.device import Context   # noqa: E402
+from vtm_amd.lib import DistJob, IfJob, TrJob, TuJob   # noqa: E402
+
+PEAK = 8000.0   # GB/s
+
+
+def timed(ctx, fn, reps=10):
+    for _ in range(2):
+        fn()
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(reps):
+        fn()
+    return ctx.timer_stop_ms() / reps
+
+
+def emit(name, units, unit_name, alg_bytes, ms, **kw):
+    print(json.dumps(dict(kernel=name, units=units, unit=unit_name, ms=round(ms, 4), G_units_per_s=round(units / ms / 1e6, 3),
+                          alg_GBps=round(alg_bytes / ms / 1e6, 1), frac_of_hbm_peak=round(alg_bytes / ms / 1e6 / PEAK, 3), **kw)), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    a = ap.parse_args()
+    W, H = a.width, a.height
+    ctx = Context(0)
+    fr = synth.gen_frames(W, H, 2)
+    cur = np.ascontiguousarray(fr[1])
+    ref, roff, rs = synth.extend_plane(fr[0], margin=160)
+    d_cur, d_ref = ctx.to_device(cur), ctx.to_device(ref)
+    rng = np.random.default_rng(2)
+
+    # ---- SATD 8x8 grid -------------------------------------------------------------------------------------------------------
+    nb = (W // 8) * (H // 8)
+    d_out = ctx.alloc(4 * nb * 81)
+    ms = timed(ctx, lambda: ctx.satd8_grid(d_cur.ptr, W, d_ref.ptr + 2 * roff, rs, W, H, 4, d_out.ptr))
+    emit("satd8_grid", nb * 81, "8x8 block pairs", nb * 81 * 256, ms, picture="%dx%d" % (W, H))
+
+    # ---- SAD / SATD per PU size (uniform batches: several small blocks per wave) ----------------------------------------------------
+    for kind, kname in ((0, "sad_pu"), (1, "satd_pu")):
+        for (w, h) in ((8, 8), (16, 16), (32, 32), (64, 64), (128, 128), (16, 8), (8, 16), (32, 8), (64, 16)):
+            ss = 1 if (kind == 0 and h > 8 and w <= 64) else 0            # FEN sub-sampling rule of the integer search (RdCost.cpp:289-323, mode 2)
+            npu = min(20000, (W // w) * (H // h))
+            per = 32                                                       # candidates per PU
+            n = npu * per
+            jobs = np.zeros(n, np.dtype(DistJob))
+            px = rng.integers(0, W // w, npu) * w
+            py = rng.integers(0, H // h, npu) * h
+            dx, dy = rng.integers(-8, 9, n), rng.integers(-8, 9, n)
+            jobs["orgOff"] = np.repeat(py * W + px, per)
+            jobs["curOff"] = roff + (np.repeat(py, per) + dy) * rs + np.repeat(px, per) + dx
+            jobs["orgStride"], jobs["curStride"], jobs["width"], jobs["height"], jobs["subShift"], jobs["kind"] = W, rs, w, h, ss, kind
+            d_jobs, d_res = ctx.to_device(jobs.view(np.uint8)), ctx.alloc(8 * n)
+            ms = timed(ctx, lambda: ctx.dist_uniform_batch(d_cur.ptr, d_ref.ptr, d_jobs.ptr, n, kind, w, h, ss, d_res.ptr), reps=5)
+            emit(kname, n, "candidates", n * (4 * w * h >> ss), ms, size="%dx%d" % (w, h), subShift=ss)
+
+    # ---- interpolation planes of all 16x16 blocks ----------------------------------------------------------------------------
+    bx, by = np.meshgrid(np.arange(W // 16) * 16, np.arange(H // 16) * 16)
+    bx, by = bx.reshape(-1), by.reshape(-1)
+    nblk = bx.size
+    taps_h = np.array([-1, 4, -11, 40, 40, -11, 4, -1], np.int16)   # half-sample luma filter
+    taps_q = np.array([-1, 4, -10, 58, 17, -5, 1, 0], np.int16)     # quarter-sample luma filter
+    for name, taps in (("if_half", taps_h), ("if_quarter", taps_q)):
+        jh = np.zeros(nblk, np.dtype(IfJob))
+        jh["srcOff"] = roff + (by - 3) * rs + bx
+        jh["dstOff"] = np.arange(nblk) * 16 * 23
+        jh["srcStride"], jh["dstStride"], jh["width"], jh["height"] = rs, 16, 16, 23
+        jh["vertical"], jh["taps"], jh["isFirst"], jh["isLast"], jh["coeff"], jh["clipMax"], jh["bitDepth"] = 0, 8, 1, 0, taps, 1023, 10
+        jv = np.zeros(nblk, np.dtype(IfJob))
+        jv["srcOff"] = np.arange(nblk) * 16 * 23 + 3 * 16
+        jv["dstOff"] = np.arange(nblk) * 256
+        jv["srcStride"], jv["dstStride"], jv["width"], jv["height"] = 16, 16, 16, 16
+        jv["vertical"], jv["taps"], jv["isFirst"], jv["isLast"], jv["coeff"], jv["clipMax"], jv["bitDepth"] = 1, 8, 0, 1, taps, 1023, 10
+        d_tmp, d_pl = ctx.alloc(2 * nblk * 16 * 23), ctx.alloc(2 * nblk * 256)
+        d_jh, d_jv = ctx.to_device(jh.view(np.uint8)), ctx.to_device(jv.view(np.uint8))
+
+        def both():
+            ctx.if_batch(d_ref.ptr, d_tmp.ptr, d_jh.ptr, nblk)
+            ctx.if_batch(d_tmp.ptr, d_pl.ptr, d_jv.ptr, nblk)
+        ms = timed(ctx, both, reps=5)
+        samples = nblk * (16 * 23 + 256)
+        emit(name, samples, "output samples", 4 * samples, ms, blocks=nblk)
+
+    # ---- transforms ----------------------------------------------------------------------------------------------------------
+    nblk = 4096 * 16    # SURVEY.md 8d asks for 4096 blocks per combination; 16 such sets per launch take it out of the launch-latency regime
+    for ty, tname in ((0, "DCT2"), (2, "DST7"), (1, "DCT8")):
+        for (w, h) in ((4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (16, 4), (32, 8), (8, 32), (64, 16)):
+            if ty != 0 and max(w, h) > 32:
+                continue
+            resi = rng.integers(-512, 512, (nblk, h, w)).astype(np.int16)
+            jt = np.zeros(nblk, np.dtype(TrJob))
+            jt["srcOff"] = jt["dstOff"] = np.arange(nblk) * w * h
+            jt["srcStride"], jt["dstStride"], jt["width"], jt["height"], jt["typeHor"], jt["typeVer"], jt["bitDepth"] = w, w, w, h, ty, ty, 10
+            d_resi, d_coef, d_jt = ctx.to_device(resi), ctx.alloc(4 * nblk * w * h), ctx.to_device(jt.view(np.uint8))
+            ms = timed(ctx, lambda: ctx.xT_batch(d_resi.ptr, d_coef.ptr, d_jt.ptr, nblk, w, h, None), reps=5)
+            emit("xT", nblk * w * h, "samples", 6 * nblk * w * h, ms, type=tname, size="%dx%d" % (w, h))
+    for s in (8, 16, 32, 64):
+        resi = rng.integers(-512, 512, (nblk, s, s)).astype(np.int16)
+        ju = np.zeros(nblk, np.dtype(TuJob))
+        ju["resiOff"] = ju["outOff"] = np.arange(nblk) * s * s
+        ju["resiStride"], ju["width"], ju["height"], ju["qpPer"], ju["qpRem"], ju["bitDepth"] = s, s, s, 7, 2, 10
+        d_resi, d_ju, d_r, d_lv = ctx.to_device(resi), ctx.to_device(ju.view(np.uint8)), ctx.alloc(16 * nblk), ctx.alloc(4 * nblk * s * s)
+        ms = timed(ctx, lambda: ctx.tu_chain_batch(d_resi.ptr, d_ju.ptr, nblk, s, s, d_r.ptr, d_lv.ptr, None, uniform=True), reps=5)
+        emit("tu_chain", nblk * s * s, "samples", 32 * nblk * s * s, ms, type="DCT2", size="%dx%d" % (s, s))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

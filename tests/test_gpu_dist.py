@@ -136,3 +136,33 @@ def test_masked_sad_pointer_surface_and_batch(ctx):
     d_out = ctx.alloc(8 * n)
     ctx.masked_sad_batch(d_org.ptr, d_cur.ptr, d_mask.ptr, d_jobs.ptr, n, d_out.ptr)
     assert list(d_out.to_host(np.uint64)) == exp
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_dist_uniform_batch_matches_oracle(ctx, kind):
+    """vtmhip_dist_uniform_batch_dev: one block size per launch, several jobs per wave; every size class incl. the fall-back for narrow widths,
+    signed (bi-pred target) samples, a job count that leaves the last wave partly empty."""
+    W, H = 416, 240
+    fr = synth.gen_frames_hard(W, H, 2)
+    rng = np.random.default_rng(33 + kind)
+    cur = np.ascontiguousarray((2 * fr[1].astype(np.int32) - rng.integers(0, 1024, fr[1].shape)).astype(np.int16))
+    ref, off, stride = synth.extend_plane(fr[0])
+    d_org, d_ref = ctx.to_device(cur), ctx.to_device(ref)
+    for (w, h) in ((8, 8), (16, 16), (32, 32), (64, 64), (128, 128), (16, 8), (8, 16), (32, 8), (8, 4), (4, 8), (4, 4), (64, 16), (24, 8), (12, 16)):
+        if kind == 1 and (w % 4 or h % 4):
+            continue
+        ss = 1 if (kind == 0 and h > 8 and w <= 64) else 0
+        n = 333
+        jobs = (DistJob * n)()
+        exp = []
+        for k in range(n):
+            x, y = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+            dx, dy = int(rng.integers(-20, 21)), int(rng.integers(-20, 21))
+            j = jobs[k]
+            j.orgOff, j.curOff, j.orgStride, j.curStride = y * W + x, off + (y + dy) * stride + x + dx, W, stride
+            j.width, j.height, j.subShift, j.kind = w, h, ss, kind
+            exp.append(ol.o_dist(kind, cur, ref.reshape(-1, stride), w, h, ss, org_off=j.orgOff, cur_off=j.curOff))
+        d_jobs = ctx.to_device(np.frombuffer(jobs, np.uint8))
+        d_out = ctx.alloc(8 * n)
+        ctx.dist_uniform_batch(d_org.ptr, d_ref.ptr, d_jobs.ptr, n, kind, w, h, ss, d_out.ptr)
+        assert list(d_out.to_host(np.uint64)) == exp, (kind, w, h)

@@ -228,6 +228,85 @@ __global__ __launch_bounds__( 256 ) void satd8_grid_kernel( const int16_t *__res
   }
 }
 
+// ---- uniform batch: every job is W x H of one kind -> several jobs per wave -----------------------------------------------------------
+// dist_batch_kernel gives a wave to every job, so an 8x8 SATD (one tile) keeps 1 lane of 64 busy and an 8x8 SAD 16.  When the
+// caller can promise one block size per launch (the merge / AMVP candidates of one CU size, hooks B7 / B10), LPJ = the power of two
+// >= the job's work items (8-sample row segments, Hadamard tiles) lanes form a job and 64 / LPJ jobs share a wave.
+struct __attribute__( ( packed, aligned( 2 ) ) ) DPel8 { unsigned v[4]; };
+
+__global__ __launch_bounds__( 256 ) void dist_uniform_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ curBase,
+                                                             const vtmhip_dist_job *__restrict__ jobs, int n, int kind, int w, int h, int ss, int lpjShift,
+                                                             unsigned long long *__restrict__ out )
+{
+  const int lpj = 1 << lpjShift, g = 64 >> lpjShift;
+  const int lane = threadIdx.x & 63, wave = blockIdx.x * ( blockDim.x >> 6 ) + ( threadIdx.x >> 6 );
+  const int job = wave * g + ( lane >> lpjShift ), sub = lane & ( lpj - 1 );
+  const bool live = job < n;
+  const vtmhip_dist_job j = jobs[live ? job : 0];
+  const int16_t *org = orgBase + j.orgOff, *cur = curBase + j.curOff;
+  const int os = j.orgStride, cs = j.curStride;
+  unsigned long long acc = 0;
+  if( kind == VTMHIP_DIST_SATD )
+  {
+    int tw, th;
+    if( w > h && ( h & 7 ) == 0 && ( w & 15 ) == 0 ) { tw = 16; th = 8; }
+    else if( w < h && ( w & 7 ) == 0 && ( h & 15 ) == 0 ) { tw = 8; th = 16; }
+    else if( w > h && ( h & 3 ) == 0 && ( w & 7 ) == 0 ) { tw = 8; th = 4; }
+    else if( w < h && ( w & 3 ) == 0 && ( h & 7 ) == 0 ) { tw = 4; th = 8; }
+    else if( ( h & 7 ) == 0 && ( w & 7 ) == 0 ) { tw = 8; th = 8; }
+    else if( ( h & 3 ) == 0 && ( w & 3 ) == 0 ) { tw = 4; th = 4; }
+    else { tw = 2; th = 2; }
+    const int tx = w / tw, ty = h / th;
+    for( int it = sub; live && it < tx * ty; it += lpj )
+    {
+      const int      y = ( it / tx ) * th, x = ( it % tx ) * tw;
+      const int16_t *o = org + ( long ) y * os + x;
+      const int16_t *c = cur + ( long ) y * cs + x;
+      unsigned       v;
+      if( tw == 16 ) v = had_tile<16, 8>( o, os, c, cs );
+      else if( th == 16 ) v = had_tile<8, 16>( o, os, c, cs );
+      else if( tw == 8 && th == 4 ) v = had_tile<8, 4>( o, os, c, cs );
+      else if( tw == 4 && th == 8 ) v = had_tile<4, 8>( o, os, c, cs );
+      else if( tw == 8 ) v = had_tile<8, 8>( o, os, c, cs );
+      else if( tw == 4 ) v = had_tile<4, 4>( o, os, c, cs );
+      else v = had_tile<2, 2>( o, os, c, cs );
+      acc += v;
+    }
+  }
+  else
+  {
+    // 8-sample segments (host side guarantees w % 8 == 0 for this kernel); rows stepped by 1 << ss for SAD
+    const int segs = w >> 3, rows = kind == VTMHIP_DIST_SAD ? h >> ss : h, rs = kind == VTMHIP_DIST_SAD ? ss : 0;
+    unsigned  s32 = 0;
+    for( int it = sub; live && it < rows * segs; it += lpj )
+    {
+      const int   r = it / segs, x = ( it - r * segs ) << 3;
+      const DPel8 a = *reinterpret_cast<const DPel8 *>( org + ( long ) ( r << rs ) * os + x );
+      const DPel8 b = *reinterpret_cast<const DPel8 *>( cur + ( long ) ( r << rs ) * cs + x );
+      if( kind == VTMHIP_DIST_SAD )
+      {
+#pragma unroll
+        for( int k = 0; k < 4; k++ ) s32 = __builtin_amdgcn_sad_u16( a.v[k] ^ 0x80008000u, b.v[k] ^ 0x80008000u, s32 );   // sign bias: any int16 pair
+      }
+      else
+      {
+#pragma unroll
+        for( int k = 0; k < 4; k++ )
+        {
+          const int d0 = ( int ) ( short ) ( a.v[k] & 0xffffu ) - ( int ) ( short ) ( b.v[k] & 0xffffu ), d1 = ( ( int ) a.v[k] >> 16 ) - ( ( int ) b.v[k] >> 16 );
+          acc += ( unsigned long long ) ( ( unsigned ) d0 * ( unsigned ) d0 );
+          acc += ( unsigned long long ) ( ( unsigned ) d1 * ( unsigned ) d1 );
+        }
+      }
+    }
+    if( kind == VTMHIP_DIST_SAD ) acc = ( unsigned long long ) s32 << ss;
+  }
+#pragma unroll
+  for( int o = 32; o > 0; o >>= 1 )
+    if( o < lpj ) acc += __shfl_xor( acc, o, 64 );
+  if( live && sub == 0 ) out[job] = acc;
+}
+
 // ---- masked SAD (GEO merge estimation): one wave per job ---------------------------------------------------------------------------
 __global__ __launch_bounds__( 256 ) void sad_mask_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ curBase, const int16_t *__restrict__ maskBase,
                                                          const vtmhip_masked_sad_job *__restrict__ jobs, int n, unsigned long long *__restrict__ out )
@@ -397,5 +476,42 @@ extern "C" int vtmhip_xGetSADwMask( vtmhip_ctx *ctx, const int16_t *org, int org
   VTMHIP_HIP( ctx, hipMemcpyAsync( hp + outOff, dp + outOff, 8, hipMemcpyDeviceToHost, ctx->stream ) );
   VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
   memcpy( dist, hp + outOff, 8 );
+  return VTMHIP_OK;
+}
+
+
+extern "C" int vtmhip_dist_uniform_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_curBase, const vtmhip_dist_job *d_jobs, int n,
+                                              int kind, int width, int height, int subShift, uint64_t *d_dist )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_orgBase && d_curBase && d_jobs && d_dist, "null pointer" );
+  int st = check_dist_args( ctx, width, height, subShift, kind );
+  if( st ) return st;
+  if( kind != VTMHIP_DIST_SATD && ( width & 7 ) != 0 )   // narrow / odd widths: the wave-per-job kernel (reads width / height / kind from the jobs)
+    return vtmhip_dist_batch_dev( ctx, d_orgBase, d_curBase, d_jobs, n, d_dist );
+  // work items of one job -> lanes per job
+  int items;
+  if( kind == VTMHIP_DIST_SATD )
+  {
+    const int w = width, h = height;
+    int tw, th;
+    if( w > h && ( h & 7 ) == 0 && ( w & 15 ) == 0 ) { tw = 16; th = 8; }
+    else if( w < h && ( w & 7 ) == 0 && ( h & 15 ) == 0 ) { tw = 8; th = 16; }
+    else if( w > h && ( h & 3 ) == 0 && ( w & 7 ) == 0 ) { tw = 8; th = 4; }
+    else if( w < h && ( w & 3 ) == 0 && ( h & 7 ) == 0 ) { tw = 4; th = 8; }
+    else if( ( h & 7 ) == 0 && ( w & 7 ) == 0 ) { tw = 8; th = 8; }
+    else if( ( h & 3 ) == 0 && ( w & 3 ) == 0 ) { tw = 4; th = 4; }
+    else { tw = 2; th = 2; }
+    items = ( w / tw ) * ( h / th );
+  }
+  else items = ( width >> 3 ) * ( kind == VTMHIP_DIST_SAD ? height >> subShift : height );
+  int lpjShift = 0;
+  while( ( 1 << lpjShift ) < items && lpjShift < 6 ) lpjShift++;
+  const int jobsPerWave = 64 >> lpjShift, waves = ( n + jobsPerWave - 1 ) / jobsPerWave;
+  hipLaunchKernelGGL( dist_uniform_kernel, dim3( ( waves + 3 ) / 4 ), dim3( 256 ), 0, ctx->stream, d_orgBase, d_curBase, d_jobs, n, kind, width, height, subShift, lpjShift,
+                      ( unsigned long long * ) d_dist );
+  VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

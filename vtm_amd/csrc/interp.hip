@@ -62,18 +62,27 @@ __device__ __forceinline__ int16_t if_finish( int sum, const IfParams &p )
   return v;
 }
 
-// ---- generic batched filter: one workgroup per job, one thread per output sample -------------------------------------
-__global__ __launch_bounds__( 256 ) void if_batch_kernel( const int16_t *__restrict__ srcBase, int16_t *__restrict__ dstBase,
-                                                         const vtmhip_if_job *__restrict__ jobs )
+// ---- generic batched filter: one WAVE per job (four jobs per workgroup); 8 outputs per lane with 16-byte loads / stores when the width is
+//      a multiple of 8, one output per lane otherwise ------------------------------------------------------------------------------------
+__device__ __forceinline__ void if_unpack8( const Pel8u &t, int a[8] )
 {
-  const vtmhip_if_job j   = jobs[blockIdx.x];
+#pragma unroll
+  for( int k = 0; k < 4; k++ ) { a[2 * k] = ( int ) ( short ) ( t.v[k] & 0xffffu ); a[2 * k + 1] = ( int ) t.v[k] >> 16; }
+}
+
+__global__ __launch_bounds__( 256 ) void if_batch_kernel( const int16_t *__restrict__ srcBase, int16_t *__restrict__ dstBase,
+                                                         const vtmhip_if_job *__restrict__ jobs, int n )
+{
+  const int lane = threadIdx.x & 63, job = blockIdx.x * 4 + ( threadIdx.x >> 6 );
+  if( job >= n ) return;
+  const vtmhip_if_job j   = jobs[job];
   const int16_t      *src = srcBase + j.srcOff;
   int16_t            *dst = dstBase + j.dstOff;
   const int           w = j.width, h = j.height, taps = j.taps;
   if( taps == 0 )   // filterCopy<isFirst,isLast> (:398-525)
   {
     const int headRoom = max( 2, 14 - ( int ) j.bitDepth );
-    for( int i = threadIdx.x; i < w * h; i += blockDim.x )
+    for( int i = lane; i < w * h; i += 64 )
     {
       const int y = i / w, x = i - y * w;
       const int s = src[( long ) y * j.srcStride + x];
@@ -96,8 +105,52 @@ __global__ __launch_bounds__( 256 ) void if_batch_kernel( const int16_t *__restr
   }
   const IfParams p       = if_params( j.isFirst, j.isLast, j.bitDepth, j.clipMin, j.clipMax, j.biMCForDMVR );
   const long     cStride = j.vertical ? j.srcStride : 1;
-  src -= ( taps / 2 - 1 ) * cStride;
-  for( int i = threadIdx.x; i < w * h; i += blockDim.x )
+  const int      halo    = taps / 2 - 1;
+  if( ( w & 7 ) == 0 )
+  {
+    int c[8];
+#pragma unroll
+    for( int k = 0; k < 8; k++ ) c[k] = k < taps ? ( int ) j.coeff[k] : 0;
+    const int segs = w >> 3;
+    for( int i = lane; i < segs * h; i += 64 )
+    {
+      const int y = i / segs, x0 = ( i - y * segs ) << 3;
+      int       sum[8];
+#pragma unroll
+      for( int k = 0; k < 8; k++ ) sum[k] = 0;
+      if( j.vertical )
+      {
+        for( int t = 0; t < taps; t++ )
+        {
+          int row[8];
+          if_unpack8( *reinterpret_cast<const Pel8u *>( src + ( long ) ( y + t - halo ) * j.srcStride + x0 ), row );
+#pragma unroll
+          for( int k = 0; k < 8; k++ ) sum[k] += row[k] * c[t];
+        }
+      }
+      else
+      {
+        int            a[16];
+        const int16_t *s0 = src + ( long ) y * j.srcStride + x0 - halo;
+        if_unpack8( *reinterpret_cast<const Pel8u *>( s0 ), a );
+        if_unpack8( *reinterpret_cast<const Pel8u *>( s0 + 8 ), a + 8 );
+#pragma unroll
+        for( int k = 0; k < 8; k++ )
+        {
+#pragma unroll
+          for( int t = 0; t < 8; t++ ) sum[k] += a[k + t] * c[t];   // taps < 8: the remaining coefficients are zero
+        }
+      }
+      Pel8u o;
+#pragma unroll
+      for( int k = 0; k < 4; k++ )
+        o.v[k] = ( ( unsigned ) ( unsigned short ) if_finish( sum[2 * k], p ) ) | ( ( unsigned ) ( unsigned short ) if_finish( sum[2 * k + 1], p ) << 16 );
+      *reinterpret_cast<Pel8u *>( dst + ( long ) y * j.dstStride + x0 ) = o;
+    }
+    return;
+  }
+  src -= halo * cStride;
+  for( int i = lane; i < w * h; i += 64 )
   {
     const int      y = i / w, x = i - y * w;
     const int16_t *s = src + ( long ) y * j.srcStride + x;
@@ -612,7 +665,7 @@ int if_single( vtmhip_ctx *ctx, int vertical, int taps, int isFirst, int isLast,
   VTMHIP_HIP( ctx, hipMemcpyAsync( dp, hp, srcBytes, hipMemcpyHostToDevice, ctx->stream ) );
   VTMHIP_HIP( ctx, hipMemcpyAsync( dp + jobOffB, hp + jobOffB, sizeof( j ), hipMemcpyHostToDevice, ctx->stream ) );
   hipLaunchKernelGGL( if_batch_kernel, dim3( 1 ), dim3( 256 ), 0, ctx->stream, ( const int16_t * ) dp, ( int16_t * ) ( dp + dstOffB ),
-                      ( const vtmhip_if_job * ) ( dp + jobOffB ) );
+                      ( const vtmhip_if_job * ) ( dp + jobOffB ), 1 );
   VTMHIP_LAUNCHED( ctx );
   VTMHIP_HIP( ctx, hipMemcpyAsync( hp + dstOffB, dp + dstOffB, dstBytes, hipMemcpyDeviceToHost, ctx->stream ) );
   VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
@@ -661,7 +714,7 @@ int vtmhip_if_batch_dev( vtmhip_ctx *ctx, const int16_t *d_srcBase, int16_t *d_d
   VTMHIP_REQUIRE( ctx, n >= 0, "n" );
   if( n == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, d_srcBase && d_dstBase && d_jobs, "null pointer" );
-  hipLaunchKernelGGL( if_batch_kernel, dim3( n ), dim3( 256 ), 0, ctx->stream, d_srcBase, d_dstBase, d_jobs );
+  hipLaunchKernelGGL( if_batch_kernel, dim3( ( n + 3 ) / 4 ), dim3( 256 ), 0, ctx->stream, d_srcBase, d_dstBase, d_jobs, n );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

@@ -163,6 +163,10 @@ class Context:
     def dist_batch(self, d_org, d_cur, d_jobs, n, d_out):
         self._check(self.L.vtmhip_dist_batch_dev(self.h, d_org, d_cur, d_jobs, n, d_out))
 
+    def dist_uniform_batch(self, d_org, d_cur, d_jobs, n, kind, w, h, sub_shift, d_out):
+        """Every job is w x h of one kind: small blocks share a wave (vtmhip_dist_uniform_batch_dev)."""
+        self._check(self.L.vtmhip_dist_uniform_batch_dev(self.h, d_org, d_cur, d_jobs, n, kind, w, h, sub_shift, d_out))
+
     def satd8_grid(self, d_org, org_stride, d_ref, ref_stride, w, h, r, d_out):
         self._check(self.L.vtmhip_satd8_grid_dev(self.h, d_org, org_stride, d_ref, ref_stride, w, h, r, d_out))
 
