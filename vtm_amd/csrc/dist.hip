@@ -507,8 +507,10 @@ extern "C" int vtmhip_dist_uniform_batch_dev( vtmhip_ctx *ctx, const int16_t *d_
     items = ( w / tw ) * ( h / th );
   }
   else items = ( width >> 3 ) * ( kind == VTMHIP_DIST_SAD ? height >> subShift : height );
-  int lpjShift = 0;
-  while( ( 1 << lpjShift ) < items && lpjShift < 6 ) lpjShift++;
+  // lanes per job: SATD one tile per lane; SAD / SSE up to four 8-sample segments per lane (fewer waves, shorter reductions)
+  const int perLane = kind == VTMHIP_DIST_SATD ? 1 : 4;
+  int       lpjShift = 0;
+  while( ( perLane << lpjShift ) < items && lpjShift < 6 ) lpjShift++;
   const int jobsPerWave = 64 >> lpjShift, waves = ( n + jobsPerWave - 1 ) / jobsPerWave;
   hipLaunchKernelGGL( dist_uniform_kernel, dim3( ( waves + 3 ) / 4 ), dim3( 256 ), 0, ctx->stream, d_orgBase, d_curBase, d_jobs, n, kind, width, height, subShift, lpjShift,
                       ( unsigned long long * ) d_dist );
