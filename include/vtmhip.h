@@ -445,6 +445,12 @@ typedef struct
 int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int maxWidth, int maxHeight,
                                int uniformSize, int32_t *d_levelsBase, int16_t *d_recBase, vtmhip_tu_result *d_results );
 
+/* TrQuant::xT only, for a batch the caller promises to be uniform (every TU width x height, powers of two 8..64) -- the forward transforms of all
+ * MTS candidates of TrQuant::transformNxN( ..., trModes, maxCand ) (TrQuant.cpp:950-1019): same job table as the fused chain (qp fields unused);
+ * coefficients (H x W contiguous) go to d_coefBase + outOff, results[i].sumAbs = sum |coef| for vtmhip_mts_select(). */
+int vtmhip_xT_uniform_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int width, int height, int32_t *d_coefBase,
+                                 vtmhip_tu_result *d_results );
+
 /* ---- affine ME gradients: AffineGradientSearch::m_HorizontalSobelFilter / m_VerticalSobelFilter / m_EqualCoeffComputer -----------
  * (AffineGradientSearch.h:50-54, AffineGradientSearch.cpp:62-170; caller xAffineMotionEstimation, InterSearch.cpp:5340-5775) */
 typedef struct

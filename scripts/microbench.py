@@ -118,6 +118,14 @@ def main():
             d_resi, d_coef, d_jt = ctx.to_device(resi), ctx.alloc(4 * nblk * w * h), ctx.to_device(jt.view(np.uint8))
             ms = timed(ctx, lambda: ctx.xT_batch(d_resi.ptr, d_coef.ptr, d_jt.ptr, nblk, w, h, None), reps=5)
             emit("xT", nblk * w * h, "samples", 6 * nblk * w * h, ms, type=tname, size="%dx%d" % (w, h))
+    for s in (8, 16, 32, 64):   # the uniform forward transform (MTS candidate pre-selection) next to the generic one
+        resi = rng.integers(-512, 512, (nblk, s, s)).astype(np.int16)
+        ju = np.zeros(nblk, np.dtype(TuJob))
+        ju["resiOff"] = ju["outOff"] = np.arange(nblk) * s * s
+        ju["resiStride"], ju["width"], ju["height"], ju["qpPer"], ju["qpRem"], ju["bitDepth"] = s, s, s, 7, 2, 10
+        d_resi, d_ju, d_r, d_cf = ctx.to_device(resi), ctx.to_device(ju.view(np.uint8)), ctx.alloc(16 * nblk), ctx.alloc(4 * nblk * s * s)
+        ms = timed(ctx, lambda: ctx.xT_uniform_batch(d_resi.ptr, d_ju.ptr, nblk, s, s, d_cf.ptr, d_r.ptr), reps=5)
+        emit("xT_uniform", nblk * s * s, "samples", 6 * nblk * s * s, ms, type="DCT2", size="%dx%d" % (s, s))
     for s in (8, 16, 32, 64):
         resi = rng.integers(-512, 512, (nblk, s, s)).astype(np.int16)
         ju = np.zeros(nblk, np.dtype(TuJob))

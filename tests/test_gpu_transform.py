@@ -234,3 +234,32 @@ def test_tu_chain_matches_oracle(ctx, big, uniform):
     for k, (w, h, th, tv) in enumerate(tus):
         assert got[k] == exp[k], (tus[k], got[k], exp[k])
         assert np.array_equal(lv[k, :w * h], exp_lv[k, :w * h]) and np.array_equal(rc[k, :w * h], exp_rec[k, :w * h]), tus[k]
+
+
+@pytest.mark.parametrize("size", [(8, 8), (16, 16), (32, 32), (64, 64), (32, 8), (8, 32), (16, 64)])
+def test_xT_uniform_batch_matches_oracle(ctx, size):
+    """vtmhip_xT_uniform_batch_dev: forward transforms of the MTS candidates of one TU size (TuJob table), coefficients and sum|coef|."""
+    from vtm_amd.lib import TuJob, TuResult
+    L = ol.oracle()
+    w, h = size
+    rng = np.random.default_rng(700 + w + h)
+    cands = [(0, 0)] if max(w, h) > 32 else [(0, 0), (2, 2), (1, 2), (2, 1), (1, 1)]
+    nblk = 37
+    n = nblk * len(cands)
+    stride = w + 6
+    resi = rng.integers(-1023, 1024, (nblk, h, stride)).astype(np.int16)
+    jobs = (TuJob * n)()
+    exp = np.zeros((n, h * w), np.int32)
+    for k in range(n):
+        b, (th, tv) = k % nblk, cands[k // nblk]
+        j = jobs[k]
+        j.resiOff, j.outOff, j.resiStride, j.width, j.height = b * h * stride, k * w * h, stride, w, h
+        j.typeHor, j.typeVer, j.bitDepth, j.qpPer, j.qpRem = th, tv, 10, 7, 2
+        assert L.vo_fwd_2d(C.c_void_p(resi.ctypes.data + 2 * j.resiOff), stride, w, h, 10, th, tv, ol.P(exp[k])) == 0
+    d_resi, d_jobs = ctx.to_device(resi), ctx.to_device(np.frombuffer(jobs, np.uint8))
+    d_coef, d_res = ctx.alloc(4 * n * w * h), ctx.alloc(C.sizeof(TuResult) * n)
+    ctx.xT_uniform_batch(d_resi.ptr, d_jobs.ptr, n, w, h, d_coef.ptr, d_res.ptr)
+    got = d_coef.to_host(np.int32).reshape(n, w * h)
+    assert np.array_equal(got, exp)
+    res = (TuResult * n).from_buffer_copy(d_res.to_host(np.uint8).tobytes())
+    assert [r.sumAbs for r in res] == [int(np.abs(exp[k]).sum()) for k in range(n)]

@@ -612,8 +612,9 @@ __device__ __forceinline__ void tuq_pass16( const int16_t *A, int aRowStride, co
 template<int LPT>
 __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__restrict__ resiBase, const vtmhip_tu_job *__restrict__ jobs, int numJobs,
                                                              TrTables tabs, int *__restrict__ levelsBase, int16_t *__restrict__ recBase,
-                                                             vtmhip_tu_result *__restrict__ results, int w, int h )
+                                                             vtmhip_tu_result *__restrict__ results, int w, int h, int *__restrict__ fwdCoefBase )
 {
+  // fwdCoefBase != nullptr: forward transform only (TrQuant::xT): coefficients to fwdCoefBase + outOff, sum|coef| to results
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int ldsw[];
   __shared__ long long sRed[4][3];
   constexpr int TUS = 256 / LPT;
@@ -621,9 +622,10 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
   const int     perTu = w * h + w * ( h + 1 ) + ( ( w * h + 1 ) >> 1 );   // ints: blk, tmp, residual copy
   int16_t      *sMat = ( int16_t * ) ( ldsw + TUS * perTu );              // [dim][type][orientation][N*N]
   const int     lw = ilog2( w ), lh = ilog2( h );
+  const int     hBase = ( w > 32 ? 2 : 6 ) * w * w;   // only DCT-2 exists above 32: one matrix pair instead of three
   for( int ty = 0; ty < 3; ty++ )
   {
-    const int16_t *mw = tabs.m[ty][lw], *mh = tabs.m[ty][lh];
+    const int16_t *mw = ( ty == 0 || w <= 32 ) ? tabs.m[ty][lw] : nullptr, *mh = ( ty == 0 || h <= 32 ) ? tabs.m[ty][lh] : nullptr;   // DST-7 / DCT-8 exist up to 32
     // width:  slot 0 = M_W with rows k, k+1 interleaved (second inverse pass), slot 1 = M_W^T with rows n, n+1 interleaved (first forward pass)
     // height: slot 0 = M_H with rows k, k+1 interleaved (first inverse pass),   slot 1 = M_H^T plain (second forward pass: 32-bit input)
     if( mw )
@@ -637,8 +639,8 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
       for( int i = threadIdx.x; i < h * h; i += 256 )
       {
         const int k = i / h, n = i - k * h;
-        sMat[6 * w * w + ( ty * 2 + 0 ) * h * h + ( ( k >> 1 ) * h + n ) * 2 + ( k & 1 )] = mh[i];
-        sMat[6 * w * w + ( ty * 2 + 1 ) * h * h + n * h + k]                              = mh[i];
+        sMat[hBase + ( ty * 2 + 0 ) * h * h + ( ( k >> 1 ) * h + n ) * 2 + ( k & 1 )] = mh[i];
+        sMat[hBase + ( ty * 2 + 1 ) * h * h + n * h + k]                              = mh[i];
       }
   }
   __syncthreads();
@@ -650,7 +652,7 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
   const int      bd = j.bitDepth;
   int           *blk = ldsw + sub * perTu, *tmp = blk + w * h;
   int16_t       *sR  = ( int16_t * ) ( tmp + w * ( h + 1 ) );
-  const int16_t *mW = sMat + ( j.typeHor * 2 ) * w * w, *mH = sMat + 6 * w * w + ( j.typeVer * 2 ) * h * h;
+  const int16_t *mW = sMat + ( j.typeHor * 2 ) * w * w, *mH = sMat + hBase + ( j.typeVer * 2 ) * h * h;
   const int16_t *resi = resiBase + j.resiOff;
   for( int i = t; i < w * h; i += LPT )
   {
@@ -668,46 +670,54 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
   tuq_sync<LPT>();
   tuq_pass<LPT, false>( tmp, h + 1, 1, mH + h * h, h, h, w, h, w - skipW, h - skipH, blk, 1, w, lh + 6, t, &sumAbs );
   tuq_sync<LPT>();
-  // Quant::quant + Quant::dequant (flat scaling list), in place
+  if( fwdCoefBase )
   {
-    const int       needSqrt = ( lw + lh ) & 1;
-    const int       trShift  = 15 - bd - ( ( lw + lh ) >> 1 ) + ( needSqrt ? -1 : 0 );
-    const int       qBits    = 14 + j.qpPer + trShift;
-    const long long add      = ( long long ) ( j.isIRAP ? 171 : 85 ) << ( qBits - 9 );
-    const int       scale    = c_quantScales[needSqrt][j.qpRem], iscale = c_invQuantScales[needSqrt][j.qpRem];
-    const int       rightShift = 6 - ( trShift + j.qpPer );
-    const int       inBits   = min( 16, 32 + rightShift - 7 );
-    const int       inMin = -( 1 << ( inBits - 1 ) ), inMax = ( 1 << ( inBits - 1 ) ) - 1;
-    int            *levels   = ( levelsBase && live ) ? levelsBase + j.outOff : nullptr;
-    for( int i = t; i < w * h; i += LPT )
-    {
-      const int       c   = blk[i];
-      const long long tt  = ( long long ) abs( c ) * scale;
-      const int       mag = ( int ) ( ( tt + add ) >> qBits );
-      absSum += mag;
-      const int q = min( 32767, max( -32768, c < 0 ? -mag : mag ) );
-      if( levels ) levels[i] = q;
-      const int qq = min( inMax, max( inMin, q ) );
-      int       v;
-      if( rightShift > 0 ) v = ( int ) ( ( unsigned ) ( qq * iscale ) + ( 1u << ( rightShift - 1 ) ) ) >> rightShift;
-      else v = ( int ) ( ( unsigned ) ( qq * iscale ) << ( -rightShift ) );
-      dq16[( i % w ) * h + i / w] = ( int16_t ) min( 32767, max( -32768, v ) );   // transposed: the vertical index contiguous
-    }
+    if( live )
+      for( int i = t; i < w * h; i += LPT ) fwdCoefBase[j.outOff + i] = blk[i];
   }
-  tuq_sync<LPT>();
-  // inverse (TrQuant::xIT): tmp[i][y] = clip( sum_k blk[k][i] * M_ver[k][y] );  rec[y][x] = clip( sum_k tmp[k][y] * M_hor[k][x] )
-  tuq_pass16<LPT, true>( dq16, h, reinterpret_cast<const unsigned *>( mH ), h - skipH, w, h, w - skipW, h, t16, 1, w, 7, t );
-  tuq_sync<LPT>();
-  tuq_pass16<LPT, true>( t16, w, reinterpret_cast<const unsigned *>( mW ), w - skipW, h, w, h, w, rec32, w, 1, 20 - bd, t );
-  tuq_sync<LPT>();
+  else
   {
-    int16_t *rec = ( recBase && live ) ? recBase + j.outOff : nullptr;
-    for( int i = t; i < w * h; i += LPT )
+    // Quant::quant + Quant::dequant (flat scaling list), in place
     {
-      const int v = rec32[i];
-      if( rec ) rec[i] = ( int16_t ) v;
-      const int d = ( int ) sR[i] - v;
-      sse += ( long long ) ( unsigned long long ) ( ( unsigned ) d * ( unsigned ) d );
+      const int       needSqrt = ( lw + lh ) & 1;
+      const int       trShift  = 15 - bd - ( ( lw + lh ) >> 1 ) + ( needSqrt ? -1 : 0 );
+      const int       qBits    = 14 + j.qpPer + trShift;
+      const long long add      = ( long long ) ( j.isIRAP ? 171 : 85 ) << ( qBits - 9 );
+      const int       scale    = c_quantScales[needSqrt][j.qpRem], iscale = c_invQuantScales[needSqrt][j.qpRem];
+      const int       rightShift = 6 - ( trShift + j.qpPer );
+      const int       inBits   = min( 16, 32 + rightShift - 7 );
+      const int       inMin = -( 1 << ( inBits - 1 ) ), inMax = ( 1 << ( inBits - 1 ) ) - 1;
+      int            *levels   = ( levelsBase && live ) ? levelsBase + j.outOff : nullptr;
+      for( int i = t; i < w * h; i += LPT )
+      {
+        const int       c   = blk[i];
+        const long long tt  = ( long long ) abs( c ) * scale;
+        const int       mag = ( int ) ( ( tt + add ) >> qBits );
+        absSum += mag;
+        const int q = min( 32767, max( -32768, c < 0 ? -mag : mag ) );
+        if( levels ) levels[i] = q;
+        const int qq = min( inMax, max( inMin, q ) );
+        int       v;
+        if( rightShift > 0 ) v = ( int ) ( ( unsigned ) ( qq * iscale ) + ( 1u << ( rightShift - 1 ) ) ) >> rightShift;
+        else v = ( int ) ( ( unsigned ) ( qq * iscale ) << ( -rightShift ) );
+        dq16[( i % w ) * h + i / w] = ( int16_t ) min( 32767, max( -32768, v ) );   // transposed: the vertical index contiguous
+      }
+    }
+    tuq_sync<LPT>();
+    // inverse (TrQuant::xIT): tmp[i][y] = clip( sum_k blk[k][i] * M_ver[k][y] );  rec[y][x] = clip( sum_k tmp[k][y] * M_hor[k][x] )
+    tuq_pass16<LPT, true>( dq16, h, reinterpret_cast<const unsigned *>( mH ), h - skipH, w, h, w - skipW, h, t16, 1, w, 7, t );
+    tuq_sync<LPT>();
+    tuq_pass16<LPT, true>( t16, w, reinterpret_cast<const unsigned *>( mW ), w - skipW, h, w, h, w, rec32, w, 1, 20 - bd, t );
+    tuq_sync<LPT>();
+    {
+      int16_t *rec = ( recBase && live ) ? recBase + j.outOff : nullptr;
+      for( int i = t; i < w * h; i += LPT )
+      {
+        const int v = rec32[i];
+        if( rec ) rec[i] = ( int16_t ) v;
+        const int d = ( int ) sR[i] - v;
+        sse += ( long long ) ( unsigned long long ) ( ( unsigned ) d * ( unsigned ) d );
+      }
     }
   }
   // reduce the three sums over the LPT lanes of the TU
@@ -745,17 +755,31 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
 
 template<int LPT>
 int launch_tu_uni( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int w, int h, int32_t *d_levelsBase, int16_t *d_recBase,
-                   vtmhip_tu_result *d_results, const TrTables &tabs )
+                   vtmhip_tu_result *d_results, const TrTables &tabs, int32_t *d_fwdCoefBase = nullptr )
 {
   constexpr int TUS   = 256 / LPT;
   const size_t  perTu = ( size_t ) w * h + ( size_t ) w * ( h + 1 ) + ( ( w * h + 1 ) >> 1 );
-  const size_t  lds   = TUS * perTu * sizeof( int ) + ( size_t ) 6 * ( w * w + h * h ) * sizeof( int16_t );
+  const size_t  lds   = TUS * perTu * sizeof( int ) + ( ( size_t ) ( w > 32 ? 2 : 6 ) * w * w + ( size_t ) ( h > 32 ? 2 : 6 ) * h * h ) * sizeof( int16_t );
   if( lds > 64 * 1024 )
     VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( tu_chain_uni_kernel<LPT> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
   hipLaunchKernelGGL( tu_chain_uni_kernel<LPT>, dim3( ( n + TUS - 1 ) / TUS ), dim3( 256 ), lds, ctx->stream, d_resiBase, d_jobs, n, tabs, d_levelsBase, d_recBase,
-                      d_results, w, h );
+                      d_results, w, h, d_fwdCoefBase );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
+}
+
+// LPT by block size: one lane = 2 x 8 outputs of a transform pass
+int launch_tu_uni_sized( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int w, int h, int32_t *d_levelsBase, int16_t *d_recBase,
+                         vtmhip_tu_result *d_results, const TrTables &tb, int32_t *d_fwdCoefBase )
+{
+  const int items = w * h / 16;
+  if( items <= 4 ) return launch_tu_uni<4>( ctx, d_resiBase, d_jobs, n, w, h, d_levelsBase, d_recBase, d_results, tb, d_fwdCoefBase );
+  if( items <= 8 ) return launch_tu_uni<8>( ctx, d_resiBase, d_jobs, n, w, h, d_levelsBase, d_recBase, d_results, tb, d_fwdCoefBase );
+  if( items <= 16 ) return launch_tu_uni<16>( ctx, d_resiBase, d_jobs, n, w, h, d_levelsBase, d_recBase, d_results, tb, d_fwdCoefBase );
+  if( items <= 32 ) return launch_tu_uni<32>( ctx, d_resiBase, d_jobs, n, w, h, d_levelsBase, d_recBase, d_results, tb, d_fwdCoefBase );
+  if( items <= 64 ) return launch_tu_uni<64>( ctx, d_resiBase, d_jobs, n, w, h, d_levelsBase, d_recBase, d_results, tb, d_fwdCoefBase );
+  if( items <= 128 ) return launch_tu_uni<128>( ctx, d_resiBase, d_jobs, n, w, h, d_levelsBase, d_recBase, d_results, tb, d_fwdCoefBase );
+  return launch_tu_uni<256>( ctx, d_resiBase, d_jobs, n, w, h, d_levelsBase, d_recBase, d_results, tb, d_fwdCoefBase );
 }
 
 bool pow2( int v ) { return v > 0 && ( v & ( v - 1 ) ) == 0; }
@@ -889,15 +913,7 @@ int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const
   if( uniformSize && maxWidth >= 8 && maxHeight >= 8 )
   {
     // caller's promise: every TU is exactly maxWidth x maxHeight -> register-blocked kernel, LPT lanes per TU
-    const int      items = maxWidth * maxHeight / 16;   // one lane = 2 x 8 outputs of a transform pass
-    const TrTables &tb   = g_tabs[ctx->device & 15];
-    if( items <= 4 ) return launch_tu_uni<4>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
-    if( items <= 8 ) return launch_tu_uni<8>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
-    if( items <= 16 ) return launch_tu_uni<16>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
-    if( items <= 32 ) return launch_tu_uni<32>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
-    if( items <= 64 ) return launch_tu_uni<64>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
-    if( items <= 128 ) return launch_tu_uni<128>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
-    return launch_tu_uni<256>( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tb );
+    return launch_tu_uni_sized( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, g_tabs[ctx->device & 15], nullptr );
   }
   const int    mx    = maxWidth > maxHeight ? maxWidth : maxHeight;
   const size_t perTu = ( size_t ) maxWidth * maxHeight + ( size_t ) maxWidth * ( maxHeight + 1 ) + ( ( mx * mx + 1 ) >> 1 ) + ( ( maxWidth * maxHeight + 1 ) >> 1 );
@@ -939,3 +955,17 @@ int vtmhip_mts_select( const int32_t *sumAbs, int numCand, int width, int height
 }
 
 }   // extern "C"
+
+
+extern "C" int vtmhip_xT_uniform_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int width, int height, int32_t *d_coefBase,
+                                            vtmhip_tu_result *d_results )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_resiBase && d_jobs && d_coefBase && d_results, "null pointer" );
+  VTMHIP_REQUIRE( ctx, width >= 8 && width <= TB && height >= 8 && height <= TB && pow2( width ) && pow2( height ), "width / height: powers of two 8..64" );
+  int st = ensure_tables( ctx );
+  if( st ) return st;
+  return launch_tu_uni_sized( ctx, d_resiBase, d_jobs, n, width, height, nullptr, nullptr, d_results, g_tabs[ctx->device & 15], d_coefBase );
+}

@@ -179,6 +179,10 @@ class Context:
     def xT_batch(self, d_resi, d_coef, d_jobs, n, max_w, max_h, d_sum_abs=None):
         self._check(self.L.vtmhip_xT_batch_dev(self.h, d_resi, d_coef, d_jobs, n, max_w, max_h, d_sum_abs))
 
+    def xT_uniform_batch(self, d_resi, d_jobs, n, w, h, d_coef, d_results):
+        """Forward transforms of n uniform w x h TUs (TuJob table): coefficients + sum|coef| (vtmhip_xT_uniform_batch_dev)."""
+        self._check(self.L.vtmhip_xT_uniform_batch_dev(self.h, d_resi, d_jobs, n, w, h, d_coef, d_results))
+
     def xIT_batch(self, d_coef, d_resi, d_jobs, n, max_w, max_h):
         self._check(self.L.vtmhip_xIT_batch_dev(self.h, d_coef, d_resi, d_jobs, n, max_w, max_h))
 
