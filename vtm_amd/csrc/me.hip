@@ -119,6 +119,25 @@ __device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy,
   if( j.seg == 8 && j.orgLds )
   {
     // items are 16-byte aligned in the LDS copy (w is a multiple of 8): one ds_read_b128 per item instead of a second vector-memory load
+    if( j.lpc == 64 && j.sprShift >= 0 && j.sprShift <= 6 )
+    {
+      // a whole wave on one candidate, power-of-two row length: lane `sub` keeps its column and walks down 64 >> sprShift rows per step,
+      // so both addresses advance by constants
+      const int      rowsPerStep = 64 >> j.sprShift;
+      const int16_t *pr = c0 + ( long ) ( sub >> j.sprShift ) * cs + ( ( sub & ( j.segsPerRow - 1 ) ) << 3 );
+      const int16_t *po = j.orgLds + ( sub << 3 );
+      const long     dr = cs * rowsPerStep;
+      for( int it = sub; it < j.items; it += 64 )
+      {
+        const uint4 a = *reinterpret_cast<const uint4 *>( po );
+        const Pel8  b = *reinterpret_cast<const Pel8 *>( pr );
+        s = sad2( a.x, b.v[0] ^ j.bias, s ); s = sad2( a.y, b.v[1] ^ j.bias, s );
+        s = sad2( a.z, b.v[2] ^ j.bias, s ); s = sad2( a.w, b.v[3] ^ j.bias, s );
+        pr += dr;
+        po += 512;
+      }
+      return s;
+    }
     for( int it = sub; it < j.items; it += j.lpc )
     {
       const int   r = j.sprShift >= 0 ? it >> j.sprShift : it / j.segsPerRow, x = ( it - r * j.segsPerRow ) << 3;
