@@ -297,6 +297,28 @@ def gen_mc():
     print("mc:", len(meta), "blocks")
 
 
+def gen_masked():
+    """RdCost::xGetSADwMask through the table entry (x86) -- ref_sad_mask: blocks, the 112x112 weight plane, walk parameters, results."""
+    R.ref_sad_mask.restype = C.c_uint64
+    g = np.random.default_rng(808)
+    M = 112
+    plane = ol.i16(g.integers(0, 9, (M, M)))
+    meta, orgs, curs, res = [], [], [], []
+    for k in range(160):
+        w, h = int(g.choice([8, 16, 32, 64])), int(g.choice([8, 16, 32, 64]))
+        org, cur = ol.i16(g.integers(0, 1024, (h, w))), ol.i16(g.integers(0, 1024, (h, w)))
+        sx, rd = (1 if k % 3 else -1), (1 if k % 2 else -1)
+        x0 = int(g.integers(0, M - w)) + (w - 1 if sx < 0 else 0)
+        y0 = int(g.integers(0, M - h)) + (h - 1 if rd < 0 else 0)
+        off, ms, ms2 = y0 * M + x0, rd * M, -sx * w
+        v = R.ref_sad_mask(1, ol.P(org), w, ol.P(cur), w, w, h, 10, C.c_void_p(plane.ctypes.data + 2 * off), ms, sx, ms2)
+        meta.append((w, h, off, ms, sx, ms2))
+        orgs.append(org.reshape(-1)); curs.append(cur.reshape(-1)); res.append(v)
+    np.savez_compressed(os.path.join(HERE, "masked.npz"), plane=plane, meta=np.array(meta, np.int32), org=np.concatenate(orgs), cur=np.concatenate(curs),
+                        res=np.array(res, np.uint64))
+    print("masked:", len(meta), "cases")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected fixtures only: gen_golden.py mest quant ...
         for name in sys.argv[1:]:
@@ -311,3 +333,4 @@ if __name__ == "__main__":
     gen_quant()
     gen_mest()
     gen_mc()
+    gen_masked()

@@ -109,3 +109,15 @@ def test_mc_luma_chroma_golden(ctx):
     ctx.mc_batch(d_ref.ptr, d_dst.ptr, d_jobs.ptr, len(meta), 128, 128)
     got = d_dst.to_host(np.int16)
     assert np.array_equal(got, z["out"])
+
+
+def test_masked_sad_golden(ctx):
+    """vtmhip_xGetSADwMask vs the values recorded from the reference's DF_SAD_WITH_MASK table entry."""
+    z = np.load(os.path.join(G, "masked.npz"))
+    plane = np.ascontiguousarray(z["plane"]).reshape(-1)
+    pos = 0
+    for (w, h, off, ms, sx, ms2), exp in zip(z["meta"].tolist(), z["res"].tolist()):
+        org = np.ascontiguousarray(z["org"][pos:pos + w * h]).reshape(h, w)
+        cur = np.ascontiguousarray(z["cur"][pos:pos + w * h]).reshape(h, w)
+        pos += w * h
+        assert ctx.xGetSADwMask(org, w, cur, w, w, h, plane, off, ms, sx, ms2) == exp, (w, h, off, ms, sx, ms2)

@@ -158,3 +158,16 @@ def test_mc_golden(oracle):
         oracle.vo_mc_block(comp, C.c_void_p(refp), st, cw, ch, mvh, mvv, bi, 10, int(imv == 3), ol.P(a), cw)
         assert np.array_equal(a.reshape(-1), z["out"][pos:pos + cw * ch]), (comp, x, y, w, h, mvh, mvv, bi, imv)
         pos += cw * ch
+
+
+def test_masked_sad_golden(oracle):
+    """DF_SAD_WITH_MASK values recorded from the reference's table entry (gen_golden.py gen_masked)."""
+    oracle.vo_sad_mask.restype = C.c_uint64
+    z = np.load(os.path.join(G, "masked.npz"))
+    plane = np.ascontiguousarray(z["plane"]).reshape(-1)
+    pos = 0
+    for (w, h, off, ms, sx, ms2), exp in zip(z["meta"].tolist(), z["res"].tolist()):
+        org, cur = np.ascontiguousarray(z["org"][pos:pos + w * h]), np.ascontiguousarray(z["cur"][pos:pos + w * h])
+        pos += w * h
+        got = oracle.vo_sad_mask(ol.P(org), w, ol.P(cur), w, w, h, 0, C.c_void_p(plane.ctypes.data + 2 * off), ms, sx, ms2)
+        assert got == exp, (w, h, off, ms, sx, ms2)
