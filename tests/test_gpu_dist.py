@@ -166,3 +166,26 @@ def test_dist_uniform_batch_matches_oracle(ctx, kind):
         d_out = ctx.alloc(8 * n)
         ctx.dist_uniform_batch(d_org.ptr, d_ref.ptr, d_jobs.ptr, n, kind, w, h, ss, d_out.ptr)
         assert list(d_out.to_host(np.uint64)) == exp, (kind, w, h)
+
+
+@pytest.mark.parametrize("rng_kind", ["10bit", "12bit", "signed"])
+def test_satd8_grid_sample_ranges(ctx, rng_kind):
+    """The grid kernel picks its arithmetic per workgroup from the staged samples: five packed 16-bit butterfly levels for [0, 1023],
+    three for [0, 4095], 32-bit otherwise -- all must equal the oracle."""
+    L = ol.oracle()
+    W, H, r = 128, 64, 4
+    rng = np.random.default_rng(len(rng_kind))
+    lo, hi = {"10bit": (0, 1024), "12bit": (0, 4096), "signed": (-20000, 20000)}[rng_kind]
+    org = ol.i16(rng.integers(lo, hi, (H, W)))
+    refp = ol.i16(rng.integers(lo, hi, (H + 2 * r, W + 2 * r + 8)))
+    if rng_kind == "12bit":
+        org[0:8, 0:8] = 4095   # extreme block: 8 * 4095 after three levels
+        refp[r:r + 8, r:r + 8] = 0
+    rs = refp.shape[1]
+    nb = (W // 8) * (H // 8)
+    exp = np.zeros(nb * 81, np.uint64)
+    L.vo_satd8_grid(ol.P(org), W, C.c_void_p(refp.ctypes.data + 2 * (r * rs + r)), rs, W, H, r, ol.P(exp))
+    d_org, d_ref = ctx.to_device(org), ctx.to_device(refp)
+    d_out = ctx.alloc(4 * nb * 81)
+    ctx.satd8_grid(d_org.ptr, W, d_ref.ptr + 2 * (r * rs + r), rs, W, H, r, d_out.ptr)
+    assert np.array_equal(d_out.to_host(np.uint32).astype(np.uint64), exp)

@@ -171,6 +171,108 @@ __global__ __launch_bounds__( 256 ) void dist_batch_kernel( const int16_t *__res
   if( lane == 0 ) out[job] = acc;
 }
 
+// 8x8 SATD on PACKED 16-bit differences: valid when every |org - ref| <= 4095 (all samples in [0, 4095]), so that three butterfly levels stay
+// inside int16.  D[y][k] = (d[y][2k], d[y][2k+1]); the vertical transform runs on the packed words (v_pk_add_i16 / v_pk_sub_i16: half the
+// instructions), the horizontal one in 32 bits after unpacking, its last level folded into the absolute sum.
+typedef short v2s __attribute__( ( ext_vector_type( 2 ) ) );
+
+__device__ __forceinline__ unsigned satd8_packed( v2s D[8][4] )
+{
+#pragma unroll
+  for( int len = 1; len < 8; len <<= 1 )
+#pragma unroll
+    for( int i = 0; i < 8; i += len << 1 )
+#pragma unroll
+      for( int j = i; j < i + len; j++ )
+#pragma unroll
+        for( int k = 0; k < 4; k++ )
+        {
+          const v2s a = D[j][k], b = D[j + len][k];
+          D[j][k]       = a + b;
+          D[j + len][k] = a - b;
+        }
+  int t = 0, dc = 0;
+#pragma unroll
+  for( int y = 0; y < 8; y++ )
+  {
+    int m[8];
+#pragma unroll
+    for( int k = 0; k < 4; k++ ) { m[2 * k] = D[y][k].x; m[2 * k + 1] = D[y][k].y; }
+    // horizontal: levels 1 and 2, then |a + b| + |a - b| = 2 max(|a|, |b|) for the pairs (x, x + 4)
+#pragma unroll
+    for( int len = 1; len < 4; len <<= 1 )
+#pragma unroll
+      for( int i = 0; i < 8; i += len << 1 )
+#pragma unroll
+        for( int j = i; j < i + len; j++ )
+        {
+          const int a = m[j], b = m[j + len];
+          m[j] = a + b; m[j + len] = a - b;
+        }
+#pragma unroll
+    for( int x = 0; x < 4; x++ ) t += max( abs( m[x] ), abs( m[x + 4] ) );
+    if( y == 0 ) dc = abs( m[0] + m[4] );
+  }
+  t <<= 1;
+  t = t - dc + ( dc >> 2 );
+  return ( unsigned ) ( ( t + 2 ) >> 2 );
+}
+
+// The same with five of the six butterfly levels in packed 16-bit arithmetic: valid when every |org - ref| <= 1023 (all samples in [0, 1023],
+// 10-bit pictures), so that 32 * 1023 still fits int16.  The sixth level pairs the two halves of a word: |lo + hi| + |lo - hi| =
+// 2 max(|lo|, |hi|): packed |.|, then one max of the two halves per word.
+__device__ __forceinline__ unsigned satd8_packed10( v2s D[8][4] )
+{
+  // vertical: three levels between rows
+#pragma unroll
+  for( int len = 1; len < 8; len <<= 1 )
+#pragma unroll
+    for( int i = 0; i < 8; i += len << 1 )
+#pragma unroll
+      for( int j = i; j < i + len; j++ )
+#pragma unroll
+        for( int k = 0; k < 4; k++ )
+        {
+          const v2s a = D[j][k], b = D[j + len][k];
+          D[j][k]       = a + b;
+          D[j + len][k] = a - b;
+        }
+  // horizontal: the two levels between words (columns x vs x + 2, x vs x + 4)
+#pragma unroll
+  for( int y = 0; y < 8; y++ )
+  {
+#pragma unroll
+    for( int len = 1; len < 4; len <<= 1 )
+#pragma unroll
+      for( int i = 0; i < 4; i += len << 1 )
+#pragma unroll
+        for( int j = i; j < i + len; j++ )
+        {
+          const v2s a = D[y][j], b = D[y][j + len];
+          D[y][j]       = a + b;
+          D[y][j + len] = a - b;
+        }
+  }
+  const int dc = abs( ( int ) D[0][0].x + ( int ) D[0][0].y );
+  unsigned  t  = 0;
+  const v2s zero = { 0, 0 };
+#pragma unroll
+  for( int y = 0; y < 8; y++ )
+#pragma unroll
+    for( int k = 0; k < 4; k++ )
+    {
+      const v2s neg = zero - D[y][k];
+      v2s       av;
+      av.x = D[y][k].x > neg.x ? D[y][k].x : neg.x;      // packed |.| (v_pk_max_i16)
+      av.y = D[y][k].y > neg.y ? D[y][k].y : neg.y;
+      unsigned aw;
+      __builtin_memcpy( &aw, &av, 4 );
+      t += max( aw & 0xffffu, aw >> 16 );   // one v_max_u32 with sub-dword operand selects
+    }
+  const int tt = ( int ) ( t << 1 ) - dc + ( dc >> 2 );
+  return ( unsigned ) ( ( tt + 2 ) >> 2 );
+}
+
 // ---- SATD 8x8 grid ---------------------------------------------------------------------------------------------------
 // Workgroup = 256 threads = TBX x TBY org blocks; LDS holds the org tile and the reference tile (+r halo).
 constexpr int GRID_TBX = 8, GRID_TBY = 4;
@@ -186,6 +288,7 @@ __global__ __launch_bounds__( 256 ) void satd8_grid_kernel( const int16_t *__res
   int16_t  *sRef = lds + GRID_TBY * 8 * GRID_TBX * 8;     // [refH][refLd]
   const int bx0 = blockIdx.x * GRID_TBX, by0 = blockIdx.y * GRID_TBY;
 
+  unsigned wide = 0, wide10 = 0;   // any sample outside [0, 4095] in this workgroup's tiles -> 32-bit path; outside [0, 1023] -> three packed levels only
   // stage org tile: 32 rows x 64 samples = 256 x 16-byte vectors, one per thread (coalesced 128-byte rows)
   {
     const int row = threadIdx.x >> 3, seg = threadIdx.x & 7;
@@ -193,6 +296,8 @@ __global__ __launch_bounds__( 256 ) void satd8_grid_kernel( const int16_t *__res
     int4      v  = make_int4( 0, 0, 0, 0 );
     if( gy < bh * 8 && gx < bw * 8 ) v = *reinterpret_cast<const int4 *>( org + ( long ) gy * orgStride + gx );
     *reinterpret_cast<int4 *>( sOrg + row * 64 + seg * 8 ) = v;
+    wide |= ( unsigned ) ( v.x | v.y | v.z | v.w ) & 0xf000f000u;
+    wide10 |= ( unsigned ) ( v.x | v.y | v.z | v.w ) & 0xfc00fc00u;
   }
   // stage reference tile: refH rows x refW samples starting at (bx0*8 - r, by0*8 - r); 2-byte granularity on the
   // global side (the halo start is not 16-byte aligned), dword stores on the LDS side
@@ -204,9 +309,12 @@ __global__ __launch_bounds__( 256 ) void satd8_grid_kernel( const int16_t *__res
     int16_t        a = 0, b = 0;
     if( row < needH && c2 < needW ) a = p[0];
     if( row < needH && c2 + 1 < needW ) b = p[1];
-    *reinterpret_cast<unsigned *>( sRef + row * refLd + c2 ) = ( unsigned ) ( unsigned short ) a | ( ( unsigned ) ( unsigned short ) b << 16 );
+    const unsigned pk = ( unsigned ) ( unsigned short ) a | ( ( unsigned ) ( unsigned short ) b << 16 );
+    *reinterpret_cast<unsigned *>( sRef + row * refLd + c2 ) = pk;
+    wide |= pk & 0xf000f000u;
+    wide10 |= pk & 0xfc00fc00u;
   }
-  __syncthreads();
+  const bool packed = __syncthreads_or( ( int ) wide ) == 0, packed10 = __syncthreads_or( ( int ) wide10 ) == 0;
 
   const int pairs = GRID_TBX * GRID_TBY * nd2;
   for( int p = threadIdx.x; p < pairs; p += 256 )
@@ -217,6 +325,32 @@ __global__ __launch_bounds__( 256 ) void satd8_grid_kernel( const int16_t *__res
     if( bx0 + lbx >= bw || by0 + lby >= bh ) continue;
     const int16_t *o = sOrg + lby * 8 * 64 + lbx * 8;
     const int16_t *c = sRef + ( lby * 8 + dy ) * refLd + lbx * 8 + dx;
+    if( packed )
+    {
+      // dword reads: the reference row starts at an even or odd sample -> 5 dwords and v_alignbit by 0 / 16 bits
+      const unsigned sh = ( unsigned ) ( dx & 1 ) << 4;
+      v2s            D[8][4];
+#pragma unroll
+      for( int y = 0; y < 8; y++ )
+      {
+        const uint4     ov = *reinterpret_cast<const uint4 *>( o + y * 64 );
+        const unsigned *cr = reinterpret_cast<const unsigned *>( c + y * refLd - ( dx & 1 ) );
+        const unsigned  r0 = cr[0], r1 = cr[1], r2 = cr[2], r3 = cr[3], r4 = cr[4];
+        const unsigned  ow[4] = { ov.x, ov.y, ov.z, ov.w };
+        const unsigned  cw[4] = { __builtin_amdgcn_alignbit( r1, r0, sh ), __builtin_amdgcn_alignbit( r2, r1, sh ), __builtin_amdgcn_alignbit( r3, r2, sh ),
+                                  __builtin_amdgcn_alignbit( r4, r3, sh ) };
+#pragma unroll
+        for( int k = 0; k < 4; k++ )
+        {
+          v2s ovv, cvv;
+          __builtin_memcpy( &ovv, &ow[k], 4 );
+          __builtin_memcpy( &cvv, &cw[k], 4 );
+          D[y][k] = ovv - cvv;
+        }
+      }
+      out[( ( long ) ( by0 + lby ) * bw + ( bx0 + lbx ) ) * nd2 + d] = packed10 ? satd8_packed10( D ) : satd8_packed( D );
+      continue;
+    }
     int            m[64];
 #pragma unroll
     for( int y = 0; y < 8; y++ )
@@ -414,7 +548,7 @@ int vtmhip_satd8_grid_dev( vtmhip_ctx *ctx, const int16_t *d_org, int orgStride,
   VTMHIP_REQUIRE( ctx, ( orgStride & 7 ) == 0 && ( ( ( uintptr_t ) d_org ) & 15 ) == 0, "org plane must be 16-byte aligned with a stride multiple of 8" );
   const int    bw = width / 8, bh = height / 8;
   const int    refW = GRID_TBX * 8 + 2 * r, refH = GRID_TBY * 8 + 2 * r, refLd = ( refW + 7 ) & ~7;
-  const size_t lds = ( size_t ) ( GRID_TBY * 8 * GRID_TBX * 8 + refH * refLd ) * sizeof( int16_t );
+  const size_t lds = ( size_t ) ( GRID_TBY * 8 * GRID_TBX * 8 + refH * refLd ) * sizeof( int16_t ) + 16;   // + one spare vector: the packed path reads a fifth dword per row
   dim3         grid( ( bw + GRID_TBX - 1 ) / GRID_TBX, ( bh + GRID_TBY - 1 ) / GRID_TBY );
   hipLaunchKernelGGL( satd8_grid_kernel, grid, dim3( 256 ), lds, ctx->stream, d_org, orgStride, d_ref, refStride, bw, bh, r, d_dist );
   VTMHIP_LAUNCHED( ctx );
