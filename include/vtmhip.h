@@ -365,7 +365,8 @@ typedef struct
   int16_t intX, intY;       /* rcMvInt: result of the integer search */
   int32_t predHor, predVer; /* RdCost::setPredictor, quarter-sample units */
   double  motionLambda;
-  uint8_t useHad;           /* HadamardME && !DisableSATDForRD: SATD, else SAD */
+  uint8_t useHad;           /* HadamardME && !DisableSATDForRD: SATD, else SAD.  For bitDepth <= 10 the tiled kernel forms the SATD differences in 16 bits (as the
+                               reference's SIMD does): the original samples must lie in [-3072, 3071] -- picture samples or the bi-pred target 2*org - pred */
   uint8_t useAltHpelIf;     /* cu.imv == IMV_HPEL */
   uint8_t imvShift;         /* 0: half + quarter refinement; 1 (IMV_HPEL): half only */
   uint8_t bitDepth;

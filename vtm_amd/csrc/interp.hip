@@ -14,6 +14,7 @@
 // through the same FIR with taps {0,0,0,64,0,0,0,0}, which is arithmetically identical to filterCopy.
 // One wave per PU: window -> LDS once, 3 H passes per round (one per horizontal phase), 9 V passes + SATDs.
 #include "ctx.hpp"
+#include "had.hpp"
 
 namespace
 {
@@ -558,7 +559,30 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
       // |sum of taps| <= 112 and |plane sample| <= 32768: (acc >> shift) fits 16 bits, so the reference's Pel truncation is the identity here
       const int16_t *org = orgBase + j.orgOff + ( long ) ( ty * 8 ) * j.orgStride + tx * 8;
       unsigned       d;
-      if( j.useHad )
+      if( j.useHad && j.bitDepth <= 10 )
+      {
+        // 10-bit prediction and |org| <= 3071 (picture samples or the bi-pred target 2*org - pred): |diff| <= 4095, so the first three
+        // butterfly levels run on packed 16-bit words (the reference's own SIMD SATD is 16-bit for bitDepth <= 10, x86/RdCostX86.h:2157)
+        v2s D[8][4];
+#pragma unroll
+        for( int y = 0; y < 8; y++ )
+        {
+          const Pel8u o = *reinterpret_cast<const Pel8u *>( org + ( long ) y * j.orgStride );
+#pragma unroll
+          for( int k = 0; k < 4; k++ )
+          {
+            const unsigned p0 = ( unsigned ) min( pV.cmax, max( 0, acc[y * 8 + 2 * k] >> pV.shift ) );
+            const unsigned p1 = ( unsigned ) min( pV.cmax, max( 0, acc[y * 8 + 2 * k + 1] >> pV.shift ) );
+            const unsigned pw = p0 | ( p1 << 16 );
+            v2s ov, pv;
+            __builtin_memcpy( &ov, &o.v[k], 4 );
+            __builtin_memcpy( &pv, &pw, 4 );
+            D[y][k] = ov - pv;
+          }
+        }
+        d = satd8_packed( D );
+      }
+      else if( j.useHad )
       {
 #pragma unroll
         for( int y = 0; y < 8; y++ )
