@@ -341,6 +341,26 @@ int vtmhip_subtract_batch_dev( vtmhip_ctx *ctx, const int16_t *d_aBase, const in
 int vtmhip_add_avg_batch_dev( vtmhip_ctx *ctx, const int16_t *d_src0Base, const int16_t *d_src1Base, int16_t *d_dstBase,
                               const vtmhip_pelop_job *d_jobs, int n );
 
+/* InterpolationFilter::m_weightedGeoBlk (InterpolationFilter.h:99; xWeightedGeoBlk InterpolationFilter.cpp:902-957, x86/InterpolationFilterX86.h:1343-1470;
+ * callers InterPrediction::weightedGeoBlk InterPrediction.cpp:1642-1661, EncCu.cpp:3004,3030): blend of the two GEO partitions' 14-bit predictions,
+ *   dst = clip( ( w * src0 + (8 - w) * src1 + offset ) >> shift ),  shift = max(2, 14 - bitDepth) + 3,  offset = (1 << (shift-1)) + (8192 << 3),
+ * with w = weight[y * weightStride + x * stepX] in 0..8.  The caller (the trampoline that receives pu / splitDir) derives weight, stepX and
+ * weightStride from g_GeoParams / g_angle2mirror / g_weightOffset exactly as the reference does: stepX = +-1 (luma) or +-2 (4:2:0 chroma),
+ * weightStride = +-GEO_WEIGHT_MASK_SIZE << scaleY (the scalar version's `width * stepX + stepY`). */
+int vtmhip_weightedGeoBlk( vtmhip_ctx *ctx, const int16_t *src0, int src0Stride, const int16_t *src1, int src1Stride, int16_t *dst, int dstStride, int width,
+                           int height, const int16_t *weight, int stepX, int weightStride, int bitDepth, int clipMin, int clipMax );
+typedef struct
+{
+  int64_t src0Off, src1Off, dstOff;   /* samples inside d_srcBase / d_srcBase / d_dstBase */
+  int64_t weightOff;                  /* first weight (top-left output sample) inside d_weightBase */
+  int32_t src0Stride, src1Stride, dstStride, weightStride;
+  int16_t width, height, stepX, pad;
+} vtmhip_geo_blend_job;
+/* n GEO blends in one launch (e.g. every tested (split, candidate pair) of a CU, EncCu.cpp:2990-3035); d_weightBase: the g_globalGeoWeights planes,
+ * uploaded once */
+int vtmhip_weightedGeoBlk_batch_dev( vtmhip_ctx *ctx, const int16_t *d_srcBase, int16_t *d_dstBase, const int16_t *d_weightBase,
+                                     const vtmhip_geo_blend_job *d_jobs, int n, int bitDepth, int clipMin, int clipMax );
+
 /* ---- interpolation ----------------------------------------------------------------------------------------------- */
 typedef struct
 {

@@ -5,6 +5,7 @@
 // section 2 says a maintainer would:
 //   RdCost::m_afpDistortFunc[DF_SAD*, DF_HAD*, DF_SSE*, DF_SAD_WITH_MASK]  (RdCost.h:113, RdCost.cpp:125-217)
 //   InterpolationFilter::m_filterHor / m_filterVer / m_filterCopy    (InterpolationFilter.h:93-95) of EncLib's InterSearch
+//   InterpolationFilter::m_weightedGeoBlk                            (InterpolationFilter.h:99)
 //   fastFwdTrans / fastInvTrans                                      (TrQuant.cpp:69-81)
 // A hooked call is routed to the device through the C ABI of include/vtmhip.h; its result is what the encoder continues with
 // (replace mode), and it is also compared with the reference's own function on the same arguments.  Only every `stride`-th
@@ -62,6 +63,7 @@ struct Api
   decltype( &vtmhip_filterHor )    fhor;
   decltype( &vtmhip_filterVer )    fver;
   decltype( &vtmhip_filterCopy )   fcopy;
+  decltype( &vtmhip_weightedGeoBlk ) geo;
   decltype( &vtmhip_fastFwdTrans ) fwd;
   decltype( &vtmhip_fastInvTrans ) inv;
   decltype( &vtmhip_dev_alloc )    dalloc;
@@ -183,6 +185,32 @@ void ifCopyTramp( const ClpRng &c, Pel const *src, int ss, Pel *dst, int ds, int
   compare_block( 1, 900 + FIRST * 2 + LAST, w * 1000 + h, dst, ds, g_ifTmp.data(), w, w, h );
   for( int y = 0; y < h; y++ ) memcpy( dst + y * ds, g_ifTmp.data() + y * w, sizeof( Pel ) * w );
 }
+// m_weightedGeoBlk (InterpolationFilter.h:99): the trampoline derives the weight walk from the reference's GEO tables the way xWeightedGeoBlk does
+// (InterpolationFilter.cpp:925-945) and hands plain pointers to the C ABI
+typedef void ( *GeoFn )( const PredictionUnit &, const uint32_t, const uint32_t, const ComponentID, const uint8_t, PelUnitBuf &, PelUnitBuf &, PelUnitBuf & );
+GeoFn    g_geoOrig = nullptr;
+uint64_t g_geoCtr  = 0;
+void geoTramp( const PredictionUnit &pu, const uint32_t width, const uint32_t height, const ComponentID compIdx, const uint8_t splitDir, PelUnitBuf &predDst,
+               PelUnitBuf &predSrc0, PelUnitBuf &predSrc1 )
+{
+  g_st->calls[1]++;
+  g_geoOrig( pu, width, height, compIdx, splitDir, predDst, predSrc0, predSrc1 );
+  if( !sampled( g_geoCtr ) ) return;
+  const ClpRng &c = pu.cu->slice->clpRngs().comp[compIdx];
+  const int M = GEO_WEIGHT_MASK_SIZE, angle = g_GeoParams[splitDir][0], mirror = g_angle2mirror[angle];
+  const int wIdx = floorLog2( pu.lwidth() ) - GEO_MIN_CU_LOG2, hIdx = floorLog2( pu.lheight() ) - GEO_MIN_CU_LOG2;
+  const int ox = g_weightOffset[splitDir][hIdx][wIdx][0], oy = g_weightOffset[splitDir][hIdx][wIdx][1];
+  const int scX = getComponentScaleX( compIdx, pu.chromaFormat ), scY = getComponentScaleY( compIdx, pu.chromaFormat );
+  const int16_t *weight = g_globalGeoWeights[g_angle2mask[angle]] + ( mirror == 2 ? ( M - 1 - oy ) * M + ox : mirror == 1 ? oy * M + ( M - 1 - ox ) : oy * M + ox );
+  const int stepX = ( mirror == 1 ? -1 : 1 ) * ( 1 << scX ), wStride = ( mirror == 2 ? -M : M ) * ( 1 << scY );
+  const PelBuf &d = predDst.get( compIdx ), &a = predSrc0.get( compIdx ), &b = predSrc1.get( compIdx );
+  g_ifTmp.resize( size_t( width ) * height );
+  const int st = A.geo( g_ctx, a.buf, a.stride, b.buf, b.stride, g_ifTmp.data(), width, width, height, weight, stepX, wStride, c.bd, c.min, c.max );
+  if( st != VTMHIP_OK ) { note_error(); return; }
+  g_st->device[1]++;
+  compare_block( 1, 800 + compIdx, width * 1000 + height, d.buf, d.stride, g_ifTmp.data(), width, width, height );
+  for( uint32_t y = 0; y < height; y++ ) memcpy( d.buf + y * d.stride, g_ifTmp.data() + y * width, sizeof( Pel ) * width );
+}
 template<int VER, int TI> void installIfSlot( InterpolationFilter &f )
 {
   auto &tab = VER ? f.m_filterVer : f.m_filterHor;
@@ -199,6 +227,7 @@ void installIf( InterpolationFilter &f )
   g_ifCopyOrig[0][1] = f.m_filterCopy[0][1]; f.m_filterCopy[0][1] = ifCopyTramp<0, 1>;
   g_ifCopyOrig[1][0] = f.m_filterCopy[1][0]; f.m_filterCopy[1][0] = ifCopyTramp<1, 0>;
   g_ifCopyOrig[1][1] = f.m_filterCopy[1][1]; f.m_filterCopy[1][1] = ifCopyTramp<1, 1>;
+  g_geoOrig = f.m_weightedGeoBlk; f.m_weightedGeoBlk = geoTramp;
 }
 
 // ---- transforms ------------------------------------------------------------------------------------------------------------
@@ -381,7 +410,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
 {
   memset( stats, 0, sizeof( *stats ) );
   g_st = stats; g_stride = stride ? stride : 1; g_head = head; g_mask = familyMask; g_countOnly = ( familyMask & 8 ) != 0;
-  memset( g_distCtr, 0, sizeof( g_distCtr ) ); memset( g_ifCtr, 0, sizeof( g_ifCtr ) ); memset( g_ifCopyCtr, 0, sizeof( g_ifCopyCtr ) ); memset( g_trCtr, 0, sizeof( g_trCtr ) ); memset( g_auxCtr, 0, sizeof( g_auxCtr ) );
+  memset( g_distCtr, 0, sizeof( g_distCtr ) ); memset( g_ifCtr, 0, sizeof( g_ifCtr ) ); memset( g_ifCopyCtr, 0, sizeof( g_ifCopyCtr ) ); g_geoCtr = 0; memset( g_trCtr, 0, sizeof( g_trCtr ) ); memset( g_auxCtr, 0, sizeof( g_auxCtr ) );
   memset( g_distOrig, 0, sizeof( g_distOrig ) ); memset( g_fwdOrig, 0, sizeof( g_fwdOrig ) ); memset( g_invOrig, 0, sizeof( g_invOrig ) );
   if( vtmhipPath && !g_countOnly )
   {
@@ -389,7 +418,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
     if( !A.so ) { fprintf( stderr, "ref_encode: %s\n", dlerror() ); return -10; }
     const bool ok = sym( A.create, "vtmhip_create" ) && sym( A.destroy, "vtmhip_destroy" ) && sym( A.last_error, "vtmhip_last_error" ) && sym( A.sad, "vtmhip_xGetSAD" )
                  && sym( A.had, "vtmhip_xGetHADs" ) && sym( A.sse, "vtmhip_xGetSSE" ) && sym( A.sadmask, "vtmhip_xGetSADwMask" ) && sym( A.fhor, "vtmhip_filterHor" ) && sym( A.fver, "vtmhip_filterVer" )
-                 && sym( A.fcopy, "vtmhip_filterCopy" ) && sym( A.fwd, "vtmhip_fastFwdTrans" ) && sym( A.inv, "vtmhip_fastInvTrans" )
+                 && sym( A.fcopy, "vtmhip_filterCopy" ) && sym( A.geo, "vtmhip_weightedGeoBlk" ) && sym( A.fwd, "vtmhip_fastFwdTrans" ) && sym( A.inv, "vtmhip_fastInvTrans" )
                  && sym( A.dalloc, "vtmhip_dev_alloc" ) && sym( A.dfree, "vtmhip_dev_free" ) && sym( A.h2d, "vtmhip_h2d" ) && sym( A.d2h, "vtmhip_d2h" )
                  && sym( A.addAvg, "vtmhip_add_avg_batch_dev" ) && sym( A.rhf, "vtmhip_remove_high_freq_batch_dev" )
                  && sym( A.sobel, "vtmhip_affine_sobel_batch_dev" ) && sym( A.eqc, "vtmhip_affine_equal_coeff_batch_dev" );

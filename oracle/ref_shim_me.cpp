@@ -87,6 +87,12 @@ struct MeRig
 
 MeRig *g_rig = nullptr;
 
+void ensureRom()
+{
+  static bool romInit = false;
+  if( !romInit ) { initROM(); romInit = true; }
+}
+
 struct MeCtxC   // must match vo_me_ctx_t (oracle/vtm_oracle.h)
 {
   const int16_t *org; int orgStride; const int16_t *ref; int refStride; int w, h, subShift, bitDepth; unsigned imvShift;
@@ -223,9 +229,8 @@ extern "C" int ref_quant_dequant( const int32_t *coef, int w, int h, int bitDept
 {
   if( !g_rig ) g_rig = new MeRig();
   MeRig &r = *g_rig;
-  static bool   romInit = false;
   static Quant *quant   = nullptr;
-  if( !romInit ) { initROM(); romInit = true; }
+  ensureRom();
   if( !quant ) { quant = new Quant( nullptr ); quant->init( 64, false, false, false ); }
   r.sps.setBitDepth( CHANNEL_TYPE_LUMA, bitDepth );
   r.sps.setBitDepth( CHANNEL_TYPE_CHROMA, bitDepth );
@@ -390,6 +395,59 @@ extern "C" void ref_pred_inter_blk( int comp, const int16_t *planeY, int strideY
   PelUnitBuf dstPic( CHROMA_420, comp == 0 ? d : PelBuf(), comp == 1 ? d : PelBuf(), comp == 2 ? d : PelBuf() );
   r.is.xPredInterBlk( ComponentID( comp ), r.pu, pic, Mv( mvHor, mvVer ), dstPic, bi != 0, clp, false, false );
   r.cu.imv = 0;
+  r.cu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+  r.pu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// GEO blending: InterpolationFilter::m_weightedGeoBlk (x86, simd 1) / xWeightedGeoBlk (scalar, simd 0), CommonLib/InterpolationFilter.cpp:902-957.
+// ref_geo_walk gives what a device trampoline would pass on: which prestored plane, the first weight and the two steps, derived from the
+// reference's own tables (g_GeoParams, g_angle2mask, g_angle2mirror, g_weightOffset) the way those functions do.
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" void ref_geo_weights( int maskIdx, int16_t *out )
+{
+  ensureRom();
+  memcpy( out, g_globalGeoWeights[maskIdx], sizeof( int16_t ) * GEO_WEIGHT_MASK_SIZE * GEO_WEIGHT_MASK_SIZE );
+}
+
+extern "C" void ref_geo_walk( int splitDir, int comp, int lumaW, int lumaH, int out[4] )
+{
+  ensureRom();
+  const int  M = GEO_WEIGHT_MASK_SIZE;
+  const int  angle = g_GeoParams[splitDir][0], mirror = g_angle2mirror[angle];
+  const int  wIdx = floorLog2( lumaW ) - GEO_MIN_CU_LOG2, hIdx = floorLog2( lumaH ) - GEO_MIN_CU_LOG2;
+  const int  ox = g_weightOffset[splitDir][hIdx][wIdx][0], oy = g_weightOffset[splitDir][hIdx][wIdx][1];
+  const int  sc = comp ? 1 : 0;   // 4:2:0
+  out[0] = g_angle2mask[angle];
+  out[1] = mirror == 2 ? ( M - 1 - oy ) * M + ox : mirror == 1 ? oy * M + ( M - 1 - ox ) : oy * M + ox;
+  out[2] = ( mirror == 1 ? -1 : 1 ) * ( 1 << sc );
+  out[3] = ( mirror == 2 ? -M : M ) * ( 1 << sc );
+}
+
+extern "C" void ref_weighted_geo_blk( int simd, int splitDir, int comp, int lumaW, int lumaH, const int16_t *src0, int s0Stride, const int16_t *src1,
+                                      int s1Stride, int16_t *dst, int dstStride, int bitDepth )
+{
+  ensureRom();
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  const UnitArea ua( CHROMA_420, Area( 0, 0, lumaW, lumaH ) );
+  r.cu.UnitArea::operator=( ua );
+  r.pu.UnitArea::operator=( ua );
+  r.cu.chromaFormat = CHROMA_420;
+  r.pu.chromaFormat = CHROMA_420;
+  for( int c = 0; c < 3; c++ )
+  {
+    ClpRng &clp = r.slice.getClpRngs().comp[c];
+    clp.min = 0; clp.max = ( 1 << bitDepth ) - 1; clp.bd = bitDepth; clp.n = 0;
+  }
+  const int w = comp ? lumaW / 2 : lumaW, h = comp ? lumaH / 2 : lumaH;
+  auto mk = [&]( const int16_t *p, int stride ) {
+    PelBuf b( const_cast<Pel *>( p ), stride, w, h );
+    return PelUnitBuf( CHROMA_420, comp == 0 ? b : PelBuf(), comp == 1 ? b : PelBuf(), comp == 2 ? b : PelBuf() );
+  };
+  PelUnitBuf a = mk( src0, s0Stride ), b = mk( src1, s1Stride ), d = mk( dst, dstStride );
+  if( simd ) r.is.m_if.m_weightedGeoBlk( r.pu, w, h, ComponentID( comp ), uint8_t( splitDir ), d, a, b );
+  else       InterpolationFilter::xWeightedGeoBlk( r.pu, w, h, ComponentID( comp ), uint8_t( splitDir ), d, a, b );
   r.cu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
   r.pu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
 }

@@ -73,6 +73,27 @@ uint64_t vo_sad_mask( const int16_t *org, int orgStride, const int16_t *cur, int
   return sum << subShift;
 }
 
+/* InterpolationFilter::xWeightedGeoBlk (CommonLib/InterpolationFilter.cpp:902-957): blend of the two GEO partitions' 14-bit predictions with the
+ * 0..8 weights of one prestored mask plane.  The reference walks the plane with stepX per sample and stepY at the end of a row; here the
+ * row advance is given whole: weightStride = width * stepX + stepY (what the x86 version uses, x86/InterpolationFilterX86.h:1366-1389). */
+void vo_weighted_geo_blk( const int16_t *src0, int src0Stride, const int16_t *src1, int src1Stride, int16_t *dst, int dstStride, int w, int h,
+                          const int16_t *weight, int stepX, int weightStride, int bitDepth, int clipMin, int clipMax )
+{
+  const int headRoom = 14 - bitDepth > 2 ? 14 - bitDepth : 2;
+  const int shift    = headRoom + 3;
+  const int offset   = ( 1 << ( shift - 1 ) ) + ( 8192 << 3 );
+  for( int y = 0; y < h; y++ )
+  {
+    const int16_t *wr = weight + ( ptrdiff_t ) y * weightStride;
+    for( int x = 0; x < w; x++ )
+    {
+      const int wt = wr[( ptrdiff_t ) x * stepX];
+      const int v  = ( wt * ( int ) src0[( ptrdiff_t ) y * src0Stride + x] + ( 8 - wt ) * ( int ) src1[( ptrdiff_t ) y * src1Stride + x] + offset ) >> shift;
+      dst[( ptrdiff_t ) y * dstStride + x] = ( int16_t ) ( v < clipMin ? clipMin : v > clipMax ? clipMax : v );
+    }
+  }
+}
+
 /* RdCost::setDistParam subShift rule, CommonLib/RdCost.cpp:289-323 */
 int vo_subshift_for_mode( int w, int h, int subShiftMode )
 {

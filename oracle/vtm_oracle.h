@@ -63,6 +63,9 @@ typedef struct
 uint64_t vo_sad( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h, int subShift );
 uint64_t vo_sad_mask( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h, int subShift, const int16_t *mask,
                       int maskStride, int stepX, int maskStride2 );
+/* InterpolationFilter::xWeightedGeoBlk, CommonLib/InterpolationFilter.cpp:902-957 */
+void vo_weighted_geo_blk( const int16_t *src0, int src0Stride, const int16_t *src1, int src1Stride, int16_t *dst, int dstStride, int w, int h,
+                          const int16_t *weight, int stepX, int weightStride, int bitDepth, int clipMin, int clipMax );
 uint64_t vo_sse( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h );
 uint64_t vo_satd( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h );
 int      vo_satd_tile_shape( int w, int h, int *tw, int *th );

@@ -319,6 +319,32 @@ def gen_masked():
     print("masked:", len(meta), "cases")
 
 
+def gen_geo():
+    """InterpolationFilter::m_weightedGeoBlk (x86 entry) -- ref_weighted_geo_blk: the six prestored weight planes (data the reference builds in
+    initGeoTemplate), per case the walk a trampoline derives (ref_geo_walk), both 14-bit predictions and the blended block."""
+    M = 112
+    planes = np.zeros((6, M, M), np.int16)
+    for i in range(6):
+        R.ref_geo_weights(i, ol.P(planes[i]))
+    g = np.random.default_rng(909)
+    meta, s0s, s1s, outs = [], [], [], []
+    for k in range(128):
+        split = k % 64
+        lw, lh = int(g.choice([8, 16, 32, 64], p=[.3, .3, .25, .15])), int(g.choice([8, 16, 32, 64], p=[.3, .3, .25, .15]))
+        comp = k % 3 if k >= 64 else 0
+        w, h = (lw >> 1, lh >> 1) if comp else (lw, lh)
+        s0, s1 = ol.i16(g.integers(-8192, 8192 + 1023 * 16, (h, w))), ol.i16(g.integers(-8192, 8192 + 1023 * 16, (h, w)))
+        walk = (C.c_int * 4)()
+        R.ref_geo_walk(split, comp, lw, lh, walk)
+        dst = np.zeros((h, w), np.int16)
+        R.ref_weighted_geo_blk(1, split, comp, lw, lh, ol.P(s0), w, ol.P(s1), w, ol.P(dst), w, 10)
+        meta.append((split, comp, w, h) + tuple(walk))
+        s0s.append(s0.reshape(-1)); s1s.append(s1.reshape(-1)); outs.append(dst.reshape(-1))
+    np.savez_compressed(os.path.join(HERE, "geo.npz"), planes=planes, meta=np.array(meta, np.int32), src0=np.concatenate(s0s), src1=np.concatenate(s1s),
+                        out=np.concatenate(outs))
+    print("geo:", len(meta), "blends")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected fixtures only: gen_golden.py mest quant ...
         for name in sys.argv[1:]:
@@ -334,3 +360,4 @@ if __name__ == "__main__":
     gen_mest()
     gen_mc()
     gen_masked()
+    gen_geo()

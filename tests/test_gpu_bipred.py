@@ -264,3 +264,45 @@ def test_full_search_square_kernel_matches_oracle(ctx, size):
         got = [(r.mvX, r.mvY, r.cost, r.dist, r.nEval) for r in res]
         bad = [k for k in range(n) if got[k] != exp[k]]
         assert not bad, (signed, [(got[k], exp[k]) for k in bad[:5]])
+
+
+def test_geo_blend_matches_oracle(ctx):
+    """vtmhip_weightedGeoBlk / _batch_dev vs the oracle on synthetic weight planes: all four walk directions, chroma step 2, odd widths and unaligned
+    strides (scalar path of the kernel), 8- and 10-bit, a narrowed clip range."""
+    from vtm_amd.lib import GeoBlendJob
+    L = ol.oracle()
+    rng = np.random.default_rng(911)
+    M = 224
+    plane = ol.i16(rng.integers(0, 9, (M, M))).reshape(-1)
+    for bd, clip in ((10, (0, 1023)), (8, (0, 255)), (10, (64, 940))):
+        n = 200
+        jobs = (GeoBlendJob * n)()
+        srcs, exp, pos, spos = [], [], 0, 0
+        for k in range(n):
+            w = int(rng.choice([4, 8, 16, 32, 64, 6, 2])); h = int(rng.choice([4, 8, 16, 32, 64]))
+            pad0, pad1 = (0, 0) if k % 3 else (int(rng.integers(0, 5)), int(rng.integers(0, 5)))
+            s0 = ol.i16(rng.integers(-8192, 8192 + ((1 << bd) - 1) * (1 << (14 - bd)), (h, w + pad0)))
+            s1 = ol.i16(rng.integers(-8192, 8192 + ((1 << bd) - 1) * (1 << (14 - bd)), (h, w + pad1)))
+            sx = int(rng.choice([1, -1, 2, -2])); rd = int(rng.choice([1, -1])) * (2 if abs(sx) == 2 else 1)
+            x0 = (int(rng.integers(0, M - abs(sx) * w)) + (abs(sx) * (w - 1) if sx < 0 else 0))
+            y0 = (int(rng.integers(0, M - abs(rd) * h)) + (abs(rd) * (h - 1) if rd < 0 else 0))
+            off, ws = y0 * M + x0, rd * M
+            e = np.zeros((h, w), np.int16)
+            L.vo_weighted_geo_blk(ol.P(s0), w + pad0, ol.P(s1), w + pad1, ol.P(e), w, w, h, C.c_void_p(plane.ctypes.data + 2 * off), sx, ws, bd, clip[0], clip[1])
+            exp.append(e.reshape(-1))
+            if k < 40:
+                got = ctx.weightedGeoBlk(s0, s1, w, h, plane, off, sx, ws, bd, clip)
+                assert np.array_equal(got, e), (k, w, h, sx, rd, bd)
+            j = jobs[k]
+            j.src0Off, j.src0Stride = spos, w + pad0
+            spos += s0.size
+            j.src1Off, j.src1Stride = spos, w + pad1
+            spos += s1.size
+            j.dstOff, j.dstStride, j.weightOff, j.weightStride = pos, w, off, ws
+            j.width, j.height, j.stepX = w, h, sx
+            srcs += [s0.reshape(-1), s1.reshape(-1)]
+            pos += w * h
+        d_src, d_w = ctx.to_device(np.concatenate(srcs)), ctx.to_device(plane)
+        d_jobs, d_dst = ctx.to_device(np.frombuffer(jobs, np.uint8)), ctx.alloc(2 * pos)
+        ctx.weightedGeoBlk_batch(d_src.ptr, d_dst.ptr, d_w.ptr, d_jobs.ptr, n, bd, clip)
+        assert np.array_equal(d_dst.to_host(np.int16), np.concatenate(exp)), bd

@@ -121,3 +121,27 @@ def test_masked_sad_golden(ctx):
         cur = np.ascontiguousarray(z["cur"][pos:pos + w * h]).reshape(h, w)
         pos += w * h
         assert ctx.xGetSADwMask(org, w, cur, w, w, h, plane, off, ms, sx, ms2) == exp, (w, h, off, ms, sx, ms2)
+
+
+def test_geo_blend_golden(ctx):
+    """vtmhip_weightedGeoBlk (pointer surface) and the batched form vs the blocks recorded from the reference's m_weightedGeoBlk entry."""
+    from vtm_amd.lib import GeoBlendJob
+    z = np.load(os.path.join(G, "geo.npz"))
+    planes = np.ascontiguousarray(z["planes"]).reshape(-1)
+    meta = z["meta"].tolist()
+    jobs = (GeoBlendJob * len(meta))()
+    pos = 0
+    for k, (split, comp, w, h, mi, off, sx, ws) in enumerate(meta):
+        s0, s1 = (np.ascontiguousarray(z[n][pos:pos + w * h]).reshape(h, w) for n in ("src0", "src1"))
+        if k % 4 == 0:
+            got = ctx.weightedGeoBlk(s0, s1, w, h, planes, mi * 112 * 112 + off, sx, ws)
+            assert np.array_equal(got.reshape(-1), z["out"][pos:pos + w * h]), (split, comp, w, h)
+        j = jobs[k]
+        j.src0Off, j.src1Off, j.dstOff, j.weightOff = pos, len(z["src0"]) + pos, pos, mi * 112 * 112 + off
+        j.src0Stride = j.src1Stride = j.dstStride = w
+        j.weightStride, j.width, j.height, j.stepX = ws, w, h, sx
+        pos += w * h
+    d_src = ctx.to_device(np.concatenate([z["src0"], z["src1"]]))
+    d_w, d_jobs, d_dst = ctx.to_device(planes), ctx.to_device(np.frombuffer(jobs, np.uint8)), ctx.alloc(2 * pos)
+    ctx.weightedGeoBlk_batch(d_src.ptr, d_dst.ptr, d_w.ptr, d_jobs.ptr, len(meta))
+    assert np.array_equal(d_dst.to_host(np.int16), z["out"])

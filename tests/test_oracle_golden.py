@@ -171,3 +171,17 @@ def test_masked_sad_golden(oracle):
         pos += w * h
         got = oracle.vo_sad_mask(ol.P(org), w, ol.P(cur), w, w, h, 0, C.c_void_p(plane.ctypes.data + 2 * off), ms, sx, ms2)
         assert got == exp, (w, h, off, ms, sx, ms2)
+
+
+def test_geo_blend_golden(oracle):
+    """m_weightedGeoBlk blocks recorded from the reference's x86 entry (gen_golden.py gen_geo), incl. mirrored walks and 4:2:0 chroma steps."""
+    z = np.load(os.path.join(G, "geo.npz"))
+    planes = np.ascontiguousarray(z["planes"])
+    pos = 0
+    for split, comp, w, h, mi, off, sx, ws in z["meta"].tolist():
+        s0, s1 = np.ascontiguousarray(z["src0"][pos:pos + w * h]), np.ascontiguousarray(z["src1"][pos:pos + w * h])
+        exp = z["out"][pos:pos + w * h]
+        pos += w * h
+        got = np.zeros(w * h, np.int16)
+        oracle.vo_weighted_geo_blk(ol.P(s0), w, ol.P(s1), w, ol.P(got), w, w, h, C.c_void_p(planes[mi].ctypes.data + 2 * off), sx, ws, 10, 0, 1023)
+        assert np.array_equal(got, exp), (split, comp, w, h)

@@ -270,3 +270,30 @@ def test_masked_sad_equals_reference(oracle, reflib):
         b = reflib.ref_sad_mask(1, ol.P(org), org.shape[1], ol.P(cur), cur.shape[1], w, h, 10, mp, ms, sx, ms2)
         c = reflib.ref_sad_mask(0, ol.P(org), org.shape[1], ol.P(cur), cur.shape[1], w, h, 10, mp, ms, sx, ms2)
         assert a == b == c, (w, h, ms, sx, ms2)
+
+
+def test_geo_blend_equals_reference(oracle, reflib):
+    """vo_weighted_geo_blk vs InterpolationFilter::xWeightedGeoBlk (scalar) and the x86 m_weightedGeoBlk entry: every split direction, luma and
+    4:2:0 chroma, 8- and 10-bit; the walk comes from the reference's own GEO tables (ref_geo_walk)."""
+    M = 112
+    planes = np.zeros((6, M, M), np.int16)
+    for i in range(6):
+        reflib.ref_geo_weights(i, ol.P(planes[i]))
+    assert planes.min() == 0 and planes.max() == 8
+    rng = np.random.default_rng(910)
+    for split in range(64):
+        for k in range(6):
+            lw, lh = int(rng.choice([8, 16, 32, 64])), int(rng.choice([8, 16, 32, 64]))
+            comp, bd = k % 3, (8 if k == 5 else 10)
+            w, h = (lw >> 1, lh >> 1) if comp else (lw, lh)
+            s0 = ol.i16(rng.integers(-8192, 8192 + 1023 * 16, (h, w + 3)))
+            s1 = ol.i16(rng.integers(-8192, 8192 + 1023 * 16, (h, w + 5)))
+            walk = (C.c_int * 4)()
+            reflib.ref_geo_walk(split, comp, lw, lh, walk)
+            mi, off, sx, ws = list(walk)
+            a, b, c = (np.zeros((h, w), np.int16) for _ in range(3))
+            reflib.ref_weighted_geo_blk(0, split, comp, lw, lh, ol.P(s0), w + 3, ol.P(s1), w + 5, ol.P(a), w, bd)
+            reflib.ref_weighted_geo_blk(1, split, comp, lw, lh, ol.P(s0), w + 3, ol.P(s1), w + 5, ol.P(b), w, bd)
+            oracle.vo_weighted_geo_blk(ol.P(s0), w + 3, ol.P(s1), w + 5, ol.P(c), w, w, h, C.c_void_p(planes[mi].ctypes.data + 2 * off), sx, ws, bd, 0,
+                                       (1 << bd) - 1)
+            assert np.array_equal(a, b) and np.array_equal(a, c), (split, comp, lw, lh, bd)

@@ -31,6 +31,7 @@ int vtmhip_struct_size( int which )
   case 18: return ( int ) sizeof( vtmhip_pred_job );
   case 19: return ( int ) sizeof( vtmhip_frame_tabs );
   case 20: return ( int ) sizeof( vtmhip_masked_sad_job );
+  case 21: return ( int ) sizeof( vtmhip_geo_blend_job );
   default: return -1;
   }
 }

@@ -411,6 +411,55 @@ __global__ __launch_bounds__( 256 ) void pelop_kernel( const int16_t *__restrict
   }
 }
 
+
+// InterpolationFilter::xWeightedGeoBlk (InterpolationFilter.cpp:902-957): one wave per blend, four output samples per lane and step when the width
+// allows (8-byte loads of both predictions, the weights gathered one by one -- their walk may be mirrored or 2:1 sub-sampled)
+__global__ __launch_bounds__( 256 ) void geo_blend_kernel( const int16_t *__restrict__ srcBase, int16_t *__restrict__ dstBase, const int16_t *__restrict__ wBase,
+                                                          const vtmhip_geo_blend_job *__restrict__ jobs, int n, int shift, int offset, int cmin, int cmax )
+{
+  const int lane = threadIdx.x & 63;
+  const int job  = blockIdx.x * ( blockDim.x >> 6 ) + ( threadIdx.x >> 6 );
+  if( job >= n ) return;
+  const vtmhip_geo_blend_job j = jobs[job];
+  const int16_t *s0 = srcBase + j.src0Off, *s1 = srcBase + j.src1Off, *wt = wBase + j.weightOff;
+  int16_t       *d  = dstBase + j.dstOff;
+  const int      w = j.width, h = j.height, sx = j.stepX;
+  const bool     vec = ( w & 3 ) == 0 && ( ( j.src0Off | j.src1Off | j.dstOff | j.src0Stride | j.src1Stride | j.dstStride ) & 3 ) == 0;
+  if( vec )
+  {
+    const int qw = w >> 2;
+    for( int it = lane; it < qw * h; it += 64 )
+    {
+      const int   y = it / qw, x = ( it - y * qw ) << 2;
+      const uint2 a = *( const uint2 * ) ( s0 + ( long ) y * j.src0Stride + x ), b = *( const uint2 * ) ( s1 + ( long ) y * j.src1Stride + x );
+      const int16_t *wp = wt + ( long ) y * j.weightStride + ( long ) x * sx;
+      const int   av[4] = { ( int16_t ) a.x, ( int ) a.x >> 16, ( int16_t ) a.y, ( int ) a.y >> 16 };
+      const int   bv[4] = { ( int16_t ) b.x, ( int ) b.x >> 16, ( int16_t ) b.y, ( int ) b.y >> 16 };
+      int         o[4];
+#pragma unroll
+      for( int k = 0; k < 4; k++ )
+      {
+        const int wk = wp[k * sx];
+        o[k] = min( cmax, max( cmin, ( wk * av[k] + ( 8 - wk ) * bv[k] + offset ) >> shift ) );
+      }
+      uint2 r;
+      r.x = ( unsigned ) ( o[0] & 0xffff ) | ( ( unsigned ) o[1] << 16 );
+      r.y = ( unsigned ) ( o[2] & 0xffff ) | ( ( unsigned ) o[3] << 16 );
+      *( uint2 * ) ( d + ( long ) y * j.dstStride + x ) = r;
+    }
+  }
+  else
+  {
+    for( int it = lane; it < w * h; it += 64 )
+    {
+      const int y = it / w, x = it - y * w;
+      const int wk = wt[( long ) y * j.weightStride + ( long ) x * sx];
+      const int v  = wk * ( int ) s0[( long ) y * j.src0Stride + x] + ( 8 - wk ) * ( int ) s1[( long ) y * j.src1Stride + x] + offset;
+      d[( long ) y * j.dstStride + x] = ( int16_t ) min( cmax, max( cmin, v >> shift ) );
+    }
+  }
+}
+
 }   // namespace
 
 extern "C"
@@ -490,6 +539,73 @@ int vtmhip_add_avg_batch_dev( vtmhip_ctx *ctx, const int16_t *d_src0Base, const 
   VTMHIP_REQUIRE( ctx, d_src0Base && d_src1Base && d_dstBase && d_jobs, "null pointer" );
   hipLaunchKernelGGL( pelop_kernel, dim3( n ), dim3( 256 ), 0, ctx->stream, d_src0Base, d_src1Base, d_dstBase, d_jobs, 1 );
   VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+static int geo_blend_params( vtmhip_ctx *ctx, int bitDepth, int clipMin, int clipMax, int *shift, int *offset )
+{
+  VTMHIP_REQUIRE( ctx, bitDepth >= 8 && bitDepth <= 12, "bitDepth" );
+  VTMHIP_REQUIRE( ctx, clipMin >= 0 && clipMin <= clipMax && clipMax < ( 1 << bitDepth ), "clip range" );
+  *shift  = ( 14 - bitDepth > 2 ? 14 - bitDepth : 2 ) + 3;
+  *offset = ( 1 << ( *shift - 1 ) ) + ( 8192 << 3 );
+  return VTMHIP_OK;
+}
+
+int vtmhip_weightedGeoBlk_batch_dev( vtmhip_ctx *ctx, const int16_t *d_srcBase, int16_t *d_dstBase, const int16_t *d_weightBase,
+                                     const vtmhip_geo_blend_job *d_jobs, int n, int bitDepth, int clipMin, int clipMax )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_srcBase && d_dstBase && d_weightBase && d_jobs, "null pointer" );
+  int shift, offset;
+  int st = geo_blend_params( ctx, bitDepth, clipMin, clipMax, &shift, &offset );
+  if( st ) return st;
+  hipLaunchKernelGGL( geo_blend_kernel, dim3( ( n + 3 ) / 4 ), dim3( 256 ), 0, ctx->stream, d_srcBase, d_dstBase, d_weightBase, d_jobs, n, shift, offset, clipMin, clipMax );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_weightedGeoBlk( vtmhip_ctx *ctx, const int16_t *src0, int src0Stride, const int16_t *src1, int src1Stride, int16_t *dst, int dstStride, int width,
+                           int height, const int16_t *weight, int stepX, int weightStride, int bitDepth, int clipMin, int clipMax )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, src0 && src1 && dst && weight, "null pointer" );
+  VTMHIP_REQUIRE( ctx, width >= 1 && height >= 1 && width <= 128 && height <= 128, "block size must be 1..128" );
+  VTMHIP_REQUIRE( ctx, stepX != 0 && stepX >= -2 && stepX <= 2, "stepX must be +-1 or +-2" );
+  int shift, offset;
+  int st = geo_blend_params( ctx, bitDepth, clipMin, clipMax, &shift, &offset );
+  if( st ) return st;
+  // span of the weight plane the walk touches
+  long       lo = 0, hi = 0;
+  const long corners[4] = { 0, ( long ) ( width - 1 ) * stepX, ( long ) ( height - 1 ) * weightStride, ( long ) ( height - 1 ) * weightStride + ( long ) ( width - 1 ) * stepX };
+  for( long c : corners ) { lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
+  const size_t wN = ( size_t ) ( hi - lo + 1 );
+  VTMHIP_REQUIRE( ctx, wN <= ( size_t ) 1 << 22, "weight walk spans more than 4 M samples" );
+  const size_t blk = ( size_t ) width * height * sizeof( int16_t );
+  const size_t dstOff = ( 2 * blk + 63 ) & ~( size_t ) 63, wOff = ( dstOff + blk + 63 ) & ~( size_t ) 63, jobOff = ( wOff + wN * 2 + 63 ) & ~( size_t ) 63, total = jobOff + 64;
+  st = vtmhip_internal_scratch( ctx, total );
+  if( st ) return st;
+  char *hp = ( char * ) ctx->pinned, *dp = ( char * ) ctx->scratch;
+  for( int y = 0; y < height; y++ )
+  {
+    memcpy( hp + ( size_t ) y * width * 2, src0 + ( ptrdiff_t ) y * src0Stride, ( size_t ) width * 2 );
+    memcpy( hp + blk + ( size_t ) y * width * 2, src1 + ( ptrdiff_t ) y * src1Stride, ( size_t ) width * 2 );
+  }
+  memcpy( hp + wOff, weight + lo, wN * 2 );
+  vtmhip_geo_blend_job j;
+  memset( &j, 0, sizeof( j ) );
+  j.src0Off = 0; j.src1Off = ( int64_t ) width * height; j.dstOff = ( int64_t ) ( dstOff / 2 ); j.weightOff = ( int64_t ) ( wOff / 2 ) - lo;
+  j.src0Stride = j.src1Stride = j.dstStride = width; j.weightStride = weightStride;
+  j.width = ( int16_t ) width; j.height = ( int16_t ) height; j.stepX = ( int16_t ) stepX;
+  memcpy( hp + jobOff, &j, sizeof( j ) );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( dp, hp, total, hipMemcpyHostToDevice, ctx->stream ) );
+  hipLaunchKernelGGL( geo_blend_kernel, dim3( 1 ), dim3( 256 ), 0, ctx->stream, ( const int16_t * ) dp, ( int16_t * ) dp, ( const int16_t * ) dp,
+                      ( const vtmhip_geo_blend_job * ) ( dp + jobOff ), 1, shift, offset, clipMin, clipMax );
+  VTMHIP_LAUNCHED( ctx );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( hp + dstOff, dp + dstOff, blk, hipMemcpyDeviceToHost, ctx->stream ) );
+  VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  for( int y = 0; y < height; y++ ) memcpy( dst + ( ptrdiff_t ) y * dstStride, hp + dstOff + ( size_t ) y * width * 2, ( size_t ) width * 2 );
   return VTMHIP_OK;
 }
 

@@ -130,6 +130,18 @@ class Context:
     def masked_sad_batch(self, d_org, d_cur, d_mask, d_jobs, n, d_dist):
         self._check(self.L.vtmhip_masked_sad_batch_dev(self.h, d_org, d_cur, d_mask, d_jobs, n, d_dist))
 
+    def weightedGeoBlk(self, src0, src1, w, h, weight, weight_off, step_x, weight_stride, bit_depth=10, clip=None):
+        """m_weightedGeoBlk on host arrays (h x w int16 blocks); `weight` is a 1-D int16 array, weight_off the index of the first weight."""
+        clip = clip or (0, (1 << bit_depth) - 1)
+        dst = np.zeros((h, w), np.int16)
+        self._check(self.L.vtmhip_weightedGeoBlk(self.h, src0.ctypes.data, src0.strides[0] // 2, src1.ctypes.data, src1.strides[0] // 2, dst.ctypes.data, w,
+                                                 w, h, weight.ctypes.data + 2 * weight_off, step_x, weight_stride, bit_depth, clip[0], clip[1]))
+        return dst
+
+    def weightedGeoBlk_batch(self, d_src, d_dst, d_weight, d_jobs, n, bit_depth=10, clip=None):
+        clip = clip or (0, (1 << bit_depth) - 1)
+        self._check(self.L.vtmhip_weightedGeoBlk_batch_dev(self.h, d_src, d_dst, d_weight, d_jobs, n, bit_depth, clip[0], clip[1]))
+
     def filter(self, vertical, taps, is_first, is_last, src, src_off, src_stride, w, h, coeff, bit_depth=10, clip=None, bimc=0):
         """m_filterHor/m_filterVer[taps][isFirst][isLast] on a host array; returns the h x w int16 block."""
         clip = clip or (0, (1 << bit_depth) - 1)

@@ -146,8 +146,14 @@ class MaskedSadJob(C.Structure):
                 ("stepX", C.c_int16)]
 
 
+class GeoBlendJob(C.Structure):
+    _fields_ = [("src0Off", C.c_int64), ("src1Off", C.c_int64), ("dstOff", C.c_int64), ("weightOff", C.c_int64), ("src0Stride", C.c_int32),
+                ("src1Stride", C.c_int32), ("dstStride", C.c_int32), ("weightStride", C.c_int32), ("width", C.c_int16), ("height", C.c_int16),
+                ("stepX", C.c_int16), ("pad", C.c_int16)]
+
+
 _STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob,
-            TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut, PredJob, FrameTabs, MaskedSadJob]   # order of vtmhip_struct_size(which)
+            TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut, PredJob, FrameTabs, MaskedSadJob, GeoBlendJob]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
 _PROTOS = {
@@ -174,6 +180,9 @@ _PROTOS = {
     "vtmhip_xGetSADwMask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                       C.c_int, C.POINTER(C.c_uint64)]),
     "vtmhip_masked_sad_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vtmhip_weightedGeoBlk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vtmhip_weightedGeoBlk_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vtmhip_xGetSSE": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_uint64)]),
     "vtmhip_filterHor": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
