@@ -341,6 +341,15 @@ int vtmhip_subtract_batch_dev( vtmhip_ctx *ctx, const int16_t *d_aBase, const in
 int vtmhip_add_avg_batch_dev( vtmhip_ctx *ctx, const int16_t *d_src0Base, const int16_t *d_src1Base, int16_t *d_dstBase,
                               const vtmhip_pelop_job *d_jobs, int n );
 
+/* BDOF: InterPrediction::xPredInterBi with bioApplied for bi-predicted LUMA PUs (InterPrediction.cpp:527-660: xSubPuBio :352-443 cuts the PU into
+ * regions of at most 16 x 16, xPredInterBlk(..., bioApplied) :733-810 predicts each from both lists inside a ring of integer samples, and
+ * xWeightedAverage -> applyBiOptFlow :1233-1334 refines every 4 x 4 unit with g_pelBufOP.bioGradFilter / calcBIOSums / addBIOAvg4, Buffer.cpp:88-200).
+ * The job table is the one of vtmhip_motion_compensation_batch_dev: the caller sends here the PUs for which the reference sets bioApplied (:527-572:
+ * true bi-prediction with equal and opposite POC distances, w, h >= 8, w*h >= 128, no affine / SMVD / CIIP / BCW / weighted prediction); mode must be
+ * 2, chroma 0 (the chroma planes of such a PU take the plain addAvg path).  The epilogue and the NULL rules are those of that call. */
+int vtmhip_bdof_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, int16_t *d_predBase, int16_t *d_outBase,
+                           const vtmhip_pred_job *d_jobs, int n, int maxWidth, int maxHeight );
+
 /* InterpolationFilter::m_weightedGeoBlk (InterpolationFilter.h:99; xWeightedGeoBlk InterpolationFilter.cpp:902-957, x86/InterpolationFilterX86.h:1343-1470;
  * callers InterPrediction::weightedGeoBlk InterPrediction.cpp:1642-1661, EncCu.cpp:3004,3030): blend of the two GEO partitions' 14-bit predictions,
  *   dst = clip( ( w * src0 + (8 - w) * src1 + offset ) >> shift ),  shift = max(2, 14 - bitDepth) + 3,  offset = (1 << (shift-1)) + (8192 << 3),

@@ -451,3 +451,66 @@ extern "C" void ref_weighted_geo_blk( int simd, int splitDir, int comp, int luma
   r.cu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
   r.pu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// BDOF of one bi-predicted luma PU with the reference's own pieces: per region of at most 16 x 16 (the cut xSubPuBio makes,
+// InterPrediction.cpp:414-417) xPredInterBlk(..., bioApplied = true) for both lists (:660-810) and applyBiOptFlow (:1233-1334).
+// simd 0: scalar g_pelBufOP (Buffer.cpp:88-200), 1: the x86 entries (initPelBufOpsX86).  plane0 / plane1: origins of the two reference
+// luma planes (same stride and size).
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" void ref_bdof_pu( int simd, const int16_t *plane0, const int16_t *plane1, int stride, int picW, int picH, int puX, int puY, int w, int h,
+                             int mv0Hor, int mv0Ver, int mv1Hor, int mv1Ver, int bitDepth, int16_t *dst, int dstStride )
+{
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  static Picture *pic = nullptr;
+  static Pel     *dummy = nullptr;
+  if( !pic )
+  {
+    pic   = new Picture();
+    dummy = ( Pel * ) xMalloc( Pel, MAX_CU_SIZE * MAX_CU_SIZE );
+  }
+  if( !r.is.m_gradX0 )
+  {
+    r.is.m_gradX0 = ( Pel * ) xMalloc( Pel, BIO_TEMP_BUFFER_SIZE ); r.is.m_gradY0 = ( Pel * ) xMalloc( Pel, BIO_TEMP_BUFFER_SIZE );
+    r.is.m_gradX1 = ( Pel * ) xMalloc( Pel, BIO_TEMP_BUFFER_SIZE ); r.is.m_gradY1 = ( Pel * ) xMalloc( Pel, BIO_TEMP_BUFFER_SIZE );
+  }
+  const PelBufferOps saved = g_pelBufOP;
+  g_pelBufOP = PelBufferOps();
+  if( simd ) g_pelBufOP.initPelBufOpsX86();
+  r.pps.setPicWidthInLumaSamples( picW );
+  r.pps.setPicHeightInLumaSamples( picH );
+  r.cu.chromaFormat = CHROMA_420;
+  r.pu.chromaFormat = CHROMA_420;
+  r.cu.imv = 0;
+  pic->chromaFormat = CHROMA_420;
+  pic->unscaledPic  = pic;
+  ClpRng clp; clp.min = 0; clp.max = ( 1 << bitDepth ) - 1; clp.bd = bitDepth; clp.n = 0;
+  for( int c = 0; c < 3; c++ ) r.slice.getClpRngs().comp[c] = clp;
+  BitDepths bds; bds.recon[CHANNEL_TYPE_LUMA] = bds.recon[CHANNEL_TYPE_CHROMA] = bitDepth;
+  const Mv  mv[2] = { Mv( mv0Hor, mv0Ver ), Mv( mv1Hor, mv1Ver ) };
+  const int dx = std::min( ( int ) MAX_BDOF_APPLICATION_REGION, w ), dy = std::min( ( int ) MAX_BDOF_APPLICATION_REGION, h );
+  for( int y = 0; y < h; y += dy )
+  {
+    for( int x = 0; x < w; x += dx )
+    {
+      const UnitArea ua( CHROMA_420, Area( puX + x, puY + y, dx, dy ) );
+      r.cu.UnitArea::operator=( ua );
+      r.pu.UnitArea::operator=( ua );
+      PelUnitBuf scratch( CHROMA_420, PelBuf( dummy, dx, dx, dy ), PelBuf(), PelBuf() );
+      for( int l = 0; l < 2; l++ )
+      {
+        Pel *py = const_cast<Pel *>( l ? plane1 : plane0 );
+        pic->m_bufs[PIC_RECONSTRUCTION].createFromBuf( PelUnitBuf( CHROMA_420, PelBuf( py, stride, picW, picH ), PelBuf(), PelBuf() ) );
+        r.is.m_iRefListIdx = l;
+        r.is.xPredInterBlk( COMPONENT_Y, r.pu, pic, mv[l], scratch, true, clp, true, false );
+      }
+      PelUnitBuf  out( CHROMA_420, PelBuf( dst + y * dstStride + x, dstStride, dx, dy ), PelBuf(), PelBuf() );
+      CPelUnitBuf none0( CHROMA_420, CPelBuf( dummy, dx, dx, dy ), CPelBuf(), CPelBuf() ), none1( CHROMA_420, CPelBuf( dummy, dx, dx, dy ), CPelBuf(), CPelBuf() );
+      r.is.applyBiOptFlow( r.pu, none0, none1, 0, 0, out, bds );
+    }
+  }
+  g_pelBufOP = saved;
+  r.cu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+  r.pu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+}

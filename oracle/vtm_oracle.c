@@ -1242,6 +1242,110 @@ void vo_mc_block( int comp, const int16_t *ref, int refStride, int w, int h, int
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * BDOF (bi-directional optical flow) of one bi-predicted luma PU -- InterPrediction::xPredInterBi with bioApplied
+ * (CommonLib/InterPrediction.cpp:527-660): xSubPuBio (:352-443) cuts the PU into regions of at most 16 x 16, every region is predicted
+ * from both lists by xPredInterBlk(..., bioApplied) (:733-810: the 14-bit prediction plus a one-sample ring taken from the NEAREST
+ * INTEGER reference samples), and xWeightedAverage -> applyBiOptFlow (:1233-1334) refines each 4 x 4 unit with
+ * gradFilterCore / calcBIOSumsCore / addBIOAvgCore (CommonLib/Buffer.cpp:88-200).  ref0 / ref1 point at the PU position with MV (0,0).
+ * ------------------------------------------------------------------------------------------------ */
+static void vo_bdof_region( const int16_t *ref0, int stride0, const int16_t *ref1, int stride1, int w, int h, const int mv[2][2], int bitDepth,
+                            int16_t *dst, int dstStride )
+{
+  enum { S = 16 + 4, G = 16 + 2 };
+  int16_t   pred[2][S * S], gx[2][G * G], gy[2][G * G];
+  const int headRoom = 14 - bitDepth > 2 ? 14 - bitDepth : 2;
+  for( int l = 0; l < 2; l++ )
+  {
+    const int16_t *ref = l ? ref1 : ref0;
+    const int      rs = l ? stride1 : stride0;
+    int16_t       *P = pred[l];
+    /* interior at (2,2), stride S: xPredInterBlk redirects its output there (:733-741) */
+    vo_mc_block( 0, ref, rs, w, h, mv[l][0], mv[l][1], 1, bitDepth, 0, P + 2 * S + 2, S );
+    /* ring (:768-803): integer sample nearest to the fractional position, as 14-bit intermediate */
+    const int      xo = ( mv[l][0] & 15 ) < 8 ? 1 : 0, yo = ( mv[l][1] & 15 ) < 8 ? 1 : 0;
+    const int16_t *src = ref + ( ptrdiff_t )( mv[l][1] >> 4 ) * rs + ( mv[l][0] >> 4 );
+    for( int r = -1; r <= h; r++ )
+      for( int c = -1; c <= w; c++ )
+        if( r == -1 || r == h || c == -1 || c == w )
+          P[( r + 2 ) * S + c + 2] = ( int16_t )( ( src[( ptrdiff_t )( r + 1 - yo ) * rs + c + 1 - xo ] << headRoom ) - 8192 );
+    /* gradFilterCore<true> (Buffer.cpp:130-170) on the (w+2) x (h+2) window whose origin is the ring corner */
+    int16_t *X = gx[l], *Y = gy[l];
+    for( int y = 0; y < h; y++ )
+      for( int x = 0; x < w; x++ )
+      {
+        const int16_t *q = P + ( y + 2 ) * S + x + 2;
+        Y[( y + 1 ) * G + x + 1] = ( int16_t )( ( q[S] >> 6 ) - ( q[-S] >> 6 ) );
+        X[( y + 1 ) * G + x + 1] = ( int16_t )( ( q[1] >> 6 ) - ( q[-1] >> 6 ) );
+      }
+    for( int y = 1; y <= h; y++ )
+    {
+      X[y * G] = X[y * G + 1]; X[y * G + w + 1] = X[y * G + w];
+      Y[y * G] = Y[y * G + 1]; Y[y * G + w + 1] = Y[y * G + w];
+    }
+    for( int x = 0; x < w + 2; x++ )
+    {
+      X[x] = X[G + x]; X[( h + 1 ) * G + x] = X[h * G + x];
+      Y[x] = Y[G + x]; Y[( h + 1 ) * G + x] = Y[h * G + x];
+    }
+    /* applyBiOptFlow then replaces the ring of the prediction by its replicated border (:1266-1276) */
+    for( int y = 0; y < h; y++ )
+    {
+      P[( y + 2 ) * S + 1]     = P[( y + 2 ) * S + 2];
+      P[( y + 2 ) * S + w + 2] = P[( y + 2 ) * S + w + 1];
+    }
+    for( int x = 1; x < w + 3; x++ )
+    {
+      P[S + x]             = P[2 * S + x];
+      P[( h + 2 ) * S + x] = P[( h + 1 ) * S + x];
+    }
+  }
+  const int shiftNum = headRoom + 1, offset = ( 1 << ( shiftNum - 1 ) ) + 2 * 8192, limit = 15, cmax = ( 1 << bitDepth ) - 1;
+  for( int yu = 0; yu < ( h >> 2 ); yu++ )
+    for( int xu = 0; xu < ( w >> 2 ); xu++ )
+    {
+      int sumAbsGX = 0, sumAbsGY = 0, sumDIX = 0, sumDIY = 0, sumSignGYGX = 0;
+      for( int y = 0; y < 6; y++ )   /* calcBIOSumsCore (Buffer.cpp:173-200): 6 x 6 window around the unit */
+        for( int x = 0; x < 6; x++ )
+        {
+          const int gi = ( yu * 4 + y ) * G + xu * 4 + x, pi = ( yu * 4 + y + 1 ) * S + xu * 4 + x + 1;
+          const int tGX = ( gx[0][gi] + gx[1][gi] ) >> 1, tGY = ( gy[0][gi] + gy[1][gi] ) >> 1;
+          const int tDI = ( pred[1][pi] >> 4 ) - ( pred[0][pi] >> 4 );
+          sumAbsGX += tGX < 0 ? -tGX : tGX;
+          sumAbsGY += tGY < 0 ? -tGY : tGY;
+          sumDIX += tGX < 0 ? -tDI : tGX == 0 ? 0 : tDI;
+          sumDIY += tGY < 0 ? -tDI : tGY == 0 ? 0 : tDI;
+          sumSignGYGX += tGY < 0 ? -tGX : tGY == 0 ? 0 : tGX;
+        }
+      int tmpx = sumAbsGX == 0 ? 0 : ( sumDIX * 4 ) >> vo_floor_log2( ( unsigned ) sumAbsGX );   /* rightShiftMSB (:1606-1609) */
+      tmpx = tmpx < -limit ? -limit : tmpx > limit ? limit : tmpx;
+      const int mains = sumSignGYGX >> 12, secs = sumSignGYGX & 4095;
+      int       tmpData = tmpx * mains;
+      tmpData = ( tmpData * 4096 + tmpx * secs ) >> 1;
+      int tmpy = sumAbsGY == 0 ? 0 : ( sumDIY * 4 - tmpData ) >> vo_floor_log2( ( unsigned ) sumAbsGY );
+      tmpy = tmpy < -limit ? -limit : tmpy > limit ? limit : tmpy;
+      for( int y = 0; y < 4; y++ )   /* addBIOAvgCore (Buffer.cpp:88-127) */
+        for( int x = 0; x < 4; x++ )
+        {
+          const int gi = ( yu * 4 + y + 1 ) * G + xu * 4 + x + 1, pi = ( yu * 4 + y + 2 ) * S + xu * 4 + x + 2;
+          const int b  = tmpx * ( gx[0][gi] - gx[1][gi] ) + tmpy * ( gy[0][gi] - gy[1][gi] );
+          const int v  = ( int16_t )( ( pred[0][pi] + pred[1][pi] + b + offset ) >> shiftNum );
+          dst[( ptrdiff_t )( yu * 4 + y ) * dstStride + xu * 4 + x] = ( int16_t )( v < 0 ? 0 : v > cmax ? cmax : v );
+        }
+    }
+}
+
+void vo_bdof_pu( const int16_t *ref0, int stride0, const int16_t *ref1, int stride1, int w, int h, int mv0Hor, int mv0Ver, int mv1Hor, int mv1Ver,
+                 int bitDepth, int16_t *dst, int dstStride )
+{
+  const int mv[2][2] = { { mv0Hor, mv0Ver }, { mv1Hor, mv1Ver } };
+  const int dx = w < 16 ? w : 16, dy = h < 16 ? h : 16;   /* MAX_BDOF_APPLICATION_REGION, xSubPuBio :414-417 */
+  for( int y = 0; y < h; y += dy )
+    for( int x = 0; x < w; x += dx )
+      vo_bdof_region( ref0 + ( ptrdiff_t ) y * stride0 + x, stride0, ref1 + ( ptrdiff_t ) y * stride1 + x, stride1, dx, dy, mv, bitDepth,
+                      dst + ( ptrdiff_t ) y * dstStride + x, dstStride );
+}
+
+/* ------------------------------------------------------------------------------------------------
  * InterSearch::xMotionEstimation (EncoderLib/InterSearch.cpp:3299-3494) for one (PU, list, refIdx), without BCW,
  * weighted prediction, MCTS, composite references and the block-MV cache (none is on in the CTC), with
  * xPatternSearchIntRefine (:4172-4282) for the integer / 4-sample AMVR modes.  Composition of the pinned stages

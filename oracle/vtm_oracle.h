@@ -63,6 +63,9 @@ typedef struct
 uint64_t vo_sad( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h, int subShift );
 uint64_t vo_sad_mask( const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h, int subShift, const int16_t *mask,
                       int maskStride, int stepX, int maskStride2 );
+/* BDOF of one bi-predicted luma PU: xSubPuBio + xPredInterBlk(bioApplied) + applyBiOptFlow, CommonLib/InterPrediction.cpp:352-443, 733-810, 1233-1334 */
+void vo_bdof_pu( const int16_t *ref0, int stride0, const int16_t *ref1, int stride1, int w, int h, int mv0Hor, int mv0Ver, int mv1Hor, int mv1Ver,
+                 int bitDepth, int16_t *dst, int dstStride );
 /* InterpolationFilter::xWeightedGeoBlk, CommonLib/InterpolationFilter.cpp:902-957 */
 void vo_weighted_geo_blk( const int16_t *src0, int src0Stride, const int16_t *src1, int src1Stride, int16_t *dst, int dstStride, int w, int h,
                           const int16_t *weight, int stepX, int weightStride, int bitDepth, int clipMin, int clipMax );

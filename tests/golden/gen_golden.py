@@ -345,6 +345,37 @@ def gen_geo():
     print("geo:", len(meta), "blends")
 
 
+def gen_bdof():
+    """BDOF of bi-predicted luma PUs through the reference's own xPredInterBlk(bioApplied) + applyBiOptFlow with the x86 buffer ops (ref_bdof_pu):
+    two padded reference planes, per PU position / size / both vectors, and the refined prediction."""
+    from vtm_amd import synth
+    W, H, M = 160, 96, 40
+    fr = list(synth.gen_frames(W, H, 3, seed=21))
+    planes = [np.ascontiguousarray(np.pad(f.astype(np.int16), M, mode="edge")) for f in (fr[0], fr[2])]
+    S = planes[0].shape[1]
+    org = [C.c_void_p(p.ctypes.data + 2 * (M * S + M)) for p in planes]
+    g = np.random.default_rng(1010)
+    meta, outs = [], []
+    sizes = [(8, 16), (16, 8), (16, 16), (32, 16), (16, 32), (32, 32), (64, 32), (64, 64), (128, 64), (8, 64)]
+    for k in range(40):
+        w, h = sizes[k % len(sizes)]
+        x, y = int(g.integers(0, (W - w) // 4 + 1)) * 4, int(g.integers(0, (H - h) // 4 + 1)) * 4
+        mv = [int(v) for v in g.integers(-400, 400, 4)]
+        if k % 5 == 0:
+            mv[0] &= ~15
+        if k % 7 == 0:
+            mv[3] &= ~15
+        if k % 9 == 0:
+            mv = [v & ~15 for v in mv]
+        dst = np.zeros((h, w), np.int16)
+        R.ref_bdof_pu(1, org[0], org[1], S, W, H, x, y, w, h, *mv, 10, ol.P(dst), w)
+        meta.append((x, y, w, h, *mv))
+        outs.append(dst.reshape(-1))
+    np.savez_compressed(os.path.join(HERE, "bdof.npz"), planes=np.stack(planes), dims=np.array([W, H, M], np.int32), meta=np.array(meta, np.int32),
+                        out=np.concatenate(outs))
+    print("bdof:", len(meta), "PUs")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected fixtures only: gen_golden.py mest quant ...
         for name in sys.argv[1:]:
@@ -361,3 +392,4 @@ if __name__ == "__main__":
     gen_mc()
     gen_masked()
     gen_geo()
+    gen_bdof()

@@ -306,3 +306,57 @@ def test_geo_blend_matches_oracle(ctx):
         d_jobs, d_dst = ctx.to_device(np.frombuffer(jobs, np.uint8)), ctx.alloc(2 * pos)
         ctx.weightedGeoBlk_batch(d_src.ptr, d_dst.ptr, d_w.ptr, d_jobs.ptr, n, bd, clip)
         assert np.array_equal(d_dst.to_host(np.int16), np.concatenate(exp)), bd
+
+
+def test_bdof_matches_oracle(ctx):
+    """vtmhip_bdof_batch_dev vs vo_bdof_pu: every PU size class the reference enables BDOF for, integer / half / mixed phases on either list,
+    8- and 10-bit, prediction and both fused epilogues."""
+    from vtm_amd import synth
+    from vtm_amd.lib import PredJob
+    L = ol.oracle()
+    W, H, M = 256, 192, 48
+    fr = list(synth.gen_frames(W, H, 3, seed=9))
+    rng = np.random.default_rng(1012)
+    for bd in (10, 8):
+        planes = [np.ascontiguousarray(np.pad((f >> (10 - bd)).astype(np.int16), M, mode="edge")) for f in (fr[0], fr[2])]
+        org = np.ascontiguousarray((fr[1] >> (10 - bd)).astype(np.int16))
+        S, plane_sz = planes[0].shape[1], planes[0].size
+        n = 150
+        jobs = (PredJob * n)()
+        exp_pred, exp_out, pos = [], [], 0
+        for k in range(n):
+            w, h = int(rng.choice([8, 16, 32, 64, 128])), int(rng.choice([8, 16, 32, 64, 128]))
+            if w * h < 128:
+                w = 16
+            x, y = int(rng.integers(0, (W - w) // 4 + 1)) * 4, int(rng.integers(0, (H - h) // 4 + 1)) * 4
+            mv = [int(v) for v in rng.integers(-500, 500, 4)]
+            if k % 5 == 0:
+                mv[k % 4] &= ~15
+            if k % 13 == 0:
+                mv = [v & ~15 for v in mv]
+            if k % 17 == 0:
+                mv = [(v & ~15) | 8 for v in mv]
+            e = np.zeros((h, w), np.int16)
+            at = [C.c_void_p(p.ctypes.data + 2 * ((y + M) * S + x + M)) for p in planes]
+            L.vo_bdof_pu(at[0], S, at[1], S, w, h, *mv, bd, ol.P(e), w)
+            j = jobs[k]
+            for l in range(2):
+                j.refOff[l], j.refStride[l] = l * plane_sz + (M + y) * S + M + x, S
+            j.mv[0][0], j.mv[0][1], j.mv[1][0], j.mv[1][1] = mv
+            j.orgOff, j.orgStride = y * W + x, W
+            j.predOff = j.outOff = pos
+            j.predStride = j.outStride = w
+            j.width, j.height, j.mode, j.bitDepth, j.epilogue = w, h, 2, bd, 1 + k % 2
+            o = org[y:y + h, x:x + w].astype(np.int32)
+            exp_pred.append(e.reshape(-1))
+            exp_out.append(((o if j.epilogue == 1 else 2 * o) - e).astype(np.int16).reshape(-1))
+            pos += w * h
+        d_ref = ctx.to_device(np.concatenate([p.reshape(-1) for p in planes]))
+        d_org, d_jobs = ctx.to_device(org.reshape(-1)), ctx.to_device(np.frombuffer(jobs, np.uint8))
+        d_pred, d_out = ctx.alloc(2 * pos), ctx.alloc(2 * pos)
+        ctx.bdof_batch(d_org.ptr, d_ref.ptr, d_pred.ptr, d_out.ptr, d_jobs.ptr, n, 128, 128)
+        assert np.array_equal(d_pred.to_host(np.int16), np.concatenate(exp_pred)), bd
+        assert np.array_equal(d_out.to_host(np.int16), np.concatenate(exp_out)), bd
+        d_pred2 = ctx.alloc(2 * pos)
+        ctx.bdof_batch(0, d_ref.ptr, d_pred2.ptr, 0, d_jobs.ptr, n, 128, 128)   # prediction only
+        assert np.array_equal(d_pred2.to_host(np.int16), np.concatenate(exp_pred)), bd

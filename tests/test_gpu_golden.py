@@ -145,3 +145,25 @@ def test_geo_blend_golden(ctx):
     d_w, d_jobs, d_dst = ctx.to_device(planes), ctx.to_device(np.frombuffer(jobs, np.uint8)), ctx.alloc(2 * pos)
     ctx.weightedGeoBlk_batch(d_src.ptr, d_dst.ptr, d_w.ptr, d_jobs.ptr, len(meta))
     assert np.array_equal(d_dst.to_host(np.int16), z["out"])
+
+
+def test_bdof_golden(ctx):
+    """vtmhip_bdof_batch_dev vs the BDOF predictions recorded from the reference."""
+    from vtm_amd.lib import PredJob
+    z = np.load(os.path.join(G, "bdof.npz"))
+    planes = np.ascontiguousarray(z["planes"])
+    W, H, M = z["dims"].tolist()
+    S, plane_sz = planes.shape[2], planes.shape[1] * planes.shape[2]
+    meta = z["meta"].tolist()
+    jobs = (PredJob * len(meta))()
+    pos = 0
+    for k, (x, y, w, h, a, b, c, d) in enumerate(meta):
+        j = jobs[k]
+        for l in range(2):
+            j.refOff[l], j.refStride[l] = l * plane_sz + (M + y) * S + M + x, S
+        j.mv[0][0], j.mv[0][1], j.mv[1][0], j.mv[1][1] = a, b, c, d
+        j.predOff, j.predStride, j.width, j.height, j.mode, j.bitDepth = pos, w, w, h, 2, 10
+        pos += w * h
+    d_ref, d_jobs, d_pred = ctx.to_device(planes.reshape(-1)), ctx.to_device(np.frombuffer(jobs, np.uint8)), ctx.alloc(2 * pos)
+    ctx.bdof_batch(0, d_ref.ptr, d_pred.ptr, 0, d_jobs.ptr, len(meta), 128, 128)
+    assert np.array_equal(d_pred.to_host(np.int16), z["out"])

@@ -185,3 +185,18 @@ def test_geo_blend_golden(oracle):
         got = np.zeros(w * h, np.int16)
         oracle.vo_weighted_geo_blk(ol.P(s0), w, ol.P(s1), w, ol.P(got), w, w, h, C.c_void_p(planes[mi].ctypes.data + 2 * off), sx, ws, 10, 0, 1023)
         assert np.array_equal(got, exp), (split, comp, w, h)
+
+
+def test_bdof_golden(oracle):
+    """BDOF predictions recorded from the reference (gen_golden.py gen_bdof: xPredInterBlk(bioApplied) + applyBiOptFlow, x86 buffer ops)."""
+    z = np.load(os.path.join(G, "bdof.npz"))
+    planes = np.ascontiguousarray(z["planes"])
+    W, H, M = z["dims"].tolist()
+    S = planes.shape[2]
+    pos = 0
+    for x, y, w, h, a, b, c, d in z["meta"].tolist():
+        got = np.zeros((h, w), np.int16)
+        o = [C.c_void_p(planes[l].ctypes.data + 2 * ((M + y) * S + M + x)) for l in range(2)]
+        oracle.vo_bdof_pu(o[0], S, o[1], S, w, h, a, b, c, d, 10, ol.P(got), w)
+        assert np.array_equal(got.reshape(-1), z["out"][pos:pos + w * h]), (x, y, w, h, a, b, c, d)
+        pos += w * h

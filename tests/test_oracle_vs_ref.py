@@ -297,3 +297,41 @@ def test_geo_blend_equals_reference(oracle, reflib):
             oracle.vo_weighted_geo_blk(ol.P(s0), w + 3, ol.P(s1), w + 5, ol.P(c), w, w, h, C.c_void_p(planes[mi].ctypes.data + 2 * off), sx, ws, bd, 0,
                                        (1 << bd) - 1)
             assert np.array_equal(a, b) and np.array_equal(a, c), (split, comp, lw, lh, bd)
+
+
+def test_bdof_equals_reference(oracle, reflib):
+    """vo_bdof_pu vs the reference's xPredInterBlk(bioApplied) + applyBiOptFlow, with the scalar and with the x86 buffer ops; the refinement must
+    actually move samples (differs from the plain bi-prediction average on this content)."""
+    from vtm_amd import synth
+    W, H, M = 192, 128, 48
+    fr = list(synth.gen_frames(W, H, 3, seed=5))
+    p0, p1 = (np.ascontiguousarray(np.pad(f.astype(np.int16), M, mode="edge")) for f in (fr[0], fr[2]))
+    S = p0.shape[1]
+
+    def at(p, x, y):
+        return C.c_void_p(p.ctypes.data + 2 * ((y + M) * S + x + M))
+    rng = np.random.default_rng(1011)
+    moved = 0
+    for k in range(120):
+        w, h = int(rng.choice([8, 16, 32, 64, 128])), int(rng.choice([8, 16, 32, 64, 128]))
+        if w * h < 128:
+            continue
+        x, y = int(rng.integers(0, (W - w) // 4 + 1)) * 4, int(rng.integers(0, (H - h) // 4 + 1)) * 4
+        mv = [int(v) for v in rng.integers(-500, 500, 4)]
+        if k % 6 == 0:
+            mv[k % 4] &= ~15
+        bd = 8 if k % 10 == 9 else 10
+        q0, q1 = (p0 >> 2, p1 >> 2) if bd == 8 else (p0, p1)
+        q0, q1 = np.ascontiguousarray(q0), np.ascontiguousarray(q1)
+        a, b, c, avg = (np.zeros((h, w), np.int16) for _ in range(4))
+        reflib.ref_bdof_pu(0, at(q0, 0, 0), at(q1, 0, 0), S, W, H, x, y, w, h, *mv, bd, ol.P(a), w)
+        reflib.ref_bdof_pu(1, at(q0, 0, 0), at(q1, 0, 0), S, W, H, x, y, w, h, *mv, bd, ol.P(b), w)
+        oracle.vo_bdof_pu(at(q0, x, y), S, at(q1, x, y), S, w, h, *mv, bd, ol.P(c), w)
+        assert np.array_equal(a, b) and np.array_equal(a, c), (k, x, y, w, h, mv, bd)
+        t0, t1 = np.zeros((h, w), np.int16), np.zeros((h, w), np.int16)
+        oracle.vo_mc_block(0, at(q0, x, y), S, w, h, mv[0], mv[1], 1, bd, 0, ol.P(t0), w)
+        oracle.vo_mc_block(0, at(q1, x, y), S, w, h, mv[2], mv[3], 1, bd, 0, ol.P(t1), w)
+        sh = max(2, 14 - bd) + 1
+        avg = np.clip((t0.astype(np.int32) + t1 + (1 << (sh - 1)) + 2 * 8192) >> sh, 0, (1 << bd) - 1)
+        moved += int(np.count_nonzero(avg != c))
+    assert moved > 1000

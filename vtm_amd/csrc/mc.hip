@@ -412,6 +412,142 @@ __global__ __launch_bounds__( 256 ) void pelop_kernel( const int16_t *__restrict
 }
 
 
+// ---- BDOF: xPredInterBi with bioApplied (InterPrediction.cpp:527-660) for a bi-predicted luma PU.  One wave per region of at most 16 x 16 (the cut
+// xSubPuBio makes, :414-417): both 14-bit predictions go to LDS inside a one-sample ring of nearest-integer reference samples (xPredInterBlk
+// :733-810), gradients as gradFilterCore (Buffer.cpp:130-170), then per 4 x 4 unit the 6 x 6 sums of calcBIOSumsCore (:173-200), the clipped
+// refinement (applyBiOptFlow :1296-1318) and addBIOAvgCore (:88-127).  Four lanes share a unit (9 window samples each, then one output row each).
+struct StorePad   // prediction interior at (2,2) of a [h+4][BDOF_S] tile
+{
+  int16_t *p; int stride;
+  __device__ __forceinline__ void operator()( int y, int x, int16_t v ) const { p[( y + 2 ) * stride + x + 2] = v; }
+  __device__ __forceinline__ void vec( int y, int x0, const int v[8] ) const
+  {
+    unsigned *q = reinterpret_cast<unsigned *>( p + ( y + 2 ) * stride + x0 + 2 );   // even sample index: 4-byte aligned
+    const uint4 u = pack8( v );
+    q[0] = u.x; q[1] = u.y; q[2] = u.z; q[3] = u.w;
+  }
+};
+
+constexpr int BDOF_S = 20, BDOF_G = 18;
+
+__global__ __launch_bounds__( 64 ) void bdof_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase, int16_t *__restrict__ predBase,
+                                                    int16_t *__restrict__ outBase, const vtmhip_pred_job *__restrict__ jobs )
+{
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t tmp[16 * ( 16 + 7 )];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sPred[2][BDOF_S * BDOF_S];
+  __shared__ int16_t sGx[2][BDOF_G * BDOF_G], sGy[2][BDOF_G * BDOF_G];
+  const vtmhip_pred_job j = jobs[blockIdx.y];
+  const int lane = threadIdx.x;
+  const int dx = min( 16, ( int ) j.width ), dy = min( 16, ( int ) j.height ), perRow = j.width / dx;
+  const int region = blockIdx.x;
+  if( region >= perRow * ( j.height / dy ) ) return;
+  const int ry = ( region / perRow ) * dy, rx = ( region % perRow ) * dx;
+  const int bd = j.bitDepth, headRoom = max( 2, 14 - bd );
+  vtmhip_mc_job m;
+  m.width = ( int16_t ) dx; m.height = ( int16_t ) dy; m.bitDepth = j.bitDepth; m.useAltHpelIf = 0; m.chroma = 0; m.bi = 1;
+  m.dstOff = 0; m.dstStride = 0;
+#pragma unroll
+  for( int l = 0; l < 2; l++ )
+  {
+    int16_t *P = sPred[l], *X = sGx[l], *Y = sGy[l];
+    m.refOff = ( l ? j.refOff[1] : j.refOff[0] ) + ( long ) ry * ( l ? j.refStride[1] : j.refStride[0] ) + rx;
+    m.refStride = l ? j.refStride[1] : j.refStride[0];
+    m.mvHor = l ? j.mv[1][0] : j.mv[0][0]; m.mvVer = l ? j.mv[1][1] : j.mv[0][1];
+    mc_any<64>( m, refBase, tmp, lane, StorePad{ P, BDOF_S } );
+    // ring: the integer sample nearest to the fractional position, as a 14-bit intermediate (:768-803)
+    const int16_t *src = refBase + m.refOff + ( long ) ( ( m.mvVer >> 4 ) + ( ( m.mvVer & 15 ) < 8 ? 0 : 1 ) ) * m.refStride + ( m.mvHor >> 4 ) + ( ( m.mvHor & 15 ) < 8 ? 0 : 1 );
+    for( int i = lane; i < 2 * ( dx + 2 ) + 2 * dy; i += 64 )
+    {
+      int r, c;
+      if( i < 2 * ( dx + 2 ) ) { r = i < dx + 2 ? -1 : dy; c = ( i < dx + 2 ? i : i - ( dx + 2 ) ) - 1; }
+      else { const int t = i - 2 * ( dx + 2 ); r = t >> 1; c = ( t & 1 ) ? dx : -1; }
+      P[( r + 2 ) * BDOF_S + c + 2] = ( int16_t ) ( ( ( int ) src[( long ) r * m.refStride + c] << headRoom ) - 8192 );
+    }
+    block_sync<64>();
+    for( int i = lane; i < dx * dy; i += 64 )
+    {
+      const int      y = i / dx, x = i - y * dx;
+      const int16_t *q = P + ( y + 2 ) * BDOF_S + x + 2;
+      Y[( y + 1 ) * BDOF_G + x + 1] = ( int16_t ) ( ( q[BDOF_S] >> 6 ) - ( q[-BDOF_S] >> 6 ) );
+      X[( y + 1 ) * BDOF_G + x + 1] = ( int16_t ) ( ( q[1] >> 6 ) - ( q[-1] >> 6 ) );
+    }
+    block_sync<64>();
+    // replicate the borders: gradients (gradFilterCore PAD part), then the prediction's ring (applyBiOptFlow :1266-1276) -- columns first, rows after
+    for( int y = lane; y < dy; y += 64 )
+    {
+      X[( y + 1 ) * BDOF_G] = X[( y + 1 ) * BDOF_G + 1]; X[( y + 1 ) * BDOF_G + dx + 1] = X[( y + 1 ) * BDOF_G + dx];
+      Y[( y + 1 ) * BDOF_G] = Y[( y + 1 ) * BDOF_G + 1]; Y[( y + 1 ) * BDOF_G + dx + 1] = Y[( y + 1 ) * BDOF_G + dx];
+      P[( y + 2 ) * BDOF_S + 1] = P[( y + 2 ) * BDOF_S + 2]; P[( y + 2 ) * BDOF_S + dx + 2] = P[( y + 2 ) * BDOF_S + dx + 1];
+    }
+    block_sync<64>();
+    for( int x = lane; x < dx + 2; x += 64 )
+    {
+      X[x] = X[BDOF_G + x]; X[( dy + 1 ) * BDOF_G + x] = X[dy * BDOF_G + x];
+      Y[x] = Y[BDOF_G + x]; Y[( dy + 1 ) * BDOF_G + x] = Y[dy * BDOF_G + x];
+      P[BDOF_S + x + 1] = P[2 * BDOF_S + x + 1]; P[( dy + 2 ) * BDOF_S + x + 1] = P[( dy + 1 ) * BDOF_S + x + 1];
+    }
+    block_sync<64>();
+  }
+  const int unitsX = dx >> 2, units = unitsX * ( dy >> 2 );
+  const int u = lane >> 2, q = lane & 3;
+  const bool live = u < units;
+  const int yu = live ? u / unitsX : 0, xu = live ? u - yu * unitsX : 0;
+  int sAbsGX = 0, sAbsGY = 0, sDIX = 0, sDIY = 0, sSign = 0;
+  if( live )
+  {
+#pragma unroll
+    for( int t = 0; t < 9; t++ )
+    {
+      const int k = q + 4 * t, wy = k / 6, wx = k - wy * 6;
+      const int gi = ( yu * 4 + wy ) * BDOF_G + xu * 4 + wx, pi = ( yu * 4 + wy + 1 ) * BDOF_S + xu * 4 + wx + 1;
+      const int tGX = ( ( int ) sGx[0][gi] + ( int ) sGx[1][gi] ) >> 1, tGY = ( ( int ) sGy[0][gi] + ( int ) sGy[1][gi] ) >> 1;
+      const int tDI = ( ( int ) sPred[1][pi] >> 4 ) - ( ( int ) sPred[0][pi] >> 4 );
+      sAbsGX += abs( tGX ); sAbsGY += abs( tGY );
+      sDIX += tGX < 0 ? -tDI : tGX == 0 ? 0 : tDI;
+      sDIY += tGY < 0 ? -tDI : tGY == 0 ? 0 : tDI;
+      sSign += tGY < 0 ? -tGX : tGY == 0 ? 0 : tGX;
+    }
+  }
+#pragma unroll
+  for( int o = 1; o <= 2; o <<= 1 )
+  {
+    sAbsGX += __shfl_xor( sAbsGX, o, 64 ); sAbsGY += __shfl_xor( sAbsGY, o, 64 ); sDIX += __shfl_xor( sDIX, o, 64 );
+    sDIY += __shfl_xor( sDIY, o, 64 ); sSign += __shfl_xor( sSign, o, 64 );
+  }
+  if( !live ) return;
+  int tmpx = sAbsGX == 0 ? 0 : ( sDIX * 4 ) >> ( 31 - __clz( sAbsGX ) );   // rightShiftMSB (:1606-1609)
+  tmpx = min( 15, max( -15, tmpx ) );
+  const int mains = sSign >> 12, secs = sSign & 4095;
+  const int tmpData = ( tmpx * mains * 4096 + tmpx * secs ) >> 1;
+  int tmpy = sAbsGY == 0 ? 0 : ( sDIY * 4 - tmpData ) >> ( 31 - __clz( sAbsGY ) );
+  tmpy = min( 15, max( -15, tmpy ) );
+  const int shiftNum = headRoom + 1, offset = ( 1 << ( shiftNum - 1 ) ) + 2 * 8192, cmax = ( 1 << bd ) - 1;
+  const int y = yu * 4 + q;   // lane q of the unit writes its row q
+  int v[4];
+#pragma unroll
+  for( int x = 0; x < 4; x++ )
+  {
+    const int gi = ( y + 1 ) * BDOF_G + xu * 4 + x + 1, pi = ( y + 2 ) * BDOF_S + xu * 4 + x + 2;
+    const int b  = tmpx * ( ( int ) sGx[0][gi] - ( int ) sGx[1][gi] ) + tmpy * ( ( int ) sGy[0][gi] - ( int ) sGy[1][gi] );
+    v[x] = min( cmax, max( 0, ( int ) ( int16_t ) ( ( ( int ) sPred[0][pi] + ( int ) sPred[1][pi] + b + offset ) >> shiftNum ) ) );
+  }
+  const int  py = ry + y, px = rx + xu * 4;
+  const int  mode = ( outBase && orgBase ) ? j.epilogue : 0;
+  if( predBase )
+  {
+    int16_t *d = predBase + j.predOff + ( long ) py * j.predStride + px;
+#pragma unroll
+    for( int x = 0; x < 4; x++ ) d[x] = ( int16_t ) v[x];
+  }
+  if( mode )
+  {
+    const int16_t *o = orgBase + j.orgOff + ( long ) py * j.orgStride + px;
+    int16_t       *d = outBase + j.outOff + ( long ) py * j.outStride + px;
+#pragma unroll
+    for( int x = 0; x < 4; x++ ) d[x] = ( int16_t ) ( ( mode == 1 ? ( int ) o[x] : 2 * ( int ) o[x] ) - v[x] );
+  }
+}
+
 // InterpolationFilter::xWeightedGeoBlk (InterpolationFilter.cpp:902-957): one wave per blend, four output samples per lane and step when the width
 // allows (8-byte loads of both predictions, the weights gathered one by one -- their walk may be mirrored or 2:1 sub-sampled)
 __global__ __launch_bounds__( 256 ) void geo_blend_kernel( const int16_t *__restrict__ srcBase, int16_t *__restrict__ dstBase, const int16_t *__restrict__ wBase,
@@ -538,6 +674,22 @@ int vtmhip_add_avg_batch_dev( vtmhip_ctx *ctx, const int16_t *d_src0Base, const 
   if( n == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, d_src0Base && d_src1Base && d_dstBase && d_jobs, "null pointer" );
   hipLaunchKernelGGL( pelop_kernel, dim3( n ), dim3( 256 ), 0, ctx->stream, d_src0Base, d_src1Base, d_dstBase, d_jobs, 1 );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_bdof_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, int16_t *d_predBase, int16_t *d_outBase,
+                           const vtmhip_pred_job *d_jobs, int n, int maxWidth, int maxHeight )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_refBase && d_jobs && ( d_predBase || d_outBase ), "null pointer" );
+  VTMHIP_REQUIRE( ctx, !d_outBase || d_orgBase, "an epilogue output needs the original plane" );
+  VTMHIP_REQUIRE( ctx, maxWidth >= 8 && maxWidth <= 128 && maxHeight >= 8 && maxHeight <= 128, "maxWidth / maxHeight (BDOF needs 8 <= w, h <= 128)" );
+  VTMHIP_REQUIRE( ctx, n <= 65535, "at most 65535 PUs per launch" );
+  const int regions = ( ( maxWidth + 15 ) / 16 ) * ( ( maxHeight + 15 ) / 16 );
+  hipLaunchKernelGGL( bdof_kernel, dim3( regions, n ), dim3( 64 ), 0, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

@@ -229,6 +229,10 @@ class Context:
         """InterPrediction::motionCompensation per PU (uni / bi + addAvg) with the fused residual / removeHighFreq epilogue."""
         self._check(self.L.vtmhip_motion_compensation_batch_dev(self.h, d_org, d_ref, d_pred, d_out, d_jobs, n, max_w, max_h))
 
+    def bdof_batch(self, d_org, d_ref, d_pred, d_out, d_jobs, n, max_w, max_h):
+        """xPredInterBi with bioApplied (BDOF) for bi-predicted luma PUs; same job table and epilogues as motion_compensation_batch."""
+        self._check(self.L.vtmhip_bdof_batch_dev(self.h, d_org, d_ref, d_pred, d_out, d_jobs, n, max_w, max_h))
+
     def mc_batch(self, d_ref, d_dst, d_jobs, n, max_w, max_h):
         """xPredInterBlk for luma and 4:2:0 chroma blocks (McJob.chroma)."""
         self._check(self.L.vtmhip_mc_batch_dev(self.h, d_ref, d_dst, d_jobs, n, max_w, max_h))
