@@ -6,6 +6,7 @@
   IF         half + quarter sample planes (one H pass first/!last, one V pass !first/last) of all 16x16 blocks (vtmhip_if_batch_dev)
   TR         forward 2-D transform of 4096 random residual blocks per (type, W, H), and the fused xT/quant/dequant/xIT/SSE chain
              for the square sizes                                                                       (vtmhip_xT_batch_dev, vtmhip_tu_chain_batch_dev)
+  BDOF / GEO bi-predicted 16x16 and 64x64 luma PUs with and without BDOF; 32x32 GEO blends             (vtmhip_bdof_batch_dev, vtmhip_weightedGeoBlk_batch_dev)
 
 Prints one JSON object per line: algorithmic bytes (SURVEY.md 8d per-unit figures) / time against the 8 TB/s HBM peak.
 usage (GPU box): python3 scripts/microbench.py [--width 3840 --height 2160] > gpurun_out/microbench.json"""
@@ -21,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from vtm_amd import synth   # noqa: E402
 from vtm_amd.device import Context   # noqa: E402
-from vtm_amd.lib import DistJob, IfJob, TrJob, TuJob   # noqa: E402
+from vtm_amd.lib import DistJob, GeoBlendJob, IfJob, PredJob, TrJob, TuJob   # noqa: E402
 
 PEAK = 8000.0   # GB/s
 
@@ -134,6 +135,45 @@ def main():
         d_resi, d_ju, d_r, d_lv = ctx.to_device(resi), ctx.to_device(ju.view(np.uint8)), ctx.alloc(16 * nblk), ctx.alloc(4 * nblk * s * s)
         ms = timed(ctx, lambda: ctx.tu_chain_batch(d_resi.ptr, d_ju.ptr, nblk, s, s, d_r.ptr, d_lv.ptr, None, uniform=True), reps=5)
         emit("tu_chain", nblk * s * s, "samples", 32 * nblk * s * s, ms, type="DCT2", size="%dx%d" % (s, s))
+    # ---- BDOF (bi-predicted luma PUs, both vectors fractional) and GEO blending ---------------------------------------------------------
+    ref2, roff2, rs2 = synth.extend_plane(fr[1], margin=160)
+    d_refs = ctx.to_device(np.concatenate([ref.reshape(-1), ref2.reshape(-1)]))
+    for s in (16, 64):
+        nx, ny = W // s, H // s
+        n = nx * ny
+        jp = np.zeros(n, np.dtype(PredJob))
+        py, px = np.divmod(np.arange(n), nx)
+        base = (py * s) * rs + px * s
+        jp["refOff"][:, 0], jp["refOff"][:, 1] = roff + base, ref.size + roff2 + base
+        jp["refStride"][:, 0] = jp["refStride"][:, 1] = rs
+        jp["mv"] = rng.integers(-64, 65, (n, 2, 2)) | 1
+        jp["predOff"], jp["predStride"] = (py * s) * W + px * s, W
+        jp["width"], jp["height"], jp["mode"], jp["bitDepth"] = s, s, 2, 10
+        d_jp, d_pred = ctx.to_device(jp.view(np.uint8)), ctx.alloc(2 * W * H)
+        ms = timed(ctx, lambda: ctx.bdof_batch(0, d_refs.ptr, d_pred.ptr, 0, d_jp.ptr, n, s, s), reps=5)
+        emit("bdof", n * s * s, "samples", 6 * n * s * s, ms, size="%dx%d" % (s, s), pus=n)
+        ms = timed(ctx, lambda: ctx.motion_compensation_batch(0, d_refs.ptr, d_pred.ptr, 0, d_jp.ptr, n, s, s), reps=5)
+        emit("bi_pred", n * s * s, "samples", 6 * n * s * s, ms, size="%dx%d" % (s, s), pus=n)
+    M = 112
+    wplane = rng.integers(0, 9, (M, M)).astype(np.int16)
+    s, per = 32, 8
+    nx, ny = W // s, H // s
+    n = nx * ny * per
+    jg = np.zeros(n, np.dtype(GeoBlendJob))
+    py, px = np.divmod(np.arange(n) // per, nx)
+    jg["src0Off"] = (py * s) * W + px * s
+    jg["src1Off"] = W * H + jg["src0Off"]
+    jg["dstOff"] = np.arange(n) * s * s
+    jg["src0Stride"] = jg["src1Stride"] = W
+    jg["dstStride"], jg["width"], jg["height"] = s, s, s
+    sx = np.where(np.arange(n) % 3 == 0, -1, 1)
+    jg["stepX"], jg["weightStride"] = sx, np.where(np.arange(n) % 2 == 0, -M, M)
+    jg["weightOff"] = (np.where(np.arange(n) % 2 == 0, M - 1 - rng.integers(0, M - s, n), rng.integers(0, M - s, n))) * M + \
+        np.where(sx < 0, M - 1 - rng.integers(0, M - s, n), rng.integers(0, M - s, n))
+    src = rng.integers(-8192, 8192, 2 * W * H).astype(np.int16)
+    d_src, d_w, d_jg, d_dst = ctx.to_device(src), ctx.to_device(wplane), ctx.to_device(jg.view(np.uint8)), ctx.alloc(2 * n * s * s)
+    ms = timed(ctx, lambda: ctx.weightedGeoBlk_batch(d_src.ptr, d_dst.ptr, d_w.ptr, d_jg.ptr, n), reps=5)
+    emit("geo_blend", n * s * s, "samples", 6 * n * s * s, ms, size="32x32", blends=n)
     ctx.close()
 
 
