@@ -350,6 +350,30 @@ int vtmhip_add_avg_batch_dev( vtmhip_ctx *ctx, const int16_t *d_src0Base, const 
 int vtmhip_bdof_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, int16_t *d_predBase, int16_t *d_outBase,
                            const vtmhip_pred_job *d_jobs, int n, int maxWidth, int maxHeight );
 
+/* DMVR: InterPrediction::xProcessDMVR (InterPrediction.cpp:1997-2195) for the LUMA plane of the bi-predicted PUs for which the reference's
+ * PU::checkDMVRCondition holds (merge mode, equal and opposite POC distances, w, h >= 8, w*h >= 128, default weights ...; xPredInterBi :576-583).
+ * Per sub-PU of at most 16 x 16: xPrefetch, bilinear xinitMC, the 25-point mirrored integer refinement (xDMVRCost / xBIPMVRefine :1819-1927), the
+ * parametric error surface (:1733-1817, 1929-1947), xPad + xFinalPaddedMCForDMVR (:1709-1731, 1845-1917) and xWeightedAverage, with BDOF
+ * (vtmhip_bdof_batch_dev's arithmetic) where bioApplied is set and the sub-PU's matching cost is not below 2*dx*dy (:2139). */
+typedef struct
+{
+  int64_t orgOff;               /* block in the original plane (epilogue 1 / 2) */
+  int64_t refOff[2];            /* PU position with MV (0,0) in the list-0 / list-1 reference plane (both inside d_refBase) */
+  int64_t predOff, outOff;      /* prediction block inside d_predBase, epilogue output inside d_outBase */
+  int32_t orgStride, refStride[2], predStride, outStride;
+  int32_t mv[2][2];             /* the merge vectors, [list][hor, ver], internal 1/16 precision */
+  int32_t puX, puY;             /* luma position of the PU in the picture: clipMv (Mv.cpp:56-74) */
+  int16_t width, height;
+  uint8_t bioApplied;           /* what xPredInterBi decided for the PU (:527-572) */
+  uint8_t epilogue;             /* as vtmhip_pred_job */
+  uint8_t bitDepth, pad0;
+  int32_t pad1;
+} vtmhip_dmvr_job;
+/* pic: picW / picH / ctuSize / bitDepth.  d_mvd (may be NULL): pu.mvdL0SubPu, int32 [n][regions][2] with regions = ceil(maxWidth/16) * ceil(maxHeight/16),
+ * sub-PUs in the reference's raster order; the chroma planes of a moved sub-PU are predicted with mergeMv +- mvd by the caller. */
+int vtmhip_dmvr_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, int16_t *d_predBase,
+                           int16_t *d_outBase, const vtmhip_dmvr_job *d_jobs, int n, int maxWidth, int maxHeight, int32_t *d_mvd );
+
 /* InterpolationFilter::m_weightedGeoBlk (InterpolationFilter.h:99; xWeightedGeoBlk InterpolationFilter.cpp:902-957, x86/InterpolationFilterX86.h:1343-1470;
  * callers InterPrediction::weightedGeoBlk InterPrediction.cpp:1642-1661, EncCu.cpp:3004,3030): blend of the two GEO partitions' 14-bit predictions,
  *   dst = clip( ( w * src0 + (8 - w) * src1 + offset ) >> shift ),  shift = max(2, 14 - bitDepth) + 3,  offset = (1 << (shift-1)) + (8192 << 3),

@@ -514,3 +514,81 @@ extern "C" void ref_bdof_pu( int simd, const int16_t *plane0, const int16_t *pla
   r.cu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
   r.pu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// DMVR of one bi-predicted luma PU through the reference's own InterPrediction::xProcessDMVR (InterPrediction.cpp:1997-2195).  The rig PU is
+// 4:0:0, so the member runs its luma part only: xPrefetch, xinitMC (bilinear), xDMVRCost through the DF_SAD table, xBIPMVRefine, the error
+// surface, xPad, xFinalPaddedMCForDMVR and xWeightedAverage (with applyBiOptFlow when bioApplied and the cost allows).
+// mvdOut: pu.mvdL0SubPu, [num][2].
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" void ref_dmvr_pu( const int16_t *plane0, const int16_t *plane1, int stride, int picW, int picH, int ctuSize, int puX, int puY, int w, int h,
+                             int mv0Hor, int mv0Ver, int mv1Hor, int mv1Ver, int bitDepth, int bioApplied, int16_t *dst, int dstStride, int32_t *mvdOut )
+{
+  ensureRom();
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  static Picture *pics[2] = { nullptr, nullptr };
+  InterPrediction &ip = r.is;
+  if( !pics[0] )
+  {
+    pics[0] = new Picture(); pics[1] = new Picture();
+    const size_t dm = ( MAX_CU_SIZE + ( 2 * DMVR_NUM_ITERATION ) ), dr = dm + NTAPS_LUMA;
+    ip.m_cYuvPredTempDMVRL0 = ( Pel * ) xMalloc( Pel, dm * dm ); ip.m_cYuvPredTempDMVRL1 = ( Pel * ) xMalloc( Pel, dm * dm );
+    ip.m_cRefSamplesDMVRL0[0] = ( Pel * ) xMalloc( Pel, dr * dr ); ip.m_cRefSamplesDMVRL1[0] = ( Pel * ) xMalloc( Pel, dr * dr );
+    ip.m_acYuvPred[0][0] = ( Pel * ) xMalloc( Pel, MAX_CU_SIZE * MAX_CU_SIZE ); ip.m_acYuvPred[1][0] = ( Pel * ) xMalloc( Pel, MAX_CU_SIZE * MAX_CU_SIZE );
+  }
+  if( !ip.m_gradX0 )
+  {
+    ip.m_gradX0 = ( Pel * ) xMalloc( Pel, BIO_TEMP_BUFFER_SIZE ); ip.m_gradY0 = ( Pel * ) xMalloc( Pel, BIO_TEMP_BUFFER_SIZE );
+    ip.m_gradX1 = ( Pel * ) xMalloc( Pel, BIO_TEMP_BUFFER_SIZE ); ip.m_gradY1 = ( Pel * ) xMalloc( Pel, BIO_TEMP_BUFFER_SIZE );
+  }
+  ip.m_pcRdCost = &r.rd;
+  const PelBufferOps saved = g_pelBufOP;
+  g_pelBufOP = PelBufferOps();
+  g_pelBufOP.initPelBufOpsX86();
+  r.pps.setPicWidthInLumaSamples( picW );
+  r.pps.setPicHeightInLumaSamples( picH );
+  r.sps.setMaxCUWidth( ctuSize );
+  r.sps.setMaxCUHeight( ctuSize );
+  r.sps.setBitDepth( CHANNEL_TYPE_LUMA, bitDepth );
+  r.sps.setBitDepth( CHANNEL_TYPE_CHROMA, bitDepth );
+  r.slice.m_pcSPS = &r.sps;
+  ClpRng clp; clp.min = 0; clp.max = ( 1 << bitDepth ) - 1; clp.bd = bitDepth; clp.n = 0;
+  for( int c = 0; c < 3; c++ ) r.slice.getClpRngs().comp[c] = clp;
+  for( int l = 0; l < 2; l++ )
+  {
+    Picture *pic = pics[l];
+    pic->chromaFormat = CHROMA_400;
+    pic->unscaledPic  = pic;
+    Pel *py = const_cast<Pel *>( l ? plane1 : plane0 );
+    pic->m_bufs[PIC_RECONSTRUCTION].createFromBuf( PelUnitBuf( CHROMA_400, PelBuf( py, stride, picW, picH ) ) );
+    r.slice.m_apcRefPicList[l][0] = pic;
+    r.slice.m_scalingRatio[l][0]  = SCALE_1X;
+  }
+  const UnitArea ua( CHROMA_400, Area( puX, puY, w, h ) );
+  r.cu.UnitArea::operator=( ua );
+  r.pu.UnitArea::operator=( ua );
+  r.cu.chromaFormat = CHROMA_400;
+  r.pu.chromaFormat = CHROMA_400;
+  r.cu.imv = 0;
+  r.cu.BcwIdx = BCW_DEFAULT;
+  r.cu.affine = false;
+  r.cu.geoFlag = false;
+  r.pu.ciipFlag = false;
+  r.pu.refIdx[0] = r.pu.refIdx[1] = 0;
+  r.pu.mv[0] = Mv( mv0Hor, mv0Ver );
+  r.pu.mv[1] = Mv( mv1Hor, mv1Ver );
+  PelUnitBuf out( CHROMA_400, PelBuf( dst, dstStride, w, h ) );
+  ip.xProcessDMVR( r.pu, out, r.slice.clpRngs(), bioApplied != 0 );
+  if( mvdOut )
+  {
+    const int n = ( w / std::min( w, 16 ) ) * ( h / std::min( h, 16 ) );
+    for( int i = 0; i < n; i++ ) { mvdOut[2 * i] = r.pu.mvdL0SubPu[i].hor; mvdOut[2 * i + 1] = r.pu.mvdL0SubPu[i].ver; }
+  }
+  g_pelBufOP = saved;
+  r.slice.m_apcRefPicList[0][0] = r.slice.m_apcRefPicList[1][0] = nullptr;
+  r.cu.chromaFormat = CHROMA_420;
+  r.pu.chromaFormat = CHROMA_420;
+  r.cu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+  r.pu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+}

@@ -1334,6 +1334,162 @@ static void vo_bdof_region( const int16_t *ref0, int stride0, const int16_t *ref
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * DMVR of one bi-predicted LUMA PU -- InterPrediction::xProcessDMVR (CommonLib/InterPrediction.cpp:1997-2195) for the luma plane:
+ * per sub-PU of at most 16 x 16: xPrefetch (:1666-1708: the (dx+7) x (dy+7) integer window of each list into a private buffer), xinitMC
+ * (:1941-1995: bilinear (dx+4) x (dy+4) predictions, 10-bit), xDMVRCost (:1919-1927: SAD of every other row), the 25-point integer
+ * refinement xBIPMVRefine (:1819-1843) around the mirrored displacement, the parametric error surface (:1733-1817, 1929-1947), xPad (:1709-1731,
+ * paddingCore Buffer.cpp:340-364: the window replicated by 2 samples, only when the sub-PU moved), xFinalPaddedMCForDMVR (:1845-1917: 8-tap
+ * prediction out of the padded window) and xWeightedAverage (:1354-1435) with BDOF unless the matching cost was below 2*dx*dy.
+ * plane0 / plane1: origins of the two reference luma planes; the picture geometry is needed for clipMv (Mv.cpp:56-74).
+ * mvdOut (optional): pu.mvdL0SubPu of every sub-PU, [num][2].
+ * ------------------------------------------------------------------------------------------------ */
+static void vo_clip_mv_pic( int *hor, int *ver, int picW, int picH, int ctuSize, int x, int y )
+{
+  const int horMax = ( picW + 8 - x - 1 ) << 4, horMin = ( -ctuSize - 8 - x + 1 ) << 4;
+  const int verMax = ( picH + 8 - y - 1 ) << 4, verMin = ( -ctuSize - 8 - y + 1 ) << 4;
+  *hor = *hor < horMin ? horMin : *hor > horMax ? horMax : *hor;
+  *ver = *ver < verMin ? verMin : *ver > verMax ? verMax : *ver;
+}
+
+static int vo_div_for_maxq7( int64_t N, int64_t D )   /* :1733-1767 */
+{
+  int sign = 0, q = 0;
+  if( N < 0 ) { sign = 1; N = -N; }
+  D = D * 8;
+  if( N >= D ) { N -= D; q++; }
+  q = q * 2;
+  D = D >> 1;
+  if( N >= D ) { N -= D; q++; }
+  q = q * 2;
+  if( N >= ( D >> 1 ) ) q++;
+  return sign ? -q : q;
+}
+
+void vo_dmvr_pu( const int16_t *plane0, const int16_t *plane1, int stride, int picW, int picH, int ctuSize, int puX, int puY, int w, int h, int mv0Hor,
+                 int mv0Ver, int mv1Hor, int mv1Ver, int bitDepth, int bioApplied, int16_t *dst, int dstStride, int32_t *mvdOut )
+{
+  enum { MAXS = 16, PS = MAXS + 12, BS = MAXS + 4 };
+  const int mergeMv[2][2] = { { mv0Hor, mv0Ver }, { mv1Hor, mv1Ver } };
+  const int dx = w < 16 ? w : 16, dy = h < 16 ? h : 16;
+  const int headRoom = 14 - bitDepth > 2 ? 14 - bitDepth : 2, cmax = ( 1 << bitDepth ) - 1;
+  int num = 0;
+  for( int sy = 0; sy < h; sy += dy )
+    for( int sx = 0; sx < w; sx += dx, num++ )
+    {
+      const int x = puX + sx, y = puY + sy;
+      int16_t   pad[2][PS * PS], bil[2][BS * BS], tmp[BS * ( BS + 1 )];
+      for( int l = 0; l < 2; l++ )
+      {
+        const int16_t *plane = l ? plane1 : plane0;
+        /* xPrefetch, luma: the vector moved by the filter reach, clipped, whole samples */
+        int ph = mergeMv[l][0] - ( 3 << 4 ), pv = mergeMv[l][1] - ( 3 << 4 );
+        vo_clip_mv_pic( &ph, &pv, picW, picH, ctuSize, x, y );
+        const int16_t *src = plane + ( ptrdiff_t )( y + ( pv >> 4 ) ) * stride + x + ( ph >> 4 );
+        for( int r = 0; r < dy + 7; r++ ) memcpy( pad[l] + ( r + 2 ) * PS + 2, src + ( ptrdiff_t ) r * stride, sizeof( int16_t ) * ( dx + 7 ) );
+        /* xinitMC: bilinear prediction of the (dx+4) x (dy+4) block that starts 2 samples up-left of the merge position */
+        int mh = mergeMv[l][0], mvv = mergeMv[l][1];
+        vo_clip_mv_pic( &mh, &mvv, picW, picH, ctuSize, x, y );
+        const int      xFrac = mh & 15, yFrac = mvv & 15, bw = dx + 4, bh = dy + 4;
+        const int16_t *b0 = pad[l] + 3 * ( PS + 1 );
+        if( yFrac == 0 ) vo_if_hor( 0, b0, PS, bil[l], BS, bw, bh, xFrac, 0, bitDepth, 1, 1, 0 );
+        else if( xFrac == 0 ) vo_if_ver( 0, b0, PS, bil[l], BS, bw, bh, yFrac, 1, 0, bitDepth, 1, 1, 0 );
+        else
+        {
+          vo_if_hor( 0, b0, PS, tmp, bw, bw, bh + 1, xFrac, 0, bitDepth, 1, 1, 0 );
+          vo_if_ver( 0, tmp, bw, bil[l], BS, bw, bh, yFrac, 0, 0, bitDepth, 1, 1, 0 );
+        }
+      }
+      /* matching cost: SAD over every other row (setDistParam(..., subShiftMode = 1) then >> 1, RdCost.cpp:368-408) */
+#define VO_DMVR_COST( ox, oy, out )                                                                                         \
+  {                                                                                                                         \
+    const int16_t *a = bil[0] + ( 2 + ( oy ) ) * BS + 2 + ( ox ), *b = bil[1] + ( 2 - ( oy ) ) * BS + 2 - ( ox );             \
+    uint64_t       acc = 0;                                                                                                 \
+    for( int r = 0; r < dy; r += 2 )                                                                                        \
+      for( int c = 0; c < dx; c++ ) acc += ( uint64_t ) vo_abs( ( int ) a[r * BS + c] - ( int ) b[r * BS + c] );             \
+    ( out ) = ( ( acc << 1 ) >> 1 );                                                                                        \
+  }
+      uint64_t sads[25], minCost;
+      int      notZero = 1, total[2] = { 0, 0 }, best = 12;
+      for( int i = 0; i < 25; i++ ) sads[i] = UINT64_MAX;
+      VO_DMVR_COST( 0, 0, minCost );
+      minCost -= minCost >> 2;
+      if( minCost < ( uint64_t )( dx * dy ) ) notZero = 0;
+      else
+      {
+        sads[12] = minCost;
+        for( int i = 0; i < 25; i++ )   /* xBIPMVRefine: raster order over [-2,2]^2, strict '<' */
+        {
+          if( sads[i] == UINT64_MAX ) VO_DMVR_COST( i % 5 - 2, i / 5 - 2, sads[i] );
+          if( sads[i] < minCost ) { minCost = sads[i]; best = i; }
+        }
+        total[0] = best % 5 - 2; total[1] = best / 5 - 2;
+      }
+#undef VO_DMVR_COST
+      const int bio = minCost < ( uint64_t )( 2 * dx * dy ) ? 0 : bioApplied;
+      total[0] *= 16; total[1] *= 16;
+      if( notZero && total[0] != 32 && total[0] != -32 && total[1] != 32 && total[1] != -32 )   /* xDMVRSubPixelErrorSurface */
+      {
+        const uint64_t sb[5] = { sads[best], sads[best - 1], sads[best - 5], sads[best + 1], sads[best + 5] };
+        for( int d = 0; d < 2; d++ )
+        {
+          const uint64_t s1 = sb[1 + d], s3 = sb[3 + d];
+          const int64_t  numer = ( int64_t )( ( s1 - s3 ) << 4 ), denom = ( int64_t )( s1 + s3 - ( sb[0] << 1 ) );
+          if( denom != 0 )
+          {
+            if( s1 != sb[0] && s3 != sb[0] ) total[d] += vo_div_for_maxq7( numer, denom );
+            else total[d] += s1 == sb[0] ? -8 : 8;
+          }
+        }
+      }
+      total[0] = ( int16_t ) total[0]; total[1] = ( int16_t ) total[1];
+      if( mvdOut ) { mvdOut[2 * num] = total[0]; mvdOut[2 * num + 1] = total[1]; }
+      const int moved = total[0] != 0 || total[1] != 0;
+      if( moved )   /* xPad: the prefetched window replicated by DMVR_NUM_ITERATION samples on every side */
+        for( int l = 0; l < 2; l++ )
+        {
+          int16_t *p = pad[l] + 2 * ( PS + 1 );
+          const int pw = dx + 7, ph2 = dy + 7;
+          for( int r = 0; r < ph2; r++ )
+            for( int j = 1; j <= 2; j++ ) { p[r * PS - j] = p[r * PS]; p[r * PS + pw - 1 + j] = p[r * PS + pw - 1]; }
+          for( int i = 1; i <= 2; i++ )
+          {
+            memcpy( p - 2 - i * PS, p - 2, sizeof( int16_t ) * ( pw + 4 ) );
+            memcpy( p - 2 + ( ph2 - 1 + i ) * PS, p - 2 + ( ph2 - 1 ) * PS, sizeof( int16_t ) * ( pw + 4 ) );
+          }
+        }
+      /* xFinalPaddedMCForDMVR + xWeightedAverage */
+      const int16_t *fsrc[2];
+      int            frac[2][2];
+      for( int l = 0; l < 2; l++ )
+      {
+        int rh = mergeMv[l][0] + ( l ? -total[0] : total[0] ), rv = mergeMv[l][1] + ( l ? -total[1] : total[1] );
+        rh = rh < -( 1 << 17 ) ? -( 1 << 17 ) : rh > ( 1 << 17 ) - 1 ? ( 1 << 17 ) - 1 : rh;   /* clipToStorageBitDepth */
+        rv = rv < -( 1 << 17 ) ? -( 1 << 17 ) : rv > ( 1 << 17 ) - 1 ? ( 1 << 17 ) - 1 : rv;
+        int ch = rh, cv = rv;
+        vo_clip_mv_pic( &ch, &cv, picW, picH, ctuSize, x, y );
+        frac[l][0] = ch & 15; frac[l][1] = cv & 15;
+        const int dX = ( rh >> 4 ) - ( mergeMv[l][0] >> 4 ), dY = ( rv >> 4 ) - ( mergeMv[l][1] >> 4 );
+        fsrc[l] = pad[l] + 5 * ( PS + 1 ) + dY * PS + dX;
+      }
+      int16_t *out = dst + ( ptrdiff_t ) sy * dstStride + sx;
+      if( bio ) vo_bdof_region( fsrc[0], PS, fsrc[1], PS, dx, dy, ( const int( * )[2] ) frac, bitDepth, out, dstStride );
+      else
+      {
+        int16_t p0[MAXS * MAXS], p1[MAXS * MAXS];
+        vo_mc_block( 0, fsrc[0], PS, dx, dy, frac[0][0], frac[0][1], 1, bitDepth, 0, p0, dx );
+        vo_mc_block( 0, fsrc[1], PS, dx, dy, frac[1][0], frac[1][1], 1, bitDepth, 0, p1, dx );
+        const int shift = headRoom + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * 8192;
+        for( int r = 0; r < dy; r++ )
+          for( int c = 0; c < dx; c++ )
+          {
+            const int v = ( p0[r * dx + c] + p1[r * dx + c] + offset ) >> shift;
+            out[( ptrdiff_t ) r * dstStride + c] = ( int16_t )( v < 0 ? 0 : v > cmax ? cmax : v );
+          }
+      }
+    }
+}
+
 void vo_bdof_pu( const int16_t *ref0, int stride0, const int16_t *ref1, int stride1, int w, int h, int mv0Hor, int mv0Ver, int mv1Hor, int mv1Ver,
                  int bitDepth, int16_t *dst, int dstStride )
 {

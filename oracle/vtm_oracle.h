@@ -66,6 +66,9 @@ uint64_t vo_sad_mask( const int16_t *org, int orgStride, const int16_t *cur, int
 /* BDOF of one bi-predicted luma PU: xSubPuBio + xPredInterBlk(bioApplied) + applyBiOptFlow, CommonLib/InterPrediction.cpp:352-443, 733-810, 1233-1334 */
 void vo_bdof_pu( const int16_t *ref0, int stride0, const int16_t *ref1, int stride1, int w, int h, int mv0Hor, int mv0Ver, int mv1Hor, int mv1Ver,
                  int bitDepth, int16_t *dst, int dstStride );
+/* DMVR of one bi-predicted luma PU: InterPrediction::xProcessDMVR, CommonLib/InterPrediction.cpp:1997-2195 (luma plane) */
+void vo_dmvr_pu( const int16_t *plane0, const int16_t *plane1, int stride, int picW, int picH, int ctuSize, int puX, int puY, int w, int h, int mv0Hor,
+                 int mv0Ver, int mv1Hor, int mv1Ver, int bitDepth, int bioApplied, int16_t *dst, int dstStride, int32_t *mvdOut );
 /* InterpolationFilter::xWeightedGeoBlk, CommonLib/InterpolationFilter.cpp:902-957 */
 void vo_weighted_geo_blk( const int16_t *src0, int src0Stride, const int16_t *src1, int src1Stride, int16_t *dst, int dstStride, int w, int h,
                           const int16_t *weight, int stepX, int weightStride, int bitDepth, int clipMin, int clipMax );

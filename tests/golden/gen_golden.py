@@ -376,6 +376,40 @@ def gen_bdof():
     print("bdof:", len(meta), "PUs")
 
 
+def gen_dmvr():
+    """DMVR of bi-predicted luma PUs through the reference's own InterPrediction::xProcessDMVR on a 4:0:0 rig PU (ref_dmvr_pu): the refined
+    prediction and pu.mvdL0SubPu.  Shares the two padded reference planes of bdof.npz (same generator call)."""
+    from vtm_amd import synth
+    W, H, M = 160, 96, 40
+    fr = list(synth.gen_frames(W, H, 3, seed=21))
+    planes = [np.ascontiguousarray(np.pad(f.astype(np.int16), M, mode="edge")) for f in (fr[0], fr[2])]
+    S = planes[0].shape[1]
+    org = [C.c_void_p(p.ctypes.data + 2 * (M * S + M)) for p in planes]
+    g = np.random.default_rng(1013)
+    meta, outs, mvds = [], [], []
+    sizes = [(8, 16), (16, 8), (16, 16), (32, 16), (16, 32), (32, 32), (64, 32), (64, 64), (128, 64), (8, 64)]
+    for k in range(40):
+        w, h = sizes[k % len(sizes)]
+        x, y = int(g.integers(0, (W - w) // 4 + 1)) * 4, int(g.integers(0, (H - h) // 4 + 1)) * 4
+        base = np.array([48, 32]) + g.integers(-40, 41, 2)      # near the clip's true pan, so that the refinement has something to find
+        mv = [int(-base[0]), int(-base[1]), int(base[0] + g.integers(-24, 25)), int(base[1] + g.integers(-24, 25))]
+        if k % 5 == 0:
+            mv[0] &= ~15
+        if k % 7 == 0:
+            mv[3] &= ~15
+        if k % 9 == 0:
+            mv = [v & ~15 for v in mv]
+        bio = k % 2
+        nsub = (w // min(w, 16)) * (h // min(h, 16))
+        dst, mvd = np.zeros((h, w), np.int16), np.zeros(2 * nsub, np.int32)
+        R.ref_dmvr_pu(org[0], org[1], S, W, H, 128, x, y, w, h, *mv, 10, bio, ol.P(dst), w, C.c_void_p(mvd.ctypes.data))
+        meta.append((x, y, w, h, *mv, bio))
+        outs.append(dst.reshape(-1)); mvds.append(mvd)
+    np.savez_compressed(os.path.join(HERE, "dmvr.npz"), dims=np.array([W, H, M], np.int32), meta=np.array(meta, np.int32), out=np.concatenate(outs),
+                        mvd=np.concatenate(mvds))
+    print("dmvr:", len(meta), "PUs,", int(np.count_nonzero(np.concatenate(mvds))), "non-zero vector components")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected fixtures only: gen_golden.py mest quant ...
         for name in sys.argv[1:]:
@@ -393,3 +427,4 @@ if __name__ == "__main__":
     gen_masked()
     gen_geo()
     gen_bdof()
+    gen_dmvr()

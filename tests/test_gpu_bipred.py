@@ -360,3 +360,64 @@ def test_bdof_matches_oracle(ctx):
         d_pred2 = ctx.alloc(2 * pos)
         ctx.bdof_batch(0, d_ref.ptr, d_pred2.ptr, 0, d_jobs.ptr, n, 128, 128)   # prediction only
         assert np.array_equal(d_pred2.to_host(np.int16), np.concatenate(exp_pred)), bd
+
+
+def test_dmvr_matches_oracle(ctx):
+    """vtmhip_dmvr_batch_dev vs vo_dmvr_pu: all PU size classes, with / without BDOF, vectors around the clip's motion, integer phases, far
+    out-of-picture vectors (clipMv), 8- and 10-bit, prediction + fused epilogues + vector differences."""
+    from vtm_amd import synth
+    from vtm_amd.lib import DmvrJob, PicParams
+    L = ol.oracle()
+    W, H, M = 256, 192, 160
+    fr = list(synth.gen_frames(W, H, 3, seed=9))
+    rng = np.random.default_rng(1015)
+    for bd in (10, 8):
+        planes = [np.ascontiguousarray(np.pad((f >> (10 - bd)).astype(np.int16), M, mode="edge")) for f in (fr[0], fr[2])]
+        org = np.ascontiguousarray((fr[1] >> (10 - bd)).astype(np.int16))
+        S, plane_sz = planes[0].shape[1], planes[0].size
+        o = [C.c_void_p(p.ctypes.data + 2 * (M * S + M)) for p in planes]
+        n, regions = 160, 64
+        jobs = (DmvrJob * n)()
+        exp_pred, exp_out, exp_mvd, pos = [], [], np.zeros((n, regions, 2), np.int32), 0
+        for k in range(n):
+            w, h = int(rng.choice([8, 16, 32, 64, 128])), int(rng.choice([8, 16, 32, 64, 128]))
+            if w * h < 128:
+                w = 16
+            x, y = int(rng.integers(0, (W - w) // 4 + 1)) * 4, int(rng.integers(0, (H - h) // 4 + 1)) * 4
+            base = np.array([48, 32]) + rng.integers(-40, 41, 2)
+            mv = [int(-base[0]), int(-base[1]), int(base[0] + rng.integers(-24, 25)), int(base[1] + rng.integers(-24, 25))]
+            if k % 9 == 0:
+                mv = [int(v) for v in rng.integers(-4000, 4000, 4)]
+            if k % 7 == 0:
+                mv[k % 4] &= ~15
+            if k % 11 == 0:
+                mv = [v & ~15 for v in mv]
+            bio = k % 2
+            nsub = (w // min(w, 16)) * (h // min(h, 16))
+            e, mvd = np.zeros((h, w), np.int16), np.zeros(2 * nsub, np.int32)
+            L.vo_dmvr_pu(o[0], o[1], S, W, H, 128, x, y, w, h, *mv, bd, bio, ol.P(e), w, C.c_void_p(mvd.ctypes.data))
+            exp_mvd[k, :nsub] = mvd.reshape(-1, 2)
+            j = jobs[k]
+            for l in range(2):
+                j.refOff[l], j.refStride[l] = l * plane_sz + (M + y) * S + M + x, S
+            j.mv[0][0], j.mv[0][1], j.mv[1][0], j.mv[1][1] = mv
+            j.orgOff, j.orgStride, j.puX, j.puY = y * W + x, W, x, y
+            j.predOff = j.outOff = pos
+            j.predStride = j.outStride = w
+            j.width, j.height, j.bitDepth, j.bioApplied, j.epilogue = w, h, bd, bio, 1 + k % 2
+            ob = org[y:y + h, x:x + w].astype(np.int32)
+            exp_pred.append(e.reshape(-1))
+            exp_out.append(((ob if j.epilogue == 1 else 2 * ob) - e).astype(np.int16).reshape(-1))
+            pos += w * h
+        assert np.count_nonzero(exp_mvd) > 300
+        pic = PicParams(W, H, 128, bd, 0)
+        d_ref = ctx.to_device(np.concatenate([p.reshape(-1) for p in planes]))
+        d_org, d_jobs = ctx.to_device(org.reshape(-1)), ctx.to_device(np.frombuffer(jobs, np.uint8))
+        d_pred, d_out, d_mvd = ctx.alloc(2 * pos), ctx.alloc(2 * pos), ctx.alloc(4 * exp_mvd.size)
+        ctx.dmvr_batch(pic, d_org.ptr, d_ref.ptr, d_pred.ptr, d_out.ptr, d_jobs.ptr, n, 128, 128, d_mvd.ptr)
+        got_mvd = d_mvd.to_host(np.int32).reshape(n, regions, 2)
+        for k in range(n):
+            nsub = (jobs[k].width // min(jobs[k].width, 16)) * (jobs[k].height // min(jobs[k].height, 16))
+            assert np.array_equal(got_mvd[k, :nsub], exp_mvd[k, :nsub]), (bd, k)
+        assert np.array_equal(d_pred.to_host(np.int16), np.concatenate(exp_pred)), bd
+        assert np.array_equal(d_out.to_host(np.int16), np.concatenate(exp_out)), bd

@@ -167,3 +167,34 @@ def test_bdof_golden(ctx):
     d_ref, d_jobs, d_pred = ctx.to_device(planes.reshape(-1)), ctx.to_device(np.frombuffer(jobs, np.uint8)), ctx.alloc(2 * pos)
     ctx.bdof_batch(0, d_ref.ptr, d_pred.ptr, 0, d_jobs.ptr, len(meta), 128, 128)
     assert np.array_equal(d_pred.to_host(np.int16), z["out"])
+
+
+def test_dmvr_golden(ctx):
+    """vtmhip_dmvr_batch_dev vs the predictions and pu.mvdL0SubPu recorded from the reference's xProcessDMVR."""
+    from vtm_amd.lib import DmvrJob, PicParams
+    z, zb = np.load(os.path.join(G, "dmvr.npz")), np.load(os.path.join(G, "bdof.npz"))
+    planes = np.ascontiguousarray(zb["planes"])
+    W, H, M = z["dims"].tolist()
+    S, plane_sz = planes.shape[2], planes.shape[1] * planes.shape[2]
+    meta = z["meta"].tolist()
+    jobs = (DmvrJob * len(meta))()
+    pos = 0
+    for k, (x, y, w, h, a, b, c, d, bio) in enumerate(meta):
+        j = jobs[k]
+        for l in range(2):
+            j.refOff[l], j.refStride[l] = l * plane_sz + (M + y) * S + M + x, S
+        j.mv[0][0], j.mv[0][1], j.mv[1][0], j.mv[1][1] = a, b, c, d
+        j.predOff, j.predStride, j.width, j.height, j.bitDepth, j.bioApplied, j.puX, j.puY = pos, w, w, h, 10, bio, x, y
+        pos += w * h
+    pic = PicParams(W, H, 128, 10, 0)
+    regions = 64
+    d_ref, d_jobs, d_pred = ctx.to_device(planes.reshape(-1)), ctx.to_device(np.frombuffer(jobs, np.uint8)), ctx.alloc(2 * pos)
+    d_mvd = ctx.alloc(4 * 2 * regions * len(meta))
+    ctx.dmvr_batch(pic, 0, d_ref.ptr, d_pred.ptr, 0, d_jobs.ptr, len(meta), 128, 128, d_mvd.ptr)
+    mvd = d_mvd.to_host(np.int32).reshape(len(meta), regions, 2)
+    mpos = 0
+    for k, (x, y, w, h, *_rest) in enumerate(meta):
+        nsub = (w // min(w, 16)) * (h // min(h, 16))
+        assert np.array_equal(mvd[k, :nsub].reshape(-1), z["mvd"][mpos:mpos + 2 * nsub]), (k, x, y, w, h)
+        mpos += 2 * nsub
+    assert np.array_equal(d_pred.to_host(np.int16), z["out"])

@@ -200,3 +200,22 @@ def test_bdof_golden(oracle):
         oracle.vo_bdof_pu(o[0], S, o[1], S, w, h, a, b, c, d, 10, ol.P(got), w)
         assert np.array_equal(got.reshape(-1), z["out"][pos:pos + w * h]), (x, y, w, h, a, b, c, d)
         pos += w * h
+
+
+def test_dmvr_golden(oracle):
+    """DMVR predictions and sub-PU vector differences recorded from the reference's xProcessDMVR (gen_golden.py gen_dmvr; planes of bdof.npz)."""
+    z, zb = np.load(os.path.join(G, "dmvr.npz")), np.load(os.path.join(G, "bdof.npz"))
+    planes = np.ascontiguousarray(zb["planes"])
+    W, H, M = z["dims"].tolist()
+    assert zb["dims"].tolist() == [W, H, M]
+    S = planes.shape[2]
+    o = [C.c_void_p(planes[l].ctypes.data + 2 * (M * S + M)) for l in range(2)]
+    pos = mpos = 0
+    for x, y, w, h, a, b, c, d, bio in z["meta"].tolist():
+        nsub = (w // min(w, 16)) * (h // min(h, 16))
+        got, mvd = np.zeros((h, w), np.int16), np.zeros(2 * nsub, np.int32)
+        oracle.vo_dmvr_pu(o[0], o[1], S, W, H, 128, x, y, w, h, a, b, c, d, 10, bio, ol.P(got), w, C.c_void_p(mvd.ctypes.data))
+        assert np.array_equal(mvd, z["mvd"][mpos:mpos + 2 * nsub]), (x, y, w, h)
+        assert np.array_equal(got.reshape(-1), z["out"][pos:pos + w * h]), (x, y, w, h, a, b, c, d, bio)
+        pos += w * h
+        mpos += 2 * nsub

@@ -335,3 +335,39 @@ def test_bdof_equals_reference(oracle, reflib):
         avg = np.clip((t0.astype(np.int32) + t1 + (1 << (sh - 1)) + 2 * 8192) >> sh, 0, (1 << bd) - 1)
         moved += int(np.count_nonzero(avg != c))
     assert moved > 1000
+
+
+def test_dmvr_equals_reference(oracle, reflib):
+    """vo_dmvr_pu vs the reference's InterPrediction::xProcessDMVR (luma; 4:0:0 rig PU): prediction and pu.mvdL0SubPu, with and without BDOF, vectors
+    near the clip's motion (the refinement moves), integer / fractional phases, and far out-of-picture vectors (every clipMv call takes effect)."""
+    from vtm_amd import synth
+    W, H, M = 256, 128, 160
+    fr = list(synth.gen_frames(W, H, 3, seed=5))
+    p0, p1 = (np.ascontiguousarray(np.pad(f.astype(np.int16), M, mode="edge")) for f in (fr[0], fr[2]))
+    S = p0.shape[1]
+    o0, o1 = (C.c_void_p(p.ctypes.data + 2 * (M * S + M)) for p in (p0, p1))
+    rng = np.random.default_rng(1014)
+    moved = 0
+    for k in range(160):
+        w, h = int(rng.choice([8, 16, 32, 64, 128])), int(rng.choice([8, 16, 32, 64, 128]))
+        if w * h < 128:
+            continue
+        x, y = int(rng.integers(0, (W - w) // 4 + 1)) * 4, int(rng.integers(0, (H - h) // 4 + 1)) * 4
+        base = np.array([48, 32]) + rng.integers(-40, 41, 2)
+        mv = [int(-base[0]), int(-base[1]), int(base[0] + rng.integers(-24, 25)), int(base[1] + rng.integers(-24, 25))]
+        if k % 9 == 0:
+            mv = [int(v) for v in rng.integers(-4000, 4000, 4)]
+        if k % 7 == 0:
+            mv[0] &= ~15
+        if k % 11 == 0:
+            mv = [v & ~15 for v in mv]
+        bio = k % 2
+        nsub = (w // min(w, 16)) * (h // min(h, 16))
+        a, c = np.zeros((h, w), np.int16), np.zeros((h, w), np.int16)
+        ma, mc = np.zeros(2 * nsub, np.int32), np.zeros(2 * nsub, np.int32)
+        reflib.ref_dmvr_pu(o0, o1, S, W, H, 128, x, y, w, h, *mv, 10, bio, ol.P(a), w, C.c_void_p(ma.ctypes.data))
+        oracle.vo_dmvr_pu(o0, o1, S, W, H, 128, x, y, w, h, *mv, 10, bio, ol.P(c), w, C.c_void_p(mc.ctypes.data))
+        assert np.array_equal(ma, mc), (k, x, y, w, h, mv, bio)
+        assert np.array_equal(a, c), (k, x, y, w, h, mv, bio)
+        moved += int(np.count_nonzero(ma))
+    assert moved > 500

@@ -32,6 +32,7 @@ int vtmhip_struct_size( int which )
   case 19: return ( int ) sizeof( vtmhip_frame_tabs );
   case 20: return ( int ) sizeof( vtmhip_masked_sad_job );
   case 21: return ( int ) sizeof( vtmhip_geo_blend_job );
+  case 22: return ( int ) sizeof( vtmhip_dmvr_job );
   default: return -1;
   }
 }

@@ -430,122 +430,331 @@ struct StorePad   // prediction interior at (2,2) of a [h+4][BDOF_S] tile
 
 constexpr int BDOF_S = 20, BDOF_G = 18;
 
+struct BdofLds
+{
+  __attribute__( ( aligned( 16 ) ) ) int16_t tmp[16 * ( 16 + 7 )];   // H-pass intermediates of the 8-tap prediction
+  __attribute__( ( aligned( 16 ) ) ) int16_t pred[2][BDOF_S * BDOF_S];   // 14-bit predictions, interior at (2,2), ring at (1,1)
+  int16_t gx[2][BDOF_G * BDOF_G], gy[2][BDOF_G * BDOF_G];
+};
+
+// one list of a region: 8-tap prediction into the padded tile; with `bio` also the ring, the gradients and the border replication.
+// m.refOff / refStride / mvHor / mvVer describe the list (refBase may be global memory or an LDS window).
+__device__ __forceinline__ void bdof_list( BdofLds &L, int l, const vtmhip_mc_job &m, const int16_t *refBase, int lane, bool bio )
+{
+  const int dx = m.width, dy = m.height, headRoom = max( 2, 14 - ( int ) m.bitDepth );
+  int16_t  *P = L.pred[l], *X = L.gx[l], *Y = L.gy[l];
+  mc_any<64>( m, refBase, L.tmp, lane, StorePad{ P, BDOF_S } );
+  if( !bio ) { block_sync<64>(); return; }
+  // ring: the integer sample nearest to the fractional position, as a 14-bit intermediate (:768-803)
+  const int16_t *src = refBase + m.refOff + ( long ) ( ( m.mvVer >> 4 ) + ( ( m.mvVer & 15 ) < 8 ? 0 : 1 ) ) * m.refStride + ( m.mvHor >> 4 ) + ( ( m.mvHor & 15 ) < 8 ? 0 : 1 );
+  for( int i = lane; i < 2 * ( dx + 2 ) + 2 * dy; i += 64 )
+  {
+    int r, c;
+    if( i < 2 * ( dx + 2 ) ) { r = i < dx + 2 ? -1 : dy; c = ( i < dx + 2 ? i : i - ( dx + 2 ) ) - 1; }
+    else { const int t = i - 2 * ( dx + 2 ); r = t >> 1; c = ( t & 1 ) ? dx : -1; }
+    P[( r + 2 ) * BDOF_S + c + 2] = ( int16_t ) ( ( ( int ) src[( long ) r * m.refStride + c] << headRoom ) - 8192 );
+  }
+  block_sync<64>();
+  for( int i = lane; i < dx * dy; i += 64 )
+  {
+    const int      y = i / dx, x = i - y * dx;
+    const int16_t *q = P + ( y + 2 ) * BDOF_S + x + 2;
+    Y[( y + 1 ) * BDOF_G + x + 1] = ( int16_t ) ( ( q[BDOF_S] >> 6 ) - ( q[-BDOF_S] >> 6 ) );
+    X[( y + 1 ) * BDOF_G + x + 1] = ( int16_t ) ( ( q[1] >> 6 ) - ( q[-1] >> 6 ) );
+  }
+  block_sync<64>();
+  // replicate the borders: gradients (gradFilterCore PAD part), then the prediction's ring (applyBiOptFlow :1266-1276) -- columns first, rows after
+  for( int y = lane; y < dy; y += 64 )
+  {
+    X[( y + 1 ) * BDOF_G] = X[( y + 1 ) * BDOF_G + 1]; X[( y + 1 ) * BDOF_G + dx + 1] = X[( y + 1 ) * BDOF_G + dx];
+    Y[( y + 1 ) * BDOF_G] = Y[( y + 1 ) * BDOF_G + 1]; Y[( y + 1 ) * BDOF_G + dx + 1] = Y[( y + 1 ) * BDOF_G + dx];
+    P[( y + 2 ) * BDOF_S + 1] = P[( y + 2 ) * BDOF_S + 2]; P[( y + 2 ) * BDOF_S + dx + 2] = P[( y + 2 ) * BDOF_S + dx + 1];
+  }
+  block_sync<64>();
+  for( int x = lane; x < dx + 2; x += 64 )
+  {
+    X[x] = X[BDOF_G + x]; X[( dy + 1 ) * BDOF_G + x] = X[dy * BDOF_G + x];
+    Y[x] = Y[BDOF_G + x]; Y[( dy + 1 ) * BDOF_G + x] = Y[dy * BDOF_G + x];
+    P[BDOF_S + x + 1] = P[2 * BDOF_S + x + 1]; P[( dy + 2 ) * BDOF_S + x + 1] = P[( dy + 1 ) * BDOF_S + x + 1];
+  }
+  block_sync<64>();
+}
+
+// where the final samples of a region go: the prediction and / or the fused consumer (residual, 2*org - pred)
+struct RegionOut
+{
+  const int16_t *org; int orgStride; int16_t *pred; int predStride; int16_t *out; int outStride; int mode;
+  __device__ __forceinline__ void row4( int y, int x0, const int v[4] ) const
+  {
+    if( pred )
+    {
+      int16_t *d = pred + ( long ) y * predStride + x0;
+#pragma unroll
+      for( int x = 0; x < 4; x++ ) d[x] = ( int16_t ) v[x];
+    }
+    if( mode )
+    {
+      const int16_t *o = org + ( long ) y * orgStride + x0;
+      int16_t       *d = out + ( long ) y * outStride + x0;
+#pragma unroll
+      for( int x = 0; x < 4; x++ ) d[x] = ( int16_t ) ( ( mode == 1 ? ( int ) o[x] : 2 * ( int ) o[x] ) - v[x] );
+    }
+  }
+};
+
+// both predictions are in L.pred: per 4 x 4 unit the 6 x 6 sums, the clipped refinement and the refined average (bio), or the plain addAvg.
+// Four lanes share a unit; lane q writes row q.  (y, x) passed to `ro` are relative to the region.
+__device__ __forceinline__ void bdof_units( const BdofLds &L, int dx, int dy, int bd, int lane, bool bio, const RegionOut &ro )
+{
+  const int  unitsX = dx >> 2, units = unitsX * ( dy >> 2 );
+  const int  u = lane >> 2, q = lane & 3;
+  const bool live = u < units;
+  const int  yu = live ? u / unitsX : 0, xu = live ? u - yu * unitsX : 0;
+  const int  headRoom = max( 2, 14 - bd ), shiftNum = headRoom + 1, offset = ( 1 << ( shiftNum - 1 ) ) + 2 * 8192, cmax = ( 1 << bd ) - 1;
+  int        tmpx = 0, tmpy = 0;
+  if( bio )
+  {
+    int sAbsGX = 0, sAbsGY = 0, sDIX = 0, sDIY = 0, sSign = 0;
+    if( live )
+    {
+#pragma unroll
+      for( int t = 0; t < 9; t++ )
+      {
+        const int k = q + 4 * t, wy = k / 6, wx = k - wy * 6;
+        const int gi = ( yu * 4 + wy ) * BDOF_G + xu * 4 + wx, pi = ( yu * 4 + wy + 1 ) * BDOF_S + xu * 4 + wx + 1;
+        const int tGX = ( ( int ) L.gx[0][gi] + ( int ) L.gx[1][gi] ) >> 1, tGY = ( ( int ) L.gy[0][gi] + ( int ) L.gy[1][gi] ) >> 1;
+        const int tDI = ( ( int ) L.pred[1][pi] >> 4 ) - ( ( int ) L.pred[0][pi] >> 4 );
+        sAbsGX += abs( tGX ); sAbsGY += abs( tGY );
+        sDIX += tGX < 0 ? -tDI : tGX == 0 ? 0 : tDI;
+        sDIY += tGY < 0 ? -tDI : tGY == 0 ? 0 : tDI;
+        sSign += tGY < 0 ? -tGX : tGY == 0 ? 0 : tGX;
+      }
+    }
+#pragma unroll
+    for( int o = 1; o <= 2; o <<= 1 )
+    {
+      sAbsGX += __shfl_xor( sAbsGX, o, 64 ); sAbsGY += __shfl_xor( sAbsGY, o, 64 ); sDIX += __shfl_xor( sDIX, o, 64 );
+      sDIY += __shfl_xor( sDIY, o, 64 ); sSign += __shfl_xor( sSign, o, 64 );
+    }
+    tmpx = sAbsGX == 0 ? 0 : ( sDIX * 4 ) >> ( 31 - __clz( sAbsGX ) );   // rightShiftMSB (:1606-1609)
+    tmpx = min( 15, max( -15, tmpx ) );
+    const int mains = sSign >> 12, secs = sSign & 4095;
+    const int tmpData = ( tmpx * mains * 4096 + tmpx * secs ) >> 1;
+    tmpy = sAbsGY == 0 ? 0 : ( sDIY * 4 - tmpData ) >> ( 31 - __clz( sAbsGY ) );
+    tmpy = min( 15, max( -15, tmpy ) );
+  }
+  if( !live ) return;
+  const int y = yu * 4 + q;
+  int v[4];
+#pragma unroll
+  for( int x = 0; x < 4; x++ )
+  {
+    const int gi = ( y + 1 ) * BDOF_G + xu * 4 + x + 1, pi = ( y + 2 ) * BDOF_S + xu * 4 + x + 2;
+    const int b  = bio ? tmpx * ( ( int ) L.gx[0][gi] - ( int ) L.gx[1][gi] ) + tmpy * ( ( int ) L.gy[0][gi] - ( int ) L.gy[1][gi] ) : 0;
+    v[x] = min( cmax, max( 0, ( int ) ( int16_t ) ( ( ( int ) L.pred[0][pi] + ( int ) L.pred[1][pi] + b + offset ) >> shiftNum ) ) );
+  }
+  ro.row4( y, xu * 4, v );
+}
+
 __global__ __launch_bounds__( 64 ) void bdof_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase, int16_t *__restrict__ predBase,
                                                     int16_t *__restrict__ outBase, const vtmhip_pred_job *__restrict__ jobs )
 {
-  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t tmp[16 * ( 16 + 7 )];
-  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sPred[2][BDOF_S * BDOF_S];
-  __shared__ int16_t sGx[2][BDOF_G * BDOF_G], sGy[2][BDOF_G * BDOF_G];
+  __shared__ BdofLds L;
   const vtmhip_pred_job j = jobs[blockIdx.y];
   const int lane = threadIdx.x;
   const int dx = min( 16, ( int ) j.width ), dy = min( 16, ( int ) j.height ), perRow = j.width / dx;
   const int region = blockIdx.x;
   if( region >= perRow * ( j.height / dy ) ) return;
   const int ry = ( region / perRow ) * dy, rx = ( region % perRow ) * dx;
-  const int bd = j.bitDepth, headRoom = max( 2, 14 - bd );
   vtmhip_mc_job m;
   m.width = ( int16_t ) dx; m.height = ( int16_t ) dy; m.bitDepth = j.bitDepth; m.useAltHpelIf = 0; m.chroma = 0; m.bi = 1;
   m.dstOff = 0; m.dstStride = 0;
 #pragma unroll
   for( int l = 0; l < 2; l++ )
   {
-    int16_t *P = sPred[l], *X = sGx[l], *Y = sGy[l];
     m.refOff = ( l ? j.refOff[1] : j.refOff[0] ) + ( long ) ry * ( l ? j.refStride[1] : j.refStride[0] ) + rx;
     m.refStride = l ? j.refStride[1] : j.refStride[0];
     m.mvHor = l ? j.mv[1][0] : j.mv[0][0]; m.mvVer = l ? j.mv[1][1] : j.mv[0][1];
-    mc_any<64>( m, refBase, tmp, lane, StorePad{ P, BDOF_S } );
-    // ring: the integer sample nearest to the fractional position, as a 14-bit intermediate (:768-803)
-    const int16_t *src = refBase + m.refOff + ( long ) ( ( m.mvVer >> 4 ) + ( ( m.mvVer & 15 ) < 8 ? 0 : 1 ) ) * m.refStride + ( m.mvHor >> 4 ) + ( ( m.mvHor & 15 ) < 8 ? 0 : 1 );
-    for( int i = lane; i < 2 * ( dx + 2 ) + 2 * dy; i += 64 )
+    bdof_list( L, l, m, refBase, lane, true );
+  }
+  const int mode = ( outBase && orgBase ) ? j.epilogue : 0;
+  const RegionOut ro{ orgBase ? orgBase + j.orgOff + ( long ) ry * j.orgStride + rx : nullptr, j.orgStride,
+                      predBase ? predBase + j.predOff + ( long ) ry * j.predStride + rx : nullptr, j.predStride,
+                      outBase ? outBase + j.outOff + ( long ) ry * j.outStride + rx : nullptr, j.outStride, mode };
+  bdof_units( L, dx, dy, j.bitDepth, lane, true, ro );
+}
+
+// ---- DMVR: InterPrediction::xProcessDMVR (InterPrediction.cpp:1997-2195) for the luma plane of a bi-predicted PU.  One wave per sub-PU of at most
+// 16 x 16: the (dx+7) x (dy+7) integer window of each list is fetched ONCE into LDS (xPrefetch :1666-1708) and everything else works from there:
+// bilinear (dx+4) x (dy+4) predictions (xinitMC :1941-1995), the 25 row-sub-sampled SADs of the mirrored displacements (xDMVRCost, xBIPMVRefine
+// :1819-1843; 2 lanes per displacement), the error surface (:1733-1817), the 2-sample replication of the window when the sub-PU moved (xPad
+// :1709-1731), the 8-tap prediction out of the padded window (xFinalPaddedMCForDMVR :1845-1917) and the average, with BDOF when the caller's
+// bioApplied holds and the matching cost is not below 2*dx*dy (:2139).
+constexpr int DMVR_PS = 28, DMVR_BS = 20;
+
+__device__ __forceinline__ void clip_mv_pic( int &hor, int &ver, const vtmhip_pic_params &pp, int x, int y )   // clipMvInPic, Mv.cpp:56-74
+{
+  hor = min( ( pp.picW + 8 - x - 1 ) << 4, max( ( -pp.ctuSize - 8 - x + 1 ) << 4, hor ) );
+  ver = min( ( pp.picH + 8 - y - 1 ) << 4, max( ( -pp.ctuSize - 8 - y + 1 ) << 4, ver ) );
+}
+
+__device__ __forceinline__ int div_for_maxq7( long long N, long long D )   // :1733-1767
+{
+  int sign = 0, q = 0;
+  if( N < 0 ) { sign = 1; N = -N; }
+  D = D * 8;
+  if( N >= D ) { N -= D; q++; }
+  q = q * 2;
+  D = D >> 1;
+  if( N >= D ) { N -= D; q++; }
+  q = q * 2;
+  if( N >= ( D >> 1 ) ) q++;
+  return sign ? -q : q;
+}
+
+__global__ __launch_bounds__( 64 ) void dmvr_kernel( vtmhip_pic_params pp, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+                                                    int16_t *__restrict__ predBase, int16_t *__restrict__ outBase, const vtmhip_dmvr_job *__restrict__ jobs,
+                                                    int32_t *__restrict__ mvdOut )
+{
+  __shared__ BdofLds L;
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sPad[2][DMVR_PS * DMVR_PS];
+  __shared__ int16_t  sBil[2][DMVR_BS * DMVR_BS];
+  __shared__ unsigned sSad[32];
+  const vtmhip_dmvr_job j = jobs[blockIdx.y];
+  const int lane = threadIdx.x;
+  const int dx = min( 16, ( int ) j.width ), dy = min( 16, ( int ) j.height ), perRow = j.width / dx;
+  const int region = blockIdx.x;
+  if( region >= perRow * ( j.height / dy ) ) return;
+  const int ry = ( region / perRow ) * dy, rx = ( region % perRow ) * dx;
+  const int x = j.puX + rx, y = j.puY + ry, bd = j.bitDepth;
+  // xPrefetch + xinitMC
+#pragma unroll
+  for( int l = 0; l < 2; l++ )
+  {
+    const int  mvH = l ? j.mv[1][0] : j.mv[0][0], mvV = l ? j.mv[1][1] : j.mv[0][1];
+    const long rs  = l ? j.refStride[1] : j.refStride[0];
+    int ph = mvH - ( 3 << 4 ), pv = mvV - ( 3 << 4 );
+    clip_mv_pic( ph, pv, pp, x, y );
+    const int16_t *src = refBase + ( l ? j.refOff[1] : j.refOff[0] ) + ( long ) ( ry + ( pv >> 4 ) ) * rs + rx + ( ph >> 4 );
+    for( int i = lane; i < ( dx + 7 ) * ( dy + 7 ); i += 64 )
     {
-      int r, c;
-      if( i < 2 * ( dx + 2 ) ) { r = i < dx + 2 ? -1 : dy; c = ( i < dx + 2 ? i : i - ( dx + 2 ) ) - 1; }
-      else { const int t = i - 2 * ( dx + 2 ); r = t >> 1; c = ( t & 1 ) ? dx : -1; }
-      P[( r + 2 ) * BDOF_S + c + 2] = ( int16_t ) ( ( ( int ) src[( long ) r * m.refStride + c] << headRoom ) - 8192 );
+      const int r = i / ( dx + 7 ), c = i - r * ( dx + 7 );
+      sPad[l][( r + 2 ) * DMVR_PS + c + 2] = src[r * rs + c];
+    }
+  }
+  block_sync<64>();
+#pragma unroll
+  for( int l = 0; l < 2; l++ )
+  {
+    int mh = l ? j.mv[1][0] : j.mv[0][0], mv = l ? j.mv[1][1] : j.mv[0][1];
+    clip_mv_pic( mh, mv, pp, x, y );
+    const int xFrac = mh & 15, yFrac = mv & 15, bw = dx + 4, bh = dy + 4;
+    const int sh1 = 4 - ( 10 - bd ), off1 = 1 << ( sh1 - 1 );   // biMCForDMVR, first pass (InterpolationFilter.cpp:603-614)
+    const int16_t *b0 = sPad[l] + 3 * ( DMVR_PS + 1 );
+    for( int i = lane; i < bw * bh; i += 64 )
+    {
+      const int      r = i / bw, c = i - r * bw;
+      const int16_t *p = b0 + r * DMVR_PS + c;
+      int v;
+      if( xFrac == 0 && yFrac == 0 ) v = bd > 10 ? ( ( int ) p[0] + ( 1 << ( bd - 11 ) ) ) >> ( bd - 10 ) : ( int ) p[0] << ( 10 - bd );   // filterCopy, :417-447
+      else if( yFrac == 0 ) v = ( ( 16 - xFrac ) * ( int ) p[0] + xFrac * ( int ) p[1] + off1 ) >> sh1;
+      else if( xFrac == 0 ) v = ( ( 16 - yFrac ) * ( int ) p[0] + yFrac * ( int ) p[DMVR_PS] + off1 ) >> sh1;
+      else
+      {
+        const int t0 = ( int16_t ) ( ( ( 16 - xFrac ) * ( int ) p[0] + xFrac * ( int ) p[1] + off1 ) >> sh1 );
+        const int t1 = ( int16_t ) ( ( ( 16 - xFrac ) * ( int ) p[DMVR_PS] + xFrac * ( int ) p[DMVR_PS + 1] + off1 ) >> sh1 );
+        v = ( ( 16 - yFrac ) * t0 + yFrac * t1 + 8 ) >> 4;
+      }
+      sBil[l][r * DMVR_BS + c] = ( int16_t ) v;
+    }
+  }
+  block_sync<64>();
+  // the 25 matching costs: lane = 2 * displacement + half; every other row (setDistParam subShift 1, then >> 1: RdCost.cpp:368-408)
+  {
+    const int o = lane >> 1, half = lane & 1;
+    unsigned  acc = 0;
+    if( o < 25 )
+    {
+      const int      ox = o % 5 - 2, oy = o / 5 - 2, rows = dy >> 2;   // even rows of this half
+      const int16_t *a = sBil[0] + ( 2 + oy ) * DMVR_BS + 2 + ox, *b = sBil[1] + ( 2 - oy ) * DMVR_BS + 2 - ox;
+      for( int t = 0; t < rows; t++ )
+      {
+        const int r = 2 * ( half * rows + t );
+        for( int c = 0; c < dx; c++ ) acc += ( unsigned ) abs( ( int ) a[r * DMVR_BS + c] - ( int ) b[r * DMVR_BS + c] );
+      }
+    }
+    acc += __shfl_xor( acc, 1, 64 );
+    if( o < 25 && half == 0 ) sSad[o] = acc;
+  }
+  block_sync<64>();
+  // decisions, computed by every lane alike (wave-uniform): xProcessDMVR :2110-2150
+  unsigned minCost = sSad[12] - ( sSad[12] >> 2 );
+  int      best = 12, notZero = 1, total0 = 0, total1 = 0;
+  if( minCost < ( unsigned ) ( dx * dy ) ) notZero = 0;
+  else
+  {
+    const unsigned centre = minCost;
+    for( int i = 0; i < 25; i++ )
+    {
+      const unsigned s = i == 12 ? centre : sSad[i];
+      if( s < minCost ) { minCost = s; best = i; }
+    }
+    total0 = ( best % 5 - 2 ) * 16; total1 = ( best / 5 - 2 ) * 16;
+  }
+  const bool bio = minCost < ( unsigned ) ( 2 * dx * dy ) ? false : j.bioApplied != 0;
+  if( notZero && abs( total0 ) != 32 && abs( total1 ) != 32 )   // xDMVRSubPixelErrorSurface :1929-1947
+  {
+    const unsigned centre = sSad[12] - ( sSad[12] >> 2 );
+    auto sad = [&]( int i ) -> long long { return ( long long ) ( i == 12 ? centre : sSad[i] ); };
+    const long long s0 = sad( best ), sl = sad( best - 1 ), st = sad( best - 5 ), sr = sad( best + 1 ), sb = sad( best + 5 );
+    const long long dh = sl + sr - 2 * s0, dv = st + sb - 2 * s0;
+    if( dh != 0 ) total0 += ( sl != s0 && sr != s0 ) ? div_for_maxq7( ( sl - sr ) * 16, dh ) : ( sl == s0 ? -8 : 8 );
+    if( dv != 0 ) total1 += ( st != s0 && sb != s0 ) ? div_for_maxq7( ( st - sb ) * 16, dv ) : ( st == s0 ? -8 : 8 );
+  }
+  if( mvdOut && lane == 0 )
+  {
+    int32_t *m = mvdOut + ( ( long ) blockIdx.y * gridDim.x + region ) * 2;
+    m[0] = total0; m[1] = total1;
+  }
+  if( total0 != 0 || total1 != 0 )   // xPad (paddingCore, Buffer.cpp:340-364): columns, then rows
+  {
+    const int pw = dx + 7, ph = dy + 7;
+    for( int i = lane; i < 2 * ph; i += 64 )
+    {
+      int16_t *p = sPad[i & 1] + 2 * ( DMVR_PS + 1 ) + ( i >> 1 ) * DMVR_PS;
+      p[-1] = p[-2] = p[0];
+      p[pw] = p[pw + 1] = p[pw - 1];
     }
     block_sync<64>();
-    for( int i = lane; i < dx * dy; i += 64 )
+    for( int i = lane; i < 2 * ( pw + 4 ); i += 64 )
     {
-      const int      y = i / dx, x = i - y * dx;
-      const int16_t *q = P + ( y + 2 ) * BDOF_S + x + 2;
-      Y[( y + 1 ) * BDOF_G + x + 1] = ( int16_t ) ( ( q[BDOF_S] >> 6 ) - ( q[-BDOF_S] >> 6 ) );
-      X[( y + 1 ) * BDOF_G + x + 1] = ( int16_t ) ( ( q[1] >> 6 ) - ( q[-1] >> 6 ) );
-    }
-    block_sync<64>();
-    // replicate the borders: gradients (gradFilterCore PAD part), then the prediction's ring (applyBiOptFlow :1266-1276) -- columns first, rows after
-    for( int y = lane; y < dy; y += 64 )
-    {
-      X[( y + 1 ) * BDOF_G] = X[( y + 1 ) * BDOF_G + 1]; X[( y + 1 ) * BDOF_G + dx + 1] = X[( y + 1 ) * BDOF_G + dx];
-      Y[( y + 1 ) * BDOF_G] = Y[( y + 1 ) * BDOF_G + 1]; Y[( y + 1 ) * BDOF_G + dx + 1] = Y[( y + 1 ) * BDOF_G + dx];
-      P[( y + 2 ) * BDOF_S + 1] = P[( y + 2 ) * BDOF_S + 2]; P[( y + 2 ) * BDOF_S + dx + 2] = P[( y + 2 ) * BDOF_S + dx + 1];
-    }
-    block_sync<64>();
-    for( int x = lane; x < dx + 2; x += 64 )
-    {
-      X[x] = X[BDOF_G + x]; X[( dy + 1 ) * BDOF_G + x] = X[dy * BDOF_G + x];
-      Y[x] = Y[BDOF_G + x]; Y[( dy + 1 ) * BDOF_G + x] = Y[dy * BDOF_G + x];
-      P[BDOF_S + x + 1] = P[2 * BDOF_S + x + 1]; P[( dy + 2 ) * BDOF_S + x + 1] = P[( dy + 1 ) * BDOF_S + x + 1];
+      int16_t *p = sPad[i & 1] + 2 * DMVR_PS + ( i >> 1 );
+      p[-DMVR_PS] = p[-2 * DMVR_PS] = p[0];
+      p[ph * DMVR_PS] = p[( ph + 1 ) * DMVR_PS] = p[( ph - 1 ) * DMVR_PS];
     }
     block_sync<64>();
   }
-  const int unitsX = dx >> 2, units = unitsX * ( dy >> 2 );
-  const int u = lane >> 2, q = lane & 3;
-  const bool live = u < units;
-  const int yu = live ? u / unitsX : 0, xu = live ? u - yu * unitsX : 0;
-  int sAbsGX = 0, sAbsGY = 0, sDIX = 0, sDIY = 0, sSign = 0;
-  if( live )
-  {
+  // xFinalPaddedMCForDMVR + xWeightedAverage
+  vtmhip_mc_job m;
+  m.width = ( int16_t ) dx; m.height = ( int16_t ) dy; m.bitDepth = j.bitDepth; m.useAltHpelIf = 0; m.chroma = 0; m.bi = 1;
+  m.dstOff = 0; m.dstStride = 0; m.refStride = DMVR_PS;
 #pragma unroll
-    for( int t = 0; t < 9; t++ )
-    {
-      const int k = q + 4 * t, wy = k / 6, wx = k - wy * 6;
-      const int gi = ( yu * 4 + wy ) * BDOF_G + xu * 4 + wx, pi = ( yu * 4 + wy + 1 ) * BDOF_S + xu * 4 + wx + 1;
-      const int tGX = ( ( int ) sGx[0][gi] + ( int ) sGx[1][gi] ) >> 1, tGY = ( ( int ) sGy[0][gi] + ( int ) sGy[1][gi] ) >> 1;
-      const int tDI = ( ( int ) sPred[1][pi] >> 4 ) - ( ( int ) sPred[0][pi] >> 4 );
-      sAbsGX += abs( tGX ); sAbsGY += abs( tGY );
-      sDIX += tGX < 0 ? -tDI : tGX == 0 ? 0 : tDI;
-      sDIY += tGY < 0 ? -tDI : tGY == 0 ? 0 : tDI;
-      sSign += tGY < 0 ? -tGX : tGY == 0 ? 0 : tGX;
-    }
-  }
-#pragma unroll
-  for( int o = 1; o <= 2; o <<= 1 )
+  for( int l = 0; l < 2; l++ )
   {
-    sAbsGX += __shfl_xor( sAbsGX, o, 64 ); sAbsGY += __shfl_xor( sAbsGY, o, 64 ); sDIX += __shfl_xor( sDIX, o, 64 );
-    sDIY += __shfl_xor( sDIY, o, 64 ); sSign += __shfl_xor( sSign, o, 64 );
+    const int mvH = l ? j.mv[1][0] : j.mv[0][0], mvV = l ? j.mv[1][1] : j.mv[0][1];
+    int rh = min( ( 1 << 17 ) - 1, max( -( 1 << 17 ), mvH + ( l ? -total0 : total0 ) ) );   // clipToStorageBitDepth
+    int rv = min( ( 1 << 17 ) - 1, max( -( 1 << 17 ), mvV + ( l ? -total1 : total1 ) ) );
+    const int dX = ( rh >> 4 ) - ( mvH >> 4 ), dY = ( rv >> 4 ) - ( mvV >> 4 );
+    clip_mv_pic( rh, rv, pp, x, y );
+    m.refOff = 5 * ( DMVR_PS + 1 ) + dY * DMVR_PS + dX;
+    m.mvHor = rh & 15; m.mvVer = rv & 15;
+    bdof_list( L, l, m, l ? sPad[1] : sPad[0], lane, bio );
   }
-  if( !live ) return;
-  int tmpx = sAbsGX == 0 ? 0 : ( sDIX * 4 ) >> ( 31 - __clz( sAbsGX ) );   // rightShiftMSB (:1606-1609)
-  tmpx = min( 15, max( -15, tmpx ) );
-  const int mains = sSign >> 12, secs = sSign & 4095;
-  const int tmpData = ( tmpx * mains * 4096 + tmpx * secs ) >> 1;
-  int tmpy = sAbsGY == 0 ? 0 : ( sDIY * 4 - tmpData ) >> ( 31 - __clz( sAbsGY ) );
-  tmpy = min( 15, max( -15, tmpy ) );
-  const int shiftNum = headRoom + 1, offset = ( 1 << ( shiftNum - 1 ) ) + 2 * 8192, cmax = ( 1 << bd ) - 1;
-  const int y = yu * 4 + q;   // lane q of the unit writes its row q
-  int v[4];
-#pragma unroll
-  for( int x = 0; x < 4; x++ )
-  {
-    const int gi = ( y + 1 ) * BDOF_G + xu * 4 + x + 1, pi = ( y + 2 ) * BDOF_S + xu * 4 + x + 2;
-    const int b  = tmpx * ( ( int ) sGx[0][gi] - ( int ) sGx[1][gi] ) + tmpy * ( ( int ) sGy[0][gi] - ( int ) sGy[1][gi] );
-    v[x] = min( cmax, max( 0, ( int ) ( int16_t ) ( ( ( int ) sPred[0][pi] + ( int ) sPred[1][pi] + b + offset ) >> shiftNum ) ) );
-  }
-  const int  py = ry + y, px = rx + xu * 4;
-  const int  mode = ( outBase && orgBase ) ? j.epilogue : 0;
-  if( predBase )
-  {
-    int16_t *d = predBase + j.predOff + ( long ) py * j.predStride + px;
-#pragma unroll
-    for( int x = 0; x < 4; x++ ) d[x] = ( int16_t ) v[x];
-  }
-  if( mode )
-  {
-    const int16_t *o = orgBase + j.orgOff + ( long ) py * j.orgStride + px;
-    int16_t       *d = outBase + j.outOff + ( long ) py * j.outStride + px;
-#pragma unroll
-    for( int x = 0; x < 4; x++ ) d[x] = ( int16_t ) ( ( mode == 1 ? ( int ) o[x] : 2 * ( int ) o[x] ) - v[x] );
-  }
+  const int mode = ( outBase && orgBase ) ? j.epilogue : 0;
+  const RegionOut ro{ orgBase ? orgBase + j.orgOff + ( long ) ry * j.orgStride + rx : nullptr, j.orgStride,
+                      predBase ? predBase + j.predOff + ( long ) ry * j.predStride + rx : nullptr, j.predStride,
+                      outBase ? outBase + j.outOff + ( long ) ry * j.outStride + rx : nullptr, j.outStride, mode };
+  bdof_units( L, dx, dy, bd, lane, bio, ro );
 }
 
 // InterpolationFilter::xWeightedGeoBlk (InterpolationFilter.cpp:902-957): one wave per blend, four output samples per lane and step when the width
@@ -690,6 +899,23 @@ int vtmhip_bdof_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int1
   VTMHIP_REQUIRE( ctx, n <= 65535, "at most 65535 PUs per launch" );
   const int regions = ( ( maxWidth + 15 ) / 16 ) * ( ( maxHeight + 15 ) / 16 );
   hipLaunchKernelGGL( bdof_kernel, dim3( regions, n ), dim3( 64 ), 0, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_dmvr_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, int16_t *d_predBase,
+                           int16_t *d_outBase, const vtmhip_dmvr_job *d_jobs, int n, int maxWidth, int maxHeight, int32_t *d_mvd )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, pic && d_refBase && d_jobs && ( d_predBase || d_outBase || d_mvd ), "null pointer" );
+  VTMHIP_REQUIRE( ctx, !d_outBase || d_orgBase, "an epilogue output needs the original plane" );
+  VTMHIP_REQUIRE( ctx, pic->bitDepth >= 8 && pic->bitDepth <= 12 && pic->picW > 0 && pic->picH > 0 && pic->ctuSize >= 16, "picture parameters" );
+  VTMHIP_REQUIRE( ctx, maxWidth >= 8 && maxWidth <= 128 && maxHeight >= 8 && maxHeight <= 128, "maxWidth / maxHeight (DMVR needs 8 <= w, h <= 128)" );
+  VTMHIP_REQUIRE( ctx, n <= 65535, "at most 65535 PUs per launch" );
+  const int regions = ( ( maxWidth + 15 ) / 16 ) * ( ( maxHeight + 15 ) / 16 );
+  hipLaunchKernelGGL( dmvr_kernel, dim3( regions, n ), dim3( 64 ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, d_mvd );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

@@ -233,6 +233,10 @@ class Context:
         """xPredInterBi with bioApplied (BDOF) for bi-predicted luma PUs; same job table and epilogues as motion_compensation_batch."""
         self._check(self.L.vtmhip_bdof_batch_dev(self.h, d_org, d_ref, d_pred, d_out, d_jobs, n, max_w, max_h))
 
+    def dmvr_batch(self, pic, d_org, d_ref, d_pred, d_out, d_jobs, n, max_w, max_h, d_mvd=0):
+        """xProcessDMVR (luma) for bi-predicted merge PUs: refined prediction (+ epilogue) and the sub-PU vector differences."""
+        self._check(self.L.vtmhip_dmvr_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_pred, d_out, d_jobs, n, max_w, max_h, d_mvd))
+
     def mc_batch(self, d_ref, d_dst, d_jobs, n, max_w, max_h):
         """xPredInterBlk for luma and 4:2:0 chroma blocks (McJob.chroma)."""
         self._check(self.L.vtmhip_mc_batch_dev(self.h, d_ref, d_dst, d_jobs, n, max_w, max_h))
