@@ -367,12 +367,20 @@ typedef struct
   uint8_t bioApplied;           /* what xPredInterBi decided for the PU (:527-572) */
   uint8_t epilogue;             /* as vtmhip_pred_job */
   uint8_t bitDepth, pad0;
-  int32_t pad1;
+  int32_t mvdRow;               /* chroma call only: the d_mvd row (= job index of the luma call) that holds this PU's vector differences */
 } vtmhip_dmvr_job;
 /* pic: picW / picH / ctuSize / bitDepth.  d_mvd (may be NULL): pu.mvdL0SubPu, int32 [n][regions][2] with regions = ceil(maxWidth/16) * ceil(maxHeight/16),
- * sub-PUs in the reference's raster order; the chroma planes of a moved sub-PU are predicted with mergeMv +- mvd by the caller. */
+ * sub-PUs in the reference's raster order. */
 int vtmhip_dmvr_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, int16_t *d_predBase,
                            int16_t *d_outBase, const vtmhip_dmvr_job *d_jobs, int n, int maxWidth, int maxHeight, int32_t *d_mvd );
+
+/* One 4:2:0 chroma plane of the same PUs, after the luma call: a sub-PU whose difference is zero is predicted from the reference pictures, a moved one
+ * out of its (w/2+3) x (h/2+3) window -- prefetched with the MERGE vector (xPrefetch forLuma = 0, :1666-1708), replicated by one sample (xPad: padsize =
+ * 2 >> scaleY, :1709-1731), addressed with the whole-sample part of the refined vector (xFinalPaddedMCForDMVR :1879-1905) -- then the plain addAvg.
+ * The jobs keep width / height / puX / puY / mv in LUMA units; refOff / strides / orgOff / predOff / outOff address THAT chroma plane (refOff: the PU's
+ * position in it); d_mvd, maxWidth and maxHeight are those of the luma call (same `regions`), vtmhip_dmvr_job::mvdRow picks the row. */
+int vtmhip_dmvr_chroma_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, int16_t *d_predBase,
+                                  int16_t *d_outBase, const vtmhip_dmvr_job *d_jobs, int n, int maxWidth, int maxHeight, const int32_t *d_mvd );
 
 /* InterpolationFilter::m_weightedGeoBlk (InterpolationFilter.h:99; xWeightedGeoBlk InterpolationFilter.cpp:902-957, x86/InterpolationFilterX86.h:1343-1470;
  * callers InterPrediction::weightedGeoBlk InterPrediction.cpp:1642-1661, EncCu.cpp:3004,3030): blend of the two GEO partitions' 14-bit predictions,

@@ -529,14 +529,11 @@ extern "C" void ref_dmvr_pu( const int16_t *plane0, const int16_t *plane1, int s
   MeRig &r = *g_rig;
   static Picture *pics[2] = { nullptr, nullptr };
   InterPrediction &ip = r.is;
-  if( !pics[0] )
-  {
-    pics[0] = new Picture(); pics[1] = new Picture();
-    const size_t dm = ( MAX_CU_SIZE + ( 2 * DMVR_NUM_ITERATION ) ), dr = dm + NTAPS_LUMA;
-    ip.m_cYuvPredTempDMVRL0 = ( Pel * ) xMalloc( Pel, dm * dm ); ip.m_cYuvPredTempDMVRL1 = ( Pel * ) xMalloc( Pel, dm * dm );
-    ip.m_cRefSamplesDMVRL0[0] = ( Pel * ) xMalloc( Pel, dr * dr ); ip.m_cRefSamplesDMVRL1[0] = ( Pel * ) xMalloc( Pel, dr * dr );
-    ip.m_acYuvPred[0][0] = ( Pel * ) xMalloc( Pel, MAX_CU_SIZE * MAX_CU_SIZE ); ip.m_acYuvPred[1][0] = ( Pel * ) xMalloc( Pel, MAX_CU_SIZE * MAX_CU_SIZE );
-  }
+  if( !pics[0] ) { pics[0] = new Picture(); pics[1] = new Picture(); }
+  const size_t dm = ( MAX_CU_SIZE + ( 2 * DMVR_NUM_ITERATION ) ), dr = dm + NTAPS_LUMA;
+  if( !ip.m_cYuvPredTempDMVRL0 ) { ip.m_cYuvPredTempDMVRL0 = ( Pel * ) xMalloc( Pel, dm * dm ); ip.m_cYuvPredTempDMVRL1 = ( Pel * ) xMalloc( Pel, dm * dm ); }
+  if( !ip.m_cRefSamplesDMVRL0[0] ) { ip.m_cRefSamplesDMVRL0[0] = ( Pel * ) xMalloc( Pel, dr * dr ); ip.m_cRefSamplesDMVRL1[0] = ( Pel * ) xMalloc( Pel, dr * dr ); }
+  if( !ip.m_acYuvPred[0][0] ) { ip.m_acYuvPred[0][0] = ( Pel * ) xMalloc( Pel, MAX_CU_SIZE * MAX_CU_SIZE ); ip.m_acYuvPred[1][0] = ( Pel * ) xMalloc( Pel, MAX_CU_SIZE * MAX_CU_SIZE ); }
   if( !ip.m_gradX0 )
   {
     ip.m_gradX0 = ( Pel * ) xMalloc( Pel, BIO_TEMP_BUFFER_SIZE ); ip.m_gradY0 = ( Pel * ) xMalloc( Pel, BIO_TEMP_BUFFER_SIZE );
@@ -589,6 +586,81 @@ extern "C" void ref_dmvr_pu( const int16_t *plane0, const int16_t *plane1, int s
   r.slice.m_apcRefPicList[0][0] = r.slice.m_apcRefPicList[1][0] = nullptr;
   r.cu.chromaFormat = CHROMA_420;
   r.pu.chromaFormat = CHROMA_420;
+  r.cu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+  r.pu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+}
+
+// The same member on a 4:2:0 PU: luma and both chroma planes (xPrefetch forLuma = 0, xPad and the padded 4-tap prediction of moved sub-PUs).
+// planes[l][c]: origin of component c of reference picture l; dst[c]: the three prediction blocks.
+extern "C" void ref_dmvr_pu420( const int16_t *const planes[2][3], int strideY, int strideC, int picW, int picH, int ctuSize, int puX, int puY, int w, int h,
+                                int mv0Hor, int mv0Ver, int mv1Hor, int mv1Ver, int bitDepth, int bioApplied, int16_t *const dst[3], int dstStrideY,
+                                int dstStrideC, int32_t *mvdOut )
+{
+  ensureRom();
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  static Picture *pics[2] = { nullptr, nullptr };
+  InterPrediction &ip = r.is;
+  if( !pics[0] ) { pics[0] = new Picture(); pics[1] = new Picture(); }
+  const size_t dm = ( MAX_CU_SIZE + ( 2 * DMVR_NUM_ITERATION ) ), dr = dm + NTAPS_LUMA;
+  if( !ip.m_cYuvPredTempDMVRL0 ) { ip.m_cYuvPredTempDMVRL0 = ( Pel * ) xMalloc( Pel, dm * dm ); ip.m_cYuvPredTempDMVRL1 = ( Pel * ) xMalloc( Pel, dm * dm ); }
+  for( int c = 0; c < 3; c++ )
+  {
+    if( !ip.m_cRefSamplesDMVRL0[c] ) { ip.m_cRefSamplesDMVRL0[c] = ( Pel * ) xMalloc( Pel, dr * dr ); ip.m_cRefSamplesDMVRL1[c] = ( Pel * ) xMalloc( Pel, dr * dr ); }
+    if( !ip.m_acYuvPred[0][c] ) { ip.m_acYuvPred[0][c] = ( Pel * ) xMalloc( Pel, MAX_CU_SIZE * MAX_CU_SIZE ); ip.m_acYuvPred[1][c] = ( Pel * ) xMalloc( Pel, MAX_CU_SIZE * MAX_CU_SIZE ); }
+    if( !ip.m_filteredBlockTmp[0][c] ) ip.m_filteredBlockTmp[0][c] = ( Pel * ) xMalloc( Pel, ( MAX_CU_SIZE + 16 + 4 ) * ( MAX_CU_SIZE + 1 + 16 + 7 + 4 ) );
+  }
+  if( !ip.m_gradX0 )
+  {
+    ip.m_gradX0 = ( Pel * ) xMalloc( Pel, BIO_TEMP_BUFFER_SIZE ); ip.m_gradY0 = ( Pel * ) xMalloc( Pel, BIO_TEMP_BUFFER_SIZE );
+    ip.m_gradX1 = ( Pel * ) xMalloc( Pel, BIO_TEMP_BUFFER_SIZE ); ip.m_gradY1 = ( Pel * ) xMalloc( Pel, BIO_TEMP_BUFFER_SIZE );
+  }
+  ip.m_pcRdCost = &r.rd;
+  const PelBufferOps saved = g_pelBufOP;
+  g_pelBufOP = PelBufferOps();
+  g_pelBufOP.initPelBufOpsX86();
+  r.pps.setPicWidthInLumaSamples( picW );
+  r.pps.setPicHeightInLumaSamples( picH );
+  r.sps.setMaxCUWidth( ctuSize );
+  r.sps.setMaxCUHeight( ctuSize );
+  r.sps.setBitDepth( CHANNEL_TYPE_LUMA, bitDepth );
+  r.sps.setBitDepth( CHANNEL_TYPE_CHROMA, bitDepth );
+  r.slice.m_pcSPS = &r.sps;
+  ClpRng clp; clp.min = 0; clp.max = ( 1 << bitDepth ) - 1; clp.bd = bitDepth; clp.n = 0;
+  for( int c = 0; c < 3; c++ ) r.slice.getClpRngs().comp[c] = clp;
+  for( int l = 0; l < 2; l++ )
+  {
+    Picture *pic = pics[l];
+    pic->chromaFormat = CHROMA_420;
+    pic->unscaledPic  = pic;
+    pic->m_bufs[PIC_RECONSTRUCTION].createFromBuf( PelUnitBuf( CHROMA_420, PelBuf( const_cast<Pel *>( planes[l][0] ), strideY, picW, picH ),
+                                                               PelBuf( const_cast<Pel *>( planes[l][1] ), strideC, picW / 2, picH / 2 ),
+                                                               PelBuf( const_cast<Pel *>( planes[l][2] ), strideC, picW / 2, picH / 2 ) ) );
+    r.slice.m_apcRefPicList[l][0] = pic;
+    r.slice.m_scalingRatio[l][0]  = SCALE_1X;
+  }
+  const UnitArea ua( CHROMA_420, Area( puX, puY, w, h ) );
+  r.cu.UnitArea::operator=( ua );
+  r.pu.UnitArea::operator=( ua );
+  r.cu.chromaFormat = CHROMA_420;
+  r.pu.chromaFormat = CHROMA_420;
+  r.cu.imv = 0;
+  r.cu.BcwIdx = BCW_DEFAULT;
+  r.cu.affine = false;
+  r.cu.geoFlag = false;
+  r.pu.ciipFlag = false;
+  r.pu.refIdx[0] = r.pu.refIdx[1] = 0;
+  r.pu.mv[0] = Mv( mv0Hor, mv0Ver );
+  r.pu.mv[1] = Mv( mv1Hor, mv1Ver );
+  PelUnitBuf out( CHROMA_420, PelBuf( dst[0], dstStrideY, w, h ), PelBuf( dst[1], dstStrideC, w / 2, h / 2 ), PelBuf( dst[2], dstStrideC, w / 2, h / 2 ) );
+  ip.xProcessDMVR( r.pu, out, r.slice.clpRngs(), bioApplied != 0 );
+  if( mvdOut )
+  {
+    const int n = ( w / std::min( w, 16 ) ) * ( h / std::min( h, 16 ) );
+    for( int i = 0; i < n; i++ ) { mvdOut[2 * i] = r.pu.mvdL0SubPu[i].hor; mvdOut[2 * i + 1] = r.pu.mvdL0SubPu[i].ver; }
+  }
+  g_pelBufOP = saved;
+  r.slice.m_apcRefPicList[0][0] = r.slice.m_apcRefPicList[1][0] = nullptr;
   r.cu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
   r.pu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
 }

@@ -1490,6 +1490,62 @@ void vo_dmvr_pu( const int16_t *plane0, const int16_t *plane1, int stride, int p
     }
 }
 
+/* The 4:2:0 chroma planes of the same PU (xProcessDMVR with chroma enabled): a sub-PU that did not move is predicted straight from the reference
+ * pictures (xFinalPaddedMCForDMVR passes no window, :1879-1905), a moved one out of its own (w/2+3) x (h/2+3) window, prefetched with the MERGE vector
+ * (xPrefetch forLuma = 0, :1666-1708), replicated by ONE sample (xPad: padsize = 2 >> scaleY, :1709-1731) and addressed with the whole-sample part of
+ * the refined vector; then the plain addAvg.  planeC0 / planeC1: origins of that chroma plane in the two reference pictures; puX, puY, w, h and the
+ * vectors stay in luma units; mvd: pu.mvdL0SubPu as vo_dmvr_pu returned it. */
+void vo_dmvr_chroma( const int16_t *planeC0, const int16_t *planeC1, int strideC, int picW, int picH, int ctuSize, int puX, int puY, int w, int h,
+                     int mv0Hor, int mv0Ver, int mv1Hor, int mv1Ver, const int32_t *mvd, int bitDepth, int16_t *dst, int dstStride )
+{
+  enum { MAXC = 8, PSC = MAXC + 12 };
+  const int mergeMv[2][2] = { { mv0Hor, mv0Ver }, { mv1Hor, mv1Ver } };
+  const int dx = w < 16 ? w : 16, dy = h < 16 ? h : 16, cw = dx >> 1, chh = dy >> 1;
+  const int headRoom = 14 - bitDepth > 2 ? 14 - bitDepth : 2, cmax = ( 1 << bitDepth ) - 1;
+  int num = 0;
+  for( int sy = 0; sy < h; sy += dy )
+    for( int sx = 0; sx < w; sx += dx, num++ )
+    {
+      const int x = puX + sx, y = puY + sy, xc = x >> 1, yc = y >> 1;
+      const int moved = mvd[2 * num] != 0 || mvd[2 * num + 1] != 0;
+      int16_t   p[2][MAXC * MAXC];
+      for( int l = 0; l < 2; l++ )
+      {
+        const int16_t *plane = l ? planeC1 : planeC0;
+        int rh = mergeMv[l][0] + ( l ? -mvd[2 * num] : mvd[2 * num] ), rv = mergeMv[l][1] + ( l ? -mvd[2 * num + 1] : mvd[2 * num + 1] );
+        rh = rh < -( 1 << 17 ) ? -( 1 << 17 ) : rh > ( 1 << 17 ) - 1 ? ( 1 << 17 ) - 1 : rh;
+        rv = rv < -( 1 << 17 ) ? -( 1 << 17 ) : rv > ( 1 << 17 ) - 1 ? ( 1 << 17 ) - 1 : rv;
+        int ch = rh, cv = rv;
+        vo_clip_mv_pic( &ch, &cv, picW, picH, ctuSize, x, y );
+        if( !moved )
+        {
+          vo_mc_block( 1, plane + ( ptrdiff_t ) yc * strideC + xc, strideC, cw, chh, ch, cv, 1, bitDepth, 0, p[l], cw );
+          continue;
+        }
+        int16_t pad[PSC * PSC];
+        int     ph = mergeMv[l][0] - ( 1 << 5 ), pv = mergeMv[l][1] - ( 1 << 5 );
+        vo_clip_mv_pic( &ph, &pv, picW, picH, ctuSize, x, y );
+        const int16_t *src = plane + ( ptrdiff_t )( yc + ( pv >> 5 ) ) * strideC + xc + ( ph >> 5 );
+        const int      pw = cw + 3, phh = chh + 3;
+        for( int r = 0; r < phh; r++ ) memcpy( pad + ( r + 2 ) * PSC + 2, src + ( ptrdiff_t ) r * strideC, sizeof( int16_t ) * pw );
+        int16_t *q = pad + 2 * ( PSC + 1 );
+        for( int r = 0; r < phh; r++ ) { q[r * PSC - 1] = q[r * PSC]; q[r * PSC + pw] = q[r * PSC + pw - 1]; }
+        memcpy( q - 1 - PSC, q - 1, sizeof( int16_t ) * ( pw + 2 ) );
+        memcpy( q - 1 + phh * PSC, q - 1 + ( phh - 1 ) * PSC, sizeof( int16_t ) * ( pw + 2 ) );
+        const int dX = ( rh >> 5 ) - ( mergeMv[l][0] >> 5 ), dY = ( rv >> 5 ) - ( mergeMv[l][1] >> 5 );
+        vo_mc_block( 1, pad + 3 * ( PSC + 1 ) + dY * PSC + dX, PSC, cw, chh, ch & 31, cv & 31, 1, bitDepth, 0, p[l], cw );
+      }
+      const int shift = headRoom + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * 8192;
+      int16_t  *out = dst + ( ptrdiff_t )( sy >> 1 ) * dstStride + ( sx >> 1 );
+      for( int r = 0; r < chh; r++ )
+        for( int c = 0; c < cw; c++ )
+        {
+          const int v = ( p[0][r * cw + c] + p[1][r * cw + c] + offset ) >> shift;
+          out[( ptrdiff_t ) r * dstStride + c] = ( int16_t )( v < 0 ? 0 : v > cmax ? cmax : v );
+        }
+    }
+}
+
 void vo_bdof_pu( const int16_t *ref0, int stride0, const int16_t *ref1, int stride1, int w, int h, int mv0Hor, int mv0Ver, int mv1Hor, int mv1Ver,
                  int bitDepth, int16_t *dst, int dstStride )
 {

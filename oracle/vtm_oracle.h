@@ -69,6 +69,9 @@ void vo_bdof_pu( const int16_t *ref0, int stride0, const int16_t *ref1, int stri
 /* DMVR of one bi-predicted luma PU: InterPrediction::xProcessDMVR, CommonLib/InterPrediction.cpp:1997-2195 (luma plane) */
 void vo_dmvr_pu( const int16_t *plane0, const int16_t *plane1, int stride, int picW, int picH, int ctuSize, int puX, int puY, int w, int h, int mv0Hor,
                  int mv0Ver, int mv1Hor, int mv1Ver, int bitDepth, int bioApplied, int16_t *dst, int dstStride, int32_t *mvdOut );
+/* ... and one 4:2:0 chroma plane of the same PU, given pu.mvdL0SubPu (xPrefetch forLuma = 0, xPad, xFinalPaddedMCForDMVR, addAvg) */
+void vo_dmvr_chroma( const int16_t *planeC0, const int16_t *planeC1, int strideC, int picW, int picH, int ctuSize, int puX, int puY, int w, int h,
+                     int mv0Hor, int mv0Ver, int mv1Hor, int mv1Ver, const int32_t *mvd, int bitDepth, int16_t *dst, int dstStride );
 /* InterpolationFilter::xWeightedGeoBlk, CommonLib/InterpolationFilter.cpp:902-957 */
 void vo_weighted_geo_blk( const int16_t *src0, int src0Stride, const int16_t *src1, int src1Stride, int16_t *dst, int dstStride, int w, int h,
                           const int16_t *weight, int stepX, int weightStride, int bitDepth, int clipMin, int clipMax );

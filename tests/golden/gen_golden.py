@@ -377,20 +377,25 @@ def gen_bdof():
 
 
 def gen_dmvr():
-    """DMVR of bi-predicted luma PUs through the reference's own InterPrediction::xProcessDMVR on a 4:0:0 rig PU (ref_dmvr_pu): the refined
-    prediction and pu.mvdL0SubPu.  Shares the two padded reference planes of bdof.npz (same generator call)."""
+    """DMVR of bi-predicted 4:2:0 PUs through the reference's own InterPrediction::xProcessDMVR (ref_dmvr_pu420): the refined luma and chroma
+    predictions and pu.mvdL0SubPu.  Luma planes: those of bdof.npz (same generator call); the chroma planes are stored here."""
     from vtm_amd import synth
     W, H, M = 160, 96, 40
-    fr = list(synth.gen_frames(W, H, 3, seed=21))
-    planes = [np.ascontiguousarray(np.pad(f.astype(np.int16), M, mode="edge")) for f in (fr[0], fr[2])]
-    S = planes[0].shape[1]
-    org = [C.c_void_p(p.ctypes.data + 2 * (M * S + M)) for p in planes]
+    fr = list(synth.gen_frames(W, H, 3, seed=21, chroma=True))
+    P = [[np.ascontiguousarray(np.pad(f[c].astype(np.int16), M if c == 0 else M // 2, mode="edge")) for c in range(3)] for f in (fr[0], fr[2])]
+    assert np.array_equal(np.stack([P[0][0], P[1][0]]), np.load(os.path.join(HERE, "bdof.npz"))["planes"])
+    SY, SC = P[0][0].shape[1], P[0][1].shape[1]
+    planes = ((C.c_void_p * 3) * 2)()
+    for l in range(2):
+        for c in range(3):
+            m, st = (M, SY) if c == 0 else (M // 2, SC)
+            planes[l][c] = P[l][c].ctypes.data + 2 * (m * st + m)
     g = np.random.default_rng(1013)
-    meta, outs, mvds = [], [], []
+    meta, outs, outc, mvds = [], [], [], []
     sizes = [(8, 16), (16, 8), (16, 16), (32, 16), (16, 32), (32, 32), (64, 32), (64, 64), (128, 64), (8, 64)]
     for k in range(40):
         w, h = sizes[k % len(sizes)]
-        x, y = int(g.integers(0, (W - w) // 4 + 1)) * 4, int(g.integers(0, (H - h) // 4 + 1)) * 4
+        x, y = int(g.integers(0, (W - w) // 8 + 1)) * 8, int(g.integers(0, (H - h) // 8 + 1)) * 8
         base = np.array([48, 32]) + g.integers(-40, 41, 2)      # near the clip's true pan, so that the refinement has something to find
         mv = [int(-base[0]), int(-base[1]), int(base[0] + g.integers(-24, 25)), int(base[1] + g.integers(-24, 25))]
         if k % 5 == 0:
@@ -401,12 +406,14 @@ def gen_dmvr():
             mv = [v & ~15 for v in mv]
         bio = k % 2
         nsub = (w // min(w, 16)) * (h // min(h, 16))
-        dst, mvd = np.zeros((h, w), np.int16), np.zeros(2 * nsub, np.int32)
-        R.ref_dmvr_pu(org[0], org[1], S, W, H, 128, x, y, w, h, *mv, 10, bio, ol.P(dst), w, C.c_void_p(mvd.ctypes.data))
+        d = [np.zeros((h, w), np.int16), np.zeros((h // 2, w // 2), np.int16), np.zeros((h // 2, w // 2), np.int16)]
+        dp = (C.c_void_p * 3)(*[a.ctypes.data for a in d])
+        mvd = np.zeros(2 * nsub, np.int32)
+        R.ref_dmvr_pu420(planes, SY, SC, W, H, 128, x, y, w, h, *mv, 10, bio, dp, w, w // 2, C.c_void_p(mvd.ctypes.data))
         meta.append((x, y, w, h, *mv, bio))
-        outs.append(dst.reshape(-1)); mvds.append(mvd)
+        outs.append(d[0].reshape(-1)); outc.append(np.concatenate([d[1].reshape(-1), d[2].reshape(-1)])); mvds.append(mvd)
     np.savez_compressed(os.path.join(HERE, "dmvr.npz"), dims=np.array([W, H, M], np.int32), meta=np.array(meta, np.int32), out=np.concatenate(outs),
-                        mvd=np.concatenate(mvds))
+                        outc=np.concatenate(outc), mvd=np.concatenate(mvds), planesC=np.stack([np.stack(P[0][1:]), np.stack(P[1][1:])]))
     print("dmvr:", len(meta), "PUs,", int(np.count_nonzero(np.concatenate(mvds))), "non-zero vector components")
 
 

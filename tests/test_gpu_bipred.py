@@ -421,3 +421,59 @@ def test_dmvr_matches_oracle(ctx):
             assert np.array_equal(got_mvd[k, :nsub], exp_mvd[k, :nsub]), (bd, k)
         assert np.array_equal(d_pred.to_host(np.int16), np.concatenate(exp_pred)), bd
         assert np.array_equal(d_out.to_host(np.int16), np.concatenate(exp_out)), bd
+
+
+def test_dmvr_chroma_matches_oracle(ctx):
+    """vtmhip_dmvr_chroma_batch_dev vs vo_dmvr_chroma on vector differences taken from vo_dmvr_pu: moved and unmoved sub-PUs, clipped vectors, 8- and
+    10-bit, both fused epilogues."""
+    from vtm_amd import synth
+    from vtm_amd.lib import DmvrJob, PicParams
+    L = ol.oracle()
+    W, H, M = 256, 192, 160
+    fr = list(synth.gen_frames(W, H, 3, seed=9, chroma=True))
+    rng = np.random.default_rng(1017)
+    for bd in (10, 8):
+        P = [[np.ascontiguousarray(np.pad((f[c] >> (10 - bd)).astype(np.int16), M if c == 0 else M // 2, mode="edge")) for c in range(3)] for f in (fr[0], fr[2])]
+        orgc = np.ascontiguousarray((fr[1][1] >> (10 - bd)).astype(np.int16))
+        SY, SC, csz = P[0][0].shape[1], P[0][1].shape[1], P[0][1].size
+        oy = [C.c_void_p(P[l][0].ctypes.data + 2 * (M * SY + M)) for l in range(2)]
+        n, regions = 120, 64
+        jobs = (DmvrJob * n)()
+        mvd_all = np.zeros((n, regions, 2), np.int32)
+        exp_pred, exp_out, pos = [], [], 0
+        for k in range(n):
+            w, h = int(rng.choice([8, 16, 32, 64, 128])), int(rng.choice([8, 16, 32, 64, 128]))
+            if w * h < 128:
+                w = 16
+            x, y = int(rng.integers(0, (W - w) // 8 + 1)) * 8, int(rng.integers(0, (H - h) // 8 + 1)) * 8
+            base = np.array([48, 32]) + rng.integers(-40, 41, 2)
+            mv = [int(-base[0]), int(-base[1]), int(base[0] + rng.integers(-24, 25)), int(base[1] + rng.integers(-24, 25))]
+            if k % 9 == 0:
+                mv = [int(v) for v in rng.integers(-4000, 4000, 4)]
+            comp = 1 + k % 2
+            nsub = (w // min(w, 16)) * (h // min(h, 16))
+            lum, mvd = np.zeros((h, w), np.int16), np.zeros(2 * nsub, np.int32)
+            L.vo_dmvr_pu(oy[0], oy[1], SY, W, H, 128, x, y, w, h, *mv, bd, 0, ol.P(lum), w, C.c_void_p(mvd.ctypes.data))
+            mvd_all[k, :nsub] = mvd.reshape(-1, 2)
+            oc = [C.c_void_p(P[l][comp].ctypes.data + 2 * ((M // 2) * SC + M // 2)) for l in range(2)]
+            e = np.zeros((h // 2, w // 2), np.int16)
+            L.vo_dmvr_chroma(oc[0], oc[1], SC, W, H, 128, x, y, w, h, *mv, C.c_void_p(mvd.ctypes.data), bd, ol.P(e), w // 2)
+            j = jobs[k]
+            for l in range(2):
+                j.refOff[l], j.refStride[l] = (2 * l + comp - 1) * csz + (M // 2 + y // 2) * SC + M // 2 + x // 2, SC
+            j.mv[0][0], j.mv[0][1], j.mv[1][0], j.mv[1][1] = mv
+            j.orgOff, j.orgStride, j.puX, j.puY, j.mvdRow = (y // 2) * (W // 2) + x // 2, W // 2, x, y, k
+            j.predOff = j.outOff = pos
+            j.predStride = j.outStride = w // 2
+            j.width, j.height, j.bitDepth, j.epilogue = w, h, bd, 1 + (k // 2) % 2
+            ob = orgc[y // 2:(y + h) // 2, x // 2:(x + w) // 2].astype(np.int32)
+            exp_pred.append(e.reshape(-1))
+            exp_out.append(((ob if j.epilogue == 1 else 2 * ob) - e).astype(np.int16).reshape(-1))
+            pos += w * h // 4
+        pic = PicParams(W, H, 128, bd, 0)
+        d_ref = ctx.to_device(np.concatenate([P[l][c].reshape(-1) for l in range(2) for c in (1, 2)]))
+        d_org, d_jobs, d_mvd = ctx.to_device(orgc.reshape(-1)), ctx.to_device(np.frombuffer(jobs, np.uint8)), ctx.to_device(mvd_all.reshape(-1))
+        d_pred, d_out = ctx.alloc(2 * pos), ctx.alloc(2 * pos)
+        ctx.dmvr_chroma_batch(pic, d_org.ptr, d_ref.ptr, d_pred.ptr, d_out.ptr, d_jobs.ptr, n, 128, 128, d_mvd.ptr)
+        assert np.array_equal(d_pred.to_host(np.int16), np.concatenate(exp_pred)), bd
+        assert np.array_equal(d_out.to_host(np.int16), np.concatenate(exp_out)), bd

@@ -198,3 +198,20 @@ def test_dmvr_golden(ctx):
         assert np.array_equal(mvd[k, :nsub].reshape(-1), z["mvd"][mpos:mpos + 2 * nsub]), (k, x, y, w, h)
         mpos += 2 * nsub
     assert np.array_equal(d_pred.to_host(np.int16), z["out"])
+    # the chroma planes of the same PUs from the device-resident vector differences
+    planesC = np.ascontiguousarray(z["planesC"])   # [picture][Cb, Cr][rows][cols]
+    SC, csz = planesC.shape[3], planesC.shape[2] * planesC.shape[3]
+    d_refc = ctx.to_device(planesC.reshape(-1))
+    cjobs = (DmvrJob * (2 * len(meta)))()
+    cpos = 0
+    for k, (x, y, w, h, a, b, c, d, bio) in enumerate(meta):
+        for comp in range(2):
+            j = cjobs[2 * k + comp]
+            for l in range(2):
+                j.refOff[l], j.refStride[l] = (2 * l + comp) * csz + (M // 2 + y // 2) * SC + M // 2 + x // 2, SC
+            j.mv[0][0], j.mv[0][1], j.mv[1][0], j.mv[1][1] = a, b, c, d
+            j.predOff, j.predStride, j.width, j.height, j.bitDepth, j.puX, j.puY, j.mvdRow = cpos, w // 2, w, h, 10, x, y, k
+            cpos += w * h // 4
+    d_cj, d_cpred = ctx.to_device(np.frombuffer(cjobs, np.uint8)), ctx.alloc(2 * cpos)
+    ctx.dmvr_chroma_batch(pic, 0, d_refc.ptr, d_cpred.ptr, 0, d_cj.ptr, 2 * len(meta), 128, 128, d_mvd.ptr)
+    assert np.array_equal(d_cpred.to_host(np.int16), z["outc"])

@@ -210,12 +210,21 @@ def test_dmvr_golden(oracle):
     assert zb["dims"].tolist() == [W, H, M]
     S = planes.shape[2]
     o = [C.c_void_p(planes[l].ctypes.data + 2 * (M * S + M)) for l in range(2)]
-    pos = mpos = 0
+    planesC = np.ascontiguousarray(z["planesC"])
+    SC = planesC.shape[3]
+    pos = mpos = cpos = 0
     for x, y, w, h, a, b, c, d, bio in z["meta"].tolist():
         nsub = (w // min(w, 16)) * (h // min(h, 16))
         got, mvd = np.zeros((h, w), np.int16), np.zeros(2 * nsub, np.int32)
         oracle.vo_dmvr_pu(o[0], o[1], S, W, H, 128, x, y, w, h, a, b, c, d, 10, bio, ol.P(got), w, C.c_void_p(mvd.ctypes.data))
         assert np.array_equal(mvd, z["mvd"][mpos:mpos + 2 * nsub]), (x, y, w, h)
         assert np.array_equal(got.reshape(-1), z["out"][pos:pos + w * h]), (x, y, w, h, a, b, c, d, bio)
+        for comp in range(2):   # Cb, Cr
+            cgot = np.zeros((h // 2, w // 2), np.int16)
+            oc = [C.c_void_p(planesC[l, comp].ctypes.data + 2 * ((M // 2) * SC + M // 2)) for l in range(2)]
+            oracle.vo_dmvr_chroma(oc[0], oc[1], SC, W, H, 128, x, y, w, h, a, b, c, d, C.c_void_p(mvd.ctypes.data), 10, ol.P(cgot), w // 2)
+            q = w * h // 4
+            assert np.array_equal(cgot.reshape(-1), z["outc"][cpos + comp * q:cpos + (comp + 1) * q]), (comp, x, y, w, h)
+        cpos += w * h // 2
         pos += w * h
         mpos += 2 * nsub

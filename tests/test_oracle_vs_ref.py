@@ -371,3 +371,49 @@ def test_dmvr_equals_reference(oracle, reflib):
         assert np.array_equal(a, c), (k, x, y, w, h, mv, bio)
         moved += int(np.count_nonzero(ma))
     assert moved > 500
+
+
+def test_dmvr_420_equals_reference(oracle, reflib):
+    """Luma and both chroma planes of 4:2:0 PUs: vo_dmvr_pu + vo_dmvr_chroma vs the reference's xProcessDMVR (moved sub-PUs out of the padded chroma
+    window, unmoved ones straight from the pictures)."""
+    from vtm_amd import synth
+    W, H, M = 256, 128, 160
+    fr = list(synth.gen_frames(W, H, 3, seed=5, chroma=True))
+    P = [[np.ascontiguousarray(np.pad(f[c].astype(np.int16), M if c == 0 else M // 2, mode="edge")) for c in range(3)] for f in (fr[0], fr[2])]
+    SY, SC = P[0][0].shape[1], P[0][1].shape[1]
+    planes = ((C.c_void_p * 3) * 2)()
+    for l in range(2):
+        for c in range(3):
+            m, st = (M, SY) if c == 0 else (M // 2, SC)
+            planes[l][c] = P[l][c].ctypes.data + 2 * (m * st + m)
+    rng = np.random.default_rng(1016)
+    moved = still = 0
+    for k in range(120):
+        w, h = int(rng.choice([8, 16, 32, 64, 128])), int(rng.choice([8, 16, 32, 64, 128]))
+        if w * h < 128:
+            continue
+        x, y = int(rng.integers(0, (W - w) // 8 + 1)) * 8, int(rng.integers(0, (H - h) // 8 + 1)) * 8
+        base = np.array([48, 32]) + rng.integers(-40, 41, 2)
+        mv = [int(-base[0]), int(-base[1]), int(base[0] + rng.integers(-24, 25)), int(base[1] + rng.integers(-24, 25))]
+        if k % 9 == 0:
+            mv = [int(v) for v in rng.integers(-4000, 4000, 4)]
+        if k % 7 == 0:
+            mv[0] &= ~15
+        bio = k % 2
+        nsub = (w // min(w, 16)) * (h // min(h, 16))
+        d = [np.zeros((h, w), np.int16), np.zeros((h // 2, w // 2), np.int16), np.zeros((h // 2, w // 2), np.int16)]
+        dp = (C.c_void_p * 3)(*[a.ctypes.data for a in d])
+        ma, mc = np.zeros(2 * nsub, np.int32), np.zeros(2 * nsub, np.int32)
+        reflib.ref_dmvr_pu420(planes, SY, SC, W, H, 128, x, y, w, h, *mv, 10, bio, dp, w, w // 2, C.c_void_p(ma.ctypes.data))
+        c = np.zeros((h, w), np.int16)
+        oracle.vo_dmvr_pu(C.c_void_p(planes[0][0]), C.c_void_p(planes[1][0]), SY, W, H, 128, x, y, w, h, *mv, 10, bio, ol.P(c), w, C.c_void_p(mc.ctypes.data))
+        assert np.array_equal(ma, mc) and np.array_equal(c, d[0]), (k, x, y, w, h, mv, bio)
+        for comp in (1, 2):
+            e = np.zeros((h // 2, w // 2), np.int16)
+            oracle.vo_dmvr_chroma(C.c_void_p(planes[0][comp]), C.c_void_p(planes[1][comp]), SC, W, H, 128, x, y, w, h, *mv, C.c_void_p(mc.ctypes.data), 10,
+                                  ol.P(e), w // 2)
+            assert np.array_equal(e, d[comp]), (k, comp, x, y, w, h, mv)
+        mm = ma.reshape(-1, 2).any(axis=1)
+        moved += int(mm.sum())
+        still += int((~mm).sum())
+    assert moved > 100 and still > 100

@@ -757,6 +757,89 @@ __global__ __launch_bounds__( 64 ) void dmvr_kernel( vtmhip_pic_params pp, const
   bdof_units( L, dx, dy, bd, lane, bio, ro );
 }
 
+// One 4:2:0 chroma plane of the same PUs (xProcessDMVR with chroma): a sub-PU that did not move is predicted from the reference pictures, a moved one
+// out of its (w/2+3) x (h/2+3) window -- fetched with the MERGE vector (xPrefetch forLuma = 0), replicated by one sample (xPad) -- then addAvg.
+constexpr int DMVR_PSC = 20;
+
+__global__ __launch_bounds__( 64 ) void dmvr_chroma_kernel( vtmhip_pic_params pp, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+                                                           int16_t *__restrict__ predBase, int16_t *__restrict__ outBase,
+                                                           const vtmhip_dmvr_job *__restrict__ jobs, const int32_t *__restrict__ mvdIn )
+{
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t tmp[8 * ( 8 + 3 )];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sP[2][64];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sPad[2][DMVR_PSC * DMVR_PSC];
+  const vtmhip_dmvr_job j = jobs[blockIdx.y];
+  const int lane = threadIdx.x;
+  const int dx = min( 16, ( int ) j.width ), dy = min( 16, ( int ) j.height ), perRow = j.width / dx;
+  const int region = blockIdx.x;
+  if( region >= perRow * ( j.height / dy ) ) return;
+  const int ry = ( region / perRow ) * dy, rx = ( region % perRow ) * dx;
+  const int x = j.puX + rx, y = j.puY + ry, bd = j.bitDepth, cw = dx >> 1, ch = dy >> 1, ryc = ry >> 1, rxc = rx >> 1;
+  const int32_t *mvd = mvdIn + ( ( long ) j.mvdRow * gridDim.x + region ) * 2;
+  const int  md0 = mvd[0], md1 = mvd[1];
+  const bool moved = md0 != 0 || md1 != 0;
+  vtmhip_mc_job m;
+  m.width = ( int16_t ) cw; m.height = ( int16_t ) ch; m.bitDepth = j.bitDepth; m.useAltHpelIf = 0; m.chroma = 1; m.bi = 1;
+  m.dstOff = 0; m.dstStride = 0;
+#pragma unroll
+  for( int l = 0; l < 2; l++ )
+  {
+    const int  mvH = l ? j.mv[1][0] : j.mv[0][0], mvV = l ? j.mv[1][1] : j.mv[0][1];
+    const long rs  = l ? j.refStride[1] : j.refStride[0];
+    const long blk = ( l ? j.refOff[1] : j.refOff[0] ) + ( long ) ryc * rs + rxc;
+    int rh = min( ( 1 << 17 ) - 1, max( -( 1 << 17 ), mvH + ( l ? -md0 : md0 ) ) );
+    int rv = min( ( 1 << 17 ) - 1, max( -( 1 << 17 ), mvV + ( l ? -md1 : md1 ) ) );
+    const int dX = ( rh >> 5 ) - ( mvH >> 5 ), dY = ( rv >> 5 ) - ( mvV >> 5 );
+    clip_mv_pic( rh, rv, pp, x, y );
+    const StoreLds st{ sP[l], cw };
+    if( !moved )
+    {
+      m.refOff = blk; m.refStride = ( int ) rs; m.mvHor = rh; m.mvVer = rv;
+      mc_any<64>( m, refBase, tmp, lane, st );
+    }
+    else
+    {
+      int ph = mvH - ( 1 << 5 ), pv = mvV - ( 1 << 5 );
+      clip_mv_pic( ph, pv, pp, x, y );
+      const int16_t *src = refBase + blk + ( long ) ( pv >> 5 ) * rs + ( ph >> 5 );
+      const int      pw = cw + 3, phh = ch + 3;
+      int16_t       *W = sPad[l];
+      for( int i = lane; i < pw * phh; i += 64 )
+      {
+        const int r = i / pw, c = i - r * pw;
+        W[( r + 2 ) * DMVR_PSC + c + 2] = src[r * rs + c];
+      }
+      block_sync<64>();
+      for( int r = lane; r < phh; r += 64 )
+      {
+        int16_t *q = W + ( r + 2 ) * DMVR_PSC + 2;
+        q[-1] = q[0]; q[pw] = q[pw - 1];
+      }
+      block_sync<64>();
+      for( int c = lane; c < pw + 2; c += 64 )
+      {
+        int16_t *q = W + 2 * DMVR_PSC + 1 + c;
+        q[-DMVR_PSC] = q[0]; q[phh * DMVR_PSC] = q[( phh - 1 ) * DMVR_PSC];
+      }
+      block_sync<64>();
+      m.refOff = 3 * ( DMVR_PSC + 1 ) + dY * DMVR_PSC + dX; m.refStride = DMVR_PSC; m.mvHor = rh & 31; m.mvVer = rv & 31;
+      mc_any<64>( m, W, tmp, lane, st );
+    }
+    block_sync<64>();
+  }
+  if( lane >= cw * ch ) return;
+  const int r = lane / cw, c = lane - r * cw;
+  const int headRoom = max( 2, 14 - bd ), shift = headRoom + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * 8192;
+  const int v = min( ( 1 << bd ) - 1, max( 0, ( ( int ) sP[0][lane] + ( int ) sP[1][lane] + offset ) >> shift ) );
+  if( predBase ) predBase[j.predOff + ( long ) ( ryc + r ) * j.predStride + rxc + c] = ( int16_t ) v;
+  const int mode = ( outBase && orgBase ) ? j.epilogue : 0;
+  if( mode )
+  {
+    const int o = orgBase[j.orgOff + ( long ) ( ryc + r ) * j.orgStride + rxc + c];
+    outBase[j.outOff + ( long ) ( ryc + r ) * j.outStride + rxc + c] = ( int16_t ) ( ( mode == 1 ? o : 2 * o ) - v );
+  }
+}
+
 // InterpolationFilter::xWeightedGeoBlk (InterpolationFilter.cpp:902-957): one wave per blend, four output samples per lane and step when the width
 // allows (8-byte loads of both predictions, the weights gathered one by one -- their walk may be mirrored or 2:1 sub-sampled)
 __global__ __launch_bounds__( 256 ) void geo_blend_kernel( const int16_t *__restrict__ srcBase, int16_t *__restrict__ dstBase, const int16_t *__restrict__ wBase,
@@ -916,6 +999,23 @@ int vtmhip_dmvr_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const 
   VTMHIP_REQUIRE( ctx, n <= 65535, "at most 65535 PUs per launch" );
   const int regions = ( ( maxWidth + 15 ) / 16 ) * ( ( maxHeight + 15 ) / 16 );
   hipLaunchKernelGGL( dmvr_kernel, dim3( regions, n ), dim3( 64 ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, d_mvd );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_dmvr_chroma_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, int16_t *d_predBase,
+                                  int16_t *d_outBase, const vtmhip_dmvr_job *d_jobs, int n, int maxWidth, int maxHeight, const int32_t *d_mvd )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, pic && d_refBase && d_jobs && d_mvd && ( d_predBase || d_outBase ), "null pointer" );
+  VTMHIP_REQUIRE( ctx, !d_outBase || d_orgBase, "an epilogue output needs the original plane" );
+  VTMHIP_REQUIRE( ctx, pic->bitDepth >= 8 && pic->bitDepth <= 12 && pic->picW > 0 && pic->picH > 0 && pic->ctuSize >= 16, "picture parameters" );
+  VTMHIP_REQUIRE( ctx, maxWidth >= 8 && maxWidth <= 128 && maxHeight >= 8 && maxHeight <= 128, "maxWidth / maxHeight (luma size of the PUs, 8..128)" );
+  VTMHIP_REQUIRE( ctx, n <= 65535, "at most 65535 PUs per launch" );
+  const int regions = ( ( maxWidth + 15 ) / 16 ) * ( ( maxHeight + 15 ) / 16 );
+  hipLaunchKernelGGL( dmvr_chroma_kernel, dim3( regions, n ), dim3( 64 ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, d_mvd );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

@@ -237,6 +237,10 @@ class Context:
         """xProcessDMVR (luma) for bi-predicted merge PUs: refined prediction (+ epilogue) and the sub-PU vector differences."""
         self._check(self.L.vtmhip_dmvr_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_pred, d_out, d_jobs, n, max_w, max_h, d_mvd))
 
+    def dmvr_chroma_batch(self, pic, d_org, d_ref, d_pred, d_out, d_jobs, n, max_w, max_h, d_mvd):
+        """One 4:2:0 chroma plane of the PUs of a dmvr_batch call (jobs address that plane; d_mvd from the luma call)."""
+        self._check(self.L.vtmhip_dmvr_chroma_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_pred, d_out, d_jobs, n, max_w, max_h, d_mvd))
+
     def mc_batch(self, d_ref, d_dst, d_jobs, n, max_w, max_h):
         """xPredInterBlk for luma and 4:2:0 chroma blocks (McJob.chroma)."""
         self._check(self.L.vtmhip_mc_batch_dev(self.h, d_ref, d_dst, d_jobs, n, max_w, max_h))

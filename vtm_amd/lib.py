@@ -156,7 +156,7 @@ class DmvrJob(C.Structure):
     _fields_ = [("orgOff", C.c_int64), ("refOff", C.c_int64 * 2), ("predOff", C.c_int64), ("outOff", C.c_int64), ("orgStride", C.c_int32),
                 ("refStride", C.c_int32 * 2), ("predStride", C.c_int32), ("outStride", C.c_int32), ("mv", (C.c_int32 * 2) * 2), ("puX", C.c_int32),
                 ("puY", C.c_int32), ("width", C.c_int16), ("height", C.c_int16), ("bioApplied", C.c_uint8), ("epilogue", C.c_uint8),
-                ("bitDepth", C.c_uint8), ("pad0", C.c_uint8), ("pad1", C.c_int32)]
+                ("bitDepth", C.c_uint8), ("pad0", C.c_uint8), ("mvdRow", C.c_int32)]
 
 
 _STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob,
@@ -190,6 +190,8 @@ _PROTOS = {
     "vtmhip_bdof_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "vtmhip_dmvr_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),
+    "vtmhip_dmvr_chroma_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                               C.c_int, C.c_void_p]),
     "vtmhip_weightedGeoBlk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_int]),
     "vtmhip_weightedGeoBlk_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
