@@ -50,6 +50,23 @@ int main()
       try { dp.distFunc( dp ); } catch( const Exception & ) { threw = true; }
       checks++; if( !threw ) { fails++; printf( "useMR guard\n" ); }
     }
+    // GEO masked SAD through the mask overload of setDistParam
+    {
+      const int M = 112;
+      std::vector<Pel> plane( M * M ), org( 64 * 64 ), cur( 64 * 64 );
+      for( auto &v : plane ) v = ( Pel ) ( rng() % 9 );
+      for( auto &v : org ) v = ( Pel ) ( rng() % 1024 );
+      for( auto &v : cur ) v = ( Pel ) ( rng() % 1024 );
+      for( int k = 0; k < 24; k++ )
+      {
+        const int w = 8 << ( k % 4 ), h = 8 << ( ( k / 4 ) % 4 ), sx = ( k % 3 ) ? 1 : -1, rd2 = ( k % 2 ) ? 1 : -1;
+        const int x0 = ( int ) ( rng() % ( M - w ) ) + ( sx < 0 ? w - 1 : 0 ), y0 = ( int ) ( rng() % ( M - h ) ) + ( rd2 < 0 ? h - 1 : 0 );
+        DistParam dp;
+        rd.setDistParam( dp, CPelBuf( org.data(), 64, w, h ), cur.data(), 64, plane.data() + y0 * M + x0, rd2 * M, sx, -sx * w, 10, COMPONENT_Y );
+        checks++;
+        if( dp.distFunc( dp ) != vo_sad_mask( org.data(), 64, cur.data(), 64, w, h, 0, plane.data() + y0 * M + x0, rd2 * M, sx, -sx * w ) ) { fails++; printf( "masked SAD %dx%d\n", w, h ); }
+      }
+    }
     // motion cost
     vo_mvcost_t mc = { 7.25, -13, 22, 2 };
     rd.setMotionLambda( 7.25 ); rd.setPredictor( -13, 22 ); rd.setCostScale( 2 );

@@ -52,6 +52,7 @@ enum DFunc
   DF_SAD, DF_SAD2, DF_SAD4, DF_SAD8, DF_SAD16, DF_SAD32, DF_SAD64, DF_SAD16N,
   DF_HAD, DF_HAD2, DF_HAD4, DF_HAD8, DF_HAD16, DF_HAD32, DF_HAD64, DF_HAD16N,
   DF_SAD12, DF_SAD24, DF_SAD48,
+  DF_SAD_WITH_MASK,
   DF_TOTAL_FUNCTIONS
 };
 
@@ -69,6 +70,8 @@ public:
   ComponentID compID = MAX_NUM_COMPONENT;
   Distortion  maximumDistortionForEarlyExit = std::numeric_limits<Distortion>::max();
   int         subShift = 0;
+  const Pel  *mask = nullptr;   // GEO merge estimation (RdCost.h:97-100)
+  int         maskStride = 0, stepX = 0, maskStride2 = 0;
 };
 
 inline int floorLog2( unsigned v ) { int r = -1; while( v ) { v >>= 1; r++; } return r; }
@@ -103,6 +106,14 @@ class RdCost
     return d;
   }
 
+  static Distortion xGetSADwMask( const DistParam &p )   // RdCost.cpp:3513-3549
+  {
+    guard( p ); uint64_t d = 0;
+    check( vtmhip_xGetSADwMask( context(), p.org.buf, p.org.stride, p.cur.buf, p.cur.stride, p.org.width, p.org.height, p.subShift, p.mask, p.maskStride, p.stepX,
+                                p.maskStride2, &d ), "xGetSADwMask" );
+    return d;
+  }
+
 public:
   RdCost() { init(); }
   static FpDistFunc distFuncAt( int i ) { return table()[i]; }
@@ -114,6 +125,7 @@ public:
     for( int i = DF_SAD; i <= DF_SAD16N; i++ ) table()[i] = xGetSAD;
     for( int i = DF_HAD; i <= DF_HAD16N; i++ ) table()[i] = xGetHADs;
     table()[DF_SAD12] = table()[DF_SAD24] = table()[DF_SAD48] = xGetSAD;
+    table()[DF_SAD_WITH_MASK] = xGetSADwMask;
   }
 
   // RdCost::setDistParam( rcDP, org, piRefY, iRefStride, bitDepth, compID, subShiftMode, step, useHadamard ) (RdCost.cpp:238-324)
@@ -148,6 +160,16 @@ public:
   void setDistParam( DistParam &rcDP, const CPelBuf &org, const CPelBuf &cur, int bitDepth, ComponentID compID, bool useHadamard = false )
   {
     setDistParam( rcDP, org, cur.buf, cur.stride, bitDepth, compID, 0, 1, useHadamard );
+  }
+  // RdCost::setDistParam( rcDP, org, piRefY, iRefStride, mask, maskStride, stepX, maskStride2, bitDepth, compID ) (RdCost.cpp:3488-3511)
+  void setDistParam( DistParam &rcDP, const CPelBuf &org, const Pel *piRefY, int iRefStride, const Pel *mask, int maskStride, int stepX, int maskStride2,
+                     int bitDepth, ComponentID compID )
+  {
+    rcDP.bitDepth = bitDepth; rcDP.compID = compID; rcDP.org = org;
+    rcDP.cur = CPelBuf( piRefY, iRefStride, org.width, org.height );
+    rcDP.mask = mask; rcDP.maskStride = maskStride; rcDP.stepX = stepX; rcDP.maskStride2 = maskStride2;
+    rcDP.step = 1; rcDP.subShift = 0; rcDP.maximumDistortionForEarlyExit = std::numeric_limits<Distortion>::max();
+    rcDP.distFunc = table()[DF_SAD_WITH_MASK];
   }
   // RdCost::getDistPart (RdCost.cpp:411-455), luma (the chroma distortion weight is host arithmetic on the result)
   Distortion getDistPart( const CPelBuf &org, const CPelBuf &cur, int bitDepth, ComponentID compID, DFunc eDFunc )

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from vtm_amd import synth   # noqa: E402
 from vtm_amd.device import Context   # noqa: E402
-from vtm_amd.lib import DistJob, GeoBlendJob, IfJob, PredJob, TrJob, TuJob   # noqa: E402
+from vtm_amd.lib import DistJob, DmvrJob, GeoBlendJob, IfJob, PicParams, PredJob, TrJob, TuJob   # noqa: E402
 
 PEAK = 8000.0   # GB/s
 
@@ -154,6 +154,25 @@ def main():
         emit("bdof", n * s * s, "samples", 6 * n * s * s, ms, size="%dx%d" % (s, s), pus=n)
         ms = timed(ctx, lambda: ctx.motion_compensation_batch(0, d_refs.ptr, d_pred.ptr, 0, d_jp.ptr, n, s, s), reps=5)
         emit("bi_pred", n * s * s, "samples", 6 * n * s * s, ms, size="%dx%d" % (s, s), pus=n)
+    # DMVR (luma): every 16x16 / 64x64 PU of the picture with merge vectors a little off the clip's motion, BDOF on where the cost allows
+    for s in (16, 64):
+        nx, ny = W // s, H // s
+        n = nx * ny
+        jd = np.zeros(n, np.dtype(DmvrJob))
+        py, px = np.divmod(np.arange(n), nx)
+        base = (py * s) * rs + px * s
+        jd["refOff"][:, 0], jd["refOff"][:, 1] = roff + base, ref.size + roff2 + base
+        jd["refStride"][:, 0] = jd["refStride"][:, 1] = rs
+        off = rng.integers(-24, 25, (n, 2))
+        jd["mv"][:, 0, :], jd["mv"][:, 1, :] = off, -off + rng.integers(-20, 21, (n, 2))
+        jd["predOff"], jd["predStride"], jd["puX"], jd["puY"] = (py * s) * W + px * s, W, px * s, py * s
+        jd["width"], jd["height"], jd["bitDepth"], jd["bioApplied"] = s, s, 10, 1
+        regions = ((s + 15) // 16) ** 2
+        d_jd, d_pred, d_mvd = ctx.to_device(jd.view(np.uint8)), ctx.alloc(2 * W * H), ctx.alloc(8 * n * regions)
+        pic = PicParams(W, H, 128, 10, 0)
+        ms = timed(ctx, lambda: ctx.dmvr_batch(pic, 0, d_refs.ptr, d_pred.ptr, 0, d_jd.ptr, n, s, s, d_mvd.ptr), reps=5)
+        emit("dmvr", n * s * s, "samples", 6 * n * s * s, ms, size="%dx%d" % (s, s), pus=n,
+             moved_subpus=int(np.count_nonzero(d_mvd.to_host(np.int32).reshape(-1, 2).any(axis=1))))
     M = 112
     wplane = rng.integers(0, 9, (M, M)).astype(np.int16)
     s, per = 32, 8
