@@ -10,6 +10,7 @@
 //   satd8_grid_kernel   8x8 SATD of every aligned 8x8 block x (2r+1)^2 displacements: the reference tile of a
 //                       workgroup is staged ONCE in LDS with coalesced 16-byte loads and re-used by all displacements
 //                       (HBM traffic ~ one read of each picture; the kernel is integer-VALU bound).
+#include <cstdlib>
 #include "ctx.hpp"
 #include "had.hpp"
 
@@ -174,9 +175,10 @@ __global__ __launch_bounds__( 256 ) void dist_batch_kernel( const int16_t *__res
 
 // ---- SATD 8x8 grid ---------------------------------------------------------------------------------------------------
 // Workgroup = 256 threads = TBX x TBY org blocks; LDS holds the org tile and the reference tile (+r halo).
-constexpr int GRID_TBX = 8, GRID_TBY = 4;
+constexpr int GRID_TBX = 8;
 
-__global__ __launch_bounds__( 256 ) void satd8_grid_kernel( const int16_t *__restrict__ org, int orgStride, const int16_t *__restrict__ ref,
+template<int THREADS, int GRID_TBY>
+__global__ __launch_bounds__( THREADS ) void satd8_grid_kernel( const int16_t *__restrict__ org, int orgStride, const int16_t *__restrict__ ref,
                                                            int refStride, int bw, int bh, int r, unsigned *__restrict__ out )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];
@@ -189,8 +191,9 @@ __global__ __launch_bounds__( 256 ) void satd8_grid_kernel( const int16_t *__res
 
   unsigned wide = 0, wide10 = 0;   // any sample outside [0, 4095] in this workgroup's tiles -> 32-bit path; outside [0, 1023] -> three packed levels only
   // stage org tile: 32 rows x 64 samples = 256 x 16-byte vectors, one per thread (coalesced 128-byte rows)
+  for( int i = threadIdx.x; i < GRID_TBY * 8 * 8; i += THREADS )
   {
-    const int row = threadIdx.x >> 3, seg = threadIdx.x & 7;
+    const int row = i >> 3, seg = i & 7;
     const int gy = by0 * 8 + row, gx = bx0 * 8 + seg * 8;
     int4      v  = make_int4( 0, 0, 0, 0 );
     if( gy < bh * 8 && gx < bw * 8 ) v = *reinterpret_cast<const int4 *>( org + ( long ) gy * orgStride + gx );
@@ -201,7 +204,7 @@ __global__ __launch_bounds__( 256 ) void satd8_grid_kernel( const int16_t *__res
   // stage reference tile: refH rows x refW samples starting at (bx0*8 - r, by0*8 - r); 2-byte granularity on the
   // global side (the halo start is not 16-byte aligned), dword stores on the LDS side
   const int needW = min( GRID_TBX, bw - bx0 ) * 8 + 2 * r, needH = min( GRID_TBY, bh - by0 ) * 8 + 2 * r;   // never read past the last block's halo
-  for( int i = threadIdx.x; i < refH * ( refLd >> 1 ); i += 256 )
+  for( int i = threadIdx.x; i < refH * ( refLd >> 1 ); i += THREADS )
   {
     const int      row = i / ( refLd >> 1 ), c2 = ( i - row * ( refLd >> 1 ) ) << 1;
     const int16_t *p   = ref + ( long ) ( by0 * 8 - r + row ) * refStride + ( bx0 * 8 - r + c2 );
@@ -216,7 +219,7 @@ __global__ __launch_bounds__( 256 ) void satd8_grid_kernel( const int16_t *__res
   const bool packed = __syncthreads_or( ( int ) wide ) == 0, packed10 = __syncthreads_or( ( int ) wide10 ) == 0;
 
   const int pairs = GRID_TBX * GRID_TBY * nd2;
-  for( int p = threadIdx.x; p < pairs; p += 256 )
+  for( int p = threadIdx.x; p < pairs; p += THREADS )
   {
     const int b = p / nd2, d = p - b * nd2;
     const int lby = b / GRID_TBX, lbx = b - lby * GRID_TBX;
@@ -445,11 +448,26 @@ int vtmhip_satd8_grid_dev( vtmhip_ctx *ctx, const int16_t *d_org, int orgStride,
   VTMHIP_REQUIRE( ctx, d_org && d_ref && d_dist, "null pointer" );
   VTMHIP_REQUIRE( ctx, width >= 8 && height >= 8 && r >= 0 && r <= 16, "size / range" );
   VTMHIP_REQUIRE( ctx, ( orgStride & 7 ) == 0 && ( ( ( uintptr_t ) d_org ) & 15 ) == 0, "org plane must be 16-byte aligned with a stride multiple of 8" );
-  const int    bw = width / 8, bh = height / 8;
-  const int    refW = GRID_TBX * 8 + 2 * r, refH = GRID_TBY * 8 + 2 * r, refLd = ( refW + 7 ) & ~7;
-  const size_t lds = ( size_t ) ( GRID_TBY * 8 * GRID_TBX * 8 + refH * refLd ) * sizeof( int16_t ) + 16;   // + one spare vector: the packed path reads a fifth dword per row
-  dim3         grid( ( bw + GRID_TBX - 1 ) / GRID_TBX, ( bh + GRID_TBY - 1 ) / GRID_TBY );
-  hipLaunchKernelGGL( satd8_grid_kernel, grid, dim3( 256 ), lds, ctx->stream, d_org, orgStride, d_ref, refStride, bw, bh, r, d_dist );
+  const int bw = width / 8, bh = height / 8;
+  // workgroup shape: 8 x TBY blocks, THREADS lanes over the TBY * 8 * (2r+1)^2 pairs.  Tuned on 3840x2160, r = 4 (VTMHIP_SATD_VARIANT overrides it)
+  static const int variant = getenv( "VTMHIP_SATD_VARIANT" ) ? atoi( getenv( "VTMHIP_SATD_VARIANT" ) ) : 0;
+  auto launch = [&]( auto kern, int threads, int tby ) {
+    const int    refW = GRID_TBX * 8 + 2 * r, refH = tby * 8 + 2 * r, refLd = ( refW + 7 ) & ~7;
+    const size_t lds = ( size_t ) ( tby * 8 * GRID_TBX * 8 + refH * refLd ) * sizeof( int16_t ) + 16;   // + one spare vector: the packed path reads a fifth dword per row
+    dim3         grid( ( bw + GRID_TBX - 1 ) / GRID_TBX, ( bh + tby - 1 ) / tby );
+    hipLaunchKernelGGL( kern, grid, dim3( threads ), lds, ctx->stream, d_org, orgStride, d_ref, refStride, bw, bh, r, d_dist );
+  };
+  switch( variant )
+  {
+  case 1: launch( satd8_grid_kernel<192, 4>, 192, 4 ); break;
+  case 2: launch( satd8_grid_kernel<128, 4>, 128, 4 ); break;
+  case 3: launch( satd8_grid_kernel<256, 2>, 256, 2 ); break;
+  case 4: launch( satd8_grid_kernel<128, 2>, 128, 2 ); break;
+  case 5: launch( satd8_grid_kernel<64, 2>, 64, 2 ); break;
+  case 6: launch( satd8_grid_kernel<192, 2>, 192, 2 ); break;
+  case 7: launch( satd8_grid_kernel<64, 1>, 64, 1 ); break;
+  default: launch( satd8_grid_kernel<256, 4>, 256, 4 ); break;
+  }
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }
