@@ -521,12 +521,15 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
       // applies two taps: output row y takes the row pairs (y, y+1), (y+2, y+3), (y+4, y+5), (y+6, y+7) with the tap pairs
       // (c0,c1) .. (c6,c7) -- 256 dot products instead of 512 multiply-adds, and no 16-bit unpacking.
       typedef short v2s __attribute__( ( ext_vector_type( 2 ) ) );
+      // Packed-SATD path (bitDepth <= 10): the taps and the rounding offset are pre-scaled by 2^(16 - shift), so that the UPPER half of an accumulator
+      // is the shifted sum ((acc << up) >> 16 == acc >> shift, arithmetic) and one v_perm packs two of them -- no shifts, and the clip runs on
+      // packed words.  |taps| <= 58 and 16 - shift <= 8 keep the scaled taps in 16 bits; 112 * 2^up * 32768 + offset * 2^up < 2^31.
+      const bool pk16 = j.useHad && j.bitDepth <= 10;
+      const int  up   = pk16 ? 16 - pV.shift : 0, accInit = pV.offset << up;
       v2s cpk[4];
 #pragma unroll
-      for( int m = 0; m < 4; m++ ) { cpk[m].x = ( short ) cv[2 * m]; cpk[m].y = ( short ) cv[2 * m + 1]; }
-      int acc[64];
-#pragma unroll
-      for( int i = 0; i < 64; i++ ) acc[i] = pV.offset;
+      for( int m = 0; m < 4; m++ ) { cpk[m].x = ( short ) ( cv[2 * m] << up ); cpk[m].y = ( short ) ( cv[2 * m + 1] << up ); }
+      int  acc[64];
       int4 prev = *reinterpret_cast<const int4 *>( pl );
 #pragma unroll
       for( int r = 1; r < 15; r++ )
@@ -550,7 +553,7 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
           if( y >= 0 && y < 8 )
           {
 #pragma unroll
-            for( int x = 0; x < 8; x++ ) acc[y * 8 + x] = __builtin_amdgcn_sdot2( pr[x], cpk[m], acc[y * 8 + x], false );
+            for( int x = 0; x < 8; x++ ) acc[y * 8 + x] = __builtin_amdgcn_sdot2( pr[x], cpk[m], m == 0 ? accInit : acc[y * 8 + x], false );   // m == 0 is a row's first pair
           }
         }
         prev = cur;
@@ -559,11 +562,14 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
       // |sum of taps| <= 112 and |plane sample| <= 32768: (acc >> shift) fits 16 bits, so the reference's Pel truncation is the identity here
       const int16_t *org = orgBase + j.orgOff + ( long ) ( ty * 8 ) * j.orgStride + tx * 8;
       unsigned       d;
-      if( j.useHad && j.bitDepth <= 10 )
+      if( pk16 )
       {
         // 10-bit prediction and |org| <= 3071 (picture samples or the bi-pred target 2*org - pred): |diff| <= 4095, so the first three
-        // butterfly levels run on packed 16-bit words (the reference's own SIMD SATD is 16-bit for bitDepth <= 10, x86/RdCostX86.h:2157)
-        v2s D[8][4];
+        // butterfly levels run on packed 16-bit words (the reference's own SIMD SATD is 16-bit for bitDepth <= 10, x86/RdCostX86.h:2157);
+        // when every lane of the wave sees original samples inside [0, 1023] (|diff| <= 1023), five levels do.
+        v2s       D[8][4];
+        const v2s zero = { 0, 0 }, cmaxv = { ( short ) pV.cmax, ( short ) pV.cmax };
+        unsigned  wide = 0;
 #pragma unroll
         for( int y = 0; y < 8; y++ )
         {
@@ -571,16 +577,16 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
 #pragma unroll
           for( int k = 0; k < 4; k++ )
           {
-            const unsigned p0 = ( unsigned ) min( pV.cmax, max( 0, acc[y * 8 + 2 * k] >> pV.shift ) );
-            const unsigned p1 = ( unsigned ) min( pV.cmax, max( 0, acc[y * 8 + 2 * k + 1] >> pV.shift ) );
-            const unsigned pw = p0 | ( p1 << 16 );
+            const unsigned pw = __builtin_amdgcn_perm( ( unsigned ) acc[y * 8 + 2 * k + 1], ( unsigned ) acc[y * 8 + 2 * k], 0x07060302u );   // the two upper halves
             v2s ov, pv;
             __builtin_memcpy( &ov, &o.v[k], 4 );
             __builtin_memcpy( &pv, &pw, 4 );
+            pv      = __builtin_elementwise_min( __builtin_elementwise_max( pv, zero ), cmaxv );
             D[y][k] = ov - pv;
+            wide |= o.v[k];
           }
         }
-        d = satd8_packed( D );
+        d = __all( ( wide & 0xfc00fc00u ) == 0 ) ? satd8_packed10( D ) : satd8_packed( D );
       }
       else if( j.useHad )
       {
