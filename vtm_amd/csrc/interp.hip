@@ -257,10 +257,10 @@ __device__ __forceinline__ unsigned long long block_dist( const int16_t *org, in
 __device__ __forceinline__ int floor_log2_u( unsigned v ) { return 31 - __clz( ( int ) v ); }
 __device__ __forceinline__ unsigned eg_bits( int v )
 {
-  unsigned len = 1;
-  unsigned t   = ( v <= 0 ) ? ( ( unsigned ) ( -v ) << 1 ) + 1 : ( unsigned ) ( v << 1 );
-  while( t > 128 ) { len += 14; t >>= 7; }
-  return len + ( ( unsigned ) floor_log2_u( t ) << 1 );
+  // xGetExpGolombNumberOfBits (RdCost.h:301-313): its `while( t > 128 ) { len += 14; t >>= 7; }` only splits floorLog2( t ) = 7 + floorLog2( t >> 7 ),
+  // so the length is 1 + 2 * floorLog2( t ) for every t >= 1 -- no loop
+  const unsigned t = ( v <= 0 ) ? ( ( unsigned ) ( -v ) << 1 ) + 1 : ( unsigned ) ( v << 1 );
+  return 1u + ( ( unsigned ) ( 31 - __clz( ( int ) t ) ) << 1 );
 }
 // getCostOfVectorWithPredictor( x, y, 0 ) with m_iCostScale = costScale (RdCost.h:314-315)
 __device__ __forceinline__ unsigned long long mv_cost( double lambda, int predHor, int predVer, int costScale, int x, int y )

@@ -54,10 +54,10 @@ __device__ __forceinline__ unsigned long long uni( unsigned long long v )
 
 __device__ __forceinline__ unsigned eg_bits( int v )
 {
-  unsigned len = 1;
-  unsigned t   = ( v <= 0 ) ? ( ( unsigned ) ( -v ) << 1 ) + 1 : ( unsigned ) ( v << 1 );
-  while( t > 128 ) { len += 14; t >>= 7; }
-  return len + ( ( unsigned ) floor_log2_u( t ) << 1 );
+  // xGetExpGolombNumberOfBits (RdCost.h:301-313): its `while( t > 128 ) { len += 14; t >>= 7; }` only splits floorLog2( t ) = 7 + floorLog2( t >> 7 ),
+  // so the length is 1 + 2 * floorLog2( t ) for every t >= 1 -- no loop
+  const unsigned t = ( v <= 0 ) ? ( ( unsigned ) ( -v ) << 1 ) + 1 : ( unsigned ) ( v << 1 );
+  return 1u + ( ( unsigned ) ( 31 - __clz( ( int ) t ) ) << 1 );
 }
 
 __device__ __forceinline__ unsigned long long mv_cost( const MeJob &j, int x, int y )
@@ -201,6 +201,37 @@ __device__ __forceinline__ void stage_org( MeJob &j, int16_t *sLds, int tid )
 }
 
 // lexicographic (cost, index) minimum over the wave
+// Cross-lane steps on the DPP path of the vector ALU (one instruction each, no LDS round trip as with ds_bpermute): xor 1 / xor 2 inside a quad,
+// then the mirrors inside 8 and 16 lanes -- after each step the lanes of the growing group all hold the group's result.
+template<int CTRL>
+__device__ __forceinline__ unsigned dpp_u32( unsigned v )
+{
+  return ( unsigned ) __builtin_amdgcn_update_dpp( 0, ( int ) v, CTRL, 0xf, 0xf, true );
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;   // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+
+__device__ __forceinline__ unsigned group_sum( unsigned s, int lpc )   // sum over aligned groups of lpc (power of two) lanes; every lane gets it
+{
+  if( lpc >= 2 ) s += dpp_u32<DPP_XOR1>( s );
+  if( lpc >= 4 ) s += dpp_u32<DPP_XOR2>( s );
+  if( lpc >= 8 ) s += dpp_u32<DPP_HALF_MIRROR>( s );
+  if( lpc >= 16 ) s += dpp_u32<DPP_MIRROR>( s );
+  if( lpc >= 32 ) s += __shfl_xor( s, 16, 64 );
+  if( lpc >= 64 ) s += __shfl_xor( s, 32, 64 );
+  return s;
+}
+
+__device__ __forceinline__ unsigned wave_min_u32( unsigned v )   // all 64 lanes active; result wave-uniform (SGPR)
+{
+  v = min( v, dpp_u32<DPP_XOR1>( v ) );
+  v = min( v, dpp_u32<DPP_XOR2>( v ) );
+  v = min( v, dpp_u32<DPP_HALF_MIRROR>( v ) );
+  v = min( v, dpp_u32<DPP_MIRROR>( v ) );   // the four rows of 16 are uniform now
+  const unsigned a = ( unsigned ) __builtin_amdgcn_readlane( ( int ) v, 0 ), b = ( unsigned ) __builtin_amdgcn_readlane( ( int ) v, 16 );
+  const unsigned c = ( unsigned ) __builtin_amdgcn_readlane( ( int ) v, 32 ), d = ( unsigned ) __builtin_amdgcn_readlane( ( int ) v, 48 );
+  return min( min( a, b ), min( c, d ) );
+}
+
 __device__ __forceinline__ void wave_argmin( unsigned long long &cost, unsigned &idx )
 {
 #pragma unroll
@@ -279,10 +310,7 @@ __device__ __forceinline__ void eval_candidates( const MeJob &j, const int4 *pts
       }
       s = sad_partial( j, x, y, sub );
     }
-    // sum over the lpc lanes of the group (butterfly: every lane of the group ends with the total)
-#pragma unroll
-    for( int o = 32; o > 0; o >>= 1 )
-      if( o < lpc ) s += __shfl_xor( s, o, 64 );
+    s = group_sum( s, lpc );   // every lane of the group ends with the total
     if( k < total )
     {
       const unsigned long long c = ( ( unsigned long long ) s << j.ss ) + mv_cost( j, x, y );
@@ -291,15 +319,11 @@ __device__ __forceinline__ void eval_candidates( const MeJob &j, const int4 *pts
   }
   if( j.narrow )
   {
-    // cost < 2^32: one 64-bit key (cost << 32 | index) orders lexicographically
-    unsigned long long key = ( bestCost << 32 ) | bestIdx;
-    if( bestIdx == 0xffffffffu ) key = ~0ull;
-#pragma unroll
-    for( int o = 32; o > 0; o >>= 1 )
-    {
-      const unsigned long long ok = __shfl_xor( key, o, 64 );
-      key = ok < key ? ok : key;
-    }
+    // cost < 2^32: lexicographic minimum of (cost, index) as two 32-bit wave minima -- the cost, then the index among the lanes that hold it
+    const unsigned c32 = bestIdx == 0xffffffffu ? 0xffffffffu : ( unsigned ) bestCost;
+    const unsigned cm  = wave_min_u32( c32 );
+    const unsigned km  = wave_min_u32( c32 == cm ? bestIdx : 0xffffffffu );
+    unsigned long long key = km == 0xffffffffu ? ~0ull : ( ( unsigned long long ) cm << 32 ) | km;
     if( WPJ > 1 )
     {
       if( lane == 0 ) co.redCost[co.wave] = key;
