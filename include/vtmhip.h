@@ -328,7 +328,9 @@ typedef struct
   int64_t aOff, bOff, dstOff;
   int32_t aStride, bStride, dstStride;
   int16_t width, height;
-  uint8_t bitDepth, pad0, pad1, pad2;
+  uint8_t bitDepth;
+  int8_t  bcwWeight;            /* the BCW calls only: g_BcwWeights[bcwIdx] in {-2, 3, 4, 5, 10} (of 8), see there */
+  uint8_t pad1, pad2;
   int32_t pad3;
 } vtmhip_pelop_job;
 
@@ -340,6 +342,14 @@ int vtmhip_subtract_batch_dev( vtmhip_ctx *ctx, const int16_t *d_aBase, const in
 /* PelBuf::addAvg (Buffer.cpp:467-507): dst = clip((src0 + src1 + offset) >> shift) on 14-bit intermediates */
 int vtmhip_add_avg_batch_dev( vtmhip_ctx *ctx, const int16_t *d_src0Base, const int16_t *d_src1Base, int16_t *d_dstBase,
                               const vtmhip_pelop_job *d_jobs, int n );
+
+/* BCW (Buffer.h:417-460, Buffer.cpp:365-397).  removeWeightHighFreq: the bi-pred ME target when the searched list carries weight job.bcwWeight,
+ * dst = ( org * (n << 3) - pred * ((8 - w) * n) + 2^15 ) >> 16 with n = (2^16 + |w >> 1|) / w, unclipped (g_pelBufOP.removeWeightHighFreq4/8).
+ * addWeightedAvg: dst = clip( ( src0 * (8 - w) + src1 * w + offset ) >> shift ), job.bcwWeight = w = the LIST-1 weight g_BcwWeights[bcwIdx]. */
+int vtmhip_remove_weight_high_freq_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_predBase, int16_t *d_dstBase,
+                                              const vtmhip_pelop_job *d_jobs, int n );
+int vtmhip_add_weighted_avg_batch_dev( vtmhip_ctx *ctx, const int16_t *d_src0Base, const int16_t *d_src1Base, int16_t *d_dstBase,
+                                       const vtmhip_pelop_job *d_jobs, int n );
 
 /* BDOF: InterPrediction::xPredInterBi with bioApplied for bi-predicted LUMA PUs (InterPrediction.cpp:527-660: xSubPuBio :352-443 cuts the PU into
  * regions of at most 16 x 16, xPredInterBlk(..., bioApplied) :733-810 predicts each from both lists inside a ring of integer samples, and

@@ -307,4 +307,29 @@ void ref_add_avg( const int16_t *src0, int s0Stride, const int16_t *src1, int s1
   d.addAvg( a, b, clp );
 }
 
+// BCW: removeWeightHighFreq through g_pelBufOP (simd 1: x86 entries, 0: the scalar defaults of a fresh PelBufferOps) and addWeightedAvg (Buffer.cpp:365-397)
+void ref_remove_weight_high_freq( int simd, int16_t *org, int orgStride, const int16_t *pred, int predStride, int w, int h, int bcwWeight )
+{
+  ensureInit();
+  const PelBufferOps saved = g_pelBufOP;
+  if( !simd ) g_pelBufOP = PelBufferOps();
+  PelBuf  o( org, orgStride, w, h );
+  PelBuf  p( const_cast<int16_t *>( pred ), predStride, w, h );
+  ClpRng  clp; clp.min = 0; clp.max = 1023; clp.bd = 10; clp.n = 0;
+  o.removeWeightHighFreq( p, false, clp, ( int8_t ) bcwWeight );
+  g_pelBufOP = saved;
+}
+
+void ref_add_weighted_avg( const int16_t *src0, int s0Stride, const int16_t *src1, int s1Stride, int16_t *dst, int dstStride, int w, int h, int bitDepth, int bcwIdx )
+{
+  ensureInit();
+  PelBuf  d( dst, dstStride, w, h );
+  CPelBuf a( src0, s0Stride, w, h );
+  CPelBuf b( src1, s1Stride, w, h );
+  ClpRng  clp; clp.min = 0; clp.max = ( 1 << bitDepth ) - 1; clp.bd = bitDepth; clp.n = 0;
+  d.addWeightedAvg( a, b, clp, ( int8_t ) bcwIdx );
+}
+
+int ref_bcw_weight( int bcwIdx ) { return g_BcwWeights[bcwIdx]; }
+
 }   // extern "C"

@@ -660,6 +660,31 @@ void vo_add_avg( const int16_t *a, int aStride, const int16_t *b, int bStride, i
         ( int16_t ) vo_clip3( 0, ( 1 << bitDepth ) - 1, ( a[( ptrdiff_t ) y * aStride + x] + b[( ptrdiff_t ) y * bStride + x] + offset ) >> shift );
 }
 
+/* BCW variants (CommonLib/Buffer.h:417-460, Buffer.cpp:365-397; weights g_BcwWeights = {-2, 3, 4, 5, 10} of 8, Rom.cpp:188-190).
+ * removeWeightHighFreq: the bi-pred ME target when the searched list carries weight bcwWeight: (org * 8 - pred * (8 - w)) / w in 16.16 fixed point,
+ * unclipped.  addWeightedAvg: src0 * (8 - w1) + src1 * w1 on the 14-bit intermediates. */
+void vo_remove_weight_high_freq( int16_t *org, int orgStride, const int16_t *pred, int predStride, int w, int h, int bcwWeight )
+{
+  const int normalizer = ( ( 1 << 16 ) + ( bcwWeight > 0 ? ( bcwWeight >> 1 ) : -( bcwWeight >> 1 ) ) ) / bcwWeight;
+  const int weight0 = normalizer * 8, weight1 = ( 8 - bcwWeight ) * normalizer;
+  for( int y = 0; y < h; y++ )
+    for( int x = 0; x < w; x++ )
+      org[( ptrdiff_t ) y * orgStride + x] =
+        ( int16_t )( ( org[( ptrdiff_t ) y * orgStride + x] * weight0 - pred[( ptrdiff_t ) y * predStride + x] * weight1 + ( 1 << 15 ) ) >> 16 );
+}
+
+void vo_add_weighted_avg( const int16_t *a, int aStride, const int16_t *b, int bStride, int16_t *dst, int dstStride, int w, int h, int bitDepth, int w1 )
+{
+  const int headRoom = ( VO_IF_PREC - bitDepth ) > 2 ? ( VO_IF_PREC - bitDepth ) : 2;
+  const int shift    = headRoom + 3;
+  const int offset   = ( 1 << ( shift - 1 ) ) + ( VO_IF_OFFS << 3 );
+  const int w0       = 8 - w1;
+  for( int y = 0; y < h; y++ )
+    for( int x = 0; x < w; x++ )
+      dst[( ptrdiff_t ) y * dstStride + x] = ( int16_t ) vo_clip3( 0, ( 1 << bitDepth ) - 1,
+                                                                  ( a[( ptrdiff_t ) y * aStride + x] * w0 + b[( ptrdiff_t ) y * bStride + x] * w1 + offset ) >> shift );
+}
+
 /* ------------------------------------------------------------------------------------------------
  * K11 Affine gradient  CommonLib/AffineGradientSearch.cpp:62-170.
  * ------------------------------------------------------------------------------------------------ */

@@ -72,6 +72,9 @@ void vo_dmvr_pu( const int16_t *plane0, const int16_t *plane1, int stride, int p
 /* ... and one 4:2:0 chroma plane of the same PU, given pu.mvdL0SubPu (xPrefetch forLuma = 0, xPad, xFinalPaddedMCForDMVR, addAvg) */
 void vo_dmvr_chroma( const int16_t *planeC0, const int16_t *planeC1, int strideC, int picW, int picH, int ctuSize, int puX, int puY, int w, int h,
                      int mv0Hor, int mv0Ver, int mv1Hor, int mv1Ver, const int32_t *mvd, int bitDepth, int16_t *dst, int dstStride );
+/* BCW: AreaBuf::removeWeightHighFreq (Buffer.h:417-460), AreaBuf::addWeightedAvg (Buffer.cpp:365-397); w1 = the list-1 weight g_BcwWeights[bcwIdx] */
+void vo_remove_weight_high_freq( int16_t *org, int orgStride, const int16_t *pred, int predStride, int w, int h, int bcwWeight );
+void vo_add_weighted_avg( const int16_t *a, int aStride, const int16_t *b, int bStride, int16_t *dst, int dstStride, int w, int h, int bitDepth, int w1 );
 /* InterpolationFilter::xWeightedGeoBlk, CommonLib/InterpolationFilter.cpp:902-957 */
 void vo_weighted_geo_blk( const int16_t *src0, int src0Stride, const int16_t *src1, int src1Stride, int16_t *dst, int dstStride, int w, int h,
                           const int16_t *weight, int stepX, int weightStride, int bitDepth, int clipMin, int clipMax );

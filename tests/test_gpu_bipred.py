@@ -477,3 +477,59 @@ def test_dmvr_chroma_matches_oracle(ctx):
         ctx.dmvr_chroma_batch(pic, d_org.ptr, d_ref.ptr, d_pred.ptr, d_out.ptr, d_jobs.ptr, n, 128, 128, d_mvd.ptr)
         assert np.array_equal(d_pred.to_host(np.int16), np.concatenate(exp_pred)), bd
         assert np.array_equal(d_out.to_host(np.int16), np.concatenate(exp_out)), bd
+
+
+def test_prediction_entry_points_empty_and_invalid(ctx):
+    """Error behaviour of the GEO / BDOF / DMVR entry points: an empty batch is a no-op, wrong arguments return VTMHIP_E_INVALID (a C status, never a launch)."""
+    from vtm_amd.lib import PicParams, VtmHipError
+    buf = ctx.alloc(4096)
+    pic = PicParams(64, 64, 128, 10, 0)
+    ctx.bdof_batch(0, buf.ptr, buf.ptr, 0, buf.ptr, 0, 16, 16)                       # n == 0
+    ctx.dmvr_batch(pic, 0, buf.ptr, buf.ptr, 0, buf.ptr, 0, 16, 16, buf.ptr)
+    ctx.dmvr_chroma_batch(pic, 0, buf.ptr, buf.ptr, 0, buf.ptr, 0, 16, 16, buf.ptr)
+    ctx.weightedGeoBlk_batch(buf.ptr, buf.ptr, buf.ptr, buf.ptr, 0)
+    for bad in (lambda: ctx.bdof_batch(0, buf.ptr, buf.ptr, 0, buf.ptr, 1, 4, 16),      # BDOF needs w >= 8
+                lambda: ctx.bdof_batch(0, buf.ptr, buf.ptr, buf.ptr, buf.ptr, 1, 16, 16),   # epilogue output without the original plane
+                lambda: ctx.bdof_batch(0, 0, buf.ptr, 0, buf.ptr, 1, 16, 16),           # null reference plane
+                lambda: ctx.dmvr_batch(PicParams(64, 64, 128, 14, 0), 0, buf.ptr, buf.ptr, 0, buf.ptr, 1, 16, 16, 0),   # bit depth
+                lambda: ctx.dmvr_batch(pic, 0, buf.ptr, 0, 0, buf.ptr, 1, 16, 16, 0),   # nothing to write
+                lambda: ctx.dmvr_chroma_batch(pic, 0, buf.ptr, buf.ptr, 0, buf.ptr, 1, 16, 16, 0),   # chroma needs the vector differences
+                lambda: ctx.weightedGeoBlk_batch(buf.ptr, buf.ptr, buf.ptr, buf.ptr, 1, 10, (0, 2000)),   # clip range beyond the bit depth
+                lambda: ctx.weightedGeoBlk(np.zeros((8, 8), np.int16), np.zeros((8, 8), np.int16), 8, 8, np.zeros(64, np.int16), 0, 3, 8)):   # stepX
+        with pytest.raises(VtmHipError):
+            bad()
+
+
+def test_bcw_ops_match_oracle(ctx):
+    """vtmhip_remove_weight_high_freq_batch_dev / vtmhip_add_weighted_avg_batch_dev vs the oracle: the five BCW weights (and their list-0 complements)."""
+    L = ol.oracle()
+    rng = np.random.default_rng(1019)
+    n = 120
+    jobs = (PelOpJob * n)()
+    A, B, E0, E1, pos = [], [], [], [], 0
+    for k in range(n):
+        w, h = int(rng.choice([4, 8, 16, 32, 64, 128])), int(rng.choice([4, 8, 16, 32, 64]))
+        bw = [-2, 3, 4, 5, 10][k % 5]
+        lw = bw if k % 2 else 8 - bw
+        bd = 8 if k % 7 == 0 else 10
+        hi = 8192 + ((1 << bd) - 1) * (1 << (14 - bd))
+        a, b = ol.i16(rng.integers(0, 1 << bd, (h, w))), ol.i16(rng.integers(0, 1 << bd, (h, w)))
+        e0 = a.copy()
+        L.vo_remove_weight_high_freq(ol.P(e0), w, ol.P(b), w, w, h, lw)
+        a14, b14 = ol.i16(rng.integers(-8192, hi, (h, w))), ol.i16(rng.integers(-8192, hi, (h, w)))
+        e1 = np.zeros((h, w), np.int16)
+        L.vo_add_weighted_avg(ol.P(a14), w, ol.P(b14), w, ol.P(e1), w, w, h, bd, lw)
+        j = jobs[k]
+        j.aOff = j.bOff = j.dstOff = pos
+        j.aStride = j.bStride = j.dstStride = w
+        j.width, j.height, j.bitDepth, j.bcwWeight = w, h, bd, lw
+        A.append(np.concatenate([a.reshape(-1), a14.reshape(-1)])); B.append(np.concatenate([b.reshape(-1), b14.reshape(-1)]))
+        E0.append(e0.reshape(-1)); E1.append(e1.reshape(-1))
+        pos += w * h
+    a0 = np.concatenate([x[:x.size // 2] for x in A]); a1 = np.concatenate([x[x.size // 2:] for x in A])
+    b0 = np.concatenate([x[:x.size // 2] for x in B]); b1 = np.concatenate([x[x.size // 2:] for x in B])
+    d_jobs, d_dst = ctx.to_device(np.frombuffer(jobs, np.uint8)), ctx.alloc(2 * pos)
+    ctx.remove_weight_high_freq_batch(ctx.to_device(a0).ptr, ctx.to_device(b0).ptr, d_dst.ptr, d_jobs.ptr, n)
+    assert np.array_equal(d_dst.to_host(np.int16), np.concatenate(E0))
+    ctx.add_weighted_avg_batch(ctx.to_device(a1).ptr, ctx.to_device(b1).ptr, d_dst.ptr, d_jobs.ptr, n)
+    assert np.array_equal(d_dst.to_host(np.int16), np.concatenate(E1))

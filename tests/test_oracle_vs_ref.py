@@ -417,3 +417,37 @@ def test_dmvr_420_equals_reference(oracle, reflib):
         moved += int(mm.sum())
         still += int((~mm).sum())
     assert moved > 100 and still > 100
+
+
+def test_bcw_ops_equal_reference(oracle, reflib):
+    """BCW variants of the two buffer ops: vo_remove_weight_high_freq vs AreaBuf::removeWeightHighFreq (scalar and x86 g_pelBufOP entries, all five
+    weights incl. the negative one) and vo_add_weighted_avg vs AreaBuf::addWeightedAvg (8- and 10-bit)."""
+    rng = np.random.default_rng(1018)
+    weights = [reflib.ref_bcw_weight(i) for i in range(5)]
+    assert weights == [-2, 3, 4, 5, 10]
+    def aligned(h, stride):   # the x86 entry stores with _mm_store_si128: 16-byte aligned rows, as the encoder's buffers are
+        raw = np.zeros(h * stride + 8, np.int16)
+        off = (-raw.ctypes.data // 2) % 8
+        return raw[off:off + h * stride].reshape(h, stride)
+    for k in range(150):
+        # power-of-two widths: the x86 4-wide entry touches only the first four columns of a row (x86/BufferX86.h:822-846), as removeHighFreq4 does
+        w, h = int(rng.choice([4, 8, 16, 32, 64, 128])), int(rng.choice([4, 8, 16, 32, 64, 128]))
+        idx = k % 5
+        bw = weights[idx]
+        for lw in (bw, 8 - bw):   # weight of list 1 / of list 0: both occur as the searched list
+            st = max(8, w) + 8
+            vals = ol.i16(rng.integers(0, 1024, (h, st)))
+            pred = ol.i16(rng.integers(0, 1024, (h, w + 1)))
+            a, b, c = aligned(h, st), aligned(h, st), aligned(h, st)
+            a[:], b[:], c[:] = vals, vals, vals
+            reflib.ref_remove_weight_high_freq(0, C.c_void_p(a.ctypes.data), st, ol.P(pred), w + 1, w, h, lw)
+            reflib.ref_remove_weight_high_freq(1, C.c_void_p(b.ctypes.data), st, ol.P(pred), w + 1, w, h, lw)
+            oracle.vo_remove_weight_high_freq(C.c_void_p(c.ctypes.data), st, ol.P(pred), w + 1, w, h, lw)
+            assert np.array_equal(a, b) and np.array_equal(a, c), (w, h, lw)
+        bd = 8 if k % 7 == 0 else 10
+        hi = 8192 + ((1 << bd) - 1) * (1 << (14 - bd))
+        s0, s1 = ol.i16(rng.integers(-8192, hi, (h, w))), ol.i16(rng.integers(-8192, hi, (h, w)))
+        d0, d1 = np.zeros((h, w), np.int16), np.zeros((h, w), np.int16)
+        reflib.ref_add_weighted_avg(ol.P(s0), w, ol.P(s1), w, ol.P(d0), w, w, h, bd, idx)
+        oracle.vo_add_weighted_avg(ol.P(s0), w, ol.P(s1), w, ol.P(d1), w, w, h, bd, bw)
+        assert np.array_equal(d0, d1), (w, h, idx, bd)

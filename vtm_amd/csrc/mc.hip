@@ -399,6 +399,8 @@ __global__ __launch_bounds__( 256 ) void pelop_kernel( const int16_t *__restrict
   const int              w = j.width, h = j.height;
   const int              headRoom = max( 2, 14 - ( int ) j.bitDepth ), shift = headRoom + 1, offset = ( 1 << ( shift - 1 ) ) + 2 * 8192;
   const int              cmax = ( 1 << j.bitDepth ) - 1;
+  const int              bcw = j.bcwWeight ? j.bcwWeight : 4;   // BCW ops: weight of 8 (4 = the default pair, which these ops are not called with)
+  const int              nrm = ( ( 1 << 16 ) + ( bcw > 0 ? ( bcw >> 1 ) : -( bcw >> 1 ) ) ) / bcw, bw0 = nrm << 3, bw1 = ( 8 - bcw ) * nrm;
   for( int i = threadIdx.x; i < w * h; i += blockDim.x )
   {
     const int y = i / w, x = i - y * w;
@@ -406,6 +408,8 @@ __global__ __launch_bounds__( 256 ) void pelop_kernel( const int16_t *__restrict
     int       v;
     if( op == 0 ) v = ( int16_t ) ( 2 * av - bv );                        // removeHighFreq
     else if( op == 2 ) v = ( int16_t ) ( av - bv );                        // subtract (residual = org - pred, Buffer.cpp AreaBuf::subtract)
+    else if( op == 3 ) v = ( int16_t ) ( ( av * bw0 - bv * bw1 + ( 1 << 15 ) ) >> 16 );   // removeWeightHighFreq (Buffer.h:417-460)
+    else if( op == 4 ) v = min( cmax, max( 0, ( av * ( 8 - bcw ) + bv * bcw + ( ( 1 << ( shift + 1 ) ) + ( 8192 << 3 ) ) ) >> ( shift + 2 ) ) );   // addWeightedAvg
     else v = min( cmax, max( 0, ( av + bv + offset ) >> shift ) );         // addAvg
     d[( long ) y * j.dstStride + x] = ( int16_t ) v;
   }
@@ -954,6 +958,30 @@ int vtmhip_subtract_batch_dev( vtmhip_ctx *ctx, const int16_t *d_aBase, const in
   if( n == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, d_aBase && d_bBase && d_dstBase && d_jobs, "null pointer" );
   hipLaunchKernelGGL( pelop_kernel, dim3( n ), dim3( 256 ), 0, ctx->stream, d_aBase, d_bBase, d_dstBase, d_jobs, 2 );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_remove_weight_high_freq_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_predBase, int16_t *d_dstBase,
+                                              const vtmhip_pelop_job *d_jobs, int n )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_orgBase && d_predBase && d_dstBase && d_jobs, "null pointer" );
+  hipLaunchKernelGGL( pelop_kernel, dim3( n ), dim3( 256 ), 0, ctx->stream, d_orgBase, d_predBase, d_dstBase, d_jobs, 3 );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_add_weighted_avg_batch_dev( vtmhip_ctx *ctx, const int16_t *d_src0Base, const int16_t *d_src1Base, int16_t *d_dstBase,
+                                       const vtmhip_pelop_job *d_jobs, int n )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_src0Base && d_src1Base && d_dstBase && d_jobs, "null pointer" );
+  hipLaunchKernelGGL( pelop_kernel, dim3( n ), dim3( 256 ), 0, ctx->stream, d_src0Base, d_src1Base, d_dstBase, d_jobs, 4 );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

@@ -257,6 +257,14 @@ class Context:
     def add_avg_batch(self, d_a, d_b, d_dst, d_jobs, n):
         self._check(self.L.vtmhip_add_avg_batch_dev(self.h, d_a, d_b, d_dst, d_jobs, n))
 
+    def remove_weight_high_freq_batch(self, d_org, d_pred, d_dst, d_jobs, n):
+        """BCW bi-pred ME target (PelOpJob.bcwWeight = weight of the searched list)."""
+        self._check(self.L.vtmhip_remove_weight_high_freq_batch_dev(self.h, d_org, d_pred, d_dst, d_jobs, n))
+
+    def add_weighted_avg_batch(self, d_a, d_b, d_dst, d_jobs, n):
+        """BCW bi-prediction average (PelOpJob.bcwWeight = the list-1 weight)."""
+        self._check(self.L.vtmhip_add_weighted_avg_batch_dev(self.h, d_a, d_b, d_dst, d_jobs, n))
+
     def tu_chain_batch(self, d_resi, d_jobs, n, max_w, max_h, d_results, d_levels=None, d_rec=None, uniform=False):
         self._check(self.L.vtmhip_tu_chain_batch_dev(self.h, d_resi, d_jobs, n, max_w, max_h, int(uniform), d_levels, d_rec, d_results))
 

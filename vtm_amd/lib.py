@@ -86,7 +86,7 @@ class McJob(C.Structure):
 class PelOpJob(C.Structure):
     _fields_ = [("aOff", C.c_int64), ("bOff", C.c_int64), ("dstOff", C.c_int64), ("aStride", C.c_int32),
                 ("bStride", C.c_int32), ("dstStride", C.c_int32), ("width", C.c_int16), ("height", C.c_int16),
-                ("bitDepth", C.c_uint8), ("pad0", C.c_uint8), ("pad1", C.c_uint8), ("pad2", C.c_uint8), ("pad3", C.c_int32)]
+                ("bitDepth", C.c_uint8), ("bcwWeight", C.c_int8), ("pad1", C.c_uint8), ("pad2", C.c_uint8), ("pad3", C.c_int32)]
 
 
 class TuJob(C.Structure):
@@ -187,6 +187,8 @@ _PROTOS = {
     "vtmhip_xGetSADwMask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                       C.c_int, C.POINTER(C.c_uint64)]),
     "vtmhip_masked_sad_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vtmhip_remove_weight_high_freq_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "vtmhip_add_weighted_avg_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "vtmhip_bdof_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "vtmhip_dmvr_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),
