@@ -112,6 +112,24 @@ int vtmhip_filterCopy( vtmhip_ctx *ctx, int isFirst, int isLast, const int16_t *
 int vtmhip_fastFwdTrans( vtmhip_ctx *ctx, int type, int n, const int32_t *src, int32_t *dst, int shift, int line, int skipLine, int skipLine2 );
 int vtmhip_fastInvTrans( vtmhip_ctx *ctx, int type, int n, const int32_t *src, int32_t *dst, int shift, int line, int skipLine, int skipLine2,
                          int32_t outputMinimum, int32_t outputMaximum );
+/* LFNST kernels: TrQuant::fwdLfnstNxN / invLfnstNxN (TrQuant.cpp:233-311; called by xFwdLfnst / xInvLfnst :313-527, which gather / scatter the
+ * low-frequency region on the host).  The trained core matrices g_lfnst8x8[4][2][16][48] and g_lfnst4x4[4][2][16][16] (Rom.h:132-133, int8) are the
+ * CALLER's data: the integration hands the reference's own arrays over once per context; nothing of them is compiled into this library.
+ * forward: dst[j] = ( sum_i src[i] * M[j][i] + 64 ) >> 7 for j < zeroOutSize, zeros up to trSize (16 / 48);
+ * inverse: dst[j] = clip( ( sum_{i < zeroOutSize} src[i] * M[i][j] + 64 ) >> 7, +-2^15 ) for j < trSize.   size: 4 or 8 (the `size > 4` switch). */
+int vtmhip_lfnst_set_tables( vtmhip_ctx *ctx, const int8_t *lfnst8x8, const int8_t *lfnst4x4 );
+int vtmhip_fwdLfnstNxN( vtmhip_ctx *ctx, const int32_t *src, int32_t *dst, int mode, int index, int size, int zeroOutSize );
+int vtmhip_invLfnstNxN( vtmhip_ctx *ctx, const int32_t *src, int32_t *dst, int mode, int index, int size, int zeroOutSize );
+typedef struct
+{
+  int64_t srcOff, dstOff;       /* coefficients inside d_srcBase / d_dstBase: forward reads trSize and writes trSize, inverse reads zeroOutSize and writes trSize */
+  uint8_t mode, index;          /* g_lfnstLut[intraMode] (0..3), lfnstIdx - 1 (0..1) */
+  uint8_t size;                 /* 4: the 16 x 16 matrices, 8: the 16 x 48 ones */
+  uint8_t zeroOutSize;          /* 8 or 16 */
+  uint8_t inverse, pad0, pad1, pad2;
+} vtmhip_lfnst_job;
+int vtmhip_lfnst_batch_dev( vtmhip_ctx *ctx, const int32_t *d_srcBase, int32_t *d_dstBase, const vtmhip_lfnst_job *d_jobs, int n );
+
 /* n x n forward core matrix g_trCore<type>P<n>[TRANSFORM_FORWARD] (Rom.h:115-130), row-major int16; host-only helper */
 int vtmhip_tr_matrix_host( int type, int n, int16_t *out );
 /* MTS candidate pre-selection thresholds of TrQuant::transformNxN( tu, compID, cQP, &trModes, maxCand ) (TrQuant.cpp:950-1019); host-only */

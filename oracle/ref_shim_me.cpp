@@ -664,3 +664,24 @@ extern "C" void ref_dmvr_pu420( const int16_t *const planes[2][3], int strideY, 
   r.cu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
   r.pu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// LFNST kernels: the real TrQuant::fwdLfnstNxN / invLfnstNxN (TrQuant.cpp:233-311) and the reference's trained core matrices (Rom.h:132-133),
+// handed out as DATA the way an integration hands them to the device library.
+// ------------------------------------------------------------------------------------------------------------------
+#include "CommonLib/TrQuant.h"
+extern "C" void ref_lfnst_tables( int8_t *out8x8, int8_t *out4x4 )
+{
+  memcpy( out8x8, g_lfnst8x8, sizeof( g_lfnst8x8 ) );
+  memcpy( out4x4, g_lfnst4x4, sizeof( g_lfnst4x4 ) );
+}
+extern "C" void ref_lfnst( int inverse, const int32_t *src, int32_t *dst, int mode, int index, int size, int zeroOutSize )
+{
+  static TrQuant *tq = new TrQuant();
+  int             in[48], out[48];
+  memset( in, 0, sizeof( in ) );
+  memcpy( in, src, sizeof( int ) * ( inverse ? zeroOutSize : ( size > 4 ? 48 : 16 ) ) );
+  if( inverse ) tq->invLfnstNxN( in, out, mode, index, size, zeroOutSize, 15 );
+  else tq->fwdLfnstNxN( in, out, mode, index, size, zeroOutSize );
+  memcpy( dst, out, sizeof( int ) * ( size > 4 ? 48 : 16 ) );
+}

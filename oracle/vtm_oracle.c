@@ -685,6 +685,34 @@ void vo_add_weighted_avg( const int16_t *a, int aStride, const int16_t *b, int b
                                                                   ( a[( ptrdiff_t ) y * aStride + x] * w0 + b[( ptrdiff_t ) y * bStride + x] * w1 + offset ) >> shift );
 }
 
+/* LFNST kernels: TrQuant::fwdLfnstNxN / invLfnstNxN (CommonLib/TrQuant.cpp:233-311).  M: the 16 x trSize int8 core matrix of (mode, index) -- data of
+ * the standard that the caller supplies (g_lfnst8x8 / g_lfnst4x4, Rom.h:132-133); trSize = 48 for size > 4, else 16. */
+void vo_fwd_lfnst( const int32_t *src, int32_t *dst, const int8_t *M, int size, int zeroOutSize )
+{
+  const int trSize = size > 4 ? 48 : 16;
+  for( int j = 0; j < trSize; j++ )
+  {
+    int coef = 0;
+    if( j < zeroOutSize )
+    {
+      for( int i = 0; i < trSize; i++ ) coef += src[i] * ( int ) M[j * trSize + i];
+      coef = ( coef + 64 ) >> 7;
+    }
+    dst[j] = coef;
+  }
+}
+
+void vo_inv_lfnst( const int32_t *src, int32_t *dst, const int8_t *M, int size, int zeroOutSize )
+{
+  const int trSize = size > 4 ? 48 : 16;
+  for( int j = 0; j < trSize; j++ )
+  {
+    int resi = 0;
+    for( int i = 0; i < zeroOutSize; i++ ) resi += src[i] * ( int ) M[i * trSize + j];
+    dst[j] = vo_clip3( -32768, 32767, ( resi + 64 ) >> 7 );
+  }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * K11 Affine gradient  CommonLib/AffineGradientSearch.cpp:62-170.
  * ------------------------------------------------------------------------------------------------ */

@@ -75,6 +75,9 @@ void vo_dmvr_chroma( const int16_t *planeC0, const int16_t *planeC1, int strideC
 /* BCW: AreaBuf::removeWeightHighFreq (Buffer.h:417-460), AreaBuf::addWeightedAvg (Buffer.cpp:365-397); w1 = the list-1 weight g_BcwWeights[bcwIdx] */
 void vo_remove_weight_high_freq( int16_t *org, int orgStride, const int16_t *pred, int predStride, int w, int h, int bcwWeight );
 void vo_add_weighted_avg( const int16_t *a, int aStride, const int16_t *b, int bStride, int16_t *dst, int dstStride, int w, int h, int bitDepth, int w1 );
+/* TrQuant::fwdLfnstNxN / invLfnstNxN, CommonLib/TrQuant.cpp:233-311; M = the caller's 16 x (size > 4 ? 48 : 16) int8 core matrix */
+void vo_fwd_lfnst( const int32_t *src, int32_t *dst, const int8_t *M, int size, int zeroOutSize );
+void vo_inv_lfnst( const int32_t *src, int32_t *dst, const int8_t *M, int size, int zeroOutSize );
 /* InterpolationFilter::xWeightedGeoBlk, CommonLib/InterpolationFilter.cpp:902-957 */
 void vo_weighted_geo_blk( const int16_t *src0, int src0Stride, const int16_t *src1, int src1Stride, int16_t *dst, int dstStride, int w, int h,
                           const int16_t *weight, int stepX, int weightStride, int bitDepth, int clipMin, int clipMax );

@@ -417,6 +417,26 @@ def gen_dmvr():
     print("dmvr:", len(meta), "PUs,", int(np.count_nonzero(np.concatenate(mvds))), "non-zero vector components")
 
 
+def gen_lfnst():
+    """TrQuant::fwdLfnstNxN / invLfnstNxN (ref_lfnst) on random coefficient vectors.  The trained core matrices are INPUT DATA of these functions
+    (the integration passes the reference's arrays to the device library): stored with the vectors so that the GPU box can replay them."""
+    m8, m4 = np.zeros((4, 2, 16, 48), np.int8), np.zeros((4, 2, 16, 16), np.int8)
+    R.ref_lfnst_tables(C.c_void_p(m8.ctypes.data), C.c_void_p(m4.ctypes.data))
+    g = np.random.default_rng(1020)
+    meta, src, out = [], [], []
+    for k in range(256):
+        inverse, mode, index, size, zo = k & 1, int(g.integers(0, 4)), int(g.integers(0, 2)), int(g.choice([4, 8])), int(g.choice([8, 16]))
+        n = 48 if size > 4 else 16
+        s_ = np.zeros(48, np.int32)
+        lim = 32768 if k % 9 == 0 else 2048
+        s_[:(zo if inverse else n)] = g.integers(-lim, lim, zo if inverse else n)
+        d = np.zeros(48, np.int32)
+        R.ref_lfnst(inverse, ol.P(s_), ol.P(d), mode, index, size, zo)
+        meta.append((inverse, mode, index, size, zo)); src.append(s_); out.append(d)
+    np.savez_compressed(os.path.join(HERE, "lfnst.npz"), m8=m8, m4=m4, meta=np.array(meta, np.int32), src=np.stack(src), out=np.stack(out))
+    print("lfnst:", len(meta), "vectors")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected fixtures only: gen_golden.py mest quant ...
         for name in sys.argv[1:]:
@@ -435,3 +455,4 @@ if __name__ == "__main__":
     gen_geo()
     gen_bdof()
     gen_dmvr()
+    gen_lfnst()

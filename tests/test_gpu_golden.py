@@ -215,3 +215,26 @@ def test_dmvr_golden(ctx):
     d_cj, d_cpred = ctx.to_device(np.frombuffer(cjobs, np.uint8)), ctx.alloc(2 * cpos)
     ctx.dmvr_chroma_batch(pic, 0, d_refc.ptr, d_cpred.ptr, 0, d_cj.ptr, 2 * len(meta), 128, 128, d_mvd.ptr)
     assert np.array_equal(d_cpred.to_host(np.int16), z["outc"])
+
+
+def test_lfnst_golden(ctx):
+    """vtmhip_fwdLfnstNxN / vtmhip_invLfnstNxN and the batched call vs the vectors recorded from the reference; matrices uploaded as caller data."""
+    from vtm_amd.lib import LfnstJob
+    z = np.load(os.path.join(G, "lfnst.npz"))
+    ctx.lfnst_set_tables(z["m8"], z["m4"])
+    meta = z["meta"].tolist()
+    jobs = (LfnstJob * len(meta))()
+    for k, (inverse, mode, index, size, zo) in enumerate(meta):
+        n = 48 if size > 4 else 16
+        if k % 8 == 0:
+            got = ctx.lfnst(inverse, z["src"][k], mode, index, size, zo)
+            assert np.array_equal(got[:n], z["out"][k][:n]), (k, inverse, mode, index, size, zo)
+        j = jobs[k]
+        j.srcOff = j.dstOff = 48 * k
+        j.mode, j.index, j.size, j.zeroOutSize, j.inverse = mode, index, size, zo, inverse
+    d_src, d_jobs, d_dst = ctx.to_device(np.ascontiguousarray(z["src"]).reshape(-1)), ctx.to_device(np.frombuffer(jobs, np.uint8)), ctx.alloc(4 * 48 * len(meta))
+    ctx.lfnst_batch(d_src.ptr, d_dst.ptr, d_jobs.ptr, len(meta))
+    got = d_dst.to_host(np.int32).reshape(len(meta), 48)
+    for k, (inverse, mode, index, size, zo) in enumerate(meta):
+        n = 48 if size > 4 else 16
+        assert np.array_equal(got[k, :n], z["out"][k][:n]), (k, inverse, mode, index, size, zo)

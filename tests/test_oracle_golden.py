@@ -228,3 +228,16 @@ def test_dmvr_golden(oracle):
         cpos += w * h // 2
         pos += w * h
         mpos += 2 * nsub
+
+
+def test_lfnst_golden(oracle):
+    """LFNST kernels recorded from TrQuant::fwdLfnstNxN / invLfnstNxN (gen_golden.py gen_lfnst); the core matrices travel as input data."""
+    z = np.load(os.path.join(G, "lfnst.npz"))
+    m8, m4 = np.ascontiguousarray(z["m8"]), np.ascontiguousarray(z["m4"])
+    for (inverse, mode, index, size, zo), s_, e in zip(z["meta"].tolist(), z["src"], z["out"]):
+        M = m8[mode, index] if size > 4 else m4[mode, index]
+        n = 48 if size > 4 else 16
+        got = np.zeros(48, np.int32)
+        fn = oracle.vo_inv_lfnst if inverse else oracle.vo_fwd_lfnst
+        fn(ol.P(np.ascontiguousarray(s_)), ol.P(got), C.c_void_p(np.ascontiguousarray(M).ctypes.data), size, zo)
+        assert np.array_equal(got[:n], e[:n]), (inverse, mode, index, size, zo)

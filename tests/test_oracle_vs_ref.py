@@ -451,3 +451,26 @@ def test_bcw_ops_equal_reference(oracle, reflib):
         reflib.ref_add_weighted_avg(ol.P(s0), w, ol.P(s1), w, ol.P(d0), w, w, h, bd, idx)
         oracle.vo_add_weighted_avg(ol.P(s0), w, ol.P(s1), w, ol.P(d1), w, w, h, bd, bw)
         assert np.array_equal(d0, d1), (w, h, idx, bd)
+
+
+def test_lfnst_equals_reference(oracle, reflib):
+    """vo_fwd_lfnst / vo_inv_lfnst vs the real TrQuant::fwdLfnstNxN / invLfnstNxN for every (mode, index, size, zeroOutSize)."""
+    m8, m4 = np.zeros((4, 2, 16, 48), np.int8), np.zeros((4, 2, 16, 16), np.int8)
+    reflib.ref_lfnst_tables(C.c_void_p(m8.ctypes.data), C.c_void_p(m4.ctypes.data))
+    assert np.abs(m8).max() > 64 and np.abs(m4).max() > 64
+    rng = np.random.default_rng(1021)
+    for mode in range(4):
+        for index in range(2):
+            for size in (4, 8):
+                for zo in (8, 16):
+                    for inverse in (0, 1):
+                        for rep in range(6):
+                            n = 48 if size > 4 else 16
+                            s_ = np.zeros(48, np.int32)
+                            lim = 32768 if rep == 0 else 3000
+                            s_[:(zo if inverse else n)] = rng.integers(-lim, lim, zo if inverse else n)
+                            a, b = np.zeros(48, np.int32), np.zeros(48, np.int32)
+                            reflib.ref_lfnst(inverse, ol.P(s_), ol.P(a), mode, index, size, zo)
+                            M = np.ascontiguousarray(m8[mode, index] if size > 4 else m4[mode, index])
+                            (oracle.vo_inv_lfnst if inverse else oracle.vo_fwd_lfnst)(ol.P(s_), ol.P(b), C.c_void_p(M.ctypes.data), size, zo)
+                            assert np.array_equal(a[:n], b[:n]), (mode, index, size, zo, inverse)

@@ -33,6 +33,7 @@ int vtmhip_struct_size( int which )
   case 20: return ( int ) sizeof( vtmhip_masked_sad_job );
   case 21: return ( int ) sizeof( vtmhip_geo_blend_job );
   case 22: return ( int ) sizeof( vtmhip_dmvr_job );
+  case 23: return ( int ) sizeof( vtmhip_lfnst_job );
   default: return -1;
   }
 }
@@ -89,6 +90,7 @@ int vtmhip_destroy( vtmhip_ctx *ctx )
   ( void ) hipStreamSynchronize( ctx->stream );
   if( ctx->scratch ) ( void ) hipFree( ctx->scratch );
   if( ctx->work ) ( void ) hipFree( ctx->work );
+  if( ctx->lfnstTab ) ( void ) hipFree( ctx->lfnstTab );
   if( ctx->pinned ) ( void ) hipHostFree( ctx->pinned );
   if( ctx->evStart ) ( void ) hipEventDestroy( ctx->evStart );
   if( ctx->evStop ) ( void ) hipEventDestroy( ctx->evStop );

@@ -22,6 +22,7 @@ struct vtmhip_ctx
   size_t      pinnedSize  = 0;
   void       *work        = nullptr;   // device workspace of the multi-stage calls (vtmhip_xMotionEstimation_batch_dev)
   size_t      workSize    = 0;
+  int8_t     *lfnstTab    = nullptr;   // the caller's LFNST core matrices: g_lfnst8x8 [4][2][16][48] then g_lfnst4x4 [4][2][16][16] (vtmhip_lfnst_set_tables)
   int         numCUs      = 256;
   std::string lastError;
 };

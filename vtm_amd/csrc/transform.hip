@@ -969,3 +969,104 @@ extern "C" int vtmhip_xT_uniform_batch_dev( vtmhip_ctx *ctx, const int16_t *d_re
   if( st ) return st;
   return launch_tu_uni_sized( ctx, d_resiBase, d_jobs, n, width, height, nullptr, nullptr, d_results, g_tabs[ctx->device & 15], d_coefBase );
 }
+
+
+// =====================================================================================================================
+// LFNST kernels (TrQuant::fwdLfnstNxN / invLfnstNxN, TrQuant.cpp:233-311): a 16 x 16 or 16 x 48 int8 matrix-vector product per TU.
+// One wave per job.  Forward: lane = part * 16 + j, four lanes share output j (12 or 4 of the 48 / 16 products each).
+// Inverse: lane j < trSize sums its column over the first zeroOutSize rows.  The matrices come from the caller (vtmhip_lfnst_set_tables).
+// =====================================================================================================================
+namespace
+{
+__global__ __launch_bounds__( 256 ) void lfnst_kernel( const int8_t *__restrict__ tab, const int *__restrict__ srcBase, int *__restrict__ dstBase,
+                                                      const vtmhip_lfnst_job *__restrict__ jobs, int n )
+{
+  const int lane = threadIdx.x & 63;
+  const int job  = blockIdx.x * 4 + ( threadIdx.x >> 6 );
+  if( job >= n ) return;
+  const vtmhip_lfnst_job j = jobs[job];
+  const int     trSize = j.size > 4 ? 48 : 16, zo = j.zeroOutSize;
+  const int8_t *M   = j.size > 4 ? tab + ( ( j.mode * 2 + j.index ) * 16 ) * 48 : tab + 4 * 2 * 16 * 48 + ( ( j.mode * 2 + j.index ) * 16 ) * 16;
+  const int    *src = srcBase + j.srcOff;
+  int          *dst = dstBase + j.dstOff;
+  if( !j.inverse )
+  {
+    const int o = lane & 15, part = lane >> 4, per = trSize >> 2;
+    int       acc = 0;
+    if( o < zo )
+      for( int i = part * per; i < ( part + 1 ) * per; i++ ) acc += src[i] * ( int ) M[o * trSize + i];
+    acc += __shfl_xor( acc, 16, 64 );
+    acc += __shfl_xor( acc, 32, 64 );
+    if( lane < trSize ) dst[lane] = lane < zo ? ( acc + 64 ) >> 7 : 0;   // lanes 16..47 of the 8x8 case write the zeroed tail
+    return;
+  }
+  if( lane < trSize )
+  {
+    int acc = 0;
+    for( int i = 0; i < zo; i++ ) acc += src[i] * ( int ) M[i * trSize + lane];
+    dst[lane] = min( 32767, max( -32768, ( acc + 64 ) >> 7 ) );
+  }
+}
+}   // namespace
+
+extern "C"
+{
+
+int vtmhip_lfnst_set_tables( vtmhip_ctx *ctx, const int8_t *lfnst8x8, const int8_t *lfnst4x4 )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, lfnst8x8 && lfnst4x4, "null pointer" );
+  const size_t n8 = 4 * 2 * 16 * 48, n4 = 4 * 2 * 16 * 16;
+  if( !ctx->lfnstTab ) VTMHIP_HIP( ctx, hipMalloc( ( void ** ) &ctx->lfnstTab, n8 + n4 ) );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( ctx->lfnstTab, lfnst8x8, n8, hipMemcpyHostToDevice, ctx->stream ) );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( ctx->lfnstTab + n8, lfnst4x4, n4, hipMemcpyHostToDevice, ctx->stream ) );
+  VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );   // the host arrays may go away
+  return VTMHIP_OK;
+}
+
+int vtmhip_lfnst_batch_dev( vtmhip_ctx *ctx, const int32_t *d_srcBase, int32_t *d_dstBase, const vtmhip_lfnst_job *d_jobs, int n )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, ctx->lfnstTab, "vtmhip_lfnst_set_tables has not been called" );
+  VTMHIP_REQUIRE( ctx, d_srcBase && d_dstBase && d_jobs, "null pointer" );
+  hipLaunchKernelGGL( lfnst_kernel, dim3( ( n + 3 ) / 4 ), dim3( 256 ), 0, ctx->stream, ctx->lfnstTab, d_srcBase, d_dstBase, d_jobs, n );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+static int lfnst_single( vtmhip_ctx *ctx, const int32_t *src, int32_t *dst, int mode, int index, int size, int zeroOutSize, int inverse )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, src && dst, "null pointer" );
+  VTMHIP_REQUIRE( ctx, ctx->lfnstTab, "vtmhip_lfnst_set_tables has not been called" );
+  VTMHIP_REQUIRE( ctx, mode >= 0 && mode < 4 && index >= 0 && index < 2 && ( size == 4 || size == 8 ) && ( zeroOutSize == 8 || zeroOutSize == 16 ), "mode / index / size / zeroOutSize" );
+  const int trSize = size > 4 ? 48 : 16, nIn = inverse ? zeroOutSize : trSize;
+  int st = vtmhip_internal_scratch( ctx, 1024 );
+  if( st ) return st;
+  char *hp = ( char * ) ctx->pinned, *dp = ( char * ) ctx->scratch;
+  memcpy( hp, src, sizeof( int32_t ) * nIn );
+  vtmhip_lfnst_job j;
+  memset( &j, 0, sizeof( j ) );
+  j.srcOff = 0; j.dstOff = 64; j.mode = ( uint8_t ) mode; j.index = ( uint8_t ) index; j.size = ( uint8_t ) size; j.zeroOutSize = ( uint8_t ) zeroOutSize; j.inverse = ( uint8_t ) inverse;
+  memcpy( hp + 512, &j, sizeof( j ) );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( dp, hp, 576, hipMemcpyHostToDevice, ctx->stream ) );
+  hipLaunchKernelGGL( lfnst_kernel, dim3( 1 ), dim3( 256 ), 0, ctx->stream, ctx->lfnstTab, ( const int * ) dp, ( int * ) dp, ( const vtmhip_lfnst_job * ) ( dp + 512 ), 1 );
+  VTMHIP_LAUNCHED( ctx );
+  VTMHIP_HIP( ctx, hipMemcpyAsync( hp + 256, dp + 256, sizeof( int32_t ) * trSize, hipMemcpyDeviceToHost, ctx->stream ) );
+  VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  memcpy( dst, hp + 256, sizeof( int32_t ) * trSize );
+  return VTMHIP_OK;
+}
+
+int vtmhip_fwdLfnstNxN( vtmhip_ctx *ctx, const int32_t *src, int32_t *dst, int mode, int index, int size, int zeroOutSize )
+{
+  return lfnst_single( ctx, src, dst, mode, index, size, zeroOutSize, 0 );
+}
+int vtmhip_invLfnstNxN( vtmhip_ctx *ctx, const int32_t *src, int32_t *dst, int mode, int index, int size, int zeroOutSize )
+{
+  return lfnst_single( ctx, src, dst, mode, index, size, zeroOutSize, 1 );
+}
+
+}   // extern "C"

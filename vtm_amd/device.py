@@ -241,6 +241,23 @@ class Context:
         """One 4:2:0 chroma plane of the PUs of a dmvr_batch call (jobs address that plane; d_mvd from the luma call)."""
         self._check(self.L.vtmhip_dmvr_chroma_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_pred, d_out, d_jobs, n, max_w, max_h, d_mvd))
 
+    def lfnst_set_tables(self, lfnst8x8, lfnst4x4):
+        """The caller's LFNST core matrices (int8 [4][2][16][48] and [4][2][16][16]), once per context."""
+        a, b = np.ascontiguousarray(lfnst8x8, np.int8), np.ascontiguousarray(lfnst4x4, np.int8)
+        assert a.size == 4 * 2 * 16 * 48 and b.size == 4 * 2 * 16 * 16
+        self._check(self.L.vtmhip_lfnst_set_tables(self.h, a.ctypes.data, b.ctypes.data))
+
+    def lfnst(self, inverse, src, mode, index, size, zero_out):
+        """TrQuant::fwdLfnstNxN / invLfnstNxN on a host vector; returns the trSize outputs."""
+        src = np.ascontiguousarray(src, np.int32)
+        dst = np.zeros(48 if size > 4 else 16, np.int32)
+        fn = self.L.vtmhip_invLfnstNxN if inverse else self.L.vtmhip_fwdLfnstNxN
+        self._check(fn(self.h, src.ctypes.data, dst.ctypes.data, mode, index, size, zero_out))
+        return dst
+
+    def lfnst_batch(self, d_src, d_dst, d_jobs, n):
+        self._check(self.L.vtmhip_lfnst_batch_dev(self.h, d_src, d_dst, d_jobs, n))
+
     def mc_batch(self, d_ref, d_dst, d_jobs, n, max_w, max_h):
         """xPredInterBlk for luma and 4:2:0 chroma blocks (McJob.chroma)."""
         self._check(self.L.vtmhip_mc_batch_dev(self.h, d_ref, d_dst, d_jobs, n, max_w, max_h))

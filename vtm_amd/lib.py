@@ -159,8 +159,13 @@ class DmvrJob(C.Structure):
                 ("bitDepth", C.c_uint8), ("pad0", C.c_uint8), ("mvdRow", C.c_int32)]
 
 
+class LfnstJob(C.Structure):
+    _fields_ = [("srcOff", C.c_int64), ("dstOff", C.c_int64), ("mode", C.c_uint8), ("index", C.c_uint8), ("size", C.c_uint8), ("zeroOutSize", C.c_uint8),
+                ("inverse", C.c_uint8), ("pad0", C.c_uint8), ("pad1", C.c_uint8), ("pad2", C.c_uint8)]
+
+
 _STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob,
-            TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut, PredJob, FrameTabs, MaskedSadJob, GeoBlendJob, DmvrJob]   # order of vtmhip_struct_size(which)
+            TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut, PredJob, FrameTabs, MaskedSadJob, GeoBlendJob, DmvrJob, LfnstJob]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
 _PROTOS = {
@@ -189,6 +194,10 @@ _PROTOS = {
     "vtmhip_masked_sad_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vtmhip_remove_weight_high_freq_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "vtmhip_add_weighted_avg_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "vtmhip_lfnst_set_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vtmhip_fwdLfnstNxN": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vtmhip_invLfnstNxN": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vtmhip_lfnst_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "vtmhip_bdof_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "vtmhip_dmvr_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),
