@@ -529,10 +529,10 @@ __device__ __forceinline__ void tuq_pass( const int *A, int aRowStride, int aCol
                                           int rEff, int cEff, int *out, int oRowStride, int oColStride, int shift, int t, long long *sumAbs )
 {
   // one lane: a 2 x 8 block of outputs (rows r, r + 1): the 16-byte matrix read of a summation step feeds 16 multiply-adds
-  const int cb = cols >> 3, rnd = shift > 0 ? 1 << ( shift - 1 ) : 0;
+  const int cb = cols >> 3, lcb = 31 - __clz( cb ), rnd = shift > 0 ? 1 << ( shift - 1 ) : 0;
   for( int it = t; it < ( rows >> 1 ) * cb; it += LPT )
   {
-    const int r = ( it / cb ) << 1, c0 = ( it - ( it / cb ) * cb ) << 3;
+    const int r = ( it >> lcb ) << 1, c0 = ( it & ( cb - 1 ) ) << 3;   // cb is a power of two (TU sizes are)
     int       acc[2][8];
 #pragma unroll
     for( int i = 0; i < 8; i++ ) acc[0][i] = acc[1][i] = rnd;
@@ -569,10 +569,10 @@ __device__ __forceinline__ void tuq_pass16( const int16_t *A, int aRowStride, co
                                             int oRowStride, int oColStride, int shift, int t )
 {
   typedef short v2s __attribute__( ( ext_vector_type( 2 ) ) );
-  const int cb = cols >> 3, rnd = shift > 0 ? 1 << ( shift - 1 ) : 0;
+  const int cb = cols >> 3, lcb = 31 - __clz( cb ), rnd = shift > 0 ? 1 << ( shift - 1 ) : 0;
   for( int it = t; it < ( rows >> 1 ) * cb; it += LPT )   // a 2 x 8 block of outputs per lane
   {
-    const int r = ( it / cb ) << 1, c0 = ( it - ( it / cb ) * cb ) << 3;
+    const int r = ( it >> lcb ) << 1, c0 = ( it & ( cb - 1 ) ) << 3;   // cb is a power of two (TU sizes are)
     int       acc[2][8];
 #pragma unroll
     for( int i = 0; i < 8; i++ ) acc[0][i] = acc[1][i] = rnd;
@@ -631,14 +631,14 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
     if( mw )
       for( int i = threadIdx.x; i < w * w; i += 256 )
       {
-        const int k = i / w, n = i - k * w;
+        const int k = i >> lw, n = i & ( w - 1 );   // w, h: powers of two
         sMat[( ty * 2 + 0 ) * w * w + ( ( k >> 1 ) * w + n ) * 2 + ( k & 1 )] = mw[i];   // (M[k][n], M[k+1][n]) at pair-row k >> 1, column n
         sMat[( ty * 2 + 1 ) * w * w + ( ( n >> 1 ) * w + k ) * 2 + ( n & 1 )] = mw[i];   // (M[k][n], M[k][n+1]) at pair-row n >> 1, column k
       }
     if( mh )
       for( int i = threadIdx.x; i < h * h; i += 256 )
       {
-        const int k = i / h, n = i - k * h;
+        const int k = i >> lh, n = i & ( h - 1 );
         sMat[hBase + ( ty * 2 + 0 ) * h * h + ( ( k >> 1 ) * h + n ) * 2 + ( k & 1 )] = mh[i];
         sMat[hBase + ( ty * 2 + 1 ) * h * h + n * h + k]                              = mh[i];
       }
@@ -656,7 +656,7 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
   const int16_t *resi = resiBase + j.resiOff;
   for( int i = t; i < w * h; i += LPT )
   {
-    const int y = i / w, x = i - y * w;
+    const int y = i >> lw, x = i & ( w - 1 );
     sR[i] = resi[( long ) y * j.resiStride + x];
   }
   int16_t *dq16 = reinterpret_cast<int16_t *>( tmp );   // dequantised coefficients [k][k2] (after the second forward pass has consumed tmp)
@@ -700,7 +700,7 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
         int       v;
         if( rightShift > 0 ) v = ( int ) ( ( unsigned ) ( qq * iscale ) + ( 1u << ( rightShift - 1 ) ) ) >> rightShift;
         else v = ( int ) ( ( unsigned ) ( qq * iscale ) << ( -rightShift ) );
-        dq16[( i % w ) * h + i / w] = ( int16_t ) min( 32767, max( -32768, v ) );   // transposed: the vertical index contiguous
+        dq16[( ( i & ( w - 1 ) ) << lh ) + ( i >> lw )] = ( int16_t ) min( 32767, max( -32768, v ) );   // transposed: the vertical index contiguous
       }
     }
     tuq_sync<LPT>();
@@ -912,6 +912,7 @@ int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const
   if( st ) return st;
   if( uniformSize && maxWidth >= 8 && maxHeight >= 8 )
   {
+    VTMHIP_REQUIRE( ctx, ( maxWidth & ( maxWidth - 1 ) ) == 0 && ( maxHeight & ( maxHeight - 1 ) ) == 0, "uniformSize: width / height must be powers of two (TU sizes are)" );
     // caller's promise: every TU is exactly maxWidth x maxHeight -> register-blocked kernel, LPT lanes per TU
     return launch_tu_uni_sized( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, g_tabs[ctx->device & 15], nullptr );
   }
