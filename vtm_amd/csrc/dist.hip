@@ -183,6 +183,7 @@ __global__ __launch_bounds__( THREADS ) void satd8_grid_kernel( const int16_t *_
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];
   const int nd = 2 * r + 1, nd2 = nd * nd;
+  const unsigned magic1 = 0xffffffffu / ( unsigned ) nd, magic2 = 0xffffffffu / ( unsigned ) nd2;   // uniform: one division each per wave
   const int refW = GRID_TBX * 8 + 2 * r, refH = GRID_TBY * 8 + 2 * r;
   const int refLd = ( refW + 7 ) & ~7;   // keep rows 16-byte aligned
   int16_t  *sOrg = lds;                                   // [TBY*8][TBX*8]
@@ -221,9 +222,15 @@ __global__ __launch_bounds__( THREADS ) void satd8_grid_kernel( const int16_t *_
   const int pairs = GRID_TBX * GRID_TBY * nd2;
   for( int p = threadIdx.x; p < pairs; p += THREADS )
   {
-    const int b = p / nd2, d = p - b * nd2;
+    // p / nd2 and d / nd without the ~25-instruction division sequence: multiply-high by floor((2^32 - 1) / divisor) is the quotient or one less
+    // for these small operands (p * nd2 < 2^32); one correction step makes it exact (also for a divisor of 1)
+    int b = ( int ) __umulhi( ( unsigned ) p, magic2 );
+    b += ( b + 1 ) * nd2 <= p ? 1 : 0;
+    const int d = p - b * nd2;
     const int lby = b / GRID_TBX, lbx = b - lby * GRID_TBX;
-    const int dy = d / nd, dx = d - dy * nd;   // 0..2r
+    int       dy = ( int ) __umulhi( ( unsigned ) d, magic1 );
+    dy += ( dy + 1 ) * nd <= d ? 1 : 0;
+    const int dx = d - dy * nd;   // 0..2r
     if( bx0 + lbx >= bw || by0 + lby >= bh ) continue;
     const int16_t *o = sOrg + lby * 8 * 64 + lbx * 8;
     const int16_t *c = sRef + ( lby * 8 + dy ) * refLd + lbx * 8 + dx;

@@ -505,7 +505,8 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
 #pragma unroll 1
     for( int it = tid; it < nj * items; it += C::BLOCK )
     {
-      const int jl = it / items, rem = it - jl * items, cand = cand0 + rem / C::TILES, tile = rem - ( cand - cand0 ) * C::TILES;
+      const int jl = round == 0 ? it / C::ITEMS : it / ( C::ITEMS - C::TILES );   // constant divisors: multiply-high, not the generic division sequence
+      const int rem = it - jl * items, cand = cand0 + rem / C::TILES, tile = rem - ( cand - cand0 ) * C::TILES;
       const vtmhip_frac_job &j = jobs[job0 + jl];
       const int8_t( *tab )[2] = round == 0 ? c_refineH : c_refineQ;
       const int dx = tab[cand][0], dy = tab[cand][1];

@@ -24,6 +24,19 @@ __constant__ int16_t c_altHpelMc[8] = { 0, 3, 9, 20, 20, 9, 3, 0 };
 
 struct Fir { int shift, offset, clip, cmax; };
 
+// p / d for 0 <= p with p * d < 2^32: multiply-high by floor(2^32 / d) and one correction step (4 instructions) instead of the generic ~25-instruction
+// integer division sequence; the constructor's division is wave-uniform, once per block
+struct FastDiv
+{
+  unsigned magic; int d;
+  __device__ __forceinline__ explicit FastDiv( int dd ) : magic( 0xffffffffu / ( unsigned ) dd ), d( dd ) {}
+  __device__ __forceinline__ int operator()( int p ) const
+  {
+    const int q = ( int ) __umulhi( ( unsigned ) p, magic );
+    return q + ( ( q + 1 ) * d <= p ? 1 : 0 );
+  }
+};
+
 // InterpolationFilter::filter shift/offset rules (:577-602); integer phases use taps {0,0,0,64,0,0,0,0}, which is
 // arithmetically identical to filterCopy (:398-525) for every (isFirst, isLast) pair that occurs here except
 // (first && last), handled as a plain copy.
@@ -77,6 +90,7 @@ __device__ __forceinline__ void mc_block( const vtmhip_mc_job &j, const int16_t 
 {
   constexpr int FB = NT == 8 ? 4 : 5, HALO = NT / 2 - 1;
   const int     w = j.width, h = j.height, bd = j.bitDepth;
+  const FastDiv divW( w );
   const int     xFrac = j.mvHor & ( ( 1 << FB ) - 1 ), yFrac = j.mvVer & ( ( 1 << FB ) - 1 ), rnd = !j.bi;
   const bool    alt = j.useAltHpelIf != 0;
   const int16_t *src = refBase + j.refOff + ( long ) ( j.mvVer >> FB ) * j.refStride + ( j.mvHor >> FB );
@@ -84,14 +98,14 @@ __device__ __forceinline__ void mc_block( const vtmhip_mc_job &j, const int16_t 
   {
     if( xFrac == 0 && rnd )   // filterCopy<true,true>: plain copy
     {
-      for( int i = lane; i < w * h; i += THREADS ) { const int y = i / w, x = i - y * w; out( y, x, src[( long ) y * j.refStride + x] ); }
+      for( int i = lane; i < w * h; i += THREADS ) { const int y = divW( i ), x = i - y * w; out( y, x, src[( long ) y * j.refStride + x] ); }
       return;
     }
     const Fir      f = fir_params( 1, rnd, bd );
     const int16_t *c = NT == 8 ? luma_taps( xFrac, w, h, h, alt ) : c_chromaFilterMc[xFrac];
     for( int i = lane; i < w * h; i += THREADS )
     {
-      const int y = i / w, x = i - y * w;
+      const int y = divW( i ), x = i - y * w;
       int       sum = 0;
 #pragma unroll
       for( int k = 0; k < NT; k++ ) sum += ( int ) src[( long ) y * j.refStride + x + k - HALO] * ( int ) c[k];
@@ -104,7 +118,7 @@ __device__ __forceinline__ void mc_block( const vtmhip_mc_job &j, const int16_t 
     const int16_t *c = NT == 8 ? luma_taps( yFrac, w, h, h, alt ) : c_chromaFilterMc[yFrac];
     for( int i = lane; i < w * h; i += THREADS )
     {
-      const int y = i / w, x = i - y * w;
+      const int y = divW( i ), x = i - y * w;
       int       sum = 0;
 #pragma unroll
       for( int k = 0; k < NT; k++ ) sum += ( int ) src[( long ) ( y + k - HALO ) * j.refStride + x] * ( int ) c[k];
@@ -118,7 +132,7 @@ __device__ __forceinline__ void mc_block( const vtmhip_mc_job &j, const int16_t 
     const int16_t *cv = NT == 8 ? luma_taps( yFrac, w, h, h, alt ) : c_chromaFilterMc[yFrac];
     for( int i = lane; i < w * ( h + NT - 1 ); i += THREADS )
     {
-      const int r = i / w, x = i - r * w;
+      const int r = divW( i ), x = i - r * w;
       int       sum = 0;
 #pragma unroll
       for( int k = 0; k < NT; k++ ) sum += ( int ) src[( long ) ( r - HALO ) * j.refStride + x + k - HALO] * ( int ) ch[k];
@@ -127,7 +141,7 @@ __device__ __forceinline__ void mc_block( const vtmhip_mc_job &j, const int16_t 
     block_sync<THREADS>();
     for( int i = lane; i < w * h; i += THREADS )
     {
-      const int y = i / w, x = i - y * w;
+      const int y = divW( i ), x = i - y * w;
       int       sum = 0;
 #pragma unroll
       for( int k = 0; k < NT; k++ ) sum += ( int ) lds[( y + k ) * w + x] * ( int ) cv[k];
@@ -182,6 +196,7 @@ __device__ __forceinline__ void mc_block_vec( const vtmhip_mc_job &j, const int1
 {
   constexpr int FB = NT == 8 ? 4 : 5, HALO = NT / 2 - 1;
   const int     w = j.width, h = j.height, bd = j.bitDepth, segs = w >> 3;
+  const FastDiv divS( segs );
   const int     xFrac = j.mvHor & ( ( 1 << FB ) - 1 ), yFrac = j.mvVer & ( ( 1 << FB ) - 1 ), rnd = !j.bi;
   const bool    alt = j.useAltHpelIf != 0;
   const int16_t *src = refBase + j.refOff + ( long ) ( j.mvVer >> FB ) * j.refStride + ( j.mvHor >> FB );
@@ -189,7 +204,7 @@ __device__ __forceinline__ void mc_block_vec( const vtmhip_mc_job &j, const int1
   {
     for( int i = lane; i < segs * h; i += THREADS )
     {
-      const int   y = i / segs, x0 = ( i - y * segs ) << 3;
+      const int   y = divS( i ), x0 = ( i - y * segs ) << 3;
       int a[8];
       load8g( src + ( long ) y * j.refStride + x0, a );
       out.vec( y, x0, a );
@@ -205,7 +220,7 @@ __device__ __forceinline__ void mc_block_vec( const vtmhip_mc_job &j, const int1
     for( int t = 0; t < NT; t++ ) cc[t] = c[t];
     for( int i = lane; i < segs * h; i += THREADS )
     {
-      const int y = i / segs, x0 = ( i - y * segs ) << 3;
+      const int y = divS( i ), x0 = ( i - y * segs ) << 3;
       int       a[16];
       load16( src + ( long ) y * j.refStride + x0 - HALO, a );
       int v[8];
@@ -235,7 +250,7 @@ __device__ __forceinline__ void mc_block_vec( const vtmhip_mc_job &j, const int1
     for( int t = 0; t < NT; t++ ) ch[t] = chp[t];
     for( int i = lane; i < segs * ( h + NT - 1 ); i += THREADS )
     {
-      const int r = i / segs, x0 = ( i - r * segs ) << 3;
+      const int r = divS( i ), x0 = ( i - r * segs ) << 3;
       int       a[16];
       load16( src + ( long ) ( r - HALO ) * j.refStride + x0 - HALO, a );
       int v[8];
@@ -254,7 +269,7 @@ __device__ __forceinline__ void mc_block_vec( const vtmhip_mc_job &j, const int1
   const Fir fv = fir_params( twoPass ? 0 : 1, rnd, bd );
   for( int i = lane; i < segs * h; i += THREADS )
   {
-    const int y = i / segs, x0 = ( i - y * segs ) << 3;
+    const int y = divS( i ), x0 = ( i - y * segs ) << 3;
     int       sum[8];
 #pragma unroll
     for( int k = 0; k < 8; k++ ) sum[k] = 0;

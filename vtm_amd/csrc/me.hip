@@ -624,7 +624,7 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel(
   j.verMax    = ( pic.picH + 8 - jp->puY - 1 ) << 4;
   j.verMin    = ( -pic.ctuSize - 8 - jp->puY + 1 ) << 4;
   j.seg        = ( j.w & 7 ) == 0 ? 8 : 4;
-  j.segsPerRow = j.w / j.seg;
+  j.segsPerRow = j.seg == 8 ? j.w >> 3 : j.w >> 2;
   j.items      = j.segsPerRow * ( ( j.h + ( 1 << j.ss ) - 1 ) >> j.ss );
   j.lpc        = 1;
   while( j.lpc < 64 && ( j.lpc << 1 ) <= j.items ) j.lpc <<= 1;
@@ -827,7 +827,7 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void full_search_kerne
   j.verMax = ( pic.picH + 8 - jp->puY - 1 ) << 4;
   j.verMin = ( -pic.ctuSize - 8 - jp->puY + 1 ) << 4;
   j.seg        = ( j.w & 7 ) == 0 ? 8 : 4;
-  j.segsPerRow = j.w / j.seg;
+  j.segsPerRow = j.seg == 8 ? j.w >> 3 : j.w >> 2;
   j.items      = j.segsPerRow * ( ( j.h + ( 1 << j.ss ) - 1 ) >> j.ss );
   j.lpc        = 1;
   while( j.lpc < 64 && ( j.lpc << 1 ) <= j.items ) j.lpc <<= 1;
