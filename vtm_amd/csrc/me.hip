@@ -896,8 +896,8 @@ __global__ __launch_bounds__( FullSq<S>::THREADS ) void full_search_sq_kernel( v
 {
   constexpr int JPB = FullSq<S>::JPB, THREADS = FullSq<S>::THREADS, WLD = S + 8, WD = WLD / 2 + 1, MAXC = 81;
   __shared__ unsigned           sWin[JPB][WLD][WD];     // reference window, two samples per dword, one spare dword per row
-  __shared__ unsigned           sOrg[JPB][S][S / 2];
-  __shared__ int                sRange[JPB][4];          // left, top, nx, ny
+  __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned sOrg[JPB][S][S / 2];
+  __shared__ int                sRange[JPB][5];          // left, top, nx, ny, floor((2^32 - 1) / nx)
   __shared__ unsigned long long sBest[JPB];
   __shared__ unsigned           sIdx[JPB];
   const int tid  = threadIdx.x;
@@ -922,6 +922,7 @@ __global__ __launch_bounds__( FullSq<S>::THREADS ) void full_search_sq_kernel( v
     if( nx > 9 || ny > 9 || q.width != S || q.height != S ) nx = ny = 0;   // the caller's promise is broken: no candidates, cost stays ~0 (never touch memory outside the window)
     sRange[tid][2] = nx;
     sRange[tid][3] = ny;
+    sRange[tid][4] = ( int ) ( 0xffffffffu / ( unsigned ) max( nx, 1 ) );   // one division per job instead of one per candidate
     sBest[tid] = ~0ull; sIdx[tid] = 0xffffffffu;
   }
   __syncthreads();
@@ -966,7 +967,9 @@ __global__ __launch_bounds__( FullSq<S>::THREADS ) void full_search_sq_kernel( v
       {
         const vtmhip_full_job &q = jobs[job0 + jl];
         view( q );
-        const int cy = k / nx, cx = k - cy * nx;
+        int cy = ( int ) __umulhi( ( unsigned ) k, ( unsigned ) sRange[jl][4] );   // k / nx: the multiply-high is the quotient or one less (k < 81)
+        cy += ( cy + 1 ) * nx <= k ? 1 : 0;
+        const int      cx = k - cy * nx;
         const unsigned sh = ( unsigned ) ( cx & 1 ) << 4;
         unsigned       s = 0;
         const int      step = 1 << j.ss;
