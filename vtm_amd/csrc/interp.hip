@@ -409,7 +409,9 @@ struct FracSq
   static constexpr int WLD   = S + 8;                           // window stride
   static constexpr int WIN   = ( S + 8 ) * WLD;                 // window samples per PU
   static constexpr int PLANE = ( S + 8 ) * S;                   // one H-pass plane
-  static constexpr int PERJOB = ( ( WIN + 3 * PLANE ) + 7 ) & ~7;   // samples, keeps every plane 16-byte aligned
+  static constexpr bool SEQ  = S == 128;                        // one plane buffer, the three planes one after the other: 72 KB instead of 141 KB of LDS -> two workgroups per CU
+  static constexpr int NPL   = SEQ ? 1 : 3;
+  static constexpr int PERJOB = ( ( WIN + NPL * PLANE ) + 7 ) & ~7;   // samples, keeps every plane 16-byte aligned
   static constexpr size_t LDS = ( size_t ) JPW * PERJOB * sizeof( int16_t ) + ( size_t ) JPW * 16 * sizeof( unsigned );
 };
 
@@ -447,13 +449,19 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
   {
     const int step = round == 0 ? 2 : 1;
     if( round == 1 && jobs[job0].imvShift != 0 ) break;   // IMV_HPEL: half-sample refinement only (uniform per batch, checked on the host side)
+    // round 2: candidate 0 is the half-sample winner itself -- the block round 1 already measured -- so only 8 candidates are formed
+    for( int i = tid; i < C::JPW * 16; i += C::BLOCK ) sCost[i] = ( round == 1 && ( i & 15 ) == 0 ) ? sKeep[i >> 4] : 0u;
+#pragma unroll 1
+    for( int seqPl = 0; seqPl < ( C::SEQ ? 3 : 1 ); seqPl++ )   // SEQ: plane by plane through ONE buffer; otherwise a single trip over all three
+    {
     // ---- phase H: plane p (dx = p - 1) of PU jl: (first, !last) 8-tap FIR of window rows 0..S+7; 8 outputs per thread and step ----
     {
-      constexpr int CH = S / 8;
-      for( int i = tid; i < nj * 3 * ( S + 8 ) * CH; i += C::BLOCK )
+      constexpr int CH = S / 8, NP = C::NPL;
+      for( int i = tid; i < nj * NP * ( S + 8 ) * CH; i += C::BLOCK )
       {
-        const int jl = i / ( 3 * ( S + 8 ) * CH ), rem = i - jl * 3 * ( S + 8 ) * CH;
-        const int p = rem / ( ( S + 8 ) * CH ), o = rem - p * ( S + 8 ) * CH, r = o / CH, x0 = ( o - r * CH ) * 8;
+        const int jl = i / ( NP * ( S + 8 ) * CH ), rem = i - jl * NP * ( S + 8 ) * CH;
+        const int pp = rem / ( ( S + 8 ) * CH ), o = rem - pp * ( S + 8 ) * CH, r = o / CH, x0 = ( o - r * CH ) * 8;
+        const int p = C::SEQ ? seqPl : pp;
         const vtmhip_frac_job &j = jobs[job0 + jl];
         const int qx = sCentre[jl][0] + ( p - 1 ) * step, ix = qx >> 2, fx = qx & 3;
         const int16_t *cH = ( round == 0 && j.useAltHpelIf && fx == 2 ) ? c_lumaAltHpel : c_lumaFilter[fx << 2];
@@ -493,20 +501,21 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
           const unsigned hv = ( unsigned ) ( unsigned short ) if_finish( sum, pH );
           if( q & 1 ) outw[q >> 1] |= hv << 16; else outw[q >> 1] = hv;
         }
-        *reinterpret_cast<int4 *>( lds + jl * C::PERJOB + C::WIN + p * C::PLANE + r * S + x0 ) = make_int4( ( int ) outw[0], ( int ) outw[1], ( int ) outw[2], ( int ) outw[3] );
+        *reinterpret_cast<int4 *>( lds + jl * C::PERJOB + C::WIN + pp * C::PLANE + r * S + x0 ) = make_int4( ( int ) outw[0], ( int ) outw[1], ( int ) outw[2], ( int ) outw[3] );
       }
     }
-    // round 2: candidate 0 is the half-sample winner itself -- the block round 1 already measured -- so only 8 candidates are formed
-    for( int i = tid; i < C::JPW * 16; i += C::BLOCK ) sCost[i] = ( round == 1 && ( i & 15 ) == 0 ) ? sKeep[i >> 4] : 0u;
     __syncthreads();
 
     // ---- phase V: one (PU, candidate, tile) item per lane ------------------------------------------------------------------
-    const int items = round == 0 ? C::ITEMS : C::ITEMS - C::TILES, cand0 = round;
+    // SEQ: the candidates whose plane is in the buffer -- dx = -1: table entries 3, 5, 7; dx = 0: 0, 1, 2 (entry 0 only in the half-sample round); dx = +1: 4, 6, 8
+    const int seqSkip = ( C::SEQ && round == 1 && seqPl == 1 ) ? 1 : 0, seqN = 3 - seqSkip;
+    const int items = C::SEQ ? seqN * C::TILES : ( round == 0 ? C::ITEMS : C::ITEMS - C::TILES ), cand0 = round;
 #pragma unroll 1
     for( int it = tid; it < nj * items; it += C::BLOCK )
     {
-      const int jl = round == 0 ? it / C::ITEMS : it / ( C::ITEMS - C::TILES );   // constant divisors: multiply-high, not the generic division sequence
-      const int rem = it - jl * items, cand = cand0 + rem / C::TILES, tile = rem - ( cand - cand0 ) * C::TILES;
+      const int jl = C::SEQ ? 0 : ( round == 0 ? it / C::ITEMS : it / ( C::ITEMS - C::TILES ) );   // constant divisors: multiply-high, not the generic division sequence (SEQ: one PU per workgroup)
+      const int rem = it - jl * items, ci = rem / C::TILES, tile = rem - ci * C::TILES;
+      const int cand = C::SEQ ? ( seqPl == 1 ? ci + seqSkip : 3 + 2 * ci + ( seqPl >> 1 ) ) : cand0 + ci;
       const vtmhip_frac_job &j = jobs[job0 + jl];
       const int8_t( *tab )[2] = round == 0 ? c_refineH : c_refineQ;
       const int dx = tab[cand][0], dy = tab[cand][1];
@@ -516,7 +525,7 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
 #pragma unroll
       for( int k = 0; k < 8; k++ ) cv[k] = cV[k];
       const int      ty = tile / ( S / 8 ), tx = tile - ty * ( S / 8 );
-      const int16_t *pl = lds + jl * C::PERJOB + C::WIN + ( dx + 1 ) * C::PLANE + ( ty * 8 + iy + 1 ) * S + tx * 8;
+      const int16_t *pl = lds + jl * C::PERJOB + C::WIN + ( C::SEQ ? 0 : dx + 1 ) * C::PLANE + ( ty * 8 + iy + 1 ) * S + tx * 8;
       const IfParams pV = if_params( 0, 1, j.bitDepth, 0, ( 1 << j.bitDepth ) - 1, 0 );
       // Vertical FIR with v_dot2c_i32_i16: rows r and r + 1 are interleaved column-wise (two v_perm per dword pair), so one instruction
       // applies two taps: output row y takes the row pairs (y, y+1), (y+2, y+3), (y+4, y+5), (y+6, y+7) with the tap pairs
@@ -632,6 +641,7 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
       atomicAdd( &sCost[jl * 16 + cand], d );
     }
     __syncthreads();
+    }   // planes
 
     // ---- select: first strict minimum of distortion + MV rate in table order ------------------------------------------------
     if( tid < nj )
