@@ -405,7 +405,7 @@ struct FracSq
   static constexpr int ITEMS = 9 * TILES;                       // per PU per round
   static constexpr int BLOCK = S == 32 ? 192 : 256;
   static constexpr int MINW  = 4;                                // waves per SIMD the register budget is sized for (128 VGPRs; the dot-product V pass fits every size)
-  static constexpr int JPW   = ITEMS >= BLOCK ? 1 : BLOCK / ITEMS;   // S = 8: 28, 16: 7, 32: 1 (144 of 192 lanes), 64 / 128: 1
+  static constexpr int JPW   = S == 32 ? 4 : ITEMS >= BLOCK ? 1 : BLOCK / ITEMS;   // S = 8: 28, 16: 7, 32: 4 (4 x 144 items = 3 full trips of 192 lanes), 64 / 128: 1
   static constexpr int WLD   = S + 8;                           // window stride
   static constexpr int WIN   = ( S + 8 ) * WLD;                 // window samples per PU
   static constexpr int PLANE = ( S + 8 ) * S;                   // one H-pass plane
