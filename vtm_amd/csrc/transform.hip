@@ -619,10 +619,11 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
   __shared__ long long sRed[4][3];
   constexpr int TUS = 256 / LPT;
   const int     sub = threadIdx.x / LPT, t = threadIdx.x - sub * LPT;
-  const int     perTu = w * h + w * ( h + 1 ) + ( ( w * h + 1 ) >> 1 );   // ints: blk, tmp, residual copy
+  const int     perTu = w * h + w * ( h + 1 );   // ints: blk, tmp (the 16-bit residual copy lives in blk until the second forward pass overwrites it)
   int16_t      *sMat = ( int16_t * ) ( ldsw + TUS * perTu );              // [dim][type][orientation][N*N]
   const int     lw = ilog2( w ), lh = ilog2( h );
   const int     hBase = ( w > 32 ? 2 : 6 ) * w * w;   // only DCT-2 exists above 32: one matrix pair instead of three
+  const bool    sq    = w == h;                       // square TUs: the height's slot 0 IS the width's slot 0, only the plain transposes are stored for the height
   for( int ty = 0; ty < 3; ty++ )
   {
     const int16_t *mw = ( ty == 0 || w <= 32 ) ? tabs.m[ty][lw] : nullptr, *mh = ( ty == 0 || h <= 32 ) ? tabs.m[ty][lh] : nullptr;   // DST-7 / DCT-8 exist up to 32
@@ -639,8 +640,8 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
       for( int i = threadIdx.x; i < h * h; i += 256 )
       {
         const int k = i >> lh, n = i & ( h - 1 );
-        sMat[hBase + ( ty * 2 + 0 ) * h * h + ( ( k >> 1 ) * h + n ) * 2 + ( k & 1 )] = mh[i];
-        sMat[hBase + ( ty * 2 + 1 ) * h * h + n * h + k]                              = mh[i];
+        if( !sq ) sMat[hBase + ( ty * 2 + 0 ) * h * h + ( ( k >> 1 ) * h + n ) * 2 + ( k & 1 )] = mh[i];
+        sMat[hBase + ( sq ? ty : ty * 2 + 1 ) * h * h + n * h + k] = mh[i];
       }
   }
   __syncthreads();
@@ -651,8 +652,10 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
   else { j = jobs[numJobs - 1]; }
   const int      bd = j.bitDepth;
   int           *blk = ldsw + sub * perTu, *tmp = blk + w * h;
-  int16_t       *sR  = ( int16_t * ) ( tmp + w * ( h + 1 ) );
-  const int16_t *mW = sMat + ( j.typeHor * 2 ) * w * w, *mH = sMat + hBase + ( j.typeVer * 2 ) * h * h;
+  int16_t       *sR  = ( int16_t * ) blk;
+  const int16_t *mW = sMat + ( j.typeHor * 2 ) * w * w;
+  const int16_t *mH0 = sq ? sMat + ( j.typeVer * 2 ) * w * w : sMat + hBase + ( j.typeVer * 2 ) * h * h;          // M_H, rows k, k+1 interleaved
+  const int16_t *mH1 = sMat + hBase + ( sq ? j.typeVer : j.typeVer * 2 + 1 ) * h * h;                            // M_H^T plain
   const int16_t *resi = resiBase + j.resiOff;
   for( int i = t; i < w * h; i += LPT )
   {
@@ -668,7 +671,7 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
   // forward (TrQuant::xT): tmp[k][y] = sum_n blk[y][n] * MT_hor[n][k];  blk[k2][j2] = sum_n tmp[j2][n] * MT_ver[n][k2]
   tuq_pass16<LPT, false>( sR, w, reinterpret_cast<const unsigned *>( mW + w * w ), w, h, w, h, w - skipW, tmp, 1, h + 1, lw + bd + 6 - 15, t );
   tuq_sync<LPT>();
-  tuq_pass<LPT, false>( tmp, h + 1, 1, mH + h * h, h, h, w, h, w - skipW, h - skipH, blk, 1, w, lh + 6, t, &sumAbs );
+  tuq_pass<LPT, false>( tmp, h + 1, 1, mH1, h, h, w, h, w - skipW, h - skipH, blk, 1, w, lh + 6, t, &sumAbs );
   tuq_sync<LPT>();
   if( fwdCoefBase )
   {
@@ -705,7 +708,7 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
     }
     tuq_sync<LPT>();
     // inverse (TrQuant::xIT): tmp[i][y] = clip( sum_k blk[k][i] * M_ver[k][y] );  rec[y][x] = clip( sum_k tmp[k][y] * M_hor[k][x] )
-    tuq_pass16<LPT, true>( dq16, h, reinterpret_cast<const unsigned *>( mH ), h - skipH, w, h, w - skipW, h, t16, 1, w, 7, t );
+    tuq_pass16<LPT, true>( dq16, h, reinterpret_cast<const unsigned *>( mH0 ), h - skipH, w, h, w - skipW, h, t16, 1, w, 7, t );
     tuq_sync<LPT>();
     tuq_pass16<LPT, true>( t16, w, reinterpret_cast<const unsigned *>( mW ), w - skipW, h, w, h, w, rec32, w, 1, 20 - bd, t );
     tuq_sync<LPT>();
@@ -715,7 +718,7 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
       {
         const int v = rec32[i];
         if( rec ) rec[i] = ( int16_t ) v;
-        const int d = ( int ) sR[i] - v;
+        const int d = ( int ) resi[( long ) ( i >> lw ) * j.resiStride + ( i & ( w - 1 ) )] - v;   // the residual again, from L2: its LDS copy made room for a third workgroup per CU
         sse += ( long long ) ( unsigned long long ) ( ( unsigned ) d * ( unsigned ) d );
       }
     }
@@ -758,8 +761,8 @@ int launch_tu_uni( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_j
                    vtmhip_tu_result *d_results, const TrTables &tabs, int32_t *d_fwdCoefBase = nullptr )
 {
   constexpr int TUS   = 256 / LPT;
-  const size_t  perTu = ( size_t ) w * h + ( size_t ) w * ( h + 1 ) + ( ( w * h + 1 ) >> 1 );
-  const size_t  lds   = TUS * perTu * sizeof( int ) + ( ( size_t ) ( w > 32 ? 2 : 6 ) * w * w + ( size_t ) ( h > 32 ? 2 : 6 ) * h * h ) * sizeof( int16_t );
+  const size_t  perTu = ( size_t ) w * h + ( size_t ) w * ( h + 1 );
+  const size_t  lds   = TUS * perTu * sizeof( int ) + ( ( size_t ) ( w > 32 ? 2 : 6 ) * w * w + ( size_t ) ( h > 32 ? 2 : 6 ) * h * h / ( w == h ? 2 : 1 ) ) * sizeof( int16_t );
   if( lds > 64 * 1024 )
     VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( tu_chain_uni_kernel<LPT> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
   hipLaunchKernelGGL( tu_chain_uni_kernel<LPT>, dim3( ( n + TUS - 1 ) / TUS ), dim3( 256 ), lds, ctx->stream, d_resiBase, d_jobs, n, tabs, d_levelsBase, d_recBase,
