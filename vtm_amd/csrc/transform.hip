@@ -561,6 +561,50 @@ __device__ __forceinline__ void tuq_pass( const int *A, int aRowStride, int aCol
   }
 }
 
+// tuq_pass with the matrix in the pair-interleaved layout of tuq_pass16 (Bp[(n >> 1) * cols + c] = (B[n][c], B[n+1][c])): square TUs take the second
+// forward pass's M^T from the slot the first one uses, so no plain copy is staged.  Two summation steps per trip; same loads per step as tuq_pass.
+template<int LPT, bool CLIP>
+__device__ __forceinline__ void tuq_pass_il( const int *A, int aRowStride, int aColStride, const unsigned *Bp, int inner, int rows, int cols, int rEff, int cEff,
+                                             int *out, int oRowStride, int oColStride, int shift, int t, long long *sumAbs )
+{
+  const int cb = cols >> 3, lcb = 31 - __clz( cb ), rnd = shift > 0 ? 1 << ( shift - 1 ) : 0;
+  for( int it = t; it < ( rows >> 1 ) * cb; it += LPT )
+  {
+    const int r = ( it >> lcb ) << 1, c0 = ( it & ( cb - 1 ) ) << 3;
+    int       acc[2][8];
+#pragma unroll
+    for( int i = 0; i < 8; i++ ) acc[0][i] = acc[1][i] = rnd;
+    if( r < rEff && c0 < cEff )
+    {
+      const int *a0 = A + r * aRowStride, *a1 = a0 + aRowStride;
+      for( int n2 = 0; n2 < ( inner >> 1 ); n2++ )
+      {
+        const int   n = n2 << 1;
+        const int   e0 = a0[n * aColStride], o0 = a0[( n + 1 ) * aColStride], e1 = a1[n * aColStride], o1 = a1[( n + 1 ) * aColStride];
+        const uint4 b0 = *reinterpret_cast<const uint4 *>( Bp + n2 * cols + c0 ), b1 = *reinterpret_cast<const uint4 *>( Bp + n2 * cols + c0 + 4 );
+        const unsigned bw[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+#pragma unroll
+        for( int i = 0; i < 8; i++ )
+        {
+          const int be = ( int ) ( short ) bw[i], bo = ( int ) bw[i] >> 16;
+          acc[0][i] += __mul24( e0, be ) + __mul24( o0, bo );
+          acc[1][i] += __mul24( e1, be ) + __mul24( o1, bo );
+        }
+      }
+    }
+#pragma unroll
+    for( int q = 0; q < 2; q++ )
+#pragma unroll
+      for( int i = 0; i < 8; i++ )
+      {
+        int v = ( r + q < rEff && c0 + i < cEff ) ? acc[q][i] >> shift : 0;
+        if( CLIP ) v = min( 32767, max( -32768, v ) );
+        out[( r + q ) * oRowStride + ( c0 + i ) * oColStride] = v;
+        if( sumAbs ) *sumAbs += abs( v );
+      }
+  }
+}
+
 // The same product when every A value fits 16 bits (residuals; dequantised coefficients and the first inverse pass are clipped to
 // 16 bits): v_dot2c_i32_i16 takes two summation steps per instruction.  A: int16, the summation index contiguous (rows of
 // aRowStride samples, even); Bp: the matrix with rows n, n + 1 interleaved per column -- Bp[(n >> 1) * cols + c] = (B[n][c], B[n+1][c]).
@@ -623,7 +667,7 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
   int16_t      *sMat = ( int16_t * ) ( ldsw + TUS * perTu );              // [dim][type][orientation][N*N]
   const int     lw = ilog2( w ), lh = ilog2( h );
   const int     hBase = ( w > 32 ? 2 : 6 ) * w * w;   // only DCT-2 exists above 32: one matrix pair instead of three
-  const bool    sq    = w == h;                       // square TUs: the height's slot 0 IS the width's slot 0, only the plain transposes are stored for the height
+  const bool    sq    = w == h;                       // square TUs: both height matrices ARE the width's slots (tuq_pass_il reads the interleaved transpose)
   for( int ty = 0; ty < 3; ty++ )
   {
     const int16_t *mw = ( ty == 0 || w <= 32 ) ? tabs.m[ty][lw] : nullptr, *mh = ( ty == 0 || h <= 32 ) ? tabs.m[ty][lh] : nullptr;   // DST-7 / DCT-8 exist up to 32
@@ -636,12 +680,12 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
         sMat[( ty * 2 + 0 ) * w * w + ( ( k >> 1 ) * w + n ) * 2 + ( k & 1 )] = mw[i];   // (M[k][n], M[k+1][n]) at pair-row k >> 1, column n
         sMat[( ty * 2 + 1 ) * w * w + ( ( n >> 1 ) * w + k ) * 2 + ( n & 1 )] = mw[i];   // (M[k][n], M[k][n+1]) at pair-row n >> 1, column k
       }
-    if( mh )
+    if( mh && !sq )
       for( int i = threadIdx.x; i < h * h; i += 256 )
       {
         const int k = i >> lh, n = i & ( h - 1 );
-        if( !sq ) sMat[hBase + ( ty * 2 + 0 ) * h * h + ( ( k >> 1 ) * h + n ) * 2 + ( k & 1 )] = mh[i];
-        sMat[hBase + ( sq ? ty : ty * 2 + 1 ) * h * h + n * h + k] = mh[i];
+        sMat[hBase + ( ty * 2 + 0 ) * h * h + ( ( k >> 1 ) * h + n ) * 2 + ( k & 1 )] = mh[i];
+        sMat[hBase + ( ty * 2 + 1 ) * h * h + n * h + k]                              = mh[i];
       }
   }
   __syncthreads();
@@ -655,7 +699,7 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
   int16_t       *sR  = ( int16_t * ) blk;
   const int16_t *mW = sMat + ( j.typeHor * 2 ) * w * w;
   const int16_t *mH0 = sq ? sMat + ( j.typeVer * 2 ) * w * w : sMat + hBase + ( j.typeVer * 2 ) * h * h;          // M_H, rows k, k+1 interleaved
-  const int16_t *mH1 = sMat + hBase + ( sq ? j.typeVer : j.typeVer * 2 + 1 ) * h * h;                            // M_H^T plain
+  const int16_t *mH1 = sq ? sMat + ( j.typeVer * 2 + 1 ) * w * w : sMat + hBase + ( j.typeVer * 2 + 1 ) * h * h;   // M_H^T: pair-interleaved (square) / plain
   const int16_t *resi = resiBase + j.resiOff;
   for( int i = t; i < w * h; i += LPT )
   {
@@ -671,7 +715,8 @@ __global__ __launch_bounds__( 256 ) void tu_chain_uni_kernel( const int16_t *__r
   // forward (TrQuant::xT): tmp[k][y] = sum_n blk[y][n] * MT_hor[n][k];  blk[k2][j2] = sum_n tmp[j2][n] * MT_ver[n][k2]
   tuq_pass16<LPT, false>( sR, w, reinterpret_cast<const unsigned *>( mW + w * w ), w, h, w, h, w - skipW, tmp, 1, h + 1, lw + bd + 6 - 15, t );
   tuq_sync<LPT>();
-  tuq_pass<LPT, false>( tmp, h + 1, 1, mH1, h, h, w, h, w - skipW, h - skipH, blk, 1, w, lh + 6, t, &sumAbs );
+  if( sq ) tuq_pass_il<LPT, false>( tmp, h + 1, 1, reinterpret_cast<const unsigned *>( mH1 ), h, w, h, w - skipW, h - skipH, blk, 1, w, lh + 6, t, &sumAbs );
+  else tuq_pass<LPT, false>( tmp, h + 1, 1, mH1, h, h, w, h, w - skipW, h - skipH, blk, 1, w, lh + 6, t, &sumAbs );
   tuq_sync<LPT>();
   if( fwdCoefBase )
   {
@@ -762,7 +807,7 @@ int launch_tu_uni( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_j
 {
   constexpr int TUS   = 256 / LPT;
   const size_t  perTu = ( size_t ) w * h + ( size_t ) w * ( h + 1 );
-  const size_t  lds   = TUS * perTu * sizeof( int ) + ( ( size_t ) ( w > 32 ? 2 : 6 ) * w * w + ( size_t ) ( h > 32 ? 2 : 6 ) * h * h / ( w == h ? 2 : 1 ) ) * sizeof( int16_t );
+  const size_t  lds   = TUS * perTu * sizeof( int ) + ( ( size_t ) ( w > 32 ? 2 : 6 ) * w * w + ( w == h ? 0 : ( size_t ) ( h > 32 ? 2 : 6 ) * h * h ) ) * sizeof( int16_t );
   if( lds > 64 * 1024 )
     VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( tu_chain_uni_kernel<LPT> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
   hipLaunchKernelGGL( tu_chain_uni_kernel<LPT>, dim3( ( n + TUS - 1 ) / TUS ), dim3( 256 ), lds, ctx->stream, d_resiBase, d_jobs, n, tabs, d_levelsBase, d_recBase,
