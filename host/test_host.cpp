@@ -40,6 +40,11 @@ int main()
         if( dp.distFunc( dp ) != vo_satd( org.data(), w + 5, cur.data(), w + 9, w, h ) ) { fails++; printf( "HAD %dx%d\n", w, h ); }
         checks++;
         if( rd.getDistPart( o, CPelBuf( cur.data(), w + 9, w, h ), 10, COMPONENT_Y, DF_SSE ) != vo_sse( org.data(), w + 5, cur.data(), w + 9, w, h ) ) { fails++; printf( "SSE %dx%d\n", w, h ); }
+        // chroma: the fp64 distortion weight of the slice (RdCost.cpp:448-451; set per slice from the chroma QP offset, EncSlice.cpp:580-600)
+        const double cw = 0.5 + ( rng() % 4000 ) / 1000.0;
+        rd.setDistortionWeight( COMPONENT_Cb, cw );
+        checks++;
+        if( rd.getDistPart( o, CPelBuf( cur.data(), w + 9, w, h ), 10, COMPONENT_Cb, DF_SSE ) != ( Distortion ) ( cw * vo_sse( org.data(), w + 5, cur.data(), w + 9, w, h ) ) ) { fails++; printf( "chroma SSE %dx%d\n", w, h ); }
       }
     // guards behave like the reference's trampoline contract
     {

@@ -80,6 +80,7 @@ class RdCost
 {
   static FpDistFunc *table() { static FpDistFunc t[DF_TOTAL_FUNCTIONS] = {}; return t; }
   double m_motionLambda = 0;
+  double m_distortionWeight[MAX_NUM_COMPONENT] = { 1.0, 1.0, 1.0 };   // RdCost.h:117 (only chroma is weighted)
   int    m_iCostScale   = 0;
   int    m_predHor = 0, m_predVer = 0;
 
@@ -171,13 +172,15 @@ public:
     rcDP.step = 1; rcDP.subShift = 0; rcDP.maximumDistortionForEarlyExit = std::numeric_limits<Distortion>::max();
     rcDP.distFunc = table()[DF_SAD_WITH_MASK];
   }
-  // RdCost::getDistPart (RdCost.cpp:411-455), luma (the chroma distortion weight is host arithmetic on the result)
+  // RdCost::getDistPart (RdCost.cpp:411-455): a chroma distortion is scaled by m_distortionWeight[compID] in fp64 and truncated (:448-451)
+  void setDistortionWeight( ComponentID compID, double w ) { m_distortionWeight[compID] = w; }   // RdCost.h:151
   Distortion getDistPart( const CPelBuf &org, const CPelBuf &cur, int bitDepth, ComponentID compID, DFunc eDFunc )
   {
     DistParam dp;
     dp.org = org; dp.cur = cur; dp.step = 1; dp.bitDepth = bitDepth; dp.compID = compID;
     const bool p2 = ( org.width & ( org.width - 1 ) ) == 0;
     dp.distFunc = table()[eDFunc + ( p2 ? floorLog2( org.width ) : 0 )];
+    if( compID != COMPONENT_Y ) return ( Distortion ) ( m_distortionWeight[compID] * dp.distFunc( dp ) );
     return dp.distFunc( dp );
   }
   // motion cost (RdCost.h:186-190, 301-315)

@@ -25,6 +25,10 @@
  * Types: Pel = int16_t, TCoeff = int32_t, Distortion = uint64_t (CommonLib/TypeDef.h:259-270).
  * Every function returns VTMHIP_OK (0) or a negative VTMHIP_E_* code and never throws; a C++ trampoline turns a
  * non-zero status into the reference's THROW (TypeDef.h:1065-1081).
+ *
+ * Threading: a context is NOT re-entrant.  It owns one staging area (pointer surface), one workspace and one "current stream"; use one
+ * context per host thread (per encoder stack, as the reference keeps one RdCost / InterSearch / TrQuant per thread) and, in a multi-GPU
+ * process, one per device.  Every entry point makes the context's device the calling thread's current HIP device.
  */
 #ifndef VTMHIP_H
 #define VTMHIP_H
@@ -49,7 +53,8 @@ enum
 };
 
 enum { VTMHIP_DIST_SAD = 0, VTMHIP_DIST_SATD = 1, VTMHIP_DIST_SSE = 2 };
-enum { VTMHIP_DCT2 = 0, VTMHIP_DCT8 = 1, VTMHIP_DST7 = 2 };   /* TransType, CommonLib/TypeDef.h */
+enum { VTMHIP_DCT2 = 0, VTMHIP_DCT8 = 1, VTMHIP_DST7 = 2,      /* TransType, CommonLib/TypeDef.h */
+       VTMHIP_TRSKIP = 3 };                                    /* fused chain only: the MTS_SKIP candidate (xTransformSkip / xITransformSkip, no transform) */
 
 typedef struct vtmhip_ctx vtmhip_ctx;
 
@@ -134,6 +139,10 @@ int vtmhip_lfnst_batch_dev( vtmhip_ctx *ctx, const int32_t *d_srcBase, int32_t *
 int vtmhip_tr_matrix_host( int type, int n, int16_t *out );
 /* MTS candidate pre-selection thresholds of TrQuant::transformNxN( tu, compID, cQP, &trModes, maxCand ) (TrQuant.cpp:950-1019); host-only */
 int vtmhip_mts_select( const int32_t *sumAbs, int numCand, int width, int height, int maxCand, uint8_t *test );
+/* the same from RAW sums with the transform-skip scaling of :992-1001 applied here: mtsIdx[i] = the candidate's tu.mtsIdx (MTS_SKIP = 1 marks
+ * sum |residual| of a transform-skip candidate); maxLog2TrDynamicRange: sps.getMaxLog2TrDynamicRange() (15).  numCand <= 16. */
+int vtmhip_mts_select2( const int32_t *sumAbs, const uint8_t *mtsIdx, int numCand, int width, int height, int bitDepth, int maxLog2TrDynamicRange,
+                        int maxCand, uint8_t *test );
 
 /* ================================================================================================================
  * (2) BATCHED DEVICE CALLS -- device pointers, asynchronous on the context's stream
@@ -534,6 +543,13 @@ typedef struct
  * uniformSize != 0: the caller guarantees every TU is exactly maxWidth x maxHeight (both >= 8) -> register-blocked kernel. */
 int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int maxWidth, int maxHeight,
                                int uniformSize, int32_t *d_levelsBase, int16_t *d_recBase, vtmhip_tu_result *d_results );
+
+/* The transform-skip candidate (tu.mtsIdx == MTS_SKIP; TrQuant.cpp:976-980 xTransformSkip, :925-941 xITransformSkip; Quant.cpp:966-997 with
+ * useTransformSkip) of the same chain for a uniform batch: every job width x height (powers of two, 4..32) with typeHor == VTMHIP_TRSKIP and
+ * qpPer / qpRem = QpParam::per( true ) / rem( true ).  results[i].sumAbs = sum |residual| (unscaled: vtmhip_mts_select2 applies scaleSAD).
+ * vtmhip_tu_chain_batch_dev with uniformSize == 0 takes VTMHIP_TRSKIP jobs mixed with the others. */
+int vtmhip_tu_ts_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int width, int height,
+                                  int32_t *d_levelsBase, int16_t *d_recBase, vtmhip_tu_result *d_results );
 
 /* TrQuant::xT only, for a batch the caller promises to be uniform (every TU width x height, powers of two 8..64) -- the forward transforms of all
  * MTS candidates of TrQuant::transformNxN( ..., trModes, maxCand ) (TrQuant.cpp:950-1019): same job table as the fused chain (qp fields unused);

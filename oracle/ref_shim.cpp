@@ -85,6 +85,20 @@ uint64_t ref_dist( int kind, int simd, const int16_t *org, int orgStride, const 
   return dp.distFunc( dp );
 }
 
+// The real RdCost::getDistPart (RdCost.cpp:411-455) with the slice's chroma distortion weight installed (setDistortionWeight, RdCost.h:151)
+uint64_t ref_get_dist_part( int compID, double weight, int dfunc /* 0 SAD, 1 SATD, 2 SSE */, const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w,
+                            int h, int bitDepth )
+{
+  ensureInit();
+  if( compID != COMPONENT_Y ) g_rd->setDistortionWeight( ( ComponentID ) compID, weight );
+  const CPelBuf o( org, orgStride, w, h ), c( cur, curStride, w, h );
+#if WCG_EXT
+  return g_rd->getDistPart( o, c, bitDepth, ( ComponentID ) compID, dfunc == 0 ? DF_SAD : ( dfunc == 1 ? DF_HAD : DF_SSE ), nullptr );
+#else
+  return g_rd->getDistPart( o, c, bitDepth, ( ComponentID ) compID, dfunc == 0 ? DF_SAD : ( dfunc == 1 ? DF_HAD : DF_SSE ) );
+#endif
+}
+
 // RdCost::xGetSADwMask through the mask overload of setDistParam (RdCost.cpp:3488-3511); simd 1: the table entry (x86), 0: the scalar member
 uint64_t ref_sad_mask( int simd, const int16_t *org, int orgStride, const int16_t *cur, int curStride, int w, int h, int bitDepth, const int16_t *mask,
                        int maskStride, int stepX, int maskStride2 )

@@ -225,7 +225,13 @@ void ref_frac_search( const MeCtxC *c, int intX, int intY, int useHad, int useAl
 #include "CommonLib/Rom.h"
 #include "CommonLib/Contexts.h"
 
+extern "C" int ref_quant_dequant2( const int32_t *coef, int w, int h, int bitDepth, int qp, int isIRAP, int mtsIdx, int32_t *qcoef, int32_t *absSum, int32_t *dqcoef );
 extern "C" int ref_quant_dequant( const int32_t *coef, int w, int h, int bitDepth, int qp, int isIRAP, int32_t *qcoef, int32_t *absSum, int32_t *dqcoef )
+{
+  return ref_quant_dequant2( coef, w, h, bitDepth, qp, isIRAP, MTS_DCT2_DCT2, qcoef, absSum, dqcoef );
+}
+// mtsIdx = MTS_SKIP (1): the transform-skip forms of both members (useTransformSkip, Quant.cpp:966-997, 357-482)
+extern "C" int ref_quant_dequant2( const int32_t *coef, int w, int h, int bitDepth, int qp, int isIRAP, int mtsIdx, int32_t *qcoef, int32_t *absSum, int32_t *dqcoef )
 {
   if( !g_rig ) g_rig = new MeRig();
   MeRig &r = *g_rig;
@@ -247,7 +253,7 @@ extern "C" int ref_quant_dequant( const int32_t *coef, int w, int h, int bitDept
   tu->cs = &r.cs;
   tu->cu = &r.cu;
   tu->chromaFormat = CHROMA_400;
-  tu->mtsIdx[0]    = MTS_DCT2_DCT2;
+  tu->mtsIdx[0]    = ( uint8_t ) mtsIdx;
   tu->noResidual   = false;
   r.cu.qp = qp; r.cu.predMode = MODE_INTER; r.cu.lfnstIdx = 0; r.cu.colorTransform = false; r.cu.bdpcmMode = 0; r.cu.bdpcmModeChroma = 0;
   r.cu.chromaQpAdj = 0; r.cu.treeType = TREE_D; r.cu.modeType = MODE_TYPE_ALL;
@@ -684,4 +690,91 @@ extern "C" void ref_lfnst( int inverse, const int32_t *src, int32_t *dst, int mo
   if( inverse ) tq->invLfnstNxN( in, out, mode, index, size, zeroOutSize, 15 );
   else tq->fwdLfnstNxN( in, out, mode, index, size, zeroOutSize );
   memcpy( dst, out, sizeof( int ) * ( size > 4 ? 48 : 16 ) );
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The 2-D compositions TrQuant::xT / xIT (TrQuant.cpp:776-923: getTrTypes, shift1 / shift2, skipWidth / skipHeight, the Pel truncation of
+// xIT's output) and the MTS candidate pre-selection TrQuant::transformNxN( tu, compID, cQP, &trModes, maxCand ) (:950-1019, including the
+// transform-skip candidate xTransformSkip + scaleSAD), called as the real protected members on a rig TU of an inter CU with explicit MTS on.
+// ------------------------------------------------------------------------------------------------------------------
+namespace
+{
+struct TrRig
+{
+  TrQuant        tq;
+  TransformUnit *tu = nullptr;
+  bool           resiCreated = false;
+};
+TrRig *g_trRig = nullptr;
+
+TransformUnit &trSetup( int w, int h, int bitDepth, int mtsIdx )
+{
+  if( !g_rig ) g_rig = new MeRig();
+  if( !g_trRig ) g_trRig = new TrRig();
+  ensureRom();
+  MeRig &r = *g_rig;
+  r.sps.setBitDepth( CHANNEL_TYPE_LUMA, bitDepth );
+  r.sps.setBitDepth( CHANNEL_TYPE_CHROMA, bitDepth );
+  r.sps.setUseMTS( true );
+  r.sps.setUseInterMTS( true );
+  r.sps.setUseIntraMTS( true );
+  r.sps.setUseLFNST( false );
+  r.slice.setSPS( &r.sps );
+  const UnitArea ua( CHROMA_400, Area( 0, 0, w, h ) );
+  if( !g_trRig->tu ) g_trRig->tu = new TransformUnit( ua );
+  TransformUnit &tu = *g_trRig->tu;
+  tu.UnitArea::operator=( ua );
+  tu.cs = &r.cs;
+  tu.cu = &r.cu;
+  tu.chromaFormat = CHROMA_400;
+  tu.mtsIdx[0]    = ( uint8_t ) mtsIdx;
+  tu.noResidual   = false;
+  r.cu.predMode = MODE_INTER; r.cu.lfnstIdx = 0; r.cu.sbtInfo = 0; r.cu.ispMode = 0; r.cu.mipFlag = false; r.cu.colorTransform = false; r.cu.bdpcmMode = 0;
+  return tu;
+}
+}   // namespace
+
+extern "C" int ref_xT( const int16_t *resi, int stride, int w, int h, int bitDepth, int mtsIdx, int32_t *coef )
+{
+  TransformUnit &tu = trSetup( w, h, bitDepth, mtsIdx );
+  const CPelBuf src( resi, stride, w, h );
+  CoeffBuf      dst( coef, w, w, h );
+  g_trRig->tq.xT( tu, COMPONENT_Y, src, dst, w, h );
+  return 0;
+}
+
+extern "C" int ref_xIT( const int32_t *coef, int w, int h, int bitDepth, int mtsIdx, int16_t *resi, int stride )
+{
+  TransformUnit &tu = trSetup( w, h, bitDepth, mtsIdx );
+  const CCoeffBuf src( coef, w, w, h );
+  PelBuf          dst( resi, stride, w, h );
+  g_trRig->tq.xIT( tu, COMPONENT_Y, src, dst );
+  return 0;
+}
+
+// trModes in: mtsIdx[i]; out: test[i] (the .second the real member leaves) -- the residual is copied into the coding structure's own
+// residual buffer, where the member reads it (cs.getResiBuf)
+extern "C" int ref_transformNxN_select( const int16_t *resi, int stride, int w, int h, int bitDepth, const uint8_t *mtsIdx, int numCand, int maxCand,
+                                        uint8_t *test )
+{
+  TransformUnit &tu = trSetup( w, h, bitDepth, 0 );
+  MeRig &r = *g_rig;
+  if( !g_trRig->resiCreated )
+  {
+    r.cs.area = UnitArea( CHROMA_400, Area( 0, 0, MAX_TB_SIZEY, MAX_TB_SIZEY ) );
+    r.cs.m_resi.create( r.cs.area );
+    r.cs.parent = &r.cs;   // only consulted to decide whether the residual address is folded to the CTU (KEEP_PRED_AND_RESI_SIGNALS off): no folding
+    g_trRig->resiCreated = true;
+  }
+  PelBuf dst = r.cs.getResiBuf( tu.Y() );
+  for( int y = 0; y < h; y++ ) memcpy( dst.buf + y * dst.stride, resi + y * stride, sizeof( Pel ) * w );
+  std::vector<TrMode> modes;
+  for( int i = 0; i < numCand; i++ ) modes.push_back( TrMode( mtsIdx[i], true ) );
+  r.cu.qp = 32; r.cu.chromaQpAdj = 0; r.cu.treeType = TREE_D; r.cu.modeType = MODE_TYPE_ALL;
+  r.sps.setQpBDOffset( CHANNEL_TYPE_LUMA, 6 * ( bitDepth - 8 ) );
+  r.sps.setInternalMinusInputBitDepth( CHANNEL_TYPE_LUMA, 0 );
+  const QpParam cQP( tu, COMPONENT_Y );   // not read by this overload
+  g_trRig->tq.transformNxN( tu, COMPONENT_Y, cQP, &modes, maxCand );
+  for( int i = 0; i < numCand; i++ ) test[i] = modes[i].second;
+  return 0;
 }

@@ -263,3 +263,55 @@ def test_xT_uniform_batch_matches_oracle(ctx, size):
     assert np.array_equal(got, exp)
     res = (TuResult * n).from_buffer_copy(d_res.to_host(np.uint8).tobytes())
     assert [r.sumAbs for r in res] == [int(np.abs(exp[k]).sum()) for k in range(n)]
+
+
+@pytest.mark.parametrize("uniform", [False, True])
+def test_transform_skip_candidate_of_the_fused_chain(ctx, uniform):
+    """The MTS_SKIP candidate (TuJob.typeHor == 3): xTransformSkip -> Quant::quant(TS) -> dequant(TS) -> xITransformSkip -> SSE, mixed with
+    DCT2 jobs in the generic launch and alone in the uniform one; sumAbs = sum |residual| (vtmhip_mts_select2 scales it)."""
+    from vtm_amd.lib import TuJob, TuResult
+    L = ol.oracle()
+    rng = np.random.default_rng(991 + uniform)
+    shapes = [(4, 4), (8, 8), (16, 16), (32, 32), (8, 4), (4, 16), (32, 8), (16, 32)]
+    for (w, h) in shapes:
+        n = 24
+        stride = w + 5
+        resi = rng.integers(-700, 701, (n, h, stride)).astype(np.int16)
+        resi[rng.random(resi.shape) < 0.5] //= 40
+        jobs = (TuJob * n)()
+        exp = []
+        exp_lv, exp_rec = np.zeros((n, w * h), np.int32), np.zeros((n, w * h), np.int16)
+        for k in range(n):
+            ts = uniform or (k % 2 == 0)
+            qp = int(rng.choice([22, 27, 32, 37])) + 12
+            irap = int(rng.integers(0, 2))
+            j = jobs[k]
+            j.resiOff, j.outOff, j.resiStride, j.width, j.height = k * h * stride, k * w * h, stride, w, h
+            j.qpPer, j.qpRem, j.bitDepth, j.isIRAP = qp // 6, qp % 6, 10, irap
+            j.typeHor = j.typeVer = 3 if ts else 0
+            blk = np.ascontiguousarray(resi[k, :, :w])
+            coef, qc, dq = np.zeros(w * h, np.int32), np.zeros(w * h, np.int32), np.zeros(w * h, np.int32)
+            s = C.c_int32()
+            rec = np.zeros((h, w), np.int16)
+            if ts:
+                coef[:] = blk.reshape(-1)
+                L.vo_quant(ol.P(coef), w, h, 10, j.qpPer, j.qpRem, irap, 1, ol.P(qc), None, C.byref(s))
+                L.vo_dequant(ol.P(qc), w, h, 10, j.qpPer, j.qpRem, 1, ol.P(dq))
+                rec[:] = dq.reshape(h, w).astype(np.int16)   # xITransformSkip: Pel( coefficient )
+            else:
+                assert L.vo_fwd_2d(ol.P(blk), w, w, h, 10, 0, 0, ol.P(coef)) == 0
+                L.vo_quant(ol.P(coef), w, h, 10, j.qpPer, j.qpRem, irap, 0, ol.P(qc), None, C.byref(s))
+                L.vo_dequant(ol.P(qc), w, h, 10, j.qpPer, j.qpRem, 0, ol.P(dq))
+                assert L.vo_inv_2d(ol.P(dq), w, h, 10, 0, 0, ol.P(rec), w) == 0
+            exp.append((ol.o_dist(2, blk, rec, w, h), int(np.abs(coef.astype(np.int64)).sum()), s.value))
+            exp_lv[k], exp_rec[k] = qc, rec.reshape(-1)
+        d_resi, d_jobs = ctx.to_device(resi), ctx.to_device(np.frombuffer(jobs, np.uint8))
+        d_res = ctx.alloc(16 * n)
+        d_lv, d_rec = ctx.to_device(np.zeros((n, w * h), np.int32)), ctx.to_device(np.zeros((n, w * h), np.int16))
+        if uniform:
+            ctx.tu_ts_chain_batch(d_resi.ptr, d_jobs.ptr, n, w, h, d_res.ptr, d_lv.ptr, d_rec.ptr)
+        else:
+            ctx.tu_chain_batch(d_resi.ptr, d_jobs.ptr, n, w, h, d_res.ptr, d_lv.ptr, d_rec.ptr)
+        res = (TuResult * n).from_buffer_copy(d_res.to_host(np.uint8).tobytes())
+        assert [(r.sse, r.sumAbs, r.absSum) for r in res] == exp, (w, h)
+        assert np.array_equal(d_lv.to_host().reshape(n, w * h), exp_lv) and np.array_equal(d_rec.to_host().reshape(n, w * h), exp_rec), (w, h)

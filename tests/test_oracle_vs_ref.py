@@ -474,3 +474,116 @@ def test_lfnst_equals_reference(oracle, reflib):
                             M = np.ascontiguousarray(m8[mode, index] if size > 4 else m4[mode, index])
                             (oracle.vo_inv_lfnst if inverse else oracle.vo_fwd_lfnst)(ol.P(s_), ol.P(b), C.c_void_p(M.ctypes.data), size, zo)
                             assert np.array_equal(a[:n], b[:n]), (mode, index, size, zo, inverse)
+
+
+MTS_TYPES = {0: (0, 0), 2: (2, 2), 3: (1, 2), 4: (2, 1), 5: (1, 1)}   # tu.mtsIdx -> (typeHor, typeVer), TrQuant::getTrTypes (TrQuant.cpp:762-771)
+
+
+def test_xT_xIT_2d_composition_equals_reference_members(oracle, reflib):
+    """The real TrQuant::xT / xIT (TrQuant.cpp:776-923: shift1 / shift2, skipWidth / skipHeight, transposed passes, Pel truncation) on a rig
+    TU vs the oracle's vo_fwd_2d / vo_inv_2d -- pins the 2-D COMPOSITION, not only the 1-D fast* slots."""
+    rng = np.random.default_rng(881)
+    n = 0
+    for w in (4, 8, 16, 32, 64):
+        for h in (4, 8, 16, 32, 64):
+            for mts in (0, 2, 3, 4, 5):
+                if mts and max(w, h) > 32:
+                    continue
+                th, tv = MTS_TYPES[mts]
+                for bd in (8, 10):
+                    amp = int(rng.choice([3, 100, (1 << bd) - 1]))
+                    stride = w + int(rng.integers(0, 9))
+                    resi = rng.integers(-amp, amp + 1, (h, stride)).astype(np.int16)
+                    c_ref, c_or = np.zeros(w * h, np.int32), np.zeros(w * h, np.int32)
+                    reflib.ref_xT(ol.P(resi), stride, w, h, bd, mts, ol.P(c_ref))
+                    assert oracle.vo_fwd_2d(ol.P(resi), stride, w, h, bd, th, tv, ol.P(c_or)) == 0
+                    assert np.array_equal(c_ref, c_or), ("xT", w, h, mts, bd)
+                    # inverse of quantisation-like coefficients (sparse, 16-bit range as Quant::dequant clips them)
+                    coef = (c_ref // int(rng.choice([1, 7, 40]))).astype(np.int32)
+                    coef[rng.random(w * h) < 0.3] = int(rng.integers(-32768, 32768))
+                    c2 = coef.reshape(h, w)
+                    zw = 16 if (th != 0 and w == 32) else max(0, w - 32)
+                    zh = 16 if (tv != 0 and h == 32) else max(0, h - 32)
+                    if zw:
+                        c2[:, w - zw:] = 0
+                    if zh:
+                        c2[h - zh:, :] = 0
+                    r_ref, r_or = np.zeros((h, stride), np.int16), np.zeros((h, stride), np.int16)
+                    reflib.ref_xIT(ol.P(coef), w, h, bd, mts, ol.P(r_ref), stride)
+                    assert oracle.vo_inv_2d(ol.P(coef), w, h, bd, th, tv, ol.P(r_or), stride) == 0
+                    assert np.array_equal(r_ref[:, :w], r_or[:, :w]), ("xIT", w, h, mts, bd)
+                    n += 1
+    assert n == 178
+
+
+def test_mts_preselection_equals_reference_transformNxN(oracle, reflib):
+    """The real TrQuant::transformNxN( tu, compID, cQP, &trModes, maxCand ) (TrQuant.cpp:950-1019) incl. the transform-skip candidate
+    (xTransformSkip + scaleSAD) vs vtmhip_mts_select2 (host-only entry of libvtmhip.so) fed with the oracle's sum |coef| / sum |residual|."""
+    from vtm_amd import lib
+    L = lib.load()
+    rng = np.random.default_rng(882)
+    n_pruned = 0
+    for it in range(400):
+        w, h = int(rng.choice([4, 8, 16, 32])), int(rng.choice([4, 8, 16, 32]))
+        # trModes as EncCu / InterSearch build them: DCT2 first, then (optionally) transform skip at position 1, then the four MTS pairs
+        modes = [0] + ([1] if rng.random() < 0.6 else []) + [2, 3, 4, 5][:int(rng.integers(0, 5))]
+        max_cand = int(rng.integers(0, 5))
+        kind = it % 4
+        amp = int(rng.choice([2, 20, 300]))
+        resi = rng.integers(-amp, amp + 1, (h, w)).astype(np.int16)
+        if kind == 1:     # smooth ramp: DCT2 wins by a margin, the others get pruned
+            resi = (np.add.outer(np.arange(h), np.arange(w)) * amp // 8).astype(np.int16)
+        elif kind == 2:   # a few isolated samples: transform skip territory
+            resi[:] = 0
+            resi[rng.integers(0, h, 3), rng.integers(0, w, 3)] = amp * 3
+        sums = np.zeros(len(modes), np.int32)
+        for i, m in enumerate(modes):
+            if m == 1:
+                sums[i] = int(np.abs(resi.astype(np.int64)).sum())
+            else:
+                coef = np.zeros(w * h, np.int32)
+                th, tv = MTS_TYPES[m]
+                assert oracle.vo_fwd_2d(ol.P(resi), w, w, h, 10, th, tv, ol.P(coef)) == 0
+                sums[i] = int(np.abs(coef.astype(np.int64)).sum())
+        marr = np.array(modes, np.uint8)
+        t_lib, t_ref = np.zeros(len(modes), np.uint8), np.zeros(len(modes), np.uint8)
+        assert L.vtmhip_mts_select2(sums.ctypes.data, marr.ctypes.data, len(modes), w, h, 10, 15, max_cand, t_lib.ctypes.data) == lib.OK
+        reflib.ref_transformNxN_select(ol.P(resi), w, w, h, 10, ol.P(marr), len(modes), max_cand, ol.P(t_ref))
+        assert list(t_lib) == list(t_ref), (w, h, modes, max_cand, list(sums), list(t_lib), list(t_ref))
+        n_pruned += int(len(modes) - t_ref.sum())
+    assert n_pruned > 100   # the rule actually prunes on this content
+
+
+def test_transform_skip_quant_dequant_equal_reference(oracle, reflib):
+    """Quant::quant / dequant with tu.mtsIdx == MTS_SKIP (no transform shift, no sqrt(2) table) vs the oracle's isTransformSkip path."""
+    rng = np.random.default_rng(883)
+    for w in (4, 8, 16, 32):
+        for h in (4, 8, 16, 32):
+            for qp in (22, 27, 32, 37, 51):
+                for irap in (0, 1):
+                    c = rng.integers(-1023, 1024, w * h).astype(np.int32)   # transform-skip "coefficients" are residual samples
+                    q1, d1, q2, d2 = (np.zeros(w * h, np.int32) for _ in range(4))
+                    s1, s2 = C.c_int32(), C.c_int32()
+                    reflib.ref_quant_dequant2(ol.P(c), w, h, 10, qp, irap, 1, ol.P(q1), C.byref(s1), ol.P(d1))
+                    bq = qp + 12
+                    oracle.vo_quant(ol.P(c), w, h, 10, bq // 6, bq % 6, irap, 1, ol.P(q2), None, C.byref(s2))
+                    oracle.vo_dequant(ol.P(q2), w, h, 10, bq // 6, bq % 6, 1, ol.P(d2))
+                    assert np.array_equal(q1, q2) and np.array_equal(d1, d2) and s1.value == s2.value, (w, h, qp, irap)
+
+
+def test_get_dist_part_chroma_weight(oracle, reflib):
+    """RdCost::getDistPart (RdCost.cpp:411-455): chroma distortions are scaled by the fp64 m_distortionWeight and truncated; the host mirror
+    (host/vtmhip_host.hpp RdCost::getDistPart) and a trampoline apply exactly (Distortion)( weight * distFunc() )."""
+    reflib.ref_get_dist_part.restype = C.c_uint64
+    reflib.ref_get_dist_part.argtypes = [C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    rng = np.random.default_rng(884)
+    for _ in range(300):
+        w, h = int(rng.choice([4, 8, 16, 32, 64])), int(rng.choice([4, 8, 16, 32, 64]))
+        o, c = ol.i16(rng.integers(0, 1024, (h, w + 3))), ol.i16(rng.integers(0, 1024, (h, w + 1)))
+        comp = int(rng.integers(0, 3))
+        wt = float(rng.choice([1.0, 0.7937005259840998, 1.2599210498948732, 2.0 ** (rng.integers(-6, 7) / 3.0)]))
+        for kind in (0, 1, 2):
+            d = ol.o_dist(kind, o, c, w, h)
+            exp = d if comp == 0 else int(np.float64(wt) * np.float64(d))
+            got = reflib.ref_get_dist_part(comp, wt, kind, ol.P(o), w + 3, ol.P(c), w + 1, w, h, 10)
+            assert got == exp, (w, h, comp, wt, kind)

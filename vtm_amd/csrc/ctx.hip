@@ -91,6 +91,7 @@ int vtmhip_destroy( vtmhip_ctx *ctx )
   if( ctx->scratch ) ( void ) hipFree( ctx->scratch );
   if( ctx->work ) ( void ) hipFree( ctx->work );
   if( ctx->lfnstTab ) ( void ) hipFree( ctx->lfnstTab );
+  if( ctx->trTabBuf ) ( void ) hipFree( ctx->trTabBuf );
   if( ctx->pinned ) ( void ) hipHostFree( ctx->pinned );
   if( ctx->evStart ) ( void ) hipEventDestroy( ctx->evStart );
   if( ctx->evStop ) ( void ) hipEventDestroy( ctx->evStop );
@@ -176,7 +177,8 @@ int vtmhip_internal_scratch( vtmhip_ctx *ctx, size_t bytes )
 {
   if( bytes <= ctx->scratchSize ) return VTMHIP_OK;
   size_t want = ( bytes + ( 1u << 20 ) - 1 ) & ~( size_t )( ( 1u << 20 ) - 1 );
-  VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
+  VTMHIP_HIP( ctx, hipSetDevice( ctx->device ) );
+  VTMHIP_HIP( ctx, hipDeviceSynchronize() );   // vtmhip_set_stream may have moved the context between streams: launches queued on ANY of them may still use the old block
   if( ctx->scratch ) VTMHIP_HIP( ctx, hipFree( ctx->scratch ) );
   if( ctx->pinned ) VTMHIP_HIP( ctx, hipHostFree( ctx->pinned ) );
   ctx->scratch = nullptr; ctx->pinned = nullptr; ctx->scratchSize = 0; ctx->pinnedSize = 0;
@@ -190,7 +192,8 @@ int vtmhip_internal_workspace( vtmhip_ctx *ctx, size_t bytes )
 {
   if( bytes <= ctx->workSize ) return VTMHIP_OK;
   const size_t want = ( bytes + ( 1u << 20 ) - 1 ) & ~( size_t )( ( 1u << 20 ) - 1 );
-  VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );   // earlier launches may still use the old block
+  VTMHIP_HIP( ctx, hipSetDevice( ctx->device ) );
+  VTMHIP_HIP( ctx, hipDeviceSynchronize() );   // earlier launches -- on any stream the context was pointed at (vtmhip_set_stream) -- may still use the old block
   if( ctx->work ) VTMHIP_HIP( ctx, hipFree( ctx->work ) );
   ctx->work = nullptr; ctx->workSize = 0;
   if( hipMalloc( &ctx->work, want ) != hipSuccess )

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "../../include/vtmhip.h"
@@ -23,12 +24,25 @@ struct vtmhip_ctx
   void       *work        = nullptr;   // device workspace of the multi-stage calls (vtmhip_xMotionEstimation_batch_dev)
   size_t      workSize    = 0;
   int8_t     *lfnstTab    = nullptr;   // the caller's LFNST core matrices: g_lfnst8x8 [4][2][16][48] then g_lfnst4x4 [4][2][16][16] (vtmhip_lfnst_set_tables)
+  int16_t    *trTabBuf    = nullptr;   // the transform core matrices of THIS context's device (transform.hip ensure_tables; freed by vtmhip_destroy)
+  const int16_t *trTab[3][7] = {};     // [type][log2 N] -> N x N forward matrix inside trTabBuf
+  std::mutex  initMutex;               // guards the lazy per-context initialisations (tables, staging / workspace growth)
   int         numCUs      = 256;
   std::string lastError;
 };
 
-#define VTMHIP_CHECK_CTX( ctx ) \
-  do { if( !( ctx ) ) return VTMHIP_E_INVALID; } while( 0 )
+// every entry point starts here: a null context is an error, and the calling thread is pointed at the context's device (a host with
+// several contexts / GPUs in one process, or encoder threads that never called hipSetDevice, would otherwise allocate and launch on
+// whatever device happens to be current)
+#define VTMHIP_CHECK_CTX( ctx )                                                                    \
+  do {                                                                                             \
+    if( !( ctx ) ) return VTMHIP_E_INVALID;                                                        \
+    if( hipSetDevice( ( ctx )->device ) != hipSuccess )                                            \
+    {                                                                                              \
+      ( ctx )->lastError = "hipSetDevice failed";                                                  \
+      return VTMHIP_E_HIP;                                                                         \
+    }                                                                                              \
+  } while( 0 )
 
 #define VTMHIP_HIP( ctx, call )                                                                        \
   do {                                                                                                 \

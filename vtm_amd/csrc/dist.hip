@@ -376,8 +376,8 @@ int check_dist_args( vtmhip_ctx *ctx, int w, int h, int subShift, int kind )
 {
   VTMHIP_REQUIRE( ctx, w >= 1 && h >= 1 && w <= 128 && h <= 128, "block size must be 1..128" );
   VTMHIP_REQUIRE( ctx, kind != VTMHIP_DIST_SATD || ( ( ( w | h ) & 1 ) == 0 ), "SATD needs even width and height (RdCost.cpp:2925-2931: \"Invalid size\")" );
-  VTMHIP_REQUIRE( ctx, ( h & ( ( 1 << subShift ) - 1 ) ) == 0 || subShift == 0, "height must be a multiple of the row step" );
   VTMHIP_REQUIRE( ctx, subShift >= 0 && subShift <= 4 && ( kind == VTMHIP_DIST_SAD || subShift == 0 ), "subShift" );
+  VTMHIP_REQUIRE( ctx, ( h & ( ( 1 << subShift ) - 1 ) ) == 0 || subShift == 0, "height must be a multiple of the row step" );
   return VTMHIP_OK;
 }
 

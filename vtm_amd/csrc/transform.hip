@@ -13,6 +13,7 @@
 #include "ctx.hpp"
 #include "tr_tables.hpp"
 
+#include <cmath>
 #include <vector>
 
 namespace
@@ -20,13 +21,13 @@ namespace
 
 struct TrTables { const int16_t *m[3][7]; };   // [type][log2 N] -> device pointer to the N x N forward matrix (row-major)
 
-int16_t *g_dTables[16] = {};   // per-device table buffer
-TrTables g_tabs[16];
-
+// The core matrices live in the CONTEXT (one copy per context, on the context's device, freed by vtmhip_destroy): no process-global
+// state, so two contexts on two GPUs -- or two encoder threads with a context each -- cannot race or see the other device's pointers.
 int ensure_tables( vtmhip_ctx *ctx )
 {
-  const int d = ctx->device & 15;
-  if( g_dTables[d] ) return VTMHIP_OK;
+  std::lock_guard<std::mutex> lock( ctx->initMutex );
+  if( ctx->trTabBuf ) return VTMHIP_OK;
+  VTMHIP_HIP( ctx, hipSetDevice( ctx->device ) );
   std::vector<int16_t> host;
   size_t               offs[3][7];
   for( int t = 0; t < 3; t++ )
@@ -43,11 +44,24 @@ int ensure_tables( vtmhip_ctx *ctx )
     }
   int16_t *dbuf = nullptr;
   VTMHIP_HIP( ctx, hipMalloc( ( void ** ) &dbuf, host.size() * sizeof( int16_t ) ) );
-  VTMHIP_HIP( ctx, hipMemcpy( dbuf, host.data(), host.size() * sizeof( int16_t ), hipMemcpyHostToDevice ) );
+  if( hipMemcpy( dbuf, host.data(), host.size() * sizeof( int16_t ), hipMemcpyHostToDevice ) != hipSuccess )
+  {
+    ( void ) hipFree( dbuf );
+    ctx->lastError = "hipMemcpy of the transform core matrices failed";
+    return VTMHIP_E_HIP;
+  }
   for( int t = 0; t < 3; t++ )
-    for( int l = 0; l < 7; l++ ) g_tabs[d].m[t][l] = offs[t][l] == ( size_t ) -1 ? nullptr : dbuf + offs[t][l];
-  g_dTables[d] = dbuf;
+    for( int l = 0; l < 7; l++ ) ctx->trTab[t][l] = offs[t][l] == ( size_t ) -1 ? nullptr : dbuf + offs[t][l];
+  ctx->trTabBuf = dbuf;
   return VTMHIP_OK;
+}
+
+TrTables tabs_of( const vtmhip_ctx *ctx )
+{
+  TrTables t;
+  for( int a = 0; a < 3; a++ )
+    for( int l = 0; l < 7; l++ ) t.m[a][l] = ctx->trTab[a][l];
+  return t;
 }
 
 __device__ __forceinline__ int ilog2( int v ) { return 31 - __clz( v ); }
@@ -366,10 +380,44 @@ __global__ __launch_bounds__( 256 ) void tu_chain_kernel( const int16_t *__restr
     blk[i] = v;
     sR[i]  = v;
   }
-  const int skipW = tr_skip( j.typeHor, w ), skipH = tr_skip( j.typeVer, h );
   const int lw = ilog2( w ), lh = ilog2( h );
   long long sumAbs = 0, absSum = 0, sse = 0;
-
+  const bool ts = j.typeHor == VTMHIP_TRSKIP;   // MTS_SKIP candidate: xTransformSkip / xITransformSkip are plain copies (TrQuant.cpp:1200-1213, 925-941)
+  const int skipW = ts ? 0 : tr_skip( j.typeHor, w ), skipH = ts ? 0 : tr_skip( j.typeVer, h );
+  tu_sync<TPT>();
+  if( ts )
+  {
+    // coefficients = residual samples; Quant::quant / dequant with useTransformSkip: no transform shift, no sqrt(2) compensation
+    // (Quant.cpp:966-997, 357-482); the caller puts QpParam::per( true ) / rem( true ) into the job
+    const int       qBits = 14 + j.qpPer;
+    const long long add   = ( long long ) ( j.isIRAP ? 171 : 85 ) << ( qBits - 9 );
+    const int       scale = c_quantScales[0][j.qpRem], iscale = c_invQuantScales[0][j.qpRem];
+    const int       rightShift = 6 - j.qpPer;
+    const int       inBits = min( 16, 32 + rightShift - 7 );
+    const int       inMin = -( 1 << ( inBits - 1 ) ), inMax = ( 1 << ( inBits - 1 ) ) - 1;
+    int            *levels = levelsBase ? levelsBase + j.outOff : nullptr;
+    int16_t        *rec    = recBase ? recBase + j.outOff : nullptr;
+    for( int i = t; i < w * h; i += TPT )
+    {
+      const int c = blk[i];
+      sumAbs += abs( c );
+      const long long tt  = ( long long ) abs( c ) * scale;
+      const int       mag = ( int ) ( ( tt + add ) >> qBits );
+      absSum += mag;
+      const int q = min( 32767, max( -32768, c < 0 ? -mag : mag ) );
+      if( levels ) levels[i] = q;
+      const int qq = min( inMax, max( inMin, q ) );
+      int       v;
+      if( rightShift > 0 ) v = ( int ) ( ( unsigned ) ( qq * iscale ) + ( 1u << ( rightShift - 1 ) ) ) >> rightShift;
+      else v = ( int ) ( ( unsigned ) ( qq * iscale ) << ( -rightShift ) );
+      v = ( int ) ( int16_t ) min( 32767, max( -32768, v ) );
+      if( rec ) rec[i] = ( int16_t ) v;
+      const int d = c - v;
+      sse += ( long long ) ( unsigned long long ) ( ( unsigned ) d * ( unsigned ) d );
+    }
+  }
+  else
+  {
   // ---- forward: TrQuant::xT ----------------------------------------------------------------------------------------------------
   {
     const int s1 = lw + bd + 6 - 15, s2 = lh + 6;
@@ -482,6 +530,7 @@ __global__ __launch_bounds__( 256 ) void tu_chain_kernel( const int16_t *__restr
       }
     }
   }
+  }   // !ts
   // ---- reduce the three sums over the TU's threads ------------------------------------------------------------------------------
   sumAbs = ( long long ) wave_reduce_add_u64( ( unsigned long long ) sumAbs );
   absSum = ( long long ) wave_reduce_add_u64( ( unsigned long long ) absSum );
@@ -830,6 +879,52 @@ int launch_tu_uni_sized( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhi
   return launch_tu_uni<256>( ctx, d_resiBase, d_jobs, n, w, h, d_levelsBase, d_recBase, d_results, tb, d_fwdCoefBase );
 }
 
+// Transform-skip candidates of a uniform batch (every job typeHor == VTMHIP_TRSKIP): elementwise, LPT = 8 lanes per TU (8 TUs per wave)
+__global__ __launch_bounds__( 256 ) void tu_ts_kernel( const int16_t *__restrict__ resiBase, const vtmhip_tu_job *__restrict__ jobs, int numJobs,
+                                                      int *__restrict__ levelsBase, int16_t *__restrict__ recBase, vtmhip_tu_result *__restrict__ results, int w, int h )
+{
+  const int jobIdx = ( blockIdx.x * 256 + threadIdx.x ) >> 3, t = threadIdx.x & 7;
+  const bool live  = jobIdx < numJobs;
+  const vtmhip_tu_job j = jobs[live ? jobIdx : numJobs - 1];
+  const int       lw = ilog2( w );
+  const int       qBits = 14 + j.qpPer;
+  const long long add   = ( long long ) ( j.isIRAP ? 171 : 85 ) << ( qBits - 9 );
+  const int       scale = c_quantScales[0][j.qpRem], iscale = c_invQuantScales[0][j.qpRem];
+  const int       rightShift = 6 - j.qpPer;
+  const int       inBits = min( 16, 32 + rightShift - 7 );
+  const int       inMin = -( 1 << ( inBits - 1 ) ), inMax = ( 1 << ( inBits - 1 ) ) - 1;
+  int            *levels = ( levelsBase && live ) ? levelsBase + j.outOff : nullptr;
+  int16_t        *rec    = ( recBase && live ) ? recBase + j.outOff : nullptr;
+  const int16_t  *resi   = resiBase + j.resiOff;
+  long long sumAbs = 0, absSum = 0, sse = 0;
+  for( int i = t; i < w * h; i += 8 )
+  {
+    const int c = resi[( long ) ( i >> lw ) * j.resiStride + ( i & ( w - 1 ) )];
+    sumAbs += abs( c );
+    const long long tt  = ( long long ) abs( c ) * scale;
+    const int       mag = ( int ) ( ( tt + add ) >> qBits );
+    absSum += mag;
+    const int q = min( 32767, max( -32768, c < 0 ? -mag : mag ) );
+    if( levels ) levels[i] = q;
+    const int qq = min( inMax, max( inMin, q ) );
+    int       v;
+    if( rightShift > 0 ) v = ( int ) ( ( unsigned ) ( qq * iscale ) + ( 1u << ( rightShift - 1 ) ) ) >> rightShift;
+    else v = ( int ) ( ( unsigned ) ( qq * iscale ) << ( -rightShift ) );
+    v = ( int ) ( int16_t ) min( 32767, max( -32768, v ) );
+    if( rec ) rec[i] = ( int16_t ) v;
+    const int d = c - v;
+    sse += ( long long ) ( unsigned long long ) ( ( unsigned ) d * ( unsigned ) d );
+  }
+#pragma unroll
+  for( int o = 4; o > 0; o >>= 1 )
+  {
+    sumAbs += __shfl_xor( sumAbs, o, 64 );
+    absSum += __shfl_xor( absSum, o, 64 );
+    sse += __shfl_xor( sse, o, 64 );
+  }
+  if( t == 0 && live ) { vtmhip_tu_result r; r.sse = ( uint64_t ) sse; r.sumAbs = ( int32_t ) sumAbs; r.absSum = ( int32_t ) absSum; results[jobIdx] = r; }
+}
+
 bool pow2( int v ) { return v > 0 && ( v & ( v - 1 ) ) == 0; }
 int  hlog2( int v ) { int r = 0; while( ( 1 << r ) < v ) r++; return r; }
 
@@ -857,7 +952,7 @@ int vtmhip_fastFwdTrans( vtmhip_ctx *ctx, int type, int n, const int32_t *src, i
   memcpy( hp, src, bytes );
   VTMHIP_HIP( ctx, hipMemcpyAsync( dp, hp, bytes, hipMemcpyHostToDevice, ctx->stream ) );
   hipLaunchKernelGGL( fwd1d_kernel, dim3( ( n * line + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, ( const int * ) dp, ( int * ) ( dp + dOff ),
-                      g_tabs[ctx->device & 15].m[type][hlog2( n )], n, shift, line, skipLine, skipLine2 );
+                      ctx->trTab[type][hlog2( n )], n, shift, line, skipLine, skipLine2 );
   VTMHIP_LAUNCHED( ctx );
   VTMHIP_HIP( ctx, hipMemcpyAsync( hp + dOff, dp + dOff, bytes, hipMemcpyDeviceToHost, ctx->stream ) );
   VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
@@ -883,7 +978,7 @@ int vtmhip_fastInvTrans( vtmhip_ctx *ctx, int type, int n, const int32_t *src, i
   memcpy( hp, src, bytes );
   VTMHIP_HIP( ctx, hipMemcpyAsync( dp, hp, bytes, hipMemcpyHostToDevice, ctx->stream ) );
   hipLaunchKernelGGL( inv1d_kernel, dim3( ( n * line + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, ( const int * ) dp, ( int * ) ( dp + dOff ),
-                      g_tabs[ctx->device & 15].m[type][hlog2( n )], n, shift, line, skipLine, skipLine2, outputMinimum, outputMaximum );
+                      ctx->trTab[type][hlog2( n )], n, shift, line, skipLine, skipLine2, outputMinimum, outputMaximum );
   VTMHIP_LAUNCHED( ctx );
   VTMHIP_HIP( ctx, hipMemcpyAsync( hp + dOff, dp + dOff, bytes, hipMemcpyDeviceToHost, ctx->stream ) );
   VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );
@@ -903,7 +998,7 @@ int vtmhip_xT_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, int32_t *d_
   if( st ) return st;
   const int    mx  = maxWidth > maxHeight ? maxWidth : maxHeight;
   const size_t lds = ( size_t ) ( maxWidth * maxHeight + maxWidth * ( maxHeight + 1 ) ) * 4 + ( size_t ) mx * mx * 2 + 16;
-  hipLaunchKernelGGL( xT_kernel, dim3( n ), dim3( 256 ), lds, ctx->stream, d_resiBase, d_coefBase, d_jobs, g_tabs[ctx->device & 15], d_sumAbs );
+  hipLaunchKernelGGL( xT_kernel, dim3( n ), dim3( 256 ), lds, ctx->stream, d_resiBase, d_coefBase, d_jobs, tabs_of( ctx ), d_sumAbs );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }
@@ -920,7 +1015,7 @@ int vtmhip_xIT_batch_dev( vtmhip_ctx *ctx, const int32_t *d_coefBase, int16_t *d
   if( st ) return st;
   const int    mx  = maxWidth > maxHeight ? maxWidth : maxHeight;
   const size_t lds = ( size_t ) ( 2 * maxWidth * maxHeight ) * 4 + ( size_t ) mx * mx * 2 + 16;
-  hipLaunchKernelGGL( xIT_kernel, dim3( n ), dim3( 256 ), lds, ctx->stream, d_coefBase, d_resiBase, d_jobs, g_tabs[ctx->device & 15] );
+  hipLaunchKernelGGL( xIT_kernel, dim3( n ), dim3( 256 ), lds, ctx->stream, d_coefBase, d_resiBase, d_jobs, tabs_of( ctx ) );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }
@@ -962,22 +1057,61 @@ int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const
   {
     VTMHIP_REQUIRE( ctx, ( maxWidth & ( maxWidth - 1 ) ) == 0 && ( maxHeight & ( maxHeight - 1 ) ) == 0, "uniformSize: width / height must be powers of two (TU sizes are)" );
     // caller's promise: every TU is exactly maxWidth x maxHeight -> register-blocked kernel, LPT lanes per TU
-    return launch_tu_uni_sized( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, g_tabs[ctx->device & 15], nullptr );
+    return launch_tu_uni_sized( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tabs_of( ctx ), nullptr );
   }
   const int    mx    = maxWidth > maxHeight ? maxWidth : maxHeight;
   const size_t perTu = ( size_t ) maxWidth * maxHeight + ( size_t ) maxWidth * ( maxHeight + 1 ) + ( ( mx * mx + 1 ) >> 1 ) + ( ( maxWidth * maxHeight + 1 ) >> 1 );
   if( maxWidth * maxHeight <= 256 )
   {
     hipLaunchKernelGGL( tu_chain_kernel<64>, dim3( ( n + 3 ) / 4 ), dim3( 256 ), 4 * perTu * sizeof( int ), ctx->stream, d_resiBase, d_jobs, n,
-                        g_tabs[ctx->device & 15], d_levelsBase, d_recBase, d_results, maxWidth, maxHeight );
+                        tabs_of( ctx ), d_levelsBase, d_recBase, d_results, maxWidth, maxHeight );
   }
   else
   {
     hipLaunchKernelGGL( tu_chain_kernel<256>, dim3( n ), dim3( 256 ), perTu * sizeof( int ), ctx->stream, d_resiBase, d_jobs, n,
-                        g_tabs[ctx->device & 15], d_levelsBase, d_recBase, d_results, maxWidth, maxHeight );
+                        tabs_of( ctx ), d_levelsBase, d_recBase, d_results, maxWidth, maxHeight );
   }
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
+}
+
+int vtmhip_tu_ts_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int width, int height,
+                                  int32_t *d_levelsBase, int16_t *d_recBase, vtmhip_tu_result *d_results )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_resiBase && d_jobs && d_results, "null pointer" );
+  VTMHIP_REQUIRE( ctx, pow2( width ) && pow2( height ) && width >= 4 && height >= 4 && width <= 32 && height <= 32, "transform skip: 4..32 (log2MaxTransformSkipBlockSize)" );
+  hipLaunchKernelGGL( tu_ts_kernel, dim3( ( n + 31 ) / 32 ), dim3( 256 ), 0, ctx->stream, d_resiBase, d_jobs, n, d_levelsBase, d_recBase, d_results, width, height );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+// The same selection from RAW sums: mtsIdx[i] is the candidate's tu.mtsIdx (MTS_DCT2_DCT2 = 0, MTS_SKIP = 1, MTS_DST7_DST7 = 2 ...); the sum of a
+// transform-skip candidate (sum |residual|) is scaled here as the reference scales it (:992-1001): int( sumAbs * scaleSAD ) with scaleSAD =
+// 2^trShift, times 1/1.414213562 when log2(width) + log2(height) is odd.
+int vtmhip_mts_select2( const int32_t *sumAbs, const uint8_t *mtsIdx, int numCand, int width, int height, int bitDepth, int maxLog2TrDynamicRange, int maxCand,
+                        uint8_t *test )
+{
+  if( !sumAbs || !mtsIdx || !test || numCand < 1 || numCand > 16 || width < 1 || height < 1 ) return VTMHIP_E_INVALID;
+  int lw = 0, lh = 0;
+  while( ( 2 << lw ) <= width ) lw++;
+  while( ( 2 << lh ) <= height ) lh++;
+  int32_t scaled[16];
+  for( int i = 0; i < numCand; i++ )
+  {
+    scaled[i] = sumAbs[i];
+    if( mtsIdx[i] == 1 )
+    {
+      double scaleSAD = 1.0;
+      if( ( lw + lh ) & 1 ) scaleSAD = 1.0 / 1.414213562;
+      const int trShift = maxLog2TrDynamicRange - bitDepth - ( ( lw + lh ) >> 1 );
+      scaleSAD *= pow( 2, trShift );
+      scaled[i] = ( int ) ( sumAbs[i] * scaleSAD );
+    }
+  }
+  return vtmhip_mts_select( scaled, numCand, width, height, maxCand, test );
 }
 
 // MTS candidate pre-selection thresholds (TrQuant::transformNxN( ..., trModes, maxCand ), TrQuant.cpp:950-1019): host arithmetic (fp64).
@@ -1016,7 +1150,7 @@ extern "C" int vtmhip_xT_uniform_batch_dev( vtmhip_ctx *ctx, const int16_t *d_re
   VTMHIP_REQUIRE( ctx, width >= 8 && width <= TB && height >= 8 && height <= TB && pow2( width ) && pow2( height ), "width / height: powers of two 8..64" );
   int st = ensure_tables( ctx );
   if( st ) return st;
-  return launch_tu_uni_sized( ctx, d_resiBase, d_jobs, n, width, height, nullptr, nullptr, d_results, g_tabs[ctx->device & 15], d_coefBase );
+  return launch_tu_uni_sized( ctx, d_resiBase, d_jobs, n, width, height, nullptr, nullptr, d_results, tabs_of( ctx ), d_coefBase );
 }
 
 

@@ -285,6 +285,10 @@ class Context:
     def tu_chain_batch(self, d_resi, d_jobs, n, max_w, max_h, d_results, d_levels=None, d_rec=None, uniform=False):
         self._check(self.L.vtmhip_tu_chain_batch_dev(self.h, d_resi, d_jobs, n, max_w, max_h, int(uniform), d_levels, d_rec, d_results))
 
+    def tu_ts_chain_batch(self, d_resi, d_jobs, n, w, h, d_results, d_levels=None, d_rec=None):
+        """transform-skip candidates (TuJob.typeHor == 3) of one TU size"""
+        self._check(self.L.vtmhip_tu_ts_chain_batch_dev(self.h, d_resi, d_jobs, n, w, h, d_levels, d_rec, d_results))
+
     def affine_sobel_batch(self, d_pred, d_deriv, d_jobs, n):
         self._check(self.L.vtmhip_affine_sobel_batch_dev(self.h, d_pred, d_deriv, d_jobs, n))
 
