@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- hot-path throughput on MI355X.
 
-One STEP = one pass of the implemented hot-path stages over ONE 3840x2160 10-bit inter picture of the
-random-access configuration (synthetic YUV, SURVEY.md 8d generator):
-  tz         integer TZ search (InterSearch::xTZSearch) for every square PU of the quadtree levels 128..8 against
-             2 reference pictures (L0/L1 at |dPOC| = 2 -> ASR search range 96), SAD with the FEN sub-sampling rule;
-             level L+1 starts from / predicts with the level-L vector of the enclosing block
-  frac       half + quarter sample refinement (xPatternSearchFracDIF, SATD) per (PU, list)
-  bi_search  FEN bi-pred iteration: MC of the other list, 2*org - pred, +-4 exhaustive search, fractional refinement
-  mc         final prediction (best uni list; bi via two 14-bit MCs + addAvg) and residual
-  resi       per TU (<= 64x64) and transform candidate (DCT2 + 4 MTS up to 32x32): xT, Quant::quant, dequant, xIT, SSE
+One STEP = one pass of the hot path over ONE 3840x2160 10-bit inter picture at the operating point of encoder_randomaccess_vtm.cfg
+(synthetic YUV, SURVEY.md 8d generator; B slice, 2 + 2 reference pictures at dPOC -2 -4 / +2 +4 -> ASR search range 96, FEN, QP 32), as the
+level-order form of InterSearch::predInterSearch + xEstimateInterResidualQT over the quadtree of square PUs 128..8 (vtm_amd/pipeline.py):
+  amvp     xEstimateMvPredAMVP (template cost of the AMVP candidates) per (PU, list, refIdx)
+  uni_me   xMotionEstimation per (PU, list, refIdx): xTZSearch (SAD, FEN sub-sampling) + xPatternSearchFracDIF (SATD) + rate re-weighting,
+           xCheckBestMVP, best reference picture per list
+  bi_me    the list with the larger cost refined for every refIdx against the other list's prediction (MC -> 2*org - pred, +-4 xPatternSearch,
+           fractional search), xCheckBestMVP, uni / bi decision
+  mc       chosen prediction (uni, or two 14-bit predictions + addAvg) and the residual
+  tu       per TU (<= 64x64) and transform candidate (DCT2 + 4 MTS pairs up to 32x32): xT, Quant::quant, dequant, xIT, SSE
 Inputs (original picture, border-extended reference planes, job tables) are resident in HBM before the timed region.
-With --gpus N each rank owns the 17 CTU rows of its own picture (N pictures in flight, weak scaling); the reference
-planes are re-broadcast from rank 0 over RCCL inside every step (the reconstructed-picture exchange of SURVEY.md 8e).
 
-Prints ONE JSON line (rank 0).  `value` = pictures/s of the stages listed in config.workload -- NOT a full encode.
-Extra keys: satd_gblocks_per_s (SURVEY.md 8d SATD-8x8 grid micro-benchmark, 81 displacements), roofline, cpu_baseline.
+--gpus N: the CTUs of the ONE picture are sharded over the N ranks (raster-scan CTU ranges: whole CTU rows plus one row cut at a CTU, so that
+510 CTUs split 64 / 63 per rank -- whole rows would give 3 / 2 rows and cap the speed-up at 71 %); the reference planes travel from rank 0 to
+every rank inside every step (RCCL broadcast over xGMI, double-buffered) and every rank's result records travel back to rank 0 (gather).
+STRONG scaling: `value` = pictures/s of the whole job.
+
+Prints ONE JSON line (rank 0).  `value` = pictures/s of the stages above -- NOT a full encode (the CU recursion, CABAC and DepQuant are host work
+the path does not contain).  Extra keys: satd_gblocks_per_s (SURVEY.md 8d SATD-8x8 grid micro-benchmark, 81 displacements), roofline, cpu_baseline.
 """
 import argparse
 import json
@@ -28,6 +32,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SIMDS, CLOCK_HZ = 1024, 2.4e9          # 256 CUs x 4 SIMDs, peak shader clock (MI355X_MICROARCH.md)
+KERNELS = ("tz_search_kernel", "frac_search_sq_kernel", "full_search_sq_kernel", "full_search_kernel", "motion_comp_kernel", "tu_chain_uni_kernel",
+           "dist_uniform_kernel", "tu_ts_kernel")
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -36,22 +44,26 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--config", choices=["ra", "ldp"], default="ra", help="ra: B slices, --refs + --refs reference pictures, ASR search ranges; "
+                    "ldp: P slices, 4 list-0 pictures, SearchRange 64 (encoder_lowdelay_P_vtm.cfg)")
+    ap.add_argument("--refs", type=int, default=2, help="ra: active reference pictures per list (1 = the round-1 operating point)")
+    ap.add_argument("--qp", type=int, default=32)
+    ap.add_argument("--transform-skip", action="store_true", help="add the MTS_SKIP candidate to the TU chains")
+    ap.add_argument("--shard", choices=["ctu", "row"], default="ctu", help="--gpus N: raster-scan CTU ranges (balanced) or whole CTU rows")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--serial", action="store_true", help="stage-major order on one stream (no overlap of the levels' chains): clean per-kernel times for profiling")
-    ap.add_argument("--graph", action="store_true", help="capture the picture's launches (fork/join over the side streams) into one hipGraph and replay it per "
-                    "step; measured slower than eager multi-stream launches (5.47 vs 5.13 ms per 4K picture), so off by default")
+    ap.add_argument("--serial", action="store_true", help="one stream, no overlap of the levels' chains: clean per-kernel times for profiling")
     return ap.parse_args()
 
 
-def cpu_baseline(hp, cur_np, dpb_np, refs, W, H, lam, qp, budget_s):
-    """Runs the SAME chain (tests/cpu_chain.py) for a bounded random sample of PUs of every level on one host core and
-    extrapolates to the picture.  kind "reference": the real VTM 9.3 xTZSearch / xPatternSearchFracDIF / xPatternSearch /
-    filterHor / filterVer / fastFwdTrans / fastInvTrans / distFunc (x86 SIMD) from oracle/_ref/libvtmref.so when it
-    travelled with the repo (quant/dequant: oracle port); otherwise kind "port": the plain-C oracle throughout.
+def cpu_baseline(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, budget_s):
+    """The SAME chain (tests/cpu_pis.py) for a bounded random sample of PUs of every level on one host core, extrapolated per level to the
+    picture.  kind "reference": every step through the real VTM 9.3 members compiled in place (xEstimateMvPredAMVP, xMotionEstimation,
+    xCheckBestMVP, filterHor / filterVer, removeHighFreq / addAvg, TrQuant::xT / xIT, distFunc with the x86 SIMD tables; quant / dequant: the
+    oracle port) from oracle/_ref/libvtmref.so when it travelled with the repo; otherwise kind "port": the plain-C oracle throughout.
     Every sampled PU is also compared with the GPU result."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import cpu_chain
+    import cpu_pis
     import oracle_lib as ol
     R = None
     if ol.have_ref():
@@ -59,22 +71,24 @@ def cpu_baseline(hp, cur_np, dpb_np, refs, W, H, lam, qp, budget_s):
             R = ol.ref()
         except OSError:
             R = None
-    snaps = cpu_chain.snapshot(hp)
+    snaps = hp.snapshot()
     rng = np.random.default_rng(7)
     total_s, done, mism, detail = 0.0, 0, 0, []
     per_level = budget_s / len(snaps)
-    for lvl in snaps:
-        s, npu, jobs = lvl["size"], lvl["npu"], lvl["jobs_np"]
-        order = rng.permutation(npu)
+    for li, lvl in enumerate(snaps):
+        s, npu = lvl["size"], lvl["npu"]
+        parent = snaps[li - 1] if li and snaps[li - 1]["size"] == 2 * s else None
         t_lvl, n_lvl = 0.0, 0
-        for i in order:
+        for i in rng.permutation(npu):
+            i = int(i)
+            cands = cpu_pis.cands_of(lvl, hp.nref, i)
             t0 = time.perf_counter()
-            out = cpu_chain.run_pu(cur_np, dpb_np.ctypes.data, refs[0][1], W, H, s, int(jobs["puX"][i]), int(jobs["puY"][i]),
-                                   (jobs[i], jobs[npu + i]), lam, (qp + 12) // 6, (qp + 12) % 6, ref=R)
+            out = cpu_pis.run_pu(cur_np, dpb_np.ctypes.data, refs, sr, W, H, s, int(lvl["xs"][i]), int(lvl["ys"][i]), cands, lam, (qp + 12) // 6, (qp + 12) % 6,
+                                 lvl["cands"], ref=R)
             t_lvl += time.perf_counter() - t0
             n_lvl += 1
             try:
-                cpu_chain.compare_with_device(lvl, int(i), out)
+                cpu_pis.compare_with_device(lvl, parent, hp.nref, i, out)
             except AssertionError:
                 mism += 1
             if t_lvl > per_level and n_lvl >= 4:
@@ -88,6 +102,13 @@ def cpu_baseline(hp, cur_np, dpb_np, refs, W, H, lam, qp, budget_s):
             "seconds_per_picture": total_s, "mismatches_vs_gpu": mism}
 
 
+def load_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
 def main():
     # The contract is ONE JSON line on stdout.  Libraries print banners there (RCCL writes its version block to stdout when the process
     # group comes up), so fd 1 is pointed at stderr for the whole run and the JSON line goes to the saved descriptor.
@@ -97,7 +118,7 @@ def main():
     a = parse()
     import torch
     import torch.distributed as dist
-    from vtm_amd import synth
+    from vtm_amd import pipeline, synth
     from vtm_amd.device import Context
     from vtm_amd.pipeline import FrameHotPath
 
@@ -106,8 +127,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # VTM_BENCH_FORCE_DIST=1: run the N > 1 code path (process group, reference-plane broadcast) with a single rank -- a functional check
-    # of that path on a one-GPU box
+    # VTM_BENCH_FORCE_DIST=1: the N > 1 code path (process group, plane broadcast, result gather) with a single rank -- a functional check on a one-GPU box
     force_dist = world == 1 and a.gpus == 1 and os.environ.get("VTM_BENCH_FORCE_DIST") == "1"
     if force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -124,62 +144,57 @@ def main():
     dev = torch.device("cuda", local)
     W, H = a.width, a.height
 
-    # ---- synthetic picture set: cur = frame 2, refs = frames 0 and 4 (|dPOC| = 2) ---------------------------------
-    frames = synth.gen_frames(W, H, 5)
-    cur_np = np.ascontiguousarray(frames[2])
-    planes, refs, off_acc = [], [], 0
-    for t in (0, 4):
-        buf, off, stride = synth.extend_plane(frames[t], margin=160)
-        refs.append((off_acc + off, stride))
-        planes.append(buf.reshape(-1))
-        off_acc += buf.size
+    # ---- synthetic picture set and reference lists ------------------------------------------------------------------------------
+    if a.config == "ra":
+        cur_poc = 2 * a.refs
+        pocs = ([cur_poc - 2 * (k + 1) for k in range(a.refs)], [cur_poc + 2 * (k + 1) for k in range(a.refs)])
+        sr = tuple([pipeline.asr_search_range(p - cur_poc) for p in l] for l in pocs)   # Clip3(96, 384, (384 |dPOC| + 8) / 16), EncSlice.cpp:1127
+    else:
+        cur_poc = 4
+        pocs = ([3, 2, 1, 0], [])
+        sr = ([64] * 4, [])
+    frames = synth.gen_frames(W, H, max(pocs[0] + pocs[1] + [cur_poc]) + 1)
+    cur_np = np.ascontiguousarray(frames[cur_poc])
+    planes, refs, off_acc, seen = [], ([], []), 0, {}
+    for l in (0, 1):
+        for p in pocs[l]:
+            if p not in seen:
+                buf, off, stride = synth.extend_plane(frames[p], margin=160)
+                seen[p] = (off_acc + off, stride)
+                planes.append(buf.reshape(-1))
+                off_acc += buf.size
+            refs[l].append(seen[p])
     dpb_np = np.concatenate(planes)
     cur = torch.from_numpy(cur_np).to(dev)
     dpb = torch.from_numpy(dpb_np).to(dev)
 
     ctx = Context(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    sr = 96   # Clip3(MinSearchWindow 96, 384, (384*|dPOC| + 8)/16) for |dPOC| = 2 (EncSlice.cpp:1127)
-    lam, qp = 8.0, 32
-    fme = FrameHotPath(ctx, torch, dev, W, H, W, refs, [sr, sr], motion_lambda=lam, qp=qp)
-
-    # --graph: the launches of one picture are captured ONCE into a hipGraph and replayed per step: same kernels, same dependencies, same
-    # buffers -- only the launch path changes (the 43 launches are not launch-bound; eager launches over the side streams are the default).
-    graph = None
-    if a.graph and not use_dist:   # with RCCL initialised its watchdog thread may touch the runtime during a capture: eager there
-        try:
-            fme.run(cur.data_ptr(), dpb.data_ptr())          # allocations / lazy initialisation happen outside the capture
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-                fme.run(cur.data_ptr(), dpb.data_ptr())
-            graph = g
-        except Exception as e:   # capture unsupported on this runtime: eager launches (identical work)
-            sys.stderr.write("hipGraph capture failed (%r); launching eagerly\n" % (e,))
-            graph = None
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
+    lam, qp = 8.0, a.qp
+    bands = pipeline.ctu_bands(W, H, world, unit=a.shard)
+    ctu_filter = pipeline.band_filter(W, bands[rank]) if world > 1 else None
+    fme = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, ctu_filter=ctu_filter, transform_skip=a.transform_skip)
 
     # N > 1: the reconstructed reference planes go from rank 0 to every GPU inside every step (RCCL broadcast over xGMI; bytes view: int16 is
-    # not a collective dtype).  Double-buffered: the planes of step k + 1 travel on RCCL's stream while step k computes on the planes that
-    # arrived before (the asynchronous collective starts after the launches already queued on the compute stream, i.e. after the step that
-    # last read its target buffer); a step's compute waits -- on the stream -- for its own planes.
-    from vtm_amd.exchange import PlaneExchange
+    # not a collective dtype), double-buffered: the planes of step k + 1 travel while step k computes; the ranks' result records go back to rank 0
+    # (gather), also asynchronously.  The timed region ends only after the last transfer of either kind has landed.
+    from vtm_amd.exchange import PlaneExchange, ResultGather
     xchg = PlaneExchange([dpb, dpb.clone()], src=0) if use_dist else None
+    res_t = fme.result_tensors()
+    gath = ResultGather(sum(t.numel() for t in res_t), dev, dst=0) if use_dist else None
 
-    def step(k=None):
+    def step():
         if xchg is not None:
             planes = xchg.next()
             fme.run(cur.data_ptr(), planes.data_ptr())
-        elif graph is not None:
-            graph.replay()
+            gath.submit(res_t)
         else:
             fme.run(cur.data_ptr(), dpb.data_ptr())
 
     def drain():
         if xchg is not None:
             xchg.drain()
+            gath.drain()
 
     for _ in range(a.warmup):
         step()
@@ -189,8 +204,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(a.steps):
-        step(k)
+    for _ in range(a.steps):
+        step()
     drain()
     torch.cuda.synchronize()
     if use_dist:
@@ -202,76 +217,104 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # per-stage kernel time: a separate, event-instrumented pass after the timed region (events between the launches of one step)
-    stage_acc = {}
-    for _ in range(3):
+    # ---- per-stage and per-kernel time: a separate, event-instrumented pass after the timed region ---------------------------------
+    # stage_ms: events between the steps of the serial order; kernel times: HIP events around every launch of the main kernels, recorded by the
+    # library on the stream the kernel is launched on (vtmhip_kernel_timing)
+    stage_acc, reps = {}, 3
+    ctx.kernel_timing(True)
+    for _ in range(reps):
         fme.run(cur.data_ptr(), dpb.data_ptr(), timing=True)
         torch.cuda.synchronize()
         for k2, v in fme.stage_ms().items():
-            stage_acc[k2] = stage_acc.get(k2, 0.0) + v / 3
-    evals = fme.stats()[0]
-    alg = fme.alg_bytes()
-    stages = {k2: ({"ms": stage_acc[k2], "alg_GBps": alg[k2] / stage_acc[k2] / 1e6} if k2 in alg else {"ms": stage_acc[k2]}) for k2 in stage_acc}
-    dom = max((k2 for k2 in stage_acc if k2 in alg), key=stage_acc.get)
-    dom_kernel = {"tz": "tz_search_kernel", "frac": "frac_search_sq_kernel", "full": "full_search_kernel", "mc": "motion_comp_kernel",
-                  "tu": "tu_chain"}[dom]
-    launches = {"tz": 1, "frac": 2, "full": 1, "mc": 2, "tu": 1}[dom] * len(fme.levels)
-    # HBM-side traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
-    # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null when the file is absent
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic_per_launch_KB.json")))
-        tot = sum((2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 * v.get("launches_per_step", 1) for k2, v in pmc.items()
-                  if k2.startswith(dom_kernel))
-        traffic = tot / launches if tot else None
-    except Exception:
-        pass
+            stage_acc[k2] = stage_acc.get(k2, 0.0) + v / reps
+    kern = {}
+    for k in KERNELS:
+        ms, n = ctx.kernel_timing_read(k)
+        if n:
+            kern[k] = {"ms_per_step": ms / reps, "launches_per_step": n // reps}
+    ctx.kernel_timing(False)
 
-    # ---- SATD 8x8 grid micro-benchmark (extra key; outside the timed steps) --------------------------------------
-    nb = (W // 8) * (H // 8)
-    satd_out = torch.empty(nb * 81, dtype=torch.int32, device=dev)
-    ref0_ptr = dpb.data_ptr() + 2 * refs[0][0]
+    # ---- SATD 8x8 grid micro-benchmark (extra key; outside the timed steps): each rank takes its band of 8-sample block rows ---------------
+    rows8 = H // 8
+    r0, r1 = (rows8 * rank) // world, (rows8 * (rank + 1)) // world
+    nb = (W // 8) * (r1 - r0)
+    satd_out = torch.empty(max(1, nb) * 81, dtype=torch.int32, device=dev)
+    ref0_ptr = dpb.data_ptr() + 2 * (refs[0][0][0] + r0 * 8 * refs[0][0][1])
+    cur_ptr = cur.data_ptr() + 2 * r0 * 8 * W
+    ctx.kernel_timing(True)
     for _ in range(2):
-        ctx.satd8_grid(cur.data_ptr(), W, ref0_ptr, refs[0][1], W, H, 4, satd_out.data_ptr())
+        ctx.satd8_grid(cur_ptr, W, ref0_ptr, refs[0][0][1], W, (r1 - r0) * 8, 4, satd_out.data_ptr())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
-        ctx.satd8_grid(cur.data_ptr(), W, ref0_ptr, refs[0][1], W, H, 4, satd_out.data_ptr())
+        ctx.satd8_grid(cur_ptr, W, ref0_ptr, refs[0][0][1], W, (r1 - r0) * 8, 4, satd_out.data_ptr())
     e1.record()
     torch.cuda.synchronize()
     satd_ms = e0.elapsed_time(e1) / 10
+    satd_k_ms, satd_k_n = ctx.kernel_timing_read("satd8_grid_kernel")
+    ctx.kernel_timing(False)
     satd_g = torch.tensor([nb * 81 / satd_ms / 1e6], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(satd_g)
 
     if rank == 0:
+        wc = fme.work_counts()
+        # ---- roofline of the dominant kernel: vector-ALU ISSUE (these kernels are integer / packed-16-bit instruction streams; their HBM traffic is
+        # a few per cent of the 8 TB/s: DESIGN.md section 4).  insts = SQ_INSTS_VALU per step from the committed PMC pass of this workload
+        # (profiles/pmc_insts_per_launch.json), priced with the kernel's measured issue cost per instruction (scripts/valu_issue.hip micro-benchmark
+        # x static instruction mix, profiles/isa_mix.json); peak = what 1024 SIMDs issue at 2.4 GHz; the kernel time is measured live (HIP events).
+        mix, pmc_i, pmc_b = load_json("isa_mix.json") or {}, load_json("pmc_insts_per_launch.json") or {}, load_json("pmc_hbm_traffic_per_launch_KB.json") or {}
+        dom = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
+
+        def issue_roofline(name, ms, launches):
+            cpi = next((v["cycles_per_valu_inst"] for k, v in mix.items() if isinstance(v, dict) and k.startswith(name)), None)
+            insts = sum(v.get("SQ_INSTS_VALU", 0) * v.get("launches_per_step", 1) for k, v in pmc_i.items() if k.startswith(name)) or None
+            traffic = sum((2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 * v.get("launches_per_step", 1) for k, v in pmc_b.items() if k.startswith(name)) or None
+            r = {"bound": "valu_issue", "kernel": name, "unit": "G wave-instructions/s", "ms_per_step": ms, "launches_per_step": launches,
+                 "ms_per_launch": ms / max(1, launches), "insts": insts, "cycles_per_inst": cpi, "traffic": (traffic / launches) if traffic else None}
+            if cpi:
+                r["peak"] = SIMDS * CLOCK_HZ / cpi / 1e9
+            if insts and cpi and world == 1 and (W, H) == (3840, 2160):
+                r["achieved"] = insts / (ms * 1e-3) / 1e9
+                r["frac"] = r["achieved"] / r["peak"]
+            else:
+                r["achieved"], r["frac"] = None, None
+            if traffic:
+                r["hbm_GBps"] = traffic / (ms * 1e-3) / 1e9
+                r["hbm_frac"] = r["hbm_GBps"] / 8000.0
+            r["note"] = ("insts = SQ_INSTS_VALU per step (committed rocprofv3 --pmc pass of this command, profiles/); cycles_per_inst = the kernel's static loop-weighted "
+                         "instruction mix priced with the measured gfx950 issue costs (2.1 cycles full-rate, 4.1 half-rate opcodes; profiles/r02_valu_issue.jsonl, "
+                         "profiles/isa_mix.json); peak = 1024 SIMDs x 2.4 GHz / cycles_per_inst; time measured live with HIP events on the launch stream; "
+                         "traffic = HBM-side bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE)")
+            return r
+
         out = {
-            "metric": "hot-path pictures/sec (3840x2160 randomaccess QP32; stages: TZ integer ME, fractional ME, bi-pred refinement, MC, residual xT/quant/xIT/SSE; not a full encode) + SATD Gblocks/s",
-            "value": world * a.steps / dt, "unit": "pictures/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "hot-path pictures/sec (3840x2160 randomaccess QP32; level-order predInterSearch: AMVP estimation, TZ + fractional ME per (list, refIdx), bi refinement, "
+                      "MC, residual xT/quant/xIT/SSE; not a full encode) + SATD Gblocks/s",
+            "value": a.steps / dt, "unit": "pictures/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int16 samples, int32 accumulation (fp64 MV-rate multiply)", "data": "synthetic",
-            "config": {"workload": "%dx%d 10-bit, encoder_randomaccess_vtm.cfg operating point (QP32, SR 96 via ASR, FEN subsampling): "
-                                   "quadtree PUs 128..8 x 2 refs = %d integer searches + %d fractional + %d bi-pred refinements/picture, %d TU x transform-candidate chains"
-                                   % (W, H, fme.n_jobs, fme.n_jobs, fme.n_jobs // 2, sum(l["ntu"] * l["nc"] for l in fme.levels)),
-                       "stages": ["tz_search", "frac_search", "bi-pred refinement (mc+removeHighFreq fused, full_search, frac_search)", "final uni/bi prediction + residual (fused)",
-                                  "tu_chain (xT, quant, dequant, xIT, SSE)"], "launch": "hipGraph replay" if graph is not None else "eager",
-                       "order": "stage-major, one stream" if a.serial else "level-major over 5 side streams (each level's stages start when its integer search is done)",
-                       "pictures_in_flight": world, "parallelism": "ctu-rows: 1 picture (17 CTU rows) per GPU"},
+            "config": {"workload": "%dx%d 10-bit, %s operating point (QP%d, %s, FEN): quadtree PUs 128..8 = %d PUs x (%d + %d) reference pictures = %d uni searches + %d bi searches "
+                                   "per picture, %d TU x transform-candidate chains"
+                                   % (W, H, "encoder_randomaccess_vtm.cfg" if a.config == "ra" else "encoder_lowdelay_P_vtm.cfg", qp,
+                                      "SR 96 via ASR" if a.config == "ra" else "SR 64", wc["pus"] * world if world > 1 else wc["pus"], len(refs[0]), len(refs[1]),
+                                      wc["uni_searches"], wc["bi_searches"], wc["tu_chains"]) + (" (this rank's share)" if world > 1 else ""),
+                       "stages": ["xEstimateMvPredAMVP", "xMotionEstimation uni (TZ + frac)", "xCheckBestMVP / best reference", "bi refinement (MC + removeHighFreq fused, xPatternSearch, frac)",
+                                  "uni/bi decision", "final prediction + residual (fused)", "tu_chain (xT, quant, dequant, xIT, SSE)"],
+                       "order": "one stream" if a.serial else "level-major over 5 side streams (each level's later stages run beside the next levels' searches)",
+                       "parallelism": ("1 GPU" if world == 1 else "one picture, CTUs sharded over %d GPUs (%s): bands %s; planes broadcast from rank 0, results gathered to rank 0 every step"
+                                       % (world, "raster-scan CTU ranges" if a.shard == "ctu" else "whole CTU rows", [b[1] - b[0] for b in bands]))},
             "satd_gblocks_per_s": float(satd_g.item()),
-            "tz_candidates_per_picture": evals,
-            "stages": stages,
-            "roofline": {"bound": "hbm", "kernel": dom_kernel, "stage": dom, "achieved": stages[dom]["alg_GBps"], "peak": 8000.0, "unit": "GB/s",
-                         "frac": stages[dom]["alg_GBps"] / 8000.0, "traffic": traffic, "launches_per_step": launches,
-                         "achieved_per_launch_bytes": alg[dom] / launches, "ms_per_launch": stage_acc[dom] / launches,
-                         "note": "dominant kernel family of the step by time; achieved = algorithmic bytes (DESIGN.md section 5) / kernel time, both per "
-                                 "launch averaged over its %d launches/step, timed in the stage-major pass (one stream, no overlap between the levels' chains): "
-                                 "%.3f ms of %.3f ms there; traffic = HBM-side bytes per launch from the committed PMC passes (profiles/)"
-                                 % (launches, stage_acc[dom], sum(stage_acc.values()))},
-            "satd_roofline": {"bound": "hbm", "kernel": "satd8_grid_kernel", "achieved": nb * 81 * 256 / satd_ms / 1e6, "peak": 8000.0,
-                              "unit": "GB/s", "frac": nb * 81 * 256 / satd_ms / 1e6 / 8000.0, "ms": satd_ms},
+            "stages_ms": stage_acc, "kernels": kern,
         }
+        if dom:
+            out["roofline"] = issue_roofline(dom, kern[dom]["ms_per_step"], kern[dom]["launches_per_step"])
+        if satd_k_n:
+            r = issue_roofline("satd8_grid_kernel", satd_k_ms / satd_k_n, 1)
+            r["pairs_per_s_G"] = nb * 81 / (satd_k_ms / satd_k_n) / 1e6
+            out["satd_roofline"] = r
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fme, cur_np, dpb_np, refs, W, H, lam, qp, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(fme, cur_np, dpb_np, refs, sr, W, H, lam, qp, a.cpu_seconds)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()

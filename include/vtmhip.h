@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define VTMHIP_ABI_VERSION 1
+#define VTMHIP_ABI_VERSION 2
 
 enum
 {
@@ -78,6 +78,13 @@ int vtmhip_d2h( vtmhip_ctx *ctx, void *host, const void *dev, size_t bytes );   
 /* stream timing with HIP events (bench.py uses this around the timed region) */
 int vtmhip_timer_start( vtmhip_ctx *ctx );
 int vtmhip_timer_stop_ms( vtmhip_ctx *ctx, float *ms );   /* synchronises */
+
+/* per-kernel launch timing: while enabled, every launch of the library's main kernels (tz_search_kernel, full_search_kernel, full_search_sq_kernel,
+ * frac_search_sq_kernel, frac_search_kernel, motion_comp_kernel, tu_chain_uni_kernel, tu_ts_kernel, dist_uniform_kernel, satd8_grid_kernel) is
+ * bracketed by HIP events on the stream it is launched on.  vtmhip_kernel_timing( ctx, 1 ) clears the record and starts, ( ctx, 0 ) stops;
+ * _read synchronises the device and returns the summed duration and the number of launches of one kernel since the start. */
+int vtmhip_kernel_timing( vtmhip_ctx *ctx, int enable );
+int vtmhip_kernel_timing_read( vtmhip_ctx *ctx, const char *kernel, double *totalMs, int *launches );
 
 /* ================================================================================================================
  * (1) POINTER-SURFACE CALLS -- host pointers
@@ -273,6 +280,12 @@ typedef struct
   uint8_t firstSearchStop;         /* FastMEAssumingSmootherMVEnabled */
   int32_t uniformImv;              /* -1: jobs mix cu.imv values; 0..3: every job of the batch has this cu.imv (lets whole stages be skipped) */
   int32_t uniformSquare;           /* != 0: every job is maxWidth x maxWidth (tiled fractional kernel when uniformImv is 0 or 3) */
+  int32_t uniformBi;               /* 0: jobs mix bBi values; 1: every job is a uni search (no pattern copies: the searches read the original plane);
+                                      2: every job is a bi search (no TZ stage; lane-per-candidate exhaustive kernel when uniformSquare) */
+  uint8_t noUniMvList;             /* caller's promise: numExtraStart == 0 in every job (with uniformBi 2 the start-candidate SADs are skipped: rcMv is the start) */
+  uint8_t biPatternGiven;          /* with uniformBi 2: d_otherPredBase + otherPredOff already holds the search pattern 2*org - otherPred (a fused
+                                      vtmhip_motion_compensation_batch_dev epilogue wrote it), not the other list's prediction: no removeHighFreq pass here */
+  uint8_t pad0, pad1;
 } vtmhip_me_cfg;
 
 typedef struct
@@ -308,6 +321,16 @@ typedef struct
 int vtmhip_xMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg *cfg, const int16_t *d_orgBase,
                                         const int16_t *d_refBase, const int16_t *d_otherPredBase, const vtmhip_me_job *d_jobs, int n,
                                         int maxWidth, int maxHeight, vtmhip_me_out *d_results );
+
+/* ---- AMVP predictor estimation: InterSearch::xEstimateMvPredAMVP with xGetTemplateCost (hook B7) ----------------------------------
+ * (InterSearch.cpp:3088-3128, 3235-3270; caller predInterSearch :2367).  For each of the n (PU, list, refIdx) rows and each of its
+ * numAmvpCand candidates (amvpCand, already filled -- bFilled): clipMv, uni-directional luma prediction at the candidate (xPredInterBlk, rounded
+ * and clipped), SAD against the original block + getCost( mvpIdxBits[i] ); the FIRST candidate with the smallest cost wins (`uiBestCost >
+ * uiTmpCost`).  In place: mvPredHor / mvPredVer (the unclipped candidate), mvpIdx; with addIdxBits the winner's index bits are added to `bits`
+ * as predInterSearch does right after the call (:2381).  d_distBiP (may be NULL): the winning template cost per row (*puiDistBiP).
+ * uniformSize != 0: every row is maxWidth x maxHeight (uniform SAD kernel). */
+int vtmhip_xEstimateMvPredAMVP_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                          vtmhip_me_job *d_jobs, int n, int maxWidth, int maxHeight, int uniformSize, int addIdxBits, uint64_t *d_distBiP );
 
 /* ---- motion compensation / bi-pred buffer ops ------------------------------------------------------------------------ */
 typedef struct
@@ -615,6 +638,70 @@ typedef struct
 /* stage 0: after the uni fractional searches -> predOther / full / fracBi;  1: after the exhaustive refinement -> fracBi.intX/Y;
  * 2: after the bi fractional search -> predFinal (mode, vectors), biMv, costBi, useBi */
 int vtmhip_frame_stage( vtmhip_ctx *ctx, const vtmhip_frame_tabs *tabs, int stage );
+
+/* ================================================================================================================
+ * (4) LEVEL-ORDER predInterSearch -- InterSearch::predInterSearch (InterSearch.cpp:2245-3065, translational part: cu.imv 0, default
+ *     BCW weight, no SMVD / affine) for ALL PUs of one block size at once, on top of the batched calls above
+ * ==============================================================================================================
+ * One PU of the reference runs: for every (list, refIdx): xEstimateMvPredAMVP, xMotionEstimation, xCheckBestMVP, best reference per list
+ * (:2354-2450); B slices: the list with the larger cost is refined against the other list's prediction for every refIdx (one iteration:
+ * FASTINTERSEARCH_MODE1, :2544-2556), xCheckBestMVP, then the uni / bi decision (:2846-2893).  A level-order driver issues the same steps as
+ * batched launches over all PUs of a level; these helpers are the per-PU arithmetic in between (one thread per PU / row), so that nothing
+ * returns to the host.  Rows of the uni tables are ordered (list, refIdx)-major, PU-minor: row = (list ? numRef[0] : 0) + refIdx) * numPU + pu;
+ * rows of the bi tables: refIdx * numPU + pu.  What stands in for the CU recursion: the two AMVP candidates of a row are the enclosing
+ * parent block's vector for the same (list, refIdx) and the zero vector (the reference derives them from neighbouring CUs). */
+#define VTMHIP_MAX_REF 4
+
+typedef struct
+{
+  int32_t  mvHor, mvVer;           /* cMvTemp[list][refIdx] */
+  int32_t  mvPredHor, mvPredVer;   /* cMvPred[list][refIdx] after xCheckBestMVP */
+  int32_t  mvpIdx;                 /* aaiMvpIdx */
+  uint32_t bits;                   /* uiBitsTemp */
+  uint64_t cost;                   /* uiCostTemp */
+} vtmhip_pis_row;
+
+typedef struct
+{
+  uint64_t cost[2];                /* uiCost[list] (max when the list is empty) */
+  uint64_t costBi;                 /* uiCostBi */
+  uint32_t bits[3];                /* uiBits */
+  int32_t  refIdx[2];              /* iRefIdx */
+  int32_t  mv[2][2];               /* cMv */
+  int32_t  refIdxBi[2];            /* iRefIdxBi */
+  int32_t  mvBi[2][2];             /* cMvBi */
+  int32_t  refineList;             /* the list the bi stage searched */
+  int32_t  interDir;               /* pu.interDir: 1 list 0, 2 list 1, 3 bi-prediction */
+  int32_t  pad;
+} vtmhip_pis_pu;
+
+typedef struct
+{
+  int32_t  numPU;
+  int32_t  numRef[2];              /* slice.getNumRefIdx(); numRef[1] == 0: P slice */
+  int32_t  smvdBit;                /* slice.getBiDirPred(): one more bit on the bi rows (:2590-2593) */
+  uint32_t mbBits[3];              /* xGetBlkBits (:3164-3169) */
+  int32_t  refStride;
+  int64_t  refPlaneOff[2][VTMHIP_MAX_REF];   /* sample offset of each reference plane's (0,0) inside d_refBase */
+  vtmhip_me_job        *uniJobs;   /* [(numRef[0] + numRef[1]) * numPU]: static fields by the host, candidates / bits by stage 0 */
+  const vtmhip_me_out  *uniOut;
+  vtmhip_pis_row       *uniRows;
+  vtmhip_pis_pu        *pus;       /* [numPU] */
+  vtmhip_pred_job      *predOther; /* [numPU]: static fields by the host; mode / refOff / mv by stage 2 */
+  vtmhip_me_job        *biJobs;    /* [numRef[refined list] * numPU] (numRef[0] == numRef[1] in B slices here) */
+  const vtmhip_me_out  *biOut;
+  vtmhip_pred_job      *predFinal; /* [numPU] */
+  const int32_t        *parentIdx; /* [numPU] PU index in the parent level, or -1 (NULL: no parent level) */
+  const vtmhip_pis_row *parentRows;/* the parent level's uniRows */
+  int32_t  parentNumPU, pad;
+  const int64_t        *pos;       /* [numPU] y * refStride + x */
+} vtmhip_pis_level;
+
+/* stage 0: AMVP candidates and entry bits of the uni rows (before vtmhip_xEstimateMvPredAMVP_batch_dev)
+ * stage 1: after the uni searches: xCheckBestMVP per row, best reference per list; P slices: interDir and predFinal
+ * stage 2: B slices: refined list, predOther (the other list's prediction, epilogue as the host set it), the bi rows
+ * stage 3: after the bi searches: xCheckBestMVP, best bi row, decision, predFinal */
+int vtmhip_pis_stage( vtmhip_ctx *ctx, const vtmhip_pis_level *lvl, int stage );
 
 #ifdef __cplusplus
 }

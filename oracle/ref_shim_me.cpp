@@ -290,9 +290,9 @@ extern "C" void ref_motion_estimation( const vo_mest_cfg_t *cfg, const vo_mest_j
   if( !storage )
   {
     const UnitArea lcu( CHROMA_400, Area( 0, 0, MAX_CU_SIZE, MAX_CU_SIZE ) );
-    r.is.m_tmpStorageLCU.create( lcu );
-    r.is.m_tmpPredStorage[0].create( lcu );
-    r.is.m_tmpPredStorage[1].create( lcu );
+    if( r.is.m_tmpStorageLCU.bufs.empty() ) r.is.m_tmpStorageLCU.create( lcu );
+    if( r.is.m_tmpPredStorage[0].bufs.empty() ) r.is.m_tmpPredStorage[0].create( lcu );
+    if( r.is.m_tmpPredStorage[1].bufs.empty() ) r.is.m_tmpPredStorage[1].create( lcu );
     storage = true;
   }
   r.sps.setMaxCUWidth( j->ctuSize );
@@ -777,4 +777,80 @@ extern "C" int ref_transformNxN_select( const int16_t *resi, int stride, int w, 
   g_trRig->tq.transformNxN( tu, COMPONENT_Y, cQP, &modes, maxCand );
   for( int i = 0; i < numCand; i++ ) test[i] = modes[i].second;
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The AMVP helpers of predInterSearch as the real members: InterSearch::xEstimateMvPredAMVP (:3088-3128, bFilled = true: the
+// candidates are the caller's) with xGetTemplateCost (:3235-3270), and xCheckBestMVP (:3185-3232).  Same rig as ref_motion_estimation.
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" void ref_estimate_mvp_amvp( const vo_mest_job_t *j, int *mvpIdx, int *mvPredHor, int *mvPredVer, uint64_t *distBiP )
+{
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  static Picture *pic = nullptr;
+  static bool     storage = false;
+  if( !pic ) pic = new Picture();
+  if( !storage )
+  {
+    const UnitArea lcu( CHROMA_400, Area( 0, 0, MAX_CU_SIZE, MAX_CU_SIZE ) );
+    if( r.is.m_tmpStorageLCU.bufs.empty() ) r.is.m_tmpStorageLCU.create( lcu );
+    storage = true;
+  }
+  r.sps.setMaxCUWidth( j->ctuSize );
+  r.sps.setMaxCUHeight( j->ctuSize );
+  r.sps.setBitDepth( CHANNEL_TYPE_LUMA, j->bitDepth );
+  r.pps.setPicWidthInLumaSamples( j->picW );
+  r.pps.setPicHeightInLumaSamples( j->picH );
+  r.pps.setUseWP( false );
+  r.pps.setWPBiPred( false );
+  r.slice.setPPS( &r.pps );
+  r.slice.setSPS( &r.sps );
+  r.slice.setSliceType( B_SLICE );
+  const UnitArea ua( CHROMA_400, Area( j->puX, j->puY, j->w, j->h ) );
+  r.cu.UnitArea::operator=( ua );
+  r.pu.UnitArea::operator=( ua );
+  r.cu.chromaFormat = CHROMA_400;
+  r.pu.chromaFormat = CHROMA_400;
+  r.cu.imv    = j->imv;
+  r.cu.BcwIdx = BCW_DEFAULT;
+  r.cu.affine = false;
+  r.rd.m_motionLambda = j->motionLambda;
+  ClpRng clp; clp.min = 0; clp.max = ( 1 << j->bitDepth ) - 1; clp.bd = j->bitDepth; clp.n = 0;
+  r.slice.m_clpRngs.comp[COMPONENT_Y] = clp;
+  Pel *origin = const_cast<Pel *>( j->ref ) - ( ptrdiff_t ) j->puY * j->refStride - j->puX;
+  pic->chromaFormat = CHROMA_400;
+  pic->unscaledPic  = pic;
+  pic->m_bufs[PIC_RECONSTRUCTION].createFromBuf( PelUnitBuf( CHROMA_400, PelBuf( origin, j->refStride, j->picW, j->picH ) ) );
+  r.slice.m_apcRefPicList[REF_PIC_LIST_0][0] = pic;
+  for( int i = 0; i < 2; i++ ) r.is.m_auiMVPIdxCost[i][AMVP_MAX_NUM_CANDS] = j->mvpIdxBits[i];
+  AMVPInfo amvp;
+  amvp.numCand = j->numAmvpCand;
+  for( int i = 0; i < 2; i++ ) amvp.mvCand[i] = Mv( j->amvpCand[i][0], j->amvpCand[i][1] );
+  PelUnitBuf origBuf( CHROMA_400, PelBuf( const_cast<Pel *>( j->org ), j->orgStride, j->w, j->h ) );
+  Mv         mvPred;
+  Distortion dist = 0;
+  r.is.xEstimateMvPredAMVP( r.pu, origBuf, REF_PIC_LIST_0, 0, mvPred, amvp, true, &dist );
+  *mvpIdx = r.pu.mvpIdx[REF_PIC_LIST_0]; *mvPredHor = mvPred.hor; *mvPredVer = mvPred.ver; *distBiP = dist;
+  r.cu.imv = 0;
+  r.cu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+  r.pu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+  r.cu.chromaFormat = CHROMA_420;
+  r.pu.chromaFormat = CHROMA_420;
+}
+
+extern "C" void ref_check_best_mvp( double motionLambda, int imv, int numCand, const int cands[2][2], const unsigned idxBits[2], int mvHor, int mvVer,
+                                    int *mvPredHor, int *mvPredVer, int *mvpIdx, unsigned *bits, uint64_t *cost )
+{
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  r.rd.m_motionLambda = motionLambda;
+  for( int i = 0; i < 2; i++ ) r.is.m_auiMVPIdxCost[i][AMVP_MAX_NUM_CANDS] = idxBits[i];
+  AMVPInfo amvp;
+  amvp.numCand = numCand;
+  for( int i = 0; i < 2; i++ ) amvp.mvCand[i] = Mv( cands[i][0], cands[i][1] );
+  Mv         pred( *mvPredHor, *mvPredVer );
+  uint32_t   b = *bits;
+  Distortion c = *cost;
+  r.is.xCheckBestMVP( REF_PIC_LIST_0, Mv( mvHor, mvVer ), pred, *mvpIdx, amvp, b, c, ( uint8_t ) imv );
+  *mvPredHor = pred.hor; *mvPredVer = pred.ver; *bits = b; *cost = c;
 }

@@ -1757,3 +1757,53 @@ void vo_motion_estimation( const vo_mest_cfg_t *cfg, const vo_mest_job_t *j, vo_
   }
   free( tmp );
 }
+
+
+/* ---- AMVP helpers of predInterSearch ---------------------------------------------------------------------------------------------- */
+
+void vo_estimate_mvp_amvp( const vo_mest_job_t *j, int *mvpIdx, int *mvPredHor, int *mvPredVer, uint64_t *distBiP )
+{
+  /* InterSearch.cpp:3088-3128: iBestIdx = 0, cBestMv = mvCand[0]; for every candidate xGetTemplateCost; `uiBestCost > uiTmpCost` keeps the first minimum */
+  uint64_t best = UINT64_MAX;
+  int      bestIdx = 0;
+  static int16_t pred[128 * 128];
+  for( int i = 0; i < j->numAmvpCand; i++ )
+  {
+    /* xGetTemplateCost (:3235-3270): clipMv (clipMvInPic, Mv.cpp:56-74), xPredInterBlk uni-directional (rounded, clipped), DF_SAD + getCost( m_auiMVPIdxCost ) */
+    int       h = j->amvpCand[i][0], v = j->amvpCand[i][1];
+    const int horMax = ( j->picW + 8 - j->puX - 1 ) << 4, horMin = ( -j->ctuSize - 8 - j->puX + 1 ) << 4;
+    const int verMax = ( j->picH + 8 - j->puY - 1 ) << 4, verMin = ( -j->ctuSize - 8 - j->puY + 1 ) << 4;
+    h = h > horMax ? horMax : ( h < horMin ? horMin : h );
+    v = v > verMax ? verMax : ( v < verMin ? verMin : v );
+    vo_mc_luma( j->ref, j->refStride, j->w, j->h, h, v, 0, j->bitDepth, j->imv == 3, pred, j->w );
+    const uint64_t cost = vo_sad( j->org, j->orgStride, pred, j->w, j->w, j->h, 0 ) + ( uint64_t ) ( j->motionLambda * j->mvpIdxBits[i] );
+    if( best > cost ) { best = cost; bestIdx = i; }
+  }
+  *mvpIdx = bestIdx; *mvPredHor = j->amvpCand[bestIdx][0]; *mvPredVer = j->amvpCand[bestIdx][1]; *distBiP = best;
+}
+
+void vo_check_best_mvp( double motionLambda, int imv, int numCand, const int cands[2][2], const unsigned idxBits[2], int mvHor, int mvVer,
+                        int *mvPredHor, int *mvPredVer, int *mvpIdx, unsigned *bits, uint64_t *cost )
+{
+  /* InterSearch.cpp:3185-3232 */
+  if( imv > 0 && imv < 3 ) return;
+  if( numCand < 2 ) return;
+  const int sh = vo_amvr_shift( imv );
+  const int mh = vo_prec_down( mvHor, sh ), mv = vo_prec_down( mvVer, sh );
+  const int orgBits = ( int ) ( vo_eg_bits( mh - vo_prec_down( *mvPredHor, sh ) ) + vo_eg_bits( mv - vo_prec_down( *mvPredVer, sh ) ) + idxBits[*mvpIdx] );
+  int bestBits = orgBits, bestIdx = *mvpIdx;
+  for( int i = 0; i < numCand; i++ )
+  {
+    if( i == *mvpIdx ) continue;
+    const int b = ( int ) ( vo_eg_bits( mh - vo_prec_down( cands[i][0], sh ) ) + vo_eg_bits( mv - vo_prec_down( cands[i][1], sh ) ) + idxBits[i] );
+    if( b < bestBits ) { bestBits = b; bestIdx = i; }
+  }
+  if( bestIdx != *mvpIdx )
+  {
+    *mvPredHor = cands[bestIdx][0]; *mvPredVer = cands[bestIdx][1];
+    *mvpIdx = bestIdx;
+    const unsigned org = *bits;
+    *bits = org - ( unsigned ) orgBits + ( unsigned ) bestBits;
+    *cost = ( *cost - ( uint64_t ) ( motionLambda * org ) ) + ( uint64_t ) ( motionLambda * *bits );
+  }
+}

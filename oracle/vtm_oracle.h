@@ -166,6 +166,13 @@ typedef struct
 
 void vo_motion_estimation( const vo_mest_cfg_t *cfg, const vo_mest_job_t *job, vo_mest_result_t *res );
 
+/* InterSearch::xEstimateMvPredAMVP with bFilled = true (InterSearch.cpp:3088-3128) and xGetTemplateCost (:3235-3270): SAD of the
+ * uni-directional luma prediction at each (clipped) AMVP candidate + getCost( mvpIdxBits ); first candidate with the smallest cost */
+void vo_estimate_mvp_amvp( const vo_mest_job_t *job, int *mvpIdx, int *mvPredHor, int *mvPredVer, uint64_t *distBiP );
+/* InterSearch::xCheckBestMVP (:3185-3232): in / out predictor, index, bits, cost */
+void vo_check_best_mvp( double motionLambda, int imv, int numCand, const int cands[2][2], const unsigned idxBits[2], int mvHor, int mvVer,
+                        int *mvPredHor, int *mvPredVer, int *mvpIdx, unsigned *bits, uint64_t *cost );
+
 #ifdef __cplusplus
 }
 #endif

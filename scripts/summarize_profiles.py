@@ -69,6 +69,28 @@ def main():
             e = pmc.setdefault(k, {})
             e[cnt] = sum(v) / len(v)
             e["launches_per_step"] = len(v) // steps
+    # dynamic instruction counters per launch shape (the valu_issue roofline of bench.py prices SQ_INSTS_VALU)
+    pi = os.path.join(go, f"pmc_{tag}_INSTS", "bench_counter_collection.csv")
+    if os.path.exists(pi):
+        per_dispatch = collections.OrderedDict()
+        for r in csv.DictReader(open(pi)):
+            k = (f"{short(r['Kernel_Name'])}|grid={r['Grid_Size']}", r["Dispatch_Id"], r["Counter_Name"])
+            per_dispatch[k] = per_dispatch.get(k, 0.0) + float(r["Counter_Value"])
+        shape = collections.OrderedDict()
+        for (k, _, cnt), v in per_dispatch.items():
+            shape.setdefault(k, {}).setdefault(cnt, []).append(v)
+        insts = collections.OrderedDict()
+        for k, d in shape.items():
+            if k.startswith("native"):
+                continue
+            e = {cnt: sum(v) / len(v) for cnt, v in d.items()}
+            e["launches_per_step"] = max(1, len(next(iter(d.values()))) // steps)
+            if e.get("SQ_WAVES"):
+                e["valu_per_wave"] = e.get("SQ_INSTS_VALU", 0) / e["SQ_WAVES"]
+                e["salu_per_wave"] = e.get("SQ_INSTS_SALU", 0) / e["SQ_WAVES"]
+            insts[k] = e
+        for name in (f"{tag}_pmc_insts_per_launch.json", "pmc_insts_per_launch.json"):
+            json.dump(insts, open(os.path.join(pr, name), "w"), indent=1)
     if pmc:
         for name in (f"{tag}_pmc_hbm_traffic_per_launch_KB.json", "pmc_hbm_traffic_per_launch_KB.json"):
             json.dump(pmc, open(os.path.join(pr, name), "w"), indent=1)

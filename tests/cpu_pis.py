@@ -1,0 +1,223 @@
+"""The level-order predInterSearch chain of ONE prediction unit on the CPU: the checker for vtm_amd.pipeline.FrameHotPath (tests) and the
+cpu_baseline of bench.py.  TEST INFRASTRUCTURE: drives the oracle (oracle/libvtmoracle.so) or, when `ref` is given, the REAL reference members
+compiled in place (oracle/_ref/libvtmref.so): InterSearch::xEstimateMvPredAMVP, xMotionEstimation (xTZSearch / xPatternSearch /
+xPatternSearchFracDIF inside), xCheckBestMVP, InterpolationFilter::filterHor / filterVer, PelBuf::removeHighFreq / addAvg, TrQuant::xT / xIT,
+DistParam::distFunc (x86 SIMD tables).  What this file itself restates is only the selection logic of predInterSearch between those calls
+(InterSearch.cpp:2354-2450 best reference per list, :2452-2640 the FEN bi iteration, :2846-2893 the decision)."""
+import ctypes as C
+
+import numpy as np
+
+import oracle_lib as ol
+from vtm_amd.pipeline import MTS_IDX_TYPES
+
+CFG = (4, 1, 1, 0, 1)   # BipredSearchRange 4, HadamardME, FEN (FASTINTERSEARCH_MODE1), diamond search, FastMEAssumingSmootherMV
+U64 = (1 << 64) - 1
+
+
+def _mc(L, R, ref_ptr, rs, s, mvx, mvy, bi, dst, bd=10):
+    """xPredInterBlk luma (InterPrediction.cpp:660-815) through the reference's filterHor / filterVer when available."""
+    if R is None:
+        L.vo_mc_luma(C.c_void_p(ref_ptr), rs, s, s, mvx, mvy, bi, bd, 0, ol.P(dst), s)
+        return
+    xf, yf, rnd = mvx & 15, mvy & 15, 0 if bi else 1
+    src = ref_ptr + 2 * ((mvy >> 4) * rs + (mvx >> 4))
+    if yf == 0:
+        R.ref_if_hor(1, 0, C.c_void_p(src), rs, ol.P(dst), s, s, s, xf, rnd, bd, 0, 0, 0)
+    elif xf == 0:
+        R.ref_if_ver(1, 0, C.c_void_p(src), rs, ol.P(dst), s, s, s, yf, 1, rnd, bd, 0, 0, 0)
+    else:
+        tmp = np.zeros((s + 7, s), np.int16)
+        R.ref_if_hor(1, 0, C.c_void_p(src - 2 * 3 * rs), rs, ol.P(tmp), s, s, s + 7, xf, 0, bd, 0, 0, 0)
+        R.ref_if_ver(1, 0, C.c_void_p(tmp.ctypes.data + 2 * 3 * s), s, ol.P(dst), s, s, s, yf, 0, rnd, bd, 0, 0, 0)
+
+
+def _ref_idx_bits(num_ref, r):
+    return (r + 1 - (1 if r == num_ref - 1 else 0)) if num_ref > 1 else 0
+
+
+def _mest_job(org, s, ref_ptr, rs, x, y, W, H, lam, sr, cands, bd=10):
+    t = ol.MestJob()
+    t.org, t.orgStride, t.ref, t.refStride = org.ctypes.data, s, ref_ptr, rs
+    t.w, t.h, t.puX, t.puY, t.picW, t.picH, t.ctuSize, t.bitDepth = s, s, x, y, W, H, 128, bd
+    t.imv, t.numAmvpCand, t.searchRange, t.motionLambda, t.numExtraStart = 0, 2, sr, lam, 0
+    for i in range(2):
+        t.amvpCand[i][0], t.amvpCand[i][1] = int(cands[i][0]), int(cands[i][1])
+        t.mvpIdxBits[i] = 1
+    return t
+
+
+def _check_best(L, R, lam, cands, row):
+    """xCheckBestMVP on row = dict(mv, pred, idx, bits, cost); returns the updated dict"""
+    ca = ((C.c_int * 2) * 2)((C.c_int * 2)(*[int(v) for v in cands[0]]), (C.c_int * 2)(*[int(v) for v in cands[1]]))
+    ib = (C.c_uint * 2)(1, 1)
+    ph, pv, idx, bits, cost = C.c_int(row["pred"][0]), C.c_int(row["pred"][1]), C.c_int(row["idx"]), C.c_uint(row["bits"]), C.c_uint64(row["cost"])
+    (R.ref_check_best_mvp if R else L.vo_check_best_mvp)(C.c_double(lam), 0, 2, ca, ib, row["mv"][0], row["mv"][1], C.byref(ph), C.byref(pv), C.byref(idx),
+                                                       C.byref(bits), C.byref(cost))
+    return dict(mv=row["mv"], pred=(ph.value, pv.value), idx=idx.value, bits=bits.value, cost=cost.value)
+
+
+def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam, qp_per, qp_rem, tu_cands, ref=None, bd=10):
+    """refs / search_ranges as FrameHotPath takes them; cands_rows[list][refIdx] = the two AMVP candidates of that row ((h, v), (h, v)) as the
+    device driver derived them from the parent level.  Returns every decision the device pipeline exposes."""
+    L, R = ol.oracle(), ref
+    cfg = ol.MestCfg(*CFG)
+    org = np.ascontiguousarray(cur_np[y:y + s, x:x + s])
+    nref = [len(refs[0]), len(refs[1])]
+    is_b = nref[1] > 0
+    mb = (3 if is_b else 1, 3, 5)
+    rs = refs[0][0][1]
+    out = dict(rows={}, amvp={})
+    best = [dict(cost=U64, bits=0, mv=(0, 0), ref=-1) for _ in range(2)]
+    rows, jobs = {}, {}
+    for l in (0, 1):
+        for r in range(nref[l]):
+            ref_ptr = dpb_ptr + 2 * (refs[l][r][0] + y * rs + x)
+            cands = cands_rows[l][r]
+            t = _mest_job(org, s, ref_ptr, rs, x, y, W, H, lam, search_ranges[l][r], cands, bd)
+            idx, ph, pv, dist = C.c_int(), C.c_int(), C.c_int(), C.c_uint64()
+            (R.ref_estimate_mvp_amvp if R else L.vo_estimate_mvp_amvp)(C.byref(t), C.byref(idx), C.byref(ph), C.byref(pv), C.byref(dist))
+            out["amvp"][(l, r)] = (idx.value, ph.value, pv.value)
+            t.bi, t.mvpIdx, t.mvPredHor, t.mvPredVer = 0, idx.value, ph.value, pv.value
+            t.bits = mb[l] + _ref_idx_bits(nref[l], r) + 1
+            res = ol.MestResult()
+            (R.ref_motion_estimation if R else L.vo_motion_estimation)(C.byref(cfg), C.byref(t), C.byref(res))
+            row = dict(mv=(res.mvHor, res.mvVer), pred=(res.mvPredHor, res.mvPredVer), idx=res.mvpIdx, bits=res.bits, cost=res.cost)
+            out["rows"][(l, r, "me")] = dict(row)
+            row = _check_best(L, R, lam, cands, row)
+            rows[(l, r)], jobs[(l, r)] = row, t
+            out["rows"][(l, r)] = row
+            if row["cost"] < best[l]["cost"]:
+                best[l] = dict(cost=row["cost"], bits=row["bits"], mv=row["mv"], ref=r)
+    out["best"] = best
+    mv_final, ref_final = [best[0]["mv"], best[1]["mv"]], [best[0]["ref"], best[1]["ref"]]
+    inter_dir = 1
+    if is_b:
+        rl = 1 if best[0]["cost"] <= best[1]["cost"] else 0
+        ot = 1 - rl
+        pred_o = np.zeros((s, s), np.int16)
+        _mc(L, R, dpb_ptr + 2 * (refs[ot][best[ot]["ref"]][0] + y * rs + x), rs, s, best[ot]["mv"][0], best[ot]["mv"][1], 0, pred_o, bd)
+        mot_other = best[ot]["bits"] - mb[ot]
+        cost_bi, bits2, mv_bi, ref_bi = U64, 0, best[rl]["mv"], best[rl]["ref"]
+        out["bi_rows"] = {}
+        for r in range(nref[rl]):
+            t, u = jobs[(rl, r)], rows[(rl, r)]
+            t.bi, t.otherPred, t.otherStride = 1, pred_o.ctypes.data, s
+            t.mvpIdx, t.mvPredHor, t.mvPredVer, t.mvHor, t.mvVer = u["idx"], u["pred"][0], u["pred"][1], u["mv"][0], u["mv"][1]
+            t.bits = mb[2] + mot_other + _ref_idx_bits(nref[rl], r) + 1
+            res = ol.MestResult()
+            (R.ref_motion_estimation if R else L.vo_motion_estimation)(C.byref(cfg), C.byref(t), C.byref(res))
+            row = dict(mv=(res.mvHor, res.mvVer), pred=(res.mvPredHor, res.mvPredVer), idx=res.mvpIdx, bits=res.bits, cost=res.cost)
+            out["bi_rows"][r] = dict(row)
+            row = _check_best(L, R, lam, cands_rows[rl][r], row)
+            if row["cost"] < cost_bi:
+                cost_bi, bits2, mv_bi, ref_bi = row["cost"], row["bits"], row["mv"], r
+        inter_dir = 3 if (cost_bi <= best[0]["cost"] and cost_bi <= best[1]["cost"]) else (1 if best[0]["cost"] <= best[1]["cost"] else 2)
+        out.update(rl=rl, cost_bi=cost_bi, bits2=bits2, mv_bi=mv_bi, ref_bi=ref_bi)
+        if inter_dir == 3:
+            mv_final[rl], ref_final[rl] = mv_bi, ref_bi
+    out["inter_dir"] = inter_dir
+    # ---- final prediction and residual (motionCompensation; InterSearch.cpp:7260-7262) ----
+    pred = np.zeros((s, s), np.int16)
+    if inter_dir == 3:
+        p = [np.zeros((s, s), np.int16) for _ in range(2)]
+        for l in (0, 1):
+            _mc(L, R, dpb_ptr + 2 * (refs[l][ref_final[l]][0] + y * rs + x), rs, s, mv_final[l][0], mv_final[l][1], 1, p[l], bd)
+        (R.ref_add_avg if R else L.vo_add_avg)(ol.P(p[0]), s, ol.P(p[1]), s, ol.P(pred), s, s, s, bd)
+    else:
+        l = inter_dir - 1
+        _mc(L, R, dpb_ptr + 2 * (refs[l][ref_final[l]][0] + y * rs + x), rs, s, mv_final[l][0], mv_final[l][1], 0, pred, bd)
+    resi = (org.astype(np.int32) - pred).astype(np.int16)
+    out["resi"] = resi
+    # ---- residual coding per TU and transform candidate (xEstimateInterResidualQT :6637-6733 without the CABAC estimate) ----
+    ts = min(s, 64)
+    q = s // ts
+    out["tus"] = {}
+    for qy in range(q):
+        for qx in range(q):
+            r_tu = np.ascontiguousarray(resi[qy * ts:(qy + 1) * ts, qx * ts:(qx + 1) * ts])
+            for ci, mts in enumerate(tu_cands):
+                coef, qc, dq, asum = np.zeros(ts * ts, np.int32), np.zeros(ts * ts, np.int32), np.zeros(ts * ts, np.int32), C.c_int32()
+                rec = np.zeros((ts, ts), np.int16)
+                if mts == 1:      # transform skip: xTransformSkip / xITransformSkip are copies
+                    coef[:] = r_tu.reshape(-1)
+                    L.vo_quant(ol.P(coef), ts, ts, bd, qp_per, qp_rem, 0, 1, ol.P(qc), None, C.byref(asum))
+                    L.vo_dequant(ol.P(qc), ts, ts, bd, qp_per, qp_rem, 1, ol.P(dq))
+                    rec[:] = dq.reshape(ts, ts).astype(np.int16)
+                else:
+                    th, tv = MTS_IDX_TYPES[mts]
+                    if R is None:
+                        assert L.vo_fwd_2d(ol.P(r_tu), ts, ts, ts, bd, th, tv, ol.P(coef)) == 0
+                    else:
+                        R.ref_xT(ol.P(r_tu), ts, ts, ts, bd, mts, ol.P(coef))          # the real TrQuant::xT
+                    L.vo_quant(ol.P(coef), ts, ts, bd, qp_per, qp_rem, 0, 0, ol.P(qc), None, C.byref(asum))
+                    L.vo_dequant(ol.P(qc), ts, ts, bd, qp_per, qp_rem, 0, ol.P(dq))
+                    if R is None:
+                        assert L.vo_inv_2d(ol.P(dq), ts, ts, bd, th, tv, ol.P(rec), ts) == 0
+                    else:
+                        R.ref_xIT(ol.P(dq), ts, ts, bd, mts, ol.P(rec), ts)             # the real TrQuant::xIT
+                sse = ol.r_dist(2, 0, r_tu, rec, ts, ts, bd) if R else ol.o_dist(2, r_tu, rec, ts, ts)
+                out["tus"][(qy * q + qx, ci)] = (int(sse), int(np.abs(coef.astype(np.int64)).sum()), asum.value)
+    return out
+
+
+def cands_of(snap_level, nref, i):
+    """AMVP candidates of PU i as the device wrote them into the uni job rows: [list][refIdx] = ((h, v), (h, v))"""
+    n, jobs = snap_level["npu"], snap_level["uni_jobs"]
+    res = [[], []]
+    for l in (0, 1):
+        for r in range(nref[l]):
+            a = jobs["amvpCand"][((nref[0] if l else 0) + r) * n + i]
+            res[l].append(((int(a[0][0]), int(a[0][1])), (int(a[1][0]), int(a[1][1]))))
+    return res
+
+
+def compare_with_device(snap_level, parent_level, nref, i, out):
+    """Asserts that PU i of a FrameHotPath level (numpy snapshot) equals the CPU chain result `out`."""
+    n, s = snap_level["npu"], snap_level["size"]
+    jobs, uo, ur, pu = snap_level["uni_jobs"], snap_level["uni_out"], snap_level["uni_rows"], snap_level["pus"][i]
+    for l in (0, 1):
+        for r in range(nref[l]):
+            row = ((nref[0] if l else 0) + r) * n + i
+            j = jobs[row]
+            assert out["amvp"][(l, r)] == (int(j["mvpIdx"]), int(j["mvPredHor"]), int(j["mvPredVer"])), ("amvp", s, i, l, r, out["amvp"][(l, r)])
+            me = out["rows"][(l, r, "me")]
+            g = uo[row]
+            assert (me["mv"], me["pred"], me["idx"], me["bits"], me["cost"]) == ((int(g["mvHor"]), int(g["mvVer"])), (int(g["mvPredHor"]), int(g["mvPredVer"])),
+                                                                               int(g["mvpIdx"]), int(g["bits"]), int(g["cost"])), ("uni me", s, i, l, r, me, g)
+            cb, g = out["rows"][(l, r)], ur[row]
+            assert (cb["mv"], cb["pred"], cb["idx"], cb["bits"], cb["cost"]) == ((int(g["mvHor"]), int(g["mvVer"])), (int(g["mvPredHor"]), int(g["mvPredVer"])),
+                                                                               int(g["mvpIdx"]), int(g["bits"]), int(g["cost"])), ("checkBestMVP", s, i, l, r)
+        if nref[l]:
+            b = out["best"][l]
+            assert (b["cost"], b["bits"], b["mv"], b["ref"]) == (int(pu["cost"][l]), int(pu["bits"][l]), (int(pu["mv"][l][0]), int(pu["mv"][l][1])), int(pu["refIdx"][l])), ("best", s, i, l)
+    assert out["inter_dir"] == int(pu["interDir"]), ("interDir", s, i, out["inter_dir"], int(pu["interDir"]))
+    if nref[1]:
+        rl = out["rl"]
+        assert rl == int(pu["refineList"]) and out["cost_bi"] == int(pu["costBi"]) and out["bits2"] == int(pu["bits"][2]), ("bi cost", s, i)
+        assert (out["mv_bi"], out["ref_bi"]) == ((int(pu["mvBi"][rl][0]), int(pu["mvBi"][rl][1])), int(pu["refIdxBi"][rl])), ("bi mv", s, i)
+        bo = snap_level["bi_out"]
+        for r, me in out["bi_rows"].items():
+            g = bo[r * n + i]
+            assert (me["mv"], me["bits"], me["cost"]) == ((int(g["mvHor"]), int(g["mvVer"])), int(g["bits"]), int(g["cost"])), ("bi me", s, i, r)
+    ntu, ts = snap_level["ntu"], snap_level["ts"]
+    q = s // ts
+    tr = snap_level["tu_res"]
+    for (tu, ci), (sse, sa, asum) in out["tus"].items():
+        k = ci * ntu + i * q * q + tu
+        got = (int(tr[k, 0]), int(tr[k, 1] & 0xFFFFFFFF), int((tr[k, 1] >> 32) & 0xFFFFFFFF))
+        assert (sse, sa, asum) == got, ("tu", s, i, tu, ci, (sse, sa, asum), got)
+    # the AMVP candidates themselves: candidate 0 is the parent's vector for the same (list, refIdx), candidate 1 zero
+    if parent_level is not None:
+        ps = parent_level["size"]
+        x, y = int(snap_level["xs"][i]), int(snap_level["ys"][i])
+        hit = np.nonzero((parent_level["xs"] == x // ps * ps) & (parent_level["ys"] == y // ps * ps))[0]
+        for l in (0, 1):
+            for r in range(nref[l]):
+                lr = (nref[0] if l else 0) + r
+                c = jobs["amvpCand"][lr * n + i]
+                exp = (0, 0)
+                if hit.size:
+                    pr = parent_level["uni_rows"][lr * parent_level["npu"] + int(hit[0])]
+                    exp = (int(pr["mvHor"]), int(pr["mvVer"]))
+                assert (int(c[0][0]), int(c[0][1])) == exp and (int(c[1][0]), int(c[1][1])) == (0, 0), ("candidates", s, i, l, r)

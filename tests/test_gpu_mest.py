@@ -43,10 +43,15 @@ def hip_jobs(scene, jobs, others):
     return arr
 
 
-def run_device(ctx, scene, jobs, cfgv, uniform_imv=-1, uniform_square=0, max_wh=(128, 128)):
+def run_device(ctx, scene, jobs, cfgv, uniform_imv=-1, uniform_square=0, max_wh=(128, 128), uniform_bi=0, no_uni_mv_list=0, pattern_given=0):
     others = np.zeros(max(1, sum(j["w"] * j["h"] for j in jobs if j["bi"])), np.int16)
     arr = hip_jobs(scene, jobs, others)
-    cfg = MeCfg(cfgv[0], cfgv[1], cfgv[2], cfgv[3], cfgv[4], uniform_imv, uniform_square)
+    if pattern_given:   # the caller hands over 2*org - otherPred itself (what a fused motion-compensation epilogue writes)
+        for k, j in enumerate(jobs):
+            o, n = arr[k].otherPredOff, j["w"] * j["h"]
+            org = scene.cur[j["y"]:j["y"] + j["h"], j["x"]:j["x"] + j["w"]].astype(np.int32)
+            others[o:o + n] = (2 * org - others[o:o + n].reshape(j["h"], j["w"])).astype(np.int16).reshape(-1)
+    cfg = MeCfg(cfgv[0], cfgv[1], cfgv[2], cfgv[3], cfgv[4], uniform_imv, uniform_square, uniform_bi, no_uni_mv_list, pattern_given)
     pic = PicParams(scene.W, scene.H, 128, 10, 0)
     d_cur, d_ref, d_oth = ctx.to_device(scene.cur), ctx.to_device(scene.ref_buf), ctx.to_device(others)
     d_jobs = ctx.to_device(np.frombuffer(arr, np.uint8))
@@ -109,4 +114,31 @@ def test_uniform_batches_use_fast_paths(ctx, size, imv):
         L.vo_motion_estimation(C.byref(cfg), C.byref(t), C.byref(r))
         exp.append(r.key())
     got, _ = run_device(ctx, scene, jobs, cfgv, uniform_imv=imv, uniform_square=1, max_wh=(size, size))
+    assert got == exp
+
+
+@pytest.mark.parametrize("size,bi,opts", [(8, 0, {}), (32, 0, {}), (16, 1, {}), (16, 1, dict(no_uni_mv_list=1)), (64, 1, dict(no_uni_mv_list=1, pattern_given=1)),
+                                          (8, 1, dict(pattern_given=1)), (128, 0, {}), (128, 1, dict(no_uni_mv_list=1, pattern_given=1))])
+def test_uniform_bi_fast_paths(ctx, size, bi, opts):
+    """uniformBi 1 (all uni: the searches read the original plane, no pattern copies) / 2 (all bi: no TZ stage, lane-per-candidate exhaustive
+    kernel; optionally no start-candidate SADs and a caller-made 2*org - pred pattern): same results as the oracle's xMotionEstimation."""
+    L = ol.oracle()
+    scene = me_util.Scene(416, 240, hard=True)
+    jobs = me_util.random_mest_jobs(scene, 160, seed=300 + size + bi, sizes=([size], [size]))
+    for j in jobs:
+        j["imv"], j["bi"] = 0, bi
+        j["cands"] = [[me_util._round_amvr(v, 0) for v in c] for c in j["cands"]]
+        j["mvPred"] = tuple(j["cands"][j["mvpIdx"]])
+        if opts.get("no_uni_mv_list"):
+            j["extra"] = []
+    cfgv = (4, 1, 1, 0, 1)
+    cfg = ol.MestCfg(*cfgv)
+    exp = []
+    for j in jobs:
+        keep = []
+        t = me_util.oracle_mest_job(scene, j, keep)
+        r = ol.MestResult()
+        L.vo_motion_estimation(C.byref(cfg), C.byref(t), C.byref(r))
+        exp.append(r.key())
+    got, _ = run_device(ctx, scene, jobs, cfgv, uniform_imv=0, uniform_square=1, max_wh=(size, size), uniform_bi=1 + bi, **opts)
     assert got == exp

@@ -6,7 +6,7 @@ import pytest
 import cpu_chain
 import oracle_lib as ol
 from vtm_amd import synth
-from vtm_amd.pipeline import FrameHotPath
+from vtm_amd.pipeline import FrameHotPathV1 as FrameHotPath
 
 pytestmark = pytest.mark.gpu
 

@@ -1,0 +1,118 @@
+"""GPU end-to-end parity of the level-order predInterSearch driver (vtm_amd.pipeline.FrameHotPath: AMVP estimation -> uni ME per (list, refIdx)
+-> xCheckBestMVP -> bi refinement -> decision -> prediction / residual -> TU chains) against the same chain through the CPU oracle and
+through the REAL reference members (tests/cpu_pis.py), PU by PU, at the operating points of BASELINE.json's configurations:
+  random access B slices (1 + 1 and 2 + 2 reference pictures, SR via ASR), low-delay P slices (4 list-0 pictures, SR 64), QP 22 / 27 / 32,
+and the CTU sharding of one frame (the union of the ranks' tables is the unsharded result)."""
+import numpy as np
+import pytest
+
+import cpu_pis
+import oracle_lib as ol
+from vtm_amd import pipeline, synth
+from vtm_amd.pipeline import FrameHotPath
+
+pytestmark = pytest.mark.gpu
+
+
+def make_scene(torch, dev, W, H, pocs0, pocs1, cur_poc, hard=True):
+    nfr = max(pocs0 + pocs1 + [cur_poc]) + 1
+    frames = (synth.gen_frames_hard if hard else synth.gen_frames)(W, H, nfr)
+    planes, refs, acc = [], ([], []), 0
+    cache = {}
+    for l, pocs in enumerate((pocs0, pocs1)):
+        for p in pocs:
+            if p not in cache:
+                buf, off, stride = synth.extend_plane(frames[p], margin=160)
+                cache[p] = (acc + off, stride)
+                planes.append(buf.reshape(-1))
+                acc += buf.size
+            refs[l].append(cache[p])
+    cur_np = np.ascontiguousarray(frames[cur_poc])
+    dpb_np = np.concatenate(planes)
+    sr = ([pipeline.asr_search_range(p - cur_poc) for p in pocs0], [pipeline.asr_search_range(p - cur_poc) for p in pocs1])
+    return cur_np, dpb_np, refs, sr, torch.from_numpy(cur_np).to(dev), torch.from_numpy(dpb_np).to(dev)
+
+
+def check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, R, per_level=24, min_checked=60):
+    snaps = hp.snapshot()
+    nref = hp.nref
+    checked = 0
+    dirs = set()
+    for li, lvl in enumerate(snaps):
+        parent = snaps[li - 1] if li and snaps[li - 1]["size"] == 2 * lvl["size"] else None
+        s, npu = lvl["size"], lvl["npu"]
+        for i in range(0, npu, max(1, npu // per_level)):
+            out = cpu_pis.run_pu(cur_np, dpb_np.ctypes.data, refs, sr, W, H, s, int(lvl["xs"][i]), int(lvl["ys"][i]), cpu_pis.cands_of(lvl, nref, i), lam,
+                                 (qp + 12) // 6, (qp + 12) % 6, lvl["cands"], ref=R)
+            cpu_pis.compare_with_device(lvl, parent, nref, i, out)
+            dirs.add(out["inter_dir"])
+            checked += 1
+    assert checked >= min_checked
+    return dirs
+
+
+@pytest.mark.parametrize("use_ref", [False, True])
+@pytest.mark.parametrize("name,pocs0,pocs1,cur,qp,ts", [("ra_1+1_qp32", [0], [4], 2, 32, False), ("ra_2+2_qp27_ts", [2, 0], [4, 6], 3, 27, True),
+                                                       ("ldp_4_qp32", [3, 2, 1, 0], [], 4, 32, False), ("ra_1+1_qp22", [1], [3], 2, 22, False)])
+def test_frame_hot_path_matches_cpu_chain(use_ref, name, pocs0, pocs1, cur, qp, ts):
+    torch = pytest.importorskip("torch")
+    from vtm_amd.device import Context
+    if use_ref and not ol.have_ref():
+        pytest.skip("oracle/_ref/libvtmref.so not present")
+    W, H = 256, 128
+    dev = torch.device("cuda", 0)
+    cur_np, dpb_np, refs, sr, cur, dpb = make_scene(torch, dev, W, H, pocs0, pocs1, cur)
+    if not pocs1:
+        sr = ([64] * len(pocs0), [])          # encoder_lowdelay_P_vtm.cfg: SearchRange 64, no ASR
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    lam = 8.0
+    hp = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, transform_skip=ts)
+    for overlapped in (True, False):       # level-major over the side streams, then one stream: same tables, same results
+        hp.run(cur.data_ptr(), dpb.data_ptr(), timing=not overlapped)
+        torch.cuda.synchronize()
+        dirs = check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, ol.ref() if use_ref else None, per_level=24 if overlapped else 6, min_checked=60 if overlapped else 15)
+    if pocs1:
+        assert 3 in dirs and len(dirs) >= 2      # bi-prediction and uni-prediction both occur
+    ctx.close()
+
+
+def test_ctu_sharding_union_equals_unsharded():
+    """north_star: CTU rows of a frame shard across the GPUs.  Two ranks' tables (raster-scan CTU ranges; the boundary row is cut at a CTU) run
+    one after the other on this GPU: the union of their per-PU / per-TU results is bit-identical to the unsharded picture."""
+    torch = pytest.importorskip("torch")
+    from vtm_amd.device import Context
+    W, H = 640, 384                      # 5 x 3 CTUs: the two bands are 8 and 7 CTUs, the cut falls inside CTU row 1
+    dev = torch.device("cuda", 0)
+    cur_np, dpb_np, refs, sr, cur, dpb = make_scene(torch, dev, W, H, [0], [4], 2)
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    full = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr)
+    full.run(cur.data_ptr(), dpb.data_ptr())
+    torch.cuda.synchronize()
+    whole = {lv["size"]: lv for lv in full.snapshot()}
+    seen = {s: 0 for s in whole}
+    for unit in ("ctu", "row"):
+        bands = pipeline.ctu_bands(W, H, 2, unit=unit)
+        assert bands[0][1] == bands[1][0] and bands[0][0] == 0 and bands[1][1] == 15
+        seen = {s: 0 for s in whole}
+        for band in bands:
+            part = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, ctu_filter=pipeline.band_filter(W, band))
+            part.run(cur.data_ptr(), dpb.data_ptr())
+            torch.cuda.synchronize()
+            for lv in part.snapshot():
+                w = whole[lv["size"]]
+                lut = {(int(x), int(y)): k for k, (x, y) in enumerate(zip(w["xs"], w["ys"]))}
+                idx = np.array([lut[(int(x), int(y))] for x, y in zip(lv["xs"], lv["ys"])])
+                assert np.array_equal(lv["pus"], w["pus"][idx]), ("pus", unit, band, lv["size"])
+                R = full.nref[0] + full.nref[1]
+                for lr in range(R):
+                    assert np.array_equal(lv["uni_rows"][lr * lv["npu"]:(lr + 1) * lv["npu"]], w["uni_rows"][lr * w["npu"] + idx]), ("rows", unit, band, lv["size"])
+                q2 = (lv["size"] // lv["ts"]) ** 2
+                for ci in range(lv["nc"]):
+                    a = lv["tu_res"][ci * lv["ntu"]:(ci + 1) * lv["ntu"]].reshape(lv["npu"], q2, 2)
+                    b = w["tu_res"][ci * w["ntu"]:(ci + 1) * w["ntu"]].reshape(w["npu"], q2, 2)[idx]
+                    assert np.array_equal(a, b), ("tu", unit, band, lv["size"], ci)
+                seen[lv["size"]] += lv["npu"]
+        assert seen == {s: lv["npu"] for s, lv in whole.items()}
+    ctx.close()

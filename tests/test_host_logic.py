@@ -75,3 +75,30 @@ def test_two_rank_plane_exchange():
                           "--master-port", "29519", script], capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "EXCHANGE_OK" in out.stdout
+
+
+def test_ctu_bands_partition_and_balance():
+    """raster-scan CTU ranges: contiguous, complete, balanced to one CTU; whole-row bands for comparison (17 rows over 8 ranks: 3 / 2 rows)"""
+    b = pipeline.ctu_bands(3840, 2160, 8, unit="ctu")
+    assert b[0][0] == 0 and b[-1][1] == 30 * 17 and all(x[1] == y[0] for x, y in zip(b[:-1], b[1:]))
+    assert sorted({x[1] - x[0] for x in b}) == [63, 64]
+    r = pipeline.ctu_bands(3840, 2160, 8, unit="row")
+    assert sorted({(x[1] - x[0]) // 30 for x in r}) == [2, 3] and sum(x[1] - x[0] for x in r) == 510
+    parts = [pipeline.quadtree_levels(3840, 2160, sizes=(128, 8), ctu_filter=pipeline.band_filter(3840, x)) for x in b]
+    full = pipeline.quadtree_levels(3840, 2160, sizes=(128, 8))
+    for li in (0, 1):
+        assert sum(p[li][1].size for p in parts) == full[li][1].size
+    # parents stay inside the band: a child's parent index refers to the band's own 128-level table
+    for p in parts:
+        (s0, xs0, ys0, _), (s1, xs1, ys1, par) = p
+        ok = par >= 0
+        assert ((xs1[ok] // 128 * 128 == xs0[par[ok]]) & (ys1[ok] // 128 * 128 == ys0[par[ok]])).all()
+
+
+def test_two_rank_ctu_shards_and_result_gather():
+    """world_size 2 on CPU/gloo: CTU bands per rank + the double-buffered result gather of bench.py --gpus N (vtm_amd/exchange.py:ResultGather)"""
+    script = os.path.join(ROOT, "tests", "gloo_gather_worker.py")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29521", script], capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "GATHER_OK" in out.stdout

@@ -587,3 +587,38 @@ def test_get_dist_part_chroma_weight(oracle, reflib):
             exp = d if comp == 0 else int(np.float64(wt) * np.float64(d))
             got = reflib.ref_get_dist_part(comp, wt, kind, ol.P(o), w + 3, ol.P(c), w + 1, w, h, 10)
             assert got == exp, (w, h, comp, wt, kind)
+
+
+def test_amvp_helpers_equal_reference_members(oracle, reflib):
+    """InterSearch::xEstimateMvPredAMVP (template cost of the AMVP candidates, hook B7) and xCheckBestMVP as the real members vs the oracle."""
+    import me_util
+    scene = me_util.Scene(416, 240, hard=True)
+    jobs = me_util.random_mest_jobs(scene, 300, seed=910)
+    rng = np.random.default_rng(911)
+    n_switch = 0
+    for k, j in enumerate(jobs):
+        j["bi"] = 0
+        if k % 5 == 0:    # candidates far outside the picture: clipMv takes effect
+            j["cands"][0] = [me_util._round_amvr(int(rng.integers(-9000, 9000)), j["imv"]), me_util._round_amvr(int(rng.integers(-9000, 9000)), j["imv"])]
+            j["mvPred"] = tuple(j["cands"][j["mvpIdx"]])
+        keep = []
+        t = me_util.oracle_mest_job(scene, j, keep)
+        a, b = [C.c_int(), C.c_int(), C.c_int(), C.c_uint64()], [C.c_int(), C.c_int(), C.c_int(), C.c_uint64()]
+        oracle.vo_estimate_mvp_amvp(C.byref(t), *[C.byref(x) for x in a])
+        reflib.ref_estimate_mvp_amvp(C.byref(t), *[C.byref(x) for x in b])
+        assert [x.value for x in a] == [x.value for x in b], (j, [x.value for x in a], [x.value for x in b])
+        # xCheckBestMVP on a vector near one of the candidates
+        c = j["cands"][int(rng.integers(0, 2))]
+        shift = {0: 2, 1: 4, 2: 6, 3: 3}[j["imv"]]
+        mvh, mvv = ((c[0] >> shift) + int(rng.integers(-3, 4))) << shift, ((c[1] >> shift) + int(rng.integers(-3, 4))) << shift
+        cands = ((C.c_int * 2) * 2)((C.c_int * 2)(*j["cands"][0]), (C.c_int * 2)(*j["cands"][1]))
+        idxb = (C.c_uint * 2)(*j["idxBits"])
+        out = []
+        for fn in (oracle.vo_check_best_mvp, reflib.ref_check_best_mvp):
+            ph, pv, idx = C.c_int(j["mvPred"][0]), C.c_int(j["mvPred"][1]), C.c_int(j["mvpIdx"])
+            bits, cost = C.c_uint(j["bits"] + 40), C.c_uint64(100000 + int(j["lam"] * (j["bits"] + 40)))
+            fn(C.c_double(j["lam"]), j["imv"], j["numCand"], cands, idxb, mvh, mvv, C.byref(ph), C.byref(pv), C.byref(idx), C.byref(bits), C.byref(cost))
+            out.append((ph.value, pv.value, idx.value, bits.value, cost.value))
+        assert out[0] == out[1], (j, out)
+        n_switch += out[0][2] != j["mvpIdx"]
+    assert n_switch > 20

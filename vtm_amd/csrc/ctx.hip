@@ -34,6 +34,9 @@ int vtmhip_struct_size( int which )
   case 21: return ( int ) sizeof( vtmhip_geo_blend_job );
   case 22: return ( int ) sizeof( vtmhip_dmvr_job );
   case 23: return ( int ) sizeof( vtmhip_lfnst_job );
+  case 24: return ( int ) sizeof( vtmhip_pis_row );
+  case 25: return ( int ) sizeof( vtmhip_pis_pu );
+  case 26: return ( int ) sizeof( vtmhip_pis_level );
   default: return -1;
   }
 }
@@ -89,10 +92,11 @@ int vtmhip_destroy( vtmhip_ctx *ctx )
   ( void ) hipSetDevice( ctx->device );
   ( void ) hipStreamSynchronize( ctx->stream );
   if( ctx->scratch ) ( void ) hipFree( ctx->scratch );
-  if( ctx->work ) ( void ) hipFree( ctx->work );
+  for( auto &kv : ctx->work ) if( kv.second.ptr ) ( void ) hipFree( kv.second.ptr );
   if( ctx->lfnstTab ) ( void ) hipFree( ctx->lfnstTab );
   if( ctx->trTabBuf ) ( void ) hipFree( ctx->trTabBuf );
   if( ctx->pinned ) ( void ) hipHostFree( ctx->pinned );
+  for( auto &t : ctx->timed ) { ( void ) hipEventDestroy( t.start ); ( void ) hipEventDestroy( t.stop ); }
   if( ctx->evStart ) ( void ) hipEventDestroy( ctx->evStart );
   if( ctx->evStop ) ( void ) hipEventDestroy( ctx->evStop );
   if( ctx->ownStream ) ( void ) hipStreamDestroy( ctx->ownStream );
@@ -171,6 +175,40 @@ int vtmhip_timer_stop_ms( vtmhip_ctx *ctx, float *ms )
   return VTMHIP_OK;
 }
 
+static void clear_timed( vtmhip_ctx *ctx )
+{
+  for( auto &t : ctx->timed ) { ( void ) hipEventDestroy( t.start ); ( void ) hipEventDestroy( t.stop ); }
+  ctx->timed.clear();
+}
+
+int vtmhip_kernel_timing( vtmhip_ctx *ctx, int enable )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_HIP( ctx, hipDeviceSynchronize() );
+  clear_timed( ctx );
+  ctx->timing = enable != 0;
+  return VTMHIP_OK;
+}
+
+int vtmhip_kernel_timing_read( vtmhip_ctx *ctx, const char *kernel, double *totalMs, int *launches )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, kernel && totalMs && launches, "null pointer" );
+  VTMHIP_HIP( ctx, hipDeviceSynchronize() );
+  double sum = 0;
+  int    n   = 0;
+  for( auto &t : ctx->timed )
+    if( std::strcmp( t.kernel, kernel ) == 0 )
+    {
+      float ms = 0;
+      VTMHIP_HIP( ctx, hipEventElapsedTime( &ms, t.start, t.stop ) );
+      sum += ms;
+      n++;
+    }
+  *totalMs = sum; *launches = n;
+  return VTMHIP_OK;
+}
+
 }   // extern "C"
 
 int vtmhip_internal_scratch( vtmhip_ctx *ctx, size_t bytes )
@@ -188,21 +226,26 @@ int vtmhip_internal_scratch( vtmhip_ctx *ctx, size_t bytes )
   return VTMHIP_OK;
 }
 
-int vtmhip_internal_workspace( vtmhip_ctx *ctx, size_t bytes )
+int vtmhip_internal_workspace( vtmhip_ctx *ctx, size_t bytes, void **out )
 {
-  if( bytes <= ctx->workSize ) return VTMHIP_OK;
-  const size_t want = ( bytes + ( 1u << 20 ) - 1 ) & ~( size_t )( ( 1u << 20 ) - 1 );
-  VTMHIP_HIP( ctx, hipSetDevice( ctx->device ) );
-  VTMHIP_HIP( ctx, hipDeviceSynchronize() );   // earlier launches -- on any stream the context was pointed at (vtmhip_set_stream) -- may still use the old block
-  if( ctx->work ) VTMHIP_HIP( ctx, hipFree( ctx->work ) );
-  ctx->work = nullptr; ctx->workSize = 0;
-  if( hipMalloc( &ctx->work, want ) != hipSuccess )
+  std::lock_guard<std::mutex> lock( ctx->initMutex );
+  vtmhip_ctx::WorkArena &a = ctx->work[ctx->stream];
+  if( bytes > a.size )
   {
-    ( void ) hipGetLastError();
-    ctx->work = nullptr;
-    ctx->lastError = "out of device memory for the call's workspace";
-    return VTMHIP_E_NOMEM;
+    const size_t want = ( bytes + ( 1u << 20 ) - 1 ) & ~( size_t )( ( 1u << 20 ) - 1 );
+    VTMHIP_HIP( ctx, hipSetDevice( ctx->device ) );
+    VTMHIP_HIP( ctx, hipStreamSynchronize( ctx->stream ) );   // earlier launches of THIS stream may still use the old block (no other stream ever sees it)
+    if( a.ptr ) VTMHIP_HIP( ctx, hipFree( a.ptr ) );
+    a.ptr = nullptr; a.size = 0;
+    if( hipMalloc( &a.ptr, want ) != hipSuccess )
+    {
+      ( void ) hipGetLastError();
+      a.ptr = nullptr;
+      ctx->lastError = "out of device memory for the call's workspace";
+      return VTMHIP_E_NOMEM;
+    }
+    a.size = want;
   }
-  ctx->workSize = want;
+  *out = a.ptr;
   return VTMHIP_OK;
 }

@@ -5,8 +5,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/vtmhip.h"
 
@@ -21,15 +23,40 @@ struct vtmhip_ctx
   size_t      scratchSize = 0;
   void       *pinned      = nullptr;   // pinned host mirror of the staging area
   size_t      pinnedSize  = 0;
-  void       *work        = nullptr;   // device workspace of the multi-stage calls (vtmhip_xMotionEstimation_batch_dev)
-  size_t      workSize    = 0;
+  // device workspaces of the multi-stage calls (vtmhip_xMotionEstimation_batch_dev ...): ONE ARENA PER STREAM the context has been pointed at, so that
+  // calls queued on different streams (a level-order driver runs the levels' chains concurrently) never share scratch memory; calls on one stream are
+  // ordered and reuse their arena
+  struct WorkArena { void *ptr = nullptr; size_t size = 0; };
+  std::map<hipStream_t, WorkArena> work;
   int8_t     *lfnstTab    = nullptr;   // the caller's LFNST core matrices: g_lfnst8x8 [4][2][16][48] then g_lfnst4x4 [4][2][16][16] (vtmhip_lfnst_set_tables)
   int16_t    *trTabBuf    = nullptr;   // the transform core matrices of THIS context's device (transform.hip ensure_tables; freed by vtmhip_destroy)
   const int16_t *trTab[3][7] = {};     // [type][log2 N] -> N x N forward matrix inside trTabBuf
   std::mutex  initMutex;               // guards the lazy per-context initialisations (tables, staging / workspace growth)
   int         numCUs      = 256;
   std::string lastError;
+  // per-kernel launch timing (vtmhip_kernel_timing): HIP events recorded on the launch stream around every launch of the main kernels
+  bool        timing      = false;
+  struct TimedLaunch { const char *kernel; hipEvent_t start, stop; };
+  std::vector<TimedLaunch> timed;
 };
+
+// scope guard around a kernel launch: records start / stop events on ctx->stream when timing is on (bench.py's roofline: the dominant kernel's
+// average launch duration, measured live on the stream the kernel is launched on)
+struct vtmhip_launch_timer
+{
+  vtmhip_ctx *c;
+  hipEvent_t  stop = nullptr;
+  vtmhip_launch_timer( vtmhip_ctx *ctx, const char *kernel ) : c( ctx )
+  {
+    if( !c->timing ) return;
+    hipEvent_t start = nullptr;
+    if( hipEventCreate( &start ) != hipSuccess || hipEventCreate( &stop ) != hipSuccess ) { stop = nullptr; return; }
+    ( void ) hipEventRecord( start, c->stream );
+    c->timed.push_back( { kernel, start, stop } );
+  }
+  ~vtmhip_launch_timer() { if( stop ) ( void ) hipEventRecord( stop, c->stream ); }
+};
+#define VTMHIP_TIME_KERNEL( ctx, name ) vtmhip_launch_timer vtmhip_timer_guard_( ctx, name )
 
 // every entry point starts here: a null context is an error, and the calling thread is pointed at the context's device (a host with
 // several contexts / GPUs in one process, or encoder threads that never called hipSetDevice, would otherwise allocate and launch on
@@ -67,7 +94,7 @@ struct vtmhip_ctx
 #define VTMHIP_LAUNCHED( ctx ) VTMHIP_HIP( ctx, hipGetLastError() )
 
 int vtmhip_internal_scratch( vtmhip_ctx *ctx, size_t bytes );   // grows ctx->scratch / ctx->pinned
-int vtmhip_internal_workspace( vtmhip_ctx *ctx, size_t bytes ); // grows ctx->work (device only)
+int vtmhip_internal_workspace( vtmhip_ctx *ctx, size_t bytes, void **out ); // the arena of ctx->stream, grown to `bytes` (device only)
 
 // ---- device helpers -------------------------------------------------------------------------------------------
 __device__ __forceinline__ int wave_reduce_add( int v )

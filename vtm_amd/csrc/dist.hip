@@ -462,6 +462,7 @@ int vtmhip_satd8_grid_dev( vtmhip_ctx *ctx, const int16_t *d_org, int orgStride,
     const int    refW = GRID_TBX * 8 + 2 * r, refH = tby * 8 + 2 * r, refLd = ( refW + 7 ) & ~7;
     const size_t lds = ( size_t ) ( tby * 8 * GRID_TBX * 8 + refH * refLd ) * sizeof( int16_t ) + 16;   // + one spare vector: the packed path reads a fifth dword per row
     dim3         grid( ( bw + GRID_TBX - 1 ) / GRID_TBX, ( bh + tby - 1 ) / tby );
+    VTMHIP_TIME_KERNEL( ctx, "satd8_grid_kernel" );
     hipLaunchKernelGGL( kern, grid, dim3( threads ), lds, ctx->stream, d_org, orgStride, d_ref, refStride, bw, bh, r, d_dist );
   };
   switch( variant )
@@ -570,6 +571,7 @@ extern "C" int vtmhip_dist_uniform_batch_dev( vtmhip_ctx *ctx, const int16_t *d_
   int       lpjShift = 0;
   while( ( perLane << lpjShift ) < items && lpjShift < 6 ) lpjShift++;
   const int jobsPerWave = 64 >> lpjShift, waves = ( n + jobsPerWave - 1 ) / jobsPerWave;
+  VTMHIP_TIME_KERNEL( ctx, "dist_uniform_kernel" );
   hipLaunchKernelGGL( dist_uniform_kernel, dim3( ( waves + 3 ) / 4 ), dim3( 256 ), 0, ctx->stream, d_orgBase, d_curBase, d_jobs, n, kind, width, height, subShift, lpjShift,
                       ( unsigned long long * ) d_dist );
   VTMHIP_LAUNCHED( ctx );

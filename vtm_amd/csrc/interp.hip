@@ -720,6 +720,7 @@ int launch_frac_sq( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_
   using C = FracSq<S>;
   if( C::LDS > 64 * 1024 )
     VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( frac_search_sq_kernel<S> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) C::LDS ) );
+  VTMHIP_TIME_KERNEL( ctx, "frac_search_sq_kernel" );
   hipLaunchKernelGGL( frac_search_sq_kernel<S>, dim3( ( n + C::JPW - 1 ) / C::JPW ), dim3( C::BLOCK ), C::LDS, ctx->stream, d_orgBase, d_refBase, d_jobs, n,
                       d_results );
   VTMHIP_LAUNCHED( ctx );
@@ -785,6 +786,7 @@ int vtmhip_frac_search_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, con
   const size_t lds = frac_lds_bytes( maxWidth, maxHeight );
   if( lds > 64 * 1024 )
     VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( frac_search_kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
+  VTMHIP_TIME_KERNEL( ctx, "frac_search_kernel" );
   hipLaunchKernelGGL( frac_search_kernel, dim3( n ), dim3( 64 ), lds, ctx->stream, d_orgBase, d_refBase, d_jobs, d_results, maxWidth, maxHeight );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;

@@ -942,6 +942,7 @@ int vtmhip_motion_compensation_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgB
   VTMHIP_REQUIRE( ctx, maxWidth >= 2 && maxWidth <= 128 && maxHeight >= 2 && maxHeight <= 128, "maxWidth / maxHeight" );
   const size_t lds = ( ( size_t ) maxWidth * ( maxHeight + 7 ) + ( size_t ) maxWidth * maxHeight ) * sizeof( int16_t );
   // one wave per block up to 16x16 samples, four waves above (the samples of a block are independent; only the H -> V hand-over syncs)
+  VTMHIP_TIME_KERNEL( ctx, "motion_comp_kernel" );
   if( maxWidth * maxHeight > 256 )
   {
     if( lds > 64 * 1024 )

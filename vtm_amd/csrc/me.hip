@@ -1037,6 +1037,7 @@ extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_par
   VTMHIP_REQUIRE( ctx, wpj == 0 || wpj == 1 || wpj == 2 || wpj == 4 || wpj == 8 || wpj == 16, "wavesPerJob must be 0, 1, 2, 4, 8 or 16" );
 #define VTMHIP_TZ_LAUNCH( W, GRID ) \
   hipLaunchKernelGGL( tz_search_kernel<W>, dim3( GRID ), dim3( W == 1 ? 256 : 64 * W ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, d_results )
+  { VTMHIP_TIME_KERNEL( ctx, "tz_search_kernel" );
   switch( wpj )
   {
   case 2: VTMHIP_TZ_LAUNCH( 2, n ); break;
@@ -1044,6 +1045,7 @@ extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_par
   case 8: VTMHIP_TZ_LAUNCH( 8, n ); break;
   case 16: VTMHIP_TZ_LAUNCH( 16, n ); break;
   default: VTMHIP_TZ_LAUNCH( 1, ( n + 3 ) / 4 ); break;
+  }
   }
 #undef VTMHIP_TZ_LAUNCH
   VTMHIP_LAUNCHED( ctx );
@@ -1063,6 +1065,7 @@ extern "C" int vtmhip_full_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_p
   VTMHIP_REQUIRE( ctx, wpj == 0 || wpj == 1 || wpj == 2 || wpj == 4 || wpj == 8 || wpj == 16, "wavesPerJob must be 0, 1, 2, 4, 8 or 16" );
 #define VTMHIP_FS_LAUNCH( W, GRID ) \
   hipLaunchKernelGGL( full_search_kernel<W>, dim3( GRID ), dim3( W == 1 ? 256 : 64 * W ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, d_results )
+  { VTMHIP_TIME_KERNEL( ctx, "full_search_kernel" );
   switch( wpj )
   {
   case 2: VTMHIP_FS_LAUNCH( 2, n ); break;
@@ -1070,6 +1073,7 @@ extern "C" int vtmhip_full_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_p
   case 8: VTMHIP_FS_LAUNCH( 8, n ); break;
   case 16: VTMHIP_FS_LAUNCH( 16, n ); break;
   default: VTMHIP_FS_LAUNCH( 1, ( n + 3 ) / 4 ); break;
+  }
   }
 #undef VTMHIP_FS_LAUNCH
   VTMHIP_LAUNCHED( ctx );
@@ -1089,12 +1093,14 @@ extern "C" int vtmhip_full_search_square_batch_dev( vtmhip_ctx *ctx, const vtmhi
 #define VTMHIP_FSQ_LAUNCH( SZ ) \
   hipLaunchKernelGGL( full_search_sq_kernel<SZ>, dim3( ( n + FullSq<SZ>::JPB - 1 ) / FullSq<SZ>::JPB ), dim3( FullSq<SZ>::THREADS ), 0, ctx->stream, *pic, d_orgBase, \
                       d_refBase, d_jobs, n, d_results )
+  { VTMHIP_TIME_KERNEL( ctx, "full_search_sq_kernel" );
   switch( size )
   {
   case 8: VTMHIP_FSQ_LAUNCH( 8 ); break;
   case 16: VTMHIP_FSQ_LAUNCH( 16 ); break;
   case 32: VTMHIP_FSQ_LAUNCH( 32 ); break;
   default: VTMHIP_FSQ_LAUNCH( 64 ); break;
+  }
   }
 #undef VTMHIP_FSQ_LAUNCH
   VTMHIP_LAUNCHED( ctx );

@@ -69,7 +69,14 @@ struct Work
   vtmhip_dist_job    *dist;      // n x REFINE_SLOTS (the start candidates use the first START_SLOTS of each row)
   unsigned long long *dout;
   long                slotSamples;
+  int                 direct;    // 1: no pattern copies -- the searches read the job's own block (uni: orgOff / orgStride in the original plane; bi: the
+                                 // caller-made 2*org - pred block at otherPredOff / otherPredStride); 0: compact slots filled by mest_pattern_kernel
+  int                 hasTz, hasFull;   // 0: the batch has no uni / no bi job and that job table is not allocated
+  int                 needDist;  // 0: no job of the batch uses the per-job distortion slots (their job records are not even initialised)
 };
+
+__device__ __forceinline__ long pat_off( const Work &wk, const vtmhip_me_job &j, int i ) { return wk.direct ? ( j.bi ? j.otherPredOff : j.orgOff ) : ( long ) i * wk.slotSamples; }
+__device__ __forceinline__ int  pat_stride( const Work &wk, const vtmhip_me_job &j ) { return wk.direct ? ( j.bi ? j.otherPredStride : j.orgStride ) : ( int ) j.width; }
 
 // one workgroup per job: the search pattern in a compact slot (stride = width)
 __global__ __launch_bounds__( 256 ) void mest_pattern_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ otherBase,
@@ -98,10 +105,10 @@ __global__ __launch_bounds__( 256 ) void mest_pattern_kernel( const int16_t *__r
   }
 }
 
-__device__ __forceinline__ void sad_job( vtmhip_dist_job &d, long slot, const vtmhip_me_job &j, int intX, int intY, int ss, int kind )
+__device__ __forceinline__ void sad_job( vtmhip_dist_job &d, long slot, int slotStride, const vtmhip_me_job &j, int intX, int intY, int ss, int kind )
 {
   d.orgOff = slot; d.curOff = j.refOff + ( long ) intY * j.refStride + intX;
-  d.orgStride = j.width; d.curStride = j.refStride; d.width = j.width; d.height = j.height; d.subShift = ( int16_t ) ss; d.kind = ( int16_t ) kind;
+  d.orgStride = slotStride; d.curStride = j.refStride; d.width = j.width; d.height = j.height; d.subShift = ( int16_t ) ss; d.kind = ( int16_t ) kind;
 }
 
 __global__ __launch_bounds__( 256 ) void mest_prepare_kernel( vtmhip_pic_params pic, vtmhip_me_cfg cfg, const vtmhip_me_job *__restrict__ jobs, int n, Work wk )
@@ -109,7 +116,9 @@ __global__ __launch_bounds__( 256 ) void mest_prepare_kernel( vtmhip_pic_params 
   const int i = blockIdx.x * 256 + threadIdx.x;
   if( i >= n ) return;
   const vtmhip_me_job &j = jobs[i];
-  const long     slot = ( long ) i * wk.slotSamples;
+  if( j.bi ? !wk.hasFull : !wk.hasTz ) return;   // a job that breaks the caller's uniformBi promise is left out (its result is undefined), never written out of bounds
+  const long     slot = pat_off( wk, j, i );
+  const int      sst  = pat_stride( wk, j );
   const int      ss   = sub_shift( cfg, j.width, j.height );
   const unsigned is   = imv_shift( j.imv );
   int ex[15][2];
@@ -117,11 +126,11 @@ __global__ __launch_bounds__( 256 ) void mest_prepare_kernel( vtmhip_pic_params 
   vtmhip_tz_job   &t = wk.tz[i];
   vtmhip_full_job &f = wk.full[i];
   vtmhip_dist_job *d = wk.dist + ( long ) i * REFINE_SLOTS;
-  for( int k = 0; k < REFINE_SLOTS; k++ ) d[k].width = 0;
+  if( wk.needDist ) for( int k = 0; k < REFINE_SLOTS; k++ ) d[k].width = 0;
   if( !j.bi )
   {
-    f.width = 0;
-    t.orgOff = slot; t.refOff = j.refOff; t.orgStride = j.width; t.refStride = j.refStride;
+    if( wk.hasFull ) f.width = 0;
+    t.orgOff = slot; t.refOff = j.refOff; t.orgStride = sst; t.refStride = j.refStride;
     t.puX = j.puX; t.puY = j.puY; t.width = j.width; t.height = j.height; t.subShift = ( int16_t ) ss; t.imvShift = ( uint8_t ) is; t.signedSamples = 0;
     t.predHor = prec_down( j.mvPredHor, 2 ); t.predVer = prec_down( j.mvPredVer, 2 ); t.motionLambda = j.motionLambda;
     t.mvHor = j.mvPredHor; t.mvVer = j.mvPredVer;                      // rcMv = rcMvPred (:3441)
@@ -133,14 +142,15 @@ __global__ __launch_bounds__( 256 ) void mest_prepare_kernel( vtmhip_pic_params 
   }
   else
   {
-    t.width = 0;
+    if( wk.hasTz ) t.width = 0;
     f.width = 0;   // filled by mest_bi_start_kernel
-    for( int k = 0; k <= nex; k++ )
-    {
-      int th = k == 0 ? j.mvHor : ex[k - 1][0], tv = k == 0 ? j.mvVer : ex[k - 1][1];
-      clip_mv( pic, j, th, tv );
-      sad_job( d[k], slot, j, prec_down( th, 4 ), prec_down( tv, 4 ), ss, VTMHIP_DIST_SAD );
-    }
+    if( wk.needDist )
+      for( int k = 0; k <= nex; k++ )
+      {
+        int th = k == 0 ? j.mvHor : ex[k - 1][0], tv = k == 0 ? j.mvVer : ex[k - 1][1];
+        clip_mv( pic, j, th, tv );
+        sad_job( d[k], slot, sst, j, prec_down( th, 4 ), prec_down( tv, 4 ), ss, VTMHIP_DIST_SAD );
+      }
   }
 }
 
@@ -156,7 +166,7 @@ __global__ __launch_bounds__( 256 ) void mest_bi_start_kernel( vtmhip_pic_params
   const int nex = dedup( j, ex );
   unsigned long long best = 0;
   int                bestH = j.mvHor, bestV = j.mvVer;
-  for( int k = 0; k <= nex; k++ )
+  for( int k = 0; k <= ( wk.needDist ? nex : -1 ); k++ )   // needDist == 0: the caller promised empty m_uniMvList lists -- rcMv is the only candidate and wins whatever its cost
   {
     int th = k == 0 ? j.mvHor : ex[k - 1][0], tv = k == 0 ? j.mvVer : ex[k - 1][1];
     clip_mv( pic, j, th, tv );
@@ -165,7 +175,7 @@ __global__ __launch_bounds__( 256 ) void mest_bi_start_kernel( vtmhip_pic_params
     if( k == 0 || c < best ) { best = c; if( k ) { bestH = ex[k - 1][0]; bestV = ex[k - 1][1]; } }
   }
   vtmhip_full_job &f = wk.full[i];
-  f.orgOff = ( long ) i * wk.slotSamples; f.refOff = j.refOff; f.orgStride = j.width; f.refStride = j.refStride;
+  f.orgOff = pat_off( wk, j, i ); f.refOff = j.refOff; f.orgStride = pat_stride( wk, j ); f.refStride = j.refStride;
   f.puX = j.puX; f.puY = j.puY; f.width = j.width; f.height = j.height; f.subShift = ( int16_t ) sub_shift( cfg, j.width, j.height );
   f.imvShift = ( uint8_t ) is; f.signedSamples = 1;
   f.predHor = ph; f.predVer = pv; f.motionLambda = j.motionLambda; f.centerHor = bestH; f.centerVer = bestV; f.searchRange = cfg.bipredSearchRange; f.pad = 0;
@@ -189,13 +199,14 @@ __global__ __launch_bounds__( 256 ) void mest_mid_kernel( vtmhip_pic_params pic,
   if( i >= n ) return;
   const vtmhip_me_job   &j = jobs[i];
   const vtmhip_me_result r = wk.ires[i];
-  const long             slot = ( long ) i * wk.slotSamples;
+  const long             slot = pat_off( wk, j, i );
+  const int              sst  = pat_stride( wk, j );
   vtmhip_frac_job       &q = wk.frac[i];
   vtmhip_dist_job       *d = wk.dist + ( long ) i * REFINE_SLOTS;
-  for( int k = 0; k < REFINE_SLOTS; k++ ) d[k].width = 0;
+  if( wk.needDist ) for( int k = 0; k < REFINE_SLOTS; k++ ) d[k].width = 0;
   if( j.imv == 0 || j.imv == 3 )
   {
-    q.orgOff = slot; q.refOff = j.refOff; q.orgStride = j.width; q.refStride = j.refStride; q.width = j.width; q.height = j.height;
+    q.orgOff = slot; q.refOff = j.refOff; q.orgStride = sst; q.refStride = j.refStride; q.width = j.width; q.height = j.height;
     q.intX = ( int16_t ) r.mvX; q.intY = ( int16_t ) r.mvY;
     q.predHor = prec_down( j.mvPredHor, 2 ); q.predVer = prec_down( j.mvPredVer, 2 ); q.motionLambda = j.motionLambda;
     q.useHad = cfg.useHadME; q.useAltHpelIf = j.imv == 3; q.imvShift = j.imv == 3; q.bitDepth = ( uint8_t ) pic.bitDepth; q.pad = 0;
@@ -209,7 +220,7 @@ __global__ __launch_bounds__( 256 ) void mest_mid_kernel( vtmhip_pic_params pic,
         int th, tv;
         refine_test_mv( j, r.mvX, r.mvY, pos, c, th, tv );
         clip_mv( pic, j, th, tv );
-        sad_job( d[pos * 2 + c], slot, j, th >> 4, tv >> 4, 0, cfg.useHadME ? VTMHIP_DIST_SATD : VTMHIP_DIST_SAD );
+        sad_job( d[pos * 2 + c], slot, sst, j, th >> 4, tv >> 4, 0, cfg.useHadME ? VTMHIP_DIST_SATD : VTMHIP_DIST_SAD );
       }
   }
 }
@@ -281,22 +292,34 @@ extern "C" int vtmhip_xMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip
   VTMHIP_REQUIRE( ctx, cfg->uniformImv >= -1 && cfg->uniformImv <= 3, "uniformImv" );
   VTMHIP_REQUIRE( ctx, cfg->bipredSearchRange >= 0 && cfg->bipredSearchRange <= 64, "bipredSearchRange" );
   VTMHIP_REQUIRE( ctx, !cfg->uniformSquare || maxWidth == maxHeight, "uniformSquare needs maxWidth == maxHeight" );
+  VTMHIP_REQUIRE( ctx, cfg->uniformBi >= 0 && cfg->uniformBi <= 2, "uniformBi" );
 
-  // workspace layout
+  const int  uimv = cfg->uniformImv, ubi = cfg->uniformBi;
+  const bool fracOnly = uimv == 0 || uimv == 3;                       // no AMVR refinement in the batch: its distortion slots are never used
+  const bool allUni = ubi == 1, allBi = ubi == 2;
+  const bool noStart = allBi && cfg->noUniMvList;                    // bi jobs without m_uniMvList candidates: the start is rcMv, no start SADs
+  VTMHIP_REQUIRE( ctx, !cfg->biPatternGiven || d_otherPredBase, "biPatternGiven needs d_otherPredBase (the 2*org - pred blocks)" );
+
+  // workspace layout (regions a uniform batch never touches are not allocated)
   Work   wk;
+  // direct addressing: uniform uni batches read the original plane, uniform bi batches with a caller-made pattern read that; mixed batches copy
+  wk.direct   = allUni || ( allBi && cfg->biPatternGiven );
+  wk.needDist = !( fracOnly && ( allUni || noStart ) );
+  wk.hasTz = !allBi; wk.hasFull = !allUni;
   size_t off = 0;
   const size_t slotSamples = ( size_t ) maxWidth * maxHeight;
-  const size_t oPattern = off; off = align_up( off + ( size_t ) n * slotSamples * sizeof( int16_t ) );
-  const size_t oTz      = off; off = align_up( off + ( size_t ) n * sizeof( vtmhip_tz_job ) );
-  const size_t oFull    = off; off = align_up( off + ( size_t ) n * sizeof( vtmhip_full_job ) );
+  const size_t oPattern = off; off = align_up( off + ( wk.direct ? 0 : ( size_t ) n * slotSamples * sizeof( int16_t ) ) );
+  const size_t oTz      = off; off = align_up( off + ( allBi ? 0 : ( size_t ) n * sizeof( vtmhip_tz_job ) ) );
+  const size_t oFull    = off; off = align_up( off + ( allUni ? 0 : ( size_t ) n * sizeof( vtmhip_full_job ) ) );
   const size_t oIres    = off; off = align_up( off + ( size_t ) n * sizeof( vtmhip_me_result ) );
   const size_t oFrac    = off; off = align_up( off + ( size_t ) n * sizeof( vtmhip_frac_job ) );
   const size_t oFres    = off; off = align_up( off + ( size_t ) n * sizeof( vtmhip_frac_result ) );
-  const size_t oDist    = off; off = align_up( off + ( size_t ) n * REFINE_SLOTS * sizeof( vtmhip_dist_job ) );
-  const size_t oDout    = off; off = align_up( off + ( size_t ) n * REFINE_SLOTS * sizeof( unsigned long long ) );
-  int st = vtmhip_internal_workspace( ctx, off );
+  const size_t oDist    = off; off = align_up( off + ( wk.needDist ? ( size_t ) n * REFINE_SLOTS * sizeof( vtmhip_dist_job ) : 0 ) );
+  const size_t oDout    = off; off = align_up( off + ( wk.needDist ? ( size_t ) n * REFINE_SLOTS * sizeof( unsigned long long ) : 0 ) );
+  void *arena = nullptr;
+  int st = vtmhip_internal_workspace( ctx, off + 256, &arena );
   if( st ) return st;
-  char *base = ( char * ) ctx->work;
+  char *base = ( char * ) arena;
   wk.pattern = ( int16_t * ) ( base + oPattern ); wk.tz = ( vtmhip_tz_job * ) ( base + oTz ); wk.full = ( vtmhip_full_job * ) ( base + oFull );
   wk.ires = ( vtmhip_me_result * ) ( base + oIres ); wk.frac = ( vtmhip_frac_job * ) ( base + oFrac ); wk.fres = ( vtmhip_frac_result * ) ( base + oFres );
   wk.dist = ( vtmhip_dist_job * ) ( base + oDist ); wk.dout = ( unsigned long long * ) ( base + oDout ); wk.slotSamples = ( long ) slotSamples;
@@ -304,38 +327,50 @@ extern "C" int vtmhip_xMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip
   const dim3 perJob( ( n + 255 ) / 256 ), tpb( 256 );
   const int  big = maxWidth > maxHeight ? maxWidth : maxHeight;
   vtmhip_pic_params pTz = *pic, pFull = *pic;
-  if( pic->wavesPerJob == 0 )   // tuning defaults by block size (waves that share one search)
+  if( pic->wavesPerJob == 0 )   // tuning defaults by block size (waves that share one search; measured on 3840x2160 level batches)
   {
-    pTz.wavesPerJob   = big > 16 ? 4 : big > 8 ? 2 : 1;
+    pTz.wavesPerJob   = big > 64 ? 8 : big > 32 ? 2 : 1;
     pFull.wavesPerJob = big > 64 ? 16 : big > 32 ? 8 : big > 16 ? 4 : 1;
   }
+  const int16_t *patBase = wk.direct ? ( allUni ? d_orgBase : d_otherPredBase ) : wk.pattern;
 
-  hipLaunchKernelGGL( mest_pattern_kernel, dim3( n ), tpb, 0, ctx->stream, d_orgBase, d_otherPredBase ? d_otherPredBase : d_orgBase, d_jobs, wk );
+  if( !wk.direct ) hipLaunchKernelGGL( mest_pattern_kernel, dim3( n ), tpb, 0, ctx->stream, d_orgBase, d_otherPredBase ? d_otherPredBase : d_orgBase, d_jobs, wk );
   hipLaunchKernelGGL( mest_prepare_kernel, perJob, tpb, 0, ctx->stream, *pic, *cfg, d_jobs, n, wk );
   VTMHIP_LAUNCHED( ctx );
-  // bi-pred: start candidates -> best start -> exhaustive search
-  st = vtmhip_dist_batch_dev( ctx, wk.pattern, d_refBase, wk.dist, n * REFINE_SLOTS, ( uint64_t * ) wk.dout );
-  if( st ) return st;
-  hipLaunchKernelGGL( mest_bi_start_kernel, perJob, tpb, 0, ctx->stream, *pic, *cfg, d_jobs, n, wk );
-  VTMHIP_LAUNCHED( ctx );
-  // (the lane-per-candidate kernel needs every slot to be a real size x size job: uniform square batches of bi jobs only -- here slots of
-  //  uni jobs are empty, so the cooperative kernel, which skips them, is used)
-  st = vtmhip_full_search_batch_dev( ctx, &pFull, wk.pattern, d_refBase, wk.full, n, wk.ires );
-  if( st ) return st;
-  // uni: TZ search
-  st = vtmhip_tz_search_batch_dev( ctx, &pTz, wk.pattern, d_refBase, wk.tz, n, wk.ires );
-  if( st ) return st;
+  if( !allUni )
+  {
+    // bi-pred: start candidates -> best start -> exhaustive search
+    if( !noStart )
+    {
+      st = vtmhip_dist_batch_dev( ctx, patBase, d_refBase, wk.dist, n * REFINE_SLOTS, ( uint64_t * ) wk.dout );
+      if( st ) return st;
+    }
+    hipLaunchKernelGGL( mest_bi_start_kernel, perJob, tpb, 0, ctx->stream, *pic, *cfg, d_jobs, n, wk );
+    VTMHIP_LAUNCHED( ctx );
+    // the lane-per-candidate kernel needs every slot to be a real size x size job: uniform square batches of bi jobs only (in a mixed batch the
+    // slots of uni jobs are empty; the cooperative kernel skips them)
+    if( allBi && cfg->uniformSquare && cfg->bipredSearchRange <= 4 )
+      st = vtmhip_full_search_square_batch_dev( ctx, &pFull, patBase, d_refBase, wk.full, n, maxWidth, wk.ires );
+    else
+      st = vtmhip_full_search_batch_dev( ctx, &pFull, patBase, d_refBase, wk.full, n, wk.ires );
+    if( st ) return st;
+  }
+  if( !allBi )
+  {
+    // uni: TZ search
+    st = vtmhip_tz_search_batch_dev( ctx, &pTz, patBase, d_refBase, wk.tz, n, wk.ires );
+    if( st ) return st;
+  }
   hipLaunchKernelGGL( mest_mid_kernel, perJob, tpb, 0, ctx->stream, *pic, *cfg, d_jobs, n, wk );
   VTMHIP_LAUNCHED( ctx );
-  const int uimv = cfg->uniformImv;
   if( uimv == -1 || uimv == 0 || uimv == 3 )
   {
-    st = vtmhip_frac_search_batch_dev( ctx, wk.pattern, d_refBase, wk.frac, n, maxWidth, maxHeight, cfg->uniformSquare && uimv != -1, wk.fres );
+    st = vtmhip_frac_search_batch_dev( ctx, patBase, d_refBase, wk.frac, n, maxWidth, maxHeight, cfg->uniformSquare && uimv != -1, wk.fres );
     if( st ) return st;
   }
   if( uimv == -1 || uimv == 1 || uimv == 2 )
   {
-    st = vtmhip_dist_batch_dev( ctx, wk.pattern, d_refBase, wk.dist, n * REFINE_SLOTS, ( uint64_t * ) wk.dout );
+    st = vtmhip_dist_batch_dev( ctx, patBase, d_refBase, wk.dist, n * REFINE_SLOTS, ( uint64_t * ) wk.dout );
     if( st ) return st;
   }
   hipLaunchKernelGGL( mest_final_kernel, perJob, tpb, 0, ctx->stream, *cfg, d_jobs, n, wk, d_results );

@@ -1,0 +1,272 @@
+// pis.hip -- the per-PU arithmetic of InterSearch::predInterSearch around the batched searches (reference EncoderLib/InterSearch.cpp):
+//   xEstimateMvPredAMVP :3088-3128 + xGetTemplateCost :3235-3270   (vtmhip_xEstimateMvPredAMVP_batch_dev, hook B7)
+//   xCheckBestMVP :3185-3232, the reference selection of the uni loop :2354-2450, the bi iteration :2452-2640 (one iteration: FEN), the
+//   uni / bi decision :2846-2893                                   (vtmhip_pis_stage)
+// Heavy work stays in the library's kernels (motion_comp_kernel, dist_uniform_kernel, the searches behind vtmhip_xMotionEstimation_batch_dev);
+// here one thread per row / PU turns one stage's results into the next stage's job records, fp64 exactly where the reference uses it.
+#include "ctx.hpp"
+
+namespace
+{
+
+__device__ __forceinline__ unsigned eg_bits( int v )   // RdCost::xGetExpGolombNumberOfBits (RdCost.h:301-313), closed form (see mest.hip)
+{
+  const unsigned t = ( v <= 0 ) ? ( ( unsigned ) ( -v ) << 1 ) + 1 : ( unsigned ) ( v << 1 );
+  return 1u + ( ( unsigned ) ( 31 - __clz( ( int ) t ) ) << 1 );
+}
+__device__ __forceinline__ unsigned long long rate( double lambda, unsigned bits ) { return ( unsigned long long ) ( lambda * bits ); }   // RdCost::getCost
+__device__ __forceinline__ int prec_down( int v, int rs ) { const int o = 1 << ( rs - 1 ); return v >= 0 ? ( v + o - 1 ) >> rs : ( v + o ) >> rs; }   // Mv::changePrecision
+__device__ __forceinline__ int amvr_shift( int imv ) { return imv == 0 ? 2 : imv == 1 ? 4 : imv == 2 ? 6 : 3; }
+__device__ __forceinline__ void clip_mv( const vtmhip_pic_params &pic, const vtmhip_me_job &j, int &hor, int &ver )   // clipMvInPic (Mv.cpp:56-74)
+{
+  const int horMax = ( pic.picW + 8 - j.puX - 1 ) << 4, horMin = ( -pic.ctuSize - 8 - j.puX + 1 ) << 4;
+  const int verMax = ( pic.picH + 8 - j.puY - 1 ) << 4, verMin = ( -pic.ctuSize - 8 - j.puY + 1 ) << 4;
+  hor = min( horMax, max( horMin, hor ) );
+  ver = min( verMax, max( verMin, ver ) );
+}
+
+// ---- xEstimateMvPredAMVP ---------------------------------------------------------------------------------------------------------
+struct AmvpWork
+{
+  vtmhip_pred_job    *pred;   // [2n]
+  vtmhip_dist_job    *dist;   // [2n]
+  unsigned long long *dout;   // [2n]
+  int16_t            *slots;  // [2n] x slotSamples
+  long                slotSamples;
+};
+
+__global__ __launch_bounds__( 256 ) void amvp_jobs_kernel( vtmhip_pic_params pic, const vtmhip_me_job *__restrict__ jobs, int n, AmvpWork wk )
+{
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if( idx >= 2 * n ) return;
+  const vtmhip_me_job &j = jobs[idx >> 1];
+  const int c = ( idx & 1 ) < j.numAmvpCand ? ( idx & 1 ) : 0;   // a missing second candidate repeats the first (its cost is not looked at)
+  int th = j.amvpCand[c][0], tv = j.amvpCand[c][1];
+  clip_mv( pic, j, th, tv );
+  const long slot = ( long ) idx * wk.slotSamples;
+  vtmhip_pred_job p;
+  p.orgOff = 0; p.refOff[0] = j.refOff; p.refOff[1] = j.refOff; p.predOff = slot; p.outOff = slot;
+  p.orgStride = j.orgStride; p.refStride[0] = p.refStride[1] = j.refStride; p.predStride = j.width; p.outStride = j.width;
+  p.mv[0][0] = th; p.mv[0][1] = tv; p.mv[1][0] = p.mv[1][1] = 0;
+  p.width = j.width; p.height = j.height; p.mode = 0; p.epilogue = 0; p.bitDepth = ( uint8_t ) pic.bitDepth; p.useAltHpelIf = j.imv == 3; p.chroma = 0; p.pad0 = 0; p.pad1 = 0;
+  wk.pred[idx] = p;
+  vtmhip_dist_job d;
+  d.orgOff = j.orgOff; d.curOff = slot; d.orgStride = j.orgStride; d.curStride = j.width; d.width = j.width; d.height = j.height; d.subShift = 0; d.kind = VTMHIP_DIST_SAD;
+  wk.dist[idx] = d;
+}
+
+__global__ __launch_bounds__( 256 ) void amvp_select_kernel( vtmhip_me_job *__restrict__ jobs, int n, AmvpWork wk, int addIdxBits, unsigned long long *__restrict__ distBiP )
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if( i >= n ) return;
+  vtmhip_me_job &j = jobs[i];
+  unsigned long long best = ~0ull;
+  int                bestIdx = 0;
+  for( int c = 0; c < j.numAmvpCand && c < 2; c++ )
+  {
+    const unsigned long long cost = wk.dout[2 * i + c] + rate( j.motionLambda, j.mvpIdxBits[c] );
+    if( best > cost ) { best = cost; bestIdx = c; }
+  }
+  j.mvPredHor = j.amvpCand[bestIdx][0]; j.mvPredVer = j.amvpCand[bestIdx][1];
+  j.mvpIdx    = ( uint8_t ) bestIdx;
+  if( addIdxBits ) j.bits += j.mvpIdxBits[bestIdx];
+  if( distBiP ) distBiP[i] = best;
+}
+
+// ---- predInterSearch glue ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int uni_row( const vtmhip_pis_level &L, int list, int ref, int pu ) { return ( ( list ? L.numRef[0] : 0 ) + ref ) * L.numPU + pu; }
+__device__ __forceinline__ unsigned ref_idx_bits( int numRef, int r ) { return numRef > 1 ? ( unsigned ) ( r + 1 - ( r == numRef - 1 ) ) : 0u; }   // :2357-2364
+
+// xCheckBestMVP (:3185-3232): the vector is re-priced against the other AMVP candidate; a cheaper predictor replaces the chosen one
+__device__ __forceinline__ void check_best_mvp( const vtmhip_me_job &j, vtmhip_pis_row &r )
+{
+  if( j.imv > 0 && j.imv < 3 ) return;
+  if( j.numAmvpCand < 2 ) return;
+  const int sh = amvr_shift( j.imv );
+  const int mh = prec_down( r.mvHor, sh ), mv = prec_down( r.mvVer, sh );
+  int       bestIdx  = r.mvpIdx;
+  const int orgBits  = ( int ) ( eg_bits( mh - prec_down( r.mvPredHor, sh ) ) + eg_bits( mv - prec_down( r.mvPredVer, sh ) ) + j.mvpIdxBits[r.mvpIdx & 1] );
+  int       bestBits = orgBits;
+  for( int c = 0; c < 2; c++ )
+  {
+    if( c == r.mvpIdx ) continue;
+    const int b = ( int ) ( eg_bits( mh - prec_down( j.amvpCand[c][0], sh ) ) + eg_bits( mv - prec_down( j.amvpCand[c][1], sh ) ) + j.mvpIdxBits[c] );
+    if( b < bestBits ) { bestBits = b; bestIdx = c; }
+  }
+  if( bestIdx != r.mvpIdx )
+  {
+    r.mvPredHor = j.amvpCand[bestIdx][0]; r.mvPredVer = j.amvpCand[bestIdx][1];
+    r.mvpIdx    = bestIdx;
+    const unsigned orgAll = r.bits;
+    r.bits = orgAll - ( unsigned ) orgBits + ( unsigned ) bestBits;
+    r.cost = ( r.cost - rate( j.motionLambda, orgAll ) ) + rate( j.motionLambda, r.bits );
+  }
+}
+
+__global__ __launch_bounds__( 256 ) void pis_cands_kernel( vtmhip_pis_level L )
+{
+  const int row = blockIdx.x * 256 + threadIdx.x, rows = ( L.numRef[0] + L.numRef[1] ) * L.numPU;
+  if( row >= rows ) return;
+  const int lr = row / L.numPU, pu = row - lr * L.numPU;
+  const int list = lr >= L.numRef[0], ref = lr - ( list ? L.numRef[0] : 0 );
+  vtmhip_me_job &j = L.uniJobs[row];
+  int ph = 0, pv = 0;
+  const int par = L.parentIdx ? L.parentIdx[pu] : -1;
+  if( par >= 0 ) { const vtmhip_pis_row &p = L.parentRows[lr * L.parentNumPU + par]; ph = p.mvHor; pv = p.mvVer; }
+  j.amvpCand[0][0] = ph; j.amvpCand[0][1] = pv; j.amvpCand[1][0] = 0; j.amvpCand[1][1] = 0;
+  j.numAmvpCand = 2; j.mvpIdxBits[0] = 1; j.mvpIdxBits[1] = 1;   // m_auiMVPIdxCost[i][AMVP_MAX_NUM_CANDS] (xGetMvpIdxBits :3137-3162)
+  j.bi = 0; j.numExtraStart = 0;
+  j.bits = L.mbBits[list] + ref_idx_bits( L.numRef[list], ref );
+}
+
+__device__ __forceinline__ void final_pred( const vtmhip_pis_level &L, int pu, const vtmhip_pis_pu &P )
+{
+  vtmhip_pred_job &pf = L.predFinal[pu];
+  const bool bi = P.interDir == 3;
+  const int  r0 = bi ? P.refIdxBi[0] : P.refIdx[0], r1 = bi ? P.refIdxBi[1] : P.refIdx[1];
+  pf.mode = bi ? 2 : ( P.interDir == 2 ? 1 : 0 );
+  if( P.interDir & 1 ) { pf.refOff[0] = L.refPlaneOff[0][r0] + L.pos[pu]; pf.mv[0][0] = bi ? P.mvBi[0][0] : P.mv[0][0]; pf.mv[0][1] = bi ? P.mvBi[0][1] : P.mv[0][1]; }
+  if( P.interDir & 2 ) { pf.refOff[1] = L.refPlaneOff[1][r1] + L.pos[pu]; pf.mv[1][0] = bi ? P.mvBi[1][0] : P.mv[1][0]; pf.mv[1][1] = bi ? P.mvBi[1][1] : P.mv[1][1]; }
+}
+
+__global__ __launch_bounds__( 256 ) void pis_uni_select_kernel( vtmhip_pis_level L )
+{
+  const int pu = blockIdx.x * 256 + threadIdx.x;
+  if( pu >= L.numPU ) return;
+  vtmhip_pis_pu P;
+  P.cost[0] = P.cost[1] = P.costBi = ~0ull;
+  P.bits[0] = P.bits[1] = P.bits[2] = 0;
+  P.refIdx[0] = P.refIdx[1] = P.refIdxBi[0] = P.refIdxBi[1] = -1;
+  P.mv[0][0] = P.mv[0][1] = P.mv[1][0] = P.mv[1][1] = 0;
+  P.mvBi[0][0] = P.mvBi[0][1] = P.mvBi[1][0] = P.mvBi[1][1] = 0;
+  P.refineList = 0; P.interDir = 1; P.pad = 0;
+  for( int list = 0; list < 2; list++ )
+    for( int ref = 0; ref < L.numRef[list]; ref++ )
+    {
+      const int            row = uni_row( L, list, ref, pu );
+      const vtmhip_me_job &j   = L.uniJobs[row];
+      const vtmhip_me_out  o   = L.uniOut[row];
+      vtmhip_pis_row r;
+      r.mvHor = o.mvHor; r.mvVer = o.mvVer; r.mvPredHor = o.mvPredHor; r.mvPredVer = o.mvPredVer; r.mvpIdx = o.mvpIdx; r.bits = o.bits; r.cost = o.cost;
+      check_best_mvp( j, r );
+      L.uniRows[row] = r;
+      if( r.cost < P.cost[list] ) { P.cost[list] = r.cost; P.bits[list] = r.bits; P.mv[list][0] = r.mvHor; P.mv[list][1] = r.mvVer; P.refIdx[list] = ref; }
+    }
+  if( L.numRef[1] == 0 ) final_pred( L, pu, P );   // P slice: list 0 it is
+  L.pus[pu] = P;
+}
+
+__global__ __launch_bounds__( 256 ) void pis_bi_jobs_kernel( vtmhip_pis_level L )
+{
+  const int pu = blockIdx.x * 256 + threadIdx.x;
+  if( pu >= L.numPU ) return;
+  vtmhip_pis_pu &P = L.pus[pu];
+  const int rl = P.cost[0] <= P.cost[1] ? 1 : 0, ot = 1 - rl;   // FASTINTERSEARCH_MODE1: refine the list with the larger cost (:2544-2556)
+  P.refineList = rl;
+  vtmhip_pred_job &po = L.predOther[pu];
+  po.mode = ( uint8_t ) ot;
+  po.refOff[ot] = L.refPlaneOff[ot][P.refIdx[ot]] + L.pos[pu];
+  po.mv[ot][0] = P.mv[ot][0]; po.mv[ot][1] = P.mv[ot][1];
+  const unsigned motOther = P.bits[ot] - L.mbBits[ot];           // uiMotBits[1 - iRefList] (:2525-2527)
+  for( int ref = 0; ref < L.numRef[rl]; ref++ )
+  {
+    const int             row = uni_row( L, rl, ref, pu );
+    const vtmhip_me_job  &u   = L.uniJobs[row];
+    const vtmhip_pis_row &r   = L.uniRows[row];
+    vtmhip_me_job        &b   = L.biJobs[ref * L.numPU + pu];
+    b.refOff = u.refOff; b.refStride = u.refStride;
+    b.bi = 1; b.imv = u.imv; b.mvpIdx = ( uint8_t ) r.mvpIdx; b.numAmvpCand = u.numAmvpCand;
+    b.mvPredHor = r.mvPredHor; b.mvPredVer = r.mvPredVer;       // cMvPredBi (= cMvPred after xCheckBestMVP)
+    b.mvHor = r.mvHor; b.mvVer = r.mvVer;                       // cMvTemp[iRefList][iRefIdxTemp]: the uni result is the start of the bi search
+    b.amvpCand[0][0] = u.amvpCand[0][0]; b.amvpCand[0][1] = u.amvpCand[0][1]; b.amvpCand[1][0] = u.amvpCand[1][0]; b.amvpCand[1][1] = u.amvpCand[1][1];
+    b.mvpIdxBits[0] = u.mvpIdxBits[0]; b.mvpIdxBits[1] = u.mvpIdxBits[1];
+    b.bits = L.mbBits[2] + motOther + ref_idx_bits( L.numRef[rl], ref ) + u.mvpIdxBits[r.mvpIdx & 1] + ( L.smvdBit ? 1u : 0u );   // :2578-2593
+    b.searchRange = u.searchRange; b.motionLambda = u.motionLambda; b.numExtraStart = 0;
+  }
+}
+
+__global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
+{
+  const int pu = blockIdx.x * 256 + threadIdx.x;
+  if( pu >= L.numPU ) return;
+  vtmhip_pis_pu P  = L.pus[pu];
+  const int     rl = P.refineList, ot = 1 - rl;
+  P.mvBi[ot][0] = P.mv[ot][0]; P.mvBi[ot][1] = P.mv[ot][1]; P.refIdxBi[ot] = P.refIdx[ot];
+  P.mvBi[rl][0] = P.mv[rl][0]; P.mvBi[rl][1] = P.mv[rl][1]; P.refIdxBi[rl] = P.refIdx[rl];
+  for( int ref = 0; ref < L.numRef[rl]; ref++ )
+  {
+    const vtmhip_me_job &j = L.biJobs[ref * L.numPU + pu];
+    const vtmhip_me_out  o = L.biOut[ref * L.numPU + pu];
+    vtmhip_pis_row r;
+    r.mvHor = o.mvHor; r.mvVer = o.mvVer; r.mvPredHor = o.mvPredHor; r.mvPredVer = o.mvPredVer; r.mvpIdx = o.mvpIdx; r.bits = o.bits; r.cost = o.cost;
+    check_best_mvp( j, r );
+    if( r.cost < P.costBi ) { P.costBi = r.cost; P.bits[2] = r.bits; P.mvBi[rl][0] = r.mvHor; P.mvBi[rl][1] = r.mvVer; P.refIdxBi[rl] = ref; }
+  }
+  P.interDir = ( P.costBi <= P.cost[0] && P.costBi <= P.cost[1] ) ? 3 : ( P.cost[0] <= P.cost[1] ? 1 : 2 );   // :2846-2893
+  final_pred( L, pu, P );
+  L.pus[pu] = P;
+}
+
+size_t align_up( size_t v ) { return ( v + 255 ) & ~( size_t ) 255; }
+
+}   // namespace
+
+extern "C"
+{
+
+int vtmhip_xEstimateMvPredAMVP_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                          vtmhip_me_job *d_jobs, int n, int maxWidth, int maxHeight, int uniformSize, int addIdxBits, uint64_t *d_distBiP )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, pic && d_orgBase && d_refBase && d_jobs, "null pointer" );
+  VTMHIP_REQUIRE( ctx, maxWidth >= 4 && maxWidth <= 128 && maxHeight >= 4 && maxHeight <= 128, "maxWidth / maxHeight" );
+  AmvpWork     wk;
+  size_t       off = 0;
+  const size_t slotSamples = ( size_t ) maxWidth * maxHeight;
+  const size_t oPred = off; off = align_up( off + 2 * ( size_t ) n * sizeof( vtmhip_pred_job ) );
+  const size_t oDist = off; off = align_up( off + 2 * ( size_t ) n * sizeof( vtmhip_dist_job ) );
+  const size_t oDout = off; off = align_up( off + 2 * ( size_t ) n * sizeof( unsigned long long ) );
+  const size_t oSlot = off; off = align_up( off + 2 * ( size_t ) n * slotSamples * sizeof( int16_t ) );
+  void *arena = nullptr;
+  int   st    = vtmhip_internal_workspace( ctx, off, &arena );
+  if( st ) return st;
+  char *base = ( char * ) arena;
+  wk.pred = ( vtmhip_pred_job * ) ( base + oPred ); wk.dist = ( vtmhip_dist_job * ) ( base + oDist ); wk.dout = ( unsigned long long * ) ( base + oDout );
+  wk.slots = ( int16_t * ) ( base + oSlot ); wk.slotSamples = ( long ) slotSamples;
+  hipLaunchKernelGGL( amvp_jobs_kernel, dim3( ( 2 * n + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, *pic, d_jobs, n, wk );
+  VTMHIP_LAUNCHED( ctx );
+  st = vtmhip_motion_compensation_batch_dev( ctx, nullptr, d_refBase, wk.slots, nullptr, wk.pred, 2 * n, maxWidth, maxHeight );
+  if( st ) return st;
+  if( uniformSize ) st = vtmhip_dist_uniform_batch_dev( ctx, d_orgBase, wk.slots, wk.dist, 2 * n, VTMHIP_DIST_SAD, maxWidth, maxHeight, 0, ( uint64_t * ) wk.dout );
+  else st = vtmhip_dist_batch_dev( ctx, d_orgBase, wk.slots, wk.dist, 2 * n, ( uint64_t * ) wk.dout );
+  if( st ) return st;
+  hipLaunchKernelGGL( amvp_select_kernel, dim3( ( n + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, d_jobs, n, wk, addIdxBits, ( unsigned long long * ) d_distBiP );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_pis_stage( vtmhip_ctx *ctx, const vtmhip_pis_level *lvl, int stage )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, lvl && stage >= 0 && stage <= 3, "level / stage" );
+  VTMHIP_REQUIRE( ctx, lvl->numPU >= 0 && lvl->numRef[0] >= 1 && lvl->numRef[0] <= VTMHIP_MAX_REF && lvl->numRef[1] >= 0 && lvl->numRef[1] <= VTMHIP_MAX_REF, "numPU / numRef" );
+  if( lvl->numPU == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, lvl->uniJobs && lvl->uniOut && lvl->uniRows && lvl->pus && lvl->predFinal && lvl->pos, "null pointer in the level" );
+  VTMHIP_REQUIRE( ctx, !lvl->parentIdx || lvl->parentRows, "parentIdx without parentRows" );
+  const int  rows = ( lvl->numRef[0] + lvl->numRef[1] ) * lvl->numPU;
+  const dim3 perPU( ( lvl->numPU + 255 ) / 256 ), perRow( ( rows + 255 ) / 256 ), tpb( 256 );
+  if( stage == 0 ) hipLaunchKernelGGL( pis_cands_kernel, perRow, tpb, 0, ctx->stream, *lvl );
+  else if( stage == 1 ) hipLaunchKernelGGL( pis_uni_select_kernel, perPU, tpb, 0, ctx->stream, *lvl );
+  else
+  {
+    VTMHIP_REQUIRE( ctx, lvl->numRef[1] >= 1 && lvl->predOther && lvl->biJobs && lvl->biOut, "the bi stages need list 1 and the bi tables" );
+    if( stage == 2 ) hipLaunchKernelGGL( pis_bi_jobs_kernel, perPU, tpb, 0, ctx->stream, *lvl );
+    else hipLaunchKernelGGL( pis_final_kernel, perPU, tpb, 0, ctx->stream, *lvl );
+  }
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+}   // extern "C"

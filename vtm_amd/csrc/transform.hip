@@ -859,6 +859,7 @@ int launch_tu_uni( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_j
   const size_t  lds   = TUS * perTu * sizeof( int ) + ( ( size_t ) ( w > 32 ? 2 : 6 ) * w * w + ( w == h ? 0 : ( size_t ) ( h > 32 ? 2 : 6 ) * h * h ) ) * sizeof( int16_t );
   if( lds > 64 * 1024 )
     VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( tu_chain_uni_kernel<LPT> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
+  VTMHIP_TIME_KERNEL( ctx, "tu_chain_uni_kernel" );
   hipLaunchKernelGGL( tu_chain_uni_kernel<LPT>, dim3( ( n + TUS - 1 ) / TUS ), dim3( 256 ), lds, ctx->stream, d_resiBase, d_jobs, n, tabs, d_levelsBase, d_recBase,
                       d_results, w, h, d_fwdCoefBase );
   VTMHIP_LAUNCHED( ctx );
@@ -1083,6 +1084,7 @@ int vtmhip_tu_ts_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, co
   if( n == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, d_resiBase && d_jobs && d_results, "null pointer" );
   VTMHIP_REQUIRE( ctx, pow2( width ) && pow2( height ) && width >= 4 && height >= 4 && width <= 32 && height <= 32, "transform skip: 4..32 (log2MaxTransformSkipBlockSize)" );
+  VTMHIP_TIME_KERNEL( ctx, "tu_ts_kernel" );
   hipLaunchKernelGGL( tu_ts_kernel, dim3( ( n + 31 ) / 32 ), dim3( 256 ), 0, ctx->stream, d_resiBase, d_jobs, n, d_levelsBase, d_recBase, d_results, width, height );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;

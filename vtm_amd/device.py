@@ -216,6 +216,23 @@ class Context:
         self._check(self.L.vtmhip_xMotionEstimation_batch_dev(self.h, C.byref(pic), C.byref(cfg), d_org, d_ref, d_other, d_jobs, n,
                                                               max_w, max_h, d_results))
 
+    def estimate_mvp_amvp_batch(self, pic, d_org, d_ref, d_jobs, n, max_w, max_h, uniform=False, add_idx_bits=True, d_dist_bip=None):
+        """InterSearch::xEstimateMvPredAMVP (template cost of the AMVP candidates) for n MeJob rows, in place"""
+        self._check(self.L.vtmhip_xEstimateMvPredAMVP_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, max_w, max_h, int(uniform), int(add_idx_bits), d_dist_bip))
+
+    def kernel_timing(self, enable):
+        """HIP events around every launch of the main kernels, on the launch stream (vtmhip_kernel_timing)"""
+        self._check(self.L.vtmhip_kernel_timing(self.h, int(enable)))
+
+    def kernel_timing_read(self, kernel):
+        """(total milliseconds, launches) of one kernel since kernel_timing(True)"""
+        ms, n = C.c_double(), C.c_int()
+        self._check(self.L.vtmhip_kernel_timing_read(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def pis_stage(self, level, stage):
+        self._check(self.L.vtmhip_pis_stage(self.h, C.byref(level), stage))
+
     def frame_child_start(self, d_child_jobs, n, d_parent_idx, d_parent_res):
         self._check(self.L.vtmhip_frame_child_start(self.h, d_child_jobs, n, d_parent_idx, d_parent_res))
 

@@ -40,3 +40,44 @@ class PlaneExchange:
         if self.pending is not None:
             self.pending.wait()
             self.pending = None
+
+
+class ResultGather:
+    """The way back: every rank's per-PU / per-TU result records of a step travel to rank `dst` (where the host encoder would continue with the
+    mode decision and the entropy coder).  The ranks' shares differ by a few CTUs, so each sends a buffer padded to the largest share; double-
+    buffered and asynchronous like PlaneExchange: the gather of step k runs while step k + 1 computes, a buffer is reused only after its gather
+    has completed."""
+
+    def __init__(self, nbytes_local, device, dst=0):
+        self.rank, self.world, self.dst = dist.get_rank(), dist.get_world_size(), dst
+        sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(self.world)]
+        dist.all_gather(sizes, torch.tensor([nbytes_local], dtype=torch.int64, device=device))
+        self.sizes = [int(s.item()) for s in sizes]
+        self.max = max(self.sizes)
+        self.send = [torch.zeros(self.max, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.recv = [[torch.zeros(self.max, dtype=torch.uint8, device=device) for _ in range(self.world)] for _ in range(2)] if self.rank == dst else None
+        self.pending, self.n = [None, None], 0
+
+    def submit(self, tensors):
+        """tensors: this rank's result tensors (uint8 views) of the step just queued on the current stream"""
+        i = self.n & 1
+        if self.pending[i] is not None:
+            self.pending[i].wait()
+        off = 0
+        for t in tensors:
+            self.send[i][off:off + t.numel()].copy_(t)
+            off += t.numel()
+        assert off == self.sizes[self.rank]
+        self.pending[i] = dist.gather(self.send[i], self.recv[i] if self.rank == self.dst else None, dst=self.dst, async_op=True)
+        self.n += 1
+
+    def drain(self):
+        for i in (0, 1):
+            if self.pending[i] is not None:
+                self.pending[i].wait()
+                self.pending[i] = None
+
+    def last(self):
+        """rank dst, after drain(): the byte tensors of the last submitted step, one per rank, trimmed to that rank's share"""
+        i = (self.n - 1) & 1
+        return [self.recv[i][r][:self.sizes[r]] for r in range(self.world)]

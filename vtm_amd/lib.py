@@ -107,7 +107,8 @@ class AffineJob(C.Structure):
 
 class MeCfg(C.Structure):
     _fields_ = [("bipredSearchRange", C.c_int32), ("useHadME", C.c_uint8), ("fastInterSearchMode13", C.c_uint8),
-                ("extendedSettings", C.c_uint8), ("firstSearchStop", C.c_uint8), ("uniformImv", C.c_int32), ("uniformSquare", C.c_int32)]
+                ("extendedSettings", C.c_uint8), ("firstSearchStop", C.c_uint8), ("uniformImv", C.c_int32), ("uniformSquare", C.c_int32),
+                ("uniformBi", C.c_int32), ("noUniMvList", C.c_uint8), ("biPatternGiven", C.c_uint8), ("pad0", C.c_uint8), ("pad1", C.c_uint8)]
 
 
 class MeJob(C.Structure):
@@ -164,8 +165,29 @@ class LfnstJob(C.Structure):
                 ("inverse", C.c_uint8), ("pad0", C.c_uint8), ("pad1", C.c_uint8), ("pad2", C.c_uint8)]
 
 
+MAX_REF = 4
+
+
+class PisRow(C.Structure):
+    _fields_ = [("mvHor", C.c_int32), ("mvVer", C.c_int32), ("mvPredHor", C.c_int32), ("mvPredVer", C.c_int32), ("mvpIdx", C.c_int32),
+                ("bits", C.c_uint32), ("cost", C.c_uint64)]
+
+
+class PisPu(C.Structure):
+    _fields_ = [("cost", C.c_uint64 * 2), ("costBi", C.c_uint64), ("bits", C.c_uint32 * 3), ("refIdx", C.c_int32 * 2), ("mv", (C.c_int32 * 2) * 2),
+                ("refIdxBi", C.c_int32 * 2), ("mvBi", (C.c_int32 * 2) * 2), ("refineList", C.c_int32), ("interDir", C.c_int32), ("pad", C.c_int32)]
+
+
+class PisLevel(C.Structure):
+    _fields_ = [("numPU", C.c_int32), ("numRef", C.c_int32 * 2), ("smvdBit", C.c_int32), ("mbBits", C.c_uint32 * 3), ("refStride", C.c_int32),
+                ("refPlaneOff", (C.c_int64 * MAX_REF) * 2), ("uniJobs", C.c_void_p), ("uniOut", C.c_void_p), ("uniRows", C.c_void_p), ("pus", C.c_void_p),
+                ("predOther", C.c_void_p), ("biJobs", C.c_void_p), ("biOut", C.c_void_p), ("predFinal", C.c_void_p), ("parentIdx", C.c_void_p),
+                ("parentRows", C.c_void_p), ("parentNumPU", C.c_int32), ("pad", C.c_int32), ("pos", C.c_void_p)]
+
+
 _STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob,
-            TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut, PredJob, FrameTabs, MaskedSadJob, GeoBlendJob, DmvrJob, LfnstJob]   # order of vtmhip_struct_size(which)
+            TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut, PredJob, FrameTabs, MaskedSadJob, GeoBlendJob, DmvrJob, LfnstJob,
+            PisRow, PisPu, PisLevel]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
 _PROTOS = {
@@ -253,6 +275,11 @@ _PROTOS = {
                                         C.c_void_p]),
     "vtmhip_xMotionEstimation_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.POINTER(MeCfg), C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vtmhip_xEstimateMvPredAMVP_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                       C.c_int, C.c_int, C.c_void_p]),
+    "vtmhip_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "vtmhip_kernel_timing_read": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "vtmhip_pis_stage": (C.c_int, [C.c_void_p, C.POINTER(PisLevel), C.c_int]),
     "vtmhip_tz_search_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_void_p]),
 }

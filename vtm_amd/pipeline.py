@@ -35,9 +35,28 @@ def subshift_mode2(w, h):
     return 1 if (h > 8 and w <= 64) else 0
 
 
-def quadtree_levels(pic_w, pic_h, sizes=(128, 64, 32, 16, 8), row_filter=None):
+def ctu_bands(pic_w, pic_h, world, ctu=128, unit="ctu"):
+    """Partition of a picture's CTUs (raster order) into `world` contiguous bands, one per rank -- the CTU-row sharding of one frame
+    (the reference's row loop: EncSlice.cpp:1519-1720).  unit "row": whole CTU rows (17 rows of a 4K picture over 8 ranks
+    = 3,2,2,... rows: the slowest rank caps the speed-up at 17 / (8 * 3) = 71 %); unit "ctu": the boundary row is cut at a CTU, i.e.
+    raster-scan CTU ranges as VVC's raster-scan slices (510 CTUs over 8 ranks = 64 / 63 CTUs: 99.6 %).
+    Returns [(first_ctu, last_ctu_exclusive)] in raster-scan CTU addresses."""
+    cw, ch = -(-pic_w // ctu), -(-pic_h // ctu)
+    n = ch if unit == "row" else cw * ch
+    cuts = [(n * r) // world for r in range(world + 1)]
+    return [(a * cw, b * cw) if unit == "row" else (a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+
+
+def band_filter(pic_w, band, ctu=128):
+    """ctu_filter for quadtree_levels: keeps the PUs whose CTU address lies in band = (first, last_exclusive)"""
+    cw = -(-pic_w // ctu)
+    return lambda cy, cx: (cy * cw + cx >= band[0]) & (cy * cw + cx < band[1])
+
+
+def quadtree_levels(pic_w, pic_h, sizes=(128, 64, 32, 16, 8), row_filter=None, ctu_filter=None):
     """Square PUs of every quadtree level that lie fully inside the picture.  row_filter(ctu_row_array) -> bool array selects the
-    CTU rows (128 luma rows each) this rank owns.  Returns [(size, xs, ys, parent_index_or_None)], coarse to fine."""
+    CTU rows (128 luma rows each) this rank owns; ctu_filter(ctu_row_array, ctu_col_array) -> bool array selects single CTUs.
+    Returns [(size, xs, ys, parent_index_or_None)], coarse to fine."""
     levels = []
     prev = None
     for s in sizes:
@@ -45,6 +64,9 @@ def quadtree_levels(pic_w, pic_h, sizes=(128, 64, 32, 16, 8), row_filter=None):
         xs, ys = xs.ravel().astype(np.int64), ys.ravel().astype(np.int64)
         if row_filter is not None:
             keep = np.asarray(row_filter(ys // 128), dtype=bool)
+            xs, ys = xs[keep], ys[keep]
+        if ctu_filter is not None:
+            keep = np.asarray(ctu_filter(ys // 128, xs // 128), dtype=bool)
             xs, ys = xs[keep], ys[keep]
         parent = None
         if prev is not None:
@@ -78,7 +100,7 @@ class FrameME:
     torch tensors: `org` int16 [H*orgStride], `dpb` int16 (all reference planes, border-extended, back to back)."""
 
     def __init__(self, ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda=8.0,
-                 sizes=(128, 64, 32, 16, 8), row_filter=None, waves_per_job=None):
+                 sizes=(128, 64, 32, 16, 8), row_filter=None, waves_per_job=None, ctu_filter=None):
         """refs: [(ref_off, ref_stride)] sample offsets of each reference plane's (0,0) inside `dpb`."""
         self.ctx, self.torch, self.device = ctx, torch, device
         self.pic_w, self.pic_h = pic_w, pic_h
@@ -91,7 +113,7 @@ class FrameME:
         self.levels = []
         self.n_jobs = 0
         self.alg_bytes_per_eval = []
-        for (s, xs, ys, parent) in quadtree_levels(pic_w, pic_h, sizes, row_filter):
+        for (s, xs, ys, parent) in quadtree_levels(pic_w, pic_h, sizes, row_filter, ctu_filter):
             if xs.size == 0:
                 continue
             tabs, parents = [], []
@@ -179,7 +201,7 @@ class _Tab:
         return self.t.data_ptr()
 
 
-class FrameHotPath(FrameME):
+class FrameHotPathV1(FrameME):
     """All stages for one picture with two reference pictures (list 0 / list 1):
 
       tz      InterSearch::xTZSearch per (PU, list), level by level (children start from the parent's vector)   (InterSearch.cpp:3640-3976)
@@ -515,3 +537,268 @@ class FrameHotPath(FrameME):
                 ctx.dist_batch(self.buf["resi"].data_ptr(), self.rec_resi.data_ptr(), lvl["sse"].ptr, nt, lvl["sse_out"].data_ptr())
         self._mark("tu")
         self._publish()
+
+
+# ======================================================================================================================
+# Level-order InterSearch::predInterSearch (InterSearch.cpp:2245-3065, translational part) + residual coding of one picture
+# ======================================================================================================================
+from .lib import MAX_REF, MeCfg, MeJob, MeOut, PisLevel, PisPu, PisRow   # noqa: E402
+
+ME_DT, MEOUT_DT, ROW_DT, PU_DT = np.dtype(MeJob), np.dtype(MeOut), np.dtype(PisRow), np.dtype(PisPu)
+# (typeHor, typeVer) per tu.mtsIdx (TrQuant::getTrTypes): 0 DCT2/DCT2, 1 transform skip, 2..5 the DST7/DCT8 pairs
+TRSKIP = 3
+MTS_IDX_TYPES = {0: (0, 0), 1: (TRSKIP, TRSKIP), 2: (2, 2), 3: (1, 2), 4: (2, 1), 5: (1, 1)}
+
+
+def asr_search_range(delta_poc, search_range=384, min_window=96):
+    """EncSlice.cpp:1127 (ASR): Clip3( MinSearchWindow, SearchRange, (SearchRange * ADAPT_SR_SCALE * |dPOC| + 8) / 16 )"""
+    return int(min(search_range, max(min_window, (search_range * abs(delta_poc) + 8) // 16)))
+
+
+class FrameHotPath:
+    """All stages of one inter picture, level by level over the quadtree of square PUs (128 .. 8):
+
+      amvp    xEstimateMvPredAMVP per (PU, list, refIdx): template cost of the two AMVP candidates            (InterSearch.cpp:3088-3128)
+      uni     xMotionEstimation per (PU, list, refIdx): xTZSearch from the chosen predictor, xPatternSearchFracDIF (SATD), rate re-weighting
+              (:3299-3494); xCheckBestMVP; best reference picture per list                                     (:2354-2450)
+      bi      B slices, FEN: the list with the larger cost is refined for EVERY reference picture against the other list's prediction
+              (motionCompensation -> 2*org - pred, +-4 xPatternSearch, fractional search, fWeight 0.5); xCheckBestMVP (:2452-2640)
+      decide  uiCostBi <= uiCost[0], uiCost[1] ? bi : the cheaper list                                         (:2846-2893)
+      resi    chosen prediction (uni, or addAvg of two 14-bit predictions) -> residual -> per TU (<= 64x64) and transform candidate
+              (DCT2, optionally transform skip, 4 MTS pairs up to 32x32): xT, Quant::quant, dequant, xIT, SSE    (:6637-6733)
+
+    The reference visits one PU at a time inside the CU recursion; here every step is one launch over all PUs of a level x reference pictures
+    (C ABI: vtmhip_xEstimateMvPredAMVP_batch_dev, vtmhip_xMotionEstimation_batch_dev, vtmhip_motion_compensation_batch_dev,
+    vtmhip_tu_chain_batch_dev, glue: vtmhip_pis_stage), tables and decisions stay in HBM.  Stand-ins for what needs the CU recursion (out of
+    scope): the AMVP candidates of a PU are its parent block's vector for the same (list, refIdx) and the zero vector, there
+    is no m_uniMvList history, CABAC bit estimates and the mode decision between transform candidates stay with the host.
+
+    refs: ([(ref_off, ref_stride)] list 0, [...] list 1) -- list 1 empty: P slice (uni-prediction only, as encoder_lowdelay_P_vtm.cfg).
+    search_ranges: per list, per reference picture (m_aaiAdaptSR)."""
+
+    def __init__(self, ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda=8.0, qp=32, sizes=(128, 64, 32, 16, 8),
+                 ctu_filter=None, transform_skip=False, bit_depth=10):
+        T, dev = torch, device
+        self.ctx, self.torch, self.device = ctx, T, dev
+        self.pic_w, self.pic_h, self.org_stride, self.lam = pic_w, pic_h, org_stride, motion_lambda
+        self.refs = refs
+        nref = [len(refs[0]), len(refs[1])]
+        assert 1 <= nref[0] <= MAX_REF and nref[1] <= MAX_REF
+        assert nref[1] == 0 or nref[1] == nref[0], "B slices: equal numbers of active reference pictures per list (as the CTC GOP tables have)"
+        self.nref, self.is_b = nref, nref[1] > 0
+        R = nref[0] + nref[1]
+        rs = refs[0][0][1]
+        assert all(r[1] == rs for l in refs for r in l)
+        self.rs = rs
+        base_qp = qp + 6 * (bit_depth - 8)
+        self.qp_per, self.qp_rem = base_qp // 6, base_qp % 6
+        self.bd = bit_depth
+        wpj = dict(WAVES_PER_JOB)
+        for kv in filter(None, os.environ.get("VTM_AMD_TZ_WPJ", "").split(",")):
+            k, v = kv.split(":")
+            wpj[int(k)] = int(v)
+        cands = [0] + ([1] if transform_skip else []) + [2, 3, 4, 5]
+        self.levels, prev = [], None
+        sb = 0
+        for (s, xs, ys, parent) in quadtree_levels(pic_w, pic_h, sizes, None, ctu_filter):
+            n = xs.size
+            if n == 0:
+                prev = None
+                continue
+            lvl = dict(size=s, npu=n, xs=xs, ys=ys, sb=sb)
+            blk = sb + np.arange(n, dtype=np.int64) * s * s          # compact per-PU slots of the level-wide sample buffers
+            sb += n * s * s
+            uj = np.zeros(R * n, ME_DT)
+            for l in (0, 1):
+                for r in range(nref[l]):
+                    sl = slice(((nref[0] if l else 0) + r) * n, ((nref[0] if l else 0) + r + 1) * n)
+                    uj["refOff"][sl] = refs[l][r][0] + ys * rs + xs
+                    uj["searchRange"][sl] = search_ranges[l][r]
+            uj["orgOff"], uj["orgStride"], uj["refStride"] = np.tile(ys * org_stride + xs, R), org_stride, rs
+            uj["puX"], uj["puY"], uj["width"], uj["height"] = np.tile(xs, R), np.tile(ys, R), s, s
+            uj["motionLambda"], uj["numAmvpCand"] = motion_lambda, 2
+            lvl["uni_jobs"] = _Tab(T, dev, uj)
+            lvl["uni_out"] = T.zeros((R * n, MEOUT_DT.itemsize), dtype=T.uint8, device=dev)
+            lvl["uni_rows"] = T.zeros((R * n, ROW_DT.itemsize), dtype=T.uint8, device=dev)
+            lvl["pus"] = T.zeros((n, PU_DT.itemsize), dtype=T.uint8, device=dev)
+            pj = np.zeros(n, PRED_DT)
+            pj["orgOff"], pj["orgStride"], pj["refStride"] = ys * org_stride + xs, org_stride, rs
+            pj["predOff"], pj["outOff"], pj["predStride"], pj["outStride"] = blk, blk, s, s
+            pj["width"], pj["height"], pj["bitDepth"] = s, s, bit_depth
+            pf = pj.copy()
+            pf["epilogue"] = 1                                         # residual = org - pred
+            lvl["pred_final"] = _Tab(T, dev, pf)
+            lvl["pos"] = T.from_numpy(ys * rs + xs).to(dev)
+            if self.is_b:
+                po = pj.copy()
+                po["epilogue"] = 2                                     # bi-pred search pattern 2*org - pred (removeHighFreq)
+                lvl["pred_other"] = _Tab(T, dev, po)
+                nb = nref[0]
+                bj = np.zeros(nb * n, ME_DT)
+                bj["orgOff"], bj["orgStride"] = np.tile(ys * org_stride + xs, nb), org_stride
+                bj["otherPredOff"], bj["otherPredStride"] = np.tile(blk, nb), s
+                bj["puX"], bj["puY"], bj["width"], bj["height"] = np.tile(xs, nb), np.tile(ys, nb), s, s
+                lvl["bi_jobs"] = _Tab(T, dev, bj)
+                lvl["bi_out"] = T.zeros((nb * n, MEOUT_DT.itemsize), dtype=T.uint8, device=dev)
+            par32 = None
+            if parent is not None and prev is not None:
+                par32 = T.from_numpy(parent.astype(np.int32)).to(dev)
+            lvl["parent32"] = par32
+            L = PisLevel()
+            L.numPU, L.smvdBit, L.refStride = n, 0, rs
+            L.numRef[0], L.numRef[1] = nref
+            L.mbBits[0], L.mbBits[1], L.mbBits[2] = (3 if self.is_b else 1), 3, 5      # xGetBlkBits (:3164-3169)
+            for l in (0, 1):
+                for r in range(nref[l]):
+                    L.refPlaneOff[l][r] = int(refs[l][r][0])
+            L.uniJobs, L.uniOut, L.uniRows, L.pus = lvl["uni_jobs"].ptr, lvl["uni_out"].data_ptr(), lvl["uni_rows"].data_ptr(), lvl["pus"].data_ptr()
+            L.predFinal, L.pos = lvl["pred_final"].ptr, lvl["pos"].data_ptr()
+            if self.is_b:
+                L.predOther, L.biJobs, L.biOut = lvl["pred_other"].ptr, lvl["bi_jobs"].ptr, lvl["bi_out"].data_ptr()
+            if par32 is not None:
+                L.parentIdx, L.parentRows, L.parentNumPU = par32.data_ptr(), prev["uni_rows"].data_ptr(), prev["npu"]
+            lvl["pis"] = L
+            lvl["pic"] = PicParams(pic_w, pic_h, 128, bit_depth, wpj.get(s, 1))
+            lvl["pic_bi"] = PicParams(pic_w, pic_h, 128, bit_depth, FULL_WAVES_PER_JOB.get(s, 1))
+            lvl["cfg_uni"] = MeCfg(4, 1, 1, 0, 1, 0, 1, 1, 1, 0)           # BipredSearchRange 4, HadamardME, FEN, uniform: imv 0, square, all uni, no m_uniMvList
+            lvl["cfg_bi"] = MeCfg(4, 1, 1, 0, 1, 0, 1, 2, 1, 1)            # all bi, the pattern 2*org - pred comes from the fused MC epilogue
+            # ---- transform units: the PU itself up to 64x64, four 64x64 quadrants of a 128x128 PU (MaxTbSize 64) -------------------------
+            ts = min(s, 64)
+            q = s // ts
+            tu_src = np.stack([blk + qy * ts * s + qx * ts for qy in range(q) for qx in range(q)], 1).reshape(-1)
+            ntu = tu_src.size
+            cl = [c for c in cands if c == 0 or (ts <= 32)]
+            nc = len(cl)
+            tj = np.zeros(ntu * nc, TU_DT)
+            tj["resiOff"], tj["resiStride"], tj["width"], tj["height"] = np.tile(tu_src, nc), s, ts, ts
+            tj["outOff"] = np.arange(ntu * nc, dtype=np.int64) * ts * ts
+            tj["qpPer"], tj["qpRem"], tj["bitDepth"] = self.qp_per, self.qp_rem, bit_depth
+            tj["typeHor"] = np.repeat([MTS_IDX_TYPES[c][0] for c in cl], ntu)
+            tj["typeVer"] = np.repeat([MTS_IDX_TYPES[c][1] for c in cl], ntu)
+            lvl.update(ntu=ntu, nc=nc, ts=ts, cands=cl, tu=_Tab(T, dev, tj), tu_res=T.zeros((ntu * nc, 2), dtype=T.int64, device=dev),
+                       qcoef=T.zeros(ntu * nc * ts * ts, dtype=T.int32, device=dev))
+            self.levels.append(lvl)
+            prev = lvl
+        self.NS = sb
+        self.NP = sum(l["npu"] for l in self.levels)
+        self.n_me_jobs = sum(l["npu"] * (R + (nref[0] if self.is_b else 0)) for l in self.levels)
+        mk = lambda: T.zeros(max(1, sb), dtype=T.int16, device=dev)   # noqa: E731
+        self.buf = dict(pred=mk(), resi=mk())
+        if self.is_b:
+            self.buf["org_bi"] = mk()
+        self.side_streams = [T.cuda.Stream(device=dev) for _ in range(int(os.environ.get("VTM_AMD_SIDE_STREAMS", "5")))] if dev.type == "cuda" else []
+        self._marks = None
+
+    # ---- stage timing (HIP events on the launch stream; only when run(..., timing=True)) ----------------------------------
+    def _mark(self, name):
+        if self._marks is not None:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._marks.append((name, e))
+
+    def stage_ms(self):
+        acc = {}
+        for (n0, e0), (n1, e1) in zip(self._marks[:-1], self._marks[1:]):
+            acc[n1] = acc.get(n1, 0.0) + e0.elapsed_time(e1)
+        acc.pop("start", None)
+        return acc
+
+    # ---- the steps of one level ---------------------------------------------------------------------------------------------
+    def _uni(self, lvl, org_ptr, dpb_ptr):
+        ctx, n, s = self.ctx, lvl["npu"], lvl["size"]
+        rows = (self.nref[0] + self.nref[1]) * n
+        ctx.pis_stage(lvl["pis"], 0)
+        self._mark("glue")
+        ctx.estimate_mvp_amvp_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["uni_jobs"].ptr, rows, s, s, uniform=True)
+        self._mark("amvp")
+        ctx.motion_estimation_batch(lvl["pic"], lvl["cfg_uni"], org_ptr, dpb_ptr, None, lvl["uni_jobs"].ptr, rows, s, s, lvl["uni_out"].data_ptr())
+        self._mark("uni_me")
+        ctx.pis_stage(lvl["pis"], 1)
+        self._mark("glue")
+
+    def _rest(self, lvl, org_ptr, dpb_ptr):
+        ctx, n, s, buf = self.ctx, lvl["npu"], lvl["size"], self.buf
+        if self.is_b:
+            ctx.pis_stage(lvl["pis"], 2)
+            self._mark("glue")
+            ctx.motion_compensation_batch(org_ptr, dpb_ptr, None, buf["org_bi"].data_ptr(), lvl["pred_other"].ptr, n, s, s)
+            self._mark("mc")
+            ctx.motion_estimation_batch(lvl["pic_bi"], lvl["cfg_bi"], org_ptr, dpb_ptr, buf["org_bi"].data_ptr(), lvl["bi_jobs"].ptr, self.nref[0] * n, s, s,
+                                        lvl["bi_out"].data_ptr())
+            self._mark("bi_me")
+            ctx.pis_stage(lvl["pis"], 3)
+            self._mark("glue")
+        ctx.motion_compensation_batch(org_ptr, dpb_ptr, buf["pred"].data_ptr(), buf["resi"].data_ptr(), lvl["pred_final"].ptr, n, s, s)
+        self._mark("mc")
+        self._tu(lvl)
+        self._mark("tu")
+
+    def _tu(self, lvl):
+        ctx, ts, ntu = self.ctx, lvl["ts"], lvl["ntu"]
+        tu_p, res_p, q_p = lvl["tu"].ptr, lvl["tu_res"].data_ptr(), lvl["qcoef"].data_ptr()
+        cands, k = lvl["cands"], 0
+        while k < len(cands):            # candidates are stored one after the other; transform skip goes to its own (elementwise) kernel
+            run = 1
+            if cands[k] != 1:
+                while k + run < len(cands) and cands[k + run] != 1:
+                    run += 1
+            a, m = k * ntu, run * ntu
+            if cands[k] == 1:
+                ctx.tu_ts_chain_batch(self.buf["resi"].data_ptr(), tu_p + a * TU_DT.itemsize, m, ts, ts, res_p + a * 16, q_p)
+            else:
+                ctx.tu_chain_batch(self.buf["resi"].data_ptr(), tu_p + a * TU_DT.itemsize, m, ts, ts, res_p + a * 16, q_p, None, uniform=True)
+            k += run
+
+    def run(self, org_ptr, dpb_ptr, timing=False):
+        """timing=True (or no side streams / VTM_AMD_OVERLAP=0): every level's steps one after the other on one stream with an event after every
+        step; otherwise level-major over the side streams: the uni searches form one dependent chain (a child's AMVP candidate is its parent's vector)
+        on the caller's stream, everything after a level's uni stage runs on a side stream beside the next levels' searches."""
+        T, ctx = self.torch, self.ctx
+        overlapped = not timing and self.side_streams and os.environ.get("VTM_AMD_OVERLAP", "1") != "0"
+        self._marks = [] if timing else None
+        self._mark("start")
+        if not overlapped:
+            for lvl in self.levels:
+                self._uni(lvl, org_ptr, dpb_ptr)
+            for lvl in self.levels:
+                self._rest(lvl, org_ptr, dpb_ptr)
+            return
+        main = T.cuda.current_stream()
+        for i, lvl in enumerate(self.levels):
+            self._uni(lvl, org_ptr, dpb_ptr)
+            ev = T.cuda.Event()
+            ev.record(main)
+            st = self.side_streams[i % len(self.side_streams)]
+            st.wait_event(ev)
+            ctx.set_stream(st.cuda_stream)
+            self._rest(lvl, org_ptr, dpb_ptr)
+            ctx.set_stream(main.cuda_stream)
+        for st in self.side_streams:
+            main.wait_stream(st)
+
+    # ---- results ----------------------------------------------------------------------------------------------------------------
+    def snapshot(self):
+        """numpy copies of every decision, per level (tests/cpu_chain.py, a host encoder, the multi-GPU gather read these)"""
+        out = []
+        for lvl in self.levels:
+            d = dict(size=lvl["size"], npu=lvl["npu"], ntu=lvl["ntu"], nc=lvl["nc"], ts=lvl["ts"], cands=lvl["cands"], xs=lvl["xs"], ys=lvl["ys"],
+                     uni_jobs=lvl["uni_jobs"].t.cpu().numpy().view(ME_DT).reshape(-1), uni_out=lvl["uni_out"].cpu().numpy().view(MEOUT_DT).reshape(-1),
+                     uni_rows=lvl["uni_rows"].cpu().numpy().view(ROW_DT).reshape(-1), pus=lvl["pus"].cpu().numpy().view(PU_DT).reshape(-1),
+                     tu_res=lvl["tu_res"].cpu().numpy())
+            if self.is_b:
+                d["bi_jobs"] = lvl["bi_jobs"].t.cpu().numpy().view(ME_DT).reshape(-1)
+                d["bi_out"] = lvl["bi_out"].cpu().numpy().view(MEOUT_DT).reshape(-1)
+            out.append(d)
+        return out
+
+    def result_tensors(self):
+        """the per-PU / per-TU result tensors a rank hands to rank 0 (bytes views), coarse to fine"""
+        out = []
+        for lvl in self.levels:
+            out += [lvl["pus"].reshape(-1), lvl["tu_res"].view(self.torch.uint8).reshape(-1)]
+        return out
+
+    def work_counts(self):
+        R = self.nref[0] + self.nref[1]
+        return dict(pus=self.NP, uni_searches=R * self.NP, bi_searches=(self.nref[0] if self.is_b else 0) * self.NP,
+                    tu_chains=sum(l["ntu"] * l["nc"] for l in self.levels))
