@@ -226,10 +226,10 @@ int vtmhip_internal_scratch( vtmhip_ctx *ctx, size_t bytes )
   return VTMHIP_OK;
 }
 
-int vtmhip_internal_workspace( vtmhip_ctx *ctx, size_t bytes, void **out )
+int vtmhip_internal_workspace( vtmhip_ctx *ctx, size_t bytes, void **out, int slot )
 {
   std::lock_guard<std::mutex> lock( ctx->initMutex );
-  vtmhip_ctx::WorkArena &a = ctx->work[ctx->stream];
+  vtmhip_ctx::WorkArena &a = ctx->work[std::make_pair( ctx->stream, slot )];
   if( bytes > a.size )
   {
     const size_t want = ( bytes + ( 1u << 20 ) - 1 ) & ~( size_t )( ( 1u << 20 ) - 1 );

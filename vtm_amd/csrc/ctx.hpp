@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <utility>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -27,7 +28,7 @@ struct vtmhip_ctx
   // calls queued on different streams (a level-order driver runs the levels' chains concurrently) never share scratch memory; calls on one stream are
   // ordered and reuse their arena
   struct WorkArena { void *ptr = nullptr; size_t size = 0; };
-  std::map<hipStream_t, WorkArena> work;
+  std::map<std::pair<hipStream_t, int>, WorkArena> work;   // key: (stream, slot) -- slot 0: the multi-stage calls, slot 1: calls they nest (the split TZ search)
   int8_t     *lfnstTab    = nullptr;   // the caller's LFNST core matrices: g_lfnst8x8 [4][2][16][48] then g_lfnst4x4 [4][2][16][16] (vtmhip_lfnst_set_tables)
   int16_t    *trTabBuf    = nullptr;   // the transform core matrices of THIS context's device (transform.hip ensure_tables; freed by vtmhip_destroy)
   const int16_t *trTab[3][7] = {};     // [type][log2 N] -> N x N forward matrix inside trTabBuf
@@ -94,7 +95,7 @@ struct vtmhip_launch_timer
 #define VTMHIP_LAUNCHED( ctx ) VTMHIP_HIP( ctx, hipGetLastError() )
 
 int vtmhip_internal_scratch( vtmhip_ctx *ctx, size_t bytes );   // grows ctx->scratch / ctx->pinned
-int vtmhip_internal_workspace( vtmhip_ctx *ctx, size_t bytes, void **out ); // the arena of ctx->stream, grown to `bytes` (device only)
+int vtmhip_internal_workspace( vtmhip_ctx *ctx, size_t bytes, void **out, int slot = 0 ); // the arena (slot) of ctx->stream, grown to `bytes` (device only)
 
 // ---- device helpers -------------------------------------------------------------------------------------------
 __device__ __forceinline__ int wave_reduce_add( int v )

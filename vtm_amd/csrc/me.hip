@@ -13,6 +13,8 @@
 // thousands of jobs (all PUs x reference pictures of a picture).
 #include "ctx.hpp"
 
+#include <cstdlib>
+
 namespace
 {
 
@@ -583,21 +585,175 @@ __device__ __forceinline__ void tz_raster( const MeJob &j, TzState &s, const Ran
   }
 }
 
+// ---- split search: the raster scan as its own kernel ---------------------------------------------------------------------------------
+// A raster scan (:3888-3899) evaluates (2 SR / 5 + 1)^2 = 1521 positions of a 128x128 block: 25 M sample differences, each reference sample
+// re-read by ~26 candidates.  One candidate at a time per workgroup (eval_candidates) makes that an L2-bandwidth problem (50 MB through L1 per
+// job).  When the batch is launched in split mode the search kernel stops at the raster decision, the jobs that need a scan are collected in a
+// list, tz_raster_cols_kernel scans them with register reuse, and the search kernel resumes (mode 2) with the scan's (cost, index) minimum --
+// the same accept rule, the same result.
+struct TzSaved
+{
+  Range              sr;
+  unsigned long long bestSad;
+  int                bestX, bestY, pointNr;
+  unsigned           bestDist, bestRound, nEval;
+  unsigned long long rasterCost;
+  unsigned           rasterIdx;
+  int                pad;
+};
+constexpr int RASTER_TOT_CAP = 40 * 40;   // candidates of a scan the column kernel takes (SR 96: 39 x 39)
+constexpr int RASTER_CHUNK   = 13;        // block rows (slots) of one task at most
+
+// One lane = one raster COLUMN (dx = left + 5 lane).  The block rows the SAD visits (every (1 << ss)-th) and the scan's dy values
+// (top + 5 m) pair up by residue: with rowStep = 5 << ss, block row r = rho + rowStep * s (rho = c << ss, c = 0..4) and candidate
+// m = p + (1 << ss) * m' meet in reference row top + 5 p + rho + rowStep * (m' + s).  A task = (8-sample column segment k, class rho, parity p,
+// chunk of <= 13 rows of the class): the lane walks down those reference rows; row u feeds candidate m' = u - slot for every slot at once, so
+// ONE 16-byte reference load serves up to 13 candidates.  The chunk's block-row segments stay in registers for the whole task, the running
+// sums rotate by one slot per step (a candidate enters slot 0 and leaves slot NS - 1 complete for this task) and are added to the candidate's
+// total in LDS.  Reference traffic of a 128x128 scan: ~5 MB instead of 50 MB through L1 / L2; no per-candidate cross-lane reduction at all.
+template<int NS>
+__device__ __forceinline__ void raster_task( const MeJob &j, const Range &r, int nx, int ny, int lane, int myX, int k, int rho, int p, int chunk, int rowStep,
+                                             unsigned *sTot )
+{
+  const int par = 1 << j.ss;
+  const int nyp = ( ny - p + par - 1 ) >> j.ss;                       // candidates m = p, p + par, ...
+  if( nyp <= 0 ) return;
+  const int rowsOfClass = ( j.h - rho + rowStep - 1 ) / rowStep;       // block rows rho, rho + rowStep, ... < h
+  const int needed = min( NS, rowsOfClass - chunk * RASTER_CHUNK );
+  if( needed <= 0 ) return;
+  const int pad = NS - needed;                                         // the chunk's rows sit in slots pad .. NS - 1
+  unsigned  O[NS][4], A[NS];
+#pragma unroll
+  for( int sl = 0; sl < NS; sl++ )
+  {
+    A[sl] = 0;
+    const int  rr = rho + rowStep * ( chunk * RASTER_CHUNK + max( sl - pad, 0 ) );
+    const Pel8 a  = *reinterpret_cast<const Pel8 *>( j.org + ( long ) rr * j.orgStride + ( k << 3 ) );
+    O[sl][0] = a.v[0] ^ j.bias; O[sl][1] = a.v[1] ^ j.bias; O[sl][2] = a.v[2] ^ j.bias; O[sl][3] = a.v[3] ^ j.bias;
+  }
+  // reference row of step u: top + 5 p + rho + rowStep * (u - pad + chunk * RASTER_CHUNK)
+  const int16_t *pr = j.ref + ( long ) ( r.top + 5 * p + rho + rowStep * chunk * RASTER_CHUNK ) * j.refStride + myX + ( k << 3 );
+  const long     dr = ( long ) rowStep * j.refStride;
+  const int      uEnd = nyp - 1 + NS - 1;
+  for( int u = pad; u <= uEnd; u++ )
+  {
+    const Pel8     b  = *reinterpret_cast<const Pel8 *>( pr );
+    const unsigned b0 = b.v[0] ^ j.bias, b1 = b.v[1] ^ j.bias, b2 = b.v[2] ^ j.bias, b3 = b.v[3] ^ j.bias;
+    pr += dr;
+    if( pad == 0 )
+    {
+#pragma unroll
+      for( int sl = 0; sl < NS; sl++ )
+      {
+        unsigned a = A[sl];
+        a = sad2( O[sl][0], b0, a ); a = sad2( O[sl][1], b1, a ); a = sad2( O[sl][2], b2, a ); a = sad2( O[sl][3], b3, a );
+        A[sl] = a;
+      }
+    }
+    else
+    {
+#pragma unroll
+      for( int sl = 0; sl < NS; sl++ )
+        if( sl >= pad )
+        {
+          unsigned a = A[sl];
+          a = sad2( O[sl][0], b0, a ); a = sad2( O[sl][1], b1, a ); a = sad2( O[sl][2], b2, a ); a = sad2( O[sl][3], b3, a );
+          A[sl] = a;
+        }
+    }
+    const int mp = u - ( NS - 1 );   // the candidate in the last slot has met every row of the chunk
+    if( mp >= 0 && mp < nyp && lane < nx ) atomicAdd( &sTot[( p + ( mp << j.ss ) ) * nx + lane], A[NS - 1] );
+#pragma unroll
+    for( int sl = NS - 1; sl > 0; sl-- ) A[sl] = A[sl - 1];
+    A[0] = 0;
+  }
+}
+
+__global__ __launch_bounds__( 256 ) void tz_raster_cols_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+                                                               const vtmhip_tz_job *__restrict__ jobs, TzSaved *__restrict__ saved, const int *__restrict__ list )
+{
+  __shared__ unsigned           sTot[RASTER_TOT_CAP];
+  __shared__ unsigned long long sRedCost[4];
+  __shared__ unsigned           sRedIdx[4];
+  const int lane = threadIdx.x & 63, wv = uni( ( int ) ( threadIdx.x >> 6 ) );
+  const int count = list[0];
+  for( int e = blockIdx.x; e < count; e += gridDim.x )
+  {
+    const int            jobIdx = list[1 + e];
+    const vtmhip_tz_job *jp = jobs + jobIdx;
+    TzSaved             &sv = saved[jobIdx];
+    MeJob j;
+    j.org = orgBase + jp->orgOff; j.ref = refBase + jp->refOff; j.orgStride = jp->orgStride; j.refStride = jp->refStride;
+    j.w = jp->width; j.h = jp->height; j.ss = jp->subShift; j.imvShift = ( unsigned ) jp->imvShift;
+    j.predHor = jp->predHor; j.predVer = jp->predVer; j.costScale = 2; j.lambda = jp->motionLambda;
+    j.bias = jp->signedSamples ? 0x80008000u : 0u;
+    j.narrow = false;
+    const Range r = sv.sr;
+    const int   nx = ( r.right - r.left ) / 5 + 1, ny = ( r.bottom - r.top ) / 5 + 1, total = nx * ny;
+    for( int i = threadIdx.x; i < total; i += 256 ) sTot[i] = 0;
+    __syncthreads();
+    const int segs = j.w >> 3, par = 1 << j.ss, rowStep = 5 << j.ss;
+    const int rowsMax = ( j.h + rowStep - 1 ) / rowStep, chunks = ( rowsMax + RASTER_CHUNK - 1 ) / RASTER_CHUNK;
+    const int tasks = segs * 5 * par * chunks;
+    const int myX = r.left + 5 * min( lane, nx - 1 );   // lanes beyond the last column repeat it (their sums are never stored)
+    for( int t = wv; t < tasks; t += 4 )
+    {
+      int q = t;
+      const int k = q % segs; q /= segs;
+      const int c = q % 5; q /= 5;
+      const int p = q % par; q /= par;
+      const int chunk = q, rho = c << j.ss;
+      if( rowsMax > 7 ) raster_task<13>( j, r, nx, ny, lane, myX, k, rho, p, chunk, rowStep, sTot );
+      else if( rowsMax > 4 ) raster_task<7>( j, r, nx, ny, lane, myX, k, rho, p, chunk, rowStep, sTot );
+      else if( rowsMax > 2 ) raster_task<4>( j, r, nx, ny, lane, myX, k, rho, p, chunk, rowStep, sTot );
+      else raster_task<2>( j, r, nx, ny, lane, myX, k, rho, p, chunk, rowStep, sTot );
+    }
+    __syncthreads();
+    // first strict minimum of SAD + MV rate in raster order = lexicographic (cost, index) minimum
+    unsigned long long bc = ~0ull;
+    unsigned           bi = 0xffffffffu;
+    for( int i = threadIdx.x; i < total; i += 256 )
+    {
+      const int ry = i / nx, rx = i - ry * nx;
+      const unsigned long long c = ( ( unsigned long long ) sTot[i] << j.ss ) + mv_cost( j, r.left + 5 * rx, r.top + 5 * ry );
+      if( c < bc ) { bc = c; bi = ( unsigned ) i; }
+    }
+    wave_argmin( bc, bi );
+    if( lane == 0 ) { sRedCost[wv] = bc; sRedIdx[wv] = bi; }
+    __syncthreads();
+    if( threadIdx.x == 0 )
+    {
+      for( int w = 1; w < 4; w++ )
+        if( sRedCost[w] < bc || ( sRedCost[w] == bc && sRedIdx[w] < bi ) ) { bc = sRedCost[w]; bi = sRedIdx[w]; }
+      sv.rasterCost = bc; sv.rasterIdx = bi;
+    }
+    __syncthreads();
+  }
+}
+
 // WPJ = 1: 256 threads = 4 independent jobs.  WPJ > 1: 64 * WPJ threads = 1 job.
 template<int WPJ>
 __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase,
                                                                                 const int16_t *__restrict__ refBase,
                                                                                 const vtmhip_tz_job *__restrict__ jobs, int numJobs,
-                                                                                vtmhip_me_result *__restrict__ results )
+                                                                                vtmhip_me_result *__restrict__ results, int mode, TzSaved *__restrict__ saved,
+                                                                                int *__restrict__ list )
 {
+  // mode 0: the whole search.  Split launches: mode 1 stops at the raster decision of jobs tz_raster_cols_kernel can take (state -> saved[], job
+  // index -> list[]; every other job runs to the end here); mode 2 resumes the listed jobs after the scan.
   constexpr int JOBS_PER_BLOCK = WPJ == 1 ? 4 : 1;
   __shared__ int4               sPts[JOBS_PER_BLOCK][16];   // 15 m_uniMvList candidates / 16 diamond points at most
   __shared__ unsigned long long sRedCost[WPJ];
   __shared__ unsigned           sRedIdx[WPJ];
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sOrgLds[WPJ >= 4 ? ORG_LDS_CAP : 8];
   const int lane = threadIdx.x & 63, wv = uni( ( int ) ( threadIdx.x >> 6 ) );
-  const int blk    = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x );
-  const int jobIdx = WPJ == 1 ? blk * 4 + wv : blk;
+  const int blk    = mode == 2 ? ( int ) blockIdx.x : xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x );
+  int       jobIdx = WPJ == 1 ? blk * 4 + wv : blk;
+  if( mode == 2 )
+  {
+    if( jobIdx >= list[0] ) return;   // only the listed jobs resume
+    jobIdx = uni( list[1 + jobIdx] );
+  }
   if( jobIdx >= numJobs ) return;   // WPJ == 1: whole waves leave; WPJ > 1: never true (grid = numJobs)
   const vtmhip_tz_job *jp  = jobs + jobIdx;
   if( uni( ( int ) jp->width ) == 0 ) return;   // empty slot of a multi-stage call (job handled by another stage); uniform per wave / per block
@@ -663,6 +819,9 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel(
   s.bestSad = ~0ull; s.bestX = 0; s.bestY = 0; s.pointNr = 0; s.bestDist = 0; s.bestRound = 0; s.nEval = 0;
   s.sr.left = s.sr.right = s.sr.top = s.sr.bottom = 0;
 
+  int startX = 0, startY = 0;
+  if( mode != 2 )
+  {
   // start vector (:3675-3687)
   int mx = jp->mvHor, my = jp->mvVer;
   clip_mv( j, mx, my );
@@ -734,7 +893,7 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel(
 
   s.sr = search_range( j, s.bestX << 4, s.bestY << 4, searchRange >> ( fast ? 1 : 0 ) );
 
-  int        startX = s.bestX, startY = s.bestY;
+  startX = s.bestX; startY = s.bestY;
   const bool bestCandidateZero = ( s.bestX == 0 && s.bestY == 0 );
 
   for( int d = 1; d <= searchRange; d *= 2 )
@@ -766,7 +925,37 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel(
   else if( ( int ) s.bestDist >= iRaster )
   {
     s.bestDist = ( unsigned ) iRaster;
+    const int nx = s.sr.right >= s.sr.left ? ( s.sr.right - s.sr.left ) / iRaster + 1 : 0, ny = s.sr.bottom >= s.sr.top ? ( s.sr.bottom - s.sr.top ) / iRaster + 1 : 0;
+    if( mode == 1 && iRaster == 5 && j.seg == 8 && j.h <= 128 && nx >= 1 && nx <= 64 && ny >= 1 && nx * ny <= RASTER_TOT_CAP )
+    {
+      if( co.leader )
+      {
+        TzSaved sv;
+        sv.sr = s.sr; sv.bestSad = s.bestSad; sv.bestX = s.bestX; sv.bestY = s.bestY; sv.pointNr = s.pointNr; sv.bestDist = s.bestDist;
+        sv.bestRound = s.bestRound; sv.nEval = s.nEval; sv.rasterCost = ~0ull; sv.rasterIdx = 0; sv.pad = 0;
+        saved[jobIdx] = sv;
+        list[1 + atomicAdd( &list[0], 1 )] = jobIdx;
+      }
+      return;   // wave-uniform (WPJ == 1) / block-uniform: the search continues in the mode-2 launch
+    }
     tz_raster<WPJ>( j, s, s.sr, iRaster, co );
+  }
+  }   // mode != 2
+  else
+  {
+    // resume after tz_raster_cols_kernel: the scan's first strict minimum against the best point so far (xTZSearchHelp's rule)
+    const TzSaved sv = saved[jobIdx];
+    s.sr = sv.sr; s.bestSad = uni( sv.bestSad ); s.bestX = uni( sv.bestX ); s.bestY = uni( sv.bestY ); s.pointNr = uni( sv.pointNr );
+    s.bestDist = uni( sv.bestDist ); s.bestRound = uni( sv.bestRound ); s.nEval = uni( sv.nEval );
+    s.sr.left = uni( s.sr.left ); s.sr.right = uni( s.sr.right ); s.sr.top = uni( s.sr.top ); s.sr.bottom = uni( s.sr.bottom );
+    const int nx = ( s.sr.right - s.sr.left ) / 5 + 1, ny = ( s.sr.bottom - s.sr.top ) / 5 + 1;
+    s.nEval += ( unsigned ) ( nx * ny );
+    const unsigned long long rc = uni( sv.rasterCost );
+    if( rc < s.bestSad )
+    {
+      const int idx = ( int ) uni( sv.rasterIdx ), ry = idx / nx, rx = idx - ry * nx;
+      s.bestSad = rc; s.bestX = s.sr.left + rx * 5; s.bestY = s.sr.top + ry * 5; s.bestDist = 5; s.bestRound = 0; s.pointNr = 0;
+    }
   }
   // star refinement (:3937-3971)
   while( s.bestDist > 0 )
@@ -1035,18 +1224,44 @@ extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_par
   // 2..16: that many waves split every candidate list -- large blocks, raster scans)
   const int wpj = pic->wavesPerJob;
   VTMHIP_REQUIRE( ctx, wpj == 0 || wpj == 1 || wpj == 2 || wpj == 4 || wpj == 8 || wpj == 16, "wavesPerJob must be 0, 1, 2, 4, 8 or 16" );
-#define VTMHIP_TZ_LAUNCH( W, GRID ) \
-  hipLaunchKernelGGL( tz_search_kernel<W>, dim3( GRID ), dim3( W == 1 ? 256 : 64 * W ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, d_results )
-  { VTMHIP_TIME_KERNEL( ctx, "tz_search_kernel" );
-  switch( wpj )
+  // split search (default; VTMHIP_TZ_SPLIT=0: one launch): the raster scans of the batch run in tz_raster_cols_kernel between two launches of the search kernel
+  static const bool split = !( getenv( "VTMHIP_TZ_SPLIT" ) && atoi( getenv( "VTMHIP_TZ_SPLIT" ) ) == 0 );
+  TzSaved *d_saved = nullptr;
+  int     *d_list  = nullptr;
+  if( split )
   {
-  case 2: VTMHIP_TZ_LAUNCH( 2, n ); break;
-  case 4: VTMHIP_TZ_LAUNCH( 4, n ); break;
-  case 8: VTMHIP_TZ_LAUNCH( 8, n ); break;
-  case 16: VTMHIP_TZ_LAUNCH( 16, n ); break;
-  default: VTMHIP_TZ_LAUNCH( 1, ( n + 3 ) / 4 ); break;
+    const size_t oList = ( ( size_t ) n * sizeof( TzSaved ) + 255 ) & ~( size_t ) 255;
+    void        *arena = nullptr;
+    int          st    = vtmhip_internal_workspace( ctx, oList + ( ( size_t ) n + 1 ) * sizeof( int ), &arena, 1 );
+    if( st ) return st;
+    d_saved = ( TzSaved * ) arena;
+    d_list  = ( int * ) ( ( char * ) arena + oList );
+    VTMHIP_HIP( ctx, hipMemsetAsync( d_list, 0, sizeof( int ), ctx->stream ) );
   }
+#define VTMHIP_TZ_LAUNCH( W, GRID, MODE ) \
+  hipLaunchKernelGGL( tz_search_kernel<W>, dim3( GRID ), dim3( W == 1 ? 256 : 64 * W ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, d_results, MODE, d_saved, d_list )
+#define VTMHIP_TZ_SWITCH( MODE )                                    \
+  switch( wpj )                                                     \
+  {                                                                 \
+  case 2: VTMHIP_TZ_LAUNCH( 2, n, MODE ); break;                    \
+  case 4: VTMHIP_TZ_LAUNCH( 4, n, MODE ); break;                    \
+  case 8: VTMHIP_TZ_LAUNCH( 8, n, MODE ); break;                    \
+  case 16: VTMHIP_TZ_LAUNCH( 16, n, MODE ); break;                  \
+  default: VTMHIP_TZ_LAUNCH( 1, ( n + 3 ) / 4, MODE ); break;       \
   }
+  { VTMHIP_TIME_KERNEL( ctx, "tz_search_kernel" );
+    VTMHIP_TZ_SWITCH( split ? 1 : 0 )
+  }
+  if( split )
+  {
+    { VTMHIP_TIME_KERNEL( ctx, "tz_raster_cols_kernel" );
+      hipLaunchKernelGGL( tz_raster_cols_kernel, dim3( n < 3072 ? n : 3072 ), dim3( 256 ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, d_saved, d_list );
+    }
+    { VTMHIP_TIME_KERNEL( ctx, "tz_search_kernel" );
+      VTMHIP_TZ_SWITCH( 2 )
+    }
+  }
+#undef VTMHIP_TZ_SWITCH
 #undef VTMHIP_TZ_LAUNCH
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
