@@ -30,6 +30,8 @@
 #include "CommonLib/InterpolationFilter.h"
 #include "CommonLib/Rom.h"
 #include "EncoderLib/EncLib.h"
+#include "EncoderLib/EncModeCtrl.h"
+#include "CommonLib/UnitTools.h"
 
 #include "../include/vtmhip.h"
 
@@ -45,6 +47,10 @@ struct RefEncStats
   uint64_t errors;        // non-zero vtmhip status
   int32_t  firstMismatch[8];
   char     firstError[160]; // vtmhip_last_error() of the first failed call
+  // batched hooks, [0]: InterSearch::xMotionEstimation as ONE vtmhip_xMotionEstimation_batch_dev call (hooks B1-B6),
+  //                                       [1]: TrQuant::transformNxN( trModes ) = all MTS candidates' forward transforms + the pre-selection (hook B8)
+  uint64_t hookCalls[2], hookDevice[2], hookMismatch[2], hookUnsupported[2];
+  int32_t  hookFirstMismatch[8];
 };
 }
 
@@ -74,6 +80,10 @@ struct Api
   decltype( &vtmhip_remove_high_freq_batch_dev )   rhf;
   decltype( &vtmhip_affine_sobel_batch_dev )       sobel;
   decltype( &vtmhip_affine_equal_coeff_batch_dev ) eqc;
+  decltype( &vtmhip_xMotionEstimation_batch_dev )  me;
+  decltype( &vtmhip_xT_batch_dev )                 xT;
+  decltype( &vtmhip_tu_ts_chain_batch_dev )        tsChain;
+  decltype( &vtmhip_mts_select2 )                  mtsSelect;
 } A;
 
 vtmhip_ctx  *g_ctx = nullptr;
@@ -404,6 +414,207 @@ void restoreAux()
   g_pelBufOP.removeHighFreq4 = g_rhfOrig[0]; g_pelBufOP.removeHighFreq8 = g_rhfOrig[1];
   g_affine = nullptr;
 }
+
+// ---- batched hooks: whole member functions on the device ------------------------------------------------------------------------
+// The strong definitions below replace the (weakened) reference symbols at link time (oracle/Makefile.ref); without an installed hook they
+// just run the reference's code.
+}   // namespace
+extern "C" void vtmref_orig_xMotionEstimation( InterSearch *, PredictionUnit &, PelUnitBuf &, RefPicList, Mv &, int, Mv &, int &, uint32_t &, Distortion &, const AMVPInfo &, bool );
+extern "C" void vtmref_orig_transformNxN_select( TrQuant *, TransformUnit &, const ComponentID &, const QpParam &, std::vector<TrMode> *, const int );
+namespace
+{
+bool     g_hookMe = false, g_hookMts = false;
+uint64_t g_hookCtr[2] = { 0, 0 }, g_hookStride = 0;   // VTMREF_HOOK_STRIDE: the hooks' own sampling stride (default: the tables' stride)
+inline bool hookSampled( uint64_t &ctr )
+{
+  const uint64_t n = ctr++;
+  if( g_countOnly ) return false;
+  return n < g_head || ( n % ( g_hookStride ? g_hookStride : g_stride ) ) == 0;
+}
+
+struct RefPlane { const Picture *pic; int poc; int16_t *dev; size_t samples; int stride, margin; };
+std::vector<RefPlane> g_planes;
+int16_t *d_hOrg = nullptr, *d_hOther = nullptr;
+void    *d_hJob = nullptr, *d_hOut = nullptr;
+int32_t *d_hCoef = nullptr, *d_hSum = nullptr;
+constexpr size_t HOOK_BLK = 128 * 128;
+
+bool hookAlloc()
+{
+  return A.dalloc( g_ctx, HOOK_BLK * 2, (void **) &d_hOrg ) == VTMHIP_OK && A.dalloc( g_ctx, HOOK_BLK * 2, (void **) &d_hOther ) == VTMHIP_OK
+      && A.dalloc( g_ctx, 4096, &d_hJob ) == VTMHIP_OK && A.dalloc( g_ctx, 4096, &d_hOut ) == VTMHIP_OK
+      && A.dalloc( g_ctx, 8 * 64 * 64 * 4, (void **) &d_hCoef ) == VTMHIP_OK && A.dalloc( g_ctx, 256, (void **) &d_hSum ) == VTMHIP_OK;
+}
+
+// the reconstructed reference picture, border included, uploaded once per (picture buffer, POC)
+const RefPlane *refPlane( const Picture *pic )
+{
+  for( const RefPlane &p : g_planes ) if( p.pic == pic && p.poc == pic->getPOC() ) return &p;
+  const CPelBuf y = pic->getRecoBuf( COMPONENT_Y );
+  const int     m = pic->margin;
+  RefPlane      r; r.pic = pic; r.poc = pic->getPOC(); r.stride = y.stride; r.margin = m;
+  r.samples = size_t( y.height + 2 * m ) * y.stride;
+  for( RefPlane &p : g_planes ) if( p.pic == pic ) { A.dfree( g_ctx, p.dev ); p = g_planes.back(); g_planes.pop_back(); break; }   // the buffer now holds another picture
+  if( A.dalloc( g_ctx, r.samples * 2, (void **) &r.dev ) != VTMHIP_OK ) return nullptr;
+  // rows -margin .. height + margin - 1 of the plane; the last row is copied only up to its last sample (the allocation ends there)
+  if( A.h2d( g_ctx, r.dev, y.buf - ptrdiff_t( m ) * y.stride - m, ( r.samples - size_t( y.stride - y.width - 2 * m > 0 ? y.stride - y.width - 2 * m : 0 ) ) * 2 ) != VTMHIP_OK ) return nullptr;
+  g_planes.push_back( r );
+  return &g_planes.back();
+}
+
+void hookNoteMismatch( int which, int a, int b, int c, int d, long long ref, long long dev )
+{
+  if( g_st->hookMismatch[0] + g_st->hookMismatch[1] == 0 )
+  {
+    const int32_t v[8] = { which, a, b, c, d, (int32_t) ref, (int32_t) dev, 0 };
+    memcpy( g_st->hookFirstMismatch, v, sizeof( v ) );
+  }
+  g_st->hookMismatch[which]++;
+}
+
+void meHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPicList eRefPicList, Mv &rcMvPred, int iRefIdxPred, Mv &rcMv, int &riMVPIdx, uint32_t &ruiBits,
+             Distortion &ruiCost, const AMVPInfo &amvpInfo, bool bBi )
+{
+  g_st->hookCalls[0]++;
+  const Slice   &slice  = *pu.cu->slice;
+  const Picture *refPic = slice.getRefPic( eRefPicList, iRefIdxPred );
+  const int      w = pu.Y().width, h = pu.Y().height;
+  Mv             cachedMv;
+  auto           blkCache = dynamic_cast<CacheBlkInfoCtrl *>( is->m_modeCtrl );
+  // what vtmhip_xMotionEstimation_batch_dev does not cover stays with the reference (include/vtmhip.h): BCW / explicit weights, MCTS, composite
+  // references, the block-vector cache, full / selective search, wrap-around
+  const bool unsupported = pu.cu->BcwIdx != BCW_DEFAULT || slice.getPPS()->getUseWP() || slice.getPPS()->getWPBiPred() || is->m_pcEncCfg->getMCTSEncConstraint()
+                        || is->m_useCompositeRef || ( !bBi && blkCache && blkCache->getMv( pu, eRefPicList, iRefIdxPred, cachedMv ) )
+                        || ( is->m_motionEstimationSearchMethod != MESEARCH_DIAMOND && is->m_motionEstimationSearchMethod != MESEARCH_DIAMOND_ENHANCED )
+                        || is->m_pcEncCfg->getClipForBiPredMeEnabled() || refPic->isWrapAroundEnabled( pu.cs->pps ) || w > 128 || h > 128 || ( w == 4 && h == 4 )
+                        || is->m_uniMvListSize > 15 || amvpInfo.numCand > 2 || slice.getSPS()->getBitDepth( CHANNEL_TYPE_LUMA ) > 10;
+  if( unsupported ) g_st->hookUnsupported[0]++;
+  if( unsupported || !hookSampled( g_hookCtr[0] ) )
+  {
+    vtmref_orig_xMotionEstimation( is, pu, origBuf, eRefPicList, rcMvPred, iRefIdxPred, rcMv, riMVPIdx, ruiBits, ruiCost, amvpInfo, bBi );
+    return;
+  }
+  // ---- the job, from the arguments and the members the reference function reads (InterSearch.cpp:3299-3494) ----
+  vtmhip_me_job j; memset( &j, 0, sizeof( j ) );
+  const RefPlane *rp = refPlane( refPic );
+  const CPelBuf   org = origBuf.Y();
+  std::vector<Pel> blk( size_t( w ) * h ), oth( size_t( w ) * h );
+  for( int y = 0; y < h; y++ ) memcpy( &blk[size_t( y ) * w], org.buf + ptrdiff_t( y ) * org.stride, sizeof( Pel ) * w );
+  if( bBi )
+  {
+    const CPelBuf o = is->m_tmpPredStorage[1 - (int) eRefPicList].getBuf( UnitAreaRelative( *pu.cu, pu ) ).Y();
+    for( int y = 0; y < h; y++ ) memcpy( &oth[size_t( y ) * w], o.buf + ptrdiff_t( y ) * o.stride, sizeof( Pel ) * w );
+  }
+  const Position pos = pu.cu->lumaPos();
+  j.orgOff = 0; j.orgStride = w; j.otherPredOff = 0; j.otherPredStride = w;
+  j.refOff = rp ? ( int64_t ) ( rp->margin + pu.Y().y ) * rp->stride + rp->margin + pu.Y().x : 0; j.refStride = rp ? rp->stride : 0;
+  j.puX = ( int16_t ) pos.x; j.puY = ( int16_t ) pos.y; j.width = ( int16_t ) w; j.height = ( int16_t ) h;
+  j.bi = bBi; j.imv = pu.cu->imv; j.mvpIdx = ( uint8_t ) riMVPIdx; j.numAmvpCand = ( uint8_t ) amvpInfo.numCand;
+  j.mvPredHor = rcMvPred.hor; j.mvPredVer = rcMvPred.ver; j.mvHor = rcMv.hor; j.mvVer = rcMv.ver;
+  for( int i = 0; i < 2; i++ )
+  {
+    j.amvpCand[i][0] = amvpInfo.mvCand[i].hor; j.amvpCand[i][1] = amvpInfo.mvCand[i].ver;
+    j.mvpIdxBits[i] = is->m_auiMVPIdxCost[i][AMVP_MAX_NUM_CANDS];
+  }
+  j.bits = ruiBits; j.searchRange = is->m_aaiAdaptSR[eRefPicList][iRefIdxPred]; j.motionLambda = is->m_pcRdCost->m_motionLambda;
+  j.numExtraStart = is->m_uniMvListSize;
+  for( int i = 0; i < is->m_uniMvListSize; i++ )
+  {
+    const BlkUniMvInfo *e = is->m_uniMvList + ( ( is->m_uniMvListIdx - 1 - i + is->m_uniMvListMaxSize ) % is->m_uniMvListMaxSize );
+    j.extraStart[i][0] = e->uniMvs[eRefPicList][iRefIdxPred].hor; j.extraStart[i][1] = e->uniMvs[eRefPicList][iRefIdxPred].ver;
+  }
+  vtmhip_me_cfg cfg; memset( &cfg, 0, sizeof( cfg ) );
+  cfg.bipredSearchRange = is->m_bipredSearchRange;
+  cfg.useHadME = is->m_pcEncCfg->getUseHADME() && !pu.cu->slice->getDisableSATDForRD();
+  cfg.fastInterSearchMode13 = is->m_pcEncCfg->getFastInterSearchMode() == FASTINTERSEARCH_MODE1 || is->m_pcEncCfg->getFastInterSearchMode() == FASTINTERSEARCH_MODE3;
+  cfg.extendedSettings = is->m_motionEstimationSearchMethod == MESEARCH_DIAMOND_ENHANCED;
+  cfg.firstSearchStop = is->m_pcEncCfg->getFastMEAssumingSmootherMVEnabled();
+  cfg.uniformImv = -1;
+  vtmhip_pic_params pic; memset( &pic, 0, sizeof( pic ) );
+  pic.picW = pu.cs->pps->getPicWidthInLumaSamples(); pic.picH = pu.cs->pps->getPicHeightInLumaSamples(); pic.ctuSize = pu.cs->sps->getMaxCUWidth();
+  pic.bitDepth = slice.getSPS()->getBitDepth( CHANNEL_TYPE_LUMA );
+  // ---- the reference's own run (also leaves every member the callers look at in the reference's state) ----
+  vtmref_orig_xMotionEstimation( is, pu, origBuf, eRefPicList, rcMvPred, iRefIdxPred, rcMv, riMVPIdx, ruiBits, ruiCost, amvpInfo, bBi );
+  vtmhip_me_out o; memset( &o, 0, sizeof( o ) );
+  const bool ok = rp && A.h2d( g_ctx, d_hOrg, blk.data(), blk.size() * 2 ) == VTMHIP_OK && ( !bBi || A.h2d( g_ctx, d_hOther, oth.data(), oth.size() * 2 ) == VTMHIP_OK )
+               && A.h2d( g_ctx, d_hJob, &j, sizeof( j ) ) == VTMHIP_OK
+               && A.me( g_ctx, &pic, &cfg, d_hOrg, rp->dev, d_hOther, ( const vtmhip_me_job * ) d_hJob, 1, w, h, ( vtmhip_me_out * ) d_hOut ) == VTMHIP_OK
+               && A.d2h( g_ctx, &o, d_hOut, sizeof( o ) ) == VTMHIP_OK;
+  if( !ok ) { note_error(); return; }
+  g_st->hookDevice[0]++;
+  if( o.mvHor != rcMv.hor || o.mvVer != rcMv.ver || o.mvPredHor != rcMvPred.hor || o.mvPredVer != rcMvPred.ver || o.mvpIdx != riMVPIdx || o.bits != ruiBits || o.cost != ruiCost )
+    hookNoteMismatch( 0, w * 1000 + h, bBi * 10 + pu.cu->imv, rcMv.hor - o.mvHor, rcMv.ver - o.mvVer, ( long long ) ruiCost, ( long long ) o.cost );
+  // the encoder continues with the device's results
+  rcMv.hor = o.mvHor; rcMv.ver = o.mvVer; rcMvPred.hor = o.mvPredHor; rcMvPred.ver = o.mvPredVer; riMVPIdx = o.mvpIdx; ruiBits = o.bits; ruiCost = o.cost;
+}
+
+void mtsHook( TrQuant *tq, TransformUnit &tu, const ComponentID &compID, const QpParam &cQP, std::vector<TrMode> *trModes, const int maxCand )
+{
+  g_st->hookCalls[1]++;
+  const CompArea &rect = tu.blocks[compID];
+  const int       w = rect.width, h = rect.height, n = ( int ) trModes->size();
+  // LFNST changes the zero-out of xT; a TU without residual has nothing to transform: both stay with the reference
+  const bool skip = tu.noResidual || ( tu.cs->sps->getUseLFNST() && tu.cu->lfnstIdx ) || w < 4 || h < 4 || w > 64 || h > 64 || n > 8 || n < 1;
+  vtmref_orig_transformNxN_select( tq, tu, compID, cQP, trModes, maxCand );
+  if( skip ) { g_st->hookUnsupported[1]++; return; }
+  if( !hookSampled( g_hookCtr[1] ) ) return;
+  const CPelBuf    resi = tu.cs->getResiBuf( rect );
+  const int        bd = tu.cs->sps->getBitDepth( toChannelType( compID ) );
+  std::vector<Pel> blk( size_t( w ) * h );
+  for( int y = 0; y < h; y++ ) memcpy( &blk[size_t( y ) * w], resi.buf + ptrdiff_t( y ) * resi.stride, sizeof( Pel ) * w );
+  // one batch: the forward transform of every candidate (a transform-skip candidate: the residual itself)
+  vtmhip_tr_job jobs[8]; memset( jobs, 0, sizeof( jobs ) );
+  uint8_t       mts[8];
+  int32_t       sums[8] = { 0 };
+  int           nTr = 0, trOf[8];
+  for( int i = 0; i < n; i++ )
+  {
+    mts[i] = ( uint8_t ) trModes->at( i ).first;
+    if( mts[i] == MTS_SKIP ) { long long sa = 0; for( Pel v : blk ) sa += abs( v ); sums[i] = ( int32_t ) sa; continue; }
+    int th = DCT2, tv = DCT2;
+    tu.mtsIdx[compID] = mts[i];
+    tq->getTrTypes( tu, compID, th, tv );
+    vtmhip_tr_job &t = jobs[nTr];
+    t.srcOff = 0; t.dstOff = ( int64_t ) nTr * w * h; t.srcStride = w; t.dstStride = w; t.width = ( int16_t ) w; t.height = ( int16_t ) h;
+    t.typeHor = ( uint8_t ) th; t.typeVer = ( uint8_t ) tv; t.bitDepth = ( uint8_t ) bd;
+    trOf[nTr++] = i;
+  }
+  tu.mtsIdx[compID] = trModes->back().first;   // what the reference's loop leaves behind
+  std::vector<int32_t> coef( size_t( nTr ) * w * h ), sumsDev( 8 );
+  const bool ok = A.h2d( g_ctx, d_hOrg, blk.data(), blk.size() * 2 ) == VTMHIP_OK && A.h2d( g_ctx, d_hJob, jobs, sizeof( vtmhip_tr_job ) * ( nTr ? nTr : 1 ) ) == VTMHIP_OK
+               && ( nTr == 0 || ( A.xT( g_ctx, d_hOrg, d_hCoef, ( const vtmhip_tr_job * ) d_hJob, nTr, w, h, d_hSum ) == VTMHIP_OK
+                                  && A.d2h( g_ctx, coef.data(), d_hCoef, coef.size() * 4 ) == VTMHIP_OK && A.d2h( g_ctx, sumsDev.data(), d_hSum, 4 * nTr ) == VTMHIP_OK ) );
+  if( !ok ) { note_error(); return; }
+  g_st->hookDevice[1]++;
+  bool bad = false;
+  for( int k = 0; k < nTr; k++ )
+  {
+    sums[trOf[k]] = sumsDev[k];
+    if( memcmp( &coef[size_t( k ) * w * h], tq->m_mtsCoeffs[mts[trOf[k]]], sizeof( TCoeff ) * w * h ) != 0 ) bad = true;
+    else memcpy( tq->m_mtsCoeffs[mts[trOf[k]]], &coef[size_t( k ) * w * h], sizeof( TCoeff ) * w * h );   // the later transformNxN( loadTr ) reads these
+  }
+  uint8_t test[8];
+  if( A.mtsSelect( sums, mts, n, w, h, bd, tu.cs->sps->getMaxLog2TrDynamicRange( toChannelType( compID ) ), maxCand, test ) != VTMHIP_OK ) { note_error(); return; }
+  for( int i = 0; i < n; i++ ) if( ( test[i] != 0 ) != trModes->at( i ).second ) bad = true;
+  if( bad ) hookNoteMismatch( 1, w * 1000 + h, n, maxCand, nTr, 0, 0 );
+  for( int i = 0; i < n; i++ ) trModes->at( i ).second = test[i] != 0;
+}
+}   // namespace
+
+// the strong definitions that take over the weakened reference symbols
+void InterSearch::xMotionEstimation( PredictionUnit &pu, PelUnitBuf &origBuf, RefPicList eRefPicList, Mv &rcMvPred, int iRefIdxPred, Mv &rcMv, int &riMVPIdx, uint32_t &ruiBits,
+                                     Distortion &ruiCost, const AMVPInfo &amvpInfo, bool bBi )
+{
+  if( g_hookMe ) meHook( this, pu, origBuf, eRefPicList, rcMvPred, iRefIdxPred, rcMv, riMVPIdx, ruiBits, ruiCost, amvpInfo, bBi );
+  else vtmref_orig_xMotionEstimation( this, pu, origBuf, eRefPicList, rcMvPred, iRefIdxPred, rcMv, riMVPIdx, ruiBits, ruiCost, amvpInfo, bBi );
+}
+void TrQuant::transformNxN( TransformUnit &tu, const ComponentID &compID, const QpParam &cQP, std::vector<TrMode> *trModes, const int maxCand )
+{
+  if( g_hookMts ) mtsHook( this, tu, compID, cQP, trModes, maxCand );
+  else vtmref_orig_transformNxN_select( this, tu, compID, cQP, trModes, maxCand );
+}
+namespace
+{
 }   // namespace
 
 extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsigned familyMask, uint64_t stride, uint64_t head, RefEncStats *stats )
@@ -421,7 +632,9 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
                  && sym( A.fcopy, "vtmhip_filterCopy" ) && sym( A.geo, "vtmhip_weightedGeoBlk" ) && sym( A.fwd, "vtmhip_fastFwdTrans" ) && sym( A.inv, "vtmhip_fastInvTrans" )
                  && sym( A.dalloc, "vtmhip_dev_alloc" ) && sym( A.dfree, "vtmhip_dev_free" ) && sym( A.h2d, "vtmhip_h2d" ) && sym( A.d2h, "vtmhip_d2h" )
                  && sym( A.addAvg, "vtmhip_add_avg_batch_dev" ) && sym( A.rhf, "vtmhip_remove_high_freq_batch_dev" )
-                 && sym( A.sobel, "vtmhip_affine_sobel_batch_dev" ) && sym( A.eqc, "vtmhip_affine_equal_coeff_batch_dev" );
+                 && sym( A.sobel, "vtmhip_affine_sobel_batch_dev" ) && sym( A.eqc, "vtmhip_affine_equal_coeff_batch_dev" )
+                 && sym( A.me, "vtmhip_xMotionEstimation_batch_dev" ) && sym( A.xT, "vtmhip_xT_batch_dev" ) && sym( A.tsChain, "vtmhip_tu_ts_chain_batch_dev" )
+                 && sym( A.mtsSelect, "vtmhip_mts_select2" );
     if( !ok ) { fprintf( stderr, "ref_encode: libvtmhip.so lacks a pointer-surface symbol\n" ); return -11; }
     const int st = A.create( 0, &g_ctx );
     if( st != VTMHIP_OK ) { fprintf( stderr, "ref_encode: vtmhip_create failed (%d) -- no CPU fallback\n", st ); return -12; }
@@ -446,6 +659,8 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
         if( g_mask & 2 ) installIf( app->m_cEncLib.m_cInterSearch.m_if );
         if( g_mask & 4 ) installTr();
         if( ( g_mask & 16 ) && ( g_countOnly || auxAlloc() ) ) installAux( (AffineGradientSearch &) app->m_cEncLib.m_cInterSearch );   // private base: C-style cast
+        if( ( g_mask & 96 ) && ( g_countOnly || ( g_ctx && hookAlloc() ) ) ) { g_hookMe = ( g_mask & 32 ) != 0; g_hookMts = ( g_mask & 64 ) != 0; g_hookCtr[0] = g_hookCtr[1] = 0;
+          g_hookStride = getenv( "VTMREF_HOOK_STRIDE" ) ? strtoull( getenv( "VTMREF_HOOK_STRIDE" ), nullptr, 10 ) : 0; }
       }
       bool eos = false;
       while( !eos )
@@ -458,6 +673,9 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
     }
   }
   catch( Exception &e ) { fprintf( stderr, "ref_encode: %s\n", e.what() ); rc = 2; }
+  g_hookMe = g_hookMts = false;
+  for( RefPlane &p : g_planes ) A.dfree( g_ctx, p.dev );
+  g_planes.clear();
   if( g_ctx || g_countOnly ) { restoreDist(); restoreTr(); restoreAux(); }
   app->destroy();
   delete app;

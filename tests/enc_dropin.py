@@ -17,7 +17,9 @@ CFG = os.path.join(ROOT, "tests", "data", "enc_ra_gop4.cfg")
 
 class Stats(C.Structure):
     _fields_ = [("calls", C.c_uint64 * 4), ("device", C.c_uint64 * 4), ("mismatch", C.c_uint64 * 4), ("errors", C.c_uint64),
-                ("firstMismatch", C.c_int32 * 8), ("firstError", C.c_char * 160)]
+                ("firstMismatch", C.c_int32 * 8), ("firstError", C.c_char * 160),
+                ("hookCalls", C.c_uint64 * 2), ("hookDevice", C.c_uint64 * 2), ("hookMismatch", C.c_uint64 * 2), ("hookUnsupported", C.c_uint64 * 2),
+                ("hookFirstMismatch", C.c_int32 * 8)]
 
 
 def write_clip(path, w, h, frames, seed=77):
@@ -39,7 +41,9 @@ def _child(argv_json):
     st = Stats()
     rc = lib.ref_encode(len(args), arr, a["hip"].encode() if a["hip"] else None, a["mask"], a["stride"], a["head"], C.byref(st))
     out = {"rc": rc, "calls": list(st.calls), "device": list(st.device), "mismatch": list(st.mismatch), "errors": st.errors,
-           "firstMismatch": list(st.firstMismatch), "firstError": st.firstError.decode(errors="replace")}
+           "firstMismatch": list(st.firstMismatch), "firstError": st.firstError.decode(errors="replace"),
+           "hookCalls": list(st.hookCalls), "hookDevice": list(st.hookDevice), "hookMismatch": list(st.hookMismatch), "hookUnsupported": list(st.hookUnsupported),
+           "hookFirstMismatch": list(st.hookFirstMismatch)}
     sys.stdout.flush()
     os.write(2, ("\nDROPIN_RESULT " + json.dumps(out) + "\n").encode())
 

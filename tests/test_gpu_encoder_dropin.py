@@ -32,3 +32,32 @@ def test_reference_encoder_with_device_dispatch(tmp_path):
     # every family really went to the device: distortion, interpolation, transforms > 10^5 calls each, buffer ops + affine gradients > 5000
     assert min(st1["device"][:3]) > 100000 and st1["device"][3] > 5000, st1
     assert bits1 == bits0 and rec1 == rec0
+
+
+@pytest.mark.skipif(not os.path.exists(enc_dropin.REF_SO), reason="oracle/_ref/libvtmref.so not built (needs /root/reference)")
+def test_reference_encoder_with_batched_hooks(tmp_path, monkeypatch):
+    """SURVEY.md Appendix B inside the real encoder: InterSearch::xMotionEstimation replaced by ONE vtmhip_xMotionEstimation_batch_dev call per
+    invocation (start candidates, TZ / exhaustive search, fractional or AMVR refinement, rate re-weighting: hooks B1-B6) and the MTS candidate loop of
+    TrQuant::transformNxN( trModes ) by one batch of forward transforms + vtmhip_mts_select2 (hook B8).  The members are intercepted at link level
+    (oracle/Makefile.ref weakens the two reference symbols; oracle/ref_shim_enc.cpp holds the strong definitions).  Every 3rd supported call goes to
+    the device, its results replace the reference's and are compared with them; bitstream and reconstruction must equal the plain run's."""
+    import time
+    yuv = str(tmp_path / "clip.yuv")
+    enc_dropin.write_clip(yuv, W, H, FRAMES)
+    monkeypatch.setenv("VTMREF_HOOK_STRIDE", "3")
+    t0 = time.time()
+    st0, bits0, rec0 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "plain"))
+    t1 = time.time()
+    st1, bits1, rec1 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "hooks"), True, 32 | 64, 1000000, 64)
+    t2 = time.time()
+    print("batched hooks:", {k: st1[k] for k in ("hookCalls", "hookDevice", "hookMismatch", "hookUnsupported", "errors")}, "plain %.1f s, hooked %.1f s" % (t1 - t0, t2 - t1))
+    assert st0["rc"] == 0 and st1["rc"] == 0
+    assert st1["errors"] == 0, st1
+    assert st1["hookMismatch"] == [0, 0], st1
+    assert st1["hookDevice"][0] > 5000 and st1["hookDevice"][1] > 50000, st1
+    assert bits1 == bits0 and rec1 == rec0
+    out = os.path.join(enc_dropin.ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "encoder_batched_hooks.txt"), "w") as f:
+            f.write("clip %dx%d, %d pictures, QP %d; plain run %.1f s, hooked run %.1f s (every 3rd supported call on the device)\n%r\nbitstream md5 %s (plain %s)\n"
+                    % (W, H, FRAMES, QP, t1 - t0, t2 - t1, {k: st1[k] for k in ("hookCalls", "hookDevice", "hookMismatch", "hookUnsupported", "errors")}, bits1, bits0))
