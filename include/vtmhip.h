@@ -600,6 +600,54 @@ int vtmhip_affine_sobel_batch_dev( vtmhip_ctx *ctx, const int16_t *d_predBase, i
 int vtmhip_affine_equal_coeff_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const int32_t *d_derivBase, const vtmhip_affine_job *d_jobs, int n,
                                          int64_t *d_equalCoeff );
 
+/* ---- affine motion estimation: InterSearch::xAffineMotionEstimation for one (PU, list, refIdx) per job ----------------------------------
+ * (InterSearch.cpp:5340-5775) = the first prediction at the (clipped, AMVR-rounded) start model, up to 7 gradient iterations (error -> Sobel ->
+ * normal equations -> solveEqual :5215-5284 -> control-point update -> InterPrediction::xPredAffineBlk :856-1232 -> SATD / SAD + xCalcAffineMVBits
+ * :3067-3085) and the control-point refinement (:5655-5765), one workgroup per job from start to end: the fp64 steps run on the device in IEEE
+ * double.  Covered: cu.imv 0 / 1, and 2 without AffineAmvrEncOpt (xDetermineBestMvp stays with the host); default BCW weight; PROF as the
+ * caller's flags say.  The predictor acMvPred and the AMVP index do not change in these modes, so the result is the model, its bits and cost. */
+typedef struct
+{
+  int64_t  orgOff, refOff;          /* PU top-left in the original plane / the same position (MV 0,0) in the reference plane */
+  int64_t  otherPredOff;            /* bi: the other list's prediction inside d_otherPredBase */
+  int64_t  predOff;                 /* vtmhip_xPredAffineBlk_batch_dev only: where the prediction block goes inside d_dstBase */
+  int32_t  orgStride, refStride, otherPredStride, predStride;
+  int16_t  puX, puY, width, height; /* 16..128 */
+  uint8_t  sixParam;                /* cu.affineType == AFFINEMODEL_6PARAM */
+  uint8_t  interDir;                /* pu.interDir as isSubblockVectorSpreadOverLimit sees it */
+  uint8_t  imv, bi;
+  uint8_t  useSatd;                 /* !slice.getDisableSATDForRD() */
+  uint8_t  useAffineType;           /* sps.getUseAffineType(): iteration counts :5470-5483 */
+  uint8_t  amvrEncOpt;              /* m_pcEncCfg->getUseAffineAmvrEncOpt() */
+  uint8_t  lowDelayRounds;          /* m_pcEncCfg->getIntraPeriod() == -1 */
+  uint8_t  profAllowed;             /* sps.getUsePROF() && !m_skipPROF && !picHeader.getDisProfFlag() */
+  uint8_t  profNeedsLargeGrad;      /* m_encOnly && !slice.getCheckLDC() */
+  uint8_t  profIsBi;                /* m_isBi */
+  uint8_t  pad0;
+  int32_t  mvPred[3][2];            /* acMvPred */
+  int32_t  mv[3][2];                /* acMv on entry */
+  uint32_t bits;                    /* ruiBits on entry */
+  uint32_t pad1;
+  double   motionLambda;
+  uint64_t hevcCost;                /* m_hevcCost: the refinement stage runs when the best cost so far <= AFFINE_ME_LIST_MVP_TH * hevcCost */
+} vtmhip_affine_me_job;
+
+typedef struct
+{
+  int32_t  mv[3][2];                /* acMv */
+  uint32_t bits;                    /* ruiBits */
+  int32_t  iterations, refinements; /* predictions evaluated in the gradient stage / the refinement stage (statistics) */
+  int32_t  pad;
+  uint64_t cost;                    /* ruiCost */
+} vtmhip_affine_me_out;
+
+int vtmhip_xAffineMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                              const int16_t *d_otherPredBase, const vtmhip_affine_me_job *d_jobs, int n, int maxWidth, int maxHeight,
+                                              vtmhip_affine_me_out *d_results );
+/* InterPrediction::xPredAffineBlk, luma, uni-directional (rounded and clipped; PROF as flagged) at the jobs' `mv` models */
+int vtmhip_xPredAffineBlk_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_refBase, int16_t *d_dstBase,
+                                     const vtmhip_affine_me_job *d_jobs, int n, int maxWidth, int maxHeight );
+
 /* ================================================================================================================
  * (3) FRAME-LEVEL CHAINING -- the next stage's job table from the previous stage's results, on the device
  * ==============================================================================================================

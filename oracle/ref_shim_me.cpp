@@ -854,3 +854,118 @@ extern "C" void ref_check_best_mvp( double motionLambda, int imv, int numCand, c
   r.is.xCheckBestMVP( REF_PIC_LIST_0, Mv( mvHor, mvVer ), pred, *mvpIdx, amvp, b, c, ( uint8_t ) imv );
   *mvPredHor = pred.hor; *mvPredVer = pred.ver; *bits = b; *cost = c;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Affine motion estimation: the real InterPrediction::xPredAffineBlk (luma, PROF included; InterPrediction.cpp:856-1232) and the real
+// InterSearch::xAffineMotionEstimation (InterSearch.cpp:5340-5775: gradient iterations with solveEqual, control-point refinement) on the rig.
+// ------------------------------------------------------------------------------------------------------------------
+namespace
+{
+Picture   *g_affPic = nullptr;
+PicHeader *g_affPh  = nullptr;
+
+void affineSetup( MeRig &r, const vo_affine_pred_t *p )
+{
+  if( !g_affPic ) { g_affPic = new Picture(); g_affPh = new PicHeader(); }
+  if( !r.is.m_storedMv ) r.is.m_storedMv = new Mv[( MAX_CU_SIZE / MIN_PU_SIZE ) * ( MAX_CU_SIZE / MIN_PU_SIZE )];
+  r.sps.setMaxCUWidth( p->ctuSize ); r.sps.setMaxCUHeight( p->ctuSize );
+  r.sps.setBitDepth( CHANNEL_TYPE_LUMA, p->bitDepth );
+  r.sps.setUsePROF( p->profAllowed != 0 );
+  r.pps.setPicWidthInLumaSamples( p->picW ); r.pps.setPicHeightInLumaSamples( p->picH );
+  r.pps.setUseWP( false ); r.pps.setWPBiPred( false );
+  r.slice.setPPS( &r.pps ); r.slice.setSPS( &r.sps ); r.slice.setSliceType( B_SLICE );
+  r.slice.setCheckLDC( !p->profNeedsLargeGrad );
+  g_affPh->setDisProfFlag( false );
+  r.cs.picHeader = g_affPh;
+  r.is.m_skipPROF = false;
+  r.is.m_encOnly  = true;
+  r.is.m_isBi     = p->profIsBi != 0;
+  const UnitArea ua( CHROMA_400, Area( p->puX, p->puY, p->w, p->h ) );
+  r.cu.UnitArea::operator=( ua ); r.pu.UnitArea::operator=( ua );
+  r.cu.chromaFormat = CHROMA_400; r.pu.chromaFormat = CHROMA_400;
+  r.cu.affine = true; r.cu.affineType = p->sixParam ? AFFINEMODEL_6PARAM : AFFINEMODEL_4PARAM; r.cu.BcwIdx = BCW_DEFAULT;
+  r.pu.interDir = ( uint8_t ) p->interDir;
+  ClpRng clp; clp.min = 0; clp.max = ( 1 << p->bitDepth ) - 1; clp.bd = p->bitDepth; clp.n = 0;
+  r.slice.m_clpRngs.comp[COMPONENT_Y] = clp;
+  Pel *origin = const_cast<Pel *>( p->ref ) - ( ptrdiff_t ) p->puY * p->refStride - p->puX;
+  g_affPic->chromaFormat = CHROMA_400;
+  g_affPic->unscaledPic  = g_affPic;
+  g_affPic->m_bufs[PIC_RECONSTRUCTION].createFromBuf( PelUnitBuf( CHROMA_400, PelBuf( origin, p->refStride, p->picW, p->picH ) ) );
+  r.slice.m_apcRefPicList[REF_PIC_LIST_0][0] = g_affPic;
+}
+void affineRestore( MeRig &r )
+{
+  r.cu.affine = false; r.cu.imv = 0; r.is.m_encOnly = false; r.is.m_isBi = false; r.sps.setUsePROF( false );
+  r.cu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) ); r.pu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+  r.cu.chromaFormat = CHROMA_420; r.pu.chromaFormat = CHROMA_420;
+}
+}   // namespace
+
+extern "C" void ref_pred_affine_blk( const vo_affine_pred_t *p, const int mv[3][2], int bi, int16_t *dst, int dstStride )
+{
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  affineSetup( r, p );
+  Mv m[3] = { Mv( mv[0][0], mv[0][1] ), Mv( mv[1][0], mv[1][1] ), Mv( mv[2][0], mv[2][1] ) };
+  PelUnitBuf d( CHROMA_400, PelBuf( dst, dstStride, p->w, p->h ) );
+  r.is.m_iRefListIdx = 0;
+  r.is.xPredAffineBlk( COMPONENT_Y, r.pu, g_affPic, m, d, bi != 0, r.slice.clpRng( COMPONENT_Y ) );
+  affineRestore( r );
+}
+
+extern void solveEqual( double dEqualCoeff[7][7], int iOrder, double *dAffinePara );
+extern "C" void ref_solve_equal( double eq[7][7], int order, double *para ) { solveEqual( eq, order, para ); }
+
+extern "C" void ref_affine_motion_estimation( const vo_affine_me_job_t *j, vo_affine_me_result_t *res )
+{
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  static bool storage = false;
+  if( !storage )
+  {
+    const UnitArea lcu( CHROMA_400, Area( 0, 0, MAX_CU_SIZE, MAX_CU_SIZE ) );
+    if( r.is.m_tmpStorageLCU.bufs.empty() ) r.is.m_tmpStorageLCU.create( lcu );
+    if( r.is.m_tmpPredStorage[0].bufs.empty() ) r.is.m_tmpPredStorage[0].create( lcu );
+    if( r.is.m_tmpPredStorage[1].bufs.empty() ) r.is.m_tmpPredStorage[1].create( lcu );
+    r.is.m_tmpAffiStorage.create( lcu );
+    r.is.m_tmpAffiError   = new Pel[MAX_CU_SIZE * MAX_CU_SIZE];
+    r.is.m_tmpAffiDeri[0] = new int[MAX_CU_SIZE * MAX_CU_SIZE];
+    r.is.m_tmpAffiDeri[1] = new int[MAX_CU_SIZE * MAX_CU_SIZE];
+    storage = true;
+  }
+  affineSetup( r, &j->pred );
+  r.cu.imv = j->imv;
+  r.sps.setUseAffineType( j->useAffineType != 0 );
+  r.sps.setUseBcw( false );
+  r.slice.setDisableSATDForRD( !j->useSatd );
+  r.cfg.setUseAffineAmvrEncOpt( j->amvrEncOpt != 0 );
+  r.cfg.setIntraPeriod( j->lowDelayRounds ? -1 : 32 );
+  r.cfg.setMCTSEncConstraint( false );
+  r.cfg.setClipForBiPredMeEnabled( false );
+  r.rd.m_motionLambda = j->lambda;
+  r.is.m_hevcCost = j->hevcCost;
+  r.is.m_modeCtrl = nullptr;
+  AffineAMVPInfo aamvp;
+  aamvp.numCand = 2;
+  for( int i = 0; i < 2; i++ )
+  {
+    aamvp.mvCandLT[i] = Mv( j->mvPred[0][0], j->mvPred[0][1] ); aamvp.mvCandRT[i] = Mv( j->mvPred[1][0], j->mvPred[1][1] ); aamvp.mvCandLB[i] = Mv( j->mvPred[2][0], j->mvPred[2][1] );
+    r.is.m_auiMVPIdxCost[i][2] = 1;
+  }
+  if( j->bi )
+  {
+    PelBuf other = r.is.m_tmpPredStorage[1].getBuf( UnitAreaRelative( r.cu, r.pu ) ).Y();
+    for( int y = 0; y < j->pred.h; y++ ) memcpy( other.buf + ( ptrdiff_t ) y * other.stride, j->otherPred + ( ptrdiff_t ) y * j->otherStride, sizeof( Pel ) * j->pred.w );
+  }
+  PelUnitBuf origBuf( CHROMA_400, PelBuf( const_cast<Pel *>( j->org ), j->orgStride, j->pred.w, j->pred.h ) );
+  Mv pred[3], mv[3];
+  for( int i = 0; i < 3; i++ ) { pred[i] = Mv( j->mvPred[i][0], j->mvPred[i][1] ); mv[i] = Mv( j->mv[i][0], j->mv[i][1] ); }
+  uint32_t   bits = j->bits;
+  Distortion cost = std::numeric_limits<Distortion>::max();
+  int        mvpIdx = 0;
+  r.is.xAffineMotionEstimation( r.pu, origBuf, REF_PIC_LIST_0, pred, 0, mv, bits, cost, mvpIdx, aamvp, j->bi != 0 );
+  for( int i = 0; i < 3; i++ ) { res->mv[i][0] = mv[i].hor; res->mv[i][1] = mv[i].ver; }
+  res->bits = bits; res->cost = cost; res->iterations = res->refinements = 0;
+  r.slice.setDisableSATDForRD( false );
+  affineRestore( r );
+}

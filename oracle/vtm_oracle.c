@@ -1807,3 +1807,318 @@ void vo_check_best_mvp( double motionLambda, int imv, int numCand, const int can
     *cost = ( *cost - ( uint64_t ) ( motionLambda * org ) ) + ( uint64_t ) ( motionLambda * *bits );
   }
 }
+
+
+/* ---- affine prediction and affine motion estimation ------------------------------------------------------------------------------- */
+static void vo_round_affine_mv( int *x, int *y, int shift ) { const int o = 1 << ( shift - 1 ); *x = ( *x + o - ( *x >= 0 ) ) >> shift; *y = ( *y + o - ( *y >= 0 ) ) >> shift; }   /* Mv.cpp:47-52 */
+static int vo_ilog2( int v ) { int r = 0; while( ( 2 << r ) <= v ) r++; return r; }
+
+/* isSubblockVectorSpreadOverLimit (InterPrediction.cpp:816-854) */
+static int vo_spread_over_limit( int a, int b, int c, int d, int predType )
+{
+#define MX( x, y ) ( ( x ) > ( y ) ? ( x ) : ( y ) )
+#define MN( x, y ) ( ( x ) < ( y ) ? ( x ) : ( y ) )
+  const int s4 = 4 << 11, tap = 6;
+  if( predType == 3 )
+  {
+    int rw = MX( MX( 0, 4 * a + s4 ), MX( 4 * c, 4 * a + 4 * c + s4 ) ) - MN( MN( 0, 4 * a + s4 ), MN( 4 * c, 4 * a + 4 * c + s4 ) );
+    int rh = MX( MX( 0, 4 * b ), MX( 4 * d + s4, 4 * b + 4 * d + s4 ) ) - MN( MN( 0, 4 * b ), MN( 4 * d + s4, 4 * b + 4 * d + s4 ) );
+    rw = ( rw >> 11 ) + tap + 3; rh = ( rh >> 11 ) + tap + 3;
+    return rw * rh > ( tap + 9 ) * ( tap + 9 );
+  }
+  int rw = MX( 0, 4 * a + s4 ) - MN( 0, 4 * a + s4 ), rh = MX( 0, 4 * b ) - MN( 0, 4 * b );
+  rw = ( rw >> 11 ) + tap + 3; rh = ( rh >> 11 ) + tap + 3;
+  if( rw * rh > ( tap + 9 ) * ( tap + 5 ) ) return 1;
+  rw = MX( 0, 4 * c ) - MN( 0, 4 * c ); rh = MX( 0, 4 * d + s4 ) - MN( 0, 4 * d + s4 );
+  rw = ( rw >> 11 ) + tap + 3; rh = ( rh >> 11 ) + tap + 3;
+  return rw * rh > ( tap + 5 ) * ( tap + 9 );
+#undef MX
+#undef MN
+}
+
+/* InterPrediction::xPredAffineBlk, luma (InterPrediction.cpp:856-1232): one vector per 4x4 sub-block from the control-point vectors, the 6-tap
+ * sub-block interpolation (m_lumaFilter4x4), optionally PROF (gradients of the 14-bit prediction x per-sample vector offsets, Buffer.cpp:45-70, 130-147) */
+void vo_pred_affine_blk( const vo_affine_pred_t *p, const int mv[3][2], int bi, int16_t *dst, int dstStride )
+{
+  const int iBit = 7, w = p->w, h = p->h;
+  int dHX = ( mv[1][0] - mv[0][0] ) << ( iBit - vo_ilog2( w ) ), dHY = ( mv[1][1] - mv[0][1] ) << ( iBit - vo_ilog2( w ) ), dVX, dVY;
+  if( p->sixParam ) { dVX = ( mv[2][0] - mv[0][0] ) << ( iBit - vo_ilog2( h ) ); dVY = ( mv[2][1] - mv[0][1] ) << ( iBit - vo_ilog2( h ) ); }
+  else { dVX = -dHY; dVY = dHX; }
+  const int baseH = mv[0][0] << iBit, baseV = mv[0][1] << iBit, shift = iBit - 4 + 4;
+  const int over = vo_spread_over_limit( dHX, dHY, dVX, dVY, p->interDir );
+  int prof = p->profAllowed;
+  prof &= !( ( p->sixParam && mv[0][0] == mv[1][0] && mv[0][1] == mv[1][1] && mv[0][0] == mv[2][0] && mv[0][1] == mv[2][1] ) || ( !p->sixParam && mv[0][0] == mv[1][0] && mv[0][1] == mv[1][1] ) );
+  prof &= !over;
+  const int thr = 1 << ( iBit + ( p->profIsBi ? 1 : 0 ) );
+  prof &= !p->profNeedsLargeGrad || dHX > thr || dHY > thr || dVX > thr || dVY > thr || dHX < -thr || dHY < -thr || dVX < -thr || dVY < -thr;
+  const int isLast = prof ? 0 : !bi;
+  int dMvH[16], dMvV[16];
+  if( prof )
+  {
+    const int qHX = dHX << 2, qHY = dHY << 2, qVX = dVX << 2, qVY = dVY << 2;
+    dMvH[0] = ( ( dHX + dVX ) << 1 ) - ( ( qHX + qVX ) << 1 );
+    dMvV[0] = ( ( dHY + dVY ) << 1 ) - ( ( qHY + qVY ) << 1 );
+    for( int x = 1; x < 4; x++ ) { dMvH[x] = dMvH[x - 1] + qHX; dMvV[x] = dMvV[x - 1] + qHY; }
+    for( int y = 1; y < 4; y++ )
+      for( int x = 0; x < 4; x++ ) { dMvH[y * 4 + x] = dMvH[( y - 1 ) * 4 + x] + qVX; dMvV[y * 4 + x] = dMvV[( y - 1 ) * 4 + x] + qVY; }
+    for( int i = 0; i < 16; i++ )
+    {
+      vo_round_affine_mv( &dMvH[i], &dMvV[i], 8 );
+      dMvH[i] = vo_clip3( -31, 31, dMvH[i] ); dMvV[i] = vo_clip3( -31, 31, dMvV[i] );
+    }
+  }
+  const int horMax = ( p->picW + 8 - p->puX - 1 ) << 4, horMin = ( -p->ctuSize - 8 - p->puX + 1 ) << 4;
+  const int verMax = ( p->picH + 8 - p->puY - 1 ) << 4, verMin = ( -p->ctuSize - 8 - p->puY + 1 ) << 4;
+  const int ifShift = 14 - p->bitDepth > 2 ? 14 - p->bitDepth : 2;
+  for( int y = 0; y < h; y += 4 )
+    for( int x = 0; x < w; x += 4 )
+    {
+      int mh, mvv;
+      if( !over ) { mh = baseH + dHX * ( 2 + x ) + dVX * ( 2 + y ); mvv = baseV + dHY * ( 2 + x ) + dVY * ( 2 + y ); }
+      else { mh = baseH + dHX * ( w >> 1 ) + dVX * ( h >> 1 ); mvv = baseV + dHY * ( w >> 1 ) + dVY * ( h >> 1 ); }
+      vo_round_affine_mv( &mh, &mvv, shift );
+      mh = vo_clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mh ); mvv = vo_clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mvv );   /* clipToStorageBitDepth */
+      mh = vo_clip3( horMin, horMax, mh ); mvv = vo_clip3( verMin, verMax, mvv );                                 /* clipMv (pu position and size) */
+      const int16_t *r0 = p->ref + ( ptrdiff_t ) y * p->refStride + x;
+      if( !prof )
+      {
+        vo_mc_luma( r0, p->refStride, 4, 4, mh, mvv, !isLast, p->bitDepth, 0, dst + ( ptrdiff_t ) y * dstStride + x, dstStride );
+        continue;
+      }
+      /* PROF: 14-bit prediction of the sub-block inside a one-sample ring of integer reference samples */
+      int16_t ext[6 * 8], gx[6 * 6], gy[6 * 6];
+      const int es = 8, xInt = mh >> 4, yInt = mvv >> 4, xFrac = mh & 15, yFrac = mvv & 15;
+      vo_mc_luma( r0, p->refStride, 4, 4, mh, mvv, 1, p->bitDepth, 0, ext + es + 1, es );
+      const int16_t *rb = r0 + ( ptrdiff_t ) yInt * p->refStride + xInt;
+      const int      xo = xFrac >> 3, yo = yFrac >> 3;
+      const int16_t *rp = rb - ( 1 - yo ) * p->refStride + xo - 1;
+      for( int i = 0; i < 6; i++ )
+      {
+        ext[i]          = ( int16_t ) ( ( rp[i] << ifShift ) - 8192 );
+        ext[5 * es + i] = ( int16_t ) ( ( rp[i + 5 * p->refStride] << ifShift ) - 8192 );
+      }
+      rp = rb + yo * p->refStride + xo;
+      for( int j = 0; j < 4; j++ )
+      {
+        ext[( j + 1 ) * es]     = ( int16_t ) ( ( rp[j * p->refStride - 1] << ifShift ) - 8192 );
+        ext[( j + 1 ) * es + 5] = ( int16_t ) ( ( rp[j * p->refStride + 4] << ifShift ) - 8192 );
+      }
+      for( int j = 0; j < 4; j++ )
+        for( int i = 0; i < 4; i++ )
+        {
+          const int16_t *c = ext + ( j + 1 ) * es + i + 1;
+          gy[( j + 1 ) * 6 + i + 1] = ( int16_t ) ( ( c[es] >> 6 ) - ( c[-es] >> 6 ) );
+          gx[( j + 1 ) * 6 + i + 1] = ( int16_t ) ( ( c[1] >> 6 ) - ( c[-1] >> 6 ) );
+        }
+      const int dILimit = 1 << ( p->bitDepth + 1 > 13 ? p->bitDepth + 1 : 13 );
+      const int offset = ( 1 << ( ifShift - 1 ) ) + 8192;
+      for( int j = 0; j < 4; j++ )
+        for( int i = 0; i < 4; i++ )
+        {
+          int dI = dMvH[j * 4 + i] * gx[( j + 1 ) * 6 + i + 1] + dMvV[j * 4 + i] * gy[( j + 1 ) * 6 + i + 1];
+          dI = vo_clip3( -dILimit, dILimit - 1, dI );
+          int16_t v = ( int16_t ) ( ext[( j + 1 ) * es + i + 1] + dI );
+          if( !bi ) { int t = ( v + offset ) >> ifShift; v = ( int16_t ) vo_clip3( 0, ( 1 << p->bitDepth ) - 1, ( int16_t ) t ); }
+          dst[( ptrdiff_t ) ( y + j ) * dstStride + x + i] = v;
+        }
+    }
+}
+
+void vo_solve_equal( double eq[7][7], int order, double *para )
+{
+  for( int k = 0; k < order; k++ ) para[k] = 0.;
+  for( int i = 1; i < order; i++ )
+  {
+    double temp = fabs( eq[i][i - 1] );
+    int    idx = i;
+    for( int j = i + 1; j < order + 1; j++ ) if( fabs( eq[j][i - 1] ) > temp ) { temp = fabs( eq[j][i - 1] ); idx = j; }
+    if( idx != i )
+      for( int j = 0; j < order + 1; j++ ) { eq[0][j] = eq[i][j]; eq[i][j] = eq[idx][j]; eq[idx][j] = eq[0][j]; }
+    if( eq[i][i - 1] == 0. ) return;
+    for( int j = i + 1; j < order + 1; j++ )
+      for( int k = i; k < order + 1; k++ ) eq[j][k] = eq[j][k] - eq[i][k] * eq[j][i - 1] / eq[i][i - 1];
+  }
+  if( eq[order][order - 1] == 0. ) return;
+  para[order - 1] = eq[order][order] / eq[order][order - 1];
+  for( int i = order - 2; i >= 0; i-- )
+  {
+    if( eq[i + 1][i] == 0. ) { for( int k = 0; k < order; k++ ) para[k] = 0.; return; }
+    double temp = 0;
+    for( int j = i + 1; j < order; j++ ) temp += eq[i + 1][j] * para[j];
+    para[i] = ( eq[i + 1][order] - temp ) / eq[i + 1][i];
+  }
+}
+
+static const int vo_affine_prec_shift[3] = { 2, 0, 4 };   /* INTERNAL -> m_amvrPrecAffine[imv] = QUARTER, SIXTEENTH, INT */
+static int vo_prec_dn( int v, int rs ) { if( rs == 0 ) return v; const int o = 1 << ( rs - 1 ); return v >= 0 ? ( v + o - 1 ) >> rs : ( v + o ) >> rs; }
+static void vo_round_affine_prec( int *mv, int imv ) { const int rs = vo_affine_prec_shift[imv]; mv[0] = vo_prec_dn( mv[0], rs ) << rs; mv[1] = vo_prec_dn( mv[1], rs ) << rs; }   /* roundAffinePrecInternal2Amvr */
+
+/* xCalcAffineMVBits (InterSearch.cpp:3067-3085) */
+static unsigned vo_affine_mv_bits( int sixParam, int imv, const int mv[3][2], const int pred[3][2] )
+{
+  const int n = sixParam ? 3 : 2, rs = vo_affine_prec_shift[imv];
+  unsigned  bits = 0;
+  for( int v = 0; v < n; v++ )
+  {
+    int ph = v == 0 ? pred[0][0] : pred[v][0] + mv[0][0] - pred[0][0], pv = v == 0 ? pred[0][1] : pred[v][1] + mv[0][1] - pred[0][1];
+    ph = vo_prec_dn( ph, rs ); pv = vo_prec_dn( pv, rs );
+    bits += vo_eg_bits( vo_prec_dn( mv[v][0], rs ) - ph ) + vo_eg_bits( vo_prec_dn( mv[v][1], rs ) - pv );
+  }
+  return bits;
+}
+
+void vo_affine_motion_estimation( const vo_affine_me_job_t *j, vo_affine_me_result_t *res )
+{
+  const vo_affine_pred_t *p = &j->pred;
+  const int w = p->w, h = p->h, six = p->sixParam, mvNum = six ? 3 : 2, paraNum = six ? 7 : 5;
+  static int16_t pat[128 * 128], pred[128 * 128], err[128 * 128];
+  static int32_t deri[2][128 * 128];
+  const double fWeight = j->bi ? 0.5 : 1.0;
+  for( int y = 0; y < h; y++ ) memcpy( pat + y * w, j->org + ( ptrdiff_t ) y * j->orgStride, sizeof( int16_t ) * w );
+  if( j->bi ) vo_remove_high_freq( pat, w, j->otherPred, j->otherStride, w, h );
+  const int horMax = ( p->picW + 8 - p->puX - 1 ) << 4, horMin = ( -p->ctuSize - 8 - p->puX + 1 ) << 4;
+  const int verMax = ( p->picH + 8 - p->puY - 1 ) << 4, verMin = ( -p->ctuSize - 8 - p->puY + 1 ) << 4;
+#define CLIPMV( m ) do { ( m )[0] = vo_clip3( horMin, horMax, ( m )[0] ); ( m )[1] = vo_clip3( verMin, verMax, ( m )[1] ); } while( 0 )
+#define DIST() ( j->useSatd ? vo_satd( pred, w, pat, w, w, h ) : vo_sad( pred, w, pat, w, w, h, 0 ) )
+#define RATE( b ) ( ( uint64_t ) ( j->lambda * ( b ) ) )
+  int tmp[3][2], best[3][2];
+  memcpy( tmp, j->mv, sizeof( tmp ) );
+  for( int i = 0; i < mvNum; i++ ) { CLIPMV( tmp[i] ); vo_round_affine_prec( tmp[i], j->imv ); }
+  vo_pred_affine_blk( p, tmp, 0, pred, w );
+  uint64_t costBest = DIST();
+  unsigned bitsBest = j->bits + vo_affine_mv_bits( six, j->imv, tmp, j->mvPred );
+  costBest = ( uint64_t ) ( floor( fWeight * ( double ) costBest ) + ( double ) RATE( bitsBest ) );
+  memcpy( best, tmp, sizeof( best ) );
+  int iterTime = six ? ( j->bi ? 3 : 4 ) : ( j->bi ? 3 : 5 );
+  if( !j->useAffineType ) iterTime = j->bi ? 5 : 7;
+  int prev[7][3][2];
+  res->iterations = 0; res->refinements = 0;
+  for( int iter = 0; iter < iterTime; iter++ )
+  {
+    memcpy( prev[iter], tmp, sizeof( tmp ) );
+    for( int i = 0; i < w * h; i++ ) err[i] = ( int16_t ) ( pat[i] - pred[i] );
+    vo_sobel( 0, pred, w, deri[0], w, w, h );
+    vo_sobel( 1, pred, w, deri[1], w, w, h );
+    int64_t eq[7][7];
+    memset( eq, 0, sizeof( eq ) );
+    vo_equal_coeff( err, w, deri[0], deri[1], w, eq, w, h, six );
+    double deq[7][7], para[6], dmv[6] = { 0, 0, 0, 0, 0, 0 };
+    for( int r = 0; r < paraNum; r++ ) for( int c = 0; c < paraNum; c++ ) deq[r][c] = ( double ) eq[r][c];
+    vo_solve_equal( deq, paraNum - 1, para );
+    dmv[0] = para[0]; dmv[2] = para[2];
+    if( six ) { dmv[1] = para[1] * w + para[0]; dmv[3] = para[3] * w + para[2]; dmv[4] = para[4] * h + para[0]; dmv[5] = para[5] * h + para[2]; }
+    else { dmv[1] = para[1] * w + para[0]; dmv[3] = -para[3] * w + para[2]; }
+    static const int normShift[3] = { 2, 4, 2 }, stepShift[3] = { 2, 0, 2 };
+    const int mult = 1 << normShift[j->imv], ms = stepShift[j->imv];
+#define SGN( x ) ( ( x ) >= 0 ? 1 : -1 )
+    int delta[3][2];
+    delta[0][0] = ( int ) ( dmv[0] * mult + SGN( dmv[0] ) * 0.5 ) << ms; delta[0][1] = ( int ) ( dmv[2] * mult + SGN( dmv[2] ) * 0.5 ) << ms;
+    delta[1][0] = ( int ) ( dmv[1] * mult + SGN( dmv[1] ) * 0.5 ) << ms; delta[1][1] = ( int ) ( dmv[3] * mult + SGN( dmv[3] ) * 0.5 ) << ms;
+    delta[2][0] = delta[2][1] = 0;
+    if( six ) { delta[2][0] = ( int ) ( dmv[4] * mult + SGN( dmv[4] ) * 0.5 ) << ms; delta[2][1] = ( int ) ( dmv[5] * mult + SGN( dmv[5] ) * 0.5 ) << ms; }
+#undef SGN
+    if( !j->amvrEncOpt )
+    {
+      int allZero = 0;
+      for( int i = 0; i < mvNum; i++ )
+      {
+        int d[2] = { delta[i][0], delta[i][1] };
+        if( j->imv == 2 ) { d[0] = vo_prec_dn( d[0], 3 ) << 3; d[1] = vo_prec_dn( d[1], 3 ) << 3; }   /* roundToPrecision( INTERNAL, HALF ) */
+        if( d[0] != 0 || d[1] != 0 ) { allZero = 0; break; }
+        allZero = 1;
+      }
+      if( allZero ) break;
+    }
+    for( int i = 0; i < mvNum; i++ )
+    {
+      tmp[i][0] = vo_clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, tmp[i][0] + delta[i][0] );
+      tmp[i][1] = vo_clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, tmp[i][1] + delta[i][1] );
+      vo_round_affine_prec( tmp[i], j->imv );
+      CLIPMV( tmp[i] );
+    }
+    if( j->amvrEncOpt )
+    {
+      int identical = 0;
+      for( int k = iter; k >= 0; k-- )
+        if( tmp[0][0] == prev[k][0][0] && tmp[0][1] == prev[k][0][1] && tmp[1][0] == prev[k][1][0] && tmp[1][1] == prev[k][1][1] )
+        {
+          identical = six ? ( tmp[2][0] == prev[k][2][0] && tmp[2][1] == prev[k][2][1] ) : 1;
+          if( identical ) break;
+        }
+      if( identical ) break;
+    }
+    vo_pred_affine_blk( p, tmp, 0, pred, w );
+    res->iterations++;
+    uint64_t c = DIST();
+    const unsigned b = j->bits + vo_affine_mv_bits( six, j->imv, tmp, j->mvPred );
+    c = ( uint64_t ) ( floor( fWeight * ( double ) c ) + ( double ) RATE( b ) );
+    if( c < costBest ) { costBest = c; bitsBest = b; memcpy( best, tmp, sizeof( best ) ); }
+  }
+#define CHECK_CPMV( m ) do { vo_pred_affine_blk( p, m, 0, pred, w ); res->refinements++; uint64_t c_ = DIST(); const unsigned b_ = j->bits + vo_affine_mv_bits( six, j->imv, m, j->mvPred ); \
+    c_ = ( uint64_t ) ( floor( fWeight * ( double ) c_ ) + ( double ) RATE( b_ ) ); if( c_ < costBest ) { costBest = c_; bitsBest = b_; memcpy( best, m, sizeof( best ) ); changed = 1; } } while( 0 )
+  static const int mvShiftTab[3] = { 2, 0, 4 };
+  const int mvShift = mvShiftTab[j->imv];
+  if( ( double ) costBest <= 1.0 * ( double ) j->hevcCost )
+  {
+    int me[3][2], dMv[2], changed = 0;
+    memcpy( me, best, sizeof( me ) );
+    dMv[0] = me[0][0] - j->mvPred[0][0]; dMv[1] = me[0][1] - j->mvPred[0][1];
+    for( int k = 0; k < mvNum; k++ )
+    {
+      const int ph = j->mvPred[k][0] + ( k ? dMv[0] : 0 ), pv = j->mvPred[k][1] + ( k ? dMv[1] : 0 );
+      if( me[k][0] != ph || me[k][1] != pv )
+      {
+        memcpy( tmp, me, sizeof( tmp ) );
+        tmp[k][0] = ph; tmp[k][1] = pv;
+        CHECK_CPMV( tmp );
+      }
+    }
+    if( me[0][0] != j->mvPred[0][0] || me[0][1] != j->mvPred[0][1] )
+    {
+      memcpy( tmp, me, sizeof( tmp ) );
+      for( int i = 1; i < mvNum; i++ ) { tmp[i][0] -= dMv[0]; tmp[i][1] -= dMv[1]; }
+      tmp[0][0] = j->mvPred[0][0]; tmp[0][1] = j->mvPred[0][1];
+      CHECK_CPMV( tmp );
+    }
+    if( six && ( me[1][0] != j->mvPred[1][0] + dMv[0] || me[1][1] != j->mvPred[1][1] + dMv[1] ) && ( me[2][0] != j->mvPred[2][0] + dMv[0] || me[2][1] != j->mvPred[2][1] + dMv[1] ) )
+    {
+      memcpy( tmp, me, sizeof( tmp ) );
+      tmp[1][0] = j->mvPred[1][0] + dMv[0]; tmp[1][1] = j->mvPred[1][1] + dMv[1];
+      tmp[2][0] = j->mvPred[2][0] + dMv[0]; tmp[2][1] = j->mvPred[2][1] + dMv[1];
+      CHECK_CPMV( tmp );
+    }
+    static const int testPos[8][2] = { { -1, 0 }, { 0, -1 }, { 0, 1 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, 1 }, { 1, -1 } };
+    const int maxRound = j->imv ? 3 : ( ( j->amvrEncOpt && j->lowDelayRounds ) ? 2 : 3 );   /* :5712 */
+    for( int rnd = 0; rnd < maxRound; rnd++ )
+    {
+      int modelChange = 0;
+      for( int k = 0; k < mvNum; k++ )
+      {
+        int loopChange = 0;
+        for( int it = 0; it < 2; it++ )
+        {
+          if( it == 1 && !loopChange ) break;
+          int center[3][2];
+          memcpy( center, best, sizeof( center ) );
+          memcpy( tmp, best, sizeof( tmp ) );
+          for( int i = it == 0 ? 0 : 4; i < ( it == 0 ? 4 : 8 ); i++ )
+          {
+            tmp[k][0] = center[k][0] + ( testPos[i][0] << mvShift ); tmp[k][1] = center[k][1] + ( testPos[i][1] << mvShift );
+            CLIPMV( tmp[k] );
+            changed = 0;
+            CHECK_CPMV( tmp );
+            if( changed ) { modelChange = 1; loopChange = 1; }
+          }
+        }
+      }
+      if( !modelChange ) break;
+    }
+    ( void ) changed;
+  }
+#undef CHECK_CPMV
+#undef CLIPMV
+#undef DIST
+#undef RATE
+  memcpy( res->mv, best, sizeof( best ) );
+  res->bits = bitsBest; res->cost = costBest;
+}

@@ -173,6 +173,35 @@ void vo_estimate_mvp_amvp( const vo_mest_job_t *job, int *mvpIdx, int *mvPredHor
 void vo_check_best_mvp( double motionLambda, int imv, int numCand, const int cands[2][2], const unsigned idxBits[2], int mvHor, int mvVer,
                         int *mvPredHor, int *mvPredVer, int *mvpIdx, unsigned *bits, uint64_t *cost );
 
+/* ---- affine motion estimation: InterPrediction::xPredAffineBlk (luma, incl. PROF) and InterSearch::xAffineMotionEstimation ---- */
+typedef struct
+{
+  const int16_t *ref; int refStride;   /* reconstructed reference luma at the PU position (MV 0,0) */
+  int w, h, puX, puY, picW, picH, ctuSize, bitDepth;
+  int sixParam;                        /* cu.affineType == AFFINEMODEL_6PARAM */
+  int interDir;                        /* pu.interDir as isSubblockVectorSpreadOverLimit sees it (1, 2, 3) */
+  int profAllowed;                     /* sps.getUsePROF() && !m_skipPROF && !picHeader.getDisProfFlag() (no reference scaling) */
+  int profNeedsLargeGrad;              /* m_encOnly && !slice.getCheckLDC(): PROF only beyond the profThres gradient (InterPrediction.cpp:913-914) */
+  int profIsBi;                        /* m_isBi */
+} vo_affine_pred_t;
+void vo_pred_affine_blk( const vo_affine_pred_t *p, const int mv[3][2], int bi, int16_t *dst, int dstStride );
+
+typedef struct
+{
+  vo_affine_pred_t pred;
+  const int16_t *org; int orgStride;          /* origBuf.Y() */
+  const int16_t *otherPred; int otherStride;  /* bi: m_tmpPredStorage[1 - list] */
+  int bi, imv, useSatd, useAffineType, amvrEncOpt, lowDelayRounds;   /* lowDelayRounds: IntraPeriod == -1 (with AffineAmvrEncOpt: 2 refinement rounds for imv 0) */
+  int mvPred[3][2], mv[3][2];
+  unsigned bits;
+  double lambda;
+  uint64_t hevcCost;                          /* m_hevcCost */
+} vo_affine_me_job_t;
+typedef struct { int mv[3][2]; unsigned bits; uint64_t cost; int iterations, refinements; } vo_affine_me_result_t;
+/* InterSearch.cpp:5340-5775 for cu.imv 0 / 1, and 2 without AffineAmvrEncOpt (no xDetermineBestMvp); default BCW weight, no MCTS */
+void vo_affine_motion_estimation( const vo_affine_me_job_t *job, vo_affine_me_result_t *res );
+void vo_solve_equal( double eq[7][7], int order, double *para );   /* solveEqual, InterSearch.cpp:5215-5284 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -437,6 +437,36 @@ def gen_lfnst():
     print("lfnst:", len(meta), "vectors")
 
 
+def gen_affine_me():
+    """InterPrediction::xPredAffineBlk and InterSearch::xAffineMotionEstimation as the real members (oracle/ref_shim_me.cpp) on random affine jobs;
+    m_hevcCost is set relative to the cost of the unrestricted run so that both outcomes of the refinement gate occur"""
+    import json
+    scene = me_util.Scene(416, 240, hard=False)
+    jobs = me_util.random_affine_jobs(scene, 120, seed=777)
+    mvs, bits, costs, hevc, preds = [], [], [], [], []
+    for j in jobs:
+        keep = []
+        t = me_util.affine_me_struct(scene, j, keep)
+        t.hevcCost = 1 << 62
+        r0 = ol.AffineMeResult()
+        R.ref_affine_motion_estimation(C.byref(t), C.byref(r0))
+        t.hevcCost = int(r0.cost * j["hevc_scale"])
+        r = ol.AffineMeResult()
+        R.ref_affine_motion_estimation(C.byref(t), C.byref(r))
+        hevc.append(t.hevcCost)
+        mvs.append([list(v) for v in r.mv])
+        bits.append(r.bits)
+        costs.append(r.cost)
+        p = me_util.affine_pred_struct(scene, j)
+        mv = ((C.c_int * 2) * 3)(*[(C.c_int * 2)(*v) for v in j["mv"]])
+        a = np.zeros((j["h"], j["w"]), np.int16)
+        R.ref_pred_affine_blk(C.byref(p), mv, 0, ol.P(a), j["w"])
+        preds.append(a.reshape(-1))
+    np.savez_compressed(os.path.join(HERE, "affine_me.npz"), jobs=np.array([json.dumps(j) for j in jobs]), mv=np.array(mvs, np.int32), bits=np.array(bits, np.int64),
+                        cost=np.array(costs, np.int64), hevc=np.array(hevc, np.int64), pred=np.concatenate(preds))
+    print("affine_me:", len(jobs), "jobs")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected fixtures only: gen_golden.py mest quant ...
         for name in sys.argv[1:]:
@@ -456,3 +486,4 @@ if __name__ == "__main__":
     gen_bdof()
     gen_dmvr()
     gen_lfnst()
+    gen_affine_me()

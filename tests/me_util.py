@@ -184,3 +184,58 @@ def oracle_mest_job(scene, j, keep):
     for i, (a, b) in enumerate(j["extra"]):
         t.extraStart[i][0], t.extraStart[i][1] = a, b
     return t
+
+
+def random_affine_jobs(scene, n, seed=5, sizes=(16, 32, 64, 128)):
+    """Affine ME jobs on a scene: control-point vectors = a small rotation / zoom around a translation, predictors near them."""
+    rng = np.random.default_rng(seed)
+    jobs = []
+    while len(jobs) < n:
+        w, h = int(rng.choice(sizes)), int(rng.choice(sizes))
+        if w > scene.W or h > scene.H:
+            continue
+        x = int(rng.integers(0, (scene.W - w) // 4 + 1)) * 4
+        y = int(rng.integers(0, (scene.H - h) // 4 + 1)) * 4
+        six = int(rng.integers(0, 2))
+        imv = int(rng.choice([0, 0, 0, 1, 2]))
+        tx, ty = int(rng.integers(-12 * 16, 12 * 16)), int(rng.integers(-8 * 16, 8 * 16))
+        a, b = int(rng.integers(-40, 41)), int(rng.integers(-40, 41))          # per-block vector differences (1/16 sample)
+        mv = [[tx, ty], [tx + a, ty + b], [tx - b + int(rng.integers(-8, 9)) * six, ty + a + int(rng.integers(-8, 9)) * six]]
+        if len(jobs) % 7 == 0:
+            mv = [[tx, ty], [tx, ty], [tx, ty]]        # pure translation: PROF is off, the gradient iteration starts from a flat model
+        if len(jobs) % 11 == 0:
+            mv[1] = [tx + 900, ty - 700]              # a spread the sub-block vectors may not have (isSubblockVectorSpreadOverLimit)
+        pred = [[v[0] + int(rng.integers(-3, 4)) * 4, v[1] + int(rng.integers(-3, 4)) * 4] for v in mv]
+        sh = {0: 2, 1: 0, 2: 4}[imv]
+        rnd = lambda v: (((v + (1 << sh >> 1) - (1 if v >= 0 else 0)) >> sh) << sh) if sh else v   # noqa: E731
+        pred = [[rnd(p[0]), rnd(p[1])] for p in pred]
+        jobs.append(dict(w=w, h=h, x=x, y=y, six=six, imv=imv, mv=mv, pred=pred, bi=int(rng.integers(0, 3) == 0), satd=int(rng.integers(0, 4) != 0),
+                         affine_type=int(rng.integers(0, 5) != 0), enc_opt=int(imv != 2 and rng.integers(0, 2)), low_delay=int(rng.integers(0, 2)),
+                         inter_dir=int(rng.choice([1, 2, 3])), prof=int(rng.integers(0, 4) != 0), prof_large=int(rng.integers(0, 2)), prof_bi=int(rng.integers(0, 2)),
+                         bits=int(rng.integers(4, 14)), lam=float(rng.uniform(2, 30)), hevc_scale=float(rng.choice([0.5, 1.0, 4.0])),
+                         other_seed=int(rng.integers(0, 1 << 30))))
+    return jobs
+
+
+def affine_pred_struct(scene, j):
+    p = ol.AffinePred()
+    p.ref = scene.ref_buf.ctypes.data + 2 * (scene.ref_off + j["y"] * scene.ref_stride + j["x"])
+    p.refStride, p.w, p.h, p.puX, p.puY, p.picW, p.picH, p.ctuSize, p.bitDepth = scene.ref_stride, j["w"], j["h"], j["x"], j["y"], scene.W, scene.H, 128, 10
+    p.sixParam, p.interDir, p.profAllowed, p.profNeedsLargeGrad, p.profIsBi = j["six"], j["inter_dir"], j["prof"], j["prof_large"], j["prof_bi"]
+    return p
+
+
+def affine_me_struct(scene, j, keep):
+    t = ol.AffineMeJob()
+    t.pred = affine_pred_struct(scene, j)
+    t.org, t.orgStride = scene.cur.ctypes.data + 2 * (j["y"] * scene.W + j["x"]), scene.W
+    if j["bi"]:
+        o = other_pred(scene, j)
+        keep.append(o)
+        t.otherPred, t.otherStride = o.ctypes.data, j["w"]
+    t.bi, t.imv, t.useSatd, t.useAffineType, t.amvrEncOpt, t.lowDelayRounds = j["bi"], j["imv"], j["satd"], j["affine_type"], j["enc_opt"], j["low_delay"]
+    for i in range(3):
+        t.mvPred[i][0], t.mvPred[i][1] = j["pred"][i]
+        t.mv[i][0], t.mv[i][1] = j["mv"][i]
+    t.bits, t.motionLambda = j["bits"], j["lam"]
+    return t

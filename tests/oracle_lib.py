@@ -135,3 +135,19 @@ def r_dist(kind, simd, org, cur, w, h, bit_depth=10, sub_shift=0, org_off=0, cur
     po = org.ctypes.data + 2 * org_off
     pc = cur.ctypes.data + 2 * cur_off
     return L.ref_dist(kind, simd, C.c_void_p(po), org.shape[1], C.c_void_p(pc), cur.shape[1], w, h, bit_depth, sub_shift)
+
+
+class AffinePred(C.Structure):
+    _fields_ = [("ref", C.c_void_p), ("refStride", C.c_int), ("w", C.c_int), ("h", C.c_int), ("puX", C.c_int), ("puY", C.c_int), ("picW", C.c_int),
+                ("picH", C.c_int), ("ctuSize", C.c_int), ("bitDepth", C.c_int), ("sixParam", C.c_int), ("interDir", C.c_int), ("profAllowed", C.c_int),
+                ("profNeedsLargeGrad", C.c_int), ("profIsBi", C.c_int)]
+
+
+class AffineMeJob(C.Structure):
+    _fields_ = [("pred", AffinePred), ("org", C.c_void_p), ("orgStride", C.c_int), ("otherPred", C.c_void_p), ("otherStride", C.c_int), ("bi", C.c_int),
+                ("imv", C.c_int), ("useSatd", C.c_int), ("useAffineType", C.c_int), ("amvrEncOpt", C.c_int), ("lowDelayRounds", C.c_int),
+                ("mvPred", (C.c_int * 2) * 3), ("mv", (C.c_int * 2) * 3), ("bits", C.c_uint), ("motionLambda", C.c_double), ("hevcCost", C.c_uint64)]
+
+
+class AffineMeResult(C.Structure):
+    _fields_ = [("mv", (C.c_int * 2) * 3), ("bits", C.c_uint), ("cost", C.c_uint64), ("iterations", C.c_int), ("refinements", C.c_int)]

@@ -241,3 +241,27 @@ def test_lfnst_golden(oracle):
         fn = oracle.vo_inv_lfnst if inverse else oracle.vo_fwd_lfnst
         fn(ol.P(np.ascontiguousarray(s_)), ol.P(got), C.c_void_p(np.ascontiguousarray(M).ctypes.data), size, zo)
         assert np.array_equal(got[:n], e[:n]), (inverse, mode, index, size, zo)
+
+
+def test_affine_me_golden(oracle):
+    """golden xPredAffineBlk / xAffineMotionEstimation results recorded from the real members (tests/golden/affine_me.npz) vs the oracle"""
+    import json
+    import me_util
+    z = np.load(os.path.join(G, "affine_me.npz"))
+    scene = me_util.Scene(416, 240, hard=False)
+    jobs = [json.loads(str(s)) for s in z["jobs"]]
+    off = 0
+    for k, j in enumerate(jobs):
+        keep = []
+        t = me_util.affine_me_struct(scene, j, keep)
+        t.hevcCost = int(z["hevc"][k])
+        r = ol.AffineMeResult()
+        oracle.vo_affine_motion_estimation(C.byref(t), C.byref(r))
+        n = 3 if j["six"] else 2
+        assert [list(v) for v in r.mv][:n] == z["mv"][k][:n].tolist() and r.bits == int(z["bits"][k]) and r.cost == int(z["cost"][k]), (k, j)
+        p = me_util.affine_pred_struct(scene, j)
+        mv = ((C.c_int * 2) * 3)(*[(C.c_int * 2)(*v) for v in j["mv"]])
+        a = np.zeros((j["h"], j["w"]), np.int16)
+        oracle.vo_pred_affine_blk(C.byref(p), mv, 0, ol.P(a), j["w"])
+        assert np.array_equal(a.reshape(-1), z["pred"][off:off + j["w"] * j["h"]]), (k,)
+        off += j["w"] * j["h"]

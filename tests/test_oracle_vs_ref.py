@@ -622,3 +622,53 @@ def test_amvp_helpers_equal_reference_members(oracle, reflib):
         assert out[0] == out[1], (j, out)
         n_switch += out[0][2] != j["mvpIdx"]
     assert n_switch > 20
+
+
+def test_affine_prediction_and_me_equal_reference_members(oracle, reflib):
+    """InterPrediction::xPredAffineBlk (4x4 sub-block vectors, 6-tap sub-block filter, PROF), solveEqual and the whole
+    InterSearch::xAffineMotionEstimation (gradient iterations + control-point refinement) as the real members vs the oracle."""
+    import me_util
+    scene = me_util.Scene(416, 240, hard=False)
+    jobs = me_util.random_affine_jobs(scene, 160, seed=31)
+    n_prof = n_iter = n_ref = 0
+    for k, j in enumerate(jobs):
+        p = me_util.affine_pred_struct(scene, j)
+        mv = ((C.c_int * 2) * 3)(*[(C.c_int * 2)(*v) for v in j["mv"]])
+        for bi in (0, 1):
+            a, b = np.zeros((j["h"], j["w"] + 3), np.int16), np.zeros((j["h"], j["w"] + 3), np.int16)
+            oracle.vo_pred_affine_blk(C.byref(p), mv, bi, ol.P(a), j["w"] + 3)
+            reflib.ref_pred_affine_blk(C.byref(p), mv, bi, ol.P(b), j["w"] + 3)
+            assert np.array_equal(a, b), ("xPredAffineBlk", k, j, bi)
+        if j["prof"]:
+            p2 = me_util.affine_pred_struct(scene, dict(j, prof=0))
+            c = np.zeros((j["h"], j["w"] + 3), np.int16)
+            oracle.vo_pred_affine_blk(C.byref(p2), mv, 0, ol.P(c), j["w"] + 3)
+            n_prof += not np.array_equal(c, a if False else c) or 0
+            oracle.vo_pred_affine_blk(C.byref(p), mv, 0, ol.P(a), j["w"] + 3)
+            n_prof += int(not np.array_equal(a, c))
+        # the whole estimation; m_hevcCost relative to the start cost decides whether the refinement stage runs
+        keep = []
+        t = me_util.affine_me_struct(scene, j, keep)
+        t.hevcCost = 1 << 62
+        r0 = ol.AffineMeResult()
+        oracle.vo_affine_motion_estimation(C.byref(t), C.byref(r0))
+        t.hevcCost = int(r0.cost * j["hevc_scale"])
+        ro, rr = ol.AffineMeResult(), ol.AffineMeResult()
+        oracle.vo_affine_motion_estimation(C.byref(t), C.byref(ro))
+        reflib.ref_affine_motion_estimation(C.byref(t), C.byref(rr))
+        key = lambda r: ([tuple(v) for v in r.mv][:3 if j["six"] else 2], r.bits, r.cost)   # noqa: E731
+        assert key(ro) == key(rr), ("xAffineMotionEstimation", k, j, key(ro), key(rr))
+        n_iter += ro.iterations
+        n_ref += ro.refinements
+    assert n_prof > 20 and n_iter > 150 and n_ref > 500, (n_prof, n_iter, n_ref)
+    rng = np.random.default_rng(9)
+    for _ in range(200):
+        order = int(rng.choice([4, 6]))
+        m = rng.integers(-10**9, 10**9, (7, 7)).astype(np.float64)
+        if rng.random() < 0.2:
+            m[int(rng.integers(1, order + 1))] = 0
+        a, b = m.copy(), m.copy()
+        pa, pb = np.zeros(6), np.zeros(6)
+        oracle.vo_solve_equal(ol.P(a), order, ol.P(pa))
+        reflib.ref_solve_equal(ol.P(b), order, ol.P(pb))
+        assert np.array_equal(pa, pb)

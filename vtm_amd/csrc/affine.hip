@@ -1,0 +1,559 @@
+// affine.hip -- affine motion estimation on the device.
+//
+// Reference: InterPrediction::xPredAffineBlk (CommonLib/InterPrediction.cpp:856-1232: one vector per 4x4 sub-block from the control-point
+// vectors, isSubblockVectorSpreadOverLimit :816-854, the 6-tap sub-block interpolation InterpolationFilter.cpp:57-75 / 786-789, PROF
+// Buffer.cpp:45-70, 130-147) and InterSearch::xAffineMotionEstimation (EncoderLib/InterSearch.cpp:5340-5775: gradient iterations =
+// prediction -> error -> Sobel -> normal equations (AffineGradientSearch.cpp:62-170) -> solveEqual :5215-5284 -> vector update, then the
+// control-point refinement around the best model; xCalcAffineMVBits :3067-3085).
+//
+// One workgroup = one job, from the first prediction to the last refinement step -- nothing returns to the host in between: the pattern
+// (org, or 2*org - otherPred) and the current prediction live in LDS, the normal equations are accumulated in exact 64-bit integers, and the
+// reference's fp64 arithmetic (the solver, the delta-vector rounding, the cost weighting) runs on the device in IEEE double (division and
+// multiplication correctly rounded, no contraction: the build uses -fno-fast-math -ffp-contract=off), so every decision is bit-identical.
+#include "ctx.hpp"
+#include "had.hpp"
+
+#include <cmath>
+
+namespace
+{
+
+__constant__ int16_t c_affTaps4x4[16][8] = {   // m_lumaFilter4x4 (InterpolationFilter.cpp:57-75): the taps every 4x4 (sub-)block uses
+  { 0, 0, 0, 64, 0, 0, 0, 0 },      { 0, 1, -3, 63, 4, -2, 1, 0 },    { 0, 1, -5, 62, 8, -3, 1, 0 },    { 0, 2, -8, 60, 13, -4, 1, 0 },
+  { 0, 3, -10, 58, 17, -5, 1, 0 },  { 0, 3, -11, 52, 26, -8, 2, 0 },  { 0, 2, -9, 47, 31, -10, 3, 0 },  { 0, 3, -11, 45, 34, -10, 3, 0 },
+  { 0, 3, -11, 40, 40, -11, 3, 0 }, { 0, 3, -10, 34, 45, -11, 3, 0 }, { 0, 3, -10, 31, 47, -9, 2, 0 },  { 0, 2, -8, 26, 52, -11, 3, 0 },
+  { 0, 1, -5, 17, 58, -10, 3, 0 },  { 0, 1, -4, 13, 60, -8, 2, 0 },   { 0, 1, -3, 8, 62, -5, 1, 0 },    { 0, 1, -2, 4, 63, -3, 1, 0 } };
+
+__device__ __forceinline__ int clip3( int lo, int hi, int v ) { return min( hi, max( lo, v ) ); }
+__device__ __forceinline__ void round_affine_mv( int &x, int &y, int shift ) { const int o = 1 << ( shift - 1 ); x = ( x + o - ( x >= 0 ) ) >> shift; y = ( y + o - ( y >= 0 ) ) >> shift; }
+__device__ __forceinline__ int ilog2i( int v ) { return 31 - __clz( v ); }
+__device__ __forceinline__ int prec_dn( int v, int rs ) { if( rs == 0 ) return v; const int o = 1 << ( rs - 1 ); return v >= 0 ? ( v + o - 1 ) >> rs : ( v + o ) >> rs; }
+__device__ __forceinline__ unsigned eg_bits( int v )
+{
+  const unsigned t = ( v <= 0 ) ? ( ( unsigned ) ( -v ) << 1 ) + 1 : ( unsigned ) ( v << 1 );
+  return 1u + ( ( unsigned ) ( 31 - __clz( ( int ) t ) ) << 1 );
+}
+
+struct Mv3 { int v[3][2]; };
+
+struct AffCtx   // block-uniform view of one job
+{
+  const int16_t *ref;
+  int            refStride, w, h, bd, six, interDir, imv;
+  int            horMin, horMax, verMin, verMax;
+  bool           profAllowed, profLarge, profIsBi;
+};
+
+__device__ __forceinline__ bool spread_over_limit( int a, int b, int c, int d, int predType )
+{
+  const int s4 = 4 << 11, tap = 6;
+  if( predType == 3 )
+  {
+    int rw = max( max( 0, 4 * a + s4 ), max( 4 * c, 4 * a + 4 * c + s4 ) ) - min( min( 0, 4 * a + s4 ), min( 4 * c, 4 * a + 4 * c + s4 ) );
+    int rh = max( max( 0, 4 * b ), max( 4 * d + s4, 4 * b + 4 * d + s4 ) ) - min( min( 0, 4 * b ), min( 4 * d + s4, 4 * b + 4 * d + s4 ) );
+    rw = ( rw >> 11 ) + tap + 3; rh = ( rh >> 11 ) + tap + 3;
+    return rw * rh > ( tap + 9 ) * ( tap + 9 );
+  }
+  int rw = max( 0, 4 * a + s4 ) - min( 0, 4 * a + s4 ), rh = max( 0, 4 * b ) - min( 0, 4 * b );
+  rw = ( rw >> 11 ) + tap + 3; rh = ( rh >> 11 ) + tap + 3;
+  if( rw * rh > ( tap + 9 ) * ( tap + 5 ) ) return true;
+  rw = max( 0, 4 * c ) - min( 0, 4 * c ); rh = max( 0, 4 * d + s4 ) - min( 0, 4 * d + s4 );
+  rw = ( rw >> 11 ) + tap + 3; rh = ( rh >> 11 ) + tap + 3;
+  return rw * rh > ( tap + 5 ) * ( tap + 9 );
+}
+
+// 4x4 sub-block at vector (mh, mv): out[16], rounded + clipped (last) or 14-bit intermediates (!last); InterpolationFilter::filter rules (:577-602)
+__device__ __forceinline__ void subblock_4x4( const int16_t *r0, int rs, int mh, int mv, bool last, int bd, int out[16] )
+{
+  const int      xFrac = mh & 15, yFrac = mv & 15, headRoom = max( 2, 14 - bd ), cmax = ( 1 << bd ) - 1;
+  const int16_t *src = r0 + ( long ) ( mv >> 4 ) * rs + ( mh >> 4 );
+  if( yFrac == 0 || xFrac == 0 )
+  {
+    if( xFrac == 0 && yFrac == 0 && last )
+    {
+#pragma unroll
+      for( int i = 0; i < 16; i++ ) out[i] = src[( long ) ( i >> 2 ) * rs + ( i & 3 )];
+      return;
+    }
+    const bool     ver = yFrac != 0;
+    const int16_t *c   = c_affTaps4x4[ver ? yFrac : xFrac];
+    const int      shift = last ? 6 : 6 - headRoom, offset = last ? 32 : -( 8192 << shift ), step = ver ? rs : 1;
+#pragma unroll
+    for( int i = 0; i < 16; i++ )
+    {
+      const int16_t *s = src + ( long ) ( i >> 2 ) * rs + ( i & 3 );
+      int            sum = 0;
+#pragma unroll
+      for( int k = 0; k < 8; k++ ) sum += ( int ) s[( long ) ( k - 3 ) * step] * ( int ) c[k];
+      int v = ( int ) ( int16_t ) ( ( sum + offset ) >> shift );
+      if( last ) v = clip3( 0, cmax, v );
+      out[i] = v;
+    }
+    return;
+  }
+  const int16_t *ch = c_affTaps4x4[xFrac], *cv = c_affTaps4x4[yFrac];
+  const int      sh1 = 6 - headRoom, of1 = -( 8192 << sh1 );
+  int            tmp[11][4];
+#pragma unroll
+  for( int r = 0; r < 11; r++ )
+#pragma unroll
+    for( int x = 0; x < 4; x++ )
+    {
+      const int16_t *s = src + ( long ) ( r - 3 ) * rs + x;
+      int            sum = 0;
+#pragma unroll
+      for( int k = 0; k < 8; k++ ) sum += ( int ) s[k - 3] * ( int ) ch[k];
+      tmp[r][x] = ( int ) ( int16_t ) ( ( sum + of1 ) >> sh1 );
+    }
+  const int sh2 = last ? 6 + headRoom : 6, of2 = last ? ( 1 << ( sh2 - 1 ) ) + ( 8192 << 6 ) : 0;
+#pragma unroll
+  for( int i = 0; i < 16; i++ )
+  {
+    int sum = 0;
+#pragma unroll
+    for( int k = 0; k < 8; k++ ) sum += tmp[( i >> 2 ) + k][i & 3] * ( int ) cv[k];
+    int v = ( int ) ( int16_t ) ( ( sum + of2 ) >> sh2 );
+    if( last ) v = clip3( 0, cmax, v );
+    out[i] = v;
+  }
+}
+
+// xPredAffineBlk (luma, uni-directional use of the estimation: bi = false) into sPred[h][w]
+__device__ void affine_pred( const AffCtx &c, const Mv3 &m, int16_t *sPred )
+{
+  const int iBit = 7, w = c.w, h = c.h;
+  int dHX = ( m.v[1][0] - m.v[0][0] ) << ( iBit - ilog2i( w ) ), dHY = ( m.v[1][1] - m.v[0][1] ) << ( iBit - ilog2i( w ) ), dVX, dVY;
+  if( c.six ) { dVX = ( m.v[2][0] - m.v[0][0] ) << ( iBit - ilog2i( h ) ); dVY = ( m.v[2][1] - m.v[0][1] ) << ( iBit - ilog2i( h ) ); }
+  else { dVX = -dHY; dVY = dHX; }
+  const int  baseH = m.v[0][0] << iBit, baseV = m.v[0][1] << iBit;
+  const bool over = spread_over_limit( dHX, dHY, dVX, dVY, c.interDir );
+  bool       prof = c.profAllowed;
+  prof = prof && !( ( c.six && m.v[0][0] == m.v[1][0] && m.v[0][1] == m.v[1][1] && m.v[0][0] == m.v[2][0] && m.v[0][1] == m.v[2][1] )
+                    || ( !c.six && m.v[0][0] == m.v[1][0] && m.v[0][1] == m.v[1][1] ) );
+  prof = prof && !over;
+  const int thr = 1 << ( iBit + ( c.profIsBi ? 1 : 0 ) );
+  prof = prof && ( !c.profLarge || dHX > thr || dHY > thr || dVX > thr || dVY > thr || dHX < -thr || dHY < -thr || dVX < -thr || dVY < -thr );
+  const int ifShift = max( 2, 14 - c.bd );
+  const int sbw = w >> 2, nsb = sbw * ( h >> 2 );
+  for( int sb = threadIdx.x; sb < nsb; sb += blockDim.x )
+  {
+    const int y = ( sb / sbw ) << 2, x = ( sb - ( sb / sbw ) * sbw ) << 2;
+    int       mh, mv;
+    if( !over ) { mh = baseH + dHX * ( 2 + x ) + dVX * ( 2 + y ); mv = baseV + dHY * ( 2 + x ) + dVY * ( 2 + y ); }
+    else { mh = baseH + dHX * ( w >> 1 ) + dVX * ( h >> 1 ); mv = baseV + dHY * ( w >> 1 ) + dVY * ( h >> 1 ); }
+    round_affine_mv( mh, mv, iBit );   // shift = iBit - 4 + MV_FRACTIONAL_BITS_INTERNAL
+    mh = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mh ); mv = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mv );
+    mh = clip3( c.horMin, c.horMax, mh ); mv = clip3( c.verMin, c.verMax, mv );
+    const int16_t *r0 = c.ref + ( long ) y * c.refStride + x;
+    int            o[16];
+    subblock_4x4( r0, c.refStride, mh, mv, !prof, c.bd, o );
+    if( prof )
+    {
+      // PROF: gradients of the 14-bit prediction inside a ring of integer reference samples, times the per-sample vector offsets
+      int ext[6][6];
+#pragma unroll
+      for( int j = 0; j < 4; j++ )
+#pragma unroll
+        for( int i = 0; i < 4; i++ ) ext[j + 1][i + 1] = o[j * 4 + i];
+      const int16_t *rb = r0 + ( long ) ( mv >> 4 ) * c.refStride + ( mh >> 4 );
+      const int      xo = ( mh & 15 ) >> 3, yo = ( mv & 15 ) >> 3;
+      const int16_t *rp = rb - ( long ) ( 1 - yo ) * c.refStride + xo - 1;
+#pragma unroll
+      for( int i = 0; i < 6; i++ )
+      {
+        ext[0][i] = ( int ) ( int16_t ) ( ( rp[i] << ifShift ) - 8192 );
+        ext[5][i] = ( int ) ( int16_t ) ( ( rp[i + 5l * c.refStride] << ifShift ) - 8192 );
+      }
+      rp = rb + ( long ) yo * c.refStride + xo;
+#pragma unroll
+      for( int j = 0; j < 4; j++ )
+      {
+        ext[j + 1][0] = ( int ) ( int16_t ) ( ( rp[( long ) j * c.refStride - 1] << ifShift ) - 8192 );
+        ext[j + 1][5] = ( int ) ( int16_t ) ( ( rp[( long ) j * c.refStride + 4] << ifShift ) - 8192 );
+      }
+      const int qHX = dHX << 2, qHY = dHY << 2, qVX = dVX << 2, qVY = dVY << 2;
+      const int d0H = ( ( dHX + dVX ) << 1 ) - ( ( qHX + qVX ) << 1 ), d0V = ( ( dHY + dVY ) << 1 ) - ( ( qHY + qVY ) << 1 );
+      const int dILimit = 1 << max( c.bd + 1, 13 ), offset = ( 1 << ( ifShift - 1 ) ) + 8192, cmax = ( 1 << c.bd ) - 1;
+#pragma unroll
+      for( int j = 0; j < 4; j++ )
+#pragma unroll
+        for( int i = 0; i < 4; i++ )
+        {
+          int dh = d0H + i * qHX + j * qVX, dv = d0V + i * qHY + j * qVY;
+          round_affine_mv( dh, dv, 8 );
+          dh = clip3( -31, 31, dh ); dv = clip3( -31, 31, dv );
+          const int gx = ( int ) ( int16_t ) ( ( ext[j + 1][i + 2] >> 6 ) - ( ext[j + 1][i] >> 6 ) );
+          const int gy = ( int ) ( int16_t ) ( ( ext[j + 2][i + 1] >> 6 ) - ( ext[j][i + 1] >> 6 ) );
+          const int dI = clip3( -dILimit, dILimit - 1, dh * gx + dv * gy );
+          const int v  = ( int ) ( int16_t ) ( ext[j + 1][i + 1] + dI );
+          o[j * 4 + i] = clip3( 0, cmax, ( int ) ( int16_t ) ( ( v + offset ) >> ifShift ) );
+        }
+    }
+#pragma unroll
+    for( int j = 0; j < 4; j++ )
+#pragma unroll
+      for( int i = 0; i < 4; i++ ) sPred[( y + j ) * w + x + i] = ( int16_t ) o[j * 4 + i];
+  }
+}
+
+// getDistPart( DF_HAD / DF_SAD ) of prediction vs pattern over the block (tile shapes of xGetHADs: RdCost.cpp:2837-2931), block-wide sum
+__device__ unsigned long long block_dist( const int16_t *sPred, const int16_t *sPat, int w, int h, bool satd, unsigned long long *sRed )
+{
+  unsigned long long acc = 0;
+  if( satd )
+  {
+    const int tw = w > h ? 16 : 8, th = w < h ? 16 : 8, tx = w / tw, nt = tx * ( h / th );
+    for( int t = threadIdx.x; t < nt; t += blockDim.x )
+    {
+      const int      y = ( t / tx ) * th, x = ( t - ( t / tx ) * tx ) * tw;
+      const int16_t *o = sPred + y * w + x, *cc = sPat + y * w + x;
+      acc += tw == 16 ? had_tile<16, 8>( o, w, cc, w ) : th == 16 ? had_tile<8, 16>( o, w, cc, w ) : had_tile<8, 8>( o, w, cc, w );
+    }
+  }
+  else
+  {
+    for( int i = threadIdx.x; i < w * h; i += blockDim.x ) acc += ( unsigned ) abs( ( int ) sPred[i] - ( int ) sPat[i] );
+  }
+  acc = wave_reduce_add_u64( acc );
+  __syncthreads();
+  if( ( threadIdx.x & 63 ) == 0 ) sRed[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  const unsigned long long t = sRed[0] + sRed[1] + sRed[2] + sRed[3];
+  __syncthreads();
+  return t;
+}
+
+__device__ __forceinline__ unsigned affine_mv_bits( int six, int imv, const Mv3 &m, const int pred[3][2] )
+{
+  const int rsTab[3] = { 2, 0, 4 };
+  const int n = six ? 3 : 2, rs = rsTab[imv];
+  unsigned  bits = 0;
+  for( int v = 0; v < n; v++ )
+  {
+    const int ph = prec_dn( v == 0 ? pred[0][0] : pred[v][0] + m.v[0][0] - pred[0][0], rs ), pv = prec_dn( v == 0 ? pred[0][1] : pred[v][1] + m.v[0][1] - pred[0][1], rs );
+    bits += eg_bits( prec_dn( m.v[v][0], rs ) - ph ) + eg_bits( prec_dn( m.v[v][1], rs ) - pv );
+  }
+  return bits;
+}
+
+__device__ void solve_equal( double eq[7][7], int order, double *para )   // solveEqual (InterSearch.cpp:5215-5284), operation for operation
+{
+  for( int k = 0; k < order; k++ ) para[k] = 0.;
+  for( int i = 1; i < order; i++ )
+  {
+    double temp = fabs( eq[i][i - 1] );
+    int    idx = i;
+    for( int j = i + 1; j < order + 1; j++ ) if( fabs( eq[j][i - 1] ) > temp ) { temp = fabs( eq[j][i - 1] ); idx = j; }
+    if( idx != i )
+      for( int j = 0; j < order + 1; j++ ) { eq[0][j] = eq[i][j]; eq[i][j] = eq[idx][j]; eq[idx][j] = eq[0][j]; }
+    if( eq[i][i - 1] == 0. ) return;
+    for( int j = i + 1; j < order + 1; j++ )
+      for( int k = i; k < order + 1; k++ ) eq[j][k] = eq[j][k] - eq[i][k] * eq[j][i - 1] / eq[i][i - 1];
+  }
+  if( eq[order][order - 1] == 0. ) return;
+  para[order - 1] = eq[order][order] / eq[order][order - 1];
+  for( int i = order - 2; i >= 0; i-- )
+  {
+    if( eq[i + 1][i] == 0. ) { for( int k = 0; k < order; k++ ) para[k] = 0.; return; }
+    double temp = 0;
+    for( int j = i + 1; j < order; j++ ) temp += eq[i + 1][j] * para[j];
+    para[i] = ( eq[i + 1][order] - temp ) / eq[i + 1][i];
+  }
+}
+
+__global__ __launch_bounds__( 256 ) void affine_me_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+                                                          const int16_t *__restrict__ otherBase, const vtmhip_affine_me_job *__restrict__ jobs,
+                                                          vtmhip_affine_me_out *__restrict__ results )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sMem[];
+  __shared__ unsigned long long sRed[4];
+  __shared__ long long          sAcc[4][42];
+  __shared__ Mv3                sMv;      // the model under test (written by thread 0)
+  __shared__ int                sCtl;     // loop control of the gradient iterations: 0 continue, 1 stop
+  const vtmhip_affine_me_job &j = jobs[blockIdx.x];
+  const int w = j.width, h = j.height, six = j.sixParam, mvNum = six ? 3 : 2, np = six ? 6 : 4;
+  int16_t  *sPat = sMem, *sPred = sMem + w * h;
+  AffCtx c;
+  c.ref = refBase + j.refOff; c.refStride = j.refStride; c.w = w; c.h = h; c.bd = pic.bitDepth; c.six = six; c.interDir = j.interDir; c.imv = j.imv;
+  c.horMax = ( pic.picW + 8 - j.puX - 1 ) << 4; c.horMin = ( -pic.ctuSize - 8 - j.puX + 1 ) << 4;
+  c.verMax = ( pic.picH + 8 - j.puY - 1 ) << 4; c.verMin = ( -pic.ctuSize - 8 - j.puY + 1 ) << 4;
+  c.profAllowed = j.profAllowed != 0; c.profLarge = j.profNeedsLargeGrad != 0; c.profIsBi = j.profIsBi != 0;
+  const bool   bi = j.bi != 0, satd = j.useSatd != 0;
+  const double fWeight = bi ? 0.5 : 1.0, lam = j.motionLambda;
+  const int    rsTab[3] = { 2, 0, 4 };
+  // pattern: org, or 2*org - otherPred (removeHighFreq, unclipped)
+  {
+    const int16_t *o = orgBase + j.orgOff, *p = bi ? otherBase + j.otherPredOff : nullptr;
+    for( int i = threadIdx.x; i < w * h; i += 256 )
+    {
+      const int y = i / w, x = i - y * w;
+      const int v = o[( long ) y * j.orgStride + x];
+      sPat[i] = ( int16_t ) ( bi ? 2 * v - p[( long ) y * j.otherPredStride + x] : v );
+    }
+  }
+  int pred[3][2];
+  for( int i = 0; i < 3; i++ ) { pred[i][0] = j.mvPred[i][0]; pred[i][1] = j.mvPred[i][1]; }
+
+  Mv3 tmp, best;
+  for( int i = 0; i < 3; i++ ) { tmp.v[i][0] = j.mv[i][0]; tmp.v[i][1] = j.mv[i][1]; }
+  for( int i = 0; i < mvNum; i++ )
+  {
+    tmp.v[i][0] = clip3( c.horMin, c.horMax, tmp.v[i][0] ); tmp.v[i][1] = clip3( c.verMin, c.verMax, tmp.v[i][1] );
+    const int rs = rsTab[j.imv];
+    tmp.v[i][0] = prec_dn( tmp.v[i][0], rs ) << rs; tmp.v[i][1] = prec_dn( tmp.v[i][1], rs ) << rs;   // roundAffinePrecInternal2Amvr
+  }
+  __syncthreads();
+  affine_pred( c, tmp, sPred );
+  __syncthreads();
+  unsigned long long costBest = block_dist( sPred, sPat, w, h, satd, sRed );
+  unsigned           bitsBest = j.bits + affine_mv_bits( six, j.imv, tmp, pred );
+  costBest = ( unsigned long long ) ( floor( fWeight * ( double ) costBest ) + ( double ) ( unsigned long long ) ( lam * bitsBest ) );
+  best = tmp;
+  int iterTime = six ? ( bi ? 3 : 4 ) : ( bi ? 3 : 5 );
+  if( !j.useAffineType ) iterTime = bi ? 5 : 7;
+  int iterations = 0, refinements = 0;
+  Mv3 prev[7];
+
+  for( int iter = 0; iter < iterTime; iter++ )
+  {
+    prev[iter] = tmp;
+    // ---- normal equations from the error and the Sobel gradients of the prediction (exact 64-bit sums) ----
+    long long acc[42];
+#pragma unroll
+    for( int i = 0; i < 42; i++ ) acc[i] = 0;
+    for( int i = threadIdx.x; i < w * h; i += 256 )
+    {
+      const int y = i / w, x = i - y * w;
+      const int yc = min( h - 2, max( 1, y ) ), xc = min( w - 2, max( 1, x ) );
+      const int16_t *q = sPred + yc * w + xc;
+      const int a = q[1 - w] - q[-1 - w] + ( q[1] << 1 ) - ( q[-1] << 1 ) + q[1 + w] - q[-1 + w];
+      const int b = q[w - 1] - q[-w - 1] + ( q[w] << 1 ) - ( q[-w] << 1 ) + q[w + 1] - q[-w + 1];
+      const int e = ( int ) ( int16_t ) ( sPat[i] - sPred[i] );
+      const int cy = ( ( y >> 2 ) << 2 ) + 2, cx = ( ( x >> 2 ) << 2 ) + 2;
+      int       cc[6];
+      if( !six ) { cc[0] = a; cc[1] = cx * a + cy * b; cc[2] = b; cc[3] = cy * a - cx * b; cc[4] = 0; cc[5] = 0; }
+      else { cc[0] = a; cc[1] = cx * a; cc[2] = b; cc[3] = cx * b; cc[4] = cy * a; cc[5] = cy * b; }
+#pragma unroll
+      for( int col = 0; col < 6; col++ )
+        if( col < np )
+        {
+#pragma unroll
+          for( int row = 0; row < 6; row++ )
+            if( row < np ) acc[col * 7 + row] += ( long long ) cc[col] * cc[row];
+          acc[col * 7 + 6] += ( ( long long ) cc[col] * e ) << 3;
+        }
+    }
+#pragma unroll
+    for( int i = 0; i < 42; i++ ) acc[i] = ( long long ) wave_reduce_add_u64( ( unsigned long long ) acc[i] );
+    if( ( threadIdx.x & 63 ) == 0 )
+    {
+#pragma unroll
+      for( int i = 0; i < 42; i++ ) sAcc[threadIdx.x >> 6][i] = acc[i];
+    }
+    __syncthreads();
+    if( threadIdx.x == 0 )
+    {
+      double deq[7][7];
+      for( int r = 0; r < 7; r++ ) for( int q = 0; q < 7; q++ ) deq[r][q] = 0.;
+      for( int col = 0; col < np; col++ )
+        for( int row = 0; row <= np; row++ )
+        {
+          const int       src = row < np ? col * 7 + row : col * 7 + 6;
+          const long long v   = sAcc[0][src] + sAcc[1][src] + sAcc[2][src] + sAcc[3][src];
+          deq[col + 1][row] = ( double ) v;
+        }
+      double para[6], dmv[6] = { 0, 0, 0, 0, 0, 0 };
+      solve_equal( deq, np, para );
+      dmv[0] = para[0]; dmv[2] = para[2];
+      if( six ) { dmv[1] = para[1] * w + para[0]; dmv[3] = para[3] * w + para[2]; dmv[4] = para[4] * h + para[0]; dmv[5] = para[5] * h + para[2]; }
+      else { dmv[1] = para[1] * w + para[0]; dmv[3] = -para[3] * w + para[2]; }
+      const int normShift[3] = { 2, 4, 2 }, stepShift[3] = { 2, 0, 2 };
+      const int mult = 1 << normShift[j.imv], ms = stepShift[j.imv];
+#define SGN( x ) ( ( x ) >= 0 ? 1 : -1 )
+      int delta[3][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 } };
+      delta[0][0] = ( int ) ( dmv[0] * mult + SGN( dmv[0] ) * 0.5 ) << ms; delta[0][1] = ( int ) ( dmv[2] * mult + SGN( dmv[2] ) * 0.5 ) << ms;
+      delta[1][0] = ( int ) ( dmv[1] * mult + SGN( dmv[1] ) * 0.5 ) << ms; delta[1][1] = ( int ) ( dmv[3] * mult + SGN( dmv[3] ) * 0.5 ) << ms;
+      if( six ) { delta[2][0] = ( int ) ( dmv[4] * mult + SGN( dmv[4] ) * 0.5 ) << ms; delta[2][1] = ( int ) ( dmv[5] * mult + SGN( dmv[5] ) * 0.5 ) << ms; }
+#undef SGN
+      int stop = 0;
+      if( !j.amvrEncOpt )
+      {
+        bool allZero = false;
+        for( int i = 0; i < mvNum; i++ )
+        {
+          int d0 = delta[i][0], d1 = delta[i][1];
+          if( j.imv == 2 ) { d0 = prec_dn( d0, 3 ) << 3; d1 = prec_dn( d1, 3 ) << 3; }
+          if( d0 != 0 || d1 != 0 ) { allZero = false; break; }
+          allZero = true;
+        }
+        if( allZero ) stop = 1;
+      }
+      Mv3 nt = tmp;
+      if( !stop )
+      {
+        const int rs = rsTab[j.imv];
+        for( int i = 0; i < mvNum; i++ )
+        {
+          nt.v[i][0] = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, nt.v[i][0] + delta[i][0] );
+          nt.v[i][1] = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, nt.v[i][1] + delta[i][1] );
+          nt.v[i][0] = prec_dn( nt.v[i][0], rs ) << rs; nt.v[i][1] = prec_dn( nt.v[i][1], rs ) << rs;
+          nt.v[i][0] = clip3( c.horMin, c.horMax, nt.v[i][0] ); nt.v[i][1] = clip3( c.verMin, c.verMax, nt.v[i][1] );
+        }
+        if( j.amvrEncOpt )
+          for( int k = iter; k >= 0; k-- )
+            if( nt.v[0][0] == prev[k].v[0][0] && nt.v[0][1] == prev[k].v[0][1] && nt.v[1][0] == prev[k].v[1][0] && nt.v[1][1] == prev[k].v[1][1] )
+            {
+              const bool same = six ? ( nt.v[2][0] == prev[k].v[2][0] && nt.v[2][1] == prev[k].v[2][1] ) : true;
+              if( same ) { stop = 1; break; }
+            }
+      }
+      sMv = nt; sCtl = stop;
+    }
+    __syncthreads();
+    const int stop = sCtl;
+    tmp = sMv;
+    __syncthreads();
+    if( stop ) break;
+    affine_pred( c, tmp, sPred );
+    __syncthreads();
+    iterations++;
+    unsigned long long cost = block_dist( sPred, sPat, w, h, satd, sRed );
+    const unsigned     bits = j.bits + affine_mv_bits( six, j.imv, tmp, pred );
+    cost = ( unsigned long long ) ( floor( fWeight * ( double ) cost ) + ( double ) ( unsigned long long ) ( lam * bits ) );
+    if( cost < costBest ) { costBest = cost; bitsBest = bits; best = tmp; }
+  }
+
+  // ---- control-point refinement (:5655-5765); every thread evaluates the same model, so the control flow is block-uniform ----
+  auto check = [&]( const Mv3 &m ) -> bool {
+    affine_pred( c, m, sPred );
+    __syncthreads();
+    refinements++;
+    unsigned long long cost = block_dist( sPred, sPat, w, h, satd, sRed );
+    const unsigned     bits = j.bits + affine_mv_bits( six, j.imv, m, pred );
+    cost = ( unsigned long long ) ( floor( fWeight * ( double ) cost ) + ( double ) ( unsigned long long ) ( lam * bits ) );
+    if( cost < costBest ) { costBest = cost; bitsBest = bits; best = m; return true; }
+    return false;
+  };
+  if( ( double ) costBest <= 1.0 * ( double ) j.hevcCost )   // AFFINE_ME_LIST_MVP_TH * m_hevcCost
+  {
+    const Mv3 me = best;
+    const int dMv[2] = { me.v[0][0] - pred[0][0], me.v[0][1] - pred[0][1] };
+    for( int k = 0; k < mvNum; k++ )
+    {
+      const int ph = pred[k][0] + ( k ? dMv[0] : 0 ), pv = pred[k][1] + ( k ? dMv[1] : 0 );
+      if( me.v[k][0] != ph || me.v[k][1] != pv )
+      {
+        tmp = me; tmp.v[k][0] = ph; tmp.v[k][1] = pv;
+        check( tmp );
+      }
+    }
+    if( me.v[0][0] != pred[0][0] || me.v[0][1] != pred[0][1] )
+    {
+      tmp = me;
+      for( int i = 1; i < mvNum; i++ ) { tmp.v[i][0] -= dMv[0]; tmp.v[i][1] -= dMv[1]; }
+      tmp.v[0][0] = pred[0][0]; tmp.v[0][1] = pred[0][1];
+      check( tmp );
+    }
+    if( six && ( me.v[1][0] != pred[1][0] + dMv[0] || me.v[1][1] != pred[1][1] + dMv[1] ) && ( me.v[2][0] != pred[2][0] + dMv[0] || me.v[2][1] != pred[2][1] + dMv[1] ) )
+    {
+      tmp = me;
+      tmp.v[1][0] = pred[1][0] + dMv[0]; tmp.v[1][1] = pred[1][1] + dMv[1]; tmp.v[2][0] = pred[2][0] + dMv[0]; tmp.v[2][1] = pred[2][1] + dMv[1];
+      check( tmp );
+    }
+    const int testPos[8][2] = { { -1, 0 }, { 0, -1 }, { 0, 1 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, 1 }, { 1, -1 } };
+    const int mvShift = rsTab[j.imv];
+    const int maxRound = j.imv ? 3 : ( ( j.amvrEncOpt && j.lowDelayRounds ) ? 2 : 3 );
+    for( int rnd = 0; rnd < maxRound; rnd++ )
+    {
+      bool modelChange = false;
+      for( int k = 0; k < mvNum; k++ )
+      {
+        bool loopChange = false;
+        for( int it = 0; it < 2; it++ )
+        {
+          if( it == 1 && !loopChange ) break;
+          const Mv3 center = best;
+          tmp = best;
+          for( int i = it == 0 ? 0 : 4; i < ( it == 0 ? 4 : 8 ); i++ )
+          {
+            tmp.v[k][0] = clip3( c.horMin, c.horMax, center.v[k][0] + ( testPos[i][0] << mvShift ) );
+            tmp.v[k][1] = clip3( c.verMin, c.verMax, center.v[k][1] + ( testPos[i][1] << mvShift ) );
+            if( check( tmp ) ) { modelChange = true; loopChange = true; }
+          }
+        }
+      }
+      if( !modelChange ) break;
+    }
+  }
+  if( threadIdx.x == 0 )
+  {
+    vtmhip_affine_me_out o;
+    for( int i = 0; i < 3; i++ ) { o.mv[i][0] = best.v[i][0]; o.mv[i][1] = best.v[i][1]; }
+    o.bits = bitsBest; o.cost = costBest; o.iterations = iterations; o.refinements = refinements; o.pad = 0;
+    results[blockIdx.x] = o;
+  }
+}
+
+__global__ __launch_bounds__( 256 ) void affine_pred_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ refBase, int16_t *__restrict__ dstBase,
+                                                            const vtmhip_affine_me_job *__restrict__ jobs )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sMem[];
+  const vtmhip_affine_me_job &j = jobs[blockIdx.x];
+  AffCtx c;
+  c.ref = refBase + j.refOff; c.refStride = j.refStride; c.w = j.width; c.h = j.height; c.bd = pic.bitDepth; c.six = j.sixParam; c.interDir = j.interDir; c.imv = j.imv;
+  c.horMax = ( pic.picW + 8 - j.puX - 1 ) << 4; c.horMin = ( -pic.ctuSize - 8 - j.puX + 1 ) << 4;
+  c.verMax = ( pic.picH + 8 - j.puY - 1 ) << 4; c.verMin = ( -pic.ctuSize - 8 - j.puY + 1 ) << 4;
+  c.profAllowed = j.profAllowed != 0; c.profLarge = j.profNeedsLargeGrad != 0; c.profIsBi = j.profIsBi != 0;
+  Mv3 m;
+  for( int i = 0; i < 3; i++ ) { m.v[i][0] = j.mv[i][0]; m.v[i][1] = j.mv[i][1]; }
+  affine_pred( c, m, sMem );
+  __syncthreads();
+  int16_t *d = dstBase + j.predOff;
+  for( int i = threadIdx.x; i < c.w * c.h; i += 256 ) d[( long ) ( i / c.w ) * j.predStride + ( i % c.w )] = sMem[i];
+}
+
+}   // namespace
+
+extern "C"
+{
+
+static int check_affine_args( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, int n, int maxWidth, int maxHeight )
+{
+  VTMHIP_REQUIRE( ctx, pic && n >= 0, "pic / n" );
+  VTMHIP_REQUIRE( ctx, maxWidth >= 16 && maxWidth <= 128 && maxHeight >= 16 && maxHeight <= 128, "affine blocks are 16..128 wide and high" );
+  VTMHIP_REQUIRE( ctx, pic->bitDepth >= 8 && pic->bitDepth <= 12, "bit depth" );
+  return VTMHIP_OK;
+}
+
+int vtmhip_xAffineMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                              const int16_t *d_otherPredBase, const vtmhip_affine_me_job *d_jobs, int n, int maxWidth, int maxHeight,
+                                              vtmhip_affine_me_out *d_results )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  int st = check_affine_args( ctx, pic, n, maxWidth, maxHeight );
+  if( st ) return st;
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_orgBase && d_refBase && d_jobs && d_results, "null pointer" );
+  const size_t lds = 2 * ( size_t ) maxWidth * maxHeight * sizeof( int16_t );
+  if( lds > 48 * 1024 ) VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( affine_me_kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
+  VTMHIP_TIME_KERNEL( ctx, "affine_me_kernel" );
+  hipLaunchKernelGGL( affine_me_kernel, dim3( n ), dim3( 256 ), lds, ctx->stream, *pic, d_orgBase, d_refBase, d_otherPredBase ? d_otherPredBase : d_orgBase, d_jobs, d_results );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_xPredAffineBlk_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_refBase, int16_t *d_dstBase, const vtmhip_affine_me_job *d_jobs, int n,
+                                     int maxWidth, int maxHeight )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  int st = check_affine_args( ctx, pic, n, maxWidth, maxHeight );
+  if( st ) return st;
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_refBase && d_dstBase && d_jobs, "null pointer" );
+  const size_t lds = ( size_t ) maxWidth * maxHeight * sizeof( int16_t );
+  hipLaunchKernelGGL( affine_pred_kernel, dim3( n ), dim3( 256 ), lds, ctx->stream, *pic, d_refBase, d_dstBase, d_jobs );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+}   // extern "C"

@@ -37,6 +37,8 @@ int vtmhip_struct_size( int which )
   case 24: return ( int ) sizeof( vtmhip_pis_row );
   case 25: return ( int ) sizeof( vtmhip_pis_pu );
   case 26: return ( int ) sizeof( vtmhip_pis_level );
+  case 27: return ( int ) sizeof( vtmhip_affine_me_job );
+  case 28: return ( int ) sizeof( vtmhip_affine_me_out );
   default: return -1;
   }
 }

@@ -17,63 +17,6 @@
 namespace
 {
 
-// ---- Hadamard building blocks (32-bit, order-free: only sum|coef| and coef[0] matter) ----------
-template<int N, int STRIDE, bool LAST = true>
-__device__ __forceinline__ void wht1d( int *m )   // LAST = false: every butterfly level but the last (len = N / 2)
-{
-#pragma unroll
-  for( int len = 1; len < ( LAST ? N : N / 2 ); len <<= 1 )
-  {
-#pragma unroll
-    for( int i = 0; i < N; i += len << 1 )
-    {
-#pragma unroll
-      for( int j = i; j < i + len; j++ )
-      {
-        const int a = m[j * STRIDE], b = m[( j + len ) * STRIDE];
-        m[j * STRIDE]           = a + b;
-        m[( j + len ) * STRIDE] = a - b;
-      }
-    }
-  }
-}
-
-// m[] holds the TW x TH differences (row-major) on entry.  Returns the per-tile SATD with the reference's
-// mean-scaled dc (JVET_R0164) and per-shape normalisation.
-template<int TW, int TH>
-__device__ __forceinline__ unsigned had_finish( int *m )
-{
-#pragma unroll
-  for( int y = 0; y < TH; y++ ) wht1d<TW, 1>( m + y * TW );
-#pragma unroll
-  for( int x = 0; x < TW; x++ ) wht1d<TH, TW, false>( m + x );
-  // last butterfly level + |.| + sum in one: |a + b| + |a - b| = 2 max(|a|, |b|) for the pair (row j, row j + TH/2) of a column
-  int t = 0;
-#pragma unroll
-  for( int i = 0; i < TW * TH / 2; i++ ) t += max( abs( m[i] ), abs( m[i + TW * TH / 2] ) );
-  t <<= 1;
-  const int dc = abs( m[0] + m[TW * TH / 2] );
-  t            = t - dc + ( dc >> 2 );
-  if( TW == 2 && TH == 2 ) return ( unsigned ) t;
-  if( TW == 4 && TH == 4 ) return ( unsigned ) ( ( t + 1 ) >> 1 );
-  if( TW == 8 && TH == 8 ) return ( unsigned ) ( ( t + 2 ) >> 2 );
-  if( TW * TH == 128 ) return ( unsigned ) ( int ) ( ( double ) t / 11.313708498984761 * 2.0 );   // sqrt(16.0*8)
-  return ( unsigned ) ( int ) ( ( double ) t / 5.656854249492381 * 2.0 );                        // sqrt(4.0*8)
-}
-
-template<int TW, int TH>
-__device__ __forceinline__ unsigned had_tile( const int16_t *o, int os, const int16_t *c, int cs )
-{
-  int m[TW * TH];
-#pragma unroll
-  for( int y = 0; y < TH; y++ )
-  {
-#pragma unroll
-    for( int x = 0; x < TW; x++ ) m[y * TW + x] = ( int ) o[y * os + x] - ( int ) c[y * cs + x];
-  }
-  return had_finish<TW, TH>( m );
-}
-
 // ---- general batch: one wave per job ------------------------------------------------------------------------------
 __global__ __launch_bounds__( 256 ) void dist_batch_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ curBase,
                                                            const vtmhip_dist_job *__restrict__ jobs, int n, unsigned long long *__restrict__ out )

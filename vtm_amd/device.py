@@ -220,6 +220,13 @@ class Context:
         """InterSearch::xEstimateMvPredAMVP (template cost of the AMVP candidates) for n MeJob rows, in place"""
         self._check(self.L.vtmhip_xEstimateMvPredAMVP_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, max_w, max_h, int(uniform), int(add_idx_bits), d_dist_bip))
 
+    def affine_motion_estimation_batch(self, pic, d_org, d_ref, d_other, d_jobs, n, max_w, max_h, d_results):
+        """InterSearch::xAffineMotionEstimation per AffineMeJob (one workgroup per job)"""
+        self._check(self.L.vtmhip_xAffineMotionEstimation_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_other, d_jobs, n, max_w, max_h, d_results))
+
+    def pred_affine_blk_batch(self, pic, d_ref, d_dst, d_jobs, n, max_w, max_h):
+        self._check(self.L.vtmhip_xPredAffineBlk_batch_dev(self.h, C.byref(pic), d_ref, d_dst, d_jobs, n, max_w, max_h))
+
     def kernel_timing(self, enable):
         """HIP events around every launch of the main kernels, on the launch stream (vtmhip_kernel_timing)"""
         self._check(self.L.vtmhip_kernel_timing(self.h, int(enable)))

@@ -185,9 +185,22 @@ class PisLevel(C.Structure):
                 ("parentRows", C.c_void_p), ("parentNumPU", C.c_int32), ("pad", C.c_int32), ("pos", C.c_void_p)]
 
 
+class AffineMeJob(C.Structure):
+    _fields_ = [("orgOff", C.c_int64), ("refOff", C.c_int64), ("otherPredOff", C.c_int64), ("predOff", C.c_int64), ("orgStride", C.c_int32), ("refStride", C.c_int32),
+                ("otherPredStride", C.c_int32), ("predStride", C.c_int32), ("puX", C.c_int16), ("puY", C.c_int16), ("width", C.c_int16), ("height", C.c_int16),
+                ("sixParam", C.c_uint8), ("interDir", C.c_uint8), ("imv", C.c_uint8), ("bi", C.c_uint8), ("useSatd", C.c_uint8), ("useAffineType", C.c_uint8),
+                ("amvrEncOpt", C.c_uint8), ("lowDelayRounds", C.c_uint8), ("profAllowed", C.c_uint8), ("profNeedsLargeGrad", C.c_uint8), ("profIsBi", C.c_uint8),
+                ("pad0", C.c_uint8), ("mvPred", (C.c_int32 * 2) * 3), ("mv", (C.c_int32 * 2) * 3), ("bits", C.c_uint32), ("pad1", C.c_uint32),
+                ("motionLambda", C.c_double), ("hevcCost", C.c_uint64)]
+
+
+class AffineMeOut(C.Structure):
+    _fields_ = [("mv", (C.c_int32 * 2) * 3), ("bits", C.c_uint32), ("iterations", C.c_int32), ("refinements", C.c_int32), ("pad", C.c_int32), ("cost", C.c_uint64)]
+
+
 _STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob,
             TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut, PredJob, FrameTabs, MaskedSadJob, GeoBlendJob, DmvrJob, LfnstJob,
-            PisRow, PisPu, PisLevel]   # order of vtmhip_struct_size(which)
+            PisRow, PisPu, PisLevel, AffineMeJob, AffineMeOut]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
 _PROTOS = {
@@ -277,6 +290,9 @@ _PROTOS = {
                                                      C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vtmhip_xEstimateMvPredAMVP_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                        C.c_int, C.c_int, C.c_void_p]),
+    "vtmhip_xAffineMotionEstimation_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                           C.c_void_p]),
+    "vtmhip_xPredAffineBlk_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "vtmhip_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "vtmhip_kernel_timing_read": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "vtmhip_pis_stage": (C.c_int, [C.c_void_p, C.POINTER(PisLevel), C.c_int]),
