@@ -51,6 +51,7 @@ struct RefEncStats
   //                                       [1]: TrQuant::transformNxN( trModes ) = all MTS candidates' forward transforms + the pre-selection (hook B8)
   uint64_t hookCalls[2], hookDevice[2], hookMismatch[2], hookUnsupported[2];
   int32_t  hookFirstMismatch[8];
+  uint64_t affineCalls, affineDevice, affineMismatch, affineUnsupported;   // InterSearch::xAffineMotionEstimation as one vtmhip_xAffineMotionEstimation_batch_dev call
 };
 }
 
@@ -84,6 +85,7 @@ struct Api
   decltype( &vtmhip_xT_batch_dev )                 xT;
   decltype( &vtmhip_tu_ts_chain_batch_dev )        tsChain;
   decltype( &vtmhip_mts_select2 )                  mtsSelect;
+  decltype( &vtmhip_xAffineMotionEstimation_batch_dev ) affineMe;
 } A;
 
 vtmhip_ctx  *g_ctx = nullptr;
@@ -420,10 +422,12 @@ void restoreAux()
 // just run the reference's code.
 }   // namespace
 extern "C" void vtmref_orig_xMotionEstimation( InterSearch *, PredictionUnit &, PelUnitBuf &, RefPicList, Mv &, int, Mv &, int &, uint32_t &, Distortion &, const AMVPInfo &, bool );
+extern "C" void vtmref_orig_xAffineMotionEstimation( InterSearch *, PredictionUnit &, PelUnitBuf &, RefPicList, Mv *, int, Mv *, uint32_t &, Distortion &, int &, const AffineAMVPInfo &, bool );
 extern "C" void vtmref_orig_transformNxN_select( TrQuant *, TransformUnit &, const ComponentID &, const QpParam &, std::vector<TrMode> *, const int );
 namespace
 {
-bool     g_hookMe = false, g_hookMts = false;
+bool     g_hookMe = false, g_hookMts = false, g_hookAffine = false;
+uint64_t g_affineCtr = 0;
 uint64_t g_hookCtr[2] = { 0, 0 }, g_hookStride = 0;   // VTMREF_HOOK_STRIDE: the hooks' own sampling stride (default: the tables' stride)
 inline bool hookSampled( uint64_t &ctr )
 {
@@ -548,6 +552,64 @@ void meHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPicLis
   rcMv.hor = o.mvHor; rcMv.ver = o.mvVer; rcMvPred.hor = o.mvPredHor; rcMvPred.ver = o.mvPredVer; riMVPIdx = o.mvpIdx; ruiBits = o.bits; ruiCost = o.cost;
 }
 
+
+void affineHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPicList eRefPicList, Mv acMvPred[3], int iRefIdxPred, Mv acMv[3], uint32_t &ruiBits, Distortion &ruiCost,
+                 int &mvpIdx, const AffineAMVPInfo &aamvpi, bool bBi )
+{
+  g_st->affineCalls++;
+  const Slice   &slice  = *pu.cu->slice;
+  const Picture *refPic = slice.getRefPic( eRefPicList, iRefIdxPred );
+  const int      w = pu.Y().width, h = pu.Y().height;
+  const bool     encOpt = is->m_pcEncCfg->getUseAffineAmvrEncOpt();
+  const bool unsupported = pu.cu->BcwIdx != BCW_DEFAULT || is->m_pcEncCfg->getMCTSEncConstraint() || is->m_pcEncCfg->getClipForBiPredMeEnabled() || ( pu.cu->imv == 2 && encOpt )
+                        || refPic->isWrapAroundEnabled( pu.cs->pps ) || refPic->isRefScaled( pu.cs->pps ) || w < 16 || h < 16 || w > 128 || h > 128
+                        || slice.getSPS()->getBitDepth( CHANNEL_TYPE_LUMA ) > 10 || slice.getPPS()->getUseWP() || slice.getPPS()->getWPBiPred();
+  if( unsupported ) g_st->affineUnsupported++;
+  if( unsupported || !hookSampled( g_affineCtr ) )
+  {
+    vtmref_orig_xAffineMotionEstimation( is, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi );
+    return;
+  }
+  vtmhip_affine_me_job j; memset( &j, 0, sizeof( j ) );
+  const RefPlane *rp = refPlane( refPic );
+  const CPelBuf   org = origBuf.Y();
+  std::vector<Pel> blk( size_t( w ) * h ), oth( size_t( w ) * h );
+  for( int y = 0; y < h; y++ ) memcpy( &blk[size_t( y ) * w], org.buf + ptrdiff_t( y ) * org.stride, sizeof( Pel ) * w );
+  if( bBi )
+  {
+    const CPelBuf o = is->m_tmpPredStorage[1 - (int) eRefPicList].getBuf( UnitAreaRelative( *pu.cu, pu ) ).Y();
+    for( int y = 0; y < h; y++ ) memcpy( &oth[size_t( y ) * w], o.buf + ptrdiff_t( y ) * o.stride, sizeof( Pel ) * w );
+  }
+  const Position pos = pu.cu->lumaPos();
+  j.orgOff = 0; j.orgStride = w; j.otherPredOff = 0; j.otherPredStride = w;
+  j.refOff = rp ? ( int64_t ) ( rp->margin + pu.Y().y ) * rp->stride + rp->margin + pu.Y().x : 0; j.refStride = rp ? rp->stride : 0;
+  j.puX = ( int16_t ) pos.x; j.puY = ( int16_t ) pos.y; j.width = ( int16_t ) w; j.height = ( int16_t ) h;
+  j.sixParam = pu.cu->affineType == AFFINEMODEL_6PARAM; j.interDir = pu.interDir; j.imv = pu.cu->imv; j.bi = bBi;
+  j.useSatd = !pu.cs->slice->getDisableSATDForRD(); j.useAffineType = pu.cu->cs->sps->getUseAffineType(); j.amvrEncOpt = encOpt;
+  j.lowDelayRounds = is->m_pcEncCfg->getIntraPeriod() == -1;
+  j.profAllowed = pu.cs->sps->getUsePROF() && !is->m_skipPROF && !pu.cs->picHeader->getDisProfFlag();
+  j.profNeedsLargeGrad = is->m_encOnly && !pu.cu->slice->getCheckLDC(); j.profIsBi = is->m_isBi;
+  for( int i = 0; i < 3; i++ ) { j.mvPred[i][0] = acMvPred[i].hor; j.mvPred[i][1] = acMvPred[i].ver; j.mv[i][0] = acMv[i].hor; j.mv[i][1] = acMv[i].ver; }
+  j.bits = ruiBits; j.motionLambda = is->m_pcRdCost->m_motionLambda; j.hevcCost = is->m_hevcCost;
+  vtmhip_pic_params pic; memset( &pic, 0, sizeof( pic ) );
+  pic.picW = pu.cs->pps->getPicWidthInLumaSamples(); pic.picH = pu.cs->pps->getPicHeightInLumaSamples(); pic.ctuSize = pu.cs->sps->getMaxCUWidth();
+  pic.bitDepth = slice.getSPS()->getBitDepth( CHANNEL_TYPE_LUMA );
+  vtmref_orig_xAffineMotionEstimation( is, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi );
+  vtmhip_affine_me_out o; memset( &o, 0, sizeof( o ) );
+  const bool ok = rp && A.h2d( g_ctx, d_hOrg, blk.data(), blk.size() * 2 ) == VTMHIP_OK && ( !bBi || A.h2d( g_ctx, d_hOther, oth.data(), oth.size() * 2 ) == VTMHIP_OK )
+               && A.h2d( g_ctx, d_hJob, &j, sizeof( j ) ) == VTMHIP_OK
+               && A.affineMe( g_ctx, &pic, d_hOrg, rp->dev, d_hOther, ( const vtmhip_affine_me_job * ) d_hJob, 1, w, h, ( vtmhip_affine_me_out * ) d_hOut ) == VTMHIP_OK
+               && A.d2h( g_ctx, &o, d_hOut, sizeof( o ) ) == VTMHIP_OK;
+  if( !ok ) { note_error(); return; }
+  g_st->affineDevice++;
+  const int mvNum = j.sixParam ? 3 : 2;
+  bool bad = o.bits != ruiBits || o.cost != ruiCost;
+  for( int i = 0; i < mvNum; i++ ) bad |= o.mv[i][0] != acMv[i].hor || o.mv[i][1] != acMv[i].ver;
+  if( bad ) { if( g_st->affineMismatch++ == 0 && g_st->hookMismatch[0] + g_st->hookMismatch[1] == 0 ) { const int32_t v[8] = { 2, w * 1000 + h, j.sixParam * 100 + j.bi * 10 + j.imv, o.mv[0][0] - acMv[0].hor, o.mv[1][0] - acMv[1].hor, ( int32_t ) ruiCost, ( int32_t ) o.cost, 0 }; memcpy( g_st->hookFirstMismatch, v, sizeof( v ) ); } }
+  for( int i = 0; i < mvNum; i++ ) { acMv[i].hor = o.mv[i][0]; acMv[i].ver = o.mv[i][1]; }
+  ruiBits = o.bits; ruiCost = o.cost;
+}
+
 void mtsHook( TrQuant *tq, TransformUnit &tu, const ComponentID &compID, const QpParam &cQP, std::vector<TrMode> *trModes, const int maxCand )
 {
   g_st->hookCalls[1]++;
@@ -608,6 +670,12 @@ void InterSearch::xMotionEstimation( PredictionUnit &pu, PelUnitBuf &origBuf, Re
   if( g_hookMe ) meHook( this, pu, origBuf, eRefPicList, rcMvPred, iRefIdxPred, rcMv, riMVPIdx, ruiBits, ruiCost, amvpInfo, bBi );
   else vtmref_orig_xMotionEstimation( this, pu, origBuf, eRefPicList, rcMvPred, iRefIdxPred, rcMv, riMVPIdx, ruiBits, ruiCost, amvpInfo, bBi );
 }
+void InterSearch::xAffineMotionEstimation( PredictionUnit &pu, PelUnitBuf &origBuf, RefPicList eRefPicList, Mv acMvPred[3], int iRefIdxPred, Mv acMv[3], uint32_t &ruiBits,
+                                           Distortion &ruiCost, int &mvpIdx, const AffineAMVPInfo &aamvpi, bool bBi )
+{
+  if( g_hookAffine ) affineHook( this, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi );
+  else vtmref_orig_xAffineMotionEstimation( this, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi );
+}
 void TrQuant::transformNxN( TransformUnit &tu, const ComponentID &compID, const QpParam &cQP, std::vector<TrMode> *trModes, const int maxCand )
 {
   if( g_hookMts ) mtsHook( this, tu, compID, cQP, trModes, maxCand );
@@ -634,7 +702,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
                  && sym( A.addAvg, "vtmhip_add_avg_batch_dev" ) && sym( A.rhf, "vtmhip_remove_high_freq_batch_dev" )
                  && sym( A.sobel, "vtmhip_affine_sobel_batch_dev" ) && sym( A.eqc, "vtmhip_affine_equal_coeff_batch_dev" )
                  && sym( A.me, "vtmhip_xMotionEstimation_batch_dev" ) && sym( A.xT, "vtmhip_xT_batch_dev" ) && sym( A.tsChain, "vtmhip_tu_ts_chain_batch_dev" )
-                 && sym( A.mtsSelect, "vtmhip_mts_select2" );
+                 && sym( A.mtsSelect, "vtmhip_mts_select2" ) && sym( A.affineMe, "vtmhip_xAffineMotionEstimation_batch_dev" );
     if( !ok ) { fprintf( stderr, "ref_encode: libvtmhip.so lacks a pointer-surface symbol\n" ); return -11; }
     const int st = A.create( 0, &g_ctx );
     if( st != VTMHIP_OK ) { fprintf( stderr, "ref_encode: vtmhip_create failed (%d) -- no CPU fallback\n", st ); return -12; }
@@ -659,7 +727,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
         if( g_mask & 2 ) installIf( app->m_cEncLib.m_cInterSearch.m_if );
         if( g_mask & 4 ) installTr();
         if( ( g_mask & 16 ) && ( g_countOnly || auxAlloc() ) ) installAux( (AffineGradientSearch &) app->m_cEncLib.m_cInterSearch );   // private base: C-style cast
-        if( ( g_mask & 96 ) && ( g_countOnly || ( g_ctx && hookAlloc() ) ) ) { g_hookMe = ( g_mask & 32 ) != 0; g_hookMts = ( g_mask & 64 ) != 0; g_hookCtr[0] = g_hookCtr[1] = 0;
+        if( ( g_mask & ( 96 | 128 ) ) && ( g_countOnly || ( g_ctx && hookAlloc() ) ) ) { g_hookAffine = ( g_mask & 128 ) != 0; g_affineCtr = 0; g_hookMe = ( g_mask & 32 ) != 0; g_hookMts = ( g_mask & 64 ) != 0; g_hookCtr[0] = g_hookCtr[1] = 0;
           g_hookStride = getenv( "VTMREF_HOOK_STRIDE" ) ? strtoull( getenv( "VTMREF_HOOK_STRIDE" ), nullptr, 10 ) : 0; }
       }
       bool eos = false;
@@ -673,7 +741,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
     }
   }
   catch( Exception &e ) { fprintf( stderr, "ref_encode: %s\n", e.what() ); rc = 2; }
-  g_hookMe = g_hookMts = false;
+  g_hookMe = g_hookMts = g_hookAffine = false;
   for( RefPlane &p : g_planes ) A.dfree( g_ctx, p.dev );
   g_planes.clear();
   if( g_ctx || g_countOnly ) { restoreDist(); restoreTr(); restoreAux(); }

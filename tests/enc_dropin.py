@@ -19,7 +19,8 @@ class Stats(C.Structure):
     _fields_ = [("calls", C.c_uint64 * 4), ("device", C.c_uint64 * 4), ("mismatch", C.c_uint64 * 4), ("errors", C.c_uint64),
                 ("firstMismatch", C.c_int32 * 8), ("firstError", C.c_char * 160),
                 ("hookCalls", C.c_uint64 * 2), ("hookDevice", C.c_uint64 * 2), ("hookMismatch", C.c_uint64 * 2), ("hookUnsupported", C.c_uint64 * 2),
-                ("hookFirstMismatch", C.c_int32 * 8)]
+                ("hookFirstMismatch", C.c_int32 * 8), ("affineCalls", C.c_uint64), ("affineDevice", C.c_uint64), ("affineMismatch", C.c_uint64),
+                ("affineUnsupported", C.c_uint64)]
 
 
 def write_clip(path, w, h, frames, seed=77):
@@ -43,7 +44,7 @@ def _child(argv_json):
     out = {"rc": rc, "calls": list(st.calls), "device": list(st.device), "mismatch": list(st.mismatch), "errors": st.errors,
            "firstMismatch": list(st.firstMismatch), "firstError": st.firstError.decode(errors="replace"),
            "hookCalls": list(st.hookCalls), "hookDevice": list(st.hookDevice), "hookMismatch": list(st.hookMismatch), "hookUnsupported": list(st.hookUnsupported),
-           "hookFirstMismatch": list(st.hookFirstMismatch)}
+           "hookFirstMismatch": list(st.hookFirstMismatch), "affine": [st.affineCalls, st.affineDevice, st.affineMismatch, st.affineUnsupported]}
     sys.stdout.flush()
     os.write(2, ("\nDROPIN_RESULT " + json.dumps(out) + "\n").encode())
 
