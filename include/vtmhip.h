@@ -687,6 +687,16 @@ typedef struct
  * 2: after the bi fractional search -> predFinal (mode, vectors), biMv, costBi, useBi */
 int vtmhip_frame_stage( vtmhip_ctx *ctx, const vtmhip_frame_tabs *tabs, int stage );
 
+/* ---- merge-candidate estimation: the SATD pre-selection of EncCu::xCheckRDCostMerge2Nx2N (hook B10) ---------------------------------------
+ * (EncCu.cpp:2399-2440; the MMVD and CIIP candidate loops :2470-2549 use the same two steps).  For every candidate the reference runs
+ * motionCompensation( pu, ..., luma ) -- plain uni / bi prediction, BDOF or DMVR (+ BDOF) by the candidate's motion -- and the Hadamard (or SAD)
+ * distortion against the original block; the candidate's bits x sqrt(lambda) and the sorted insertion (updateCandList) stay with the host.
+ * One call: the three job tables (candidates grouped by the kind of prediction; any may be empty) -> predictions into d_predBase + predOff (kept:
+ * they are the encoder's acMergeBuffer) -> d_dist[nPlain + nBdof + nDmvr] in table order.  Jobs: epilogue 0; d_mvd as vtmhip_dmvr_batch_dev. */
+int vtmhip_merge_cand_satd_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, int16_t *d_predBase,
+                                      const vtmhip_pred_job *d_plain, int nPlain, const vtmhip_pred_job *d_bdof, int nBdof, const vtmhip_dmvr_job *d_dmvr, int nDmvr,
+                                      int32_t *d_mvd, int maxWidth, int maxHeight, int uniformSize, int useSatd, uint64_t *d_dist );
+
 /* ================================================================================================================
  * (4) LEVEL-ORDER predInterSearch -- InterSearch::predInterSearch (InterSearch.cpp:2245-3065, translational part: cu.imv 0, default
  *     BCW weight, no SMVD / affine) for ALL PUs of one block size at once, on top of the batched calls above

@@ -533,3 +533,66 @@ def test_bcw_ops_match_oracle(ctx):
     assert np.array_equal(d_dst.to_host(np.int16), np.concatenate(E0))
     ctx.add_weighted_avg_batch(ctx.to_device(a1).ptr, ctx.to_device(b1).ptr, d_dst.ptr, d_jobs.ptr, n)
     assert np.array_equal(d_dst.to_host(np.int16), np.concatenate(E1))
+
+
+def test_merge_candidate_satd_batch(ctx):
+    """Hook B10 (EncCu::xCheckRDCostMerge2Nx2N :2399-2440): one call = the luma prediction of every merge candidate (plain uni / bi, BDOF, DMVR (+ BDOF) by
+    the candidate's motion) + the Hadamard distortion against the original block; predictions stay in the buffer (acMergeBuffer).  vs the oracle."""
+    from vtm_amd import synth
+    from vtm_amd.lib import DmvrJob, PicParams, PredJob
+    L = ol.oracle()
+    W, H, M, bd = 256, 192, 160, 10
+    fr = list(synth.gen_frames(W, H, 3, seed=9))
+    rng = np.random.default_rng(2024)
+    planes = [np.ascontiguousarray(np.pad(f.astype(np.int16), M, mode="edge")) for f in (fr[0], fr[2])]
+    org = np.ascontiguousarray(fr[1].astype(np.int16))
+    S, plane_sz = planes[0].shape[1], planes[0].size
+    o = [C.c_void_p(p.ctypes.data + 2 * (M * S + M)) for p in planes]
+    for (w, h) in ((16, 16), (32, 16), (8, 32), (64, 64)):
+        n_each = 20
+        plain, bdof, dmvr = (PredJob * n_each)(), (PredJob * n_each)(), (DmvrJob * n_each)()
+        exp, preds, pos = [], [], 0
+        for kind, tab in ((0, plain), (1, bdof), (2, dmvr)):
+            for k in range(n_each):
+                x, y = int(rng.integers(0, (W - w) // 4 + 1)) * 4, int(rng.integers(0, (H - h) // 4 + 1)) * 4
+                base = np.array([48, 32]) + rng.integers(-40, 41, 2)
+                mv = [int(-base[0]), int(-base[1]), int(base[0] + rng.integers(-24, 25)), int(base[1] + rng.integers(-24, 25))]
+                e = np.zeros((h, w), np.int16)
+                at = [C.c_void_p(p.ctypes.data + 2 * ((y + M) * S + x + M)) for p in planes]
+                j = tab[k]
+                mode = 2
+                if kind == 0:
+                    mode = k % 3                      # list 0, list 1, bi (addAvg)
+                    if mode == 2:
+                        p0, p1 = np.zeros((h, w), np.int16), np.zeros((h, w), np.int16)
+                        L.vo_mc_luma(at[0], S, w, h, mv[0], mv[1], 1, bd, 0, ol.P(p0), w)
+                        L.vo_mc_luma(at[1], S, w, h, mv[2], mv[3], 1, bd, 0, ol.P(p1), w)
+                        L.vo_add_avg(ol.P(p0), w, ol.P(p1), w, ol.P(e), w, w, h, bd)
+                    else:
+                        L.vo_mc_luma(at[mode], S, w, h, mv[2 * mode], mv[2 * mode + 1], 0, bd, 0, ol.P(e), w)
+                elif kind == 1:
+                    L.vo_bdof_pu(at[0], S, at[1], S, w, h, *mv, bd, ol.P(e), w)
+                else:
+                    mvd = np.zeros(2 * 64, np.int32)
+                    L.vo_dmvr_pu(o[0], o[1], S, W, H, 128, x, y, w, h, *mv, bd, k % 2, ol.P(e), w, C.c_void_p(mvd.ctypes.data))
+                    j.puX, j.puY, j.bioApplied = x, y, k % 2
+                for l in range(2):
+                    j.refOff[l], j.refStride[l] = l * plane_sz + (M + y) * S + M + x, S
+                j.mv[0][0], j.mv[0][1], j.mv[1][0], j.mv[1][1] = mv
+                j.orgOff, j.orgStride, j.predOff, j.predStride = y * W + x, W, pos, w
+                j.width, j.height, j.bitDepth, j.epilogue = w, h, bd, 0
+                if kind < 2:
+                    j.mode = mode
+                ob = np.ascontiguousarray(org[y:y + h, x:x + w])
+                exp.append(ol.o_dist(1, ob, e, w, h))
+                preds.append(e.reshape(-1))
+                pos += w * h
+        pic = PicParams(W, H, 128, bd, 0)
+        d_ref = ctx.to_device(np.concatenate([p.reshape(-1) for p in planes]))
+        d_org = ctx.to_device(org.reshape(-1))
+        d_p, d_b, d_d = (ctx.to_device(np.frombuffer(t, np.uint8)) for t in (plain, bdof, dmvr))
+        d_pred, d_dist, d_mvd = ctx.alloc(2 * pos), ctx.alloc(8 * 3 * n_each), ctx.alloc(4 * n_each * 64 * 2)
+        for uniform in (False, True):
+            ctx.merge_cand_satd_batch(pic, d_org.ptr, d_ref.ptr, d_pred.ptr, d_p.ptr, n_each, d_b.ptr, n_each, d_d.ptr, n_each, d_mvd.ptr, w, h, d_dist.ptr, uniform=uniform)
+            assert d_dist.to_host(np.uint64).tolist() == exp, (w, h, uniform)
+            assert np.array_equal(d_pred.to_host(np.int16), np.concatenate(preds)), (w, h, uniform)

@@ -207,6 +207,27 @@ __global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
   L.pus[pu] = P;
 }
 
+// ---- merge-candidate SATD (EncCu::xCheckRDCostMerge2Nx2N, EncCu.cpp:2399-2440): the distortion job of every candidate prediction ----
+__global__ __launch_bounds__( 256 ) void merge_dist_jobs_kernel( const vtmhip_pred_job *__restrict__ plain, int nPlain, const vtmhip_pred_job *__restrict__ bdof, int nBdof,
+                                                                const vtmhip_dmvr_job *__restrict__ dmvr, int nDmvr, int useSatd, vtmhip_dist_job *__restrict__ out )
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if( i >= nPlain + nBdof + nDmvr ) return;
+  vtmhip_dist_job d;
+  if( i < nPlain + nBdof )
+  {
+    const vtmhip_pred_job &j = i < nPlain ? plain[i] : bdof[i - nPlain];
+    d.orgOff = j.orgOff; d.curOff = j.predOff; d.orgStride = j.orgStride; d.curStride = j.predStride; d.width = j.width; d.height = j.height;
+  }
+  else
+  {
+    const vtmhip_dmvr_job &j = dmvr[i - nPlain - nBdof];
+    d.orgOff = j.orgOff; d.curOff = j.predOff; d.orgStride = j.orgStride; d.curStride = j.predStride; d.width = j.width; d.height = j.height;
+  }
+  d.subShift = 0; d.kind = ( int16_t ) ( useSatd ? VTMHIP_DIST_SATD : VTMHIP_DIST_SAD );
+  out[i] = d;
+}
+
 size_t align_up( size_t v ) { return ( v + 255 ) & ~( size_t ) 255; }
 
 }   // namespace
@@ -245,6 +266,33 @@ int vtmhip_xEstimateMvPredAMVP_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_para
   hipLaunchKernelGGL( amvp_select_kernel, dim3( ( n + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, d_jobs, n, wk, addIdxBits, ( unsigned long long * ) d_distBiP );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
+}
+
+int vtmhip_merge_cand_satd_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, int16_t *d_predBase,
+                                      const vtmhip_pred_job *d_plain, int nPlain, const vtmhip_pred_job *d_bdof, int nBdof, const vtmhip_dmvr_job *d_dmvr, int nDmvr,
+                                      int32_t *d_mvd, int maxWidth, int maxHeight, int uniformSize, int useSatd, uint64_t *d_dist )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, nPlain >= 0 && nBdof >= 0 && nDmvr >= 0, "n" );
+  const int n = nPlain + nBdof + nDmvr;
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, pic && d_orgBase && d_refBase && d_predBase && d_dist, "null pointer" );
+  VTMHIP_REQUIRE( ctx, ( nPlain == 0 || d_plain ) && ( nBdof == 0 || d_bdof ) && ( nDmvr == 0 || d_dmvr ), "null job table" );
+  // the candidates' predictions (kept in d_predBase: the encoder's acMergeBuffer), by the kind of motion compensation the reference runs for them
+  int st = vtmhip_motion_compensation_batch_dev( ctx, nullptr, d_refBase, d_predBase, nullptr, d_plain, nPlain, maxWidth, maxHeight );
+  if( st ) return st;
+  st = vtmhip_bdof_batch_dev( ctx, nullptr, d_refBase, d_predBase, nullptr, d_bdof, nBdof, maxWidth, maxHeight );
+  if( st ) return st;
+  st = vtmhip_dmvr_batch_dev( ctx, pic, nullptr, d_refBase, d_predBase, nullptr, d_dmvr, nDmvr, maxWidth, maxHeight, d_mvd );
+  if( st ) return st;
+  void *arena = nullptr;
+  st = vtmhip_internal_workspace( ctx, ( size_t ) n * sizeof( vtmhip_dist_job ), &arena );
+  if( st ) return st;
+  vtmhip_dist_job *dj = ( vtmhip_dist_job * ) arena;
+  hipLaunchKernelGGL( merge_dist_jobs_kernel, dim3( ( n + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, d_plain, nPlain, d_bdof, nBdof, d_dmvr, nDmvr, useSatd, dj );
+  VTMHIP_LAUNCHED( ctx );
+  if( uniformSize ) return vtmhip_dist_uniform_batch_dev( ctx, d_orgBase, d_predBase, dj, n, useSatd ? VTMHIP_DIST_SATD : VTMHIP_DIST_SAD, maxWidth, maxHeight, 0, d_dist );
+  return vtmhip_dist_batch_dev( ctx, d_orgBase, d_predBase, dj, n, d_dist );
 }
 
 int vtmhip_pis_stage( vtmhip_ctx *ctx, const vtmhip_pis_level *lvl, int stage )

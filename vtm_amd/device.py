@@ -237,6 +237,11 @@ class Context:
         self._check(self.L.vtmhip_kernel_timing_read(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def merge_cand_satd_batch(self, pic, d_org, d_ref, d_pred, d_plain, n_plain, d_bdof, n_bdof, d_dmvr, n_dmvr, d_mvd, max_w, max_h, d_dist, uniform=False, use_satd=True):
+        """merge-candidate SATD pre-selection (hook B10): predictions of the three candidate classes + Hadamard distortion"""
+        self._check(self.L.vtmhip_merge_cand_satd_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_pred, d_plain, n_plain, d_bdof, n_bdof, d_dmvr, n_dmvr, d_mvd, max_w, max_h,
+                                                            int(uniform), int(use_satd), d_dist))
+
     def pis_stage(self, level, stage):
         self._check(self.L.vtmhip_pis_stage(self.h, C.byref(level), stage))
 

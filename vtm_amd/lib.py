@@ -295,6 +295,8 @@ _PROTOS = {
     "vtmhip_xPredAffineBlk_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "vtmhip_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "vtmhip_kernel_timing_read": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "vtmhip_merge_cand_satd_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                   C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vtmhip_pis_stage": (C.c_int, [C.c_void_p, C.POINTER(PisLevel), C.c_int]),
     "vtmhip_tz_search_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_void_p]),
