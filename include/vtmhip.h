@@ -142,6 +142,21 @@ typedef struct
 } vtmhip_lfnst_job;
 int vtmhip_lfnst_batch_dev( vtmhip_ctx *ctx, const int32_t *d_srcBase, int32_t *d_dstBase, const vtmhip_lfnst_job *d_jobs, int n );
 
+/* The whole secondary transform of a TU, TrQuant::xFwdLfnst / xInvLfnst (TrQuant.cpp:340-527), IN PLACE on its W x H coefficient block (stride W):
+ * gather of the low-frequency region (transposed for the intra modes past the diagonal, getTransposeFlag :334-338), the core multiply above, scatter along
+ * the coefficient scan (forward: 16 / 48 positions; inverse: gather 16 scan positions, write the 16 / 48 region samples).  The trampoline derives
+ * mode = g_lfnstLut[ getLFNSTIntraMode( PU::getWideAngle( ... ) ) ] and transpose from the PU exactly as the reference does (:350-366, 438-454). */
+typedef struct
+{
+  int64_t coefOff;          /* the TU's coefficients inside d_coefBase */
+  int16_t width, height;    /* 4..64 */
+  uint8_t mode, index;      /* g_lfnstLut[intraMode] (0..3), lfnstIdx - 1 (0..1) */
+  uint8_t transpose, inverse;
+} vtmhip_lfnst_tu_job;
+int vtmhip_lfnst_tu_batch_dev( vtmhip_ctx *ctx, int32_t *d_coefBase, const vtmhip_lfnst_tu_job *d_jobs, int n );
+/* host-only: the scan positions (x + y * width) the calls above use, 16 (4-wide / 4-high TUs) or 48 entries */
+int vtmhip_lfnst_scan_host( int width, int height, int32_t *pos48 );
+
 /* n x n forward core matrix g_trCore<type>P<n>[TRANSFORM_FORWARD] (Rom.h:115-130), row-major int16; host-only helper */
 int vtmhip_tr_matrix_host( int type, int n, int16_t *out );
 /* MTS candidate pre-selection thresholds of TrQuant::transformNxN( tu, compID, cQP, &trModes, maxCand ) (TrQuant.cpp:950-1019); host-only */

@@ -51,7 +51,8 @@ struct RefEncStats
   //                                       [1]: TrQuant::transformNxN( trModes ) = all MTS candidates' forward transforms + the pre-selection (hook B8)
   uint64_t hookCalls[2], hookDevice[2], hookMismatch[2], hookUnsupported[2];
   int32_t  hookFirstMismatch[8];
-  uint64_t affineCalls, affineDevice, affineMismatch, affineUnsupported;   // InterSearch::xAffineMotionEstimation as one vtmhip_xAffineMotionEstimation_batch_dev call
+  uint64_t affineCalls, affineDevice, affineMismatch, affineUnsupported;
+  uint64_t lfnstCalls[2], lfnstDevice[2], lfnstMismatch[2];   // TrQuant::xFwdLfnst / xInvLfnst (gather + core multiply + scatter) as vtmhip_lfnst_tu_batch_dev   // InterSearch::xAffineMotionEstimation as one vtmhip_xAffineMotionEstimation_batch_dev call
 };
 }
 
@@ -86,6 +87,8 @@ struct Api
   decltype( &vtmhip_tu_ts_chain_batch_dev )        tsChain;
   decltype( &vtmhip_mts_select2 )                  mtsSelect;
   decltype( &vtmhip_xAffineMotionEstimation_batch_dev ) affineMe;
+  decltype( &vtmhip_lfnst_set_tables )             lfnstTables;
+  decltype( &vtmhip_lfnst_tu_batch_dev )           lfnstTu;
 } A;
 
 vtmhip_ctx  *g_ctx = nullptr;
@@ -423,10 +426,13 @@ void restoreAux()
 }   // namespace
 extern "C" void vtmref_orig_xMotionEstimation( InterSearch *, PredictionUnit &, PelUnitBuf &, RefPicList, Mv &, int, Mv &, int &, uint32_t &, Distortion &, const AMVPInfo &, bool );
 extern "C" void vtmref_orig_xAffineMotionEstimation( InterSearch *, PredictionUnit &, PelUnitBuf &, RefPicList, Mv *, int, Mv *, uint32_t &, Distortion &, int &, const AffineAMVPInfo &, bool );
+extern "C" void vtmref_orig_xFwdLfnst( TrQuant *, const TransformUnit &, const ComponentID, const bool );
+extern "C" void vtmref_orig_xInvLfnst( TrQuant *, const TransformUnit &, const ComponentID );
 extern "C" void vtmref_orig_transformNxN_select( TrQuant *, TransformUnit &, const ComponentID &, const QpParam &, std::vector<TrMode> *, const int );
 namespace
 {
-bool     g_hookMe = false, g_hookMts = false, g_hookAffine = false;
+bool     g_hookMe = false, g_hookMts = false, g_hookAffine = false, g_hookLfnst = false;
+uint64_t g_lfnstCtr[2] = { 0, 0 };
 uint64_t g_affineCtr = 0;
 uint64_t g_hookCtr[2] = { 0, 0 }, g_hookStride = 0;   // VTMREF_HOOK_STRIDE: the hooks' own sampling stride (default: the tables' stride)
 inline bool hookSampled( uint64_t &ctr )
@@ -610,6 +616,50 @@ void affineHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPi
   ruiBits = o.bits; ruiCost = o.cost;
 }
 
+// what the trampoline of xFwdLfnst / xInvLfnst derives from the TU exactly as the reference does (TrQuant.cpp:346-366): does LFNST apply, and with
+// which matrix set / orientation
+bool lfnstParams( const TransformUnit &tu, const ComponentID compID, int &mode, bool &transpose )
+{
+  const CompArea &area = tu.blocks[compID];
+  const uint32_t  lfnstIdx = tu.cu->lfnstIdx;
+  if( !( lfnstIdx && tu.mtsIdx[compID] != MTS_SKIP && ( tu.cu->isSepTree() ? true : isLuma( compID ) ) ) || lfnstIdx >= 3 ) return false;
+  uint32_t intraMode = PU::getFinalIntraMode( *tu.cs->getPU( area.pos(), toChannelType( compID ) ), toChannelType( compID ) );
+  if( PU::isLMCMode( tu.cs->getPU( area.pos(), toChannelType( compID ) )->intraDir[toChannelType( compID )] ) ) intraMode = PU::getCoLocatedIntraLumaMode( *tu.cs->getPU( area.pos(), toChannelType( compID ) ) );
+  if( PU::isMIP( *tu.cs->getPU( area.pos(), toChannelType( compID ) ), toChannelType( compID ) ) ) intraMode = PLANAR_IDX;
+  TrQuant dummy;
+  intraMode = dummy.getLFNSTIntraMode( PU::getWideAngle( tu, intraMode, compID ) );
+  transpose = dummy.getTransposeFlag( intraMode );
+  mode      = g_lfnstLut[intraMode];
+  return true;
+}
+
+void lfnstHook( TrQuant *tq, const TransformUnit &tu, const ComponentID compID, bool inverse, bool loadTr )
+{
+  const int which = inverse ? 1 : 0;
+  g_st->lfnstCalls[which]++;
+  const CompArea &area = tu.blocks[compID];
+  const int       w = area.width, h = area.height;
+  int  mode = 0;
+  bool transpose = false;
+  TCoeff *buf = inverse ? tq->m_tempCoeff : ( loadTr ? tq->m_mtsCoeffs[tu.mtsIdx[compID]] : tq->m_tempCoeff );
+  const bool applies = lfnstParams( tu, compID, mode, transpose ) && w >= 4 && h >= 4 && w <= 64 && h <= 64;
+  std::vector<TCoeff> before;
+  // an encode makes ~10^6 LFNST calls: every 16th sampled call is enough
+  const bool dev = applies && hookSampled( g_lfnstCtr[which] ) && ( g_lfnstCtr[which] & 15 ) == 1;
+  if( dev ) before.assign( buf, buf + size_t( w ) * h );
+  if( inverse ) vtmref_orig_xInvLfnst( tq, tu, compID ); else vtmref_orig_xFwdLfnst( tq, tu, compID, loadTr );
+  if( !dev ) return;
+  vtmhip_lfnst_tu_job j; memset( &j, 0, sizeof( j ) );
+  j.coefOff = 0; j.width = ( int16_t ) w; j.height = ( int16_t ) h; j.mode = ( uint8_t ) mode; j.index = ( uint8_t ) ( tu.cu->lfnstIdx - 1 ); j.transpose = transpose; j.inverse = inverse;
+  std::vector<TCoeff> out( size_t( w ) * h );
+  const bool ok = A.h2d( g_ctx, d_hCoef, before.data(), before.size() * 4 ) == VTMHIP_OK && A.h2d( g_ctx, d_hJob, &j, sizeof( j ) ) == VTMHIP_OK
+               && A.lfnstTu( g_ctx, d_hCoef, ( const vtmhip_lfnst_tu_job * ) d_hJob, 1 ) == VTMHIP_OK && A.d2h( g_ctx, out.data(), d_hCoef, out.size() * 4 ) == VTMHIP_OK;
+  if( !ok ) { note_error(); return; }
+  g_st->lfnstDevice[which]++;
+  if( memcmp( out.data(), buf, out.size() * 4 ) != 0 ) g_st->lfnstMismatch[which]++;
+  else memcpy( buf, out.data(), out.size() * 4 );
+}
+
 void mtsHook( TrQuant *tq, TransformUnit &tu, const ComponentID &compID, const QpParam &cQP, std::vector<TrMode> *trModes, const int maxCand )
 {
   g_st->hookCalls[1]++;
@@ -676,6 +726,14 @@ void InterSearch::xAffineMotionEstimation( PredictionUnit &pu, PelUnitBuf &origB
   if( g_hookAffine ) affineHook( this, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi );
   else vtmref_orig_xAffineMotionEstimation( this, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi );
 }
+void TrQuant::xFwdLfnst( const TransformUnit &tu, const ComponentID compID, const bool loadTr )
+{
+  if( g_hookLfnst ) lfnstHook( this, tu, compID, false, loadTr ); else vtmref_orig_xFwdLfnst( this, tu, compID, loadTr );
+}
+void TrQuant::xInvLfnst( const TransformUnit &tu, const ComponentID compID )
+{
+  if( g_hookLfnst ) lfnstHook( this, tu, compID, true, false ); else vtmref_orig_xInvLfnst( this, tu, compID );
+}
 void TrQuant::transformNxN( TransformUnit &tu, const ComponentID &compID, const QpParam &cQP, std::vector<TrMode> *trModes, const int maxCand )
 {
   if( g_hookMts ) mtsHook( this, tu, compID, cQP, trModes, maxCand );
@@ -702,7 +760,8 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
                  && sym( A.addAvg, "vtmhip_add_avg_batch_dev" ) && sym( A.rhf, "vtmhip_remove_high_freq_batch_dev" )
                  && sym( A.sobel, "vtmhip_affine_sobel_batch_dev" ) && sym( A.eqc, "vtmhip_affine_equal_coeff_batch_dev" )
                  && sym( A.me, "vtmhip_xMotionEstimation_batch_dev" ) && sym( A.xT, "vtmhip_xT_batch_dev" ) && sym( A.tsChain, "vtmhip_tu_ts_chain_batch_dev" )
-                 && sym( A.mtsSelect, "vtmhip_mts_select2" ) && sym( A.affineMe, "vtmhip_xAffineMotionEstimation_batch_dev" );
+                 && sym( A.mtsSelect, "vtmhip_mts_select2" ) && sym( A.affineMe, "vtmhip_xAffineMotionEstimation_batch_dev" )
+                 && sym( A.lfnstTables, "vtmhip_lfnst_set_tables" ) && sym( A.lfnstTu, "vtmhip_lfnst_tu_batch_dev" );
     if( !ok ) { fprintf( stderr, "ref_encode: libvtmhip.so lacks a pointer-surface symbol\n" ); return -11; }
     const int st = A.create( 0, &g_ctx );
     if( st != VTMHIP_OK ) { fprintf( stderr, "ref_encode: vtmhip_create failed (%d) -- no CPU fallback\n", st ); return -12; }
@@ -727,7 +786,8 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
         if( g_mask & 2 ) installIf( app->m_cEncLib.m_cInterSearch.m_if );
         if( g_mask & 4 ) installTr();
         if( ( g_mask & 16 ) && ( g_countOnly || auxAlloc() ) ) installAux( (AffineGradientSearch &) app->m_cEncLib.m_cInterSearch );   // private base: C-style cast
-        if( ( g_mask & ( 96 | 128 ) ) && ( g_countOnly || ( g_ctx && hookAlloc() ) ) ) { g_hookAffine = ( g_mask & 128 ) != 0; g_affineCtr = 0; g_hookMe = ( g_mask & 32 ) != 0; g_hookMts = ( g_mask & 64 ) != 0; g_hookCtr[0] = g_hookCtr[1] = 0;
+        if( ( g_mask & ( 96 | 128 | 256 ) ) && ( g_countOnly || ( g_ctx && hookAlloc() ) ) ) { g_hookAffine = ( g_mask & 128 ) != 0; g_affineCtr = 0;
+          g_hookLfnst = ( g_mask & 256 ) != 0 && ( g_countOnly || A.lfnstTables( g_ctx, &g_lfnst8x8[0][0][0][0], &g_lfnst4x4[0][0][0][0] ) == VTMHIP_OK ); g_lfnstCtr[0] = g_lfnstCtr[1] = 0; g_hookMe = ( g_mask & 32 ) != 0; g_hookMts = ( g_mask & 64 ) != 0; g_hookCtr[0] = g_hookCtr[1] = 0;
           g_hookStride = getenv( "VTMREF_HOOK_STRIDE" ) ? strtoull( getenv( "VTMREF_HOOK_STRIDE" ), nullptr, 10 ) : 0; }
       }
       bool eos = false;
@@ -741,7 +801,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
     }
   }
   catch( Exception &e ) { fprintf( stderr, "ref_encode: %s\n", e.what() ); rc = 2; }
-  g_hookMe = g_hookMts = g_hookAffine = false;
+  g_hookMe = g_hookMts = g_hookAffine = g_hookLfnst = false;
   for( RefPlane &p : g_planes ) A.dfree( g_ctx, p.dev );
   g_planes.clear();
   if( g_ctx || g_countOnly ) { restoreDist(); restoreTr(); restoreAux(); }

@@ -969,3 +969,13 @@ extern "C" void ref_affine_motion_estimation( const vo_affine_me_job_t *j, vo_af
   r.slice.setDisableSATDForRD( false );
   affineRestore( r );
 }
+
+// the reference's own scan tables for the LFNST scatter / gather (TrQuant.cpp:347, 435): g_coefTopLeftDiagScan8x8 for TUs >= 8x8, else the grouped
+// diagonal scan of the block
+extern "C" void ref_lfnst_scan( int w, int h, int32_t *pos48 )
+{
+  ensureRom();
+  const bool whge3 = w >= 8 && h >= 8;
+  const ScanElement *scan = whge3 ? g_coefTopLeftDiagScan8x8[gp_sizeIdxInfo->idxFrom( w )] : g_scanOrder[SCAN_GROUPED_4x4][SCAN_DIAG][gp_sizeIdxInfo->idxFrom( w )][gp_sizeIdxInfo->idxFrom( h )];
+  for( int k = 0; k < ( whge3 ? 48 : 16 ); k++ ) pos48[k] = scan[k].idx;
+}

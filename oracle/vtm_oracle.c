@@ -2122,3 +2122,51 @@ void vo_affine_motion_estimation( const vo_affine_me_job_t *j, vo_affine_me_resu
   memcpy( res->mv, best, sizeof( best ) );
   res->bits = bitsBest; res->cost = costBest;
 }
+
+
+/* ---- LFNST at TU level ------------------------------------------------------------------------------------------------------------ */
+void vo_lfnst_scan( int w, int h, int32_t *pos )
+{
+  /* the first 16 (TUs 4 wide or high) or 48 positions of g_scanOrder[SCAN_GROUPED_4x4][SCAN_DIAG] / g_coefTopLeftDiagScan8x8 (Rom.cpp: up-right
+   * diagonal scan inside 4x4 coefficient groups, the groups of the 8x8 region in the same diagonal order) */
+  const int sb8 = w >= 8 && h >= 8;
+  int       gxs[4], gys[4], ng = 0;
+  for( int d = 0; d < 3 && sb8; d++ )
+    for( int gy = d < 1 ? d : 1; gy >= 0 && d - gy <= 1; gy-- ) { gxs[ng] = d - gy; gys[ng] = gy; ng++; }
+  if( !sb8 ) { gxs[0] = gys[0] = 0; ng = 1; }
+  int k = 0;
+  for( int g = 0; g < ng && k < ( sb8 ? 48 : 16 ); g++ )
+    for( int d = 0; d < 7; d++ )
+      for( int y = d < 3 ? d : 3; y >= 0 && d - y <= 3; y-- ) pos[k++] = ( gxs[g] * 4 + d - y ) + ( gys[g] * 4 + y ) * w;
+}
+
+void vo_lfnst_tu( int32_t *coef, int w, int h, const int8_t *M, int transpose, int inverse )
+{
+  const int sb8 = w >= 8 && h >= 8, sb = sb8 ? 8 : 4, trSize = sb8 ? 48 : 16, zo = ( ( w == 4 && h == 4 ) || ( w == 8 && h == 8 ) ) ? 8 : 16;
+  int32_t   scan[48], in[48], out[48];
+  vo_lfnst_scan( w, h, scan );
+  memset( in, 0, sizeof( in ) );
+  if( !inverse )
+  {
+    /* TrQuant.cpp:456-497: rows 0..3 are sb wide, rows 4..7 (8x8 region) 4 wide; transposed: vector index 8 x + y (x < 4), 32 + 4 (x - 4) + y */
+    for( int y = 0; y < sb; y++ )
+      for( int x = 0; x < ( y < 4 ? sb : 4 ); x++ )
+      {
+        const int v = y < 4 ? y * sb + x : 32 + ( y - 4 ) * 4 + x;
+        in[v] = transpose ? coef[x * w + y] : coef[y * w + x];
+      }
+    vo_fwd_lfnst( in, out, M, sb, zo );
+    for( int k = 0; k < trSize; k++ ) coef[scan[k]] = out[k];
+  }
+  else
+  {
+    for( int k = 0; k < 16; k++ ) in[k] = coef[scan[k]];
+    vo_inv_lfnst( in, out, M, sb, zo );
+    for( int y = 0; y < sb; y++ )
+      for( int x = 0; x < ( y < 4 ? sb : 4 ); x++ )
+      {
+        const int v = y < 4 ? y * sb + x : 32 + ( y - 4 ) * 4 + x;
+        if( transpose ) coef[x * w + y] = out[v]; else coef[y * w + x] = out[v];
+      }
+  }
+}

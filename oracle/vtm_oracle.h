@@ -173,6 +173,11 @@ void vo_estimate_mvp_amvp( const vo_mest_job_t *job, int *mvpIdx, int *mvPredHor
 void vo_check_best_mvp( double motionLambda, int imv, int numCand, const int cands[2][2], const unsigned idxBits[2], int mvHor, int mvVer,
                         int *mvPredHor, int *mvPredVer, int *mvpIdx, unsigned *bits, uint64_t *cost );
 
+/* TrQuant::xFwdLfnst / xInvLfnst (TrQuant.cpp:340-527) in place on a W x H coefficient block (stride W): gather (transposed when `transpose`), core
+ * multiply with M ([16][trSize] for this mode / index), scatter along the diagonal coefficient scan in 4x4 groups */
+void vo_lfnst_tu( int32_t *coef, int w, int h, const int8_t *M, int transpose, int inverse );
+void vo_lfnst_scan( int w, int h, int32_t *pos48 );
+
 /* ---- affine motion estimation: InterPrediction::xPredAffineBlk (luma, incl. PROF) and InterSearch::xAffineMotionEstimation ---- */
 typedef struct
 {

@@ -46,19 +46,20 @@ def test_reference_encoder_with_batched_hooks(tmp_path, monkeypatch):
     enc_dropin.write_clip(yuv, W, H, FRAMES)
     monkeypatch.setenv("VTMREF_HOOK_STRIDE", "3")
     t0 = time.time()
-    st0, bits0, rec0 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "plain"))
+    st0, bits0, rec0 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "plain"), extra=("--LFNST=1",))
     t1 = time.time()
-    st1, bits1, rec1 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "hooks"), True, 32 | 64 | 128, 1000000, 64)
+    st1, bits1, rec1 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "hooks"), True, 32 | 64 | 128 | 256, 1000000, 64, extra=("--LFNST=1",))
     t2 = time.time()
-    print("batched hooks:", {k: st1[k] for k in ("hookCalls", "hookDevice", "hookMismatch", "hookUnsupported", "affine", "errors")}, "plain %.1f s, hooked %.1f s" % (t1 - t0, t2 - t1))
+    print("batched hooks:", {k: st1[k] for k in ("hookCalls", "hookDevice", "hookMismatch", "hookUnsupported", "affine", "lfnst", "errors")}, "plain %.1f s, hooked %.1f s" % (t1 - t0, t2 - t1))
     assert st0["rc"] == 0 and st1["rc"] == 0
     assert st1["errors"] == 0, st1
     assert st1["hookMismatch"] == [0, 0], st1
     assert st1["hookDevice"][0] > 5000 and st1["hookDevice"][1] > 50000, st1
     assert st1["affine"][2] == 0 and st1["affine"][1] > 500, st1          # xAffineMotionEstimation: [calls, on the device, mismatches, unsupported]
+    assert st1["lfnst"][2] == [0, 0] and min(st1["lfnst"][1]) > 1000, st1  # xFwdLfnst / xInvLfnst: [[calls], [on the device], [mismatches]]
     assert bits1 == bits0 and rec1 == rec0
     out = os.path.join(enc_dropin.ROOT, "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "encoder_batched_hooks.txt"), "w") as f:
-            f.write("clip %dx%d, %d pictures, QP %d; plain run %.1f s, hooked run %.1f s (every 3rd supported call of xMotionEstimation / transformNxN(trModes) / xAffineMotionEstimation on the device)\n%r\nbitstream md5 %s (plain %s)\n"
-                    % (W, H, FRAMES, QP, t1 - t0, t2 - t1, {k: st1[k] for k in ("hookCalls", "hookDevice", "hookMismatch", "hookUnsupported", "affine", "errors")}, bits1, bits0))
+            f.write("clip %dx%d, %d pictures, QP %d; plain run %.1f s, hooked run %.1f s (every 3rd supported call of xMotionEstimation / transformNxN(trModes) / xAffineMotionEstimation / xFwdLfnst / xInvLfnst on the device)\n%r\nbitstream md5 %s (plain %s)\n"
+                    % (W, H, FRAMES, QP, t1 - t0, t2 - t1, {k: st1[k] for k in ("hookCalls", "hookDevice", "hookMismatch", "hookUnsupported", "affine", "lfnst", "errors")}, bits1, bits0))

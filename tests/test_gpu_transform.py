@@ -315,3 +315,36 @@ def test_transform_skip_candidate_of_the_fused_chain(ctx, uniform):
         res = (TuResult * n).from_buffer_copy(d_res.to_host(np.uint8).tobytes())
         assert [(r.sse, r.sumAbs, r.absSum) for r in res] == exp, (w, h)
         assert np.array_equal(d_lv.to_host().reshape(n, w * h), exp_lv) and np.array_equal(d_rec.to_host().reshape(n, w * h), exp_rec), (w, h)
+
+
+def test_lfnst_tu_matches_oracle(ctx):
+    """vtmhip_lfnst_tu_batch_dev = TrQuant::xFwdLfnst / xInvLfnst on whole TUs (gather, core multiply, scatter along the scan) vs the oracle restatement;
+    the core matrices are the golden copy of the reference's tables (tests/golden/lfnst.npz)."""
+    import os
+    from vtm_amd.lib import LfnstTuJob
+    L = ol.oracle()
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lfnst.npz"))
+    m8, m4 = np.ascontiguousarray(z["m8"]), np.ascontiguousarray(z["m4"])
+    ctx.lfnst_set_tables(m8, m4)
+    rng = np.random.default_rng(4711)
+    shapes = [(4, 4), (8, 8), (4, 16), (16, 4), (8, 16), (16, 16), (32, 8), (64, 64), (4, 8)]
+    n = 400
+    jobs = (LfnstTuJob * n)()
+    coef = np.zeros(n * 4096, np.int32)
+    exp = coef.copy()
+    for k in range(n):
+        w, h = shapes[k % len(shapes)]
+        mode, index, tr, inv = int(rng.integers(0, 4)), int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        blk = rng.integers(-2000, 2001, w * h).astype(np.int32)
+        coef[k * 4096:k * 4096 + w * h] = blk
+        j = jobs[k]
+        j.coefOff, j.width, j.height, j.mode, j.index, j.transpose, j.inverse = k * 4096, w, h, mode, index, tr, inv
+        M = np.ascontiguousarray((m8 if (w >= 8 and h >= 8) else m4)[mode, index])
+        e = blk.copy()
+        L.vo_lfnst_tu(ol.P(e), w, h, ol.P(M), tr, inv)
+        exp[k * 4096:k * 4096 + w * h] = e
+    d_coef, d_jobs = ctx.to_device(coef), ctx.to_device(np.frombuffer(jobs, np.uint8))
+    ctx.lfnst_tu_batch(d_coef.ptr, d_jobs.ptr, n)
+    got = d_coef.to_host(np.int32)
+    assert np.array_equal(got, exp)
+    assert not np.array_equal(got, coef)

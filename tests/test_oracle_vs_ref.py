@@ -672,3 +672,17 @@ def test_affine_prediction_and_me_equal_reference_members(oracle, reflib):
         oracle.vo_solve_equal(ol.P(a), order, ol.P(pa))
         reflib.ref_solve_equal(ol.P(b), order, ol.P(pb))
         assert np.array_equal(pa, pb)
+
+
+def test_lfnst_scan_positions_equal_reference_tables(oracle, reflib):
+    """the coefficient-scan positions of the LFNST gather / scatter: oracle (loop) and libvtmhip.so (table) vs g_coefTopLeftDiagScan8x8 / g_scanOrder"""
+    from vtm_amd import lib
+    L = lib.load()
+    for w in (4, 8, 16, 32, 64):
+        for h in (4, 8, 16, 32, 64):
+            n = 48 if (w >= 8 and h >= 8) else 16
+            a, b, c = np.zeros(48, np.int32), np.zeros(48, np.int32), np.zeros(48, np.int32)
+            reflib.ref_lfnst_scan(w, h, ol.P(a))
+            oracle.vo_lfnst_scan(w, h, ol.P(b))
+            assert L.vtmhip_lfnst_scan_host(w, h, c.ctypes.data) == lib.OK
+            assert np.array_equal(a[:n], b[:n]) and np.array_equal(a[:n], c[:n]), (w, h, a[:n], b[:n], c[:n])

@@ -39,6 +39,7 @@ int vtmhip_struct_size( int which )
   case 26: return ( int ) sizeof( vtmhip_pis_level );
   case 27: return ( int ) sizeof( vtmhip_affine_me_job );
   case 28: return ( int ) sizeof( vtmhip_affine_me_out );
+  case 29: return ( int ) sizeof( vtmhip_lfnst_tu_job );
   default: return -1;
   }
 }

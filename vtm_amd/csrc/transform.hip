@@ -1192,10 +1192,96 @@ __global__ __launch_bounds__( 256 ) void lfnst_kernel( const int8_t *__restrict_
     dst[lane] = min( 32767, max( -32768, ( acc + 64 ) >> 7 ) );
   }
 }
+
+// TrQuant::xFwdLfnst / xInvLfnst (TrQuant.cpp:340-420, 422-527) on a TU's coefficient block IN PLACE: the low-frequency region is gathered
+// (row-major, or transposed for the intra modes past the diagonal), multiplied with the 16 x 16 / 16 x 48 core matrix and written back along the
+// coefficient scan (forward) -- or the reverse.  The scan positions are the first 16 / 48 of the diagonal scan in 4x4 coefficient groups
+// (g_scanOrder[SCAN_GROUPED_4x4][SCAN_DIAG] / g_coefTopLeftDiagScan8x8): generated here, checked against the reference's tables in the tests.
+__device__ __forceinline__ int lfnst_scan_pos( int k, int width, bool sb8 )   // k-th scan position -> index x + y * width
+{
+  // inside a 4x4 group: up-right diagonals, each from bottom-left to top-right; groups of the 8x8 region in the same diagonal order: (0,0), (0,1), (1,0), (1,1)
+  const int g = k >> 4, i = k & 15;
+  const int dx[16] = { 0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 1, 2, 3, 2, 3, 3 }, dy[16] = { 0, 1, 0, 2, 1, 0, 3, 2, 1, 0, 3, 2, 1, 3, 2, 3 };
+  const int gx = sb8 ? ( g == 2 || g == 3 ) : 0, gy = sb8 ? ( g == 1 || g == 3 ) : 0;
+  return ( gx * 4 + dx[i] ) + ( gy * 4 + dy[i] ) * width;
+}
+
+__global__ __launch_bounds__( 256 ) void lfnst_tu_kernel( const int8_t *__restrict__ tab, int *__restrict__ coefBase, const vtmhip_lfnst_tu_job *__restrict__ jobs, int n )
+{
+  __shared__ int sIn[4][48], sOut[4][48];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int job  = blockIdx.x * 4 + wv;
+  if( job >= n ) return;
+  const vtmhip_lfnst_tu_job j = jobs[job];
+  const int  w = j.width, h = j.height;
+  const bool sb8 = w >= 8 && h >= 8;
+  const int  sbSize = sb8 ? 8 : 4, trSize = sb8 ? 48 : 16, zo = ( ( w == 4 && h == 4 ) || ( w == 8 && h == 8 ) ) ? 8 : 16;
+  const int8_t *M = sb8 ? tab + ( ( j.mode * 2 + j.index ) * 16 ) * 48 : tab + 4 * 2 * 16 * 48 + ( ( j.mode * 2 + j.index ) * 16 ) * 16;
+  int *coef = coefBase + j.coefOff;
+  // region position r (0 .. trSize-1) of the LFNST input / output vector -> (x, y) in the block
+  auto region_xy = [&]( int r, int &x, int &y ) {
+    int row, col;
+    if( sbSize == 4 ) { row = r >> 2; col = r & 3; }
+    else if( r < 32 ) { row = r >> 3; col = r & 7; }
+    else { row = 4 + ( ( r - 32 ) >> 2 ); col = ( r - 32 ) & 3; }
+    // transposed gather: lfnstTemp[col' * sbSize(or 4) ...]: the vector index of block position (x, y) is that of (y, x) in the untransposed layout
+    if( j.transpose ) { x = row; y = col; } else { x = col; y = row; }
+  };
+  if( !j.inverse )
+  {
+    if( lane < trSize ) { int x, y; region_xy( lane, x, y ); sIn[wv][lane] = coef[y * w + x]; }
+    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier();
+    if( lane < trSize )
+    {
+      int acc = 0;
+      if( lane < zo ) { for( int i = 0; i < trSize; i++ ) acc += sIn[wv][i] * ( int ) M[lane * trSize + i]; acc = ( acc + 64 ) >> 7; }
+      sOut[wv][lane] = lane < zo ? acc : 0;
+    }
+    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier();
+    if( lane < trSize ) coef[lfnst_scan_pos( lane, w, sb8 )] = sOut[wv][lane];
+  }
+  else
+  {
+    if( lane < 16 ) sIn[wv][lane] = coef[lfnst_scan_pos( lane, w, sb8 )];
+    __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" ); __builtin_amdgcn_wave_barrier();
+    if( lane < trSize )
+    {
+      int acc = 0;
+      for( int i = 0; i < zo; i++ ) acc += sIn[wv][i] * ( int ) M[i * trSize + lane];
+      int x, y; region_xy( lane, x, y );
+      coef[y * w + x] = min( 32767, max( -32768, ( acc + 64 ) >> 7 ) );
+    }
+  }
+}
 }   // namespace
 
 extern "C"
 {
+
+int vtmhip_lfnst_tu_batch_dev( vtmhip_ctx *ctx, int32_t *d_coefBase, const vtmhip_lfnst_tu_job *d_jobs, int n )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, ctx->lfnstTab, "vtmhip_lfnst_set_tables has not been called" );
+  VTMHIP_REQUIRE( ctx, d_coefBase && d_jobs, "null pointer" );
+  hipLaunchKernelGGL( lfnst_tu_kernel, dim3( ( n + 3 ) / 4 ), dim3( 256 ), 0, ctx->stream, ctx->lfnstTab, d_coefBase, d_jobs, n );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+int vtmhip_lfnst_scan_host( int width, int height, int32_t *pos48 )
+{
+  if( !pos48 || width < 4 || height < 4 ) return VTMHIP_E_INVALID;
+  const bool sb8 = width >= 8 && height >= 8;
+  static const int dx[16] = { 0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 1, 2, 3, 2, 3, 3 }, dy[16] = { 0, 1, 0, 2, 1, 0, 3, 2, 1, 0, 3, 2, 1, 3, 2, 3 };
+  for( int k = 0; k < ( sb8 ? 48 : 16 ); k++ )
+  {
+    const int g = k >> 4, i = k & 15, gx = sb8 ? ( g == 2 || g == 3 ) : 0, gy = sb8 ? ( g == 1 || g == 3 ) : 0;
+    pos48[k] = ( gx * 4 + dx[i] ) + ( gy * 4 + dy[i] ) * width;
+  }
+  return VTMHIP_OK;
+}
 
 int vtmhip_lfnst_set_tables( vtmhip_ctx *ctx, const int8_t *lfnst8x8, const int8_t *lfnst4x4 )
 {

@@ -227,6 +227,10 @@ class Context:
     def pred_affine_blk_batch(self, pic, d_ref, d_dst, d_jobs, n, max_w, max_h):
         self._check(self.L.vtmhip_xPredAffineBlk_batch_dev(self.h, C.byref(pic), d_ref, d_dst, d_jobs, n, max_w, max_h))
 
+    def lfnst_tu_batch(self, d_coef, d_jobs, n):
+        """TrQuant::xFwdLfnst / xInvLfnst (gather, core multiply, scatter) in place on n TU coefficient blocks"""
+        self._check(self.L.vtmhip_lfnst_tu_batch_dev(self.h, d_coef, d_jobs, n))
+
     def kernel_timing(self, enable):
         """HIP events around every launch of the main kernels, on the launch stream (vtmhip_kernel_timing)"""
         self._check(self.L.vtmhip_kernel_timing(self.h, int(enable)))

@@ -198,9 +198,14 @@ class AffineMeOut(C.Structure):
     _fields_ = [("mv", (C.c_int32 * 2) * 3), ("bits", C.c_uint32), ("iterations", C.c_int32), ("refinements", C.c_int32), ("pad", C.c_int32), ("cost", C.c_uint64)]
 
 
+class LfnstTuJob(C.Structure):
+    _fields_ = [("coefOff", C.c_int64), ("width", C.c_int16), ("height", C.c_int16), ("mode", C.c_uint8), ("index", C.c_uint8), ("transpose", C.c_uint8),
+                ("inverse", C.c_uint8)]
+
+
 _STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob,
             TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut, PredJob, FrameTabs, MaskedSadJob, GeoBlendJob, DmvrJob, LfnstJob,
-            PisRow, PisPu, PisLevel, AffineMeJob, AffineMeOut]   # order of vtmhip_struct_size(which)
+            PisRow, PisPu, PisLevel, AffineMeJob, AffineMeOut, LfnstTuJob]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
 _PROTOS = {
@@ -293,6 +298,8 @@ _PROTOS = {
     "vtmhip_xAffineMotionEstimation_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                            C.c_void_p]),
     "vtmhip_xPredAffineBlk_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "vtmhip_lfnst_tu_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "vtmhip_lfnst_scan_host": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     "vtmhip_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "vtmhip_kernel_timing_read": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "vtmhip_merge_cand_satd_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
