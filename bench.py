@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 SIMDS, CLOCK_HZ = 1024, 2.4e9          # 256 CUs x 4 SIMDs, peak shader clock (MI355X_MICROARCH.md)
 KERNELS = ("tz_search_kernel", "tz_raster_cols_kernel", "frac_search_sq_kernel", "full_search_sq_kernel", "full_search_kernel", "motion_comp_kernel", "tu_chain_uni_kernel",
-           "dist_uniform_kernel", "tu_ts_kernel")
+           "dist_uniform_kernel", "tu_ts_kernel", "bdof_kernel")
 
 
 def parse():
@@ -52,11 +52,12 @@ def parse():
     ap.add_argument("--shard", choices=["ctu", "row"], default="ctu", help="--gpus N: raster-scan CTU ranges (balanced) or whole CTU rows")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--luma-only", action="store_true", help="no chroma planes and no BDOF in the final prediction (the round-2 mid-round operating point)")
     ap.add_argument("--serial", action="store_true", help="one stream, no overlap of the levels' chains: clean per-kernel times for profiling")
     return ap.parse_args()
 
 
-def cpu_baseline(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, budget_s):
+def cpu_baseline(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, budget_s, pocs=None, chroma=None):
     """The SAME chain (tests/cpu_pis.py) for a bounded random sample of PUs of every level on one host core, extrapolated per level to the
     picture.  kind "reference": every step through the real VTM 9.3 members compiled in place (xEstimateMvPredAMVP, xMotionEstimation,
     xCheckBestMVP, filterHor / filterVer, removeHighFreq / addAvg, TrQuant::xT / xIT, distFunc with the x86 SIMD tables; quant / dequant: the
@@ -84,7 +85,7 @@ def cpu_baseline(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, budget_s):
             cands = cpu_pis.cands_of(lvl, hp.nref, i)
             t0 = time.perf_counter()
             out = cpu_pis.run_pu(cur_np, dpb_np.ctypes.data, refs, sr, W, H, s, int(lvl["xs"][i]), int(lvl["ys"][i]), cands, lam, (qp + 12) // 6, (qp + 12) % 6,
-                                 lvl["cands"], ref=R)
+                                 lvl["cands"], ref=R, pocs=pocs, chroma=chroma)
             t_lvl += time.perf_counter() - t0
             n_lvl += 1
             try:
@@ -153,19 +154,39 @@ def main():
         cur_poc = 4
         pocs = ([3, 2, 1, 0], [])
         sr = ([64] * 4, [])
-    frames = synth.gen_frames(W, H, max(pocs[0] + pocs[1] + [cur_poc]) + 1)
-    cur_np = np.ascontiguousarray(frames[cur_poc])
-    planes, refs, off_acc, seen = [], ([], []), 0, {}
+    with_c = not a.luma_only
+    frames = synth.gen_frames(W, H, max(pocs[0] + pocs[1] + [cur_poc]) + 1, chroma=with_c)
+    planes, refs, refs_c, off_acc, seen, rsc = [], ([], []), ([], []), 0, {}, 0
     for l in (0, 1):
         for p in pocs[l]:
-            if p not in seen:
-                buf, off, stride = synth.extend_plane(frames[p], margin=160)
-                seen[p] = (off_acc + off, stride)
+            if p not in seen:      # one reference picture = its extended luma plane, then (4:2:0) its extended Cb and Cr planes
+                buf, off, stride = synth.extend_plane(frames[p][0] if with_c else frames[p], margin=160)
+                ent = [(off_acc + off, stride), None]
                 planes.append(buf.reshape(-1))
                 off_acc += buf.size
-            refs[l].append(seen[p])
+                if with_c:
+                    offs = []
+                    for c in (1, 2):
+                        buf, off, rsc = synth.extend_plane(frames[p][c], margin=80)
+                        offs.append(off_acc + off)
+                        planes.append(buf.reshape(-1))
+                        off_acc += buf.size
+                    ent[1] = tuple(offs)
+                seen[p] = ent
+            refs[l].append(seen[p][0])
+            refs_c[l].append(seen[p][1])
     dpb_np = np.concatenate(planes)
-    cur = torch.from_numpy(cur_np).to(dev)
+    if with_c:
+        cur_np, cu, cv = (np.ascontiguousarray(x) for x in frames[cur_poc])
+        cur = torch.from_numpy(np.concatenate([cur_np.reshape(-1), cu.reshape(-1), cv.reshape(-1)])).to(dev)      # the original picture: Y | Cb | Cr
+        ch_dev = dict(org_off=(W * H, W * H + (W // 2) * (H // 2)), org_stride=W // 2, refs=refs_c, ref_stride=rsc)
+        cqp = pipeline.chroma_qp(a.qp) + 12
+        ch_cpu = dict(cur=(cu, cv), refs=refs_c, ref_stride=rsc, qp_per=cqp // 6, qp_rem=cqp % 6)
+        poc_arg = (cur_poc, pocs[0], pocs[1])
+    else:
+        cur_np = np.ascontiguousarray(frames[cur_poc])
+        cur = torch.from_numpy(cur_np).to(dev)
+        ch_dev = ch_cpu = poc_arg = None
     dpb = torch.from_numpy(dpb_np).to(dev)
 
     ctx = Context(local)
@@ -173,7 +194,7 @@ def main():
     lam, qp = 8.0, a.qp
     bands = pipeline.ctu_bands(W, H, world, unit=a.shard)
     ctu_filter = pipeline.band_filter(W, bands[rank]) if world > 1 else None
-    fme = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, ctu_filter=ctu_filter, transform_skip=a.transform_skip)
+    fme = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, ctu_filter=ctu_filter, transform_skip=a.transform_skip, pocs=poc_arg, chroma=ch_dev)
 
     # N > 1: the reconstructed reference planes go from rank 0 to every GPU inside every step (RCCL broadcast over xGMI; bytes view: int16 is
     # not a collective dtype), double-buffered: the planes of step k + 1 travel while step k computes; the ranks' result records go back to rank 0
@@ -266,10 +287,12 @@ def main():
         mix, pmc_i, pmc_b = load_json("isa_mix.json") or {}, load_json("pmc_insts_per_launch.json") or {}, load_json("pmc_hbm_traffic_per_launch_KB.json") or {}
         dom = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
 
-        def issue_roofline(name, ms, launches):
+        def issue_roofline(name, ms, launches, in_step=True):
+            # in_step: the kernel runs inside the picture step -> counters summed over its launches of one step; otherwise (the SATD micro-benchmark) ONE launch
             cpi = next((v["cycles_per_valu_inst"] for k, v in mix.items() if isinstance(v, dict) and k.startswith(name)), None)
-            insts = sum(v.get("SQ_INSTS_VALU", 0) * v.get("launches_per_step", 1) for k, v in pmc_i.items() if k.startswith(name)) or None
-            traffic = sum((2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 * v.get("launches_per_step", 1) for k, v in pmc_b.items() if k.startswith(name)) or None
+            lps = (lambda v: v.get("launches_per_step", 1)) if in_step else (lambda v: 1)
+            insts = sum(v.get("SQ_INSTS_VALU", 0) * lps(v) for k, v in pmc_i.items() if k.startswith(name)) or None
+            traffic = sum((2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 * lps(v) for k, v in pmc_b.items() if k.startswith(name)) or None
             r = {"bound": "valu_issue", "kernel": name, "unit": "G wave-instructions/s", "ms_per_step": ms, "launches_per_step": launches,
                  "ms_per_launch": ms / max(1, launches), "insts": insts, "cycles_per_inst": cpi, "traffic": (traffic / launches) if traffic else None}
             if cpi:
@@ -282,9 +305,10 @@ def main():
             if traffic:
                 r["hbm_GBps"] = traffic / (ms * 1e-3) / 1e9
                 r["hbm_frac"] = r["hbm_GBps"] / 8000.0
-            r["note"] = ("insts = SQ_INSTS_VALU per step (committed rocprofv3 --pmc pass of this command, profiles/); cycles_per_inst = the kernel's static loop-weighted "
-                         "instruction mix priced with the measured gfx950 issue costs (2.1 cycles full-rate, 4.1 half-rate opcodes; profiles/r02_valu_issue.jsonl, "
-                         "profiles/isa_mix.json); peak = 1024 SIMDs x 2.4 GHz / cycles_per_inst; time measured live with HIP events on the launch stream; "
+            r["note"] = ("insts = SQ_INSTS_VALU per step (committed rocprofv3 --pmc pass of this command, profiles/); cycles_per_inst = the measured gfx950 issue cost of a "
+                         "MIXED wave64 instruction stream at this kernel's static share of half-rate opcodes (pure full-rate streams issue at 2.1 cycles, any stream with "
+                         ">= 12 % packed-16 / sad / dot / min-max / mul / cmp opcodes at 3.5 .. 4.0: the imix rows of profiles/r02_valu_issue.jsonl; profiles/isa_mix.json); "
+                         "peak = 1024 SIMDs x 2.4 GHz / cycles_per_inst; time measured live with HIP events on the launch stream; "
                          "traffic = HBM-side bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE)")
             return r
 
@@ -300,7 +324,8 @@ def main():
                                       "SR 96 via ASR" if a.config == "ra" else "SR 64", wc["pus"] * world if world > 1 else wc["pus"], len(refs[0]), len(refs[1]),
                                       wc["uni_searches"], wc["bi_searches"], wc["tu_chains"]) + (" (this rank's share)" if world > 1 else ""),
                        "stages": ["xEstimateMvPredAMVP", "xMotionEstimation uni (TZ + frac)", "xCheckBestMVP / best reference", "bi refinement (MC + removeHighFreq fused, xPatternSearch, frac)",
-                                  "uni/bi decision", "final prediction + residual (fused)", "tu_chain (xT, quant, dequant, xIT, SSE)"],
+                                  "uni/bi decision", "final prediction + residual (fused)" + ("" if a.luma_only else "; BDOF where xPredInterBi applies it; Cb / Cr prediction + residual"),
+                                  "tu_chain (xT, quant, dequant, xIT, SSE)" + ("" if a.luma_only else ", luma MTS candidates + chroma DCT2 at the mapped chroma QP")],
                        "order": "one stream" if a.serial else "level-major over 5 side streams (each level's later stages run beside the next levels' searches)",
                        "parallelism": ("1 GPU" if world == 1 else "one picture, CTUs sharded over %d GPUs (%s): bands %s; planes broadcast from rank 0, results gathered to rank 0 every step"
                                        % (world, "raster-scan CTU ranges" if a.shard == "ctu" else "whole CTU rows", [b[1] - b[0] for b in bands]))},
@@ -310,11 +335,11 @@ def main():
         if dom:
             out["roofline"] = issue_roofline(dom, kern[dom]["ms_per_step"], kern[dom]["launches_per_step"])
         if satd_k_n:
-            r = issue_roofline("satd8_grid_kernel", satd_k_ms / satd_k_n, 1)
+            r = issue_roofline("satd8_grid_kernel", satd_k_ms / satd_k_n, 1, in_step=False)
             r["pairs_per_s_G"] = nb * 81 / (satd_k_ms / satd_k_n) / 1e6
             out["satd_roofline"] = r
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fme, cur_np, dpb_np, refs, sr, W, H, lam, qp, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(fme, cur_np, dpb_np, refs, sr, W, H, lam, qp, a.cpu_seconds, pocs=poc_arg, chroma=ch_cpu)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()

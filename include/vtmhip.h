@@ -380,7 +380,9 @@ typedef struct
   int16_t width, height;
   uint8_t mode;                 /* 0: uni-prediction from list 0, 1: from list 1, 2: bi-prediction (two 14-bit predictions, addAvg) */
   uint8_t epilogue;             /* 0: none; 1: out = org - pred (residual, InterSearch.cpp:7260-7262); 2: out = 2*org - pred (removeHighFreq) */
-  uint8_t bitDepth, useAltHpelIf, chroma, pad0;
+  uint8_t bitDepth, useAltHpelIf, chroma;
+  uint8_t route;                /* 0: every call processes the job; a driver that launches BOTH vtmhip_motion_compensation_batch_dev and vtmhip_bdof_batch_dev over
+                                   one table marks each job on the device: 1 = BDOF's (the plain call skips it), 2 = the plain call's (BDOF skips it) */
   int16_t pad1;
 } vtmhip_pred_job;
 
@@ -768,6 +770,14 @@ typedef struct
   const vtmhip_pis_row *parentRows;/* the parent level's uniRows */
   int32_t  parentNumPU, pad;
   const int64_t        *pos;       /* [numPU] y * refStride + x */
+  /* final prediction of the chosen mode (InterPrediction::motionCompensation with luma and chroma): BDOF where xPredInterBi applies it (:527-572) and
+   * the two 4:2:0 chroma planes */
+  int32_t  bdofEnabled;            /* sps.getBDOFEnabledFlag() && !picHeader.getDisBdofFlag() */
+  int32_t  curPoc;
+  int32_t  refPoc[2][VTMHIP_MAX_REF];
+  vtmhip_pred_job      *predFinalC;/* [2 * numPU] or NULL: the Cb jobs, then the Cr jobs (static fields by the host; mode / refOff / mv by the final stage) */
+  const int64_t        *posC;      /* [numPU] (y / 2) * refStrideC + x / 2 */
+  int64_t  refPlaneOffC[2][2][VTMHIP_MAX_REF];   /* [Cb / Cr][list][refIdx] sample offset of the chroma plane's (0,0) inside d_refBase */
 } vtmhip_pis_level;
 
 /* stage 0: AMVP candidates and entry bits of the uni rows (before vtmhip_xEstimateMvPredAMVP_batch_dev)

@@ -8,7 +8,9 @@
 // ticks, MI355X_MICROARCH.md constants table); reported: cycles per wave-instruction per SIMD = mean(ticks) / (W * instructions) and max/mean (the scheduler favours
 // older waves, so with 4+ waves per SIMD they finish at different times: the steady-state issue cost is max(ticks) / (W * instructions)).  A value of
 // 2 is the full wave64 rate of a SIMD-32 (32 lanes per cycle), 4 = half rate, 8 = quarter rate.  The DESIGN.md roofline for the VALU-bound
-// kernels (`bound: "valu_issue"`) prices each kernel's dynamic instruction mix with these numbers.
+// kernels (`bound: "valu_issue"`) prices each kernel's instruction mix with these numbers.  The "imix" rows answer how MIXED streams issue: a stream
+// with any sizeable share of half-rate opcodes runs at 3.7 .. 4.0 cycles per instruction whatever the order (it is NOT the share-weighted sum
+// of the two rates), so scripts/isa_mix.py prices a kernel by interpolating these rows at the kernel's half-rate share.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -115,6 +117,10 @@ static constexpr int TRIPS = 1500;
 #define OP_MIX_ADDSUB( i )   "v_pk_add_i16 %" #i ", %" #i ", %8\nv_pk_sub_i16 %" #i ", %" #i ", %9\n"
 #define OP_MIX_VS( i )       "v_pk_add_i16 %" #i ", %" #i ", %8\ns_add_u32 s20, s20, 1\n"               /* VALU + SALU pairs: do they co-issue? */
 
+#define OP_MIX_FH( i )       "v_add_u32 %" #i ", %" #i ", %8\nv_pk_add_i16 %" #i ", %" #i ", %9\n"             /* full-rate + half-rate alternating */
+#define OP_MIX_FFFH( i )     "v_add_u32 %" #i ", %" #i ", %8\nv_xor_b32 %" #i ", %" #i ", %9\nv_sub_u32 %" #i ", %" #i ", %8\nv_pk_add_i16 %" #i ", %" #i ", %9\n"
+#define OP_MIX_FHHH( i )     "v_add_u32 %" #i ", %" #i ", %8\nv_pk_sub_i16 %" #i ", %" #i ", %9\nv_pk_max_i16 %" #i ", %" #i ", %8\nv_pk_add_i16 %" #i ", %" #i ", %9\n"
+
 template<int OPID, int CH>
 __global__ void __launch_bounds__( 1024 ) bench_kernel( uint32_t *sink, uint64_t *ticks, uint32_t seed )
 {
@@ -152,6 +158,19 @@ __global__ void __launch_bounds__( 1024 ) bench_kernel( uint32_t *sink, uint64_t
     SPECIAL( 65, OP_CMP_E64, "s22", "s23" )
     SPECIAL( 66, OP_CMP_CND, "vcc" )
     SPECIAL( 69, OP_ABS_PAIR, "vcc" )
+    SPECIAL( 70, OP_MIX_FH, "vcc" )
+    SPECIAL( 71, OP_MIX_FFFH, "vcc" )
+    SPECIAL( 72, OP_MIX_FHHH, "vcc" )
+    // independent mixes: every chain keeps ONE opcode; neighbouring instructions of a wave never depend on each other
+#define MIXI( ID, O0, O1, O2, O3, O4, O5, O6, O7 ) if constexpr( OPID == ID ) { asm volatile( REP8( O0( 0 ), O1( 1 ), O2( 2 ), O3( 3 ), O4( 4 ), O5( 5 ), O6( 6 ), O7( 7 ) ) REP8( O0( 0 ), O1( 1 ), O2( 2 ), O3( 3 ), O4( 4 ), O5( 5 ), O6( 6 ), O7( 7 ) ) REP8( O0( 0 ), O1( 1 ), O2( 2 ), O3( 3 ), O4( 4 ), O5( 5 ), O6( 6 ), O7( 7 ) ) REP8( O0( 0 ), O1( 1 ), O2( 2 ), O3( 3 ), O4( 4 ), O5( 5 ), O6( 6 ), O7( 7 ) ) : "+v"( a[0] ), "+v"( a[1] ), "+v"( a[2] ), "+v"( a[3] ), "+v"( a[4] ), "+v"( a[5] ), "+v"( a[6] ), "+v"( a[7] ) : "v"( s0 ), "v"( s1 ) ); }
+    MIXI( 73, OP_ADD_U32, OP_PK_ADD_I16, OP_ADD_U32, OP_PK_ADD_I16, OP_ADD_U32, OP_PK_ADD_I16, OP_ADD_U32, OP_PK_ADD_I16 )
+    MIXI( 74, OP_ADD_U32, OP_SUB_U32, OP_XOR, OP_PK_ADD_I16, OP_ADD_U32, OP_SUB_U32, OP_XOR, OP_PK_SUB_I16 )
+    MIXI( 75, OP_ADD_U32, OP_PK_ADD_I16, OP_PK_SUB_I16, OP_PK_MAX_I16, OP_SUB_U32, OP_PK_ADD_I16, OP_PK_SUB_I16, OP_PK_MAX_I16 )
+    MIXI( 76, OP_ADD_U32, OP_MAX_I32, OP_SUB_U32, OP_MAX_I32, OP_ADD_U32, OP_MAX_I32, OP_SUB_U32, OP_MAX_I32 )
+    MIXI( 77, OP_ADD_U32, OP_ADD_U32, OP_ADD_U32, OP_ADD_U32, OP_PK_ADD_I16, OP_PK_ADD_I16, OP_PK_ADD_I16, OP_PK_ADD_I16 )
+    MIXI( 80, OP_ADD_U32, OP_SUB_U32, OP_XOR, OP_AND_B32, OP_ADD_U32, OP_SUB_U32, OP_OR, OP_PK_ADD_I16 )
+    MIXI( 78, OP_ADD_U32, OP_SUB_U32, OP_ADD_U32, OP_SUB_U32, OP_XOR, OP_AND_B32, OP_ASHR, OP_OR )
+    MIXI( 79, OP_PK_ADD_I16, OP_MAX_I32, OP_PK_SUB_I16, OP_SAD_U16, OP_PERM, OP_MAD_I24, OP_LSHL, OP_BFE_I32 )
     if constexpr( OPID == 31 ) { asm volatile( REP8( OP_MAD_U64_U32( 0 ), OP_MAD_U64_U32( 1 ), OP_MAD_U64_U32( 2 ), OP_MAD_U64_U32( 3 ), OP_MAD_U64_U32( 4 ), OP_MAD_U64_U32( 5 ), OP_MAD_U64_U32( 6 ), OP_MAD_U64_U32( 7 ) ) : "+v"( a[0] ), "+v"( a[1] ), "+v"( a[2] ), "+v"( a[3] ), "+v"( a[4] ), "+v"( a[5] ), "+v"( a[6] ), "+v"( a[7] ) : "v"( s0 ), "v"( s1 ) : "v100", "v101", "vcc" ); }
     if constexpr( OPID == 44 ) { asm volatile( REP8( OP_CVT_F64( 0 ), OP_CVT_F64( 1 ), OP_CVT_F64( 2 ), OP_CVT_F64( 3 ), OP_CVT_F64( 4 ), OP_CVT_F64( 5 ), OP_CVT_F64( 6 ), OP_CVT_F64( 7 ) ) : "+v"( a[0] ), "+v"( a[1] ), "+v"( a[2] ), "+v"( a[3] ), "+v"( a[4] ), "+v"( a[5] ), "+v"( a[6] ), "+v"( a[7] ) : "v"( s0 ), "v"( s1 ) : "v100", "v101" ); }
     if constexpr( OPID == 45 ) { asm volatile( REP8( OP_MUL_F64( 0 ), OP_MUL_F64( 1 ), OP_MUL_F64( 2 ), OP_MUL_F64( 3 ), OP_MUL_F64( 4 ), OP_MUL_F64( 5 ), OP_MUL_F64( 6 ), OP_MUL_F64( 7 ) ) : "+v"( a[0] ), "+v"( a[1] ), "+v"( a[2] ), "+v"( a[3] ), "+v"( a[4] ), "+v"( a[5] ), "+v"( a[6] ), "+v"( a[7] ) : "v"( s0 ), "v"( s1 ) : "v100", "v101", "v102", "v103" ); }
@@ -180,6 +199,11 @@ static const Op OPS[] = {
   { 57, "v_mul_i32_i24_sdwa", 32 }, { 58, "v_sub_u32_sdwa", 32 }, { 59, "v_lshl_add_u64", 32 }, { 60, "v_mov_b64", 32 }, { 61, "v_lshl_or_b32", 32 }, { 62, "v_med3_i32", 32 },
   { 63, "v_min_u32_dpp row_shr", 32 }, { 64, "v_cndmask_b32 (sgpr-pair mask)", 32 }, { 65, "v_cmp_lt_i32 e64 -> sgpr pair", 32 },
   { 66, "pair: v_cmp_lt_i32 vcc + v_cndmask_b32 vcc", 64 }, { 67, "v_addc_co_u32", 32 }, { 68, "v_bfe_u32", 32 }, { 69, "pair: |x| packed = v_pk_sub_i16(0-x) + v_pk_max_i16", 64 },
+  { 70, "mix: v_add_u32 + v_pk_add_i16 (1 full : 1 half)", 64 }, { 71, "mix: 3 full-rate + 1 half-rate", 128 }, { 72, "mix: 1 full-rate + 3 half-rate", 128 },
+  { 73, "imix: add_u32 / pk_add_i16 alternating, independent chains (1 full : 1 half)", 32 }, { 74, "imix: 3 full : 1 half, independent chains", 32 },
+  { 75, "imix: 1 full : 3 half, independent chains", 32 }, { 76, "imix: add_u32 / max_i32 alternating (1 full : 1 half)", 32 },
+  { 77, "imix: 4 add_u32 then 4 pk_add_i16 (runs of four)", 32 }, { 78, "imix: eight different full-rate opcodes", 32 }, { 79, "imix: eight different half-rate opcodes", 32 },
+  { 80, "imix: 7 full : 1 half, independent chains", 32 },
   { 48, "mix: v_perm_b32 -> v_dot2c_i32_i16 (dependent pair)", 64 }, { 49, "mix: v_pk_add_i16 + v_pk_sub_i16", 64 }, { 50, "mix: v_pk_add_i16 + s_add_u32 (pairs)", 32 },
 };
 
@@ -204,7 +228,7 @@ template<int... IDS> static void dispatch( Seq<IDS...>, int id, int ch, int grid
 template<int N, int... IDS> struct MakeSeq : MakeSeq<N - 1, N - 1, IDS...> {};
 template<int... IDS> struct MakeSeq<0, IDS...> { using type = Seq<IDS...>; };
 
-int main()
+int main( int argc, char **argv )   // optional arguments: the op ids to run (default: all)
 {
   hipDeviceProp_t prop;
   CHECK( hipGetDeviceProperties( &prop, 0 ) );
@@ -217,6 +241,9 @@ int main()
   for( const Op &op : OPS )
     for( int ch : { 8, 1 } )
     {
+      bool wanted = argc <= 1;
+      for( int k = 1; k < argc; k++ ) wanted |= atoi( argv[k] ) == op.id;
+      if( !wanted ) continue;
       if( ch == 1 && ( op.id == 31 || ( op.id >= 43 && op.id <= 50 ) || op.id == 59 || op.id == 60 || op.id >= 64 ) ) continue;
       for( int w : wavesPerSimd )
       {
@@ -227,9 +254,9 @@ int main()
         const int grid    = nCU * wgPerCU;
         hipEvent_t e0, e1;
         CHECK( hipEventCreate( &e0 ) ); CHECK( hipEventCreate( &e1 ) );
-        dispatch( MakeSeq<70>::type(), op.id, ch, grid, block, lds, sink, ticks );   // warm-up (clocks, code fetch)
+        dispatch( MakeSeq<81>::type(), op.id, ch, grid, block, lds, sink, ticks );   // warm-up (clocks, code fetch)
         CHECK( hipEventRecord( e0 ) );
-        dispatch( MakeSeq<70>::type(), op.id, ch, grid, block, lds, sink, ticks );
+        dispatch( MakeSeq<81>::type(), op.id, ch, grid, block, lds, sink, ticks );
         CHECK( hipEventRecord( e1 ) );
         CHECK( hipDeviceSynchronize() );
         float ms = 0;

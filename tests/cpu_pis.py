@@ -57,7 +57,32 @@ def _check_best(L, R, lam, cands, row):
     return dict(mv=row["mv"], pred=(ph.value, pv.value), idx=idx.value, bits=bits.value, cost=cost.value)
 
 
-def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam, qp_per, qp_rem, tu_cands, ref=None, bd=10):
+def _tu_chain(L, R, r_tu, ts, mts, qp_per, qp_rem, bd):
+    """one TU, one transform candidate: xT (or transform skip), Quant::quant, dequant, xIT, SSE -> (sse, sum |coef|, absSum)"""
+    coef, qc, dq, asum = np.zeros(ts * ts, np.int32), np.zeros(ts * ts, np.int32), np.zeros(ts * ts, np.int32), C.c_int32()
+    rec = np.zeros((ts, ts), np.int16)
+    if mts == 1:      # transform skip: xTransformSkip / xITransformSkip are copies
+        coef[:] = r_tu.reshape(-1)
+        L.vo_quant(ol.P(coef), ts, ts, bd, qp_per, qp_rem, 0, 1, ol.P(qc), None, C.byref(asum))
+        L.vo_dequant(ol.P(qc), ts, ts, bd, qp_per, qp_rem, 1, ol.P(dq))
+        rec[:] = dq.reshape(ts, ts).astype(np.int16)
+    else:
+        th, tv = MTS_IDX_TYPES[mts]
+        if R is None:
+            assert L.vo_fwd_2d(ol.P(r_tu), ts, ts, ts, bd, th, tv, ol.P(coef)) == 0
+        else:
+            R.ref_xT(ol.P(r_tu), ts, ts, ts, bd, mts, ol.P(coef))          # the real TrQuant::xT
+        L.vo_quant(ol.P(coef), ts, ts, bd, qp_per, qp_rem, 0, 0, ol.P(qc), None, C.byref(asum))
+        L.vo_dequant(ol.P(qc), ts, ts, bd, qp_per, qp_rem, 0, ol.P(dq))
+        if R is None:
+            assert L.vo_inv_2d(ol.P(dq), ts, ts, bd, th, tv, ol.P(rec), ts) == 0
+        else:
+            R.ref_xIT(ol.P(dq), ts, ts, bd, mts, ol.P(rec), ts)             # the real TrQuant::xIT
+    sse = ol.r_dist(2, 0, r_tu, rec, ts, ts, bd) if R else ol.o_dist(2, r_tu, rec, ts, ts)
+    return (int(sse), int(np.abs(coef.astype(np.int64)).sum()), asum.value)
+
+
+def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam, qp_per, qp_rem, tu_cands, ref=None, bd=10, pocs=None, bdof=True, chroma=None):
     """refs / search_ranges as FrameHotPath takes them; cands_rows[list][refIdx] = the two AMVP candidates of that row ((h, v), (h, v)) as the
     device driver derived them from the parent level.  Returns every decision the device pipeline exposes."""
     L, R = ol.oracle(), ref
@@ -119,7 +144,19 @@ def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam,
     out["inter_dir"] = inter_dir
     # ---- final prediction and residual (motionCompensation; InterSearch.cpp:7260-7262) ----
     pred = np.zeros((s, s), np.int16)
-    if inter_dir == 3:
+    bio = False
+    if inter_dir == 3 and pocs is not None and bdof:     # InterPrediction::xPredInterBi :527-572 / PU::isBiPredFromDifferentDirEqDistPoc
+        d0, d1 = pocs[0] - pocs[1][ref_final[0]], pocs[0] - pocs[2][ref_final[1]]
+        bio = d0 * d1 < 0 and abs(d0) == abs(d1) and s >= 8 and s * s >= 128
+    out["bio"] = bio
+    if bio:
+        if R:
+            R.ref_bdof_pu(1, C.c_void_p(dpb_ptr + 2 * refs[0][ref_final[0]][0]), C.c_void_p(dpb_ptr + 2 * refs[1][ref_final[1]][0]), rs, W, H, x, y, s, s,
+                          mv_final[0][0], mv_final[0][1], mv_final[1][0], mv_final[1][1], bd, ol.P(pred), s)
+        else:
+            L.vo_bdof_pu(C.c_void_p(dpb_ptr + 2 * (refs[0][ref_final[0]][0] + y * rs + x)), rs, C.c_void_p(dpb_ptr + 2 * (refs[1][ref_final[1]][0] + y * rs + x)), rs, s, s,
+                         mv_final[0][0], mv_final[0][1], mv_final[1][0], mv_final[1][1], bd, ol.P(pred), s)
+    elif inter_dir == 3:
         p = [np.zeros((s, s), np.int16) for _ in range(2)]
         for l in (0, 1):
             _mc(L, R, dpb_ptr + 2 * (refs[l][ref_final[l]][0] + y * rs + x), rs, s, mv_final[l][0], mv_final[l][1], 1, p[l], bd)
@@ -137,27 +174,36 @@ def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam,
         for qx in range(q):
             r_tu = np.ascontiguousarray(resi[qy * ts:(qy + 1) * ts, qx * ts:(qx + 1) * ts])
             for ci, mts in enumerate(tu_cands):
-                coef, qc, dq, asum = np.zeros(ts * ts, np.int32), np.zeros(ts * ts, np.int32), np.zeros(ts * ts, np.int32), C.c_int32()
-                rec = np.zeros((ts, ts), np.int16)
-                if mts == 1:      # transform skip: xTransformSkip / xITransformSkip are copies
-                    coef[:] = r_tu.reshape(-1)
-                    L.vo_quant(ol.P(coef), ts, ts, bd, qp_per, qp_rem, 0, 1, ol.P(qc), None, C.byref(asum))
-                    L.vo_dequant(ol.P(qc), ts, ts, bd, qp_per, qp_rem, 1, ol.P(dq))
-                    rec[:] = dq.reshape(ts, ts).astype(np.int16)
+                out["tus"][(qy * q + qx, ci)] = _tu_chain(L, R, r_tu, ts, mts, qp_per, qp_rem, bd)
+    # ---- the 4:2:0 chroma planes: xPredInterBlk with the 4-tap filter at 1/32 phase, addAvg, residual, DCT2 chain at the chroma QP ----
+    if chroma is not None:
+        sc, rsc = s // 2, chroma["ref_stride"]
+        out["tus_c"] = {}
+        for c in (0, 1):
+            org_c = np.ascontiguousarray(chroma["cur"][c][y // 2:y // 2 + sc, x // 2:x // 2 + sc])
+
+            def mc_c(l, bi, dst):
+                plane = dpb_ptr + 2 * chroma["refs"][l][ref_final[l]][c]
+                if R:
+                    R.ref_pred_inter_blk(1 + c, C.c_void_p(dpb_ptr + 2 * refs[l][ref_final[l]][0]), rs, C.c_void_p(plane), rsc, W, H, x, y, s, s, mv_final[l][0], mv_final[l][1],
+                                         bi, bd, 0, ol.P(dst), sc)
                 else:
-                    th, tv = MTS_IDX_TYPES[mts]
-                    if R is None:
-                        assert L.vo_fwd_2d(ol.P(r_tu), ts, ts, ts, bd, th, tv, ol.P(coef)) == 0
-                    else:
-                        R.ref_xT(ol.P(r_tu), ts, ts, ts, bd, mts, ol.P(coef))          # the real TrQuant::xT
-                    L.vo_quant(ol.P(coef), ts, ts, bd, qp_per, qp_rem, 0, 0, ol.P(qc), None, C.byref(asum))
-                    L.vo_dequant(ol.P(qc), ts, ts, bd, qp_per, qp_rem, 0, ol.P(dq))
-                    if R is None:
-                        assert L.vo_inv_2d(ol.P(dq), ts, ts, bd, th, tv, ol.P(rec), ts) == 0
-                    else:
-                        R.ref_xIT(ol.P(dq), ts, ts, bd, mts, ol.P(rec), ts)             # the real TrQuant::xIT
-                sse = ol.r_dist(2, 0, r_tu, rec, ts, ts, bd) if R else ol.o_dist(2, r_tu, rec, ts, ts)
-                out["tus"][(qy * q + qx, ci)] = (int(sse), int(np.abs(coef.astype(np.int64)).sum()), asum.value)
+                    L.vo_mc_block(1 + c, C.c_void_p(plane + 2 * ((y // 2) * rsc + x // 2)), rsc, sc, sc, mv_final[l][0], mv_final[l][1], bi, bd, 0, ol.P(dst), sc)
+            pc = np.zeros((sc, sc), np.int16)
+            if inter_dir == 3:
+                pp = [np.zeros((sc, sc), np.int16) for _ in range(2)]
+                for l in (0, 1):
+                    mc_c(l, 1, pp[l])
+                (R.ref_add_avg if R else L.vo_add_avg)(ol.P(pp[0]), sc, ol.P(pp[1]), sc, ol.P(pc), sc, sc, sc, bd)
+            else:
+                mc_c(inter_dir - 1, 0, pc)
+            resi_c = (org_c.astype(np.int32) - pc).astype(np.int16)
+            tsc = min(sc, 32)
+            qc = sc // tsc
+            for qy in range(qc):
+                for qx in range(qc):
+                    r_tu = np.ascontiguousarray(resi_c[qy * tsc:(qy + 1) * tsc, qx * tsc:(qx + 1) * tsc])
+                    out["tus_c"][(c, qy * qc + qx)] = _tu_chain(L, R, r_tu, tsc, 0, chroma["qp_per"], chroma["qp_rem"], bd)
     return out
 
 
@@ -207,6 +253,16 @@ def compare_with_device(snap_level, parent_level, nref, i, out):
         k = ci * ntu + i * q * q + tu
         got = (int(tr[k, 0]), int(tr[k, 1] & 0xFFFFFFFF), int((tr[k, 1] >> 32) & 0xFFFFFFFF))
         assert (sse, sa, asum) == got, ("tu", s, i, tu, ci, (sse, sa, asum), got)
+    if "route" in snap_level:
+        assert int(snap_level["route"][i]) == (1 if out["bio"] else 2), ("BDOF routing", s, i)
+    if "tus_c" in out:
+        ntc, sc, tsc = snap_level["ntu_c"], s // 2, snap_level["ts_c"]
+        qc = sc // tsc
+        trc = snap_level["tu_res_c"]
+        for (c, tu), (sse, sa, asum) in out["tus_c"].items():
+            k = c * ntc + i * qc * qc + tu
+            got = (int(trc[k, 0]), int(trc[k, 1] & 0xFFFFFFFF), int((trc[k, 1] >> 32) & 0xFFFFFFFF))
+            assert (sse, sa, asum) == got, ("chroma tu", s, i, c, tu, (sse, sa, asum), got)
     # the AMVP candidates themselves: candidate 0 is the parent's vector for the same (list, refIdx), candidate 1 zero
     if parent_level is not None:
         ps = parent_level["size"]

@@ -14,38 +14,65 @@ from vtm_amd.pipeline import FrameHotPath
 pytestmark = pytest.mark.gpu
 
 
-def make_scene(torch, dev, W, H, pocs0, pocs1, cur_poc, hard=True):
+def make_scene(torch, dev, W, H, pocs0, pocs1, cur_poc, hard=True, chroma=False):
+    """-> (cur_np, dpb_np, refs, sr, cur, dpb[, chroma_dev, chroma_cpu]): with chroma=True the original buffer is Y | Cb | Cr, every reference picture's
+    extended Cb / Cr planes follow its luma plane in the reference buffer, and the two dicts are FrameHotPath's / cpu_pis.run_pu's `chroma` arguments"""
     nfr = max(pocs0 + pocs1 + [cur_poc]) + 1
-    frames = (synth.gen_frames_hard if hard else synth.gen_frames)(W, H, nfr)
+    frames = (synth.gen_frames_hard if hard else synth.gen_frames)(W, H, nfr, chroma=chroma)
     planes, refs, acc = [], ([], []), 0
+    refs_c = ([], [])
     cache = {}
+    rsc = 0
     for l, pocs in enumerate((pocs0, pocs1)):
         for p in pocs:
             if p not in cache:
-                buf, off, stride = synth.extend_plane(frames[p], margin=160)
-                cache[p] = (acc + off, stride)
+                buf, off, stride = synth.extend_plane(frames[p][0] if chroma else frames[p], margin=160)
+                ent = [(acc + off, stride)]
                 planes.append(buf.reshape(-1))
                 acc += buf.size
-            refs[l].append(cache[p])
-    cur_np = np.ascontiguousarray(frames[cur_poc])
+                if chroma:
+                    offs = []
+                    for c in (1, 2):
+                        buf, off, rsc = synth.extend_plane(frames[p][c], margin=80)
+                        offs.append(acc + off)
+                        planes.append(buf.reshape(-1))
+                        acc += buf.size
+                    ent.append(tuple(offs))
+                cache[p] = ent
+            refs[l].append(cache[p][0])
+            if chroma:
+                refs_c[l].append(cache[p][1])
     dpb_np = np.concatenate(planes)
     sr = ([pipeline.asr_search_range(p - cur_poc) for p in pocs0], [pipeline.asr_search_range(p - cur_poc) for p in pocs1])
-    return cur_np, dpb_np, refs, sr, torch.from_numpy(cur_np).to(dev), torch.from_numpy(dpb_np).to(dev)
+    if not chroma:
+        cur_np = np.ascontiguousarray(frames[cur_poc])
+        return cur_np, dpb_np, refs, sr, torch.from_numpy(cur_np).to(dev), torch.from_numpy(dpb_np).to(dev)
+    y, u, v = (np.ascontiguousarray(a) for a in frames[cur_poc])
+    cur_all = np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)])
+    ch_dev = dict(org_off=(W * H, W * H + (W // 2) * (H // 2)), org_stride=W // 2, refs=refs_c, ref_stride=rsc)
+    ch_cpu = dict(cur=(u, v), refs=refs_c, ref_stride=rsc)
+    return y, dpb_np, refs, sr, torch.from_numpy(cur_all).to(dev), torch.from_numpy(dpb_np).to(dev), ch_dev, ch_cpu
 
 
-def check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, R, per_level=24, min_checked=60):
+def check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, R, per_level=24, min_checked=60, pocs=None, chroma=None, stats=None):
     snaps = hp.snapshot()
     nref = hp.nref
     checked = 0
     dirs = set()
+    if chroma is not None:
+        cqp = pipeline.chroma_qp(qp) + 12
+        chroma = dict(chroma, qp_per=cqp // 6, qp_rem=cqp % 6)
     for li, lvl in enumerate(snaps):
         parent = snaps[li - 1] if li and snaps[li - 1]["size"] == 2 * lvl["size"] else None
         s, npu = lvl["size"], lvl["npu"]
         for i in range(0, npu, max(1, npu // per_level)):
             out = cpu_pis.run_pu(cur_np, dpb_np.ctypes.data, refs, sr, W, H, s, int(lvl["xs"][i]), int(lvl["ys"][i]), cpu_pis.cands_of(lvl, nref, i), lam,
-                                 (qp + 12) // 6, (qp + 12) % 6, lvl["cands"], ref=R)
+                                 (qp + 12) // 6, (qp + 12) % 6, lvl["cands"], ref=R, pocs=pocs, chroma=chroma)
             cpu_pis.compare_with_device(lvl, parent, nref, i, out)
             dirs.add(out["inter_dir"])
+            if stats is not None:
+                stats["bio"] = stats.get("bio", 0) + int(out["bio"])
+                stats["chroma_nz"] = stats.get("chroma_nz", 0) + sum(1 for v in out.get("tus_c", {}).values() if v[2])
             checked += 1
     assert checked >= min_checked
     return dirs
@@ -74,6 +101,36 @@ def test_frame_hot_path_matches_cpu_chain(use_ref, name, pocs0, pocs1, cur, qp, 
         dirs = check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, ol.ref() if use_ref else None, per_level=24 if overlapped else 6, min_checked=60 if overlapped else 15)
     if pocs1:
         assert 3 in dirs and len(dirs) >= 2      # bi-prediction and uni-prediction both occur
+    ctx.close()
+
+
+@pytest.mark.parametrize("use_ref", [False, True])
+@pytest.mark.parametrize("name,pocs0,pocs1,cur,qp", [("ra_1+1_qp32", [0], [4], 2, 32), ("ra_2+2_qp27", [2, 0], [4, 6], 3, 27), ("ldp_2_qp32", [1, 0], [], 2, 32)])
+def test_frame_hot_path_with_bdof_and_chroma(use_ref, name, pocs0, pocs1, cur, qp):
+    """The full final prediction of the driver: BDOF on the bi-predicted PUs xPredInterBi gives it to (opposite directions, equal POC distance,
+    size rule), plain weighted average on the rest, the two 4:2:0 chroma planes through the 4-tap chroma filter, chroma residual and the DCT2
+    TU chain at the mapped chroma QP -- PU by PU against the oracle and against the reference's own xPredInterBlk / applyBiOptFlow / xT / xIT."""
+    torch = pytest.importorskip("torch")
+    from vtm_amd.device import Context
+    if use_ref and not ol.have_ref():
+        pytest.skip("oracle/_ref/libvtmref.so not present")
+    W, H = 256, 128
+    dev = torch.device("cuda", 0)
+    cur_np, dpb_np, refs, sr, cur_d, dpb, ch_dev, ch_cpu = make_scene(torch, dev, W, H, pocs0, pocs1, cur, chroma=True)
+    if not pocs1:
+        sr = ([64] * len(pocs0), [])
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    lam = 8.0
+    pocs = (cur, pocs0, pocs1)
+    hp = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, pocs=pocs, chroma=ch_dev)
+    hp.run(cur_d.data_ptr(), dpb.data_ptr())
+    torch.cuda.synchronize()
+    stats = {}
+    check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, ol.ref() if use_ref else None, per_level=20, min_checked=50, pocs=pocs, chroma=ch_cpu, stats=stats)
+    if pocs1:
+        assert stats["bio"] >= 5, stats         # BDOF really ran on some of the checked PUs
+    assert stats["chroma_nz"] >= 5, stats        # and chroma TUs with non-zero levels were compared
     ctx.close()
 
 

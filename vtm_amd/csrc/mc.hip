@@ -378,6 +378,7 @@ __global__ __launch_bounds__( THREADS ) void motion_comp_kernel( const int16_t *
   int16_t              *p0  = lds + maxW * ( maxH + 7 );       // [h][w] list-0 prediction of a bi-predicted block (14-bit)
   const vtmhip_pred_job j    = jobs[blockIdx.x];
   const int             lane = threadIdx.x;
+  if( j.route == 1 ) return;   // routed to vtmhip_bdof_batch_dev (a table both calls are launched over)
   Epilogue ep;
   ep.org = orgBase ? orgBase + j.orgOff : nullptr; ep.orgStride = j.orgStride;
   ep.pred = predBase ? predBase + j.predOff : nullptr; ep.predStride = j.predStride;
@@ -581,6 +582,7 @@ __global__ __launch_bounds__( 64 ) void bdof_kernel( const int16_t *__restrict__
   __shared__ BdofLds L;
   const vtmhip_pred_job j = jobs[blockIdx.y];
   const int lane = threadIdx.x;
+  if( j.route == 2 ) return;   // routed to vtmhip_motion_compensation_batch_dev
   const int dx = min( 16, ( int ) j.width ), dy = min( 16, ( int ) j.height ), perRow = j.width / dx;
   const int region = blockIdx.x;
   if( region >= perRow * ( j.height / dy ) ) return;
@@ -1023,9 +1025,13 @@ int vtmhip_bdof_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int1
   VTMHIP_REQUIRE( ctx, d_refBase && d_jobs && ( d_predBase || d_outBase ), "null pointer" );
   VTMHIP_REQUIRE( ctx, !d_outBase || d_orgBase, "an epilogue output needs the original plane" );
   VTMHIP_REQUIRE( ctx, maxWidth >= 8 && maxWidth <= 128 && maxHeight >= 8 && maxHeight <= 128, "maxWidth / maxHeight (BDOF needs 8 <= w, h <= 128)" );
-  VTMHIP_REQUIRE( ctx, n <= 65535, "at most 65535 PUs per launch" );
   const int regions = ( ( maxWidth + 15 ) / 16 ) * ( ( maxHeight + 15 ) / 16 );
-  hipLaunchKernelGGL( bdof_kernel, dim3( regions, n ), dim3( 64 ), 0, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs );
+  VTMHIP_TIME_KERNEL( ctx, "bdof_kernel" );
+  for( int at = 0; at < n; at += 65535 )   // grid.y carries the PU index: 65535 per launch
+  {
+    const int m = n - at < 65535 ? n - at : 65535;
+    hipLaunchKernelGGL( bdof_kernel, dim3( regions, m ), dim3( 64 ), 0, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs + at );
+  }
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

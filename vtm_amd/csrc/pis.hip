@@ -48,7 +48,7 @@ __global__ __launch_bounds__( 256 ) void amvp_jobs_kernel( vtmhip_pic_params pic
   p.orgOff = 0; p.refOff[0] = j.refOff; p.refOff[1] = j.refOff; p.predOff = slot; p.outOff = slot;
   p.orgStride = j.orgStride; p.refStride[0] = p.refStride[1] = j.refStride; p.predStride = j.width; p.outStride = j.width;
   p.mv[0][0] = th; p.mv[0][1] = tv; p.mv[1][0] = p.mv[1][1] = 0;
-  p.width = j.width; p.height = j.height; p.mode = 0; p.epilogue = 0; p.bitDepth = ( uint8_t ) pic.bitDepth; p.useAltHpelIf = j.imv == 3; p.chroma = 0; p.pad0 = 0; p.pad1 = 0;
+  p.width = j.width; p.height = j.height; p.mode = 0; p.epilogue = 0; p.bitDepth = ( uint8_t ) pic.bitDepth; p.useAltHpelIf = j.imv == 3; p.chroma = 0; p.route = 0; p.pad1 = 0;
   wk.pred[idx] = p;
   vtmhip_dist_job d;
   d.orgOff = j.orgOff; d.curOff = slot; d.orgStride = j.orgStride; d.curStride = j.width; d.width = j.width; d.height = j.height; d.subShift = 0; d.kind = VTMHIP_DIST_SAD;
@@ -127,6 +127,23 @@ __device__ __forceinline__ void final_pred( const vtmhip_pis_level &L, int pu, c
   pf.mode = bi ? 2 : ( P.interDir == 2 ? 1 : 0 );
   if( P.interDir & 1 ) { pf.refOff[0] = L.refPlaneOff[0][r0] + L.pos[pu]; pf.mv[0][0] = bi ? P.mvBi[0][0] : P.mv[0][0]; pf.mv[0][1] = bi ? P.mvBi[0][1] : P.mv[0][1]; }
   if( P.interDir & 2 ) { pf.refOff[1] = L.refPlaneOff[1][r1] + L.pos[pu]; pf.mv[1][0] = bi ? P.mvBi[1][0] : P.mv[1][0]; pf.mv[1][1] = bi ? P.mvBi[1][1] : P.mv[1][1]; }
+  // BDOF as InterPrediction::xPredInterBi decides it (:527-572; no weighted prediction / BCW / SMVD / CIIP / affine in this driver): true bi-prediction from
+  // opposite directions at equal POC distance (PU::isBiPredFromDifferentDirEqDistPoc, UnitTools.cpp:3239-3260), w, h >= 8, w * h >= 128
+  bool bio = false;
+  if( bi && L.bdofEnabled )
+  {
+    const int d0 = L.curPoc - L.refPoc[0][r0], d1 = L.curPoc - L.refPoc[1][r1];
+    bio = d0 * d1 < 0 && abs( d0 ) == abs( d1 ) && pf.width >= 8 && pf.height >= 8 && pf.width * pf.height >= 128;
+  }
+  pf.route = bio ? 1 : 2;
+  if( L.predFinalC )
+    for( int c = 0; c < 2; c++ )
+    {
+      vtmhip_pred_job &pc = L.predFinalC[c * L.numPU + pu];
+      pc.mode = pf.mode; pc.route = 0;
+      if( P.interDir & 1 ) { pc.refOff[0] = L.refPlaneOffC[c][0][r0] + L.posC[pu]; pc.mv[0][0] = pf.mv[0][0]; pc.mv[0][1] = pf.mv[0][1]; }
+      if( P.interDir & 2 ) { pc.refOff[1] = L.refPlaneOffC[c][1][r1] + L.posC[pu]; pc.mv[1][0] = pf.mv[1][0]; pc.mv[1][1] = pf.mv[1][1]; }
+    }
 }
 
 __global__ __launch_bounds__( 256 ) void pis_uni_select_kernel( vtmhip_pis_level L )

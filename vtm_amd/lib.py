@@ -131,7 +131,7 @@ class PredJob(C.Structure):
     _fields_ = [("orgOff", C.c_int64), ("refOff", C.c_int64 * 2), ("predOff", C.c_int64), ("outOff", C.c_int64), ("orgStride", C.c_int32),
                 ("refStride", C.c_int32 * 2), ("predStride", C.c_int32), ("outStride", C.c_int32), ("mv", (C.c_int32 * 2) * 2),
                 ("width", C.c_int16), ("height", C.c_int16), ("mode", C.c_uint8), ("epilogue", C.c_uint8), ("bitDepth", C.c_uint8),
-                ("useAltHpelIf", C.c_uint8), ("chroma", C.c_uint8), ("pad0", C.c_uint8), ("pad1", C.c_int16)]
+                ("useAltHpelIf", C.c_uint8), ("chroma", C.c_uint8), ("route", C.c_uint8), ("pad1", C.c_int16)]
 
 
 class FrameTabs(C.Structure):
@@ -182,7 +182,8 @@ class PisLevel(C.Structure):
     _fields_ = [("numPU", C.c_int32), ("numRef", C.c_int32 * 2), ("smvdBit", C.c_int32), ("mbBits", C.c_uint32 * 3), ("refStride", C.c_int32),
                 ("refPlaneOff", (C.c_int64 * MAX_REF) * 2), ("uniJobs", C.c_void_p), ("uniOut", C.c_void_p), ("uniRows", C.c_void_p), ("pus", C.c_void_p),
                 ("predOther", C.c_void_p), ("biJobs", C.c_void_p), ("biOut", C.c_void_p), ("predFinal", C.c_void_p), ("parentIdx", C.c_void_p),
-                ("parentRows", C.c_void_p), ("parentNumPU", C.c_int32), ("pad", C.c_int32), ("pos", C.c_void_p)]
+                ("parentRows", C.c_void_p), ("parentNumPU", C.c_int32), ("pad", C.c_int32), ("pos", C.c_void_p), ("bdofEnabled", C.c_int32), ("curPoc", C.c_int32),
+                ("refPoc", (C.c_int32 * MAX_REF) * 2), ("predFinalC", C.c_void_p), ("posC", C.c_void_p), ("refPlaneOffC", ((C.c_int64 * MAX_REF) * 2) * 2)]
 
 
 class AffineMeJob(C.Structure):

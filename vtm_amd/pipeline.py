@@ -555,6 +555,21 @@ def asr_search_range(delta_poc, search_range=384, min_window=96):
     return int(min(search_range, max(min_window, (search_range * abs(delta_poc) + 8) // 16)))
 
 
+def chroma_qp(qp, q_in=(17, 22, 34, 42), q_out=(17, 23, 35 , 39)):
+    """ChromaQpMappingTable::derivedChromaQPMappingTables (Slice.cpp:2851-2892) with the table of encoder_randomaccess_vtm.cfg:96-97
+    (QpInValCb 17 22 34 42 -> QpOutValCb 17 23 35 39, same table for Cb / Cr, CbQpOffset = CrQpOffset = 0)"""
+    tab = {q_in[0]: q_out[0]}
+    for k in range(q_in[0] - 1, -13, -1):
+        tab[k] = tab[k + 1] - 1
+    for j in range(len(q_in) - 1):
+        d = q_in[j + 1] - q_in[j]
+        for m, k in enumerate(range(q_in[j] + 1, q_in[j + 1] + 1), 1):
+            tab[k] = tab[q_in[j]] + ((q_out[j + 1] - q_out[j]) * m + (d >> 1)) // d
+    for k in range(q_in[-1] + 1, 64):
+        tab[k] = min(63, tab[k - 1] + 1)
+    return tab[qp]
+
+
 class FrameHotPath:
     """All stages of one inter picture, level by level over the quadtree of square PUs (128 .. 8):
 
@@ -574,10 +589,14 @@ class FrameHotPath:
     is no m_uniMvList history, CABAC bit estimates and the mode decision between transform candidates stay with the host.
 
     refs: ([(ref_off, ref_stride)] list 0, [...] list 1) -- list 1 empty: P slice (uni-prediction only, as encoder_lowdelay_P_vtm.cfg).
-    search_ranges: per list, per reference picture (m_aaiAdaptSR)."""
+    search_ranges: per list, per reference picture (m_aaiAdaptSR).
+    pocs: (current POC, [list-0 POCs], [list-1 POCs]) -- enables BDOF in the final prediction of bi-predicted PUs where xPredInterBi applies it.
+    chroma: dict(org_off=(Cb, Cr sample offsets of the original chroma planes behind the luma plane in the original buffer), org_stride=..., refs=([(Cb off, Cr off)]
+    per list, per reference picture, inside the reference buffer), ref_stride=...) -- adds the 4:2:0 chroma planes to the final prediction, the residual and
+    the TU chains (DCT2, chroma QP by the CTC mapping table)."""
 
     def __init__(self, ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda=8.0, qp=32, sizes=(128, 64, 32, 16, 8),
-                 ctu_filter=None, transform_skip=False, bit_depth=10):
+                 ctu_filter=None, transform_skip=False, bit_depth=10, pocs=None, chroma=None, bdof=True):
         T, dev = torch, device
         self.ctx, self.torch, self.device = ctx, T, dev
         self.pic_w, self.pic_h, self.org_stride, self.lam = pic_w, pic_h, org_stride, motion_lambda
@@ -598,6 +617,11 @@ class FrameHotPath:
             k, v = kv.split(":")
             wpj[int(k)] = int(v)
         cands = [0] + ([1] if transform_skip else []) + [2, 3, 4, 5]
+        self.pocs, self.chroma = pocs, chroma
+        self.bdof = bool(bdof and pocs is not None and self.is_b)
+        if chroma is not None:
+            cqp = chroma_qp(qp) + 6 * (bit_depth - 8)
+            self.cqp_per, self.cqp_rem = cqp // 6, cqp % 6
         self.levels, prev = [], None
         sb = 0
         for (s, xs, ys, parent) in quadtree_levels(pic_w, pic_h, sizes, None, ctu_filter):
@@ -657,6 +681,40 @@ class FrameHotPath:
                 L.predOther, L.biJobs, L.biOut = lvl["pred_other"].ptr, lvl["bi_jobs"].ptr, lvl["bi_out"].data_ptr()
             if par32 is not None:
                 L.parentIdx, L.parentRows, L.parentNumPU = par32.data_ptr(), prev["uni_rows"].data_ptr(), prev["npu"]
+            if pocs is not None:
+                L.bdofEnabled, L.curPoc = int(self.bdof), int(pocs[0])
+                for l in (0, 1):
+                    for r in range(nref[l]):
+                        L.refPoc[l][r] = int(pocs[1 + l][r])
+            if chroma is not None:
+                # ---- the two 4:2:0 chroma planes of every PU: prediction + residual jobs (Cb jobs, then Cr jobs), compact slots in level-wide chroma buffers ----
+                sc, rsc, osc = s // 2, chroma["ref_stride"], chroma["org_stride"]
+                blk_c = (sb - n * s * s) // 4 + np.arange(n, dtype=np.int64) * sc * sc
+                cj = np.zeros(2 * n, PRED_DT)
+                for c in (0, 1):
+                    sl = slice(c * n, (c + 1) * n)
+                    cj["orgOff"][sl] = chroma["org_off"][c] + (ys // 2) * osc + xs // 2
+                    cj["predOff"][sl] = cj["outOff"][sl] = blk_c      # + c * NSC (the Cr half of the chroma buffers), added below once NSC is known
+                cj["orgStride"], cj["refStride"], cj["predStride"], cj["outStride"] = osc, rsc, sc, sc
+                cj["width"], cj["height"], cj["bitDepth"], cj["chroma"], cj["epilogue"] = sc, sc, bit_depth, 1, 1
+                lvl["blk_c"] = blk_c
+                lvl["pred_final_c"] = _Tab(T, dev, cj)
+                lvl["pos_c"] = T.from_numpy((ys // 2) * rsc + xs // 2).to(dev)
+                L.predFinalC, L.posC = lvl["pred_final_c"].ptr, lvl["pos_c"].data_ptr()
+                for c in (0, 1):
+                    for l in (0, 1):
+                        for r in range(nref[l]):
+                            L.refPlaneOffC[c][l][r] = int(chroma["refs"][l][r][c])
+                tsc = min(sc, 32)
+                qc = sc // tsc
+                tu_src_c = np.stack([blk_c + qy * tsc * sc + qx * tsc for qy in range(qc) for qx in range(qc)], 1).reshape(-1)
+                ntc = tu_src_c.size
+                tc = np.zeros(2 * ntc, TU_DT)       # Cb TUs, then Cr TUs (the Cr plane's buffers start NSC samples further: added in _finish_chroma)
+                tc["resiOff"], tc["resiStride"], tc["width"], tc["height"] = np.tile(tu_src_c, 2), sc, tsc, tsc
+                tc["outOff"] = np.arange(2 * ntc, dtype=np.int64) * tsc * tsc
+                tc["qpPer"], tc["qpRem"], tc["bitDepth"] = self.cqp_per, self.cqp_rem, bit_depth
+                lvl.update(ntu_c=ntc, ts_c=tsc, tu_c_np=tc, tu_res_c=T.zeros((2 * ntc, 2), dtype=T.int64, device=dev),
+                           qcoef_c=T.zeros(2 * ntc * tsc * tsc, dtype=T.int32, device=dev))
             lvl["pis"] = L
             lvl["pic"] = PicParams(pic_w, pic_h, 128, bit_depth, wpj.get(s, 1))
             lvl["pic_bi"] = PicParams(pic_w, pic_h, 128, bit_depth, FULL_WAVES_PER_JOB.get(s, 1))
@@ -686,6 +744,19 @@ class FrameHotPath:
         self.buf = dict(pred=mk(), resi=mk())
         if self.is_b:
             self.buf["org_bi"] = mk()
+        if chroma is not None:
+            nsc = sb // 4                                            # samples of ONE chroma plane over all levels; buffers hold Cb then Cr
+            self.NSC = nsc
+            self.buf["pred_c"] = T.zeros(max(1, 2 * nsc), dtype=T.int16, device=dev)
+            self.buf["resi_c"] = T.zeros(max(1, 2 * nsc), dtype=T.int16, device=dev)
+            for lvl in self.levels:
+                n = lvl["npu"]
+                t = lvl["pred_final_c"]
+                for f in ("predOff", "outOff"):
+                    t.col(f)[n:] += nsc
+                tc = lvl.pop("tu_c_np")
+                tc["resiOff"][lvl["ntu_c"]:] += nsc
+                lvl["tu_c"] = _Tab(T, dev, tc)
         self.side_streams = [T.cuda.Stream(device=dev) for _ in range(int(os.environ.get("VTM_AMD_SIDE_STREAMS", "5")))] if dev.type == "cuda" else []
         self._marks = None
 
@@ -729,8 +800,15 @@ class FrameHotPath:
             ctx.pis_stage(lvl["pis"], 3)
             self._mark("glue")
         ctx.motion_compensation_batch(org_ptr, dpb_ptr, buf["pred"].data_ptr(), buf["resi"].data_ptr(), lvl["pred_final"].ptr, n, s, s)
+        if self.bdof and s >= 16:      # the PUs the final stage routed to BDOF (bi-prediction from opposite directions at equal POC distance; 8x8 never qualifies)
+            ctx.bdof_batch(org_ptr, dpb_ptr, buf["pred"].data_ptr(), buf["resi"].data_ptr(), lvl["pred_final"].ptr, n, s, s)
+        if self.chroma is not None:
+            ctx.motion_compensation_batch(org_ptr, dpb_ptr, buf["pred_c"].data_ptr(), buf["resi_c"].data_ptr(), lvl["pred_final_c"].ptr, 2 * n, s // 2, s // 2)
         self._mark("mc")
         self._tu(lvl)
+        if self.chroma is not None:
+            tsc = lvl["ts_c"]
+            ctx.tu_chain_batch(buf["resi_c"].data_ptr(), lvl["tu_c"].ptr, 2 * lvl["ntu_c"], tsc, tsc, lvl["tu_res_c"].data_ptr(), lvl["qcoef_c"].data_ptr(), None, uniform=tsc >= 8)
         self._mark("tu")
 
     def _tu(self, lvl):
@@ -788,6 +866,9 @@ class FrameHotPath:
             if self.is_b:
                 d["bi_jobs"] = lvl["bi_jobs"].t.cpu().numpy().view(ME_DT).reshape(-1)
                 d["bi_out"] = lvl["bi_out"].cpu().numpy().view(MEOUT_DT).reshape(-1)
+            d["route"] = lvl["pred_final"].col("route").cpu().numpy()
+            if self.chroma is not None:
+                d.update(ntu_c=lvl["ntu_c"], ts_c=lvl["ts_c"], tu_res_c=lvl["tu_res_c"].cpu().numpy())
             out.append(d)
         return out
 
@@ -796,6 +877,8 @@ class FrameHotPath:
         out = []
         for lvl in self.levels:
             out += [lvl["pus"].reshape(-1), lvl["tu_res"].view(self.torch.uint8).reshape(-1)]
+            if self.chroma is not None:
+                out.append(lvl["tu_res_c"].view(self.torch.uint8).reshape(-1))
         return out
 
     def work_counts(self):

@@ -44,7 +44,7 @@ def gen_frames(w, h, frames, seed=1234, bd=10, chroma=False):
     return out
 
 
-def gen_frames_hard(w, h, frames, seed=4321, bd=10, sigma=10.0):
+def gen_frames_hard(w, h, frames, seed=4321, bd=10, sigma=10.0, chroma=False):
     rng = np.random.default_rng(seed)
     W, H = w + 256, h + 256
     A = _texture(rng, W, H, bd)
@@ -56,7 +56,13 @@ def gen_frames_hard(w, h, frames, seed=4321, bd=10, sigma=10.0):
         a = A[2 * t:2 * t + h, 5 * t:5 * t + w]
         b = B[128 - 3 * t:128 - 3 * t + h, 128 - 4 * t:128 - 4 * t + w]
         Y = np.clip(np.rint(np.where(mask, a, b) + rng.normal(0, sigma, size=(h, w))), 0, (1 << bd) - 1)
-        out.append(Y.astype(np.int16))
+        if not chroma:
+            out.append(Y.astype(np.int16))
+            continue
+        m2 = np.where(mask, a, b)[::2, ::2]
+        U = np.clip(np.rint(m2 * 0.25 + (1 << (bd - 1)) * 0.75 + rng.normal(0, sigma / 4, size=m2.shape)), 0, (1 << bd) - 1)
+        V = np.clip(np.rint((1 << bd) - 1 - m2 * 0.25 - (1 << (bd - 1)) * 0.25 + rng.normal(0, sigma / 4, size=m2.shape)), 0, (1 << bd) - 1)
+        out.append((Y.astype(np.int16), U.astype(np.int16), V.astype(np.int16)))
     return out
 
 
