@@ -272,9 +272,13 @@ typedef struct
 
 int vtmhip_full_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
                                   const vtmhip_full_job *d_jobs, int n, vtmhip_me_result *d_results );
-/* Same searches, same results, for a batch the caller promises to be uniform: EVERY job is size x size with searchRange <= 4
- * (the bi-pred refinement of one quadtree level).  size 8 / 16 / 32 / 64: one lane per candidate over an LDS-resident window; any other size
- * forwards to vtmhip_full_search_batch_dev.  The reference plane must be readable 7 samples beyond the search window's right edge. */
+/* Same searches, same results, for a batch the caller promises to be uniform: EVERY job is width x height with searchRange <= 4
+ * (the bi-pred refinement of one quadtree level or of one split shape).  Squares 8 .. 64 and the binary / ternary split shapes 16x8, 32x8, 32x16, 64x16,
+ * 64x32 in both orientations: one lane per candidate over an LDS-resident window; any other shape forwards to vtmhip_full_search_batch_dev.
+ * The reference plane must be readable 7 samples beyond the search window's right edge. */
+int vtmhip_full_search_uniform_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                          const vtmhip_full_job *d_jobs, int n, int width, int height, vtmhip_me_result *d_results );
+/* width == height == size */
 int vtmhip_full_search_square_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
                                          const vtmhip_full_job *d_jobs, int n, int size, vtmhip_me_result *d_results );
 
@@ -294,7 +298,8 @@ typedef struct
   uint8_t extendedSettings;        /* MESEARCH_DIAMOND_ENHANCED */
   uint8_t firstSearchStop;         /* FastMEAssumingSmootherMVEnabled */
   int32_t uniformImv;              /* -1: jobs mix cu.imv values; 0..3: every job of the batch has this cu.imv (lets whole stages be skipped) */
-  int32_t uniformSquare;           /* != 0: every job is maxWidth x maxWidth (tiled fractional kernel when uniformImv is 0 or 3) */
+  int32_t uniformSquare;           /* != 0: every job is exactly maxWidth x maxHeight (squares 8 .. 128 or a split shape 16x8 .. 64x32, either orientation:
+                                      tiled fractional kernel when uniformImv is 0 or 3); the name predates the rectangular fast paths */
   int32_t uniformBi;               /* 0: jobs mix bBi values; 1: every job is a uni search (no pattern copies: the searches read the original plane);
                                       2: every job is a bi search (no TZ stage; lane-per-candidate exhaustive kernel when uniformSquare) */
   uint8_t noUniMvList;             /* caller's promise: numExtraStart == 0 in every job (with uniformBi 2 the start-candidate SADs are skipped: rcMv is the start) */
@@ -519,9 +524,10 @@ typedef struct
 } vtmhip_frac_result;
 
 /* maxWidth/maxHeight: upper bounds of the job sizes in this batch (they size the per-workgroup LDS window).
- * uniformSquare != 0: the caller guarantees that EVERY job is exactly maxWidth x maxHeight with maxWidth == maxHeight in
- * {8,16,32,64,128} and that all jobs share imvShift; the library then uses the tiled kernel (one lane per
- * (PU, candidate, 8x8 tile)); 0 = any mix of sizes (one wave per PU). */
+ * uniformSquare != 0: the caller guarantees that EVERY job is exactly maxWidth x maxHeight -- a square in {8,16,32,64,128} or one of the split
+ * shapes 16x8, 32x8, 32x16, 64x16, 64x32 in either orientation (their SATD tiles are the reference's 16x8 / 8x16 Hadamards) -- and that all
+ * jobs share imvShift; the library then uses the tiled kernel (one lane per (PU, candidate, 8x8 tile)); other uniform shapes and
+ * 0 = any mix of sizes: one wave per PU. */
 int vtmhip_frac_search_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_frac_job *d_jobs, int n,
                                   int maxWidth, int maxHeight, int uniformSquare, vtmhip_frac_result *d_results );
 

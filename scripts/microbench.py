@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from vtm_amd import synth   # noqa: E402
 from vtm_amd.device import Context   # noqa: E402
-from vtm_amd.lib import DistJob, DmvrJob, GeoBlendJob, IfJob, PicParams, PredJob, TrJob, TuJob   # noqa: E402
+from vtm_amd.lib import DistJob, DmvrJob, FracJob, FullJob, GeoBlendJob, IfJob, PicParams, PredJob, TrJob, TuJob   # noqa: E402
 
 PEAK = 8000.0   # GB/s
 
@@ -46,6 +46,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--only", default="", help="'shapes': only the per-shape rows of the uniform fast paths (squares vs the split rectangles)")
     a = ap.parse_args()
     W, H = a.width, a.height
     ctx = Context(0)
@@ -54,6 +55,43 @@ def main():
     ref, roff, rs = synth.extend_plane(fr[0], margin=160)
     d_cur, d_ref = ctx.to_device(cur), ctx.to_device(ref)
     rng = np.random.default_rng(2)
+
+    # ---- the uniform fast paths per block shape: fractional search (tiled kernel), +-4 exhaustive search (lane per candidate), TU chain -----------
+    # Per-sample rates of the split rectangles next to the squares of the same area class (within 20 %).
+    shapes = ((8, 8), (16, 8), (8, 16), (16, 16), (32, 8), (8, 32), (32, 16), (16, 32), (32, 32), (64, 16), (16, 64), (64, 32), (32, 64), (64, 64))
+    for (w, h) in shapes:
+        n = min(60000, (W // w) * (H // h))
+        py, px = np.divmod(np.arange(n), W // w)
+        fj = np.zeros(n, np.dtype(FracJob))
+        fj["orgOff"], fj["refOff"] = (py * h) * W + px * w, roff + (py * h) * rs + px * w
+        fj["orgStride"], fj["refStride"], fj["width"], fj["height"] = W, rs, w, h
+        fj["intX"], fj["intY"] = rng.integers(-8, 9, n), rng.integers(-8, 9, n)
+        fj["motionLambda"], fj["useHad"], fj["bitDepth"] = 8.0, 1, 10
+        d_fj, d_fr = ctx.to_device(fj.view(np.uint8)), ctx.alloc(16 * n)
+        ms = timed(ctx, lambda: ctx.frac_search_batch(d_cur.ptr, d_ref.ptr, d_fj.ptr, n, w, h, d_fr.ptr, uniform_square=True), reps=5)
+        emit("frac_search_uniform", n * w * h, "PU samples", n * (24 * (w + 8) * (h + 8) + 144 * w * h) // 8, ms, size="%dx%d" % (w, h), pus=n,
+             ns_per_sample=round(ms * 1e6 / (n * w * h), 4))
+        if w <= 64 and h <= 64:
+            uj = np.zeros(n, np.dtype(FullJob))
+            uj["orgOff"], uj["refOff"] = fj["orgOff"], fj["refOff"]
+            uj["orgStride"], uj["refStride"], uj["width"], uj["height"], uj["puX"], uj["puY"] = W, rs, w, h, px * w, py * h
+            uj["motionLambda"], uj["searchRange"] = 8.0, 4
+            uj["centerHor"], uj["centerVer"] = rng.integers(-8, 9, n) * 16, rng.integers(-8, 9, n) * 16
+            d_uj, d_ur = ctx.to_device(uj.view(np.uint8)), ctx.alloc(32 * n)
+            pic = PicParams(W, H, 128, 10, 0)
+            ms = timed(ctx, lambda: ctx.full_search_batch(pic, d_cur.ptr, d_ref.ptr, d_uj.ptr, n, d_ur.ptr, uniform=(w, h)), reps=5)
+            emit("full_search_uniform", n * w * h, "PU samples", n * 2 * ((w + 8) * (h + 8) + w * h), ms, size="%dx%d" % (w, h), pus=n,
+                 ns_per_sample=round(ms * 1e6 / (n * w * h), 4))
+            resi = rng.integers(-512, 512, (n, h, w)).astype(np.int16)
+            ju = np.zeros(n, np.dtype(TuJob))
+            ju["resiOff"] = ju["outOff"] = np.arange(n) * w * h
+            ju["resiStride"], ju["width"], ju["height"], ju["qpPer"], ju["qpRem"], ju["bitDepth"] = w, w, h, 7, 2, 10
+            d_resi, d_ju, d_r, d_lv = ctx.to_device(resi), ctx.to_device(ju.view(np.uint8)), ctx.alloc(16 * n), ctx.alloc(4 * n * w * h)
+            ms = timed(ctx, lambda: ctx.tu_chain_batch(d_resi.ptr, d_ju.ptr, n, w, h, d_r.ptr, d_lv.ptr, None, uniform=True), reps=5)
+            emit("tu_chain_uniform", n * w * h, "samples", 32 * n * w * h, ms, size="%dx%d" % (w, h), tus=n, ns_per_sample=round(ms * 1e6 / (n * w * h), 4))
+    if a.only == "shapes":
+        ctx.close()
+        return
 
     # ---- SATD 8x8 grid -------------------------------------------------------------------------------------------------------
     nb = (W // 8) * (H // 8)

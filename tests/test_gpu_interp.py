@@ -194,3 +194,47 @@ def test_frac_search_tiled_square_path(ctx, size, use_had, signed):
     got = [(r.halfX, r.halfY, r.qterX, r.qterY, r.cost) for r in res]
     bad = [k for k in range(n) if got[k] != exp[k]]
     assert not bad, [(got[k], exp[k]) for k in bad[:5]]
+
+
+RECT_SHAPES = [(16, 8), (8, 16), (32, 8), (8, 32), (32, 16), (16, 32), (64, 16), (16, 64), (64, 32), (32, 64)]
+
+
+@pytest.mark.parametrize("w,h", RECT_SHAPES)
+@pytest.mark.parametrize("use_had,signed,bd", [(1, 0, 10), (0, 0, 10), (1, 1, 10), (1, 0, 12)])
+def test_frac_search_tiled_rect_path(ctx, w, h, use_had, signed, bd):
+    """The tiled fast path on the binary / ternary split shapes: their SATD tiles are the reference's 16x8 / 8x16 Hadamards (RdCost.cpp:2837-2931),
+    formed from two 8x8 lane items through a DPP exchange -- packed 10-bit path, packed 12-bit-difference path (signed bi-pred target) and the
+    32-bit path (bitDepth 12) -- vs the oracle."""
+    L = ol.oracle()
+    scene = me_util.Scene(416, 240, hard=True)
+    rng = np.random.default_rng(1000 + 64 * w + h)
+    cur = scene.cur
+    if signed:
+        cur = np.ascontiguousarray((2 * cur.astype(np.int32) - rng.integers(0, 1024, cur.shape)).astype(np.int16))
+    n = max(10, 9000 // (w * h))
+    arr = (FracJob * n)()
+    exp = []
+    for k in range(n):
+        x = int(rng.integers(0, (416 - w) // 4 + 1)) * 4
+        y = int(rng.integers(0, (240 - h) // 4 + 1)) * 4
+        j = dict(w=w, h=h, x=x, y=y, subShift=0, lam=float(rng.uniform(1, 40)), predHor=int(rng.integers(-64, 64)), predVer=int(rng.integers(-64, 64)))
+        ix, iy = int(rng.integers(-12, 12)), int(rng.integers(-12, 12))
+        org = np.ascontiguousarray(cur[y:y + h, x:x + w])
+        c = me_util.oracle_ctx(scene, j, org)
+        c.bitDepth = bd
+        fr = ol.FracResult()
+        L.vo_frac_search(C.byref(c), ix, iy, use_had, 0, C.byref(fr))
+        exp.append((fr.halfX, fr.halfY, fr.qterX, fr.qterY, fr.cost))
+        t = arr[k]
+        t.orgOff, t.refOff = y * 416 + x, scene.ref_off + y * scene.ref_stride + x
+        t.orgStride, t.refStride, t.width, t.height = 416, scene.ref_stride, w, h
+        t.intX, t.intY, t.predHor, t.predVer, t.motionLambda = ix, iy, j["predHor"], j["predVer"], j["lam"]
+        t.useHad, t.useAltHpelIf, t.imvShift, t.bitDepth = use_had, 0, 0, bd
+    d_cur, d_ref = ctx.to_device(cur), ctx.to_device(scene.ref_buf)
+    d_jobs = ctx.to_device(np.frombuffer(arr, np.uint8))
+    d_res = ctx.alloc(16 * n)
+    ctx.frac_search_batch(d_cur.ptr, d_ref.ptr, d_jobs.ptr, n, w, h, d_res.ptr, uniform_square=True)
+    res = (FracResult * n).from_buffer_copy(d_res.to_host(np.uint8).tobytes())
+    got = [(r.halfX, r.halfY, r.qterX, r.qterY, r.cost) for r in res]
+    bad = [k for k in range(n) if got[k] != exp[k]]
+    assert not bad, [(got[k], exp[k]) for k in bad[:5]]

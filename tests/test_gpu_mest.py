@@ -142,3 +142,31 @@ def test_uniform_bi_fast_paths(ctx, size, bi, opts):
         exp.append(r.key())
     got, _ = run_device(ctx, scene, jobs, cfgv, uniform_imv=0, uniform_square=1, max_wh=(size, size), uniform_bi=1 + bi, **opts)
     assert got == exp
+
+
+@pytest.mark.parametrize("w,h", [(16, 8), (8, 16), (32, 8), (8, 32), (32, 16), (16, 32), (64, 16), (16, 64), (64, 32), (32, 64)])
+@pytest.mark.parametrize("bi,opts", [(0, {}), (1, {}), (1, dict(no_uni_mv_list=1, pattern_given=1))])
+def test_uniform_rect_fast_paths(ctx, w, h, bi, opts):
+    """The uniform fast paths on the binary / ternary split shapes: all-uni batches (TZ on the original plane + the tiled
+    fractional kernel with 16x8 / 8x16 Hadamard tiles) and all-bi batches (lane-per-candidate exhaustive kernel on W x H) = the oracle's
+    xMotionEstimation."""
+    L = ol.oracle()
+    scene = me_util.Scene(416, 240, hard=True)
+    jobs = me_util.random_mest_jobs(scene, 96, seed=500 + 64 * w + h + bi, sizes=([w], [h]))
+    for j in jobs:
+        j["imv"], j["bi"] = 0, bi
+        j["cands"] = [[me_util._round_amvr(v, 0) for v in c] for c in j["cands"]]
+        j["mvPred"] = tuple(j["cands"][j["mvpIdx"]])
+        if opts.get("no_uni_mv_list"):
+            j["extra"] = []
+    cfgv = (4, 1, 1, 0, 1)
+    cfg = ol.MestCfg(*cfgv)
+    exp = []
+    for j in jobs:
+        keep = []
+        t = me_util.oracle_mest_job(scene, j, keep)
+        r = ol.MestResult()
+        L.vo_motion_estimation(C.byref(cfg), C.byref(t), C.byref(r))
+        exp.append(r.key())
+    got, _ = run_device(ctx, scene, jobs, cfgv, uniform_imv=0, uniform_square=1, max_wh=(w, h), uniform_bi=1 + bi, **opts)
+    assert got == exp

@@ -341,39 +341,44 @@ __global__ __launch_bounds__( 64 ) void frac_search_kernel( const int16_t *__res
 
 
 // =====================================================================================================================
-// Tiled fractional search for square PUs (S = 8, 16, 32, 64, 128): the fast path.
+// Tiled fractional search for uniform W x H PUs (squares 8 .. 128 and the binary / ternary split shapes 16x8 .. 64x32, both orientations): the fast path.
 //
 // The generic kernel above gives a whole wave to one PU and its SATD phase keeps one lane per 8x8 tile busy -- one lane
 // of 64 for an 8x8 PU.  Here a workgroup takes JPW PUs and every lane owns one (PU, candidate, 8x8 tile) ITEM:
-//   phase H   3 horizontal passes per PU (one per horizontal quarter position of the round) -> LDS planes [(S+8)][S]
+//   phase H   3 horizontal passes per PU (one per horizontal quarter position of the round) -> LDS planes [(H+8)][W]
 //   phase V   per item: 15 plane rows (16-byte LDS reads) -> 8x8 vertical FIR in registers (64 accumulators) ->
 //             round/clip -> difference to the original tile -> 8x8 Hadamard in registers -> LDS atomic add into cost[PU][cand]
 //   select    one lane per PU: + MV rate, first strict minimum in the reference's table order (xPatternRefinement :707-761)
 // The fractional search has no data-dependent control flow (2 rounds x 9 candidates), so PUs batch perfectly.
+// Rectangles: the reference's SATD tiles are 16x8 (W > H) or 8x16 (W < H) Hadamards (RdCost.cpp:2837-2931).  Such a transform is the 8x8 transforms A, B of
+// its two halves plus one more butterfly level, sum |A_i + B_i| + |A_i - B_i| = 2 sum max(|A_i|, |B_i|): the two 8x8 items of a tile sit in
+// neighbouring lanes (tile order: the long direction fastest) and finish through one DPP exchange (had.hpp satd8_pair_*).
 // =====================================================================================================================
-template<int S>
+template<int W, int H>
 struct FracSq
 {
-  static constexpr int TILES = ( S / 8 ) * ( S / 8 );
+  static constexpr int TX = W / 8, TY = H / 8;
+  static constexpr int TILES = TX * TY;
+  static constexpr bool PAIR = W != H;                          // 16x8 / 8x16 Hadamard tiles: two neighbouring 8x8 items per tile
   static constexpr int ITEMS = 9 * TILES;                       // per PU per round
-  static constexpr int BLOCK = S == 32 ? 192 : 256;
+  static constexpr int BLOCK = TILES == 16 ? 192 : 256;
   static constexpr int MINW  = 4;                                // waves per SIMD the register budget is sized for (128 VGPRs; the dot-product V pass fits every size)
-  static constexpr int JPW   = S == 32 ? 4 : ITEMS >= BLOCK ? 1 : BLOCK / ITEMS;   // S = 8: 28, 16: 7, 32: 4 (4 x 144 items = 3 full trips of 192 lanes), 64 / 128: 1
-  static constexpr int WLD   = S + 8;                           // window stride
-  static constexpr int WIN   = ( S + 8 ) * WLD;                 // window samples per PU
-  static constexpr int PLANE = ( S + 8 ) * S;                   // one H-pass plane
-  static constexpr bool SEQ  = S == 128;                        // one plane buffer, the three planes one after the other: 72 KB instead of 141 KB of LDS -> two workgroups per CU
+  static constexpr int JPW   = TILES == 16 ? 4 : ITEMS >= BLOCK ? 1 : BLOCK / ITEMS;   // 8x8: 28, 16x8: 14, 16x16 / 32x8: 7, 32x16: 3, 32x32 / 64x16: 4 (4 x 144 items = 3 full trips of 192 lanes), larger: 1
+  static constexpr int WLD   = W + 8;                           // window stride
+  static constexpr int WIN   = ( H + 8 ) * WLD;                 // window samples per PU
+  static constexpr int PLANE = ( H + 8 ) * W;                   // one H-pass plane
+  static constexpr bool SEQ  = W == 128 && H == 128;            // one plane buffer, the three planes one after the other: 72 KB instead of 141 KB of LDS -> two workgroups per CU
   static constexpr int NPL   = SEQ ? 1 : 3;
   static constexpr int PERJOB = ( ( WIN + NPL * PLANE ) + 7 ) & ~7;   // samples, keeps every plane 16-byte aligned
   static constexpr size_t LDS = ( size_t ) JPW * PERJOB * sizeof( int16_t ) + ( size_t ) JPW * 16 * sizeof( unsigned );
 };
 
-template<int S>
-__global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_search_sq_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+template<int W, int H>
+__global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) void frac_search_sq_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
                                                                             const vtmhip_frac_job *__restrict__ jobs, int numJobs,
                                                                             vtmhip_frac_result *__restrict__ results )
 {
-  using C = FracSq<S>;
+  using C = FracSq<W, H>;
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];
   unsigned *sCost = reinterpret_cast<unsigned *>( lds + C::JPW * C::PERJOB );   // [JPW][16]: 9 candidate distortions (+ scratch)
   __shared__ int sCentre[C::JPW][2];                                            // half-sample winner per PU (round 2 centre)
@@ -382,12 +387,12 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
   const int job0 = blockIdx.x * C::JPW;
   const int nj = min( C::JPW, numJobs - job0 );
 
-  // ---- windows: rows/cols -4 .. S+3 around the integer vector; 8 samples (16 bytes) per thread and step ----------------------
+  // ---- windows: rows -4 .. H+3, columns -4 .. W+3 around the integer vector; 8 samples (16 bytes) per thread and step ----------------------
   {
     constexpr int CH = C::WLD / 8;   // 16-byte chunks per window row
-    for( int i = tid; i < nj * ( S + 8 ) * CH; i += C::BLOCK )
+    for( int i = tid; i < nj * ( H + 8 ) * CH; i += C::BLOCK )
     {
-      const int               jl = i / ( ( S + 8 ) * CH ), rem = i - jl * ( S + 8 ) * CH, r = rem / CH, c = ( rem - r * CH ) * 8;
+      const int               jl = i / ( ( H + 8 ) * CH ), rem = i - jl * ( H + 8 ) * CH, r = rem / CH, c = ( rem - r * CH ) * 8;
       const vtmhip_frac_job &j  = jobs[job0 + jl];
       const int16_t         *ref = refBase + j.refOff + ( long ) ( j.intY + r - 4 ) * j.refStride + ( j.intX + c - 4 );
       const Pel8u            v   = *reinterpret_cast<const Pel8u *>( ref );
@@ -407,13 +412,13 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
 #pragma unroll 1
     for( int seqPl = 0; seqPl < ( C::SEQ ? 3 : 1 ); seqPl++ )   // SEQ: plane by plane through ONE buffer; otherwise a single trip over all three
     {
-    // ---- phase H: plane p (dx = p - 1) of PU jl: (first, !last) 8-tap FIR of window rows 0..S+7; 8 outputs per thread and step ----
+    // ---- phase H: plane p (dx = p - 1) of PU jl: (first, !last) 8-tap FIR of window rows 0..H+7; 8 outputs per thread and step ----
     {
-      constexpr int CH = S / 8, NP = C::NPL;
-      for( int i = tid; i < nj * NP * ( S + 8 ) * CH; i += C::BLOCK )
+      constexpr int CH = W / 8, NP = C::NPL;
+      for( int i = tid; i < nj * NP * ( H + 8 ) * CH; i += C::BLOCK )
       {
-        const int jl = i / ( NP * ( S + 8 ) * CH ), rem = i - jl * NP * ( S + 8 ) * CH;
-        const int pp = rem / ( ( S + 8 ) * CH ), o = rem - pp * ( S + 8 ) * CH, r = o / CH, x0 = ( o - r * CH ) * 8;
+        const int jl = i / ( NP * ( H + 8 ) * CH ), rem = i - jl * NP * ( H + 8 ) * CH;
+        const int pp = rem / ( ( H + 8 ) * CH ), o = rem - pp * ( H + 8 ) * CH, r = o / CH, x0 = ( o - r * CH ) * 8;
         const int p = C::SEQ ? seqPl : pp;
         const vtmhip_frac_job &j = jobs[job0 + jl];
         const int qx = sCentre[jl][0] + ( p - 1 ) * step, ix = qx >> 2, fx = qx & 3;
@@ -454,7 +459,7 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
           const unsigned hv = ( unsigned ) ( unsigned short ) if_finish( sum, pH );
           if( q & 1 ) outw[q >> 1] |= hv << 16; else outw[q >> 1] = hv;
         }
-        *reinterpret_cast<int4 *>( lds + jl * C::PERJOB + C::WIN + pp * C::PLANE + r * S + x0 ) = make_int4( ( int ) outw[0], ( int ) outw[1], ( int ) outw[2], ( int ) outw[3] );
+        *reinterpret_cast<int4 *>( lds + jl * C::PERJOB + C::WIN + pp * C::PLANE + r * W + x0 ) = make_int4( ( int ) outw[0], ( int ) outw[1], ( int ) outw[2], ( int ) outw[3] );
       }
     }
     __syncthreads();
@@ -477,8 +482,9 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
       int cv[8];
 #pragma unroll
       for( int k = 0; k < 8; k++ ) cv[k] = cV[k];
-      const int      ty = tile / ( S / 8 ), tx = tile - ty * ( S / 8 );
-      const int16_t *pl = lds + jl * C::PERJOB + C::WIN + ( C::SEQ ? 0 : dx + 1 ) * C::PLANE + ( ty * 8 + iy + 1 ) * S + tx * 8;
+      // tile order: the long direction of the PU fastest, so that the two 8x8 halves of a 16x8 / 8x16 Hadamard tile are the items of lanes 2k, 2k + 1
+      const int      ty = W >= H ? tile / C::TX : tile % C::TY, tx = W >= H ? tile - ty * C::TX : tile / C::TY;
+      const int16_t *pl = lds + jl * C::PERJOB + C::WIN + ( C::SEQ ? 0 : dx + 1 ) * C::PLANE + ( ty * 8 + iy + 1 ) * W + tx * 8;
       const IfParams pV = if_params( 0, 1, j.bitDepth, 0, ( 1 << j.bitDepth ) - 1, 0 );
       // Vertical FIR with v_dot2c_i32_i16: rows r and r + 1 are interleaved column-wise (two v_perm per dword pair), so one instruction
       // applies two taps: output row y takes the row pairs (y, y+1), (y+2, y+3), (y+4, y+5), (y+6, y+7) with the tap pairs
@@ -497,7 +503,7 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
 #pragma unroll
       for( int r = 1; r < 15; r++ )
       {
-        const int4     cur = *reinterpret_cast<const int4 *>( pl + r * S );   // 8 samples of plane row r
+        const int4     cur = *reinterpret_cast<const int4 *>( pl + r * W );   // 8 samples of plane row r
         const unsigned pw[4] = { ( unsigned ) prev.x, ( unsigned ) prev.y, ( unsigned ) prev.z, ( unsigned ) prev.w };
         const unsigned cw[4] = { ( unsigned ) cur.x, ( unsigned ) cur.y, ( unsigned ) cur.z, ( unsigned ) cur.w };
         v2s pr[8];   // column x: (row r-1, row r)
@@ -549,7 +555,8 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
             wide |= o.v[k];
           }
         }
-        d = __all( ( wide & 0xfc00fc00u ) == 0 ) ? satd8_packed10( D ) : satd8_packed( D );
+        if( C::PAIR ) d = __all( ( wide & 0xfc00fc00u ) == 0 ) ? satd8_pair_packed10( D, ( tile & 1 ) != 0 ) : satd8_pair_packed( D );
+        else          d = __all( ( wide & 0xfc00fc00u ) == 0 ) ? satd8_packed10( D ) : satd8_packed( D );
       }
       else if( j.useHad )
       {
@@ -566,14 +573,23 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
         }
 #pragma unroll
         for( int y = 0; y < 8; y++ ) wht1d<8, 1>( acc + y * 8 );
+        if( C::PAIR )
+        {
 #pragma unroll
-        for( int x = 0; x < 8; x++ ) wht1d<8, 8, false>( acc + x );
-        int t = 0;   // last level + |.| + sum: |a + b| + |a - b| = 2 max(|a|, |b|)
+          for( int x = 0; x < 8; x++ ) wht1d<8, 8>( acc + x );
+          d = satd8_pair_finish32( acc );
+        }
+        else
+        {
 #pragma unroll
-        for( int i = 0; i < 32; i++ ) t += max( abs( acc[i] ), abs( acc[i + 32] ) );
-        t <<= 1;
-        const int dc = abs( acc[0] + acc[32] );
-        d            = ( unsigned ) ( ( t - dc + ( dc >> 2 ) + 2 ) >> 2 );
+          for( int x = 0; x < 8; x++ ) wht1d<8, 8, false>( acc + x );
+          int t = 0;   // last level + |.| + sum: |a + b| + |a - b| = 2 max(|a|, |b|)
+#pragma unroll
+          for( int i = 0; i < 32; i++ ) t += max( abs( acc[i] ), abs( acc[i + 32] ) );
+          t <<= 1;
+          const int dc = abs( acc[0] + acc[32] );
+          d            = ( unsigned ) ( ( t - dc + ( dc >> 2 ) + 2 ) >> 2 );
+        }
       }
       else
       {
@@ -591,7 +607,7 @@ __global__ __launch_bounds__( FracSq<S>::BLOCK, FracSq<S>::MINW ) void frac_sear
         }
         d = t;
       }
-      atomicAdd( &sCost[jl * 16 + cand], d );
+      if( !( C::PAIR && j.useHad ) || ( tile & 1 ) == 0 ) atomicAdd( &sCost[jl * 16 + cand], d );   // a Hadamard pair's value is the same in both lanes: the even one adds it
     }
     __syncthreads();
     }   // planes
@@ -667,14 +683,14 @@ int if_single( vtmhip_ctx *ctx, int vertical, int taps, int isFirst, int isLast,
   return VTMHIP_OK;
 }
 
-template<int S>
+template<int W, int H>
 int launch_frac_sq( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_frac_job *d_jobs, int n, vtmhip_frac_result *d_results )
 {
-  using C = FracSq<S>;
+  using C = FracSq<W, H>;
   if( C::LDS > 64 * 1024 )
-    VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( frac_search_sq_kernel<S> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) C::LDS ) );
+    VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( frac_search_sq_kernel<W, H> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) C::LDS ) );
   VTMHIP_TIME_KERNEL( ctx, "frac_search_sq_kernel" );
-  hipLaunchKernelGGL( frac_search_sq_kernel<S>, dim3( ( n + C::JPW - 1 ) / C::JPW ), dim3( C::BLOCK ), C::LDS, ctx->stream, d_orgBase, d_refBase, d_jobs, n,
+  hipLaunchKernelGGL( ( frac_search_sq_kernel<W, H> ), dim3( ( n + C::JPW - 1 ) / C::JPW ), dim3( C::BLOCK ), C::LDS, ctx->stream, d_orgBase, d_refBase, d_jobs, n,
                       d_results );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
@@ -724,17 +740,16 @@ int vtmhip_frac_search_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, con
   VTMHIP_REQUIRE( ctx, maxWidth >= 4 && maxWidth <= 128 && maxHeight >= 4 && maxHeight <= 128, "maxWidth / maxHeight" );
   if( uniformSquare )
   {
-    // caller's promise: every job is exactly maxWidth x maxHeight, square, and all jobs share imvShift -> tiled fast path
-    VTMHIP_REQUIRE( ctx, maxWidth == maxHeight, "uniformSquare needs maxWidth == maxHeight" );
-    switch( maxWidth )
+    // caller's promise: every job is exactly maxWidth x maxHeight and all jobs share imvShift -> tiled fast path (squares and the split shapes)
+#define VTMHIP_FRAC_CASE( WW, HH ) case ( WW ) * 256 + ( HH ): return launch_frac_sq<WW, HH>( ctx, d_orgBase, d_refBase, d_jobs, n, d_results );
+    switch( maxWidth * 256 + maxHeight )
     {
-    case 8: return launch_frac_sq<8>( ctx, d_orgBase, d_refBase, d_jobs, n, d_results );
-    case 16: return launch_frac_sq<16>( ctx, d_orgBase, d_refBase, d_jobs, n, d_results );
-    case 32: return launch_frac_sq<32>( ctx, d_orgBase, d_refBase, d_jobs, n, d_results );
-    case 64: return launch_frac_sq<64>( ctx, d_orgBase, d_refBase, d_jobs, n, d_results );
-    case 128: return launch_frac_sq<128>( ctx, d_orgBase, d_refBase, d_jobs, n, d_results );
-    default: break;   // other sizes: generic kernel below
+      VTMHIP_FRAC_CASE( 8, 8 ) VTMHIP_FRAC_CASE( 16, 16 ) VTMHIP_FRAC_CASE( 32, 32 ) VTMHIP_FRAC_CASE( 64, 64 ) VTMHIP_FRAC_CASE( 128, 128 )
+      VTMHIP_FRAC_CASE( 16, 8 ) VTMHIP_FRAC_CASE( 8, 16 ) VTMHIP_FRAC_CASE( 32, 8 ) VTMHIP_FRAC_CASE( 8, 32 ) VTMHIP_FRAC_CASE( 32, 16 ) VTMHIP_FRAC_CASE( 16, 32 )
+      VTMHIP_FRAC_CASE( 64, 16 ) VTMHIP_FRAC_CASE( 16, 64 ) VTMHIP_FRAC_CASE( 64, 32 ) VTMHIP_FRAC_CASE( 32, 64 )
+    default: break;   // other shapes: generic kernel below
     }
+#undef VTMHIP_FRAC_CASE
   }
   const size_t lds = frac_lds_bytes( maxWidth, maxHeight );
   if( lds > 64 * 1024 )

@@ -1069,23 +1069,24 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void full_search_kerne
   }
 }
 
-// ---- exhaustive search of small square blocks (8x8, 16x16), +-4: one LANE per candidate -------------------------------------
-// The cooperative kernel above spends a wave-step (8 or 4 candidates) on ~110 instructions; here the (S+8)^2 reference window and
-// the original block of every job of the workgroup are staged in LDS once and each lane owns one of the <= 81 candidates: S*S/2
+// ---- exhaustive search of uniform W x H blocks (squares 8 .. 64 and the binary / ternary split shapes between them), +-4: one LANE per candidate ----
+// The cooperative kernel above spends a wave-step (8 or 4 candidates) on ~110 instructions; here the (W+8) x (H+8) reference window and
+// the original block of every job of the workgroup are staged in LDS once and each lane owns one of the <= 81 candidates: W*H/2
 // v_sad_u16 over dword LDS reads (odd columns through v_alignbit), then the MV rate and an LDS arg-min per job.
-template<int S> struct FullSq
+template<int W, int H> struct FullSq
 {
-  static constexpr int JPB     = S == 8 ? 12 : S == 16 ? 6 : S == 32 ? 3 : 1;   // jobs per workgroup
-  static constexpr int THREADS = S <= 32 ? 256 : 128;                           // 81 candidates per job
+  static constexpr int AREA    = W * H;
+  static constexpr int JPB     = AREA <= 64 ? 12 : AREA <= 128 ? 9 : AREA <= 256 ? 6 : AREA <= 512 ? 4 : AREA <= 1024 ? 3 : 1;   // jobs per workgroup (LDS: windows + blocks <= 64 KB)
+  static constexpr int THREADS = AREA <= 1024 ? 256 : 128;                     // 81 candidates per job
 };
 
-template<int S>
-__global__ __launch_bounds__( FullSq<S>::THREADS ) void full_search_sq_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+template<int W, int H>
+__global__ __launch_bounds__( ( FullSq<W, H>::THREADS ) ) void full_search_sq_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
                                                                const vtmhip_full_job *__restrict__ jobs, int numJobs, vtmhip_me_result *__restrict__ results )
 {
-  constexpr int JPB = FullSq<S>::JPB, THREADS = FullSq<S>::THREADS, WLD = S + 8, WD = WLD / 2 + 1, MAXC = 81;
-  __shared__ unsigned           sWin[JPB][WLD][WD];     // reference window, two samples per dword, one spare dword per row
-  __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned sOrg[JPB][S][S / 2];
+  constexpr int JPB = FullSq<W, H>::JPB, THREADS = FullSq<W, H>::THREADS, WLD = W + 8, WLR = H + 8, WD = WLD / 2 + 1, MAXC = 81;
+  __shared__ unsigned           sWin[JPB][WLR][WD];     // reference window, two samples per dword, one spare dword per row
+  __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned sOrg[JPB][H][W / 2];
   __shared__ int                sRange[JPB][5];          // left, top, nx, ny, floor((2^32 - 1) / nx)
   __shared__ unsigned long long sBest[JPB];
   __shared__ unsigned           sIdx[JPB];
@@ -1108,32 +1109,32 @@ __global__ __launch_bounds__( FullSq<S>::THREADS ) void full_search_sq_kernel( v
     const Range sr = search_range( j, q.centerHor, q.centerVer, q.searchRange );
     sRange[tid][0] = sr.left; sRange[tid][1] = sr.top;
     int nx = sr.right >= sr.left ? sr.right - sr.left + 1 : 0, ny = sr.bottom >= sr.top ? sr.bottom - sr.top + 1 : 0;
-    if( nx > 9 || ny > 9 || q.width != S || q.height != S ) nx = ny = 0;   // the caller's promise is broken: no candidates, cost stays ~0 (never touch memory outside the window)
+    if( nx > 9 || ny > 9 || q.width != W || q.height != H ) nx = ny = 0;   // the caller's promise is broken: no candidates, cost stays ~0 (never touch memory outside the window)
     sRange[tid][2] = nx;
     sRange[tid][3] = ny;
     sRange[tid][4] = ( int ) ( 0xffffffffu / ( unsigned ) max( nx, 1 ) );   // one division per job instead of one per candidate
     sBest[tid] = ~0ull; sIdx[tid] = 0xffffffffu;
   }
   __syncthreads();
-  // stage windows (rows top .. top + ny + S - 2, columns left .. left + nx + S - 2) and original blocks, two samples per thread and step
-  for( int i = tid; i < nj * WLD * ( WLD / 2 ); i += THREADS )
+  // stage windows (rows top .. top + ny + H - 2, columns left .. left + nx + W - 2) and original blocks, two samples per thread and step
+  for( int i = tid; i < nj * WLR * ( WLD / 2 ); i += THREADS )
   {
-    const int jl = i / ( WLD * ( WLD / 2 ) ), rem = i - jl * ( WLD * ( WLD / 2 ) ), r = rem / ( WLD / 2 ), c2 = ( rem - r * ( WLD / 2 ) ) * 2;
+    const int jl = i / ( WLR * ( WLD / 2 ) ), rem = i - jl * ( WLR * ( WLD / 2 ) ), r = rem / ( WLD / 2 ), c2 = ( rem - r * ( WLD / 2 ) ) * 2;
     const int nx = sRange[jl][2], ny = sRange[jl][3];
     unsigned  v = 0;
-    if( r < ny + S - 1 && c2 < nx + S - 1 )
+    if( r < ny + H - 1 && c2 < nx + W - 1 )
     {
       const vtmhip_full_job &q = jobs[job0 + jl];
       const int16_t *p = refBase + q.refOff + ( long ) ( sRange[jl][1] + r ) * q.refStride + ( sRange[jl][0] + c2 );
-      const unsigned lo = ( unsigned short ) p[0], hi = c2 + 1 < nx + S - 1 ? ( unsigned short ) p[1] : 0u;
+      const unsigned lo = ( unsigned short ) p[0], hi = c2 + 1 < nx + W - 1 ? ( unsigned short ) p[1] : 0u;
       v = ( lo | ( hi << 16 ) ) ^ ( q.signedSamples ? 0x80008000u : 0u );
     }
     sWin[jl][r][c2 >> 1] = v;
   }
-  for( int i = tid; i < nj * WLD; i += THREADS ) sWin[i / WLD][i % WLD][WD - 1] = 0;
-  for( int i = tid; i < nj * S * ( S / 2 ); i += THREADS )
+  for( int i = tid; i < nj * WLR; i += THREADS ) sWin[i / WLR][i % WLR][WD - 1] = 0;
+  for( int i = tid; i < nj * H * ( W / 2 ); i += THREADS )
   {
-    const int jl = i / ( S * ( S / 2 ) ), rem = i - jl * ( S * ( S / 2 ) ), r = rem / ( S / 2 ), c2 = ( rem - r * ( S / 2 ) ) * 2;
+    const int jl = i / ( H * ( W / 2 ) ), rem = i - jl * ( H * ( W / 2 ) ), r = rem / ( W / 2 ), c2 = ( rem - r * ( W / 2 ) ) * 2;
     const vtmhip_full_job &q = jobs[job0 + jl];
     const int16_t *p = orgBase + q.orgOff + ( long ) r * q.orgStride + c2;
     sOrg[jl][r][c2 >> 1] = ( ( unsigned ) ( unsigned short ) p[0] | ( ( unsigned ) ( unsigned short ) p[1] << 16 ) ) ^ ( q.signedSamples ? 0x80008000u : 0u );
@@ -1163,15 +1164,15 @@ __global__ __launch_bounds__( FullSq<S>::THREADS ) void full_search_sq_kernel( v
         unsigned       s = 0;
         const int      step = 1 << j.ss;
 #pragma unroll 2
-        for( int r = 0; r < S; r += step )
+        for( int r = 0; r < H; r += step )
         {
           const unsigned *w = &sWin[jl][cy + r][cx >> 1];
           const unsigned *o = &sOrg[jl][r][0];
-          unsigned        d[S / 2 + 1];
+          unsigned        d[W / 2 + 1];
 #pragma unroll
-          for( int m = 0; m <= S / 2; m++ ) d[m] = w[m];
+          for( int m = 0; m <= W / 2; m++ ) d[m] = w[m];
 #pragma unroll
-          for( int m = 0; m < S / 2; m++ ) s = sad2( o[m], __builtin_amdgcn_alignbit( d[m + 1], d[m], sh ), s );
+          for( int m = 0; m < W / 2; m++ ) s = sad2( o[m], __builtin_amdgcn_alignbit( d[m + 1], d[m], sh ), s );
         }
         const int x = sRange[jl][0] + cx, y = sRange[jl][1] + cy;
         myCost[pass] = ( ( unsigned long long ) s << j.ss ) + mv_cost( j, x, y );
@@ -1296,28 +1297,36 @@ extern "C" int vtmhip_full_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_p
 }
 
 
-extern "C" int vtmhip_full_search_square_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
-                                                    const vtmhip_full_job *d_jobs, int n, int size, vtmhip_me_result *d_results )
+extern "C" int vtmhip_full_search_uniform_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                                     const vtmhip_full_job *d_jobs, int n, int width, int height, vtmhip_me_result *d_results )
 {
   VTMHIP_CHECK_CTX( ctx );
-  if( size != 8 && size != 16 && size != 32 && size != 64 ) return vtmhip_full_search_batch_dev( ctx, pic, d_orgBase, d_refBase, d_jobs, n, d_results );
   VTMHIP_REQUIRE( ctx, pic && n >= 0, "pic / n" );
   if( n == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, d_orgBase && d_refBase && d_jobs && d_results, "null pointer" );
   VTMHIP_REQUIRE( ctx, pic->picW > 0 && pic->picH > 0 && pic->ctuSize > 0, "picture parameters" );
-#define VTMHIP_FSQ_LAUNCH( SZ ) \
-  hipLaunchKernelGGL( full_search_sq_kernel<SZ>, dim3( ( n + FullSq<SZ>::JPB - 1 ) / FullSq<SZ>::JPB ), dim3( FullSq<SZ>::THREADS ), 0, ctx->stream, *pic, d_orgBase, \
-                      d_refBase, d_jobs, n, d_results )
-  { VTMHIP_TIME_KERNEL( ctx, "full_search_sq_kernel" );
-  switch( size )
+#define VTMHIP_FSQ_LAUNCH( WW, HH )                                                                                                                                     \
+  case ( WW ) * 256 + ( HH ):                                                                                                                                           \
+    hipLaunchKernelGGL( ( full_search_sq_kernel<WW, HH> ), dim3( ( n + FullSq<WW, HH>::JPB - 1 ) / FullSq<WW, HH>::JPB ), dim3( FullSq<WW, HH>::THREADS ), 0, ctx->stream, \
+                        *pic, d_orgBase, d_refBase, d_jobs, n, d_results );                                                                                             \
+    break;
   {
-  case 8: VTMHIP_FSQ_LAUNCH( 8 ); break;
-  case 16: VTMHIP_FSQ_LAUNCH( 16 ); break;
-  case 32: VTMHIP_FSQ_LAUNCH( 32 ); break;
-  default: VTMHIP_FSQ_LAUNCH( 64 ); break;
-  }
+    VTMHIP_TIME_KERNEL( ctx, "full_search_sq_kernel" );
+    switch( width * 256 + height )
+    {
+      VTMHIP_FSQ_LAUNCH( 8, 8 ) VTMHIP_FSQ_LAUNCH( 16, 16 ) VTMHIP_FSQ_LAUNCH( 32, 32 ) VTMHIP_FSQ_LAUNCH( 64, 64 )
+      VTMHIP_FSQ_LAUNCH( 16, 8 ) VTMHIP_FSQ_LAUNCH( 8, 16 ) VTMHIP_FSQ_LAUNCH( 32, 8 ) VTMHIP_FSQ_LAUNCH( 8, 32 ) VTMHIP_FSQ_LAUNCH( 32, 16 ) VTMHIP_FSQ_LAUNCH( 16, 32 )
+      VTMHIP_FSQ_LAUNCH( 64, 16 ) VTMHIP_FSQ_LAUNCH( 16, 64 ) VTMHIP_FSQ_LAUNCH( 64, 32 ) VTMHIP_FSQ_LAUNCH( 32, 64 )
+    default: return vtmhip_full_search_batch_dev( ctx, pic, d_orgBase, d_refBase, d_jobs, n, d_results );   // other shapes: the cooperative kernel
+    }
   }
 #undef VTMHIP_FSQ_LAUNCH
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
+}
+
+extern "C" int vtmhip_full_search_square_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                                    const vtmhip_full_job *d_jobs, int n, int size, vtmhip_me_result *d_results )
+{
+  return vtmhip_full_search_uniform_batch_dev( ctx, pic, d_orgBase, d_refBase, d_jobs, n, size, size, d_results );
 }

@@ -291,7 +291,6 @@ extern "C" int vtmhip_xMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip
   VTMHIP_REQUIRE( ctx, maxWidth >= 4 && maxWidth <= 128 && maxHeight >= 4 && maxHeight <= 128, "maxWidth / maxHeight" );
   VTMHIP_REQUIRE( ctx, cfg->uniformImv >= -1 && cfg->uniformImv <= 3, "uniformImv" );
   VTMHIP_REQUIRE( ctx, cfg->bipredSearchRange >= 0 && cfg->bipredSearchRange <= 64, "bipredSearchRange" );
-  VTMHIP_REQUIRE( ctx, !cfg->uniformSquare || maxWidth == maxHeight, "uniformSquare needs maxWidth == maxHeight" );
   VTMHIP_REQUIRE( ctx, cfg->uniformBi >= 0 && cfg->uniformBi <= 2, "uniformBi" );
 
   const int  uimv = cfg->uniformImv, ubi = cfg->uniformBi;
@@ -347,10 +346,10 @@ extern "C" int vtmhip_xMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip
     }
     hipLaunchKernelGGL( mest_bi_start_kernel, perJob, tpb, 0, ctx->stream, *pic, *cfg, d_jobs, n, wk );
     VTMHIP_LAUNCHED( ctx );
-    // the lane-per-candidate kernel needs every slot to be a real size x size job: uniform square batches of bi jobs only (in a mixed batch the
+    // the lane-per-candidate kernel needs every slot to be a real maxWidth x maxHeight job: uniform batches of bi jobs only (in a mixed batch the
     // slots of uni jobs are empty; the cooperative kernel skips them)
     if( allBi && cfg->uniformSquare && cfg->bipredSearchRange <= 4 )
-      st = vtmhip_full_search_square_batch_dev( ctx, &pFull, patBase, d_refBase, wk.full, n, maxWidth, wk.ires );
+      st = vtmhip_full_search_uniform_batch_dev( ctx, &pFull, patBase, d_refBase, wk.full, n, maxWidth, maxHeight, wk.ires );
     else
       st = vtmhip_full_search_batch_dev( ctx, &pFull, patBase, d_refBase, wk.full, n, wk.ires );
     if( st ) return st;

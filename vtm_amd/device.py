@@ -204,9 +204,11 @@ class Context:
     def dequant_batch(self, d_q, d_coef, d_jobs, n):
         self._check(self.L.vtmhip_dequant_batch_dev(self.h, d_q, d_coef, d_jobs, n))
 
-    def full_search_batch(self, pic, d_org, d_ref, d_jobs, n, d_results, square=0):
-        """square = S: the caller promises S x S jobs with searchRange <= 4 (lane-per-candidate kernel for S = 8 / 16)."""
-        if square:
+    def full_search_batch(self, pic, d_org, d_ref, d_jobs, n, d_results, square=0, uniform=None):
+        """square = S / uniform = (W, H): the caller promises S x S (W x H) jobs with searchRange <= 4 (lane-per-candidate kernel)."""
+        if uniform:
+            self._check(self.L.vtmhip_full_search_uniform_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, uniform[0], uniform[1], d_results))
+        elif square:
             self._check(self.L.vtmhip_full_search_square_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, square, d_results))
         else:
             self._check(self.L.vtmhip_full_search_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, d_results))

@@ -278,6 +278,8 @@ _PROTOS = {
     "vtmhip_frame_child_start": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "vtmhip_frame_frac_jobs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "vtmhip_frame_stage": (C.c_int, [C.c_void_p, C.POINTER(FrameTabs), C.c_int]),
+    "vtmhip_full_search_uniform_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                       C.c_void_p]),
     "vtmhip_full_search_square_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                       C.c_void_p]),
     "vtmhip_mc_luma_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
