@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--shard", choices=["ctu", "row"], default="ctu", help="--gpus N: raster-scan CTU ranges (balanced) or whole CTU rows")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--partition", choices=["qt", "btt"], default="qt", help="qt: the five quadtree levels 128 .. 8 (the headline workload); btt: a binary / ternary "
+                    "split mix -- 128x128, 64x64, 64x32, 32x32, 32x16, 16x16, 16x8, 8x8 -- through the rectangular fast paths")
     ap.add_argument("--luma-only", action="store_true", help="no chroma planes and no BDOF in the final prediction (the round-2 mid-round operating point)")
     ap.add_argument("--serial", action="store_true", help="one stream, no overlap of the levels' chains: clean per-kernel times for profiling")
     return ap.parse_args()
@@ -78,7 +80,7 @@ def cpu_baseline(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, budget_s, pocs=Non
     per_level = budget_s / len(snaps)
     for li, lvl in enumerate(snaps):
         s, npu = lvl["size"], lvl["npu"]
-        parent = snaps[li - 1] if li and snaps[li - 1]["size"] == 2 * s else None
+        parent = snaps[li - 1] if li else None
         t_lvl, n_lvl = 0.0, 0
         for i in rng.permutation(npu):
             i = int(i)
@@ -96,7 +98,7 @@ def cpu_baseline(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, budget_s, pocs=Non
                 break
         total_s += t_lvl / n_lvl * npu
         done += n_lvl
-        detail.append("%dx%d:%d" % (s, s, n_lvl))
+        detail.append("%dx%d:%d" % (lvl["w"], lvl["h"], n_lvl))
     return {"value": 1.0 / total_s, "unit": "pictures/s", "cores": 1, "kind": "reference" if R is not None else "port",
             "sample": "%d PUs (%s) of the same picture through the whole chain, per-level time extrapolated to all %d PUs; %d mismatches vs GPU"
                       % (done, " ".join(detail), sum(l["npu"] for l in snaps), mism),
@@ -194,7 +196,8 @@ def main():
     lam, qp = 8.0, a.qp
     bands = pipeline.ctu_bands(W, H, world, unit=a.shard)
     ctu_filter = pipeline.band_filter(W, bands[rank]) if world > 1 else None
-    fme = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, ctu_filter=ctu_filter, transform_skip=a.transform_skip, pocs=poc_arg, chroma=ch_dev)
+    fme = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, ctu_filter=ctu_filter, transform_skip=a.transform_skip, pocs=poc_arg, chroma=ch_dev,
+                       sizes=(128, 64, 32, 16, 8) if a.partition == "qt" else (128, (64, 64), (64, 32), (32, 32), (32, 16), (16, 16), (16, 8), (8, 8)))
 
     # N > 1: the reconstructed reference planes go from rank 0 to every GPU inside every step (RCCL broadcast over xGMI; bytes view: int16 is
     # not a collective dtype), double-buffered: the planes of step k + 1 travel while step k computes; the ranks' result records go back to rank 0
@@ -318,10 +321,11 @@ def main():
             "value": a.steps / dt, "unit": "pictures/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int16 samples, int32 accumulation (fp64 MV-rate multiply)", "data": "synthetic",
-            "config": {"workload": "%dx%d 10-bit, %s operating point (QP%d, %s, FEN): quadtree PUs 128..8 = %d PUs x (%d + %d) reference pictures = %d uni searches + %d bi searches "
+            "config": {"workload": "%dx%d 10-bit, %s operating point (QP%d, %s, FEN): %s = %d PUs x (%d + %d) reference pictures = %d uni searches + %d bi searches "
                                    "per picture, %d TU x transform-candidate chains"
                                    % (W, H, "encoder_randomaccess_vtm.cfg" if a.config == "ra" else "encoder_lowdelay_P_vtm.cfg", qp,
-                                      "SR 96 via ASR" if a.config == "ra" else "SR 64", wc["pus"] * world if world > 1 else wc["pus"], len(refs[0]), len(refs[1]),
+                                      "SR 96 via ASR" if a.config == "ra" else "SR 64", "quadtree PUs 128..8" if a.partition == "qt" else "split-shape PU levels 128x128 64x64 64x32 32x32 32x16 16x16 16x8 8x8",
+                                      wc["pus"] * world if world > 1 else wc["pus"], len(refs[0]), len(refs[1]),
                                       wc["uni_searches"], wc["bi_searches"], wc["tu_chains"]) + (" (this rank's share)" if world > 1 else ""),
                        "stages": ["xEstimateMvPredAMVP", "xMotionEstimation uni (TZ + frac)", "xCheckBestMVP / best reference", "bi refinement (MC + removeHighFreq fused, xPatternSearch, frac)",
                                   "uni/bi decision", "final prediction + residual (fused)" + ("" if a.luma_only else "; BDOF where xPredInterBi applies it; Cb / Cr prediction + residual"),

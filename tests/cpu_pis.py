@@ -15,31 +15,32 @@ CFG = (4, 1, 1, 0, 1)   # BipredSearchRange 4, HadamardME, FEN (FASTINTERSEARCH_
 U64 = (1 << 64) - 1
 
 
-def _mc(L, R, ref_ptr, rs, s, mvx, mvy, bi, dst, bd=10):
+def _mc(L, R, ref_ptr, rs, wh, mvx, mvy, bi, dst, bd=10):
     """xPredInterBlk luma (InterPrediction.cpp:660-815) through the reference's filterHor / filterVer when available."""
+    w, h = wh
     if R is None:
-        L.vo_mc_luma(C.c_void_p(ref_ptr), rs, s, s, mvx, mvy, bi, bd, 0, ol.P(dst), s)
+        L.vo_mc_luma(C.c_void_p(ref_ptr), rs, w, h, mvx, mvy, bi, bd, 0, ol.P(dst), w)
         return
     xf, yf, rnd = mvx & 15, mvy & 15, 0 if bi else 1
     src = ref_ptr + 2 * ((mvy >> 4) * rs + (mvx >> 4))
     if yf == 0:
-        R.ref_if_hor(1, 0, C.c_void_p(src), rs, ol.P(dst), s, s, s, xf, rnd, bd, 0, 0, 0)
+        R.ref_if_hor(1, 0, C.c_void_p(src), rs, ol.P(dst), w, w, h, xf, rnd, bd, 0, 0, 0)
     elif xf == 0:
-        R.ref_if_ver(1, 0, C.c_void_p(src), rs, ol.P(dst), s, s, s, yf, 1, rnd, bd, 0, 0, 0)
+        R.ref_if_ver(1, 0, C.c_void_p(src), rs, ol.P(dst), w, w, h, yf, 1, rnd, bd, 0, 0, 0)
     else:
-        tmp = np.zeros((s + 7, s), np.int16)
-        R.ref_if_hor(1, 0, C.c_void_p(src - 2 * 3 * rs), rs, ol.P(tmp), s, s, s + 7, xf, 0, bd, 0, 0, 0)
-        R.ref_if_ver(1, 0, C.c_void_p(tmp.ctypes.data + 2 * 3 * s), s, ol.P(dst), s, s, s, yf, 0, rnd, bd, 0, 0, 0)
+        tmp = np.zeros((h + 7, w), np.int16)
+        R.ref_if_hor(1, 0, C.c_void_p(src - 2 * 3 * rs), rs, ol.P(tmp), w, w, h + 7, xf, 0, bd, 0, 0, 0)
+        R.ref_if_ver(1, 0, C.c_void_p(tmp.ctypes.data + 2 * 3 * w), w, ol.P(dst), w, w, h, yf, 0, rnd, bd, 0, 0, 0)
 
 
 def _ref_idx_bits(num_ref, r):
     return (r + 1 - (1 if r == num_ref - 1 else 0)) if num_ref > 1 else 0
 
 
-def _mest_job(org, s, ref_ptr, rs, x, y, W, H, lam, sr, cands, bd=10):
+def _mest_job(org, wh, ref_ptr, rs, x, y, W, H, lam, sr, cands, bd=10):
     t = ol.MestJob()
-    t.org, t.orgStride, t.ref, t.refStride = org.ctypes.data, s, ref_ptr, rs
-    t.w, t.h, t.puX, t.puY, t.picW, t.picH, t.ctuSize, t.bitDepth = s, s, x, y, W, H, 128, bd
+    t.org, t.orgStride, t.ref, t.refStride = org.ctypes.data, wh[0], ref_ptr, rs
+    t.w, t.h, t.puX, t.puY, t.picW, t.picH, t.ctuSize, t.bitDepth = wh[0], wh[1], x, y, W, H, 128, bd
     t.imv, t.numAmvpCand, t.searchRange, t.motionLambda, t.numExtraStart = 0, 2, sr, lam, 0
     for i in range(2):
         t.amvpCand[i][0], t.amvpCand[i][1] = int(cands[i][0]), int(cands[i][1])
@@ -58,27 +59,28 @@ def _check_best(L, R, lam, cands, row):
 
 
 def _tu_chain(L, R, r_tu, ts, mts, qp_per, qp_rem, bd):
-    """one TU, one transform candidate: xT (or transform skip), Quant::quant, dequant, xIT, SSE -> (sse, sum |coef|, absSum)"""
-    coef, qc, dq, asum = np.zeros(ts * ts, np.int32), np.zeros(ts * ts, np.int32), np.zeros(ts * ts, np.int32), C.c_int32()
-    rec = np.zeros((ts, ts), np.int16)
+    """one TU (ts: side of a square or (tw, th)), one transform candidate: xT (or transform skip), Quant::quant, dequant, xIT, SSE -> (sse, sum |coef|, absSum)"""
+    tw, th_ = (ts, ts) if np.isscalar(ts) else ts
+    coef, qc, dq, asum = np.zeros(tw * th_, np.int32), np.zeros(tw * th_, np.int32), np.zeros(tw * th_, np.int32), C.c_int32()
+    rec = np.zeros((th_, tw), np.int16)
     if mts == 1:      # transform skip: xTransformSkip / xITransformSkip are copies
         coef[:] = r_tu.reshape(-1)
-        L.vo_quant(ol.P(coef), ts, ts, bd, qp_per, qp_rem, 0, 1, ol.P(qc), None, C.byref(asum))
-        L.vo_dequant(ol.P(qc), ts, ts, bd, qp_per, qp_rem, 1, ol.P(dq))
-        rec[:] = dq.reshape(ts, ts).astype(np.int16)
+        L.vo_quant(ol.P(coef), tw, th_, bd, qp_per, qp_rem, 0, 1, ol.P(qc), None, C.byref(asum))
+        L.vo_dequant(ol.P(qc), tw, th_, bd, qp_per, qp_rem, 1, ol.P(dq))
+        rec[:] = dq.reshape(th_, tw).astype(np.int16)
     else:
         th, tv = MTS_IDX_TYPES[mts]
         if R is None:
-            assert L.vo_fwd_2d(ol.P(r_tu), ts, ts, ts, bd, th, tv, ol.P(coef)) == 0
+            assert L.vo_fwd_2d(ol.P(r_tu), tw, tw, th_, bd, th, tv, ol.P(coef)) == 0
         else:
-            R.ref_xT(ol.P(r_tu), ts, ts, ts, bd, mts, ol.P(coef))          # the real TrQuant::xT
-        L.vo_quant(ol.P(coef), ts, ts, bd, qp_per, qp_rem, 0, 0, ol.P(qc), None, C.byref(asum))
-        L.vo_dequant(ol.P(qc), ts, ts, bd, qp_per, qp_rem, 0, ol.P(dq))
+            R.ref_xT(ol.P(r_tu), tw, tw, th_, bd, mts, ol.P(coef))          # the real TrQuant::xT
+        L.vo_quant(ol.P(coef), tw, th_, bd, qp_per, qp_rem, 0, 0, ol.P(qc), None, C.byref(asum))
+        L.vo_dequant(ol.P(qc), tw, th_, bd, qp_per, qp_rem, 0, ol.P(dq))
         if R is None:
-            assert L.vo_inv_2d(ol.P(dq), ts, ts, bd, th, tv, ol.P(rec), ts) == 0
+            assert L.vo_inv_2d(ol.P(dq), tw, th_, bd, th, tv, ol.P(rec), tw) == 0
         else:
-            R.ref_xIT(ol.P(dq), ts, ts, bd, mts, ol.P(rec), ts)             # the real TrQuant::xIT
-    sse = ol.r_dist(2, 0, r_tu, rec, ts, ts, bd) if R else ol.o_dist(2, r_tu, rec, ts, ts)
+            R.ref_xIT(ol.P(dq), tw, th_, bd, mts, ol.P(rec), tw)             # the real TrQuant::xIT
+    sse = ol.r_dist(2, 0, r_tu, rec, tw, th_, bd) if R else ol.o_dist(2, r_tu, rec, tw, th_)
     return (int(sse), int(np.abs(coef.astype(np.int64)).sum()), asum.value)
 
 
@@ -87,7 +89,8 @@ def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam,
     device driver derived them from the parent level.  Returns every decision the device pipeline exposes."""
     L, R = ol.oracle(), ref
     cfg = ol.MestCfg(*CFG)
-    org = np.ascontiguousarray(cur_np[y:y + s, x:x + s])
+    w, h = wh = (s, s) if np.isscalar(s) else tuple(s)          # a quadtree level's square, or a split shape
+    org = np.ascontiguousarray(cur_np[y:y + h, x:x + w])
     nref = [len(refs[0]), len(refs[1])]
     is_b = nref[1] > 0
     mb = (3 if is_b else 1, 3, 5)
@@ -99,7 +102,7 @@ def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam,
         for r in range(nref[l]):
             ref_ptr = dpb_ptr + 2 * (refs[l][r][0] + y * rs + x)
             cands = cands_rows[l][r]
-            t = _mest_job(org, s, ref_ptr, rs, x, y, W, H, lam, search_ranges[l][r], cands, bd)
+            t = _mest_job(org, wh, ref_ptr, rs, x, y, W, H, lam, search_ranges[l][r], cands, bd)
             idx, ph, pv, dist = C.c_int(), C.c_int(), C.c_int(), C.c_uint64()
             (R.ref_estimate_mvp_amvp if R else L.vo_estimate_mvp_amvp)(C.byref(t), C.byref(idx), C.byref(ph), C.byref(pv), C.byref(dist))
             out["amvp"][(l, r)] = (idx.value, ph.value, pv.value)
@@ -120,14 +123,14 @@ def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam,
     if is_b:
         rl = 1 if best[0]["cost"] <= best[1]["cost"] else 0
         ot = 1 - rl
-        pred_o = np.zeros((s, s), np.int16)
-        _mc(L, R, dpb_ptr + 2 * (refs[ot][best[ot]["ref"]][0] + y * rs + x), rs, s, best[ot]["mv"][0], best[ot]["mv"][1], 0, pred_o, bd)
+        pred_o = np.zeros((h, w), np.int16)
+        _mc(L, R, dpb_ptr + 2 * (refs[ot][best[ot]["ref"]][0] + y * rs + x), rs, wh, best[ot]["mv"][0], best[ot]["mv"][1], 0, pred_o, bd)
         mot_other = best[ot]["bits"] - mb[ot]
         cost_bi, bits2, mv_bi, ref_bi = U64, 0, best[rl]["mv"], best[rl]["ref"]
         out["bi_rows"] = {}
         for r in range(nref[rl]):
             t, u = jobs[(rl, r)], rows[(rl, r)]
-            t.bi, t.otherPred, t.otherStride = 1, pred_o.ctypes.data, s
+            t.bi, t.otherPred, t.otherStride = 1, pred_o.ctypes.data, w
             t.mvpIdx, t.mvPredHor, t.mvPredVer, t.mvHor, t.mvVer = u["idx"], u["pred"][0], u["pred"][1], u["mv"][0], u["mv"][1]
             t.bits = mb[2] + mot_other + _ref_idx_bits(nref[rl], r) + 1
             res = ol.MestResult()
@@ -143,67 +146,65 @@ def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam,
             mv_final[rl], ref_final[rl] = mv_bi, ref_bi
     out["inter_dir"] = inter_dir
     # ---- final prediction and residual (motionCompensation; InterSearch.cpp:7260-7262) ----
-    pred = np.zeros((s, s), np.int16)
+    pred = np.zeros((h, w), np.int16)
     bio = False
     if inter_dir == 3 and pocs is not None and bdof:     # InterPrediction::xPredInterBi :527-572 / PU::isBiPredFromDifferentDirEqDistPoc
         d0, d1 = pocs[0] - pocs[1][ref_final[0]], pocs[0] - pocs[2][ref_final[1]]
-        bio = d0 * d1 < 0 and abs(d0) == abs(d1) and s >= 8 and s * s >= 128
+        bio = d0 * d1 < 0 and abs(d0) == abs(d1) and w >= 8 and h >= 8 and w * h >= 128
     out["bio"] = bio
     if bio:
         if R:
-            R.ref_bdof_pu(1, C.c_void_p(dpb_ptr + 2 * refs[0][ref_final[0]][0]), C.c_void_p(dpb_ptr + 2 * refs[1][ref_final[1]][0]), rs, W, H, x, y, s, s,
-                          mv_final[0][0], mv_final[0][1], mv_final[1][0], mv_final[1][1], bd, ol.P(pred), s)
+            R.ref_bdof_pu(1, C.c_void_p(dpb_ptr + 2 * refs[0][ref_final[0]][0]), C.c_void_p(dpb_ptr + 2 * refs[1][ref_final[1]][0]), rs, W, H, x, y, w, h,
+                          mv_final[0][0], mv_final[0][1], mv_final[1][0], mv_final[1][1], bd, ol.P(pred), w)
         else:
-            L.vo_bdof_pu(C.c_void_p(dpb_ptr + 2 * (refs[0][ref_final[0]][0] + y * rs + x)), rs, C.c_void_p(dpb_ptr + 2 * (refs[1][ref_final[1]][0] + y * rs + x)), rs, s, s,
-                         mv_final[0][0], mv_final[0][1], mv_final[1][0], mv_final[1][1], bd, ol.P(pred), s)
+            L.vo_bdof_pu(C.c_void_p(dpb_ptr + 2 * (refs[0][ref_final[0]][0] + y * rs + x)), rs, C.c_void_p(dpb_ptr + 2 * (refs[1][ref_final[1]][0] + y * rs + x)), rs, w, h,
+                         mv_final[0][0], mv_final[0][1], mv_final[1][0], mv_final[1][1], bd, ol.P(pred), w)
     elif inter_dir == 3:
-        p = [np.zeros((s, s), np.int16) for _ in range(2)]
+        p = [np.zeros((h, w), np.int16) for _ in range(2)]
         for l in (0, 1):
-            _mc(L, R, dpb_ptr + 2 * (refs[l][ref_final[l]][0] + y * rs + x), rs, s, mv_final[l][0], mv_final[l][1], 1, p[l], bd)
-        (R.ref_add_avg if R else L.vo_add_avg)(ol.P(p[0]), s, ol.P(p[1]), s, ol.P(pred), s, s, s, bd)
+            _mc(L, R, dpb_ptr + 2 * (refs[l][ref_final[l]][0] + y * rs + x), rs, wh, mv_final[l][0], mv_final[l][1], 1, p[l], bd)
+        (R.ref_add_avg if R else L.vo_add_avg)(ol.P(p[0]), w, ol.P(p[1]), w, ol.P(pred), w, w, h, bd)
     else:
         l = inter_dir - 1
-        _mc(L, R, dpb_ptr + 2 * (refs[l][ref_final[l]][0] + y * rs + x), rs, s, mv_final[l][0], mv_final[l][1], 0, pred, bd)
+        _mc(L, R, dpb_ptr + 2 * (refs[l][ref_final[l]][0] + y * rs + x), rs, wh, mv_final[l][0], mv_final[l][1], 0, pred, bd)
     resi = (org.astype(np.int32) - pred).astype(np.int16)
     out["resi"] = resi
     # ---- residual coding per TU and transform candidate (xEstimateInterResidualQT :6637-6733 without the CABAC estimate) ----
-    ts = min(s, 64)
-    q = s // ts
+    tw, th = min(w, 64), min(h, 64)
     out["tus"] = {}
-    for qy in range(q):
-        for qx in range(q):
-            r_tu = np.ascontiguousarray(resi[qy * ts:(qy + 1) * ts, qx * ts:(qx + 1) * ts])
+    for qy in range(h // th):
+        for qx in range(w // tw):
+            r_tu = np.ascontiguousarray(resi[qy * th:(qy + 1) * th, qx * tw:(qx + 1) * tw])
             for ci, mts in enumerate(tu_cands):
-                out["tus"][(qy * q + qx, ci)] = _tu_chain(L, R, r_tu, ts, mts, qp_per, qp_rem, bd)
+                out["tus"][(qy * (w // tw) + qx, ci)] = _tu_chain(L, R, r_tu, (tw, th), mts, qp_per, qp_rem, bd)
     # ---- the 4:2:0 chroma planes: xPredInterBlk with the 4-tap filter at 1/32 phase, addAvg, residual, DCT2 chain at the chroma QP ----
     if chroma is not None:
-        sc, rsc = s // 2, chroma["ref_stride"]
+        wc, hc, rsc = w // 2, h // 2, chroma["ref_stride"]
         out["tus_c"] = {}
         for c in (0, 1):
-            org_c = np.ascontiguousarray(chroma["cur"][c][y // 2:y // 2 + sc, x // 2:x // 2 + sc])
+            org_c = np.ascontiguousarray(chroma["cur"][c][y // 2:y // 2 + hc, x // 2:x // 2 + wc])
 
             def mc_c(l, bi, dst):
                 plane = dpb_ptr + 2 * chroma["refs"][l][ref_final[l]][c]
                 if R:
-                    R.ref_pred_inter_blk(1 + c, C.c_void_p(dpb_ptr + 2 * refs[l][ref_final[l]][0]), rs, C.c_void_p(plane), rsc, W, H, x, y, s, s, mv_final[l][0], mv_final[l][1],
-                                         bi, bd, 0, ol.P(dst), sc)
+                    R.ref_pred_inter_blk(1 + c, C.c_void_p(dpb_ptr + 2 * refs[l][ref_final[l]][0]), rs, C.c_void_p(plane), rsc, W, H, x, y, w, h, mv_final[l][0], mv_final[l][1],
+                                         bi, bd, 0, ol.P(dst), wc)
                 else:
-                    L.vo_mc_block(1 + c, C.c_void_p(plane + 2 * ((y // 2) * rsc + x // 2)), rsc, sc, sc, mv_final[l][0], mv_final[l][1], bi, bd, 0, ol.P(dst), sc)
-            pc = np.zeros((sc, sc), np.int16)
+                    L.vo_mc_block(1 + c, C.c_void_p(plane + 2 * ((y // 2) * rsc + x // 2)), rsc, wc, hc, mv_final[l][0], mv_final[l][1], bi, bd, 0, ol.P(dst), wc)
+            pc = np.zeros((hc, wc), np.int16)
             if inter_dir == 3:
-                pp = [np.zeros((sc, sc), np.int16) for _ in range(2)]
+                pp = [np.zeros((hc, wc), np.int16) for _ in range(2)]
                 for l in (0, 1):
                     mc_c(l, 1, pp[l])
-                (R.ref_add_avg if R else L.vo_add_avg)(ol.P(pp[0]), sc, ol.P(pp[1]), sc, ol.P(pc), sc, sc, sc, bd)
+                (R.ref_add_avg if R else L.vo_add_avg)(ol.P(pp[0]), wc, ol.P(pp[1]), wc, ol.P(pc), wc, wc, hc, bd)
             else:
                 mc_c(inter_dir - 1, 0, pc)
             resi_c = (org_c.astype(np.int32) - pc).astype(np.int16)
-            tsc = min(sc, 32)
-            qc = sc // tsc
-            for qy in range(qc):
-                for qx in range(qc):
-                    r_tu = np.ascontiguousarray(resi_c[qy * tsc:(qy + 1) * tsc, qx * tsc:(qx + 1) * tsc])
-                    out["tus_c"][(c, qy * qc + qx)] = _tu_chain(L, R, r_tu, tsc, 0, chroma["qp_per"], chroma["qp_rem"], bd)
+            twc, thc = min(wc, 32), min(hc, 32)
+            for qy in range(hc // thc):
+                for qx in range(wc // twc):
+                    r_tu = np.ascontiguousarray(resi_c[qy * thc:(qy + 1) * thc, qx * twc:(qx + 1) * twc])
+                    out["tus_c"][(c, qy * (wc // twc) + qx)] = _tu_chain(L, R, r_tu, (twc, thc), 0, chroma["qp_per"], chroma["qp_rem"], bd)
     return out
 
 
@@ -246,28 +247,29 @@ def compare_with_device(snap_level, parent_level, nref, i, out):
         for r, me in out["bi_rows"].items():
             g = bo[r * n + i]
             assert (me["mv"], me["bits"], me["cost"]) == ((int(g["mvHor"]), int(g["mvVer"])), int(g["bits"]), int(g["cost"])), ("bi me", s, i, r)
-    ntu, ts = snap_level["ntu"], snap_level["ts"]
-    q = s // ts
+    ntu = snap_level["ntu"]
+    w, h = snap_level["w"], snap_level["h"]
+    q2 = (w // snap_level["tw"]) * (h // snap_level["th"])
     tr = snap_level["tu_res"]
     for (tu, ci), (sse, sa, asum) in out["tus"].items():
-        k = ci * ntu + i * q * q + tu
+        k = ci * ntu + i * q2 + tu
         got = (int(tr[k, 0]), int(tr[k, 1] & 0xFFFFFFFF), int((tr[k, 1] >> 32) & 0xFFFFFFFF))
         assert (sse, sa, asum) == got, ("tu", s, i, tu, ci, (sse, sa, asum), got)
     if "route" in snap_level:
         assert int(snap_level["route"][i]) == (1 if out["bio"] else 2), ("BDOF routing", s, i)
     if "tus_c" in out:
-        ntc, sc, tsc = snap_level["ntu_c"], s // 2, snap_level["ts_c"]
-        qc = sc // tsc
+        ntc = snap_level["ntu_c"]
+        qc2 = ((w // 2) // snap_level["tw_c"]) * ((h // 2) // snap_level["th_c"])
         trc = snap_level["tu_res_c"]
         for (c, tu), (sse, sa, asum) in out["tus_c"].items():
-            k = c * ntc + i * qc * qc + tu
+            k = c * ntc + i * qc2 + tu
             got = (int(trc[k, 0]), int(trc[k, 1] & 0xFFFFFFFF), int((trc[k, 1] >> 32) & 0xFFFFFFFF))
             assert (sse, sa, asum) == got, ("chroma tu", s, i, c, tu, (sse, sa, asum), got)
     # the AMVP candidates themselves: candidate 0 is the parent's vector for the same (list, refIdx), candidate 1 zero
     if parent_level is not None:
-        ps = parent_level["size"]
+        pw, ph = parent_level["w"], parent_level["h"]
         x, y = int(snap_level["xs"][i]), int(snap_level["ys"][i])
-        hit = np.nonzero((parent_level["xs"] == x // ps * ps) & (parent_level["ys"] == y // ps * ps))[0]
+        hit = np.nonzero((parent_level["xs"] == x // pw * pw) & (parent_level["ys"] == y // ph * ph))[0]
         for l in (0, 1):
             for r in range(nref[l]):
                 lr = (nref[0] if l else 0) + r

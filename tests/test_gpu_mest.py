@@ -170,3 +170,35 @@ def test_uniform_rect_fast_paths(ctx, w, h, bi, opts):
         exp.append(r.key())
     got, _ = run_device(ctx, scene, jobs, cfgv, uniform_imv=0, uniform_square=1, max_wh=(w, h), uniform_bi=1 + bi, **opts)
     assert got == exp
+
+
+@pytest.mark.parametrize("bi", [0, 1])
+def test_mixed_shape_batch_is_bucketed_by_shape(ctx, bi):
+    """One call with blocks of every shape (squares, split rectangles, odd sizes) and no uniform-size promise: the library buckets the job table by shape
+    on the device and runs the uniform chains per class (the tiled fractional kernel needs uniformImv 0); results come back at the jobs' own indices."""
+    L = ol.oracle()
+    scene = me_util.Scene(416, 240, hard=True)
+    ws = [8, 16, 32, 64, 16, 8, 32, 8, 32, 16, 64, 16, 64, 32, 24, 4, 128]
+    hs = [8, 16, 32, 64, 8, 16, 8, 32, 16, 32, 16, 64, 32, 64, 16, 8, 128]
+    rng = np.random.default_rng(77 + bi)
+    jobs = []
+    for k in range(340):
+        i = int(rng.integers(0, len(ws)))
+        jobs += me_util.random_mest_jobs(scene, 1, seed=9000 + 10 * k + bi, sizes=([ws[i]], [hs[i]]))
+    for j in jobs:
+        j["imv"], j["bi"] = 0, bi
+        j["cands"] = [[me_util._round_amvr(v, 0) for v in c] for c in j["cands"]]
+        j["mvPred"] = tuple(j["cands"][j["mvpIdx"]])
+    assert len({(j["w"], j["h"]) for j in jobs}) >= 15
+    cfgv = (4, 1, 1, 0, 1)
+    cfg = ol.MestCfg(*cfgv)
+    exp = []
+    for j in jobs:
+        keep = []
+        t = me_util.oracle_mest_job(scene, j, keep)
+        r = ol.MestResult()
+        L.vo_motion_estimation(C.byref(cfg), C.byref(t), C.byref(r))
+        exp.append(r.key())
+    got, _ = run_device(ctx, scene, jobs, cfgv, uniform_imv=0, uniform_square=0, max_wh=(128, 128), uniform_bi=1 + bi)
+    bad = [k for k in range(len(jobs)) if got[k] != exp[k]]
+    assert not bad, [(jobs[k]["w"], jobs[k]["h"], got[k], exp[k]) for k in bad[:5]]

@@ -63,7 +63,7 @@ def check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, R, per_level=24, min_chec
         cqp = pipeline.chroma_qp(qp) + 12
         chroma = dict(chroma, qp_per=cqp // 6, qp_rem=cqp % 6)
     for li, lvl in enumerate(snaps):
-        parent = snaps[li - 1] if li and snaps[li - 1]["size"] == 2 * lvl["size"] else None
+        parent = snaps[li - 1] if li else None
         s, npu = lvl["size"], lvl["npu"]
         for i in range(0, npu, max(1, npu // per_level)):
             out = cpu_pis.run_pu(cur_np, dpb_np.ctypes.data, refs, sr, W, H, s, int(lvl["xs"][i]), int(lvl["ys"][i]), cpu_pis.cands_of(lvl, nref, i), lam,
@@ -134,6 +134,34 @@ def test_frame_hot_path_with_bdof_and_chroma(use_ref, name, pocs0, pocs1, cur, q
     ctx.close()
 
 
+@pytest.mark.parametrize("use_ref", [False, True])
+@pytest.mark.parametrize("name,sizes", [("bt", (128, (64, 64), (64, 32), (32, 32), (16, 32), (16, 16), (16, 8), (8, 8))),
+                                        ("tt", ((64, 64), (64, 16), (32, 16), (32, 8), (8, 8))), ("tt_ver", ((64, 64), (16, 64), (16, 32), (8, 32), (8, 16)))])
+def test_frame_hot_path_on_split_shapes(use_ref, name, sizes):
+    """The driver on binary / ternary split shapes: every level is one W x H shape whose blocks nest inside the previous level's; the
+    uniform rectangular fast paths (TZ, tiled fractional search with 16x8 / 8x16 Hadamard tiles, lane-per-candidate refinement, rectangular TU chains,
+    BDOF, chroma) against the CPU chain through the oracle and through the reference's own members, PU by PU."""
+    torch = pytest.importorskip("torch")
+    from vtm_amd.device import Context
+    if use_ref and not ol.have_ref():
+        pytest.skip("oracle/_ref/libvtmref.so not present")
+    W, H = 256, 128
+    dev = torch.device("cuda", 0)
+    pocs0, pocs1, cur = [0], [4], 2
+    cur_np, dpb_np, refs, sr, cur_d, dpb, ch_dev, ch_cpu = make_scene(torch, dev, W, H, pocs0, pocs1, cur, chroma=True)
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    lam, qp = 8.0, 32
+    pocs = (cur, pocs0, pocs1)
+    hp = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, sizes=sizes, pocs=pocs, chroma=ch_dev)
+    hp.run(cur_d.data_ptr(), dpb.data_ptr())
+    torch.cuda.synchronize()
+    stats = {}
+    dirs = check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, ol.ref() if use_ref else None, per_level=12, min_checked=50, pocs=pocs, chroma=ch_cpu, stats=stats)
+    assert 3 in dirs and stats["bio"] >= 3 and stats["chroma_nz"] >= 5, (dirs, stats)
+    ctx.close()
+
+
 def test_ctu_sharding_union_equals_unsharded():
     """north_star: CTU rows of a frame shard across the GPUs.  Two ranks' tables (raster-scan CTU ranges; the boundary row is cut at a CTU) run
     one after the other on this GPU: the union of their per-PU / per-TU results is bit-identical to the unsharded picture."""
@@ -165,7 +193,7 @@ def test_ctu_sharding_union_equals_unsharded():
                 R = full.nref[0] + full.nref[1]
                 for lr in range(R):
                     assert np.array_equal(lv["uni_rows"][lr * lv["npu"]:(lr + 1) * lv["npu"]], w["uni_rows"][lr * w["npu"] + idx]), ("rows", unit, band, lv["size"])
-                q2 = (lv["size"] // lv["ts"]) ** 2
+                q2 = (lv["w"] // lv["tw"]) * (lv["h"] // lv["th"])
                 for ci in range(lv["nc"]):
                     a = lv["tu_res"][ci * lv["ntu"]:(ci + 1) * lv["ntu"]].reshape(lv["npu"], q2, 2)
                     b = w["tu_res"][ci * w["ntu"]:(ci + 1) * w["ntu"]].reshape(w["npu"], q2, 2)[idx]

@@ -348,3 +348,58 @@ def test_lfnst_tu_matches_oracle(ctx):
     got = d_coef.to_host(np.int32)
     assert np.array_equal(got, exp)
     assert not np.array_equal(got, coef)
+
+
+def test_mixed_tu_batch_is_bucketed_by_shape(ctx):
+    """A mixed batch (>= 256 TUs of every shape from 4x4 to 64x64, DCT2 / MTS pairs / transform skip) in ONE call without the uniform promise: the library
+    buckets the table by shape on the device (bucket.hpp), runs the register-blocked kernel per {8..64} x {8..64} class and the generic kernel on the
+    rest, and returns every result at its own index = the oracle chain TU by TU."""
+    import cpu_pis
+    from vtm_amd.lib import TuJob, TuResult
+    from vtm_amd.pipeline import MTS_IDX_TYPES
+    L = ol.oracle()
+    rng = np.random.default_rng(4242)
+    n = 700
+    stride = 72
+    resi = np.zeros((n * 64, stride), np.int16)
+    jobs = (TuJob * n)()
+    exp = []
+    shapes = set()
+    for k in range(n):
+        w, h = int(rng.choice([4, 8, 16, 32, 64])), int(rng.choice([4, 8, 16, 32, 64]))
+        mts = int(rng.integers(0, 6)) if max(w, h) <= 32 else 0
+        shapes.add((w, h, mts == 1))
+        amp = int(rng.choice([8, 60, 400, 1023]))
+        blk = np.ascontiguousarray(rng.integers(-amp, amp + 1, (h, w)).astype(np.int16))
+        resi[k * 64:k * 64 + h, 4:4 + w] = blk
+        qp = int(rng.choice([22, 27, 32, 37])) + 12
+        j = jobs[k]
+        j.resiOff, j.outOff, j.resiStride, j.width, j.height = k * 64 * stride + 4, k * 4096, stride, w, h
+        j.qpPer, j.qpRem, j.bitDepth, j.isIRAP = qp // 6, qp % 6, 10, 0
+        j.typeHor, j.typeVer = (3, 3) if mts == 1 else MTS_IDX_TYPES[mts]
+        if w == h:
+            exp.append(cpu_pis._tu_chain(L, None, blk, w, mts, qp // 6, qp % 6, 10))
+        else:   # the oracle steps for a rectangle
+            coef, qc, dq, asum = np.zeros(w * h, np.int32), np.zeros(w * h, np.int32), np.zeros(w * h, np.int32), C.c_int32()
+            rec = np.zeros((h, w), np.int16)
+            if mts == 1:
+                coef[:] = blk.reshape(-1)
+                L.vo_quant(ol.P(coef), w, h, 10, qp // 6, qp % 6, 0, 1, ol.P(qc), None, C.byref(asum))
+                L.vo_dequant(ol.P(qc), w, h, 10, qp // 6, qp % 6, 1, ol.P(dq))
+                rec[:] = dq.reshape(h, w).astype(np.int16)
+            else:
+                th, tv = MTS_IDX_TYPES[mts]
+                assert L.vo_fwd_2d(ol.P(blk), w, w, h, 10, th, tv, ol.P(coef)) == 0
+                L.vo_quant(ol.P(coef), w, h, 10, qp // 6, qp % 6, 0, 0, ol.P(qc), None, C.byref(asum))
+                L.vo_dequant(ol.P(qc), w, h, 10, qp // 6, qp % 6, 0, ol.P(dq))
+                assert L.vo_inv_2d(ol.P(dq), w, h, 10, th, tv, ol.P(rec), w) == 0
+            exp.append((int(ol.o_dist(2, blk, rec, w, h)), int(np.abs(coef.astype(np.int64)).sum()), asum.value))
+    assert len(shapes) >= 30
+    d_resi = ctx.to_device(resi)
+    d_jobs = ctx.to_device(np.frombuffer(jobs, np.uint8))
+    d_res = ctx.alloc(16 * n)
+    ctx.tu_chain_batch(d_resi.ptr, d_jobs.ptr, n, 64, 64, d_res.ptr, None, None)
+    res = (TuResult * n).from_buffer_copy(d_res.to_host(np.uint8).tobytes())
+    got = [(int(r.sse), int(r.sumAbs), int(r.absSum)) for r in res]
+    bad = [k for k in range(n) if got[k] != exp[k]]
+    assert not bad, [(jobs[k].width, jobs[k].height, jobs[k].typeHor, got[k], exp[k]) for k in bad[:6]]

@@ -11,6 +11,7 @@
 //   frac / [dist]
 //   final     rate re-weighting (:3478-3484) or the AMVR selection loop (:4208-4262), fp64 exactly as the reference
 #include "ctx.hpp"
+#include "bucket.hpp"
 
 namespace
 {
@@ -278,11 +279,57 @@ __global__ __launch_bounds__( 256 ) void mest_final_kernel( vtmhip_me_cfg cfg, c
 
 size_t align_up( size_t v ) { return ( v + 255 ) & ~( size_t ) 255; }
 
+struct MestClassOf
+{
+  __device__ int operator()( const vtmhip_me_job &j ) const { return shape_class( j.width, j.height ); }
+};
+
+int mest_run( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg *cfg, const int16_t *d_orgBase, const int16_t *d_refBase,
+              const int16_t *d_otherPredBase, const vtmhip_me_job *d_jobs, int n, int maxWidth, int maxHeight, vtmhip_me_out *d_results );
+
+// a mixed-shape batch: bucket the jobs by shape on the device and run the uniform chain of every non-empty shape class over its slice
+int mest_bucketed( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg *cfg, const int16_t *d_orgBase, const int16_t *d_refBase,
+                   const int16_t *d_otherPredBase, const vtmhip_me_job *d_jobs, int n, int maxWidth, int maxHeight, vtmhip_me_out *d_results )
+{
+  BucketPlan plan;
+  int st = bucket_begin<vtmhip_me_job, vtmhip_me_out>( ctx, d_jobs, n, MestClassOf(), plan );
+  if( st ) return st;
+  for( int c = 0; c < BUCKET_CLASSES; c++ )
+  {
+    if( !plan.count[c] ) continue;
+    vtmhip_me_cfg sub = *cfg;
+    int w = maxWidth, h = maxHeight;
+    sub.uniformSquare = c < 15;
+    if( sub.uniformSquare ) class_shape( c, w, h );
+    st = mest_run( ctx, pic, &sub, d_orgBase, d_refBase, d_otherPredBase, ( const vtmhip_me_job * ) plan.d_jobs + plan.offset[c], plan.count[c], w, h,
+                   ( vtmhip_me_out * ) plan.d_results + plan.offset[c] );
+    if( st ) return st;
+  }
+  return bucket_finish<vtmhip_me_out>( ctx, plan, n, d_results );
+}
+
 }   // namespace
 
 extern "C" int vtmhip_xMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg *cfg, const int16_t *d_orgBase,
                                                    const int16_t *d_refBase, const int16_t *d_otherPredBase, const vtmhip_me_job *d_jobs, int n,
                                                    int maxWidth, int maxHeight, vtmhip_me_out *d_results )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, pic && cfg && d_orgBase && d_refBase && d_jobs && d_results, "null pointer" );
+  // mixed shapes, enough jobs to fill launches per class: bucket by shape (VTMHIP_MEST_BUCKET=0 keeps the one-wave-per-PU chain for the whole batch)
+  static const bool bucket = !( getenv( "VTMHIP_MEST_BUCKET" ) && atoi( getenv( "VTMHIP_MEST_BUCKET" ) ) == 0 );
+  if( bucket && !cfg->uniformSquare && n >= 64 )
+    return mest_bucketed( ctx, pic, cfg, d_orgBase, d_refBase, d_otherPredBase, d_jobs, n, maxWidth, maxHeight, d_results );
+  return mest_run( ctx, pic, cfg, d_orgBase, d_refBase, d_otherPredBase, d_jobs, n, maxWidth, maxHeight, d_results );
+}
+
+namespace
+{
+
+int mest_run( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg *cfg, const int16_t *d_orgBase, const int16_t *d_refBase,
+              const int16_t *d_otherPredBase, const vtmhip_me_job *d_jobs, int n, int maxWidth, int maxHeight, vtmhip_me_out *d_results )
 {
   VTMHIP_CHECK_CTX( ctx );
   VTMHIP_REQUIRE( ctx, n >= 0, "n" );
@@ -376,3 +423,5 @@ extern "C" int vtmhip_xMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }
+
+}   // namespace

@@ -11,6 +11,7 @@
 // matrix live in LDS; lane l of a wave produces output frequency k = l (matrix columns are contiguous in LDS, the data
 // row is a broadcast), so LDS reads are conflict-free.
 #include "ctx.hpp"
+#include "bucket.hpp"
 #include "tr_tables.hpp"
 
 #include <cmath>
@@ -929,6 +930,35 @@ __global__ __launch_bounds__( 256 ) void tu_ts_kernel( const int16_t *__restrict
 bool pow2( int v ) { return v > 0 && ( v & ( v - 1 ) ) == 0; }
 int  hlog2( int v ) { int r = 0; while( ( 1 << r ) < v ) r++; return r; }
 
+struct TuClassOf   // {8, 16, 32, 64} x {8, 16, 32, 64} with a real transform: class 4 * log2(w / 8) + log2(h / 8); everything else (4-sample sides, transform skip): the last class
+{
+  __device__ int operator()( const vtmhip_tu_job &j ) const
+  {
+    const int w = j.width, h = j.height;
+    if( w < 8 || h < 8 || w > 64 || h > 64 || ( w & ( w - 1 ) ) || ( h & ( h - 1 ) ) || j.typeHor == VTMHIP_TRSKIP ) return BUCKET_OTHER;
+    return 4 * ( __ffs( w ) - 4 ) + ( __ffs( h ) - 4 );
+  }
+};
+
+int tu_chain_generic( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int maxWidth, int maxHeight, int32_t *d_levelsBase,
+                      int16_t *d_recBase, vtmhip_tu_result *d_results )
+{
+  const int    mx    = maxWidth > maxHeight ? maxWidth : maxHeight;
+  const size_t perTu = ( size_t ) maxWidth * maxHeight + ( size_t ) maxWidth * ( maxHeight + 1 ) + ( ( mx * mx + 1 ) >> 1 ) + ( ( maxWidth * maxHeight + 1 ) >> 1 );
+  if( maxWidth * maxHeight <= 256 )
+  {
+    hipLaunchKernelGGL( tu_chain_kernel<64>, dim3( ( n + 3 ) / 4 ), dim3( 256 ), 4 * perTu * sizeof( int ), ctx->stream, d_resiBase, d_jobs, n,
+                        tabs_of( ctx ), d_levelsBase, d_recBase, d_results, maxWidth, maxHeight );
+  }
+  else
+  {
+    hipLaunchKernelGGL( tu_chain_kernel<256>, dim3( n ), dim3( 256 ), perTu * sizeof( int ), ctx->stream, d_resiBase, d_jobs, n,
+                        tabs_of( ctx ), d_levelsBase, d_recBase, d_results, maxWidth, maxHeight );
+  }
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
 }   // namespace
 
 extern "C"
@@ -1054,26 +1084,32 @@ int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const
   VTMHIP_REQUIRE( ctx, maxWidth >= 2 && maxWidth <= TB && maxHeight >= 2 && maxHeight <= TB, "maxWidth / maxHeight: 2..64 (2-D transforms)" );
   int st = ensure_tables( ctx );
   if( st ) return st;
+  // a mixed batch with enough TUs: bucket by shape on the device (bucket.hpp), the register-blocked kernel per {8,16,32,64} x {8,16,32,64} class, the
+  // generic kernel for the rest (4-sample sides, transform skip).  VTMHIP_TU_BUCKET=0 keeps the generic kernel for the whole batch.
+  static const bool bucket = !( getenv( "VTMHIP_TU_BUCKET" ) && atoi( getenv( "VTMHIP_TU_BUCKET" ) ) == 0 );
+  if( bucket && !uniformSize && n >= 256 && maxWidth >= 8 && maxHeight >= 8 )
+  {
+    BucketPlan plan;
+    st = bucket_begin<vtmhip_tu_job, vtmhip_tu_result>( ctx, d_jobs, n, TuClassOf(), plan );
+    if( st ) return st;
+    for( int c = 0; c < BUCKET_CLASSES; c++ )
+    {
+      if( !plan.count[c] ) continue;
+      const vtmhip_tu_job *jobs = ( const vtmhip_tu_job * ) plan.d_jobs + plan.offset[c];
+      vtmhip_tu_result    *res  = ( vtmhip_tu_result * ) plan.d_results + plan.offset[c];
+      if( c < 16 ) st = launch_tu_uni_sized( ctx, d_resiBase, jobs, plan.count[c], 8 << ( c >> 2 ), 8 << ( c & 3 ), d_levelsBase, d_recBase, res, tabs_of( ctx ), nullptr );
+      else         st = tu_chain_generic( ctx, d_resiBase, jobs, plan.count[c], maxWidth, maxHeight, d_levelsBase, d_recBase, res );
+      if( st ) return st;
+    }
+    return bucket_finish<vtmhip_tu_result>( ctx, plan, n, d_results );
+  }
   if( uniformSize && maxWidth >= 8 && maxHeight >= 8 )
   {
     VTMHIP_REQUIRE( ctx, ( maxWidth & ( maxWidth - 1 ) ) == 0 && ( maxHeight & ( maxHeight - 1 ) ) == 0, "uniformSize: width / height must be powers of two (TU sizes are)" );
     // caller's promise: every TU is exactly maxWidth x maxHeight -> register-blocked kernel, LPT lanes per TU
     return launch_tu_uni_sized( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results, tabs_of( ctx ), nullptr );
   }
-  const int    mx    = maxWidth > maxHeight ? maxWidth : maxHeight;
-  const size_t perTu = ( size_t ) maxWidth * maxHeight + ( size_t ) maxWidth * ( maxHeight + 1 ) + ( ( mx * mx + 1 ) >> 1 ) + ( ( maxWidth * maxHeight + 1 ) >> 1 );
-  if( maxWidth * maxHeight <= 256 )
-  {
-    hipLaunchKernelGGL( tu_chain_kernel<64>, dim3( ( n + 3 ) / 4 ), dim3( 256 ), 4 * perTu * sizeof( int ), ctx->stream, d_resiBase, d_jobs, n,
-                        tabs_of( ctx ), d_levelsBase, d_recBase, d_results, maxWidth, maxHeight );
-  }
-  else
-  {
-    hipLaunchKernelGGL( tu_chain_kernel<256>, dim3( n ), dim3( 256 ), perTu * sizeof( int ), ctx->stream, d_resiBase, d_jobs, n,
-                        tabs_of( ctx ), d_levelsBase, d_recBase, d_results, maxWidth, maxHeight );
-  }
-  VTMHIP_LAUNCHED( ctx );
-  return VTMHIP_OK;
+  return tu_chain_generic( ctx, d_resiBase, d_jobs, n, maxWidth, maxHeight, d_levelsBase, d_recBase, d_results );
 }
 
 int vtmhip_tu_ts_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int width, int height,

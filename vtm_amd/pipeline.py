@@ -54,13 +54,15 @@ def band_filter(pic_w, band, ctu=128):
 
 
 def quadtree_levels(pic_w, pic_h, sizes=(128, 64, 32, 16, 8), row_filter=None, ctu_filter=None):
-    """Square PUs of every quadtree level that lie fully inside the picture.  row_filter(ctu_row_array) -> bool array selects the
+    """PUs of every partition level that lie fully inside the picture.  sizes: one entry per level, coarse to fine, an int (square PUs: the quadtree)
+    or (w, h) (the binary / ternary split shapes; a level's blocks nest inside the previous level's).  row_filter(ctu_row_array) -> bool array selects the
     CTU rows (128 luma rows each) this rank owns; ctu_filter(ctu_row_array, ctu_col_array) -> bool array selects single CTUs.
-    Returns [(size, xs, ys, parent_index_or_None)], coarse to fine."""
+    Returns [(size as given, xs, ys, parent_index_or_None)], coarse to fine."""
     levels = []
     prev = None
     for s in sizes:
-        ys, xs = np.mgrid[0:pic_h - s + 1:s, 0:pic_w - s + 1:s]
+        bw, bh = (s, s) if np.isscalar(s) else s
+        ys, xs = np.mgrid[0:pic_h - bh + 1:bh, 0:pic_w - bw + 1:bw]
         xs, ys = xs.ravel().astype(np.int64), ys.ravel().astype(np.int64)
         if row_filter is not None:
             keep = np.asarray(row_filter(ys // 128), dtype=bool)
@@ -70,11 +72,11 @@ def quadtree_levels(pic_w, pic_h, sizes=(128, 64, 32, 16, 8), row_filter=None, c
             xs, ys = xs[keep], ys[keep]
         parent = None
         if prev is not None:
-            ps, pxs, pys = prev
+            (pw, ph), pxs, pys = prev
             lut = {(int(x), int(y)): i for i, (x, y) in enumerate(zip(pxs, pys))}
-            parent = np.array([lut.get((int(x) // ps * ps, int(y) // ps * ps), -1) for x, y in zip(xs, ys)], dtype=np.int64)
+            parent = np.array([lut.get((int(x) // pw * pw, int(y) // ph * ph), -1) for x, y in zip(xs, ys)], dtype=np.int64)
         levels.append((s, xs, ys, parent))
-        prev = (s, xs, ys)
+        prev = ((bw, bh), xs, ys)
     return levels
 
 
@@ -629,9 +631,10 @@ class FrameHotPath:
             if n == 0:
                 prev = None
                 continue
-            lvl = dict(size=s, npu=n, xs=xs, ys=ys, sb=sb)
-            blk = sb + np.arange(n, dtype=np.int64) * s * s          # compact per-PU slots of the level-wide sample buffers
-            sb += n * s * s
+            w, h = (s, s) if np.isscalar(s) else s                   # a level of the quadtree, or of a binary / ternary split shape
+            lvl = dict(size=s, w=w, h=h, npu=n, xs=xs, ys=ys, sb=sb)
+            blk = sb + np.arange(n, dtype=np.int64) * w * h          # compact per-PU slots of the level-wide sample buffers
+            sb += n * w * h
             uj = np.zeros(R * n, ME_DT)
             for l in (0, 1):
                 for r in range(nref[l]):
@@ -639,7 +642,7 @@ class FrameHotPath:
                     uj["refOff"][sl] = refs[l][r][0] + ys * rs + xs
                     uj["searchRange"][sl] = search_ranges[l][r]
             uj["orgOff"], uj["orgStride"], uj["refStride"] = np.tile(ys * org_stride + xs, R), org_stride, rs
-            uj["puX"], uj["puY"], uj["width"], uj["height"] = np.tile(xs, R), np.tile(ys, R), s, s
+            uj["puX"], uj["puY"], uj["width"], uj["height"] = np.tile(xs, R), np.tile(ys, R), w, h
             uj["motionLambda"], uj["numAmvpCand"] = motion_lambda, 2
             lvl["uni_jobs"] = _Tab(T, dev, uj)
             lvl["uni_out"] = T.zeros((R * n, MEOUT_DT.itemsize), dtype=T.uint8, device=dev)
@@ -647,8 +650,8 @@ class FrameHotPath:
             lvl["pus"] = T.zeros((n, PU_DT.itemsize), dtype=T.uint8, device=dev)
             pj = np.zeros(n, PRED_DT)
             pj["orgOff"], pj["orgStride"], pj["refStride"] = ys * org_stride + xs, org_stride, rs
-            pj["predOff"], pj["outOff"], pj["predStride"], pj["outStride"] = blk, blk, s, s
-            pj["width"], pj["height"], pj["bitDepth"] = s, s, bit_depth
+            pj["predOff"], pj["outOff"], pj["predStride"], pj["outStride"] = blk, blk, w, w
+            pj["width"], pj["height"], pj["bitDepth"] = w, h, bit_depth
             pf = pj.copy()
             pf["epilogue"] = 1                                         # residual = org - pred
             lvl["pred_final"] = _Tab(T, dev, pf)
@@ -660,8 +663,8 @@ class FrameHotPath:
                 nb = nref[0]
                 bj = np.zeros(nb * n, ME_DT)
                 bj["orgOff"], bj["orgStride"] = np.tile(ys * org_stride + xs, nb), org_stride
-                bj["otherPredOff"], bj["otherPredStride"] = np.tile(blk, nb), s
-                bj["puX"], bj["puY"], bj["width"], bj["height"] = np.tile(xs, nb), np.tile(ys, nb), s, s
+                bj["otherPredOff"], bj["otherPredStride"] = np.tile(blk, nb), w
+                bj["puX"], bj["puY"], bj["width"], bj["height"] = np.tile(xs, nb), np.tile(ys, nb), w, h
                 lvl["bi_jobs"] = _Tab(T, dev, bj)
                 lvl["bi_out"] = T.zeros((nb * n, MEOUT_DT.itemsize), dtype=T.uint8, device=dev)
             par32 = None
@@ -688,15 +691,15 @@ class FrameHotPath:
                         L.refPoc[l][r] = int(pocs[1 + l][r])
             if chroma is not None:
                 # ---- the two 4:2:0 chroma planes of every PU: prediction + residual jobs (Cb jobs, then Cr jobs), compact slots in level-wide chroma buffers ----
-                sc, rsc, osc = s // 2, chroma["ref_stride"], chroma["org_stride"]
-                blk_c = (sb - n * s * s) // 4 + np.arange(n, dtype=np.int64) * sc * sc
+                wc, hc, rsc, osc = w // 2, h // 2, chroma["ref_stride"], chroma["org_stride"]
+                blk_c = (sb - n * w * h) // 4 + np.arange(n, dtype=np.int64) * wc * hc
                 cj = np.zeros(2 * n, PRED_DT)
                 for c in (0, 1):
                     sl = slice(c * n, (c + 1) * n)
                     cj["orgOff"][sl] = chroma["org_off"][c] + (ys // 2) * osc + xs // 2
                     cj["predOff"][sl] = cj["outOff"][sl] = blk_c      # + c * NSC (the Cr half of the chroma buffers), added below once NSC is known
-                cj["orgStride"], cj["refStride"], cj["predStride"], cj["outStride"] = osc, rsc, sc, sc
-                cj["width"], cj["height"], cj["bitDepth"], cj["chroma"], cj["epilogue"] = sc, sc, bit_depth, 1, 1
+                cj["orgStride"], cj["refStride"], cj["predStride"], cj["outStride"] = osc, rsc, wc, wc
+                cj["width"], cj["height"], cj["bitDepth"], cj["chroma"], cj["epilogue"] = wc, hc, bit_depth, 1, 1
                 lvl["blk_c"] = blk_c
                 lvl["pred_final_c"] = _Tab(T, dev, cj)
                 lvl["pos_c"] = T.from_numpy((ys // 2) * rsc + xs // 2).to(dev)
@@ -705,36 +708,34 @@ class FrameHotPath:
                     for l in (0, 1):
                         for r in range(nref[l]):
                             L.refPlaneOffC[c][l][r] = int(chroma["refs"][l][r][c])
-                tsc = min(sc, 32)
-                qc = sc // tsc
-                tu_src_c = np.stack([blk_c + qy * tsc * sc + qx * tsc for qy in range(qc) for qx in range(qc)], 1).reshape(-1)
+                twc, thc = min(wc, 32), min(hc, 32)
+                tu_src_c = np.stack([blk_c + qy * thc * wc + qx * twc for qy in range(hc // thc) for qx in range(wc // twc)], 1).reshape(-1)
                 ntc = tu_src_c.size
                 tc = np.zeros(2 * ntc, TU_DT)       # Cb TUs, then Cr TUs (the Cr plane's buffers start NSC samples further: added in _finish_chroma)
-                tc["resiOff"], tc["resiStride"], tc["width"], tc["height"] = np.tile(tu_src_c, 2), sc, tsc, tsc
-                tc["outOff"] = np.arange(2 * ntc, dtype=np.int64) * tsc * tsc
+                tc["resiOff"], tc["resiStride"], tc["width"], tc["height"] = np.tile(tu_src_c, 2), wc, twc, thc
+                tc["outOff"] = np.arange(2 * ntc, dtype=np.int64) * twc * thc
                 tc["qpPer"], tc["qpRem"], tc["bitDepth"] = self.cqp_per, self.cqp_rem, bit_depth
-                lvl.update(ntu_c=ntc, ts_c=tsc, tu_c_np=tc, tu_res_c=T.zeros((2 * ntc, 2), dtype=T.int64, device=dev),
-                           qcoef_c=T.zeros(2 * ntc * tsc * tsc, dtype=T.int32, device=dev))
+                lvl.update(ntu_c=ntc, ts_c=twc, tw_c=twc, th_c=thc, tu_c_np=tc, tu_res_c=T.zeros((2 * ntc, 2), dtype=T.int64, device=dev),
+                           qcoef_c=T.zeros(2 * ntc * twc * thc, dtype=T.int32, device=dev))
             lvl["pis"] = L
-            lvl["pic"] = PicParams(pic_w, pic_h, 128, bit_depth, wpj.get(s, 1))
-            lvl["pic_bi"] = PicParams(pic_w, pic_h, 128, bit_depth, FULL_WAVES_PER_JOB.get(s, 1))
+            lvl["pic"] = PicParams(pic_w, pic_h, 128, bit_depth, wpj.get(max(w, h), 1))
+            lvl["pic_bi"] = PicParams(pic_w, pic_h, 128, bit_depth, FULL_WAVES_PER_JOB.get(max(w, h), 1))
             lvl["cfg_uni"] = MeCfg(4, 1, 1, 0, 1, 0, 1, 1, 1, 0)           # BipredSearchRange 4, HadamardME, FEN, uniform: imv 0, square, all uni, no m_uniMvList
             lvl["cfg_bi"] = MeCfg(4, 1, 1, 0, 1, 0, 1, 2, 1, 1)            # all bi, the pattern 2*org - pred comes from the fused MC epilogue
             # ---- transform units: the PU itself up to 64x64, four 64x64 quadrants of a 128x128 PU (MaxTbSize 64) -------------------------
-            ts = min(s, 64)
-            q = s // ts
-            tu_src = np.stack([blk + qy * ts * s + qx * ts for qy in range(q) for qx in range(q)], 1).reshape(-1)
+            tw, th = min(w, 64), min(h, 64)
+            tu_src = np.stack([blk + qy * th * w + qx * tw for qy in range(h // th) for qx in range(w // tw)], 1).reshape(-1)
             ntu = tu_src.size
-            cl = [c for c in cands if c == 0 or (ts <= 32)]
+            cl = [c for c in cands if c == 0 or (max(tw, th) <= 32)]
             nc = len(cl)
             tj = np.zeros(ntu * nc, TU_DT)
-            tj["resiOff"], tj["resiStride"], tj["width"], tj["height"] = np.tile(tu_src, nc), s, ts, ts
-            tj["outOff"] = np.arange(ntu * nc, dtype=np.int64) * ts * ts
+            tj["resiOff"], tj["resiStride"], tj["width"], tj["height"] = np.tile(tu_src, nc), w, tw, th
+            tj["outOff"] = np.arange(ntu * nc, dtype=np.int64) * tw * th
             tj["qpPer"], tj["qpRem"], tj["bitDepth"] = self.qp_per, self.qp_rem, bit_depth
             tj["typeHor"] = np.repeat([MTS_IDX_TYPES[c][0] for c in cl], ntu)
             tj["typeVer"] = np.repeat([MTS_IDX_TYPES[c][1] for c in cl], ntu)
-            lvl.update(ntu=ntu, nc=nc, ts=ts, cands=cl, tu=_Tab(T, dev, tj), tu_res=T.zeros((ntu * nc, 2), dtype=T.int64, device=dev),
-                       qcoef=T.zeros(ntu * nc * ts * ts, dtype=T.int32, device=dev))
+            lvl.update(ntu=ntu, nc=nc, ts=tw, tw=tw, th=th, cands=cl, tu=_Tab(T, dev, tj), tu_res=T.zeros((ntu * nc, 2), dtype=T.int64, device=dev),
+                       qcoef=T.zeros(ntu * nc * tw * th, dtype=T.int32, device=dev))
             self.levels.append(lvl)
             prev = lvl
         self.NS = sb
@@ -776,43 +777,44 @@ class FrameHotPath:
 
     # ---- the steps of one level ---------------------------------------------------------------------------------------------
     def _uni(self, lvl, org_ptr, dpb_ptr):
-        ctx, n, s = self.ctx, lvl["npu"], lvl["size"]
+        ctx, n, w, h = self.ctx, lvl["npu"], lvl["w"], lvl["h"]
         rows = (self.nref[0] + self.nref[1]) * n
         ctx.pis_stage(lvl["pis"], 0)
         self._mark("glue")
-        ctx.estimate_mvp_amvp_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["uni_jobs"].ptr, rows, s, s, uniform=True)
+        ctx.estimate_mvp_amvp_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["uni_jobs"].ptr, rows, w, h, uniform=True)
         self._mark("amvp")
-        ctx.motion_estimation_batch(lvl["pic"], lvl["cfg_uni"], org_ptr, dpb_ptr, None, lvl["uni_jobs"].ptr, rows, s, s, lvl["uni_out"].data_ptr())
+        ctx.motion_estimation_batch(lvl["pic"], lvl["cfg_uni"], org_ptr, dpb_ptr, None, lvl["uni_jobs"].ptr, rows, w, h, lvl["uni_out"].data_ptr())
         self._mark("uni_me")
         ctx.pis_stage(lvl["pis"], 1)
         self._mark("glue")
 
     def _rest(self, lvl, org_ptr, dpb_ptr):
-        ctx, n, s, buf = self.ctx, lvl["npu"], lvl["size"], self.buf
+        ctx, n, w, h, buf = self.ctx, lvl["npu"], lvl["w"], lvl["h"], self.buf
         if self.is_b:
             ctx.pis_stage(lvl["pis"], 2)
             self._mark("glue")
-            ctx.motion_compensation_batch(org_ptr, dpb_ptr, None, buf["org_bi"].data_ptr(), lvl["pred_other"].ptr, n, s, s)
+            ctx.motion_compensation_batch(org_ptr, dpb_ptr, None, buf["org_bi"].data_ptr(), lvl["pred_other"].ptr, n, w, h)
             self._mark("mc")
-            ctx.motion_estimation_batch(lvl["pic_bi"], lvl["cfg_bi"], org_ptr, dpb_ptr, buf["org_bi"].data_ptr(), lvl["bi_jobs"].ptr, self.nref[0] * n, s, s,
+            ctx.motion_estimation_batch(lvl["pic_bi"], lvl["cfg_bi"], org_ptr, dpb_ptr, buf["org_bi"].data_ptr(), lvl["bi_jobs"].ptr, self.nref[0] * n, w, h,
                                         lvl["bi_out"].data_ptr())
             self._mark("bi_me")
             ctx.pis_stage(lvl["pis"], 3)
             self._mark("glue")
-        ctx.motion_compensation_batch(org_ptr, dpb_ptr, buf["pred"].data_ptr(), buf["resi"].data_ptr(), lvl["pred_final"].ptr, n, s, s)
-        if self.bdof and s >= 16:      # the PUs the final stage routed to BDOF (bi-prediction from opposite directions at equal POC distance; 8x8 never qualifies)
-            ctx.bdof_batch(org_ptr, dpb_ptr, buf["pred"].data_ptr(), buf["resi"].data_ptr(), lvl["pred_final"].ptr, n, s, s)
+        ctx.motion_compensation_batch(org_ptr, dpb_ptr, buf["pred"].data_ptr(), buf["resi"].data_ptr(), lvl["pred_final"].ptr, n, w, h)
+        if self.bdof and w * h >= 128:      # the PUs the final stage routed to BDOF (bi-prediction from opposite directions at equal POC distance; 8x8 never qualifies)
+            ctx.bdof_batch(org_ptr, dpb_ptr, buf["pred"].data_ptr(), buf["resi"].data_ptr(), lvl["pred_final"].ptr, n, w, h)
         if self.chroma is not None:
-            ctx.motion_compensation_batch(org_ptr, dpb_ptr, buf["pred_c"].data_ptr(), buf["resi_c"].data_ptr(), lvl["pred_final_c"].ptr, 2 * n, s // 2, s // 2)
+            ctx.motion_compensation_batch(org_ptr, dpb_ptr, buf["pred_c"].data_ptr(), buf["resi_c"].data_ptr(), lvl["pred_final_c"].ptr, 2 * n, w // 2, h // 2)
         self._mark("mc")
         self._tu(lvl)
         if self.chroma is not None:
-            tsc = lvl["ts_c"]
-            ctx.tu_chain_batch(buf["resi_c"].data_ptr(), lvl["tu_c"].ptr, 2 * lvl["ntu_c"], tsc, tsc, lvl["tu_res_c"].data_ptr(), lvl["qcoef_c"].data_ptr(), None, uniform=tsc >= 8)
+            twc, thc = lvl["tw_c"], lvl["th_c"]
+            ctx.tu_chain_batch(buf["resi_c"].data_ptr(), lvl["tu_c"].ptr, 2 * lvl["ntu_c"], twc, thc, lvl["tu_res_c"].data_ptr(), lvl["qcoef_c"].data_ptr(), None,
+                               uniform=min(twc, thc) >= 8)
         self._mark("tu")
 
     def _tu(self, lvl):
-        ctx, ts, ntu = self.ctx, lvl["ts"], lvl["ntu"]
+        ctx, tw, th, ntu = self.ctx, lvl["tw"], lvl["th"], lvl["ntu"]
         tu_p, res_p, q_p = lvl["tu"].ptr, lvl["tu_res"].data_ptr(), lvl["qcoef"].data_ptr()
         cands, k = lvl["cands"], 0
         while k < len(cands):            # candidates are stored one after the other; transform skip goes to its own (elementwise) kernel
@@ -822,9 +824,9 @@ class FrameHotPath:
                     run += 1
             a, m = k * ntu, run * ntu
             if cands[k] == 1:
-                ctx.tu_ts_chain_batch(self.buf["resi"].data_ptr(), tu_p + a * TU_DT.itemsize, m, ts, ts, res_p + a * 16, q_p)
+                ctx.tu_ts_chain_batch(self.buf["resi"].data_ptr(), tu_p + a * TU_DT.itemsize, m, tw, th, res_p + a * 16, q_p)
             else:
-                ctx.tu_chain_batch(self.buf["resi"].data_ptr(), tu_p + a * TU_DT.itemsize, m, ts, ts, res_p + a * 16, q_p, None, uniform=True)
+                ctx.tu_chain_batch(self.buf["resi"].data_ptr(), tu_p + a * TU_DT.itemsize, m, tw, th, res_p + a * 16, q_p, None, uniform=True)
             k += run
 
     def run(self, org_ptr, dpb_ptr, timing=False):
@@ -859,7 +861,7 @@ class FrameHotPath:
         """numpy copies of every decision, per level (tests/cpu_chain.py, a host encoder, the multi-GPU gather read these)"""
         out = []
         for lvl in self.levels:
-            d = dict(size=lvl["size"], npu=lvl["npu"], ntu=lvl["ntu"], nc=lvl["nc"], ts=lvl["ts"], cands=lvl["cands"], xs=lvl["xs"], ys=lvl["ys"],
+            d = dict(size=lvl["size"], w=lvl["w"], h=lvl["h"], tw=lvl["tw"], th=lvl["th"], npu=lvl["npu"], ntu=lvl["ntu"], nc=lvl["nc"], ts=lvl["ts"], cands=lvl["cands"], xs=lvl["xs"], ys=lvl["ys"],
                      uni_jobs=lvl["uni_jobs"].t.cpu().numpy().view(ME_DT).reshape(-1), uni_out=lvl["uni_out"].cpu().numpy().view(MEOUT_DT).reshape(-1),
                      uni_rows=lvl["uni_rows"].cpu().numpy().view(ROW_DT).reshape(-1), pus=lvl["pus"].cpu().numpy().view(PU_DT).reshape(-1),
                      tu_res=lvl["tu_res"].cpu().numpy())
@@ -868,7 +870,7 @@ class FrameHotPath:
                 d["bi_out"] = lvl["bi_out"].cpu().numpy().view(MEOUT_DT).reshape(-1)
             d["route"] = lvl["pred_final"].col("route").cpu().numpy()
             if self.chroma is not None:
-                d.update(ntu_c=lvl["ntu_c"], ts_c=lvl["ts_c"], tu_res_c=lvl["tu_res_c"].cpu().numpy())
+                d.update(ntu_c=lvl["ntu_c"], ts_c=lvl["ts_c"], tw_c=lvl["tw_c"], th_c=lvl["th_c"], tu_res_c=lvl["tu_res_c"].cpu().numpy())
             out.append(d)
         return out
 
