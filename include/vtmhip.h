@@ -586,7 +586,8 @@ typedef struct
 } vtmhip_tu_result;
 
 /* d_levelsBase (quantised levels for the host's CABAC estimate) and d_recBase (reconstructed residual) may be NULL.
- * uniformSize != 0: the caller guarantees every TU is exactly maxWidth x maxHeight (both >= 8) -> register-blocked kernel. */
+ * uniformSize != 0: the caller guarantees every TU is exactly maxWidth x maxHeight with a real transform (no VTMHIP_TRSKIP) -> register-blocked kernel
+ * (both sides >= 8) or one lane per TU (4x4, 8x4, 4x8); other uniform shapes (16x4 ...) take the generic kernel. */
 int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int maxWidth, int maxHeight,
                                int uniformSize, int32_t *d_levelsBase, int16_t *d_recBase, vtmhip_tu_result *d_results );
 

@@ -47,10 +47,11 @@ def main():
         for r in csv.DictReader(open(tr)):
             k = (short(r["Kernel_Name"]), r["Grid_Size_X"], r["Workgroup_Size_X"], r["LDS_Block_Size"], r["VGPR_Count"])
             agg.setdefault(k, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-        with open(os.path.join(pr, f"{tag}_kernel_trace_per_launch_shape.csv"), "w") as f:
-            f.write("kernel,grid_x,workgroup_x,lds_bytes,vgpr,calls,avg_ns,min_ns,max_ns\n")
+        with open(os.path.join(pr, f"{tag}_kernel_trace_per_launch_shape.csv"), "w", newline="") as f:
+            wr = csv.writer(f)
+            wr.writerow(["kernel", "grid_x", "workgroup_x", "lds_bytes", "vgpr", "calls", "avg_ns", "min_ns", "max_ns"])
             for k, v in agg.items():
-                f.write(",".join(k) + f",{len(v)},{sum(v) // len(v)},{min(v)},{max(v)}\n")
+                wr.writerow(list(k) + [len(v), sum(v) // len(v), min(v), max(v)])
     pmc = collections.OrderedDict()
     for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
         p = os.path.join(go, f"pmc_{tag}_{cnt}", "bench_counter_collection.csv")

@@ -111,3 +111,12 @@ __device__ __forceinline__ unsigned long long wave_reduce_add_u64( unsigned long
   for( int o = 32; o > 0; o >>= 1 ) v += __shfl_xor( v, o, 64 );
   return v;
 }
+
+// XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2), so block b takes
+// the work item at position (b % 8) * (n / 8) + b / 8 (bijective for any n): the workgroups running on one XCD at any moment
+// then hold NEIGHBOURING jobs of the table (PUs in raster order), whose search windows overlap and stay in that XCD's 4 MiB L2.
+__device__ __forceinline__ int xcd_order( int b, int n )
+{
+  const int q = n >> 3, r = n & 7, xcd = b & 7;
+  return ( xcd < r ? xcd * ( q + 1 ) : r * ( q + 1 ) + ( xcd - r ) * q ) + ( b >> 3 );
+}

@@ -225,7 +225,7 @@ __global__ __launch_bounds__( 256 ) void dist_uniform_kernel( const int16_t *__r
                                                              unsigned long long *__restrict__ out )
 {
   const int lpj = 1 << lpjShift, g = 64 >> lpjShift;
-  const int lane = threadIdx.x & 63, wave = blockIdx.x * ( blockDim.x >> 6 ) + ( threadIdx.x >> 6 );
+  const int lane = threadIdx.x & 63, wave = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x ) * ( blockDim.x >> 6 ) + ( threadIdx.x >> 6 );
   const int job = wave * g + ( lane >> lpjShift ), sub = lane & ( lpj - 1 );
   const bool live = job < n;
   const vtmhip_dist_job j = jobs[live ? job : 0];

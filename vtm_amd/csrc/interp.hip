@@ -384,7 +384,7 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
   __shared__ int sCentre[C::JPW][2];                                            // half-sample winner per PU (round 2 centre)
   __shared__ unsigned sKeep[C::JPW];                                            // its distortion = candidate 0 of round 2 (same samples)
   const int tid = threadIdx.x;
-  const int job0 = blockIdx.x * C::JPW;
+  const int job0 = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x ) * C::JPW;   // neighbouring PUs share most of their windows: keep them on one XCD's L2
   const int nj = min( C::JPW, numJobs - job0 );
 
   // ---- windows: rows -4 .. H+3, columns -4 .. W+3 around the integer vector; 8 samples (16 bytes) per thread and step ----------------------

@@ -369,15 +369,20 @@ struct AvgThen
   }
 };
 
-template<int THREADS>
-__global__ __launch_bounds__( THREADS ) void motion_comp_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase, int16_t *__restrict__ predBase,
-                                                           int16_t *__restrict__ outBase, const vtmhip_pred_job *__restrict__ jobs, int maxW, int maxH )
+// THREADS = 256: one block per workgroup (four waves share it); THREADS = 64: one block per WAVE, WPB waves (= blocks) per workgroup.  WPB = 4 was
+// measured SLOWER than one-wave workgroups on the 8x8 level (motion compensation of a picture 1.15 -> 1.69 ms): the launcher uses WPB = 1.
+template<int THREADS, int WPB>
+__global__ __launch_bounds__( THREADS * WPB ) void motion_comp_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase, int16_t *__restrict__ predBase,
+                                                                 int16_t *__restrict__ outBase, const vtmhip_pred_job *__restrict__ jobs, int n, int maxW, int maxH )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];
-  int16_t              *tmp = lds;                             // [(h+7)][w] H-pass intermediates
-  int16_t              *p0  = lds + maxW * ( maxH + 7 );       // [h][w] list-0 prediction of a bi-predicted block (14-bit)
-  const vtmhip_pred_job j    = jobs[blockIdx.x];
-  const int             lane = threadIdx.x;
+  const int             wave = WPB > 1 ? ( int ) ( threadIdx.x >> 6 ) : 0;
+  int16_t              *tmp = lds + wave * ( maxW * ( maxH + 7 ) + maxW * maxH );   // [(h+7)][w] H-pass intermediates
+  int16_t              *p0  = tmp + maxW * ( maxH + 7 );                             // [h][w] list-0 prediction of a bi-predicted block (14-bit)
+  const int             jobIdx = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x ) * WPB + wave;   // neighbouring PUs (overlapping reference windows) on one XCD's L2
+  if( jobIdx >= n ) return;
+  const vtmhip_pred_job j    = jobs[jobIdx];
+  const int             lane = WPB > 1 ? ( int ) ( threadIdx.x & 63 ) : ( int ) threadIdx.x;
   if( j.route == 1 ) return;   // routed to vtmhip_bdof_batch_dev (a table both calls are launched over)
   Epilogue ep;
   ep.org = orgBase ? orgBase + j.orgOff : nullptr; ep.orgStride = j.orgStride;
@@ -948,11 +953,11 @@ int vtmhip_motion_compensation_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgB
   if( maxWidth * maxHeight > 256 )
   {
     if( lds > 64 * 1024 )
-      VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( motion_comp_kernel<256> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
-    hipLaunchKernelGGL( motion_comp_kernel<256>, dim3( n ), dim3( 256 ), lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, maxWidth, maxHeight );
+      VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( motion_comp_kernel<256, 1> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
+    hipLaunchKernelGGL( ( motion_comp_kernel<256, 1> ), dim3( n ), dim3( 256 ), lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth, maxHeight );
   }
   else
-    hipLaunchKernelGGL( motion_comp_kernel<64>, dim3( n ), dim3( 64 ), lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, maxWidth, maxHeight );
+    hipLaunchKernelGGL( ( motion_comp_kernel<64, 1> ), dim3( n ), dim3( 64 ), lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth, maxHeight );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

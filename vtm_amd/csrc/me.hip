@@ -97,6 +97,7 @@ struct __attribute__( ( packed, aligned( 2 ) ) ) Pel4 { unsigned v[2]; };
 __device__ __forceinline__ unsigned sad2( unsigned a, unsigned b, unsigned acc ) { return __builtin_amdgcn_sad_u16( a, b, acc ); }
 
 // partial SAD of candidate (cx, cy) over the items sub, sub + lpc, ... (RdCost.cpp:493-528 arithmetic)
+template<int WPJ>
 __device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy, int sub )
 {
   const int16_t *c0 = j.ref + ( long ) cy * j.refStride + cx;
@@ -118,7 +119,7 @@ __device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy,
     }
     return s;
   }
-  if( j.seg == 8 && j.orgLds )
+  if( WPJ >= 2 && j.seg == 8 && j.orgLds )   // (single-wave kernels never stage the block: keep this path out of their register budget)
   {
     // items are 16-byte aligned in the LDS copy (w is a multiple of 8): one ds_read_b128 per item instead of a second vector-memory load
     if( j.lpc == 64 && j.sprShift >= 0 && j.sprShift <= 6 )
@@ -129,7 +130,23 @@ __device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy,
       const int16_t *pr = c0 + ( long ) ( sub >> j.sprShift ) * cs + ( ( sub & ( j.segsPerRow - 1 ) ) << 3 );
       const int16_t *po = j.orgLds + ( sub << 3 );
       const long     dr = cs * rowsPerStep;
-      for( int it = sub; it < j.items; it += 64 )
+      int            it = sub;
+      // four steps per trip: the four reference loads of a lane are in flight together (a wave walks ONE candidate here, so without this every
+      // step pays a full vector-memory latency: 100+ cycles per vector instruction on the 128x128 level)
+      for( ; it + 192 < j.items; it += 256 )
+      {
+        const Pel8  b0 = *reinterpret_cast<const Pel8 *>( pr ), b1 = *reinterpret_cast<const Pel8 *>( pr + dr );
+        const Pel8  b2 = *reinterpret_cast<const Pel8 *>( pr + 2 * dr ), b3 = *reinterpret_cast<const Pel8 *>( pr + 3 * dr );
+        const uint4 a0 = *reinterpret_cast<const uint4 *>( po ), a1 = *reinterpret_cast<const uint4 *>( po + 512 );
+        const uint4 a2 = *reinterpret_cast<const uint4 *>( po + 1024 ), a3 = *reinterpret_cast<const uint4 *>( po + 1536 );
+        s = sad2( a0.x, b0.v[0] ^ j.bias, s ); s = sad2( a0.y, b0.v[1] ^ j.bias, s ); s = sad2( a0.z, b0.v[2] ^ j.bias, s ); s = sad2( a0.w, b0.v[3] ^ j.bias, s );
+        s = sad2( a1.x, b1.v[0] ^ j.bias, s ); s = sad2( a1.y, b1.v[1] ^ j.bias, s ); s = sad2( a1.z, b1.v[2] ^ j.bias, s ); s = sad2( a1.w, b1.v[3] ^ j.bias, s );
+        s = sad2( a2.x, b2.v[0] ^ j.bias, s ); s = sad2( a2.y, b2.v[1] ^ j.bias, s ); s = sad2( a2.z, b2.v[2] ^ j.bias, s ); s = sad2( a2.w, b2.v[3] ^ j.bias, s );
+        s = sad2( a3.x, b3.v[0] ^ j.bias, s ); s = sad2( a3.y, b3.v[1] ^ j.bias, s ); s = sad2( a3.z, b3.v[2] ^ j.bias, s ); s = sad2( a3.w, b3.v[3] ^ j.bias, s );
+        pr += 4 * dr;
+        po += 2048;
+      }
+      for( ; it < j.items; it += 64 )
       {
         const uint4 a = *reinterpret_cast<const uint4 *>( po );
         const Pel8  b = *reinterpret_cast<const Pel8 *>( pr );
@@ -174,15 +191,6 @@ __device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy,
   return s;
 }
 
-// XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2), so block b takes
-// the work item at position (b % 8) * (n / 8) + b / 8 (bijective for any n): the workgroups running on one XCD at any moment
-// then hold NEIGHBOURING jobs of the table (PUs in raster order), whose search windows overlap and stay in that XCD's 4 MiB L2.
-__device__ __forceinline__ int xcd_order( int b, int n )
-{
-  const int q = n >> 3, r = n & 7, xcd = b & 7;
-  return ( xcd < r ? xcd * ( q + 1 ) : r * ( q + 1 ) + ( xcd - r ) * q ) + ( b >> 3 );
-}
-
 // Multi-wave jobs (large blocks): the original block -- read again for EVERY candidate -- is staged once in LDS, item-major
 // (item it = 8 samples at sLds[it * 8]), already XORed with the sign bias; candidates then fetch only the reference through the vector
 // memory path and the original through the LDS port.  Blocks that do not fit (or 4-sample segments) keep the global path.
@@ -190,7 +198,7 @@ template<int WPJ, int CAP>
 __device__ __forceinline__ void stage_org( MeJob &j, int16_t *sLds, int tid )
 {
   j.orgLds = nullptr;
-  if( WPJ < 4 || j.seg != 8 || j.items * 8 > CAP ) return;
+  if( WPJ < 2 || j.seg != 8 || j.items * 8 > CAP ) return;
   const long os = ( long ) j.orgStride << j.ss;
   for( int it = tid; it < j.items; it += 64 * WPJ )
   {
@@ -245,7 +253,8 @@ __device__ __forceinline__ void wave_argmin( unsigned long long &cost, unsigned 
   }
 }
 
-constexpr int ORG_LDS_CAP = 128 * 128;   // samples of the LDS copy of the original block (multi-wave kernels)
+constexpr int ORG_LDS_CAP  = 128 * 128;   // samples of the LDS copy of the original block (kernels with 4+ waves per job)
+constexpr int ORG_LDS_CAP2 = 64 * 64;     // two waves per job (blocks up to 64x64)
 
 struct TzState
 {
@@ -310,7 +319,7 @@ __device__ __forceinline__ void eval_candidates( const MeJob &j, const int4 *pts
         x = p.x;
         y = p.y;
       }
-      s = sad_partial( j, x, y, sub );
+      s = sad_partial<WPJ>( j, x, y, sub );
     }
     s = group_sum( s, lpc );   // every lane of the group ends with the total
     if( k < total )
@@ -745,7 +754,7 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel(
   __shared__ int4               sPts[JOBS_PER_BLOCK][16];   // 15 m_uniMvList candidates / 16 diamond points at most
   __shared__ unsigned long long sRedCost[WPJ];
   __shared__ unsigned           sRedIdx[WPJ];
-  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sOrgLds[WPJ >= 4 ? ORG_LDS_CAP : 8];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sOrgLds[WPJ >= 4 ? ORG_LDS_CAP : WPJ == 2 ? ORG_LDS_CAP2 : 8];
   const int lane = threadIdx.x & 63, wv = uni( ( int ) ( threadIdx.x >> 6 ) );
   const int blk    = mode == 2 ? ( int ) blockIdx.x : xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x );
   int       jobIdx = WPJ == 1 ? blk * 4 + wv : blk;
@@ -810,7 +819,7 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel(
     }
     j.resOff = ( int ) ( r * ( ( long ) j.refStride << j.ss ) + x );
   }
-  stage_org<WPJ, ORG_LDS_CAP>( j, sOrgLds, ( int ) threadIdx.x );
+  stage_org<WPJ, ( WPJ >= 4 ? ORG_LDS_CAP : ORG_LDS_CAP2 )>( j, sOrgLds, ( int ) threadIdx.x );
 
   const bool ext = jp->extendedSettings != 0, fast = jp->fastSettings != 0, firstStop = jp->firstSearchStop != 0;
   const int  iRaster = fast ? 8 : 5, searchRange = jp->searchRange;
@@ -997,7 +1006,7 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void full_search_kerne
 {
   __shared__ unsigned long long sRedCost[WPJ];
   __shared__ unsigned           sRedIdx[WPJ];
-  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sOrgLds[WPJ >= 4 ? ORG_LDS_CAP : 8];
+  __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sOrgLds[WPJ >= 4 ? ORG_LDS_CAP : WPJ == 2 ? ORG_LDS_CAP2 : 8];
   const int lane = threadIdx.x & 63, wv = uni( ( int ) ( threadIdx.x >> 6 ) );
   const int blk    = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x );
   const int jobIdx = WPJ == 1 ? blk * 4 + wv : blk;
@@ -1046,7 +1055,7 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void full_search_kerne
     }
     j.resOff = ( int ) ( r * ( ( long ) j.refStride << j.ss ) + x );
   }
-  stage_org<WPJ, ORG_LDS_CAP>( j, sOrgLds, ( int ) threadIdx.x );
+  stage_org<WPJ, ( WPJ >= 4 ? ORG_LDS_CAP : ORG_LDS_CAP2 )>( j, sOrgLds, ( int ) threadIdx.x );
 
   const Range sr = search_range( j, jp->centerHor, jp->centerVer, jp->searchRange );
   const int   nx = sr.right >= sr.left ? sr.right - sr.left + 1 : 0, ny = sr.bottom >= sr.top ? sr.bottom - sr.top + 1 : 0;

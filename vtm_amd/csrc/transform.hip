@@ -557,6 +557,144 @@ __global__ __launch_bounds__( 256 ) void tu_chain_kernel( const int16_t *__restr
 }
 
 
+// ---- the smallest TUs (4x4, 8x4, 4x8: the chroma TUs of 8x8 / 16x8 / 8x16 PUs; 4x4 luma) of a uniform batch: ONE LANE per TU ---------------------------
+// The whole block lives in registers (W * H <= 32 values), the 4- / 8-point core matrices of the three types sit in LDS (staged once per workgroup);
+// the generic kernel above spends 64 threads and a dozen LDS round trips on such a block.  Same arithmetic, same order of the integer operations.
+template<int W, int H>
+__global__ __launch_bounds__( 256 ) void tu_chain_lane_kernel( const int16_t *__restrict__ resiBase, const vtmhip_tu_job *__restrict__ jobs, int numJobs, TrTables tabs,
+                                                              int *__restrict__ levelsBase, int16_t *__restrict__ recBase, vtmhip_tu_result *__restrict__ results )
+{
+  constexpr int LW = W == 4 ? 2 : 3, LH = H == 4 ? 2 : 3, N = W * H;
+  __shared__ int16_t sMH[3][W * W], sMV[3][H * H];
+  for( int i = threadIdx.x; i < 3 * W * W; i += 256 ) sMH[i / ( W * W )][i % ( W * W )] = tabs.m[i / ( W * W )][LW][i % ( W * W )];
+  for( int i = threadIdx.x; i < 3 * H * H; i += 256 ) sMV[i / ( H * H )][i % ( H * H )] = tabs.m[i / ( H * H )][LH][i % ( H * H )];
+  __syncthreads();
+  const int jobIdx = blockIdx.x * 256 + threadIdx.x;
+  if( jobIdx >= numJobs ) return;
+  const vtmhip_tu_job j = jobs[jobIdx];
+  if( j.width != W || j.height != H || j.typeHor > 2 || j.typeVer > 2 ) return;   // the caller's promise is broken: leave the result untouched
+  const int      bd = j.bitDepth;
+  const int16_t *mh = sMH[j.typeHor], *mv = sMV[j.typeVer];
+  int            r[N], b[N], t[N];
+  const int16_t *resi = resiBase + j.resiOff;
+  if( ( ( j.resiOff | j.resiStride ) & 3 ) == 0 )   // 8-byte aligned rows (offsets and strides of 4-sample blocks normally are): 4 samples per load
+  {
+#pragma unroll
+    for( int y = 0; y < H; y++ )
+#pragma unroll
+      for( int x = 0; x < W; x += 4 )
+      {
+        const int2 v = *reinterpret_cast<const int2 *>( resi + ( long ) y * j.resiStride + x );
+        r[y * W + x] = ( int ) ( short ) v.x; r[y * W + x + 1] = v.x >> 16; r[y * W + x + 2] = ( int ) ( short ) v.y; r[y * W + x + 3] = v.y >> 16;
+      }
+  }
+  else
+  {
+#pragma unroll
+    for( int y = 0; y < H; y++ )
+#pragma unroll
+      for( int x = 0; x < W; x++ ) r[y * W + x] = resi[( long ) y * j.resiStride + x];
+  }
+  long long sumAbs = 0, absSum = 0, sse = 0;
+  // forward: rows with the horizontal matrix, then columns with the vertical one (TrQuant::xT; no zero-out at these sizes)
+  {
+    const int s1 = LW + bd + 6 - 15, s2 = LH + 6;
+    const int rnd1 = s1 > 0 ? 1 << ( s1 - 1 ) : 0, rnd2 = 1 << ( s2 - 1 );
+#pragma unroll
+    for( int y = 0; y < H; y++ )
+#pragma unroll
+      for( int k = 0; k < W; k++ )
+      {
+        unsigned sum = 0;
+#pragma unroll
+        for( int n = 0; n < W; n++ ) sum += ( unsigned ) r[y * W + n] * ( unsigned ) ( int ) mh[k * W + n];
+        t[k * H + y] = ( int ) ( sum + ( unsigned ) rnd1 ) >> s1;
+      }
+#pragma unroll
+    for( int x = 0; x < W; x++ )
+#pragma unroll
+      for( int k = 0; k < H; k++ )
+      {
+        unsigned sum = 0;
+#pragma unroll
+        for( int n = 0; n < H; n++ ) sum += ( unsigned ) t[x * H + n] * ( unsigned ) ( int ) mv[k * H + n];
+        const int v = ( int ) ( sum + ( unsigned ) rnd2 ) >> s2;
+        b[k * W + x] = v;
+        sumAbs += abs( v );
+      }
+  }
+  // Quant::quant + Quant::dequant, flat scaling list
+  {
+    constexpr int   needSqrt = ( LW + LH ) & 1;
+    const int       trShift  = 15 - bd - ( ( LW + LH ) >> 1 ) + ( needSqrt ? -1 : 0 );
+    const int       qBits    = 14 + j.qpPer + trShift;
+    const long long add      = ( long long ) ( j.isIRAP ? 171 : 85 ) << ( qBits - 9 );
+    const int       scale    = c_quantScales[needSqrt][j.qpRem], iscale = c_invQuantScales[needSqrt][j.qpRem];
+    const int       rightShift = 6 - ( trShift + j.qpPer );
+    const int       inBits   = min( 16, 32 + rightShift - 7 );
+    const int       inMin = -( 1 << ( inBits - 1 ) ), inMax = ( 1 << ( inBits - 1 ) ) - 1;
+    int            *levels   = levelsBase ? levelsBase + j.outOff : nullptr;
+#pragma unroll
+    for( int i = 0; i < N; i++ )
+    {
+      const int       c   = b[i];
+      const long long tt  = ( long long ) abs( c ) * scale;
+      const int       mag = ( int ) ( ( tt + add ) >> qBits );
+      absSum += mag;
+      const int q = min( 32767, max( -32768, c < 0 ? -mag : mag ) );
+      if( levels ) levels[i] = q;
+      const int qq = min( inMax, max( inMin, q ) );
+      int       v;
+      if( rightShift > 0 ) v = ( int ) ( ( unsigned ) ( qq * iscale ) + ( 1u << ( rightShift - 1 ) ) ) >> rightShift;
+      else v = ( int ) ( ( unsigned ) ( qq * iscale ) << ( -rightShift ) );
+      b[i] = min( 32767, max( -32768, v ) );
+    }
+  }
+  // inverse: columns, then rows (TrQuant::xIT), SSE against the residual
+  {
+    const int      s2 = 20 - bd;
+    const unsigned rnd1 = 1u << 6, rnd2 = 1u << ( s2 - 1 );
+    int16_t       *rec = recBase ? recBase + j.outOff : nullptr;
+#pragma unroll
+    for( int x = 0; x < W; x++ )
+#pragma unroll
+      for( int y = 0; y < H; y++ )
+      {
+        unsigned sum = 0;
+#pragma unroll
+        for( int k = 0; k < H; k++ ) sum += ( unsigned ) b[k * W + x] * ( unsigned ) ( int ) mv[k * H + y];
+        t[x * H + y] = min( 32767, max( -32768, ( int ) ( sum + rnd1 ) >> 7 ) );
+      }
+#pragma unroll
+    for( int y = 0; y < H; y++ )
+#pragma unroll
+      for( int x = 0; x < W; x++ )
+      {
+        unsigned sum = 0;
+#pragma unroll
+        for( int k = 0; k < W; k++ ) sum += ( unsigned ) t[k * H + y] * ( unsigned ) ( int ) mh[k * W + x];
+        const int v = min( 32767, max( -32768, ( int ) ( sum + rnd2 ) >> s2 ) );
+        if( rec ) rec[y * W + x] = ( int16_t ) v;
+        const int d = r[y * W + x] - v;
+        sse += ( long long ) ( unsigned long long ) ( ( unsigned ) d * ( unsigned ) d );
+      }
+  }
+  vtmhip_tu_result res;
+  res.sse = ( uint64_t ) sse; res.sumAbs = ( int32_t ) sumAbs; res.absSum = ( int32_t ) absSum;
+  results[jobIdx] = res;
+}
+
+template<int W, int H>
+int launch_tu_lane( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int32_t *d_levelsBase, int16_t *d_recBase, vtmhip_tu_result *d_results,
+                    const TrTables &tb )
+{
+  VTMHIP_TIME_KERNEL( ctx, "tu_chain_lane_kernel" );
+  hipLaunchKernelGGL( ( tu_chain_lane_kernel<W, H> ), dim3( ( n + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, d_resiBase, d_jobs, n, tb, d_levelsBase, d_recBase, d_results );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+
 // ---- register-blocked fast path of the fused chain for batches of ONE TU size (W, H >= 8) --------------------------------------
 // Every pass is out[r][c] = sum_n A(r, n) * B[n][c] with B = the core matrix in the orientation that makes B[n][c .. c+7]
 // contiguous (forward: transposed, inverse: plain).  A lane owns 8 consecutive outputs of one row: per inner step it needs ONE
@@ -1102,6 +1240,13 @@ int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const
       if( st ) return st;
     }
     return bucket_finish<vtmhip_tu_result>( ctx, plan, n, d_results );
+  }
+  if( uniformSize && maxWidth * maxHeight <= 32 && maxWidth >= 4 && maxHeight >= 4 )
+  {
+    // caller's promise: every TU is exactly maxWidth x maxHeight (4x4, 8x4 or 4x8) with a real transform -> one lane per TU
+    if( maxWidth == 4 && maxHeight == 4 ) return launch_tu_lane<4, 4>( ctx, d_resiBase, d_jobs, n, d_levelsBase, d_recBase, d_results, tabs_of( ctx ) );
+    if( maxWidth == 8 ) return launch_tu_lane<8, 4>( ctx, d_resiBase, d_jobs, n, d_levelsBase, d_recBase, d_results, tabs_of( ctx ) );
+    return launch_tu_lane<4, 8>( ctx, d_resiBase, d_jobs, n, d_levelsBase, d_recBase, d_results, tabs_of( ctx ) );
   }
   if( uniformSize && maxWidth >= 8 && maxHeight >= 8 )
   {

@@ -810,7 +810,7 @@ class FrameHotPath:
         if self.chroma is not None:
             twc, thc = lvl["tw_c"], lvl["th_c"]
             ctx.tu_chain_batch(buf["resi_c"].data_ptr(), lvl["tu_c"].ptr, 2 * lvl["ntu_c"], twc, thc, lvl["tu_res_c"].data_ptr(), lvl["qcoef_c"].data_ptr(), None,
-                               uniform=min(twc, thc) >= 8)
+                               uniform=True)      # 4x4 / 8x4 / 4x8: one lane per TU; from 8x8: the register-blocked kernel; 16x4-like shapes: the library's generic kernel
         self._mark("tu")
 
     def _tu(self, lvl):
