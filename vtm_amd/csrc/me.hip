@@ -613,15 +613,75 @@ struct TzSaved
 constexpr int RASTER_TOT_CAP = 40 * 40;   // candidates of a scan the column kernel takes (SR 96: 39 x 39)
 constexpr int RASTER_CHUNK   = 13;        // block rows (slots) of one task at most
 
-// One lane = one raster COLUMN (dx = left + 5 lane).  The block rows the SAD visits (every (1 << ss)-th) and the scan's dy values
+// One lane = one raster COLUMN (dx = left + 5 col) of one 8-sample column segment k.  The block rows the SAD visits (every (1 << ss)-th) and the scan's dy values
 // (top + 5 m) pair up by residue: with rowStep = 5 << ss, block row r = rho + rowStep * s (rho = c << ss, c = 0..4) and candidate
 // m = p + (1 << ss) * m' meet in reference row top + 5 p + rho + rowStep * (m' + s).  A task = (8-sample column segment k, class rho, parity p,
 // chunk of <= 13 rows of the class): the lane walks down those reference rows; row u feeds candidate m' = u - slot for every slot at once, so
 // ONE 16-byte reference load serves up to 13 candidates.  The chunk's block-row segments stay in registers for the whole task, the running
 // sums rotate by one slot per step (a candidate enters slot 0 and leaves slot NS - 1 complete for this task) and are added to the candidate's
 // total in LDS.  Reference traffic of a 128x128 scan: ~5 MB instead of 50 MB through L1 / L2; no per-candidate cross-lane reduction at all.
+// A chunk of exactly N block rows: N steps per trip with the accumulators addressed by candidate modulo N -- at step u = u0 + d slot sl works for
+// candidate u - sl, whose accumulator is A[(d - sl) mod N]: a compile-time index, so nothing rotates; the candidate entering slot 0 starts from zero,
+// the one in slot N - 1 is complete for this task and goes to its total (from step N - 1 on, every step completes one).  Scalar instructions
+// issue at one per 4 cycles per SIMD like the vector ones (profiles/r02_valu_issue.jsonl, s_add_u32), so the steady-state trips carry no
+// per-step range checks, branches or exec-mask edits: lanes without a column add into a dummy slot, the reference rows arrive two steps ahead.
+#define RASTER_STEP( D, FLUSH, GUARDED )                                                                                            \
+  {                                                                                                                                 \
+    const Pel8 b = q0;                                                                                                              \
+    q0 = q1;                                                                                                                        \
+    if( !( GUARDED ) || u0 + ( D ) + 2 <= uEnd ) q1 = *reinterpret_cast<const Pel8 *>( pr );                                        \
+    pr += dr;                                                                                                                       \
+    const unsigned b0 = b.v[0] ^ j.bias, b1 = b.v[1] ^ j.bias, b2 = b.v[2] ^ j.bias, b3 = b.v[3] ^ j.bias;                          \
+    _Pragma( "unroll" ) for( int sl = 0; sl < N; sl++ )                                                                             \
+    {                                                                                                                               \
+      const int ai = ( ( D ) - sl + N ) % N;                                                                                        \
+      unsigned  a  = sl == 0 ? 0u : A[ai];                                                                                          \
+      a = sad2( O[sl][0], b0, a ); a = sad2( O[sl][1], b1, a ); a = sad2( O[sl][2], b2, a ); a = sad2( O[sl][3], b3, a );           \
+      A[ai] = a;                                                                                                                    \
+    }                                                                                                                               \
+    if( FLUSH ) { atomicAdd( &sTot[fa], A[( ( D ) + 1 ) % N] ); fa += fstep; }                                                      \
+  }
+
+template<int N>
+__device__ __forceinline__ void raster_run( const MeJob &j, int nx, int nyp, int p, int col, bool live, const int16_t *po, long orgStep, const int16_t *pr, long dr,
+                                            unsigned *sTot )
+{
+  unsigned O[N][4], A[N];
+#pragma unroll
+  for( int sl = 0; sl < N; sl++ )
+  {
+    A[sl] = 0;
+    const Pel8 a = *reinterpret_cast<const Pel8 *>( po + sl * orgStep );
+    O[sl][0] = a.v[0] ^ j.bias; O[sl][1] = a.v[1] ^ j.bias; O[sl][2] = a.v[2] ^ j.bias; O[sl][3] = a.v[3] ^ j.bias;
+  }
+  const int uEnd = nyp - 1 + N - 1;
+  int       fa = live ? p * nx + col : RASTER_TOT_CAP;   // total of candidate (p + (mp << ss)) of this lane's column; lanes without a column: the dummy slot
+  const int fstep = live ? nx << j.ss : 0;
+  Pel8 q0 = *reinterpret_cast<const Pel8 *>( pr ), q1 = q0;
+  if( uEnd >= 1 ) q1 = *reinterpret_cast<const Pel8 *>( pr + dr );
+  pr += 2 * dr;
+  int u0 = 0;
+#pragma unroll
+  for( int d = 0; d < N; d++ ) RASTER_STEP( d, d == N - 1, true )      // trip 0: the first candidate completes at its last step
+  for( u0 = N; u0 + N + 1 <= uEnd; u0 += N )
+  {
+#pragma unroll
+    for( int d = 0; d < N; d++ ) RASTER_STEP( d, true, false )         // steady state
+  }
+  for( ; u0 <= uEnd; u0 += N )
+  {
+#pragma unroll
+    for( int d = 0; d < N; d++ )
+    {
+      if( u0 + d > uEnd ) break;
+      RASTER_STEP( d, true, true )
+    }
+  }
+}
+#undef RASTER_STEP
+
 template<int NS>
-__device__ __forceinline__ void raster_task( const MeJob &j, const Range &r, int nx, int ny, int lane, int myX, int k, int rho, int p, int chunk, int rowStep,
+__device__ __forceinline__ void raster_task( const MeJob &j, const Range &r, int nx, int ny, int col, bool live, int myX, int k, int rho, int p, int chunk, int rowStep,
                                              unsigned *sTot )
 {
   const int par = 1 << j.ss;
@@ -630,6 +690,27 @@ __device__ __forceinline__ void raster_task( const MeJob &j, const Range &r, int
   const int rowsOfClass = ( j.h - rho + rowStep - 1 ) / rowStep;       // block rows rho, rho + rowStep, ... < h
   const int needed = min( NS, rowsOfClass - chunk * RASTER_CHUNK );
   if( needed <= 0 ) return;
+  // reference row of step u: top + 5 p + rho + rowStep * (u - pad + chunk * RASTER_CHUNK)
+  const int16_t *pr = j.ref + ( long ) ( r.top + 5 * p + rho + rowStep * chunk * RASTER_CHUNK ) * j.refStride + myX + ( k << 3 );
+  const long     dr = ( long ) rowStep * j.refStride;
+  {
+    // row counts of the power-of-two block heights (128: 13 / 12 per chunk, 64 with row sub-sampling: 7 / 6, 32: 4 / 3, 16 and 8: 2 / 1) take the
+    // branch-free form; any other count the rotating form below
+    const int16_t *po = j.org + ( long ) ( rho + rowStep * chunk * RASTER_CHUNK ) * j.orgStride + ( k << 3 );
+    const long     os = ( long ) rowStep * j.orgStride;
+    switch( needed )
+    {
+    case 13: if( NS >= 13 ) { raster_run<13>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
+    case 12: if( NS >= 12 ) { raster_run<12>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
+    case 7: if( NS >= 7 ) { raster_run<7>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
+    case 6: if( NS >= 6 ) { raster_run<6>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
+    case 4: if( NS >= 4 ) { raster_run<4>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
+    case 3: if( NS >= 3 ) { raster_run<3>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
+    case 2: raster_run<2>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return;
+    case 1: raster_run<1>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return;
+    default: break;
+    }
+  }
   const int pad = NS - needed;                                         // the chunk's rows sit in slots pad .. NS - 1
   unsigned  O[NS][4], A[NS];
 #pragma unroll
@@ -640,38 +721,22 @@ __device__ __forceinline__ void raster_task( const MeJob &j, const Range &r, int
     const Pel8 a  = *reinterpret_cast<const Pel8 *>( j.org + ( long ) rr * j.orgStride + ( k << 3 ) );
     O[sl][0] = a.v[0] ^ j.bias; O[sl][1] = a.v[1] ^ j.bias; O[sl][2] = a.v[2] ^ j.bias; O[sl][3] = a.v[3] ^ j.bias;
   }
-  // reference row of step u: top + 5 p + rho + rowStep * (u - pad + chunk * RASTER_CHUNK)
-  const int16_t *pr = j.ref + ( long ) ( r.top + 5 * p + rho + rowStep * chunk * RASTER_CHUNK ) * j.refStride + myX + ( k << 3 );
-  const long     dr = ( long ) rowStep * j.refStride;
-  const int      uEnd = nyp - 1 + NS - 1;
-  for( int u = pad; u <= uEnd; u++ )
+  const int uEnd = nyp - 1 + NS - 1;
+  for( int u = pad; u <= uEnd; u++ )   // slots below pad stay empty, the sums rotate by one slot per step
   {
     const Pel8     b  = *reinterpret_cast<const Pel8 *>( pr );
     const unsigned b0 = b.v[0] ^ j.bias, b1 = b.v[1] ^ j.bias, b2 = b.v[2] ^ j.bias, b3 = b.v[3] ^ j.bias;
     pr += dr;
-    if( pad == 0 )
-    {
 #pragma unroll
-      for( int sl = 0; sl < NS; sl++ )
+    for( int sl = 0; sl < NS; sl++ )
+      if( sl >= pad )
       {
         unsigned a = A[sl];
         a = sad2( O[sl][0], b0, a ); a = sad2( O[sl][1], b1, a ); a = sad2( O[sl][2], b2, a ); a = sad2( O[sl][3], b3, a );
         A[sl] = a;
       }
-    }
-    else
-    {
-#pragma unroll
-      for( int sl = 0; sl < NS; sl++ )
-        if( sl >= pad )
-        {
-          unsigned a = A[sl];
-          a = sad2( O[sl][0], b0, a ); a = sad2( O[sl][1], b1, a ); a = sad2( O[sl][2], b2, a ); a = sad2( O[sl][3], b3, a );
-          A[sl] = a;
-        }
-    }
     const int mp = u - ( NS - 1 );   // the candidate in the last slot has met every row of the chunk
-    if( mp >= 0 && mp < nyp && lane < nx ) atomicAdd( &sTot[( p + ( mp << j.ss ) ) * nx + lane], A[NS - 1] );
+    if( mp >= 0 && mp < nyp && live ) atomicAdd( &sTot[( p + ( mp << j.ss ) ) * nx + col], A[NS - 1] );
 #pragma unroll
     for( int sl = NS - 1; sl > 0; sl-- ) A[sl] = A[sl - 1];
     A[0] = 0;
@@ -681,7 +746,7 @@ __device__ __forceinline__ void raster_task( const MeJob &j, const Range &r, int
 __global__ __launch_bounds__( 256 ) void tz_raster_cols_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
                                                                const vtmhip_tz_job *__restrict__ jobs, TzSaved *__restrict__ saved, const int *__restrict__ list )
 {
-  __shared__ unsigned           sTot[RASTER_TOT_CAP];
+  __shared__ unsigned           sTot[RASTER_TOT_CAP + 1];   // + the dummy slot of lanes without a column
   __shared__ unsigned long long sRedCost[4];
   __shared__ unsigned           sRedIdx[4];
   const int lane = threadIdx.x & 63, wv = uni( ( int ) ( threadIdx.x >> 6 ) );
@@ -703,19 +768,25 @@ __global__ __launch_bounds__( 256 ) void tz_raster_cols_kernel( vtmhip_pic_param
     __syncthreads();
     const int segs = j.w >> 3, par = 1 << j.ss, rowStep = 5 << j.ss;
     const int rowsMax = ( j.h + rowStep - 1 ) / rowStep, chunks = ( rowsMax + RASTER_CHUNK - 1 ) / RASTER_CHUNK;
-    const int tasks = segs * 5 * par * chunks;
-    const int myX = r.left + 5 * min( lane, nx - 1 );   // lanes beyond the last column repeat it (their sums are never stored)
+    // a lane = one (8-sample segment k, raster column) pair: the pairs of a (class, parity, chunk) combination are dealt to whole waves, so a 39-column scan
+    // of a 16-segment block fills 624 of 640 lanes instead of 39 of every 64
+    const int pairs = segs * nx, wslots = ( pairs + 63 ) >> 6;
+    const int tasks = wslots * 5 * par * chunks;
     for( int t = wv; t < tasks; t += 4 )
     {
       int q = t;
-      const int k = q % segs; q /= segs;
+      const int ws = q % wslots; q /= wslots;
       const int c = q % 5; q /= 5;
       const int p = q % par; q /= par;
       const int chunk = q, rho = c << j.ss;
-      if( rowsMax > 7 ) raster_task<13>( j, r, nx, ny, lane, myX, k, rho, p, chunk, rowStep, sTot );
-      else if( rowsMax > 4 ) raster_task<7>( j, r, nx, ny, lane, myX, k, rho, p, chunk, rowStep, sTot );
-      else if( rowsMax > 2 ) raster_task<4>( j, r, nx, ny, lane, myX, k, rho, p, chunk, rowStep, sTot );
-      else raster_task<2>( j, r, nx, ny, lane, myX, k, rho, p, chunk, rowStep, sTot );
+      const int  pi = ws * 64 + lane;
+      const bool live = pi < pairs;
+      const int  pc = min( pi, pairs - 1 );             // lanes beyond the last pair repeat it (their sums are never stored)
+      const int  k = pc / nx, col = pc - k * nx, myX = r.left + 5 * col;
+      if( rowsMax > 7 ) raster_task<13>( j, r, nx, ny, col, live, myX, k, rho, p, chunk, rowStep, sTot );
+      else if( rowsMax > 4 ) raster_task<7>( j, r, nx, ny, col, live, myX, k, rho, p, chunk, rowStep, sTot );
+      else if( rowsMax > 2 ) raster_task<4>( j, r, nx, ny, col, live, myX, k, rho, p, chunk, rowStep, sTot );
+      else raster_task<2>( j, r, nx, ny, col, live, myX, k, rho, p, chunk, rowStep, sTot );
     }
     __syncthreads();
     // first strict minimum of SAD + MV rate in raster order = lexicographic (cost, index) minimum
