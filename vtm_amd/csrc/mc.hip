@@ -77,7 +77,7 @@ __constant__ int16_t c_chromaFilterMc[32][4] = {
 template<int THREADS>
 __device__ __forceinline__ void block_sync()
 {
-  if( THREADS == 64 )
+  if( THREADS <= 64 )
   {
     __builtin_amdgcn_fence( __ATOMIC_ACQ_REL, "wavefront" );
     __builtin_amdgcn_wave_barrier();
@@ -369,20 +369,22 @@ struct AvgThen
   }
 };
 
-// THREADS = 256: one block per workgroup (four waves share it); THREADS = 64: one block per WAVE, WPB waves (= blocks) per workgroup.  WPB = 4 was
-// measured SLOWER than one-wave workgroups on the 8x8 level (motion compensation of a picture 1.15 -> 1.69 ms): the launcher uses WPB = 1.
-template<int THREADS, int WPB>
-__global__ __launch_bounds__( THREADS * WPB ) void motion_comp_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase, int16_t *__restrict__ predBase,
+// THREADS lanes work on one block: 256 = a workgroup of four waves, 64 = a wave, 16 = a quarter of a wave (blocks of up to 64 samples: an 8x8 block has eight
+// 8-sample segments per row pass, so a whole wave per block leaves 49 of 64 lanes idle and makes the launch a queue of 129 600 one-block waves whose
+// time is the latency chain job -> window -> LDS -> store; four blocks per wave quarter the number of waves).  JPB blocks per workgroup (lanes of a block
+// never span waves, so the H -> V hand-over needs no more than the wave-level fence).
+template<int THREADS, int JPB>
+__global__ __launch_bounds__( THREADS * JPB ) void motion_comp_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase, int16_t *__restrict__ predBase,
                                                                  int16_t *__restrict__ outBase, const vtmhip_pred_job *__restrict__ jobs, int n, int maxW, int maxH )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];
-  const int             wave = WPB > 1 ? ( int ) ( threadIdx.x >> 6 ) : 0;
-  int16_t              *tmp = lds + wave * ( maxW * ( maxH + 7 ) + maxW * maxH );   // [(h+7)][w] H-pass intermediates
-  int16_t              *p0  = tmp + maxW * ( maxH + 7 );                             // [h][w] list-0 prediction of a bi-predicted block (14-bit)
-  const int             jobIdx = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x ) * WPB + wave;   // neighbouring PUs (overlapping reference windows) on one XCD's L2
+  const int             sub = JPB > 1 ? ( int ) threadIdx.x / THREADS : 0;
+  int16_t              *tmp = lds + sub * ( ( maxW * ( maxH + 7 ) + maxW * maxH + 7 ) & ~7 );   // [(h+7)][w] H-pass intermediates (16-byte aligned per block)
+  int16_t              *p0  = tmp + maxW * ( maxH + 7 );                                         // [h][w] list-0 prediction of a bi-predicted block (14-bit)
+  const int             jobIdx = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x ) * JPB + sub;   // neighbouring PUs (overlapping reference windows) on one XCD's L2
   if( jobIdx >= n ) return;
   const vtmhip_pred_job j    = jobs[jobIdx];
-  const int             lane = WPB > 1 ? ( int ) ( threadIdx.x & 63 ) : ( int ) threadIdx.x;
+  const int             lane = JPB > 1 ? ( int ) threadIdx.x % THREADS : ( int ) threadIdx.x;
   if( j.route == 1 ) return;   // routed to vtmhip_bdof_batch_dev (a table both calls are launched over)
   Epilogue ep;
   ep.org = orgBase ? orgBase + j.orgOff : nullptr; ep.orgStride = j.orgStride;
@@ -947,8 +949,8 @@ int vtmhip_motion_compensation_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgB
   VTMHIP_REQUIRE( ctx, d_refBase && d_jobs && ( d_predBase || d_outBase ), "null pointer" );
   VTMHIP_REQUIRE( ctx, !d_outBase || d_orgBase, "an epilogue output needs the original plane" );
   VTMHIP_REQUIRE( ctx, maxWidth >= 2 && maxWidth <= 128 && maxHeight >= 2 && maxHeight <= 128, "maxWidth / maxHeight" );
-  const size_t lds = ( ( size_t ) maxWidth * ( maxHeight + 7 ) + ( size_t ) maxWidth * maxHeight ) * sizeof( int16_t );
-  // one wave per block up to 16x16 samples, four waves above (the samples of a block are independent; only the H -> V hand-over syncs)
+  const size_t lds = ( ( ( size_t ) maxWidth * ( maxHeight + 7 ) + ( size_t ) maxWidth * maxHeight + 7 ) & ~( size_t ) 7 ) * sizeof( int16_t );
+  // a quarter wave per block up to 64 samples, one wave up to 16x16 samples, four waves above (the samples of a block are independent; only the H -> V hand-over syncs)
   VTMHIP_TIME_KERNEL( ctx, "motion_comp_kernel" );
   if( maxWidth * maxHeight > 256 )
   {
@@ -956,8 +958,12 @@ int vtmhip_motion_compensation_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgB
       VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( motion_comp_kernel<256, 1> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
     hipLaunchKernelGGL( ( motion_comp_kernel<256, 1> ), dim3( n ), dim3( 256 ), lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth, maxHeight );
   }
+  else if( maxWidth * maxHeight > 64 )
+    hipLaunchKernelGGL( ( motion_comp_kernel<32, 2> ), dim3( ( n + 1 ) / 2 ), dim3( 64 ), 2 * lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth,
+                        maxHeight );
   else
-    hipLaunchKernelGGL( ( motion_comp_kernel<64, 1> ), dim3( n ), dim3( 64 ), lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth, maxHeight );
+    hipLaunchKernelGGL( ( motion_comp_kernel<16, 4> ), dim3( ( n + 3 ) / 4 ), dim3( 64 ), 4 * lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth,
+                        maxHeight );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }
