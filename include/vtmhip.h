@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define VTMHIP_ABI_VERSION 2
+#define VTMHIP_ABI_VERSION 3
 
 enum
 {
@@ -673,43 +673,8 @@ int vtmhip_xPredAffineBlk_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *p
                                      const vtmhip_affine_me_job *d_jobs, int n, int maxWidth, int maxHeight );
 
 /* ================================================================================================================
- * (3) FRAME-LEVEL CHAINING -- the next stage's job table from the previous stage's results, on the device
- * ==============================================================================================================
- * A level-order driver (vtm_amd/pipeline.py) keeps every job table in HBM; these helpers patch them with one
- * thread per job so that no decision returns to the host between the stages of a picture.  The decisions are those of
- * InterSearch::predInterSearch at the FEN operating point (InterSearch.cpp:2531-2680). */
-
-/* children of a quadtree level start from / predict with their parent's integer vector (parentIdx < 0: zero vector) */
-int vtmhip_frame_child_start( vtmhip_ctx *ctx, vtmhip_tz_job *d_childJobs, int n, const int32_t *d_parentIdx, const vtmhip_me_result *d_parentRes );
-/* fractional jobs take rcMvInt from the integer results and the predictor from the integer jobs (same order, n entries) */
-int vtmhip_frame_frac_jobs( vtmhip_ctx *ctx, vtmhip_frac_job *d_fracJobs, const vtmhip_tz_job *d_tzJobs, const vtmhip_me_result *d_tzRes, int n );
-
-typedef struct
-{
-  int32_t numPU;                        /* PUs of the picture (all levels); every PU has one row per list in the 2*numPU-row tables */
-  int32_t pad;
-  const vtmhip_tz_job      *tz;         /* [2*numPU] integer jobs   */
-  const vtmhip_me_result   *tzRes;      /* [2*numPU] their results  */
-  const vtmhip_frac_result *fracRes;    /* [2*numPU] uni fractional results */
-  const int32_t            *row0, *row1;/* [numPU] row of the PU's list-0 / list-1 search */
-  const int64_t            *pos;        /* [numPU] y * refStride + x */
-  int64_t                   refBase[2]; /* sample offset of the list-0 / list-1 reference plane origin */
-  vtmhip_pred_job          *predOther;  /* [numPU] stage 0 out: prediction of the other list -> 2*org - pred */
-  vtmhip_full_job          *full;       /* [numPU] stage 0 out: exhaustive refinement around the refined list's vector */
-  vtmhip_frac_job          *fracBi;     /* [numPU] stage 0 / 1 out */
-  const vtmhip_me_result   *fullRes;    /* [numPU] */
-  const vtmhip_frac_result *fracBiRes;  /* [numPU] */
-  vtmhip_pred_job          *predFinal;  /* [numPU] stage 2 out: chosen uni / bi prediction */
-  int32_t                  *mvq;        /* [2*numPU][2] uni vectors, quarter-sample units (stage 0 out) */
-  int32_t                  *refineList; /* [numPU] 1: list 1 is refined (stage 0 out) */
-  int32_t                  *biMv;       /* [numPU][2] refined vector, quarter-sample units (stage 2 out) */
-  int64_t                  *costBi;     /* [numPU] (stage 2 out) */
-  int32_t                  *useBi;      /* [numPU] (stage 2 out) */
-} vtmhip_frame_tabs;
-
-/* stage 0: after the uni fractional searches -> predOther / full / fracBi;  1: after the exhaustive refinement -> fracBi.intX/Y;
- * 2: after the bi fractional search -> predFinal (mode, vectors), biMv, costBi, useBi */
-int vtmhip_frame_stage( vtmhip_ctx *ctx, const vtmhip_frame_tabs *tabs, int stage );
+ * (3) LEVEL-ORDER DRIVER SUPPORT -- whole functions per batch and the glue between them, decisions kept on the device
+ * ============================================================================================================== */
 
 /* ---- merge-candidate estimation: the SATD pre-selection of EncCu::xCheckRDCostMerge2Nx2N (hook B10) ---------------------------------------
  * (EncCu.cpp:2399-2440; the MMVD and CIIP candidate loops :2470-2549 use the same two steps).  For every candidate the reference runs

@@ -7,7 +7,7 @@ import sys
 import numpy as np
 
 from vtm_amd import pipeline, synth
-from vtm_amd.lib import TzJob
+from vtm_amd.lib import TzJob  # noqa: F401
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -41,13 +41,31 @@ def test_row_filter_partitions_the_picture():
             seen.add((x, y))
 
 
-def test_tz_job_table_layout():
-    xs, ys = np.array([0, 64]), np.array([128, 128])
-    a = pipeline.build_tz_jobs(64, xs, ys, 3840, 1000, 4160, 96, 8.0)
-    raw = a.view(np.uint8).reshape(2, -1)
-    j = TzJob.from_buffer_copy(raw[1].tobytes())
-    assert (j.orgOff, j.refOff, j.puX, j.puY, j.width, j.height) == (128 * 3840 + 64, 1000 + 128 * 4160 + 64, 64, 128, 64, 64)
-    assert (j.subShift, j.searchRange, j.motionLambda, j.firstSearchStop) == (1, 96, 8.0, 1)
+def test_driver_job_tables_layout():
+    """FrameHotPath builds its job tables on the host (numpy -> HBM): the uni-ME rows of a split-shape level, their transform units and the chroma jobs
+    carry the positions, sizes and strides the C structs expect (checked through the ctypes mirrors on a CPU-resident table)."""
+    import torch
+    from vtm_amd.lib import MeJob, PredJob, TuJob
+    W, H, rs = 256, 128, 640
+    refs = ([(1000, rs)], [(500000, rs)])
+    chroma = dict(org_off=(W * H, W * H + W * H // 4), org_stride=W // 2, refs=([(900000, 910000)], [(920000, 930000)]), ref_stride=320)
+    hp = pipeline.FrameHotPath(None, torch, torch.device("cpu"), W, H, W, refs, ([96], [96]), sizes=((64, 64), (64, 32), (16, 8)), pocs=(2, [0], [4]), chroma=chroma)
+    lv = {l["size"]: l for l in hp.levels}
+    l = lv[(64, 32)]
+    assert l["npu"] == (W // 64) * (H // 32) and (l["w"], l["h"], l["tw"], l["th"]) == (64, 32, 64, 32)
+    raw = l["uni_jobs"].t.numpy()
+    n = l["npu"]
+    j = MeJob.from_buffer_copy(raw[n + 5].tobytes())          # list 1, PU 5 = (x 64, y 32)
+    assert (j.puX, j.puY, j.width, j.height, j.orgOff, j.refOff, j.searchRange) == (64, 32, 64, 32, 32 * W + 64, 500000 + 32 * rs + 64, 96)
+    t = TuJob.from_buffer_copy(l["tu"].t.numpy()[5].tobytes())
+    assert (t.width, t.height, t.resiStride, t.resiOff) == (64, 32, 64, l["sb"] + 5 * 64 * 32)
+    c = PredJob.from_buffer_copy(l["pred_final_c"].t.numpy()[n + 5].tobytes())   # the Cr job of PU 5
+    assert (c.width, c.height, c.chroma, c.orgOff, c.predStride) == (32, 16, 1, chroma["org_off"][1] + 16 * (W // 2) + 32, 32)
+    s8 = lv[(16, 8)]
+    assert (s8["tw_c"], s8["th_c"]) == (8, 4) and s8["parent32"] is not None    # 16x8 PUs nest in the 64x32 level; their chroma TUs are 8x4
+    par = s8["parent32"].numpy()
+    k = int(np.nonzero((s8["xs"] == 80) & (s8["ys"] == 40))[0][0])
+    assert (l["xs"][par[k]], l["ys"][par[k]]) == (64, 32)
 
 
 def test_extend_plane_replicates_border():

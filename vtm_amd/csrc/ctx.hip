@@ -29,17 +29,16 @@ int vtmhip_struct_size( int which )
   case 16: return ( int ) sizeof( vtmhip_me_job );
   case 17: return ( int ) sizeof( vtmhip_me_out );
   case 18: return ( int ) sizeof( vtmhip_pred_job );
-  case 19: return ( int ) sizeof( vtmhip_frame_tabs );
-  case 20: return ( int ) sizeof( vtmhip_masked_sad_job );
-  case 21: return ( int ) sizeof( vtmhip_geo_blend_job );
-  case 22: return ( int ) sizeof( vtmhip_dmvr_job );
-  case 23: return ( int ) sizeof( vtmhip_lfnst_job );
-  case 24: return ( int ) sizeof( vtmhip_pis_row );
-  case 25: return ( int ) sizeof( vtmhip_pis_pu );
-  case 26: return ( int ) sizeof( vtmhip_pis_level );
-  case 27: return ( int ) sizeof( vtmhip_affine_me_job );
-  case 28: return ( int ) sizeof( vtmhip_affine_me_out );
-  case 29: return ( int ) sizeof( vtmhip_lfnst_tu_job );
+  case 19: return ( int ) sizeof( vtmhip_masked_sad_job );
+  case 20: return ( int ) sizeof( vtmhip_geo_blend_job );
+  case 21: return ( int ) sizeof( vtmhip_dmvr_job );
+  case 22: return ( int ) sizeof( vtmhip_lfnst_job );
+  case 23: return ( int ) sizeof( vtmhip_pis_row );
+  case 24: return ( int ) sizeof( vtmhip_pis_pu );
+  case 25: return ( int ) sizeof( vtmhip_pis_level );
+  case 26: return ( int ) sizeof( vtmhip_affine_me_job );
+  case 27: return ( int ) sizeof( vtmhip_affine_me_out );
+  case 28: return ( int ) sizeof( vtmhip_lfnst_tu_job );
   default: return -1;
   }
 }

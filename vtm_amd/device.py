@@ -251,15 +251,6 @@ class Context:
     def pis_stage(self, level, stage):
         self._check(self.L.vtmhip_pis_stage(self.h, C.byref(level), stage))
 
-    def frame_child_start(self, d_child_jobs, n, d_parent_idx, d_parent_res):
-        self._check(self.L.vtmhip_frame_child_start(self.h, d_child_jobs, n, d_parent_idx, d_parent_res))
-
-    def frame_frac_jobs(self, d_frac_jobs, d_tz_jobs, d_tz_res, n):
-        self._check(self.L.vtmhip_frame_frac_jobs(self.h, d_frac_jobs, d_tz_jobs, d_tz_res, n))
-
-    def frame_stage(self, tabs, stage):
-        self._check(self.L.vtmhip_frame_stage(self.h, C.byref(tabs), stage))
-
     def motion_compensation_batch(self, d_org, d_ref, d_pred, d_out, d_jobs, n, max_w, max_h):
         """InterPrediction::motionCompensation per PU (uni / bi + addAvg) with the fused residual / removeHighFreq epilogue."""
         self._check(self.L.vtmhip_motion_compensation_batch_dev(self.h, d_org, d_ref, d_pred, d_out, d_jobs, n, max_w, max_h))

@@ -134,13 +134,6 @@ class PredJob(C.Structure):
                 ("useAltHpelIf", C.c_uint8), ("chroma", C.c_uint8), ("route", C.c_uint8), ("pad1", C.c_int16)]
 
 
-class FrameTabs(C.Structure):
-    _fields_ = [("numPU", C.c_int32), ("pad", C.c_int32), ("tz", C.c_void_p), ("tzRes", C.c_void_p), ("fracRes", C.c_void_p), ("row0", C.c_void_p),
-                ("row1", C.c_void_p), ("pos", C.c_void_p), ("refBase", C.c_int64 * 2), ("predOther", C.c_void_p), ("full", C.c_void_p),
-                ("fracBi", C.c_void_p), ("fullRes", C.c_void_p), ("fracBiRes", C.c_void_p), ("predFinal", C.c_void_p), ("mvq", C.c_void_p),
-                ("refineList", C.c_void_p), ("biMv", C.c_void_p), ("costBi", C.c_void_p), ("useBi", C.c_void_p)]
-
-
 class MaskedSadJob(C.Structure):
     _fields_ = [("orgOff", C.c_int64), ("curOff", C.c_int64), ("maskOff", C.c_int64), ("orgStride", C.c_int32), ("curStride", C.c_int32),
                 ("maskStride", C.c_int32), ("maskStride2", C.c_int32), ("width", C.c_int16), ("height", C.c_int16), ("subShift", C.c_int16),
@@ -205,7 +198,7 @@ class LfnstTuJob(C.Structure):
 
 
 _STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob,
-            TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut, PredJob, FrameTabs, MaskedSadJob, GeoBlendJob, DmvrJob, LfnstJob,
+            TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut, PredJob, MaskedSadJob, GeoBlendJob, DmvrJob, LfnstJob,
             PisRow, PisPu, PisLevel, AffineMeJob, AffineMeOut, LfnstTuJob]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
@@ -275,9 +268,6 @@ _PROTOS = {
     "vtmhip_motion_compensation_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                        C.c_int]),
     "vtmhip_mc_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
-    "vtmhip_frame_child_start": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
-    "vtmhip_frame_frac_jobs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
-    "vtmhip_frame_stage": (C.c_int, [C.c_void_p, C.POINTER(FrameTabs), C.c_int]),
     "vtmhip_full_search_uniform_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                        C.c_void_p]),
     "vtmhip_full_search_square_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

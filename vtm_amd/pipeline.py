@@ -80,95 +80,15 @@ def quadtree_levels(pic_w, pic_h, sizes=(128, 64, 32, 16, 8), row_filter=None, c
     return levels
 
 
-def build_tz_jobs(size, xs, ys, org_stride, ref_off, ref_stride, search_range, motion_lambda, org_off=0):
-    """TzJob table for n square PUs against one reference plane (zero start / zero predictor; the driver patches
-    the predictor words from the parent level on the device)."""
-    n = xs.size
-    a = np.zeros(n, dtype=TZ_DT)
-    a["orgOff"] = org_off + ys * org_stride + xs
-    a["refOff"] = ref_off + ys * ref_stride + xs
-    a["orgStride"], a["refStride"] = org_stride, ref_stride
-    a["puX"], a["puY"], a["width"], a["height"] = xs, ys, size, size
-    a["subShift"] = subshift_mode2(size, size)
-    a["motionLambda"] = motion_lambda
-    a["searchRange"] = search_range
-    a["firstSearchStop"] = 1   # FastMEAssumingSmootherMVEnabled default (EncAppCfg.cpp:981)
-    return a
-
-
-class FrameME:
-    """Integer ME of one picture: quadtree levels x reference pictures, device-resident.
-
-    torch tensors: `org` int16 [H*orgStride], `dpb` int16 (all reference planes, border-extended, back to back)."""
-
-    def __init__(self, ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda=8.0,
-                 sizes=(128, 64, 32, 16, 8), row_filter=None, waves_per_job=None, ctu_filter=None):
-        """refs: [(ref_off, ref_stride)] sample offsets of each reference plane's (0,0) inside `dpb`."""
-        self.ctx, self.torch, self.device = ctx, torch, device
-        self.pic_w, self.pic_h = pic_w, pic_h
-        # waves that share one search: big PUs have long SADs and (at the top level, which has no predictor) raster scans
-        self.wpj = dict(WAVES_PER_JOB)
-        self.wpj.update(waves_per_job or {})
-        for kv in filter(None, os.environ.get("VTM_AMD_TZ_WPJ", "").split(",")):   # tuning knob, e.g. VTM_AMD_TZ_WPJ=128:8,64:4
-            k, v = kv.split(":")
-            self.wpj[int(k)] = int(v)
-        self.levels = []
-        self.n_jobs = 0
-        self.alg_bytes_per_eval = []
-        for (s, xs, ys, parent) in quadtree_levels(pic_w, pic_h, sizes, row_filter, ctu_filter):
-            if xs.size == 0:
-                continue
-            tabs, parents = [], []
-            for (roff, rstride), sr in zip(refs, search_ranges):
-                tabs.append(build_tz_jobs(s, xs, ys, org_stride, roff, rstride, sr, motion_lambda))
-            nref = len(refs)
-            jobs = np.concatenate(tabs)
-            n = jobs.size
-            par = None
-            if parent is not None:
-                npar = self.levels[-1]["n"] // nref
-                par = np.concatenate([np.where(parent >= 0, parent + r * npar, -1) for r in range(nref)])
-            lvl = dict(size=s, n=n, pic=PicParams(pic_w, pic_h, 128, 10, self.wpj.get(s, 1)),
-                       jobs=torch.from_numpy(jobs.view(np.uint8).reshape(n, TZ_DT.itemsize).copy()).to(device),
-                       res=torch.zeros((n, 8), dtype=torch.int32, device=device),
-                       parent=None if par is None else torch.from_numpy(par).to(device),
-                       parent32=None if par is None else torch.from_numpy(par.astype(np.int32)).to(device))
-            self.levels.append(lvl)
-            self.n_jobs += n
-            self.alg_bytes_per_eval.append(4 * s * s >> subshift_mode2(s, s))
-
-    def run(self, org_ptr, dpb_ptr):
-        """Launches every level (coarse to fine) on the context's stream; no host synchronisation."""
-        for i, lvl in enumerate(self.levels):
-            if lvl["parent"] is not None:   # start vector and MV predictor = the parent's integer vector (device-side patch)
-                self.ctx.frame_child_start(lvl["jobs"].data_ptr(), lvl["n"], lvl["parent32"].data_ptr(), self.levels[i - 1]["res"].data_ptr())
-            self.ctx.tz_search_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["jobs"].data_ptr(), lvl["n"], lvl["res"].data_ptr())
-
-    def stats(self):
-        """(total candidate evaluations, algorithmic bytes = sum over jobs of nEval * 4*W*H >> subShift)."""
-        ev, by = 0, 0
-        for lvl, b in zip(self.levels, self.alg_bytes_per_eval):
-            ne = int(lvl["res"][:, 2].to(self.torch.int64).sum().item())
-            ev += ne
-            by += ne * b
-        return ev, by
-
-    def results_numpy(self):
-        return [lvl["res"].cpu().numpy().view(RES_DT).reshape(-1) for lvl in self.levels]
-
-
 # ======================================================================================================================
-# Full hot path of one inter picture: integer ME -> fractional ME -> bi-predictive refinement -> residual coding.
+# Level-order InterSearch::predInterSearch (InterSearch.cpp:2245-3065, translational part) + residual coding of one picture
 # ======================================================================================================================
-from .lib import DistJob, FracJob, FracResult, FrameTabs, FullJob, McJob, PelOpJob, PredJob, QuantJob, TrJob, TuJob   # noqa: E402
+from .lib import MAX_REF, FracJob, FracResult, MeCfg, MeJob, MeOut, PisLevel, PisPu, PisRow, PredJob, TuJob   # noqa: E402
 
-FRAC_DT, FRACRES_DT, MC_DT, FULL_DT = np.dtype(FracJob), np.dtype(FracResult), np.dtype(McJob), np.dtype(FullJob)
-PEL_DT, TR_DT, Q_DT, DIST_DT = np.dtype(PelOpJob), np.dtype(TrJob), np.dtype(QuantJob), np.dtype(DistJob)
+FRAC_DT, FRACRES_DT = np.dtype(FracJob), np.dtype(FracResult)
 TU_DT = np.dtype(TuJob)
 PRED_DT = np.dtype(PredJob)
-
-# (typeHor, typeVer) of mtsIdx 0, 2, 3, 4, 5 (TrQuant::getTrTypes, TrQuant.cpp:695-772): DCT2 = 0, DCT8 = 1, DST7 = 2
-MTS_CANDS = ((0, 0), (2, 2), (1, 2), (2, 1), (1, 1))
+ME_DT, MEOUT_DT, ROW_DT, PU_DT = np.dtype(MeJob), np.dtype(MeOut), np.dtype(PisRow), np.dtype(PisPu)
 
 
 class _Tab:
@@ -203,351 +123,6 @@ class _Tab:
         return self.t.data_ptr()
 
 
-class FrameHotPathV1(FrameME):
-    """All stages for one picture with two reference pictures (list 0 / list 1):
-
-      tz      InterSearch::xTZSearch per (PU, list), level by level (children start from the parent's vector)   (InterSearch.cpp:3640-3976)
-      frac    xPatternSearchFracDIF per (PU, list): half + quarter refinement, SATD                               (:4284-4339)
-      bi      FEN bi-pred iteration (:2531-2680): refine the list with the LARGER uni cost: motion-compensate the other
-              list, org' = 2*org - pred (removeHighFreq), +-4 exhaustive search (xPatternSearch), fractional search on org'
-      resi    final prediction (bi via addAvg when cheaper, else best uni) -> residual -> per TU (<= 64x64) and transform
-              candidate (DCT2 + 4 MTS candidates up to 32x32): xT -> Quant::quant -> dequant -> xIT -> SSE (one fused launch per level)
-    Mode decision between the candidates, CABAC bit estimation and DepQuant stay on the host (out of scope, SURVEY.md 8a);
-    every MTS candidate is taken through the whole chain (the reference prunes with the sum|coef| threshold).
-
-    STAGE-MAJOR execution: the integer search runs level by level (parent -> child dependence); every later stage is one
-    launch per level over job tables that are concatenated across levels, so the on-device bookkeeping between stages
-    (list choice, vector arithmetic, job patching -- a few dozen tiny tensor ops) happens once per picture, not per level.
-    """
-
-    def __init__(self, ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda=8.0, qp=32, fused_tu=True, **kw):
-        assert len(refs) == 2 and refs[0][1] == refs[1][1]
-        super().__init__(ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda, **kw)
-        self.fused_tu = fused_tu
-        self.refs, self.org_stride, self.lam = refs, org_stride, motion_lambda
-        base_qp = qp + 12   # 10-bit: qpBdOffset = 12 (Quant.cpp:65-104)
-        self.qp_per, self.qp_rem = base_qp // 6, base_qp % 6
-        T, dev, rs = torch, device, refs[0][1]
-
-        # ---- concatenate the per-level TZ tables so that every later stage sees one table ----------------------------------
-        NP = sum(l["n"] // 2 for l in self.levels)
-        self.NP = NP
-        self.tz_jobs_all = T.cat([l["jobs"] for l in self.levels])            # [2*NP, 208] rows: per level [list0 PUs | list1 PUs]
-        self.tz_res_all = T.zeros((2 * NP, 8), dtype=T.int32, device=dev)
-        row0, row1, pos, blk, sizes = [], [], [], [], []
-        pb, sb = 0, 0
-        for lvl in self.levels:
-            s, npu = lvl["size"], lvl["n"] // 2
-            lvl["npu"], lvl["pb"], lvl["sb"] = npu, pb, sb
-            lvl["jobs"] = self.tz_jobs_all[2 * pb:2 * pb + 2 * npu]           # views: launches and parent patching act on the big table
-            lvl["res"] = self.tz_res_all[2 * pb:2 * pb + 2 * npu]
-            lvl["pic_full"] = PicParams(pic_w, pic_h, 128, 10, FULL_WAVES_PER_JOB.get(s, 1))
-            jn = lvl["jobs"].cpu().numpy().view(TZ_DT).reshape(-1)
-            xs, ys = jn["puX"][:npu].astype(np.int64), jn["puY"][:npu].astype(np.int64)
-            lvl["xs"], lvl["ys"] = xs, ys
-            row0.append(2 * pb + np.arange(npu))
-            row1.append(2 * pb + npu + np.arange(npu))
-            pos.append(ys * rs + xs)
-            blk.append(sb + np.arange(npu, dtype=np.int64) * s * s)
-            sizes.append(np.full(npu, s))
-            pb += npu
-            sb += npu * s * s
-        self.NS = sb                                                            # samples of one full-coverage buffer (all levels)
-        row0, row1, pos, blk, sizes = (np.concatenate(a) for a in (row0, row1, pos, blk, sizes))
-        xs_all = np.concatenate([l["xs"] for l in self.levels])
-        ys_all = np.concatenate([l["ys"] for l in self.levels])
-        self.row0, self.row1 = T.from_numpy(row0).to(dev), T.from_numpy(row1).to(dev)
-        self.pos, self.blk_off = T.from_numpy(pos).to(dev), T.from_numpy(blk).to(dev)
-        self.ref_base = T.tensor([r[0] for r in refs], dtype=T.int64, device=dev)
-        tzj = self.tz_jobs_all.cpu().numpy().view(TZ_DT).reshape(-1)
-
-        fj = np.zeros(2 * NP, FRAC_DT)
-        fj["orgOff"], fj["refOff"] = tzj["orgOff"], tzj["refOff"]
-        fj["orgStride"], fj["refStride"], fj["width"], fj["height"] = org_stride, rs, tzj["width"], tzj["height"]
-        fj["motionLambda"], fj["useHad"], fj["bitDepth"] = motion_lambda, 1, 10
-        self.frac = _Tab(T, dev, fj)
-        self.frac_res = T.zeros((2 * NP, 16), dtype=T.uint8, device=dev)
-
-        # motion compensation with the consumer fused in (vtmhip_motion_compensation_batch_dev):
-        #   pred_other  other list's uni prediction -> bi-pred ME target 2*org - pred        (xMotionEstimation bBi branch, :3316-3329)
-        #   pred_final  chosen uni / bi (addAvg) prediction -> prediction + residual org - pred
-        qj0 = np.zeros(NP, PRED_DT)
-        qj0["orgOff"], qj0["orgStride"] = ys_all * org_stride + xs_all, org_stride
-        qj0["refStride"] = rs
-        qj0["predOff"], qj0["outOff"], qj0["predStride"], qj0["outStride"] = blk, blk, sizes, sizes
-        qj0["width"], qj0["height"], qj0["bitDepth"] = sizes, sizes, 10
-        qo = qj0.copy()
-        qo["epilogue"] = 2
-        self.pred_other = _Tab(T, dev, qo)
-        qf = qj0.copy()
-        qf["epilogue"] = 1
-        self.pred_final = _Tab(T, dev, qf)
-        uj = np.zeros(NP, FULL_DT)
-        uj["orgOff"], uj["orgStride"], uj["refStride"] = blk, sizes, rs
-        uj["puX"], uj["puY"], uj["width"], uj["height"] = xs_all, ys_all, sizes, sizes
-        uj["subShift"] = np.where((sizes > 8) & (sizes <= 64), 1, 0)
-        uj["signedSamples"], uj["motionLambda"], uj["searchRange"] = 1, motion_lambda, 4
-        self.full = _Tab(T, dev, uj)
-        self.full_res = T.zeros((NP, 8), dtype=T.int32, device=dev)
-        bj = np.zeros(NP, FRAC_DT)
-        bj["orgOff"], bj["orgStride"], bj["refStride"], bj["width"], bj["height"] = blk, sizes, rs, sizes, sizes
-        bj["motionLambda"], bj["useHad"], bj["bitDepth"] = motion_lambda, 1, 10
-        self.frac_bi = _Tab(T, dev, bj)
-        self.frac_bi_res = T.zeros((NP, 16), dtype=T.uint8, device=dev)
-
-        # ---- device-side chaining (vtmhip_frame_*): static columns once, decisions in HBM -----------------------------------
-        for tab in (self.pred_other, self.pred_final):
-            for l in (0, 1):
-                tab.col2("refOff", l).copy_(self.ref_base[l] + self.pos)
-        self.row0_32, self.row1_32 = self.row0.to(T.int32), self.row1.to(T.int32)
-        self.mvq = T.zeros((2 * NP, 2), dtype=T.int32, device=dev)
-        self.refine = T.zeros(NP, dtype=T.int32, device=dev)
-        self.bi_mv = T.zeros((NP, 2), dtype=T.int32, device=dev)
-        self.cost_bi = T.zeros(NP, dtype=T.int64, device=dev)
-        self.use_bi = T.zeros(NP, dtype=T.int32, device=dev)
-        ft = FrameTabs()
-        ft.numPU = NP
-        ft.tz, ft.tzRes, ft.fracRes = self.tz_jobs_all.data_ptr(), self.tz_res_all.data_ptr(), self.frac_res.data_ptr()
-        ft.row0, ft.row1, ft.pos = self.row0_32.data_ptr(), self.row1_32.data_ptr(), self.pos.data_ptr()
-        ft.refBase[0], ft.refBase[1] = int(refs[0][0]), int(refs[1][0])
-        ft.predOther, ft.full, ft.fracBi = self.pred_other.ptr, self.full.ptr, self.frac_bi.ptr
-        ft.fullRes, ft.fracBiRes, ft.predFinal = self.full_res.data_ptr(), self.frac_bi_res.data_ptr(), self.pred_final.ptr
-        ft.mvq, ft.refineList, ft.biMv = self.mvq.data_ptr(), self.refine.data_ptr(), self.bi_mv.data_ptr()
-        ft.costBi, ft.useBi = self.cost_bi.data_ptr(), self.use_bi.data_ptr()
-        self.frame_tabs = ft
-        # per-level views of the same table set (the per-PU arrays advanced to the level's first PU): each level's chain of stages can then
-        # run on its own stream as soon as that level's integer search is done
-        for lvl in self.levels:
-            pb, n = lvl["pb"], lvl["npu"]
-            lt = FrameTabs()
-            C.memmove(C.byref(lt), C.byref(ft), C.sizeof(FrameTabs))
-            lt.numPU = n
-            for name, isz in (("row0", 4), ("row1", 4), ("pos", 8), ("predOther", PRED_DT.itemsize), ("full", FULL_DT.itemsize), ("fracBi", FRAC_DT.itemsize),
-                              ("fullRes", 32), ("fracBiRes", 16), ("predFinal", PRED_DT.itemsize), ("refineList", 4), ("biMv", 8), ("costBi", 8), ("useBi", 4)):
-                setattr(lt, name, getattr(ft, name) + pb * isz)
-            lvl["ftabs"] = lt
-        self.side_streams = [T.cuda.Stream(device=dev) for _ in range(int(os.environ.get("VTM_AMD_SIDE_STREAMS", "5")))] if dev.type == "cuda" else []
-
-        # ---- transform units: the PU itself up to 64x64, four 64x64 quadrants of a 128x128 PU (MaxTbSize 64) ---------------
-        tu_tabs, legacy, tb, max_coef = [], [], 0, 0
-        for lvl in self.levels:
-            s, npu = lvl["size"], lvl["npu"]
-            ts = min(s, 64)
-            q = s // ts
-            blk_l = lvl["sb"] + np.arange(npu, dtype=np.int64) * s * s
-            tu_src = np.stack([blk_l + qy * ts * s + qx * ts for qy in range(q) for qx in range(q)], 1).reshape(-1)
-            ntu = tu_src.size
-            cands = MTS_CANDS if ts <= 32 else MTS_CANDS[:1]
-            nc = len(cands)
-            coef_off = np.arange(ntu * nc, dtype=np.int64) * ts * ts        # per-level arena (levels run one after the other)
-            uj2 = np.zeros(ntu * nc, TU_DT)
-            uj2["resiOff"], uj2["outOff"], uj2["resiStride"], uj2["width"], uj2["height"] = np.tile(tu_src, nc), coef_off, s, ts, ts
-            uj2["qpPer"], uj2["qpRem"], uj2["bitDepth"] = self.qp_per, self.qp_rem, 10
-            uj2["typeHor"] = np.repeat([c[0] for c in cands], ntu)
-            uj2["typeVer"] = np.repeat([c[1] for c in cands], ntu)
-            tu_tabs.append(uj2)
-            lvl["ntu"], lvl["nc"], lvl["ts"], lvl["tb"] = ntu, nc, ts, tb
-            tb += ntu * nc
-            max_coef = max(max_coef, ntu * nc * ts * ts)
-            if not fused_tu:   # the five separate kernels (kept for A/B and as the non-fused parity path)
-                tj = np.zeros(ntu * nc, TR_DT)
-                tj["srcOff"], tj["dstOff"], tj["srcStride"], tj["dstStride"] = np.tile(tu_src, nc), coef_off, s, ts
-                tj["width"], tj["height"], tj["bitDepth"], tj["typeHor"], tj["typeVer"] = ts, ts, 10, uj2["typeHor"], uj2["typeVer"]
-                ij = tj.copy()
-                ij["srcOff"] = coef_off
-                qj = np.zeros(ntu * nc, Q_DT)
-                qj["srcOff"], qj["dstOff"], qj["width"], qj["height"] = coef_off, coef_off, ts, ts
-                qj["qpPer"], qj["qpRem"], qj["bitDepth"] = self.qp_per, self.qp_rem, 10
-                dj = np.zeros(ntu * nc, DIST_DT)
-                dj["orgOff"], dj["curOff"], dj["orgStride"], dj["curStride"] = np.tile(tu_src, nc), coef_off, s, ts
-                dj["width"], dj["height"], dj["kind"] = ts, ts, _lib.DIST_SSE
-                lvl["xt"], lvl["xit"], lvl["quant"], lvl["sse"] = (_Tab(T, dev, x) for x in (tj, ij, qj, dj))
-        self.tu = _Tab(T, dev, np.concatenate(tu_tabs))
-        self.tu_res = T.zeros((tb, 2), dtype=T.int64, device=dev)   # vtmhip_tu_result {sse u64, sumAbs i32, absSum i32}
-        for lvl in self.levels:
-            n_l = lvl["ntu"] * lvl["nc"]
-            r = self.tu_res[lvl["tb"]:lvl["tb"] + n_l]
-            lvl["sse_out"], lvl["sum_abs"], lvl["abs_sum"] = r[:, 0], r.view(T.int32)[:, 2], r.view(T.int32)[:, 3]
-            if not fused_tu:
-                lvl["sum_abs"] = T.zeros(n_l, dtype=T.int32, device=dev)
-                lvl["abs_sum"] = T.zeros(n_l, dtype=T.int32, device=dev)
-                lvl["sse_out"] = T.zeros(n_l, dtype=T.int64, device=dev)
-        mk = lambda n: T.zeros(n, dtype=T.int16, device=dev)   # noqa: E731
-        self.buf = dict(org_bi=mk(sb), pred=mk(sb), resi=mk(sb))
-        # quantised levels: one arena per level (the levels' chains may run concurrently)
-        qoff = 0
-        for lvl in self.levels:
-            lvl["qoff"] = qoff
-            qoff += lvl["ntu"] * lvl["nc"] * lvl["ts"] * lvl["ts"]
-        self.qcoef = T.zeros(qoff, dtype=T.int32, device=dev)
-        if not fused_tu:
-            self.coef = T.zeros(max_coef, dtype=T.int32, device=dev)
-            self.dqcoef = T.zeros(max_coef, dtype=T.int32, device=dev)
-            self.rec_resi = T.zeros(max_coef, dtype=T.int16, device=dev)
-        self._marks = None
-
-    # ---- stage timing (HIP events on the launch stream; only when run(..., timing=True)) ----------------------------------
-    def _mark(self, name):
-        if self._marks is not None:
-            e = self.torch.cuda.Event(enable_timing=True)
-            e.record()
-            self._marks.append((name, e))
-
-    def stage_ms(self):
-        """{stage: milliseconds} of the last timed run (call after a synchronize); 'glue' = on-device bookkeeping between stages."""
-        acc = {}
-        for (n0, e0), (n1, e1) in zip(self._marks[:-1], self._marks[1:]):
-            acc[n1] = acc.get(n1, 0.0) + e0.elapsed_time(e1)
-        acc.pop("start", None)
-        return acc
-
-    def alg_bytes(self):
-        """Algorithmic bytes per kernel family for one picture (SURVEY.md 8d per-unit figures):
-        tz    sum over searches of nEval * (4*W*H >> subShift)                       [SAD: 4*W*H >> subShift per candidate]
-        frac  per search: 6 H + 18 V filter passes (4 B per output sample) + 18 SATDs (256 B per 8x8 tile = 4 B per sample)
-        full  81 candidates * (4*W*H >> subShift)
-        mc    4 B per output sample of every filter pass (H pass on H+7 rows, V pass) of the predictions formed (other-list uni, final
-              uni or bi) + 6 B per sample of each fused epilogue (org read, prediction / target / residual written)
-        tu    per sample: xT 6 + quant 8 + dequant 8 + xIT 6 + SSE 4 = 32 B"""
-        b = dict(tz=self.stats()[1], frac=0, full=0, mc=0, tu=0)
-        nbi = int(self._use_bi.sum().item()) if getattr(self, "_use_bi", None) is not None else 0
-        frac_bi = nbi / max(1, self.NP)
-        for lvl in self.levels:
-            s, npu, nt, ts = lvl["size"], lvl["npu"], lvl["ntu"] * lvl["nc"], lvl["ts"]
-            b["frac"] += 3 * npu * (24 * (s + 8) * s + 144 * s * s)
-            b["full"] += npu * 81 * (4 * s * s >> subshift_mode2(s, s))
-            b["mc"] += int(npu * (2 + frac_bi) * 4 * ((2 * s + 7) * s)) + 2 * npu * 6 * s * s
-            b["tu"] += nt * ts * ts * 32
-        return b
-
-    def _per_level(self, fn):
-        for lvl in self.levels:
-            fn(lvl, lvl["pb"], lvl["npu"], lvl["size"])
-
-    def _level_chain(self, lvl, org_ptr, dpb_ptr):
-        """Stages (2)-(5) of ONE quadtree level, in order, on the context's current stream."""
-        ctx, pb, n, s, lt = self.ctx, lvl["pb"], lvl["npu"], lvl["size"], lvl["ftabs"]
-        fr, po, fu, fb, pf = self.frac, self.pred_other, self.full, self.frac_bi, self.pred_final
-        ctx.frame_frac_jobs(fr.ptr + 2 * pb * FRAC_DT.itemsize, self.tz_jobs_all.data_ptr() + 2 * pb * TZ_DT.itemsize, self.tz_res_all.data_ptr() + 2 * pb * 32, 2 * n)
-        ctx.frac_search_batch(org_ptr, dpb_ptr, fr.ptr + 2 * pb * FRAC_DT.itemsize, 2 * n, s, s, self.frac_res.data_ptr() + 2 * pb * 16, uniform_square=True)
-        ctx.frame_stage(lt, 0)
-        ctx.motion_compensation_batch(org_ptr, dpb_ptr, None, self.buf["org_bi"].data_ptr(), po.ptr + pb * PRED_DT.itemsize, n, s, s)
-        ctx.full_search_batch(lvl["pic_full"], self.buf["org_bi"].data_ptr(), dpb_ptr, fu.ptr + pb * FULL_DT.itemsize, n, self.full_res.data_ptr() + pb * 32,
-                              square=s if s <= 64 else 0)
-        ctx.frame_stage(lt, 1)
-        ctx.frac_search_batch(self.buf["org_bi"].data_ptr(), dpb_ptr, fb.ptr + pb * FRAC_DT.itemsize, n, s, s, self.frac_bi_res.data_ptr() + pb * 16, uniform_square=True)
-        ctx.frame_stage(lt, 2)
-        ctx.motion_compensation_batch(org_ptr, dpb_ptr, self.buf["pred"].data_ptr(), self.buf["resi"].data_ptr(), pf.ptr + pb * PRED_DT.itemsize, n, s, s)
-        nt, ts = lvl["ntu"] * lvl["nc"], lvl["ts"]
-        ctx.tu_chain_batch(self.buf["resi"].data_ptr(), self.tu.ptr + lvl["tb"] * TU_DT.itemsize, nt, ts, ts, self.tu_res.data_ptr() + lvl["tb"] * 16,
-                           self.qcoef.data_ptr() + 4 * lvl["qoff"], None, uniform=True)
-
-    def _run_overlapped(self, org_ptr, dpb_ptr):
-        """Level-major order over several streams: the integer searches stay one dependent chain (child <- parent) on the caller's stream;
-        every level's remaining stages start as soon as ITS integer search is done, on a side stream, so the low-parallelism launches of
-        the large blocks (960 searches of 128x128) share the chip with the other levels' work.  Same launches, same tables, same results
-        as the stage-major order."""
-        T, ctx = self.torch, self.ctx
-        main = T.cuda.current_stream()
-        for i, lvl in enumerate(self.levels):
-            if lvl["parent"] is not None:
-                ctx.frame_child_start(lvl["jobs"].data_ptr(), lvl["n"], lvl["parent32"].data_ptr(), self.levels[i - 1]["res"].data_ptr())
-            ctx.tz_search_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["jobs"].data_ptr(), lvl["n"], lvl["res"].data_ptr())
-            ev = T.cuda.Event()
-            ev.record(main)
-            st = self.side_streams[i % len(self.side_streams)]
-            st.wait_event(ev)
-            ctx.set_stream(st.cuda_stream)
-            self._level_chain(lvl, org_ptr, dpb_ptr)
-            ctx.set_stream(main.cuda_stream)
-        for st in self.side_streams:
-            main.wait_stream(st)
-        self._use_bi = self.use_bi
-        self._publish()
-
-    def _publish(self):
-        """per-level views of every decision (what tests/cpu_chain.py and a host encoder read back)"""
-        T = self.torch
-        cost_uni = self.frac_res.view(T.int64)[:, 1]
-        for lvl in self.levels:
-            pb, n = lvl["pb"], lvl["npu"]
-            sl2, sl = slice(2 * pb, 2 * pb + 2 * n), slice(pb, pb + n)
-            lvl["out"] = dict(mvq_x=self.mvq[sl2, 0], mvq_y=self.mvq[sl2, 1], cost_uni=cost_uni[sl2], rl=self.refine[sl], bi_x=self.bi_mv[sl, 0],
-                              bi_y=self.bi_mv[sl, 1], cost_bi=self.cost_bi[sl], use_bi=self.use_bi[sl])
-
-    def run(self, org_ptr, dpb_ptr, timing=False):
-        """timing=True (or no side streams / VTM_AMD_OVERLAP=0): stage-major order on one stream with an event after every stage;
-        otherwise the overlapped level-major order."""
-        T, ctx, NP = self.torch, self.ctx, self.NP
-        if not timing and self.fused_tu and self.side_streams and os.environ.get("VTM_AMD_OVERLAP", "1") != "0":
-            self._marks = None
-            return self._run_overlapped(org_ptr, dpb_ptr)
-        self._marks = [] if timing else None
-        self._mark("start")
-        # (1) integer ME, coarse to fine: children start from / predict with the parent's vector
-        for i, lvl in enumerate(self.levels):
-            if lvl["parent"] is not None:
-                ctx.frame_child_start(lvl["jobs"].data_ptr(), lvl["n"], lvl["parent32"].data_ptr(), self.levels[i - 1]["res"].data_ptr())
-            ctx.tz_search_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["jobs"].data_ptr(), lvl["n"], lvl["res"].data_ptr())
-        self._mark("tz")
-
-        # (2) fractional ME per (PU, list)
-        fr, ft = self.frac, self.frame_tabs
-        ctx.frame_frac_jobs(fr.ptr, self.tz_jobs_all.data_ptr(), self.tz_res_all.data_ptr(), 2 * NP)
-        self._mark("glue")
-        self._per_level(lambda l, pb, n, s: ctx.frac_search_batch(org_ptr, dpb_ptr, fr.ptr + 2 * pb * FRAC_DT.itemsize, 2 * n, s, s,
-                                                                  self.frac_res.data_ptr() + 2 * pb * 16, uniform_square=True))
-        self._mark("frac")
-
-        # (3) bi-pred refinement of the list with the larger uni cost (FASTINTERSEARCH_MODE1: one iteration, :2544-2556):
-        #     prediction of the other list fused with 2*org - pred, +-4 exhaustive search, fractional search on the new target
-        po, fu, fb = self.pred_other, self.full, self.frac_bi
-        ctx.frame_stage(ft, 0)
-        self._mark("glue")
-        self._per_level(lambda l, pb, n, s: ctx.motion_compensation_batch(org_ptr, dpb_ptr, None, self.buf["org_bi"].data_ptr(),
-                                                                          po.ptr + pb * PRED_DT.itemsize, n, s, s))
-        self._mark("mc")
-        self._per_level(lambda l, pb, n, s: ctx.full_search_batch(l["pic_full"], self.buf["org_bi"].data_ptr(), dpb_ptr, fu.ptr + pb * FULL_DT.itemsize, n,
-                                                                  self.full_res.data_ptr() + pb * 32, square=s if s <= 64 else 0))
-        self._mark("full")
-        ctx.frame_stage(ft, 1)
-        self._mark("glue")
-        self._per_level(lambda l, pb, n, s: ctx.frac_search_batch(self.buf["org_bi"].data_ptr(), dpb_ptr, fb.ptr + pb * FRAC_DT.itemsize, n, s, s,
-                                                                  self.frac_bi_res.data_ptr() + pb * 16, uniform_square=True))
-        self._mark("frac")
-
-        # (4) final prediction and residual: bi-prediction (addAvg of the two 14-bit predictions) when cheaper, else the best uni list
-        pf = self.pred_final
-        ctx.frame_stage(ft, 2)
-        self._use_bi = self.use_bi
-        self._mark("glue")
-        self._per_level(lambda l, pb, n, s: ctx.motion_compensation_batch(org_ptr, dpb_ptr, self.buf["pred"].data_ptr(), self.buf["resi"].data_ptr(),
-                                                                          pf.ptr + pb * PRED_DT.itemsize, n, s, s))
-        self._mark("mc")
-        # (5) residual coding per TU and transform candidate
-        for lvl in self.levels:
-            nt, ts = lvl["ntu"] * lvl["nc"], lvl["ts"]
-            if self.fused_tu:
-                # levels go to the host for the CABAC estimate in the real encoder; the bench keeps them in HBM
-                ctx.tu_chain_batch(self.buf["resi"].data_ptr(), self.tu.ptr + lvl["tb"] * TU_DT.itemsize, nt, ts, ts,
-                                   self.tu_res.data_ptr() + lvl["tb"] * 16, self.qcoef.data_ptr() + 4 * lvl["qoff"], None, uniform=True)
-            else:
-                ctx.xT_batch(self.buf["resi"].data_ptr(), self.coef.data_ptr(), lvl["xt"].ptr, nt, ts, ts, lvl["sum_abs"].data_ptr())
-                ctx.quant_batch(self.coef.data_ptr(), self.qcoef.data_ptr(), None, lvl["quant"].ptr, nt, lvl["abs_sum"].data_ptr())
-                ctx.dequant_batch(self.qcoef.data_ptr(), self.dqcoef.data_ptr(), lvl["quant"].ptr, nt)
-                ctx.xIT_batch(self.dqcoef.data_ptr(), self.rec_resi.data_ptr(), lvl["xit"].ptr, nt, ts, ts)
-                ctx.dist_batch(self.buf["resi"].data_ptr(), self.rec_resi.data_ptr(), lvl["sse"].ptr, nt, lvl["sse_out"].data_ptr())
-        self._mark("tu")
-        self._publish()
-
-
-# ======================================================================================================================
-# Level-order InterSearch::predInterSearch (InterSearch.cpp:2245-3065, translational part) + residual coding of one picture
-# ======================================================================================================================
-from .lib import MAX_REF, MeCfg, MeJob, MeOut, PisLevel, PisPu, PisRow   # noqa: E402
-
-ME_DT, MEOUT_DT, ROW_DT, PU_DT = np.dtype(MeJob), np.dtype(MeOut), np.dtype(PisRow), np.dtype(PisPu)
-# (typeHor, typeVer) per tu.mtsIdx (TrQuant::getTrTypes): 0 DCT2/DCT2, 1 transform skip, 2..5 the DST7/DCT8 pairs
 TRSKIP = 3
 MTS_IDX_TYPES = {0: (0, 0), 1: (TRSKIP, TRSKIP), 2: (2, 2), 3: (1, 2), 4: (2, 1), 5: (1, 1)}
 
