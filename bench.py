@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--partition", choices=["qt", "btt"], default="qt", help="qt: the five quadtree levels 128 .. 8 (the headline workload); btt: a binary / ternary "
                     "split mix -- 128x128, 64x64, 64x32, 32x32, 32x16, 16x16, 16x8, 8x8 -- through the rectangular fast paths")
     ap.add_argument("--luma-only", action="store_true", help="no chroma planes and no BDOF in the final prediction (the round-2 mid-round operating point)")
+    ap.add_argument("--inflight", type=int, default=1, help="pictures in flight: step k + 1 starts on a second stream set while step k's tail still runs (each has its own tables)")
     ap.add_argument("--serial", action="store_true", help="one stream, no overlap of the levels' chains: clean per-kernel times for profiling")
     return ap.parse_args()
 
@@ -196,8 +197,9 @@ def main():
     lam, qp = 8.0, a.qp
     bands = pipeline.ctu_bands(W, H, world, unit=a.shard)
     ctu_filter = pipeline.band_filter(W, bands[rank]) if world > 1 else None
+    fme_sizes = (128, 64, 32, 16, 8) if a.partition == "qt" else (128, (64, 64), (64, 32), (32, 32), (32, 16), (16, 16), (16, 8), (8, 8))
     fme = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, ctu_filter=ctu_filter, transform_skip=a.transform_skip, pocs=poc_arg, chroma=ch_dev,
-                       sizes=(128, 64, 32, 16, 8) if a.partition == "qt" else (128, (64, 64), (64, 32), (32, 32), (32, 16), (16, 16), (16, 8), (8, 8)))
+                       sizes=fme_sizes)
 
     # N > 1: the reconstructed reference planes go from rank 0 to every GPU inside every step (RCCL broadcast over xGMI; bytes view: int16 is
     # not a collective dtype), double-buffered: the planes of step k + 1 travel while step k computes; the ranks' result records go back to rank 0
@@ -207,13 +209,28 @@ def main():
     res_t = fme.result_tensors()
     gath = ResultGather(sum(t.numel() for t in res_t), dev, dst=0) if use_dist else None
 
+    # --inflight 2: a second set of tables and streams; consecutive steps alternate between the two, so the latency-bound head of picture k + 1
+    # (the 128x128 level's searches) runs under the tail of picture k.  Every picture is still computed completely inside the timed region.
+    fmes, lanes, turn = [fme], [torch.cuda.current_stream()], [0]
+    for _ in range(1, max(1, a.inflight) if not use_dist else 1):
+        fmes.append(FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, ctu_filter=ctu_filter, transform_skip=a.transform_skip, pocs=poc_arg, chroma=ch_dev,
+                                 sizes=fme_sizes))
+        lanes.append(torch.cuda.Stream(device=dev))
+
     def step():
         if xchg is not None:
             planes = xchg.next()
             fme.run(cur.data_ptr(), planes.data_ptr())
             gath.submit(res_t)
-        else:
+        elif len(fmes) == 1:
             fme.run(cur.data_ptr(), dpb.data_ptr())
+        else:
+            k = turn[0] % len(fmes)
+            turn[0] += 1
+            with torch.cuda.stream(lanes[k]):
+                ctx.set_stream(lanes[k].cuda_stream)
+                fmes[k].run(cur.data_ptr(), dpb.data_ptr())
+            ctx.set_stream(lanes[0].cuda_stream)
 
     def drain():
         if xchg is not None:
