@@ -33,8 +33,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SIMDS, CLOCK_HZ = 1024, 2.4e9          # 256 CUs x 4 SIMDs, peak shader clock (MI355X_MICROARCH.md)
+SALU_CYCLES = 4.03   # measured: cycles per scalar instruction per SIMD (profiles/r02_valu_issue.jsonl, s_add_u32, 1 .. 8 waves)
 KERNELS = ("tz_search_kernel", "tz_raster_cols_kernel", "frac_search_sq_kernel", "full_search_sq_kernel", "full_search_kernel", "motion_comp_kernel", "tu_chain_uni_kernel",
-           "dist_uniform_kernel", "tu_ts_kernel", "bdof_kernel")
+           "dist_uniform_kernel", "tu_ts_kernel", "bdof_kernel", "tu_chain_lane_kernel")
 
 
 def parse():
@@ -312,6 +313,7 @@ def main():
             cpi = next((v["cycles_per_valu_inst"] for k, v in mix.items() if isinstance(v, dict) and k.startswith(name)), None)
             lps = (lambda v: v.get("launches_per_step", 1)) if in_step else (lambda v: 1)
             insts = sum(v.get("SQ_INSTS_VALU", 0) * lps(v) for k, v in pmc_i.items() if k.startswith(name)) or None
+            salu = sum(v.get("SQ_INSTS_SALU", 0) * lps(v) for k, v in pmc_i.items() if k.startswith(name)) or None
             traffic = sum((2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 * lps(v) for k, v in pmc_b.items() if k.startswith(name)) or None
             r = {"bound": "valu_issue", "kernel": name, "unit": "G wave-instructions/s", "ms_per_step": ms, "launches_per_step": launches,
                  "ms_per_launch": ms / max(1, launches), "insts": insts, "cycles_per_inst": cpi, "traffic": (traffic / launches) if traffic else None}
@@ -322,6 +324,11 @@ def main():
                 r["frac"] = r["achieved"] / r["peak"]
             else:
                 r["achieved"], r["frac"] = None, None
+            if salu and world == 1 and (W, H) == (3840, 2160):
+                # the scalar port of a SIMD issues one instruction per 4.03 cycles whatever the number of waves, beside the vector port (s_add_u32 rows and the
+                # vector + scalar pair row of profiles/r02_valu_issue.jsonl): a kernel is bounded by the busier of the two
+                r["salu_insts"] = salu
+                r["salu_frac"] = salu * SALU_CYCLES / (SIMDS * CLOCK_HZ * ms * 1e-3)
             if traffic:
                 r["hbm_GBps"] = traffic / (ms * 1e-3) / 1e9
                 r["hbm_frac"] = r["hbm_GBps"] / 8000.0
