@@ -289,6 +289,8 @@ __device__ __forceinline__ void job_sync()
   }
 }
 
+constexpr int TZ_UNR = 2;   // passes whose reference loads are issued together when the block sits in registers
+
 // Evaluates `total` candidates, 64 / lpc at a time, and returns the lexicographic (cost, index) minimum (wave-uniform).
 // RASTER: candidate k = grid point (k % nx, k / nx) of the raster; otherwise pts[k].
 template<bool RASTER, int WPJ>
@@ -300,7 +302,40 @@ __device__ __forceinline__ void eval_candidates( const MeJob &j, const int4 *pts
   const int grp = lane >> j.lpcShift, sub = lane & ( lpc - 1 );
   bestCost = ~0ull;
   bestIdx  = 0xffffffffu;
-  for( int base = co.wave * cpw; base < total; base += cpw * WPJ )
+  int first = co.wave * cpw;
+  if( !RASTER && WPJ == 1 && j.orgResident && j.seg == 8 && lpc == 64 )   // (32x32 blocks: single-wave jobs, one candidate per pass)
+  {
+    // block in registers (one 16-byte segment per lane): a pass is ONE reference load per lane, so the loads of TZ_UNR passes go out together --
+    // a 16-point round of a 32x32 block (one candidate per pass) otherwise waits out 16 vector-memory latencies in a row
+    for( ; first < total; first += TZ_UNR * cpw * WPJ )
+    {
+      Pel8 b[TZ_UNR];
+      int  xs[TZ_UNR], ys[TZ_UNR];
+#pragma unroll
+      for( int q = 0; q < TZ_UNR; q++ )
+      {
+        const int  k = first + q * cpw * WPJ + grp;
+        const int4 p = pts[min( k, total - 1 )];
+        xs[q] = p.x; ys[q] = p.y;
+        b[q]  = *reinterpret_cast<const Pel8 *>( j.ref + ( long ) p.y * j.refStride + p.x + j.resOff );
+      }
+#pragma unroll
+      for( int q = 0; q < TZ_UNR; q++ )
+      {
+        const int k = first + q * cpw * WPJ + grp;
+        unsigned  s = 0;
+#pragma unroll
+        for( int i = 0; i < 4; i++ ) s = sad2( j.orgSeg[i], b[q].v[i] ^ j.bias, s );
+        s = group_sum( s, lpc );
+        if( k < total )
+        {
+          const unsigned long long c = ( ( unsigned long long ) s << j.ss ) + mv_cost( j, xs[q], ys[q] );
+          if( c < bestCost ) { bestCost = c; bestIdx = ( unsigned ) k; }
+        }
+      }
+    }
+  }
+  for( int base = first; base < total; base += cpw * WPJ )
   {
     const int k = base + grp;
     unsigned  s = 0;
