@@ -8,7 +8,8 @@
              for the square sizes                                                                       (vtmhip_xT_batch_dev, vtmhip_tu_chain_batch_dev)
   BDOF / GEO bi-predicted 16x16 and 64x64 luma PUs with and without BDOF; 32x32 GEO blends             (vtmhip_bdof_batch_dev, vtmhip_weightedGeoBlk_batch_dev)
 
-Prints one JSON object per line: algorithmic bytes (SURVEY.md 8d per-unit figures) / time against the 8 TB/s HBM peak.
+Prints one JSON object per line: units per second and the algorithmic GB/s (SURVEY.md 8d per-unit bytes / time -- a descriptive figure: the data is re-used
+out of LDS / L1 / L2, so it is NOT an HBM utilisation; the kernels are bounded by instruction issue).
 usage (GPU box): python3 scripts/microbench.py [--width 3840 --height 2160] > gpurun_out/microbench.json"""
 import argparse
 import ctypes as C
@@ -24,7 +25,6 @@ from vtm_amd import synth   # noqa: E402
 from vtm_amd.device import Context   # noqa: E402
 from vtm_amd.lib import DistJob, DmvrJob, FracJob, FullJob, GeoBlendJob, IfJob, PicParams, PredJob, TrJob, TuJob   # noqa: E402
 
-PEAK = 8000.0   # GB/s
 
 
 def timed(ctx, fn, reps=10):
@@ -39,7 +39,7 @@ def timed(ctx, fn, reps=10):
 
 def emit(name, units, unit_name, alg_bytes, ms, **kw):
     print(json.dumps(dict(kernel=name, units=units, unit=unit_name, ms=round(ms, 4), G_units_per_s=round(units / ms / 1e6, 3),
-                          alg_GBps=round(alg_bytes / ms / 1e6, 1), frac_of_hbm_peak=round(alg_bytes / ms / 1e6 / PEAK, 3), **kw)), flush=True)
+                          alg_GBps=round(alg_bytes / ms / 1e6, 1), **kw)), flush=True)
 
 
 def main():
