@@ -333,16 +333,27 @@ struct StoreLds
 struct Epilogue
 {
   const int16_t *org; int orgStride; int16_t *pred; int predStride; int16_t *out; int outStride; int mode;
+  unsigned *sad;   // mode 3: this lane's running SAD of the prediction against the original (the AMVP template cost: nothing is stored)
   __device__ __forceinline__ void operator()( int y, int x, int16_t v ) const
   {
     if( pred ) pred[( long ) y * predStride + x] = v;
     if( mode == 1 ) out[( long ) y * outStride + x] = ( int16_t ) ( org[( long ) y * orgStride + x] - v );
     else if( mode == 2 ) out[( long ) y * outStride + x] = ( int16_t ) ( 2 * org[( long ) y * orgStride + x] - v );
+    else if( mode == 3 ) *sad += ( unsigned ) abs( ( int ) org[( long ) y * orgStride + x] - ( int ) v );
   }
   __device__ __forceinline__ void vec( int y, int x0, const int v[8] ) const
   {
     if( pred ) store8g( pred + ( long ) y * predStride + x0, v );
-    if( mode )
+    if( mode == 3 )
+    {
+      int o[8];
+      load8g( org + ( long ) y * orgStride + x0, o );
+      unsigned t = 0;
+#pragma unroll
+      for( int k = 0; k < 8; k++ ) t += ( unsigned ) abs( o[k] - v[k] );
+      *sad += t;
+    }
+    else if( mode )
     {
       int o[8], r[8];
       load8g( org + ( long ) y * orgStride + x0, o );
@@ -375,9 +386,11 @@ struct AvgThen
 // never span waves, so the H -> V hand-over needs no more than the wave-level fence).
 template<int THREADS, int JPB>
 __global__ __launch_bounds__( THREADS * JPB ) void motion_comp_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase, int16_t *__restrict__ predBase,
-                                                                 int16_t *__restrict__ outBase, const vtmhip_pred_job *__restrict__ jobs, int n, int maxW, int maxH )
+                                                                 int16_t *__restrict__ outBase, const vtmhip_pred_job *__restrict__ jobs, int n, int maxW, int maxH,
+                                                                 unsigned long long *__restrict__ sadOut )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];
+  __shared__ unsigned sSad;   // THREADS == 256 with sadOut: the block's SAD
   const int             sub = JPB > 1 ? ( int ) threadIdx.x / THREADS : 0;
   int16_t              *tmp = lds + sub * ( ( maxW * ( maxH + 7 ) + maxW * maxH + 7 ) & ~7 );   // [(h+7)][w] H-pass intermediates (16-byte aligned per block)
   int16_t              *p0  = tmp + maxW * ( maxH + 7 );                                         // [h][w] list-0 prediction of a bi-predicted block (14-bit)
@@ -390,7 +403,10 @@ __global__ __launch_bounds__( THREADS * JPB ) void motion_comp_kernel( const int
   ep.org = orgBase ? orgBase + j.orgOff : nullptr; ep.orgStride = j.orgStride;
   ep.pred = predBase ? predBase + j.predOff : nullptr; ep.predStride = j.predStride;
   ep.out = outBase ? outBase + j.outOff : nullptr; ep.outStride = j.outStride;
-  ep.mode = ( outBase && orgBase ) ? j.epilogue : 0;
+  ep.mode = sadOut ? 3 : ( outBase && orgBase ) ? j.epilogue : 0;
+  unsigned sadAcc = 0;
+  ep.sad = &sadAcc;
+  if( THREADS == 256 && sadOut ) { if( threadIdx.x == 0 ) sSad = 0; __syncthreads(); }
   vtmhip_mc_job m;
   m.width = j.width; m.height = j.height; m.bitDepth = j.bitDepth; m.useAltHpelIf = j.useAltHpelIf; m.chroma = j.chroma;
   m.dstOff = 0; m.dstStride = 0;
@@ -400,17 +416,31 @@ __global__ __launch_bounds__( THREADS * JPB ) void motion_comp_kernel( const int
     m.refOff = l ? j.refOff[1] : j.refOff[0]; m.refStride = l ? j.refStride[1] : j.refStride[0];   // (no dynamic indexing: keeps the job in registers)
     m.mvHor = l ? j.mv[1][0] : j.mv[0][0]; m.mvVer = l ? j.mv[1][1] : j.mv[0][1]; m.bi = 0;
     mc_any<THREADS>( m, refBase, tmp, lane, ep );
-    return;
   }
-  m.bi = 1;
-  m.refOff = j.refOff[0]; m.refStride = j.refStride[0]; m.mvHor = j.mv[0][0]; m.mvVer = j.mv[0][1];
-  const StoreLds s0{ p0, j.width };
-  mc_any<THREADS>( m, refBase, tmp, lane, s0 );
-  block_sync<THREADS>();   // p0 complete, tmp free again
-  const int headRoom = max( 2, 14 - ( int ) j.bitDepth ), shift = headRoom + 1;
-  const AvgThen av{ p0, j.width, shift, ( 1 << ( shift - 1 ) ) + 2 * 8192, ( 1 << j.bitDepth ) - 1, ep };
-  m.refOff = j.refOff[1]; m.refStride = j.refStride[1]; m.mvHor = j.mv[1][0]; m.mvVer = j.mv[1][1];
-  mc_any<THREADS>( m, refBase, tmp, lane, av );
+  else
+  {
+    m.bi = 1;
+    m.refOff = j.refOff[0]; m.refStride = j.refStride[0]; m.mvHor = j.mv[0][0]; m.mvVer = j.mv[0][1];
+    const StoreLds s0{ p0, j.width };
+    mc_any<THREADS>( m, refBase, tmp, lane, s0 );
+    block_sync<THREADS>();   // p0 complete, tmp free again
+    const int headRoom = max( 2, 14 - ( int ) j.bitDepth ), shift = headRoom + 1;
+    const AvgThen av{ p0, j.width, shift, ( 1 << ( shift - 1 ) ) + 2 * 8192, ( 1 << j.bitDepth ) - 1, ep };
+    m.refOff = j.refOff[1]; m.refStride = j.refStride[1]; m.mvHor = j.mv[1][0]; m.mvVer = j.mv[1][1];
+    mc_any<THREADS>( m, refBase, tmp, lane, av );
+  }
+  if( sadOut )   // SAD of the whole block: over the block's lanes (a sub-wave group, a wave, or the workgroup)
+  {
+#pragma unroll
+    for( int o = ( THREADS < 64 ? THREADS : 64 ) >> 1; o > 0; o >>= 1 ) sadAcc += __shfl_xor( sadAcc, o, 64 );
+    if( THREADS == 256 )
+    {
+      if( ( threadIdx.x & 63 ) == 0 ) atomicAdd( &sSad, sadAcc );
+      __syncthreads();
+      if( threadIdx.x == 0 ) sadOut[jobIdx] = sSad;
+    }
+    else if( lane == 0 ) sadOut[jobIdx] = sadAcc;
+  }
 }
 
 __global__ __launch_bounds__( 256 ) void pelop_kernel( const int16_t *__restrict__ aBase, const int16_t *__restrict__ bBase, int16_t *__restrict__ dstBase,
@@ -918,6 +948,31 @@ __global__ __launch_bounds__( 256 ) void geo_blend_kernel( const int16_t *__rest
 
 }   // namespace
 
+// motionCompensation of a job table; sadOut != nullptr: nothing is stored, the SAD of every prediction against its original block goes to sadOut[job]
+// (xEstimateMvPredAMVP's template cost: prediction and distortion in one pass)
+int vtmhip_internal_mc_launch( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, int16_t *d_predBase, int16_t *d_outBase, const vtmhip_pred_job *d_jobs,
+                               int n, int maxWidth, int maxHeight, unsigned long long *d_sadOut )
+{
+  const size_t lds = ( ( ( size_t ) maxWidth * ( maxHeight + 7 ) + ( size_t ) maxWidth * maxHeight + 7 ) & ~( size_t ) 7 ) * sizeof( int16_t );
+  // a quarter wave per block up to 64 samples, half a wave up to 16x16 samples, four waves above (the samples of a block are independent; only the H -> V hand-over syncs)
+  VTMHIP_TIME_KERNEL( ctx, "motion_comp_kernel" );
+  if( maxWidth * maxHeight > 256 )
+  {
+    if( lds > 64 * 1024 )
+      VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( motion_comp_kernel<256, 1> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
+    hipLaunchKernelGGL( ( motion_comp_kernel<256, 1> ), dim3( n ), dim3( 256 ), lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth, maxHeight,
+                        d_sadOut );
+  }
+  else if( maxWidth * maxHeight > 64 )
+    hipLaunchKernelGGL( ( motion_comp_kernel<32, 2> ), dim3( ( n + 1 ) / 2 ), dim3( 64 ), 2 * lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth,
+                        maxHeight, d_sadOut );
+  else
+    hipLaunchKernelGGL( ( motion_comp_kernel<16, 4> ), dim3( ( n + 3 ) / 4 ), dim3( 64 ), 4 * lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth,
+                        maxHeight, d_sadOut );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
 extern "C"
 {
 
@@ -949,23 +1004,7 @@ int vtmhip_motion_compensation_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgB
   VTMHIP_REQUIRE( ctx, d_refBase && d_jobs && ( d_predBase || d_outBase ), "null pointer" );
   VTMHIP_REQUIRE( ctx, !d_outBase || d_orgBase, "an epilogue output needs the original plane" );
   VTMHIP_REQUIRE( ctx, maxWidth >= 2 && maxWidth <= 128 && maxHeight >= 2 && maxHeight <= 128, "maxWidth / maxHeight" );
-  const size_t lds = ( ( ( size_t ) maxWidth * ( maxHeight + 7 ) + ( size_t ) maxWidth * maxHeight + 7 ) & ~( size_t ) 7 ) * sizeof( int16_t );
-  // a quarter wave per block up to 64 samples, one wave up to 16x16 samples, four waves above (the samples of a block are independent; only the H -> V hand-over syncs)
-  VTMHIP_TIME_KERNEL( ctx, "motion_comp_kernel" );
-  if( maxWidth * maxHeight > 256 )
-  {
-    if( lds > 64 * 1024 )
-      VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( motion_comp_kernel<256, 1> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
-    hipLaunchKernelGGL( ( motion_comp_kernel<256, 1> ), dim3( n ), dim3( 256 ), lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth, maxHeight );
-  }
-  else if( maxWidth * maxHeight > 64 )
-    hipLaunchKernelGGL( ( motion_comp_kernel<32, 2> ), dim3( ( n + 1 ) / 2 ), dim3( 64 ), 2 * lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth,
-                        maxHeight );
-  else
-    hipLaunchKernelGGL( ( motion_comp_kernel<16, 4> ), dim3( ( n + 3 ) / 4 ), dim3( 64 ), 4 * lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth,
-                        maxHeight );
-  VTMHIP_LAUNCHED( ctx );
-  return VTMHIP_OK;
+  return vtmhip_internal_mc_launch( ctx, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth, maxHeight, nullptr );
 }
 
 int vtmhip_remove_high_freq_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_predBase, int16_t *d_dstBase,
