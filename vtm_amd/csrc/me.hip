@@ -97,8 +97,12 @@ struct __attribute__( ( packed, aligned( 2 ) ) ) Pel4 { unsigned v[2]; };
 __device__ __forceinline__ unsigned sad2( unsigned a, unsigned b, unsigned acc ) { return __builtin_amdgcn_sad_u16( a, b, acc ); }
 
 // partial SAD of candidate (cx, cy) over the items sub, sub + lpc, ... (RdCost.cpp:493-528 arithmetic)
-template<int WPJ>
-__device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy, int sub )
+// The sign-bias XOR (samples that may be negative: the bi-prediction target 2 org - pred) is needed on a minority of jobs; unsigned jobs -- every uni
+// search -- take the instantiation without it (one vector instruction less per v_sad_u16 in the inner loops)
+template<bool SGN> __device__ __forceinline__ unsigned bx( unsigned v, unsigned bias ) { return SGN ? v ^ bias : v; }
+
+template<int WPJ, bool SGN>
+__device__ __forceinline__ unsigned sad_partial_impl( const MeJob &j, int cx, int cy, int sub )
 {
   const int16_t *c0 = j.ref + ( long ) cy * j.refStride + cx;
   const long     os = ( long ) j.orgStride << j.ss, cs = ( long ) j.refStride << j.ss;
@@ -109,13 +113,13 @@ __device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy,
     {
       const Pel8 b = *reinterpret_cast<const Pel8 *>( c0 + j.resOff );
 #pragma unroll
-      for( int k = 0; k < 4; k++ ) s = sad2( j.orgSeg[k], b.v[k] ^ j.bias, s );
+      for( int k = 0; k < 4; k++ ) s = sad2( j.orgSeg[k], bx<SGN>( b.v[k], j.bias ), s );
     }
     else
     {
       const Pel4 b = *reinterpret_cast<const Pel4 *>( c0 + j.resOff );
 #pragma unroll
-      for( int k = 0; k < 2; k++ ) s = sad2( j.orgSeg[k], b.v[k] ^ j.bias, s );
+      for( int k = 0; k < 2; k++ ) s = sad2( j.orgSeg[k], bx<SGN>( b.v[k], j.bias ), s );
     }
     return s;
   }
@@ -139,10 +143,10 @@ __device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy,
         const Pel8  b2 = *reinterpret_cast<const Pel8 *>( pr + 2 * dr ), b3 = *reinterpret_cast<const Pel8 *>( pr + 3 * dr );
         const uint4 a0 = *reinterpret_cast<const uint4 *>( po ), a1 = *reinterpret_cast<const uint4 *>( po + 512 );
         const uint4 a2 = *reinterpret_cast<const uint4 *>( po + 1024 ), a3 = *reinterpret_cast<const uint4 *>( po + 1536 );
-        s = sad2( a0.x, b0.v[0] ^ j.bias, s ); s = sad2( a0.y, b0.v[1] ^ j.bias, s ); s = sad2( a0.z, b0.v[2] ^ j.bias, s ); s = sad2( a0.w, b0.v[3] ^ j.bias, s );
-        s = sad2( a1.x, b1.v[0] ^ j.bias, s ); s = sad2( a1.y, b1.v[1] ^ j.bias, s ); s = sad2( a1.z, b1.v[2] ^ j.bias, s ); s = sad2( a1.w, b1.v[3] ^ j.bias, s );
-        s = sad2( a2.x, b2.v[0] ^ j.bias, s ); s = sad2( a2.y, b2.v[1] ^ j.bias, s ); s = sad2( a2.z, b2.v[2] ^ j.bias, s ); s = sad2( a2.w, b2.v[3] ^ j.bias, s );
-        s = sad2( a3.x, b3.v[0] ^ j.bias, s ); s = sad2( a3.y, b3.v[1] ^ j.bias, s ); s = sad2( a3.z, b3.v[2] ^ j.bias, s ); s = sad2( a3.w, b3.v[3] ^ j.bias, s );
+        s = sad2( a0.x, bx<SGN>( b0.v[0], j.bias ), s ); s = sad2( a0.y, bx<SGN>( b0.v[1], j.bias ), s ); s = sad2( a0.z, bx<SGN>( b0.v[2], j.bias ), s ); s = sad2( a0.w, bx<SGN>( b0.v[3], j.bias ), s );
+        s = sad2( a1.x, bx<SGN>( b1.v[0], j.bias ), s ); s = sad2( a1.y, bx<SGN>( b1.v[1], j.bias ), s ); s = sad2( a1.z, bx<SGN>( b1.v[2], j.bias ), s ); s = sad2( a1.w, bx<SGN>( b1.v[3], j.bias ), s );
+        s = sad2( a2.x, bx<SGN>( b2.v[0], j.bias ), s ); s = sad2( a2.y, bx<SGN>( b2.v[1], j.bias ), s ); s = sad2( a2.z, bx<SGN>( b2.v[2], j.bias ), s ); s = sad2( a2.w, bx<SGN>( b2.v[3], j.bias ), s );
+        s = sad2( a3.x, bx<SGN>( b3.v[0], j.bias ), s ); s = sad2( a3.y, bx<SGN>( b3.v[1], j.bias ), s ); s = sad2( a3.z, bx<SGN>( b3.v[2], j.bias ), s ); s = sad2( a3.w, bx<SGN>( b3.v[3], j.bias ), s );
         pr += 4 * dr;
         po += 2048;
       }
@@ -150,8 +154,8 @@ __device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy,
       {
         const uint4 a = *reinterpret_cast<const uint4 *>( po );
         const Pel8  b = *reinterpret_cast<const Pel8 *>( pr );
-        s = sad2( a.x, b.v[0] ^ j.bias, s ); s = sad2( a.y, b.v[1] ^ j.bias, s );
-        s = sad2( a.z, b.v[2] ^ j.bias, s ); s = sad2( a.w, b.v[3] ^ j.bias, s );
+        s = sad2( a.x, bx<SGN>( b.v[0], j.bias ), s ); s = sad2( a.y, bx<SGN>( b.v[1], j.bias ), s );
+        s = sad2( a.z, bx<SGN>( b.v[2], j.bias ), s ); s = sad2( a.w, bx<SGN>( b.v[3], j.bias ), s );
         pr += dr;
         po += 512;
       }
@@ -162,8 +166,8 @@ __device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy,
       const int   r = j.sprShift >= 0 ? it >> j.sprShift : it / j.segsPerRow, x = ( it - r * j.segsPerRow ) << 3;
       const uint4 a = *reinterpret_cast<const uint4 *>( j.orgLds + ( it << 3 ) );
       const Pel8  b = *reinterpret_cast<const Pel8 *>( c0 + r * cs + x );
-      s = sad2( a.x, b.v[0] ^ j.bias, s ); s = sad2( a.y, b.v[1] ^ j.bias, s );
-      s = sad2( a.z, b.v[2] ^ j.bias, s ); s = sad2( a.w, b.v[3] ^ j.bias, s );
+      s = sad2( a.x, bx<SGN>( b.v[0], j.bias ), s ); s = sad2( a.y, bx<SGN>( b.v[1], j.bias ), s );
+      s = sad2( a.z, bx<SGN>( b.v[2], j.bias ), s ); s = sad2( a.w, bx<SGN>( b.v[3], j.bias ), s );
     }
   }
   else if( j.seg == 8 )
@@ -174,7 +178,7 @@ __device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy,
       const Pel8 a = *reinterpret_cast<const Pel8 *>( j.org + r * os + x );
       const Pel8 b = *reinterpret_cast<const Pel8 *>( c0 + r * cs + x );
 #pragma unroll
-      for( int k = 0; k < 4; k++ ) s = sad2( a.v[k] ^ j.bias, b.v[k] ^ j.bias, s );
+      for( int k = 0; k < 4; k++ ) s = sad2( bx<SGN>( a.v[k], j.bias ), bx<SGN>( b.v[k], j.bias ), s );
     }
   }
   else
@@ -185,10 +189,16 @@ __device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy,
       const Pel4 a = *reinterpret_cast<const Pel4 *>( j.org + r * os + x );
       const Pel4 b = *reinterpret_cast<const Pel4 *>( c0 + r * cs + x );
 #pragma unroll
-      for( int k = 0; k < 2; k++ ) s = sad2( a.v[k] ^ j.bias, b.v[k] ^ j.bias, s );
+      for( int k = 0; k < 2; k++ ) s = sad2( bx<SGN>( a.v[k], j.bias ), bx<SGN>( b.v[k], j.bias ), s );
     }
   }
   return s;
+}
+
+template<int WPJ>
+__device__ __forceinline__ unsigned sad_partial( const MeJob &j, int cx, int cy, int sub )
+{
+  return j.bias ? sad_partial_impl<WPJ, true>( j, cx, cy, sub ) : sad_partial_impl<WPJ, false>( j, cx, cy, sub );
 }
 
 // Multi-wave jobs (large blocks): the original block -- read again for EVERY candidate -- is staged once in LDS, item-major
@@ -324,8 +334,16 @@ __device__ __forceinline__ void eval_candidates( const MeJob &j, const int4 *pts
       {
         const int k = first + q * cpw * WPJ + grp;
         unsigned  s = 0;
+        if( j.bias )
+        {
 #pragma unroll
-        for( int i = 0; i < 4; i++ ) s = sad2( j.orgSeg[i], b[q].v[i] ^ j.bias, s );
+          for( int i = 0; i < 4; i++ ) s = sad2( j.orgSeg[i], b[q].v[i] ^ j.bias, s );
+        }
+        else
+        {
+#pragma unroll
+          for( int i = 0; i < 4; i++ ) s = sad2( j.orgSeg[i], b[q].v[i], s );
+        }
         s = group_sum( s, lpc );
         if( k < total )
         {
