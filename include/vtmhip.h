@@ -750,12 +750,19 @@ typedef struct
   vtmhip_pred_job      *predFinalC;/* [2 * numPU] or NULL: the Cb jobs, then the Cr jobs (static fields by the host; mode / refOff / mv by the final stage) */
   const int64_t        *posC;      /* [numPU] (y / 2) * refStrideC + x / 2 */
   int64_t  refPlaneOffC[2][2][VTMHIP_MAX_REF];   /* [Cb / Cr][list][refIdx] sample offset of the chroma plane's (0,0) inside d_refBase */
+  /* affine uni stage (predAffineInterSearch's uni loop :4480-4660, 4-parameter model) for PUs of at least 16x16: one xAffineMotionEstimation job per
+   * (PU, list, refIdx) row, starting from / predicted by the row's translational result (the affine AMVP list needs the CU recursion: stand-in as for AMVP) */
+  vtmhip_affine_me_job *affJobs;   /* [(numRef[0] + numRef[1]) * numPU] or NULL; filled by stage 4 */
+  int32_t  affLowDelay;            /* m_pcEncCfg->getIntraPeriod() == -1 (refinement rounds) */
+  int32_t  affCheckLDC;            /* slice.getCheckLDC(): PROF's large-gradient rule */
 } vtmhip_pis_level;
 
 /* stage 0: AMVP candidates and entry bits of the uni rows (before vtmhip_xEstimateMvPredAMVP_batch_dev)
  * stage 1: after the uni searches: xCheckBestMVP per row, best reference per list; P slices: interDir and predFinal
  * stage 2: B slices: refined list, predOther (the other list's prediction, epilogue as the host set it), the bi rows
- * stage 3: after the bi searches: xCheckBestMVP, best bi row, decision, predFinal */
+ * stage 3: after the bi searches: xCheckBestMVP, best bi row, decision, predFinal
+ * stage 4: (affJobs != NULL) the affine uni jobs of every row: start vector and predictor = the row's translational result at all control points,
+ *          bits = the row's bits before the vector rate, hevcCost = the PU's best translational cost -> vtmhip_xAffineMotionEstimation_batch_dev */
 int vtmhip_pis_stage( vtmhip_ctx *ctx, const vtmhip_pis_level *lvl, int stage );
 
 #ifdef __cplusplus

@@ -84,7 +84,8 @@ def _tu_chain(L, R, r_tu, ts, mts, qp_per, qp_rem, bd):
     return (int(sse), int(np.abs(coef.astype(np.int64)).sum()), asum.value)
 
 
-def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam, qp_per, qp_rem, tu_cands, ref=None, bd=10, pocs=None, bdof=True, chroma=None):
+def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam, qp_per, qp_rem, tu_cands, ref=None, bd=10, pocs=None, bdof=True, chroma=None,
+           affine=False, low_delay=False):
     """refs / search_ranges as FrameHotPath takes them; cands_rows[list][refIdx] = the two AMVP candidates of that row ((h, v), (h, v)) as the
     device driver derived them from the parent level.  Returns every decision the device pipeline exposes."""
     L, R = ol.oracle(), ref
@@ -145,6 +146,28 @@ def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam,
         if inter_dir == 3:
             mv_final[rl], ref_final[rl] = mv_bi, ref_bi
     out["inter_dir"] = inter_dir
+    # ---- affine uni stage (predAffineInterSearch's uni loop, 4-parameter): xAffineMotionEstimation per (list, refIdx) from the translational result ----
+    if affine and min(w, h) >= 16:
+        hevc = min(best[0]["cost"], best[1]["cost"])
+        if is_b:
+            hevc = min(hevc, out["cost_bi"])
+        out["aff"] = {}
+        for l in (0, 1):
+            for r in range(nref[l]):
+                row = rows[(l, r)]
+                t = ol.AffineMeJob()
+                t.pred.ref = dpb_ptr + 2 * (refs[l][r][0] + y * rs + x)
+                t.pred.refStride, t.pred.w, t.pred.h, t.pred.puX, t.pred.puY, t.pred.picW, t.pred.picH, t.pred.ctuSize, t.pred.bitDepth = rs, w, h, x, y, W, H, 128, bd
+                t.pred.sixParam, t.pred.interDir, t.pred.profAllowed, t.pred.profNeedsLargeGrad, t.pred.profIsBi = 0, 1 + l, 1, int(not low_delay), 0
+                t.org, t.orgStride = org.ctypes.data, w
+                t.bi, t.imv, t.useSatd, t.useAffineType, t.amvrEncOpt, t.lowDelayRounds = 0, 0, 1, 1, 0, int(low_delay)
+                for c in range(3):
+                    t.mvPred[c][0], t.mvPred[c][1] = row["pred"]
+                    t.mv[c][0], t.mv[c][1] = row["mv"]
+                t.bits, t.motionLambda, t.hevcCost = mb[l] + _ref_idx_bits(nref[l], r) + 1, lam, hevc
+                res = ol.AffineMeResult()
+                (R.ref_affine_motion_estimation if R else L.vo_affine_motion_estimation)(C.byref(t), C.byref(res))
+                out["aff"][(l, r)] = (tuple((res.mv[c][0], res.mv[c][1]) for c in range(3)), res.bits, res.cost)
     # ---- final prediction and residual (motionCompensation; InterSearch.cpp:7260-7262) ----
     pred = np.zeros((h, w), np.int16)
     bio = False
@@ -255,6 +278,13 @@ def compare_with_device(snap_level, parent_level, nref, i, out):
         k = ci * ntu + i * q2 + tu
         got = (int(tr[k, 0]), int(tr[k, 1] & 0xFFFFFFFF), int((tr[k, 1] >> 32) & 0xFFFFFFFF))
         assert (sse, sa, asum) == got, ("tu", s, i, tu, ci, (sse, sa, asum), got)
+    if "aff" in out:
+        ao, aj = snap_level["aff_out"], snap_level["aff_jobs"]
+        for (l, r), (mv, bits, cost) in out["aff"].items():
+            row = ((nref[0] if l else 0) + r) * n + i
+            g = ao[row]
+            got = (tuple((int(g["mv"][c][0]), int(g["mv"][c][1])) for c in range(3)), int(g["bits"]), int(g["cost"]))
+            assert (mv, bits, cost) == got, ("affine", s, i, l, r, (mv, bits, cost), got, int(aj[row]["hevcCost"]))
     if "route" in snap_level:
         assert int(snap_level["route"][i]) == (1 if out["bio"] else 2), ("BDOF routing", s, i)
     if "tus_c" in out:

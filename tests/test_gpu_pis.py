@@ -54,7 +54,7 @@ def make_scene(torch, dev, W, H, pocs0, pocs1, cur_poc, hard=True, chroma=False)
     return y, dpb_np, refs, sr, torch.from_numpy(cur_all).to(dev), torch.from_numpy(dpb_np).to(dev), ch_dev, ch_cpu
 
 
-def check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, R, per_level=24, min_checked=60, pocs=None, chroma=None, stats=None):
+def check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, R, per_level=24, min_checked=60, pocs=None, chroma=None, stats=None, affine=False, low_delay=False):
     snaps = hp.snapshot()
     nref = hp.nref
     checked = 0
@@ -67,8 +67,11 @@ def check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, R, per_level=24, min_chec
         s, npu = lvl["size"], lvl["npu"]
         for i in range(0, npu, max(1, npu // per_level)):
             out = cpu_pis.run_pu(cur_np, dpb_np.ctypes.data, refs, sr, W, H, s, int(lvl["xs"][i]), int(lvl["ys"][i]), cpu_pis.cands_of(lvl, nref, i), lam,
-                                 (qp + 12) // 6, (qp + 12) % 6, lvl["cands"], ref=R, pocs=pocs, chroma=chroma)
+                                 (qp + 12) // 6, (qp + 12) % 6, lvl["cands"], ref=R, pocs=pocs, chroma=chroma, affine=affine, low_delay=low_delay)
             cpu_pis.compare_with_device(lvl, parent, nref, i, out)
+            if stats is not None and "aff" in out:
+                stats["aff"] = stats.get("aff", 0) + len(out["aff"])
+                stats["aff_moved"] = stats.get("aff_moved", 0) + sum(1 for (mv, _, _) in out["aff"].values() if len(set(mv)) > 1)
             dirs.add(out["inter_dir"])
             if stats is not None:
                 stats["bio"] = stats.get("bio", 0) + int(out["bio"])
@@ -159,6 +162,33 @@ def test_frame_hot_path_on_split_shapes(use_ref, name, sizes):
     stats = {}
     dirs = check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, ol.ref() if use_ref else None, per_level=12, min_checked=50, pocs=pocs, chroma=ch_cpu, stats=stats)
     assert 3 in dirs and stats["bio"] >= 3 and stats["chroma_nz"] >= 5, (dirs, stats)
+    ctx.close()
+
+
+@pytest.mark.parametrize("use_ref", [False, True])
+@pytest.mark.parametrize("name,pocs0,pocs1,cur,low_delay", [("ra_1+1", [0], [4], 2, False), ("ldp_2", [1, 0], [], 2, True)])
+def test_frame_hot_path_affine_uni_stage(use_ref, name, pocs0, pocs1, cur, low_delay):
+    """The affine uni stage of the driver: InterSearch::xAffineMotionEstimation (4-parameter, PROF, gradient iterations + control-point refinement) for every
+    (PU >= 16x16, list, refIdx) row, started from the row's translational result -- vector triple, bits and cost of every sampled row against the oracle and
+    against the reference's own member."""
+    torch = pytest.importorskip("torch")
+    from vtm_amd.device import Context
+    if use_ref and not ol.have_ref():
+        pytest.skip("oracle/_ref/libvtmref.so not present")
+    W, H = 256, 128
+    dev = torch.device("cuda", 0)
+    cur_np, dpb_np, refs, sr, cur_d, dpb = make_scene(torch, dev, W, H, pocs0, pocs1, cur, hard=False)
+    if not pocs1:
+        sr = ([64] * len(pocs0), [])
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    lam, qp = 8.0, 32
+    hp = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, sizes=(64, 32, (32, 16), 16), affine=True, low_delay=low_delay)
+    hp.run(cur_d.data_ptr(), dpb.data_ptr())
+    torch.cuda.synchronize()
+    stats = {}
+    check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, ol.ref() if use_ref else None, per_level=8, min_checked=24, stats=stats, affine=True, low_delay=low_delay)
+    assert stats["aff"] >= 40 and stats["aff_moved"] >= 3, stats      # rows compared, and rows whose model left pure translation
     ctx.close()
 
 

@@ -217,6 +217,34 @@ __global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
   L.pus[pu] = P;
 }
 
+// ---- affine uni jobs (stage 4) ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__( 256 ) void pis_affine_jobs_kernel( vtmhip_pis_level L )
+{
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  const int rows = ( L.numRef[0] + L.numRef[1] ) * L.numPU;
+  if( row >= rows ) return;
+  const int                  pu = row % L.numPU, list = row / L.numPU >= L.numRef[0] ? 1 : 0;
+  const vtmhip_me_job       &u = L.uniJobs[row];
+  const vtmhip_pis_row      &r = L.uniRows[row];
+  const vtmhip_pis_pu       &P = L.pus[pu];
+  vtmhip_affine_me_job       a;
+  a.orgOff = u.orgOff; a.refOff = u.refOff; a.otherPredOff = 0; a.predOff = 0;
+  a.orgStride = u.orgStride; a.refStride = u.refStride; a.otherPredStride = 0; a.predStride = 0;
+  a.puX = u.puX; a.puY = u.puY; a.width = u.width; a.height = u.height;
+  a.sixParam = 0; a.interDir = ( uint8_t ) ( 1 + list ); a.imv = 0; a.bi = 0; a.useSatd = 1; a.useAffineType = 1; a.amvrEncOpt = 0;
+  a.lowDelayRounds = ( uint8_t ) L.affLowDelay; a.profAllowed = 1; a.profNeedsLargeGrad = ( uint8_t ) !L.affCheckLDC; a.profIsBi = 0; a.pad0 = 0;
+  for( int c = 0; c < 3; c++ )
+  {
+    a.mvPred[c][0] = r.mvPredHor; a.mvPred[c][1] = r.mvPredVer;
+    a.mv[c][0] = r.mvHor; a.mv[c][1] = r.mvVer;
+  }
+  a.bits = u.bits; a.pad1 = 0; a.motionLambda = u.motionLambda;
+  unsigned long long hc = P.cost[0] < P.cost[1] ? P.cost[0] : P.cost[1];
+  if( L.numRef[1] > 0 && P.costBi < hc ) hc = P.costBi;
+  a.hevcCost = hc;
+  L.affJobs[row] = a;
+}
+
 // ---- merge-candidate SATD (EncCu::xCheckRDCostMerge2Nx2N, EncCu.cpp:2399-2440): the distortion job of every candidate prediction ----
 __global__ __launch_bounds__( 256 ) void merge_dist_jobs_kernel( const vtmhip_pred_job *__restrict__ plain, int nPlain, const vtmhip_pred_job *__restrict__ bdof, int nBdof,
                                                                 const vtmhip_dmvr_job *__restrict__ dmvr, int nDmvr, int useSatd, vtmhip_dist_job *__restrict__ out )
@@ -303,7 +331,7 @@ int vtmhip_merge_cand_satd_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *
 int vtmhip_pis_stage( vtmhip_ctx *ctx, const vtmhip_pis_level *lvl, int stage )
 {
   VTMHIP_CHECK_CTX( ctx );
-  VTMHIP_REQUIRE( ctx, lvl && stage >= 0 && stage <= 3, "level / stage" );
+  VTMHIP_REQUIRE( ctx, lvl && stage >= 0 && stage <= 4, "level / stage" );
   VTMHIP_REQUIRE( ctx, lvl->numPU >= 0 && lvl->numRef[0] >= 1 && lvl->numRef[0] <= VTMHIP_MAX_REF && lvl->numRef[1] >= 0 && lvl->numRef[1] <= VTMHIP_MAX_REF, "numPU / numRef" );
   if( lvl->numPU == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, lvl->uniJobs && lvl->uniOut && lvl->uniRows && lvl->pus && lvl->predFinal && lvl->pos, "null pointer in the level" );
@@ -312,6 +340,11 @@ int vtmhip_pis_stage( vtmhip_ctx *ctx, const vtmhip_pis_level *lvl, int stage )
   const dim3 perPU( ( lvl->numPU + 255 ) / 256 ), perRow( ( rows + 255 ) / 256 ), tpb( 256 );
   if( stage == 0 ) hipLaunchKernelGGL( pis_cands_kernel, perRow, tpb, 0, ctx->stream, *lvl );
   else if( stage == 1 ) hipLaunchKernelGGL( pis_uni_select_kernel, perPU, tpb, 0, ctx->stream, *lvl );
+  else if( stage == 4 )
+  {
+    VTMHIP_REQUIRE( ctx, lvl->affJobs, "stage 4 needs the affine job table" );
+    hipLaunchKernelGGL( pis_affine_jobs_kernel, perRow, tpb, 0, ctx->stream, *lvl );
+  }
   else
   {
     VTMHIP_REQUIRE( ctx, lvl->numRef[1] >= 1 && lvl->predOther && lvl->biJobs && lvl->biOut, "the bi stages need list 1 and the bi tables" );

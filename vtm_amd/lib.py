@@ -176,7 +176,8 @@ class PisLevel(C.Structure):
                 ("refPlaneOff", (C.c_int64 * MAX_REF) * 2), ("uniJobs", C.c_void_p), ("uniOut", C.c_void_p), ("uniRows", C.c_void_p), ("pus", C.c_void_p),
                 ("predOther", C.c_void_p), ("biJobs", C.c_void_p), ("biOut", C.c_void_p), ("predFinal", C.c_void_p), ("parentIdx", C.c_void_p),
                 ("parentRows", C.c_void_p), ("parentNumPU", C.c_int32), ("pad", C.c_int32), ("pos", C.c_void_p), ("bdofEnabled", C.c_int32), ("curPoc", C.c_int32),
-                ("refPoc", (C.c_int32 * MAX_REF) * 2), ("predFinalC", C.c_void_p), ("posC", C.c_void_p), ("refPlaneOffC", ((C.c_int64 * MAX_REF) * 2) * 2)]
+                ("refPoc", (C.c_int32 * MAX_REF) * 2), ("predFinalC", C.c_void_p), ("posC", C.c_void_p), ("refPlaneOffC", ((C.c_int64 * MAX_REF) * 2) * 2),
+                ("affJobs", C.c_void_p), ("affLowDelay", C.c_int32), ("affCheckLDC", C.c_int32)]
 
 
 class AffineMeJob(C.Structure):

@@ -83,7 +83,9 @@ def quadtree_levels(pic_w, pic_h, sizes=(128, 64, 32, 16, 8), row_filter=None, c
 # ======================================================================================================================
 # Level-order InterSearch::predInterSearch (InterSearch.cpp:2245-3065, translational part) + residual coding of one picture
 # ======================================================================================================================
-from .lib import MAX_REF, FracJob, FracResult, MeCfg, MeJob, MeOut, PisLevel, PisPu, PisRow, PredJob, TuJob   # noqa: E402
+from .lib import MAX_REF, AffineMeJob, AffineMeOut, FracJob, FracResult, MeCfg, MeJob, MeOut, PisLevel, PisPu, PisRow, PredJob, TuJob   # noqa: E402
+
+AFF_DT, AFFOUT_DT = np.dtype(AffineMeJob), np.dtype(AffineMeOut)
 
 FRAC_DT, FRACRES_DT = np.dtype(FracJob), np.dtype(FracResult)
 TU_DT = np.dtype(TuJob)
@@ -170,10 +172,12 @@ class FrameHotPath:
     pocs: (current POC, [list-0 POCs], [list-1 POCs]) -- enables BDOF in the final prediction of bi-predicted PUs where xPredInterBi applies it.
     chroma: dict(org_off=(Cb, Cr sample offsets of the original chroma planes behind the luma plane in the original buffer), org_stride=..., refs=([(Cb off, Cr off)]
     per list, per reference picture, inside the reference buffer), ref_stride=...) -- adds the 4:2:0 chroma planes to the final prediction, the residual and
-    the TU chains (DCT2, chroma QP by the CTC mapping table)."""
+    the TU chains (DCT2, chroma QP by the CTC mapping table).
+    affine: adds the affine uni stage for PUs of at least 16x16: InterSearch::xAffineMotionEstimation (4-parameter model, uni-directional) per (PU, list, refIdx),
+    started from and predicted by the row's translational result; low_delay: getIntraPeriod() == -1 / getCheckLDC() of the low-delay configurations."""
 
     def __init__(self, ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda=8.0, qp=32, sizes=(128, 64, 32, 16, 8),
-                 ctu_filter=None, transform_skip=False, bit_depth=10, pocs=None, chroma=None, bdof=True):
+                 ctu_filter=None, transform_skip=False, bit_depth=10, pocs=None, chroma=None, bdof=True, affine=False, low_delay=False):
         T, dev = torch, device
         self.ctx, self.torch, self.device = ctx, T, dev
         self.pic_w, self.pic_h, self.org_stride, self.lam = pic_w, pic_h, org_stride, motion_lambda
@@ -195,6 +199,7 @@ class FrameHotPath:
             wpj[int(k)] = int(v)
         cands = [0] + ([1] if transform_skip else []) + [2, 3, 4, 5]
         self.pocs, self.chroma = pocs, chroma
+        self.affine = bool(affine)
         self.bdof = bool(bdof and pocs is not None and self.is_b)
         if chroma is not None:
             cqp = chroma_qp(qp) + 6 * (bit_depth - 8)
@@ -292,6 +297,11 @@ class FrameHotPath:
                 tc["qpPer"], tc["qpRem"], tc["bitDepth"] = self.cqp_per, self.cqp_rem, bit_depth
                 lvl.update(ntu_c=ntc, ts_c=twc, tw_c=twc, th_c=thc, tu_c_np=tc, tu_res_c=T.zeros((2 * ntc, 2), dtype=T.int64, device=dev),
                            qcoef_c=T.zeros(2 * ntc * twc * thc, dtype=T.int32, device=dev))
+            if self.affine and min(w, h) >= 16:
+                # ---- affine uni stage: one xAffineMotionEstimation job per row, written by stage 4 from the translational results ----
+                lvl["aff_jobs"] = T.zeros((R * n, AFF_DT.itemsize), dtype=T.uint8, device=dev)
+                lvl["aff_out"] = T.zeros((R * n, AFFOUT_DT.itemsize), dtype=T.uint8, device=dev)
+                L.affJobs, L.affLowDelay, L.affCheckLDC = lvl["aff_jobs"].data_ptr(), int(low_delay), int(low_delay)
             lvl["pis"] = L
             lvl["pic"] = PicParams(pic_w, pic_h, 128, bit_depth, wpj.get(max(w, h), 1))
             lvl["pic_bi"] = PicParams(pic_w, pic_h, 128, bit_depth, FULL_WAVES_PER_JOB.get(max(w, h), 1))
@@ -381,6 +391,11 @@ class FrameHotPath:
         if self.chroma is not None:
             ctx.motion_compensation_batch(org_ptr, dpb_ptr, buf["pred_c"].data_ptr(), buf["resi_c"].data_ptr(), lvl["pred_final_c"].ptr, 2 * n, w // 2, h // 2)
         self._mark("mc")
+        if "aff_jobs" in lvl:
+            rows = (self.nref[0] + self.nref[1]) * n
+            ctx.pis_stage(lvl["pis"], 4)
+            ctx.affine_motion_estimation_batch(lvl["pic"], org_ptr, dpb_ptr, None, lvl["aff_jobs"].data_ptr(), rows, w, h, lvl["aff_out"].data_ptr())
+            self._mark("affine")
         self._tu(lvl)
         if self.chroma is not None:
             twc, thc = lvl["tw_c"], lvl["th_c"]
@@ -444,6 +459,9 @@ class FrameHotPath:
                 d["bi_jobs"] = lvl["bi_jobs"].t.cpu().numpy().view(ME_DT).reshape(-1)
                 d["bi_out"] = lvl["bi_out"].cpu().numpy().view(MEOUT_DT).reshape(-1)
             d["route"] = lvl["pred_final"].col("route").cpu().numpy()
+            if "aff_jobs" in lvl:
+                d["aff_jobs"] = lvl["aff_jobs"].cpu().numpy().view(AFF_DT).reshape(-1)
+                d["aff_out"] = lvl["aff_out"].cpu().numpy().view(AFFOUT_DT).reshape(-1)
             if self.chroma is not None:
                 d.update(ntu_c=lvl["ntu_c"], ts_c=lvl["ts_c"], tw_c=lvl["tw_c"], th_c=lvl["th_c"], tu_res_c=lvl["tu_res_c"].cpu().numpy())
             out.append(d)
@@ -456,9 +474,11 @@ class FrameHotPath:
             out += [lvl["pus"].reshape(-1), lvl["tu_res"].view(self.torch.uint8).reshape(-1)]
             if self.chroma is not None:
                 out.append(lvl["tu_res_c"].view(self.torch.uint8).reshape(-1))
+            if "aff_out" in lvl:
+                out.append(lvl["aff_out"].reshape(-1))
         return out
 
     def work_counts(self):
         R = self.nref[0] + self.nref[1]
         return dict(pus=self.NP, uni_searches=R * self.NP, bi_searches=(self.nref[0] if self.is_b else 0) * self.NP,
-                    tu_chains=sum(l["ntu"] * l["nc"] for l in self.levels))
+                    tu_chains=sum(l["ntu"] * l["nc"] for l in self.levels), affine_searches=sum(R * l["npu"] for l in self.levels if "aff_jobs" in l))
