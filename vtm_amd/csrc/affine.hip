@@ -118,7 +118,85 @@ __device__ __forceinline__ void subblock_4x4( const int16_t *r0, int rs, int mh,
   }
 }
 
-// xPredAffineBlk (luma, uni-directional use of the estimation: bi = false) into sPred[h][w]
+struct __attribute__( ( packed, aligned( 2 ) ) ) Pel8u { unsigned v[4]; };   // 8 samples from a 2-byte aligned address
+
+// One COLUMN of a 4x4 sub-block at vector (mh, mv): o[4] = rows 0..3 of column q, rounded + clipped (last) or 14-bit intermediates (!last); the same
+// arithmetic as subblock_4x4, split so that the four lanes of a quad share one sub-block without talking to each other: a lane filters the 11 rows of
+// its column horizontally (ONE 16-byte load per row holds its eight taps' samples), then its own column vertically.
+__device__ __forceinline__ void subblock_column( const int16_t *r0, int rs, int mh, int mv, int q, bool last, int bd, int o[4] )
+{
+  const int      xFrac = mh & 15, yFrac = mv & 15, headRoom = max( 2, 14 - bd ), cmax = ( 1 << bd ) - 1;
+  const int16_t *src = r0 + ( long ) ( mv >> 4 ) * rs + ( mh >> 4 ) + q;
+  if( xFrac == 0 && yFrac == 0 && last )
+  {
+#pragma unroll
+    for( int y = 0; y < 4; y++ ) o[y] = src[( long ) y * rs];
+    return;
+  }
+  if( yFrac == 0 )   // horizontal only (also the 14-bit copy: taps {0,0,0,64,0,0,0,0})
+  {
+    const int16_t *c = c_affTaps4x4[xFrac];
+    const int      shift = last ? 6 : 6 - headRoom, offset = last ? 32 : -( 8192 << shift );
+#pragma unroll
+    for( int y = 0; y < 4; y++ )
+    {
+      const Pel8u v = *reinterpret_cast<const Pel8u *>( src + ( long ) y * rs - 3 );
+      int         sum = 0;
+#pragma unroll
+      for( int k = 0; k < 4; k++ ) sum += ( int ) ( short ) v.v[k] * ( int ) c[2 * k] + ( ( int ) v.v[k] >> 16 ) * ( int ) c[2 * k + 1];
+      int r = ( int ) ( int16_t ) ( ( sum + offset ) >> shift );
+      if( last ) r = clip3( 0, cmax, r );
+      o[y] = r;
+    }
+    return;
+  }
+  if( xFrac == 0 )   // vertical only
+  {
+    const int16_t *c = c_affTaps4x4[yFrac];
+    const int      shift = last ? 6 : 6 - headRoom, offset = last ? 32 : -( 8192 << shift );
+    int            col[11];
+#pragma unroll
+    for( int r = 0; r < 11; r++ ) col[r] = src[( long ) ( r - 3 ) * rs];
+#pragma unroll
+    for( int y = 0; y < 4; y++ )
+    {
+      int sum = 0;
+#pragma unroll
+      for( int k = 0; k < 8; k++ ) sum += col[y + k] * ( int ) c[k];
+      int r = ( int ) ( int16_t ) ( ( sum + offset ) >> shift );
+      if( last ) r = clip3( 0, cmax, r );
+      o[y] = r;
+    }
+    return;
+  }
+  const int16_t *ch = c_affTaps4x4[xFrac], *cv = c_affTaps4x4[yFrac];
+  const int      sh1 = 6 - headRoom, of1 = -( 8192 << sh1 );
+  int            col[11];
+#pragma unroll
+  for( int r = 0; r < 11; r++ )
+  {
+    const Pel8u v = *reinterpret_cast<const Pel8u *>( src + ( long ) ( r - 3 ) * rs - 3 );
+    int         sum = 0;
+#pragma unroll
+    for( int k = 0; k < 4; k++ ) sum += ( int ) ( short ) v.v[k] * ( int ) ch[2 * k] + ( ( int ) v.v[k] >> 16 ) * ( int ) ch[2 * k + 1];
+    col[r] = ( int ) ( int16_t ) ( ( sum + of1 ) >> sh1 );
+  }
+  const int sh2 = last ? 6 + headRoom : 6, of2 = last ? ( 1 << ( sh2 - 1 ) ) + ( 8192 << 6 ) : 0;
+#pragma unroll
+  for( int y = 0; y < 4; y++ )
+  {
+    int sum = 0;
+#pragma unroll
+    for( int k = 0; k < 8; k++ ) sum += col[y + k] * ( int ) cv[k];
+    int r = ( int ) ( int16_t ) ( ( sum + of2 ) >> sh2 );
+    if( last ) r = clip3( 0, cmax, r );
+    o[y] = r;
+  }
+}
+
+// xPredAffineBlk (luma, uni-directional use of the estimation: bi = false) into sPred[h][w]: a QUAD of lanes per 4x4 sub-block, lane q = column q.
+// PROF needs the horizontal neighbours of a sample: the neighbouring lanes of the quad (DPP quad_perm) or, at the sub-block's edge, the ring of
+// integer reference samples; the vertical neighbours are the lane's own column and the ring.
 __device__ void affine_pred( const AffCtx &c, const Mv3 &m, int16_t *sPred )
 {
   const int iBit = 7, w = c.w, h = c.h;
@@ -135,7 +213,8 @@ __device__ void affine_pred( const AffCtx &c, const Mv3 &m, int16_t *sPred )
   prof = prof && ( !c.profLarge || dHX > thr || dHY > thr || dVX > thr || dVY > thr || dHX < -thr || dHY < -thr || dVX < -thr || dVY < -thr );
   const int ifShift = max( 2, 14 - c.bd );
   const int sbw = w >> 2, nsb = sbw * ( h >> 2 );
-  for( int sb = threadIdx.x; sb < nsb; sb += blockDim.x )
+  const int q = threadIdx.x & 3;
+  for( int sb = threadIdx.x >> 2; sb < nsb; sb += blockDim.x >> 2 )   // whole quads enter and leave together
   {
     const int y = ( sb / sbw ) << 2, x = ( sb - ( sb / sbw ) * sbw ) << 2;
     int       mh, mv;
@@ -145,54 +224,55 @@ __device__ void affine_pred( const AffCtx &c, const Mv3 &m, int16_t *sPred )
     mh = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mh ); mv = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, mv );
     mh = clip3( c.horMin, c.horMax, mh ); mv = clip3( c.verMin, c.verMax, mv );
     const int16_t *r0 = c.ref + ( long ) y * c.refStride + x;
-    int            o[16];
-    subblock_4x4( r0, c.refStride, mh, mv, !prof, c.bd, o );
+    int            o[4];
+    subblock_column( r0, c.refStride, mh, mv, q, !prof, c.bd, o );
     if( prof )
     {
       // PROF: gradients of the 14-bit prediction inside a ring of integer reference samples, times the per-sample vector offsets
-      int ext[6][6];
-#pragma unroll
-      for( int j = 0; j < 4; j++ )
-#pragma unroll
-        for( int i = 0; i < 4; i++ ) ext[j + 1][i + 1] = o[j * 4 + i];
       const int16_t *rb = r0 + ( long ) ( mv >> 4 ) * c.refStride + ( mh >> 4 );
       const int      xo = ( mh & 15 ) >> 3, yo = ( mv & 15 ) >> 3;
       const int16_t *rp = rb - ( long ) ( 1 - yo ) * c.refStride + xo - 1;
-#pragma unroll
-      for( int i = 0; i < 6; i++ )
-      {
-        ext[0][i] = ( int ) ( int16_t ) ( ( rp[i] << ifShift ) - 8192 );
-        ext[5][i] = ( int ) ( int16_t ) ( ( rp[i + 5l * c.refStride] << ifShift ) - 8192 );
-      }
-      rp = rb + ( long ) yo * c.refStride + xo;
+      const int      top = ( int ) ( int16_t ) ( ( rp[q + 1] << ifShift ) - 8192 ), bot = ( int ) ( int16_t ) ( ( rp[q + 1 + 5l * c.refStride] << ifShift ) - 8192 );
+      const int16_t *rq = rb + ( long ) yo * c.refStride + xo;
+      int            lf[4], rt[4];
 #pragma unroll
       for( int j = 0; j < 4; j++ )
       {
-        ext[j + 1][0] = ( int ) ( int16_t ) ( ( rp[( long ) j * c.refStride - 1] << ifShift ) - 8192 );
-        ext[j + 1][5] = ( int ) ( int16_t ) ( ( rp[( long ) j * c.refStride + 4] << ifShift ) - 8192 );
+        lf[j] = __builtin_amdgcn_mov_dpp( o[j], 0x90, 0xF, 0xF, false );   // quad_perm [0, 0, 1, 2]: the lane to the left
+        rt[j] = __builtin_amdgcn_mov_dpp( o[j], 0xF9, 0xF, 0xF, false );   // quad_perm [1, 2, 3, 3]: the lane to the right
+      }
+      if( q == 0 )
+      {
+#pragma unroll
+        for( int j = 0; j < 4; j++ ) lf[j] = ( int ) ( int16_t ) ( ( rq[( long ) j * c.refStride - 1] << ifShift ) - 8192 );
+      }
+      if( q == 3 )
+      {
+#pragma unroll
+        for( int j = 0; j < 4; j++ ) rt[j] = ( int ) ( int16_t ) ( ( rq[( long ) j * c.refStride + 4] << ifShift ) - 8192 );
       }
       const int qHX = dHX << 2, qHY = dHY << 2, qVX = dVX << 2, qVY = dVY << 2;
       const int d0H = ( ( dHX + dVX ) << 1 ) - ( ( qHX + qVX ) << 1 ), d0V = ( ( dHY + dVY ) << 1 ) - ( ( qHY + qVY ) << 1 );
       const int dILimit = 1 << max( c.bd + 1, 13 ), offset = ( 1 << ( ifShift - 1 ) ) + 8192, cmax = ( 1 << c.bd ) - 1;
+      int       res[4];
 #pragma unroll
       for( int j = 0; j < 4; j++ )
+      {
+        int dh = d0H + q * qHX + j * qVX, dv = d0V + q * qHY + j * qVY;
+        round_affine_mv( dh, dv, 8 );
+        dh = clip3( -31, 31, dh ); dv = clip3( -31, 31, dv );
+        const int up = j == 0 ? top : o[j > 0 ? j - 1 : 0], dn = j == 3 ? bot : o[j < 3 ? j + 1 : 3];
+        const int gx = ( int ) ( int16_t ) ( ( rt[j] >> 6 ) - ( lf[j] >> 6 ) );
+        const int gy = ( int ) ( int16_t ) ( ( dn >> 6 ) - ( up >> 6 ) );
+        const int dI = clip3( -dILimit, dILimit - 1, dh * gx + dv * gy );
+        const int v  = ( int ) ( int16_t ) ( o[j] + dI );
+        res[j] = clip3( 0, cmax, ( int ) ( int16_t ) ( ( v + offset ) >> ifShift ) );
+      }
 #pragma unroll
-        for( int i = 0; i < 4; i++ )
-        {
-          int dh = d0H + i * qHX + j * qVX, dv = d0V + i * qHY + j * qVY;
-          round_affine_mv( dh, dv, 8 );
-          dh = clip3( -31, 31, dh ); dv = clip3( -31, 31, dv );
-          const int gx = ( int ) ( int16_t ) ( ( ext[j + 1][i + 2] >> 6 ) - ( ext[j + 1][i] >> 6 ) );
-          const int gy = ( int ) ( int16_t ) ( ( ext[j + 2][i + 1] >> 6 ) - ( ext[j][i + 1] >> 6 ) );
-          const int dI = clip3( -dILimit, dILimit - 1, dh * gx + dv * gy );
-          const int v  = ( int ) ( int16_t ) ( ext[j + 1][i + 1] + dI );
-          o[j * 4 + i] = clip3( 0, cmax, ( int ) ( int16_t ) ( ( v + offset ) >> ifShift ) );
-        }
+      for( int j = 0; j < 4; j++ ) o[j] = res[j];
     }
 #pragma unroll
-    for( int j = 0; j < 4; j++ )
-#pragma unroll
-      for( int i = 0; i < 4; i++ ) sPred[( y + j ) * w + x + i] = ( int16_t ) o[j * 4 + i];
+    for( int j = 0; j < 4; j++ ) sPred[( y + j ) * w + x + q] = ( int16_t ) o[j];
   }
 }
 
@@ -218,7 +298,8 @@ __device__ unsigned long long block_dist( const int16_t *sPred, const int16_t *s
   __syncthreads();
   if( ( threadIdx.x & 63 ) == 0 ) sRed[threadIdx.x >> 6] = acc;
   __syncthreads();
-  const unsigned long long t = sRed[0] + sRed[1] + sRed[2] + sRed[3];
+  unsigned long long t = 0;
+  for( int wv = 0; wv < ( int ) ( blockDim.x >> 6 ); wv++ ) t += sRed[wv];   // one or four waves per job
   __syncthreads();
   return t;
 }
@@ -284,7 +365,7 @@ __global__ __launch_bounds__( 256 ) void affine_me_kernel( vtmhip_pic_params pic
   // pattern: org, or 2*org - otherPred (removeHighFreq, unclipped)
   {
     const int16_t *o = orgBase + j.orgOff, *p = bi ? otherBase + j.otherPredOff : nullptr;
-    for( int i = threadIdx.x; i < w * h; i += 256 )
+    for( int i = threadIdx.x; i < w * h; i += blockDim.x )
     {
       const int y = i / w, x = i - y * w;
       const int v = o[( long ) y * j.orgStride + x];
@@ -321,7 +402,7 @@ __global__ __launch_bounds__( 256 ) void affine_me_kernel( vtmhip_pic_params pic
     long long acc[42];
 #pragma unroll
     for( int i = 0; i < 42; i++ ) acc[i] = 0;
-    for( int i = threadIdx.x; i < w * h; i += 256 )
+    for( int i = threadIdx.x; i < w * h; i += blockDim.x )
     {
       const int y = i / w, x = i - y * w;
       const int yc = min( h - 2, max( 1, y ) ), xc = min( w - 2, max( 1, x ) );
@@ -344,7 +425,13 @@ __global__ __launch_bounds__( 256 ) void affine_me_kernel( vtmhip_pic_params pic
         }
     }
 #pragma unroll
-    for( int i = 0; i < 42; i++ ) acc[i] = ( long long ) wave_reduce_add_u64( ( unsigned long long ) acc[i] );
+    for( int col = 0; col < 6; col++ )
+      if( col < np )   // only the entries the model has: 20 of 42 for four parameters
+      {
+#pragma unroll
+        for( int row = 0; row < 7; row++ )
+          if( row < np || row == 6 ) acc[col * 7 + row] = ( long long ) wave_reduce_add_u64( ( unsigned long long ) acc[col * 7 + row] );
+      }
     if( ( threadIdx.x & 63 ) == 0 )
     {
 #pragma unroll
@@ -359,7 +446,8 @@ __global__ __launch_bounds__( 256 ) void affine_me_kernel( vtmhip_pic_params pic
         for( int row = 0; row <= np; row++ )
         {
           const int       src = row < np ? col * 7 + row : col * 7 + 6;
-          const long long v   = sAcc[0][src] + sAcc[1][src] + sAcc[2][src] + sAcc[3][src];
+          long long       v   = sAcc[0][src];
+          for( int wv = 1; wv < ( int ) ( blockDim.x >> 6 ); wv++ ) v += sAcc[wv][src];
           deq[col + 1][row] = ( double ) v;
         }
       double para[6], dmv[6] = { 0, 0, 0, 0, 0, 0 };
@@ -537,7 +625,10 @@ int vtmhip_xAffineMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_
   const size_t lds = 2 * ( size_t ) maxWidth * maxHeight * sizeof( int16_t );
   if( lds > 48 * 1024 ) VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( affine_me_kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
   VTMHIP_TIME_KERNEL( ctx, "affine_me_kernel" );
-  hipLaunchKernelGGL( affine_me_kernel, dim3( n ), dim3( 256 ), lds, ctx->stream, *pic, d_orgBase, d_refBase, d_otherPredBase ? d_otherPredBase : d_orgBase, d_jobs, d_results );
+  // one wave per job up to 32x32 (64 4x4 sub-blocks: a lane each), four waves above: the model iterations are a serial chain per job, so small blocks gain
+  // from four times as many jobs in flight, not from idle lanes
+  const int threads = maxWidth * maxHeight <= 1024 ? 64 : 256;
+  hipLaunchKernelGGL( affine_me_kernel, dim3( n ), dim3( threads ), lds, ctx->stream, *pic, d_orgBase, d_refBase, d_otherPredBase ? d_otherPredBase : d_orgBase, d_jobs, d_results );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }
