@@ -165,6 +165,8 @@ def main():
     for l in (0, 1):
         for p in pocs[l]:
             if p not in seen:      # one reference picture = its extended luma plane, then (4:2:0) its extended Cb and Cr planes
+                if not seen:
+                    newest = [off_acc, 0]      # the first picture of list 0 = the picture reconstructed last: [first element, elements] inside the DPB buffer
                 buf, off, stride = synth.extend_plane(frames[p][0] if with_c else frames[p], margin=160)
                 ent = [(off_acc + off, stride), None]
                 planes.append(buf.reshape(-1))
@@ -178,6 +180,8 @@ def main():
                         off_acc += buf.size
                     ent[1] = tuple(offs)
                 seen[p] = ent
+                if len(seen) == 1:
+                    newest[1] = off_acc - newest[0]
             refs[l].append(seen[p][0])
             refs_c[l].append(seen[p][1])
     dpb_np = np.concatenate(planes)
@@ -203,11 +207,11 @@ def main():
     fme = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, ctu_filter=ctu_filter, transform_skip=a.transform_skip, pocs=poc_arg, chroma=ch_dev,
                        sizes=fme_sizes, affine=a.affine, low_delay=a.config == "ldp")
 
-    # N > 1: the reconstructed reference planes go from rank 0 to every GPU inside every step (RCCL broadcast over xGMI; bytes view: int16 is
+    # N > 1: the planes of the picture reconstructed last go from rank 0 to every GPU inside every step (RCCL broadcast over xGMI; bytes view: int16 is
     # not a collective dtype), double-buffered: the planes of step k + 1 travel while step k computes; the ranks' result records go back to rank 0
     # (gather), also asynchronously.  The timed region ends only after the last transfer of either kind has landed.
     from vtm_amd.exchange import PlaneExchange, ResultGather
-    xchg = PlaneExchange([dpb, dpb.clone()], src=0) if use_dist else None
+    xchg = PlaneExchange([dpb, dpb.clone()], src=0, window=tuple(newest)) if use_dist else None    # one broadcast per reconstructed picture
     res_t = fme.result_tensors()
     gath = ResultGather(sum(t.numel() for t in res_t), dev, dst=0) if use_dist else None
 
@@ -358,7 +362,7 @@ def main():
                                   "uni/bi decision", "final prediction + residual (fused)" + ("" if a.luma_only else "; BDOF where xPredInterBi applies it; Cb / Cr prediction + residual"),
                                   "tu_chain (xT, quant, dequant, xIT, SSE)" + ("" if a.luma_only else ", luma MTS candidates + chroma DCT2 at the mapped chroma QP")],
                        "order": "one stream" if a.serial else "level-major over 5 side streams (each level's later stages run beside the next levels' searches)",
-                       "parallelism": ("1 GPU" if world == 1 else "one picture, CTUs sharded over %d GPUs (%s): bands %s; planes broadcast from rank 0, results gathered to rank 0 every step"
+                       "parallelism": ("1 GPU" if world == 1 else "one picture, CTUs sharded over %d GPUs (%s): bands %s; the planes of the newest reference picture (Y, Cb, Cr) broadcast from rank 0 and the results gathered to rank 0 every step"
                                        % (world, "raster-scan CTU ranges" if a.shard == "ctu" else "whole CTU rows", [b[1] - b[0] for b in bands]))},
             "satd_gblocks_per_s": float(satd_g.item()),
             "stages_ms": stage_acc, "kernels": kern,

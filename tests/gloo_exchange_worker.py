@@ -26,6 +26,13 @@ def main():
     assert seen == [100 + k for k in range(7)]
     if rank == 0:
         assert sent == list(range(8))   # one transfer ahead
+    # window: only the newest picture's planes travel; the rest of the buffer (older pictures, here: a marker each rank wrote itself) stays untouched
+    bufs = [torch.full((5000,), 7 + rank, dtype=torch.int16), torch.full((5000,), 7 + rank, dtype=torch.int16)]
+    x = PlaneExchange(bufs, src=0, produce=lambda b, k: b[1000:3000].fill_(200 + k), window=(1000, 2000))
+    for k in range(4):
+        planes = x.next()
+        assert bool((planes[1000:3000] == 200 + k).all()) and bool((planes[:1000] == 7 + rank).all()) and bool((planes[3000:] == 7 + rank).all()), (rank, k)
+    x.drain()
     dist.barrier()
     if rank == 0:
         print("EXCHANGE_OK")

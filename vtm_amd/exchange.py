@@ -13,17 +13,23 @@ import torch.distributed as dist
 
 
 class PlaneExchange:
-    def __init__(self, buffers, src=0, produce=None):
+    def __init__(self, buffers, src=0, produce=None, window=None):
         """buffers: two equally sized tensors (the collective moves their bytes: int16 is not a collective dtype);
-        produce(buf, k): optional, called on rank `src` before the planes of step k are sent (the encoder writing its reconstruction)."""
+        produce(buf, k): optional, called on rank `src` before the planes of step k are sent (the encoder writing its reconstruction);
+        window: (first element, number of elements) of the buffers that a step sends -- the planes of the picture reconstructed last; the older
+        pictures of the decoded-picture buffer arrived with earlier steps and stay resident (None: the whole buffer)."""
         assert len(buffers) == 2 and buffers[0].numel() == buffers[1].numel()
         self.bufs, self.src, self.produce = buffers, src, produce
+        self.window = window
         self.n, self.pending = 0, None
 
     def _send(self, i, k):
         if self.produce is not None and dist.get_rank() == self.src:
             self.produce(self.bufs[i], k)
-        return dist.broadcast(self.bufs[i].reshape(-1).view(torch.uint8), src=self.src, async_op=True)
+        flat = self.bufs[i].reshape(-1)
+        if self.window is not None:
+            flat = flat[self.window[0]:self.window[0] + self.window[1]]
+        return dist.broadcast(flat.view(torch.uint8), src=self.src, async_op=True)
 
     def next(self):
         """Returns the buffer holding the planes of this step (ready for use on the current stream) and starts the next step's transfer."""
