@@ -57,6 +57,8 @@ def parse():
                     "split mix -- 128x128, 64x64, 64x32, 32x32, 32x16, 16x16, 16x8, 8x8 -- through the rectangular fast paths")
     ap.add_argument("--affine", action="store_true", help="add the affine uni stage: xAffineMotionEstimation (4-parameter) per (PU >= 16x16, list, refIdx) -- BASELINE config 5's tool set")
     ap.add_argument("--luma-only", action="store_true", help="no chroma planes and no BDOF in the final prediction (the round-2 mid-round operating point)")
+    ap.add_argument("--graph", choices=["on", "off"], default="off", help="replay the picture's launches from a hipGraph (captured once per reference buffer).  Measured: no gain -- "
+                    "9.83 vs 9.89 ms on one GPU, 2.08 vs 2.09 ms for a rank's share of an 8-GPU run: the step is bound by its dependent chain of kernels, not by launches")
     ap.add_argument("--inflight", type=int, default=1, help="pictures in flight: step k + 1 starts on a second stream set while step k's tail still runs (each has its own tables)")
     ap.add_argument("--serial", action="store_true", help="one stream, no overlap of the levels' chains: clean per-kernel times for profiling")
     return ap.parse_args()
@@ -203,6 +205,9 @@ def main():
     lam, qp = 8.0, a.qp
     bands = pipeline.ctu_bands(W, H, world, unit=a.shard)
     ctu_filter = pipeline.band_filter(W, bands[rank]) if world > 1 else None
+    sim = int(os.environ.get("VTM_BENCH_SIMULATE_WORLD", "0"))      # one GPU computing rank 0's share of an N-GPU run (no exchange): what a rank's step costs
+    if sim > 1 and world == 1:
+        ctu_filter = pipeline.band_filter(W, pipeline.ctu_bands(W, H, sim, unit=a.shard)[0])
     fme_sizes = (128, 64, 32, 16, 8) if a.partition == "qt" else (128, (64, 64), (64, 32), (32, 32), (32, 16), (16, 16), (16, 8), (8, 8))
     fme = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, ctu_filter=ctu_filter, transform_skip=a.transform_skip, pocs=poc_arg, chroma=ch_dev,
                        sizes=fme_sizes, affine=a.affine, low_delay=a.config == "ldp")
@@ -223,13 +228,40 @@ def main():
                                  sizes=fme_sizes, affine=a.affine, low_delay=a.config == "ldp"))
         lanes.append(torch.cuda.Stream(device=dev))
 
+    use_graph = a.graph == "on" and not a.serial
+    graphs = {}
+
+    def run_picture(dpb_ptr):
+        """one picture on the current stream: eager launches, or the replay of the graph captured for this reference buffer"""
+        if not use_graph:
+            fme.run(cur.data_ptr(), dpb_ptr)
+            return
+        g = graphs.get(dpb_ptr)
+        if g is None:
+            outer = torch.cuda.current_stream()
+            if "stream" not in graphs:
+                graphs["stream"] = torch.cuda.Stream(device=dev)
+            cap = graphs["stream"]
+            cap.wait_stream(outer)
+            with torch.cuda.stream(cap):   # one eager pass on the capture stream first: the library sizes its per-stream workspaces outside the capture
+                ctx.set_stream(cap.cuda_stream)
+                fme.run(cur.data_ptr(), dpb_ptr)
+            cap.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cap):      # the side streams of FrameHotPath.run join the capture through its fork / join events
+                ctx.set_stream(cap.cuda_stream)
+                fme.run(cur.data_ptr(), dpb_ptr)
+            ctx.set_stream(outer.cuda_stream)
+            graphs[dpb_ptr] = g
+        g.replay()
+
     def step():
         if xchg is not None:
             planes = xchg.next()
-            fme.run(cur.data_ptr(), planes.data_ptr())
+            run_picture(planes.data_ptr())
             gath.submit(res_t)
         elif len(fmes) == 1:
-            fme.run(cur.data_ptr(), dpb.data_ptr())
+            run_picture(dpb.data_ptr())
         else:
             k = turn[0] % len(fmes)
             turn[0] += 1
@@ -361,7 +393,8 @@ def main():
                        "stages": ["xEstimateMvPredAMVP", "xMotionEstimation uni (TZ + frac)", "xCheckBestMVP / best reference", "bi refinement (MC + removeHighFreq fused, xPatternSearch, frac)",
                                   "uni/bi decision", "final prediction + residual (fused)" + ("" if a.luma_only else "; BDOF where xPredInterBi applies it; Cb / Cr prediction + residual"),
                                   "tu_chain (xT, quant, dequant, xIT, SSE)" + ("" if a.luma_only else ", luma MTS candidates + chroma DCT2 at the mapped chroma QP")],
-                       "order": "one stream" if a.serial else "level-major over 5 side streams (each level's later stages run beside the next levels' searches)",
+                       "order": ("one stream" if a.serial else "level-major over 5 side streams (each level's later stages run beside the next levels' searches)")
+                                + (", replayed from a hipGraph" if use_graph else ""),
                        "parallelism": ("1 GPU" if world == 1 else "one picture, CTUs sharded over %d GPUs (%s): bands %s; the planes of the newest reference picture (Y, Cb, Cr) broadcast from rank 0 and the results gathered to rank 0 every step"
                                        % (world, "raster-scan CTU ranges" if a.shard == "ctu" else "whole CTU rows", [b[1] - b[0] for b in bands]))},
             "satd_gblocks_per_s": float(satd_g.item()),
