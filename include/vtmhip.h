@@ -765,6 +765,49 @@ typedef struct
  *          bits = the row's bits before the vector rate, hevcCost = the PU's best translational cost -> vtmhip_xAffineMotionEstimation_batch_dev */
 int vtmhip_pis_stage( vtmhip_ctx *ctx, const vtmhip_pis_level *lvl, int stage );
 
+/* ---- the level-order picture loop itself, natively -------------------------------------------------------------------------------------------
+ * One call runs the whole chain of a picture over the levels' tables (what vtm_amd/pipeline.py:FrameHotPath.run does call by call from Python:
+ * ~130 library calls, 2 ms of interpreter time per picture -- more than a GPU needs for its share of a picture sharded over eight GPUs).
+ * Per level: stage 0, xEstimateMvPredAMVP, the uni searches, stage 1 on `mainStream` (a level's AMVP candidates are its parent's vectors: one dependent
+ * chain); everything after that -- stage 2, the other list's prediction, the bi refinement, stage 3, the final prediction (plain / BDOF / chroma),
+ * the affine uni stage, the TU chains -- on sideStreams[level % numSide] behind an event, beside the next levels' searches; the side streams join
+ * `mainStream` at the end.  numSide == 0: everything on mainStream in level order.  The context's stream is mainStream on return. */
+typedef struct
+{
+  vtmhip_pis_level  pis;
+  vtmhip_pic_params pic, picBi;        /* wavesPerJob tuned per level for the uni / bi searches */
+  vtmhip_me_cfg     cfgUni, cfgBi;
+  int32_t  width, height;              /* the level's PU shape */
+  int32_t  bdof;                       /* launch vtmhip_bdof_batch_dev over predFinal after the plain prediction */
+  int32_t  pad0;
+  vtmhip_me_out        *uniOut;        /* = pis.uniOut, writable */
+  vtmhip_me_out        *biOut;
+  /* luma TU chains: `numCands` candidate runs of `numTU` jobs each, stored one after the other in tu[] / tuRes[]; cand[i] = 1: transform skip */
+  vtmhip_tu_job        *tu;
+  vtmhip_tu_result     *tuRes;
+  int32_t              *qcoef;
+  int32_t  numTU, numCands, tuW, tuH;
+  uint8_t  cand[8];
+  /* chroma TU chains (NULL: none): 2 * numTUC jobs (Cb then Cr) */
+  vtmhip_tu_job        *tuC;
+  vtmhip_tu_result     *tuResC;
+  int32_t              *qcoefC;
+  int32_t  numTUC, tuWC, tuHC, pad1;
+  vtmhip_affine_me_out *affOut;        /* affine uni stage when pis.affJobs != NULL */
+} vtmhip_pis_level_run;
+
+typedef struct
+{
+  const int16_t *org;                  /* original picture (Y | Cb | Cr) */
+  const int16_t *dpb;                  /* reference pictures */
+  int16_t *pred, *resi;                /* level-wide luma sample buffers (compact per-PU slots, offsets in the job tables) */
+  int16_t *orgBi;                      /* 2 * org - pred of the other list (B slices) */
+  int16_t *predC, *resiC;              /* chroma (NULL: luma only) */
+} vtmhip_pis_buffers;
+
+int vtmhip_pis_run_picture( vtmhip_ctx *ctx, const vtmhip_pis_level_run *levels, int numLevels, const vtmhip_pis_buffers *buf, void *mainStream,
+                            void *const *sideStreams, int numSide );
+
 #ifdef __cplusplus
 }
 #endif

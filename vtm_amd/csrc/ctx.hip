@@ -39,6 +39,8 @@ int vtmhip_struct_size( int which )
   case 26: return ( int ) sizeof( vtmhip_affine_me_job );
   case 27: return ( int ) sizeof( vtmhip_affine_me_out );
   case 28: return ( int ) sizeof( vtmhip_lfnst_tu_job );
+  case 29: return ( int ) sizeof( vtmhip_pis_level_run );
+  case 30: return ( int ) sizeof( vtmhip_pis_buffers );
   default: return -1;
   }
 }

@@ -1,0 +1,131 @@
+// driver.hip -- the level-order picture loop of predInterSearch + residual coding as ONE library call (vtmhip_pis_run_picture): the sequence of batched
+// calls per partition level and the fork / join between the uni-search chain and the levels' remaining stages, issued natively (no interpreter between the
+// ~130 launches of a picture).  Every step is a public entry point of this library; nothing here computes.
+#include "ctx.hpp"
+
+#include <vector>
+
+namespace
+{
+
+struct EventPool   // events of the fork / join: created on demand, kept by the context for its lifetime
+{
+  std::vector<hipEvent_t> ev;
+  size_t                  used = 0;
+  hipEvent_t get()
+  {
+    if( used == ev.size() )
+    {
+      hipEvent_t e = nullptr;
+      if( hipEventCreateWithFlags( &e, hipEventDisableTiming ) != hipSuccess ) return nullptr;
+      ev.push_back( e );
+    }
+    return ev[used++];
+  }
+};
+
+int run_uni( vtmhip_ctx *ctx, const vtmhip_pis_level_run &L, const vtmhip_pis_buffers &b )
+{
+  const int rows = ( L.pis.numRef[0] + L.pis.numRef[1] ) * L.pis.numPU;
+  int st = vtmhip_pis_stage( ctx, &L.pis, 0 );
+  if( st ) return st;
+  st = vtmhip_xEstimateMvPredAMVP_batch_dev( ctx, &L.pic, b.org, b.dpb, L.pis.uniJobs, rows, L.width, L.height, 1, 1, nullptr );   // (the index bits of the chosen predictor join the row's bits)
+  if( st ) return st;
+  st = vtmhip_xMotionEstimation_batch_dev( ctx, &L.pic, &L.cfgUni, b.org, b.dpb, nullptr, L.pis.uniJobs, rows, L.width, L.height, L.uniOut );
+  if( st ) return st;
+  return vtmhip_pis_stage( ctx, &L.pis, 1 );
+}
+
+int run_rest( vtmhip_ctx *ctx, const vtmhip_pis_level_run &L, const vtmhip_pis_buffers &b )
+{
+  const int n = L.pis.numPU, w = L.width, h = L.height;
+  int       st = VTMHIP_OK;
+  if( L.pis.numRef[1] > 0 )
+  {
+    st = vtmhip_pis_stage( ctx, &L.pis, 2 );
+    if( st ) return st;
+    st = vtmhip_motion_compensation_batch_dev( ctx, b.org, b.dpb, nullptr, b.orgBi, L.pis.predOther, n, w, h );
+    if( st ) return st;
+    st = vtmhip_xMotionEstimation_batch_dev( ctx, &L.picBi, &L.cfgBi, b.org, b.dpb, b.orgBi, L.pis.biJobs, L.pis.numRef[0] * n, w, h, L.biOut );
+    if( st ) return st;
+    st = vtmhip_pis_stage( ctx, &L.pis, 3 );
+    if( st ) return st;
+  }
+  st = vtmhip_motion_compensation_batch_dev( ctx, b.org, b.dpb, b.pred, b.resi, L.pis.predFinal, n, w, h );
+  if( st ) return st;
+  if( L.bdof )
+  {
+    st = vtmhip_bdof_batch_dev( ctx, b.org, b.dpb, b.pred, b.resi, L.pis.predFinal, n, w, h );
+    if( st ) return st;
+  }
+  if( L.pis.predFinalC )
+  {
+    st = vtmhip_motion_compensation_batch_dev( ctx, b.org, b.dpb, b.predC, b.resiC, L.pis.predFinalC, 2 * n, w / 2, h / 2 );
+    if( st ) return st;
+  }
+  if( L.pis.affJobs )
+  {
+    const int rows = ( L.pis.numRef[0] + L.pis.numRef[1] ) * n;
+    st = vtmhip_pis_stage( ctx, &L.pis, 4 );
+    if( st ) return st;
+    st = vtmhip_xAffineMotionEstimation_batch_dev( ctx, &L.pic, b.org, b.dpb, nullptr, L.pis.affJobs, rows, w, h, L.affOut );
+    if( st ) return st;
+  }
+  // luma TU chains: runs of consecutive candidates with a real transform go to the uniform kernel in one launch, transform skip to its own kernel
+  for( int k = 0; k < L.numCands; )
+  {
+    int run = 1;
+    if( L.cand[k] != 1 )
+      while( k + run < L.numCands && L.cand[k + run] != 1 ) run++;
+    const long a = ( long ) k * L.numTU, m = ( long ) run * L.numTU;
+    if( L.cand[k] == 1 ) st = vtmhip_tu_ts_chain_batch_dev( ctx, b.resi, L.tu + a, ( int ) m, L.tuW, L.tuH, L.qcoef, nullptr, L.tuRes + a );
+    else st = vtmhip_tu_chain_batch_dev( ctx, b.resi, L.tu + a, ( int ) m, L.tuW, L.tuH, 1, L.qcoef, nullptr, L.tuRes + a );
+    if( st ) return st;
+    k += run;
+  }
+  if( L.tuC ) st = vtmhip_tu_chain_batch_dev( ctx, b.resiC, L.tuC, 2 * L.numTUC, L.tuWC, L.tuHC, 1, L.qcoefC, nullptr, L.tuResC );
+  return st;
+}
+
+}   // namespace
+
+extern "C" int vtmhip_pis_run_picture( vtmhip_ctx *ctx, const vtmhip_pis_level_run *levels, int numLevels, const vtmhip_pis_buffers *buf, void *mainStream,
+                                       void *const *sideStreams, int numSide )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, levels && buf && numLevels >= 0 && numSide >= 0 && ( numSide == 0 || sideStreams ), "levels / buffers / streams" );
+  VTMHIP_REQUIRE( ctx, buf->org && buf->dpb && buf->pred && buf->resi, "null picture buffer" );
+  static thread_local EventPool pool;   // (one context per thread: the pool follows the thread)
+  pool.used = 0;
+  hipStream_t main = ( hipStream_t ) mainStream;
+  int         st = VTMHIP_OK;
+  ctx->stream = main;
+  if( numSide == 0 )
+  {
+    for( int i = 0; i < numLevels && !st; i++ ) st = run_uni( ctx, levels[i], *buf );
+    for( int i = 0; i < numLevels && !st; i++ ) st = run_rest( ctx, levels[i], *buf );
+    return st;
+  }
+  for( int i = 0; i < numLevels && !st; i++ )
+  {
+    ctx->stream = main;
+    st = run_uni( ctx, levels[i], *buf );
+    if( st ) break;
+    hipEvent_t  e    = pool.get();
+    hipStream_t side = ( hipStream_t ) sideStreams[i % numSide];
+    VTMHIP_REQUIRE( ctx, e, "hipEventCreate" );
+    VTMHIP_HIP( ctx, hipEventRecord( e, main ) );
+    VTMHIP_HIP( ctx, hipStreamWaitEvent( side, e, 0 ) );
+    ctx->stream = side;
+    st = run_rest( ctx, levels[i], *buf );
+  }
+  ctx->stream = main;
+  for( int s = 0; s < numSide && s < numLevels; s++ )   // join
+  {
+    hipEvent_t e = pool.get();
+    VTMHIP_REQUIRE( ctx, e, "hipEventCreate" );
+    VTMHIP_HIP( ctx, hipEventRecord( e, ( hipStream_t ) sideStreams[s] ) );
+    VTMHIP_HIP( ctx, hipStreamWaitEvent( main, e, 0 ) );
+  }
+  return st;
+}

@@ -222,6 +222,11 @@ class Context:
         """InterSearch::xEstimateMvPredAMVP (template cost of the AMVP candidates) for n MeJob rows, in place"""
         self._check(self.L.vtmhip_xEstimateMvPredAMVP_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, max_w, max_h, int(uniform), int(add_idx_bits), d_dist_bip))
 
+    def pis_run_picture(self, levels, n_levels, buffers, main_stream, side_streams):
+        """the whole level-order chain of a picture in one native call (levels: ctypes array of PisLevelRun; side_streams: list of raw stream handles)"""
+        arr = (C.c_void_p * max(1, len(side_streams)))(*side_streams)
+        self._check(self.L.vtmhip_pis_run_picture(self.h, levels, n_levels, C.byref(buffers), C.c_void_p(main_stream), arr, len(side_streams)))
+
     def affine_motion_estimation_batch(self, pic, d_org, d_ref, d_other, d_jobs, n, max_w, max_h, d_results):
         """InterSearch::xAffineMotionEstimation per AffineMeJob (one workgroup per job)"""
         self._check(self.L.vtmhip_xAffineMotionEstimation_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_other, d_jobs, n, max_w, max_h, d_results))

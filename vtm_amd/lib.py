@@ -180,6 +180,17 @@ class PisLevel(C.Structure):
                 ("affJobs", C.c_void_p), ("affLowDelay", C.c_int32), ("affCheckLDC", C.c_int32)]
 
 
+class PisLevelRun(C.Structure):
+    _fields_ = [("pis", PisLevel), ("pic", PicParams), ("picBi", PicParams), ("cfgUni", MeCfg), ("cfgBi", MeCfg), ("width", C.c_int32), ("height", C.c_int32),
+                ("bdof", C.c_int32), ("pad0", C.c_int32), ("uniOut", C.c_void_p), ("biOut", C.c_void_p), ("tu", C.c_void_p), ("tuRes", C.c_void_p), ("qcoef", C.c_void_p),
+                ("numTU", C.c_int32), ("numCands", C.c_int32), ("tuW", C.c_int32), ("tuH", C.c_int32), ("cand", C.c_uint8 * 8), ("tuC", C.c_void_p),
+                ("tuResC", C.c_void_p), ("qcoefC", C.c_void_p), ("numTUC", C.c_int32), ("tuWC", C.c_int32), ("tuHC", C.c_int32), ("pad1", C.c_int32), ("affOut", C.c_void_p)]
+
+
+class PisBuffers(C.Structure):
+    _fields_ = [("org", C.c_void_p), ("dpb", C.c_void_p), ("pred", C.c_void_p), ("resi", C.c_void_p), ("orgBi", C.c_void_p), ("predC", C.c_void_p), ("resiC", C.c_void_p)]
+
+
 class AffineMeJob(C.Structure):
     _fields_ = [("orgOff", C.c_int64), ("refOff", C.c_int64), ("otherPredOff", C.c_int64), ("predOff", C.c_int64), ("orgStride", C.c_int32), ("refStride", C.c_int32),
                 ("otherPredStride", C.c_int32), ("predStride", C.c_int32), ("puX", C.c_int16), ("puY", C.c_int16), ("width", C.c_int16), ("height", C.c_int16),
@@ -200,7 +211,7 @@ class LfnstTuJob(C.Structure):
 
 _STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob,
             TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut, PredJob, MaskedSadJob, GeoBlendJob, DmvrJob, LfnstJob,
-            PisRow, PisPu, PisLevel, AffineMeJob, AffineMeOut, LfnstTuJob]   # order of vtmhip_struct_size(which)
+            PisRow, PisPu, PisLevel, AffineMeJob, AffineMeOut, LfnstTuJob, PisLevelRun, PisBuffers]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
 _PROTOS = {
@@ -298,6 +309,7 @@ _PROTOS = {
     "vtmhip_kernel_timing_read": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "vtmhip_merge_cand_satd_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                    C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vtmhip_pis_run_picture": (C.c_int, [C.c_void_p, C.POINTER(PisLevelRun), C.c_int, C.POINTER(PisBuffers), C.c_void_p, C.POINTER(C.c_void_p), C.c_int]),
     "vtmhip_pis_stage": (C.c_int, [C.c_void_p, C.POINTER(PisLevel), C.c_int]),
     "vtmhip_tz_search_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_void_p]),

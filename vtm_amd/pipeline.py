@@ -83,7 +83,7 @@ def quadtree_levels(pic_w, pic_h, sizes=(128, 64, 32, 16, 8), row_filter=None, c
 # ======================================================================================================================
 # Level-order InterSearch::predInterSearch (InterSearch.cpp:2245-3065, translational part) + residual coding of one picture
 # ======================================================================================================================
-from .lib import MAX_REF, AffineMeJob, AffineMeOut, FracJob, FracResult, MeCfg, MeJob, MeOut, PisLevel, PisPu, PisRow, PredJob, TuJob   # noqa: E402
+from .lib import MAX_REF, AffineMeJob, AffineMeOut, FracJob, FracResult, MeCfg, MeJob, MeOut, PisBuffers, PisLevel, PisLevelRun, PisPu, PisRow, PredJob, TuJob   # noqa: E402
 
 AFF_DT, AFFOUT_DT = np.dtype(AffineMeJob), np.dtype(AffineMeOut)
 
@@ -345,6 +345,24 @@ class FrameHotPath:
                 lvl["tu_c"] = _Tab(T, dev, tc)
         self.side_streams = [T.cuda.Stream(device=dev) for _ in range(int(os.environ.get("VTM_AMD_SIDE_STREAMS", "5")))] if dev.type == "cuda" else []
         self._marks = None
+        # ---- the same chain as a table for the native loop (vtmhip_pis_run_picture: one library call per picture instead of ~130 from Python) ----
+        self.run_levels = (PisLevelRun * max(1, len(self.levels)))()
+        for k, lvl in enumerate(self.levels):
+            r = self.run_levels[k]
+            C.memmove(C.byref(r.pis), C.byref(lvl["pis"]), C.sizeof(PisLevel))
+            r.pic, r.picBi, r.cfgUni, r.cfgBi = lvl["pic"], lvl["pic_bi"], lvl["cfg_uni"], lvl["cfg_bi"]
+            r.width, r.height, r.bdof = lvl["w"], lvl["h"], int(self.bdof and lvl["w"] * lvl["h"] >= 128)
+            r.uniOut = lvl["uni_out"].data_ptr()
+            r.biOut = lvl["bi_out"].data_ptr() if self.is_b else None
+            r.tu, r.tuRes, r.qcoef = lvl["tu"].ptr, lvl["tu_res"].data_ptr(), lvl["qcoef"].data_ptr()
+            r.numTU, r.numCands, r.tuW, r.tuH = lvl["ntu"], lvl["nc"], lvl["tw"], lvl["th"]
+            for i, c in enumerate(lvl["cands"]):
+                r.cand[i] = c
+            if chroma is not None:
+                r.tuC, r.tuResC, r.qcoefC = lvl["tu_c"].ptr, lvl["tu_res_c"].data_ptr(), lvl["qcoef_c"].data_ptr()
+                r.numTUC, r.tuWC, r.tuHC = lvl["ntu_c"], lvl["tw_c"], lvl["th_c"]
+            if "aff_out" in lvl:
+                r.affOut = lvl["aff_out"].data_ptr()
 
     # ---- stage timing (HIP events on the launch stream; only when run(..., timing=True)) ----------------------------------
     def _mark(self, name):
@@ -434,6 +452,11 @@ class FrameHotPath:
                 self._rest(lvl, org_ptr, dpb_ptr)
             return
         main = T.cuda.current_stream()
+        if os.environ.get("VTM_AMD_NATIVE_LOOP", "1") != "0":      # the native loop: the same calls in the same order on the same streams
+            b = PisBuffers(org_ptr, dpb_ptr, self.buf["pred"].data_ptr(), self.buf["resi"].data_ptr(), self.buf["org_bi"].data_ptr() if self.is_b else None,
+                           self.buf["pred_c"].data_ptr() if self.chroma is not None else None, self.buf["resi_c"].data_ptr() if self.chroma is not None else None)
+            ctx.pis_run_picture(self.run_levels, len(self.levels), b, main.cuda_stream, [st.cuda_stream for st in self.side_streams])
+            return
         for i, lvl in enumerate(self.levels):
             self._uni(lvl, org_ptr, dpb_ptr)
             ev = T.cuda.Event()
