@@ -69,11 +69,9 @@ class ResultGather:
         i = self.n & 1
         if self.pending[i] is not None:
             self.pending[i].wait()
-        off = 0
-        for t in tensors:
-            self.send[i][off:off + t.numel()].copy_(t)
-            off += t.numel()
-        assert off == self.sizes[self.rank]
+        total = sum(t.numel() for t in tensors)
+        assert total == self.sizes[self.rank]
+        torch.cat(tensors, out=self.send[i][:total])      # one copy kernel for all result tables of the step
         self.pending[i] = dist.gather(self.send[i], self.recv[i] if self.rank == self.dst else None, dst=self.dst, async_op=True)
         self.n += 1
 
