@@ -101,6 +101,7 @@ int vtmhip_destroy( vtmhip_ctx *ctx )
   if( ctx->trTabBuf ) ( void ) hipFree( ctx->trTabBuf );
   if( ctx->pinned ) ( void ) hipHostFree( ctx->pinned );
   for( auto &t : ctx->timed ) { ( void ) hipEventDestroy( t.start ); ( void ) hipEventDestroy( t.stop ); }
+  for( hipEvent_t e : ctx->forkEvents ) ( void ) hipEventDestroy( e );
   if( ctx->evStart ) ( void ) hipEventDestroy( ctx->evStart );
   if( ctx->evStop ) ( void ) hipEventDestroy( ctx->evStop );
   if( ctx->ownStream ) ( void ) hipStreamDestroy( ctx->ownStream );
@@ -182,6 +183,7 @@ int vtmhip_timer_stop_ms( vtmhip_ctx *ctx, float *ms )
 static void clear_timed( vtmhip_ctx *ctx )
 {
   for( auto &t : ctx->timed ) { ( void ) hipEventDestroy( t.start ); ( void ) hipEventDestroy( t.stop ); }
+  for( hipEvent_t e : ctx->forkEvents ) ( void ) hipEventDestroy( e );
   ctx->timed.clear();
 }
 

@@ -39,6 +39,7 @@ struct vtmhip_ctx
   bool        timing      = false;
   struct TimedLaunch { const char *kernel; hipEvent_t start, stop; };
   std::vector<TimedLaunch> timed;
+  std::vector<hipEvent_t>  forkEvents;   // fork / join events of vtmhip_pis_run_picture (driver.hip): created on demand, reused by every picture, freed by vtmhip_destroy
 };
 
 // scope guard around a kernel launch: records start / stop events on ctx->stream when timing is on (bench.py's roofline: the dominant kernel's

@@ -8,10 +8,11 @@
 namespace
 {
 
-struct EventPool   // events of the fork / join: created on demand, kept by the context for its lifetime
+struct EventPool   // the context's fork / join events: created on demand (on the context's device), reused by every picture
 {
-  std::vector<hipEvent_t> ev;
-  size_t                  used = 0;
+  std::vector<hipEvent_t> &ev;
+  size_t                   used = 0;
+  explicit EventPool( std::vector<hipEvent_t> &v ) : ev( v ) {}
   hipEvent_t get()
   {
     if( used == ev.size() )
@@ -95,8 +96,7 @@ extern "C" int vtmhip_pis_run_picture( vtmhip_ctx *ctx, const vtmhip_pis_level_r
   VTMHIP_CHECK_CTX( ctx );
   VTMHIP_REQUIRE( ctx, levels && buf && numLevels >= 0 && numSide >= 0 && ( numSide == 0 || sideStreams ), "levels / buffers / streams" );
   VTMHIP_REQUIRE( ctx, buf->org && buf->dpb && buf->pred && buf->resi, "null picture buffer" );
-  static thread_local EventPool pool;   // (one context per thread: the pool follows the thread)
-  pool.used = 0;
+  EventPool pool( ctx->forkEvents );
   hipStream_t main = ( hipStream_t ) mainStream;
   int         st = VTMHIP_OK;
   ctx->stream = main;
