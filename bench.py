@@ -377,8 +377,8 @@ def main():
             return r
 
         out = {
-            "metric": "hot-path pictures/sec (3840x2160 randomaccess QP32; level-order predInterSearch: AMVP estimation, TZ + fractional ME per (list, refIdx), bi refinement, "
-                      "MC, residual xT/quant/xIT/SSE; not a full encode) + SATD Gblocks/s",
+            "metric": "hot-path pictures/sec (%dx%d %s QP%d; level-order predInterSearch: AMVP estimation, TZ + fractional ME per (list, refIdx), bi refinement, "
+                      "MC, residual xT/quant/xIT/SSE; not a full encode) + SATD Gblocks/s" % (W, H, "randomaccess" if a.config == "ra" else "lowdelay_P", qp),
             "value": a.steps / dt, "unit": "pictures/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int16 samples, int32 accumulation (fp64 MV-rate multiply)", "data": "synthetic",
