@@ -192,6 +192,38 @@ def test_frame_hot_path_affine_uni_stage(use_ref, name, pocs0, pocs1, cur, low_d
     ctx.close()
 
 
+def test_full_size_picture_is_deterministic_and_order_independent():
+    """BASELINE's picture size (3840x2160, 2 + 2 references, chroma + BDOF) through size-independent properties: the result tables of the native
+    level-major loop over six streams, of the step-by-step Python loop on one stream, and of a second run are identical byte for byte (no race between the
+    levels' chains, no dependence on atomics' order), and a spot check of PUs of every level against the oracle chain."""
+    torch = pytest.importorskip("torch")
+    from vtm_amd.device import Context
+    W, H = 3840, 2160
+    dev = torch.device("cuda", 0)
+    pocs0, pocs1, cur = [2, 0], [6, 8], 4
+    cur_np, dpb_np, refs, sr, cur_d, dpb, ch_dev, ch_cpu = make_scene(torch, dev, W, H, pocs0, pocs1, cur, hard=False, chroma=True)
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    lam, qp, pocs = 8.0, 32, (cur, pocs0, pocs1)
+    hp = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, pocs=pocs, chroma=ch_dev)
+
+    def tables():
+        torch.cuda.synchronize()
+        return [t.clone() for t in hp.result_tensors()] + [lvl["uni_rows"].clone() for lvl in hp.levels]
+    hp.run(cur_d.data_ptr(), dpb.data_ptr())                     # native loop, levels overlapping
+    a = tables()
+    hp.run(cur_d.data_ptr(), dpb.data_ptr())                     # again
+    b = tables()
+    hp.run(cur_d.data_ptr(), dpb.data_ptr(), timing=True)        # Python loop, one stream, stage by stage
+    c = tables()
+    for k, (x, y, z) in enumerate(zip(a, b, c)):
+        assert torch.equal(x, y), ("second run differs", k)
+        assert torch.equal(x, z), ("serial order differs", k)
+    assert sum(int(l["npu"]) for l in hp.snapshot()) == 172500
+    check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, None, per_level=3, min_checked=10, pocs=pocs, chroma=ch_cpu)
+    ctx.close()
+
+
 def test_ctu_sharding_union_equals_unsharded():
     """north_star: CTU rows of a frame shard across the GPUs.  Two ranks' tables (raster-scan CTU ranges; the boundary row is cut at a CTU) run
     one after the other on this GPU: the union of their per-PU / per-TU results is bit-identical to the unsharded picture."""
