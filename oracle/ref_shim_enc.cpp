@@ -53,6 +53,7 @@ struct RefEncStats
   int32_t  hookFirstMismatch[8];
   uint64_t affineCalls, affineDevice, affineMismatch, affineUnsupported;
   uint64_t lfnstCalls[2], lfnstDevice[2], lfnstMismatch[2];   // TrQuant::xFwdLfnst / xInvLfnst (gather + core multiply + scatter) as vtmhip_lfnst_tu_batch_dev   // InterSearch::xAffineMotionEstimation as one vtmhip_xAffineMotionEstimation_batch_dev call
+  uint64_t amvpCalls, amvpDevice, amvpMismatch, amvpUnsupported;   // InterSearch::xEstimateMvPredAMVP's candidate selection as one vtmhip_xEstimateMvPredAMVP_batch_dev call (hook B7)
 };
 }
 
@@ -89,6 +90,7 @@ struct Api
   decltype( &vtmhip_xAffineMotionEstimation_batch_dev ) affineMe;
   decltype( &vtmhip_lfnst_set_tables )             lfnstTables;
   decltype( &vtmhip_lfnst_tu_batch_dev )           lfnstTu;
+  decltype( &vtmhip_xEstimateMvPredAMVP_batch_dev ) amvp;
 } A;
 
 vtmhip_ctx  *g_ctx = nullptr;
@@ -426,12 +428,14 @@ void restoreAux()
 }   // namespace
 extern "C" void vtmref_orig_xMotionEstimation( InterSearch *, PredictionUnit &, PelUnitBuf &, RefPicList, Mv &, int, Mv &, int &, uint32_t &, Distortion &, const AMVPInfo &, bool );
 extern "C" void vtmref_orig_xAffineMotionEstimation( InterSearch *, PredictionUnit &, PelUnitBuf &, RefPicList, Mv *, int, Mv *, uint32_t &, Distortion &, int &, const AffineAMVPInfo &, bool );
+extern "C" void vtmref_orig_xEstimateMvPredAMVP( InterSearch *, PredictionUnit &, PelUnitBuf &, RefPicList, int, Mv &, AMVPInfo &, bool, Distortion * );
 extern "C" void vtmref_orig_xFwdLfnst( TrQuant *, const TransformUnit &, const ComponentID, const bool );
 extern "C" void vtmref_orig_xInvLfnst( TrQuant *, const TransformUnit &, const ComponentID );
 extern "C" void vtmref_orig_transformNxN_select( TrQuant *, TransformUnit &, const ComponentID &, const QpParam &, std::vector<TrMode> *, const int );
 namespace
 {
-bool     g_hookMe = false, g_hookMts = false, g_hookAffine = false, g_hookLfnst = false;
+bool     g_hookMe = false, g_hookMts = false, g_hookAffine = false, g_hookLfnst = false, g_hookAmvp = false;
+uint64_t g_amvpCtr = 0;
 uint64_t g_lfnstCtr[2] = { 0, 0 };
 uint64_t g_affineCtr = 0;
 uint64_t g_hookCtr[2] = { 0, 0 }, g_hookStride = 0;   // VTMREF_HOOK_STRIDE: the hooks' own sampling stride (default: the tables' stride)
@@ -558,6 +562,56 @@ void meHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPicLis
   rcMv.hor = o.mvHor; rcMv.ver = o.mvVer; rcMvPred.hor = o.mvPredHor; rcMvPred.ver = o.mvPredVer; riMVPIdx = o.mvpIdx; ruiBits = o.bits; ruiCost = o.cost;
 }
 
+
+// InterSearch::xEstimateMvPredAMVP (InterSearch.cpp:3088-3128): the candidate list needs the CU context (PU::fillMvpCand) and stays with the reference; the
+// template cost of every candidate (xGetTemplateCost: prediction at the clipped candidate + SAD + index rate) and the selection run on the device
+void amvpHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPicList eRefPicList, int iRefIdx, Mv &rcMvPred, AMVPInfo &info, bool bFilled, Distortion *puiDistBiP )
+{
+  g_st->amvpCalls++;
+  vtmref_orig_xEstimateMvPredAMVP( is, pu, origBuf, eRefPicList, iRefIdx, rcMvPred, info, bFilled, puiDistBiP );
+  const Slice   &slice  = *pu.cu->slice;
+  const Picture *refPic = slice.getRefPic( eRefPicList, iRefIdx );
+  const int      w = pu.Y().width, h = pu.Y().height;
+  const bool unsupported = slice.testWeightPred() || slice.testWeightBiPred() || refPic->isWrapAroundEnabled( pu.cs->pps ) || refPic->isRefScaled( pu.cs->pps ) || w > 128 || h > 128
+                        || info.numCand < 1 || info.numCand > 2 || slice.getSPS()->getBitDepth( CHANNEL_TYPE_LUMA ) > 10 || !puiDistBiP;
+  if( unsupported ) g_st->amvpUnsupported++;
+  if( unsupported || !hookSampled( g_amvpCtr ) ) return;
+  vtmhip_me_job j; memset( &j, 0, sizeof( j ) );
+  const RefPlane *rp = refPlane( refPic );
+  const CPelBuf   org = origBuf.Y();
+  std::vector<Pel> blk( size_t( w ) * h );
+  for( int y = 0; y < h; y++ ) memcpy( &blk[size_t( y ) * w], org.buf + ptrdiff_t( y ) * org.stride, sizeof( Pel ) * w );
+  const Position pos = pu.cu->lumaPos();
+  j.orgOff = 0; j.orgStride = w;
+  j.refOff = rp ? ( int64_t ) ( rp->margin + pu.Y().y ) * rp->stride + rp->margin + pu.Y().x : 0; j.refStride = rp ? rp->stride : 0;
+  j.puX = ( int16_t ) pos.x; j.puY = ( int16_t ) pos.y; j.width = ( int16_t ) w; j.height = ( int16_t ) h;
+  j.imv = pu.cu->imv; j.numAmvpCand = ( uint8_t ) info.numCand;
+  for( int i = 0; i < info.numCand; i++ )
+  {
+    j.amvpCand[i][0] = info.mvCand[i].hor; j.amvpCand[i][1] = info.mvCand[i].ver;
+    j.mvpIdxBits[i] = is->m_auiMVPIdxCost[i][AMVP_MAX_NUM_CANDS];
+  }
+  j.motionLambda = is->m_pcRdCost->m_motionLambda;
+  vtmhip_pic_params pic; memset( &pic, 0, sizeof( pic ) );
+  pic.picW = pu.cs->pps->getPicWidthInLumaSamples(); pic.picH = pu.cs->pps->getPicHeightInLumaSamples(); pic.ctuSize = pu.cs->sps->getMaxCUWidth();
+  pic.bitDepth = slice.getSPS()->getBitDepth( CHANNEL_TYPE_LUMA );
+  uint64_t dist = 0;
+  const bool ok = rp && A.h2d( g_ctx, d_hOrg, blk.data(), blk.size() * 2 ) == VTMHIP_OK && A.h2d( g_ctx, d_hJob, &j, sizeof( j ) ) == VTMHIP_OK
+               && A.amvp( g_ctx, &pic, d_hOrg, rp->dev, ( vtmhip_me_job * ) d_hJob, 1, w, h, 0, 0, ( uint64_t * ) d_hOut ) == VTMHIP_OK
+               && A.d2h( g_ctx, &j, d_hJob, sizeof( j ) ) == VTMHIP_OK && A.d2h( g_ctx, &dist, d_hOut, sizeof( dist ) ) == VTMHIP_OK;
+  if( !ok ) { note_error(); return; }
+  g_st->amvpDevice++;
+  if( j.mvpIdx != pu.mvpIdx[eRefPicList] || j.mvPredHor != rcMvPred.hor || j.mvPredVer != rcMvPred.ver || dist != *puiDistBiP )
+  {
+    if( g_st->amvpMismatch++ == 0 && g_st->hookMismatch[0] + g_st->hookMismatch[1] == 0 )
+    {
+      const int32_t v[8] = { 3, w * 1000 + h, info.numCand * 10 + pu.cu->imv, j.mvpIdx - pu.mvpIdx[eRefPicList], j.mvPredHor - rcMvPred.hor, ( int32_t ) *puiDistBiP, ( int32_t ) dist, 0 };
+      memcpy( g_st->hookFirstMismatch, v, sizeof( v ) );
+    }
+  }
+  // the encoder continues with the device's choice
+  rcMvPred.hor = j.mvPredHor; rcMvPred.ver = j.mvPredVer; pu.mvpIdx[eRefPicList] = j.mvpIdx; *puiDistBiP = dist;
+}
 
 void affineHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPicList eRefPicList, Mv acMvPred[3], int iRefIdxPred, Mv acMv[3], uint32_t &ruiBits, Distortion &ruiCost,
                  int &mvpIdx, const AffineAMVPInfo &aamvpi, bool bBi )
@@ -726,6 +780,11 @@ void InterSearch::xAffineMotionEstimation( PredictionUnit &pu, PelUnitBuf &origB
   if( g_hookAffine ) affineHook( this, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi );
   else vtmref_orig_xAffineMotionEstimation( this, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi );
 }
+void InterSearch::xEstimateMvPredAMVP( PredictionUnit &pu, PelUnitBuf &origBuf, RefPicList eRefPicList, int iRefIdx, Mv &rcMvPred, AMVPInfo &amvpInfo, bool bFilled, Distortion *puiDistBiP )
+{
+  if( g_hookAmvp ) amvpHook( this, pu, origBuf, eRefPicList, iRefIdx, rcMvPred, amvpInfo, bFilled, puiDistBiP );
+  else vtmref_orig_xEstimateMvPredAMVP( this, pu, origBuf, eRefPicList, iRefIdx, rcMvPred, amvpInfo, bFilled, puiDistBiP );
+}
 void TrQuant::xFwdLfnst( const TransformUnit &tu, const ComponentID compID, const bool loadTr )
 {
   if( g_hookLfnst ) lfnstHook( this, tu, compID, false, loadTr ); else vtmref_orig_xFwdLfnst( this, tu, compID, loadTr );
@@ -759,7 +818,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
                  && sym( A.dalloc, "vtmhip_dev_alloc" ) && sym( A.dfree, "vtmhip_dev_free" ) && sym( A.h2d, "vtmhip_h2d" ) && sym( A.d2h, "vtmhip_d2h" )
                  && sym( A.addAvg, "vtmhip_add_avg_batch_dev" ) && sym( A.rhf, "vtmhip_remove_high_freq_batch_dev" )
                  && sym( A.sobel, "vtmhip_affine_sobel_batch_dev" ) && sym( A.eqc, "vtmhip_affine_equal_coeff_batch_dev" )
-                 && sym( A.me, "vtmhip_xMotionEstimation_batch_dev" ) && sym( A.xT, "vtmhip_xT_batch_dev" ) && sym( A.tsChain, "vtmhip_tu_ts_chain_batch_dev" )
+                 && sym( A.amvp, "vtmhip_xEstimateMvPredAMVP_batch_dev" ) && sym( A.me, "vtmhip_xMotionEstimation_batch_dev" ) && sym( A.xT, "vtmhip_xT_batch_dev" ) && sym( A.tsChain, "vtmhip_tu_ts_chain_batch_dev" )
                  && sym( A.mtsSelect, "vtmhip_mts_select2" ) && sym( A.affineMe, "vtmhip_xAffineMotionEstimation_batch_dev" )
                  && sym( A.lfnstTables, "vtmhip_lfnst_set_tables" ) && sym( A.lfnstTu, "vtmhip_lfnst_tu_batch_dev" );
     if( !ok ) { fprintf( stderr, "ref_encode: libvtmhip.so lacks a pointer-surface symbol\n" ); return -11; }
@@ -786,7 +845,8 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
         if( g_mask & 2 ) installIf( app->m_cEncLib.m_cInterSearch.m_if );
         if( g_mask & 4 ) installTr();
         if( ( g_mask & 16 ) && ( g_countOnly || auxAlloc() ) ) installAux( (AffineGradientSearch &) app->m_cEncLib.m_cInterSearch );   // private base: C-style cast
-        if( ( g_mask & ( 96 | 128 | 256 ) ) && ( g_countOnly || ( g_ctx && hookAlloc() ) ) ) { g_hookAffine = ( g_mask & 128 ) != 0; g_affineCtr = 0;
+        if( ( g_mask & ( 96 | 128 | 256 | 512 ) ) && ( g_countOnly || ( g_ctx && hookAlloc() ) ) ) { g_hookAffine = ( g_mask & 128 ) != 0; g_affineCtr = 0;
+          g_hookAmvp = ( g_mask & 512 ) != 0 && !g_countOnly; g_amvpCtr = 0;
           g_hookLfnst = ( g_mask & 256 ) != 0 && ( g_countOnly || A.lfnstTables( g_ctx, &g_lfnst8x8[0][0][0][0], &g_lfnst4x4[0][0][0][0] ) == VTMHIP_OK ); g_lfnstCtr[0] = g_lfnstCtr[1] = 0; g_hookMe = ( g_mask & 32 ) != 0; g_hookMts = ( g_mask & 64 ) != 0; g_hookCtr[0] = g_hookCtr[1] = 0;
           g_hookStride = getenv( "VTMREF_HOOK_STRIDE" ) ? strtoull( getenv( "VTMREF_HOOK_STRIDE" ), nullptr, 10 ) : 0; }
       }
@@ -801,7 +861,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
     }
   }
   catch( Exception &e ) { fprintf( stderr, "ref_encode: %s\n", e.what() ); rc = 2; }
-  g_hookMe = g_hookMts = g_hookAffine = g_hookLfnst = false;
+  g_hookMe = g_hookMts = g_hookAffine = g_hookLfnst = g_hookAmvp = false;
   for( RefPlane &p : g_planes ) A.dfree( g_ctx, p.dev );
   g_planes.clear();
   if( g_ctx || g_countOnly ) { restoreDist(); restoreTr(); restoreAux(); }
