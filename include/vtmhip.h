@@ -672,6 +672,60 @@ int vtmhip_xAffineMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_
 int vtmhip_xPredAffineBlk_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_refBase, int16_t *d_dstBase,
                                      const vtmhip_affine_me_job *d_jobs, int n, int maxWidth, int maxHeight );
 
+/* ---- symmetric MVD search (SMVD) of predInterSearch (InterSearch.cpp:2656-2790) -----------------------------------------------------
+ * One job = one PU with its two symmetric reference pictures: [0] the searched list (list 0 in predInterSearch :2662), [1] the mirrored list.
+ *   op VTMHIP_SMVD_COST      InterSearch::xGetSymmetricCost (:4341-4391): cost = floor( fWeight * HAD-or-SAD( clip?( 2 * org - predA( mvCur ) ), predB( mvTar ) ) ),
+ *                            each vector clipped (clipMv), integer vectors = the reconstruction, others xPredInterBlk (uni-directional, rounded, clipped);
+ *                            BCW weights other than the default use removeWeightHighFreq and fWeight = |w| / 8 (xGetMEDistortionWeight :7666-7676)
+ *   op VTMHIP_SMVD_ME        InterSearch::xSymmetricMotionEstimation (:4506-4518) with xSymmeticRefineMvSearch (:4393-4503): 8 >> imv diamond rounds and one
+ *                            cross round of one AMVR step around mvCur, the mirrored vector predSym[1] - ( mv - predSym[0] ); in / out mvCur, mvTar, cost
+ *   op VTMHIP_SMVD_CHECK_MVP InterSearch::symmvdCheckBestMvp (:7787-7886) for curMv = mvCur: every (i, j) of the two AMVP lists (skip != 0: but the current
+ *                            pair); in / out predSym, mvpIdxSym, cost
+ *   op VTMHIP_SMVD_SEARCH    the whole block :2656-2790: shortened AMVP lists (:2668-2671), best predictor pair, the distinct start vectors (starts[0..numFixed)
+ *                            as they are = cMvHevcTemp, cMvTemp[, cMvBi]; the rest = m_uniMvList entries newest first, rounded to the AMVR precision, while
+ *                            fewer than 5 are collected), symmvdCheckBestMvp per start, the search, the final predictor check, + getCost( modeBits );
+ *                            out mvCur, mvTar, predSym, mvpIdxSym, cost (= symCost, to be compared with uiCostBi by the caller)
+ * No MCTS constraint, no weighted prediction / RPR / wrap-around (the host keeps those PUs). */
+#define VTMHIP_SMVD_COST 0
+#define VTMHIP_SMVD_ME 1
+#define VTMHIP_SMVD_CHECK_MVP 2
+#define VTMHIP_SMVD_SEARCH 3
+#define VTMHIP_SMVD_MAX_START 16
+typedef struct
+{
+  int64_t  orgOff;                 /* origBuf.Y() inside d_orgBase */
+  int64_t  refOff[2];              /* PU position with MV (0,0) inside d_refBase: [0] searched list, [1] mirrored list */
+  int32_t  orgStride, refStride[2];
+  int16_t  puX, puY, width, height;
+  uint8_t  imv;                    /* cu.imv: 0 quarter, 1 integer, 2 four-sample, 3 half (alternative half-sample filter) */
+  uint8_t  useSatd;                /* !slice.getDisableSATDForRD() */
+  uint8_t  clipBiPred;             /* cfg ClipForBiPredMEEnabled */
+  int8_t   bcwWeightTar;           /* getBcwWeight( cu.BcwIdx, mirrored list ): 0 or 4 = default */
+  uint8_t  numCand[2];             /* AMVP lists of the two symmetric references */
+  uint8_t  numStart, numFixed;     /* SEARCH: start vectors */
+  uint8_t  skip;                   /* CHECK_MVP */
+  uint8_t  pad_[3];
+  int32_t  cand[2][2][2];          /* [list][i][hor / ver] */
+  uint32_t mvpIdxBits[2];          /* m_auiMVPIdxCost[i][AMVP_MAX_NUM_CANDS] */
+  uint32_t modeBits;               /* SEARCH: uiMbBits[2] + 1 + BCW index bits (:2782-2785) */
+  double   motionLambda;
+  int32_t  starts[VTMHIP_SMVD_MAX_START][2];
+  /* in / out */
+  int32_t  mvCur[2], mvTar[2];
+  int32_t  predSym[2][2];          /* cMvPredSym */
+  int32_t  mvpIdxSym[2];
+  uint64_t cost;
+} vtmhip_smvd_job;
+int vtmhip_smvd_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, vtmhip_smvd_job *d_jobs, int n,
+                           int maxWidth, int maxHeight, int op );
+/* the reference's names for the four ops */
+int vtmhip_xGetSymmetricCost_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, vtmhip_smvd_job *d_jobs,
+                                        int n, int maxWidth, int maxHeight );
+int vtmhip_xSymmetricMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                                 vtmhip_smvd_job *d_jobs, int n, int maxWidth, int maxHeight );
+int vtmhip_symmvdCheckBestMvp_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, vtmhip_smvd_job *d_jobs,
+                                         int n, int maxWidth, int maxHeight );
+
 /* ================================================================================================================
  * (3) LEVEL-ORDER DRIVER SUPPORT -- whole functions per batch and the glue between them, decisions kept on the device
  * ============================================================================================================== */

@@ -979,3 +979,118 @@ extern "C" void ref_lfnst_scan( int w, int h, int32_t *pos48 )
   const ScanElement *scan = whge3 ? g_coefTopLeftDiagScan8x8[gp_sizeIdxInfo->idxFrom( w )] : g_scanOrder[SCAN_GROUPED_4x4][SCAN_DIAG][gp_sizeIdxInfo->idxFrom( w )][gp_sizeIdxInfo->idxFrom( h )];
   for( int k = 0; k < ( whge3 ? 48 : 16 ); k++ ) pos48[k] = scan[k].idx;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// SMVD: the real InterSearch::xGetSymmetricCost / xSymmetricMotionEstimation / symmvdCheckBestMvp (InterSearch.cpp:4341-4518, 7787-7886) on
+// caller-supplied planes.  The searched list is list 0 (as in predInterSearch :2662), its symmetric reference index 0 in both lists.
+// ------------------------------------------------------------------------------------------------------------------
+namespace
+{
+void smvdSetup( MeRig &r, const vo_smvd_job_t *j, PelUnitBuf &origBuf )
+{
+  static Picture *pic[2] = { nullptr, nullptr };
+  const UnitArea  lcu( CHROMA_400, Area( 0, 0, MAX_CU_SIZE, MAX_CU_SIZE ) );
+  if( r.is.m_tmpStorageLCU.bufs.empty() ) r.is.m_tmpStorageLCU.create( lcu );
+  if( r.is.m_tmpPredStorage[0].bufs.empty() ) r.is.m_tmpPredStorage[0].create( lcu );
+  if( r.is.m_tmpPredStorage[1].bufs.empty() ) r.is.m_tmpPredStorage[1].create( lcu );
+  r.sps.setMaxCUWidth( j->ctuSize );
+  r.sps.setMaxCUHeight( j->ctuSize );
+  r.sps.setBitDepth( CHANNEL_TYPE_LUMA, j->bitDepth );
+  r.sps.setUseBcw( j->bcwWeightTar != 4 );
+  r.pps.setPicWidthInLumaSamples( j->picW );
+  r.pps.setPicHeightInLumaSamples( j->picH );
+  r.pps.setUseWP( false );
+  r.pps.setWPBiPred( false );
+  r.slice.setPPS( &r.pps );
+  r.slice.setSPS( &r.sps );
+  r.slice.setSliceType( B_SLICE );
+  r.slice.setDisableSATDForRD( !j->useSatd );
+  r.slice.m_symRefIdx[0] = r.slice.m_symRefIdx[1] = 0;
+  const UnitArea ua( CHROMA_400, Area( j->puX, j->puY, j->w, j->h ) );
+  r.cu.UnitArea::operator=( ua );
+  r.pu.UnitArea::operator=( ua );
+  r.cu.chromaFormat = CHROMA_400;
+  r.pu.chromaFormat = CHROMA_400;
+  r.cu.imv    = j->imv;
+  r.cu.affine = false;
+  r.cu.BcwIdx = BCW_DEFAULT;
+  for( int i = 0; i < BCW_NUM; i++ ) if( g_BcwWeights[i] == j->bcwWeightTar ) r.cu.BcwIdx = ( uint8_t ) i;
+  r.cfg.setClipForBiPredMeEnabled( j->clipBiPred != 0 );
+  r.cfg.setMCTSEncConstraint( false );
+  r.rd.m_motionLambda = j->motionLambda;
+  ClpRng clp; clp.min = 0; clp.max = ( 1 << j->bitDepth ) - 1; clp.bd = j->bitDepth; clp.n = 0;
+  r.slice.m_clpRngs.comp[COMPONENT_Y] = clp;
+  for( int l = 0; l < 2; l++ )
+  {
+    if( !pic[l] ) pic[l] = new Picture();
+    Pel *origin = const_cast<Pel *>( j->ref[l] ) - ( ptrdiff_t ) j->puY * j->refStride[l] - j->puX;
+    pic[l]->chromaFormat = CHROMA_400;
+    pic[l]->unscaledPic  = pic[l];
+    pic[l]->m_bufs[PIC_RECONSTRUCTION].createFromBuf( PelUnitBuf( CHROMA_400, PelBuf( origin, j->refStride[l], j->picW, j->picH ) ) );
+    r.slice.m_apcRefPicList[l][0] = pic[l];
+  }
+  for( int i = 0; i < 2; i++ ) r.is.m_auiMVPIdxCost[i][AMVP_MAX_NUM_CANDS] = j->mvpIdxBits[i];
+  origBuf = PelUnitBuf( CHROMA_400, PelBuf( const_cast<Pel *>( j->org ), j->orgStride, j->w, j->h ) );
+}
+void smvdRestore( MeRig &r )
+{
+  r.cu.imv = 0; r.cu.BcwIdx = BCW_DEFAULT;
+  r.slice.setDisableSATDForRD( false );
+  r.cfg.setClipForBiPredMeEnabled( false );
+  r.sps.setUseBcw( false );
+  r.cu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+  r.pu.UnitArea::operator=( UnitArea( CHROMA_420, Area( 0, 0, 8, 8 ) ) );
+  r.cu.chromaFormat = CHROMA_420;
+  r.pu.chromaFormat = CHROMA_420;
+}
+}   // namespace
+
+extern "C" uint64_t ref_symmetric_cost( const vo_smvd_job_t *j, const int mvCur[2], const int mvTar[2] )
+{
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  PelUnitBuf origBuf;
+  smvdSetup( r, j, origBuf );
+  MvField cur, tar;
+  cur.setMvField( Mv( mvCur[0], mvCur[1] ), 0 ); tar.setMvField( Mv( mvTar[0], mvTar[1] ), 0 );
+  const Distortion d = r.is.xGetSymmetricCost( r.pu, origBuf, REF_PIC_LIST_0, cur, tar, r.cu.BcwIdx );
+  smvdRestore( r );
+  return d;
+}
+
+extern "C" void ref_symmetric_me( const vo_smvd_job_t *j, const int predCur[2], const int predTar[2], int mvCur[2], int mvTar[2], uint64_t *cost )
+{
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  PelUnitBuf origBuf;
+  smvdSetup( r, j, origBuf );
+  Mv pc( predCur[0], predCur[1] ), pt( predTar[0], predTar[1] );
+  MvField cur, tar;
+  cur.setMvField( Mv( mvCur[0], mvCur[1] ), 0 ); tar.setMvField( Mv( mvTar[0], mvTar[1] ), 0 );
+  Distortion c = *cost;
+  r.is.xSymmetricMotionEstimation( r.pu, origBuf, pc, pt, REF_PIC_LIST_0, cur, tar, c, r.cu.BcwIdx );
+  mvCur[0] = cur.mv.hor; mvCur[1] = cur.mv.ver; mvTar[0] = tar.mv.hor; mvTar[1] = tar.mv.ver; *cost = c;
+  smvdRestore( r );
+}
+
+extern "C" void ref_symmvd_check_best_mvp( const vo_smvd_job_t *j, const int curMv[2], int skip, int predSym[2][2], int mvpIdxSym[2], uint64_t *bestCost )
+{
+  if( !g_rig ) g_rig = new MeRig();
+  MeRig &r = *g_rig;
+  PelUnitBuf origBuf;
+  smvdSetup( r, j, origBuf );
+  static AMVPInfo ( *amvp )[33] = nullptr;
+  if( !amvp ) amvp = new AMVPInfo[2][33];
+  for( int l = 0; l < 2; l++ )
+  {
+    amvp[l][0].numCand = j->numCand[l];
+    for( int i = 0; i < 2; i++ ) amvp[l][0].mvCand[i] = Mv( j->cand[l][i][0], j->cand[l][i][1] );
+  }
+  Mv      pred[2] = { Mv( predSym[0][0], predSym[0][1] ), Mv( predSym[1][0], predSym[1][1] ) };
+  int32_t idx[2]  = { mvpIdxSym[0], mvpIdxSym[1] };
+  Distortion c = *bestCost;
+  r.is.symmvdCheckBestMvp( r.pu, origBuf, Mv( curMv[0], curMv[1] ), REF_PIC_LIST_0, amvp, r.cu.BcwIdx, pred, idx, c, skip != 0 );
+  for( int l = 0; l < 2; l++ ) { predSym[l][0] = pred[l].hor; predSym[l][1] = pred[l].ver; mvpIdxSym[l] = idx[l]; }
+  *bestCost = c;
+  smvdRestore( r );
+}

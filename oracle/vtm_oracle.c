@@ -2170,3 +2170,188 @@ void vo_lfnst_tu( int32_t *coef, int w, int h, const int8_t *M, int transpose, i
       }
   }
 }
+
+/* ---- symmetric MVD (SMVD) search of predInterSearch ----------------------------------------------------------------------------------
+ * InterSearch::xGetSymmetricCost (InterSearch.cpp:4341-4391), xSymmeticRefineMvSearch (:4393-4503), xSymmetricMotionEstimation (:4506-4518),
+ * symmvdCheckBestMvp (:7787-7886) and the SMVD block of predInterSearch that composes them (:2656-2790).  No MCTS constraint, no weighted
+ * prediction.  "cur" is the searched list (list 0 in predInterSearch), "tar" the mirrored one. */
+static void vo_smvd_pred( const vo_smvd_job_t *j, int l, const int mv[2], int16_t *dst )
+{
+  int h = mv[0], v = mv[1];
+  vo_clip_mv_pic( &h, &v, j->picW, j->picH, j->ctuSize, j->puX, j->puY );
+  /* integer vectors alias the reconstruction (:4351-4358), others go through xPredInterBlk (uni-directional: rounded and clipped) -- the copy is the same samples */
+  vo_mc_luma( j->ref[l], j->refStride[l], j->w, j->h, h, v, 0, j->bitDepth, j->imv == 3, dst, j->w );
+}
+
+static void vo_smvd_pattern( const vo_smvd_job_t *j, const int16_t *predA, int16_t *pat )
+{
+  /* bufTmp.copyFrom( origBuf ); bufTmp.removeHighFreq( predBufA, clip, clpRngs, getBcwWeight( BcwIdx, tarList ) ) (Buffer.h:417-520, 946-957) */
+  const int w = j->w, h = j->h, maxV = ( 1 << j->bitDepth ) - 1;
+  for( int y = 0; y < h; y++ ) memcpy( pat + y * w, j->org + ( ptrdiff_t ) y * j->orgStride, sizeof( int16_t ) * w );
+  if( j->bcwWeightTar != 4 ) vo_remove_weight_high_freq( pat, w, predA, w, w, h, j->bcwWeightTar );
+  else vo_remove_high_freq( pat, w, predA, w, w, h );
+  if( j->clipBiPred )
+  {
+    /* the clipped forms clip the int result before the store */
+    const int bw = j->bcwWeightTar;
+    const int normalizer = bw != 4 ? ( ( 1 << 16 ) + ( bw > 0 ? ( bw >> 1 ) : -( bw >> 1 ) ) ) / bw : 0;
+    for( int y = 0; y < h; y++ )
+      for( int x = 0; x < w; x++ )
+      {
+        const int o = j->org[( ptrdiff_t ) y * j->orgStride + x], p = predA[y * w + x];
+        const int v = bw != 4 ? ( o * ( normalizer * 8 ) - p * ( ( 8 - bw ) * normalizer ) + ( 1 << 15 ) ) >> 16 : 2 * o - p;
+        pat[y * w + x] = ( int16_t ) vo_clip3( 0, maxV, v );
+      }
+  }
+}
+
+static uint64_t vo_smvd_dist( const vo_smvd_job_t *j, const int16_t *pat, const int16_t *predB )
+{
+  const double   fWeight = j->bcwWeightTar != 4 ? fabs( ( double ) j->bcwWeightTar / 8.0 ) : 0.5;   /* xGetMEDistortionWeight :7666-7676 */
+  const uint64_t d = j->useSatd ? vo_satd( pat, j->w, predB, j->w, j->w, j->h ) : vo_sad( pat, j->w, predB, j->w, j->w, j->h, 0 );
+  return ( uint64_t ) floor( fWeight * ( double ) d );
+}
+
+uint64_t vo_symmetric_cost( const vo_smvd_job_t *j, const int mvCur[2], const int mvTar[2] )
+{
+  int16_t *buf = ( int16_t * ) malloc( sizeof( int16_t ) * 3 * j->w * j->h );
+  int16_t *a = buf, *b = buf + j->w * j->h, *pat = b + j->w * j->h;
+  vo_smvd_pred( j, 0, mvCur, a );
+  vo_smvd_pred( j, 1, mvTar, b );
+  vo_smvd_pattern( j, a, pat );
+  const uint64_t c = vo_smvd_dist( j, pat, b );
+  free( buf );
+  return c;
+}
+
+static unsigned vo_smvd_mv_bits( const vo_smvd_job_t *j, const int mv[2], const int pred[2] )
+{
+  /* pred / mv .changeTransPrecInternal2Amvr( imv ); getBitsOfVectorWithPredictor( hor, ver, 0 ) at cost scale 0 */
+  const int sh = vo_amvr_shift( j->imv );
+  return vo_eg_bits( vo_prec_down( mv[0], sh ) - vo_prec_down( pred[0], sh ) ) + vo_eg_bits( vo_prec_down( mv[1], sh ) - vo_prec_down( pred[1], sh ) );
+}
+
+static uint64_t vo_smvd_refine( const vo_smvd_job_t *j, const int predCur[2], const int predTar[2], int mvCur[2], int mvTar[2], uint64_t minCost, int pattern,
+                                int stepShift, unsigned maxRounds )
+{
+  static const int cross[4][2]   = { { 0, 1 }, { 1, 0 }, { 0, -1 }, { -1, 0 } };
+  static const int diamond[8][2] = { { 0, 2 }, { 1, 1 }, { 2, 0 }, { 1, -1 }, { 0, -2 }, { -1, -1 }, { -2, 0 }, { -1, 1 } };
+  const int ( *off )[2] = pattern == 0 ? cross : diamond;
+  const int rounding = pattern == 0 ? 4 : 8, mask = rounding - 1;
+  int       start = 0, end = pattern == 0 ? 3 : 7;
+  for( unsigned round = 0; round < maxRounds; round++ )
+  {
+    int       bestDirect = -1;
+    const int centre[2]  = { mvCur[0], mvCur[1] };
+    for( int idx = start; idx <= end; idx++ )
+    {
+      const int direct  = ( idx + rounding ) & mask;
+      const int cand[2] = { centre[0] + ( off[direct][0] << stepShift ), centre[1] + ( off[direct][1] << stepShift ) };
+      const int pair[2] = { predTar[0] - ( cand[0] - predCur[0] ), predTar[1] - ( cand[1] - predCur[1] ) };
+      uint64_t  cost    = ( uint64_t ) ( j->motionLambda * vo_smvd_mv_bits( j, cand, predCur ) );
+      cost += vo_symmetric_cost( j, cand, pair );
+      if( cost < minCost ) { minCost = cost; mvCur[0] = cand[0]; mvCur[1] = cand[1]; mvTar[0] = pair[0]; mvTar[1] = pair[1]; bestDirect = direct; }
+    }
+    if( bestDirect == -1 ) break;
+    const int step = pattern == 2 ? 2 - ( bestDirect & 1 ) : 1;
+    start = bestDirect - step; end = bestDirect + step;
+  }
+  return minCost;
+}
+
+void vo_symmetric_me( const vo_smvd_job_t *j, const int predCur[2], const int predTar[2], int mvCur[2], int mvTar[2], uint64_t *cost )
+{
+  /* :4506-4518: step = one AMVR unit, 8 >> imv diamond rounds (pattern 2), then one cross round (pattern 0) */
+  const int stepShift = 2 + ( j->imv == 3 ? 1 : ( j->imv << 1 ) );
+  *cost = vo_smvd_refine( j, predCur, predTar, mvCur, mvTar, *cost, 2, stepShift, 8u >> j->imv );
+  *cost = vo_smvd_refine( j, predCur, predTar, mvCur, mvTar, *cost, 0, stepShift, 1 );
+}
+
+void vo_symmvd_check_best_mvp( const vo_smvd_job_t *j, const int curMv[2], int skip, int predSym[2][2], int mvpIdxSym[2], uint64_t *bestCost )
+{
+  const int w = j->w, h = j->h;
+  int16_t  *buf = ( int16_t * ) malloc( sizeof( int16_t ) * 3 * w * h );
+  int16_t  *a = buf, *b = buf + w * h, *pat = b + w * h;
+  vo_smvd_pred( j, 0, curMv, a );
+  vo_smvd_pattern( j, a, pat );
+  const int skip0 = skip ? mvpIdxSym[0] : -1, skip1 = skip ? mvpIdxSym[1] : -1;
+  for( int i = 0; i < j->numCand[0]; i++ )
+    for( int k = 0; k < j->numCand[1]; k++ )
+    {
+      if( skip0 == i && skip1 == k ) continue;
+      const int tar[2] = { j->cand[1][k][0] - curMv[0] + j->cand[0][i][0], j->cand[1][k][1] - curMv[1] + j->cand[0][i][1] };   /* Mv::getSymmvdMv */
+      vo_smvd_pred( j, 1, tar, b );
+      uint64_t       cost = vo_smvd_dist( j, pat, b );
+      const unsigned bits = vo_smvd_mv_bits( j, curMv, j->cand[0][i] ) + j->mvpIdxBits[i] + j->mvpIdxBits[k];
+      cost += ( uint64_t ) ( j->motionLambda * bits );
+      if( cost < *bestCost )
+      {
+        *bestCost = cost;
+        predSym[0][0] = j->cand[0][i][0]; predSym[0][1] = j->cand[0][i][1]; predSym[1][0] = j->cand[1][k][0]; predSym[1][1] = j->cand[1][k][1];
+        mvpIdxSym[0] = i; mvpIdxSym[1] = k;
+      }
+    }
+  free( buf );
+}
+
+void vo_smvd_search( const vo_smvd_job_t *job, int numFixed, int numStart, const int starts[][2], unsigned modeBits, vo_smvd_result_t *res )
+{
+  /* predInterSearch :2656-2790 (curRefList = list 0).  starts: cMvHevcTemp, cMvTemp, [cMvBi] (numFixed, taken as they are), then the m_uniMvList
+   * entries newest first (rounded to the AMVR precision, while fewer than 5 distinct candidates are collected).  modeBits: uiMbBits[2] + 1 + BCW index bits */
+  vo_smvd_job_t jj = *job;
+  vo_smvd_job_t *j = &jj;
+  for( int l = 0; l < 2; l++ )
+    if( j->numCand[l] > 1 && j->cand[l][0][0] == j->cand[l][1][0] && j->cand[l][0][1] == j->cand[l][1][1] ) j->numCand[l] = 1;   /* :2668-2671 */
+  int      predSym[2][2] = { { 0, 0 }, { 0, 0 } }, mvpIdxSym[2] = { 0, 0 };
+  uint64_t costStart = UINT64_MAX;
+  for( int i = 0; i < j->numCand[0]; i++ )
+    for( int k = 0; k < j->numCand[1]; k++ )
+    {
+      const uint64_t c = vo_symmetric_cost( j, j->cand[0][i], j->cand[1][k] );
+      if( c < costStart )
+      {
+        costStart = c; mvpIdxSym[0] = i; mvpIdxSym[1] = k;
+        predSym[0][0] = j->cand[0][i][0]; predSym[0][1] = j->cand[0][i][1]; predSym[1][0] = j->cand[1][k][0]; predSym[1][1] = j->cand[1][k][1];
+      }
+    }
+  int mvCur[2] = { predSym[0][0], predSym[0][1] }, mvTar[2] = { predSym[1][0], predSym[1][1] };
+  costStart += ( uint64_t ) ( j->motionLambda * ( vo_smvd_mv_bits( j, mvCur, predSym[0] ) + j->mvpIdxBits[mvpIdxSym[0]] + j->mvpIdxBits[mvpIdxSym[1]] ) );
+  /* distinct start candidates (smmvdCandsGen) */
+  int cands[16][2], nc = 0;
+  for( int s = 0; s < numStart; s++ )
+  {
+    int c[2] = { starts[s][0], starts[s][1] };
+    if( s >= numFixed )
+    {
+      if( nc >= 5 ) break;
+      if( j->imv ) { const int sh = vo_amvr_shift( j->imv ); c[0] = vo_prec_down( c[0], sh ) * ( 1 << sh ); c[1] = vo_prec_down( c[1], sh ) * ( 1 << sh ); }   /* roundTransPrecInternal2Amvr */
+    }
+    int dup = 0;
+    for( int q = 0; q < nc; q++ ) dup |= cands[q][0] == c[0] && cands[q][1] == c[1];
+    if( !dup ) { cands[nc][0] = c[0]; cands[nc][1] = c[1]; nc++; }
+  }
+  for( int s = 0; s < nc; s++ )
+  {
+    int checked = 0;
+    for( int i = 0; i < j->numCand[0] && !checked; i++ ) checked |= cands[s][0] == j->cand[0][i][0] && cands[s][1] == j->cand[0][i][1];
+    if( checked ) continue;
+    const uint64_t before = costStart;
+    vo_symmvd_check_best_mvp( j, cands[s], 0, predSym, mvpIdxSym, &costStart );
+    if( costStart < before )
+    {
+      mvCur[0] = cands[s][0]; mvCur[1] = cands[s][1];
+      mvTar[0] = predSym[1][0] - mvCur[0] + predSym[0][0]; mvTar[1] = predSym[1][1] - mvCur[1] + predSym[0][1];
+    }
+  }
+  const int      startPt[2] = { mvCur[0], mvCur[1] };
+  const uint64_t mvpCost    = ( uint64_t ) ( j->motionLambda * ( j->mvpIdxBits[mvpIdxSym[0]] + j->mvpIdxBits[mvpIdxSym[1]] ) );
+  uint64_t       symCost    = costStart - mvpCost;
+  vo_symmetric_me( j, predSym[0], predSym[1], mvCur, mvTar, &symCost );
+  symCost += mvpCost;
+  if( startPt[0] != mvCur[0] || startPt[1] != mvCur[1] ) vo_symmvd_check_best_mvp( j, mvCur, 1, predSym, mvpIdxSym, &symCost );
+  symCost += ( uint64_t ) ( j->motionLambda * modeBits );
+  mvTar[0] = predSym[1][0] - mvCur[0] + predSym[0][0]; mvTar[1] = predSym[1][1] - mvCur[1] + predSym[0][1];
+  res->mvCur[0] = mvCur[0]; res->mvCur[1] = mvCur[1]; res->mvTar[0] = mvTar[0]; res->mvTar[1] = mvTar[1];
+  for( int l = 0; l < 2; l++ ) { res->predSym[l][0] = predSym[l][0]; res->predSym[l][1] = predSym[l][1]; res->mvpIdxSym[l] = mvpIdxSym[l]; }
+  res->cost = symCost;
+}

@@ -207,6 +207,24 @@ typedef struct { int mv[3][2]; unsigned bits; uint64_t cost; int iterations, ref
 void vo_affine_motion_estimation( const vo_affine_me_job_t *job, vo_affine_me_result_t *res );
 void vo_solve_equal( double eq[7][7], int order, double *para );   /* solveEqual, InterSearch.cpp:5215-5284 */
 
+/* ---- symmetric MVD search (SMVD): InterSearch::xGetSymmetricCost (InterSearch.cpp:4341-4391), xSymmetricMotionEstimation with xSymmeticRefineMvSearch
+ * (:4393-4518), symmvdCheckBestMvp (:7787-7886) and the SMVD block of predInterSearch (:2656-2790) ---- */
+typedef struct
+{
+  const int16_t *org; int orgStride;            /* origBuf.Y() */
+  const int16_t *ref[2]; int refStride[2];      /* reconstructed luma of the searched list's symmetric reference [0] and the mirrored list's [1], at the PU position */
+  int w, h, puX, puY, picW, picH, ctuSize, bitDepth;
+  int imv, useSatd, clipBiPred, bcwWeightTar;   /* cu.imv; !slice.getDisableSATDForRD(); cfg ClipForBiPredMEEnabled; getBcwWeight( BcwIdx, tarList ): 4 = default */
+  int numCand[2]; int cand[2][2][2];            /* AMVP lists [searched / mirrored][i][hor / ver] */
+  unsigned mvpIdxBits[2];                       /* m_auiMVPIdxCost[i][AMVP_MAX_NUM_CANDS] */
+  double motionLambda;
+} vo_smvd_job_t;
+typedef struct { int mvCur[2], mvTar[2], predSym[2][2], mvpIdxSym[2]; uint64_t cost; } vo_smvd_result_t;
+uint64_t vo_symmetric_cost( const vo_smvd_job_t *job, const int mvCur[2], const int mvTar[2] );
+void vo_symmetric_me( const vo_smvd_job_t *job, const int predCur[2], const int predTar[2], int mvCur[2], int mvTar[2], uint64_t *cost );
+void vo_symmvd_check_best_mvp( const vo_smvd_job_t *job, const int curMv[2], int skip, int predSym[2][2], int mvpIdxSym[2], uint64_t *bestCost );
+void vo_smvd_search( const vo_smvd_job_t *job, int numFixed, int numStart, const int starts[][2], unsigned modeBits, vo_smvd_result_t *res );
+
 #ifdef __cplusplus
 }
 #endif

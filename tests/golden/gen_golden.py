@@ -467,6 +467,19 @@ def gen_affine_me():
     print("affine_me:", len(jobs), "jobs")
 
 
+def gen_smvd():
+    """InterSearch::xGetSymmetricCost, xSymmetricMotionEstimation and symmvdCheckBestMvp as the real members (oracle/ref_shim_me.cpp) on random SMVD jobs"""
+    import json
+    scene = me_util.SmvdScene(416, 240)
+    jobs = me_util.random_smvd_jobs(scene, 150, seed=4242)
+    rows = []
+    for j in jobs:
+        c0, me, chk = me_util.smvd_member_results(scene, j, R, "ref_")
+        rows.append([c0, *me[0], *me[1], me[2], *chk[0], *chk[1], *chk[2], chk[3]])
+    np.savez_compressed(os.path.join(HERE, "smvd.npz"), jobs=np.array([json.dumps(j) for j in jobs]), out=np.array(rows, np.int64))
+    print("smvd:", len(jobs), "jobs")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:   # regenerate selected fixtures only: gen_golden.py mest quant ...
         for name in sys.argv[1:]:
@@ -487,3 +500,4 @@ if __name__ == "__main__":
     gen_dmvr()
     gen_lfnst()
     gen_affine_me()
+    gen_smvd()

@@ -239,3 +239,88 @@ def affine_me_struct(scene, j, keep):
         t.mv[i][0], t.mv[i][1] = j["mv"][i]
     t.bits, t.motionLambda = j["bits"], j["lam"]
     return t
+
+
+# ---- SMVD (symmetric MVD search of predInterSearch) -------------------------------------------------------------------------------
+class SmvdScene(Scene):
+    """The original picture between two references: list 0 = an earlier frame (ref_buf), list 1 = a later one (ref_buf2)."""
+
+    def __init__(self, w=416, h=240, hard=False, margin=160):
+        fr = (synth.gen_frames_hard if hard else synth.gen_frames)(w, h, 5)
+        self.W, self.H = w, h
+        self.cur = np.ascontiguousarray(fr[2])
+        self.ref_buf, self.ref_off, self.ref_stride = synth.extend_plane(fr[0], margin)
+        self.ref_buf2, _, _ = synth.extend_plane(fr[4], margin)
+        self.margin = margin
+
+
+SMVD_SIZES = [(8, 8), (16, 16), (32, 32), (64, 64), (128, 128), (16, 8), (8, 16), (32, 16), (16, 32), (64, 32), (32, 8), (8, 32), (16, 4), (4, 16), (64, 16), (4, 32), (128, 64)]
+
+
+def random_smvd_jobs(scene, n, seed=3, sizes=None):
+    """(PU, AMVP lists, start vectors) as predInterSearch hands them to the SMVD block; vectors in 1/16 sample, candidates at the AMVR precision."""
+    rng = np.random.default_rng(seed)
+    jobs = []
+    while len(jobs) < n:
+        w, h = (sizes or SMVD_SIZES)[int(rng.integers(0, len(sizes or SMVD_SIZES)))]
+        if w > scene.W or h > scene.H:
+            continue
+        x = int(rng.integers(0, (scene.W - w) // 4 + 1)) * 4
+        y = int(rng.integers(0, (scene.H - h) // 4 + 1)) * 4
+        imv = int(rng.choice([0, 0, 0, 1, 2, 3]))
+        base = (int(rng.integers(-10 * 16, 10 * 16)), int(rng.integers(-6 * 16, 6 * 16)))
+        near = lambda c, r: (_round_amvr(c[0] + int(rng.integers(-r, r + 1)), imv), _round_amvr(c[1] + int(rng.integers(-r, r + 1)), imv))   # noqa: E731
+        cands = [[near(base, 40), near(base, 40)], [near((-base[0], -base[1]), 40), near((-base[0], -base[1]), 40)]]
+        for l in range(2):
+            if rng.integers(0, 6) == 0:
+                cands[l][1] = cands[l][0]              # equal candidates: the SMVD block shortens the list (:2668-2671)
+        num = [int(rng.choice([1, 2, 2, 2])), int(rng.choice([1, 2, 2, 2]))]
+        starts = [near(base, 60) if rng.integers(0, 4) else cands[0][int(rng.integers(0, 2))] for _ in range(int(rng.integers(2, 9)))]
+        starts = [(s[0] + int(rng.integers(-2, 3)) * (k >= 3), s[1]) for k, s in enumerate(starts)]   # history entries need not sit on the AMVR grid
+        jobs.append(dict(w=w, h=h, x=x, y=y, imv=imv, satd=int(rng.integers(0, 5) != 0), clip=int(rng.integers(0, 3) == 0),
+                         bcw=int(rng.choice([4, 4, 4, 4, -2, 3, 5, 10])), num=num, cands=cands, idxBits=[int(rng.integers(1, 3)), int(rng.integers(1, 4))],
+                         lam=float(rng.uniform(2, 40)), starts=starts, numFixed=int(rng.integers(2, 4)), modeBits=int(rng.integers(3, 9))))
+    return jobs
+
+
+def smvd_struct(scene, j):
+    t = ol.SmvdJob()
+    t.org, t.orgStride = scene.cur.ctypes.data + 2 * (j["y"] * scene.W + j["x"]), scene.W
+    t.ref[0] = scene.ref_buf.ctypes.data + 2 * (scene.ref_off + j["y"] * scene.ref_stride + j["x"])
+    t.ref[1] = scene.ref_buf2.ctypes.data + 2 * (scene.ref_off + j["y"] * scene.ref_stride + j["x"])
+    t.refStride[0] = t.refStride[1] = scene.ref_stride
+    t.w, t.h, t.puX, t.puY, t.picW, t.picH, t.ctuSize, t.bitDepth = j["w"], j["h"], j["x"], j["y"], scene.W, scene.H, 128, 10
+    t.imv, t.useSatd, t.clipBiPred, t.bcwWeightTar = j["imv"], j["satd"], j["clip"], j["bcw"]
+    for l in range(2):
+        t.numCand[l] = j["num"][l]
+        for i in range(2):
+            t.cand[l][i][0], t.cand[l][i][1] = j["cands"][l][i]
+        t.mvpIdxBits[l] = j["idxBits"][l]
+    t.motionLambda = j["lam"]
+    return t
+
+
+def smvd_member_results(scene, j, lib, prefix):
+    """(xGetSymmetricCost, xSymmetricMotionEstimation, symmvdCheckBestMvp) results of one job through `lib` (prefix "vo_": oracle, "ref_": the real members).
+    Inputs derived from the job alone: start vector starts[0], its mirror around the first predictor pair, costs a little above the start cost."""
+    I2 = C.c_int * 2
+    t = smvd_struct(scene, j)
+    pc, pt, start = j["cands"][0][0], j["cands"][1][0], j["starts"][0]
+    pair = (pt[0] - (start[0] - pc[0]), pt[1] - (start[1] - pc[1]))
+    fn = getattr(lib, prefix + "symmetric_cost")
+    fn.restype = C.c_uint64
+    c0 = fn(C.byref(t), I2(*start), I2(*pair))
+    mc, mt, cost = I2(*start), I2(*pair), C.c_uint64(c0 + int(j["lam"] * 6))
+    getattr(lib, prefix + "symmetric_me")(C.byref(t), I2(*pc), I2(*pt), mc, mt, C.byref(cost))
+    me = (tuple(mc), tuple(mt), cost.value)
+    pred, idx, cost = (I2 * 2)(I2(*pc), I2(*pt)), I2(0, 0), C.c_uint64(c0 + int(j["lam"] * 9))
+    getattr(lib, prefix + "symmvd_check_best_mvp")(C.byref(t), I2(*start), j["x"] // 4 & 1, pred, idx, C.byref(cost))
+    return c0, me, (tuple(pred[0]), tuple(pred[1]), tuple(idx), cost.value)
+
+
+def smvd_search_oracle(scene, j, L):
+    t = smvd_struct(scene, j)
+    st = ((C.c_int * 2) * len(j["starts"]))(*[(C.c_int * 2)(*v) for v in j["starts"]])
+    r = ol.SmvdResult()
+    L.vo_smvd_search(C.byref(t), j["numFixed"], len(j["starts"]), st, j["modeBits"], C.byref(r))
+    return r.key()

@@ -90,7 +90,7 @@ def oracle():
     global _oracle
     if _oracle is None:
         L = C.CDLL(build_oracle())
-        for n in ("vo_sad", "vo_sse", "vo_satd", "vo_mv_cost"):
+        for n in ("vo_sad", "vo_sse", "vo_satd", "vo_mv_cost", "vo_symmetric_cost"):
             getattr(L, n).restype = C.c_uint64
         L.vo_mv_bits.restype = C.c_uint
         _oracle = L
@@ -107,6 +107,8 @@ def ref():
         L = C.CDLL(REF_SO)
         L.ref_dist.restype = C.c_uint64
         L.ref_mv_cost.restype = C.c_uint64
+        if hasattr(L, "ref_symmetric_cost"):
+            L.ref_symmetric_cost.restype = C.c_uint64
         L.ref_mv_cost.argtypes = [C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]
         _ref = L
     return _ref
@@ -147,6 +149,20 @@ class AffineMeJob(C.Structure):
     _fields_ = [("pred", AffinePred), ("org", C.c_void_p), ("orgStride", C.c_int), ("otherPred", C.c_void_p), ("otherStride", C.c_int), ("bi", C.c_int),
                 ("imv", C.c_int), ("useSatd", C.c_int), ("useAffineType", C.c_int), ("amvrEncOpt", C.c_int), ("lowDelayRounds", C.c_int),
                 ("mvPred", (C.c_int * 2) * 3), ("mv", (C.c_int * 2) * 3), ("bits", C.c_uint), ("motionLambda", C.c_double), ("hevcCost", C.c_uint64)]
+
+
+class SmvdJob(C.Structure):      # vo_smvd_job_t
+    _fields_ = [("org", C.c_void_p), ("orgStride", C.c_int), ("ref", C.c_void_p * 2), ("refStride", C.c_int * 2), ("w", C.c_int), ("h", C.c_int), ("puX", C.c_int),
+                ("puY", C.c_int), ("picW", C.c_int), ("picH", C.c_int), ("ctuSize", C.c_int), ("bitDepth", C.c_int), ("imv", C.c_int), ("useSatd", C.c_int),
+                ("clipBiPred", C.c_int), ("bcwWeightTar", C.c_int), ("numCand", C.c_int * 2), ("cand", ((C.c_int * 2) * 2) * 2), ("mvpIdxBits", C.c_uint * 2),
+                ("motionLambda", C.c_double)]
+
+
+class SmvdResult(C.Structure):   # vo_smvd_result_t
+    _fields_ = [("mvCur", C.c_int * 2), ("mvTar", C.c_int * 2), ("predSym", (C.c_int * 2) * 2), ("mvpIdxSym", C.c_int * 2), ("cost", C.c_uint64)]
+
+    def key(self):
+        return (tuple(self.mvCur), tuple(self.mvTar), tuple(self.predSym[0]), tuple(self.predSym[1]), tuple(self.mvpIdxSym), self.cost)
 
 
 class AffineMeResult(C.Structure):

@@ -1,0 +1,109 @@
+"""GPU parity: the symmetric-MVD search -- vtmhip_xGetSymmetricCost_batch_dev, vtmhip_xSymmetricMotionEstimation_batch_dev,
+vtmhip_symmvdCheckBestMvp_batch_dev and the whole block (vtmhip_smvd_batch_dev, op VTMHIP_SMVD_SEARCH) vs the oracle (pinned against the real members,
+tests/test_oracle_vs_ref.py) and vs golden vectors recorded from the real members.  Bit-exact."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import me_util
+import oracle_lib as ol
+from test_oracle_golden import smvd_flat
+from vtm_amd.lib import PicParams, SmvdJob
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def hip_jobs(scene, jobs):
+    arr = (SmvdJob * len(jobs))()
+    for k, j in enumerate(jobs):
+        t = arr[k]
+        t.orgOff, t.orgStride = j["y"] * scene.W + j["x"], scene.W
+        pos = scene.ref_off + j["y"] * scene.ref_stride + j["x"]
+        t.refOff[0], t.refOff[1] = pos, scene.ref_buf.size + pos            # the two planes live back to back in one device buffer
+        t.refStride[0] = t.refStride[1] = scene.ref_stride
+        t.puX, t.puY, t.width, t.height = j["x"], j["y"], j["w"], j["h"]
+        t.imv, t.useSatd, t.clipBiPred, t.bcwWeightTar = j["imv"], j["satd"], j["clip"], j["bcw"]
+        for l in range(2):
+            t.numCand[l] = j["num"][l]
+            for i in range(2):
+                t.cand[l][i][0], t.cand[l][i][1] = j["cands"][l][i]
+            t.mvpIdxBits[l] = j["idxBits"][l]
+        t.numStart, t.numFixed, t.modeBits, t.motionLambda = len(j["starts"]), j["numFixed"], j["modeBits"], j["lam"]
+        for i, v in enumerate(j["starts"]):
+            t.starts[i][0], t.starts[i][1] = v
+    return arr
+
+
+def run_op(ctx, scene, d_cur, d_ref, arr, n, op, max_w=128, max_h=128):
+    pic = PicParams(scene.W, scene.H, 128, 10, 0)
+    d_jobs = ctx.to_device(np.frombuffer(arr, np.uint8))
+    ctx.smvd_batch(pic, d_cur.ptr, d_ref.ptr, d_jobs.ptr, n, max_w, max_h, op)
+    return (SmvdJob * n).from_buffer_copy(d_jobs.to_host(np.uint8).tobytes())
+
+
+def device_member_results(ctx, scene, jobs):
+    """the same three calls as me_util.smvd_member_results, each as one batch"""
+    d_cur = ctx.to_device(scene.cur)
+    d_ref = ctx.to_device(np.concatenate([scene.ref_buf.reshape(-1), scene.ref_buf2.reshape(-1)]))
+    arr = hip_jobs(scene, jobs)
+    n = len(jobs)
+    for t, j in zip(arr, jobs):
+        pc, pt, start = j["cands"][0][0], j["cands"][1][0], j["starts"][0]
+        t.mvCur[0], t.mvCur[1] = start
+        t.mvTar[0], t.mvTar[1] = pt[0] - (start[0] - pc[0]), pt[1] - (start[1] - pc[1])
+        t.predSym[0][0], t.predSym[0][1] = pc
+        t.predSym[1][0], t.predSym[1][1] = pt
+    c0 = [r.cost for r in run_op(ctx, scene, d_cur, d_ref, arr, n, 0)]
+    for t, j, c in zip(arr, jobs, c0):
+        t.cost = c + int(j["lam"] * 6)
+    me = [(tuple(r.mvCur), tuple(r.mvTar), r.cost) for r in run_op(ctx, scene, d_cur, d_ref, arr, n, 1)]
+    for t, j, c in zip(arr, jobs, c0):
+        t.cost, t.skip = c + int(j["lam"] * 9), j["x"] // 4 & 1
+        t.mvpIdxSym[0] = t.mvpIdxSym[1] = 0
+    chk = [(tuple(r.predSym[0]), tuple(r.predSym[1]), tuple(r.mvpIdxSym), r.cost) for r in run_op(ctx, scene, d_cur, d_ref, arr, n, 2)]
+    full = [(tuple(r.mvCur), tuple(r.mvTar), tuple(r.predSym[0]), tuple(r.predSym[1]), tuple(r.mvpIdxSym), r.cost) for r in run_op(ctx, scene, d_cur, d_ref, arr, n, 3)]
+    return list(zip(c0, me, chk)), full
+
+
+@pytest.mark.parametrize("hard", [False, True])
+def test_smvd_matches_oracle(ctx, hard):
+    L = ol.oracle()
+    scene = me_util.SmvdScene(416, 240, hard=hard)
+    jobs = me_util.random_smvd_jobs(scene, 400, seed=77 + hard)
+    got, full = device_member_results(ctx, scene, jobs)
+    moved = 0
+    for k, j in enumerate(jobs):
+        exp = me_util.smvd_member_results(scene, j, L, "vo_")
+        assert got[k] == exp, ("members", k, j, got[k], exp)
+        e = me_util.smvd_search_oracle(scene, j, L)
+        assert full[k] == e, ("whole block", k, j, full[k], e)
+        moved += e[0] != e[2]
+    assert moved > 100, moved
+
+
+def test_smvd_uniform_small_batches(ctx):
+    """one wave per PU (<= 32x32) and the four-wave form, every size alone so that maxWidth / maxHeight equal the block"""
+    L = ol.oracle()
+    scene = me_util.SmvdScene(416, 240, hard=True)
+    d_cur = ctx.to_device(scene.cur)
+    d_ref = ctx.to_device(np.concatenate([scene.ref_buf.reshape(-1), scene.ref_buf2.reshape(-1)]))
+    for size in me_util.SMVD_SIZES:
+        jobs = me_util.random_smvd_jobs(scene, 24, seed=size[0] * 131 + size[1], sizes=[size])
+        arr = hip_jobs(scene, jobs)
+        res = run_op(ctx, scene, d_cur, d_ref, arr, len(jobs), 3, size[0], size[1])
+        for k, (r, j) in enumerate(zip(res, jobs)):
+            got = (tuple(r.mvCur), tuple(r.mvTar), tuple(r.predSym[0]), tuple(r.predSym[1]), tuple(r.mvpIdxSym), r.cost)
+            assert got == me_util.smvd_search_oracle(scene, j, L), (size, k, j)
+
+
+def test_smvd_matches_golden_from_reference(ctx):
+    z = np.load(os.path.join(G, "smvd.npz"))
+    scene = me_util.SmvdScene(416, 240)
+    jobs = [json.loads(str(s)) for s in z["jobs"]]
+    got, _ = device_member_results(ctx, scene, jobs)
+    for k, j in enumerate(jobs):
+        assert smvd_flat(got[k]) == z["out"][k].tolist(), ("golden", k, j)

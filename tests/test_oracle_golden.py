@@ -265,3 +265,19 @@ def test_affine_me_golden(oracle):
         oracle.vo_pred_affine_blk(C.byref(p), mv, 0, ol.P(a), j["w"])
         assert np.array_equal(a.reshape(-1), z["pred"][off:off + j["w"] * j["h"]]), (k,)
         off += j["w"] * j["h"]
+
+
+def smvd_flat(res):
+    c0, me, chk = res
+    return [c0, *me[0], *me[1], me[2], *chk[0], *chk[1], *chk[2], chk[3]]
+
+
+def test_smvd_golden(oracle):
+    """golden xGetSymmetricCost / xSymmetricMotionEstimation / symmvdCheckBestMvp results recorded from the real members (tests/golden/smvd.npz) vs the oracle"""
+    import json
+    import me_util
+    z = np.load(os.path.join(G, "smvd.npz"))
+    scene = me_util.SmvdScene(416, 240)
+    for k, s in enumerate(z["jobs"]):
+        j = json.loads(str(s))
+        assert smvd_flat(me_util.smvd_member_results(scene, j, oracle, "vo_")) == z["out"][k].tolist(), (k, j)

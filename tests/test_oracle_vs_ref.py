@@ -686,3 +686,19 @@ def test_lfnst_scan_positions_equal_reference_tables(oracle, reflib):
             oracle.vo_lfnst_scan(w, h, ol.P(b))
             assert L.vtmhip_lfnst_scan_host(w, h, c.ctypes.data) == lib.OK
             assert np.array_equal(a[:n], b[:n]) and np.array_equal(a[:n], c[:n]), (w, h, a[:n], b[:n], c[:n])
+
+
+def test_smvd_members_equal_reference(oracle, reflib):
+    """InterSearch::xGetSymmetricCost, xSymmetricMotionEstimation (diamond + cross rounds of xSymmeticRefineMvSearch) and symmvdCheckBestMvp as the real
+    members (two reference pictures aliasing the caller's planes) vs the oracle: all AMVR modes, SAD / SATD, clipped target, BCW weights."""
+    import me_util
+    for hard in (False, True):
+        scene = me_util.SmvdScene(416, 240, hard=hard)
+        jobs = me_util.random_smvd_jobs(scene, 200, seed=9 + hard)
+        moved = switched = 0
+        for k, j in enumerate(jobs):
+            a, b = me_util.smvd_member_results(scene, j, oracle, "vo_"), me_util.smvd_member_results(scene, j, reflib, "ref_")
+            assert a == b, (k, j, a, b)
+            moved += a[1][0] != tuple(j["starts"][0])
+            switched += a[2][2] != (0, 0)
+        assert moved > 60 and switched > 15, (moved, switched)

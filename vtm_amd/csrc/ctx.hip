@@ -41,6 +41,7 @@ int vtmhip_struct_size( int which )
   case 28: return ( int ) sizeof( vtmhip_lfnst_tu_job );
   case 29: return ( int ) sizeof( vtmhip_pis_level_run );
   case 30: return ( int ) sizeof( vtmhip_pis_buffers );
+  case 31: return ( int ) sizeof( vtmhip_smvd_job );
   default: return -1;
   }
 }

@@ -204,6 +204,15 @@ class AffineMeOut(C.Structure):
     _fields_ = [("mv", (C.c_int32 * 2) * 3), ("bits", C.c_uint32), ("iterations", C.c_int32), ("refinements", C.c_int32), ("pad", C.c_int32), ("cost", C.c_uint64)]
 
 
+class SmvdJob(C.Structure):
+    _fields_ = [("orgOff", C.c_int64), ("refOff", C.c_int64 * 2), ("orgStride", C.c_int32), ("refStride", C.c_int32 * 2), ("puX", C.c_int16), ("puY", C.c_int16),
+                ("width", C.c_int16), ("height", C.c_int16), ("imv", C.c_uint8), ("useSatd", C.c_uint8), ("clipBiPred", C.c_uint8), ("bcwWeightTar", C.c_int8),
+                ("numCand", C.c_uint8 * 2), ("numStart", C.c_uint8), ("numFixed", C.c_uint8), ("skip", C.c_uint8), ("pad_", C.c_uint8 * 3),
+                ("cand", ((C.c_int32 * 2) * 2) * 2), ("mvpIdxBits", C.c_uint32 * 2), ("modeBits", C.c_uint32), ("motionLambda", C.c_double),
+                ("starts", (C.c_int32 * 2) * 16), ("mvCur", C.c_int32 * 2), ("mvTar", C.c_int32 * 2), ("predSym", (C.c_int32 * 2) * 2), ("mvpIdxSym", C.c_int32 * 2),
+                ("cost", C.c_uint64)]
+
+
 class LfnstTuJob(C.Structure):
     _fields_ = [("coefOff", C.c_int64), ("width", C.c_int16), ("height", C.c_int16), ("mode", C.c_uint8), ("index", C.c_uint8), ("transpose", C.c_uint8),
                 ("inverse", C.c_uint8)]
@@ -211,7 +220,7 @@ class LfnstTuJob(C.Structure):
 
 _STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob,
             TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut, PredJob, MaskedSadJob, GeoBlendJob, DmvrJob, LfnstJob,
-            PisRow, PisPu, PisLevel, AffineMeJob, AffineMeOut, LfnstTuJob, PisLevelRun, PisBuffers]   # order of vtmhip_struct_size(which)
+            PisRow, PisPu, PisLevel, AffineMeJob, AffineMeOut, LfnstTuJob, PisLevelRun, PisBuffers, SmvdJob]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
 _PROTOS = {
@@ -302,6 +311,10 @@ _PROTOS = {
                                                        C.c_int, C.c_int, C.c_void_p]),
     "vtmhip_xAffineMotionEstimation_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                            C.c_void_p]),
+    "vtmhip_smvd_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vtmhip_xGetSymmetricCost_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "vtmhip_xSymmetricMotionEstimation_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "vtmhip_symmvdCheckBestMvp_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "vtmhip_xPredAffineBlk_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "vtmhip_lfnst_tu_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "vtmhip_lfnst_scan_host": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
