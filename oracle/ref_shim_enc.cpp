@@ -54,6 +54,7 @@ struct RefEncStats
   uint64_t affineCalls, affineDevice, affineMismatch, affineUnsupported;
   uint64_t lfnstCalls[2], lfnstDevice[2], lfnstMismatch[2];   // TrQuant::xFwdLfnst / xInvLfnst (gather + core multiply + scatter) as vtmhip_lfnst_tu_batch_dev   // InterSearch::xAffineMotionEstimation as one vtmhip_xAffineMotionEstimation_batch_dev call
   uint64_t amvpCalls, amvpDevice, amvpMismatch, amvpUnsupported;   // InterSearch::xEstimateMvPredAMVP's candidate selection as one vtmhip_xEstimateMvPredAMVP_batch_dev call (hook B7)
+  uint64_t smvdCalls[3], smvdDevice[3], smvdMismatch[3], smvdUnsupported;   // xGetSymmetricCost / xSymmetricMotionEstimation / symmvdCheckBestMvp as vtmhip_smvd_batch_dev ops
 };
 }
 
@@ -91,6 +92,7 @@ struct Api
   decltype( &vtmhip_lfnst_set_tables )             lfnstTables;
   decltype( &vtmhip_lfnst_tu_batch_dev )           lfnstTu;
   decltype( &vtmhip_xEstimateMvPredAMVP_batch_dev ) amvp;
+  decltype( &vtmhip_smvd_batch_dev )               smvd;
 } A;
 
 vtmhip_ctx  *g_ctx = nullptr;
@@ -429,13 +431,16 @@ void restoreAux()
 extern "C" void vtmref_orig_xMotionEstimation( InterSearch *, PredictionUnit &, PelUnitBuf &, RefPicList, Mv &, int, Mv &, int &, uint32_t &, Distortion &, const AMVPInfo &, bool );
 extern "C" void vtmref_orig_xAffineMotionEstimation( InterSearch *, PredictionUnit &, PelUnitBuf &, RefPicList, Mv *, int, Mv *, uint32_t &, Distortion &, int &, const AffineAMVPInfo &, bool );
 extern "C" void vtmref_orig_xEstimateMvPredAMVP( InterSearch *, PredictionUnit &, PelUnitBuf &, RefPicList, int, Mv &, AMVPInfo &, bool, Distortion * );
+extern "C" Distortion vtmref_orig_xGetSymmetricCost( InterSearch *, PredictionUnit &, PelUnitBuf &, RefPicList, const MvField &, MvField &, int );
+extern "C" void vtmref_orig_xSymmetricMotionEstimation( InterSearch *, PredictionUnit &, PelUnitBuf &, Mv &, Mv &, RefPicList, MvField &, MvField &, Distortion &, int );
+extern "C" void vtmref_orig_symmvdCheckBestMvp( InterSearch *, PredictionUnit &, PelUnitBuf &, Mv, RefPicList, AMVPInfo ( * )[33], int32_t, Mv *, int32_t *, Distortion &, bool );
 extern "C" void vtmref_orig_xFwdLfnst( TrQuant *, const TransformUnit &, const ComponentID, const bool );
 extern "C" void vtmref_orig_xInvLfnst( TrQuant *, const TransformUnit &, const ComponentID );
 extern "C" void vtmref_orig_transformNxN_select( TrQuant *, TransformUnit &, const ComponentID &, const QpParam &, std::vector<TrMode> *, const int );
 namespace
 {
-bool     g_hookMe = false, g_hookMts = false, g_hookAffine = false, g_hookLfnst = false, g_hookAmvp = false;
-uint64_t g_amvpCtr = 0;
+bool     g_hookMe = false, g_hookMts = false, g_hookAffine = false, g_hookLfnst = false, g_hookAmvp = false, g_hookSmvd = false;
+uint64_t g_amvpCtr = 0, g_smvdCtr[3] = { 0, 0, 0 };
 uint64_t g_lfnstCtr[2] = { 0, 0 };
 uint64_t g_affineCtr = 0;
 uint64_t g_hookCtr[2] = { 0, 0 }, g_hookStride = 0;   // VTMREF_HOOK_STRIDE: the hooks' own sampling stride (default: the tables' stride)
@@ -613,6 +618,131 @@ void amvpHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPicL
   rcMvPred.hor = j.mvPredHor; rcMvPred.ver = j.mvPredVer; pu.mvpIdx[eRefPicList] = j.mvpIdx; *puiDistBiP = dist;
 }
 
+// ---- SMVD (InterSearch.cpp:4341-4518, 7787-7886): one vtmhip_smvd_job per call; the two reference planes are separate device allocations, addressed from the
+// searched list's plane ----
+struct SmvdCall { vtmhip_smvd_job j; vtmhip_pic_params pic; const int16_t *base; bool ok; };
+SmvdCall smvdJob( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPicList eCur, int refIdxCur, int refIdxTar )
+{
+  SmvdCall c; memset( &c.j, 0, sizeof( c.j ) ); memset( &c.pic, 0, sizeof( c.pic ) ); c.base = nullptr; c.ok = false;
+  const Slice   &slice = *pu.cu->slice;
+  const RefPicList eTar = RefPicList( 1 - eCur );
+  const Picture *picA = slice.getRefPic( eCur, refIdxCur ), *picB = slice.getRefPic( eTar, refIdxTar );
+  const int      w = pu.Y().width, h = pu.Y().height;
+  if( slice.testWeightPred() || slice.testWeightBiPred() || picA->isWrapAroundEnabled( pu.cs->pps ) || picB->isWrapAroundEnabled( pu.cs->pps ) || picA->isRefScaled( pu.cs->pps )
+      || picB->isRefScaled( pu.cs->pps ) || is->m_pcEncCfg->getMCTSEncConstraint() || w > 128 || h > 128 || slice.getSPS()->getBitDepth( CHANNEL_TYPE_LUMA ) > 12 ) return c;
+  const RefPlane *pa = refPlane( picA );
+  if( !pa ) return c;
+  const RefPlane a = *pa;                     // the table may move when the second plane is uploaded
+  const RefPlane *pb = refPlane( picB );
+  if( !pb ) return c;
+  const RefPlane b = *pb;
+  const Position  pos = pu.cu->lumaPos();
+  vtmhip_smvd_job &j = c.j;
+  j.orgOff = 0; j.orgStride = w;
+  j.refOff[0] = ( int64_t ) ( a.margin + pu.Y().y ) * a.stride + a.margin + pu.Y().x; j.refStride[0] = a.stride;
+  j.refOff[1] = ( int64_t ) ( b.dev - a.dev ) + ( int64_t ) ( b.margin + pu.Y().y ) * b.stride + b.margin + pu.Y().x; j.refStride[1] = b.stride;
+  j.puX = ( int16_t ) pos.x; j.puY = ( int16_t ) pos.y; j.width = ( int16_t ) w; j.height = ( int16_t ) h;
+  j.imv = pu.cu->imv; j.useSatd = !pu.cu->slice->getDisableSATDForRD(); j.clipBiPred = is->m_pcEncCfg->getClipForBiPredMeEnabled();
+  j.bcwWeightTar = getBcwWeight( pu.cu->BcwIdx, eTar );
+  for( int i = 0; i < 2; i++ ) j.mvpIdxBits[i] = is->m_auiMVPIdxCost[i][AMVP_MAX_NUM_CANDS];
+  j.motionLambda = is->m_pcRdCost->m_motionLambda;
+  c.pic.picW = pu.cs->pps->getPicWidthInLumaSamples(); c.pic.picH = pu.cs->pps->getPicHeightInLumaSamples(); c.pic.ctuSize = pu.cs->sps->getMaxCUWidth();
+  c.pic.bitDepth = slice.getSPS()->getBitDepth( CHANNEL_TYPE_LUMA );
+  c.base = a.dev;
+  const CPelBuf org = origBuf.Y();
+  std::vector<Pel> blk( size_t( w ) * h );
+  for( int y = 0; y < h; y++ ) memcpy( &blk[size_t( y ) * w], org.buf + ptrdiff_t( y ) * org.stride, sizeof( Pel ) * w );
+  c.ok = A.h2d( g_ctx, d_hOrg, blk.data(), blk.size() * 2 ) == VTMHIP_OK;
+  return c;
+}
+bool smvdRun( SmvdCall &c, int op )
+{
+  const bool ok = A.h2d( g_ctx, d_hJob, &c.j, sizeof( c.j ) ) == VTMHIP_OK
+               && A.smvd( g_ctx, &c.pic, d_hOrg, c.base, ( vtmhip_smvd_job * ) d_hJob, 1, c.j.width, c.j.height, op ) == VTMHIP_OK
+               && A.d2h( g_ctx, &c.j, d_hJob, sizeof( c.j ) ) == VTMHIP_OK;
+  if( !ok ) note_error();
+  return ok;
+}
+void smvdMismatch( int op, const vtmhip_smvd_job &j, long long ref, long long dev )
+{
+  if( g_st->smvdMismatch[op]++ == 0 && g_st->hookMismatch[0] + g_st->hookMismatch[1] == 0 )
+  {
+    const int32_t v[8] = { 4 + op, j.width * 1000 + j.height, j.imv, j.bcwWeightTar, j.useSatd, ( int32_t ) ref, ( int32_t ) dev, 0 };
+    memcpy( g_st->hookFirstMismatch, v, sizeof( v ) );
+  }
+}
+
+Distortion smvdCostHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPicList eCur, const MvField &cur, MvField &tar, int bcwIdx )
+{
+  g_st->smvdCalls[0]++;
+  const Distortion ref = vtmref_orig_xGetSymmetricCost( is, pu, origBuf, eCur, cur, tar, bcwIdx );
+  if( !hookSampled( g_smvdCtr[0] ) ) return ref;
+  SmvdCall c = smvdJob( is, pu, origBuf, eCur, cur.refIdx, tar.refIdx );
+  if( !c.ok ) { g_st->smvdUnsupported++; return ref; }
+  c.j.mvCur[0] = cur.mv.hor; c.j.mvCur[1] = cur.mv.ver; c.j.mvTar[0] = tar.mv.hor; c.j.mvTar[1] = tar.mv.ver;
+  if( !smvdRun( c, VTMHIP_SMVD_COST ) ) return ref;
+  g_st->smvdDevice[0]++;
+  if( c.j.cost != ref ) smvdMismatch( 0, c.j, ( long long ) ref, ( long long ) c.j.cost );
+  return c.j.cost;
+}
+
+void smvdMeHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, Mv &predCur, Mv &predTar, RefPicList eCur, MvField &cur, MvField &tar, Distortion &cost, int bcwIdx )
+{
+  g_st->smvdCalls[1]++;
+  const MvField    cur0 = cur, tar0 = tar;
+  const Distortion cost0 = cost;
+  vtmref_orig_xSymmetricMotionEstimation( is, pu, origBuf, predCur, predTar, eCur, cur, tar, cost, bcwIdx );
+  if( !hookSampled( g_smvdCtr[1] ) ) return;
+  SmvdCall c = smvdJob( is, pu, origBuf, eCur, cur0.refIdx, tar0.refIdx );
+  if( !c.ok ) { g_st->smvdUnsupported++; return; }
+  c.j.mvCur[0] = cur0.mv.hor; c.j.mvCur[1] = cur0.mv.ver; c.j.mvTar[0] = tar0.mv.hor; c.j.mvTar[1] = tar0.mv.ver;
+  c.j.predSym[0][0] = predCur.hor; c.j.predSym[0][1] = predCur.ver; c.j.predSym[1][0] = predTar.hor; c.j.predSym[1][1] = predTar.ver;
+  c.j.cost = cost0;
+  if( !smvdRun( c, VTMHIP_SMVD_ME ) ) return;
+  g_st->smvdDevice[1]++;
+  if( c.j.mvCur[0] != cur.mv.hor || c.j.mvCur[1] != cur.mv.ver || c.j.mvTar[0] != tar.mv.hor || c.j.mvTar[1] != tar.mv.ver || c.j.cost != cost )
+    smvdMismatch( 1, c.j, ( long long ) cost, ( long long ) c.j.cost );
+  cur.mv.set( c.j.mvCur[0], c.j.mvCur[1] ); tar.mv.set( c.j.mvTar[0], c.j.mvTar[1] ); cost = c.j.cost;
+}
+
+void smvdCheckHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, Mv curMv, RefPicList curList, AMVPInfo amvpInfo[2][33], int32_t bcwIdx, Mv predSym[2], int32_t idxSym[2],
+                    Distortion &bestCost, bool skip )
+{
+  g_st->smvdCalls[2]++;
+  const int        tarList = 1 - curList;
+  const Mv         pred0[2] = { predSym[0], predSym[1] };
+  const int32_t    idx0[2]  = { idxSym[0], idxSym[1] };
+  const Distortion cost0 = bestCost;
+  vtmref_orig_symmvdCheckBestMvp( is, pu, origBuf, curMv, curList, amvpInfo, bcwIdx, predSym, idxSym, bestCost, skip );
+  if( !hookSampled( g_smvdCtr[2] ) ) return;
+  const int refIdxCur = pu.cu->slice->getSymRefIdx( curList ), refIdxTar = pu.cu->slice->getSymRefIdx( tarList );
+  SmvdCall  c = smvdJob( is, pu, origBuf, curList, refIdxCur, refIdxTar );
+  const AMVPInfo &ac = amvpInfo[curList][refIdxCur], &at = amvpInfo[tarList][refIdxTar];
+  if( !c.ok || ac.numCand > 2 || at.numCand > 2 ) { g_st->smvdUnsupported++; return; }
+  c.j.numCand[0] = ( uint8_t ) ac.numCand; c.j.numCand[1] = ( uint8_t ) at.numCand;
+  for( int i = 0; i < 2; i++ )
+  {
+    c.j.cand[0][i][0] = ac.mvCand[i].hor; c.j.cand[0][i][1] = ac.mvCand[i].ver; c.j.cand[1][i][0] = at.mvCand[i].hor; c.j.cand[1][i][1] = at.mvCand[i].ver;
+  }
+  c.j.mvCur[0] = curMv.hor; c.j.mvCur[1] = curMv.ver; c.j.skip = skip;
+  c.j.predSym[0][0] = pred0[curList].hor; c.j.predSym[0][1] = pred0[curList].ver; c.j.predSym[1][0] = pred0[tarList].hor; c.j.predSym[1][1] = pred0[tarList].ver;
+  c.j.mvpIdxSym[0] = idx0[curList]; c.j.mvpIdxSym[1] = idx0[tarList];
+  c.j.cost = cost0;
+  if( !smvdRun( c, VTMHIP_SMVD_CHECK_MVP ) ) return;
+  g_st->smvdDevice[2]++;
+  const bool changed = bestCost != cost0;     // the predictors are outputs only when a pair improved the cost
+  bool bad = c.j.cost != bestCost;
+  if( changed ) bad |= c.j.predSym[0][0] != predSym[curList].hor || c.j.predSym[0][1] != predSym[curList].ver || c.j.predSym[1][0] != predSym[tarList].hor
+                    || c.j.predSym[1][1] != predSym[tarList].ver || c.j.mvpIdxSym[0] != idxSym[curList] || c.j.mvpIdxSym[1] != idxSym[tarList];
+  if( bad ) smvdMismatch( 2, c.j, ( long long ) bestCost, ( long long ) c.j.cost );
+  bestCost = c.j.cost;
+  if( c.j.cost != cost0 )
+  {
+    predSym[curList].set( c.j.predSym[0][0], c.j.predSym[0][1] ); predSym[tarList].set( c.j.predSym[1][0], c.j.predSym[1][1] );
+    idxSym[curList] = c.j.mvpIdxSym[0]; idxSym[tarList] = c.j.mvpIdxSym[1];
+  }
+}
+
 void affineHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPicList eRefPicList, Mv acMvPred[3], int iRefIdxPred, Mv acMv[3], uint32_t &ruiBits, Distortion &ruiCost,
                  int &mvpIdx, const AffineAMVPInfo &aamvpi, bool bBi )
 {
@@ -785,6 +915,23 @@ void InterSearch::xEstimateMvPredAMVP( PredictionUnit &pu, PelUnitBuf &origBuf, 
   if( g_hookAmvp ) amvpHook( this, pu, origBuf, eRefPicList, iRefIdx, rcMvPred, amvpInfo, bFilled, puiDistBiP );
   else vtmref_orig_xEstimateMvPredAMVP( this, pu, origBuf, eRefPicList, iRefIdx, rcMvPred, amvpInfo, bFilled, puiDistBiP );
 }
+Distortion InterSearch::xGetSymmetricCost( PredictionUnit &pu, PelUnitBuf &origBuf, RefPicList eCurRefPicList, const MvField &cCurMvField, MvField &cTarMvField, int bcwIdx )
+{
+  if( g_hookSmvd ) return smvdCostHook( this, pu, origBuf, eCurRefPicList, cCurMvField, cTarMvField, bcwIdx );
+  return vtmref_orig_xGetSymmetricCost( this, pu, origBuf, eCurRefPicList, cCurMvField, cTarMvField, bcwIdx );
+}
+void InterSearch::xSymmetricMotionEstimation( PredictionUnit &pu, PelUnitBuf &origBuf, Mv &rcMvCurPred, Mv &rcMvTarPred, RefPicList eRefPicList, MvField &rCurMvField,
+                                              MvField &rTarMvField, Distortion &ruiCost, int bcwIdx )
+{
+  if( g_hookSmvd ) smvdMeHook( this, pu, origBuf, rcMvCurPred, rcMvTarPred, eRefPicList, rCurMvField, rTarMvField, ruiCost, bcwIdx );
+  else vtmref_orig_xSymmetricMotionEstimation( this, pu, origBuf, rcMvCurPred, rcMvTarPred, eRefPicList, rCurMvField, rTarMvField, ruiCost, bcwIdx );
+}
+void InterSearch::symmvdCheckBestMvp( PredictionUnit &pu, PelUnitBuf &origBuf, Mv curMv, RefPicList curRefList, AMVPInfo amvpInfo[2][33], int32_t bcwIdx, Mv cMvPredSym[2],
+                                      int32_t mvpIdxSym[2], Distortion &bestCost, bool skip )
+{
+  if( g_hookSmvd ) smvdCheckHook( this, pu, origBuf, curMv, curRefList, amvpInfo, bcwIdx, cMvPredSym, mvpIdxSym, bestCost, skip );
+  else vtmref_orig_symmvdCheckBestMvp( this, pu, origBuf, curMv, curRefList, amvpInfo, bcwIdx, cMvPredSym, mvpIdxSym, bestCost, skip );
+}
 void TrQuant::xFwdLfnst( const TransformUnit &tu, const ComponentID compID, const bool loadTr )
 {
   if( g_hookLfnst ) lfnstHook( this, tu, compID, false, loadTr ); else vtmref_orig_xFwdLfnst( this, tu, compID, loadTr );
@@ -818,7 +965,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
                  && sym( A.dalloc, "vtmhip_dev_alloc" ) && sym( A.dfree, "vtmhip_dev_free" ) && sym( A.h2d, "vtmhip_h2d" ) && sym( A.d2h, "vtmhip_d2h" )
                  && sym( A.addAvg, "vtmhip_add_avg_batch_dev" ) && sym( A.rhf, "vtmhip_remove_high_freq_batch_dev" )
                  && sym( A.sobel, "vtmhip_affine_sobel_batch_dev" ) && sym( A.eqc, "vtmhip_affine_equal_coeff_batch_dev" )
-                 && sym( A.amvp, "vtmhip_xEstimateMvPredAMVP_batch_dev" ) && sym( A.me, "vtmhip_xMotionEstimation_batch_dev" ) && sym( A.xT, "vtmhip_xT_batch_dev" ) && sym( A.tsChain, "vtmhip_tu_ts_chain_batch_dev" )
+                 && sym( A.amvp, "vtmhip_xEstimateMvPredAMVP_batch_dev" ) && sym( A.smvd, "vtmhip_smvd_batch_dev" ) && sym( A.me, "vtmhip_xMotionEstimation_batch_dev" ) && sym( A.xT, "vtmhip_xT_batch_dev" ) && sym( A.tsChain, "vtmhip_tu_ts_chain_batch_dev" )
                  && sym( A.mtsSelect, "vtmhip_mts_select2" ) && sym( A.affineMe, "vtmhip_xAffineMotionEstimation_batch_dev" )
                  && sym( A.lfnstTables, "vtmhip_lfnst_set_tables" ) && sym( A.lfnstTu, "vtmhip_lfnst_tu_batch_dev" );
     if( !ok ) { fprintf( stderr, "ref_encode: libvtmhip.so lacks a pointer-surface symbol\n" ); return -11; }
@@ -845,8 +992,9 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
         if( g_mask & 2 ) installIf( app->m_cEncLib.m_cInterSearch.m_if );
         if( g_mask & 4 ) installTr();
         if( ( g_mask & 16 ) && ( g_countOnly || auxAlloc() ) ) installAux( (AffineGradientSearch &) app->m_cEncLib.m_cInterSearch );   // private base: C-style cast
-        if( ( g_mask & ( 96 | 128 | 256 | 512 ) ) && ( g_countOnly || ( g_ctx && hookAlloc() ) ) ) { g_hookAffine = ( g_mask & 128 ) != 0; g_affineCtr = 0;
+        if( ( g_mask & ( 96 | 128 | 256 | 512 | 1024 ) ) && ( g_countOnly || ( g_ctx && hookAlloc() ) ) ) { g_hookAffine = ( g_mask & 128 ) != 0; g_affineCtr = 0;
           g_hookAmvp = ( g_mask & 512 ) != 0 && !g_countOnly; g_amvpCtr = 0;
+          g_hookSmvd = ( g_mask & 1024 ) != 0 && !g_countOnly; g_smvdCtr[0] = g_smvdCtr[1] = g_smvdCtr[2] = 0;
           g_hookLfnst = ( g_mask & 256 ) != 0 && ( g_countOnly || A.lfnstTables( g_ctx, &g_lfnst8x8[0][0][0][0], &g_lfnst4x4[0][0][0][0] ) == VTMHIP_OK ); g_lfnstCtr[0] = g_lfnstCtr[1] = 0; g_hookMe = ( g_mask & 32 ) != 0; g_hookMts = ( g_mask & 64 ) != 0; g_hookCtr[0] = g_hookCtr[1] = 0;
           g_hookStride = getenv( "VTMREF_HOOK_STRIDE" ) ? strtoull( getenv( "VTMREF_HOOK_STRIDE" ), nullptr, 10 ) : 0; }
       }
@@ -861,7 +1009,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
     }
   }
   catch( Exception &e ) { fprintf( stderr, "ref_encode: %s\n", e.what() ); rc = 2; }
-  g_hookMe = g_hookMts = g_hookAffine = g_hookLfnst = g_hookAmvp = false;
+  g_hookMe = g_hookMts = g_hookAffine = g_hookLfnst = g_hookAmvp = g_hookSmvd = false;
   for( RefPlane &p : g_planes ) A.dfree( g_ctx, p.dev );
   g_planes.clear();
   if( g_ctx || g_countOnly ) { restoreDist(); restoreTr(); restoreAux(); }

@@ -21,7 +21,8 @@ class Stats(C.Structure):
                 ("hookCalls", C.c_uint64 * 2), ("hookDevice", C.c_uint64 * 2), ("hookMismatch", C.c_uint64 * 2), ("hookUnsupported", C.c_uint64 * 2),
                 ("hookFirstMismatch", C.c_int32 * 8), ("affineCalls", C.c_uint64), ("affineDevice", C.c_uint64), ("affineMismatch", C.c_uint64),
                 ("affineUnsupported", C.c_uint64), ("lfnstCalls", C.c_uint64 * 2), ("lfnstDevice", C.c_uint64 * 2), ("lfnstMismatch", C.c_uint64 * 2),
-                ("amvpCalls", C.c_uint64), ("amvpDevice", C.c_uint64), ("amvpMismatch", C.c_uint64), ("amvpUnsupported", C.c_uint64)]
+                ("amvpCalls", C.c_uint64), ("amvpDevice", C.c_uint64), ("amvpMismatch", C.c_uint64), ("amvpUnsupported", C.c_uint64),
+                ("smvdCalls", C.c_uint64 * 3), ("smvdDevice", C.c_uint64 * 3), ("smvdMismatch", C.c_uint64 * 3), ("smvdUnsupported", C.c_uint64)]
 
 
 def write_clip(path, w, h, frames, seed=77):
@@ -47,7 +48,8 @@ def _child(argv_json):
            "hookCalls": list(st.hookCalls), "hookDevice": list(st.hookDevice), "hookMismatch": list(st.hookMismatch), "hookUnsupported": list(st.hookUnsupported),
            "hookFirstMismatch": list(st.hookFirstMismatch), "affine": [st.affineCalls, st.affineDevice, st.affineMismatch, st.affineUnsupported],
            "lfnst": [list(st.lfnstCalls), list(st.lfnstDevice), list(st.lfnstMismatch)],
-           "amvp": [st.amvpCalls, st.amvpDevice, st.amvpMismatch, st.amvpUnsupported]}
+           "amvp": [st.amvpCalls, st.amvpDevice, st.amvpMismatch, st.amvpUnsupported],
+           "smvd": [list(st.smvdCalls), list(st.smvdDevice), list(st.smvdMismatch), st.smvdUnsupported]}
     sys.stdout.flush()
     os.write(2, ("\nDROPIN_RESULT " + json.dumps(out) + "\n").encode())
 

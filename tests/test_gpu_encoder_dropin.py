@@ -39,7 +39,8 @@ def test_reference_encoder_with_batched_hooks(tmp_path, monkeypatch):
     """SURVEY.md Appendix B inside the real encoder: InterSearch::xMotionEstimation replaced by ONE vtmhip_xMotionEstimation_batch_dev call per
     invocation (start candidates, TZ / exhaustive search, fractional or AMVR refinement, rate re-weighting: hooks B1-B6) and the MTS candidate loop of
     TrQuant::transformNxN( trModes ) by one batch of forward transforms + vtmhip_mts_select2 (hook B8); InterSearch::xEstimateMvPredAMVP's template costs and
-    selection by vtmhip_xEstimateMvPredAMVP_batch_dev (hook B7).  The members are intercepted at link level
+    selection by vtmhip_xEstimateMvPredAMVP_batch_dev (hook B7); the three SMVD members (xGetSymmetricCost, xSymmetricMotionEstimation, symmvdCheckBestMvp) by the
+    ops of vtmhip_smvd_batch_dev.  The members are intercepted at link level
     (oracle/Makefile.ref weakens the two reference symbols; oracle/ref_shim_enc.cpp holds the strong definitions).  Every 3rd supported call goes to
     the device, its results replace the reference's and are compared with them; bitstream and reconstruction must equal the plain run's."""
     import time
@@ -49,9 +50,9 @@ def test_reference_encoder_with_batched_hooks(tmp_path, monkeypatch):
     t0 = time.time()
     st0, bits0, rec0 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "plain"), extra=("--LFNST=1",))
     t1 = time.time()
-    st1, bits1, rec1 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "hooks"), True, 32 | 64 | 128 | 256 | 512, 1000000, 64, extra=("--LFNST=1",))
+    st1, bits1, rec1 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "hooks"), True, 32 | 64 | 128 | 256 | 512 | 1024, 1000000, 64, extra=("--LFNST=1",))
     t2 = time.time()
-    print("batched hooks:", {k: st1[k] for k in ("hookCalls", "hookDevice", "hookMismatch", "hookUnsupported", "affine", "lfnst", "amvp", "errors")}, "plain %.1f s, hooked %.1f s" % (t1 - t0, t2 - t1))
+    print("batched hooks:", {k: st1[k] for k in ("hookCalls", "hookDevice", "hookMismatch", "hookUnsupported", "affine", "lfnst", "amvp", "smvd", "errors")}, "plain %.1f s, hooked %.1f s" % (t1 - t0, t2 - t1))
     assert st0["rc"] == 0 and st1["rc"] == 0
     assert st1["errors"] == 0, st1
     assert st1["hookMismatch"] == [0, 0], st1
@@ -59,9 +60,11 @@ def test_reference_encoder_with_batched_hooks(tmp_path, monkeypatch):
     assert st1["affine"][2] == 0 and st1["affine"][1] > 500, st1          # xAffineMotionEstimation: [calls, on the device, mismatches, unsupported]
     assert st1["lfnst"][2] == [0, 0] and min(st1["lfnst"][1]) > 1000, st1  # xFwdLfnst / xInvLfnst: [[calls], [on the device], [mismatches]]
     assert st1["amvp"][2] == 0 and st1["amvp"][1] > 5000, st1               # xEstimateMvPredAMVP: [calls, on the device, mismatches, unsupported]
+    # xGetSymmetricCost / xSymmetricMotionEstimation / symmvdCheckBestMvp: [[calls], [on the device], [mismatches], unsupported]
+    assert st1["smvd"][2] == [0, 0, 0] and min(st1["smvd"][1]) > 50, st1
     assert bits1 == bits0 and rec1 == rec0
     out = os.path.join(enc_dropin.ROOT, "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "encoder_batched_hooks.txt"), "w") as f:
-            f.write("clip %dx%d, %d pictures, QP %d; plain run %.1f s, hooked run %.1f s (every 3rd supported call of xMotionEstimation / xEstimateMvPredAMVP / transformNxN(trModes) / xAffineMotionEstimation / xFwdLfnst / xInvLfnst on the device)\n%r\nbitstream md5 %s (plain %s)\n"
-                    % (W, H, FRAMES, QP, t1 - t0, t2 - t1, {k: st1[k] for k in ("hookCalls", "hookDevice", "hookMismatch", "hookUnsupported", "affine", "lfnst", "amvp", "errors")}, bits1, bits0))
+            f.write("clip %dx%d, %d pictures, QP %d; plain run %.1f s, hooked run %.1f s (every 3rd supported call of xMotionEstimation / xEstimateMvPredAMVP / the SMVD members / transformNxN(trModes) / xAffineMotionEstimation / xFwdLfnst / xInvLfnst on the device)\n%r\nbitstream md5 %s (plain %s)\n"
+                    % (W, H, FRAMES, QP, t1 - t0, t2 - t1, {k: st1[k] for k in ("hookCalls", "hookDevice", "hookMismatch", "hookUnsupported", "affine", "lfnst", "amvp", "smvd", "errors")}, bits1, bits0))
