@@ -773,7 +773,7 @@ typedef struct
   int32_t  mvBi[2][2];             /* cMvBi */
   int32_t  refineList;             /* the list the bi stage searched */
   int32_t  interDir;               /* pu.interDir: 1 list 0, 2 list 1, 3 bi-prediction */
-  int32_t  pad;
+  int32_t  smvdMode;               /* symMode (:2789): 1 when the symmetric-MVD pair replaced the bi vectors, else 0 */
 } vtmhip_pis_pu;
 
 typedef struct
@@ -809,12 +809,19 @@ typedef struct
   vtmhip_affine_me_job *affJobs;   /* [(numRef[0] + numRef[1]) * numPU] or NULL; filled by stage 4 */
   int32_t  affLowDelay;            /* m_pcEncCfg->getIntraPeriod() == -1 (refinement rounds) */
   int32_t  affCheckLDC;            /* slice.getCheckLDC(): PROF's large-gradient rule */
+  /* SMVD block (:2656-2790) between the bi refinement and the uni / bi decision, when the slice has a symmetric reference pair (smvdBit != 0): one
+   * vtmhip_smvd_job per PU, searched list = list 0 */
+  vtmhip_smvd_job      *smvdJobs;  /* [numPU] or NULL; filled by stage 3, searched by vtmhip_smvd_batch_dev( VTMHIP_SMVD_SEARCH ), merged by stage 5 */
+  int32_t  symRefIdx[2];           /* slice.getSymRefIdx( list ) */
 } vtmhip_pis_level;
 
 /* stage 0: AMVP candidates and entry bits of the uni rows (before vtmhip_xEstimateMvPredAMVP_batch_dev)
  * stage 1: after the uni searches: xCheckBestMVP per row, best reference per list; P slices: interDir and predFinal
  * stage 2: B slices: refined list, predOther (the other list's prediction, epilogue as the host set it), the bi rows
- * stage 3: after the bi searches: xCheckBestMVP, best bi row, decision, predFinal
+ * stage 3: after the bi searches: xCheckBestMVP, best bi row, decision, predFinal; with smvdJobs: the SMVD job of every PU instead of the decision (start
+ *          vectors cMvHevcTemp / cMvTemp / cMvBi of list 0's symmetric reference; the m_uniMvList history is CU-recursion state and stays empty)
+ * stage 5: (smvdJobs != NULL) after the SMVD search: symCost < uiCostBi replaces the bi vectors (:2787-2803), then the decision and predFinal (no BDOF for an
+ *          SMVD pair, InterPrediction.cpp:552-555)
  * stage 4: (affJobs != NULL) the affine uni jobs of every row: start vector and predictor = the row's translational result at all control points,
  *          bits = the row's bits before the vector rate, hevcCost = the PU's best translational cost -> vtmhip_xAffineMotionEstimation_batch_dev */
 int vtmhip_pis_stage( vtmhip_ctx *ctx, const vtmhip_pis_level *lvl, int stage );
@@ -823,7 +830,7 @@ int vtmhip_pis_stage( vtmhip_ctx *ctx, const vtmhip_pis_level *lvl, int stage );
  * One call runs the whole chain of a picture over the levels' tables (what vtm_amd/pipeline.py:FrameHotPath.run does call by call from Python:
  * ~130 library calls, 2 ms of interpreter time per picture -- more than a GPU needs for its share of a picture sharded over eight GPUs).
  * Per level: stage 0, xEstimateMvPredAMVP, the uni searches, stage 1 on `mainStream` (a level's AMVP candidates are its parent's vectors: one dependent
- * chain); everything after that -- stage 2, the other list's prediction, the bi refinement, stage 3, the final prediction (plain / BDOF / chroma),
+ * chain); everything after that -- stage 2, the other list's prediction, the bi refinement, stage 3, (the SMVD search, stage 5,) the final prediction (plain / BDOF / chroma),
  * the affine uni stage, the TU chains -- on sideStreams[level % numSide] behind an event, beside the next levels' searches; the side streams join
  * `mainStream` at the end.  numSide == 0: everything on mainStream in level order.  The context's stream is mainStream on return. */
 typedef struct

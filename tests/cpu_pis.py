@@ -84,8 +84,80 @@ def _tu_chain(L, R, r_tu, ts, mts, qp_per, qp_rem, bd):
     return (int(sse), int(np.abs(coef.astype(np.int64)).sum()), asum.value)
 
 
+def _eg_bits(v):
+    t = ((-v) << 1) + 1 if v <= 0 else v << 1
+    return 1 + 2 * (t.bit_length() - 1)
+
+
+def _prec_down(v, rs):
+    o = 1 << (rs - 1)
+    return (v + o - 1) >> rs if v >= 0 else (v + o) >> rs
+
+
+def _smvd_block(L, R, t, starts, mode_bits, lam):
+    """The SMVD block of predInterSearch (InterSearch.cpp:2656-2790, cu.imv 0, no m_uniMvList history) composed here from the three members -- the real ones
+    (ref_*) or the oracle's (vo_*); without the reference the oracle's own composition (vo_smvd_search) must agree."""
+    lib, pre = (R, "ref_") if R else (L, "vo_")
+    I2 = C.c_int * 2
+    cost_fn = getattr(lib, pre + "symmetric_cost")
+    cost_fn.restype = C.c_uint64
+    num = [t.numCand[0], t.numCand[1]]
+    cand = [[(t.cand[l][i][0], t.cand[l][i][1]) for i in range(2)] for l in range(2)]
+    for l in range(2):
+        if num[l] > 1 and cand[l][0] == cand[l][1]:
+            num[l] = 1
+    tt = ol.SmvdJob.from_buffer_copy(bytes(t))
+    tt.numCand[0], tt.numCand[1] = num
+    bits = lambda mv, pred: _eg_bits(_prec_down(mv[0], 2) - _prec_down(pred[0], 2)) + _eg_bits(_prec_down(mv[1], 2) - _prec_down(pred[1], 2))   # noqa: E731
+    rate = lambda b: int(lam * b)   # noqa: E731
+    cost_start, pred_sym, idx_sym = U64, [cand[0][0], cand[1][0]], [0, 0]
+    for i in range(num[0]):
+        for k in range(num[1]):
+            c = cost_fn(C.byref(tt), I2(*cand[0][i]), I2(*cand[1][k]))
+            if c < cost_start:
+                cost_start, pred_sym, idx_sym = c, [cand[0][i], cand[1][k]], [i, k]
+    mv_cur, mv_tar = pred_sym[0], pred_sym[1]
+    cost_start += rate(bits(mv_cur, pred_sym[0]) + t.mvpIdxBits[idx_sym[0]] + t.mvpIdxBits[idx_sym[1]])
+
+    def check(cur, skip, cost):
+        nonlocal pred_sym, idx_sym
+        pr, ix, cc = (I2 * 2)(I2(*pred_sym[0]), I2(*pred_sym[1])), I2(*idx_sym), C.c_uint64(cost)
+        getattr(lib, pre + "symmvd_check_best_mvp")(C.byref(tt), I2(*cur), skip, pr, ix, C.byref(cc))
+        if cc.value < cost:
+            pred_sym, idx_sym = [tuple(pr[0]), tuple(pr[1])], list(ix)
+        return cc.value
+    seen = []
+    for v in starts:
+        if v not in seen:
+            seen.append(v)
+    for v in seen:
+        if v in cand[0][:num[0]]:
+            continue
+        before = cost_start
+        cost_start = check(v, 0, cost_start)
+        if cost_start < before:
+            mv_cur = v
+            mv_tar = (pred_sym[1][0] - v[0] + pred_sym[0][0], pred_sym[1][1] - v[1] + pred_sym[0][1])
+    start_pt = mv_cur
+    mvp_cost = rate(t.mvpIdxBits[idx_sym[0]] + t.mvpIdxBits[idx_sym[1]])
+    mc, mt, cc = I2(*mv_cur), I2(*mv_tar), C.c_uint64(cost_start - mvp_cost)
+    getattr(lib, pre + "symmetric_me")(C.byref(tt), I2(*pred_sym[0]), I2(*pred_sym[1]), mc, mt, C.byref(cc))
+    mv_cur, sym_cost = tuple(mc), cc.value + mvp_cost
+    if mv_cur != tuple(start_pt):
+        sym_cost = check(mv_cur, 1, sym_cost)
+    sym_cost += rate(mode_bits)
+    mv_tar = (pred_sym[1][0] - mv_cur[0] + pred_sym[0][0], pred_sym[1][1] - mv_cur[1] + pred_sym[0][1])
+    res = (mv_cur, mv_tar, tuple(pred_sym[0]), tuple(pred_sym[1]), tuple(idx_sym), sym_cost)
+    if not R:
+        st = ((C.c_int * 2) * len(starts))(*[(C.c_int * 2)(*v) for v in starts])
+        r = ol.SmvdResult()
+        L.vo_smvd_search(C.byref(t), len(starts), len(starts), st, mode_bits, C.byref(r))
+        assert r.key() == res, ("vo_smvd_search vs the composition of its members", r.key(), res)
+    return res
+
+
 def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam, qp_per, qp_rem, tu_cands, ref=None, bd=10, pocs=None, bdof=True, chroma=None,
-           affine=False, low_delay=False):
+           affine=False, low_delay=False, smvd=None):
     """refs / search_ranges as FrameHotPath takes them; cands_rows[list][refIdx] = the two AMVP candidates of that row ((h, v), (h, v)) as the
     device driver derived them from the parent level.  Returns every decision the device pipeline exposes."""
     L, R = ol.oracle(), ref
@@ -133,7 +205,7 @@ def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam,
             t, u = jobs[(rl, r)], rows[(rl, r)]
             t.bi, t.otherPred, t.otherStride = 1, pred_o.ctypes.data, w
             t.mvpIdx, t.mvPredHor, t.mvPredVer, t.mvHor, t.mvVer = u["idx"], u["pred"][0], u["pred"][1], u["mv"][0], u["mv"][1]
-            t.bits = mb[2] + mot_other + _ref_idx_bits(nref[rl], r) + 1
+            t.bits = mb[2] + mot_other + _ref_idx_bits(nref[rl], r) + 1 + (1 if smvd is not None else 0)   # one bit for the SMVD flag (:2590-2593)
             res = ol.MestResult()
             (R.ref_motion_estimation if R else L.vo_motion_estimation)(C.byref(cfg), C.byref(t), C.byref(res))
             row = dict(mv=(res.mvHor, res.mvVer), pred=(res.mvPredHor, res.mvPredVer), idx=res.mvpIdx, bits=res.bits, cost=res.cost)
@@ -141,10 +213,36 @@ def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam,
             row = _check_best(L, R, lam, cands_rows[rl][r], row)
             if row["cost"] < cost_bi:
                 cost_bi, bits2, mv_bi, ref_bi = row["cost"], row["bits"], row["mv"], r
+        mv_bi2, ref_bi2 = [best[0]["mv"], best[1]["mv"]], [best[0]["ref"], best[1]["ref"]]      # cMvBi / iRefIdxBi
+        mv_bi2[rl], ref_bi2[rl] = mv_bi, ref_bi
+        smvd_mode = 0
+        if smvd is not None and w + h > 12:
+            s0, s1 = smvd
+            t = ol.SmvdJob()
+            t.org, t.orgStride = org.ctypes.data, w
+            t.ref[0], t.ref[1] = dpb_ptr + 2 * (refs[0][s0][0] + y * rs + x), dpb_ptr + 2 * (refs[1][s1][0] + y * rs + x)
+            t.refStride[0] = t.refStride[1] = rs
+            t.w, t.h, t.puX, t.puY, t.picW, t.picH, t.ctuSize, t.bitDepth = w, h, x, y, W, H, 128, bd
+            t.imv, t.useSatd, t.clipBiPred, t.bcwWeightTar = 0, 1, 0, 4
+            for l, sr_ in ((0, s0), (1, s1)):
+                t.numCand[l] = 2
+                for i in range(2):
+                    t.cand[l][i][0], t.cand[l][i][1] = cands_rows[l][sr_][i]
+                t.mvpIdxBits[l] = 1
+            t.motionLambda = lam
+            # start vectors: cMvHevcTemp (the uni result), cMvTemp (the bi search overwrote list 0's rows when list 0 was refined), cMvBi on the symmetric reference
+            starts = [rows[(0, s0)]["mv"], out["bi_rows"][s0]["mv"] if rl == 0 else rows[(0, s0)]["mv"]]
+            if ref_bi2[0] == s0:
+                starts.append(mv_bi2[0])
+            sm = _smvd_block(L, R, t, [tuple(v) for v in starts], mb[2] + 1, lam)
+            out["smvd"] = sm
+            if sm[5] < cost_bi:
+                cost_bi, smvd_mode = sm[5], 1
+                mv_bi2, ref_bi2 = [sm[0], sm[1]], [s0, s1]
         inter_dir = 3 if (cost_bi <= best[0]["cost"] and cost_bi <= best[1]["cost"]) else (1 if best[0]["cost"] <= best[1]["cost"] else 2)
-        out.update(rl=rl, cost_bi=cost_bi, bits2=bits2, mv_bi=mv_bi, ref_bi=ref_bi)
+        out.update(rl=rl, cost_bi=cost_bi, bits2=bits2, mv_bi=mv_bi2[rl], ref_bi=ref_bi2[rl], mv_bi2=mv_bi2, ref_bi2=ref_bi2, smvd_mode=smvd_mode)
         if inter_dir == 3:
-            mv_final[rl], ref_final[rl] = mv_bi, ref_bi
+            mv_final, ref_final = list(mv_bi2), list(ref_bi2)
     out["inter_dir"] = inter_dir
     # ---- affine uni stage (predAffineInterSearch's uni loop, 4-parameter): xAffineMotionEstimation per (list, refIdx) from the translational result ----
     if affine and min(w, h) >= 16:
@@ -173,7 +271,7 @@ def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam,
     bio = False
     if inter_dir == 3 and pocs is not None and bdof:     # InterPrediction::xPredInterBi :527-572 / PU::isBiPredFromDifferentDirEqDistPoc
         d0, d1 = pocs[0] - pocs[1][ref_final[0]], pocs[0] - pocs[2][ref_final[1]]
-        bio = d0 * d1 < 0 and abs(d0) == abs(d1) and w >= 8 and h >= 8 and w * h >= 128
+        bio = d0 * d1 < 0 and abs(d0) == abs(d1) and w >= 8 and h >= 8 and w * h >= 128 and not out.get("smvd_mode")
     out["bio"] = bio
     if bio:
         if R:
@@ -266,6 +364,14 @@ def compare_with_device(snap_level, parent_level, nref, i, out):
         rl = out["rl"]
         assert rl == int(pu["refineList"]) and out["cost_bi"] == int(pu["costBi"]) and out["bits2"] == int(pu["bits"][2]), ("bi cost", s, i)
         assert (out["mv_bi"], out["ref_bi"]) == ((int(pu["mvBi"][rl][0]), int(pu["mvBi"][rl][1])), int(pu["refIdxBi"][rl])), ("bi mv", s, i)
+        assert out["smvd_mode"] == int(pu["smvdMode"]), ("smvdMode", s, i)
+        for l in (0, 1):
+            assert (tuple(out["mv_bi2"][l]), out["ref_bi2"][l]) == ((int(pu["mvBi"][l][0]), int(pu["mvBi"][l][1])), int(pu["refIdxBi"][l])), ("bi pair", s, i, l)
+        if "smvd" in out:
+            g = snap_level["smvd_jobs"][i]
+            got = (tuple(int(v) for v in g["mvCur"]), tuple(int(v) for v in g["mvTar"]), tuple(int(v) for v in g["predSym"][0]), tuple(int(v) for v in g["predSym"][1]),
+                   tuple(int(v) for v in g["mvpIdxSym"]), int(g["cost"]))
+            assert out["smvd"] == got, ("smvd search", s, i, out["smvd"], got)
         bo = snap_level["bi_out"]
         for r, me in out["bi_rows"].items():
             g = bo[r * n + i]

@@ -54,7 +54,7 @@ def make_scene(torch, dev, W, H, pocs0, pocs1, cur_poc, hard=True, chroma=False)
     return y, dpb_np, refs, sr, torch.from_numpy(cur_all).to(dev), torch.from_numpy(dpb_np).to(dev), ch_dev, ch_cpu
 
 
-def check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, R, per_level=24, min_checked=60, pocs=None, chroma=None, stats=None, affine=False, low_delay=False):
+def check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, R, per_level=24, min_checked=60, pocs=None, chroma=None, stats=None, affine=False, low_delay=False, smvd=None):
     snaps = hp.snapshot()
     nref = hp.nref
     checked = 0
@@ -67,8 +67,12 @@ def check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, R, per_level=24, min_chec
         s, npu = lvl["size"], lvl["npu"]
         for i in range(0, npu, max(1, npu // per_level)):
             out = cpu_pis.run_pu(cur_np, dpb_np.ctypes.data, refs, sr, W, H, s, int(lvl["xs"][i]), int(lvl["ys"][i]), cpu_pis.cands_of(lvl, nref, i), lam,
-                                 (qp + 12) // 6, (qp + 12) % 6, lvl["cands"], ref=R, pocs=pocs, chroma=chroma, affine=affine, low_delay=low_delay)
+                                 (qp + 12) // 6, (qp + 12) % 6, lvl["cands"], ref=R, pocs=pocs, chroma=chroma, affine=affine, low_delay=low_delay, smvd=smvd)
             cpu_pis.compare_with_device(lvl, parent, nref, i, out)
+            if stats is not None and "smvd" in out:
+                stats["smvd"] = stats.get("smvd", 0) + 1
+                stats["smvd_won"] = stats.get("smvd_won", 0) + out["smvd_mode"]
+                stats["smvd_moved"] = stats.get("smvd_moved", 0) + int(out["smvd"][0] != out["smvd"][2])
             if stats is not None and "aff" in out:
                 stats["aff"] = stats.get("aff", 0) + len(out["aff"])
                 stats["aff_moved"] = stats.get("aff_moved", 0) + sum(1 for (mv, _, _) in out["aff"].values() if len(set(mv)) > 1)
@@ -189,6 +193,36 @@ def test_frame_hot_path_affine_uni_stage(use_ref, name, pocs0, pocs1, cur, low_d
     stats = {}
     check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, ol.ref() if use_ref else None, per_level=8, min_checked=24, stats=stats, affine=True, low_delay=low_delay)
     assert stats["aff"] >= 40 and stats["aff_moved"] >= 3, stats      # rows compared, and rows whose model left pure translation
+    ctx.close()
+
+
+@pytest.mark.parametrize("use_ref", [False, True])
+@pytest.mark.parametrize("name,pocs0,pocs1,cur,sym,hard", [("ra_1+1", [0], [4], 2, (0, 0), True), ("ra_2+2", [2, 0], [4, 6], 3, (0, 0), False), ("ra_2+2_far", [2, 0], [6, 4], 3, (1, 0), True)])
+def test_frame_hot_path_smvd_stage(use_ref, name, pocs0, pocs1, cur, sym, hard):
+    """The SMVD block of predInterSearch in the driver (between the bi refinement and the uni / bi decision): predictor pair, start vectors, symmvdCheckBestMvp,
+    xSymmetricMotionEstimation, the final predictor check and the symCost < uiCostBi replacement -- every sampled PU against the chain built from the oracle's
+    members and from the reference's own three members; BDOF is off for the PUs the pair wins, the final prediction and the TU chains follow."""
+    torch = pytest.importorskip("torch")
+    from vtm_amd.device import Context
+    if use_ref and not ol.have_ref():
+        pytest.skip("oracle/_ref/libvtmref.so not present")
+    W, H = 256, 128
+    dev = torch.device("cuda", 0)
+    cur_np, dpb_np, refs, sr, cur_d, dpb = make_scene(torch, dev, W, H, pocs0, pocs1, cur, hard=hard)
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    lam, qp = 8.0, 32
+    pocs = (cur, pocs0, pocs1)
+    hp = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, sizes=(128, 64, 32, (32, 16), 16, 8), pocs=pocs, smvd=sym)
+    for native in (True, False):
+        hp.run(cur_d.data_ptr(), dpb.data_ptr(), timing=not native)
+        torch.cuda.synchronize()
+        stats = {}
+        check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, ol.ref() if use_ref else None, per_level=16 if native else 5, min_checked=40 if native else 12, pocs=pocs,
+              stats=stats, smvd=sym)
+        assert stats["smvd"] >= (40 if native else 12), stats
+    print("smvd:", name, stats)
+    assert stats["smvd_moved"] >= 1, stats
     ctx.close()
 
 

@@ -126,7 +126,7 @@ __device__ __forceinline__ void final_pred( const vtmhip_pis_level &L, int pu, c
   if( bi && L.bdofEnabled )
   {
     const int d0 = L.curPoc - L.refPoc[0][r0], d1 = L.curPoc - L.refPoc[1][r1];
-    bio = d0 * d1 < 0 && abs( d0 ) == abs( d1 ) && pf.width >= 8 && pf.height >= 8 && pf.width * pf.height >= 128;
+    bio = d0 * d1 < 0 && abs( d0 ) == abs( d1 ) && pf.width >= 8 && pf.height >= 8 && pf.width * pf.height >= 128 && !P.smvdMode;
   }
   pf.route = bio ? 1 : 2;
   if( L.predFinalC )
@@ -149,7 +149,7 @@ __global__ __launch_bounds__( 256 ) void pis_uni_select_kernel( vtmhip_pis_level
   P.refIdx[0] = P.refIdx[1] = P.refIdxBi[0] = P.refIdxBi[1] = -1;
   P.mv[0][0] = P.mv[0][1] = P.mv[1][0] = P.mv[1][1] = 0;
   P.mvBi[0][0] = P.mvBi[0][1] = P.mvBi[1][0] = P.mvBi[1][1] = 0;
-  P.refineList = 0; P.interDir = 1; P.pad = 0;
+  P.refineList = 0; P.interDir = 1; P.smvdMode = 0;
   for( int list = 0; list < 2; list++ )
     for( int ref = 0; ref < L.numRef[list]; ref++ )
     {
@@ -212,7 +212,57 @@ __global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
     check_best_mvp( j, r );
     if( r.cost < P.costBi ) { P.costBi = r.cost; P.bits[2] = r.bits; P.mvBi[rl][0] = r.mvHor; P.mvBi[rl][1] = r.mvVer; P.refIdxBi[rl] = ref; }
   }
+  if( L.smvdJobs )
+  {
+    // the SMVD block (:2656-2790) for list 0 and the slice's symmetric reference pair: AMVP lists of the two rows, start vectors cMvHevcTemp (the uni
+    // result), cMvTemp (overwritten by the bi search when list 0 was the refined one) and cMvBi when it points at the symmetric reference
+    const int s0 = L.symRefIdx[0], s1 = L.symRefIdx[1];
+    const vtmhip_me_job &u0 = L.uniJobs[uni_row( L, 0, s0, pu )], &u1 = L.uniJobs[uni_row( L, 1, s1, pu )];
+    const vtmhip_pis_row &r0 = L.uniRows[uni_row( L, 0, s0, pu )];
+    vtmhip_smvd_job j;
+    j.orgOff = u0.orgOff; j.refOff[0] = u0.refOff; j.refOff[1] = u1.refOff; j.orgStride = u0.orgStride; j.refStride[0] = u0.refStride; j.refStride[1] = u1.refStride;
+    j.puX = u0.puX; j.puY = u0.puY; j.width = u0.width; j.height = u0.height;
+    j.imv = 0; j.useSatd = 1; j.clipBiPred = 0; j.bcwWeightTar = 4;
+    j.numCand[0] = u0.numAmvpCand; j.numCand[1] = u1.numAmvpCand; j.skip = 0; j.pad_[0] = j.pad_[1] = j.pad_[2] = 0;
+    for( int c = 0; c < 2; c++ )
+    {
+      j.cand[0][c][0] = u0.amvpCand[c][0]; j.cand[0][c][1] = u0.amvpCand[c][1]; j.cand[1][c][0] = u1.amvpCand[c][0]; j.cand[1][c][1] = u1.amvpCand[c][1];
+      j.mvpIdxBits[c] = u0.mvpIdxBits[c];
+    }
+    j.modeBits = L.mbBits[2] + 1; j.motionLambda = u0.motionLambda;
+    int ns = 0;
+    j.starts[ns][0] = r0.mvHor; j.starts[ns][1] = r0.mvVer; ns++;
+    if( rl == 0 ) { const vtmhip_me_out o = L.biOut[s0 * L.numPU + pu]; j.starts[ns][0] = o.mvHor; j.starts[ns][1] = o.mvVer; }
+    else { j.starts[ns][0] = r0.mvHor; j.starts[ns][1] = r0.mvVer; }
+    ns++;
+    if( P.refIdxBi[0] == s0 ) { j.starts[ns][0] = P.mvBi[0][0]; j.starts[ns][1] = P.mvBi[0][1]; ns++; }
+    for( int k = ns; k < VTMHIP_SMVD_MAX_START; k++ ) j.starts[k][0] = j.starts[k][1] = 0;
+    j.numStart = ( uint8_t ) ns; j.numFixed = ( uint8_t ) ns;
+    j.mvCur[0] = j.mvCur[1] = j.mvTar[0] = j.mvTar[1] = 0;
+    for( int l = 0; l < 2; l++ ) { j.predSym[l][0] = j.predSym[l][1] = 0; j.mvpIdxSym[l] = 0; }
+    j.cost = ~0ull;
+    L.smvdJobs[pu] = j;
+    L.pus[pu] = P;
+    return;
+  }
   P.interDir = ( P.costBi <= P.cost[0] && P.costBi <= P.cost[1] ) ? 3 : ( P.cost[0] <= P.cost[1] ? 1 : 2 );   // :2846-2893
+  final_pred( L, pu, P );
+  L.pus[pu] = P;
+}
+
+__global__ __launch_bounds__( 256 ) void pis_smvd_merge_kernel( vtmhip_pis_level L )
+{
+  const int pu = blockIdx.x * 256 + threadIdx.x;
+  if( pu >= L.numPU ) return;
+  vtmhip_pis_pu          P = L.pus[pu];
+  const vtmhip_smvd_job &j = L.smvdJobs[pu];
+  if( j.cost < P.costBi )   // :2787-2803
+  {
+    P.costBi = j.cost; P.smvdMode = 1;
+    P.mvBi[0][0] = j.mvCur[0]; P.mvBi[0][1] = j.mvCur[1]; P.refIdxBi[0] = L.symRefIdx[0];
+    P.mvBi[1][0] = j.mvTar[0]; P.mvBi[1][1] = j.mvTar[1]; P.refIdxBi[1] = L.symRefIdx[1];
+  }
+  P.interDir = ( P.costBi <= P.cost[0] && P.costBi <= P.cost[1] ) ? 3 : ( P.cost[0] <= P.cost[1] ? 1 : 2 );
   final_pred( L, pu, P );
   L.pus[pu] = P;
 }
@@ -331,7 +381,7 @@ int vtmhip_merge_cand_satd_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *
 int vtmhip_pis_stage( vtmhip_ctx *ctx, const vtmhip_pis_level *lvl, int stage )
 {
   VTMHIP_CHECK_CTX( ctx );
-  VTMHIP_REQUIRE( ctx, lvl && stage >= 0 && stage <= 4, "level / stage" );
+  VTMHIP_REQUIRE( ctx, lvl && stage >= 0 && stage <= 5, "level / stage" );
   VTMHIP_REQUIRE( ctx, lvl->numPU >= 0 && lvl->numRef[0] >= 1 && lvl->numRef[0] <= VTMHIP_MAX_REF && lvl->numRef[1] >= 0 && lvl->numRef[1] <= VTMHIP_MAX_REF, "numPU / numRef" );
   if( lvl->numPU == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, lvl->uniJobs && lvl->uniOut && lvl->uniRows && lvl->pus && lvl->predFinal && lvl->pos, "null pointer in the level" );
@@ -340,6 +390,11 @@ int vtmhip_pis_stage( vtmhip_ctx *ctx, const vtmhip_pis_level *lvl, int stage )
   const dim3 perPU( ( lvl->numPU + 255 ) / 256 ), perRow( ( rows + 255 ) / 256 ), tpb( 256 );
   if( stage == 0 ) hipLaunchKernelGGL( pis_cands_kernel, perRow, tpb, 0, ctx->stream, *lvl );
   else if( stage == 1 ) hipLaunchKernelGGL( pis_uni_select_kernel, perPU, tpb, 0, ctx->stream, *lvl );
+  else if( stage == 5 )
+  {
+    VTMHIP_REQUIRE( ctx, lvl->smvdJobs && lvl->numRef[1] > 0, "stage 5 needs the SMVD job table of a B slice" );
+    hipLaunchKernelGGL( pis_smvd_merge_kernel, perPU, tpb, 0, ctx->stream, *lvl );
+  }
   else if( stage == 4 )
   {
     VTMHIP_REQUIRE( ctx, lvl->affJobs, "stage 4 needs the affine job table" );

@@ -168,7 +168,7 @@ class PisRow(C.Structure):
 
 class PisPu(C.Structure):
     _fields_ = [("cost", C.c_uint64 * 2), ("costBi", C.c_uint64), ("bits", C.c_uint32 * 3), ("refIdx", C.c_int32 * 2), ("mv", (C.c_int32 * 2) * 2),
-                ("refIdxBi", C.c_int32 * 2), ("mvBi", (C.c_int32 * 2) * 2), ("refineList", C.c_int32), ("interDir", C.c_int32), ("pad", C.c_int32)]
+                ("refIdxBi", C.c_int32 * 2), ("mvBi", (C.c_int32 * 2) * 2), ("refineList", C.c_int32), ("interDir", C.c_int32), ("smvdMode", C.c_int32)]
 
 
 class PisLevel(C.Structure):
@@ -177,7 +177,7 @@ class PisLevel(C.Structure):
                 ("predOther", C.c_void_p), ("biJobs", C.c_void_p), ("biOut", C.c_void_p), ("predFinal", C.c_void_p), ("parentIdx", C.c_void_p),
                 ("parentRows", C.c_void_p), ("parentNumPU", C.c_int32), ("pad", C.c_int32), ("pos", C.c_void_p), ("bdofEnabled", C.c_int32), ("curPoc", C.c_int32),
                 ("refPoc", (C.c_int32 * MAX_REF) * 2), ("predFinalC", C.c_void_p), ("posC", C.c_void_p), ("refPlaneOffC", ((C.c_int64 * MAX_REF) * 2) * 2),
-                ("affJobs", C.c_void_p), ("affLowDelay", C.c_int32), ("affCheckLDC", C.c_int32)]
+                ("affJobs", C.c_void_p), ("affLowDelay", C.c_int32), ("affCheckLDC", C.c_int32), ("smvdJobs", C.c_void_p), ("symRefIdx", C.c_int32 * 2)]
 
 
 class PisLevelRun(C.Structure):

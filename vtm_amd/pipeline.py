@@ -83,9 +83,10 @@ def quadtree_levels(pic_w, pic_h, sizes=(128, 64, 32, 16, 8), row_filter=None, c
 # ======================================================================================================================
 # Level-order InterSearch::predInterSearch (InterSearch.cpp:2245-3065, translational part) + residual coding of one picture
 # ======================================================================================================================
-from .lib import MAX_REF, AffineMeJob, AffineMeOut, FracJob, FracResult, MeCfg, MeJob, MeOut, PisBuffers, PisLevel, PisLevelRun, PisPu, PisRow, PredJob, TuJob   # noqa: E402
+from .lib import MAX_REF, AffineMeJob, AffineMeOut, FracJob, FracResult, MeCfg, MeJob, MeOut, PisBuffers, PisLevel, PisLevelRun, PisPu, PisRow, PredJob, SmvdJob, TuJob   # noqa: E402
 
 AFF_DT, AFFOUT_DT = np.dtype(AffineMeJob), np.dtype(AffineMeOut)
+SMVD_DT = np.dtype(SmvdJob)
 
 FRAC_DT, FRACRES_DT = np.dtype(FracJob), np.dtype(FracResult)
 TU_DT = np.dtype(TuJob)
@@ -174,10 +175,12 @@ class FrameHotPath:
     per list, per reference picture, inside the reference buffer), ref_stride=...) -- adds the 4:2:0 chroma planes to the final prediction, the residual and
     the TU chains (DCT2, chroma QP by the CTC mapping table).
     affine: adds the affine uni stage for PUs of at least 16x16: InterSearch::xAffineMotionEstimation (4-parameter model, uni-directional) per (PU, list, refIdx),
-    started from and predicted by the row's translational result; low_delay: getIntraPeriod() == -1 / getCheckLDC() of the low-delay configurations."""
+    started from and predicted by the row's translational result; low_delay: getIntraPeriod() == -1 / getCheckLDC() of the low-delay configurations.
+    smvd: (refIdx in list 0, refIdx in list 1) = slice.getSymRefIdx() of a slice with getBiDirPred(): adds the symmetric-MVD block of predInterSearch (:2656-2790)
+    between the bi refinement and the uni / bi decision (one vtmhip_smvd_batch_dev search per PU; one more bit on the bi rows, :2590-2593)."""
 
     def __init__(self, ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda=8.0, qp=32, sizes=(128, 64, 32, 16, 8),
-                 ctu_filter=None, transform_skip=False, bit_depth=10, pocs=None, chroma=None, bdof=True, affine=False, low_delay=False):
+                 ctu_filter=None, transform_skip=False, bit_depth=10, pocs=None, chroma=None, bdof=True, affine=False, low_delay=False, smvd=None):
         T, dev = torch, device
         self.ctx, self.torch, self.device = ctx, T, dev
         self.pic_w, self.pic_h, self.org_stride, self.lam = pic_w, pic_h, org_stride, motion_lambda
@@ -200,6 +203,7 @@ class FrameHotPath:
         cands = [0] + ([1] if transform_skip else []) + [2, 3, 4, 5]
         self.pocs, self.chroma = pocs, chroma
         self.affine = bool(affine)
+        self.smvd = tuple(smvd) if (smvd is not None and nref[1] > 0) else None
         self.bdof = bool(bdof and pocs is not None and self.is_b)
         if chroma is not None:
             cqp = chroma_qp(qp) + 6 * (bit_depth - 8)
@@ -252,7 +256,7 @@ class FrameHotPath:
                 par32 = T.from_numpy(parent.astype(np.int32)).to(dev)
             lvl["parent32"] = par32
             L = PisLevel()
-            L.numPU, L.smvdBit, L.refStride = n, 0, rs
+            L.numPU, L.smvdBit, L.refStride = n, int(self.smvd is not None), rs
             L.numRef[0], L.numRef[1] = nref
             L.mbBits[0], L.mbBits[1], L.mbBits[2] = (3 if self.is_b else 1), 3, 5      # xGetBlkBits (:3164-3169)
             for l in (0, 1):
@@ -302,6 +306,9 @@ class FrameHotPath:
                 lvl["aff_jobs"] = T.zeros((R * n, AFF_DT.itemsize), dtype=T.uint8, device=dev)
                 lvl["aff_out"] = T.zeros((R * n, AFFOUT_DT.itemsize), dtype=T.uint8, device=dev)
                 L.affJobs, L.affLowDelay, L.affCheckLDC = lvl["aff_jobs"].data_ptr(), int(low_delay), int(low_delay)
+            if self.smvd is not None and w + h > 12:
+                lvl["smvd_jobs"] = T.zeros((n, SMVD_DT.itemsize), dtype=T.uint8, device=dev)
+                L.smvdJobs, L.symRefIdx[0], L.symRefIdx[1] = lvl["smvd_jobs"].data_ptr(), self.smvd[0], self.smvd[1]
             lvl["pis"] = L
             lvl["pic"] = PicParams(pic_w, pic_h, 128, bit_depth, wpj.get(max(w, h), 1))
             lvl["pic_bi"] = PicParams(pic_w, pic_h, 128, bit_depth, FULL_WAVES_PER_JOB.get(max(w, h), 1))
@@ -403,6 +410,11 @@ class FrameHotPath:
             self._mark("bi_me")
             ctx.pis_stage(lvl["pis"], 3)
             self._mark("glue")
+            if "smvd_jobs" in lvl:
+                ctx.smvd_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["smvd_jobs"].data_ptr(), n, w, h, 3)
+                self._mark("smvd")
+                ctx.pis_stage(lvl["pis"], 5)
+                self._mark("glue")
         ctx.motion_compensation_batch(org_ptr, dpb_ptr, buf["pred"].data_ptr(), buf["resi"].data_ptr(), lvl["pred_final"].ptr, n, w, h)
         if self.bdof and w * h >= 128:      # the PUs the final stage routed to BDOF (bi-prediction from opposite directions at equal POC distance; 8x8 never qualifies)
             ctx.bdof_batch(org_ptr, dpb_ptr, buf["pred"].data_ptr(), buf["resi"].data_ptr(), lvl["pred_final"].ptr, n, w, h)
@@ -482,6 +494,8 @@ class FrameHotPath:
                 d["bi_jobs"] = lvl["bi_jobs"].t.cpu().numpy().view(ME_DT).reshape(-1)
                 d["bi_out"] = lvl["bi_out"].cpu().numpy().view(MEOUT_DT).reshape(-1)
             d["route"] = lvl["pred_final"].col("route").cpu().numpy()
+            if "smvd_jobs" in lvl:
+                d["smvd_jobs"] = lvl["smvd_jobs"].cpu().numpy().view(SMVD_DT).reshape(-1)
             if "aff_jobs" in lvl:
                 d["aff_jobs"] = lvl["aff_jobs"].cpu().numpy().view(AFF_DT).reshape(-1)
                 d["aff_out"] = lvl["aff_out"].cpu().numpy().view(AFFOUT_DT).reshape(-1)
@@ -504,4 +518,5 @@ class FrameHotPath:
     def work_counts(self):
         R = self.nref[0] + self.nref[1]
         return dict(pus=self.NP, uni_searches=R * self.NP, bi_searches=(self.nref[0] if self.is_b else 0) * self.NP,
-                    tu_chains=sum(l["ntu"] * l["nc"] for l in self.levels), affine_searches=sum(R * l["npu"] for l in self.levels if "aff_jobs" in l))
+                    tu_chains=sum(l["ntu"] * l["nc"] for l in self.levels), affine_searches=sum(R * l["npu"] for l in self.levels if "aff_jobs" in l),
+                    smvd_searches=sum(l["npu"] for l in self.levels if "smvd_jobs" in l))
