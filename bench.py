@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 SIMDS, CLOCK_HZ = 1024, 2.4e9          # 256 CUs x 4 SIMDs, peak shader clock (MI355X_MICROARCH.md)
 SALU_CYCLES = 4.03   # measured: cycles per scalar instruction per SIMD (profiles/r02_valu_issue.jsonl, s_add_u32, 1 .. 8 waves)
 KERNELS = ("tz_search_kernel", "tz_raster_cols_kernel", "frac_search_sq_kernel", "full_search_sq_kernel", "full_search_kernel", "motion_comp_kernel", "tu_chain_uni_kernel",
-           "dist_uniform_kernel", "tu_ts_kernel", "bdof_kernel", "tu_chain_lane_kernel", "affine_me_kernel")
+           "dist_uniform_kernel", "tu_ts_kernel", "bdof_kernel", "tu_chain_lane_kernel", "affine_me_kernel", "smvd_kernel")
 
 
 def parse():
@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--partition", choices=["qt", "btt"], default="qt", help="qt: the five quadtree levels 128 .. 8 (the headline workload); btt: a binary / ternary "
                     "split mix -- 128x128, 64x64, 64x32, 32x32, 32x16, 16x16, 16x8, 8x8 -- through the rectangular fast paths")
+    ap.add_argument("--smvd", action="store_true", help="add the symmetric-MVD block of predInterSearch (one search per PU between the bi refinement and the uni / bi decision; ra only)")
     ap.add_argument("--affine", action="store_true", help="add the affine uni stage: xAffineMotionEstimation (4-parameter) per (PU >= 16x16, list, refIdx) -- BASELINE config 5's tool set")
     ap.add_argument("--luma-only", action="store_true", help="no chroma planes and no BDOF in the final prediction (the round-2 mid-round operating point)")
     ap.add_argument("--graph", choices=["on", "off"], default="off", help="replay the picture's launches from a hipGraph (captured once per reference buffer).  Measured: no gain -- "
@@ -64,7 +65,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, budget_s, pocs=None, chroma=None, affine=False, low_delay=False):
+def cpu_baseline(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, budget_s, pocs=None, chroma=None, affine=False, low_delay=False, smvd=None):
     """The SAME chain (tests/cpu_pis.py) for a bounded random sample of PUs of every level on one host core, extrapolated per level to the
     picture.  kind "reference": every step through the real VTM 9.3 members compiled in place (xEstimateMvPredAMVP, xMotionEstimation,
     xCheckBestMVP, filterHor / filterVer, removeHighFreq / addAvg, TrQuant::xT / xIT, distFunc with the x86 SIMD tables; quant / dequant: the
@@ -92,7 +93,7 @@ def cpu_baseline(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, budget_s, pocs=Non
             cands = cpu_pis.cands_of(lvl, hp.nref, i)
             t0 = time.perf_counter()
             out = cpu_pis.run_pu(cur_np, dpb_np.ctypes.data, refs, sr, W, H, s, int(lvl["xs"][i]), int(lvl["ys"][i]), cands, lam, (qp + 12) // 6, (qp + 12) % 6,
-                                 lvl["cands"], ref=R, pocs=pocs, chroma=chroma, affine=affine, low_delay=low_delay)
+                                 lvl["cands"], ref=R, pocs=pocs, chroma=chroma, affine=affine, low_delay=low_delay, smvd=smvd)
             t_lvl += time.perf_counter() - t0
             n_lvl += 1
             try:
@@ -208,9 +209,10 @@ def main():
     sim = int(os.environ.get("VTM_BENCH_SIMULATE_WORLD", "0"))      # one GPU computing rank 0's share of an N-GPU run (no exchange): what a rank's step costs
     if sim > 1 and world == 1:
         ctu_filter = pipeline.band_filter(W, pipeline.ctu_bands(W, H, sim, unit=a.shard)[0])
+    smvd = (0, 0) if (a.smvd and a.config == "ra") else None      # the nearest picture of either list: equal POC distance, opposite directions (Slice::checkBiDirPred)
     fme_sizes = (128, 64, 32, 16, 8) if a.partition == "qt" else (128, (64, 64), (64, 32), (32, 32), (32, 16), (16, 16), (16, 8), (8, 8))
     fme = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, ctu_filter=ctu_filter, transform_skip=a.transform_skip, pocs=poc_arg, chroma=ch_dev,
-                       sizes=fme_sizes, affine=a.affine, low_delay=a.config == "ldp")
+                       sizes=fme_sizes, affine=a.affine, low_delay=a.config == "ldp", smvd=smvd)
 
     # N > 1: the planes of the picture reconstructed last go from rank 0 to every GPU inside every step (RCCL broadcast over xGMI; bytes view: int16 is
     # not a collective dtype), double-buffered: the planes of step k + 1 travel while step k computes; the ranks' result records go back to rank 0
@@ -225,7 +227,7 @@ def main():
     fmes, lanes, turn = [fme], [torch.cuda.current_stream()], [0]
     for _ in range(1, max(1, a.inflight) if not use_dist else 1):
         fmes.append(FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, ctu_filter=ctu_filter, transform_skip=a.transform_skip, pocs=poc_arg, chroma=ch_dev,
-                                 sizes=fme_sizes, affine=a.affine, low_delay=a.config == "ldp"))
+                                 sizes=fme_sizes, affine=a.affine, low_delay=a.config == "ldp", smvd=smvd))
         lanes.append(torch.cuda.Stream(device=dev))
 
     use_graph = a.graph == "on" and not a.serial
@@ -389,6 +391,7 @@ def main():
                                       wc["pus"] * world if world > 1 else wc["pus"], len(refs[0]), len(refs[1]),
                                       wc["uni_searches"], wc["bi_searches"], wc["tu_chains"])
                                    + (", %d affine uni searches (4-parameter xAffineMotionEstimation, PUs >= 16x16)" % wc["affine_searches"] if a.affine else "")
+                                   + (", %d SMVD searches (the symmetric-MVD block of predInterSearch)" % wc["smvd_searches"] if smvd else "")
                                    + (" (this rank's share)" if world > 1 else ""),
                        "stages": ["xEstimateMvPredAMVP", "xMotionEstimation uni (TZ + frac)", "xCheckBestMVP / best reference", "bi refinement (MC + removeHighFreq fused, xPatternSearch, frac)",
                                   "uni/bi decision", "final prediction + residual (fused)" + ("" if a.luma_only else "; BDOF where xPredInterBi applies it; Cb / Cr prediction + residual"),
@@ -407,7 +410,7 @@ def main():
             r["pairs_per_s_G"] = nb * 81 / (satd_k_ms / satd_k_n) / 1e6
             out["satd_roofline"] = r
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fme, cur_np, dpb_np, refs, sr, W, H, lam, qp, a.cpu_seconds, pocs=poc_arg, chroma=ch_cpu, affine=a.affine, low_delay=a.config == "ldp")
+            out["cpu_baseline"] = cpu_baseline(fme, cur_np, dpb_np, refs, sr, W, H, lam, qp, a.cpu_seconds, pocs=poc_arg, chroma=ch_cpu, affine=a.affine, low_delay=a.config == "ldp", smvd=smvd)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()

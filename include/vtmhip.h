@@ -690,6 +690,7 @@ int vtmhip_xPredAffineBlk_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *p
 #define VTMHIP_SMVD_ME 1
 #define VTMHIP_SMVD_CHECK_MVP 2
 #define VTMHIP_SMVD_SEARCH 3
+#define VTMHIP_SMVD_UNIFORM 0x100  /* or-ed into op: every job is exactly maxWidth x maxHeight (8x8 .. 16x16, bitDepth <= 10: the lane-per-tile kernel) */
 #define VTMHIP_SMVD_MAX_START 16
 typedef struct
 {

@@ -38,15 +38,16 @@ def hip_jobs(scene, jobs):
     return arr
 
 
-def run_op(ctx, scene, d_cur, d_ref, arr, n, op, max_w=128, max_h=128):
+def run_op(ctx, scene, d_cur, d_ref, arr, n, op, max_w=128, max_h=128, uniform=False):
     pic = PicParams(scene.W, scene.H, 128, 10, 0)
     d_jobs = ctx.to_device(np.frombuffer(arr, np.uint8))
-    ctx.smvd_batch(pic, d_cur.ptr, d_ref.ptr, d_jobs.ptr, n, max_w, max_h, op)
+    ctx.smvd_batch(pic, d_cur.ptr, d_ref.ptr, d_jobs.ptr, n, max_w, max_h, op, uniform=uniform)
     return (SmvdJob * n).from_buffer_copy(d_jobs.to_host(np.uint8).tobytes())
 
 
-def device_member_results(ctx, scene, jobs):
-    """the same three calls as me_util.smvd_member_results, each as one batch"""
+def device_member_results(ctx, scene, jobs, size=None):
+    """the same three calls as me_util.smvd_member_results, each as one batch (size: all jobs have that shape -> the uniform form of the call)"""
+    kw = dict(max_w=size[0], max_h=size[1], uniform=True) if size else {}
     d_cur = ctx.to_device(scene.cur)
     d_ref = ctx.to_device(np.concatenate([scene.ref_buf.reshape(-1), scene.ref_buf2.reshape(-1)]))
     arr = hip_jobs(scene, jobs)
@@ -57,15 +58,15 @@ def device_member_results(ctx, scene, jobs):
         t.mvTar[0], t.mvTar[1] = pt[0] - (start[0] - pc[0]), pt[1] - (start[1] - pc[1])
         t.predSym[0][0], t.predSym[0][1] = pc
         t.predSym[1][0], t.predSym[1][1] = pt
-    c0 = [r.cost for r in run_op(ctx, scene, d_cur, d_ref, arr, n, 0)]
+    c0 = [r.cost for r in run_op(ctx, scene, d_cur, d_ref, arr, n, 0, **kw)]
     for t, j, c in zip(arr, jobs, c0):
         t.cost = c + int(j["lam"] * 6)
-    me = [(tuple(r.mvCur), tuple(r.mvTar), r.cost) for r in run_op(ctx, scene, d_cur, d_ref, arr, n, 1)]
+    me = [(tuple(r.mvCur), tuple(r.mvTar), r.cost) for r in run_op(ctx, scene, d_cur, d_ref, arr, n, 1, **kw)]
     for t, j, c in zip(arr, jobs, c0):
         t.cost, t.skip = c + int(j["lam"] * 9), j["x"] // 4 & 1
         t.mvpIdxSym[0] = t.mvpIdxSym[1] = 0
-    chk = [(tuple(r.predSym[0]), tuple(r.predSym[1]), tuple(r.mvpIdxSym), r.cost) for r in run_op(ctx, scene, d_cur, d_ref, arr, n, 2)]
-    full = [(tuple(r.mvCur), tuple(r.mvTar), tuple(r.predSym[0]), tuple(r.predSym[1]), tuple(r.mvpIdxSym), r.cost) for r in run_op(ctx, scene, d_cur, d_ref, arr, n, 3)]
+    chk = [(tuple(r.predSym[0]), tuple(r.predSym[1]), tuple(r.mvpIdxSym), r.cost) for r in run_op(ctx, scene, d_cur, d_ref, arr, n, 2, **kw)]
+    full = [(tuple(r.mvCur), tuple(r.mvTar), tuple(r.predSym[0]), tuple(r.predSym[1]), tuple(r.mvpIdxSym), r.cost) for r in run_op(ctx, scene, d_cur, d_ref, arr, n, 3, **kw)]
     return list(zip(c0, me, chk)), full
 
 
@@ -85,19 +86,21 @@ def test_smvd_matches_oracle(ctx, hard):
     assert moved > 100, moved
 
 
-def test_smvd_uniform_small_batches(ctx):
-    """one wave per PU (<= 32x32) and the four-wave form, every size alone so that maxWidth / maxHeight equal the block"""
+@pytest.mark.parametrize("hard", [False, True])
+def test_smvd_uniform_batches(ctx, hard):
+    """every size alone as a uniform batch: the lane-per-tile kernel (8x8, 16x8, 8x16, 16x16: up to eight candidates of a PU per pass, 2 .. 8 PUs per wave),
+    one wave per PU up to 32x32 and the four-wave form above -- all four ops"""
     L = ol.oracle()
-    scene = me_util.SmvdScene(416, 240, hard=True)
-    d_cur = ctx.to_device(scene.cur)
-    d_ref = ctx.to_device(np.concatenate([scene.ref_buf.reshape(-1), scene.ref_buf2.reshape(-1)]))
+    scene = me_util.SmvdScene(416, 240, hard=hard)
     for size in me_util.SMVD_SIZES:
-        jobs = me_util.random_smvd_jobs(scene, 24, seed=size[0] * 131 + size[1], sizes=[size])
-        arr = hip_jobs(scene, jobs)
-        res = run_op(ctx, scene, d_cur, d_ref, arr, len(jobs), 3, size[0], size[1])
-        for k, (r, j) in enumerate(zip(res, jobs)):
-            got = (tuple(r.mvCur), tuple(r.mvTar), tuple(r.predSym[0]), tuple(r.predSym[1]), tuple(r.mvpIdxSym), r.cost)
-            assert got == me_util.smvd_search_oracle(scene, j, L), (size, k, j)
+        tile = max(size) <= 16 and min(size) >= 8
+        jobs = me_util.random_smvd_jobs(scene, 150 if tile else 20, seed=size[0] * 131 + size[1] + hard, sizes=[size])
+        got, full = device_member_results(ctx, scene, jobs, size)
+        for k, j in enumerate(jobs):
+            exp = me_util.smvd_member_results(scene, j, L, "vo_")
+            assert got[k] == exp, ("members", size, k, j, got[k], exp)
+            e = me_util.smvd_search_oracle(scene, j, L)
+            assert full[k] == e, ("whole block", size, k, j, full[k], e)
 
 
 def test_smvd_matches_golden_from_reference(ctx):

@@ -53,7 +53,7 @@ int run_rest( vtmhip_ctx *ctx, const vtmhip_pis_level_run &L, const vtmhip_pis_b
     if( st ) return st;
     if( L.pis.smvdJobs )   // the SMVD block sits between the bi refinement and the uni / bi decision
     {
-      st = vtmhip_smvd_batch_dev( ctx, &L.pic, b.org, b.dpb, L.pis.smvdJobs, n, w, h, VTMHIP_SMVD_SEARCH );
+      st = vtmhip_smvd_batch_dev( ctx, &L.pic, b.org, b.dpb, L.pis.smvdJobs, n, w, h, VTMHIP_SMVD_SEARCH | VTMHIP_SMVD_UNIFORM );
       if( st ) return st;
       st = vtmhip_pis_stage( ctx, &L.pis, 5 );
       if( st ) return st;

@@ -10,6 +10,7 @@
 #include "ctx.hpp"
 #include "had.hpp"
 #include "mc_block.hpp"
+#include <cstdlib>
 
 namespace
 {
@@ -303,6 +304,385 @@ __global__ __launch_bounds__( THREADS ) void smvd_kernel( vtmhip_pic_params pic,
   }
 }
 
+
+// =====================================================================================================================================
+// Small PUs (8x8, 16x8, 8x16, 16x16; bitDepth <= 10): one LANE per (candidate slot, 8x8 tile).  A pass of the search evaluates up to eight candidates of a PU
+// at once -- the eight directions of a diamond round, the four of the cross round, the (i, k) predictor pairs -- so a wave holds 64 / (8 * tiles) PUs, each
+// with its own search state (kept redundantly in every lane of the PU's group).  A lane predicts its tile of both lists straight from the reference planes
+// (L2 / TCP resident windows), all in registers: horizontal FIR of input row r with v_dot2_i32_i16 on sample pairs, the row pair (r - 1, r) interleaved
+// column-wise (v_perm) feeds the vertical v_dot2 of the up to four output rows it belongs to; the target 2 * org - predA and the difference to predB are
+// packed 16-bit words, the Hadamard is the packed 8x8 form of had.hpp (two lanes = one 16x8 / 8x16 tile).  No LDS, no barriers: the only cross-lane traffic
+// is the tile sum and the (cost, slot) minimum of a group.  The sequential "first candidate below the best so far" rule of the reference equals the
+// lexicographic (cost, evaluation order) minimum of a pass compared with the cost on entry.
+// The integer phases run the same two passes with the taps {0,0,0,64,0,0,0,0}: for rounded uni-prediction that is exactly filterCopy / the single-pass forms
+// ((sum >> s) + 2^(h-1)) >> h == (sum + 32) >> 6 for sum = 2^s q + r.
+// =====================================================================================================================================
+struct TileFir { int shH, offH, shV, offV, cmax; };
+
+__device__ __forceinline__ void load_taps( int frac, bool alt, v2s c[4] )
+{
+  const int16_t *t = ( alt && frac == 8 ) ? c_altHpelMc : c_lumaFilterMc[frac];
+#pragma unroll
+  for( int m = 0; m < 4; m++ ) { c[m].x = t[2 * m]; c[m].y = t[2 * m + 1]; }
+}
+
+// the rounded, clipped uni-directional prediction of one 8x8 tile: out( y, packed words of row y ) in row order
+template<class RowOut>
+__device__ __forceinline__ void pred_tile( const int16_t *__restrict__ ref, int stride, int mvHor, int mvVer, bool alt, const TileFir &f, RowOut out )
+{
+  v2s ch[4], cv[4];
+  load_taps( mvHor & 15, alt, ch );
+  load_taps( mvVer & 15, alt, cv );
+  const int16_t *src = ref + ( long ) ( ( mvVer >> 4 ) - 3 ) * stride + ( mvHor >> 4 ) - 3;
+  int      acc[64];
+  unsigned prevH[4] = { 0, 0, 0, 0 };
+#pragma unroll
+  for( int r = 0; r < 15; r++ )
+  {
+    const Pel8u a = *reinterpret_cast<const Pel8u *>( src + ( long ) r * stride ), b = *reinterpret_cast<const Pel8u *>( src + ( long ) r * stride + 8 );
+    const unsigned d[8] = { a.v[0], a.v[1], a.v[2], a.v[3], b.v[0], b.v[1], b.v[2], b.v[3] };   // d[m] = samples (2m, 2m + 1)
+    unsigned e[7];                                                                             // e[m] = samples (2m + 1, 2m + 2)
+#pragma unroll
+    for( int m = 0; m < 7; m++ ) e[m] = __builtin_amdgcn_alignbit( d[m + 1], d[m], 16 );
+    unsigned curH[4];
+#pragma unroll
+    for( int q = 0; q < 8; q++ )
+    {
+      int sum = f.offH;
+#pragma unroll
+      for( int m = 0; m < 4; m++ )
+      {
+        const unsigned pw = ( q & 1 ) ? e[( q >> 1 ) + m] : d[( q >> 1 ) + m];
+        v2s pv;
+        __builtin_memcpy( &pv, &pw, 4 );
+        sum = __builtin_amdgcn_sdot2( pv, ch[m], sum, false );
+      }
+      const unsigned hv = ( unsigned ) ( sum >> f.shH ) & 0xffffu;
+      if( q & 1 ) curH[q >> 1] |= hv << 16; else curH[q >> 1] = hv;
+    }
+    if( r >= 1 )
+    {
+      v2s pr[8];   // column x: (row r - 1, row r)
+#pragma unroll
+      for( int k = 0; k < 4; k++ )
+      {
+        const unsigned lo = __builtin_amdgcn_perm( curH[k], prevH[k], 0x05040100u ), hi = __builtin_amdgcn_perm( curH[k], prevH[k], 0x07060302u );
+        __builtin_memcpy( &pr[2 * k], &lo, 4 );
+        __builtin_memcpy( &pr[2 * k + 1], &hi, 4 );
+      }
+      const int q = r - 1;
+#pragma unroll
+      for( int m = 0; m < 4; m++ )
+      {
+        const int y = q - 2 * m;
+        if( y >= 0 && y < 8 )
+        {
+#pragma unroll
+          for( int x = 0; x < 8; x++ ) acc[y * 8 + x] = __builtin_amdgcn_sdot2( pr[x], cv[m], m == 0 ? f.offV : acc[y * 8 + x], false );
+        }
+      }
+      if( r >= 7 )   // output row r - 7 is complete
+      {
+        const int y = r - 7;
+        unsigned  w[4];
+#pragma unroll
+        for( int k = 0; k < 4; k++ )
+        {
+          const int lo = min( f.cmax, max( 0, acc[y * 8 + 2 * k] >> f.shV ) ), hi = min( f.cmax, max( 0, acc[y * 8 + 2 * k + 1] >> f.shV ) );
+          w[k] = ( unsigned ) lo | ( ( unsigned ) hi << 16 );
+        }
+        out( y, w );
+      }
+    }
+#pragma unroll
+    for( int k = 0; k < 4; k++ ) prevH[k] = curH[k];
+  }
+}
+
+struct TileJob   // what a lane needs of its PU for the evaluation (group-uniform but for the tile origin)
+{
+  const int16_t *org, *refA, *refB;   // tile origins (MV 0,0)
+  int orgStride, strideA, strideB;
+  int horMin, horMax, verMin, verMax;
+  int w0, w1;                         // BCW form of removeHighFreq (w0 == 0: the default 2 * org - pred)
+  bool clip, alt, satd;
+  TileFir f;
+};
+
+// distortion of this lane's tile for the vector pair (A, B); PAIR: lanes 2k, 2k + 1 hold the halves of one 16x8 / 8x16 Hadamard tile (both return its value)
+template<bool PAIR>
+__device__ __forceinline__ unsigned tile_eval( const TileJob &t, int ax, int ay, int bx, int by )
+{
+  ax = min( t.horMax, max( t.horMin, ax ) ); ay = min( t.verMax, max( t.verMin, ay ) );   // clipMv
+  bx = min( t.horMax, max( t.horMin, bx ) ); by = min( t.verMax, max( t.verMin, by ) );
+  v2s D[8][4];
+  pred_tile( t.refA, t.strideA, ax, ay, t.alt, t.f, [&]( int y, const unsigned w[4] )
+  {
+    const Pel8u o = *reinterpret_cast<const Pel8u *>( t.org + ( long ) y * t.orgStride );
+#pragma unroll
+    for( int k = 0; k < 4; k++ )
+    {
+      const int o0 = ( int ) ( short ) ( o.v[k] & 0xffffu ), o1 = ( int ) o.v[k] >> 16, p0 = ( int ) ( w[k] & 0xffffu ), p1 = ( int ) ( w[k] >> 16 );
+      int r0 = t.w0 ? ( o0 * t.w0 - p0 * t.w1 + ( 1 << 15 ) ) >> 16 : 2 * o0 - p0, r1 = t.w0 ? ( o1 * t.w0 - p1 * t.w1 + ( 1 << 15 ) ) >> 16 : 2 * o1 - p1;
+      if( t.clip ) { r0 = min( t.f.cmax, max( 0, r0 ) ); r1 = min( t.f.cmax, max( 0, r1 ) ); }
+      D[y][k].x = ( short ) r0; D[y][k].y = ( short ) r1;
+    }
+  } );
+  pred_tile( t.refB, t.strideB, bx, by, t.alt, t.f, [&]( int y, const unsigned w[4] )
+  {
+#pragma unroll
+    for( int k = 0; k < 4; k++ )
+    {
+      v2s b;
+      __builtin_memcpy( &b, &w[k], 4 );
+      D[y][k] = D[y][k] - b;     // |pattern - predB| <= 2 * 1023 + 1023 (clipped or not: the BCW forms stay below 4095 for 10-bit samples too)
+    }
+  } );
+  if( !t.satd )
+  {
+    int s = 0;
+#pragma unroll
+    for( int y = 0; y < 8; y++ )
+#pragma unroll
+      for( int k = 0; k < 4; k++ ) s += abs( ( int ) D[y][k].x ) + abs( ( int ) D[y][k].y );
+    return ( unsigned ) s;
+  }
+  return PAIR ? satd8_pair_packed( D ) : satd8_packed( D );
+}
+
+__device__ __forceinline__ int      shfl_x( int v, int m ) { return __shfl_xor( v, m, 64 ); }
+__device__ __forceinline__ unsigned long long shfl_x64( unsigned long long v, int m )
+{
+  return ( ( unsigned long long ) ( unsigned ) __shfl_xor( ( int ) ( v >> 32 ), m, 64 ) << 32 ) | ( unsigned ) __shfl_xor( ( int ) v, m, 64 );
+}
+
+enum { PH_INIT = 0, PH_STARTS, PH_DIAMOND, PH_CROSS, PH_FINAL, PH_COST, PH_DONE };
+
+template<int TX, int TY>
+__global__ __launch_bounds__( 64 ) void smvd_tile_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+                                                         vtmhip_smvd_job *__restrict__ jobs, int n, int op )
+{
+  constexpr int  T = TX * TY, LPP = 8 * T, PPW = 64 / LPP;
+  constexpr bool PAIR = T == 2;
+  const int lane = threadIdx.x, g = lane / LPP, l = lane - g * LPP, slot = l / T, tile = l - slot * T;
+  const int tx = TX == 2 ? ( tile & 1 ) : 0, ty = TY == 2 ? ( TX == 2 ? tile >> 1 : tile ) : 0;
+  const int puRaw = blockIdx.x * PPW + g;
+  const bool live = puRaw < n;
+  vtmhip_smvd_job &j = jobs[live ? xcd_order( puRaw, n ) : 0];
+
+  TileJob t;
+  t.orgStride = j.orgStride; t.strideA = j.refStride[0]; t.strideB = j.refStride[1];
+  t.org  = orgBase + j.orgOff + ( long ) ( ty * 8 ) * t.orgStride + tx * 8;
+  t.refA = refBase + j.refOff[0] + ( long ) ( ty * 8 ) * t.strideA + tx * 8;
+  t.refB = refBase + j.refOff[1] + ( long ) ( ty * 8 ) * t.strideB + tx * 8;
+  t.horMax = ( pic.picW + 8 - j.puX - 1 ) << 4; t.horMin = ( -pic.ctuSize - 8 - j.puX + 1 ) << 4;
+  t.verMax = ( pic.picH + 8 - j.puY - 1 ) << 4; t.verMin = ( -pic.ctuSize - 8 - j.puY + 1 ) << 4;
+  const int bcw = j.bcwWeightTar ? j.bcwWeightTar : 4;
+  const int normalizer = bcw != 4 ? ( ( 1 << 16 ) + ( bcw > 0 ? ( bcw >> 1 ) : -( bcw >> 1 ) ) ) / bcw : 0;
+  t.w0 = normalizer * 8; t.w1 = ( 8 - bcw ) * normalizer;
+  t.clip = j.clipBiPred != 0; t.alt = j.imv == 3; t.satd = j.useSatd != 0;
+  {
+    const int bd = pic.bitDepth, headRoom = max( 2, 14 - bd );
+    t.f.shH = 6 - headRoom; t.f.offH = -( 8192 << t.f.shH ); t.f.shV = 6 + headRoom; t.f.offV = ( 1 << ( t.f.shV - 1 ) ) + ( 8192 << 6 ); t.f.cmax = ( 1 << bd ) - 1;
+  }
+  const int    imv = j.imv, amvrShift = imv == 0 ? 2 : imv == 1 ? 4 : imv == 2 ? 6 : 3, stepShift = 2 + ( imv == 3 ? 1 : ( imv << 1 ) );
+  const double lam = j.motionLambda, fWeight = bcw != 4 ? fabs( ( double ) bcw / 8.0 ) : 0.5;
+  const unsigned idxBits0 = j.mvpIdxBits[0], idxBits1 = j.mvpIdxBits[1];
+  auto idx_bits = [&]( int i ) { return i ? idxBits1 : idxBits0; };
+  auto rate = [&]( unsigned bits ) { return ( unsigned long long ) ( lam * bits ); };
+  auto mvbits = [&]( int mx, int my, int px, int py )
+  { return eg_bits( prec_dn( mx, amvrShift ) - prec_dn( px, amvrShift ) ) + eg_bits( prec_dn( my, amvrShift ) - prec_dn( py, amvrShift ) ); };
+
+  // AMVP lists
+  int cnd[2][2][2], num0 = j.numCand[0], num1 = j.numCand[1];
+#pragma unroll
+  for( int a = 0; a < 2; a++ )
+#pragma unroll
+    for( int i = 0; i < 2; i++ ) { cnd[a][i][0] = j.cand[a][i][0]; cnd[a][i][1] = j.cand[a][i][1]; }
+  auto cand = [&]( int a, int i, int c ) { return i ? cnd[a][1][c] : cnd[a][0][c]; };
+
+  // search state of this lane's PU
+  int mvCur[2] = { j.mvCur[0], j.mvCur[1] }, mvTar[2] = { j.mvTar[0], j.mvTar[1] };
+  int pred[2][2] = { { j.predSym[0][0], j.predSym[0][1] }, { j.predSym[1][0], j.predSym[1][1] } }, idxSym[2] = { j.mvpIdxSym[0], j.mvpIdxSym[1] };
+  unsigned long long cost = j.cost, mvpCost = 0;
+  int phase = !live ? PH_DONE : op == VTMHIP_SMVD_COST ? PH_COST : op == VTMHIP_SMVD_ME ? PH_DIAMOND : op == VTMHIP_SMVD_CHECK_MVP ? PH_FINAL : PH_INIT;
+  int round = 0, dStart = 0, dEnd = 7, startX = 0, startY = 0, si = 0;
+  const int maxRounds = 8 >> imv;
+  bool skipPair = op == VTMHIP_SMVD_CHECK_MVP ? j.skip != 0 : true;
+  unsigned startMask = 0;
+  const int numFixed = j.numFixed;
+  auto start_vec = [&]( int s, int c )
+  {
+    int v = j.starts[s][c];
+    if( s >= numFixed && imv ) v = prec_dn( v, amvrShift ) * ( 1 << amvrShift );   // roundTransPrecInternal2Amvr
+    return v;
+  };
+  if( phase == PH_INIT )
+  {
+    if( num0 > 1 && cnd[0][0][0] == cnd[0][1][0] && cnd[0][0][1] == cnd[0][1][1] ) num0 = 1;   // :2668-2671
+    if( num1 > 1 && cnd[1][0][0] == cnd[1][1][0] && cnd[1][0][1] == cnd[1][1][1] ) num1 = 1;
+    // distinct start vectors (smmvdCandsGen): bit s = raw entry s is evaluated
+    const int numStart = min( ( int ) j.numStart, VTMHIP_SMVD_MAX_START );
+    int nc = 0;
+    for( int s = 0; s < numStart; s++ )
+    {
+      if( s >= numFixed && nc >= 5 ) break;
+      const int vx = start_vec( s, 0 ), vy = start_vec( s, 1 );
+      bool dup = false;
+      for( int q = 0; q < s; q++ ) dup |= ( ( startMask >> q ) & 1 ) && start_vec( q, 0 ) == vx && start_vec( q, 1 ) == vy;
+      if( !dup ) { startMask |= 1u << s; nc++; }
+    }
+    cost = ~0ull;
+  }
+  // the next start vector that is not one of the searched list's predictors (those were covered by the predictor pairs), or -1
+  auto next_start = [&]( int from )
+  {
+    for( int s = from; s < VTMHIP_SMVD_MAX_START; s++ )
+    {
+      if( !( ( startMask >> s ) & 1 ) ) continue;
+      const int vx = start_vec( s, 0 ), vy = start_vec( s, 1 );
+      bool checked = false;
+      for( int i = 0; i < num0; i++ ) checked |= vx == cand( 0, i, 0 ) && vy == cand( 0, i, 1 );
+      if( !checked ) return s;
+    }
+    return -1;
+  };
+  auto to_me = [&]()   // ME preparation (:2765-2770)
+  {
+    startX = mvCur[0]; startY = mvCur[1];
+    mvpCost = rate( idx_bits( idxSym[0] ) + idx_bits( idxSym[1] ) );
+    cost -= mvpCost;
+    phase = PH_DIAMOND; round = 0; dStart = 0; dEnd = 7;
+  };
+  auto finish = [&]()   // :2781-2786
+  {
+    cost += rate( j.modeBits );
+    mvTar[0] = pred[1][0] - mvCur[0] + pred[0][0]; mvTar[1] = pred[1][1] - mvCur[1] + pred[0][1];
+    phase = PH_DONE;
+  };
+
+  while( __any( phase != PH_DONE ) )
+  {
+    // ---- this lane's candidate of the pass ----
+    bool valid = false;
+    int  ax = 0, ay = 0, bx = 0, by = 0, pi = 0, pk = 0;
+    unsigned bits = 0;
+    if( phase == PH_INIT || phase == PH_STARTS || phase == PH_FINAL )
+    {
+      pi = slot / num1; pk = slot - pi * num1;
+      valid = slot < num0 * num1;
+      if( !valid ) pi = pk = 0;
+      if( phase == PH_INIT ) { ax = cand( 0, pi, 0 ); ay = cand( 0, pi, 1 ); bx = cand( 1, pk, 0 ); by = cand( 1, pk, 1 ); }
+      else
+      {
+        ax = phase == PH_STARTS ? start_vec( si, 0 ) : mvCur[0]; ay = phase == PH_STARTS ? start_vec( si, 1 ) : mvCur[1];
+        bx = cand( 1, pk, 0 ) - ax + cand( 0, pi, 0 ); by = cand( 1, pk, 1 ) - ay + cand( 0, pi, 1 );   // Mv::getSymmvdMv
+        bits = mvbits( ax, ay, cand( 0, pi, 0 ), cand( 0, pi, 1 ) ) + idx_bits( pi ) + idx_bits( pk );
+        if( phase == PH_FINAL && skipPair && pi == idxSym[0] && pk == idxSym[1] ) valid = false;
+      }
+    }
+    else if( phase == PH_DIAMOND || phase == PH_CROSS )
+    {
+      const int idx = dStart + slot;
+      valid = idx <= dEnd;
+      const int direct = phase == PH_CROSS ? ( idx + 4 ) & 3 : ( idx + 8 ) & 7;
+      const int ox = phase == PH_CROSS ? c_cross[direct][0] : c_diamond[direct][0], oy = phase == PH_CROSS ? c_cross[direct][1] : c_diamond[direct][1];
+      ax = mvCur[0] + ( ox << stepShift ); ay = mvCur[1] + ( oy << stepShift );
+      bx = pred[1][0] - ( ax - pred[0][0] ); by = pred[1][1] - ( ay - pred[0][1] );
+      bits = mvbits( ax, ay, pred[0][0], pred[0][1] );
+    }
+    else if( phase == PH_COST ) { valid = slot == 0; ax = mvCur[0]; ay = mvCur[1]; bx = mvTar[0]; by = mvTar[1]; }
+    // ---- the distortion of every lane's tile, the PU sum, the rate ----
+    unsigned d = tile_eval<PAIR>( t, valid ? ax : 0, valid ? ay : 0, valid ? bx : 0, valid ? by : 0 );
+    if( T == 4 ) { d += ( unsigned ) shfl_x( ( int ) d, 1 ); d += ( unsigned ) shfl_x( ( int ) d, 2 ); }
+    if( PAIR && !t.satd ) d += ( unsigned ) shfl_x( ( int ) d, 1 );
+    unsigned long long c = valid ? ( unsigned long long ) floor( fWeight * ( double ) d ) + ( phase == PH_INIT || phase == PH_COST ? 0ull : rate( bits ) ) : ~0ull;
+    // ---- first minimum of the pass over the slots of the group ----
+    int bs = slot;
+#pragma unroll
+    for( int off = T; off < LPP; off <<= 1 )
+    {
+      const unsigned long long oc = shfl_x64( c, off );
+      const int                os = shfl_x( bs, off );
+      if( oc < c || ( oc == c && os < bs ) ) { c = oc; bs = os; }
+    }
+    const bool found = c < cost;
+    // ---- state update (group-uniform) ----
+    if( phase == PH_INIT )
+    {
+      const int bi = bs / num1, bk = bs - bi * num1;
+      idxSym[0] = bi; idxSym[1] = bk;
+      pred[0][0] = cand( 0, bi, 0 ); pred[0][1] = cand( 0, bi, 1 ); pred[1][0] = cand( 1, bk, 0 ); pred[1][1] = cand( 1, bk, 1 );
+      mvCur[0] = pred[0][0]; mvCur[1] = pred[0][1]; mvTar[0] = pred[1][0]; mvTar[1] = pred[1][1];
+      cost = c + rate( mvbits( mvCur[0], mvCur[1], pred[0][0], pred[0][1] ) + idx_bits( bi ) + idx_bits( bk ) );
+      si = next_start( 0 );
+      if( si >= 0 ) phase = PH_STARTS; else to_me();
+    }
+    else if( phase == PH_STARTS )
+    {
+      if( found )
+      {
+        const int bi = bs / num1, bk = bs - bi * num1;
+        cost = c; idxSym[0] = bi; idxSym[1] = bk;
+        pred[0][0] = cand( 0, bi, 0 ); pred[0][1] = cand( 0, bi, 1 ); pred[1][0] = cand( 1, bk, 0 ); pred[1][1] = cand( 1, bk, 1 );
+        mvCur[0] = start_vec( si, 0 ); mvCur[1] = start_vec( si, 1 );
+        mvTar[0] = pred[1][0] - mvCur[0] + pred[0][0]; mvTar[1] = pred[1][1] - mvCur[1] + pred[0][1];
+      }
+      si = next_start( si + 1 );
+      if( si < 0 ) to_me();
+    }
+    else if( phase == PH_DIAMOND || phase == PH_CROSS )
+    {
+      int direct = 0;
+      if( found )
+      {
+        const int idx = dStart + bs;
+        direct = phase == PH_CROSS ? ( idx + 4 ) & 3 : ( idx + 8 ) & 7;
+        const int ox = phase == PH_CROSS ? c_cross[direct][0] : c_diamond[direct][0], oy = phase == PH_CROSS ? c_cross[direct][1] : c_diamond[direct][1];
+        cost = c;
+        mvCur[0] += ox << stepShift; mvCur[1] += oy << stepShift;
+        mvTar[0] = pred[1][0] - ( mvCur[0] - pred[0][0] ); mvTar[1] = pred[1][1] - ( mvCur[1] - pred[0][1] );
+      }
+      if( phase == PH_DIAMOND )
+      {
+        round++;
+        if( found && round < maxRounds ) { const int step = 2 - ( direct & 1 ); dStart = direct - step; dEnd = direct + step; }
+        else { phase = PH_CROSS; dStart = 0; dEnd = 3; }
+      }
+      else if( op == VTMHIP_SMVD_ME ) phase = PH_DONE;
+      else
+      {
+        cost += mvpCost;
+        if( startX != mvCur[0] || startY != mvCur[1] ) phase = PH_FINAL; else finish();
+      }
+    }
+    else if( phase == PH_FINAL )
+    {
+      if( found )
+      {
+        const int bi = bs / num1, bk = bs - bi * num1;
+        cost = c; idxSym[0] = bi; idxSym[1] = bk;
+        pred[0][0] = cand( 0, bi, 0 ); pred[0][1] = cand( 0, bi, 1 ); pred[1][0] = cand( 1, bk, 0 ); pred[1][1] = cand( 1, bk, 1 );
+      }
+      if( op == VTMHIP_SMVD_CHECK_MVP ) phase = PH_DONE; else finish();
+    }
+    else if( phase == PH_COST ) { cost = c; phase = PH_DONE; }
+  }
+  if( live && l == 0 )
+  {
+    j.mvCur[0] = mvCur[0]; j.mvCur[1] = mvCur[1]; j.mvTar[0] = mvTar[0]; j.mvTar[1] = mvTar[1];
+    for( int a = 0; a < 2; a++ ) { j.predSym[a][0] = pred[a][0]; j.predSym[a][1] = pred[a][1]; j.mvpIdxSym[a] = idxSym[a]; }
+    j.cost = cost;
+  }
+}
+
+template<int TX, int TY>
+void launch_tile( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, vtmhip_smvd_job *d_jobs, int n, int op )
+{
+  constexpr int PPW = 64 / ( 8 * TX * TY );
+  hipLaunchKernelGGL( ( smvd_tile_kernel<TX, TY> ), dim3( ( n + PPW - 1 ) / PPW ), dim3( 64 ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, op );
+}
+
 }   // namespace
 
 extern "C" {
@@ -312,6 +692,8 @@ int vtmhip_smvd_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const 
 {
   VTMHIP_CHECK_CTX( ctx );
   VTMHIP_REQUIRE( ctx, pic && n >= 0, "bad arguments" );
+  const bool uniform = ( op & VTMHIP_SMVD_UNIFORM ) != 0;   // every job is exactly maxWidth x maxHeight
+  op &= ~VTMHIP_SMVD_UNIFORM;
   VTMHIP_REQUIRE( ctx, op >= VTMHIP_SMVD_COST && op <= VTMHIP_SMVD_SEARCH, "unknown SMVD op" );
   VTMHIP_REQUIRE( ctx, maxWidth >= 4 && maxHeight >= 4 && maxWidth <= 128 && maxHeight <= 128 && ( maxWidth & 3 ) == 0 && ( maxHeight & 3 ) == 0, "block size out of range" );
   VTMHIP_REQUIRE( ctx, pic->bitDepth >= 8 && pic->bitDepth <= 12, "bit depth out of range" );
@@ -320,7 +702,14 @@ int vtmhip_smvd_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const 
   // pattern + prediction B + the (h + 7) x w intermediates of the separable filter
   const size_t lds = ( 2 * ( size_t ) maxWidth * maxHeight + ( size_t ) maxWidth * ( maxHeight + 7 ) ) * sizeof( int16_t );
   VTMHIP_TIME_KERNEL( ctx, "smvd_kernel" );
-  if( maxWidth * maxHeight <= 1024 )
+  if( uniform && pic->bitDepth <= 10 && maxWidth <= 16 && maxHeight <= 16 && maxWidth >= 8 && maxHeight >= 8 && !getenv( "VTMHIP_SMVD_NO_TILE" ) )
+  {
+    if( maxWidth == 8 && maxHeight == 8 ) launch_tile<1, 1>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op );
+    else if( maxWidth == 16 && maxHeight == 8 ) launch_tile<2, 1>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op );
+    else if( maxWidth == 8 ) launch_tile<1, 2>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op );
+    else launch_tile<2, 2>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op );
+  }
+  else if( maxWidth * maxHeight <= 1024 )
   {
     hipLaunchKernelGGL( smvd_kernel<64>, dim3( n ), dim3( 64 ), lds, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, op );
   }

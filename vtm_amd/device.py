@@ -231,13 +231,14 @@ class Context:
         """InterSearch::xAffineMotionEstimation per AffineMeJob (one workgroup per job)"""
         self._check(self.L.vtmhip_xAffineMotionEstimation_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_other, d_jobs, n, max_w, max_h, d_results))
 
-    def smvd_batch(self, pic, d_org, d_ref, d_jobs, n, max_w, max_h, op):
-        """the SMVD block of predInterSearch per SmvdJob, in place: op 0 xGetSymmetricCost, 1 xSymmetricMotionEstimation, 2 symmvdCheckBestMvp, 3 the whole block"""
+    def smvd_batch(self, pic, d_org, d_ref, d_jobs, n, max_w, max_h, op, uniform=False):
+        """the SMVD block of predInterSearch per SmvdJob, in place: op 0 xGetSymmetricCost, 1 xSymmetricMotionEstimation, 2 symmvdCheckBestMvp, 3 the whole block;
+        uniform: every job is exactly max_w x max_h (VTMHIP_SMVD_UNIFORM: the lane-per-tile kernel for 8x8 .. 16x16)"""
         fn = (self.L.vtmhip_xGetSymmetricCost_batch_dev, self.L.vtmhip_xSymmetricMotionEstimation_batch_dev, self.L.vtmhip_symmvdCheckBestMvp_batch_dev)
-        if op < 3:
+        if op < 3 and not uniform:
             self._check(fn[op](self.h, C.byref(pic), d_org, d_ref, d_jobs, n, max_w, max_h))
         else:
-            self._check(self.L.vtmhip_smvd_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, max_w, max_h, op))
+            self._check(self.L.vtmhip_smvd_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_jobs, n, max_w, max_h, op | (0x100 if uniform else 0)))
 
     def pred_affine_blk_batch(self, pic, d_ref, d_dst, d_jobs, n, max_w, max_h):
         self._check(self.L.vtmhip_xPredAffineBlk_batch_dev(self.h, C.byref(pic), d_ref, d_dst, d_jobs, n, max_w, max_h))

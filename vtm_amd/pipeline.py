@@ -411,7 +411,7 @@ class FrameHotPath:
             ctx.pis_stage(lvl["pis"], 3)
             self._mark("glue")
             if "smvd_jobs" in lvl:
-                ctx.smvd_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["smvd_jobs"].data_ptr(), n, w, h, 3)
+                ctx.smvd_batch(lvl["pic"], org_ptr, dpb_ptr, lvl["smvd_jobs"].data_ptr(), n, w, h, 3, uniform=True)
                 self._mark("smvd")
                 ctx.pis_stage(lvl["pis"], 5)
                 self._mark("glue")
