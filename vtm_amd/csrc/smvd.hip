@@ -399,9 +399,9 @@ __device__ __forceinline__ void pred_tile( const int16_t *__restrict__ ref, int 
   }
 }
 
-struct TileJob   // what a lane needs of its PU for the evaluation (group-uniform but for the tile origin)
+struct TileJob   // what a lane needs of its PU for the evaluation (workgroup- / group-uniform)
 {
-  const int16_t *org, *refA, *refB;   // tile origins (MV 0,0)
+  const int16_t *org, *refA, *refB;   // PU origins (MV 0,0)
   int orgStride, strideA, strideB;
   int horMin, horMax, verMin, verMax;
   int w0, w1;                         // BCW form of removeHighFreq (w0 == 0: the default 2 * org - pred)
@@ -409,16 +409,18 @@ struct TileJob   // what a lane needs of its PU for the evaluation (group-unifor
   TileFir f;
 };
 
-// distortion of this lane's tile for the vector pair (A, B); PAIR: lanes 2k, 2k + 1 hold the halves of one 16x8 / 8x16 Hadamard tile (both return its value)
+// distortion of the tile at (tx, ty) (in tiles) for the vector pair (A, B); PAIR: lanes 2k, 2k + 1 hold the halves of one 16x8 / 8x16 Hadamard tile (both return
+// its value)
 template<bool PAIR>
-__device__ __forceinline__ unsigned tile_eval( const TileJob &t, int ax, int ay, int bx, int by )
+__device__ __forceinline__ unsigned tile_eval( const TileJob &t, int tx, int ty, int ax, int ay, int bx, int by )
 {
   ax = min( t.horMax, max( t.horMin, ax ) ); ay = min( t.verMax, max( t.verMin, ay ) );   // clipMv
   bx = min( t.horMax, max( t.horMin, bx ) ); by = min( t.verMax, max( t.verMin, by ) );
+  const int16_t *org = t.org + ( long ) ( ty * 8 ) * t.orgStride + tx * 8;
   v2s D[8][4];
-  pred_tile( t.refA, t.strideA, ax, ay, t.alt, t.f, [&]( int y, const unsigned w[4] )
+  pred_tile( t.refA + ( long ) ( ty * 8 ) * t.strideA + tx * 8, t.strideA, ax, ay, t.alt, t.f, [&]( int y, const unsigned w[4] )
   {
-    const Pel8u o = *reinterpret_cast<const Pel8u *>( t.org + ( long ) y * t.orgStride );
+    const Pel8u o = *reinterpret_cast<const Pel8u *>( org + ( long ) y * t.orgStride );
 #pragma unroll
     for( int k = 0; k < 4; k++ )
     {
@@ -428,7 +430,7 @@ __device__ __forceinline__ unsigned tile_eval( const TileJob &t, int ax, int ay,
       D[y][k].x = ( short ) r0; D[y][k].y = ( short ) r1;
     }
   } );
-  pred_tile( t.refB, t.strideB, bx, by, t.alt, t.f, [&]( int y, const unsigned w[4] )
+  pred_tile( t.refB + ( long ) ( ty * 8 ) * t.strideB + tx * 8, t.strideB, bx, by, t.alt, t.f, [&]( int y, const unsigned w[4] )
   {
 #pragma unroll
     for( int k = 0; k < 4; k++ )
@@ -458,23 +460,25 @@ __device__ __forceinline__ unsigned long long shfl_x64( unsigned long long v, in
 
 enum { PH_INIT = 0, PH_STARTS, PH_DIAMOND, PH_CROSS, PH_FINAL, PH_COST, PH_DONE };
 
-template<int TX, int TY>
-__global__ __launch_bounds__( 64 ) void smvd_tile_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
-                                                         vtmhip_smvd_job *__restrict__ jobs, int n, int op )
+// NW == 0: "group" form for PUs of at most four tiles -- a lane is (PU of the wave, candidate slot, tile), 64 / (8 * tiles) PUs per wave.
+// NW >= 1: one PU per workgroup of NW waves -- the (slot, tile) items of a pass are dealt to the lanes, the per-slot sums meet in LDS.
+template<int TX, int TY, int NW>
+__global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+                                                                        vtmhip_smvd_job *__restrict__ jobs, int n, int op )
 {
-  constexpr int  T = TX * TY, LPP = 8 * T, PPW = 64 / LPP;
-  constexpr bool PAIR = T == 2;
-  const int lane = threadIdx.x, g = lane / LPP, l = lane - g * LPP, slot = l / T, tile = l - slot * T;
-  const int tx = TX == 2 ? ( tile & 1 ) : 0, ty = TY == 2 ? ( TX == 2 ? tile >> 1 : tile ) : 0;
+  constexpr int  T = TX * TY, LPP = 8 * T, PPW = NW ? 1 : 64 / LPP, NT = NW ? 64 * NW : 64;
+  constexpr bool PAIR = TX != TY, GROUP = NW == 0;
+  static_assert( NW != 0 || T <= 4, "the group form holds at most four tiles per PU" );
+  __shared__ unsigned sDist[8];
+  const int lane = threadIdx.x, g = GROUP ? lane / LPP : 0, l = GROUP ? lane - g * LPP : lane, slot = GROUP ? l / T : 0, tile = GROUP ? l - slot * T : 0;
+  auto tile_xy = [&]( int tl, int &tx, int &ty ) { if( TX >= TY ) { ty = tl / TX; tx = tl - ty * TX; } else { tx = tl / TY; ty = tl - tx * TY; } };   // pair halves adjacent
   const int puRaw = blockIdx.x * PPW + g;
   const bool live = puRaw < n;
   vtmhip_smvd_job &j = jobs[live ? xcd_order( puRaw, n ) : 0];
 
   TileJob t;
   t.orgStride = j.orgStride; t.strideA = j.refStride[0]; t.strideB = j.refStride[1];
-  t.org  = orgBase + j.orgOff + ( long ) ( ty * 8 ) * t.orgStride + tx * 8;
-  t.refA = refBase + j.refOff[0] + ( long ) ( ty * 8 ) * t.strideA + tx * 8;
-  t.refB = refBase + j.refOff[1] + ( long ) ( ty * 8 ) * t.strideB + tx * 8;
+  t.org = orgBase + j.orgOff; t.refA = refBase + j.refOff[0]; t.refB = refBase + j.refOff[1];
   t.horMax = ( pic.picW + 8 - j.puX - 1 ) << 4; t.horMin = ( -pic.ctuSize - 8 - j.puX + 1 ) << 4;
   t.verMax = ( pic.picH + 8 - j.puY - 1 ) << 4; t.verMin = ( -pic.ctuSize - 8 - j.puY + 1 ) << 4;
   const int bcw = j.bcwWeightTar ? j.bcwWeightTar : 4;
@@ -508,7 +512,7 @@ __global__ __launch_bounds__( 64 ) void smvd_tile_kernel( vtmhip_pic_params pic,
   int phase = !live ? PH_DONE : op == VTMHIP_SMVD_COST ? PH_COST : op == VTMHIP_SMVD_ME ? PH_DIAMOND : op == VTMHIP_SMVD_CHECK_MVP ? PH_FINAL : PH_INIT;
   int round = 0, dStart = 0, dEnd = 7, startX = 0, startY = 0, si = 0;
   const int maxRounds = 8 >> imv;
-  bool skipPair = op == VTMHIP_SMVD_CHECK_MVP ? j.skip != 0 : true;
+  const bool skipPair = op == VTMHIP_SMVD_CHECK_MVP ? j.skip != 0 : true;
   unsigned startMask = 0;
   const int numFixed = j.numFixed;
   auto start_vec = [&]( int s, int c )
@@ -560,17 +564,15 @@ __global__ __launch_bounds__( 64 ) void smvd_tile_kernel( vtmhip_pic_params pic,
     mvTar[0] = pred[1][0] - mvCur[0] + pred[0][0]; mvTar[1] = pred[1][1] - mvCur[1] + pred[0][1];
     phase = PH_DONE;
   };
-
-  while( __any( phase != PH_DONE ) )
+  // candidate of slot s in the current pass: vectors, rate bits; false: the slot is empty
+  auto slot_params = [&]( int s, int &ax, int &ay, int &bx, int &by, unsigned &bits )
   {
-    // ---- this lane's candidate of the pass ----
     bool valid = false;
-    int  ax = 0, ay = 0, bx = 0, by = 0, pi = 0, pk = 0;
-    unsigned bits = 0;
+    ax = ay = bx = by = 0; bits = 0;
     if( phase == PH_INIT || phase == PH_STARTS || phase == PH_FINAL )
     {
-      pi = slot / num1; pk = slot - pi * num1;
-      valid = slot < num0 * num1;
+      int pi = s / num1, pk = s - pi * num1;
+      valid = s < num0 * num1;
       if( !valid ) pi = pk = 0;
       if( phase == PH_INIT ) { ax = cand( 0, pi, 0 ); ay = cand( 0, pi, 1 ); bx = cand( 1, pk, 0 ); by = cand( 1, pk, 1 ); }
       else
@@ -583,7 +585,7 @@ __global__ __launch_bounds__( 64 ) void smvd_tile_kernel( vtmhip_pic_params pic,
     }
     else if( phase == PH_DIAMOND || phase == PH_CROSS )
     {
-      const int idx = dStart + slot;
+      const int idx = dStart + s;
       valid = idx <= dEnd;
       const int direct = phase == PH_CROSS ? ( idx + 4 ) & 3 : ( idx + 8 ) & 7;
       const int ox = phase == PH_CROSS ? c_cross[direct][0] : c_diamond[direct][0], oy = phase == PH_CROSS ? c_cross[direct][1] : c_diamond[direct][1];
@@ -591,23 +593,67 @@ __global__ __launch_bounds__( 64 ) void smvd_tile_kernel( vtmhip_pic_params pic,
       bx = pred[1][0] - ( ax - pred[0][0] ); by = pred[1][1] - ( ay - pred[0][1] );
       bits = mvbits( ax, ay, pred[0][0], pred[0][1] );
     }
-    else if( phase == PH_COST ) { valid = slot == 0; ax = mvCur[0]; ay = mvCur[1]; bx = mvTar[0]; by = mvTar[1]; }
-    // ---- the distortion of every lane's tile, the PU sum, the rate ----
-    unsigned d = tile_eval<PAIR>( t, valid ? ax : 0, valid ? ay : 0, valid ? bx : 0, valid ? by : 0 );
-    if( T == 4 ) { d += ( unsigned ) shfl_x( ( int ) d, 1 ); d += ( unsigned ) shfl_x( ( int ) d, 2 ); }
-    if( PAIR && !t.satd ) d += ( unsigned ) shfl_x( ( int ) d, 1 );
-    unsigned long long c = valid ? ( unsigned long long ) floor( fWeight * ( double ) d ) + ( phase == PH_INIT || phase == PH_COST ? 0ull : rate( bits ) ) : ~0ull;
-    // ---- first minimum of the pass over the slots of the group ----
-    int bs = slot;
-#pragma unroll
-    for( int off = T; off < LPP; off <<= 1 )
+    else if( phase == PH_COST ) { valid = s == 0; ax = mvCur[0]; ay = mvCur[1]; bx = mvTar[0]; by = mvTar[1]; }
+    return valid;
+  };
+  auto slot_cost = [&]( bool valid, unsigned d, unsigned bits )
+  { return valid ? ( unsigned long long ) floor( fWeight * ( double ) d ) + ( phase == PH_INIT || phase == PH_COST ? 0ull : rate( bits ) ) : ~0ull; };
+
+  while( GROUP ? __any( phase != PH_DONE ) : phase != PH_DONE )
+  {
+    unsigned long long c;
+    int bs;
+    if( GROUP )
     {
-      const unsigned long long oc = shfl_x64( c, off );
-      const int                os = shfl_x( bs, off );
-      if( oc < c || ( oc == c && os < bs ) ) { c = oc; bs = os; }
+      int ax, ay, bx, by, tx, ty;
+      unsigned bits;
+      const bool valid = slot_params( slot, ax, ay, bx, by, bits );
+      tile_xy( tile, tx, ty );
+      unsigned d = tile_eval<PAIR>( t, tx, ty, ax, ay, bx, by );
+      // PU sum over the tile lanes of the slot; a Hadamard pair already holds its tile's value in both lanes
+#pragma unroll
+      for( int off = 1; off < T; off <<= 1 )
+        if( off > 1 || !PAIR || !t.satd ) d += ( unsigned ) shfl_x( ( int ) d, off );
+      c = slot_cost( valid, d, bits ); bs = slot;
+      // first minimum of the pass over the slots of the group
+#pragma unroll
+      for( int off = T; off < LPP; off <<= 1 )
+      {
+        const unsigned long long oc = shfl_x64( c, off );
+        const int                os = shfl_x( bs, off );
+        if( oc < c || ( oc == c && os < bs ) ) { c = oc; bs = os; }
+      }
+    }
+    else
+    {
+      if( lane < 8 ) sDist[lane] = 0;
+      __syncthreads();
+      const int nSlots = ( phase == PH_DIAMOND || phase == PH_CROSS ) ? dEnd - dStart + 1 : phase == PH_COST ? 1 : num0 * num1;
+#pragma unroll 1
+      for( int it = lane; it < nSlots * T; it += NT )
+      {
+        const int s = it / T, tl = it - s * T;
+        int ax, ay, bx, by, tx, ty;
+        unsigned bits;
+        if( !slot_params( s, ax, ay, bx, by, bits ) ) continue;    // the skipped pair of the final check (whole tiles: pair lanes stay together)
+        tile_xy( tl, tx, ty );
+        const unsigned d = tile_eval<PAIR>( t, tx, ty, ax, ay, bx, by );
+        if( !PAIR || !t.satd || !( tl & 1 ) ) atomicAdd( &sDist[s], d );
+      }
+      __syncthreads();
+      c = ~0ull; bs = 0;
+      for( int s = 0; s < nSlots; s++ )
+      {
+        int ax, ay, bx, by;
+        unsigned bits;
+        const bool valid = slot_params( s, ax, ay, bx, by, bits );
+        const unsigned long long cs = slot_cost( valid, sDist[s], bits );
+        if( cs < c ) { c = cs; bs = s; }
+      }
+      __syncthreads();
     }
     const bool found = c < cost;
-    // ---- state update (group-uniform) ----
+    // ---- state update (group- / workgroup-uniform) ----
     if( phase == PH_INIT )
     {
       const int bi = bs / num1, bk = bs - bi * num1;
@@ -676,11 +722,11 @@ __global__ __launch_bounds__( 64 ) void smvd_tile_kernel( vtmhip_pic_params pic,
   }
 }
 
-template<int TX, int TY>
+template<int TX, int TY, int NW>
 void launch_tile( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, vtmhip_smvd_job *d_jobs, int n, int op )
 {
-  constexpr int PPW = 64 / ( 8 * TX * TY );
-  hipLaunchKernelGGL( ( smvd_tile_kernel<TX, TY> ), dim3( ( n + PPW - 1 ) / PPW ), dim3( 64 ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, op );
+  constexpr int PPW = NW ? 1 : 64 / ( 8 * TX * TY );
+  hipLaunchKernelGGL( ( smvd_tile_kernel<TX, TY, NW> ), dim3( ( n + PPW - 1 ) / PPW ), dim3( NW ? 64 * NW : 64 ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, op );
 }
 
 }   // namespace
@@ -702,13 +748,34 @@ int vtmhip_smvd_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const 
   // pattern + prediction B + the (h + 7) x w intermediates of the separable filter
   const size_t lds = ( 2 * ( size_t ) maxWidth * maxHeight + ( size_t ) maxWidth * ( maxHeight + 7 ) ) * sizeof( int16_t );
   VTMHIP_TIME_KERNEL( ctx, "smvd_kernel" );
-  if( uniform && pic->bitDepth <= 10 && maxWidth <= 16 && maxHeight <= 16 && maxWidth >= 8 && maxHeight >= 8 && !getenv( "VTMHIP_SMVD_NO_TILE" ) )
+  bool tiled = true;
+  if( uniform && pic->bitDepth <= 10 && maxWidth >= 8 && maxHeight >= 8 && !getenv( "VTMHIP_SMVD_NO_TILE" ) )
   {
-    if( maxWidth == 8 && maxHeight == 8 ) launch_tile<1, 1>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op );
-    else if( maxWidth == 16 && maxHeight == 8 ) launch_tile<2, 1>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op );
-    else if( maxWidth == 8 ) launch_tile<1, 2>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op );
-    else launch_tile<2, 2>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op );
+    // group form up to four tiles; above: one PU per workgroup, waves by the number of (candidate, tile) items of a pass (8 candidates x tiles)
+    switch( maxWidth * 256 + maxHeight )
+    {
+    case 8 * 256 + 8:     launch_tile<1, 1, 0>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 16 * 256 + 8:    launch_tile<2, 1, 0>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 8 * 256 + 16:    launch_tile<1, 2, 0>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 16 * 256 + 16:   launch_tile<2, 2, 0>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 32 * 256 + 8:    launch_tile<4, 1, 0>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 8 * 256 + 32:    launch_tile<1, 4, 0>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 32 * 256 + 16:   launch_tile<4, 2, 1>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 16 * 256 + 32:   launch_tile<2, 4, 1>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 32 * 256 + 32:   launch_tile<4, 4, 2>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 64 * 256 + 16:   launch_tile<8, 2, 2>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 16 * 256 + 64:   launch_tile<2, 8, 2>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 64 * 256 + 32:   launch_tile<8, 4, 4>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 32 * 256 + 64:   launch_tile<4, 8, 4>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 64 * 256 + 64:   launch_tile<8, 8, 4>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 128 * 256 + 64:  launch_tile<16, 8, 4>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 64 * 256 + 128:  launch_tile<8, 16, 4>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 128 * 256 + 128: launch_tile<16, 16, 4>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    default: tiled = false;
+    }
   }
+  else tiled = false;
+  if( tiled ) {}
   else if( maxWidth * maxHeight <= 1024 )
   {
     hipLaunchKernelGGL( smvd_kernel<64>, dim3( n ), dim3( 64 ), lds, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, op );
