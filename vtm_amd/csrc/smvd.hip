@@ -396,6 +396,7 @@ __device__ __forceinline__ void pred_tile( const int16_t *__restrict__ ref, int 
     }
 #pragma unroll
     for( int k = 0; k < 4; k++ ) prevH[k] = curH[k];
+    __builtin_amdgcn_sched_barrier( 0 );   // keep the row loads from being hoisted together (register pressure -> occupancy)
   }
 }
 
