@@ -21,10 +21,17 @@
 #include "EncoderLib/InterSearch.h"
 
 #include <cstdint>
+#include <cstdlib>
+#include <new>
+#include <utility>
 #include <cstring>
 
 namespace
 {
+// every rig object starts from zeroed storage: the reference's constructors leave members the encoder normally sets elsewhere (and these rigs set only where the
+// member under test reads them) indeterminate, which made a result depend on what the heap block held before
+template<class T, class... A> T *zeroNew( A &&... a ) { void *m = calloc( 1, sizeof( T ) ); return new( m ) T( std::forward<A>( a )... ); }
+
 struct MeRig
 {
   SPS             sps;
@@ -142,7 +149,7 @@ extern "C"
 
 void ref_tz_search( const MeCtxC *c, const TzJobC *job, MeResC *res )
 {
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   InterSearch::IntTZSearchStruct st;
   CPelBuf pattern;
@@ -171,7 +178,7 @@ void ref_tz_search( const MeCtxC *c, const TzJobC *job, MeResC *res )
 
 void ref_set_search_range( const MeCtxC *c, int predHor, int predVer, int range, int out[4] )
 {
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   InterSearch::IntTZSearchStruct st;
   CPelBuf pattern;
@@ -183,7 +190,7 @@ void ref_set_search_range( const MeCtxC *c, int predHor, int predVer, int range,
 
 void ref_full_search( const MeCtxC *c, const int range[4], MeResC *res )
 {
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   InterSearch::IntTZSearchStruct st;
   CPelBuf pattern;
@@ -197,7 +204,7 @@ void ref_full_search( const MeCtxC *c, const int range[4], MeResC *res )
 
 void ref_frac_search( const MeCtxC *c, int intX, int intY, int useHad, int useAltHpelIf, FracResC *res )
 {
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   InterSearch::IntTZSearchStruct st;
   CPelBuf pattern;
@@ -233,11 +240,11 @@ extern "C" int ref_quant_dequant( const int32_t *coef, int w, int h, int bitDept
 // mtsIdx = MTS_SKIP (1): the transform-skip forms of both members (useTransformSkip, Quant.cpp:966-997, 357-482)
 extern "C" int ref_quant_dequant2( const int32_t *coef, int w, int h, int bitDepth, int qp, int isIRAP, int mtsIdx, int32_t *qcoef, int32_t *absSum, int32_t *dqcoef )
 {
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   static Quant *quant   = nullptr;
   ensureRom();
-  if( !quant ) { quant = new Quant( nullptr ); quant->init( 64, false, false, false ); }
+  if( !quant ) { quant = zeroNew<Quant>( nullptr ); quant->init( 64, false, false, false ); }
   r.sps.setBitDepth( CHANNEL_TYPE_LUMA, bitDepth );
   r.sps.setBitDepth( CHANNEL_TYPE_CHROMA, bitDepth );
   r.sps.setQpBDOffset( CHANNEL_TYPE_LUMA, 6 * ( bitDepth - 8 ) );
@@ -248,7 +255,7 @@ extern "C" int ref_quant_dequant2( const int32_t *coef, int w, int h, int bitDep
   r.slice.setExplicitScalingListUsed( false );
   r.slice.setSPS( &r.sps );
   static TransformUnit *tu = nullptr;
-  if( !tu ) tu = new TransformUnit( UnitArea( CHROMA_400, Area( 0, 0, w, h ) ) );
+  if( !tu ) tu = zeroNew<TransformUnit>( UnitArea( CHROMA_400, Area( 0, 0, w, h ) ) );
   tu->UnitArea::operator=( UnitArea( CHROMA_400, Area( 0, 0, w, h ) ) );
   tu->cs = &r.cs;
   tu->cu = &r.cu;
@@ -282,11 +289,11 @@ extern "C" int ref_quant_dequant2( const int32_t *coef, int w, int h, int bitDep
 
 extern "C" void ref_motion_estimation( const vo_mest_cfg_t *cfg, const vo_mest_job_t *j, vo_mest_result_t *res )
 {
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   static Picture *pic = nullptr;
   static bool     storage = false;
-  if( !pic ) pic = new Picture();
+  if( !pic ) pic = zeroNew<Picture>();
   if( !storage )
   {
     const UnitArea lcu( CHROMA_400, Area( 0, 0, MAX_CU_SIZE, MAX_CU_SIZE ) );
@@ -374,12 +381,12 @@ extern "C" void ref_motion_estimation( const vo_mest_cfg_t *cfg, const vo_mest_j
 extern "C" void ref_pred_inter_blk( int comp, const int16_t *planeY, int strideY, const int16_t *planeC, int strideC, int picW, int picH, int puX, int puY,
                                     int w, int h, int mvHor, int mvVer, int bi, int bitDepth, int imv, int16_t *dst, int dstStride )
 {
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   static Picture *pic = nullptr;
   if( !pic )
   {
-    pic = new Picture();
+    pic = zeroNew<Picture>();
     for( int c = 1; c < 3; c++ ) r.is.m_filteredBlockTmp[0][c] = ( Pel * ) xMalloc( Pel, ( MAX_CU_SIZE + 16 + 4 ) * ( MAX_CU_SIZE + 1 + 16 + 7 + 4 ) );
   }
   r.pps.setPicWidthInLumaSamples( picW );
@@ -434,7 +441,7 @@ extern "C" void ref_weighted_geo_blk( int simd, int splitDir, int comp, int luma
                                       int s1Stride, int16_t *dst, int dstStride, int bitDepth )
 {
   ensureRom();
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   const UnitArea ua( CHROMA_420, Area( 0, 0, lumaW, lumaH ) );
   r.cu.UnitArea::operator=( ua );
@@ -467,13 +474,13 @@ extern "C" void ref_weighted_geo_blk( int simd, int splitDir, int comp, int luma
 extern "C" void ref_bdof_pu( int simd, const int16_t *plane0, const int16_t *plane1, int stride, int picW, int picH, int puX, int puY, int w, int h,
                              int mv0Hor, int mv0Ver, int mv1Hor, int mv1Ver, int bitDepth, int16_t *dst, int dstStride )
 {
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   static Picture *pic = nullptr;
   static Pel     *dummy = nullptr;
   if( !pic )
   {
-    pic   = new Picture();
+    pic   = zeroNew<Picture>();
     dummy = ( Pel * ) xMalloc( Pel, MAX_CU_SIZE * MAX_CU_SIZE );
   }
   if( !r.is.m_gradX0 )
@@ -531,11 +538,11 @@ extern "C" void ref_dmvr_pu( const int16_t *plane0, const int16_t *plane1, int s
                              int mv0Hor, int mv0Ver, int mv1Hor, int mv1Ver, int bitDepth, int bioApplied, int16_t *dst, int dstStride, int32_t *mvdOut )
 {
   ensureRom();
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   static Picture *pics[2] = { nullptr, nullptr };
   InterPrediction &ip = r.is;
-  if( !pics[0] ) { pics[0] = new Picture(); pics[1] = new Picture(); }
+  if( !pics[0] ) { pics[0] = zeroNew<Picture>(); pics[1] = zeroNew<Picture>(); }
   const size_t dm = ( MAX_CU_SIZE + ( 2 * DMVR_NUM_ITERATION ) ), dr = dm + NTAPS_LUMA;
   if( !ip.m_cYuvPredTempDMVRL0 ) { ip.m_cYuvPredTempDMVRL0 = ( Pel * ) xMalloc( Pel, dm * dm ); ip.m_cYuvPredTempDMVRL1 = ( Pel * ) xMalloc( Pel, dm * dm ); }
   if( !ip.m_cRefSamplesDMVRL0[0] ) { ip.m_cRefSamplesDMVRL0[0] = ( Pel * ) xMalloc( Pel, dr * dr ); ip.m_cRefSamplesDMVRL1[0] = ( Pel * ) xMalloc( Pel, dr * dr ); }
@@ -603,11 +610,11 @@ extern "C" void ref_dmvr_pu420( const int16_t *const planes[2][3], int strideY, 
                                 int dstStrideC, int32_t *mvdOut )
 {
   ensureRom();
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   static Picture *pics[2] = { nullptr, nullptr };
   InterPrediction &ip = r.is;
-  if( !pics[0] ) { pics[0] = new Picture(); pics[1] = new Picture(); }
+  if( !pics[0] ) { pics[0] = zeroNew<Picture>(); pics[1] = zeroNew<Picture>(); }
   const size_t dm = ( MAX_CU_SIZE + ( 2 * DMVR_NUM_ITERATION ) ), dr = dm + NTAPS_LUMA;
   if( !ip.m_cYuvPredTempDMVRL0 ) { ip.m_cYuvPredTempDMVRL0 = ( Pel * ) xMalloc( Pel, dm * dm ); ip.m_cYuvPredTempDMVRL1 = ( Pel * ) xMalloc( Pel, dm * dm ); }
   for( int c = 0; c < 3; c++ )
@@ -709,8 +716,8 @@ TrRig *g_trRig = nullptr;
 
 TransformUnit &trSetup( int w, int h, int bitDepth, int mtsIdx )
 {
-  if( !g_rig ) g_rig = new MeRig();
-  if( !g_trRig ) g_trRig = new TrRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
+  if( !g_trRig ) g_trRig = zeroNew<TrRig>();
   ensureRom();
   MeRig &r = *g_rig;
   r.sps.setBitDepth( CHANNEL_TYPE_LUMA, bitDepth );
@@ -721,7 +728,7 @@ TransformUnit &trSetup( int w, int h, int bitDepth, int mtsIdx )
   r.sps.setUseLFNST( false );
   r.slice.setSPS( &r.sps );
   const UnitArea ua( CHROMA_400, Area( 0, 0, w, h ) );
-  if( !g_trRig->tu ) g_trRig->tu = new TransformUnit( ua );
+  if( !g_trRig->tu ) g_trRig->tu = zeroNew<TransformUnit>( ua );
   TransformUnit &tu = *g_trRig->tu;
   tu.UnitArea::operator=( ua );
   tu.cs = &r.cs;
@@ -785,11 +792,11 @@ extern "C" int ref_transformNxN_select( const int16_t *resi, int stride, int w, 
 // ------------------------------------------------------------------------------------------------------------------
 extern "C" void ref_estimate_mvp_amvp( const vo_mest_job_t *j, int *mvpIdx, int *mvPredHor, int *mvPredVer, uint64_t *distBiP )
 {
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   static Picture *pic = nullptr;
   static bool     storage = false;
-  if( !pic ) pic = new Picture();
+  if( !pic ) pic = zeroNew<Picture>();
   if( !storage )
   {
     const UnitArea lcu( CHROMA_400, Area( 0, 0, MAX_CU_SIZE, MAX_CU_SIZE ) );
@@ -841,7 +848,7 @@ extern "C" void ref_estimate_mvp_amvp( const vo_mest_job_t *j, int *mvpIdx, int 
 extern "C" void ref_check_best_mvp( double motionLambda, int imv, int numCand, const int cands[2][2], const unsigned idxBits[2], int mvHor, int mvVer,
                                     int *mvPredHor, int *mvPredVer, int *mvpIdx, unsigned *bits, uint64_t *cost )
 {
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   r.rd.m_motionLambda = motionLambda;
   for( int i = 0; i < 2; i++ ) r.is.m_auiMVPIdxCost[i][AMVP_MAX_NUM_CANDS] = idxBits[i];
@@ -866,7 +873,7 @@ PicHeader *g_affPh  = nullptr;
 
 void affineSetup( MeRig &r, const vo_affine_pred_t *p )
 {
-  if( !g_affPic ) { g_affPic = new Picture(); g_affPh = new PicHeader(); }
+  if( !g_affPic ) { g_affPic = zeroNew<Picture>(); g_affPh = zeroNew<PicHeader>(); }
   if( !r.is.m_storedMv ) r.is.m_storedMv = new Mv[( MAX_CU_SIZE / MIN_PU_SIZE ) * ( MAX_CU_SIZE / MIN_PU_SIZE )];
   r.sps.setMaxCUWidth( p->ctuSize ); r.sps.setMaxCUHeight( p->ctuSize );
   r.sps.setBitDepth( CHANNEL_TYPE_LUMA, p->bitDepth );
@@ -903,7 +910,7 @@ void affineRestore( MeRig &r )
 
 extern "C" void ref_pred_affine_blk( const vo_affine_pred_t *p, const int mv[3][2], int bi, int16_t *dst, int dstStride )
 {
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   affineSetup( r, p );
   Mv m[3] = { Mv( mv[0][0], mv[0][1] ), Mv( mv[1][0], mv[1][1] ), Mv( mv[2][0], mv[2][1] ) };
@@ -918,7 +925,7 @@ extern "C" void ref_solve_equal( double eq[7][7], int order, double *para ) { so
 
 extern "C" void ref_affine_motion_estimation( const vo_affine_me_job_t *j, vo_affine_me_result_t *res )
 {
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   static bool storage = false;
   if( !storage )
@@ -1022,7 +1029,7 @@ void smvdSetup( MeRig &r, const vo_smvd_job_t *j, PelUnitBuf &origBuf )
   r.slice.m_clpRngs.comp[COMPONENT_Y] = clp;
   for( int l = 0; l < 2; l++ )
   {
-    if( !pic[l] ) pic[l] = new Picture();
+    if( !pic[l] ) pic[l] = zeroNew<Picture>();
     Pel *origin = const_cast<Pel *>( j->ref[l] ) - ( ptrdiff_t ) j->puY * j->refStride[l] - j->puX;
     pic[l]->chromaFormat = CHROMA_400;
     pic[l]->unscaledPic  = pic[l];
@@ -1047,7 +1054,7 @@ void smvdRestore( MeRig &r )
 
 extern "C" uint64_t ref_symmetric_cost( const vo_smvd_job_t *j, const int mvCur[2], const int mvTar[2] )
 {
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   PelUnitBuf origBuf;
   smvdSetup( r, j, origBuf );
@@ -1060,7 +1067,7 @@ extern "C" uint64_t ref_symmetric_cost( const vo_smvd_job_t *j, const int mvCur[
 
 extern "C" void ref_symmetric_me( const vo_smvd_job_t *j, const int predCur[2], const int predTar[2], int mvCur[2], int mvTar[2], uint64_t *cost )
 {
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   PelUnitBuf origBuf;
   smvdSetup( r, j, origBuf );
@@ -1075,7 +1082,7 @@ extern "C" void ref_symmetric_me( const vo_smvd_job_t *j, const int predCur[2], 
 
 extern "C" void ref_symmvd_check_best_mvp( const vo_smvd_job_t *j, const int curMv[2], int skip, int predSym[2][2], int mvpIdxSym[2], uint64_t *bestCost )
 {
-  if( !g_rig ) g_rig = new MeRig();
+  if( !g_rig ) g_rig = zeroNew<MeRig>();
   MeRig &r = *g_rig;
   PelUnitBuf origBuf;
   smvdSetup( r, j, origBuf );
