@@ -409,6 +409,24 @@ def main():
             r = issue_roofline("satd8_grid_kernel", satd_k_ms / satd_k_n, 1, in_step=False)
             r["pairs_per_s_G"] = nb * 81 / (satd_k_ms / satd_k_n) / 1e6
             out["satd_roofline"] = r
+        if world == 1:
+            # what a host encoder would add per picture if the inputs were NOT resident: the original picture and the picture reconstructed last (the other
+            # reference pictures are already on the device) from pinned host memory, measured here, not overlapped -- never part of `value`
+            n_up = int(cur.numel() + newest[1])
+            host = torch.empty(n_up, dtype=torch.int16).pin_memory()
+            stage = torch.empty(n_up, dtype=torch.int16, device=dev)
+            stage.copy_(host, non_blocking=True)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                stage.copy_(host, non_blocking=True)
+            e1.record()
+            torch.cuda.synchronize()
+            up_ms = e0.elapsed_time(e1) / 5
+            out["pcie"] = {"h2d_bytes_per_picture": 2 * n_up, "h2d_ms_per_picture": up_ms, "h2d_GBps": 2 * n_up / up_ms / 1e6,
+                           "pictures_per_s_if_not_overlapped": 1000.0 / (1e3 * dt / a.steps + up_ms)}
+            del host, stage
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fme, cur_np, dpb_np, refs, sr, W, H, lam, qp, a.cpu_seconds, pocs=poc_arg, chroma=ch_cpu, affine=a.affine, low_delay=a.config == "ldp", smvd=smvd)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
