@@ -245,8 +245,11 @@ def affine_me_struct(scene, j, keep):
 class SmvdScene(Scene):
     """The original picture between two references: list 0 = an earlier frame (ref_buf), list 1 = a later one (ref_buf2)."""
 
-    def __init__(self, w=416, h=240, hard=False, margin=160):
+    def __init__(self, w=416, h=240, hard=False, margin=160, bit_depth=10):
         fr = (synth.gen_frames_hard if hard else synth.gen_frames)(w, h, 5)
+        if bit_depth != 10:      # the generator makes 10-bit samples
+            fr = [(f.astype(np.int32) << (bit_depth - 10)).astype(np.int16) if bit_depth > 10 else (f >> (10 - bit_depth)).astype(np.int16) for f in fr]
+        self.bd = bit_depth
         self.W, self.H = w, h
         self.cur = np.ascontiguousarray(fr[2])
         self.ref_buf, self.ref_off, self.ref_stride = synth.extend_plane(fr[0], margin)
@@ -289,7 +292,7 @@ def smvd_struct(scene, j):
     t.ref[0] = scene.ref_buf.ctypes.data + 2 * (scene.ref_off + j["y"] * scene.ref_stride + j["x"])
     t.ref[1] = scene.ref_buf2.ctypes.data + 2 * (scene.ref_off + j["y"] * scene.ref_stride + j["x"])
     t.refStride[0] = t.refStride[1] = scene.ref_stride
-    t.w, t.h, t.puX, t.puY, t.picW, t.picH, t.ctuSize, t.bitDepth = j["w"], j["h"], j["x"], j["y"], scene.W, scene.H, 128, 10
+    t.w, t.h, t.puX, t.puY, t.picW, t.picH, t.ctuSize, t.bitDepth = j["w"], j["h"], j["x"], j["y"], scene.W, scene.H, 128, getattr(scene, "bd", 10)
     t.imv, t.useSatd, t.clipBiPred, t.bcwWeightTar = j["imv"], j["satd"], j["clip"], j["bcw"]
     for l in range(2):
         t.numCand[l] = j["num"][l]

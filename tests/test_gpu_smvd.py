@@ -39,7 +39,7 @@ def hip_jobs(scene, jobs):
 
 
 def run_op(ctx, scene, d_cur, d_ref, arr, n, op, max_w=128, max_h=128, uniform=False):
-    pic = PicParams(scene.W, scene.H, 128, 10, 0)
+    pic = PicParams(scene.W, scene.H, 128, getattr(scene, "bd", 10), 0)
     d_jobs = ctx.to_device(np.frombuffer(arr, np.uint8))
     ctx.smvd_batch(pic, d_cur.ptr, d_ref.ptr, d_jobs.ptr, n, max_w, max_h, op, uniform=uniform)
     return (SmvdJob * n).from_buffer_copy(d_jobs.to_host(np.uint8).tobytes())
@@ -101,6 +101,25 @@ def test_smvd_uniform_batches(ctx, hard):
             assert got[k] == exp, ("members", size, k, j, got[k], exp)
             e = me_util.smvd_search_oracle(scene, j, L)
             assert full[k] == e, ("whole block", size, k, j, full[k], e)
+
+
+@pytest.mark.parametrize("bd", [8, 12])
+def test_smvd_other_bit_depths(ctx, bd):
+    """8-bit samples through the tile kernel (no head-room shift in the first filter pass) and 12-bit samples (differences beyond the packed Hadamard's range:
+    the block-wide kernel with the 32-bit Hadamard), mixed and uniform batches"""
+    L = ol.oracle()
+    scene = me_util.SmvdScene(416, 240, hard=True, bit_depth=bd)
+    jobs = me_util.random_smvd_jobs(scene, 160, seed=500 + bd)
+    got, full = device_member_results(ctx, scene, jobs)
+    for k, j in enumerate(jobs):
+        assert got[k] == me_util.smvd_member_results(scene, j, L, "vo_"), ("members", bd, k, j)
+        assert full[k] == me_util.smvd_search_oracle(scene, j, L), ("whole block", bd, k, j)
+    for size in ((8, 8), (16, 16), (32, 16), (64, 64)):
+        jobs = me_util.random_smvd_jobs(scene, 60, seed=size[0] + bd, sizes=[size])
+        got, full = device_member_results(ctx, scene, jobs, size)
+        for k, j in enumerate(jobs):
+            assert got[k] == me_util.smvd_member_results(scene, j, L, "vo_"), ("members", bd, size, k, j)
+            assert full[k] == me_util.smvd_search_oracle(scene, j, L), ("whole block", bd, size, k, j)
 
 
 def test_smvd_matches_golden_from_reference(ctx):
