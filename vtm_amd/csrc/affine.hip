@@ -276,11 +276,40 @@ __device__ void affine_pred( const AffCtx &c, const Mv3 &m, int16_t *sPred )
   }
 }
 
-// getDistPart( DF_HAD / DF_SAD ) of prediction vs pattern over the block (tile shapes of xGetHADs: RdCost.cpp:2837-2931), block-wide sum
-__device__ unsigned long long block_dist( const int16_t *sPred, const int16_t *sPat, int w, int h, bool satd, unsigned long long *sRed )
+// getDistPart( DF_HAD / DF_SAD ) of prediction vs pattern over the block (tile shapes of xGetHADs: RdCost.cpp:2837-2931), block-wide sum.
+// packed (bitDepth <= 10: |pattern - prediction| <= 3 * 1023): a lane takes one 8x8 unit with the packed 16-bit Hadamard of had.hpp; the two halves of a
+// 16x8 / 8x16 tile sit in neighbouring lanes (units in pair order), each returns the finished tile value and the even lane counts it.
+__device__ unsigned long long block_dist( const int16_t *sPred, const int16_t *sPat, int w, int h, bool satd, unsigned long long *sRed, bool packed )
 {
   unsigned long long acc = 0;
-  if( satd )
+  if( satd && packed )
+  {
+    const int nu = ( w >> 3 ) * ( h >> 3 );   // 8x8 units; w, h >= 16 here, so nu is even and pair lanes enter the loop together
+    for( int u = threadIdx.x; u < nu; u += blockDim.x )
+    {
+      int x, y;
+      if( w == h ) { const int ux = w >> 3; y = ( u / ux ) << 3; x = ( u - ( u / ux ) * ux ) << 3; }
+      else if( w > h ) { const int px = w >> 4, p = u >> 1; y = ( p / px ) << 3; x = ( ( p - ( p / px ) * px ) << 4 ) + ( ( u & 1 ) << 3 ); }
+      else { const int px = w >> 3, p = u >> 1; y = ( ( p / px ) << 4 ) + ( ( u & 1 ) << 3 ); x = ( p - ( p / px ) * px ) << 3; }
+      v2s D[8][4];
+#pragma unroll
+      for( int r = 0; r < 8; r++ )
+      {
+        const uint4 a = *reinterpret_cast<const uint4 *>( sPred + ( y + r ) * w + x ), b = *reinterpret_cast<const uint4 *>( sPat + ( y + r ) * w + x );
+        const unsigned aw[4] = { a.x, a.y, a.z, a.w }, bw[4] = { b.x, b.y, b.z, b.w };
+#pragma unroll
+        for( int k = 0; k < 4; k++ )
+        {
+          v2s p, q;
+          __builtin_memcpy( &p, &aw[k], 4 ); __builtin_memcpy( &q, &bw[k], 4 );
+          D[r][k] = p - q;
+        }
+      }
+      if( w == h ) acc += satd8_packed( D );
+      else { const unsigned tv = satd8_pair_packed( D ); acc += ( u & 1 ) ? 0u : tv; }
+    }
+  }
+  else if( satd )
   {
     const int tw = w > h ? 16 : 8, th = w < h ? 16 : 8, tx = w / tw, nt = tx * ( h / th );
     for( int t = threadIdx.x; t < nt; t += blockDim.x )
@@ -386,7 +415,7 @@ __global__ __launch_bounds__( 256 ) void affine_me_kernel( vtmhip_pic_params pic
   __syncthreads();
   affine_pred( c, tmp, sPred );
   __syncthreads();
-  unsigned long long costBest = block_dist( sPred, sPat, w, h, satd, sRed );
+  unsigned long long costBest = block_dist( sPred, sPat, w, h, satd, sRed, pic.bitDepth <= 10 );
   unsigned           bitsBest = j.bits + affine_mv_bits( six, j.imv, tmp, pred );
   costBest = ( unsigned long long ) ( floor( fWeight * ( double ) costBest ) + ( double ) ( unsigned long long ) ( lam * bitsBest ) );
   best = tmp;
@@ -505,7 +534,7 @@ __global__ __launch_bounds__( 256 ) void affine_me_kernel( vtmhip_pic_params pic
     affine_pred( c, tmp, sPred );
     __syncthreads();
     iterations++;
-    unsigned long long cost = block_dist( sPred, sPat, w, h, satd, sRed );
+    unsigned long long cost = block_dist( sPred, sPat, w, h, satd, sRed, pic.bitDepth <= 10 );
     const unsigned     bits = j.bits + affine_mv_bits( six, j.imv, tmp, pred );
     cost = ( unsigned long long ) ( floor( fWeight * ( double ) cost ) + ( double ) ( unsigned long long ) ( lam * bits ) );
     if( cost < costBest ) { costBest = cost; bitsBest = bits; best = tmp; }
@@ -516,7 +545,7 @@ __global__ __launch_bounds__( 256 ) void affine_me_kernel( vtmhip_pic_params pic
     affine_pred( c, m, sPred );
     __syncthreads();
     refinements++;
-    unsigned long long cost = block_dist( sPred, sPat, w, h, satd, sRed );
+    unsigned long long cost = block_dist( sPred, sPat, w, h, satd, sRed, pic.bitDepth <= 10 );
     const unsigned     bits = j.bits + affine_mv_bits( six, j.imv, m, pred );
     cost = ( unsigned long long ) ( floor( fWeight * ( double ) cost ) + ( double ) ( unsigned long long ) ( lam * bits ) );
     if( cost < costBest ) { costBest = cost; bitsBest = bits; best = m; return true; }
