@@ -598,6 +598,12 @@ int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const
 int vtmhip_tu_ts_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_tu_job *d_jobs, int n, int width, int height,
                                   int32_t *d_levelsBase, int16_t *d_recBase, vtmhip_tu_result *d_results );
 
+/* The MTS pre-selection of a whole level on the device (vtmhip_mts_select2 per TU): d_results holds numCand runs of numTU results one after the other (the
+ * layout vtmhip_pis_level_run uses: results[c * numTU + t]), mtsIdx[c] = the candidate's tu.mtsIdx (1 = transform skip: sumAbs is sum |residual|);
+ * d_test[c * numTU + t] = 1 when candidate c of TU t survives.  numCand <= 8. */
+int vtmhip_mts_select_batch_dev( vtmhip_ctx *ctx, const vtmhip_tu_result *d_results, int numTU, int numCand, const uint8_t *mtsIdx, int width, int height,
+                                 int bitDepth, int maxLog2TrDynamicRange, int maxCand, uint8_t *d_test );
+
 /* TrQuant::xT only, for a batch the caller promises to be uniform (every TU width x height, powers of two 8..64) -- the forward transforms of all
  * MTS candidates of TrQuant::transformNxN( ..., trModes, maxCand ) (TrQuant.cpp:950-1019): same job table as the fused chain (qp fields unused);
  * coefficients (H x W contiguous) go to d_coefBase + outOff, results[i].sumAbs = sum |coef| for vtmhip_mts_select(). */
@@ -856,6 +862,8 @@ typedef struct
   int32_t              *qcoefC;
   int32_t  numTUC, tuWC, tuHC, pad1;
   vtmhip_affine_me_out *affOut;        /* affine uni stage when pis.affJobs != NULL */
+  uint8_t *mtsTest;                    /* [numCands * numTU] or NULL: the MTS pre-selection flags of the luma candidates (vtmhip_mts_select_batch_dev) */
+  int32_t  mtsMaxCand, pad2;           /* cfg MTSInterMaxCand */
 } vtmhip_pis_level_run;
 
 typedef struct

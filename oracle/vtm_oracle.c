@@ -2355,3 +2355,38 @@ void vo_smvd_search( const vo_smvd_job_t *job, int numFixed, int numStart, const
   for( int l = 0; l < 2; l++ ) { res->predSym[l][0] = predSym[l][0]; res->predSym[l][1] = predSym[l][1]; res->mvpIdxSym[l] = mvpIdxSym[l]; }
   res->cost = symCost;
 }
+
+
+/* ---- MTS candidate pre-selection of TrQuant::transformNxN( tu, compID, cQP, &trModes, maxCand ) (TrQuant.cpp:950-1019) ------------------------------
+ * sumAbs[i]: sum |coef| of candidate i after xT (sum |residual| for a transform-skip candidate, scaled here as :992-1001 scale it); the list is in trModes
+ * order (DCT2 first).  A candidate survives when its cost is at most facBB[log2 size] x the first candidate's cost -- the candidate at list position 1
+ * against the unscaled cost (:1012) -- and no more than maxCand + 1 have survived before it. */
+void vo_mts_select( const int32_t *sumAbs, const uint8_t *mtsIdx, int numCand, int w, int h, int bitDepth, int maxLog2TrDynamicRange, int maxCand, uint8_t *test )
+{
+  static const double facBB[] = { 1.2, 1.3, 1.3, 1.4, 1.5 };
+  int lw = 0, lh = 0;
+  while( ( 2 << lw ) <= w ) lw++;
+  while( ( 2 << lh ) <= h ) lh++;
+  int32_t cost[16];
+  for( int i = 0; i < numCand; i++ )
+  {
+    cost[i] = sumAbs[i];
+    if( mtsIdx[i] == 1 )
+    {
+      double scaleSAD = 1.0;
+      if( ( lw + lh ) & 1 ) scaleSAD = 1.0 / 1.414213562;
+      scaleSAD *= pow( 2, maxLog2TrDynamicRange - bitDepth - ( ( lw + lh ) >> 1 ) );
+      cost[i] = ( int ) ( sumAbs[i] * scaleSAD );
+    }
+  }
+  const int    lg  = lw > lh ? lw : lh;
+  const int    fi  = lg - 2 > 0 ? ( lg - 2 > 4 ? 4 : lg - 2 ) : 0;
+  const double thr = facBB[fi] * cost[0], thrTS = cost[0];
+  int numTests = 0;
+  for( int i = 0; i < numCand; i++ )
+  {
+    const int t = cost[i] <= ( i == 1 ? thrTS : thr ) && numTests <= maxCand;
+    test[i] = ( uint8_t ) t;
+    numTests += t;
+  }
+}

@@ -225,6 +225,9 @@ void vo_symmetric_me( const vo_smvd_job_t *job, const int predCur[2], const int 
 void vo_symmvd_check_best_mvp( const vo_smvd_job_t *job, const int curMv[2], int skip, int predSym[2][2], int mvpIdxSym[2], uint64_t *bestCost );
 void vo_smvd_search( const vo_smvd_job_t *job, int numFixed, int numStart, const int starts[][2], unsigned modeBits, vo_smvd_result_t *res );
 
+/* TrQuant::transformNxN( tu, compID, cQP, &trModes, maxCand ) (TrQuant.cpp:950-1019): which candidates survive the sum |coef| pre-selection */
+void vo_mts_select( const int32_t *sumAbs, const uint8_t *mtsIdx, int numCand, int w, int h, int bitDepth, int maxLog2TrDynamicRange, int maxCand, uint8_t *test );
+
 #ifdef __cplusplus
 }
 #endif

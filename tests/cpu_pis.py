@@ -298,6 +298,17 @@ def run_pu(cur_np, dpb_ptr, refs, search_ranges, W, H, s, x, y, cands_rows, lam,
             r_tu = np.ascontiguousarray(resi[qy * th:(qy + 1) * th, qx * tw:(qx + 1) * tw])
             for ci, mts in enumerate(tu_cands):
                 out["tus"][(qy * (w // tw) + qx, ci)] = _tu_chain(L, R, r_tu, (tw, th), mts, qp_per, qp_rem, bd)
+            # which candidates the reference would go on to quantise: TrQuant::transformNxN( trModes, MTSInterMaxCand ) -- the real member on the residual, or the
+            # oracle's rule on the chain's sum |coef|
+            marr, flags = np.array(list(tu_cands), np.uint8), np.zeros(len(tu_cands), np.uint8)
+            if len(tu_cands) == 1:
+                flags[0] = 1          # the first candidate always survives (64-sample TUs carry DCT2 only)
+            elif R:
+                R.ref_transformNxN_select(ol.P(r_tu), tw, tw, th, bd, ol.P(marr), len(tu_cands), 4, ol.P(flags))
+            else:
+                sums = np.array([out["tus"][(qy * (w // tw) + qx, ci)][1] for ci in range(len(tu_cands))], np.int32)
+                L.vo_mts_select(ol.P(sums), ol.P(marr), len(tu_cands), tw, th, bd, 15, 4, ol.P(flags))
+            out.setdefault("mts", {})[qy * (w // tw) + qx] = [int(v) for v in flags]
     # ---- the 4:2:0 chroma planes: xPredInterBlk with the 4-tap filter at 1/32 phase, addAvg, residual, DCT2 chain at the chroma QP ----
     if chroma is not None:
         wc, hc, rsc = w // 2, h // 2, chroma["ref_stride"]
@@ -384,6 +395,9 @@ def compare_with_device(snap_level, parent_level, nref, i, out):
         k = ci * ntu + i * q2 + tu
         got = (int(tr[k, 0]), int(tr[k, 1] & 0xFFFFFFFF), int((tr[k, 1] >> 32) & 0xFFFFFFFF))
         assert (sse, sa, asum) == got, ("tu", s, i, tu, ci, (sse, sa, asum), got)
+    for tu, flags in out.get("mts", {}).items():
+        got = [int(snap_level["mts_test"][ci * ntu + i * q2 + tu]) for ci in range(len(flags))]
+        assert flags == got, ("MTS pre-selection", s, i, tu, flags, got)
     if "aff" in out:
         ao, aj = snap_level["aff_out"], snap_level["aff_jobs"]
         for (l, r), (mv, bits, cost) in out["aff"].items():

@@ -550,6 +550,9 @@ def test_mts_preselection_equals_reference_transformNxN(oracle, reflib):
         assert L.vtmhip_mts_select2(sums.ctypes.data, marr.ctypes.data, len(modes), w, h, 10, 15, max_cand, t_lib.ctypes.data) == lib.OK
         reflib.ref_transformNxN_select(ol.P(resi), w, w, h, 10, ol.P(marr), len(modes), max_cand, ol.P(t_ref))
         assert list(t_lib) == list(t_ref), (w, h, modes, max_cand, list(sums), list(t_lib), list(t_ref))
+        t_o = np.zeros(len(modes), np.uint8)
+        oracle.vo_mts_select(ol.P(sums), ol.P(marr), len(modes), w, h, 10, 15, max_cand, ol.P(t_o))
+        assert list(t_o) == list(t_ref), ("vo_mts_select", w, h, modes, max_cand, list(sums), list(t_o), list(t_ref))
         n_pruned += int(len(modes) - t_ref.sum())
     assert n_pruned > 100   # the rule actually prunes on this content
 

@@ -91,6 +91,9 @@ int run_rest( vtmhip_ctx *ctx, const vtmhip_pis_level_run &L, const vtmhip_pis_b
     if( st ) return st;
     k += run;
   }
+  if( L.mtsTest && !st )
+    st = vtmhip_mts_select_batch_dev( ctx, L.tuRes, L.numTU, L.numCands, L.cand, L.tuW, L.tuH, L.pic.bitDepth, 15, L.mtsMaxCand, L.mtsTest );
+  if( st ) return st;
   if( L.tuC ) st = vtmhip_tu_chain_batch_dev( ctx, b.resiC, L.tuC, 2 * L.numTUC, L.tuWC, L.tuHC, 1, L.qcoefC, nullptr, L.tuResC );
   return st;
 }

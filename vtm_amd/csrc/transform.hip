@@ -1097,6 +1097,26 @@ int tu_chain_generic( vtmhip_ctx *ctx, const int16_t *d_resiBase, const vtmhip_t
   return VTMHIP_OK;
 }
 
+struct MtsSelectArgs { double scaleSAD, fac; int numTU, numCand, maxCand; bool skip[8]; };
+
+// TrQuant::transformNxN( tu, compID, cQP, &trModes, maxCand ) (TrQuant.cpp:950-1019) per TU: results[c * numTU + t].sumAbs -> test[c * numTU + t]
+__global__ __launch_bounds__( 256 ) void mts_select_kernel( const vtmhip_tu_result *__restrict__ results, MtsSelectArgs a, uint8_t *__restrict__ test )
+{
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if( t >= a.numTU ) return;
+  int cost0 = 0, numTests = 0;
+  double thr = 0.0;
+  for( int c = 0; c < a.numCand; c++ )
+  {
+    int cost = results[( long ) c * a.numTU + t].sumAbs;
+    if( a.skip[c] ) cost = ( int ) ( cost * a.scaleSAD );      // scaleSAD of the transform-skip candidate (:992-1001)
+    if( c == 0 ) { cost0 = cost; thr = a.fac * cost0; }
+    const bool keep = ( double ) cost <= ( c == 1 ? ( double ) cost0 : thr ) && numTests <= a.maxCand;
+    test[( long ) c * a.numTU + t] = keep;
+    numTests += keep;
+  }
+}
+
 }   // namespace
 
 extern "C"
@@ -1295,6 +1315,30 @@ int vtmhip_mts_select2( const int32_t *sumAbs, const uint8_t *mtsIdx, int numCan
     }
   }
   return vtmhip_mts_select( scaled, numCand, width, height, maxCand, test );
+}
+
+// the same rule for every TU of a level, one thread per TU (fp64 compare as the reference: facBB[] x the first candidate's cost)
+int vtmhip_mts_select_batch_dev( vtmhip_ctx *ctx, const vtmhip_tu_result *d_results, int numTU, int numCand, const uint8_t *mtsIdx, int width, int height,
+                                 int bitDepth, int maxLog2TrDynamicRange, int maxCand, uint8_t *d_test )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, numTU >= 0 && numCand >= 1 && numCand <= 8 && width >= 4 && height >= 4 && mtsIdx, "numTU / numCand / size" );
+  if( numTU == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_results && d_test, "null pointer" );
+  int lw = 0, lh = 0;
+  while( ( 2 << lw ) <= width ) lw++;
+  while( ( 2 << lh ) <= height ) lh++;
+  MtsSelectArgs a;
+  for( int i = 0; i < 8; i++ ) a.skip[i] = i < numCand && mtsIdx[i] == 1;
+  a.scaleSAD = ( ( lw + lh ) & 1 ) ? 1.0 / 1.414213562 : 1.0;
+  a.scaleSAD *= pow( 2, maxLog2TrDynamicRange - bitDepth - ( ( lw + lh ) >> 1 ) );
+  static const double facBB[] = { 1.2, 1.3, 1.3, 1.4, 1.5 };
+  const int lg = lw > lh ? lw : lh;
+  a.fac = facBB[lg - 2 > 0 ? ( lg - 2 > 4 ? 4 : lg - 2 ) : 0];
+  a.numTU = numTU; a.numCand = numCand; a.maxCand = maxCand;
+  hipLaunchKernelGGL( mts_select_kernel, dim3( ( numTU + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, d_results, a, d_test );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
 }
 
 // MTS candidate pre-selection thresholds (TrQuant::transformNxN( ..., trModes, maxCand ), TrQuant.cpp:950-1019): host arithmetic (fp64).

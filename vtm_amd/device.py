@@ -231,6 +231,11 @@ class Context:
         """InterSearch::xAffineMotionEstimation per AffineMeJob (one workgroup per job)"""
         self._check(self.L.vtmhip_xAffineMotionEstimation_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_other, d_jobs, n, max_w, max_h, d_results))
 
+    def mts_select_batch(self, d_results, num_tu, cands, w, h, bit_depth, max_cand, d_test):
+        """TrQuant::transformNxN( trModes ) pre-selection of every TU of a level from the sum |coef| of its candidates (runs of num_tu results per candidate)"""
+        arr = (C.c_uint8 * 8)(*cands)
+        self._check(self.L.vtmhip_mts_select_batch_dev(self.h, d_results, num_tu, len(cands), arr, w, h, bit_depth, 15, max_cand, d_test))
+
     def smvd_batch(self, pic, d_org, d_ref, d_jobs, n, max_w, max_h, op, uniform=False):
         """the SMVD block of predInterSearch per SmvdJob, in place: op 0 xGetSymmetricCost, 1 xSymmetricMotionEstimation, 2 symmvdCheckBestMvp, 3 the whole block;
         uniform: every job is exactly max_w x max_h (VTMHIP_SMVD_UNIFORM: the lane-per-tile kernel for 8x8 .. 16x16)"""

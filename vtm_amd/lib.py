@@ -184,7 +184,8 @@ class PisLevelRun(C.Structure):
     _fields_ = [("pis", PisLevel), ("pic", PicParams), ("picBi", PicParams), ("cfgUni", MeCfg), ("cfgBi", MeCfg), ("width", C.c_int32), ("height", C.c_int32),
                 ("bdof", C.c_int32), ("pad0", C.c_int32), ("uniOut", C.c_void_p), ("biOut", C.c_void_p), ("tu", C.c_void_p), ("tuRes", C.c_void_p), ("qcoef", C.c_void_p),
                 ("numTU", C.c_int32), ("numCands", C.c_int32), ("tuW", C.c_int32), ("tuH", C.c_int32), ("cand", C.c_uint8 * 8), ("tuC", C.c_void_p),
-                ("tuResC", C.c_void_p), ("qcoefC", C.c_void_p), ("numTUC", C.c_int32), ("tuWC", C.c_int32), ("tuHC", C.c_int32), ("pad1", C.c_int32), ("affOut", C.c_void_p)]
+                ("tuResC", C.c_void_p), ("qcoefC", C.c_void_p), ("numTUC", C.c_int32), ("tuWC", C.c_int32), ("tuHC", C.c_int32), ("pad1", C.c_int32), ("affOut", C.c_void_p),
+                ("mtsTest", C.c_void_p), ("mtsMaxCand", C.c_int32), ("pad2", C.c_int32)]
 
 
 class PisBuffers(C.Structure):
@@ -277,6 +278,7 @@ _PROTOS = {
                                       C.c_int32, C.c_int32]),
     "vtmhip_tr_matrix_host": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     "vtmhip_mts_select": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vtmhip_mts_select_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vtmhip_mts_select2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vtmhip_tu_ts_chain_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vtmhip_xT_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -87,6 +87,7 @@ from .lib import MAX_REF, AffineMeJob, AffineMeOut, FracJob, FracResult, MeCfg, 
 
 AFF_DT, AFFOUT_DT = np.dtype(AffineMeJob), np.dtype(AffineMeOut)
 SMVD_DT = np.dtype(SmvdJob)
+MTS_INTER_MAX_CAND = 4      # cfg MTSInterMaxCand (encoder_randomaccess_vtm.cfg / encoder_lowdelay_P_vtm.cfg)
 
 FRAC_DT, FRACRES_DT = np.dtype(FracJob), np.dtype(FracResult)
 TU_DT = np.dtype(TuJob)
@@ -326,7 +327,7 @@ class FrameHotPath:
             tj["qpPer"], tj["qpRem"], tj["bitDepth"] = self.qp_per, self.qp_rem, bit_depth
             tj["typeHor"] = np.repeat([MTS_IDX_TYPES[c][0] for c in cl], ntu)
             tj["typeVer"] = np.repeat([MTS_IDX_TYPES[c][1] for c in cl], ntu)
-            lvl.update(ntu=ntu, nc=nc, ts=tw, tw=tw, th=th, cands=cl, tu=_Tab(T, dev, tj), tu_res=T.zeros((ntu * nc, 2), dtype=T.int64, device=dev),
+            lvl.update(ntu=ntu, nc=nc, ts=tw, tw=tw, th=th, cands=cl, tu=_Tab(T, dev, tj), tu_res=T.zeros((ntu * nc, 2), dtype=T.int64, device=dev), mts_test=T.zeros(ntu * nc, dtype=T.uint8, device=dev),
                        qcoef=T.zeros(ntu * nc * tw * th, dtype=T.int32, device=dev))
             self.levels.append(lvl)
             prev = lvl
@@ -363,6 +364,7 @@ class FrameHotPath:
             r.biOut = lvl["bi_out"].data_ptr() if self.is_b else None
             r.tu, r.tuRes, r.qcoef = lvl["tu"].ptr, lvl["tu_res"].data_ptr(), lvl["qcoef"].data_ptr()
             r.numTU, r.numCands, r.tuW, r.tuH = lvl["ntu"], lvl["nc"], lvl["tw"], lvl["th"]
+            r.mtsTest, r.mtsMaxCand = lvl["mts_test"].data_ptr(), MTS_INTER_MAX_CAND
             for i, c in enumerate(lvl["cands"]):
                 r.cand[i] = c
             if chroma is not None:
@@ -448,6 +450,7 @@ class FrameHotPath:
             else:
                 ctx.tu_chain_batch(self.buf["resi"].data_ptr(), tu_p + a * TU_DT.itemsize, m, tw, th, res_p + a * 16, q_p, None, uniform=True)
             k += run
+        ctx.mts_select_batch(res_p, ntu, cands, tw, th, self.bd, MTS_INTER_MAX_CAND, lvl["mts_test"].data_ptr())
 
     def run(self, org_ptr, dpb_ptr, timing=False):
         """timing=True (or no side streams / VTM_AMD_OVERLAP=0): every level's steps one after the other on one stream with an event after every
@@ -489,7 +492,7 @@ class FrameHotPath:
             d = dict(size=lvl["size"], w=lvl["w"], h=lvl["h"], tw=lvl["tw"], th=lvl["th"], npu=lvl["npu"], ntu=lvl["ntu"], nc=lvl["nc"], ts=lvl["ts"], cands=lvl["cands"], xs=lvl["xs"], ys=lvl["ys"],
                      uni_jobs=lvl["uni_jobs"].t.cpu().numpy().view(ME_DT).reshape(-1), uni_out=lvl["uni_out"].cpu().numpy().view(MEOUT_DT).reshape(-1),
                      uni_rows=lvl["uni_rows"].cpu().numpy().view(ROW_DT).reshape(-1), pus=lvl["pus"].cpu().numpy().view(PU_DT).reshape(-1),
-                     tu_res=lvl["tu_res"].cpu().numpy())
+                     tu_res=lvl["tu_res"].cpu().numpy(), mts_test=lvl["mts_test"].cpu().numpy())
             if self.is_b:
                 d["bi_jobs"] = lvl["bi_jobs"].t.cpu().numpy().view(ME_DT).reshape(-1)
                 d["bi_out"] = lvl["bi_out"].cpu().numpy().view(MEOUT_DT).reshape(-1)
@@ -508,7 +511,7 @@ class FrameHotPath:
         """the per-PU / per-TU result tensors a rank hands to rank 0 (bytes views), coarse to fine"""
         out = []
         for lvl in self.levels:
-            out += [lvl["pus"].reshape(-1), lvl["tu_res"].view(self.torch.uint8).reshape(-1)]
+            out += [lvl["pus"].reshape(-1), lvl["tu_res"].view(self.torch.uint8).reshape(-1), lvl["mts_test"]]
             if self.chroma is not None:
                 out.append(lvl["tu_res_c"].view(self.torch.uint8).reshape(-1))
             if "aff_out" in lvl:
