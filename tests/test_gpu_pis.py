@@ -80,6 +80,8 @@ def check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, R, per_level=24, min_chec
             if stats is not None:
                 stats["bio"] = stats.get("bio", 0) + int(out["bio"])
                 stats["chroma_nz"] = stats.get("chroma_nz", 0) + sum(1 for v in out.get("tus_c", {}).values() if v[2])
+                stats["mts_pruned"] = stats.get("mts_pruned", 0) + sum(f.count(0) for f in out.get("mts", {}).values())
+                stats["mts_kept"] = stats.get("mts_kept", 0) + sum(f.count(1) for f in out.get("mts", {}).values())
             checked += 1
     assert checked >= min_checked
     return dirs
@@ -166,6 +168,8 @@ def test_frame_hot_path_on_split_shapes(use_ref, name, sizes):
     stats = {}
     dirs = check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, ol.ref() if use_ref else None, per_level=12, min_checked=50, pocs=pocs, chroma=ch_cpu, stats=stats)
     assert 3 in dirs and stats["bio"] >= 3 and stats["chroma_nz"] >= 5, (dirs, stats)
+    assert stats["mts_pruned"] >= 20 and stats["mts_kept"] > stats["mts_pruned"] // 4, stats     # the pre-selection of transformNxN( trModes ) really prunes here
+    print("mts:", name, stats["mts_kept"], "kept,", stats["mts_pruned"], "pruned")
     ctx.close()
 
 
