@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define VTMHIP_ABI_VERSION 3
+#define VTMHIP_ABI_VERSION 4
 
 enum
 {
