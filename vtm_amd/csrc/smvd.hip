@@ -511,7 +511,7 @@ __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_
   int pred[2][2] = { { j.predSym[0][0], j.predSym[0][1] }, { j.predSym[1][0], j.predSym[1][1] } }, idxSym[2] = { j.mvpIdxSym[0], j.mvpIdxSym[1] };
   unsigned long long cost = j.cost, mvpCost = 0;
   int phase = !live ? PH_DONE : op == VTMHIP_SMVD_COST ? PH_COST : op == VTMHIP_SMVD_ME ? PH_DIAMOND : op == VTMHIP_SMVD_CHECK_MVP ? PH_FINAL : PH_INIT;
-  int round = 0, dStart = 0, dEnd = 7, startX = 0, startY = 0, si = 0;
+  int round = 0, dStart = 0, dEnd = 7, startX = 0, startY = 0, si = 0, sj = -1;   // si, sj: the (up to) two start vectors of a STARTS pass
   const int maxRounds = 8 >> imv;
   const bool skipPair = op == VTMHIP_SMVD_CHECK_MVP ? j.skip != 0 : true;
   unsigned startMask = 0;
@@ -572,13 +572,16 @@ __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_
     ax = ay = bx = by = 0; bits = 0;
     if( phase == PH_INIT || phase == PH_STARTS || phase == PH_FINAL )
     {
-      int pi = s / num1, pk = s - pi * num1;
-      valid = s < num0 * num1;
+      // STARTS: two start vectors per pass, slots 0..3 the pairs of the first, 4..7 of the second (the order the reference visits them in)
+      const int second = phase == PH_STARTS ? s >> 2 : 0, ps = phase == PH_STARTS ? s & 3 : s;
+      int pi = ps / num1, pk = ps - pi * num1;
+      valid = ps < num0 * num1 && ( !second || sj >= 0 );
       if( !valid ) pi = pk = 0;
       if( phase == PH_INIT ) { ax = cand( 0, pi, 0 ); ay = cand( 0, pi, 1 ); bx = cand( 1, pk, 0 ); by = cand( 1, pk, 1 ); }
       else
       {
-        ax = phase == PH_STARTS ? start_vec( si, 0 ) : mvCur[0]; ay = phase == PH_STARTS ? start_vec( si, 1 ) : mvCur[1];
+        const int sv = second && sj >= 0 ? sj : si;
+        ax = phase == PH_STARTS ? start_vec( sv, 0 ) : mvCur[0]; ay = phase == PH_STARTS ? start_vec( sv, 1 ) : mvCur[1];
         bx = cand( 1, pk, 0 ) - ax + cand( 0, pi, 0 ); by = cand( 1, pk, 1 ) - ay + cand( 0, pi, 1 );   // Mv::getSymmvdMv
         bits = mvbits( ax, ay, cand( 0, pi, 0 ), cand( 0, pi, 1 ) ) + idx_bits( pi ) + idx_bits( pk );
         if( phase == PH_FINAL && skipPair && pi == idxSym[0] && pk == idxSym[1] ) valid = false;
@@ -629,7 +632,7 @@ __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_
     {
       if( lane < 8 ) sDist[lane] = 0;
       __syncthreads();
-      const int nSlots = ( phase == PH_DIAMOND || phase == PH_CROSS ) ? dEnd - dStart + 1 : phase == PH_COST ? 1 : num0 * num1;
+      const int nSlots = ( phase == PH_DIAMOND || phase == PH_CROSS ) ? dEnd - dStart + 1 : phase == PH_COST ? 1 : phase == PH_STARTS && sj >= 0 ? 8 : num0 * num1;
 #pragma unroll 1
       for( int it = lane; it < nSlots * T; it += NT )
       {
@@ -663,19 +666,21 @@ __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_
       mvCur[0] = pred[0][0]; mvCur[1] = pred[0][1]; mvTar[0] = pred[1][0]; mvTar[1] = pred[1][1];
       cost = c + rate( mvbits( mvCur[0], mvCur[1], pred[0][0], pred[0][1] ) + idx_bits( bi ) + idx_bits( bk ) );
       si = next_start( 0 );
+      sj = si >= 0 ? next_start( si + 1 ) : -1;
       if( si >= 0 ) phase = PH_STARTS; else to_me();
     }
     else if( phase == PH_STARTS )
     {
-      if( found )
+      if( found )   // the first minimum over (start vector, i, k) in the reference's order = what its one-by-one strict comparisons keep
       {
-        const int bi = bs / num1, bk = bs - bi * num1;
+        const int sv = ( bs >> 2 ) ? sj : si, ps = bs & 3, bi = ps / num1, bk = ps - bi * num1;
         cost = c; idxSym[0] = bi; idxSym[1] = bk;
         pred[0][0] = cand( 0, bi, 0 ); pred[0][1] = cand( 0, bi, 1 ); pred[1][0] = cand( 1, bk, 0 ); pred[1][1] = cand( 1, bk, 1 );
-        mvCur[0] = start_vec( si, 0 ); mvCur[1] = start_vec( si, 1 );
+        mvCur[0] = start_vec( sv, 0 ); mvCur[1] = start_vec( sv, 1 );
         mvTar[0] = pred[1][0] - mvCur[0] + pred[0][0]; mvTar[1] = pred[1][1] - mvCur[1] + pred[0][1];
       }
-      si = next_start( si + 1 );
+      si = next_start( ( sj >= 0 ? sj : si ) + 1 );
+      sj = si >= 0 ? next_start( si + 1 ) : -1;
       if( si < 0 ) to_me();
     }
     else if( phase == PH_DIAMOND || phase == PH_CROSS )
