@@ -92,6 +92,34 @@ __device__ __forceinline__ Range search_range( const MeJob &j, int predHor, int 
 struct __attribute__( ( packed, aligned( 2 ) ) ) Pel8 { unsigned v[4]; };
 struct __attribute__( ( packed, aligned( 2 ) ) ) Pel4 { unsigned v[2]; };
 
+// 8 (4) reference samples at a candidate's sample offset.  A multi-dword load whose address is only 2-byte aligned runs at 0.28x the rate of a 4-byte aligned one
+// on gfx950 (scripts/unaligned_load.hip: 9.2 vs 33 TB/s out of L2 / TCP), and half of all candidates sit at odd sample offsets -- so the segment is always
+// fetched from the dword below (one 16- / 8-byte load + the next dword, both 4-byte aligned) and funnel-shifted by 0 or 16 bits: no branch, the loads of an
+// unrolled trip still go out together.  Reads at most 2 bytes before and 4 bytes after the segment (inside the plane's margin rows / the next segment).
+struct __attribute__( ( packed, aligned( 4 ) ) ) Dw4 { unsigned v[4]; };
+struct __attribute__( ( packed, aligned( 4 ) ) ) Dw2 { unsigned v[2]; };
+__device__ __forceinline__ Pel8 ld8( const int16_t *p )
+{
+  const unsigned  sh = ( ( unsigned ) reinterpret_cast<uintptr_t>( p ) & 2u ) << 3;
+  const unsigned *q  = reinterpret_cast<const unsigned *>( reinterpret_cast<uintptr_t>( p ) & ~( uintptr_t ) 3 );
+  const Dw4       a  = *reinterpret_cast<const Dw4 *>( q );
+  const unsigned  e  = q[4];
+  Pel8 r;
+  r.v[0] = __builtin_amdgcn_alignbit( a.v[1], a.v[0], sh ); r.v[1] = __builtin_amdgcn_alignbit( a.v[2], a.v[1], sh );
+  r.v[2] = __builtin_amdgcn_alignbit( a.v[3], a.v[2], sh ); r.v[3] = __builtin_amdgcn_alignbit( e, a.v[3], sh );
+  return r;
+}
+__device__ __forceinline__ Pel4 ld4( const int16_t *p )
+{
+  const unsigned  sh = ( ( unsigned ) reinterpret_cast<uintptr_t>( p ) & 2u ) << 3;
+  const unsigned *q  = reinterpret_cast<const unsigned *>( reinterpret_cast<uintptr_t>( p ) & ~( uintptr_t ) 3 );
+  const Dw2       a  = *reinterpret_cast<const Dw2 *>( q );
+  const unsigned  e  = q[2];
+  Pel4 r;
+  r.v[0] = __builtin_amdgcn_alignbit( a.v[1], a.v[0], sh ); r.v[1] = __builtin_amdgcn_alignbit( e, a.v[1], sh );
+  return r;
+}
+
 // |a.lo - b.lo| + |a.hi - b.hi| + acc on unsigned 16-bit halves: one VALU instruction per two samples.
 // Signed samples are made unsigned by flipping the sign bits of both operands (bias), which leaves |a - b| unchanged.
 __device__ __forceinline__ unsigned sad2( unsigned a, unsigned b, unsigned acc ) { return __builtin_amdgcn_sad_u16( a, b, acc ); }
@@ -137,10 +165,16 @@ __device__ __forceinline__ unsigned sad_partial_impl( const MeJob &j, int cx, in
       int            it = sub;
       // four steps per trip: the four reference loads of a lane are in flight together (a wave walks ONE candidate here, so without this every
       // step pays a full vector-memory latency: 100+ cycles per vector instruction on the 128x128 level)
+      const bool odd = ( reinterpret_cast<uintptr_t>( pr ) & 2 ) != 0 && !( cs & 1 );   // wave-uniform: every lane's address has the candidate's parity (even strides)
       for( ; it + 192 < j.items; it += 256 )
       {
-        const Pel8  b0 = *reinterpret_cast<const Pel8 *>( pr ), b1 = *reinterpret_cast<const Pel8 *>( pr + dr );
-        const Pel8  b2 = *reinterpret_cast<const Pel8 *>( pr + 2 * dr ), b3 = *reinterpret_cast<const Pel8 *>( pr + 3 * dr );
+        Pel8 b0, b1, b2, b3;
+        if( odd ) { b0 = ld8( pr ); b1 = ld8( pr + dr ); b2 = ld8( pr + 2 * dr ); b3 = ld8( pr + 3 * dr ); }
+        else
+        {
+          b0 = *reinterpret_cast<const Pel8 *>( pr ); b1 = *reinterpret_cast<const Pel8 *>( pr + dr );
+          b2 = *reinterpret_cast<const Pel8 *>( pr + 2 * dr ); b3 = *reinterpret_cast<const Pel8 *>( pr + 3 * dr );
+        }
         const uint4 a0 = *reinterpret_cast<const uint4 *>( po ), a1 = *reinterpret_cast<const uint4 *>( po + 512 );
         const uint4 a2 = *reinterpret_cast<const uint4 *>( po + 1024 ), a3 = *reinterpret_cast<const uint4 *>( po + 1536 );
         s = sad2( a0.x, bx<SGN>( b0.v[0], j.bias ), s ); s = sad2( a0.y, bx<SGN>( b0.v[1], j.bias ), s ); s = sad2( a0.z, bx<SGN>( b0.v[2], j.bias ), s ); s = sad2( a0.w, bx<SGN>( b0.v[3], j.bias ), s );
