@@ -232,7 +232,7 @@ __global__ __launch_bounds__( THREADS ) void smvd_kernel( vtmhip_pic_params pic,
   AmvpLists a;
   for( int l = 0; l < 2; l++ )
   {
-    a.num[l] = j.numCand[l];
+    a.num[l] = min( 2, max( 1, ( int ) j.numCand[l] ) );   // AMVP lists hold one or two candidates
     for( int i = 0; i < 2; i++ ) { a.cand[l][i][0] = j.cand[l][i][0]; a.cand[l][i][1] = j.cand[l][i][1]; }
   }
   int mvCur[2] = { j.mvCur[0], j.mvCur[1] }, mvTar[2] = { j.mvTar[0], j.mvTar[1] };
@@ -499,7 +499,7 @@ __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_
   { return eg_bits( prec_dn( mx, amvrShift ) - prec_dn( px, amvrShift ) ) + eg_bits( prec_dn( my, amvrShift ) - prec_dn( py, amvrShift ) ); };
 
   // AMVP lists
-  int cnd[2][2][2], num0 = j.numCand[0], num1 = j.numCand[1];
+  int cnd[2][2][2], num0 = min( 2, max( 1, ( int ) j.numCand[0] ) ), num1 = min( 2, max( 1, ( int ) j.numCand[1] ) );   // AMVP lists hold one or two candidates
 #pragma unroll
   for( int a = 0; a < 2; a++ )
 #pragma unroll
