@@ -363,7 +363,9 @@ struct FracSq
   static constexpr int ITEMS = 9 * TILES;                       // per PU per round
   static constexpr int BLOCK = TILES == 16 ? 192 : 256;
   static constexpr int MINW  = 4;                                // waves per SIMD the register budget is sized for (128 VGPRs; the dot-product V pass fits every size)
-  static constexpr int JPW   = TILES == 16 ? 4 : ITEMS >= BLOCK ? 1 : BLOCK / ITEMS;   // 8x8: 28, 16x8: 14, 16x16 / 32x8: 7, 32x16: 3, 32x32 / 64x16: 4 (4 x 144 items = 3 full trips of 192 lanes), larger: 1
+  // PUs per workgroup.  32x32 / 64x16 (16 tiles, 3 waves): 2 -- 288 / 256 items = 1.5 / 1.33 trips of 192 lanes, but 22 KB of LDS per workgroup instead of 44 KB
+  // lets five workgroups (15 waves) share a CU instead of three (9): 4 PUs (full trips) measured 3.23 ms for the picture's fractional searches, 3: 3.15, 2: 3.14, 1: 3.19
+  static constexpr int JPW   = TILES == 16 ? 2 : ITEMS >= BLOCK ? 1 : BLOCK / ITEMS;   // 8x8: 28, 16x8: 14, 16x16 / 32x8: 7, 32x16: 3, larger: 1
   static constexpr int WLD   = W + 8;                           // window stride
   static constexpr int WIN   = ( H + 8 ) * WLD;                 // window samples per PU
   static constexpr int PLANE = ( H + 8 ) * W;                   // one H-pass plane
