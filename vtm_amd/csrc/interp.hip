@@ -361,7 +361,7 @@ struct FracSq
   static constexpr int TILES = TX * TY;
   static constexpr bool PAIR = W != H;                          // 16x8 / 8x16 Hadamard tiles: two neighbouring 8x8 items per tile
   static constexpr int ITEMS = 9 * TILES;                       // per PU per round
-  static constexpr int BLOCK = TILES == 16 ? 192 : 256;
+  static constexpr int BLOCK = TILES == 16 ? 192 : TILES == 256 ? 512 : 256;   // 128x128: 72 KB of LDS = two workgroups per CU, so eight waves each (768 items per plane pass = 1.5 trips): 3.13 -> 3.03 ms per picture; 16 waves 3.09; 64x64 with six waves 3.23
   static constexpr int MINW  = 4;                                // waves per SIMD the register budget is sized for (128 VGPRs; the dot-product V pass fits every size)
   // PUs per workgroup.  32x32 / 64x16 (16 tiles, 3 waves): 2 -- 288 / 256 items = 1.5 / 1.33 trips of 192 lanes, but 22 KB of LDS per workgroup instead of 44 KB
   // lets five workgroups (15 waves) share a CU instead of three (9): 4 PUs (full trips) measured 3.23 ms for the picture's fractional searches, 3: 3.15, 2: 3.14, 1: 3.19
