@@ -831,14 +831,20 @@ __device__ __forceinline__ void raster_task( const MeJob &j, const Range &r, int
 }
 
 __global__ __launch_bounds__( 256 ) void tz_raster_cols_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
-                                                               const vtmhip_tz_job *__restrict__ jobs, TzSaved *__restrict__ saved, const int *__restrict__ list )
+                                                               const vtmhip_tz_job *__restrict__ jobs, TzSaved *__restrict__ saved, const int *__restrict__ list,
+                                                               unsigned *__restrict__ gTot, int parts )
 {
+  // parts > 1 (few searches in the batch: one band of a picture sharded over several GPUs, the 128x128 level): `parts` workgroups share one scan -- each takes
+  // every parts-th task, adds its partial totals into the scan's global totals (gTot[e][RASTER_TOT_CAP + 1], zeroed by the host; the last entry counts the
+  // workgroups that are done) and the one that arrives last picks the minimum.  Integer sums: the result does not depend on the split.
   __shared__ unsigned           sTot[RASTER_TOT_CAP + 1];   // + the dummy slot of lanes without a column
   __shared__ unsigned long long sRedCost[4];
   __shared__ unsigned           sRedIdx[4];
+  __shared__ int                sLast;
   const int lane = threadIdx.x & 63, wv = uni( ( int ) ( threadIdx.x >> 6 ) );
   const int count = list[0];
-  for( int e = blockIdx.x; e < count; e += gridDim.x )
+  const int part = parts > 1 ? ( int ) blockIdx.x % parts : 0, eStride = parts > 1 ? ( int ) gridDim.x / parts : ( int ) gridDim.x;
+  for( int e = parts > 1 ? ( int ) blockIdx.x / parts : ( int ) blockIdx.x; e < count; e += eStride )
   {
     const int            jobIdx = list[1 + e];
     const vtmhip_tz_job *jp = jobs + jobIdx;
@@ -859,7 +865,7 @@ __global__ __launch_bounds__( 256 ) void tz_raster_cols_kernel( vtmhip_pic_param
     // of a 16-segment block fills 624 of 640 lanes instead of 39 of every 64
     const int pairs = segs * nx, wslots = ( pairs + 63 ) >> 6;
     const int tasks = wslots * 5 * par * chunks;
-    for( int t = wv; t < tasks; t += 4 )
+    for( int t = wv + 4 * part; t < tasks; t += 4 * parts )
     {
       int q = t;
       const int ws = q % wslots; q /= wslots;
@@ -876,6 +882,20 @@ __global__ __launch_bounds__( 256 ) void tz_raster_cols_kernel( vtmhip_pic_param
       else raster_task<2>( j, r, nx, ny, col, live, myX, k, rho, p, chunk, rowStep, sTot );
     }
     __syncthreads();
+    if( parts > 1 )
+    {
+      unsigned *g = gTot + ( size_t ) e * ( RASTER_TOT_CAP + 1 );
+      for( int i = threadIdx.x; i < total; i += 256 )
+        if( sTot[i] ) atomicAdd( &g[i], sTot[i] );
+      __threadfence();
+      __syncthreads();
+      if( threadIdx.x == 0 ) sLast = atomicAdd( &g[RASTER_TOT_CAP], 1u ) == ( unsigned ) ( parts - 1 );
+      __syncthreads();
+      if( !sLast ) continue;   // block-uniform
+      __threadfence();
+      for( int i = threadIdx.x; i < total; i += 256 ) sTot[i] = __hip_atomic_load( &g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      __syncthreads();
+    }
     // first strict minimum of SAD + MV rate in raster order = lexicographic (cost, index) minimum
     unsigned long long bc = ~0ull;
     unsigned           bi = 0xffffffffu;
@@ -1394,17 +1414,26 @@ extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_par
   VTMHIP_REQUIRE( ctx, wpj == 0 || wpj == 1 || wpj == 2 || wpj == 4 || wpj == 8 || wpj == 16, "wavesPerJob must be 0, 1, 2, 4, 8 or 16" );
   // split search (default; VTMHIP_TZ_SPLIT=0: one launch): the raster scans of the batch run in tz_raster_cols_kernel between two launches of the search kernel
   static const bool split = !( getenv( "VTMHIP_TZ_SPLIT" ) && atoi( getenv( "VTMHIP_TZ_SPLIT" ) ) == 0 );
-  TzSaved *d_saved = nullptr;
-  int     *d_list  = nullptr;
+  TzSaved  *d_saved = nullptr;
+  int      *d_list  = nullptr;
+  unsigned *d_tot   = nullptr;
+  int       rasterParts = 1;
   if( split )
   {
+    // few searches (one band of a sharded picture): several workgroups per raster scan, so that the scans of a 128x128 level still fill the GPU
+    static const bool splitScan = !( getenv( "VTMHIP_RASTER_PARTS" ) && atoi( getenv( "VTMHIP_RASTER_PARTS" ) ) == 0 );
+    rasterParts = ( splitScan && n <= 640 ) ? ( 1280 / n < 8 ? 1280 / n : 8 ) : 1;   // aim at the 1280 resident workgroups (5 per CU); twice that measured slower
     const size_t oList = ( ( size_t ) n * sizeof( TzSaved ) + 255 ) & ~( size_t ) 255;
+    const size_t oTot  = ( oList + ( ( size_t ) n + 1 ) * sizeof( int ) + 255 ) & ~( size_t ) 255;
+    const size_t totBytes = rasterParts > 1 ? ( size_t ) n * ( RASTER_TOT_CAP + 1 ) * sizeof( unsigned ) : 0;
     void        *arena = nullptr;
-    int          st    = vtmhip_internal_workspace( ctx, oList + ( ( size_t ) n + 1 ) * sizeof( int ), &arena, 1 );
+    int          st    = vtmhip_internal_workspace( ctx, oTot + totBytes, &arena, 1 );
     if( st ) return st;
     d_saved = ( TzSaved * ) arena;
     d_list  = ( int * ) ( ( char * ) arena + oList );
+    d_tot   = ( unsigned * ) ( ( char * ) arena + oTot );
     VTMHIP_HIP( ctx, hipMemsetAsync( d_list, 0, sizeof( int ), ctx->stream ) );
+    if( totBytes ) VTMHIP_HIP( ctx, hipMemsetAsync( d_tot, 0, totBytes, ctx->stream ) );
   }
 #define VTMHIP_TZ_LAUNCH( W, GRID, MODE ) \
   hipLaunchKernelGGL( tz_search_kernel<W>, dim3( GRID ), dim3( W == 1 ? 256 : 64 * W ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, d_results, MODE, d_saved, d_list )
@@ -1423,7 +1452,8 @@ extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_par
   if( split )
   {
     { VTMHIP_TIME_KERNEL( ctx, "tz_raster_cols_kernel" );
-      hipLaunchKernelGGL( tz_raster_cols_kernel, dim3( n < 3072 ? n : 3072 ), dim3( 256 ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, d_saved, d_list );
+      hipLaunchKernelGGL( tz_raster_cols_kernel, dim3( rasterParts > 1 ? n * rasterParts : ( n < 3072 ? n : 3072 ) ), dim3( 256 ), 0, ctx->stream, *pic, d_orgBase,
+                          d_refBase, d_jobs, d_saved, d_list, d_tot, rasterParts );
     }
     { VTMHIP_TIME_KERNEL( ctx, "tz_search_kernel" );
       VTMHIP_TZ_SWITCH( 2 )
