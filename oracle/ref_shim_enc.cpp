@@ -658,7 +658,7 @@ SmvdCall smvdJob( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefP
 bool smvdRun( SmvdCall &c, int op )
 {
   const bool ok = A.h2d( g_ctx, d_hJob, &c.j, sizeof( c.j ) ) == VTMHIP_OK
-               && A.smvd( g_ctx, &c.pic, d_hOrg, c.base, ( vtmhip_smvd_job * ) d_hJob, 1, c.j.width, c.j.height, op ) == VTMHIP_OK
+               && A.smvd( g_ctx, &c.pic, d_hOrg, c.base, ( vtmhip_smvd_job * ) d_hJob, 1, c.j.width, c.j.height, op | VTMHIP_SMVD_UNIFORM ) == VTMHIP_OK   // one job: uniform by construction -> the lane-per-tile kernel the level-order driver uses (PUs with a side of 4: the block-wide kernel)
                && A.d2h( g_ctx, &c.j, d_hJob, sizeof( c.j ) ) == VTMHIP_OK;
   if( !ok ) note_error();
   return ok;
