@@ -660,20 +660,25 @@ int vtmhip_internal_mc_launch( vtmhip_ctx *ctx, const int16_t *d_orgBase, const 
                                int n, int maxWidth, int maxHeight, unsigned long long *d_sadOut )
 {
   const size_t lds = ( ( ( size_t ) maxWidth * ( maxHeight + 7 ) + ( size_t ) maxWidth * maxHeight + 7 ) & ~( size_t ) 7 ) * sizeof( int16_t );
-  // a quarter wave per block up to 64 samples, half a wave up to 16x16 samples, four waves above (the samples of a block are independent; only the H -> V hand-over syncs)
+  // lanes per block by its number of 8-sample items (a lane filters 8 samples per step; the samples of a block are independent, only the H -> V hand-over syncs):
+  // 8 lanes up to 64 samples (8 blocks per wave), 16 up to 16x16 (4 per wave), one wave up to 32x32, four waves above.  Measured on the bench picture (AMVP stage +
+  // all predictions): 16 / 32 / 256 / 256 lanes 0.90 ms, 16 / 32 / 64 / 256: 0.83, 8 / 32 / 64 / 256: 0.72, 8 / 16 / 64 / 256: 0.70, 8 / 16 / 32 / 256: 0.71
   VTMHIP_TIME_KERNEL( ctx, "motion_comp_kernel" );
-  if( maxWidth * maxHeight > 256 )
+  if( maxWidth * maxHeight > 1024 )
   {
     if( lds > 64 * 1024 )
       VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( motion_comp_kernel<256, 1> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
     hipLaunchKernelGGL( ( motion_comp_kernel<256, 1> ), dim3( n ), dim3( 256 ), lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth, maxHeight,
                         d_sadOut );
   }
+  else if( maxWidth * maxHeight > 256 )   // (see the threshold above) up to 32x32 samples: one wave per block -- the H -> V hand-over is a wave barrier, not a workgroup one
+    hipLaunchKernelGGL( ( motion_comp_kernel<64, 1> ), dim3( n ), dim3( 64 ), lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth, maxHeight,
+                        d_sadOut );
   else if( maxWidth * maxHeight > 64 )
-    hipLaunchKernelGGL( ( motion_comp_kernel<32, 2> ), dim3( ( n + 1 ) / 2 ), dim3( 64 ), 2 * lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth,
+    hipLaunchKernelGGL( ( motion_comp_kernel<16, 4> ), dim3( ( n + 3 ) / 4 ), dim3( 64 ), 4 * lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth,
                         maxHeight, d_sadOut );
   else
-    hipLaunchKernelGGL( ( motion_comp_kernel<16, 4> ), dim3( ( n + 3 ) / 4 ), dim3( 64 ), 4 * lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth,
+    hipLaunchKernelGGL( ( motion_comp_kernel<8, 8> ), dim3( ( n + 7 ) / 8 ), dim3( 64 ), 8 * lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth,
                         maxHeight, d_sadOut );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
