@@ -90,10 +90,10 @@ struct AvgThen
 // 8-sample segments per row pass, so a whole wave per block leaves 49 of 64 lanes idle and makes the launch a queue of 129 600 one-block waves whose
 // time is the latency chain job -> window -> LDS -> store; four blocks per wave quarter the number of waves).  JPB blocks per workgroup (lanes of a block
 // never span waves, so the H -> V hand-over needs no more than the wave-level fence).
-template<int THREADS, int JPB>
-__global__ __launch_bounds__( THREADS * JPB ) void motion_comp_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase, int16_t *__restrict__ predBase,
-                                                                 int16_t *__restrict__ outBase, const vtmhip_pred_job *__restrict__ jobs, int n, int maxW, int maxH,
-                                                                 unsigned long long *__restrict__ sadOut )
+// the block of one job; JobFn: jobIdx -> vtmhip_pred_job (a table entry, or built in registers from another table)
+template<int THREADS, int JPB, class JobFn>
+__device__ __forceinline__ void motion_comp_body( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase, int16_t *__restrict__ predBase,
+                                                  int16_t *__restrict__ outBase, JobFn job, int n, int maxW, int maxH, unsigned long long *__restrict__ sadOut )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];
   __shared__ unsigned sSad;   // THREADS == 256 with sadOut: the block's SAD
@@ -102,7 +102,7 @@ __global__ __launch_bounds__( THREADS * JPB ) void motion_comp_kernel( const int
   int16_t              *p0  = tmp + maxW * ( maxH + 7 );                                         // [h][w] list-0 prediction of a bi-predicted block (14-bit)
   const int             jobIdx = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x ) * JPB + sub;   // neighbouring PUs (overlapping reference windows) on one XCD's L2
   if( jobIdx >= n ) return;
-  const vtmhip_pred_job j    = jobs[jobIdx];
+  const vtmhip_pred_job j    = job( jobIdx );
   const int             lane = JPB > 1 ? ( int ) threadIdx.x % THREADS : ( int ) threadIdx.x;
   if( j.route == 1 ) return;   // routed to vtmhip_bdof_batch_dev (a table both calls are launched over)
   Epilogue ep;
@@ -147,6 +147,37 @@ __global__ __launch_bounds__( THREADS * JPB ) void motion_comp_kernel( const int
     }
     else if( lane == 0 ) sadOut[jobIdx] = sadAcc;
   }
+}
+
+template<int THREADS, int JPB>
+__global__ __launch_bounds__( THREADS * JPB ) void motion_comp_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase, int16_t *__restrict__ predBase,
+                                                                 int16_t *__restrict__ outBase, const vtmhip_pred_job *__restrict__ jobs, int n, int maxW, int maxH,
+                                                                 unsigned long long *__restrict__ sadOut )
+{
+  motion_comp_body<THREADS, JPB>( orgBase, refBase, predBase, outBase, [=]( int i ) { return jobs[i]; }, n, maxW, maxH, sadOut );
+}
+
+// xGetTemplateCost of the AMVP candidates (InterSearch.cpp:3235-3270): prediction job 2 * row + c = candidate c of ME job `row`, built in registers (no job table
+// between the ME rows and the prediction: 112 bytes per candidate less to write and read); the block is reduced to its SAD against the original
+template<int THREADS, int JPB>
+__global__ __launch_bounds__( THREADS * JPB ) void motion_comp_amvp_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+                                                                      const vtmhip_me_job *__restrict__ rows, int n2, int maxW, int maxH,
+                                                                      unsigned long long *__restrict__ sadOut )
+{
+  motion_comp_body<THREADS, JPB>( orgBase, refBase, nullptr, nullptr, [=]( int i )
+  {
+    const vtmhip_me_job &r = rows[i >> 1];
+    const int c = ( i & 1 ) < r.numAmvpCand ? ( i & 1 ) : 0;   // a missing second candidate repeats the first (its cost is not looked at)
+    int th = r.amvpCand[c][0], tv = r.amvpCand[c][1];
+    th = min( ( pic.picW + 8 - r.puX - 1 ) << 4, max( ( -pic.ctuSize - 8 - r.puX + 1 ) << 4, th ) );   // clipMvInPic (Mv.cpp:56-74)
+    tv = min( ( pic.picH + 8 - r.puY - 1 ) << 4, max( ( -pic.ctuSize - 8 - r.puY + 1 ) << 4, tv ) );
+    vtmhip_pred_job p;
+    p.orgOff = r.orgOff; p.refOff[0] = r.refOff; p.refOff[1] = r.refOff; p.predOff = 0; p.outOff = 0;
+    p.orgStride = r.orgStride; p.refStride[0] = p.refStride[1] = r.refStride; p.predStride = r.width; p.outStride = r.width;
+    p.mv[0][0] = th; p.mv[0][1] = tv; p.mv[1][0] = p.mv[1][1] = 0;
+    p.width = r.width; p.height = r.height; p.mode = 0; p.epilogue = 0; p.bitDepth = ( uint8_t ) pic.bitDepth; p.useAltHpelIf = r.imv == 3; p.chroma = 0; p.route = 0; p.pad1 = 0;
+    return p;
+  }, n2, maxW, maxH, sadOut );
 }
 
 __global__ __launch_bounds__( 256 ) void pelop_kernel( const int16_t *__restrict__ aBase, const int16_t *__restrict__ bBase, int16_t *__restrict__ dstBase,
@@ -680,6 +711,31 @@ int vtmhip_internal_mc_launch( vtmhip_ctx *ctx, const int16_t *d_orgBase, const 
   else
     hipLaunchKernelGGL( ( motion_comp_kernel<8, 8> ), dim3( ( n + 7 ) / 8 ), dim3( 64 ), 8 * lds, ctx->stream, d_orgBase, d_refBase, d_predBase, d_outBase, d_jobs, n, maxWidth,
                         maxHeight, d_sadOut );
+  VTMHIP_LAUNCHED( ctx );
+  return VTMHIP_OK;
+}
+
+// the AMVP form of the launch above: the prediction jobs are derived from the ME rows inside the kernel
+int vtmhip_internal_mc_amvp_launch( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_me_job *d_rows, int n,
+                                    int maxWidth, int maxHeight, unsigned long long *d_sadOut )
+{
+  const size_t lds = ( ( ( size_t ) maxWidth * ( maxHeight + 7 ) + ( size_t ) maxWidth * maxHeight + 7 ) & ~( size_t ) 7 ) * sizeof( int16_t );
+  const int    n2  = 2 * n;
+  VTMHIP_TIME_KERNEL( ctx, "motion_comp_kernel" );
+  if( maxWidth * maxHeight > 1024 )
+  {
+    if( lds > 64 * 1024 )
+      VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( motion_comp_amvp_kernel<256, 1> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
+    hipLaunchKernelGGL( ( motion_comp_amvp_kernel<256, 1> ), dim3( n2 ), dim3( 256 ), lds, ctx->stream, *pic, d_orgBase, d_refBase, d_rows, n2, maxWidth, maxHeight, d_sadOut );
+  }
+  else if( maxWidth * maxHeight > 256 )
+    hipLaunchKernelGGL( ( motion_comp_amvp_kernel<64, 1> ), dim3( n2 ), dim3( 64 ), lds, ctx->stream, *pic, d_orgBase, d_refBase, d_rows, n2, maxWidth, maxHeight, d_sadOut );
+  else if( maxWidth * maxHeight > 64 )
+    hipLaunchKernelGGL( ( motion_comp_amvp_kernel<16, 4> ), dim3( ( n2 + 3 ) / 4 ), dim3( 64 ), 4 * lds, ctx->stream, *pic, d_orgBase, d_refBase, d_rows, n2, maxWidth, maxHeight,
+                        d_sadOut );
+  else
+    hipLaunchKernelGGL( ( motion_comp_amvp_kernel<8, 8> ), dim3( ( n2 + 7 ) / 8 ), dim3( 64 ), 8 * lds, ctx->stream, *pic, d_orgBase, d_refBase, d_rows, n2, maxWidth, maxHeight,
+                        d_sadOut );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

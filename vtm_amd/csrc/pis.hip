@@ -28,25 +28,8 @@ __device__ __forceinline__ void clip_mv( const vtmhip_pic_params &pic, const vtm
 // ---- xEstimateMvPredAMVP ---------------------------------------------------------------------------------------------------------
 struct AmvpWork
 {
-  vtmhip_pred_job    *pred;   // [2n]
-  unsigned long long *dout;   // [2n] SAD of the candidates' predictions
+  unsigned long long *dout;   // [2n] SAD of the candidates' predictions (motion_comp_amvp_kernel, mc.hip: job 2 * row + c = candidate c of ME row `row`)
 };
-
-__global__ __launch_bounds__( 256 ) void amvp_jobs_kernel( vtmhip_pic_params pic, const vtmhip_me_job *__restrict__ jobs, int n, AmvpWork wk )
-{
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if( idx >= 2 * n ) return;
-  const vtmhip_me_job &j = jobs[idx >> 1];
-  const int c = ( idx & 1 ) < j.numAmvpCand ? ( idx & 1 ) : 0;   // a missing second candidate repeats the first (its cost is not looked at)
-  int th = j.amvpCand[c][0], tv = j.amvpCand[c][1];
-  clip_mv( pic, j, th, tv );
-  vtmhip_pred_job p;
-  p.orgOff = j.orgOff; p.refOff[0] = j.refOff; p.refOff[1] = j.refOff; p.predOff = 0; p.outOff = 0;   // nothing is stored: the launch reduces every prediction to its SAD
-  p.orgStride = j.orgStride; p.refStride[0] = p.refStride[1] = j.refStride; p.predStride = j.width; p.outStride = j.width;
-  p.mv[0][0] = th; p.mv[0][1] = tv; p.mv[1][0] = p.mv[1][1] = 0;
-  p.width = j.width; p.height = j.height; p.mode = 0; p.epilogue = 0; p.bitDepth = ( uint8_t ) pic.bitDepth; p.useAltHpelIf = j.imv == 3; p.chroma = 0; p.route = 0; p.pad1 = 0;
-  wk.pred[idx] = p;
-}
 
 __global__ __launch_bounds__( 256 ) void amvp_select_kernel( vtmhip_me_job *__restrict__ jobs, int n, AmvpWork wk, int addIdxBits, unsigned long long *__restrict__ distBiP )
 {
@@ -333,18 +316,16 @@ int vtmhip_xEstimateMvPredAMVP_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_para
   VTMHIP_REQUIRE( ctx, maxWidth >= 4 && maxWidth <= 128 && maxHeight >= 4 && maxHeight <= 128, "maxWidth / maxHeight" );
   AmvpWork     wk;
   size_t       off = 0;
-  const size_t oPred = off; off = align_up( off + 2 * ( size_t ) n * sizeof( vtmhip_pred_job ) );
   const size_t oDout = off; off = align_up( off + 2 * ( size_t ) n * sizeof( unsigned long long ) );
   void *arena = nullptr;
   int   st    = vtmhip_internal_workspace( ctx, off, &arena );
   if( st ) return st;
   char *base = ( char * ) arena;
-  wk.pred = ( vtmhip_pred_job * ) ( base + oPred ); wk.dout = ( unsigned long long * ) ( base + oDout );
-  hipLaunchKernelGGL( amvp_jobs_kernel, dim3( ( 2 * n + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, *pic, d_jobs, n, wk );
-  VTMHIP_LAUNCHED( ctx );
-  // xGetTemplateCost (:3162-3183): the candidate's prediction and its SAD against the original in ONE pass (no prediction buffer, no distortion jobs)
+  wk.dout = ( unsigned long long * ) ( base + oDout );
+  // xGetTemplateCost (:3162-3183): the candidate's prediction and its SAD against the original in ONE pass (no prediction buffer, no distortion jobs, and no
+  // prediction-job table either: the kernel derives job 2 * row + c from the ME row)
   ( void ) uniformSize;
-  st = vtmhip_internal_mc_launch( ctx, d_orgBase, d_refBase, nullptr, nullptr, wk.pred, 2 * n, maxWidth, maxHeight, wk.dout );
+  st = vtmhip_internal_mc_amvp_launch( ctx, pic, d_orgBase, d_refBase, d_jobs, n, maxWidth, maxHeight, wk.dout );
   if( st ) return st;
   hipLaunchKernelGGL( amvp_select_kernel, dim3( ( n + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, d_jobs, n, wk, addIdxBits, ( unsigned long long * ) d_distBiP );
   VTMHIP_LAUNCHED( ctx );
