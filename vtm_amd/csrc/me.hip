@@ -718,7 +718,7 @@ constexpr int RASTER_CHUNK   = 13;        // block rows (slots) of one task at m
     q0 = q1;                                                                                                                        \
     if( !( GUARDED ) || u0 + ( D ) + 2 <= uEnd ) q1 = *reinterpret_cast<const Pel8 *>( pr );                                        \
     pr += dr;                                                                                                                       \
-    const unsigned b0 = b.v[0] ^ j.bias, b1 = b.v[1] ^ j.bias, b2 = b.v[2] ^ j.bias, b3 = b.v[3] ^ j.bias;                          \
+    const unsigned b0 = bx<SGN>( b.v[0], j.bias ), b1 = bx<SGN>( b.v[1], j.bias ), b2 = bx<SGN>( b.v[2], j.bias ), b3 = bx<SGN>( b.v[3], j.bias );  \
     _Pragma( "unroll" ) for( int sl = 0; sl < N; sl++ )                                                                             \
     {                                                                                                                               \
       const int ai = ( ( D ) - sl + N ) % N;                                                                                        \
@@ -729,7 +729,7 @@ constexpr int RASTER_CHUNK   = 13;        // block rows (slots) of one task at m
     if( FLUSH ) { atomicAdd( &sTot[fa], A[( ( D ) + 1 ) % N] ); fa += fstep; }                                                      \
   }
 
-template<int N>
+template<int N, bool SGN>
 __device__ __forceinline__ void raster_run( const MeJob &j, int nx, int nyp, int p, int col, bool live, const int16_t *po, long orgStep, const int16_t *pr, long dr,
                                             unsigned *sTot )
 {
@@ -739,7 +739,7 @@ __device__ __forceinline__ void raster_run( const MeJob &j, int nx, int nyp, int
   {
     A[sl] = 0;
     const Pel8 a = *reinterpret_cast<const Pel8 *>( po + sl * orgStep );
-    O[sl][0] = a.v[0] ^ j.bias; O[sl][1] = a.v[1] ^ j.bias; O[sl][2] = a.v[2] ^ j.bias; O[sl][3] = a.v[3] ^ j.bias;
+    O[sl][0] = bx<SGN>( a.v[0], j.bias ); O[sl][1] = bx<SGN>( a.v[1], j.bias ); O[sl][2] = bx<SGN>( a.v[2], j.bias ); O[sl][3] = bx<SGN>( a.v[3], j.bias );
   }
   const int uEnd = nyp - 1 + N - 1;
   int       fa = live ? p * nx + col : RASTER_TOT_CAP;   // total of candidate (p + (mp << ss)) of this lane's column; lanes without a column: the dummy slot
@@ -767,7 +767,7 @@ __device__ __forceinline__ void raster_run( const MeJob &j, int nx, int nyp, int
 }
 #undef RASTER_STEP
 
-template<int NS>
+template<int NS, bool SGN>
 __device__ __forceinline__ void raster_task( const MeJob &j, const Range &r, int nx, int ny, int col, bool live, int myX, int k, int rho, int p, int chunk, int rowStep,
                                              unsigned *sTot )
 {
@@ -787,14 +787,14 @@ __device__ __forceinline__ void raster_task( const MeJob &j, const Range &r, int
     const long     os = ( long ) rowStep * j.orgStride;
     switch( needed )
     {
-    case 13: if( NS >= 13 ) { raster_run<13>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
-    case 12: if( NS >= 12 ) { raster_run<12>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
-    case 7: if( NS >= 7 ) { raster_run<7>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
-    case 6: if( NS >= 6 ) { raster_run<6>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
-    case 4: if( NS >= 4 ) { raster_run<4>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
-    case 3: if( NS >= 3 ) { raster_run<3>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
-    case 2: raster_run<2>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return;
-    case 1: raster_run<1>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return;
+    case 13: if( NS >= 13 ) { raster_run<13, SGN>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
+    case 12: if( NS >= 12 ) { raster_run<12, SGN>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
+    case 7: if( NS >= 7 ) { raster_run<7, SGN>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
+    case 6: if( NS >= 6 ) { raster_run<6, SGN>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
+    case 4: if( NS >= 4 ) { raster_run<4, SGN>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
+    case 3: if( NS >= 3 ) { raster_run<3, SGN>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return; } break;
+    case 2: raster_run<2, SGN>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return;
+    case 1: raster_run<1, SGN>( j, nx, nyp, p, col, live, po, os, pr, dr, sTot ); return;
     default: break;
     }
   }
@@ -806,13 +806,13 @@ __device__ __forceinline__ void raster_task( const MeJob &j, const Range &r, int
     A[sl] = 0;
     const int  rr = rho + rowStep * ( chunk * RASTER_CHUNK + max( sl - pad, 0 ) );
     const Pel8 a  = *reinterpret_cast<const Pel8 *>( j.org + ( long ) rr * j.orgStride + ( k << 3 ) );
-    O[sl][0] = a.v[0] ^ j.bias; O[sl][1] = a.v[1] ^ j.bias; O[sl][2] = a.v[2] ^ j.bias; O[sl][3] = a.v[3] ^ j.bias;
+    O[sl][0] = bx<SGN>( a.v[0], j.bias ); O[sl][1] = bx<SGN>( a.v[1], j.bias ); O[sl][2] = bx<SGN>( a.v[2], j.bias ); O[sl][3] = bx<SGN>( a.v[3], j.bias );
   }
   const int uEnd = nyp - 1 + NS - 1;
   for( int u = pad; u <= uEnd; u++ )   // slots below pad stay empty, the sums rotate by one slot per step
   {
     const Pel8     b  = *reinterpret_cast<const Pel8 *>( pr );
-    const unsigned b0 = b.v[0] ^ j.bias, b1 = b.v[1] ^ j.bias, b2 = b.v[2] ^ j.bias, b3 = b.v[3] ^ j.bias;
+    const unsigned b0 = bx<SGN>( b.v[0], j.bias ), b1 = bx<SGN>( b.v[1], j.bias ), b2 = bx<SGN>( b.v[2], j.bias ), b3 = bx<SGN>( b.v[3], j.bias );
     pr += dr;
 #pragma unroll
     for( int sl = 0; sl < NS; sl++ )
@@ -876,10 +876,14 @@ __global__ __launch_bounds__( 256 ) void tz_raster_cols_kernel( vtmhip_pic_param
       const bool live = pi < pairs;
       const int  pc = min( pi, pairs - 1 );             // lanes beyond the last pair repeat it (their sums are never stored)
       const int  k = pc / nx, col = pc - k * nx, myX = r.left + 5 * col;
-      if( rowsMax > 7 ) raster_task<13>( j, r, nx, ny, col, live, myX, k, rho, p, chunk, rowStep, sTot );
-      else if( rowsMax > 4 ) raster_task<7>( j, r, nx, ny, col, live, myX, k, rho, p, chunk, rowStep, sTot );
-      else if( rowsMax > 2 ) raster_task<4>( j, r, nx, ny, col, live, myX, k, rho, p, chunk, rowStep, sTot );
-      else raster_task<2>( j, r, nx, ny, col, live, myX, k, rho, p, chunk, rowStep, sTot );
+      // unsigned samples (every uni search): the instantiation without the sign-bias XOR of the reference segments (4 of 60 vector instructions per step)
+#define RASTER_DISPATCH( SGN )                                                                                  \
+      if( rowsMax > 7 ) raster_task<13, SGN>( j, r, nx, ny, col, live, myX, k, rho, p, chunk, rowStep, sTot );         \
+      else if( rowsMax > 4 ) raster_task<7, SGN>( j, r, nx, ny, col, live, myX, k, rho, p, chunk, rowStep, sTot );     \
+      else if( rowsMax > 2 ) raster_task<4, SGN>( j, r, nx, ny, col, live, myX, k, rho, p, chunk, rowStep, sTot );     \
+      else raster_task<2, SGN>( j, r, nx, ny, col, live, myX, k, rho, p, chunk, rowStep, sTot );
+      if( j.bias ) { RASTER_DISPATCH( true ) } else { RASTER_DISPATCH( false ) }
+#undef RASTER_DISPATCH
     }
     __syncthreads();
     if( parts > 1 )
