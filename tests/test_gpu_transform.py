@@ -403,3 +403,39 @@ def test_mixed_tu_batch_is_bucketed_by_shape(ctx):
     got = [(int(r.sse), int(r.sumAbs), int(r.absSum)) for r in res]
     bad = [k for k in range(n) if got[k] != exp[k]]
     assert not bad, [(jobs[k].width, jobs[k].height, jobs[k].typeHor, got[k], exp[k]) for k in bad[:6]]
+
+
+def test_mts_select_batch_matches_oracle(ctx):
+    """vtmhip_mts_select_batch_dev (the pre-selection of TrQuant::transformNxN( trModes, maxCand ) for every TU of a level, from the sum |coef| of its candidates)
+    vs vo_mts_select (pinned against the real member in tests/test_oracle_vs_ref.py): candidate lists with and without the transform-skip entry, every TU
+    shape class of the threshold table, maxCand 0 .. 4, costs that tie with the threshold."""
+    from vtm_amd.lib import TuResult
+    L = ol.oracle()
+    rng = np.random.default_rng(4711)
+    for it in range(24):
+        w, h = int(rng.choice([4, 8, 16, 32])), int(rng.choice([4, 8, 16, 32]))
+        modes = [0] + ([1] if it % 3 else []) + [2, 3, 4, 5][:int(rng.integers(0, 5))]
+        max_cand = int(rng.integers(0, 5))
+        ntu, nc = 700, len(modes)
+        base = rng.integers(0, 200000, ntu)
+        sums = np.zeros((nc, ntu), np.int32)
+        for c in range(nc):
+            f = rng.choice([0.5, 0.9, 1.0, 1.2, 1.3, 1.4, 1.5, 2.0], ntu)
+            sums[c] = (base * f).astype(np.int32) if c else base
+            if modes[c] == 1:
+                sums[c] = (sums[c] * rng.choice([0.25, 1.0, 4.0])).astype(np.int32)     # sum |residual| of the transform-skip candidate: another scale
+        res = np.zeros(nc * ntu, np.dtype(TuResult))
+        res["sumAbs"] = sums.reshape(-1)
+        d_res = ctx.to_device(res.view(np.uint8))
+        d_test = ctx.alloc(nc * ntu)
+        ctx.mts_select_batch(d_res.ptr, ntu, modes, w, h, 10, max_cand, d_test.ptr)
+        got = d_test.to_host(np.uint8).reshape(nc, ntu)
+        marr = np.array(modes, np.uint8)
+        pruned = 0
+        for t in range(0, ntu, 7):
+            col = np.ascontiguousarray(sums[:, t])
+            exp = np.zeros(nc, np.uint8)
+            L.vo_mts_select(ol.P(col), ol.P(marr), nc, w, h, 10, 15, max_cand, ol.P(exp))
+            assert list(got[:, t]) == list(exp), (w, h, modes, max_cand, list(col), list(got[:, t]), list(exp))
+            pruned += int(nc - exp.sum())
+        assert nc == 1 or pruned > 0
