@@ -122,6 +122,21 @@ def test_smvd_other_bit_depths(ctx, bd):
             assert full[k] == me_util.smvd_search_oracle(scene, j, L), ("whole block", bd, size, k, j)
 
 
+def test_smvd_bcw_weight_minus2(ctx):
+    """BCW weight -2 makes the search target -4 org + 5 predA: differences to predB beyond the 4095 the packed 16-bit Hadamard levels can take (10-bit samples:
+    up to 6138) -- the tile kernel switches to two packed levels + 32-bit ones.  Hard scene, every tile-kernel shape, unclipped and clipped targets."""
+    L = ol.oracle()
+    scene = me_util.SmvdScene(416, 240, hard=True)
+    for size in ((8, 8), (16, 8), (8, 16), (16, 16), (32, 32), (64, 32), (64, 64), (128, 128)):
+        jobs = me_util.random_smvd_jobs(scene, 90, seed=9000 + size[0] * 5 + size[1], sizes=[size])
+        for k, j in enumerate(jobs):
+            j["bcw"], j["satd"], j["clip"] = -2, 1, int(k % 5 == 0)
+        got, full = device_member_results(ctx, scene, jobs, size)
+        for k, j in enumerate(jobs):
+            assert got[k] == me_util.smvd_member_results(scene, j, L, "vo_"), ("members", size, k, j)
+            assert full[k] == me_util.smvd_search_oracle(scene, j, L), ("whole block", size, k, j)
+
+
 def test_smvd_matches_golden_from_reference(ctx):
     z = np.load(os.path.join(G, "smvd.npz"))
     scene = me_util.SmvdScene(416, 240)

@@ -400,13 +400,60 @@ __device__ __forceinline__ void pred_tile( const int16_t *__restrict__ ref, int 
   }
 }
 
+// The packed Hadamard of had.hpp runs three butterfly levels in 16 bits: |difference| <= 4095.  The BCW weight -2 makes the target -4 org + 5 pred (up to 5115
+// for 10-bit samples) and the difference to predB up to 6138: two packed levels (x4 fits 16 bits), the third vertical one and the horizontal ones in 32 bits.
+__device__ __forceinline__ void rows_unpack( const v2s r[4], int m[8] )
+{
+#pragma unroll
+  for( int k = 0; k < 4; k++ ) { m[2 * k] = r[k].x; m[2 * k + 1] = r[k].y; }
+}
+template<bool PAIR>
+__device__ __forceinline__ unsigned satd8_wide( v2s D[8][4] )
+{
+#pragma unroll
+  for( int len = 1; len < 4; len <<= 1 )
+#pragma unroll
+    for( int i = 0; i < 8; i += len << 1 )
+#pragma unroll
+      for( int jj = i; jj < i + len; jj++ )
+#pragma unroll
+        for( int k = 0; k < 4; k++ )
+        {
+          const v2s a = D[jj][k], b = D[jj + len][k];
+          D[jj][k]       = a + b;
+          D[jj + len][k] = a - b;
+        }
+  int t = 0, dc = 0;
+#pragma unroll
+  for( int y = 0; y < 4; y++ )
+  {
+    int m0[8], m1[8], a[8], b[8];
+    rows_unpack( D[y], m0 );
+    rows_unpack( D[y + 4], m1 );
+#pragma unroll
+    for( int x = 0; x < 8; x++ ) { a[x] = m0[x] + m1[x]; b[x] = m0[x] - m1[x]; }
+    wht1d_inl8( a );
+    wht1d_inl8( b );
+    if( y == 0 ) dc = PAIR ? abs( a[0] + dpp_swap1( a[0] ) ) : abs( a[0] );
+#pragma unroll
+    for( int x = 0; x < 8; x++ )
+    {
+      const int ua = abs( a[x] ), ub = abs( b[x] );
+      t += PAIR ? max( ua, dpp_swap1( ua ) ) + max( ub, dpp_swap1( ub ) ) : ua + ub;
+    }
+  }
+  if( PAIR ) return satd_pair_norm( t << 1, dc );
+  t = t - dc + ( dc >> 2 );
+  return ( unsigned ) ( ( t + 2 ) >> 2 );
+}
+
 struct TileJob   // what a lane needs of its PU for the evaluation (workgroup- / group-uniform)
 {
   const int16_t *org, *refA, *refB;   // PU origins (MV 0,0)
   int orgStride, strideA, strideB;
   int horMin, horMax, verMin, verMax;
   int w0, w1;                         // BCW form of removeHighFreq (w0 == 0: the default 2 * org - pred)
-  bool clip, alt, satd;
+  bool clip, alt, satd, wide;         // wide: differences beyond the packed Hadamard's range (BCW weight -2)
   TileFir f;
 };
 
@@ -438,7 +485,7 @@ __device__ __forceinline__ unsigned tile_eval( const TileJob &t, int tx, int ty,
     {
       v2s b;
       __builtin_memcpy( &b, &w[k], 4 );
-      D[y][k] = D[y][k] - b;     // |pattern - predB| <= 2 * 1023 + 1023 (clipped or not: the BCW forms stay below 4095 for 10-bit samples too)
+      D[y][k] = D[y][k] - b;     // |pattern - predB| <= 2 * 1023 + 1023; BCW weights 3, 5, 10 stay below that, -2 reaches 6138 (t.wide)
     }
   } );
   if( !t.satd )
@@ -450,6 +497,7 @@ __device__ __forceinline__ unsigned tile_eval( const TileJob &t, int tx, int ty,
       for( int k = 0; k < 4; k++ ) s += abs( ( int ) D[y][k].x ) + abs( ( int ) D[y][k].y );
     return ( unsigned ) s;
   }
+  if( t.wide ) return satd8_wide<PAIR>( D );
   return PAIR ? satd8_pair_packed( D ) : satd8_packed( D );
 }
 
@@ -485,7 +533,7 @@ __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_
   const int bcw = j.bcwWeightTar ? j.bcwWeightTar : 4;
   const int normalizer = bcw != 4 ? ( ( 1 << 16 ) + ( bcw > 0 ? ( bcw >> 1 ) : -( bcw >> 1 ) ) ) / bcw : 0;
   t.w0 = normalizer * 8; t.w1 = ( 8 - bcw ) * normalizer;
-  t.clip = j.clipBiPred != 0; t.alt = j.imv == 3; t.satd = j.useSatd != 0;
+  t.clip = j.clipBiPred != 0; t.alt = j.imv == 3; t.satd = j.useSatd != 0; t.wide = bcw < 0 && !t.clip;
   {
     const int bd = pic.bitDepth, headRoom = max( 2, 14 - bd );
     t.f.shH = 6 - headRoom; t.f.offH = -( 8192 << t.f.shH ); t.f.shV = 6 + headRoom; t.f.offV = ( 1 << ( t.f.shV - 1 ) ) + ( 8192 << 6 ); t.f.cmax = ( 1 << bd ) - 1;
