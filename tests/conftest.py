@@ -10,6 +10,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 
 def pytest_configure(config):
+    # VTM_TEST_SEED_OFFSET=N: every np.random.default_rng( seed ) of the tests draws from seed + N instead -- a soak over other job sets / sample data with the same
+    # test code (the expected values come from the oracle inside each test; tests bound to golden files or to counts of a particular draw are left out by -k)
+    off = int(os.environ.get("VTM_TEST_SEED_OFFSET", "0"))
+    if off:
+        import numpy as np
+        orig = np.random.default_rng
+        np.random.default_rng = lambda seed=None, _o=orig: _o(seed if seed is None or not isinstance(seed, (int, np.integer)) else int(seed) + off)
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "ref: needs oracle/_ref/libvtmref.so (the real reference, built in the dev container)")
 

@@ -165,10 +165,10 @@ def test_motion_compensation_fused_matches_oracle(ctx):
     pos = 0
     for k in range(n):
         w, h = int(rng.choice([4, 8, 16, 32, 64, 128])), int(rng.choice([4, 8, 16, 32, 64, 128]))
-        x, y = int(rng.integers(0, (W - w) // 4 + 1)) * 4, int(rng.integers(0, (H - h) // 4 + 1)) * 4
         chroma, mode, epi, alt = int(k % 3 == 1), int(k % 4 if k % 4 < 3 else 2), int(k % 3), int(k % 7 == 0)
         if w == 4 and h == 4 and not chroma:
             w = 8
+        x, y = int(rng.integers(0, (W - w) // 4 + 1)) * 4, int(rng.integers(0, (H - h) // 4 + 1)) * 4      # (drawn after the size is final: the block stays inside the picture)
         cw, ch, cx, cy = (w // 2, h // 2, x // 2, y // 2) if chroma else (w, h, x, y)
         st, o0 = (us, uo) if chroma else (ys, yo)
         mv = [[int(rng.integers(-20 * 16, 20 * 16)), int(rng.integers(-20 * 16, 20 * 16))] for _ in range(2)]
