@@ -2,7 +2,8 @@
 """bench.py -- hot-path throughput on MI355X.
 
 One STEP = one pass of the hot path over ONE 3840x2160 10-bit inter picture at the operating point of encoder_randomaccess_vtm.cfg
-(synthetic YUV, SURVEY.md 8d generator; B slice, 2 + 2 reference pictures at dPOC -2 -4 / +2 +4 -> ASR search range 96, FEN, QP 32), as the
+(synthetic YUV, SURVEY.md 8d generator; B slice, 2 + 2 reference pictures at dPOC -2 -4 / +2 +4 -> ASR search range 96, FEN, QP 32; SMVD, Affine and
+TransformSkip ON as in the cfg (cfg/encoder_randomaccess_vtm.cfg:71,120,142) -- `--lite` switches the three off: the round-2 default), as the
 level-order form of InterSearch::predInterSearch + xEstimateInterResidualQT over the quadtree of square PUs 128..8 (vtm_amd/pipeline.py):
   amvp     xEstimateMvPredAMVP (template cost of the AMVP candidates) per (PU, list, refIdx)
   uni_me   xMotionEstimation per (PU, list, refIdx): xTZSearch (SAD, FEN sub-sampling) + xPatternSearchFracDIF (SATD) + rate re-weighting,
@@ -10,7 +11,9 @@ level-order form of InterSearch::predInterSearch + xEstimateInterResidualQT over
   bi_me    the list with the larger cost refined for every refIdx against the other list's prediction (MC -> 2*org - pred, +-4 xPatternSearch,
            fractional search), xCheckBestMVP, uni / bi decision
   mc       chosen prediction (uni, or two 14-bit predictions + addAvg) and the residual
-  tu       per TU (<= 64x64) and transform candidate (DCT2 + 4 MTS pairs up to 32x32): xT, Quant::quant, dequant, xIT, SSE
+  smvd     the symmetric-MVD block of predInterSearch per PU (between the bi refinement and the decision)
+  affine   xAffineMotionEstimation (4-parameter, uni) per (PU >= 16x16, list, refIdx)
+  tu       per TU (<= 64x64) and transform candidate (DCT2, transform skip, 4 MTS pairs up to 32x32): xT, Quant::quant, dequant, xIT, SSE
 Inputs (original picture, border-extended reference planes, job tables) are resident in HBM before the timed region.
 
 --gpus N: the CTUs of the ONE picture are sharded over the N ranks (raster-scan CTU ranges: whole CTU rows plus one row cut at a CTU, so that
@@ -33,9 +36,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SIMDS, CLOCK_HZ = 1024, 2.4e9          # 256 CUs x 4 SIMDs, peak shader clock (MI355X_MICROARCH.md)
+GUIDE_CYCLES = 2.0                     # MI355X_MICROARCH.md: one wave64 VALU instruction per 2 cycles per SIMD (>= 2 waves) -- the machine's full-rate issue peak
+MIX_CLOCK_HZ = 2.3e9                   # the clock the issue micro-benchmark actually held on mixed streams (implied_MHz 2 280 .. 2 360, profiles/r02_valu_issue.jsonl)
 SALU_CYCLES = 4.03   # measured: cycles per scalar instruction per SIMD (profiles/r02_valu_issue.jsonl, s_add_u32, 1 .. 8 waves)
 KERNELS = ("tz_search_kernel", "tz_raster_cols_kernel", "frac_search_sq_kernel", "full_search_sq_kernel", "full_search_kernel", "motion_comp_kernel", "tu_chain_uni_kernel",
-           "dist_uniform_kernel", "tu_ts_kernel", "bdof_kernel", "tu_chain_lane_kernel", "affine_me_kernel", "smvd_kernel")
+           "dist_uniform_kernel", "tu_ts_kernel", "bdof_kernel", "tu_chain_lane_kernel", "affine_me_kernel", "smvd_tile_kernel", "smvd_kernel")
 
 
 def parse():
@@ -49,6 +54,10 @@ def parse():
                     "ldp: P slices, 4 list-0 pictures, SearchRange 64 (encoder_lowdelay_P_vtm.cfg)")
     ap.add_argument("--refs", type=int, default=2, help="ra: active reference pictures per list (1 = the round-1 operating point)")
     ap.add_argument("--qp", type=int, default=32)
+    ap.add_argument("--lite", action="store_true", help="the lighter tool set of rounds 1-2: no SMVD block, no affine stage, no transform-skip candidate (each can be added back "
+                    "with --smvd / --affine / --transform-skip).  Default: all three ON, as encoder_randomaccess_vtm.cfg has them (SMVD:1 Affine:1 TransformSkip:1)")
+    ap.add_argument("--dpoc", type=str, default="", help="ra: |dPOC| of the reference pictures of EACH list, nearest first, e.g. 8,16 = the top layers of the RA GOP "
+                    "(ASR search ranges 192 / 384); default 2,4,.. (--refs of them: search range 96)")
     ap.add_argument("--transform-skip", action="store_true", help="add the MTS_SKIP candidate to the TU chains")
     ap.add_argument("--shard", choices=["ctu", "row"], default="ctu", help="--gpus N: raster-scan CTU ranges (balanced) or whole CTU rows")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample (rank 0, N=1)")
@@ -62,7 +71,25 @@ def parse():
                     "9.83 vs 9.89 ms on one GPU, 2.08 vs 2.09 ms for a rank's share of an 8-GPU run: the step is bound by its dependent chain of kernels, not by launches")
     ap.add_argument("--inflight", type=int, default=1, help="pictures in flight: step k + 1 starts on a second stream set while step k's tail still runs (each has its own tables)")
     ap.add_argument("--serial", action="store_true", help="one stream, no overlap of the levels' chains: clean per-kernel times for profiling")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if not a.lite:
+        a.smvd, a.affine, a.transform_skip = True, True, True
+    a.dpoc_list = [int(x) for x in a.dpoc.split(",") if x] if a.dpoc else [2 * (k + 1) for k in range(a.refs)]
+    assert a.dpoc_list == sorted(a.dpoc_list) and len(set(a.dpoc_list)) == len(a.dpoc_list) and 1 <= len(a.dpoc_list) <= 4 and a.dpoc_list[0] >= 1
+    return a
+
+
+def workload_key(a, world):
+    """what the PMC instruction counters of a run depend on: the argument vector that shapes the work + the kernel sources.  The committed counters
+    (profiles/pmc_insts_per_launch.json, written from a run of THIS script) carry the key of their run; a roofline fraction is only formed when it matches."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(os.path.join(ROOT, "vtm_amd", "csrc"))):
+        h.update(open(os.path.join(ROOT, "vtm_amd", "csrc", f), "rb").read())
+    args = dict(width=a.width, height=a.height, config=a.config, dpoc=a.dpoc_list if a.config == "ra" else None, qp=a.qp, ts=bool(a.transform_skip), smvd=bool(a.smvd and a.config == "ra"),
+                affine=bool(a.affine), partition=a.partition, luma_only=bool(a.luma_only), shard=a.shard if world > 1 else None, world=world,
+                sim=int(os.environ.get("VTM_BENCH_SIMULATE_WORLD", "0")))
+    return {"args": args, "kernel_src_sha1": h.hexdigest()}
 
 
 def cpu_baseline(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, budget_s, pocs=None, chroma=None, affine=False, low_delay=False, smvd=None):
@@ -155,8 +182,8 @@ def main():
 
     # ---- synthetic picture set and reference lists ------------------------------------------------------------------------------
     if a.config == "ra":
-        cur_poc = 2 * a.refs
-        pocs = ([cur_poc - 2 * (k + 1) for k in range(a.refs)], [cur_poc + 2 * (k + 1) for k in range(a.refs)])
+        cur_poc = max(a.dpoc_list)
+        pocs = ([cur_poc - d for d in a.dpoc_list], [cur_poc + d for d in a.dpoc_list])
         sr = tuple([pipeline.asr_search_range(p - cur_poc) for p in l] for l in pocs)   # Clip3(96, 384, (384 |dPOC| + 8) / 16), EncSlice.cpp:1127
     else:
         cur_poc = 4
@@ -215,12 +242,27 @@ def main():
                        sizes=fme_sizes, affine=a.affine, low_delay=a.config == "ldp", smvd=smvd)
 
     # N > 1: the planes of the picture reconstructed last go from rank 0 to every GPU inside every step (RCCL broadcast over xGMI; bytes view: int16 is
-    # not a collective dtype), double-buffered: the planes of step k + 1 travel while step k computes; the ranks' result records go back to rank 0
-    # (gather), also asynchronously.  The timed region ends only after the last transfer of either kind has landed.
+    # not a collective dtype).  Every rank keeps ONE resident DPB; the new picture lands in a slot the running step does not reference (a ring of two slots: the
+    # newest picture's own slot and a spare one behind the DPB), so the planes of step k + 1 travel while step k computes and every other picture of the DPB
+    # stays where it is on every rank.  One table set per slot (the newest picture's offsets differ); the ranks' result records go back to rank 0 (gather),
+    # also asynchronously.  The timed region ends only after the last transfer of either kind has landed.
     from vtm_amd.exchange import PlaneExchange, ResultGather
-    xchg = PlaneExchange([dpb, dpb.clone()], src=0, window=tuple(newest)) if use_dist else None    # one broadcast per reconstructed picture
-    res_t = fme.result_tensors()
-    gath = ResultGather(sum(t.numel() for t in res_t), dev, dst=0) if use_dist else None
+    xchg, gath, fme_slot, res_slot = None, None, [fme], None
+    if use_dist:
+        spare = int(dpb.numel())
+        dpb = torch.cat([dpb, dpb[newest[0]:newest[0] + newest[1]]])          # slot 1 of the ring starts as a copy of the newest picture
+        shift = spare - newest[0]
+        in_new = lambda off: newest[0] <= off < newest[0] + newest[1]          # noqa: E731
+        refs_b = tuple([(o + shift if in_new(o) else o, st) for (o, st) in l] for l in refs)
+        ch_b = None
+        if ch_dev is not None:
+            ch_b = dict(ch_dev, refs=tuple([tuple(c + shift if in_new(c) else c for c in e) for e in l] for l in refs_c))
+        fme_slot.append(FrameHotPath(ctx, torch, dev, W, H, W, refs_b, sr, motion_lambda=lam, qp=qp, ctu_filter=ctu_filter, transform_skip=a.transform_skip, pocs=poc_arg,
+                                     chroma=ch_b, sizes=fme_sizes, affine=a.affine, low_delay=a.config == "ldp", smvd=smvd))
+        xchg = PlaneExchange(dpb, [(newest[0], newest[1]), (spare, newest[1])], src=0)    # one broadcast per reconstructed picture
+        xchg.sync_all()                                                                     # set-up: every rank starts from rank 0's pictures
+        res_slot = [f.result_tensors() for f in fme_slot]
+        gath = ResultGather(sum(t.numel() for t in res_slot[0]), dev, dst=0)
 
     # --inflight 2: a second set of tables and streams; consecutive steps alternate between the two, so the latency-bound head of picture k + 1
     # (the 128x128 level's searches) runs under the tail of picture k.  Every picture is still computed completely inside the timed region.
@@ -233,12 +275,12 @@ def main():
     use_graph = a.graph == "on" and not a.serial
     graphs = {}
 
-    def run_picture(dpb_ptr):
-        """one picture on the current stream: eager launches, or the replay of the graph captured for this reference buffer"""
+    def run_picture(f, dpb_ptr):
+        """one picture on the current stream: eager launches, or the replay of the graph captured for this table set"""
         if not use_graph:
-            fme.run(cur.data_ptr(), dpb_ptr)
+            f.run(cur.data_ptr(), dpb_ptr)
             return
-        g = graphs.get(dpb_ptr)
+        g = graphs.get(id(f))
         if g is None:
             outer = torch.cuda.current_stream()
             if "stream" not in graphs:
@@ -247,23 +289,23 @@ def main():
             cap.wait_stream(outer)
             with torch.cuda.stream(cap):   # one eager pass on the capture stream first: the library sizes its per-stream workspaces outside the capture
                 ctx.set_stream(cap.cuda_stream)
-                fme.run(cur.data_ptr(), dpb_ptr)
+                f.run(cur.data_ptr(), dpb_ptr)
             cap.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=cap):      # the side streams of FrameHotPath.run join the capture through its fork / join events
                 ctx.set_stream(cap.cuda_stream)
-                fme.run(cur.data_ptr(), dpb_ptr)
+                f.run(cur.data_ptr(), dpb_ptr)
             ctx.set_stream(outer.cuda_stream)
-            graphs[dpb_ptr] = g
+            graphs[id(f)] = g
         g.replay()
 
     def step():
         if xchg is not None:
-            planes = xchg.next()
-            run_picture(planes.data_ptr())
-            gath.submit(res_t)
+            slot = xchg.next()
+            run_picture(fme_slot[slot], dpb.data_ptr())
+            gath.submit(res_slot[slot])
         elif len(fmes) == 1:
-            run_picture(dpb.data_ptr())
+            run_picture(fme, dpb.data_ptr())
         else:
             k = turn[0] % len(fmes)
             turn[0] += 1
@@ -347,35 +389,41 @@ def main():
         mix, pmc_i, pmc_b = load_json("isa_mix.json") or {}, load_json("pmc_insts_per_launch.json") or {}, load_json("pmc_hbm_traffic_per_launch_KB.json") or {}
         dom = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
 
+        wkey = workload_key(a, world)
+        pmc_meta = pmc_i.get("_meta")
+        counters_match = pmc_meta is not None and pmc_meta == wkey      # the committed counters were collected from THIS command on THESE kernel sources
+
         def issue_roofline(name, ms, launches, in_step=True):
             # in_step: the kernel runs inside the picture step -> counters summed over its launches of one step; otherwise (the SATD micro-benchmark) ONE launch
             cpi = next((v["cycles_per_valu_inst"] for k, v in mix.items() if isinstance(v, dict) and k.startswith(name)), None)
             lps = (lambda v: v.get("launches_per_step", 1)) if in_step else (lambda v: 1)
-            insts = sum(v.get("SQ_INSTS_VALU", 0) * lps(v) for k, v in pmc_i.items() if k.startswith(name)) or None
-            salu = sum(v.get("SQ_INSTS_SALU", 0) * lps(v) for k, v in pmc_i.items() if k.startswith(name)) or None
-            traffic = sum((2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 * lps(v) for k, v in pmc_b.items() if k.startswith(name)) or None
+            ok = counters_match or (not in_step and pmc_meta is not None and pmc_meta.get("kernel_src_sha1") == wkey["kernel_src_sha1"] and (W, H) == (3840, 2160) and world == 1)
+            sel = [v for k, v in pmc_i.items() if k.startswith(name) and isinstance(v, dict)] if ok else []
+            insts = sum(v.get("SQ_INSTS_VALU", 0) * lps(v) for v in sel) or None
+            salu = sum(v.get("SQ_INSTS_SALU", 0) * lps(v) for v in sel) or None
+            traffic = (sum((2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 * lps(v) for k, v in pmc_b.items() if k.startswith(name) and isinstance(v, dict)) or None) if ok else None
             r = {"bound": "valu_issue", "kernel": name, "unit": "G wave-instructions/s", "ms_per_step": ms, "launches_per_step": launches,
-                 "ms_per_launch": ms / max(1, launches), "insts": insts, "cycles_per_inst": cpi, "traffic": (traffic / launches) if traffic else None}
-            if cpi:
-                r["peak"] = SIMDS * CLOCK_HZ / cpi / 1e9
-            if insts and cpi and world == 1 and (W, H) == (3840, 2160):
+                 "ms_per_launch": ms / max(1, launches), "insts": insts, "traffic": (traffic / launches) if traffic else None,
+                 "peak": SIMDS * CLOCK_HZ / GUIDE_CYCLES / 1e9, "achieved": None, "frac": None, "counters_match_this_run": bool(ok)}
+            if insts:
                 r["achieved"] = insts / (ms * 1e-3) / 1e9
                 r["frac"] = r["achieved"] / r["peak"]
-            else:
-                r["achieved"], r["frac"] = None, None
-            if salu and world == 1 and (W, H) == (3840, 2160):
+                if cpi:      # the same achieved rate against what this kernel's instruction MIX can issue at the clock the micro-benchmark held
+                    r["mixed_issue"] = {"cycles_per_inst": cpi, "clock_GHz": MIX_CLOCK_HZ / 1e9, "peak": SIMDS * MIX_CLOCK_HZ / cpi / 1e9,
+                                        "frac": r["achieved"] / (SIMDS * MIX_CLOCK_HZ / cpi / 1e9)}
+            if salu:
                 # the scalar port of a SIMD issues one instruction per 4.03 cycles whatever the number of waves, beside the vector port (s_add_u32 rows and the
                 # vector + scalar pair row of profiles/r02_valu_issue.jsonl): a kernel is bounded by the busier of the two
                 r["salu_insts"] = salu
-                r["salu_frac"] = salu * SALU_CYCLES / (SIMDS * CLOCK_HZ * ms * 1e-3)
+                r["salu_frac"] = salu * SALU_CYCLES / (SIMDS * MIX_CLOCK_HZ * ms * 1e-3)
             if traffic:
                 r["hbm_GBps"] = traffic / (ms * 1e-3) / 1e9
                 r["hbm_frac"] = r["hbm_GBps"] / 8000.0
-            r["note"] = ("insts = SQ_INSTS_VALU per step (committed rocprofv3 --pmc pass of this command, profiles/); cycles_per_inst = the measured gfx950 issue cost of a "
-                         "MIXED wave64 instruction stream at this kernel's static share of half-rate opcodes (pure full-rate streams issue at 2.1 cycles, any stream with "
-                         ">= 12 % packed-16 / sad / dot / min-max / mul / cmp opcodes at 3.5 .. 4.0: the imix rows of profiles/r02_valu_issue.jsonl; profiles/isa_mix.json); "
-                         "peak = 1024 SIMDs x 2.4 GHz / cycles_per_inst; time measured live with HIP events on the launch stream; "
-                         "traffic = HBM-side bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE)")
+            r["note"] = ("insts = SQ_INSTS_VALU per step from the committed rocprofv3 --pmc pass (profiles/pmc_insts_per_launch.json); used only when that pass ran this command on these "
+                         "kernel sources (its _meta key), else achieved / frac are null.  peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md: "
+                         "the machine's full-rate issue peak).  mixed_issue: the same rate against the measured issue cost of this kernel's static mix of half-rate opcodes "
+                         "(packed-16 / sad / dot / perm / min-max / mul / cmp: 3.5 .. 4.0 cycles, profiles/r02_valu_issue.jsonl x profiles/isa_mix.json) at the 2.3 GHz that "
+                         "benchmark held.  Kernel time measured live with HIP events on the launch stream; traffic = HBM-side bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE)")
             return r
 
         out = {
@@ -401,7 +449,7 @@ def main():
                        "parallelism": ("1 GPU" if world == 1 else "one picture, CTUs sharded over %d GPUs (%s): bands %s; the planes of the newest reference picture (Y, Cb, Cr) broadcast from rank 0 and the results gathered to rank 0 every step"
                                        % (world, "raster-scan CTU ranges" if a.shard == "ctu" else "whole CTU rows", [b[1] - b[0] for b in bands]))},
             "satd_gblocks_per_s": float(satd_g.item()),
-            "stages_ms": stage_acc, "kernels": kern,
+            "stages_ms": stage_acc, "kernels": kern, "workload_key": wkey,
         }
         if dom:
             out["roofline"] = issue_roofline(dom, kern[dom]["ms_per_step"], kern[dom]["launches_per_step"])

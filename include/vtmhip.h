@@ -168,6 +168,10 @@ int vtmhip_mts_select2( const int32_t *sumAbs, const uint8_t *mtsIdx, int numCan
 
 /* ================================================================================================================
  * (2) BATCHED DEVICE CALLS -- device pointers, asynchronous on the context's stream
+ *     One exception to "asynchronous": a MIXED-shape batch (no uniform promise) of >= 64 jobs to vtmhip_xMotionEstimation_batch_dev or >= 256 jobs to
+ *     vtmhip_tu_chain_batch_dev is bucketed by block shape on the device, and the class counts (80 bytes) are read back with ONE
+ *     hipStreamSynchronize inside the call.  While the stream is being captured into a hipGraph the bucketing is skipped (the generic chain runs the
+ *     whole batch: same results); uniform batches never synchronise.
  * ============================================================================================================== */
 
 /* One distortion evaluation: org block at orgBase + orgOff, candidate block at curBase + curOff (offsets in samples). */

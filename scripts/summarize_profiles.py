@@ -90,6 +90,14 @@ def main():
                 e["valu_per_wave"] = e.get("SQ_INSTS_VALU", 0) / e["SQ_WAVES"]
                 e["salu_per_wave"] = e.get("SQ_INSTS_SALU", 0) / e["SQ_WAVES"]
             insts[k] = e
+        # the bench line of the PMC run itself names the command and the kernel sources the counters belong to: bench.py forms a roofline fraction only
+        # from counters whose key equals its own (stale counters must not price another workload)
+        try:
+            meta = json.loads(open(os.path.join(go, f"pmc_{tag}_INSTS", "stdout.json")).read().strip().splitlines()[-1]).get("workload_key")
+        except Exception:
+            meta = None
+        if meta:
+            insts["_meta"] = meta
         for name in (f"{tag}_pmc_insts_per_launch.json", "pmc_insts_per_launch.json"):
             json.dump(insts, open(os.path.join(pr, name), "w"), indent=1)
     if pmc:

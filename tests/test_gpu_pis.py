@@ -301,3 +301,63 @@ def test_ctu_sharding_union_equals_unsharded():
                 seen[lv["size"]] += lv["npu"]
         assert seen == {s: lv["npu"] for s, lv in whole.items()}
     ctx.close()
+
+
+@pytest.mark.parametrize("use_ref", [False, True])
+def test_frame_hot_path_config5_tool_set(use_ref):
+    """BASELINE config 5's tool set as ONE operating point: QP 22, 2 + 2 reference pictures, affine uni stage + SMVD block + MTS candidates + the
+    transform-skip candidate + chroma + BDOF together -- every sampled PU of every level against the oracle chain and against the reference's own members."""
+    torch = pytest.importorskip("torch")
+    from vtm_amd.device import Context
+    if use_ref and not ol.have_ref():
+        pytest.skip("oracle/_ref/libvtmref.so not present")
+    W, H = 256, 128
+    dev = torch.device("cuda", 0)
+    pocs0, pocs1, cur, sym = [2, 0], [6, 8], 4, (0, 0)
+    cur_np, dpb_np, refs, sr, cur_d, dpb, ch_dev, ch_cpu = make_scene(torch, dev, W, H, pocs0, pocs1, cur, hard=False, chroma=True)
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    lam, qp, pocs = 8.0, 22, (cur, pocs0, pocs1)
+    hp = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr, motion_lambda=lam, qp=qp, sizes=(128, 64, 32, 16, 8), transform_skip=True, pocs=pocs, chroma=ch_dev, affine=True, smvd=sym)
+    hp.run(cur_d.data_ptr(), dpb.data_ptr())
+    torch.cuda.synchronize()
+    stats = {}
+    check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, ol.ref() if use_ref else None, per_level=10, min_checked=30, pocs=pocs, chroma=ch_cpu, stats=stats, affine=True, smvd=sym)
+    assert stats["aff"] >= 40 and stats["smvd"] >= 30 and stats["chroma_nz"] >= 5 and stats["mts_kept"] >= 20, stats
+    assert any(lv["cands"][:2] == [0, 1] for lv in hp.snapshot())      # the transform-skip candidate is in the TU chains
+    print("config5:", stats)
+    ctx.close()
+
+
+def test_kernel_timing_does_not_disturb_the_picture_loop():
+    """vtmhip_kernel_timing used to destroy the fork / join events of vtmhip_pis_run_picture and leave the stale handles in the pool.  Timing on,
+    timing off, then an overlapped picture: the tables must equal the serial run's, and the timed kernels must report launches."""
+    torch = pytest.importorskip("torch")
+    from vtm_amd.device import Context
+    W, H = 256, 128
+    dev = torch.device("cuda", 0)
+    cur_np, dpb_np, refs, sr, cur, dpb = make_scene(torch, dev, W, H, [0], [4], 2)
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    hp = FrameHotPath(ctx, torch, dev, W, H, W, refs, sr)
+
+    def tables():
+        torch.cuda.synchronize()
+        return [t.clone() for t in hp.result_tensors()] + [lvl["uni_rows"].clone() for lvl in hp.levels]
+    hp.run(cur.data_ptr(), dpb.data_ptr(), timing=True)          # one stream
+    serial = tables()
+    hp.run(cur.data_ptr(), dpb.data_ptr())                       # overlapped: fills the context's fork / join event pool
+    torch.cuda.synchronize()
+    for _ in range(2):
+        ctx.kernel_timing(True)
+        hp.run(cur.data_ptr(), dpb.data_ptr())
+        torch.cuda.synchronize()
+        ms, n = ctx.kernel_timing_read("tz_search_kernel")
+        assert n > 0 and ms > 0
+        ctx.kernel_timing(False)
+        for t in hp.result_tensors():
+            t.zero_()
+        hp.run(cur.data_ptr(), dpb.data_ptr())                   # overlapped again, on the (reused) events
+        for k, (x, y) in enumerate(zip(serial, tables())):
+            assert torch.equal(x, y), ("overlapped run after kernel_timing differs from the serial run", k)
+    ctx.close()

@@ -79,6 +79,14 @@ __global__ __launch_bounds__( 256 ) void bucket_gather_kernel( const R *__restri
   if( i < n ) out[perm[i]] = in[i];
 }
 
+// The bucketed path reads the class counts back (one hipStreamSynchronize): it is NOT usable while the stream is being captured into a hipGraph -- callers
+// check this and keep their non-bucketed chain then (same results, one generic launch chain for the whole batch).
+inline bool bucket_allowed( vtmhip_ctx *ctx )
+{
+  hipStreamCaptureStatus s = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing( ctx->stream, &s ) == hipSuccess && s == hipStreamCaptureStatusNone;
+}
+
 struct BucketPlan
 {
   int count[BUCKET_CLASSES], offset[BUCKET_CLASSES];

@@ -184,8 +184,7 @@ int vtmhip_timer_stop_ms( vtmhip_ctx *ctx, float *ms )
 static void clear_timed( vtmhip_ctx *ctx )
 {
   for( auto &t : ctx->timed ) { ( void ) hipEventDestroy( t.start ); ( void ) hipEventDestroy( t.stop ); }
-  for( hipEvent_t e : ctx->forkEvents ) ( void ) hipEventDestroy( e );
-  ctx->timed.clear();
+  ctx->timed.clear();   // the fork / join events of the picture loop (ctx->forkEvents) are reused by every picture and live until vtmhip_destroy
 }
 
 int vtmhip_kernel_timing( vtmhip_ctx *ctx, int enable )

@@ -320,7 +320,7 @@ extern "C" int vtmhip_xMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip
   VTMHIP_REQUIRE( ctx, pic && cfg && d_orgBase && d_refBase && d_jobs && d_results, "null pointer" );
   // mixed shapes, enough jobs to fill launches per class: bucket by shape (VTMHIP_MEST_BUCKET=0 keeps the one-wave-per-PU chain for the whole batch)
   static const bool bucket = !( getenv( "VTMHIP_MEST_BUCKET" ) && atoi( getenv( "VTMHIP_MEST_BUCKET" ) ) == 0 );
-  if( bucket && !cfg->uniformSquare && n >= 64 )
+  if( bucket && !cfg->uniformSquare && n >= 64 && bucket_allowed( ctx ) )   // (not under hipGraph capture: the bucketing synchronises the stream once)
     return mest_bucketed( ctx, pic, cfg, d_orgBase, d_refBase, d_otherPredBase, d_jobs, n, maxWidth, maxHeight, d_results );
   return mest_run( ctx, pic, cfg, d_orgBase, d_refBase, d_otherPredBase, d_jobs, n, maxWidth, maxHeight, d_results );
 }

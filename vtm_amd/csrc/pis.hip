@@ -367,6 +367,8 @@ int vtmhip_pis_stage( vtmhip_ctx *ctx, const vtmhip_pis_level *lvl, int stage )
   if( lvl->numPU == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, lvl->uniJobs && lvl->uniOut && lvl->uniRows && lvl->pus && lvl->predFinal && lvl->pos, "null pointer in the level" );
   VTMHIP_REQUIRE( ctx, !lvl->parentIdx || lvl->parentRows, "parentIdx without parentRows" );
+  VTMHIP_REQUIRE( ctx, !lvl->smvdJobs || ( lvl->symRefIdx[0] >= 0 && lvl->symRefIdx[0] < lvl->numRef[0] && lvl->symRefIdx[1] >= 0 && lvl->symRefIdx[1] < lvl->numRef[1] ),
+                  "symRefIdx outside the reference lists" );
   const int  rows = ( lvl->numRef[0] + lvl->numRef[1] ) * lvl->numPU;
   const dim3 perPU( ( lvl->numPU + 255 ) / 256 ), perRow( ( rows + 255 ) / 256 ), tpb( 256 );
   if( stage == 0 ) hipLaunchKernelGGL( pis_cands_kernel, perRow, tpb, 0, ctx->stream, *lvl );

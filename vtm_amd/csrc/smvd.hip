@@ -211,11 +211,16 @@ __device__ void check_best_mvp( const SmvdCtx &c, const AmvpLists &a, const int 
 
 template<int THREADS>
 __global__ __launch_bounds__( THREADS ) void smvd_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
-                                                         vtmhip_smvd_job *__restrict__ jobs, int n, int op )
+                                                         vtmhip_smvd_job *__restrict__ jobs, int n, int op, int maxWidth, int maxHeight )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sMem[];
   __shared__ unsigned long long sRed[4];
   vtmhip_smvd_job &j = jobs[xcd_order( blockIdx.x, n )];
+  if( j.width > maxWidth || j.height > maxHeight || j.width < 4 || j.height < 4 )   // the launch sized its LDS for maxWidth x maxHeight: a larger job is the caller's error
+  {
+    if( threadIdx.x == 0 ) j.cost = ~0ull;
+    return;
+  }
   SmvdCtx c;
   c.w = j.width; c.h = j.height;
   c.org = orgBase + j.orgOff; c.orgStride = j.orgStride; c.refBase = refBase;
@@ -801,9 +806,10 @@ int vtmhip_smvd_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const 
   VTMHIP_REQUIRE( ctx, d_orgBase && d_refBase && d_jobs, "null pointer" );
   // pattern + prediction B + the (h + 7) x w intermediates of the separable filter
   const size_t lds = ( 2 * ( size_t ) maxWidth * maxHeight + ( size_t ) maxWidth * ( maxHeight + 7 ) ) * sizeof( int16_t );
-  VTMHIP_TIME_KERNEL( ctx, "smvd_kernel" );
+  const bool tileForm = uniform && pic->bitDepth <= 10 && maxWidth >= 8 && maxHeight >= 8 && !getenv( "VTMHIP_SMVD_NO_TILE" );
+  VTMHIP_TIME_KERNEL( ctx, tileForm ? "smvd_tile_kernel" : "smvd_kernel" );
   bool tiled = true;
-  if( uniform && pic->bitDepth <= 10 && maxWidth >= 8 && maxHeight >= 8 && !getenv( "VTMHIP_SMVD_NO_TILE" ) )
+  if( tileForm )
   {
     // group form up to four tiles; above: one PU per workgroup, waves by the number of (candidate, tile) items of a pass (8 candidates x tiles)
     switch( maxWidth * 256 + maxHeight )
@@ -832,12 +838,12 @@ int vtmhip_smvd_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const 
   if( tiled ) {}
   else if( maxWidth * maxHeight <= 1024 )
   {
-    hipLaunchKernelGGL( smvd_kernel<64>, dim3( n ), dim3( 64 ), lds, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, op );
+    hipLaunchKernelGGL( smvd_kernel<64>, dim3( n ), dim3( 64 ), lds, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, op, maxWidth, maxHeight );
   }
   else
   {
     if( lds > 48 * 1024 ) VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( smvd_kernel<256> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
-    hipLaunchKernelGGL( smvd_kernel<256>, dim3( n ), dim3( 256 ), lds, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, op );
+    hipLaunchKernelGGL( smvd_kernel<256>, dim3( n ), dim3( 256 ), lds, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, op, maxWidth, maxHeight );
   }
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;

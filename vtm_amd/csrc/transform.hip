@@ -1245,7 +1245,7 @@ int vtmhip_tu_chain_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiBase, const
   // a mixed batch with enough TUs: bucket by shape on the device (bucket.hpp), the register-blocked kernel per {8,16,32,64} x {8,16,32,64} class, the
   // generic kernel for the rest (4-sample sides, transform skip).  VTMHIP_TU_BUCKET=0 keeps the generic kernel for the whole batch.
   static const bool bucket = !( getenv( "VTMHIP_TU_BUCKET" ) && atoi( getenv( "VTMHIP_TU_BUCKET" ) ) == 0 );
-  if( bucket && !uniformSize && n >= 256 && maxWidth >= 8 && maxHeight >= 8 )
+  if( bucket && !uniformSize && n >= 256 && maxWidth >= 8 && maxHeight >= 8 && bucket_allowed( ctx ) )
   {
     BucketPlan plan;
     st = bucket_begin<vtmhip_tu_job, vtmhip_tu_result>( ctx, d_jobs, n, TuClassOf(), plan );

@@ -1,45 +1,58 @@
 """Reference-plane exchange between the GPUs of a node: rank `src` owns the reconstructed picture, every rank needs it before
-its searches start.  Double-buffered asynchronous broadcast on torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs; "gloo" in the
-CPU tests): while step k computes on buffer k % 2, the planes of step k + 1 travel into the other buffer.
+its searches start.  Every rank keeps ONE resident decoded-picture buffer; a newly reconstructed picture travels (asynchronous broadcast on
+torch.distributed: backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests) into a SLOT of that buffer which the running step does
+not reference, exactly as an encoder writes a reconstruction into a free DPB slot.  All other slots stay where they are on every rank, so a step
+always sees the same set of pictures on every rank -- also when the DPB really changes from step to step.
 
 Hazards and how they are excluded:
-  * the planes of step k must have landed before step k computes      -> `Work.wait()` of that broadcast (a stream wait on GPUs)
-  * buffer (k + 1) % 2 was read by step k - 1                         -> the next broadcast is issued after step k - 1's launches are queued;
-                                                                         an asynchronous collective starts behind the work already on the
-                                                                         caller's stream (with gloo the calls are host-ordered anyway)
+  * the picture of step k must have landed before step k computes    -> `Work.wait()` of that broadcast (a stream wait on GPUs)
+  * the slot receiving the picture of step k + 1 must not be read by step k -> the caller passes a ring of >= 2 slots and step k's tables address
+                                                                         slot k % len(slots) as the newest picture (bench.py keeps one table set per slot)
+  * slot (k + 1) % len(slots) was read by step k + 1 - len(slots)     -> the broadcast is issued after that step's launches are queued; an asynchronous
+                                                                         collective starts behind the work already on the caller's stream (gloo: host order)
+A step may therefore reference the pictures of the last len(slots) - 1 steps out of the ring (plus anything outside the ring, which never changes after
+sync_all()); a longer reference history needs a longer ring.
 """
 import torch
 import torch.distributed as dist
 
 
 class PlaneExchange:
-    def __init__(self, buffers, src=0, produce=None, window=None):
-        """buffers: two equally sized tensors (the collective moves their bytes: int16 is not a collective dtype);
-        produce(buf, k): optional, called on rank `src` before the planes of step k are sent (the encoder writing its reconstruction);
-        window: (first element, number of elements) of the buffers that a step sends -- the planes of the picture reconstructed last; the older
-        pictures of the decoded-picture buffer arrived with earlier steps and stay resident (None: the whole buffer)."""
-        assert len(buffers) == 2 and buffers[0].numel() == buffers[1].numel()
-        self.bufs, self.src, self.produce = buffers, src, produce
-        self.window = window
+    def __init__(self, dpb, slots, src=0, produce=None):
+        """dpb: the rank's resident decoded-picture buffer (one tensor; the collective moves bytes: int16 is not a collective dtype);
+        slots: ring of (first element, number of elements) windows of `dpb`, all of one size -- the picture of step k lands in slots[k % len(slots)];
+        produce(dpb, slot, k): optional, called on rank `src` before the picture of step k is sent (the encoder writing its reconstruction there)."""
+        assert len(slots) >= 2 and len({int(s[1]) for s in slots}) == 1, "a ring of at least two equally sized slots"
+        flat = dpb.reshape(-1)
+        for a, n in slots:
+            assert 0 <= a and a + n <= flat.numel()
+        for i, (a, n) in enumerate(slots):
+            for b, m in slots[i + 1:]:
+                assert a + n <= b or b + m <= a, "slots overlap"
+        self.dpb, self.slots, self.src, self.produce = dpb, [(int(a), int(n)) for a, n in slots], src, produce
         self.n, self.pending = 0, None
 
-    def _send(self, i, k):
+    def sync_all(self):
+        """One blocking broadcast of the WHOLE buffer (setup, outside any timed region): every rank starts from rank `src`'s pictures."""
+        dist.broadcast(self.dpb.reshape(-1).view(torch.uint8), src=self.src)
+
+    def _send(self, k):
+        i = k % len(self.slots)
         if self.produce is not None and dist.get_rank() == self.src:
-            self.produce(self.bufs[i], k)
-        flat = self.bufs[i].reshape(-1)
-        if self.window is not None:
-            flat = flat[self.window[0]:self.window[0] + self.window[1]]
-        return dist.broadcast(flat.view(torch.uint8), src=self.src, async_op=True)
+            self.produce(self.dpb, i, k)
+        a, n = self.slots[i]
+        return dist.broadcast(self.dpb.reshape(-1)[a:a + n].view(torch.uint8), src=self.src, async_op=True)
 
     def next(self):
-        """Returns the buffer holding the planes of this step (ready for use on the current stream) and starts the next step's transfer."""
-        i = self.n & 1
+        """Returns the index of the slot that holds the picture of this step (landed; usable on the current stream) and starts the next step's transfer
+        into the following slot of the ring."""
         if self.pending is None:
-            self.pending = self._send(i, self.n)
+            self.pending = self._send(self.n)
         self.pending.wait()
-        self.pending = self._send(1 - i, self.n + 1)
+        i = self.n % len(self.slots)
+        self.pending = self._send(self.n + 1)
         self.n += 1
-        return self.bufs[i]
+        return i
 
     def drain(self):
         """Waits for the transfer that is still in flight (call before stopping a clock or destroying the process group)."""
