@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define VTMHIP_ABI_VERSION 4
+#define VTMHIP_ABI_VERSION 5
 
 enum
 {
@@ -328,8 +328,11 @@ typedef struct
   double   motionLambda;
   int32_t  numExtraStart;           /* m_uniMvListSize */
   int32_t  extraStart[15][2];       /* uniMvs[list][refIdx] of the m_uniMvList entries, newest first, duplicates allowed */
-  int32_t  pad;
+  uint32_t flags;                   /* VTMHIP_MEJ_* */
 } vtmhip_me_job;
+/* uni job: the block-vector cache of the mode control holds an integer vector for this (block, list, refIdx) (CacheBlkInfoCtrl::getMv, InterSearch.cpp:3360-3368):
+ * rcMv = mvHor / mvVer (that vector in internal precision) and xTZSearch runs with bFastSettings (:3434-3441) instead of starting at rcMvPred */
+#define VTMHIP_MEJ_CACHED_INT_MV 1u
 
 typedef struct
 {
@@ -701,7 +704,7 @@ int vtmhip_xPredAffineBlk_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *p
 #define VTMHIP_SMVD_CHECK_MVP 2
 #define VTMHIP_SMVD_SEARCH 3
 #define VTMHIP_SMVD_UNIFORM 0x100  /* or-ed into op: every job is exactly maxWidth x maxHeight (8x8 .. 16x16, bitDepth <= 10: the lane-per-tile kernel) */
-#define VTMHIP_SMVD_MAX_START 16
+#define VTMHIP_SMVD_MAX_START 18   /* cMvHevcTemp, cMvTemp, cMvBi + the 15 entries of m_uniMvList */
 typedef struct
 {
   int64_t  orgOff;                 /* origBuf.Y() inside d_orgBase */
@@ -726,6 +729,13 @@ typedef struct
   int32_t  predSym[2][2];          /* cMvPredSym */
   int32_t  mvpIdxSym[2];
   uint64_t cost;
+  /* op VTMHIP_SMVD_SEARCH only: the state of the block at the points where the reference's code sits between two member calls (a host that replays predInterSearch's
+   * own glue over device results -- INTEGRATION.md section 3.1 -- serves the members from these):
+   *   [0] after the predictor-pair loop (:2675-2691): cost = the winning pair's xGetSymmetricCost (no rate), idx = the pair
+   *   [1] after the start-vector loop (:2744-2763):   mv = cCurMvField.mv, idx = mvpIdxSym, cost = costStart
+   *   [2] after xSymmetricMotionEstimation (:2770):   mv = cCurMvField.mv, cost = symCost as the member returns it (without mvpCost)
+   *   [3] after the final predictor check (:2774-2777): idx = mvpIdxSym, cost = symCost (with mvpCost, before the mode bits) */
+  struct { uint64_t cost; int32_t mv[2]; int32_t idx[2]; } trace[4];
 } vtmhip_smvd_job;
 int vtmhip_smvd_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, vtmhip_smvd_job *d_jobs, int n,
                            int maxWidth, int maxHeight, int op );
@@ -787,6 +797,17 @@ typedef struct
   int32_t  smvdMode;               /* symMode (:2789): 1 when the symmetric-MVD pair replaced the bi vectors, else 0 */
 } vtmhip_pis_pu;
 
+/* per-PU state of the CU recursion that predInterSearch reads */
+typedef struct
+{
+  uint8_t  noSmvd;                 /* !trySmvd (:2301) */
+  uint8_t  uniMvInsert;            /* insertUniMvCands runs between the uni loop and the bi stage (:2451-2459: cu.imv == 0, default BCW): the bi searches and the SMVD
+                                      start list see the PU's own uni vectors in m_uniMvList */
+  uint8_t  uniMvSelfIsNew;         /* with uniMvInsert: the block has no entry yet -- its vectors become the newest entry (of 15 entries the oldest drops out) */
+  uint8_t  pad;
+  int32_t  uniMvSelfPos;           /* with uniMvInsert && !uniMvSelfIsNew: position (newest first) of the block's entry, overwritten in place (InterSearch.h:247-275) */
+} vtmhip_pis_pu_in;
+
 typedef struct
 {
   int32_t  numPU;
@@ -824,7 +845,17 @@ typedef struct
    * vtmhip_smvd_job per PU, searched list = list 0 */
   vtmhip_smvd_job      *smvdJobs;  /* [numPU] or NULL; filled by stage 3, searched by vtmhip_smvd_batch_dev( VTMHIP_SMVD_SEARCH ), merged by stage 5 */
   int32_t  symRefIdx[2];           /* slice.getSymRefIdx( list ) */
+  /* ---- the caller's CU context instead of the level-order stand-ins (vtmhip_predInterSearch_batch_dev: one call = predInterSearch of n real PUs) ---- */
+  int32_t  candsGiven;             /* != 0: uniJobs already hold the real AMVP lists (PU::fillMvpCand: amvpCand, numAmvpCand 1 or 2), mvpIdxBits, the m_uniMvList start vectors
+                                      (numExtraStart / extraStart), imv, flags and the entry bits (mbBits + reference-index bits): stage 0 is skipped */
+  int32_t  biRestricted;           /* PU::isBipredRestriction (8x4 / 4x8): no bi stage, no SMVD */
+  int32_t  list1FromList0[VTMHIP_MAX_REF]; /* FastMEForGenBLowDelay (:2391-2404): v > 0: list-1 picture refIdx is list-0 picture v - 1 (slice.getList1IdxToList0Idx() + 1); its
+                                      rows take the list-0 vector and a re-priced cost instead of a search (their jobs are not searched).  0: search (also when the option is off) */
+  const vtmhip_pis_pu_in *puIn;    /* [numPU] or NULL */
+  vtmhip_pis_row       *biRows;    /* [numRef[refined list] * numPU] or NULL: the bi rows after xCheckBestMVP (cMvTemp, cMvPredBi, aaiMvpIdxBi, bits, cost) */
+  uint64_t             *distBiP;   /* [(numRef[0] + numRef[1]) * numPU] or NULL: *puiDistBiP of xEstimateMvPredAMVP per row */
 } vtmhip_pis_level;
+
 
 /* stage 0: AMVP candidates and entry bits of the uni rows (before vtmhip_xEstimateMvPredAMVP_batch_dev)
  * stage 1: after the uni searches: xCheckBestMVP per row, best reference per list; P slices: interDir and predFinal
@@ -881,6 +912,20 @@ typedef struct
 
 int vtmhip_pis_run_picture( vtmhip_ctx *ctx, const vtmhip_pis_level_run *levels, int numLevels, const vtmhip_pis_buffers *buf, void *mainStream,
                             void *const *sideStreams, int numSide );
+
+/* ---- InterSearch::predInterSearch (InterSearch.cpp:2245-2893, the translational part incl. the SMVD block) of n real PUs of one slice and one block shape in ONE call ------
+ * The batched hook a CU-level integration uses (oracle/ref_shim_enc.cpp drives it from inside the real encoder): L->pis.candsGiven = 1, the
+ * uni rows carry the PUs' real AMVP lists, m_uniMvList start vectors, cu.imv (0 .. 3: fractional or AMVR integer refinement) and block-vector cache hits.  Runs on the
+ * context's stream, no host synchronisation:
+ *   xEstimateMvPredAMVP per row -> xMotionEstimation per searched row -> xCheckBestMVP, list-1 rows copied from list 0 (FastMEForGenBLowDelay), best reference per list
+ *   -> B slices without bi-prediction restriction: the other list's prediction, the bi refinement of the costlier list (one iteration: FASTINTERSEARCH_MODE1 / 2), xCheckBestMVP
+ *   -> the SMVD block (L->pis.smvdJobs) -> uni / bi decision.
+ * Results: L->pis.uniRows, L->uniOut (every row's vector / bits / cost BEFORE xCheckBestMVP: what m_uniMotions and the block-vector cache store), L->pis.biRows, L->biOut,
+ * L->pis.smvdJobs (with the trace), L->pis.pus.  No prediction, no residual coding (predFinal may be NULL); buf->orgBi: numPU * width * height samples of scratch.
+ * Not covered (the caller keeps the reference path): BCW weights, weighted prediction, MvdL1Zero, four bi iterations (FEN off), MCTS, composite references, IBC. */
+int vtmhip_predInterSearch_batch_dev( vtmhip_ctx *ctx, const vtmhip_pis_level_run *L, const vtmhip_pis_buffers *buf );
+/* 1 when a batch of width x height blocks may promise cfg.uniformSquare (the tiled kernels know the shape) */
+int vtmhip_is_uniform_shape( int width, int height );
 
 #ifdef __cplusplus
 }

@@ -373,7 +373,7 @@ __device__ void solve_equal( double eq[7][7], int order, double *para )   // sol
 
 __global__ __launch_bounds__( 256 ) void affine_me_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
                                                           const int16_t *__restrict__ otherBase, const vtmhip_affine_me_job *__restrict__ jobs,
-                                                          vtmhip_affine_me_out *__restrict__ results, int maxSamples )
+                                                          vtmhip_affine_me_out *__restrict__ results )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sMem[];
   __shared__ unsigned long long sRed[4];
@@ -381,11 +381,6 @@ __global__ __launch_bounds__( 256 ) void affine_me_kernel( vtmhip_pic_params pic
   __shared__ Mv3                sMv;      // the model under test (written by thread 0)
   __shared__ int                sCtl;     // loop control of the gradient iterations: 0 continue, 1 stop
   const vtmhip_affine_me_job &j = jobs[blockIdx.x];
-  if( j.width * j.height > maxSamples || j.width < 16 || j.height < 16 )   // the launch sized its LDS for maxWidth x maxHeight: a larger job is the caller's error
-  {
-    if( threadIdx.x == 0 ) { vtmhip_affine_me_out o = {}; o.cost = ~0ull; results[blockIdx.x] = o; }
-    return;
-  }
   const int w = j.width, h = j.height, six = j.sixParam, mvNum = six ? 3 : 2, np = six ? 6 : 4;
   int16_t  *sPat = sMem, *sPred = sMem + w * h;
   AffCtx c;
@@ -617,11 +612,10 @@ __global__ __launch_bounds__( 256 ) void affine_me_kernel( vtmhip_pic_params pic
 }
 
 __global__ __launch_bounds__( 256 ) void affine_pred_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ refBase, int16_t *__restrict__ dstBase,
-                                                            const vtmhip_affine_me_job *__restrict__ jobs, int maxSamples )
+                                                            const vtmhip_affine_me_job *__restrict__ jobs )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sMem[];
   const vtmhip_affine_me_job &j = jobs[blockIdx.x];
-  if( j.width * j.height > maxSamples ) return;
   AffCtx c;
   c.ref = refBase + j.refOff; c.refStride = j.refStride; c.w = j.width; c.h = j.height; c.bd = pic.bitDepth; c.six = j.sixParam; c.interDir = j.interDir; c.imv = j.imv;
   c.horMax = ( pic.picW + 8 - j.puX - 1 ) << 4; c.horMin = ( -pic.ctuSize - 8 - j.puX + 1 ) << 4;
@@ -663,7 +657,7 @@ int vtmhip_xAffineMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_
   // one wave per job up to 32x32 (64 4x4 sub-blocks: a lane each), four waves above: the model iterations are a serial chain per job, so small blocks gain
   // from four times as many jobs in flight, not from idle lanes
   const int threads = maxWidth * maxHeight <= 1024 ? 64 : 256;
-  hipLaunchKernelGGL( affine_me_kernel, dim3( n ), dim3( threads ), lds, ctx->stream, *pic, d_orgBase, d_refBase, d_otherPredBase ? d_otherPredBase : d_orgBase, d_jobs, d_results, maxWidth * maxHeight );
+  hipLaunchKernelGGL( affine_me_kernel, dim3( n ), dim3( threads ), lds, ctx->stream, *pic, d_orgBase, d_refBase, d_otherPredBase ? d_otherPredBase : d_orgBase, d_jobs, d_results );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }
@@ -677,7 +671,7 @@ int vtmhip_xPredAffineBlk_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *p
   if( n == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, d_refBase && d_dstBase && d_jobs, "null pointer" );
   const size_t lds = ( size_t ) maxWidth * maxHeight * sizeof( int16_t );
-  hipLaunchKernelGGL( affine_pred_kernel, dim3( n ), dim3( 256 ), lds, ctx->stream, *pic, d_refBase, d_dstBase, d_jobs, maxWidth * maxHeight );
+  hipLaunchKernelGGL( affine_pred_kernel, dim3( n ), dim3( 256 ), lds, ctx->stream, *pic, d_refBase, d_dstBase, d_jobs );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }

@@ -42,6 +42,7 @@ int vtmhip_struct_size( int which )
   case 29: return ( int ) sizeof( vtmhip_pis_level_run );
   case 30: return ( int ) sizeof( vtmhip_pis_buffers );
   case 31: return ( int ) sizeof( vtmhip_smvd_job );
+  case 32: return ( int ) sizeof( vtmhip_pis_pu_in );
   default: return -1;
   }
 }

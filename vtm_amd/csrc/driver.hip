@@ -27,21 +27,34 @@ struct EventPool   // the context's fork / join events: created on demand (on th
 
 int run_uni( vtmhip_ctx *ctx, const vtmhip_pis_level_run &L, const vtmhip_pis_buffers &b )
 {
-  const int rows = ( L.pis.numRef[0] + L.pis.numRef[1] ) * L.pis.numPU;
-  int st = vtmhip_pis_stage( ctx, &L.pis, 0 );
+  const int n = L.pis.numPU, rows = ( L.pis.numRef[0] + L.pis.numRef[1] ) * n;
+  int st = L.pis.candsGiven ? VTMHIP_OK : vtmhip_pis_stage( ctx, &L.pis, 0 );   // candsGiven: the rows carry the caller's real AMVP lists
   if( st ) return st;
-  st = vtmhip_xEstimateMvPredAMVP_batch_dev( ctx, &L.pic, b.org, b.dpb, L.pis.uniJobs, rows, L.width, L.height, 1, 1, nullptr );   // (the index bits of the chosen predictor join the row's bits)
+  st = vtmhip_xEstimateMvPredAMVP_batch_dev( ctx, &L.pic, b.org, b.dpb, L.pis.uniJobs, rows, L.width, L.height, 1, 1, L.pis.distBiP );   // (the index bits of the chosen predictor join the row's bits)
   if( st ) return st;
-  st = vtmhip_xMotionEstimation_batch_dev( ctx, &L.pic, &L.cfgUni, b.org, b.dpb, nullptr, L.pis.uniJobs, rows, L.width, L.height, L.uniOut );
-  if( st ) return st;
+  // the searched rows: all of list 0, and the list-1 pictures that are not list-0 pictures too (FastMEForGenBLowDelay copies those in stage 1); rows of one
+  // (list, refIdx) are contiguous, so the searched rows are a few contiguous runs
+  int first = 0, count = L.pis.numRef[0];
+  for( int r = 0; r <= L.pis.numRef[1]; r++ )
+  {
+    const bool searched = r < L.pis.numRef[1] && !( L.pis.list1FromList0[r] > 0 && L.pis.list1FromList0[r] <= L.pis.numRef[0] );
+    if( searched ) { if( !count ) first = L.pis.numRef[0] + r; count++; continue; }
+    if( count )
+    {
+      st = vtmhip_xMotionEstimation_batch_dev( ctx, &L.pic, &L.cfgUni, b.org, b.dpb, nullptr, L.pis.uniJobs + ( size_t ) first * n, count * n, L.width, L.height, L.uniOut + ( size_t ) first * n );
+      if( st ) return st;
+    }
+    count = 0;
+  }
   return vtmhip_pis_stage( ctx, &L.pis, 1 );
 }
 
-int run_rest( vtmhip_ctx *ctx, const vtmhip_pis_level_run &L, const vtmhip_pis_buffers &b )
+// B slices: the other list's prediction, the bi refinement, (the SMVD block,) the uni / bi decision
+int run_bi( vtmhip_ctx *ctx, const vtmhip_pis_level_run &L, const vtmhip_pis_buffers &b )
 {
   const int n = L.pis.numPU, w = L.width, h = L.height;
   int       st = VTMHIP_OK;
-  if( L.pis.numRef[1] > 0 )
+  if( L.pis.numRef[1] > 0 && !L.pis.biRestricted )
   {
     st = vtmhip_pis_stage( ctx, &L.pis, 2 );
     if( st ) return st;
@@ -53,12 +66,21 @@ int run_rest( vtmhip_ctx *ctx, const vtmhip_pis_level_run &L, const vtmhip_pis_b
     if( st ) return st;
     if( L.pis.smvdJobs )   // the SMVD block sits between the bi refinement and the uni / bi decision
     {
-      st = vtmhip_smvd_batch_dev( ctx, &L.pic, b.org, b.dpb, L.pis.smvdJobs, n, w, h, VTMHIP_SMVD_SEARCH | VTMHIP_SMVD_UNIFORM );
+      st = vtmhip_smvd_batch_dev( ctx, &L.pic, b.org, b.dpb, L.pis.smvdJobs, n, w, h, VTMHIP_SMVD_SEARCH | ( L.cfgUni.uniformSquare ? VTMHIP_SMVD_UNIFORM : 0 ) );
       if( st ) return st;
       st = vtmhip_pis_stage( ctx, &L.pis, 5 );
       if( st ) return st;
     }
   }
+  return st;
+}
+
+int run_rest( vtmhip_ctx *ctx, const vtmhip_pis_level_run &L, const vtmhip_pis_buffers &b )
+{
+  const int n = L.pis.numPU, w = L.width, h = L.height;
+  int       st = VTMHIP_OK;
+  st = run_bi( ctx, L, b );
+  if( st ) return st;
   st = vtmhip_motion_compensation_batch_dev( ctx, b.org, b.dpb, b.pred, b.resi, L.pis.predFinal, n, w, h );
   if( st ) return st;
   if( L.bdof )
@@ -99,6 +121,26 @@ int run_rest( vtmhip_ctx *ctx, const vtmhip_pis_level_run &L, const vtmhip_pis_b
 }
 
 }   // namespace
+
+extern "C" int vtmhip_is_uniform_shape( int w, int h )
+{
+  if( w == h ) return w == 8 || w == 16 || w == 32 || w == 64 || w == 128;
+  const int a = w > h ? w : h, b = w > h ? h : w;
+  return ( a == 16 && b == 8 ) || ( a == 32 && ( b == 8 || b == 16 ) ) || ( a == 64 && ( b == 16 || b == 32 ) );
+}
+
+extern "C" int vtmhip_predInterSearch_batch_dev( vtmhip_ctx *ctx, const vtmhip_pis_level_run *L, const vtmhip_pis_buffers *buf )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, L && buf && buf->org && buf->dpb, "level / buffers" );
+  VTMHIP_REQUIRE( ctx, L->pis.candsGiven, "vtmhip_predInterSearch_batch_dev takes the caller's AMVP lists (pis.candsGiven)" );
+  VTMHIP_REQUIRE( ctx, L->pis.numRef[1] == 0 || L->pis.biRestricted || ( buf->orgBi && L->pis.numRef[0] == L->pis.numRef[1] ), "B slices: orgBi scratch and equal list sizes" );
+  VTMHIP_REQUIRE( ctx, L->uniOut == L->pis.uniOut && ( L->pis.numRef[1] == 0 || L->pis.biRestricted || L->biOut == L->pis.biOut ), "uniOut / biOut of the run and of the level differ" );
+  if( L->pis.numPU == 0 ) return VTMHIP_OK;
+  int st = run_uni( ctx, *L, *buf );
+  if( st ) return st;
+  return run_bi( ctx, *L, *buf );
+}
 
 extern "C" int vtmhip_pis_run_picture( vtmhip_ctx *ctx, const vtmhip_pis_level_run *levels, int numLevels, const vtmhip_pis_buffers *buf, void *mainStream,
                                        void *const *sideStreams, int numSide )

@@ -134,9 +134,10 @@ __global__ __launch_bounds__( 256 ) void mest_prepare_kernel( vtmhip_pic_params 
     t.orgOff = slot; t.refOff = j.refOff; t.orgStride = sst; t.refStride = j.refStride;
     t.puX = j.puX; t.puY = j.puY; t.width = j.width; t.height = j.height; t.subShift = ( int16_t ) ss; t.imvShift = ( uint8_t ) is; t.signedSamples = 0;
     t.predHor = prec_down( j.mvPredHor, 2 ); t.predVer = prec_down( j.mvPredVer, 2 ); t.motionLambda = j.motionLambda;
-    t.mvHor = j.mvPredHor; t.mvVer = j.mvPredVer;                      // rcMv = rcMvPred (:3441)
+    const bool cached = ( j.flags & VTMHIP_MEJ_CACHED_INT_MV ) != 0;   // block-vector cache hit (:3360-3368): rcMv = the cached vector, xTZSearch with bFastSettings (:3434-3441)
+    t.mvHor = cached ? j.mvHor : j.mvPredHor; t.mvVer = cached ? j.mvVer : j.mvPredVer;   // else rcMv = rcMvPred (:3446)
     t.searchRange = j.searchRange;
-    t.extendedSettings = cfg.extendedSettings; t.fastSettings = 0; t.firstSearchStop = cfg.firstSearchStop; t.hasIntMv2Nx2NPred = 0;
+    t.extendedSettings = cfg.extendedSettings; t.fastSettings = cached; t.firstSearchStop = cfg.firstSearchStop; t.hasIntMv2Nx2NPred = 0;
     t.intMv2Nx2NPredHor = t.intMv2Nx2NPredVer = 0;
     t.numExtraStart = nex;
     for( int k = 0; k < nex; k++ ) { t.extraStart[k][0] = ex[k][0]; t.extraStart[k][1] = ex[k][1]; }

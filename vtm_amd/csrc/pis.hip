@@ -95,8 +95,36 @@ __global__ __launch_bounds__( 256 ) void pis_cands_kernel( vtmhip_pis_level L )
   j.bits = L.mbBits[list] + ref_idx_bits( L.numRef[list], ref );
 }
 
+// m_uniMvList as the bi stage and the SMVD block see it for row (list, refIdx) of a PU: the caller's list (extraStart of the uni row: the state BEFORE the uni loop) after
+// insertUniMvCands( pu.Y(), cMvTemp ) (InterSearch.cpp:2451-2459, InterSearch.h:247-275) -- the block's own uni vector (selfH, selfV) replaces its existing entry in place,
+// or becomes the newest entry (of 15 the oldest drops out).  Returns the number of entries written to out[][2], newest first.
+__device__ __forceinline__ int uni_mv_list_after_insert( const vtmhip_pis_level &L, int pu, const vtmhip_me_job &u, int selfH, int selfV, int out[15][2] )
+{
+  const int n0 = min( 15, max( 0, u.numExtraStart ) );
+  const vtmhip_pis_pu_in *pi = L.puIn ? &L.puIn[pu] : nullptr;
+  if( !pi || !pi->uniMvInsert )
+  {
+    for( int k = 0; k < n0; k++ ) { out[k][0] = u.extraStart[k][0]; out[k][1] = u.extraStart[k][1]; }
+    return n0;
+  }
+  if( pi->uniMvSelfIsNew )
+  {
+    const int n = min( 15, n0 + 1 );
+    out[0][0] = selfH; out[0][1] = selfV;
+    for( int k = 1; k < n; k++ ) { out[k][0] = u.extraStart[k - 1][0]; out[k][1] = u.extraStart[k - 1][1]; }
+    return n;
+  }
+  for( int k = 0; k < n0; k++ )
+  {
+    const bool self = k == pi->uniMvSelfPos;
+    out[k][0] = self ? selfH : u.extraStart[k][0]; out[k][1] = self ? selfV : u.extraStart[k][1];
+  }
+  return n0;
+}
+
 __device__ __forceinline__ void final_pred( const vtmhip_pis_level &L, int pu, const vtmhip_pis_pu &P )
 {
+  if( !L.predFinal ) return;      // vtmhip_predInterSearch_batch_dev: decisions only
   vtmhip_pred_job &pf = L.predFinal[pu];
   const bool bi = P.interDir == 3;
   const int  r0 = bi ? P.refIdxBi[0] : P.refIdx[0], r1 = bi ? P.refIdxBi[1] : P.refIdx[1];
@@ -138,14 +166,36 @@ __global__ __launch_bounds__( 256 ) void pis_uni_select_kernel( vtmhip_pis_level
     {
       const int            row = uni_row( L, list, ref, pu );
       const vtmhip_me_job &j   = L.uniJobs[row];
-      const vtmhip_me_out  o   = L.uniOut[row];
       vtmhip_pis_row r;
-      r.mvHor = o.mvHor; r.mvVer = o.mvVer; r.mvPredHor = o.mvPredHor; r.mvPredVer = o.mvPredVer; r.mvpIdx = o.mvpIdx; r.bits = o.bits; r.cost = o.cost;
+      const int from0 = list == 1 ? L.list1FromList0[ref] - 1 : -1;
+      if( from0 >= 0 && from0 < L.numRef[0] )
+      {
+        // FastMEForGenBLowDelay (:2391-2404): the same picture sits in list 0 -- its vector, and its cost with the rate part re-priced against this row's predictor
+        // (getBitsOfVectorWithPredictor at cost scale 0: the raw difference shifted by imvShift + MV_FRACTIONAL_BITS_DIFF)
+        const vtmhip_pis_row &r0 = L.uniRows[uni_row( L, 0, from0, pu )];      // written by this thread (after xCheckBestMVP: uiCostTempL0 / uiBitsTempL0 of :2423-2427)
+        const int sh = ( j.imv == 3 ? 1 : ( int ) j.imv << 1 ) + 2;
+        r.mvHor = r0.mvHor; r.mvVer = r0.mvVer; r.mvPredHor = j.mvPredHor; r.mvPredVer = j.mvPredVer; r.mvpIdx = j.mvpIdx;
+        r.bits = j.bits + eg_bits( ( r.mvHor - j.mvPredHor ) >> sh ) + eg_bits( ( r.mvVer - j.mvPredVer ) >> sh );
+        r.cost = r0.cost - rate( j.motionLambda, r0.bits ) + rate( j.motionLambda, r.bits );
+        vtmhip_me_out c;       // the row's "search result" for the caller (m_uniMotions stores vector and cost before xCheckBestMVP)
+        c.mvHor = r.mvHor; c.mvVer = r.mvVer; c.mvPredHor = r.mvPredHor; c.mvPredVer = r.mvPredVer; c.mvpIdx = r.mvpIdx; c.bits = r.bits; c.cost = r.cost;
+        c.intX = c.intY = 0; c.intDist = 0;
+        const_cast<vtmhip_me_out *>( L.uniOut )[row] = c;
+      }
+      else
+      {
+        const vtmhip_me_out o = L.uniOut[row];
+        r.mvHor = o.mvHor; r.mvVer = o.mvVer; r.mvPredHor = o.mvPredHor; r.mvPredVer = o.mvPredVer; r.mvpIdx = o.mvpIdx; r.bits = o.bits; r.cost = o.cost;
+      }
       check_best_mvp( j, r );
       L.uniRows[row] = r;
       if( r.cost < P.cost[list] ) { P.cost[list] = r.cost; P.bits[list] = r.bits; P.mv[list][0] = r.mvHor; P.mv[list][1] = r.mvVer; P.refIdx[list] = ref; }
     }
-  if( L.numRef[1] == 0 ) final_pred( L, pu, P );   // P slice: list 0 it is
+  if( L.numRef[1] == 0 || L.biRestricted )      // P slice: list 0 it is; 8x4 / 4x8 PUs of a B slice (PU::isBipredRestriction): the cheaper list (:2866-2885)
+  {
+    P.interDir = ( L.numRef[1] == 0 || P.cost[0] <= P.cost[1] ) ? 1 : 2;
+    final_pred( L, pu, P );
+  }
   L.pus[pu] = P;
 }
 
@@ -174,7 +224,11 @@ __global__ __launch_bounds__( 256 ) void pis_bi_jobs_kernel( vtmhip_pis_level L 
     b.amvpCand[0][0] = u.amvpCand[0][0]; b.amvpCand[0][1] = u.amvpCand[0][1]; b.amvpCand[1][0] = u.amvpCand[1][0]; b.amvpCand[1][1] = u.amvpCand[1][1];
     b.mvpIdxBits[0] = u.mvpIdxBits[0]; b.mvpIdxBits[1] = u.mvpIdxBits[1];
     b.bits = L.mbBits[2] + motOther + ref_idx_bits( L.numRef[rl], ref ) + u.mvpIdxBits[r.mvpIdx & 1] + ( L.smvdBit ? 1u : 0u );   // :2578-2593
-    b.searchRange = u.searchRange; b.motionLambda = u.motionLambda; b.numExtraStart = 0;
+    b.searchRange = u.searchRange; b.motionLambda = u.motionLambda; b.flags = 0;
+    int lst[15][2];
+    const int nl = uni_mv_list_after_insert( L, pu, u, r.mvHor, r.mvVer, lst );   // the start candidates of the bi search (:3397-3426)
+    b.numExtraStart = nl;
+    for( int k = 0; k < nl; k++ ) { b.extraStart[k][0] = lst[k][0]; b.extraStart[k][1] = lst[k][1]; }
   }
 }
 
@@ -193,6 +247,7 @@ __global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
     vtmhip_pis_row r;
     r.mvHor = o.mvHor; r.mvVer = o.mvVer; r.mvPredHor = o.mvPredHor; r.mvPredVer = o.mvPredVer; r.mvpIdx = o.mvpIdx; r.bits = o.bits; r.cost = o.cost;
     check_best_mvp( j, r );
+    if( L.biRows ) L.biRows[ref * L.numPU + pu] = r;
     if( r.cost < P.costBi ) { P.costBi = r.cost; P.bits[2] = r.bits; P.mvBi[rl][0] = r.mvHor; P.mvBi[rl][1] = r.mvVer; P.refIdxBi[rl] = ref; }
   }
   if( L.smvdJobs )
@@ -205,7 +260,7 @@ __global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
     vtmhip_smvd_job j;
     j.orgOff = u0.orgOff; j.refOff[0] = u0.refOff; j.refOff[1] = u1.refOff; j.orgStride = u0.orgStride; j.refStride[0] = u0.refStride; j.refStride[1] = u1.refStride;
     j.puX = u0.puX; j.puY = u0.puY; j.width = u0.width; j.height = u0.height;
-    j.imv = 0; j.useSatd = 1; j.clipBiPred = 0; j.bcwWeightTar = 4;
+    j.imv = u0.imv; j.useSatd = 1; j.clipBiPred = 0; j.bcwWeightTar = 4;
     j.numCand[0] = u0.numAmvpCand; j.numCand[1] = u1.numAmvpCand; j.skip = 0; j.pad_[0] = j.pad_[1] = j.pad_[2] = 0;
     for( int c = 0; c < 2; c++ )
     {
@@ -219,8 +274,16 @@ __global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
     else { j.starts[ns][0] = r0.mvHor; j.starts[ns][1] = r0.mvVer; }
     ns++;
     if( P.refIdxBi[0] == s0 ) { j.starts[ns][0] = P.mvBi[0][0]; j.starts[ns][1] = P.mvBi[0][1]; ns++; }
+    j.numFixed = ( uint8_t ) ns;
+    {
+      // then the m_uniMvList entries of (list 0, symmetric reference), newest first (:2736-2742; the search rounds them to the AMVR precision and stops at five distinct vectors)
+      int lst[15][2];
+      const int nl = uni_mv_list_after_insert( L, pu, u0, r0.mvHor, r0.mvVer, lst );
+      for( int k = 0; k < nl && ns < VTMHIP_SMVD_MAX_START; k++ ) { j.starts[ns][0] = lst[k][0]; j.starts[ns][1] = lst[k][1]; ns++; }
+    }
     for( int k = ns; k < VTMHIP_SMVD_MAX_START; k++ ) j.starts[k][0] = j.starts[k][1] = 0;
-    j.numStart = ( uint8_t ) ns; j.numFixed = ( uint8_t ) ns;
+    j.numStart = ( uint8_t ) ns;
+    for( int k = 0; k < 4; k++ ) { j.trace[k].cost = ~0ull; j.trace[k].mv[0] = j.trace[k].mv[1] = 0; j.trace[k].idx[0] = j.trace[k].idx[1] = 0; }
     j.mvCur[0] = j.mvCur[1] = j.mvTar[0] = j.mvTar[1] = 0;
     for( int l = 0; l < 2; l++ ) { j.predSym[l][0] = j.predSym[l][1] = 0; j.mvpIdxSym[l] = 0; }
     j.cost = ~0ull;
@@ -239,7 +302,8 @@ __global__ __launch_bounds__( 256 ) void pis_smvd_merge_kernel( vtmhip_pis_level
   if( pu >= L.numPU ) return;
   vtmhip_pis_pu          P = L.pus[pu];
   const vtmhip_smvd_job &j = L.smvdJobs[pu];
-  if( j.cost < P.costBi )   // :2787-2803
+  const bool tried = !( L.puIn && L.puIn[pu].noSmvd );      // trySmvd (:2301)
+  if( tried && j.cost < P.costBi )   // :2787-2803
   {
     P.costBi = j.cost; P.smvdMode = 1;
     P.mvBi[0][0] = j.mvCur[0]; P.mvBi[0][1] = j.mvCur[1]; P.refIdxBi[0] = L.symRefIdx[0];

@@ -261,6 +261,10 @@ __global__ __launch_bounds__( THREADS ) void smvd_kernel( vtmhip_pic_params pic,
       }
     for( int l = 0; l < 2; l++ ) { predSym[l][0] = a.cand[l][mvpIdxSym[l]][0]; predSym[l][1] = a.cand[l][mvpIdxSym[l]][1]; }
     mvCur[0] = predSym[0][0]; mvCur[1] = predSym[0][1]; mvTar[0] = predSym[1][0]; mvTar[1] = predSym[1][1];
+    auto snap = [&]( int k, unsigned long long cst ) {      // vtmhip_smvd_job::trace: the block's state between two member calls of the reference
+      if( threadIdx.x == 0 ) { j.trace[k].cost = cst; j.trace[k].mv[0] = mvCur[0]; j.trace[k].mv[1] = mvCur[1]; j.trace[k].idx[0] = mvpIdxSym[0]; j.trace[k].idx[1] = mvpIdxSym[1]; }
+    };
+    snap( 0, costStart );
     costStart += rate( c, mv_bits( c, mvCur, predSym[0] ) + c.idxBits[mvpIdxSym[0]] + c.idxBits[mvpIdxSym[1]] );
     // distinct start vectors (smmvdCandsGen :2709-2744), evaluated as they are collected: a later duplicate is skipped exactly as the list would have dropped it
     int seen[VTMHIP_SMVD_MAX_START][2], nc = 0;
@@ -294,10 +298,13 @@ __global__ __launch_bounds__( THREADS ) void smvd_kernel( vtmhip_pic_params pic,
     }
     const int                startX = mvCur[0], startY = mvCur[1];
     const unsigned long long mvpCost = rate( c, c.idxBits[mvpIdxSym[0]] + c.idxBits[mvpIdxSym[1]] );
+    snap( 1, costStart );
     cost = costStart - mvpCost;
     symmetric_me<THREADS>( c, predSym[0], predSym[1], mvCur, mvTar, cost );
+    snap( 2, cost );
     cost += mvpCost;
     if( startX != mvCur[0] || startY != mvCur[1] ) check_best_mvp<THREADS>( c, a, mvCur, true, predSym, mvpIdxSym, cost );
+    snap( 3, cost );
     cost += rate( c, j.modeBits );
     mvTar[0] = predSym[1][0] - mvCur[0] + predSym[0][0]; mvTar[1] = predSym[1][1] - mvCur[1] + predSym[0][1];
   }
@@ -605,8 +612,13 @@ __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_
     }
     return -1;
   };
+  const bool tracing = live && l == 0 && ( op & 0xff ) == VTMHIP_SMVD_SEARCH;
+  auto snap = [&]( int k, unsigned long long cst ) {      // vtmhip_smvd_job::trace: the block's state between two member calls of the reference
+    if( tracing ) { j.trace[k].cost = cst; j.trace[k].mv[0] = mvCur[0]; j.trace[k].mv[1] = mvCur[1]; j.trace[k].idx[0] = idxSym[0]; j.trace[k].idx[1] = idxSym[1]; }
+  };
   auto to_me = [&]()   // ME preparation (:2765-2770)
   {
+    snap( 1, cost );
     startX = mvCur[0]; startY = mvCur[1];
     mvpCost = rate( idx_bits( idxSym[0] ) + idx_bits( idxSym[1] ) );
     cost -= mvpCost;
@@ -614,6 +626,7 @@ __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_
   };
   auto finish = [&]()   // :2781-2786
   {
+    snap( 3, cost );
     cost += rate( j.modeBits );
     mvTar[0] = pred[1][0] - mvCur[0] + pred[0][0]; mvTar[1] = pred[1][1] - mvCur[1] + pred[0][1];
     phase = PH_DONE;
@@ -717,6 +730,7 @@ __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_
       idxSym[0] = bi; idxSym[1] = bk;
       pred[0][0] = cand( 0, bi, 0 ); pred[0][1] = cand( 0, bi, 1 ); pred[1][0] = cand( 1, bk, 0 ); pred[1][1] = cand( 1, bk, 1 );
       mvCur[0] = pred[0][0]; mvCur[1] = pred[0][1]; mvTar[0] = pred[1][0]; mvTar[1] = pred[1][1];
+      snap( 0, c );
       cost = c + rate( mvbits( mvCur[0], mvCur[1], pred[0][0], pred[0][1] ) + idx_bits( bi ) + idx_bits( bk ) );
       si = next_start( 0 );
       sj = si >= 0 ? next_start( si + 1 ) : -1;
@@ -757,6 +771,7 @@ __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_
       else if( op == VTMHIP_SMVD_ME ) phase = PH_DONE;
       else
       {
+        snap( 2, cost );
         cost += mvpCost;
         if( startX != mvCur[0] || startY != mvCur[1] ) phase = PH_FINAL; else finish();
       }

@@ -227,6 +227,13 @@ class Context:
         arr = (C.c_void_p * max(1, len(side_streams)))(*side_streams)
         self._check(self.L.vtmhip_pis_run_picture(self.h, levels, n_levels, C.byref(buffers), C.c_void_p(main_stream), arr, len(side_streams)))
 
+    def pred_inter_search_batch(self, level_run, buffers):
+        """InterSearch::predInterSearch (translational part + SMVD block) of the n real PUs of `level_run` (a PisLevelRun with pis.candsGiven = 1) in one call"""
+        self._check(self.L.vtmhip_predInterSearch_batch_dev(self.h, C.byref(level_run), C.byref(buffers)))
+
+    def is_uniform_shape(self, w, h):
+        return bool(self.L.vtmhip_is_uniform_shape(w, h))
+
     def affine_motion_estimation_batch(self, pic, d_org, d_ref, d_other, d_jobs, n, max_w, max_h, d_results):
         """InterSearch::xAffineMotionEstimation per AffineMeJob (one workgroup per job)"""
         self._check(self.L.vtmhip_xAffineMotionEstimation_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_other, d_jobs, n, max_w, max_h, d_results))

@@ -118,7 +118,10 @@ class MeJob(C.Structure):
                 ("numAmvpCand", C.c_uint8), ("mvPredHor", C.c_int32), ("mvPredVer", C.c_int32), ("mvHor", C.c_int32),
                 ("mvVer", C.c_int32), ("amvpCand", (C.c_int32 * 2) * 2), ("mvpIdxBits", C.c_uint32 * 2), ("bits", C.c_uint32),
                 ("searchRange", C.c_int32), ("motionLambda", C.c_double), ("numExtraStart", C.c_int32),
-                ("extraStart", (C.c_int32 * 2) * 15), ("pad", C.c_int32)]
+                ("extraStart", (C.c_int32 * 2) * 15), ("flags", C.c_uint32)]
+
+
+MEJ_CACHED_INT_MV = 1
 
 
 class MeOut(C.Structure):
@@ -171,13 +174,19 @@ class PisPu(C.Structure):
                 ("refIdxBi", C.c_int32 * 2), ("mvBi", (C.c_int32 * 2) * 2), ("refineList", C.c_int32), ("interDir", C.c_int32), ("smvdMode", C.c_int32)]
 
 
+class PisPuIn(C.Structure):
+    _fields_ = [("noSmvd", C.c_uint8), ("uniMvInsert", C.c_uint8), ("uniMvSelfIsNew", C.c_uint8), ("pad", C.c_uint8), ("uniMvSelfPos", C.c_int32)]
+
+
 class PisLevel(C.Structure):
     _fields_ = [("numPU", C.c_int32), ("numRef", C.c_int32 * 2), ("smvdBit", C.c_int32), ("mbBits", C.c_uint32 * 3), ("refStride", C.c_int32),
                 ("refPlaneOff", (C.c_int64 * MAX_REF) * 2), ("uniJobs", C.c_void_p), ("uniOut", C.c_void_p), ("uniRows", C.c_void_p), ("pus", C.c_void_p),
                 ("predOther", C.c_void_p), ("biJobs", C.c_void_p), ("biOut", C.c_void_p), ("predFinal", C.c_void_p), ("parentIdx", C.c_void_p),
                 ("parentRows", C.c_void_p), ("parentNumPU", C.c_int32), ("pad", C.c_int32), ("pos", C.c_void_p), ("bdofEnabled", C.c_int32), ("curPoc", C.c_int32),
                 ("refPoc", (C.c_int32 * MAX_REF) * 2), ("predFinalC", C.c_void_p), ("posC", C.c_void_p), ("refPlaneOffC", ((C.c_int64 * MAX_REF) * 2) * 2),
-                ("affJobs", C.c_void_p), ("affLowDelay", C.c_int32), ("affCheckLDC", C.c_int32), ("smvdJobs", C.c_void_p), ("symRefIdx", C.c_int32 * 2)]
+                ("affJobs", C.c_void_p), ("affLowDelay", C.c_int32), ("affCheckLDC", C.c_int32), ("smvdJobs", C.c_void_p), ("symRefIdx", C.c_int32 * 2),
+                ("candsGiven", C.c_int32), ("biRestricted", C.c_int32), ("list1FromList0", C.c_int32 * MAX_REF), ("puIn", C.c_void_p), ("biRows", C.c_void_p),
+                ("distBiP", C.c_void_p)]
 
 
 class PisLevelRun(C.Structure):
@@ -205,13 +214,17 @@ class AffineMeOut(C.Structure):
     _fields_ = [("mv", (C.c_int32 * 2) * 3), ("bits", C.c_uint32), ("iterations", C.c_int32), ("refinements", C.c_int32), ("pad", C.c_int32), ("cost", C.c_uint64)]
 
 
+class SmvdTrace(C.Structure):
+    _fields_ = [("cost", C.c_uint64), ("mv", C.c_int32 * 2), ("idx", C.c_int32 * 2)]
+
+
 class SmvdJob(C.Structure):
     _fields_ = [("orgOff", C.c_int64), ("refOff", C.c_int64 * 2), ("orgStride", C.c_int32), ("refStride", C.c_int32 * 2), ("puX", C.c_int16), ("puY", C.c_int16),
                 ("width", C.c_int16), ("height", C.c_int16), ("imv", C.c_uint8), ("useSatd", C.c_uint8), ("clipBiPred", C.c_uint8), ("bcwWeightTar", C.c_int8),
                 ("numCand", C.c_uint8 * 2), ("numStart", C.c_uint8), ("numFixed", C.c_uint8), ("skip", C.c_uint8), ("pad_", C.c_uint8 * 3),
                 ("cand", ((C.c_int32 * 2) * 2) * 2), ("mvpIdxBits", C.c_uint32 * 2), ("modeBits", C.c_uint32), ("motionLambda", C.c_double),
-                ("starts", (C.c_int32 * 2) * 16), ("mvCur", C.c_int32 * 2), ("mvTar", C.c_int32 * 2), ("predSym", (C.c_int32 * 2) * 2), ("mvpIdxSym", C.c_int32 * 2),
-                ("cost", C.c_uint64)]
+                ("starts", (C.c_int32 * 2) * 18), ("mvCur", C.c_int32 * 2), ("mvTar", C.c_int32 * 2), ("predSym", (C.c_int32 * 2) * 2), ("mvpIdxSym", C.c_int32 * 2),
+                ("cost", C.c_uint64), ("trace", SmvdTrace * 4)]
 
 
 class LfnstTuJob(C.Structure):
@@ -221,7 +234,7 @@ class LfnstTuJob(C.Structure):
 
 _STRUCTS = [DistJob, TzJob, MeResult, PicParams, IfJob, FracJob, FracResult, TrJob, QuantJob, FullJob, McJob, PelOpJob,
             TuJob, TuResult, AffineJob, MeCfg, MeJob, MeOut, PredJob, MaskedSadJob, GeoBlendJob, DmvrJob, LfnstJob,
-            PisRow, PisPu, PisLevel, AffineMeJob, AffineMeOut, LfnstTuJob, PisLevelRun, PisBuffers, SmvdJob]   # order of vtmhip_struct_size(which)
+            PisRow, PisPu, PisLevel, AffineMeJob, AffineMeOut, LfnstTuJob, PisLevelRun, PisBuffers, SmvdJob, PisPuIn]   # order of vtmhip_struct_size(which)
 
 # every symbol include/vtmhip.h declares (tests/test_abi.py checks the exports against the header text)
 _PROTOS = {
@@ -326,6 +339,8 @@ _PROTOS = {
                                                    C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vtmhip_pis_run_picture": (C.c_int, [C.c_void_p, C.POINTER(PisLevelRun), C.c_int, C.POINTER(PisBuffers), C.c_void_p, C.POINTER(C.c_void_p), C.c_int]),
     "vtmhip_pis_stage": (C.c_int, [C.c_void_p, C.POINTER(PisLevel), C.c_int]),
+    "vtmhip_predInterSearch_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PisLevelRun), C.POINTER(PisBuffers)]),
+    "vtmhip_is_uniform_shape": (C.c_int, [C.c_int, C.c_int]),
     "vtmhip_tz_search_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(PicParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_void_p]),
 }
