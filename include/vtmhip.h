@@ -73,6 +73,8 @@ const char *vtmhip_status_string( int status );
 /* device memory helpers for hosts without their own allocator (the C++ encoder); torch hosts pass data_ptr() */
 int vtmhip_dev_alloc( vtmhip_ctx *ctx, size_t bytes, void **devPtr );
 int vtmhip_dev_free( vtmhip_ctx *ctx, void *devPtr );
+int vtmhip_host_alloc( vtmhip_ctx *ctx, size_t bytes, void **hostPtr );         /* page-locked host memory: job / result slots a hook re-uses for every call (h2d / d2h from it do not stage) */
+int vtmhip_host_free( vtmhip_ctx *ctx, void *hostPtr );
 int vtmhip_h2d( vtmhip_ctx *ctx, void *dev, const void *host, size_t bytes );   /* asynchronous on the stream */
 int vtmhip_d2h( vtmhip_ctx *ctx, void *host, const void *dev, size_t bytes );   /* synchronises before returning */
 /* stream timing with HIP events (bench.py uses this around the timed region) */

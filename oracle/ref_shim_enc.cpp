@@ -19,6 +19,7 @@
 #include <cstring>
 #include <fstream>
 #include <algorithm>
+#include <chrono>
 #include <utility>
 #include <vector>
 
@@ -55,6 +56,13 @@ struct RefEncStats
   uint64_t lfnstCalls[2], lfnstDevice[2], lfnstMismatch[2];   // TrQuant::xFwdLfnst / xInvLfnst (gather + core multiply + scatter) as vtmhip_lfnst_tu_batch_dev   // InterSearch::xAffineMotionEstimation as one vtmhip_xAffineMotionEstimation_batch_dev call
   uint64_t amvpCalls, amvpDevice, amvpMismatch, amvpUnsupported;   // InterSearch::xEstimateMvPredAMVP's candidate selection as one vtmhip_xEstimateMvPredAMVP_batch_dev call (hook B7)
   uint64_t smvdCalls[3], smvdDevice[3], smvdMismatch[3], smvdUnsupported;   // xGetSymmetricCost / xSymmetricMotionEstimation / symmvdCheckBestMvp as vtmhip_smvd_batch_dev ops
+  // InterSearch::predInterSearch as ONE vtmhip_predInterSearch_batch_dev call per CU (oracle/ref_shim_pis.hpp): calls; on the device (or recorded); unsupported (the member
+  // runs as it is); skipped (no translational part: checkNonAffine false); served member calls whose arguments differed from the device's glue (the reference's code ran instead)
+  uint64_t pisCalls, pisDevice, pisUnsupported, pisSkipped, pisReplayFallback;
+  uint64_t pisMismatch[6];      // [0] final decision, [1] xEstimateMvPredAMVP, [2] uni xMotionEstimation, [3] bi xMotionEstimation, [4] SMVD members, [5] argument checks
+  int32_t  pisFirstMismatch[8];
+  uint64_t pisNs[4];            // wall time: [0] gather + compare, [1] upload + device + download, [2] the member over the tables, [3] the member where the device was not used
+  uint64_t affineNs[2];         // xAffineMotionEstimation hook: [0] the reference's member (0 in replace mode), [1] + gather + device
 };
 }
 
@@ -437,12 +445,15 @@ extern "C" void vtmref_orig_symmvdCheckBestMvp( InterSearch *, PredictionUnit &,
 extern "C" void vtmref_orig_xFwdLfnst( TrQuant *, const TransformUnit &, const ComponentID, const bool );
 extern "C" void vtmref_orig_xInvLfnst( TrQuant *, const TransformUnit &, const ComponentID );
 extern "C" void vtmref_orig_transformNxN_select( TrQuant *, TransformUnit &, const ComponentID &, const QpParam &, std::vector<TrMode> *, const int );
+extern "C" void vtmref_orig_predInterSearch( InterSearch *, CodingUnit &, Partitioner & );
 namespace
 {
 bool     g_hookMe = false, g_hookMts = false, g_hookAffine = false, g_hookLfnst = false, g_hookAmvp = false, g_hookSmvd = false;
 uint64_t g_amvpCtr = 0, g_smvdCtr[3] = { 0, 0, 0 };
 uint64_t g_lfnstCtr[2] = { 0, 0 };
-uint64_t g_affineCtr = 0;
+uint64_t g_affineCtr = 0, g_affineNs[2] = { 0, 0 };   // [0] the reference's member, [1] + the device call
+bool     g_pisReplace = false;
+inline uint64_t nowNs() { return ( uint64_t ) std::chrono::duration_cast<std::chrono::nanoseconds>( std::chrono::steady_clock::now().time_since_epoch() ).count(); }
 uint64_t g_hookCtr[2] = { 0, 0 }, g_hookStride = 0;   // VTMREF_HOOK_STRIDE: the hooks' own sampling stride (default: the tables' stride)
 inline bool hookSampled( uint64_t &ctr )
 {
@@ -784,17 +795,21 @@ void affineHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPi
   vtmhip_pic_params pic; memset( &pic, 0, sizeof( pic ) );
   pic.picW = pu.cs->pps->getPicWidthInLumaSamples(); pic.picH = pu.cs->pps->getPicHeightInLumaSamples(); pic.ctuSize = pu.cs->sps->getMaxCUWidth();
   pic.bitDepth = slice.getSPS()->getBitDepth( CHANNEL_TYPE_LUMA );
-  vtmref_orig_xAffineMotionEstimation( is, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi );
+  const bool replaceOnly = g_pisReplace;      // VTMREF_REPLACE=1: the member's body does not run (its outputs on this path: acMv, ruiBits, ruiCost)
+  const uint64_t tA = nowNs();
+  if( !replaceOnly ) vtmref_orig_xAffineMotionEstimation( is, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi );
+  g_affineNs[0] += nowNs() - tA;
   vtmhip_affine_me_out o; memset( &o, 0, sizeof( o ) );
   const bool ok = rp && A.h2d( g_ctx, d_hOrg, blk.data(), blk.size() * 2 ) == VTMHIP_OK && ( !bBi || A.h2d( g_ctx, d_hOther, oth.data(), oth.size() * 2 ) == VTMHIP_OK )
                && A.h2d( g_ctx, d_hJob, &j, sizeof( j ) ) == VTMHIP_OK
                && A.affineMe( g_ctx, &pic, d_hOrg, rp->dev, d_hOther, ( const vtmhip_affine_me_job * ) d_hJob, 1, w, h, ( vtmhip_affine_me_out * ) d_hOut ) == VTMHIP_OK
                && A.d2h( g_ctx, &o, d_hOut, sizeof( o ) ) == VTMHIP_OK;
-  if( !ok ) { note_error(); return; }
+  g_affineNs[1] += nowNs() - tA;
+  if( !ok ) { note_error(); if( replaceOnly ) vtmref_orig_xAffineMotionEstimation( is, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi ); return; }
   g_st->affineDevice++;
   const int mvNum = j.sixParam ? 3 : 2;
-  bool bad = o.bits != ruiBits || o.cost != ruiCost;
-  for( int i = 0; i < mvNum; i++ ) bad |= o.mv[i][0] != acMv[i].hor || o.mv[i][1] != acMv[i].ver;
+  bool bad = !replaceOnly && ( o.bits != ruiBits || o.cost != ruiCost );
+  for( int i = 0; i < mvNum && !replaceOnly; i++ ) bad |= o.mv[i][0] != acMv[i].hor || o.mv[i][1] != acMv[i].ver;
   if( bad ) { if( g_st->affineMismatch++ == 0 && g_st->hookMismatch[0] + g_st->hookMismatch[1] == 0 ) { const int32_t v[8] = { 2, w * 1000 + h, j.sixParam * 100 + j.bi * 10 + j.imv, o.mv[0][0] - acMv[0].hor, o.mv[1][0] - acMv[1].hor, ( int32_t ) ruiCost, ( int32_t ) o.cost, 0 }; memcpy( g_st->hookFirstMismatch, v, sizeof( v ) ); } }
   for( int i = 0; i < mvNum; i++ ) { acMv[i].hor = o.mv[i][0]; acMv[i].ver = o.mv[i][1]; }
   ruiBits = o.bits; ruiCost = o.cost;
@@ -895,13 +910,19 @@ void mtsHook( TrQuant *tq, TransformUnit &tu, const ComponentID &compID, const Q
   if( bad ) hookNoteMismatch( 1, w * 1000 + h, n, maxCand, nTr, 0, 0 );
   for( int i = 0; i < n; i++ ) trModes->at( i ).second = test[i] != 0;
 }
+#include "ref_shim_pis.hpp"
 }   // namespace
 
 // the strong definitions that take over the weakened reference symbols
+void InterSearch::predInterSearch( CodingUnit &cu, Partitioner &partitioner )
+{
+  if( g_hookPis ) pisHook( this, cu, partitioner ); else vtmref_orig_predInterSearch( this, cu, partitioner );
+}
 void InterSearch::xMotionEstimation( PredictionUnit &pu, PelUnitBuf &origBuf, RefPicList eRefPicList, Mv &rcMvPred, int iRefIdxPred, Mv &rcMv, int &riMVPIdx, uint32_t &ruiBits,
                                      Distortion &ruiCost, const AMVPInfo &amvpInfo, bool bBi )
 {
-  if( g_hookMe ) meHook( this, pu, origBuf, eRefPicList, rcMvPred, iRefIdxPred, rcMv, riMVPIdx, ruiBits, ruiCost, amvpInfo, bBi );
+  if( g_rp.active ) pisServeMe( this, pu, origBuf, eRefPicList, rcMvPred, iRefIdxPred, rcMv, riMVPIdx, ruiBits, ruiCost, amvpInfo, bBi );
+  else if( g_hookMe ) meHook( this, pu, origBuf, eRefPicList, rcMvPred, iRefIdxPred, rcMv, riMVPIdx, ruiBits, ruiCost, amvpInfo, bBi );
   else vtmref_orig_xMotionEstimation( this, pu, origBuf, eRefPicList, rcMvPred, iRefIdxPred, rcMv, riMVPIdx, ruiBits, ruiCost, amvpInfo, bBi );
 }
 void InterSearch::xAffineMotionEstimation( PredictionUnit &pu, PelUnitBuf &origBuf, RefPicList eRefPicList, Mv acMvPred[3], int iRefIdxPred, Mv acMv[3], uint32_t &ruiBits,
@@ -912,24 +933,28 @@ void InterSearch::xAffineMotionEstimation( PredictionUnit &pu, PelUnitBuf &origB
 }
 void InterSearch::xEstimateMvPredAMVP( PredictionUnit &pu, PelUnitBuf &origBuf, RefPicList eRefPicList, int iRefIdx, Mv &rcMvPred, AMVPInfo &amvpInfo, bool bFilled, Distortion *puiDistBiP )
 {
-  if( g_hookAmvp ) amvpHook( this, pu, origBuf, eRefPicList, iRefIdx, rcMvPred, amvpInfo, bFilled, puiDistBiP );
+  if( g_rp.active ) pisServeAmvp( this, pu, origBuf, eRefPicList, iRefIdx, rcMvPred, amvpInfo, bFilled, puiDistBiP );
+  else if( g_hookAmvp ) amvpHook( this, pu, origBuf, eRefPicList, iRefIdx, rcMvPred, amvpInfo, bFilled, puiDistBiP );
   else vtmref_orig_xEstimateMvPredAMVP( this, pu, origBuf, eRefPicList, iRefIdx, rcMvPred, amvpInfo, bFilled, puiDistBiP );
 }
 Distortion InterSearch::xGetSymmetricCost( PredictionUnit &pu, PelUnitBuf &origBuf, RefPicList eCurRefPicList, const MvField &cCurMvField, MvField &cTarMvField, int bcwIdx )
 {
+  if( g_rp.active ) return pisServeSmvdCost( this, pu, origBuf, eCurRefPicList, cCurMvField, cTarMvField, bcwIdx );
   if( g_hookSmvd ) return smvdCostHook( this, pu, origBuf, eCurRefPicList, cCurMvField, cTarMvField, bcwIdx );
   return vtmref_orig_xGetSymmetricCost( this, pu, origBuf, eCurRefPicList, cCurMvField, cTarMvField, bcwIdx );
 }
 void InterSearch::xSymmetricMotionEstimation( PredictionUnit &pu, PelUnitBuf &origBuf, Mv &rcMvCurPred, Mv &rcMvTarPred, RefPicList eRefPicList, MvField &rCurMvField,
                                               MvField &rTarMvField, Distortion &ruiCost, int bcwIdx )
 {
-  if( g_hookSmvd ) smvdMeHook( this, pu, origBuf, rcMvCurPred, rcMvTarPred, eRefPicList, rCurMvField, rTarMvField, ruiCost, bcwIdx );
+  if( g_rp.active ) pisServeSmvdMe( this, pu, origBuf, rcMvCurPred, rcMvTarPred, eRefPicList, rCurMvField, rTarMvField, ruiCost, bcwIdx );
+  else if( g_hookSmvd ) smvdMeHook( this, pu, origBuf, rcMvCurPred, rcMvTarPred, eRefPicList, rCurMvField, rTarMvField, ruiCost, bcwIdx );
   else vtmref_orig_xSymmetricMotionEstimation( this, pu, origBuf, rcMvCurPred, rcMvTarPred, eRefPicList, rCurMvField, rTarMvField, ruiCost, bcwIdx );
 }
 void InterSearch::symmvdCheckBestMvp( PredictionUnit &pu, PelUnitBuf &origBuf, Mv curMv, RefPicList curRefList, AMVPInfo amvpInfo[2][33], int32_t bcwIdx, Mv cMvPredSym[2],
                                       int32_t mvpIdxSym[2], Distortion &bestCost, bool skip )
 {
-  if( g_hookSmvd ) smvdCheckHook( this, pu, origBuf, curMv, curRefList, amvpInfo, bcwIdx, cMvPredSym, mvpIdxSym, bestCost, skip );
+  if( g_rp.active ) pisServeSmvdCheck( this, pu, origBuf, curMv, curRefList, amvpInfo, bcwIdx, cMvPredSym, mvpIdxSym, bestCost, skip );
+  else if( g_hookSmvd ) smvdCheckHook( this, pu, origBuf, curMv, curRefList, amvpInfo, bcwIdx, cMvPredSym, mvpIdxSym, bestCost, skip );
   else vtmref_orig_symmvdCheckBestMvp( this, pu, origBuf, curMv, curRefList, amvpInfo, bcwIdx, cMvPredSym, mvpIdxSym, bestCost, skip );
 }
 void TrQuant::xFwdLfnst( const TransformUnit &tu, const ComponentID compID, const bool loadTr )
@@ -968,7 +993,8 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
                  && sym( A.amvp, "vtmhip_xEstimateMvPredAMVP_batch_dev" ) && sym( A.smvd, "vtmhip_smvd_batch_dev" ) && sym( A.me, "vtmhip_xMotionEstimation_batch_dev" ) && sym( A.xT, "vtmhip_xT_batch_dev" ) && sym( A.tsChain, "vtmhip_tu_ts_chain_batch_dev" )
                  && sym( A.mtsSelect, "vtmhip_mts_select2" ) && sym( A.affineMe, "vtmhip_xAffineMotionEstimation_batch_dev" )
                  && sym( A.lfnstTables, "vtmhip_lfnst_set_tables" ) && sym( A.lfnstTu, "vtmhip_lfnst_tu_batch_dev" );
-    if( !ok ) { fprintf( stderr, "ref_encode: libvtmhip.so lacks a pointer-surface symbol\n" ); return -11; }
+    if( !ok || !sym( g_apiPis, "vtmhip_predInterSearch_batch_dev" ) || !sym( g_apiUniformShape, "vtmhip_is_uniform_shape" ) || !sym( g_apiHostAlloc, "vtmhip_host_alloc" ) )
+    { fprintf( stderr, "ref_encode: libvtmhip.so lacks a pointer-surface symbol\n" ); return -11; }
     const int st = A.create( 0, &g_ctx );
     if( st != VTMHIP_OK ) { fprintf( stderr, "ref_encode: vtmhip_create failed (%d) -- no CPU fallback\n", st ); return -12; }
   }
@@ -992,6 +1018,14 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
         if( g_mask & 2 ) installIf( app->m_cEncLib.m_cInterSearch.m_if );
         if( g_mask & 4 ) installTr();
         if( ( g_mask & 16 ) && ( g_countOnly || auxAlloc() ) ) installAux( (AffineGradientSearch &) app->m_cEncLib.m_cInterSearch );   // private base: C-style cast
+        g_pisDump = nullptr; g_pisDumpedPlanes.clear(); g_pisCtr = g_pisDumpCtr = 0;
+        if( g_mask & 2048 )
+        {
+          // VTMREF_PIS_DUMP: record mode (no device); otherwise compare mode, VTMREF_REPLACE=1: replace mode
+          if( getenv( "VTMREF_PIS_DUMP" ) ) { g_pisDump = fopen( getenv( "VTMREF_PIS_DUMP" ), "wb" ); g_pisDumpStride = getenv( "VTMREF_PIS_DUMP_STRIDE" ) ? strtoull( getenv( "VTMREF_PIS_DUMP_STRIDE" ), nullptr, 10 ) : 1; }
+          g_pisReplace = getenv( "VTMREF_REPLACE" ) && atoi( getenv( "VTMREF_REPLACE" ) ) != 0;
+          g_hookPis = g_pisDump != nullptr || g_countOnly || ( g_ctx && pisAlloc() );      // (count-only: the hook only times the member)
+        }
         if( ( g_mask & ( 96 | 128 | 256 | 512 | 1024 ) ) && ( g_countOnly || ( g_ctx && hookAlloc() ) ) ) { g_hookAffine = ( g_mask & 128 ) != 0; g_affineCtr = 0;
           g_hookAmvp = ( g_mask & 512 ) != 0 && !g_countOnly; g_amvpCtr = 0;
           g_hookSmvd = ( g_mask & 1024 ) != 0 && !g_countOnly; g_smvdCtr[0] = g_smvdCtr[1] = g_smvdCtr[2] = 0;
@@ -1009,7 +1043,9 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
     }
   }
   catch( Exception &e ) { fprintf( stderr, "ref_encode: %s\n", e.what() ); rc = 2; }
-  g_hookMe = g_hookMts = g_hookAffine = g_hookLfnst = g_hookAmvp = g_hookSmvd = false;
+  g_hookMe = g_hookMts = g_hookAffine = g_hookLfnst = g_hookAmvp = g_hookSmvd = g_hookPis = false;
+  stats->affineNs[0] = g_affineNs[0]; stats->affineNs[1] = g_affineNs[1]; g_affineNs[0] = g_affineNs[1] = 0;
+  if( g_pisDump ) { fclose( g_pisDump ); g_pisDump = nullptr; }
   for( RefPlane &p : g_planes ) A.dfree( g_ctx, p.dev );
   g_planes.clear();
   if( g_ctx || g_countOnly ) { restoreDist(); restoreTr(); restoreAux(); }

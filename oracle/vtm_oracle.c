@@ -1684,8 +1684,8 @@ void vo_motion_estimation( const vo_mest_cfg_t *cfg, const vo_mest_job_t *j, vo_
     c.subShift = vo_subshift_for_mode( w, h, cfg->fastInterSearchMode13 ? 2 : 0 );
     vo_tz_job_t t;
     memset( &t, 0, sizeof( t ) );
-    t.mvHor = j->mvPredHor; t.mvVer = j->mvPredVer; t.searchRange = j->searchRange;
-    t.extendedSettings = cfg->extendedSettings; t.fastSettings = 0; t.firstSearchStop = cfg->firstSearchStop;
+    t.mvHor = j->cachedIntMv ? j->mvHor : j->mvPredHor; t.mvVer = j->cachedIntMv ? j->mvVer : j->mvPredVer; t.searchRange = j->searchRange;   /* bQTBTMV2 (:3434-3441) or rcMv = rcMvPred (:3446) */
+    t.extendedSettings = cfg->extendedSettings; t.fastSettings = j->cachedIntMv != 0; t.firstSearchStop = cfg->firstSearchStop;
     t.numExtraStart = nex;
     memcpy( t.extraStart, ex, sizeof( int ) * 2 * nex );
     vo_tz_search( &c, &t, &ir );

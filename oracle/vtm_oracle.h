@@ -153,6 +153,8 @@ typedef struct
   double motionLambda;
   int numExtraStart;                         /* m_uniMvListSize */
   int extraStart[16][2];                     /* m_uniMvList entries for (list, refIdx), newest first, NOT de-duplicated */
+  int cachedIntMv;                           /* uni: the block-vector cache holds a vector for this (block, list, refIdx) (CacheBlkInfoCtrl::getMv, :3360-3368): rcMv = mvHor / mvVer
+                                                (that integer vector in internal precision), xTZSearch with bFastSettings (:3434-3441) */
 } vo_mest_job_t;
 
 typedef struct

@@ -22,7 +22,9 @@ class Stats(C.Structure):
                 ("hookFirstMismatch", C.c_int32 * 8), ("affineCalls", C.c_uint64), ("affineDevice", C.c_uint64), ("affineMismatch", C.c_uint64),
                 ("affineUnsupported", C.c_uint64), ("lfnstCalls", C.c_uint64 * 2), ("lfnstDevice", C.c_uint64 * 2), ("lfnstMismatch", C.c_uint64 * 2),
                 ("amvpCalls", C.c_uint64), ("amvpDevice", C.c_uint64), ("amvpMismatch", C.c_uint64), ("amvpUnsupported", C.c_uint64),
-                ("smvdCalls", C.c_uint64 * 3), ("smvdDevice", C.c_uint64 * 3), ("smvdMismatch", C.c_uint64 * 3), ("smvdUnsupported", C.c_uint64)]
+                ("smvdCalls", C.c_uint64 * 3), ("smvdDevice", C.c_uint64 * 3), ("smvdMismatch", C.c_uint64 * 3), ("smvdUnsupported", C.c_uint64),
+                ("pisCalls", C.c_uint64), ("pisDevice", C.c_uint64), ("pisUnsupported", C.c_uint64), ("pisSkipped", C.c_uint64), ("pisReplayFallback", C.c_uint64),
+                ("pisMismatch", C.c_uint64 * 6), ("pisFirstMismatch", C.c_int32 * 8), ("pisNs", C.c_uint64 * 4), ("affineNs", C.c_uint64 * 2)]
 
 
 def write_clip(path, w, h, frames, seed=77):
@@ -49,19 +51,24 @@ def _child(argv_json):
            "hookFirstMismatch": list(st.hookFirstMismatch), "affine": [st.affineCalls, st.affineDevice, st.affineMismatch, st.affineUnsupported],
            "lfnst": [list(st.lfnstCalls), list(st.lfnstDevice), list(st.lfnstMismatch)],
            "amvp": [st.amvpCalls, st.amvpDevice, st.amvpMismatch, st.amvpUnsupported],
-           "smvd": [list(st.smvdCalls), list(st.smvdDevice), list(st.smvdMismatch), st.smvdUnsupported]}
+           "smvd": [list(st.smvdCalls), list(st.smvdDevice), list(st.smvdMismatch), st.smvdUnsupported],
+           "pis": {"calls": st.pisCalls, "device": st.pisDevice, "unsupported": st.pisUnsupported, "skipped": st.pisSkipped, "replayFallback": st.pisReplayFallback,
+                   "mismatch": list(st.pisMismatch), "firstMismatch": list(st.pisFirstMismatch), "seconds": [v / 1e9 for v in st.pisNs]},
+           "affineSeconds": [v / 1e9 for v in st.affineNs]}
     sys.stdout.flush()
     os.write(2, ("\nDROPIN_RESULT " + json.dumps(out) + "\n").encode())
 
 
-def encode(yuv, w, h, frames, qp, out_prefix, hip=False, mask=23, stride=1, head=0, extra=(), timeout=1500):
-    """Returns (stats dict, md5 of the bitstream, md5 of the reconstruction)."""
+def encode(yuv, w, h, frames, qp, out_prefix, hip=False, mask=23, stride=1, head=0, extra=(), timeout=1500, env=None, cfg=None):
+    """Returns (stats dict, md5 of the bitstream, md5 of the reconstruction).  mask bit 2048: InterSearch::predInterSearch as one device call per CU
+    (oracle/ref_shim_pis.hpp; env VTMREF_REPLACE=1: replace mode, VTMREF_PIS_DUMP=<file>: record mode without a device)."""
     bits, rec = out_prefix + ".bin", out_prefix + "_rec.yuv"
-    args = ["-c", CFG, "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-f", str(frames), "-q", str(qp), "-b", bits, "-o", rec,
+    args = ["-c", cfg or CFG, "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-f", str(frames), "-q", str(qp), "-b", bits, "-o", rec,
             "--SEIDecodedPictureHash=1", "--OutputBitDepth=10"] + list(extra)
     req = json.dumps({"args": args, "hip": HIP_SO if hip else "", "mask": mask, "stride": stride, "head": head})
     p = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import enc_dropin; enc_dropin._child(sys.argv[1])"
-                        % os.path.dirname(os.path.abspath(__file__)), req], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+                        % os.path.dirname(os.path.abspath(__file__)), req], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout,
+                       env=dict(os.environ, **(env or {})))
     err = p.stderr.decode(errors="replace")
     line = [l for l in err.splitlines() if l.startswith("DROPIN_RESULT ")]
     if p.returncode != 0 or not line:

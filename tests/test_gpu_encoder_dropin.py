@@ -68,3 +68,44 @@ def test_reference_encoder_with_batched_hooks(tmp_path, monkeypatch):
         with open(os.path.join(out, "encoder_batched_hooks.txt"), "w") as f:
             f.write("clip %dx%d, %d pictures, QP %d; plain run %.1f s, hooked run %.1f s (every 3rd supported call of xMotionEstimation / xEstimateMvPredAMVP / the SMVD members / transformNxN(trModes) / xAffineMotionEstimation / xFwdLfnst / xInvLfnst on the device)\n%r\nbitstream md5 %s (plain %s)\n"
                     % (W, H, FRAMES, QP, t1 - t0, t2 - t1, {k: st1[k] for k in ("hookCalls", "hookDevice", "hookMismatch", "hookUnsupported", "affine", "lfnst", "amvp", "smvd", "errors")}, bits1, bits0))
+
+
+@pytest.mark.skipif(not os.path.exists(enc_dropin.REF_SO), reason="oracle/_ref/libvtmref.so not built (needs /root/reference)")
+def test_reference_encoder_predInterSearch_one_call_per_cu(tmp_path):
+    """InterSearch::predInterSearch inside the real encoder as ONE vtmhip_predInterSearch_batch_dev call per CU (oracle/ref_shim_pis.hpp): the PU's real AMVP lists,
+    m_uniMvList, block-vector cache hits and FastMEForGenBLowDelay copies go in, every (list, refIdx) search, the bi refinement, the SMVD block and the decision come back behind
+    one synchronisation, and the reference's own predInterSearch runs over the downloaded tables (its member calls are served from them; every served call checks that the
+    reference's arguments are the ones the device's glue derived).  Compare mode: the served members also run the reference's code (results compared), and what the member
+    leaves in pu -- interDir, mv, mvd, mvpIdx, refIdx, smvdMode, best translational cost -- is compared with the device's own decision record.  Replace mode
+    (VTMREF_REPLACE=1): the members' bodies do not run at all (xAffineMotionEstimation included).  Both: bitstream and reconstruction equal the plain run's."""
+    import json
+    import time
+    yuv = str(tmp_path / "clip.yuv")
+    enc_dropin.write_clip(yuv, W, H, FRAMES)
+    mask = 2048 | 128
+    t0 = time.time()
+    st0, bits0, rec0 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "plain"), False, 2048 | 8, 1, 0)      # plain run; the hook only times the member
+    t1 = time.time()
+    st1, bits1, rec1 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "cmp"), True, mask, 1, 0)
+    t2 = time.time()
+    st2, bits2, rec2 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "rep"), True, mask, 1, 0, env={"VTMREF_REPLACE": "1"})
+    t3 = time.time()
+    print("predInterSearch compare:", st1["pis"], st1["affine"], "replace:", st2["pis"], st2["affine"], "plain %.1f s compare %.1f s replace %.1f s" % (t1 - t0, t2 - t1, t3 - t2))
+    for st in (st0, st1, st2):
+        assert st["rc"] == 0 and st["errors"] == 0, st
+    for st in (st1, st2):
+        assert st["pis"]["device"] >= 5000, st["pis"]
+        assert st["pis"]["mismatch"] == [0] * 6 and st["pis"]["replayFallback"] == 0, st["pis"]
+        assert st["affine"][2] == 0 and st["affine"][1] > 1000, st["affine"]
+    assert bits1 == bits0 and rec1 == rec0
+    assert bits2 == bits0 and rec2 == rec0
+    out = os.path.join(enc_dropin.ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        in_member = sum(st0["pis"]["seconds"])
+        p = in_member / (t1 - t0)
+        json.dump({"clip": "%dx%d, %d pictures, QP %d, tests/data/enc_ra_gop4.cfg" % (W, H, FRAMES, QP), "bitstream_md5": bits0, "identical_bitstream": True,
+                   "plain_s": t1 - t0, "compare_s": t2 - t1, "replace_s": t3 - t2, "speedup_replace_vs_plain": (t1 - t0) / (t3 - t2),
+                   "predInterSearch_share_of_plain_run": p, "amdahl_bound_if_predInterSearch_were_free": 1.0 / (1.0 - p),
+                   "plain": st0["pis"], "compare": st1["pis"], "replace": st2["pis"], "affine_compare": st1["affine"], "affine_replace": st2["affine"],
+                   "affine_seconds_compare": st1["affineSeconds"], "affine_seconds_replace": st2["affineSeconds"]},
+                  open(os.path.join(out, "encoder_replace_192x128.json"), "w"), indent=1)

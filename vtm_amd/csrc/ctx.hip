@@ -150,6 +150,21 @@ int vtmhip_dev_free( vtmhip_ctx *ctx, void *devPtr )
   return VTMHIP_OK;
 }
 
+int vtmhip_host_alloc( vtmhip_ctx *ctx, size_t bytes, void **hostPtr )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, hostPtr != nullptr, "hostPtr" );
+  VTMHIP_HIP( ctx, hipHostMalloc( hostPtr, bytes ? bytes : 1 ) );
+  return VTMHIP_OK;
+}
+
+int vtmhip_host_free( vtmhip_ctx *ctx, void *hostPtr )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  if( hostPtr ) VTMHIP_HIP( ctx, hipHostFree( hostPtr ) );
+  return VTMHIP_OK;
+}
+
 int vtmhip_h2d( vtmhip_ctx *ctx, void *dev, const void *host, size_t bytes )
 {
   VTMHIP_CHECK_CTX( ctx );

@@ -250,6 +250,8 @@ _PROTOS = {
     "vtmhip_status_string": (C.c_char_p, [C.c_int]),
     "vtmhip_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vtmhip_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vtmhip_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "vtmhip_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vtmhip_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vtmhip_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vtmhip_timer_start": (C.c_int, [C.c_void_p]),
