@@ -462,7 +462,8 @@ inline bool hookSampled( uint64_t &ctr )
   return n < g_head || ( n % ( g_hookStride ? g_hookStride : g_stride ) ) == 0;
 }
 
-struct RefPlane { const Picture *pic; int poc; int16_t *dev; size_t samples; int stride, margin; };
+struct RefPlane { const Picture *pic; int poc; int16_t *dev, *alloc; size_t samples; int stride, margin; };
+constexpr size_t PLANE_PAD = 2048;   // samples of slack before and after an uploaded plane: the tiled kernels fetch whole 16-byte groups around a search window (include/vtmhip.h)
 std::vector<RefPlane> g_planes;
 int16_t *d_hOrg = nullptr, *d_hOther = nullptr;
 void    *d_hJob = nullptr, *d_hOut = nullptr;
@@ -484,8 +485,9 @@ const RefPlane *refPlane( const Picture *pic )
   const int     m = pic->margin;
   RefPlane      r; r.pic = pic; r.poc = pic->getPOC(); r.stride = y.stride; r.margin = m;
   r.samples = size_t( y.height + 2 * m ) * y.stride;
-  for( RefPlane &p : g_planes ) if( p.pic == pic ) { A.dfree( g_ctx, p.dev ); p = g_planes.back(); g_planes.pop_back(); break; }   // the buffer now holds another picture
-  if( A.dalloc( g_ctx, r.samples * 2, (void **) &r.dev ) != VTMHIP_OK ) return nullptr;
+  for( RefPlane &p : g_planes ) if( p.pic == pic ) { A.dfree( g_ctx, p.alloc ); p = g_planes.back(); g_planes.pop_back(); break; }   // the buffer now holds another picture
+  if( A.dalloc( g_ctx, ( r.samples + 2 * PLANE_PAD ) * 2, (void **) &r.alloc ) != VTMHIP_OK ) return nullptr;
+  r.dev = r.alloc + PLANE_PAD;
   // rows -margin .. height + margin - 1 of the plane; the last row is copied only up to its last sample (the allocation ends there)
   if( A.h2d( g_ctx, r.dev, y.buf - ptrdiff_t( m ) * y.stride - m, ( r.samples - size_t( y.stride - y.width - 2 * m > 0 ? y.stride - y.width - 2 * m : 0 ) ) * 2 ) != VTMHIP_OK ) return nullptr;
   g_planes.push_back( r );
@@ -1046,7 +1048,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
   g_hookMe = g_hookMts = g_hookAffine = g_hookLfnst = g_hookAmvp = g_hookSmvd = g_hookPis = false;
   stats->affineNs[0] = g_affineNs[0]; stats->affineNs[1] = g_affineNs[1]; g_affineNs[0] = g_affineNs[1] = 0;
   if( g_pisDump ) { fclose( g_pisDump ); g_pisDump = nullptr; }
-  for( RefPlane &p : g_planes ) A.dfree( g_ctx, p.dev );
+  for( RefPlane &p : g_planes ) A.dfree( g_ctx, p.alloc );
   g_planes.clear();
   if( g_ctx || g_countOnly ) { restoreDist(); restoreTr(); restoreAux(); }
   app->destroy();

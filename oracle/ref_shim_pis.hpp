@@ -451,6 +451,9 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
   g_st->pisNs[0] += t1 - t0;
 
   // ---- device ----
+  static const bool trace = getenv( "VTMREF_PIS_TRACE" ) != nullptr;      // one line per device call BEFORE it is issued: the last line names the PU of a faulting launch
+  if( trace ) { fprintf( stderr, "PIS poc %d pu %d,%d %dx%d imv %d refs %d+%d list %d smvd %d bir %d l1from0 %d,%d cached %d%d%d%d\n", hd.poc, hd.x, hd.y, w, h, imv, numRef[0], numRef[1],
+                         is->m_uniMvListSize, hasSmvd, biRestricted, L.list1FromList0[0], L.list1FromList0[1], g_rp.cached[0], g_rp.cached[1], g_rp.cached[2], g_rp.cached[3] ); fflush( stderr ); }
   if( !dumping )
   {
     char *d = d_pis;

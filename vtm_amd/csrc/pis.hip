@@ -429,7 +429,7 @@ int vtmhip_pis_stage( vtmhip_ctx *ctx, const vtmhip_pis_level *lvl, int stage )
   VTMHIP_REQUIRE( ctx, lvl && stage >= 0 && stage <= 5, "level / stage" );
   VTMHIP_REQUIRE( ctx, lvl->numPU >= 0 && lvl->numRef[0] >= 1 && lvl->numRef[0] <= VTMHIP_MAX_REF && lvl->numRef[1] >= 0 && lvl->numRef[1] <= VTMHIP_MAX_REF, "numPU / numRef" );
   if( lvl->numPU == 0 ) return VTMHIP_OK;
-  VTMHIP_REQUIRE( ctx, lvl->uniJobs && lvl->uniOut && lvl->uniRows && lvl->pus && lvl->predFinal && lvl->pos, "null pointer in the level" );
+  VTMHIP_REQUIRE( ctx, lvl->uniJobs && lvl->uniOut && lvl->uniRows && lvl->pus && lvl->pos && ( lvl->predFinal || lvl->candsGiven ), "null pointer in the level" );
   VTMHIP_REQUIRE( ctx, !lvl->parentIdx || lvl->parentRows, "parentIdx without parentRows" );
   VTMHIP_REQUIRE( ctx, !lvl->smvdJobs || ( lvl->symRefIdx[0] >= 0 && lvl->symRefIdx[0] < lvl->numRef[0] && lvl->symRefIdx[1] >= 0 && lvl->symRefIdx[1] < lvl->numRef[1] ),
                   "symRefIdx outside the reference lists" );
