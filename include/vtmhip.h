@@ -797,6 +797,8 @@ typedef struct
   int32_t  refineList;             /* the list the bi stage searched */
   int32_t  interDir;               /* pu.interDir: 1 list 0, 2 list 1, 3 bi-prediction */
   int32_t  smvdMode;               /* symMode (:2789): 1 when the symmetric-MVD pair replaced the bi vectors, else 0 */
+  int32_t  mvpIdxL1Zero;           /* MvdL1Zero pictures: bestBiPMvpL1 (:2382-2387), the list-1 predictor index of the bi mode (its vector IS the predictor: mvBi[1], refIdxBi[1]) */
+  int32_t  pad;
 } vtmhip_pis_pu;
 
 /* per-PU state of the CU recursion that predInterSearch reads */
@@ -851,11 +853,17 @@ typedef struct
   int32_t  candsGiven;             /* != 0: uniJobs already hold the real AMVP lists (PU::fillMvpCand: amvpCand, numAmvpCand 1 or 2), mvpIdxBits, the m_uniMvList start vectors
                                       (numExtraStart / extraStart), imv, flags and the entry bits (mbBits + reference-index bits): stage 0 is skipped */
   int32_t  biRestricted;           /* PU::isBipredRestriction (8x4 / 4x8): no bi stage, no SMVD */
-  int32_t  list1FromList0[VTMHIP_MAX_REF]; /* FastMEForGenBLowDelay (:2391-2404): v > 0: list-1 picture refIdx is list-0 picture v - 1 (slice.getList1IdxToList0Idx() + 1); its
-                                      rows take the list-0 vector and a re-priced cost instead of a search (their jobs are not searched).  0: search (also when the option is off) */
+  int32_t  list1FromList0[VTMHIP_MAX_REF]; /* slice.getList1IdxToList0Idx( refIdx ) + 1: v > 0: list-1 picture refIdx is list-0 picture v - 1.  Such a row never becomes the uni-directional
+                                      list-1 result (mvValidList1 / costValidList1, :2438-2446, 2826-2829); with fastMEForGenBLowDelay it is not searched either.  0: a picture of its own */
   const vtmhip_pis_pu_in *puIn;    /* [numPU] or NULL */
   vtmhip_pis_row       *biRows;    /* [numRef[refined list] * numPU] or NULL: the bi rows after xCheckBestMVP (cMvTemp, cMvPredBi, aaiMvpIdxBi, bits, cost) */
   uint64_t             *distBiP;   /* [(numRef[0] + numRef[1]) * numPU] or NULL: *puiDistBiP of xEstimateMvPredAMVP per row */
+  int32_t  mvdL1Zero;              /* picHeader.getMvdL1ZeroFlag() (both lists hold the same pictures): the bi mode takes list 1 AT its best AMVP predictor (smallest template cost over
+                                      the list-1 rows, :2382-2387, 2477-2522: needs distBiP) and refines list 0 only (:2576-2580) */
+  int32_t  fastMEForGenBLowDelay;  /* cfg FDM (:2391-2404): the rows of list-1 pictures that are list-0 pictures too take the list-0 vector and a re-priced cost instead of a search */
+  int32_t  pad2;
+  int32_t  picW, picH, ctuSize;    /* picW != 0: the other list's vector is clipped as motionCompensation does it (clipMv, InterPrediction.cpp:445-470) before the prediction for the bi
+                                      refinement is formed -- search results are inside the clip range by construction, an AMVP predictor (MvdL1Zero) need not be */
 } vtmhip_pis_level;
 
 

@@ -54,7 +54,7 @@ struct PisHeader    // one dump record: PisHeader, PisSlots (inputs), PisSlots (
 {
   uint32_t magic, bytes;
   int32_t  poc, x, y, w, h, imv, picW, picH, ctuSize, bitDepth;
-  int32_t  numRef[2], smvdBit, symRefIdx[2], hasSmvd, biRestricted, list1FromList0[PIS_MAX_REF];
+  int32_t  numRef[2], smvdBit, symRefIdx[2], hasSmvd, biRestricted, mvdL1Zero, fdm, list1FromList0[PIS_MAX_REF];
   uint32_t mbBits[3];
   int32_t  bipredSearchRange, useHadME, fen13, extendedSettings, firstSearchStop, uniMvListSize;
   int32_t  rowPlane[PIS_ROWS];   // index of the row's reference plane among the dumped planes (PisPlaneHeader records, in file order)
@@ -305,7 +305,7 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
   if( imv == 2 && checkNonAffine && sps.getAffineAmvrEnabledFlag() ) checkNonAffine = is->m_affineMotion.hevcCost[1] < is->m_affineMotion.hevcCost[0] * 1.06f;
   const auto fsm = is->m_pcEncCfg->getFastInterSearchMode();
   bool unsupported = ( isB ? cu.BcwIdx : BCW_DEFAULT ) != BCW_DEFAULT || slice.getPPS()->getUseWP() || slice.getPPS()->getWPBiPred() || is->m_pcEncCfg->getMCTSEncConstraint()
-                  || is->m_useCompositeRef || is->m_pcEncCfg->getUseHashME() || is->m_pcEncCfg->getClipForBiPredMeEnabled() || cu.cs->picHeader->getMvdL1ZeroFlag()
+                  || is->m_useCompositeRef || is->m_pcEncCfg->getUseHashME() || is->m_pcEncCfg->getClipForBiPredMeEnabled()
                   || ( fsm != FASTINTERSEARCH_MODE1 && fsm != FASTINTERSEARCH_MODE2 )
                   || ( is->m_motionEstimationSearchMethod != MESEARCH_DIAMOND && is->m_motionEstimationSearchMethod != MESEARCH_DIAMOND_ENHANCED )
                   || w > 128 || h > 128 || w < 4 || h < 4 || w * h < 32 || numRef[0] < 1 || numRef[0] > PIS_MAX_REF || numRef[1] > PIS_MAX_REF || ( isB && numRef[0] != numRef[1] )
@@ -400,9 +400,9 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
         g_rp.cached[row] = true;
       }
       hd.rowCached[row] = g_rp.cached[row];
-      const int from0 = ( l == 1 && fdm ) ? slice.getList1IdxToList0Idx( r ) : -1;
+      const int from0 = l == 1 ? slice.getList1IdxToList0Idx( r ) : -1;
       if( l == 1 ) L.list1FromList0[r] = from0 >= 0 ? from0 + 1 : 0;
-      hd.rowCalls[row] = !( l == 1 && from0 >= 0 );
+      hd.rowCalls[row] = !( l == 1 && fdm && from0 >= 0 );
       CHECK( ry.stride != refStride, "reference planes of one picture size share a stride" );
     }
   if( !ok ) { note_error(); vtmref_orig_predInterSearch( is, cu, partitioner ); return; }
@@ -422,7 +422,8 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
   }
   L.numPU = 1; L.numRef[0] = numRef[0]; L.numRef[1] = numRef[1]; L.smvdBit = isB && slice.getBiDirPred(); L.refStride = refStride;
   for( int i = 0; i < 3; i++ ) L.mbBits[i] = mbBits[i];
-  L.candsGiven = 1; L.biRestricted = biRestricted;
+  L.candsGiven = 1; L.biRestricted = biRestricted; L.mvdL1Zero = isB && cu.cs->picHeader->getMvdL1ZeroFlag(); L.fastMEForGenBLowDelay = fdm;
+  L.picW = cu.cs->pps->getPicWidthInLumaSamples(); L.picH = cu.cs->pps->getPicHeightInLumaSamples(); L.ctuSize = sps.getMaxCUWidth();
   if( hasSmvd ) { L.symRefIdx[0] = slice.getSymRefIdx( 0 ); L.symRefIdx[1] = slice.getSymRefIdx( 1 ); }
   S.pos[0] = ( int64_t ) pu.Y().y * refStride + pu.Y().x;
   vtmhip_pred_job &po = S.predOther[0];
@@ -442,7 +443,7 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
   cfg.uniformImv = imv;
   hd.magic = PIS_MAGIC; hd.poc = slice.getPOC(); hd.x = pu.Y().x; hd.y = pu.Y().y; hd.w = w; hd.h = h; hd.imv = imv;
   hd.picW = cu.cs->pps->getPicWidthInLumaSamples(); hd.picH = cu.cs->pps->getPicHeightInLumaSamples(); hd.ctuSize = sps.getMaxCUWidth(); hd.bitDepth = sps.getBitDepth( CHANNEL_TYPE_LUMA );
-  hd.numRef[0] = numRef[0]; hd.numRef[1] = numRef[1]; hd.smvdBit = L.smvdBit; hd.symRefIdx[0] = L.symRefIdx[0]; hd.symRefIdx[1] = L.symRefIdx[1]; hd.hasSmvd = hasSmvd; hd.biRestricted = biRestricted;
+  hd.numRef[0] = numRef[0]; hd.numRef[1] = numRef[1]; hd.smvdBit = L.smvdBit; hd.symRefIdx[0] = L.symRefIdx[0]; hd.symRefIdx[1] = L.symRefIdx[1]; hd.hasSmvd = hasSmvd; hd.biRestricted = biRestricted; hd.mvdL1Zero = L.mvdL1Zero; hd.fdm = fdm;
   for( int r = 0; r < PIS_MAX_REF; r++ ) hd.list1FromList0[r] = L.list1FromList0[r];
   for( int i = 0; i < 3; i++ ) hd.mbBits[i] = mbBits[i];
   hd.bipredSearchRange = cfg.bipredSearchRange; hd.useHadME = cfg.useHadME; hd.fen13 = cfg.fastInterSearchMode13; hd.extendedSettings = cfg.extendedSettings;
@@ -527,6 +528,7 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
       int mvH = bi ? P.mvBi[l][0] : P.mv[l][0], mvV = bi ? P.mvBi[l][1] : P.mv[l][1], predH, predV, idx;
       if( bi && P.smvdMode ) { idx = S.smvd[0].mvpIdxSym[l]; predH = S.smvd[0].predSym[l][0]; predV = S.smvd[0].predSym[l][1]; }
       else if( bi && l == P.refineList ) { const vtmhip_pis_row &r = S.biRows[ref]; idx = r.mvpIdx; predH = r.mvPredHor; predV = r.mvPredVer; }
+      else if( bi && L.mvdL1Zero ) { idx = P.mvpIdxL1Zero; predH = mvH; predV = mvV; }      // list 1 at its predictor (:2477-2487)
       else { const vtmhip_pis_row &r = S.uniRows[g_rp.row( l, ref )]; idx = r.mvpIdx; predH = r.mvPredHor; predV = r.mvPredVer; }
       bad = ref != F.refIdx[l] || mvH != F.mv[l][0] || mvV != F.mv[l][1] || mvH - predH != F.mvd[l][0] || mvV - predV != F.mvd[l][1] || idx != F.mvpIdx[l];
     }

@@ -37,7 +37,7 @@ int run_uni( vtmhip_ctx *ctx, const vtmhip_pis_level_run &L, const vtmhip_pis_bu
   int first = 0, count = L.pis.numRef[0];
   for( int r = 0; r <= L.pis.numRef[1]; r++ )
   {
-    const bool searched = r < L.pis.numRef[1] && !( L.pis.list1FromList0[r] > 0 && L.pis.list1FromList0[r] <= L.pis.numRef[0] );
+    const bool searched = r < L.pis.numRef[1] && !( L.pis.fastMEForGenBLowDelay && L.pis.list1FromList0[r] > 0 && L.pis.list1FromList0[r] <= L.pis.numRef[0] );
     if( searched ) { if( !count ) first = L.pis.numRef[0] + r; count++; continue; }
     if( count )
     {

@@ -150,6 +150,22 @@ __device__ __forceinline__ void final_pred( const vtmhip_pis_level &L, int pu, c
     }
 }
 
+// Before the uni / bi decision list 1 is re-read from its "valid" rows only (:2438-2446, 2826-2829): a list-1 picture that is a list-0 picture too competes as list 0, not as
+// list 1 (the unrestricted best of list 1 served the bi stage until here)
+__device__ __forceinline__ void take_valid_list1( const vtmhip_pis_level &L, int pu, vtmhip_pis_pu &P )
+{
+  bool any = false;
+  for( int ref = 0; ref < L.numRef[1]; ref++ ) any |= L.list1FromList0[ref] > 0;
+  if( !any ) return;
+  P.cost[1] = ~0ull; P.bits[1] = ~0u; P.refIdx[1] = 0; P.mv[1][0] = P.mv[1][1] = 0;
+  for( int ref = 0; ref < L.numRef[1]; ref++ )
+  {
+    if( L.list1FromList0[ref] > 0 ) continue;
+    const vtmhip_pis_row &r = L.uniRows[uni_row( L, 1, ref, pu )];
+    if( r.cost < P.cost[1] ) { P.cost[1] = r.cost; P.bits[1] = r.bits; P.mv[1][0] = r.mvHor; P.mv[1][1] = r.mvVer; P.refIdx[1] = ref; }
+  }
+}
+
 __global__ __launch_bounds__( 256 ) void pis_uni_select_kernel( vtmhip_pis_level L )
 {
   const int pu = blockIdx.x * 256 + threadIdx.x;
@@ -160,14 +176,14 @@ __global__ __launch_bounds__( 256 ) void pis_uni_select_kernel( vtmhip_pis_level
   P.refIdx[0] = P.refIdx[1] = P.refIdxBi[0] = P.refIdxBi[1] = -1;
   P.mv[0][0] = P.mv[0][1] = P.mv[1][0] = P.mv[1][1] = 0;
   P.mvBi[0][0] = P.mvBi[0][1] = P.mvBi[1][0] = P.mvBi[1][1] = 0;
-  P.refineList = 0; P.interDir = 1; P.smvdMode = 0;
+  P.refineList = 0; P.interDir = 1; P.smvdMode = 0; P.mvpIdxL1Zero = 0; P.pad = 0;
   for( int list = 0; list < 2; list++ )
     for( int ref = 0; ref < L.numRef[list]; ref++ )
     {
       const int            row = uni_row( L, list, ref, pu );
       const vtmhip_me_job &j   = L.uniJobs[row];
       vtmhip_pis_row r;
-      const int from0 = list == 1 ? L.list1FromList0[ref] - 1 : -1;
+      const int from0 = ( list == 1 && L.fastMEForGenBLowDelay ) ? L.list1FromList0[ref] - 1 : -1;
       if( from0 >= 0 && from0 < L.numRef[0] )
       {
         // FastMEForGenBLowDelay (:2391-2404): the same picture sits in list 0 -- its vector, and its cost with the rate part re-priced against this row's predictor
@@ -193,6 +209,7 @@ __global__ __launch_bounds__( 256 ) void pis_uni_select_kernel( vtmhip_pis_level
     }
   if( L.numRef[1] == 0 || L.biRestricted )      // P slice: list 0 it is; 8x4 / 4x8 PUs of a B slice (PU::isBipredRestriction): the cheaper list (:2866-2885)
   {
+    if( L.numRef[1] ) take_valid_list1( L, pu, P );
     P.interDir = ( L.numRef[1] == 0 || P.cost[0] <= P.cost[1] ) ? 1 : 2;
     final_pred( L, pu, P );
   }
@@ -204,13 +221,39 @@ __global__ __launch_bounds__( 256 ) void pis_bi_jobs_kernel( vtmhip_pis_level L 
   const int pu = blockIdx.x * 256 + threadIdx.x;
   if( pu >= L.numPU ) return;
   vtmhip_pis_pu &P = L.pus[pu];
-  const int rl = P.cost[0] <= P.cost[1] ? 1 : 0, ot = 1 - rl;   // FASTINTERSEARCH_MODE1: refine the list with the larger cost (:2544-2556)
+  const int rl = L.mvdL1Zero ? 0 : ( P.cost[0] <= P.cost[1] ? 1 : 0 ), ot = 1 - rl;   // FASTINTERSEARCH_MODE1: refine the list with the larger cost (:2544-2556); MvdL1Zero: list 0 (:2576-2580)
   P.refineList = rl;
   vtmhip_pred_job &po = L.predOther[pu];
   po.mode = ( uint8_t ) ot;
-  po.refOff[ot] = L.refPlaneOff[ot][P.refIdx[ot]] + L.pos[pu];
-  po.mv[ot][0] = P.mv[ot][0]; po.mv[ot][1] = P.mv[ot][1];
-  const unsigned motOther = P.bits[ot] - L.mbBits[ot];           // uiMotBits[1 - iRefList] (:2525-2527)
+  unsigned motOther;
+  if( L.mvdL1Zero )
+  {
+    // list 1 enters the bi mode AT its best AMVP predictor: the row with the smallest template cost (first minimum, :2382-2387), vector = that predictor, no vector difference
+    unsigned long long bestDist = ~0ull;
+    int                bestRef = 0, bestMvp = 0;
+    for( int ref = 0; ref < L.numRef[1]; ref++ )
+    {
+      const int row = uni_row( L, 1, ref, pu );
+      if( L.distBiP[row] < bestDist ) { bestDist = L.distBiP[row]; bestRef = ref; bestMvp = L.uniJobs[row].mvpIdx; }
+    }
+    const vtmhip_me_job &u1 = L.uniJobs[uni_row( L, 1, bestRef, pu )];
+    P.mvBi[1][0] = u1.amvpCand[bestMvp & 1][0]; P.mvBi[1][1] = u1.amvpCand[bestMvp & 1][1]; P.refIdxBi[1] = bestRef; P.mvpIdxL1Zero = bestMvp;
+    po.refOff[1] = L.refPlaneOff[1][bestRef] + L.pos[pu];
+    po.mv[1][0] = P.mvBi[1][0]; po.mv[1][1] = P.mvBi[1][1];
+    motOther = L.mbBits[1] + ref_idx_bits( L.numRef[1], bestRef ) + u1.mvpIdxBits[bestMvp & 1];      // uiMotBits[1] (:2506-2517)
+  }
+  else
+  {
+    po.refOff[ot] = L.refPlaneOff[ot][P.refIdx[ot]] + L.pos[pu];
+    po.mv[ot][0] = P.mv[ot][0]; po.mv[ot][1] = P.mv[ot][1];
+    motOther = P.bits[ot] - L.mbBits[ot];           // uiMotBits[1 - iRefList] (:2525-2527)
+  }
+  if( L.picW )      // clipMv of motionCompensation (the PU's own record keeps the unclipped vector)
+  {
+    const vtmhip_me_job &u0 = L.uniJobs[uni_row( L, 0, 0, pu )];
+    po.mv[ot][0] = min( ( L.picW + 8 - u0.puX - 1 ) << 4, max( ( -L.ctuSize - 8 - u0.puX + 1 ) << 4, po.mv[ot][0] ) );
+    po.mv[ot][1] = min( ( L.picH + 8 - u0.puY - 1 ) << 4, max( ( -L.ctuSize - 8 - u0.puY + 1 ) << 4, po.mv[ot][1] ) );
+  }
   for( int ref = 0; ref < L.numRef[rl]; ref++ )
   {
     const int             row = uni_row( L, rl, ref, pu );
@@ -238,7 +281,7 @@ __global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
   if( pu >= L.numPU ) return;
   vtmhip_pis_pu P  = L.pus[pu];
   const int     rl = P.refineList, ot = 1 - rl;
-  P.mvBi[ot][0] = P.mv[ot][0]; P.mvBi[ot][1] = P.mv[ot][1]; P.refIdxBi[ot] = P.refIdx[ot];
+  if( !L.mvdL1Zero ) { P.mvBi[ot][0] = P.mv[ot][0]; P.mvBi[ot][1] = P.mv[ot][1]; P.refIdxBi[ot] = P.refIdx[ot]; }      // (MvdL1Zero: stage 2 put list 1 at its predictor)
   P.mvBi[rl][0] = P.mv[rl][0]; P.mvBi[rl][1] = P.mv[rl][1]; P.refIdxBi[rl] = P.refIdx[rl];
   for( int ref = 0; ref < L.numRef[rl]; ref++ )
   {
@@ -291,6 +334,7 @@ __global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
     L.pus[pu] = P;
     return;
   }
+  take_valid_list1( L, pu, P );
   P.interDir = ( P.costBi <= P.cost[0] && P.costBi <= P.cost[1] ) ? 3 : ( P.cost[0] <= P.cost[1] ? 1 : 2 );   // :2846-2893
   final_pred( L, pu, P );
   L.pus[pu] = P;
@@ -309,6 +353,7 @@ __global__ __launch_bounds__( 256 ) void pis_smvd_merge_kernel( vtmhip_pis_level
     P.mvBi[0][0] = j.mvCur[0]; P.mvBi[0][1] = j.mvCur[1]; P.refIdxBi[0] = L.symRefIdx[0];
     P.mvBi[1][0] = j.mvTar[0]; P.mvBi[1][1] = j.mvTar[1]; P.refIdxBi[1] = L.symRefIdx[1];
   }
+  take_valid_list1( L, pu, P );
   P.interDir = ( P.costBi <= P.cost[0] && P.costBi <= P.cost[1] ) ? 3 : ( P.cost[0] <= P.cost[1] ? 1 : 2 );
   final_pred( L, pu, P );
   L.pus[pu] = P;
@@ -450,6 +495,7 @@ int vtmhip_pis_stage( vtmhip_ctx *ctx, const vtmhip_pis_level *lvl, int stage )
   else
   {
     VTMHIP_REQUIRE( ctx, lvl->numRef[1] >= 1 && lvl->predOther && lvl->biJobs && lvl->biOut, "the bi stages need list 1 and the bi tables" );
+    VTMHIP_REQUIRE( ctx, !lvl->mvdL1Zero || ( lvl->distBiP && !lvl->smvdJobs ), "MvdL1Zero needs the template costs (distBiP) and has no SMVD block" );
     if( stage == 2 ) hipLaunchKernelGGL( pis_bi_jobs_kernel, perPU, tpb, 0, ctx->stream, *lvl );
     else hipLaunchKernelGGL( pis_final_kernel, perPU, tpb, 0, ctx->stream, *lvl );
   }

@@ -171,7 +171,8 @@ class PisRow(C.Structure):
 
 class PisPu(C.Structure):
     _fields_ = [("cost", C.c_uint64 * 2), ("costBi", C.c_uint64), ("bits", C.c_uint32 * 3), ("refIdx", C.c_int32 * 2), ("mv", (C.c_int32 * 2) * 2),
-                ("refIdxBi", C.c_int32 * 2), ("mvBi", (C.c_int32 * 2) * 2), ("refineList", C.c_int32), ("interDir", C.c_int32), ("smvdMode", C.c_int32)]
+                ("refIdxBi", C.c_int32 * 2), ("mvBi", (C.c_int32 * 2) * 2), ("refineList", C.c_int32), ("interDir", C.c_int32), ("smvdMode", C.c_int32),
+                ("mvpIdxL1Zero", C.c_int32), ("pad", C.c_int32)]
 
 
 class PisPuIn(C.Structure):
@@ -186,7 +187,7 @@ class PisLevel(C.Structure):
                 ("refPoc", (C.c_int32 * MAX_REF) * 2), ("predFinalC", C.c_void_p), ("posC", C.c_void_p), ("refPlaneOffC", ((C.c_int64 * MAX_REF) * 2) * 2),
                 ("affJobs", C.c_void_p), ("affLowDelay", C.c_int32), ("affCheckLDC", C.c_int32), ("smvdJobs", C.c_void_p), ("symRefIdx", C.c_int32 * 2),
                 ("candsGiven", C.c_int32), ("biRestricted", C.c_int32), ("list1FromList0", C.c_int32 * MAX_REF), ("puIn", C.c_void_p), ("biRows", C.c_void_p),
-                ("distBiP", C.c_void_p)]
+                ("distBiP", C.c_void_p), ("mvdL1Zero", C.c_int32), ("fastMEForGenBLowDelay", C.c_int32), ("pad2", C.c_int32), ("picW", C.c_int32), ("picH", C.c_int32), ("ctuSize", C.c_int32)]
 
 
 class PisLevelRun(C.Structure):
