@@ -1,0 +1,31 @@
+"""Makes tests/golden/pis_enc.npz (DATA ONLY: sample planes and job / result records): runs the REAL reference encoder of oracle/_ref/libvtmref.so on the small
+random-access clip of the encoder tests with the predInterSearch hook in RECORD mode (oracle/ref_shim_pis.hpp, no device) and keeps every STRIDE-th CU's record.
+
+    python tests/golden/gen_pis_golden.py [stride = 45]
+
+Needs /root/reference (the reference is compiled in place by oracle/Makefile.ref); the .npz travels, the reference does not."""
+import os
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import enc_dropin      # noqa: E402
+import pis_golden      # noqa: E402
+
+
+def main():
+    stride = int(sys.argv[1]) if len(sys.argv) > 1 else 45
+    with tempfile.TemporaryDirectory() as tmp:
+        yuv, dump = os.path.join(tmp, "clip.yuv"), os.path.join(tmp, "pis.bin")
+        enc_dropin.write_clip(yuv, 192, 128, 5)
+        st, bits, rec = enc_dropin.encode(yuv, 192, 128, 5, 30, os.path.join(tmp, "rec"), False, 2048 | 8, 1, 0, env={"VTMREF_PIS_DUMP": dump, "VTMREF_PIS_DUMP_STRIDE": str(stride)})
+        assert st["rc"] == 0, st
+        planes, recs = pis_golden.parse_dump(dump)
+    out = os.path.join(HERE, "pis_enc.npz")
+    pis_golden.save_npz(out, planes, recs)
+    print("%d planes, %d records (of %d predInterSearch calls) -> %s (%d bytes); bitstream md5 %s" % (len(planes), len(recs), st["pis"]["calls"], out, os.path.getsize(out), bits))
+
+
+if __name__ == "__main__":
+    main()

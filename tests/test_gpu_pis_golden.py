@@ -1,0 +1,139 @@
+"""GPU replay of tests/golden/pis_enc.npz: 353 predInterSearch calls recorded INSIDE the real reference encoder (oracle/ref_shim_pis.hpp in record mode, gen_pis_golden.py) --
+the PU's real AMVP lists, m_uniMvList, block-vector cache hits, FastMEForGenBLowDelay copies, MvdL1Zero pictures, AMVR modes, and what the reference's own members returned --
+through ONE vtmhip_predInterSearch_batch_dev call each, compared field by field with the recorded reference results.  The reference itself is not needed here."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import pis_golden as G
+from vtm_amd.lib import MeCfg, PicParams, PisBuffers, PisLevelRun
+
+pytestmark = pytest.mark.gpu
+NPZ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pis_enc.npz")
+
+
+def rate(lam, bits):
+    return int(lam * bits)
+
+
+def same(a, b, fields):
+    return all(getattr(a, f) == getattr(b, f) for f in fields)
+
+
+def test_predInterSearch_one_call_per_pu_matches_the_real_encoder():
+    from vtm_amd.device import Context
+    planes, recs = G.load_npz(NPZ)
+    ctx = Context(0)
+    dpb_np, bases = G.build_dpb(planes)
+    d_dpb = ctx.to_device(dpb_np)
+    d_slots = ctx.alloc(C.sizeof(G.PisSlots) + 128 * 128 * 2)
+    d_orgbi = ctx.alloc(128 * 128 * 2)
+    off = {f: getattr(G.PisSlots, f).offset for f, _ in G.PisSlots._fields_}
+    stats = dict(recs=0, rows=0, copies=0, cached=0, bi=0, smvd=0, smvd_won=0, mvdl1zero=0, imv=[0, 0, 0, 0], affine_won=0, dirs=[0, 0, 0, 0])
+    for hd, sin, sout, org, fin in recs:
+        w, h, n0, n1 = hd.w, hd.h, hd.numRef[0], hd.numRef[1]
+        rows = n0 + n1
+        S = G.PisSlots.from_buffer_copy(bytes(sin))
+        R = PisLevelRun()
+        L = R.pis
+        stride = planes[hd.rowPlane[0]][0].stride
+        for l in (0, 1):
+            for r in range((n0, n1)[l]):
+                row = (n0 if l else 0) + r
+                pl = planes[hd.rowPlane[row]][0]
+                assert pl.stride == stride
+                zero = bases[hd.rowPlane[row]] + pl.margin * pl.stride + pl.margin      # the plane's sample (0, 0) inside the rebuilt DPB
+                L.refPlaneOff[l][r] = zero
+                S.uniJobs[row].refOff = zero + hd.y * pl.stride + hd.x
+                assert bases[hd.rowPlane[row]] + hd.rowOff[row] == S.uniJobs[row].refOff
+        S.pos[0] = hd.y * stride + hd.x
+        base = d_slots.ptr
+        L.numPU, L.smvdBit, L.refStride, L.candsGiven, L.biRestricted, L.mvdL1Zero, L.fastMEForGenBLowDelay = 1, hd.smvdBit, stride, 1, hd.biRestricted, hd.mvdL1Zero, hd.fdm
+        L.picW, L.picH, L.ctuSize = hd.picW, hd.picH, hd.ctuSize
+        L.numRef[0], L.numRef[1] = n0, n1
+        for i in range(3):
+            L.mbBits[i] = hd.mbBits[i]
+        for r in range(4):
+            L.list1FromList0[r] = hd.list1FromList0[r]
+        L.symRefIdx[0], L.symRefIdx[1] = hd.symRefIdx[0], hd.symRefIdx[1]
+        L.uniJobs, L.uniOut, L.uniRows, L.distBiP = base + off["uniJobs"], base + off["uniOut"], base + off["uniRows"], base + off["distBiP"]
+        L.pus, L.puIn, L.predOther, L.biJobs, L.biOut, L.biRows, L.pos = (base + off[k] for k in ("pus", "puIn", "predOther", "biJobs", "biOut", "biRows", "pos"))
+        L.smvdJobs = base + off["smvd"] if hd.hasSmvd else None
+        R.uniOut, R.biOut, R.width, R.height = L.uniOut, L.biOut, w, h
+        big = max(w, h)
+        R.pic = PicParams(hd.picW, hd.picH, hd.ctuSize, hd.bitDepth, 8 if big >= 128 else 2 if big >= 64 else 1)
+        R.picBi = PicParams(hd.picW, hd.picH, hd.ctuSize, hd.bitDepth, 16 if big >= 128 else 8 if big >= 64 else 4 if big >= 32 else 1)
+        uni_shape = int(ctx.is_uniform_shape(w, h))
+        ins = int(S.puIn[0].uniMvInsert)
+        R.cfgUni = MeCfg(hd.bipredSearchRange, hd.useHadME, hd.fen13, hd.extendedSettings, hd.firstSearchStop, hd.imv, uni_shape, 1, int(hd.uniMvListSize == 0), 0)
+        R.cfgBi = MeCfg(hd.bipredSearchRange, hd.useHadME, hd.fen13, hd.extendedSettings, hd.firstSearchStop, hd.imv, uni_shape, 2, int(hd.uniMvListSize == 0 and not ins), 1)
+        B = PisBuffers(base + C.sizeof(G.PisSlots), d_dpb.ptr, None, None, d_orgbi.ptr, None, None)
+        d_slots.upload(np.concatenate([np.frombuffer(bytes(S), np.uint8), np.ascontiguousarray(org).view(np.uint8).reshape(-1)]))
+        ctx.pred_inter_search_batch(R, B)
+        D = G.PisSlots.from_buffer_copy(d_slots.to_host(np.uint8)[:C.sizeof(G.PisSlots)].tobytes())
+        E, lam = sout, S.uniJobs[0].motionLambda
+        tag = (hd.poc, hd.x, hd.y, w, h, hd.imv)
+        # ---- every row: the AMVP stage; the searched rows: xMotionEstimation ----
+        for row in range(rows):
+            assert same(D.uniJobs[row], E.uniJobs[row], ("mvpIdx", "mvPredHor", "mvPredVer", "bits")) and D.distBiP[row] == E.distBiP[row], ("amvp", tag, row)
+            if hd.rowCalls[row]:
+                assert E.uniOut[row].intDist == 1, ("the reference did not search a row it should have", tag, row)
+                assert same(D.uniOut[row], E.uniOut[row], ("mvHor", "mvVer", "mvPredHor", "mvPredVer", "mvpIdx", "bits", "cost")), ("uni", tag, row, hd.rowCached[row])
+            else:
+                assert E.uniOut[row].intDist == 0
+                stats["copies"] += 1
+            stats["rows"] += 1
+            stats["cached"] += hd.rowCached[row]
+        P = D.pus[0]
+        # ---- the bi iteration ----
+        if fin.biList >= 0:
+            assert P.refineList == fin.biList, ("refined list", tag)
+            for r in range((n0, n1)[fin.biList]):
+                assert same(D.biJobs[r], E.biJobs[r], ("mvPredHor", "mvPredVer", "mvHor", "mvVer", "mvpIdx", "bits")), ("bi entry", tag, r)
+                assert same(D.biOut[r], E.biOut[r], ("mvHor", "mvVer", "mvPredHor", "mvPredVer", "mvpIdx", "bits", "cost")), ("bi", tag, r)
+            stats["bi"] += 1
+        # ---- the SMVD block ----
+        if fin.smvdRan:
+            assert hd.hasSmvd
+            j, e = D.smvd[0], E.smvd[0]
+            mvp = rate(lam, j.mvpIdxBits[j.trace[1].idx[0]] + j.mvpIdxBits[j.trace[1].idx[1]])
+            assert tuple(j.trace[1].mv) == tuple(e.trace[1].mv) and j.trace[1].cost - mvp == e.trace[1].cost, ("smvd start", tag)
+            assert [j.cand[0][j.trace[1].idx[0]][c] for c in (0, 1)] == list(e.predSym[0]) and [j.cand[1][j.trace[1].idx[1]][c] for c in (0, 1)] == list(e.predSym[1]), ("smvd predictors", tag)
+            assert tuple(j.trace[2].mv) == tuple(e.trace[2].mv) and j.trace[2].cost == e.trace[2].cost, ("smvd me", tag)
+            if e.trace[3].cost:      # the final predictor check ran in the reference (the search moved the vector)
+                assert j.trace[3].cost == e.trace[3].cost and tuple(j.trace[3].idx) == tuple(e.trace[3].idx), ("smvd final", tag)
+            stats["smvd"] += 1
+        # ---- what the member left in pu ----
+        bi = P.interDir == 3
+        dev_cost = P.costBi if bi else P.cost[1 if P.interDir == 2 else 0]
+        assert dev_cost == fin.hevcCost, ("best translational cost", tag, dev_cost, fin.hevcCost)
+        if not fin.affine:
+            assert P.interDir == fin.interDir and (not bi or bool(P.smvdMode) == bool(fin.smvdMode)), ("decision", tag)
+            for l in (0, 1):
+                if not P.interDir & (1 << l):
+                    continue
+                ref = P.refIdxBi[l] if bi else P.refIdx[l]
+                mv = tuple(P.mvBi[l]) if bi else tuple(P.mv[l])
+                if bi and P.smvdMode:
+                    idx, pred = D.smvd[0].mvpIdxSym[l], tuple(D.smvd[0].predSym[l])
+                elif bi and l == P.refineList:
+                    idx, pred = D.biRows[ref].mvpIdx, (D.biRows[ref].mvPredHor, D.biRows[ref].mvPredVer)
+                elif bi and hd.mvdL1Zero:
+                    idx, pred = P.mvpIdxL1Zero, mv
+                else:
+                    rw = D.uniRows[(n0 if l else 0) + ref]
+                    idx, pred = rw.mvpIdx, (rw.mvPredHor, rw.mvPredVer)
+                assert ref == fin.refIdx[l] and mv == tuple(fin.mv[l]) and (mv[0] - pred[0], mv[1] - pred[1]) == tuple(fin.mvd[l]) and idx == fin.mvpIdx[l], ("pu", tag, l)
+            stats["dirs"][P.interDir] += 1
+            stats["smvd_won"] += int(bi and P.smvdMode != 0)
+        else:
+            stats["affine_won"] += 1
+        stats["recs"] += 1
+        stats["imv"][hd.imv] += 1
+        stats["mvdl1zero"] += hd.mvdL1Zero
+    print("pis golden:", stats)
+    assert stats["recs"] >= 300 and stats["copies"] >= 100 and stats["cached"] >= 100 and stats["bi"] >= 200 and stats["smvd"] >= 30 and stats["mvdl1zero"] >= 100
+    assert min(stats["imv"][:3]) >= 20 and stats["dirs"][3] >= 50 and stats["dirs"][1] >= 20
+    ctx.close()

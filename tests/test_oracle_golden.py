@@ -281,3 +281,43 @@ def test_smvd_golden(oracle):
     for k, s in enumerate(z["jobs"]):
         j = json.loads(str(s))
         assert smvd_flat(me_util.smvd_member_results(scene, j, oracle, "vo_")) == z["out"][k].tolist(), (k, j)
+
+
+def test_oracle_members_on_real_encoder_records():
+    """tests/golden/pis_enc.npz (predInterSearch calls recorded INSIDE the real encoder, tests/golden/gen_pis_golden.py): the oracle's xEstimateMvPredAMVP and xMotionEstimation
+    on the encoder's own inputs -- real AMVP lists, m_uniMvList start vectors, block-vector cache hits (the fast-settings TZ path), the four AMVR modes, every PU shape the
+    encoder tried -- against what the reference's members returned there."""
+    import pis_golden as G
+    L = ol.oracle()
+    planes, recs = G.load_npz(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pis_enc.npz"))
+    dpb, bases = G.build_dpb(planes)
+    rows = cached = 0
+    for hd, sin, sout, org, fin in recs:
+        cfg = ol.MestCfg(hd.bipredSearchRange, hd.useHadME, hd.fen13, hd.extendedSettings, hd.firstSearchStop)
+        org = np.ascontiguousarray(org)
+        for row in range(hd.numRef[0] + hd.numRef[1]):
+            j, e, pl = sin.uniJobs[row], sout.uniJobs[row], planes[hd.rowPlane[row]][0]
+            t = ol.MestJob()
+            t.org, t.orgStride = org.ctypes.data, hd.w
+            t.ref, t.refStride = dpb.ctypes.data + 2 * (bases[hd.rowPlane[row]] + hd.rowOff[row]), pl.stride
+            t.w, t.h, t.puX, t.puY, t.picW, t.picH, t.ctuSize, t.bitDepth = hd.w, hd.h, j.puX, j.puY, hd.picW, hd.picH, hd.ctuSize, hd.bitDepth
+            t.bi, t.imv, t.numAmvpCand, t.searchRange, t.motionLambda = 0, hd.imv, j.numAmvpCand, j.searchRange, j.motionLambda
+            for i in range(2):
+                t.amvpCand[i][0], t.amvpCand[i][1], t.mvpIdxBits[i] = j.amvpCand[i][0], j.amvpCand[i][1], j.mvpIdxBits[i]
+            t.numExtraStart = j.numExtraStart
+            for i in range(j.numExtraStart):
+                t.extraStart[i][0], t.extraStart[i][1] = j.extraStart[i][0], j.extraStart[i][1]
+            idx, ph, pv, dist = C.c_int(), C.c_int(), C.c_int(), C.c_uint64()
+            L.vo_estimate_mvp_amvp(C.byref(t), C.byref(idx), C.byref(ph), C.byref(pv), C.byref(dist))
+            assert (idx.value, ph.value, pv.value, dist.value) == (e.mvpIdx, e.mvPredHor, e.mvPredVer, sout.distBiP[row]), ("amvp", hd.poc, hd.x, hd.y, hd.w, hd.h, row)
+            if not hd.rowCalls[row]:
+                continue
+            t.mvpIdx, t.mvPredHor, t.mvPredVer, t.bits = e.mvpIdx, e.mvPredHor, e.mvPredVer, e.bits      # the row as xMotionEstimation receives it
+            t.cachedIntMv, t.mvHor, t.mvVer = int(hd.rowCached[row]), j.mvHor, j.mvVer
+            r, o = ol.MestResult(), sout.uniOut[row]
+            L.vo_motion_estimation(C.byref(cfg), C.byref(t), C.byref(r))
+            assert (r.mvHor, r.mvVer, r.mvPredHor, r.mvPredVer, r.mvpIdx, r.bits, r.cost) == (o.mvHor, o.mvVer, o.mvPredHor, o.mvPredVer, o.mvpIdx, o.bits, o.cost), \
+                ("uni", hd.poc, hd.x, hd.y, hd.w, hd.h, hd.imv, row, hd.rowCached[row])
+            rows += 1
+            cached += hd.rowCached[row]
+    assert rows >= 450 and cached >= 300, (rows, cached)
