@@ -279,7 +279,8 @@ __device__ void affine_pred( const AffCtx &c, const Mv3 &m, int16_t *sPred )
 // getDistPart( DF_HAD / DF_SAD ) of prediction vs pattern over the block (tile shapes of xGetHADs: RdCost.cpp:2837-2931), block-wide sum.
 // packed (bitDepth <= 10: |pattern - prediction| <= 3 * 1023): a lane takes one 8x8 unit with the packed 16-bit Hadamard of had.hpp; the two halves of a
 // 16x8 / 8x16 tile sit in neighbouring lanes (units in pair order), each returns the finished tile value and the even lane counts it.
-__device__ unsigned long long block_dist( const int16_t *sPred, const int16_t *sPat, int w, int h, bool satd, unsigned long long *sRed, bool packed )
+template<bool packed>
+__device__ unsigned long long block_dist( const int16_t *sPred, const int16_t *sPat, int w, int h, bool satd, unsigned long long *sRed )
 {
   unsigned long long acc = 0;
   if( satd && packed )
@@ -309,7 +310,7 @@ __device__ unsigned long long block_dist( const int16_t *sPred, const int16_t *s
       else { const unsigned tv = satd8_pair_packed( D ); acc += ( u & 1 ) ? 0u : tv; }
     }
   }
-  else if( satd )
+  else if( satd && !packed )
   {
     const int tw = w > h ? 16 : 8, th = w < h ? 16 : 8, tx = w / tw, nt = tx * ( h / th );
     for( int t = threadIdx.x; t < nt; t += blockDim.x )
@@ -346,51 +347,95 @@ __device__ __forceinline__ unsigned affine_mv_bits( int six, int imv, const Mv3 
   return bits;
 }
 
-__device__ void solve_equal( double eq[7][7], int order, double *para )   // solveEqual (InterSearch.cpp:5215-5284), operation for operation
+// solveEqual (InterSearch.cpp:5215-5284), operation for operation; ORDER is a compile-time constant so that the system lives in registers (rows 1 .. ORDER, columns 0 .. ORDER)
+template<int ORDER>
+__device__ __forceinline__ void solve_equal( double eq[ORDER + 1][ORDER + 1], double *para )
 {
+  constexpr int order = ORDER;
+#pragma unroll
   for( int k = 0; k < order; k++ ) para[k] = 0.;
+#pragma unroll
   for( int i = 1; i < order; i++ )
   {
     double temp = fabs( eq[i][i - 1] );
     int    idx = i;
+#pragma unroll
     for( int j = i + 1; j < order + 1; j++ ) if( fabs( eq[j][i - 1] ) > temp ) { temp = fabs( eq[j][i - 1] ); idx = j; }
     if( idx != i )
-      for( int j = 0; j < order + 1; j++ ) { eq[0][j] = eq[i][j]; eq[i][j] = eq[idx][j]; eq[idx][j] = eq[0][j]; }
+    {
+      // the reference swaps rows i and idx through row 0 as scratch; the row index is data dependent, the columns are not
+#pragma unroll
+      for( int j = 0; j < order + 1; j++ )
+      {
+        double other = 0.;
+#pragma unroll
+        for( int r = 2; r < order + 1; r++ ) if( r == idx ) other = eq[r][j];
+        eq[0][j] = eq[i][j]; eq[i][j] = other;
+#pragma unroll
+        for( int r = 2; r < order + 1; r++ ) if( r == idx ) eq[r][j] = eq[0][j];
+      }
+    }
     if( eq[i][i - 1] == 0. ) return;
+#pragma unroll
     for( int j = i + 1; j < order + 1; j++ )
+#pragma unroll
       for( int k = i; k < order + 1; k++ ) eq[j][k] = eq[j][k] - eq[i][k] * eq[j][i - 1] / eq[i][i - 1];
   }
   if( eq[order][order - 1] == 0. ) return;
   para[order - 1] = eq[order][order] / eq[order][order - 1];
+#pragma unroll
   for( int i = order - 2; i >= 0; i-- )
   {
-    if( eq[i + 1][i] == 0. ) { for( int k = 0; k < order; k++ ) para[k] = 0.; return; }
+    if( eq[i + 1][i] == 0. )
+    {
+#pragma unroll
+      for( int k = 0; k < order; k++ ) para[k] = 0.;
+      return;
+    }
     double temp = 0;
+#pragma unroll
     for( int j = i + 1; j < order; j++ ) temp += eq[i + 1][j] * para[j];
     para[i] = ( eq[i + 1][order] - temp ) / eq[i + 1][i];
   }
 }
 
-__global__ __launch_bounds__( 256 ) void affine_me_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+__device__ __forceinline__ int uni( int v ) { return __builtin_amdgcn_readfirstlane( v ); }      // a block-uniform value: keep it on the scalar side
+__device__ __forceinline__ unsigned long long uni64( unsigned long long v )
+{
+  return ( ( unsigned long long ) ( unsigned ) __builtin_amdgcn_readfirstlane( ( int ) ( v >> 32 ) ) << 32 ) | ( unsigned ) __builtin_amdgcn_readfirstlane( ( int ) v );
+}
+__device__ __forceinline__ void uni_mv3( Mv3 &m ) { for( int i = 0; i < 3; i++ ) { m.v[i][0] = uni( m.v[i][0] ); m.v[i][1] = uni( m.v[i][1] ); } }
+
+// One job = one xAffineMotionEstimation (:5340-5775).  The member evaluates a SEQUENCE of models -- the start model, one per gradient iteration, then the control-point
+// refinement around the best -- and every evaluation is the same work: prediction (xPredAffineBlk), distortion, vector bits, strict comparison with the best so far.
+// The kernel is therefore ONE loop with one evaluation site; what differs per step is how the next model is produced (a small block-uniform state machine).  That keeps the
+// code a quarter of the size of the member written out call by call (the evaluation inlined at seven sites: 60 KB of code, more than the instruction cache two CUs share)
+// and the search state in scalar registers.  SIX: the 6-parameter model (3 control points, 6 x 6 normal equations); the 4-parameter kernel carries 4 x 4.
+// The normal equations are symmetric in their first NP columns ((int64) a * b commutes): the upper triangle is accumulated.
+template<bool SIX, bool PACKED>      // PACKED: bitDepth <= 10 (the distortion runs on packed 16-bit words; deeper samples take the 32-bit Hadamard tiles, a kernel of its own)
+__global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( PACKED ? 4 : 1 ) ) ) void affine_me_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
                                                           const int16_t *__restrict__ otherBase, const vtmhip_affine_me_job *__restrict__ jobs,
                                                           vtmhip_affine_me_out *__restrict__ results )
 {
+  constexpr int NP = SIX ? 6 : 4, NTRI = NP * ( NP + 1 ) / 2, NACC = NTRI + NP, MVNUM = SIX ? 3 : 2;
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sMem[];
   __shared__ unsigned long long sRed[4];
-  __shared__ long long          sAcc[4][42];
-  __shared__ Mv3                sMv;      // the model under test (written by thread 0)
+  __shared__ long long          sAcc[4][NACC];
+  __shared__ Mv3                sMv;      // the model of the next gradient step (written by thread 0)
+  __shared__ Mv3                sPrev[7]; // models of the earlier gradient steps (thread 0; the AMVR encoder option compares against them)
   __shared__ int                sCtl;     // loop control of the gradient iterations: 0 continue, 1 stop
   const vtmhip_affine_me_job &j = jobs[blockIdx.x];
-  const int w = j.width, h = j.height, six = j.sixParam, mvNum = six ? 3 : 2, np = six ? 6 : 4;
+  if( ( j.sixParam != 0 ) != SIX ) return;      // a mixed batch is launched once per model; every job belongs to exactly one of the two launches
+  const int w = j.width, h = j.height;
   int16_t  *sPat = sMem, *sPred = sMem + w * h;
   AffCtx c;
-  c.ref = refBase + j.refOff; c.refStride = j.refStride; c.w = w; c.h = h; c.bd = pic.bitDepth; c.six = six; c.interDir = j.interDir; c.imv = j.imv;
+  c.ref = refBase + j.refOff; c.refStride = j.refStride; c.w = w; c.h = h; c.bd = pic.bitDepth; c.six = SIX; c.interDir = j.interDir; c.imv = j.imv;
   c.horMax = ( pic.picW + 8 - j.puX - 1 ) << 4; c.horMin = ( -pic.ctuSize - 8 - j.puX + 1 ) << 4;
   c.verMax = ( pic.picH + 8 - j.puY - 1 ) << 4; c.verMin = ( -pic.ctuSize - 8 - j.puY + 1 ) << 4;
   c.profAllowed = j.profAllowed != 0; c.profLarge = j.profNeedsLargeGrad != 0; c.profIsBi = j.profIsBi != 0;
   const bool   bi = j.bi != 0, satd = j.useSatd != 0;
   const double fWeight = bi ? 0.5 : 1.0, lam = j.motionLambda;
-  const int    rsTab[3] = { 2, 0, 4 };
+  const int    imv = j.imv, rs = imv == 0 ? 2 : imv == 1 ? 0 : 4;      // (rsTab of the reference: MV_PRECISION of the AMVR mode)
   // pattern: org, or 2*org - otherPred (removeHighFreq, unclipped)
   {
     const int16_t *o = orgBase + j.orgOff, *p = bi ? otherBase + j.otherPredOff : nullptr;
@@ -404,202 +449,228 @@ __global__ __launch_bounds__( 256 ) void affine_me_kernel( vtmhip_pic_params pic
   int pred[3][2];
   for( int i = 0; i < 3; i++ ) { pred[i][0] = j.mvPred[i][0]; pred[i][1] = j.mvPred[i][1]; }
 
-  Mv3 tmp, best;
+  Mv3 tmp, best, cand, me, base;
+  int center[2] = { 0, 0 }, dMv[2] = { 0, 0 };
   for( int i = 0; i < 3; i++ ) { tmp.v[i][0] = j.mv[i][0]; tmp.v[i][1] = j.mv[i][1]; }
-  for( int i = 0; i < mvNum; i++ )
+  for( int i = 0; i < MVNUM; i++ )
   {
     tmp.v[i][0] = clip3( c.horMin, c.horMax, tmp.v[i][0] ); tmp.v[i][1] = clip3( c.verMin, c.verMax, tmp.v[i][1] );
-    const int rs = rsTab[j.imv];
     tmp.v[i][0] = prec_dn( tmp.v[i][0], rs ) << rs; tmp.v[i][1] = prec_dn( tmp.v[i][1], rs ) << rs;   // roundAffinePrecInternal2Amvr
   }
-  __syncthreads();
-  affine_pred( c, tmp, sPred );
-  __syncthreads();
-  unsigned long long costBest = block_dist( sPred, sPat, w, h, satd, sRed, pic.bitDepth <= 10 );
-  unsigned           bitsBest = j.bits + affine_mv_bits( six, j.imv, tmp, pred );
-  costBest = ( unsigned long long ) ( floor( fWeight * ( double ) costBest ) + ( double ) ( unsigned long long ) ( lam * bitsBest ) );
-  best = tmp;
-  int iterTime = six ? ( bi ? 3 : 4 ) : ( bi ? 3 : 5 );
+  best = me = base = cand = tmp;
+  unsigned long long costBest = ~0ull;
+  unsigned           bitsBest = 0;
+  int iterTime = SIX ? ( bi ? 3 : 4 ) : ( bi ? 3 : 5 );
   if( !j.useAffineType ) iterTime = bi ? 5 : 7;
+  const int maxRound = imv ? 3 : ( ( j.amvrEncOpt && j.lowDelayRounds ) ? 2 : 3 );
   int iterations = 0, refinements = 0;
-  Mv3 prev[7];
+  enum { P_INIT, P_ITER, P_REF_START, P_C1, P_C2, P_C3, P_RND, P_DONE };
+  int  phase = P_INIT, iter = 0, k = 0, it = 0, pos = 0, rnd = 0;
+  bool modelChange = false, loopChange = false;
+  __syncthreads();
 
-  for( int iter = 0; iter < iterTime; iter++ )
+#pragma unroll 1
+  while( phase != P_DONE )
   {
-    prev[iter] = tmp;
-    // ---- normal equations from the error and the Sobel gradients of the prediction (exact 64-bit sums) ----
-    long long acc[42];
-#pragma unroll
-    for( int i = 0; i < 42; i++ ) acc[i] = 0;
-    for( int i = threadIdx.x; i < w * h; i += blockDim.x )
+    bool have = false;
+    const int cur = phase;
+    if( phase == P_INIT ) { cand = tmp; have = true; }
+    else if( phase == P_ITER )
     {
-      const int y = i / w, x = i - y * w;
-      const int yc = min( h - 2, max( 1, y ) ), xc = min( w - 2, max( 1, x ) );
-      const int16_t *q = sPred + yc * w + xc;
-      const int a = q[1 - w] - q[-1 - w] + ( q[1] << 1 ) - ( q[-1] << 1 ) + q[1 + w] - q[-1 + w];
-      const int b = q[w - 1] - q[-w - 1] + ( q[w] << 1 ) - ( q[-w] << 1 ) + q[w + 1] - q[-w + 1];
-      const int e = ( int ) ( int16_t ) ( sPat[i] - sPred[i] );
-      const int cy = ( ( y >> 2 ) << 2 ) + 2, cx = ( ( x >> 2 ) << 2 ) + 2;
-      int       cc[6];
-      if( !six ) { cc[0] = a; cc[1] = cx * a + cy * b; cc[2] = b; cc[3] = cy * a - cx * b; cc[4] = 0; cc[5] = 0; }
-      else { cc[0] = a; cc[1] = cx * a; cc[2] = b; cc[3] = cx * b; cc[4] = cy * a; cc[5] = cy * b; }
+      if( iter >= iterTime ) { phase = P_REF_START; continue; }
+      // ---- normal equations from the error and the Sobel gradients of the current prediction (exact 64-bit sums) ----
+      long long acc[NACC];
 #pragma unroll
-      for( int col = 0; col < 6; col++ )
-        if( col < np )
+      for( int i = 0; i < NACC; i++ ) acc[i] = 0;
+      for( int i = threadIdx.x; i < w * h; i += blockDim.x )
+      {
+        const int y = i / w, x = i - y * w;
+        const int yc = min( h - 2, max( 1, y ) ), xc = min( w - 2, max( 1, x ) );
+        const int16_t *q = sPred + yc * w + xc;
+        const int a = q[1 - w] - q[-1 - w] + ( q[1] << 1 ) - ( q[-1] << 1 ) + q[1 + w] - q[-1 + w];
+        const int b = q[w - 1] - q[-w - 1] + ( q[w] << 1 ) - ( q[-w] << 1 ) + q[w + 1] - q[-w + 1];
+        const int e = ( int ) ( int16_t ) ( sPat[i] - sPred[i] );
+        const int cy = ( ( y >> 2 ) << 2 ) + 2, cx = ( ( x >> 2 ) << 2 ) + 2;
+        int       cc[NP];
+        if( !SIX ) { cc[0] = a; cc[1] = cx * a + cy * b; cc[2] = b; cc[3] = cy * a - cx * b; }
+        else { cc[0] = a; cc[1] = cx * a; cc[2] = b; cc[3] = cx * b; cc[4] = cy * a; cc[5] = cy * b; }
+        int t = 0;
+#pragma unroll
+        for( int col = 0; col < NP; col++ )
         {
 #pragma unroll
-          for( int row = 0; row < 6; row++ )
-            if( row < np ) acc[col * 7 + row] += ( long long ) cc[col] * cc[row];
-          acc[col * 7 + 6] += ( ( long long ) cc[col] * e ) << 3;
+          for( int row = col; row < NP; row++ ) acc[t++] += ( long long ) cc[col] * cc[row];
+          acc[NTRI + col] += ( ( long long ) cc[col] * e ) << 3;
         }
-    }
+      }
 #pragma unroll
-    for( int col = 0; col < 6; col++ )
-      if( col < np )   // only the entries the model has: 20 of 42 for four parameters
+      for( int i = 0; i < NACC; i++ ) acc[i] = ( long long ) wave_reduce_add_u64( ( unsigned long long ) acc[i] );
+      if( ( threadIdx.x & 63 ) == 0 )
       {
 #pragma unroll
-        for( int row = 0; row < 7; row++ )
-          if( row < np || row == 6 ) acc[col * 7 + row] = ( long long ) wave_reduce_add_u64( ( unsigned long long ) acc[col * 7 + row] );
+        for( int i = 0; i < NACC; i++ ) sAcc[threadIdx.x >> 6][i] = acc[i];
       }
-    if( ( threadIdx.x & 63 ) == 0 )
-    {
+      __syncthreads();
+      if( threadIdx.x == 0 )
+      {
+        sPrev[iter] = tmp;
+        double deq[NP + 1][NP + 1];
 #pragma unroll
-      for( int i = 0; i < 42; i++ ) sAcc[threadIdx.x >> 6][i] = acc[i];
-    }
-    __syncthreads();
-    if( threadIdx.x == 0 )
-    {
-      double deq[7][7];
-      for( int r = 0; r < 7; r++ ) for( int q = 0; q < 7; q++ ) deq[r][q] = 0.;
-      for( int col = 0; col < np; col++ )
-        for( int row = 0; row <= np; row++ )
+        for( int r = 0; r <= NP; r++ )
+#pragma unroll
+          for( int q = 0; q <= NP; q++ ) deq[r][q] = 0.;
         {
-          const int       src = row < np ? col * 7 + row : col * 7 + 6;
-          long long       v   = sAcc[0][src];
-          for( int wv = 1; wv < ( int ) ( blockDim.x >> 6 ); wv++ ) v += sAcc[wv][src];
-          deq[col + 1][row] = ( double ) v;
-        }
-      double para[6], dmv[6] = { 0, 0, 0, 0, 0, 0 };
-      solve_equal( deq, np, para );
-      dmv[0] = para[0]; dmv[2] = para[2];
-      if( six ) { dmv[1] = para[1] * w + para[0]; dmv[3] = para[3] * w + para[2]; dmv[4] = para[4] * h + para[0]; dmv[5] = para[5] * h + para[2]; }
-      else { dmv[1] = para[1] * w + para[0]; dmv[3] = -para[3] * w + para[2]; }
-      const int normShift[3] = { 2, 4, 2 }, stepShift[3] = { 2, 0, 2 };
-      const int mult = 1 << normShift[j.imv], ms = stepShift[j.imv];
-#define SGN( x ) ( ( x ) >= 0 ? 1 : -1 )
-      int delta[3][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 } };
-      delta[0][0] = ( int ) ( dmv[0] * mult + SGN( dmv[0] ) * 0.5 ) << ms; delta[0][1] = ( int ) ( dmv[2] * mult + SGN( dmv[2] ) * 0.5 ) << ms;
-      delta[1][0] = ( int ) ( dmv[1] * mult + SGN( dmv[1] ) * 0.5 ) << ms; delta[1][1] = ( int ) ( dmv[3] * mult + SGN( dmv[3] ) * 0.5 ) << ms;
-      if( six ) { delta[2][0] = ( int ) ( dmv[4] * mult + SGN( dmv[4] ) * 0.5 ) << ms; delta[2][1] = ( int ) ( dmv[5] * mult + SGN( dmv[5] ) * 0.5 ) << ms; }
-#undef SGN
-      int stop = 0;
-      if( !j.amvrEncOpt )
-      {
-        bool allZero = false;
-        for( int i = 0; i < mvNum; i++ )
-        {
-          int d0 = delta[i][0], d1 = delta[i][1];
-          if( j.imv == 2 ) { d0 = prec_dn( d0, 3 ) << 3; d1 = prec_dn( d1, 3 ) << 3; }
-          if( d0 != 0 || d1 != 0 ) { allZero = false; break; }
-          allZero = true;
-        }
-        if( allZero ) stop = 1;
-      }
-      Mv3 nt = tmp;
-      if( !stop )
-      {
-        const int rs = rsTab[j.imv];
-        for( int i = 0; i < mvNum; i++ )
-        {
-          nt.v[i][0] = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, nt.v[i][0] + delta[i][0] );
-          nt.v[i][1] = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, nt.v[i][1] + delta[i][1] );
-          nt.v[i][0] = prec_dn( nt.v[i][0], rs ) << rs; nt.v[i][1] = prec_dn( nt.v[i][1], rs ) << rs;
-          nt.v[i][0] = clip3( c.horMin, c.horMax, nt.v[i][0] ); nt.v[i][1] = clip3( c.verMin, c.verMax, nt.v[i][1] );
-        }
-        if( j.amvrEncOpt )
-          for( int k = iter; k >= 0; k-- )
-            if( nt.v[0][0] == prev[k].v[0][0] && nt.v[0][1] == prev[k].v[0][1] && nt.v[1][0] == prev[k].v[1][0] && nt.v[1][1] == prev[k].v[1][1] )
-            {
-              const bool same = six ? ( nt.v[2][0] == prev[k].v[2][0] && nt.v[2][1] == prev[k].v[2][1] ) : true;
-              if( same ) { stop = 1; break; }
-            }
-      }
-      sMv = nt; sCtl = stop;
-    }
-    __syncthreads();
-    const int stop = sCtl;
-    tmp = sMv;
-    __syncthreads();
-    if( stop ) break;
-    affine_pred( c, tmp, sPred );
-    __syncthreads();
-    iterations++;
-    unsigned long long cost = block_dist( sPred, sPat, w, h, satd, sRed, pic.bitDepth <= 10 );
-    const unsigned     bits = j.bits + affine_mv_bits( six, j.imv, tmp, pred );
-    cost = ( unsigned long long ) ( floor( fWeight * ( double ) cost ) + ( double ) ( unsigned long long ) ( lam * bits ) );
-    if( cost < costBest ) { costBest = cost; bitsBest = bits; best = tmp; }
-  }
-
-  // ---- control-point refinement (:5655-5765); every thread evaluates the same model, so the control flow is block-uniform ----
-  auto check = [&]( const Mv3 &m ) -> bool {
-    affine_pred( c, m, sPred );
-    __syncthreads();
-    refinements++;
-    unsigned long long cost = block_dist( sPred, sPat, w, h, satd, sRed, pic.bitDepth <= 10 );
-    const unsigned     bits = j.bits + affine_mv_bits( six, j.imv, m, pred );
-    cost = ( unsigned long long ) ( floor( fWeight * ( double ) cost ) + ( double ) ( unsigned long long ) ( lam * bits ) );
-    if( cost < costBest ) { costBest = cost; bitsBest = bits; best = m; return true; }
-    return false;
-  };
-  if( ( double ) costBest <= 1.0 * ( double ) j.hevcCost )   // AFFINE_ME_LIST_MVP_TH * m_hevcCost
-  {
-    const Mv3 me = best;
-    const int dMv[2] = { me.v[0][0] - pred[0][0], me.v[0][1] - pred[0][1] };
-    for( int k = 0; k < mvNum; k++ )
-    {
-      const int ph = pred[k][0] + ( k ? dMv[0] : 0 ), pv = pred[k][1] + ( k ? dMv[1] : 0 );
-      if( me.v[k][0] != ph || me.v[k][1] != pv )
-      {
-        tmp = me; tmp.v[k][0] = ph; tmp.v[k][1] = pv;
-        check( tmp );
-      }
-    }
-    if( me.v[0][0] != pred[0][0] || me.v[0][1] != pred[0][1] )
-    {
-      tmp = me;
-      for( int i = 1; i < mvNum; i++ ) { tmp.v[i][0] -= dMv[0]; tmp.v[i][1] -= dMv[1]; }
-      tmp.v[0][0] = pred[0][0]; tmp.v[0][1] = pred[0][1];
-      check( tmp );
-    }
-    if( six && ( me.v[1][0] != pred[1][0] + dMv[0] || me.v[1][1] != pred[1][1] + dMv[1] ) && ( me.v[2][0] != pred[2][0] + dMv[0] || me.v[2][1] != pred[2][1] + dMv[1] ) )
-    {
-      tmp = me;
-      tmp.v[1][0] = pred[1][0] + dMv[0]; tmp.v[1][1] = pred[1][1] + dMv[1]; tmp.v[2][0] = pred[2][0] + dMv[0]; tmp.v[2][1] = pred[2][1] + dMv[1];
-      check( tmp );
-    }
-    const int testPos[8][2] = { { -1, 0 }, { 0, -1 }, { 0, 1 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, 1 }, { 1, -1 } };
-    const int mvShift = rsTab[j.imv];
-    const int maxRound = j.imv ? 3 : ( ( j.amvrEncOpt && j.lowDelayRounds ) ? 2 : 3 );
-    for( int rnd = 0; rnd < maxRound; rnd++ )
-    {
-      bool modelChange = false;
-      for( int k = 0; k < mvNum; k++ )
-      {
-        bool loopChange = false;
-        for( int it = 0; it < 2; it++ )
-        {
-          if( it == 1 && !loopChange ) break;
-          const Mv3 center = best;
-          tmp = best;
-          for( int i = it == 0 ? 0 : 4; i < ( it == 0 ? 4 : 8 ); i++ )
+          int t = 0;
+#pragma unroll
+          for( int col = 0; col < NP; col++ )
           {
-            tmp.v[k][0] = clip3( c.horMin, c.horMax, center.v[k][0] + ( testPos[i][0] << mvShift ) );
-            tmp.v[k][1] = clip3( c.verMin, c.verMax, center.v[k][1] + ( testPos[i][1] << mvShift ) );
-            if( check( tmp ) ) { modelChange = true; loopChange = true; }
+#pragma unroll
+            for( int row = col; row < NP; row++ )
+            {
+              long long v = sAcc[0][t];
+              for( int wv = 1; wv < ( int ) ( blockDim.x >> 6 ); wv++ ) v += sAcc[wv][t];
+              deq[col + 1][row] = ( double ) v; deq[row + 1][col] = ( double ) v;
+              t++;
+            }
+            long long v = sAcc[0][NTRI + col];
+            for( int wv = 1; wv < ( int ) ( blockDim.x >> 6 ); wv++ ) v += sAcc[wv][NTRI + col];
+            deq[col + 1][NP] = ( double ) v;
+          }
+        }
+        double para[NP], dmv[6] = { 0, 0, 0, 0, 0, 0 };
+        solve_equal<NP>( deq, para );
+        dmv[0] = para[0]; dmv[2] = para[2];
+        if( SIX ) { dmv[1] = para[1] * w + para[0]; dmv[3] = para[3] * w + para[2]; dmv[4] = para[NP - 2] * h + para[0]; dmv[5] = para[NP - 1] * h + para[2]; }
+        else { dmv[1] = para[1] * w + para[0]; dmv[3] = -para[3] * w + para[2]; }
+        const int mult = 1 << ( imv == 1 ? 4 : 2 ), ms = imv == 1 ? 0 : 2;      // normShift / stepShift of the reference
+#define SGN( x ) ( ( x ) >= 0 ? 1 : -1 )
+        int delta[3][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 } };
+        delta[0][0] = ( int ) ( dmv[0] * mult + SGN( dmv[0] ) * 0.5 ) << ms; delta[0][1] = ( int ) ( dmv[2] * mult + SGN( dmv[2] ) * 0.5 ) << ms;
+        delta[1][0] = ( int ) ( dmv[1] * mult + SGN( dmv[1] ) * 0.5 ) << ms; delta[1][1] = ( int ) ( dmv[3] * mult + SGN( dmv[3] ) * 0.5 ) << ms;
+        if( SIX ) { delta[2][0] = ( int ) ( dmv[4] * mult + SGN( dmv[4] ) * 0.5 ) << ms; delta[2][1] = ( int ) ( dmv[5] * mult + SGN( dmv[5] ) * 0.5 ) << ms; }
+#undef SGN
+        int stop = 0;
+        if( !j.amvrEncOpt )
+        {
+          bool allZero = false;
+          for( int i = 0; i < MVNUM; i++ )
+          {
+            int d0 = delta[i][0], d1 = delta[i][1];
+            if( imv == 2 ) { d0 = prec_dn( d0, 3 ) << 3; d1 = prec_dn( d1, 3 ) << 3; }
+            if( d0 != 0 || d1 != 0 ) { allZero = false; break; }
+            allZero = true;
+          }
+          if( allZero ) stop = 1;
+        }
+        Mv3 nt = tmp;
+        if( !stop )
+        {
+          for( int i = 0; i < MVNUM; i++ )
+          {
+            nt.v[i][0] = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, nt.v[i][0] + delta[i][0] );
+            nt.v[i][1] = clip3( -( 1 << 17 ), ( 1 << 17 ) - 1, nt.v[i][1] + delta[i][1] );
+            nt.v[i][0] = prec_dn( nt.v[i][0], rs ) << rs; nt.v[i][1] = prec_dn( nt.v[i][1], rs ) << rs;
+            nt.v[i][0] = clip3( c.horMin, c.horMax, nt.v[i][0] ); nt.v[i][1] = clip3( c.verMin, c.verMax, nt.v[i][1] );
+          }
+          if( j.amvrEncOpt )
+            for( int q = iter; q >= 0; q-- )
+              if( nt.v[0][0] == sPrev[q].v[0][0] && nt.v[0][1] == sPrev[q].v[0][1] && nt.v[1][0] == sPrev[q].v[1][0] && nt.v[1][1] == sPrev[q].v[1][1] )
+              {
+                const bool same = SIX ? ( nt.v[2][0] == sPrev[q].v[2][0] && nt.v[2][1] == sPrev[q].v[2][1] ) : true;
+                if( same ) { stop = 1; break; }
+              }
+        }
+        sMv = nt; sCtl = stop;
+      }
+      __syncthreads();
+      const int stop = uni( sCtl );
+      tmp = sMv;
+      uni_mv3( tmp );
+      __syncthreads();
+      iter++;
+      if( stop ) { phase = P_REF_START; continue; }
+      cand = tmp; have = true;
+    }
+    else if( phase == P_REF_START )
+    {
+      if( !( ( double ) costBest <= 1.0 * ( double ) j.hevcCost ) ) break;      // AFFINE_ME_LIST_MVP_TH * m_hevcCost
+      me = best; dMv[0] = me.v[0][0] - pred[0][0]; dMv[1] = me.v[0][1] - pred[0][1];
+      k = 0; phase = P_C1;
+      continue;
+    }
+    else if( phase == P_C1 )      // each control point at its predictor (:5655-5671)
+    {
+      if( k >= MVNUM ) { phase = P_C2; continue; }
+      const int kk = k++;
+      const int ph = pred[kk][0] + ( kk ? dMv[0] : 0 ), pv = pred[kk][1] + ( kk ? dMv[1] : 0 );
+      if( me.v[kk][0] != ph || me.v[kk][1] != pv ) { cand = me; cand.v[kk][0] = ph; cand.v[kk][1] = pv; have = true; }
+    }
+    else if( phase == P_C2 )
+    {
+      phase = P_C3;
+      if( me.v[0][0] != pred[0][0] || me.v[0][1] != pred[0][1] )
+      {
+        cand = me;
+        for( int i = 1; i < MVNUM; i++ ) { cand.v[i][0] -= dMv[0]; cand.v[i][1] -= dMv[1]; }
+        cand.v[0][0] = pred[0][0]; cand.v[0][1] = pred[0][1];
+        have = true;
+      }
+    }
+    else if( phase == P_C3 )
+    {
+      phase = P_RND; rnd = 0; k = 0; it = 0; pos = 0; modelChange = false; loopChange = false;
+      if( SIX && ( me.v[1][0] != pred[1][0] + dMv[0] || me.v[1][1] != pred[1][1] + dMv[1] ) && ( me.v[2][0] != pred[2][0] + dMv[0] || me.v[2][1] != pred[2][1] + dMv[1] ) )
+      {
+        cand = me;
+        cand.v[1][0] = pred[1][0] + dMv[0]; cand.v[1][1] = pred[1][1] + dMv[1]; cand.v[2][0] = pred[2][0] + dMv[0]; cand.v[2][1] = pred[2][1] + dMv[1];
+        have = true;
+      }
+    }
+    else      // P_RND: rounds x control points x { the four direct, then (if one of them won) the four diagonal neighbours } (:5696-5765)
+    {
+      if( pos == 0 ) { base = best; center[0] = best.v[k][0]; center[1] = best.v[k][1]; }
+      const int idx = it * 4 + pos;
+      const int tx = idx == 0 || idx == 4 || idx == 5 ? -1 : idx == 3 || idx == 6 || idx == 7 ? 1 : 0;           // testPos { -1,0 } { 0,-1 } { 0,1 } { 1,0 } { -1,-1 } { -1,1 } { 1,1 } { 1,-1 }
+      const int ty = idx == 1 || idx == 4 || idx == 7 ? -1 : idx == 2 || idx == 5 || idx == 6 ? 1 : 0;
+      cand = base;
+      cand.v[k][0] = clip3( c.horMin, c.horMax, center[0] + ( tx << rs ) );
+      cand.v[k][1] = clip3( c.verMin, c.verMax, center[1] + ( ty << rs ) );
+      have = true;
+    }
+    if( !have ) continue;
+
+    // ---- the one evaluation site: prediction, distortion, bits, comparison ----
+    affine_pred( c, cand, sPred );
+    __syncthreads();
+    unsigned long long cost = uni64( block_dist<PACKED>( sPred, sPat, w, h, satd, sRed ) );
+    const unsigned     bits = j.bits + affine_mv_bits( SIX, imv, cand, pred );
+    cost = ( unsigned long long ) ( floor( fWeight * ( double ) cost ) + ( double ) ( unsigned long long ) ( lam * bits ) );
+    const bool better = cur == P_INIT || cost < costBest;
+    if( better ) { costBest = cost; bitsBest = bits; best = cand; }
+    if( cur == P_INIT ) phase = P_ITER;
+    else if( cur == P_ITER ) iterations++;
+    else
+    {
+      refinements++;
+      if( cur == P_RND )
+      {
+        if( better ) { modelChange = true; loopChange = true; }
+        if( ++pos == 4 )
+        {
+          pos = 0;
+          if( it == 0 && loopChange ) it = 1;
+          else
+          {
+            it = 0; loopChange = false;
+            if( ++k == MVNUM )
+            {
+              k = 0;
+              if( !modelChange || ++rnd == maxRound ) phase = P_DONE;
+              modelChange = false;
+            }
           }
         }
       }
-      if( !modelChange ) break;
     }
   }
   if( threadIdx.x == 0 )
@@ -642,9 +713,11 @@ static int check_affine_args( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, int
   return VTMHIP_OK;
 }
 
-int vtmhip_xAffineMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
-                                              const int16_t *d_otherPredBase, const vtmhip_affine_me_job *d_jobs, int n, int maxWidth, int maxHeight,
-                                              vtmhip_affine_me_out *d_results )
+}   // extern "C"
+
+// models: 0 = the caller knows every job is 4-parameter, 1 = every job 6-parameter, -1 = unknown / mixed (both launches; a job runs in the launch of its own model)
+int vtmhip_internal_affine_me_launch( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, const int16_t *d_otherPredBase,
+                                      const vtmhip_affine_me_job *d_jobs, int n, int maxWidth, int maxHeight, vtmhip_affine_me_out *d_results, int models )
 {
   VTMHIP_CHECK_CTX( ctx );
   int st = check_affine_args( ctx, pic, n, maxWidth, maxHeight );
@@ -652,14 +725,42 @@ int vtmhip_xAffineMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_
   if( n == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, d_orgBase && d_refBase && d_jobs && d_results, "null pointer" );
   const size_t lds = 2 * ( size_t ) maxWidth * maxHeight * sizeof( int16_t );
-  if( lds > 48 * 1024 ) VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( affine_me_kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
+  const bool packed = pic->bitDepth <= 10;
+  const void *k4 = packed ? reinterpret_cast<const void *>( affine_me_kernel<false, true> ) : reinterpret_cast<const void *>( affine_me_kernel<false, false> );
+  const void *k6 = packed ? reinterpret_cast<const void *>( affine_me_kernel<true, true> ) : reinterpret_cast<const void *>( affine_me_kernel<true, false> );
+  if( lds > 48 * 1024 )
+  {
+    VTMHIP_HIP( ctx, hipFuncSetAttribute( k4, hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
+    VTMHIP_HIP( ctx, hipFuncSetAttribute( k6, hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
+  }
   VTMHIP_TIME_KERNEL( ctx, "affine_me_kernel" );
   // one wave per job up to 32x32 (64 4x4 sub-blocks: a lane each), four waves above: the model iterations are a serial chain per job, so small blocks gain
   // from four times as many jobs in flight, not from idle lanes
   const int threads = maxWidth * maxHeight <= 1024 ? 64 : 256;
-  hipLaunchKernelGGL( affine_me_kernel, dim3( n ), dim3( threads ), lds, ctx->stream, *pic, d_orgBase, d_refBase, d_otherPredBase ? d_otherPredBase : d_orgBase, d_jobs, d_results );
+  const int sel = models;
+  const int16_t *oth = d_otherPredBase ? d_otherPredBase : d_orgBase;
+  if( packed )
+  {
+    if( sel != 1 ) hipLaunchKernelGGL( ( affine_me_kernel<false, true> ), dim3( n ), dim3( threads ), lds, ctx->stream, *pic, d_orgBase, d_refBase, oth, d_jobs, d_results );
+    if( sel != 0 ) hipLaunchKernelGGL( ( affine_me_kernel<true, true> ), dim3( n ), dim3( threads ), lds, ctx->stream, *pic, d_orgBase, d_refBase, oth, d_jobs, d_results );
+  }
+  else
+  {
+    if( sel != 1 ) hipLaunchKernelGGL( ( affine_me_kernel<false, false> ), dim3( n ), dim3( threads ), lds, ctx->stream, *pic, d_orgBase, d_refBase, oth, d_jobs, d_results );
+    if( sel != 0 ) hipLaunchKernelGGL( ( affine_me_kernel<true, false> ), dim3( n ), dim3( threads ), lds, ctx->stream, *pic, d_orgBase, d_refBase, oth, d_jobs, d_results );
+  }
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
+}
+
+extern "C"
+{
+
+int vtmhip_xAffineMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                              const int16_t *d_otherPredBase, const vtmhip_affine_me_job *d_jobs, int n, int maxWidth, int maxHeight,
+                                              vtmhip_affine_me_out *d_results )
+{
+  return vtmhip_internal_affine_me_launch( ctx, pic, d_orgBase, d_refBase, d_otherPredBase, d_jobs, n, maxWidth, maxHeight, d_results, -1 );
 }
 
 int vtmhip_xPredAffineBlk_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_refBase, int16_t *d_dstBase, const vtmhip_affine_me_job *d_jobs, int n,

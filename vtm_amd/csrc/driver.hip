@@ -98,7 +98,7 @@ int run_rest( vtmhip_ctx *ctx, const vtmhip_pis_level_run &L, const vtmhip_pis_b
     const int rows = ( L.pis.numRef[0] + L.pis.numRef[1] ) * n;
     st = vtmhip_pis_stage( ctx, &L.pis, 4 );
     if( st ) return st;
-    st = vtmhip_xAffineMotionEstimation_batch_dev( ctx, &L.pic, b.org, b.dpb, nullptr, L.pis.affJobs, rows, w, h, L.affOut );
+    st = vtmhip_internal_affine_me_launch( ctx, &L.pic, b.org, b.dpb, nullptr, L.pis.affJobs, rows, w, h, L.affOut, 0 );      // stage 4 writes 4-parameter jobs
     if( st ) return st;
   }
   // luma TU chains: runs of consecutive candidates with a real transform go to the uniform kernel in one launch, transform skip to its own kernel
