@@ -210,6 +210,13 @@ int vtmhip_masked_sad_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, cons
 int vtmhip_dist_uniform_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_curBase, const vtmhip_dist_job *d_jobs, int n,
                                    int kind, int width, int height, int subShift, uint64_t *d_dist );
 
+/* Intra mode pre-selection (IntraSearch::estIntraPredLumaQT, EncoderLib/IntraSearch.cpp:555-592: per tested mode `min( 2 * SAD, SATD )` of the mode's prediction against
+ * the original block -- the same DistParam::distFunc slots as the inter path): the N candidate predictions of ONE block in one call.  The host forms the predictors
+ * (predIntraAng: angular / planar / DC with PDPC, reference smoothing -- not part of this library) as N consecutive width x height blocks (stride = width) at d_predBase +
+ * predOff; the original block sits at d_orgBase + orgOff.  d_dist[0 .. N) = the SADs, d_dist[N .. 2N) = the SATDs (xGetHADs tile rules), in candidate order. */
+int vtmhip_intra_cand_cost_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, int64_t orgOff, int orgStride, const int16_t *d_predBase, int64_t predOff, int n, int width,
+                                      int height, uint64_t *d_dist );
+
 /* SATD 8x8 block-grid micro-benchmark: every 8-aligned 8x8 block of the W x H org picture against the
  * reference picture displaced by (dx,dy) in [-r,r]^2.  d_ref must carry >= r samples of valid margin on every side.
  * d_dist[(by*(W/8)+bx)*(2r+1)^2 + (dy+r)*(2r+1) + (dx+r)], 32-bit (an 8x8 SATD of int16 samples fits). */

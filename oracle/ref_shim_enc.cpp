@@ -63,6 +63,10 @@ struct RefEncStats
   int32_t  pisFirstMismatch[8];
   uint64_t pisNs[4];            // wall time: [0] gather + compare, [1] upload + device + download, [2] the member over the tables, [3] the member where the device was not used
   uint64_t affineNs[2];         // xAffineMotionEstimation hook: [0] the reference's member (0 in replace mode), [1] + gather + device
+  // the SATD pre-selection of IntraSearch::estIntraPredLumaQT as one vtmhip_intra_cand_cost_batch_dev call per CU (oracle/ref_shim_intra.hpp): [0] pre-selections seen,
+  // [1] batched on the device, [2] (unused), [3] served calls refused because the reference's prediction differed from the batch's
+  uint64_t intraBatches[4], intraServed, intraMismatch;
+  int32_t  intraFirstMismatch[8];
 };
 }
 
@@ -132,6 +136,8 @@ inline void note_mismatch( int family, int a, int b, int c, int d, long long ref
 }
 
 // ---- distortion ------------------------------------------------------------------------------------------------------------
+bool intraServe( const DistParam &p, int kind, FpDistFunc orig, Distortion &out );      // oracle/ref_shim_intra.hpp
+extern bool g_intraLive;
 FpDistFunc g_distOrig[DF_TOTAL_FUNCTIONS];
 uint64_t   g_distCtr[DF_TOTAL_FUNCTIONS];
 
@@ -139,6 +145,11 @@ template<int IDX> Distortion distTramp( const DistParam &p )
 {
   constexpr int kind = ( IDX >= DF_HAD && IDX <= DF_HAD16N ) ? 1 : ( IDX >= DF_SSE && IDX <= DF_SSE16N ) ? 2 : IDX == DF_SAD_WITH_MASK ? 3 : 0;
   g_st->calls[0]++;
+  if( g_intraLive && kind <= 1 && !p.applyWeight && !p.useMR && p.step == 1 && p.mask == nullptr )      // the batched intra pre-selection serves its own calls
+  {
+    Distortion d;
+    if( intraServe( p, kind, g_distOrig[IDX], d ) ) return d;
+  }
   // same guards as the x86 table entries (x86/RdCostX86.h:213,344,2065,2157) -- what the device path does not cover stays on the host
   if( p.applyWeight || p.useMR || p.step != 1 || ( ( p.mask != nullptr ) != ( kind == 3 ) ) || p.bitDepth > 12 || ( ( kind == 1 || kind == 2 ) && p.subShift != 0 )
       || ( kind == 3 && p.stepX != 1 && p.stepX != -1 ) || !sampled( g_distCtr[IDX] ) )
@@ -446,6 +457,7 @@ extern "C" void vtmref_orig_xFwdLfnst( TrQuant *, const TransformUnit &, const C
 extern "C" void vtmref_orig_xInvLfnst( TrQuant *, const TransformUnit &, const ComponentID );
 extern "C" void vtmref_orig_transformNxN_select( TrQuant *, TransformUnit &, const ComponentID &, const QpParam &, std::vector<TrMode> *, const int );
 extern "C" void vtmref_orig_predInterSearch( InterSearch *, CodingUnit &, Partitioner & );
+extern "C" void vtmref_orig_initIntraPatternChType( IntraPrediction *, const CodingUnit &, const CompArea &, const bool );
 namespace
 {
 bool     g_hookMe = false, g_hookMts = false, g_hookAffine = false, g_hookLfnst = false, g_hookAmvp = false, g_hookSmvd = false;
@@ -913,9 +925,17 @@ void mtsHook( TrQuant *tq, TransformUnit &tu, const ComponentID &compID, const Q
   for( int i = 0; i < n; i++ ) trModes->at( i ).second = test[i] != 0;
 }
 #include "ref_shim_pis.hpp"
+#include "ref_shim_intra.hpp"
+bool g_intraLive = false;      // the intra hook is installed: the distortion trampolines ask intraServe first
 }   // namespace
 
 // the strong definitions that take over the weakened reference symbols
+void IntraPrediction::initIntraPatternChType( const CodingUnit &cu, const CompArea &area, const bool forceRefFilterFlag )
+{
+  vtmref_orig_initIntraPatternChType( this, cu, area, forceRefFilterFlag );
+  if( g_hookIntra && forceRefFilterFlag ) intraArm( this, cu, area );
+  else if( g_hookIntra ) g_intra.armed = g_intra.serving = false;
+}
 void InterSearch::predInterSearch( CodingUnit &cu, Partitioner &partitioner )
 {
   if( g_hookPis ) pisHook( this, cu, partitioner ); else vtmref_orig_predInterSearch( this, cu, partitioner );
@@ -1021,6 +1041,11 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
         if( g_mask & 4 ) installTr();
         if( ( g_mask & 16 ) && ( g_countOnly || auxAlloc() ) ) installAux( (AffineGradientSearch &) app->m_cEncLib.m_cInterSearch );   // private base: C-style cast
         g_pisDump = nullptr; g_pisDumpedPlanes.clear(); g_pisCtr = g_pisDumpCtr = 0;
+        if( ( g_mask & 4096 ) && g_ctx && !g_countOnly && sym( g_apiIntra, "vtmhip_intra_cand_cost_batch_dev" ) && intraAlloc() )
+        {
+          g_hookIntra = g_intraLive = true;
+          if( !( g_mask & 2048 ) ) g_pisReplace = getenv( "VTMREF_REPLACE" ) && atoi( getenv( "VTMREF_REPLACE" ) ) != 0;
+        }
         if( g_mask & 2048 )
         {
           // VTMREF_PIS_DUMP: record mode (no device); otherwise compare mode, VTMREF_REPLACE=1: replace mode
@@ -1045,7 +1070,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
     }
   }
   catch( Exception &e ) { fprintf( stderr, "ref_encode: %s\n", e.what() ); rc = 2; }
-  g_hookMe = g_hookMts = g_hookAffine = g_hookLfnst = g_hookAmvp = g_hookSmvd = g_hookPis = false;
+  g_hookMe = g_hookMts = g_hookAffine = g_hookLfnst = g_hookAmvp = g_hookSmvd = g_hookPis = g_hookIntra = g_intraLive = false; g_intra = IntraBatch();
   stats->affineNs[0] = g_affineNs[0]; stats->affineNs[1] = g_affineNs[1]; g_affineNs[0] = g_affineNs[1] = 0;
   if( g_pisDump ) { fclose( g_pisDump ); g_pisDump = nullptr; }
   for( RefPlane &p : g_planes ) A.dfree( g_ctx, p.alloc );

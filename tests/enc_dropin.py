@@ -24,7 +24,8 @@ class Stats(C.Structure):
                 ("amvpCalls", C.c_uint64), ("amvpDevice", C.c_uint64), ("amvpMismatch", C.c_uint64), ("amvpUnsupported", C.c_uint64),
                 ("smvdCalls", C.c_uint64 * 3), ("smvdDevice", C.c_uint64 * 3), ("smvdMismatch", C.c_uint64 * 3), ("smvdUnsupported", C.c_uint64),
                 ("pisCalls", C.c_uint64), ("pisDevice", C.c_uint64), ("pisUnsupported", C.c_uint64), ("pisSkipped", C.c_uint64), ("pisReplayFallback", C.c_uint64),
-                ("pisMismatch", C.c_uint64 * 6), ("pisFirstMismatch", C.c_int32 * 8), ("pisNs", C.c_uint64 * 4), ("affineNs", C.c_uint64 * 2)]
+                ("pisMismatch", C.c_uint64 * 6), ("pisFirstMismatch", C.c_int32 * 8), ("pisNs", C.c_uint64 * 4), ("affineNs", C.c_uint64 * 2),
+                ("intraBatches", C.c_uint64 * 4), ("intraServed", C.c_uint64), ("intraMismatch", C.c_uint64), ("intraFirstMismatch", C.c_int32 * 8)]
 
 
 def write_clip(path, w, h, frames, seed=77):
@@ -54,7 +55,8 @@ def _child(argv_json):
            "smvd": [list(st.smvdCalls), list(st.smvdDevice), list(st.smvdMismatch), st.smvdUnsupported],
            "pis": {"calls": st.pisCalls, "device": st.pisDevice, "unsupported": st.pisUnsupported, "skipped": st.pisSkipped, "replayFallback": st.pisReplayFallback,
                    "mismatch": list(st.pisMismatch), "firstMismatch": list(st.pisFirstMismatch), "seconds": [v / 1e9 for v in st.pisNs]},
-           "affineSeconds": [v / 1e9 for v in st.affineNs]}
+           "affineSeconds": [v / 1e9 for v in st.affineNs],
+           "intra": {"batches": list(st.intraBatches), "served": st.intraServed, "mismatch": st.intraMismatch, "firstMismatch": list(st.intraFirstMismatch)}}
     sys.stdout.flush()
     os.write(2, ("\nDROPIN_RESULT " + json.dumps(out) + "\n").encode())
 

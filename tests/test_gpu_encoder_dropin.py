@@ -109,3 +109,20 @@ def test_reference_encoder_predInterSearch_one_call_per_cu(tmp_path):
                    "plain": st0["pis"], "compare": st1["pis"], "replace": st2["pis"], "affine_compare": st1["affine"], "affine_replace": st2["affine"],
                    "affine_seconds_compare": st1["affineSeconds"], "affine_seconds_replace": st2["affineSeconds"]},
                   open(os.path.join(out, "encoder_replace_192x128.json"), "w"), indent=1)
+
+
+@pytest.mark.skipif(not os.path.exists(enc_dropin.REF_SO), reason="oracle/_ref/libvtmref.so not built (needs /root/reference)")
+def test_reference_encoder_intra_preselection_batched(tmp_path):
+    """SURVEY.md 8(f) row 4, first part: the SATD pre-selection of IntraSearch::estIntraPredLumaQT (IntraSearch.cpp:549-592) as ONE vtmhip_intra_cand_cost_batch_dev call per CU
+    inside the real encoder (oracle/ref_shim_intra.hpp): the 35 first-round predictors (formed by the reference's own predIntraAng) against the original block -> 35 SADs + 35
+    SATDs; the distFunc calls of the member's loop are served from the batch (compare mode: and checked against the reference's functions; replace mode: served only)."""
+    yuv = str(tmp_path / "clip.yuv")
+    enc_dropin.write_clip(yuv, W, H, 3)
+    st0, bits0, rec0 = enc_dropin.encode(yuv, W, H, 3, QP, str(tmp_path / "plain"))
+    st1, bits1, rec1 = enc_dropin.encode(yuv, W, H, 3, QP, str(tmp_path / "cmp"), True, 1 | 4096, 10 ** 12, 0)
+    st2, bits2, rec2 = enc_dropin.encode(yuv, W, H, 3, QP, str(tmp_path / "rep"), True, 1 | 4096, 10 ** 12, 0, env={"VTMREF_REPLACE": "1"})
+    print("intra pre-selection:", st1["intra"], st2["intra"])
+    for st in (st1, st2):
+        assert st["rc"] == 0 and st["errors"] == 0, st
+        assert st["intra"]["batches"][1] >= 2000 and st["intra"]["served"] >= 100000 and st["intra"]["mismatch"] == 0 and st["intra"]["batches"][3] == 0, st["intra"]
+    assert bits1 == bits0 and rec1 == rec0 and bits2 == bits0 and rec2 == rec0

@@ -413,7 +413,7 @@ __device__ __forceinline__ void uni_mv3( Mv3 &m ) { for( int i = 0; i < 3; i++ )
 // and the search state in scalar registers.  SIX: the 6-parameter model (3 control points, 6 x 6 normal equations); the 4-parameter kernel carries 4 x 4.
 // The normal equations are symmetric in their first NP columns ((int64) a * b commutes): the upper triangle is accumulated.
 template<bool SIX, bool PACKED>      // PACKED: bitDepth <= 10 (the distortion runs on packed 16-bit words; deeper samples take the 32-bit Hadamard tiles, a kernel of its own)
-__global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( PACKED ? 4 : 1 ) ) ) void affine_me_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+__global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( PACKED ? ( SIX ? 2 : 4 ) : 1 ) ) ) void affine_me_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
                                                           const int16_t *__restrict__ otherBase, const vtmhip_affine_me_job *__restrict__ jobs,
                                                           vtmhip_affine_me_out *__restrict__ results )
 {
@@ -602,8 +602,19 @@ __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( PACKED
     {
       if( k >= MVNUM ) { phase = P_C2; continue; }
       const int kk = k++;
-      const int ph = pred[kk][0] + ( kk ? dMv[0] : 0 ), pv = pred[kk][1] + ( kk ? dMv[1] : 0 );
-      if( me.v[kk][0] != ph || me.v[kk][1] != pv ) { cand = me; cand.v[kk][0] = ph; cand.v[kk][1] = pv; have = true; }
+      // (control-point arrays are indexed through constant loops: a run-time index would move the whole search state to scratch memory)
+      int ph = 0, pv = 0, mh = 0, mv = 0;
+#pragma unroll
+      for( int i = 0; i < MVNUM; i++ )
+        if( i == kk ) { ph = pred[i][0] + ( i ? dMv[0] : 0 ); pv = pred[i][1] + ( i ? dMv[1] : 0 ); mh = me.v[i][0]; mv = me.v[i][1]; }
+      if( mh != ph || mv != pv )
+      {
+        cand = me;
+#pragma unroll
+        for( int i = 0; i < MVNUM; i++ )
+          if( i == kk ) { cand.v[i][0] = ph; cand.v[i][1] = pv; }
+        have = true;
+      }
     }
     else if( phase == P_C2 )
     {
@@ -628,13 +639,20 @@ __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( PACKED
     }
     else      // P_RND: rounds x control points x { the four direct, then (if one of them won) the four diagonal neighbours } (:5696-5765)
     {
-      if( pos == 0 ) { base = best; center[0] = best.v[k][0]; center[1] = best.v[k][1]; }
+      if( pos == 0 )
+      {
+        base = best;
+#pragma unroll
+        for( int i = 0; i < MVNUM; i++ )
+          if( i == k ) { center[0] = best.v[i][0]; center[1] = best.v[i][1]; }
+      }
       const int idx = it * 4 + pos;
       const int tx = idx == 0 || idx == 4 || idx == 5 ? -1 : idx == 3 || idx == 6 || idx == 7 ? 1 : 0;           // testPos { -1,0 } { 0,-1 } { 0,1 } { 1,0 } { -1,-1 } { -1,1 } { 1,1 } { 1,-1 }
       const int ty = idx == 1 || idx == 4 || idx == 7 ? -1 : idx == 2 || idx == 5 || idx == 6 ? 1 : 0;
       cand = base;
-      cand.v[k][0] = clip3( c.horMin, c.horMax, center[0] + ( tx << rs ) );
-      cand.v[k][1] = clip3( c.verMin, c.verMax, center[1] + ( ty << rs ) );
+#pragma unroll
+      for( int i = 0; i < MVNUM; i++ )
+        if( i == k ) { cand.v[i][0] = clip3( c.horMin, c.horMax, center[0] + ( tx << rs ) ); cand.v[i][1] = clip3( c.verMin, c.verMax, center[1] + ( ty << rs ) ); }
       have = true;
     }
     if( !have ) continue;

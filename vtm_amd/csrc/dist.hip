@@ -391,6 +391,41 @@ int vtmhip_dist_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int1
   return VTMHIP_OK;
 }
 
+// ---- intra mode pre-selection (IntraSearch::estIntraPredLumaQT, EncoderLib/IntraSearch.cpp:555-592): SAD and SATD of N predictor blocks against ONE original block ----
+}   // extern "C"
+namespace
+{
+__global__ __launch_bounds__( 256 ) void intra_cand_jobs_kernel( vtmhip_dist_job *__restrict__ jobs, int n, long orgOff, int orgStride, long predOff, int w, int h )
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if( i >= 2 * n ) return;
+  const int cand = i < n ? i : i - n;
+  vtmhip_dist_job d;
+  d.orgOff = orgOff; d.curOff = predOff + ( long ) cand * w * h; d.orgStride = orgStride; d.curStride = w; d.width = ( int16_t ) w; d.height = ( int16_t ) h;
+  d.subShift = 0; d.kind = ( int16_t ) ( i < n ? VTMHIP_DIST_SAD : VTMHIP_DIST_SATD );
+  jobs[i] = d;
+}
+}   // namespace
+extern "C"
+{
+
+int vtmhip_intra_cand_cost_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, int64_t orgOff, int orgStride, const int16_t *d_predBase, int64_t predOff, int n, int width,
+                                      int height, uint64_t *d_dist )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n >= 0 && n <= 4096, "n" );
+  if( n == 0 ) return VTMHIP_OK;
+  VTMHIP_REQUIRE( ctx, d_orgBase && d_predBase && d_dist, "null pointer" );
+  VTMHIP_REQUIRE( ctx, width >= 4 && width <= 128 && height >= 4 && height <= 128 && ( width & 3 ) == 0 && ( height & 3 ) == 0, "block size" );
+  void *arena = nullptr;
+  int   st    = vtmhip_internal_workspace( ctx, 2 * ( size_t ) n * sizeof( vtmhip_dist_job ), &arena );
+  if( st ) return st;
+  vtmhip_dist_job *jobs = ( vtmhip_dist_job * ) arena;
+  hipLaunchKernelGGL( intra_cand_jobs_kernel, dim3( ( 2 * n + 255 ) / 256 ), dim3( 256 ), 0, ctx->stream, jobs, n, ( long ) orgOff, orgStride, ( long ) predOff, width, height );
+  VTMHIP_LAUNCHED( ctx );
+  return vtmhip_dist_batch_dev( ctx, d_orgBase, d_predBase, jobs, 2 * n, d_dist );
+}
+
 int vtmhip_satd8_grid_dev( vtmhip_ctx *ctx, const int16_t *d_org, int orgStride, const int16_t *d_ref, int refStride, int width, int height, int r,
                            uint32_t *d_dist )
 {
