@@ -137,3 +137,135 @@ def test_predInterSearch_one_call_per_pu_matches_the_real_encoder():
     assert stats["recs"] >= 300 and stats["copies"] >= 100 and stats["cached"] >= 100 and stats["bi"] >= 200 and stats["smvd"] >= 30 and stats["mvdl1zero"] >= 100
     assert min(stats["imv"][:3]) >= 20 and stats["dirs"][3] >= 50 and stats["dirs"][1] >= 20
     ctx.close()
+
+
+def _level(ctx, planes, bases, hd, n, base_ptr, off_of):
+    """a PisLevelRun for n PUs of one slice / shape whose tables start at base_ptr + off_of(name) on the device"""
+    R = PisLevelRun()
+    L = R.pis
+    n0, n1 = hd.numRef[0], hd.numRef[1]
+    stride = planes[hd.rowPlane[0]][0].stride
+    for l in (0, 1):
+        for r in range((n0, n1)[l]):
+            pl = planes[hd.rowPlane[(n0 if l else 0) + r]][0]
+            L.refPlaneOff[l][r] = bases[hd.rowPlane[(n0 if l else 0) + r]] + pl.margin * pl.stride + pl.margin
+    L.numPU, L.smvdBit, L.refStride, L.candsGiven, L.biRestricted, L.mvdL1Zero, L.fastMEForGenBLowDelay = n, hd.smvdBit, stride, 1, hd.biRestricted, hd.mvdL1Zero, hd.fdm
+    L.picW, L.picH, L.ctuSize = hd.picW, hd.picH, hd.ctuSize
+    L.numRef[0], L.numRef[1] = n0, n1
+    for i in range(3):
+        L.mbBits[i] = hd.mbBits[i]
+    for r in range(4):
+        L.list1FromList0[r] = hd.list1FromList0[r]
+    L.symRefIdx[0], L.symRefIdx[1] = hd.symRefIdx[0], hd.symRefIdx[1]
+    for name in ("uniJobs", "uniOut", "uniRows", "distBiP", "pus", "puIn", "predOther", "biJobs", "biOut", "biRows", "pos"):
+        setattr(L, name, base_ptr + off_of(name))
+    L.smvdJobs = base_ptr + off_of("smvd") if hd.hasSmvd else None
+    R.uniOut, R.biOut, R.width, R.height = L.uniOut, L.biOut, hd.w, hd.h
+    big = max(hd.w, hd.h)
+    R.pic = PicParams(hd.picW, hd.picH, hd.ctuSize, hd.bitDepth, 8 if big >= 128 else 2 if big >= 64 else 1)
+    R.picBi = PicParams(hd.picW, hd.picH, hd.ctuSize, hd.bitDepth, 16 if big >= 128 else 8 if big >= 64 else 4 if big >= 32 else 1)
+    return R, stride
+
+
+def test_predInterSearch_batches_of_several_pus_equal_the_single_calls():
+    """The same records in BATCHES: the PUs of one slice, shape and AMVR mode (up to 17 in the golden file) in one vtmhip_predInterSearch_batch_dev call -- tables in
+    the level-order layout (rows (list, refIdx)-major, PU-minor), per-PU m_uniMvList state in vtmhip_pis_pu_in -- must give every PU exactly what its own call gives."""
+    from vtm_amd.device import Context
+    from vtm_amd.lib import MeJob, MeOut, PisPu, PisPuIn, PisRow, PredJob, SmvdJob
+    planes, recs = G.load_npz(NPZ)
+    ctx = Context(0)
+    dpb_np, bases = G.build_dpb(planes)
+    d_dpb = ctx.to_device(dpb_np)
+    groups = {}
+    for rec in recs:
+        hd, sin = rec[0], rec[1]
+        key = (hd.poc, hd.w, hd.h, hd.imv, hd.hasSmvd, hd.biRestricted, hd.mvdL1Zero, hd.numRef[0], hd.numRef[1], hd.uniMvListSize == 0, int(sin.puIn[0].uniMvInsert))
+        groups.setdefault(key, []).append(rec)
+    types = [("uniJobs", MeJob, 8), ("uniOut", MeOut, 8), ("uniRows", PisRow, 8), ("distBiP", C.c_uint64, 8), ("pus", PisPu, 1), ("puIn", PisPuIn, 1), ("predOther", PredJob, 1),
+             ("biJobs", MeJob, 4), ("biOut", MeOut, 4), ("biRows", PisRow, 4), ("smvd", SmvdJob, 1), ("pos", C.c_int64, 1)]
+    checked = batches = 0
+    for key, rs in groups.items():
+        if len(rs) < 2:
+            continue
+        n, hd = len(rs), rs[0][0]
+        w, h, n0, n1 = hd.w, hd.h, hd.numRef[0], hd.numRef[1]
+        rows = n0 + n1
+        # ---- table offsets of the n-PU layout inside one device block ----
+        offs, acc = {}, 0
+        for name, T, per in types:
+            offs[name] = acc
+            acc += (C.sizeof(T) * per * n + 255) & ~255
+        org_off = acc
+        total = org_off + 2 * n * w * h
+        host = bytearray(total)
+
+        def put(name, T, idx, obj):
+            o = offs[name] + idx * C.sizeof(T)
+            host[o:o + C.sizeof(T)] = bytes(obj)
+        stride = planes[hd.rowPlane[0]][0].stride
+        for p, (hp, sin, sout, org, fin) in enumerate(rs):
+            for row in range(rows):
+                j = MeJob.from_buffer_copy(bytes(sin.uniJobs[row]))
+                pl = planes[hp.rowPlane[row]][0]
+                j.refOff = bases[hp.rowPlane[row]] + pl.margin * pl.stride + pl.margin + hp.y * pl.stride + hp.x
+                j.orgOff = p * w * h
+                put("uniJobs", MeJob, row * n + p, j)
+            put("puIn", PisPuIn, p, sin.puIn[0])
+            po = PredJob.from_buffer_copy(bytes(sin.predOther[0]))
+            po.orgOff = po.predOff = po.outOff = p * w * h
+            put("predOther", PredJob, p, po)
+            for r in range(n0 if n1 else 0):
+                b = MeJob.from_buffer_copy(bytes(sin.biJobs[r]))
+                b.orgOff = b.otherPredOff = p * w * h
+                put("biJobs", MeJob, r * n + p, b)
+            put("pos", C.c_int64, p, C.c_int64(hp.y * stride + hp.x))
+            host[org_off + 2 * p * w * h:org_off + 2 * (p + 1) * w * h] = np.ascontiguousarray(org).tobytes()
+        d = ctx.alloc(total)
+        d_bi = ctx.alloc(2 * n * w * h)
+        R, _ = _level(ctx, planes, bases, hd, n, d.ptr, lambda name: offs[name])
+        uni_shape = int(ctx.is_uniform_shape(w, h))
+        ins = key[-1]
+        R.cfgUni = MeCfg(hd.bipredSearchRange, hd.useHadME, hd.fen13, hd.extendedSettings, hd.firstSearchStop, hd.imv, uni_shape, 1, int(key[-2]), 0)
+        R.cfgBi = MeCfg(hd.bipredSearchRange, hd.useHadME, hd.fen13, hd.extendedSettings, hd.firstSearchStop, hd.imv, uni_shape, 2, int(key[-2] and not ins), 1)
+        B = PisBuffers(d.ptr + org_off, d_dpb.ptr, None, None, d_bi.ptr, None, None)
+        d.upload(np.frombuffer(bytes(host), np.uint8))
+        ctx.pred_inter_search_batch(R, B)
+        got = d.to_host(np.uint8).tobytes()
+
+        def get(name, T, idx):
+            o = offs[name] + idx * C.sizeof(T)
+            return T.from_buffer_copy(got[o:o + C.sizeof(T)])
+        # ---- every PU on its own ----
+        d1 = ctx.alloc(C.sizeof(G.PisSlots) + 2 * w * h)
+        off1 = {f: getattr(G.PisSlots, f).offset for f, _ in G.PisSlots._fields_}
+        for p, (hp, sin, sout, org, fin) in enumerate(rs):
+            S = G.PisSlots.from_buffer_copy(bytes(sin))
+            for row in range(rows):
+                pl = planes[hp.rowPlane[row]][0]
+                S.uniJobs[row].refOff = bases[hp.rowPlane[row]] + pl.margin * pl.stride + pl.margin + hp.y * pl.stride + hp.x
+            S.pos[0] = hp.y * stride + hp.x
+            R1, _ = _level(ctx, planes, bases, hp, 1, d1.ptr, lambda name: off1[name])
+            R1.cfgUni, R1.cfgBi = R.cfgUni, R.cfgBi
+            B1 = PisBuffers(d1.ptr + C.sizeof(G.PisSlots), d_dpb.ptr, None, None, d_bi.ptr, None, None)
+            d1.upload(np.concatenate([np.frombuffer(bytes(S), np.uint8), np.ascontiguousarray(org).view(np.uint8).reshape(-1)]))
+            ctx.pred_inter_search_batch(R1, B1)
+            D = G.PisSlots.from_buffer_copy(d1.to_host(np.uint8)[:C.sizeof(G.PisSlots)].tobytes())
+            tag = (key, p)
+            assert bytes(get("pus", PisPu, p)) == bytes(D.pus[0]), ("pus", tag)
+            for row in range(rows):
+                assert bytes(get("uniOut", MeOut, row * n + p)) == bytes(D.uniOut[row]) and bytes(get("uniRows", PisRow, row * n + p)) == bytes(D.uniRows[row]), ("uni", tag, row)
+                assert get("distBiP", C.c_uint64, row * n + p).value == D.distBiP[row], ("distBiP", tag, row)
+            if n1 and not hd.biRestricted:
+                for r in range(n0):
+                    assert bytes(get("biOut", MeOut, r * n + p)) == bytes(D.biOut[r]) and bytes(get("biRows", PisRow, r * n + p)) == bytes(D.biRows[r]), ("bi", tag, r)
+            if hd.hasSmvd:
+                a, b = get("smvd", SmvdJob, p), D.smvd[0]
+                assert (a.cost, tuple(a.mvCur), tuple(a.mvTar), tuple(a.mvpIdxSym), [tuple(x) for x in a.predSym]) == (b.cost, tuple(b.mvCur), tuple(b.mvTar), tuple(b.mvpIdxSym), [tuple(x) for x in b.predSym]), ("smvd", tag)
+                assert [(t.cost, tuple(t.mv), tuple(t.idx)) for t in a.trace] == [(t.cost, tuple(t.mv), tuple(t.idx)) for t in b.trace], ("smvd trace", tag)
+            checked += 1
+        for buf in (d, d_bi, d1):
+            buf.free()
+        batches += 1
+    print("pis golden batches:", batches, "PUs:", checked)
+    assert batches >= 40 and checked >= 200
+    ctx.close()

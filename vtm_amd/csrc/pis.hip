@@ -97,29 +97,21 @@ __global__ __launch_bounds__( 256 ) void pis_cands_kernel( vtmhip_pis_level L )
 
 // m_uniMvList as the bi stage and the SMVD block see it for row (list, refIdx) of a PU: the caller's list (extraStart of the uni row: the state BEFORE the uni loop) after
 // insertUniMvCands( pu.Y(), cMvTemp ) (InterSearch.cpp:2451-2459, InterSearch.h:247-275) -- the block's own uni vector (selfH, selfV) replaces its existing entry in place,
-// or becomes the newest entry (of 15 the oldest drops out).  Returns the number of entries written to out[][2], newest first.
-__device__ __forceinline__ int uni_mv_list_after_insert( const vtmhip_pis_level &L, int pu, const vtmhip_me_job &u, int selfH, int selfV, int out[15][2] )
+// or becomes the newest entry (of 15 the oldest drops out).  Entry k of that list (newest first) -> (h, v); the list has uni_mv_list_size() entries.
+__device__ __forceinline__ int uni_mv_list_size( const vtmhip_pis_level &L, int pu, const vtmhip_me_job &u )
 {
   const int n0 = min( 15, max( 0, u.numExtraStart ) );
   const vtmhip_pis_pu_in *pi = L.puIn ? &L.puIn[pu] : nullptr;
-  if( !pi || !pi->uniMvInsert )
-  {
-    for( int k = 0; k < n0; k++ ) { out[k][0] = u.extraStart[k][0]; out[k][1] = u.extraStart[k][1]; }
-    return n0;
-  }
-  if( pi->uniMvSelfIsNew )
-  {
-    const int n = min( 15, n0 + 1 );
-    out[0][0] = selfH; out[0][1] = selfV;
-    for( int k = 1; k < n; k++ ) { out[k][0] = u.extraStart[k - 1][0]; out[k][1] = u.extraStart[k - 1][1]; }
-    return n;
-  }
-  for( int k = 0; k < n0; k++ )
-  {
-    const bool self = k == pi->uniMvSelfPos;
-    out[k][0] = self ? selfH : u.extraStart[k][0]; out[k][1] = self ? selfV : u.extraStart[k][1];
-  }
-  return n0;
+  return ( pi && pi->uniMvInsert && pi->uniMvSelfIsNew ) ? min( 15, n0 + 1 ) : n0;
+}
+__device__ __forceinline__ void uni_mv_list_entry( const vtmhip_pis_level &L, int pu, const vtmhip_me_job &u, int selfH, int selfV, int k, int &h, int &v )
+{
+  const vtmhip_pis_pu_in *pi = L.puIn ? &L.puIn[pu] : nullptr;
+  const bool ins = pi && pi->uniMvInsert;
+  const int  src = ( ins && pi->uniMvSelfIsNew ) ? k - 1 : k;
+  const bool self = ins && ( pi->uniMvSelfIsNew ? k == 0 : k == pi->uniMvSelfPos );
+  h = self ? selfH : u.extraStart[max( src, 0 )][0];
+  v = self ? selfV : u.extraStart[max( src, 0 )][1];
 }
 
 __device__ __forceinline__ void final_pred( const vtmhip_pis_level &L, int pu, const vtmhip_pis_pu &P )
@@ -268,10 +260,9 @@ __global__ __launch_bounds__( 256 ) void pis_bi_jobs_kernel( vtmhip_pis_level L 
     b.mvpIdxBits[0] = u.mvpIdxBits[0]; b.mvpIdxBits[1] = u.mvpIdxBits[1];
     b.bits = L.mbBits[2] + motOther + ref_idx_bits( L.numRef[rl], ref ) + u.mvpIdxBits[r.mvpIdx & 1] + ( L.smvdBit ? 1u : 0u );   // :2578-2593
     b.searchRange = u.searchRange; b.motionLambda = u.motionLambda; b.flags = 0;
-    int lst[15][2];
-    const int nl = uni_mv_list_after_insert( L, pu, u, r.mvHor, r.mvVer, lst );   // the start candidates of the bi search (:3397-3426)
+    const int nl = uni_mv_list_size( L, pu, u );   // the start candidates of the bi search (:3397-3426): none in the level-order driver
     b.numExtraStart = nl;
-    for( int k = 0; k < nl; k++ ) { b.extraStart[k][0] = lst[k][0]; b.extraStart[k][1] = lst[k][1]; }
+    for( int k = 0; k < nl; k++ ) { int eh, ev; uni_mv_list_entry( L, pu, u, r.mvHor, r.mvVer, k, eh, ev ); b.extraStart[k][0] = eh; b.extraStart[k][1] = ev; }
   }
 }
 
@@ -320,12 +311,10 @@ __global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
     j.numFixed = ( uint8_t ) ns;
     {
       // then the m_uniMvList entries of (list 0, symmetric reference), newest first (:2736-2742; the search rounds them to the AMVR precision and stops at five distinct vectors)
-      int lst[15][2];
-      const int nl = uni_mv_list_after_insert( L, pu, u0, r0.mvHor, r0.mvVer, lst );
-      for( int k = 0; k < nl && ns < VTMHIP_SMVD_MAX_START; k++ ) { j.starts[ns][0] = lst[k][0]; j.starts[ns][1] = lst[k][1]; ns++; }
+      const int nl = uni_mv_list_size( L, pu, u0 );
+      for( int k = 0; k < nl && ns < VTMHIP_SMVD_MAX_START; k++ ) { int eh, ev; uni_mv_list_entry( L, pu, u0, r0.mvHor, r0.mvVer, k, eh, ev ); j.starts[ns][0] = eh; j.starts[ns][1] = ev; ns++; }
     }
-    for( int k = ns; k < VTMHIP_SMVD_MAX_START; k++ ) j.starts[k][0] = j.starts[k][1] = 0;
-    j.numStart = ( uint8_t ) ns;
+    j.numStart = ( uint8_t ) ns;      // (entries beyond numStart are never read)
     for( int k = 0; k < 4; k++ ) { j.trace[k].cost = ~0ull; j.trace[k].mv[0] = j.trace[k].mv[1] = 0; j.trace[k].idx[0] = j.trace[k].idx[1] = 0; }
     j.mvCur[0] = j.mvCur[1] = j.mvTar[0] = j.mvTar[1] = 0;
     for( int l = 0; l < 2; l++ ) { j.predSym[l][0] = j.predSym[l][1] = 0; j.mvpIdxSym[l] = 0; }
