@@ -435,7 +435,7 @@ def main():
             "config": {"workload": "%dx%d 10-bit, %s operating point (QP%d, %s, FEN): %s = %d PUs x (%d + %d) reference pictures = %d uni searches + %d bi searches "
                                    "per picture, %d TU x transform-candidate chains"
                                    % (W, H, "encoder_randomaccess_vtm.cfg" if a.config == "ra" else "encoder_lowdelay_P_vtm.cfg", qp,
-                                      "SR 96 via ASR" if a.config == "ra" else "SR 64", "quadtree PUs 128..8" if a.partition == "qt" else "split-shape PU levels 128x128 64x64 64x32 32x32 32x16 16x16 16x8 8x8",
+                                      ("SR %s via ASR" % "/".join(str(x) for x in sorted({v for l in sr for v in l}))) if a.config == "ra" else "SR 64", "quadtree PUs 128..8" if a.partition == "qt" else "split-shape PU levels 128x128 64x64 64x32 32x32 32x16 16x16 16x8 8x8",
                                       wc["pus"] * world if world > 1 else wc["pus"], len(refs[0]), len(refs[1]),
                                       wc["uni_searches"], wc["bi_searches"], wc["tu_chains"])
                                    + (", %d affine uni searches (4-parameter xAffineMotionEstimation, PUs >= 16x16)" % wc["affine_searches"] if a.affine else "")

@@ -230,6 +230,9 @@ typedef struct
   int32_t ctuSize;      /* sps.getMaxCUWidth() */
   int32_t bitDepth;
   int32_t wavesPerJob;  /* tuning hint for this batch: 0/1 = one wave per search; 2, 4, 8, 16 = waves that split each candidate list (large PUs) */
+  int32_t maxSearchRange; /* tuning hint: the largest searchRange of the batch's TZ jobs (m_aaiAdaptSR: up to 384 with ASR).  The raster scan of xTZSearch (:3888-3899) is run by a
+                             column-walking kernel whose per-scan totals live in LDS: 0 (or <= 96) sizes it for the 39 x 39 points of SearchRange 96; a larger value for
+                             ((2 * range) / 5 + 1)^2 points (384: 154 x 154).  A scan that does not fit runs inside the search kernel: same result, much slower. */
 } vtmhip_pic_params;
 
 /* One (PU, reference picture) integer search = one call of InterSearch::xTZSearch. */

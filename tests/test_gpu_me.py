@@ -9,12 +9,12 @@ from vtm_amd.lib import MeResult, PicParams
 pytestmark = pytest.mark.gpu
 
 
-def _run_hip(ctx, scene, jobs, wpj=0):
+def _run_hip(ctx, scene, jobs, wpj=0, max_sr=0):
     arr = me_util.hip_tz_jobs(scene, jobs, scene.W)
     d_cur, d_ref = ctx.to_device(scene.cur), ctx.to_device(scene.ref_buf)
     d_jobs = ctx.to_device(np.frombuffer(arr, np.uint8))
     d_res = ctx.alloc(len(jobs) * 32)
-    pic = PicParams(scene.W, scene.H, 128, 10, wpj)
+    pic = PicParams(scene.W, scene.H, 128, 10, wpj, max_sr)
     ctx.tz_search_batch(pic, d_cur.ptr, d_ref.ptr, d_jobs.ptr, len(jobs), d_res.ptr)
     raw = d_res.to_host(np.uint8)
     res = (MeResult * len(jobs)).from_buffer_copy(raw.tobytes())
@@ -70,3 +70,18 @@ def test_tz_search_multi_wave_jobs(ctx, wpj):
     got = _run_hip(ctx, scene, jobs, wpj)
     bad = [k for k in range(len(jobs)) if got[k] != exp[k]]
     assert not bad, [(jobs[k], got[k], exp[k]) for k in bad[:5]]
+
+
+@pytest.mark.parametrize("wpj,max_sr", [(0, 384), (8, 384), (2, 192), (0, 130)])
+def test_tz_search_large_search_ranges_through_the_column_scan(ctx, wpj, max_sr):
+    """vtmhip_pic_params::maxSearchRange sizes the raster column kernel's LDS totals for ASR ranges up to 384 (154 x 154 scan points): the scans of SearchRange 192 / 384 jobs then
+    run in tz_raster_cols_kernel instead of inside the search kernel -- same results (scans larger than the hint still take the in-kernel path)."""
+    scene = me_util.Scene(832, 480, hard=True)
+    jobs = me_util.random_tz_jobs(scene, 300, seed=70 + wpj, ranges=(96, 192, 384))
+    for k, j in enumerate(jobs):      # far-off predictors: the first search ends >= 5 samples from its start, so the raster scan runs
+        j["mvHor"], j["mvVer"] = (-1) ** k * (400 + 16 * (k % 40)), (-1) ** (k // 2) * (300 + 16 * (k % 23))
+    exp = me_util.run_oracle_tz(scene, jobs)
+    got = _run_hip(ctx, scene, jobs, wpj, max_sr)
+    bad = [k for k in range(len(jobs)) if got[k] != exp[k]]
+    assert not bad, [(jobs[k], got[k], exp[k]) for k in bad[:5]]
+    assert sum(1 for e in exp if e[4] > 2000) >= 50      # many searches really scanned a large window (nEval counts the scan points)

@@ -41,6 +41,7 @@ struct MeJob   // wave-uniform view of one vtmhip_tz_job
   bool           orgResident;
   unsigned       orgSeg[4];
   int            resOff;   // r * (refStride << ss) + x of that segment
+  int            totCap;   // raster column kernel: entries of the scan's totals in LDS (the dummy slot of idle lanes sits behind them)
 };
 
 __device__ __forceinline__ int floor_log2_u( unsigned v ) { return 31 - __clz( ( int ) v ); }
@@ -697,7 +698,7 @@ struct TzSaved
   unsigned           rasterIdx;
   int                pad;
 };
-constexpr int RASTER_TOT_CAP = 40 * 40;   // candidates of a scan the column kernel takes (SR 96: 39 x 39)
+constexpr int RASTER_TOT_CAP = 40 * 40;   // candidates of a scan the column kernel takes by default (SR 96: 39 x 39); vtmhip_pic_params::maxSearchRange raises it per launch
 constexpr int RASTER_CHUNK   = 13;        // block rows (slots) of one task at most
 
 // One lane = one raster COLUMN (dx = left + 5 col) of one 8-sample column segment k.  The block rows the SAD visits (every (1 << ss)-th) and the scan's dy values
@@ -742,7 +743,7 @@ __device__ __forceinline__ void raster_run( const MeJob &j, int nx, int nyp, int
     O[sl][0] = bx<SGN>( a.v[0], j.bias ); O[sl][1] = bx<SGN>( a.v[1], j.bias ); O[sl][2] = bx<SGN>( a.v[2], j.bias ); O[sl][3] = bx<SGN>( a.v[3], j.bias );
   }
   const int uEnd = nyp - 1 + N - 1;
-  int       fa = live ? p * nx + col : RASTER_TOT_CAP;   // total of candidate (p + (mp << ss)) of this lane's column; lanes without a column: the dummy slot
+  int       fa = live ? p * nx + col : j.totCap;   // total of candidate (p + (mp << ss)) of this lane's column; lanes without a column: the dummy slot
   const int fstep = live ? nx << j.ss : 0;
   Pel8 q0 = *reinterpret_cast<const Pel8 *>( pr ), q1 = q0;
   if( uEnd >= 1 ) q1 = *reinterpret_cast<const Pel8 *>( pr + dr );
@@ -832,12 +833,12 @@ __device__ __forceinline__ void raster_task( const MeJob &j, const Range &r, int
 
 __global__ __launch_bounds__( 256 ) void tz_raster_cols_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
                                                                const vtmhip_tz_job *__restrict__ jobs, TzSaved *__restrict__ saved, const int *__restrict__ list,
-                                                               unsigned *__restrict__ gTot, int parts )
+                                                               unsigned *__restrict__ gTot, int parts, int totCap )
 {
   // parts > 1 (few searches in the batch: one band of a picture sharded over several GPUs, the 128x128 level): `parts` workgroups share one scan -- each takes
   // every parts-th task, adds its partial totals into the scan's global totals (gTot[e][RASTER_TOT_CAP + 1], zeroed by the host; the last entry counts the
   // workgroups that are done) and the one that arrives last picks the minimum.  Integer sums: the result does not depend on the split.
-  __shared__ unsigned           sTot[RASTER_TOT_CAP + 1];   // + the dummy slot of lanes without a column
+  extern __shared__ unsigned    sTot[];                     // totCap totals + the dummy slot of lanes without a column
   __shared__ unsigned long long sRedCost[4];
   __shared__ unsigned           sRedIdx[4];
   __shared__ int                sLast;
@@ -854,7 +855,7 @@ __global__ __launch_bounds__( 256 ) void tz_raster_cols_kernel( vtmhip_pic_param
     j.w = jp->width; j.h = jp->height; j.ss = jp->subShift; j.imvShift = ( unsigned ) jp->imvShift;
     j.predHor = jp->predHor; j.predVer = jp->predVer; j.costScale = 2; j.lambda = jp->motionLambda;
     j.bias = jp->signedSamples ? 0x80008000u : 0u;
-    j.narrow = false;
+    j.narrow = false; j.totCap = totCap;
     const Range r = sv.sr;
     const int   nx = ( r.right - r.left ) / 5 + 1, ny = ( r.bottom - r.top ) / 5 + 1, total = nx * ny;
     for( int i = threadIdx.x; i < total; i += 256 ) sTot[i] = 0;
@@ -888,12 +889,12 @@ __global__ __launch_bounds__( 256 ) void tz_raster_cols_kernel( vtmhip_pic_param
     __syncthreads();
     if( parts > 1 )
     {
-      unsigned *g = gTot + ( size_t ) e * ( RASTER_TOT_CAP + 1 );
+      unsigned *g = gTot + ( size_t ) e * ( totCap + 1 );
       for( int i = threadIdx.x; i < total; i += 256 )
         if( sTot[i] ) atomicAdd( &g[i], sTot[i] );
       __threadfence();
       __syncthreads();
-      if( threadIdx.x == 0 ) sLast = atomicAdd( &g[RASTER_TOT_CAP], 1u ) == ( unsigned ) ( parts - 1 );
+      if( threadIdx.x == 0 ) sLast = atomicAdd( &g[totCap], 1u ) == ( unsigned ) ( parts - 1 );
       __syncthreads();
       if( !sLast ) continue;   // block-uniform
       __threadfence();
@@ -928,7 +929,7 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel(
                                                                                 const int16_t *__restrict__ refBase,
                                                                                 const vtmhip_tz_job *__restrict__ jobs, int numJobs,
                                                                                 vtmhip_me_result *__restrict__ results, int mode, TzSaved *__restrict__ saved,
-                                                                                int *__restrict__ list )
+                                                                                int *__restrict__ list, int totCap )
 {
   // mode 0: the whole search.  Split launches: mode 1 stops at the raster decision of jobs tz_raster_cols_kernel can take (state -> saved[], job
   // index -> list[]; every other job runs to the end here); mode 2 resumes the listed jobs after the scan.
@@ -1117,7 +1118,7 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel(
   {
     s.bestDist = ( unsigned ) iRaster;
     const int nx = s.sr.right >= s.sr.left ? ( s.sr.right - s.sr.left ) / iRaster + 1 : 0, ny = s.sr.bottom >= s.sr.top ? ( s.sr.bottom - s.sr.top ) / iRaster + 1 : 0;
-    if( mode == 1 && iRaster == 5 && j.seg == 8 && j.h <= 128 && nx >= 1 && nx <= 64 && ny >= 1 && nx * ny <= RASTER_TOT_CAP )
+    if( mode == 1 && iRaster == 5 && j.seg == 8 && j.h <= 128 && nx >= 1 && ny >= 1 && nx * ny <= totCap )
     {
       if( co.leader )
       {
@@ -1418,6 +1419,9 @@ extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_par
   VTMHIP_REQUIRE( ctx, wpj == 0 || wpj == 1 || wpj == 2 || wpj == 4 || wpj == 8 || wpj == 16, "wavesPerJob must be 0, 1, 2, 4, 8 or 16" );
   // split search (default; VTMHIP_TZ_SPLIT=0: one launch): the raster scans of the batch run in tz_raster_cols_kernel between two launches of the search kernel
   static const bool split = !( getenv( "VTMHIP_TZ_SPLIT" ) && atoi( getenv( "VTMHIP_TZ_SPLIT" ) ) == 0 );
+  // the raster column kernel keeps a scan's totals in LDS: 39 x 39 points (SearchRange 96) by default, ((2 * range) / 5 + 1)^2 for the caller's maxSearchRange hint (384: 154 x 154 = 93 KB)
+  const int rasterSide = pic->maxSearchRange > 96 ? ( 2 * ( pic->maxSearchRange < 512 ? pic->maxSearchRange : 512 ) ) / 5 + 1 : 0;
+  const int totCap = rasterSide * rasterSide > RASTER_TOT_CAP ? rasterSide * rasterSide : RASTER_TOT_CAP;
   TzSaved  *d_saved = nullptr;
   int      *d_list  = nullptr;
   unsigned *d_tot   = nullptr;
@@ -1426,10 +1430,11 @@ extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_par
   {
     // few searches (one band of a sharded picture): several workgroups per raster scan, so that the scans of a 128x128 level still fill the GPU
     static const bool splitScan = !( getenv( "VTMHIP_RASTER_PARTS" ) && atoi( getenv( "VTMHIP_RASTER_PARTS" ) ) == 0 );
-    rasterParts = ( splitScan && n <= 640 ) ? ( 1280 / n < 8 ? 1280 / n : 8 ) : 1;   // aim at the 1280 resident workgroups (5 per CU); twice that measured slower
+    rasterParts = ( splitScan && n <= 640 ) ? ( 1280 / n < 8 ? 1280 / n : 8 ) : 1;
+    if( totCap > RASTER_TOT_CAP && splitScan && n <= 4096 && rasterParts < 4 ) rasterParts = 4;      // big scans (one workgroup per CU by LDS): a few workgroups per scan balance the tail   // aim at the 1280 resident workgroups (5 per CU); twice that measured slower
     const size_t oList = ( ( size_t ) n * sizeof( TzSaved ) + 255 ) & ~( size_t ) 255;
     const size_t oTot  = ( oList + ( ( size_t ) n + 1 ) * sizeof( int ) + 255 ) & ~( size_t ) 255;
-    const size_t totBytes = rasterParts > 1 ? ( size_t ) n * ( RASTER_TOT_CAP + 1 ) * sizeof( unsigned ) : 0;
+    const size_t totBytes = rasterParts > 1 ? ( size_t ) n * ( totCap + 1 ) * sizeof( unsigned ) : 0;
     void        *arena = nullptr;
     int          st    = vtmhip_internal_workspace( ctx, oTot + totBytes, &arena, 1 );
     if( st ) return st;
@@ -1440,7 +1445,7 @@ extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_par
     if( totBytes ) VTMHIP_HIP( ctx, hipMemsetAsync( d_tot, 0, totBytes, ctx->stream ) );
   }
 #define VTMHIP_TZ_LAUNCH( W, GRID, MODE ) \
-  hipLaunchKernelGGL( tz_search_kernel<W>, dim3( GRID ), dim3( W == 1 ? 256 : 64 * W ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, d_results, MODE, d_saved, d_list )
+  hipLaunchKernelGGL( tz_search_kernel<W>, dim3( GRID ), dim3( W == 1 ? 256 : 64 * W ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, d_results, MODE, d_saved, d_list, totCap )
 #define VTMHIP_TZ_SWITCH( MODE )                                    \
   switch( wpj )                                                     \
   {                                                                 \
@@ -1456,8 +1461,10 @@ extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_par
   if( split )
   {
     { VTMHIP_TIME_KERNEL( ctx, "tz_raster_cols_kernel" );
-      hipLaunchKernelGGL( tz_raster_cols_kernel, dim3( rasterParts > 1 ? n * rasterParts : ( n < 3072 ? n : 3072 ) ), dim3( 256 ), 0, ctx->stream, *pic, d_orgBase,
-                          d_refBase, d_jobs, d_saved, d_list, d_tot, rasterParts );
+      const size_t totLds = ( size_t ) ( totCap + 1 ) * sizeof( unsigned );
+      if( totLds > 32 * 1024 ) VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( tz_raster_cols_kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) totLds ) );
+      hipLaunchKernelGGL( tz_raster_cols_kernel, dim3( rasterParts > 1 ? n * rasterParts : ( n < 3072 ? n : 3072 ) ), dim3( 256 ), totLds, ctx->stream, *pic, d_orgBase,
+                          d_refBase, d_jobs, d_saved, d_list, d_tot, rasterParts, totCap );
     }
     { VTMHIP_TIME_KERNEL( ctx, "tz_search_kernel" );
       VTMHIP_TZ_SWITCH( 2 )

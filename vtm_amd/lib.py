@@ -19,7 +19,7 @@ class DistJob(C.Structure):
 
 class PicParams(C.Structure):
     _fields_ = [("picW", C.c_int32), ("picH", C.c_int32), ("ctuSize", C.c_int32), ("bitDepth", C.c_int32),
-                ("wavesPerJob", C.c_int32)]
+                ("wavesPerJob", C.c_int32), ("maxSearchRange", C.c_int32)]
 
 
 class TzJob(C.Structure):

@@ -311,7 +311,7 @@ class FrameHotPath:
                 lvl["smvd_jobs"] = T.zeros((n, SMVD_DT.itemsize), dtype=T.uint8, device=dev)
                 L.smvdJobs, L.symRefIdx[0], L.symRefIdx[1] = lvl["smvd_jobs"].data_ptr(), self.smvd[0], self.smvd[1]
             lvl["pis"] = L
-            lvl["pic"] = PicParams(pic_w, pic_h, 128, bit_depth, wpj.get(max(w, h), 1))
+            lvl["pic"] = PicParams(pic_w, pic_h, 128, bit_depth, wpj.get(max(w, h), 1), max(max(l) for l in search_ranges if len(l)))      # maxSearchRange: sizes the raster scans' LDS totals
             lvl["pic_bi"] = PicParams(pic_w, pic_h, 128, bit_depth, FULL_WAVES_PER_JOB.get(max(w, h), 1))
             lvl["cfg_uni"] = MeCfg(4, 1, 1, 0, 1, 0, 1, 1, 1, 0)           # BipredSearchRange 4, HadamardME, FEN, uniform: imv 0, square, all uni, no m_uniMvList
             lvl["cfg_bi"] = MeCfg(4, 1, 1, 0, 1, 0, 1, 2, 1, 1)            # all bi, the pattern 2*org - pred comes from the fused MC epilogue
