@@ -925,7 +925,8 @@ __global__ __launch_bounds__( 256 ) void tz_raster_cols_kernel( vtmhip_pic_param
 
 // WPJ = 1: 256 threads = 4 independent jobs.  WPJ > 1: 64 * WPJ threads = 1 job.
 template<int WPJ>
-__global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase,
+__global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) __attribute__( ( amdgpu_waves_per_eu( WPJ == 2 || WPJ == 4 ? 4 : 1 ) ) )      // two / four waves per search sat at 129 / 131 VGPRs: one register over the four-waves-per-SIMD budget
+void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase,
                                                                                 const int16_t *__restrict__ refBase,
                                                                                 const vtmhip_tz_job *__restrict__ jobs, int numJobs,
                                                                                 vtmhip_me_result *__restrict__ results, int mode, TzSaved *__restrict__ saved,
