@@ -80,12 +80,16 @@ def parse():
 
 
 def workload_key(a, world):
-    """what the PMC instruction counters of a run depend on: the argument vector that shapes the work + the kernel sources.  The committed counters
+    """what the PMC instruction counters of a run depend on: the argument vector that shapes the work + the sources of the counted kernel
+    (frac_search_sq_kernel: interp.hip and the headers).  The committed counters
     (profiles/pmc_insts_per_launch.json, written from a run of THIS script) carry the key of their run; a roofline fraction is only formed when it matches."""
     import hashlib
     h = hashlib.sha1()
+    # the sources the counted kernel is compiled from: its own file and every header (the other stages' results are bit-exact by the parity tests, so the
+    # counted kernel's job set does not depend on how they are implemented)
     for f in sorted(os.listdir(os.path.join(ROOT, "vtm_amd", "csrc"))):
-        h.update(open(os.path.join(ROOT, "vtm_amd", "csrc", f), "rb").read())
+        if f == "interp.hip" or f.endswith(".hpp"):
+            h.update(open(os.path.join(ROOT, "vtm_amd", "csrc", f), "rb").read())
     args = dict(width=a.width, height=a.height, config=a.config, dpoc=a.dpoc_list if a.config == "ra" else None, qp=a.qp, ts=bool(a.transform_skip), smvd=bool(a.smvd and a.config == "ra"),
                 affine=bool(a.affine), partition=a.partition, luma_only=bool(a.luma_only), shard=a.shard if world > 1 else None, world=world,
                 sim=int(os.environ.get("VTM_BENCH_SIMULATE_WORLD", "0")))
