@@ -16,6 +16,8 @@
 #include "ctx.hpp"
 #include "had.hpp"
 
+#include <type_traits>
+
 namespace
 {
 
@@ -402,7 +404,8 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
     }
   }
   for( int i = tid; i < C::JPW * 2; i += C::BLOCK ) sCentre[i >> 1][i & 1] = 0;
-  __syncthreads();
+  // the packed 16-bit evaluation (phase V) needs every PU of the workgroup to ask for the Hadamard cost at bitDepth <= 10
+  const bool pkAll = !__syncthreads_or( tid < nj && !( jobs[job0 + tid].useHad && jobs[job0 + tid].bitDepth <= 10 ) );
 
 #pragma unroll 1
   for( int round = 0; round < 2; round++ )
@@ -416,19 +419,43 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
     {
     // ---- phase H: plane p (dx = p - 1) of PU jl: (first, !last) 8-tap FIR of window rows 0..H+7; 8 outputs per thread and step ----
     {
-      constexpr int CH = W / 8, NP = C::NPL;
-      for( int i = tid; i < nj * NP * ( H + 8 ) * CH; i += C::BLOCK )
+      constexpr int CH = W / 8, NP = C::NPL, PER = ( H + 8 ) * CH;
+      // item order: plane slowest, so that whole waves work on the centre plane, whose horizontal phase is 0 in the half-sample round (and in the quarter-sample
+      // round of the PUs whose half-sample winner has no horizontal part): the identity filter (InterpolationFilter.cpp:77-79, m_lumaFilter[0] = {0,0,0,64,0,0,0,0})
+      for( int i = tid; i < C::JPW * NP * PER; i += C::BLOCK )
       {
-        const int jl = i / ( NP * ( H + 8 ) * CH ), rem = i - jl * NP * ( H + 8 ) * CH;
-        const int pp = rem / ( ( H + 8 ) * CH ), o = rem - pp * ( H + 8 ) * CH, r = o / CH, x0 = ( o - r * CH ) * 8;
+        const int pp = i / ( C::JPW * PER ), rem = i - pp * C::JPW * PER;
+        const int jl = rem / PER, o = rem - jl * PER, r = o / CH, x0 = ( o - r * CH ) * 8;
+        if( jl >= nj ) continue;
         const int p = C::SEQ ? seqPl : pp;
         const vtmhip_frac_job &j = jobs[job0 + jl];
         const int qx = sCentre[jl][0] + ( p - 1 ) * step, ix = qx >> 2, fx = qx & 3;
+        const IfParams pH = if_params( 1, 0, j.bitDepth, 0, ( 1 << j.bitDepth ) - 1, 0 );
+        if( fx == 0 )
+        {
+          // (64 v + offset) >> shift with offset = -(8192 << shift), shift <= 6: (v << (6 - shift)) - 8192, on packed 16-bit words (the truncation to Pel is the
+          // arithmetic modulo 2^16 either way); fx == 0 implies ix == 0: output x0 + i is window column x0 + 4 + i
+          typedef short v2s __attribute__( ( ext_vector_type( 2 ) ) );
+          const int16_t *wr = lds + jl * C::PERJOB + r * C::WLD + x0 + 4;
+          const int2     lo = *reinterpret_cast<const int2 *>( wr ), hi = *reinterpret_cast<const int2 *>( wr + 4 );
+          const int      in[4] = { lo.x, lo.y, hi.x, hi.y };
+          int            ow[4];
+          const short    up6 = ( short ) ( 6 - pH.shift );
+#pragma unroll
+          for( int m = 0; m < 4; m++ )
+          {
+            v2s v;
+            __builtin_memcpy( &v, &in[m], 4 );
+            v = ( v << up6 ) - ( short ) 8192;
+            __builtin_memcpy( &ow[m], &v, 4 );
+          }
+          *reinterpret_cast<int4 *>( lds + jl * C::PERJOB + C::WIN + pp * C::PLANE + r * W + x0 ) = make_int4( ow[0], ow[1], ow[2], ow[3] );
+          continue;
+        }
         const int16_t *cH = ( round == 0 && j.useAltHpelIf && fx == 2 ) ? c_lumaAltHpel : c_lumaFilter[fx << 2];
         int ch[8];
 #pragma unroll
         for( int k = 0; k < 8; k++ ) ch[k] = cH[k];
-        const IfParams pH = if_params( 1, 0, j.bitDepth, 0, ( 1 << j.bitDepth ) - 1, 0 );
         // output x0+i needs window columns x0 + ix + 1 + i + (0..7): 16 samples from the 16-byte aligned column x0, shifted by ix + 1 in {0, 1}
         const int4 *w4 = reinterpret_cast<const int4 *>( lds + jl * C::PERJOB + r * C::WLD + x0 );
         const int4  a = w4[0], b = w4[1];
@@ -468,14 +495,21 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
 
     // ---- phase V: one (PU, candidate, tile) item per lane ------------------------------------------------------------------
     // SEQ: the candidates whose plane is in the buffer -- dx = -1: table entries 3, 5, 7; dx = 0: 0, 1, 2 (entry 0 only in the half-sample round); dx = +1: 4, 6, 8
-    const int seqSkip = ( C::SEQ && round == 1 && seqPl == 1 ) ? 1 : 0, seqN = 3 - seqSkip;
-    const int items = C::SEQ ? seqN * C::TILES : ( round == 0 ? C::ITEMS : C::ITEMS - C::TILES ), cand0 = round;
-#pragma unroll 1
-    for( int it = tid; it < nj * items; it += C::BLOCK )
+    // Item order otherwise: candidate slowest, and the candidates without a vertical offset (table entries 0, 3, 4) first: their vertical phase is 0 in the
+    // half-sample round (and in the quarter-sample round of the PUs whose half-sample winner has no vertical part) = the identity filter, so whole waves skip the FIR.
+    // PK (every PU of the workgroup: Hadamard cost, bitDepth <= 10): the packed path with the identity shortcut; otherwise the general path.
+    auto phaseV = [&]( auto pkTag )
     {
-      const int jl = C::SEQ ? 0 : ( round == 0 ? it / C::ITEMS : it / ( C::ITEMS - C::TILES ) );   // constant divisors: multiply-high, not the generic division sequence (SEQ: one PU per workgroup)
-      const int rem = it - jl * items, ci = rem / C::TILES, tile = rem - ci * C::TILES;
-      const int cand = C::SEQ ? ( seqPl == 1 ? ci + seqSkip : 3 + 2 * ci + ( seqPl >> 1 ) ) : cand0 + ci;
+    constexpr bool PK = decltype( pkTag )::value;
+    const int seqSkip = ( C::SEQ && round == 1 && seqPl == 1 ) ? 1 : 0, seqN = 3 - seqSkip;
+    const int ncand = C::SEQ ? seqN : ( round == 0 ? 9 : 8 );
+    constexpr unsigned long long ORDER = 0x876521430ull;   // nibble k: the k-th candidate in evaluation order
+#pragma unroll 1
+    for( int it = tid; it < ncand * C::JPW * C::TILES; it += C::BLOCK )
+    {
+      const int ci = it / ( C::JPW * C::TILES ), rem = it - ci * C::JPW * C::TILES, jl = rem / C::TILES, tile = rem - jl * C::TILES;
+      if( jl >= nj ) continue;
+      const int cand = C::SEQ ? ( seqPl == 1 ? ci + seqSkip : 3 + 2 * ci + ( seqPl >> 1 ) ) : ( int ) ( ( ORDER >> ( 4 * ( ci + round ) ) ) & 15 );
       const vtmhip_frac_job &j = jobs[job0 + jl];
       const int8_t( *tab )[2] = round == 0 ? c_refineH : c_refineQ;
       const int dx = tab[cand][0], dy = tab[cand][1];
@@ -495,49 +529,83 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
       // Packed-SATD path (bitDepth <= 10): the taps and the rounding offset are pre-scaled by 2^(16 - shift), so that the UPPER half of an accumulator
       // is the shifted sum ((acc << up) >> 16 == acc >> shift, arithmetic) and one v_perm packs two of them -- no shifts, and the clip runs on
       // packed words.  |taps| <= 58 and 16 - shift <= 8 keep the scaled taps in 16 bits; 112 * 2^up * 32768 + offset * 2^up < 2^31.
-      const bool pk16 = j.useHad && j.bitDepth <= 10;
-      const int  up   = pk16 ? 16 - pV.shift : 0, accInit = pV.offset << up;
+      const int  up   = PK ? 16 - pV.shift : 0, accInit = pV.offset << up;
       v2s cpk[4];
 #pragma unroll
       for( int m = 0; m < 4; m++ ) { cpk[m].x = ( short ) ( cv[2 * m] << up ); cpk[m].y = ( short ) ( cv[2 * m + 1] << up ); }
       int  acc[64];
-      int4 prev = *reinterpret_cast<const int4 *>( pl );
-#pragma unroll
-      for( int r = 1; r < 15; r++ )
+      auto fir = [&]()
       {
-        const int4     cur = *reinterpret_cast<const int4 *>( pl + r * W );   // 8 samples of plane row r
-        const unsigned pw[4] = { ( unsigned ) prev.x, ( unsigned ) prev.y, ( unsigned ) prev.z, ( unsigned ) prev.w };
-        const unsigned cw[4] = { ( unsigned ) cur.x, ( unsigned ) cur.y, ( unsigned ) cur.z, ( unsigned ) cur.w };
-        v2s pr[8];   // column x: (row r-1, row r)
+        int4 prev = *reinterpret_cast<const int4 *>( pl );
 #pragma unroll
-        for( int k = 0; k < 4; k++ )
+        for( int r = 1; r < 15; r++ )
         {
-          const unsigned lo = __builtin_amdgcn_perm( cw[k], pw[k], 0x05040100u ), hi = __builtin_amdgcn_perm( cw[k], pw[k], 0x07060302u );
-          __builtin_memcpy( &pr[2 * k], &lo, 4 );
-          __builtin_memcpy( &pr[2 * k + 1], &hi, 4 );
-        }
-        const int q = r - 1;   // the pair (q, q+1)
+          const int4     cur = *reinterpret_cast<const int4 *>( pl + r * W );   // 8 samples of plane row r
+          const unsigned pw[4] = { ( unsigned ) prev.x, ( unsigned ) prev.y, ( unsigned ) prev.z, ( unsigned ) prev.w };
+          const unsigned cw[4] = { ( unsigned ) cur.x, ( unsigned ) cur.y, ( unsigned ) cur.z, ( unsigned ) cur.w };
+          v2s pr[8];   // column x: (row r-1, row r)
 #pragma unroll
-        for( int m = 0; m < 4; m++ )
-        {
-          const int y = q - 2 * m;
-          if( y >= 0 && y < 8 )
+          for( int k = 0; k < 4; k++ )
           {
-#pragma unroll
-            for( int x = 0; x < 8; x++ ) acc[y * 8 + x] = __builtin_amdgcn_sdot2( pr[x], cpk[m], m == 0 ? accInit : acc[y * 8 + x], false );   // m == 0 is a row's first pair
+            const unsigned lo = __builtin_amdgcn_perm( cw[k], pw[k], 0x05040100u ), hi = __builtin_amdgcn_perm( cw[k], pw[k], 0x07060302u );
+            __builtin_memcpy( &pr[2 * k], &lo, 4 );
+            __builtin_memcpy( &pr[2 * k + 1], &hi, 4 );
           }
+          const int q = r - 1;   // the pair (q, q+1)
+#pragma unroll
+          for( int m = 0; m < 4; m++ )
+          {
+            const int y = q - 2 * m;
+            if( y >= 0 && y < 8 )
+            {
+#pragma unroll
+              for( int x = 0; x < 8; x++ ) acc[y * 8 + x] = __builtin_amdgcn_sdot2( pr[x], cpk[m], m == 0 ? accInit : acc[y * 8 + x], false );   // m == 0 is a row's first pair
+            }
+          }
+          prev = cur;
+          __builtin_amdgcn_sched_barrier( 0 );   // keep the row loads from being hoisted together (register pressure -> occupancy)
         }
-        prev = cur;
-        __builtin_amdgcn_sched_barrier( 0 );   // keep the row loads from being hoisted together (register pressure -> occupancy)
-      }
+      };
       // |sum of taps| <= 112 and |plane sample| <= 32768: (acc >> shift) fits 16 bits, so the reference's Pel truncation is the identity here
       const int16_t *org = orgBase + j.orgOff + ( long ) ( ty * 8 ) * j.orgStride + tx * 8;
       unsigned       d;
-      if( pk16 )
+      if constexpr( PK )
       {
         // 10-bit prediction and |org| <= 3071 (picture samples or the bi-pred target 2*org - pred): |diff| <= 4095, so the first three
         // butterfly levels run on packed 16-bit words (the reference's own SIMD SATD is 16-bit for bitDepth <= 10, x86/RdCostX86.h:2157);
         // when every lane of the wave sees original samples inside [0, 1023] (|diff| <= 1023), five levels do.
+        v2s P[8][4];   // the shifted sums before the clip, packed
+        if( fy == 0 )
+        {
+          // m_lumaFilter[0] = {0,0,0,64,0,0,0,0}: output row y is plane row y + 3 of the item's 15.  (64 t + offset) >> shift with offset = 2^(shift - 1) + (8192 << 6),
+          // shift >= 8: (t + offset / 64) >> (shift - 6); |t| <= 13 762 for 10-bit samples (first pass minus 8192), so t + offset / 64 stays inside 16 bits
+          const v2s addv = { ( short ) ( pV.offset >> 6 ), ( short ) ( pV.offset >> 6 ) }, shv = { ( short ) ( pV.shift - 6 ), ( short ) ( pV.shift - 6 ) };
+#pragma unroll
+          for( int y = 0; y < 8; y++ )
+          {
+            const int4 t4 = *reinterpret_cast<const int4 *>( pl + ( y + 3 ) * W );
+            const int  tw[4] = { t4.x, t4.y, t4.z, t4.w };
+#pragma unroll
+            for( int k = 0; k < 4; k++ )
+            {
+              v2s t;
+              __builtin_memcpy( &t, &tw[k], 4 );
+              P[y][k] = ( t + addv ) >> shv;
+            }
+          }
+        }
+        else
+        {
+          fir();
+#pragma unroll
+          for( int y = 0; y < 8; y++ )
+#pragma unroll
+            for( int k = 0; k < 4; k++ )
+            {
+              const unsigned pw = __builtin_amdgcn_perm( ( unsigned ) acc[y * 8 + 2 * k + 1], ( unsigned ) acc[y * 8 + 2 * k], 0x07060302u );   // the two upper halves
+              __builtin_memcpy( &P[y][k], &pw, 4 );
+            }
+        }
         v2s       D[8][4];
         const v2s zero = { 0, 0 }, cmaxv = { ( short ) pV.cmax, ( short ) pV.cmax };
         unsigned  wide = 0;
@@ -548,12 +616,9 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
 #pragma unroll
           for( int k = 0; k < 4; k++ )
           {
-            const unsigned pw = __builtin_amdgcn_perm( ( unsigned ) acc[y * 8 + 2 * k + 1], ( unsigned ) acc[y * 8 + 2 * k], 0x07060302u );   // the two upper halves
-            v2s ov, pv;
+            v2s ov;
             __builtin_memcpy( &ov, &o.v[k], 4 );
-            __builtin_memcpy( &pv, &pw, 4 );
-            pv      = __builtin_elementwise_min( __builtin_elementwise_max( pv, zero ), cmaxv );
-            D[y][k] = ov - pv;
+            D[y][k] = ov - __builtin_elementwise_min( __builtin_elementwise_max( P[y][k], zero ), cmaxv );
             wide |= o.v[k];
           }
         }
@@ -562,6 +627,7 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
       }
       else if( j.useHad )
       {
+        fir();
 #pragma unroll
         for( int y = 0; y < 8; y++ )
         {
@@ -595,6 +661,7 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
       }
       else
       {
+        fir();
         unsigned t = 0;
 #pragma unroll
         for( int y = 0; y < 8; y++ )
@@ -611,6 +678,8 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
       }
       if( !( C::PAIR && j.useHad ) || ( tile & 1 ) == 0 ) atomicAdd( &sCost[jl * 16 + cand], d );   // a Hadamard pair's value is the same in both lanes: the even one adds it
     }
+    };
+    if( pkAll ) phaseV( std::true_type{} ); else phaseV( std::false_type{} );
     __syncthreads();
     }   // planes
 
