@@ -364,10 +364,8 @@ struct FracSq
   static constexpr bool PAIR = W != H;                          // 16x8 / 8x16 Hadamard tiles: two neighbouring 8x8 items per tile
   static constexpr int ITEMS = 9 * TILES;                       // per PU per round
   static constexpr int BLOCK = TILES == 16 ? 192 : TILES == 256 ? 512 : 256;   // 128x128: 72 KB of LDS = two workgroups per CU, so eight waves each (768 items per plane pass = 1.5 trips): 3.13 -> 3.03 ms per picture; 16 waves 3.09; 64x64 with six waves 3.23
-  static constexpr int MINW  = 4;                                // waves per SIMD the register budget is sized for (128 VGPRs; the dot-product V pass fits every size)
-  // PUs per workgroup.  32x32 / 64x16 (16 tiles, 3 waves): 2 -- 288 / 256 items = 1.5 / 1.33 trips of 192 lanes, but 22 KB of LDS per workgroup instead of 44 KB
-  // lets five workgroups (15 waves) share a CU instead of three (9): 4 PUs (full trips) measured 3.23 ms for the picture's fractional searches, 3: 3.15, 2: 3.14, 1: 3.19
   static constexpr int JPW   = TILES == 16 ? 2 : ITEMS >= BLOCK ? 1 : BLOCK / ITEMS;   // 8x8: 28, 16x8: 14, 16x16 / 32x8: 7, 32x16: 3, larger: 1
+  static constexpr int MINW  = 4;                                // waves per SIMD the register budget is sized for (128 VGPRs; the dot-product V pass fits every size)
   static constexpr int WLD   = W + 8;                           // window stride
   static constexpr int WIN   = ( H + 8 ) * WLD;                 // window samples per PU
   static constexpr int PLANE = ( H + 8 ) * W;                   // one H-pass plane
@@ -422,7 +420,11 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
       constexpr int CH = W / 8, NP = C::NPL, PER = ( H + 8 ) * CH;
       // item order: plane slowest, so that whole waves work on the centre plane, whose horizontal phase is 0 in the half-sample round (and in the quarter-sample
       // round of the PUs whose half-sample winner has no horizontal part): the identity filter (InterpolationFilter.cpp:77-79, m_lumaFilter[0] = {0,0,0,64,0,0,0,0})
-      for( int i = tid; i < C::JPW * NP * PER; i += C::BLOCK )
+      // Half-sample round: the planes dx = -1 and dx = +1 are the SAME filter one integer column apart (qx = -2 -> column offset -1, phase 2; qx = +2 -> offset 0,
+      // phase 2): plane(+1)[x] = plane(-1)[x + 1], so one item forms 9 sums from its 16 window samples and stores both planes' 8 outputs (36 dot products
+      // instead of 64).  SEQ has one plane buffer and keeps the two passes.
+      const bool pairH = !C::SEQ && round == 0;
+      for( int i = tid; i < C::JPW * ( pairH ? 2 : NP ) * PER; i += C::BLOCK )
       {
         const int pp = i / ( C::JPW * PER ), rem = i - pp * C::JPW * PER;
         const int jl = rem / PER, o = rem - jl * PER, r = o / CH, x0 = ( o - r * CH ) * 8;
@@ -472,9 +474,7 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
         v2s cpk[4];
 #pragma unroll
         for( int m = 0; m < 4; m++ ) { cpk[m].x = ( short ) ch[2 * m]; cpk[m].y = ( short ) ch[2 * m + 1]; }
-        unsigned outw[4];
-#pragma unroll
-        for( int q = 0; q < 8; q++ )
+        auto hsum = [&]( int q ) -> unsigned
         {
           int sum = 0;
 #pragma unroll
@@ -485,10 +485,16 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
             __builtin_memcpy( &pv, &pw, 4 );
             sum = __builtin_amdgcn_sdot2( pv, cpk[m], sum, false );
           }
-          const unsigned hv = ( unsigned ) ( unsigned short ) if_finish( sum, pH );
-          if( q & 1 ) outw[q >> 1] |= hv << 16; else outw[q >> 1] = hv;
+          return ( unsigned ) ( unsigned short ) if_finish( sum, pH );
+        };
+        const unsigned h0 = hsum( 0 ), h1 = hsum( 1 ), h2 = hsum( 2 ), h3 = hsum( 3 ), h4 = hsum( 4 ), h5 = hsum( 5 ), h6 = hsum( 6 ), h7 = hsum( 7 );
+        int16_t *out = lds + jl * C::PERJOB + C::WIN + r * W + x0;
+        *reinterpret_cast<int4 *>( out + pp * C::PLANE ) = make_int4( ( int ) ( h0 | h1 << 16 ), ( int ) ( h2 | h3 << 16 ), ( int ) ( h4 | h5 << 16 ), ( int ) ( h6 | h7 << 16 ) );
+        if( pairH )
+        {
+          const unsigned h8 = hsum( 8 );
+          *reinterpret_cast<int4 *>( out + 2 * C::PLANE ) = make_int4( ( int ) ( h1 | h2 << 16 ), ( int ) ( h3 | h4 << 16 ), ( int ) ( h5 | h6 << 16 ), ( int ) ( h7 | h8 << 16 ) );
         }
-        *reinterpret_cast<int4 *>( lds + jl * C::PERJOB + C::WIN + pp * C::PLANE + r * W + x0 ) = make_int4( ( int ) outw[0], ( int ) outw[1], ( int ) outw[2], ( int ) outw[3] );
       }
     }
     __syncthreads();
