@@ -112,6 +112,32 @@ def test_reference_encoder_predInterSearch_one_call_per_cu(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(enc_dropin.REF_SO), reason="oracle/_ref/libvtmref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("structure", ["ldp", "ldb"])
+def test_reference_encoder_predInterSearch_low_delay(tmp_path, structure):
+    """The same one-call-per-CU hook on BASELINE config 2's coding structures (tests/data/enc_ld{p,b}_gop4.cfg, SearchRange 64 without ASR, four reference pictures):
+    low-delay P -- P slices, list 0 only (InterSearch.cpp:2363 numRefDir 1, the uni decision without a bi stage); low-delay B -- both lists hold the SAME four pictures:
+    every list-1 row is a FastMEForGenBLowDelay copy (:2391-2404), mvd_l1_zero pictures (:2477-2522), no SMVD (needs references on both sides).  Replace mode, bitstream
+    and reconstruction equal the plain run's."""
+    frames = 6
+    yuv = str(tmp_path / "clip.yuv")
+    enc_dropin.write_clip(yuv, W, H, frames)
+    cfg = os.path.join(enc_dropin.ROOT, "tests", "data", "enc_%s_gop4.cfg" % structure)
+    st0, bits0, rec0 = enc_dropin.encode(yuv, W, H, frames, QP, str(tmp_path / "plain"), False, 2048 | 8, 1, 0, cfg=cfg)
+    st2, bits2, rec2 = enc_dropin.encode(yuv, W, H, frames, QP, str(tmp_path / "rep"), True, 2048 | 128, 1, 0, env={"VTMREF_REPLACE": "1"}, cfg=cfg)
+    print(structure, "plain:", st0["pis"], "replace:", st2["pis"], st2["affine"])
+    assert st0["rc"] == 0 and st2["rc"] == 0 and st2["errors"] == 0, st2
+    assert st2["pis"]["calls"] == st0["pis"]["calls"] and st2["pis"]["device"] >= 5000, st2["pis"]
+    assert st2["pis"]["unsupported"] == 0 and st2["pis"]["mismatch"] == [0] * 6 and st2["pis"]["replayFallback"] == 0, st2["pis"]
+    assert st2["affine"][2] == 0, st2["affine"]
+    assert bits2 == bits0 and rec2 == rec0
+    out = os.path.join(enc_dropin.ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        import json
+        json.dump({"clip": "%dx%d, %d pictures, QP %d, tests/data/enc_%s_gop4.cfg" % (W, H, frames, QP, structure), "bitstream_md5": bits0, "identical_bitstream": True,
+                   "plain": st0["pis"], "replace": st2["pis"], "affine_replace": st2["affine"]}, open(os.path.join(out, "encoder_replace_%s_192x128.json" % structure), "w"), indent=1)
+
+
+@pytest.mark.skipif(not os.path.exists(enc_dropin.REF_SO), reason="oracle/_ref/libvtmref.so not built (needs /root/reference)")
 def test_reference_encoder_intra_preselection_batched(tmp_path):
     """SURVEY.md 8(f) row 4, first part: the SATD pre-selection of IntraSearch::estIntraPredLumaQT (IntraSearch.cpp:549-592) as ONE vtmhip_intra_cand_cost_batch_dev call per CU
     inside the real encoder (oracle/ref_shim_intra.hpp): the 35 first-round predictors (formed by the reference's own predIntraAng) against the original block -> 35 SADs + 35
