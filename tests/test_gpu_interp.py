@@ -196,6 +196,54 @@ def test_frac_search_tiled_square_path(ctx, size, use_had, signed):
     assert not bad, [(got[k], exp[k]) for k in bad[:5]]
 
 
+@pytest.mark.parametrize("size", [8, 16, 32, 64, 128])
+@pytest.mark.parametrize("mode", ["bd8", "bd12", "mixed"])
+def test_frac_search_tiled_bit_depths_and_mixed_batches(ctx, size, mode):
+    """The tiled path picks its arithmetic per WORKGROUP: packed 16-bit (every PU of the workgroup asks for the Hadamard cost at bitDepth <= 10; with the identity
+    shortcuts for phase 0) or the general 32-bit path.  bd8: 8-bit samples through the packed path (other shifts and offsets than at 10 bits); bd12: the general
+    path; mixed: a batch whose jobs alternate between SATD / SAD and between 8 / 10 / 12 bits per job in runs of 5, so that workgroups hold both kinds."""
+    L = ol.oracle()
+    scene = me_util.Scene(416, 240, hard=True)
+    rng = np.random.default_rng(500 + size)
+    n = {8: 300, 16: 150, 32: 60, 64: 24, 128: 6}[size]
+    # three sample ranges of the same pictures: 8, 10, 12 bits
+    curs = {8: np.ascontiguousarray(scene.cur >> 2), 10: scene.cur, 12: np.ascontiguousarray(scene.cur << 2)}
+    refs = {8: np.ascontiguousarray(scene.ref_buf >> 2), 10: scene.ref_buf, 12: np.ascontiguousarray(scene.ref_buf << 2)}
+    plane = curs[10].size
+    cur_all = np.ascontiguousarray(np.concatenate([curs[8].ravel(), curs[10].ravel(), curs[12].ravel()]))
+    ref_all = np.ascontiguousarray(np.concatenate([refs[8].ravel(), refs[10].ravel(), refs[12].ravel()]))
+    arr = (FracJob * n)()
+    exp = []
+    for k in range(n):
+        bd = {"bd8": 8, "bd12": 12}.get(mode) or (8, 10, 12, 10)[(k // 5) % 4]
+        use_had = 1 if mode != "mixed" else (1, 1, 1, 0, 1)[(k // 5) % 5]
+        slot = {8: 0, 10: 1, 12: 2}[bd]
+        x = int(rng.integers(0, (416 - size) // 4 + 1)) * 4
+        y = int(rng.integers(0, (240 - size) // 4 + 1)) * 4
+        j = dict(w=size, h=size, x=x, y=y, subShift=0, lam=float(rng.uniform(1, 40)), predHor=int(rng.integers(-64, 64)), predVer=int(rng.integers(-64, 64)))
+        ix, iy = int(rng.integers(-12, 12)), int(rng.integers(-12, 12))
+        org = np.ascontiguousarray(curs[bd][y:y + size, x:x + size])
+        c = me_util.oracle_ctx(scene, j, org)
+        c.ref = refs[bd].ctypes.data + 2 * (scene.ref_off + y * scene.ref_stride + x)
+        c.bitDepth = bd
+        fr = ol.FracResult()
+        L.vo_frac_search(C.byref(c), ix, iy, use_had, 0, C.byref(fr))
+        exp.append((fr.halfX, fr.halfY, fr.qterX, fr.qterY, fr.cost))
+        t = arr[k]
+        t.orgOff, t.refOff = slot * plane + y * 416 + x, slot * refs[10].size + scene.ref_off + y * scene.ref_stride + x
+        t.orgStride, t.refStride, t.width, t.height = 416, scene.ref_stride, size, size
+        t.intX, t.intY, t.predHor, t.predVer, t.motionLambda = ix, iy, j["predHor"], j["predVer"], j["lam"]
+        t.useHad, t.useAltHpelIf, t.imvShift, t.bitDepth = use_had, 0, 0, bd
+    d_cur, d_ref = ctx.to_device(cur_all), ctx.to_device(ref_all)
+    d_jobs = ctx.to_device(np.frombuffer(arr, np.uint8))
+    d_res = ctx.alloc(16 * n)
+    ctx.frac_search_batch(d_cur.ptr, d_ref.ptr, d_jobs.ptr, n, size, size, d_res.ptr, uniform_square=True)
+    res = (FracResult * n).from_buffer_copy(d_res.to_host(np.uint8).tobytes())
+    got = [(r.halfX, r.halfY, r.qterX, r.qterY, r.cost) for r in res]
+    bad = [k for k in range(n) if got[k] != exp[k]]
+    assert not bad, [(k, got[k], exp[k]) for k in bad[:5]]
+
+
 RECT_SHAPES = [(16, 8), (8, 16), (32, 8), (8, 32), (32, 16), (16, 32), (64, 16), (16, 64), (64, 32), (32, 64)]
 
 
