@@ -280,7 +280,7 @@ __device__ void affine_pred( const AffCtx &c, const Mv3 &m, int16_t *sPred )
 // packed (bitDepth <= 10: |pattern - prediction| <= 3 * 1023): a lane takes one 8x8 unit with the packed 16-bit Hadamard of had.hpp; the two halves of a
 // 16x8 / 8x16 tile sit in neighbouring lanes (units in pair order), each returns the finished tile value and the even lane counts it.
 template<bool packed>
-__device__ unsigned long long block_dist( const int16_t *sPred, const int16_t *sPat, int w, int h, bool satd, unsigned long long *sRed )
+__device__ __forceinline__ unsigned long long block_dist( const int16_t *sPred, const int16_t *sPat, int w, int h, bool satd, unsigned long long *sRed )
 {
   unsigned long long acc = 0;
   if( satd && packed )

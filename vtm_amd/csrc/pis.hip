@@ -271,9 +271,15 @@ __global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
   const int pu = blockIdx.x * 256 + threadIdx.x;
   if( pu >= L.numPU ) return;
   vtmhip_pis_pu P  = L.pus[pu];
-  const int     rl = P.refineList, ot = 1 - rl;
-  if( !L.mvdL1Zero ) { P.mvBi[ot][0] = P.mv[ot][0]; P.mvBi[ot][1] = P.mv[ot][1]; P.refIdxBi[ot] = P.refIdx[ot]; }      // (MvdL1Zero: stage 2 put list 1 at its predictor)
-  P.mvBi[rl][0] = P.mv[rl][0]; P.mvBi[rl][1] = P.mv[rl][1]; P.refIdxBi[rl] = P.refIdx[rl];
+  const int     rl = P.refineList;
+  // (constant indices only: a run-time index into P or into a local job record would put them into scratch memory)
+  auto set_bi = [&]( int list, int h, int v, int ref )
+  {
+    if( list == 0 ) { P.mvBi[0][0] = h; P.mvBi[0][1] = v; P.refIdxBi[0] = ref; }
+    else            { P.mvBi[1][0] = h; P.mvBi[1][1] = v; P.refIdxBi[1] = ref; }
+  };
+  if( !L.mvdL1Zero || rl == 0 ) set_bi( 0, P.mv[0][0], P.mv[0][1], P.refIdx[0] );      // (MvdL1Zero: stage 2 put list 1 at its predictor, and list 0 is the refined list)
+  if( !L.mvdL1Zero || rl == 1 ) set_bi( 1, P.mv[1][0], P.mv[1][1], P.refIdx[1] );
   for( int ref = 0; ref < L.numRef[rl]; ref++ )
   {
     const vtmhip_me_job &j = L.biJobs[ref * L.numPU + pu];
@@ -282,7 +288,7 @@ __global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
     r.mvHor = o.mvHor; r.mvVer = o.mvVer; r.mvPredHor = o.mvPredHor; r.mvPredVer = o.mvPredVer; r.mvpIdx = o.mvpIdx; r.bits = o.bits; r.cost = o.cost;
     check_best_mvp( j, r );
     if( L.biRows ) L.biRows[ref * L.numPU + pu] = r;
-    if( r.cost < P.costBi ) { P.costBi = r.cost; P.bits[2] = r.bits; P.mvBi[rl][0] = r.mvHor; P.mvBi[rl][1] = r.mvVer; P.refIdxBi[rl] = ref; }
+    if( r.cost < P.costBi ) { P.costBi = r.cost; P.bits[2] = r.bits; set_bi( rl, r.mvHor, r.mvVer, ref ); }
   }
   if( L.smvdJobs )
   {
@@ -291,7 +297,7 @@ __global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
     const int s0 = L.symRefIdx[0], s1 = L.symRefIdx[1];
     const vtmhip_me_job &u0 = L.uniJobs[uni_row( L, 0, s0, pu )], &u1 = L.uniJobs[uni_row( L, 1, s1, pu )];
     const vtmhip_pis_row &r0 = L.uniRows[uni_row( L, 0, s0, pu )];
-    vtmhip_smvd_job j;
+    vtmhip_smvd_job &j = L.smvdJobs[pu];   // written in place
     j.orgOff = u0.orgOff; j.refOff[0] = u0.refOff; j.refOff[1] = u1.refOff; j.orgStride = u0.orgStride; j.refStride[0] = u0.refStride; j.refStride[1] = u1.refStride;
     j.puX = u0.puX; j.puY = u0.puY; j.width = u0.width; j.height = u0.height;
     j.imv = u0.imv; j.useSatd = 1; j.clipBiPred = 0; j.bcwWeightTar = 4;
@@ -319,7 +325,6 @@ __global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
     j.mvCur[0] = j.mvCur[1] = j.mvTar[0] = j.mvTar[1] = 0;
     for( int l = 0; l < 2; l++ ) { j.predSym[l][0] = j.predSym[l][1] = 0; j.mvpIdxSym[l] = 0; }
     j.cost = ~0ull;
-    L.smvdJobs[pu] = j;
     L.pus[pu] = P;
     return;
   }
