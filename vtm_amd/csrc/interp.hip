@@ -356,6 +356,15 @@ __global__ __launch_bounds__( 64 ) void frac_search_kernel( const int16_t *__res
 // its two halves plus one more butterfly level, sum |A_i + B_i| + |A_i - B_i| = 2 sum max(|A_i|, |B_i|): the two 8x8 items of a tile sit in
 // neighbouring lanes (tile order: the long direction fastest) and finish through one DPP exchange (had.hpp satd8_pair_*).
 // =====================================================================================================================
+// Plane slots of the tiled search (three per PU): the half-sample round stores plane dx in slot dx + 1; the quarter-sample round keeps the slot of its centre plane
+// (the half-sample winner's plane, centreX = 2 * halfX) and puts dx = -1 / +1 into the two others.
+__device__ __forceinline__ int plane_slot( int round, int centreX, int dx )
+{
+  if( round == 0 ) return dx + 1;
+  const int c = ( centreX >> 1 ) + 1, s = c + ( dx == 0 ? 0 : dx < 0 ? 1 : 2 );
+  return s >= 3 ? s - 3 : s;
+}
+
 template<int W, int H>
 struct FracSq
 {
@@ -423,13 +432,16 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
       // Half-sample round: the planes dx = -1 and dx = +1 are the SAME filter one integer column apart (qx = -2 -> column offset -1, phase 2; qx = +2 -> offset 0,
       // phase 2): plane(+1)[x] = plane(-1)[x + 1], so one item forms 9 sums from its 16 window samples and stores both planes' 8 outputs (36 dot products
       // instead of 64).  SEQ has one plane buffer and keeps the two passes.
+      // Quarter-sample round: its centre plane (qx = 2 * halfX) IS the half-sample round's plane dx = halfX, still in its slot; only dx = -1 / +1 are formed, into the
+      // two other slots (plane_slot).  So both rounds run two plane items per (PU, row, chunk).  SEQ has one plane buffer and keeps the three passes.
       const bool pairH = !C::SEQ && round == 0;
-      for( int i = tid; i < C::JPW * ( pairH ? 2 : NP ) * PER; i += C::BLOCK )
+      for( int i = tid; i < C::JPW * ( C::SEQ ? NP : 2 ) * PER; i += C::BLOCK )
       {
         const int pp = i / ( C::JPW * PER ), rem = i - pp * C::JPW * PER;
         const int jl = rem / PER, o = rem - jl * PER, r = o / CH, x0 = ( o - r * CH ) * 8;
         if( jl >= nj ) continue;
-        const int p = C::SEQ ? seqPl : pp;
+        const int p = C::SEQ ? seqPl : round == 0 ? pp : 2 * pp;                                  // dx + 1
+        const int ps = C::SEQ ? 0 : plane_slot( round, sCentre[jl][0], p - 1 );                    // the slot the plane is stored in
         const vtmhip_frac_job &j = jobs[job0 + jl];
         const int qx = sCentre[jl][0] + ( p - 1 ) * step, ix = qx >> 2, fx = qx & 3;
         const IfParams pH = if_params( 1, 0, j.bitDepth, 0, ( 1 << j.bitDepth ) - 1, 0 );
@@ -451,7 +463,7 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
             v = ( v << up6 ) - ( short ) 8192;
             __builtin_memcpy( &ow[m], &v, 4 );
           }
-          *reinterpret_cast<int4 *>( lds + jl * C::PERJOB + C::WIN + pp * C::PLANE + r * W + x0 ) = make_int4( ow[0], ow[1], ow[2], ow[3] );
+          *reinterpret_cast<int4 *>( lds + jl * C::PERJOB + C::WIN + ps * C::PLANE + r * W + x0 ) = make_int4( ow[0], ow[1], ow[2], ow[3] );
           continue;
         }
         const int16_t *cH = ( round == 0 && j.useAltHpelIf && fx == 2 ) ? c_lumaAltHpel : c_lumaFilter[fx << 2];
@@ -489,7 +501,7 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
         };
         const unsigned h0 = hsum( 0 ), h1 = hsum( 1 ), h2 = hsum( 2 ), h3 = hsum( 3 ), h4 = hsum( 4 ), h5 = hsum( 5 ), h6 = hsum( 6 ), h7 = hsum( 7 );
         int16_t *out = lds + jl * C::PERJOB + C::WIN + r * W + x0;
-        *reinterpret_cast<int4 *>( out + pp * C::PLANE ) = make_int4( ( int ) ( h0 | h1 << 16 ), ( int ) ( h2 | h3 << 16 ), ( int ) ( h4 | h5 << 16 ), ( int ) ( h6 | h7 << 16 ) );
+        *reinterpret_cast<int4 *>( out + ps * C::PLANE ) = make_int4( ( int ) ( h0 | h1 << 16 ), ( int ) ( h2 | h3 << 16 ), ( int ) ( h4 | h5 << 16 ), ( int ) ( h6 | h7 << 16 ) );
         if( pairH )
         {
           const unsigned h8 = hsum( 8 );
@@ -526,7 +538,7 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
       for( int k = 0; k < 8; k++ ) cv[k] = cV[k];
       // tile order: the long direction of the PU fastest, so that the two 8x8 halves of a 16x8 / 8x16 Hadamard tile are the items of lanes 2k, 2k + 1
       const int      ty = W >= H ? tile / C::TX : tile % C::TY, tx = W >= H ? tile - ty * C::TX : tile / C::TY;
-      const int16_t *pl = lds + jl * C::PERJOB + C::WIN + ( C::SEQ ? 0 : dx + 1 ) * C::PLANE + ( ty * 8 + iy + 1 ) * W + tx * 8;
+      const int16_t *pl = lds + jl * C::PERJOB + C::WIN + ( C::SEQ ? 0 : plane_slot( round, sCentre[jl][0], dx ) ) * C::PLANE + ( ty * 8 + iy + 1 ) * W + tx * 8;
       const IfParams pV = if_params( 0, 1, j.bitDepth, 0, ( 1 << j.bitDepth ) - 1, 0 );
       // Vertical FIR with v_dot2c_i32_i16: rows r and r + 1 are interleaved column-wise (two v_perm per dword pair), so one instruction
       // applies two taps: output row y takes the row pairs (y, y+1), (y+2, y+3), (y+4, y+5), (y+6, y+7) with the tap pairs
