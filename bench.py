@@ -79,21 +79,39 @@ def parse():
     return a
 
 
+KERNEL_SRC = {"tz_search_kernel": "me.hip", "tz_raster_cols_kernel": "me.hip", "full_search_sq_kernel": "me.hip", "full_search_kernel": "me.hip", "frac_search_sq_kernel": "interp.hip",
+              "motion_comp_kernel": "mc.hip", "bdof_kernel": "mc.hip", "tu_chain_uni_kernel": "transform.hip", "tu_ts_kernel": "transform.hip", "tu_chain_lane_kernel": "transform.hip",
+              "dist_uniform_kernel": "dist.hip", "satd8_grid_kernel": "dist.hip", "affine_me_kernel": "affine.hip", "smvd_tile_kernel": "smvd.hip", "smvd_kernel": "smvd.hip"}
+
+
 def workload_key(a, world):
-    """what the PMC instruction counters of a run depend on: the argument vector that shapes the work + the sources of the counted kernel
-    (frac_search_sq_kernel: interp.hip and the headers).  The committed counters
-    (profiles/pmc_insts_per_launch.json, written from a run of THIS script) carry the key of their run; a roofline fraction is only formed when it matches."""
+    """what the PMC instruction counters of a run depend on: the argument vector that shapes the work + the kernel sources (one hash per .hip file and one over the
+    headers: a kernel's counters stay valid while ITS file and the headers are unchanged -- the other stages' results are bit-exact by the parity tests, so its job set
+    does not depend on how they are implemented).  The committed counters (profiles/pmc_insts_per_launch.json, written from a run of THIS script) carry the key of their
+    run; a roofline fraction is only formed when it matches (counters_for)."""
     import hashlib
-    h = hashlib.sha1()
-    # the sources the counted kernel is compiled from: its own file and every header (the other stages' results are bit-exact by the parity tests, so the
-    # counted kernel's job set does not depend on how they are implemented)
-    for f in sorted(os.listdir(os.path.join(ROOT, "vtm_amd", "csrc"))):
-        if f == "interp.hip" or f.endswith(".hpp"):
-            h.update(open(os.path.join(ROOT, "vtm_amd", "csrc", f), "rb").read())
+    d, hdr = os.path.join(ROOT, "vtm_amd", "csrc"), hashlib.sha1()
+    src = {}
+    for f in sorted(os.listdir(d)):
+        b = open(os.path.join(d, f), "rb").read()
+        if f.endswith(".hpp"):
+            hdr.update(b)
+        elif f.endswith(".hip"):
+            src[f] = hashlib.sha1(b).hexdigest()
+    src["headers"] = hdr.hexdigest()
     args = dict(width=a.width, height=a.height, config=a.config, dpoc=a.dpoc_list if a.config == "ra" else None, qp=a.qp, ts=bool(a.transform_skip), smvd=bool(a.smvd and a.config == "ra"),
                 affine=bool(a.affine), partition=a.partition, luma_only=bool(a.luma_only), shard=a.shard if world > 1 else None, world=world,
                 sim=int(os.environ.get("VTM_BENCH_SIMULATE_WORLD", "0")))
-    return {"args": args, "kernel_src_sha1": h.hexdigest()}
+    return {"args": args, "src_sha1": src}
+
+
+def counters_for(kernel, meta, wkey, same_args=True):
+    """True when the committed counters (their _meta key) were collected with this kernel's source file and the headers as they are now (and, same_args, from this command)."""
+    if not meta or "src_sha1" not in meta:
+        return False
+    f = KERNEL_SRC.get(kernel)
+    m, w = meta["src_sha1"], wkey["src_sha1"]
+    return f is not None and m.get(f) == w.get(f) and m.get("headers") == w.get("headers") and (not same_args or meta.get("args") == wkey["args"])
 
 
 def cpu_baseline(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, budget_s, pocs=None, chroma=None, affine=False, low_delay=False, smvd=None):
@@ -233,6 +251,10 @@ def main():
     dpb = torch.from_numpy(dpb_np).to(dev)
 
     ctx = Context(local)
+    # the caller's stream carries the dependent chain of the uni searches (the picture's critical path): VTM_BENCH_MAIN_PRIORITY=-1 gives it a high-priority queue, so that
+    # its workgroups are dispatched ahead of the side streams' (default priority) when both have work
+    if os.environ.get("VTM_BENCH_MAIN_PRIORITY", "0") != "0":
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["VTM_BENCH_MAIN_PRIORITY"])))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     lam, qp = 8.0, a.qp
     bands = pipeline.ctu_bands(W, H, world, unit=a.shard)
@@ -395,13 +417,13 @@ def main():
 
         wkey = workload_key(a, world)
         pmc_meta = pmc_i.get("_meta")
-        counters_match = pmc_meta is not None and pmc_meta == wkey      # the committed counters were collected from THIS command on THESE kernel sources
 
         def issue_roofline(name, ms, launches, in_step=True):
             # in_step: the kernel runs inside the picture step -> counters summed over its launches of one step; otherwise (the SATD micro-benchmark) ONE launch
             cpi = next((v["cycles_per_valu_inst"] for k, v in mix.items() if isinstance(v, dict) and k.startswith(name)), None)
             lps = (lambda v: v.get("launches_per_step", 1)) if in_step else (lambda v: 1)
-            ok = counters_match or (not in_step and pmc_meta is not None and pmc_meta.get("kernel_src_sha1") == wkey["kernel_src_sha1"] and (W, H) == (3840, 2160) and world == 1)
+            # the committed counters were collected from THIS command (in-step kernels) on THIS kernel's sources; the SATD micro-benchmark only depends on the picture size
+            ok = counters_for(name, pmc_meta, wkey, same_args=in_step) and (in_step or ((W, H) == (3840, 2160) and world == 1))
             sel = [v for k, v in pmc_i.items() if k.startswith(name) and isinstance(v, dict)] if ok else []
             insts = sum(v.get("SQ_INSTS_VALU", 0) * lps(v) for v in sel) or None
             salu = sum(v.get("SQ_INSTS_SALU", 0) * lps(v) for v in sel) or None
