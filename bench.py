@@ -479,6 +479,12 @@ def main():
         }
         if dom:
             out["roofline"] = issue_roofline(dom, kern[dom]["ms_per_step"], kern[dom]["launches_per_step"])
+            # the next two kernel families by time, same definition (the three largest are within 6 % of each other at the default operating point)
+            out["roofline_next"] = []
+            for k in sorted(kern, key=lambda k: -kern[k]["ms_per_step"])[1:3]:
+                r = issue_roofline(k, kern[k]["ms_per_step"], kern[k]["launches_per_step"])
+                r.pop("note", None)
+                out["roofline_next"].append(r)
         if satd_k_n:
             r = issue_roofline("satd8_grid_kernel", satd_k_ms / satd_k_n, 1, in_step=False)
             r["pairs_per_s_G"] = nb * 81 / (satd_k_ms / satd_k_n) / 1e6
