@@ -11,7 +11,10 @@ import pis_golden as G
 from vtm_amd.lib import MeCfg, PicParams, PisBuffers, PisLevelRun
 
 pytestmark = pytest.mark.gpu
-NPZ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pis_enc.npz")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# ra: the random-access clip (353 records); ldp / ldb: BASELINE config 2's structures (147 / 148 records: P slices with four references; low-delay B with the same four
+# pictures in both lists -- every list-1 row a FastMEForGenBLowDelay copy, mvd_l1_zero)
+NPZS = {"ra": os.path.join(GOLDEN, "pis_enc.npz"), "ldp": os.path.join(GOLDEN, "pis_enc_ldp.npz"), "ldb": os.path.join(GOLDEN, "pis_enc_ldb.npz")}
 
 
 def rate(lam, bits):
@@ -22,9 +25,10 @@ def same(a, b, fields):
     return all(getattr(a, f) == getattr(b, f) for f in fields)
 
 
-def test_predInterSearch_one_call_per_pu_matches_the_real_encoder():
+@pytest.mark.parametrize("structure", ["ra", "ldp", "ldb"])
+def test_predInterSearch_one_call_per_pu_matches_the_real_encoder(structure):
     from vtm_amd.device import Context
-    planes, recs = G.load_npz(NPZ)
+    planes, recs = G.load_npz(NPZS[structure])
     ctx = Context(0)
     dpb_np, bases = G.build_dpb(planes)
     d_dpb = ctx.to_device(dpb_np)
@@ -133,9 +137,14 @@ def test_predInterSearch_one_call_per_pu_matches_the_real_encoder():
         stats["recs"] += 1
         stats["imv"][hd.imv] += 1
         stats["mvdl1zero"] += hd.mvdL1Zero
-    print("pis golden:", stats)
-    assert stats["recs"] >= 300 and stats["copies"] >= 100 and stats["cached"] >= 100 and stats["bi"] >= 200 and stats["smvd"] >= 30 and stats["mvdl1zero"] >= 100
-    assert min(stats["imv"][:3]) >= 20 and stats["dirs"][3] >= 50 and stats["dirs"][1] >= 20
+    print("pis golden:", structure, stats)
+    if structure == "ra":
+        assert stats["recs"] >= 300 and stats["copies"] >= 100 and stats["cached"] >= 100 and stats["bi"] >= 200 and stats["smvd"] >= 30 and stats["mvdl1zero"] >= 100
+        assert min(stats["imv"][:3]) >= 20 and stats["dirs"][3] >= 50 and stats["dirs"][1] >= 20
+    elif structure == "ldp":
+        assert stats["recs"] >= 100 and stats["bi"] == 0 and stats["dirs"][1] >= 50 and stats["dirs"][2] == 0 and stats["dirs"][3] == 0
+    else:
+        assert stats["recs"] >= 100 and stats["copies"] >= 100 and stats["mvdl1zero"] >= 50 and stats["smvd"] == 0
     ctx.close()
 
 
@@ -167,12 +176,13 @@ def _level(ctx, planes, bases, hd, n, base_ptr, off_of):
     return R, stride
 
 
-def test_predInterSearch_batches_of_several_pus_equal_the_single_calls():
+@pytest.mark.parametrize("structure", ["ra", "ldp", "ldb"])
+def test_predInterSearch_batches_of_several_pus_equal_the_single_calls(structure):
     """The same records in BATCHES: the PUs of one slice, shape and AMVR mode (up to 17 in the golden file) in one vtmhip_predInterSearch_batch_dev call -- tables in
     the level-order layout (rows (list, refIdx)-major, PU-minor), per-PU m_uniMvList state in vtmhip_pis_pu_in -- must give every PU exactly what its own call gives."""
     from vtm_amd.device import Context
     from vtm_amd.lib import MeJob, MeOut, PisPu, PisPuIn, PisRow, PredJob, SmvdJob
-    planes, recs = G.load_npz(NPZ)
+    planes, recs = G.load_npz(NPZS[structure])
     ctx = Context(0)
     dpb_np, bases = G.build_dpb(planes)
     d_dpb = ctx.to_device(dpb_np)
@@ -266,6 +276,6 @@ def test_predInterSearch_batches_of_several_pus_equal_the_single_calls():
         for buf in (d, d_bi, d1):
             buf.free()
         batches += 1
-    print("pis golden batches:", batches, "PUs:", checked)
-    assert batches >= 40 and checked >= 200
+    print("pis golden batches:", structure, batches, "PUs:", checked)
+    assert (batches >= 40 and checked >= 200) if structure == "ra" else (batches >= 10 and checked >= 40)
     ctx.close()
