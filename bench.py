@@ -53,7 +53,8 @@ def parse():
     ap.add_argument("--config", choices=["ra", "ldp"], default="ra", help="ra: B slices, --refs + --refs reference pictures, ASR search ranges; "
                     "ldp: P slices, 4 list-0 pictures, SearchRange 64 (encoder_lowdelay_P_vtm.cfg)")
     ap.add_argument("--refs", type=int, default=2, help="ra: active reference pictures per list (1 = the round-1 operating point)")
-    ap.add_argument("--qp", type=int, default=32)
+    ap.add_argument("--qp", type=int, default=32, help="slice QP: quantiser of the TU chains and, through the reference's lambda formula, the motion lambda of the searches")
+    ap.add_argument("--lambda-motion", type=float, default=0.0, help="override the motion lambda (rounds 1-2 used 8.0 at every QP)")
     ap.add_argument("--lite", action="store_true", help="the lighter tool set of rounds 1-2: no SMVD block, no affine stage, no transform-skip candidate (each can be added back "
                     "with --smvd / --affine / --transform-skip).  Default: all three ON, as encoder_randomaccess_vtm.cfg has them (SMVD:1 Affine:1 TransformSkip:1)")
     ap.add_argument("--dpoc", type=str, default="", help="ra: |dPOC| of the reference pictures of EACH list, nearest first, e.g. 8,16 = the top layers of the RA GOP "
@@ -100,7 +101,7 @@ def workload_key(a, world):
             src[f] = hashlib.sha1(b).hexdigest()
     src["headers"] = hdr.hexdigest()
     args = dict(width=a.width, height=a.height, config=a.config, dpoc=a.dpoc_list if a.config == "ra" else None, qp=a.qp, ts=bool(a.transform_skip), smvd=bool(a.smvd and a.config == "ra"),
-                affine=bool(a.affine), partition=a.partition, luma_only=bool(a.luma_only), shard=a.shard if world > 1 else None, world=world,
+                affine=bool(a.affine), partition=a.partition, luma_only=bool(a.luma_only), shard=a.shard if world > 1 else None, world=world, lam=a.lambda_motion,
                 sim=int(os.environ.get("VTM_BENCH_SIMULATE_WORLD", "0")))
     return {"args": args, "src_sha1": src}
 
@@ -256,7 +257,10 @@ def main():
     if os.environ.get("VTM_BENCH_MAIN_PRIORITY", "0") != "0":
         torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["VTM_BENCH_MAIN_PRIORITY"])))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    lam, qp = 8.0, a.qp
+    # lambda_motion from the slice QP as the reference derives it for this cfg (LambdaFromQpEnable, DepQuant): lambda = 0.57 * 2^((QP - 12) / 3) * 2^(0.25 / 3)
+    # (EncSlice.cpp:700-786; bitDepthShift = -12 at 10 bits), m_dLambdaMotionSAD = sqrt( lambda ) (RdCost.cpp:79-84): QP 32 -> 7.83, QP 27 -> 4.39, QP 22 -> 2.47
+    qp = a.qp
+    lam = a.lambda_motion if a.lambda_motion > 0 else (0.57 * 2.0 ** ((qp - 12) / 3.0) * 2.0 ** (0.25 / 3.0)) ** 0.5
     bands = pipeline.ctu_bands(W, H, world, unit=a.shard)
     ctu_filter = pipeline.band_filter(W, bands[rank]) if world > 1 else None
     sim = int(os.environ.get("VTM_BENCH_SIMULATE_WORLD", "0"))      # one GPU computing rank 0's share of an N-GPU run (no exchange): what a rank's step costs
@@ -458,9 +462,9 @@ def main():
             "value": a.steps / dt, "unit": "pictures/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int16 samples, int32 accumulation (fp64 MV-rate multiply)", "data": "synthetic",
-            "config": {"workload": "%dx%d 10-bit, %s operating point (QP%d, %s, FEN): %s = %d PUs x (%d + %d) reference pictures = %d uni searches + %d bi searches "
+            "config": {"workload": "%dx%d 10-bit, %s operating point (QP%d, lambda_motion %.2f, %s, FEN): %s = %d PUs x (%d + %d) reference pictures = %d uni searches + %d bi searches "
                                    "per picture, %d TU x transform-candidate chains"
-                                   % (W, H, "encoder_randomaccess_vtm.cfg" if a.config == "ra" else "encoder_lowdelay_P_vtm.cfg", qp,
+                                   % (W, H, "encoder_randomaccess_vtm.cfg" if a.config == "ra" else "encoder_lowdelay_P_vtm.cfg", qp, lam,
                                       ("SR %s via ASR" % "/".join(str(x) for x in sorted({v for l in sr for v in l}))) if a.config == "ra" else "SR 64", "quadtree PUs 128..8" if a.partition == "qt" else "split-shape PU levels 128x128 64x64 64x32 32x32 32x16 16x16 16x8 8x8",
                                       wc["pus"] * world if world > 1 else wc["pus"], len(refs[0]), len(refs[1]),
                                       wc["uni_searches"], wc["bi_searches"], wc["tu_chains"])
