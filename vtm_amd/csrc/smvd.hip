@@ -523,11 +523,18 @@ enum { PH_INIT = 0, PH_STARTS, PH_DIAMOND, PH_CROSS, PH_FINAL, PH_COST, PH_DONE 
 
 // NW == 0: "group" form for PUs of at most four tiles -- a lane is (PU of the wave, candidate slot, tile), 64 / (8 * tiles) PUs per wave.
 // NW >= 1: one PU per workgroup of NW waves -- the (slot, tile) items of a pass are dealt to the lanes, the per-slot sums meet in LDS.
+#ifndef VTMHIP_SMVD_GROUP_SLOTS
+#define VTMHIP_SMVD_GROUP_SLOTS 4
+#endif
 template<int TX, int TY, int NW>
 __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
                                                                         vtmhip_smvd_job *__restrict__ jobs, int n, int op )
 {
-  constexpr int  T = TX * TY, LPP = 8 * T, PPW = NW ? 1 : 64 / LPP, NT = NW ? 64 * NW : 64;
+  // group form: NSLOT candidate slots per PU and pass step; a pass of the search (up to 8 candidates: the diamond's first round, two start vectors x four predictor
+  // pairs) runs as ceil( candidates / NSLOT ) steps.  Four slots instead of eight: the passes with <= 4 candidates (predictor pairs, later diamond rounds, cross, final
+  // check) no longer carry four idle slots, and a wave holds twice as many PUs.
+  constexpr int  NSLOT = VTMHIP_SMVD_GROUP_SLOTS;
+  constexpr int  T = TX * TY, LPP = ( NW ? 8 : NSLOT ) * T, PPW = NW ? 1 : 64 / LPP, NT = NW ? 64 * NW : 64;
   constexpr bool PAIR = TX != TY, GROUP = NW == 0;
   static_assert( NW != 0 || T <= 4, "the group form holds at most four tiles per PU" );
   __shared__ unsigned sDist[8];
@@ -675,23 +682,34 @@ __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_
     int bs;
     if( GROUP )
     {
-      int ax, ay, bx, by, tx, ty;
-      unsigned bits;
-      const bool valid = slot_params( slot, ax, ay, bx, by, bits );
+      // candidates of this PU's pass (slot_params marks the empty ones inside that range)
+      const int nSl = phase == PH_DONE ? 0 : ( phase == PH_DIAMOND || phase == PH_CROSS ) ? dEnd - dStart + 1 : phase == PH_COST ? 1 : phase == PH_STARTS && sj >= 0 ? 8 : num0 * num1;
+      int tx, ty;
       tile_xy( tile, tx, ty );
-      unsigned d = tile_eval<PAIR>( t, tx, ty, ax, ay, bx, by );
-      // PU sum over the tile lanes of the slot; a Hadamard pair already holds its tile's value in both lanes
-#pragma unroll
-      for( int off = 1; off < T; off <<= 1 )
-        if( off > 1 || !PAIR || !t.satd ) d += ( unsigned ) shfl_x( ( int ) d, off );
-      c = slot_cost( valid, d, bits ); bs = slot;
-      // first minimum of the pass over the slots of the group
-#pragma unroll
-      for( int off = T; off < LPP; off <<= 1 )
+      c = ~0ull; bs = 0;
+#pragma unroll 1
+      for( int s0 = 0; __any( s0 < nSl ); s0 += NSLOT )
       {
-        const unsigned long long oc = shfl_x64( c, off );
-        const int                os = shfl_x( bs, off );
-        if( oc < c || ( oc == c && os < bs ) ) { c = oc; bs = os; }
+        const int s = s0 + slot;
+        int ax, ay, bx, by;
+        unsigned bits;
+        const bool valid = slot_params( s, ax, ay, bx, by, bits ) && s < nSl;
+        unsigned d = tile_eval<PAIR>( t, tx, ty, ax, ay, bx, by );
+        // PU sum over the tile lanes of the slot; a Hadamard pair already holds its tile's value in both lanes
+#pragma unroll
+        for( int off = 1; off < T; off <<= 1 )
+          if( off > 1 || !PAIR || !t.satd ) d += ( unsigned ) shfl_x( ( int ) d, off );
+        unsigned long long cs = slot_cost( valid, d, bits );
+        int ss = s;
+        // first minimum of the step over the slots of the group
+#pragma unroll
+        for( int off = T; off < LPP; off <<= 1 )
+        {
+          const unsigned long long oc = shfl_x64( cs, off );
+          const int                os = shfl_x( ss, off );
+          if( oc < cs || ( oc == cs && os < ss ) ) { cs = oc; ss = os; }
+        }
+        if( cs < c ) { c = cs; bs = ss; }   // steps run in candidate order: a tie keeps the earlier step's candidate
       }
     }
     else
@@ -799,7 +817,7 @@ __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_
 template<int TX, int TY, int NW>
 void launch_tile( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, vtmhip_smvd_job *d_jobs, int n, int op )
 {
-  constexpr int PPW = NW ? 1 : 64 / ( 8 * TX * TY );
+  constexpr int PPW = NW ? 1 : 64 / ( VTMHIP_SMVD_GROUP_SLOTS * TX * TY );
   hipLaunchKernelGGL( ( smvd_tile_kernel<TX, TY, NW> ), dim3( ( n + PPW - 1 ) / PPW ), dim3( NW ? 64 * NW : 64 ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, op );
 }
 
