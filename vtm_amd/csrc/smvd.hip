@@ -526,6 +526,12 @@ enum { PH_INIT = 0, PH_STARTS, PH_DIAMOND, PH_CROSS, PH_FINAL, PH_COST, PH_DONE 
 #ifndef VTMHIP_SMVD_GROUP_SLOTS
 #define VTMHIP_SMVD_GROUP_SLOTS 4
 #endif
+#ifndef VTMHIP_SMVD_G8
+#define VTMHIP_SMVD_G8 0    // waves per PU of the 8-tile shapes (0: group form, two PUs per wave)
+#endif
+#ifndef VTMHIP_SMVD_G16
+#define VTMHIP_SMVD_G16 1   // ... of the 16-tile shapes (measured: one wave 2.58 ms for the picture's SMVD stage, group form 2.63, two waves 2.71)
+#endif
 template<int TX, int TY, int NW>
 __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
                                                                         vtmhip_smvd_job *__restrict__ jobs, int n, int op )
@@ -536,7 +542,7 @@ __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_
   constexpr int  NSLOT = VTMHIP_SMVD_GROUP_SLOTS;
   constexpr int  T = TX * TY, LPP = ( NW ? 8 : NSLOT ) * T, PPW = NW ? 1 : 64 / LPP, NT = NW ? 64 * NW : 64;
   constexpr bool PAIR = TX != TY, GROUP = NW == 0;
-  static_assert( NW != 0 || T <= 4, "the group form holds at most four tiles per PU" );
+  static_assert( NW != 0 || NSLOT * T <= 64, "the group form keeps a PU inside one wave" );
   __shared__ unsigned sDist[8];
   const int lane = threadIdx.x, g = GROUP ? lane / LPP : 0, l = GROUP ? lane - g * LPP : lane, slot = GROUP ? l / T : 0, tile = GROUP ? l - slot * T : 0;
   auto tile_xy = [&]( int tl, int &tx, int &ty ) { if( TX >= TY ) { ty = tl / TX; tx = tl - ty * TX; } else { tx = tl / TY; ty = tl - tx * TY; } };   // pair halves adjacent
@@ -853,11 +859,11 @@ int vtmhip_smvd_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const 
     case 16 * 256 + 16:   launch_tile<2, 2, 0>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
     case 32 * 256 + 8:    launch_tile<4, 1, 0>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
     case 8 * 256 + 32:    launch_tile<1, 4, 0>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
-    case 32 * 256 + 16:   launch_tile<4, 2, 1>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
-    case 16 * 256 + 32:   launch_tile<2, 4, 1>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
-    case 32 * 256 + 32:   launch_tile<4, 4, 2>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
-    case 64 * 256 + 16:   launch_tile<8, 2, 2>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
-    case 16 * 256 + 64:   launch_tile<2, 8, 2>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 32 * 256 + 16:   launch_tile<4, 2, VTMHIP_SMVD_G8>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 16 * 256 + 32:   launch_tile<2, 4, VTMHIP_SMVD_G8>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 32 * 256 + 32:   launch_tile<4, 4, VTMHIP_SMVD_G16>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 64 * 256 + 16:   launch_tile<8, 2, VTMHIP_SMVD_G16>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
+    case 16 * 256 + 64:   launch_tile<2, 8, VTMHIP_SMVD_G16>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
     case 64 * 256 + 32:   launch_tile<8, 4, 4>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
     case 32 * 256 + 64:   launch_tile<4, 8, 4>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
     case 64 * 256 + 64:   launch_tile<8, 8, 4>( ctx, pic, d_orgBase, d_refBase, d_jobs, n, op ); break;
