@@ -523,23 +523,19 @@ enum { PH_INIT = 0, PH_STARTS, PH_DIAMOND, PH_CROSS, PH_FINAL, PH_COST, PH_DONE 
 
 // NW == 0: "group" form for PUs of at most four tiles -- a lane is (PU of the wave, candidate slot, tile), 64 / (8 * tiles) PUs per wave.
 // NW >= 1: one PU per workgroup of NW waves -- the (slot, tile) items of a pass are dealt to the lanes, the per-slot sums meet in LDS.
-#ifndef VTMHIP_SMVD_GROUP_SLOTS
-#define VTMHIP_SMVD_GROUP_SLOTS 4
-#endif
 #ifndef VTMHIP_SMVD_G8
 #define VTMHIP_SMVD_G8 0    // waves per PU of the 8-tile shapes (0: group form, two PUs per wave)
 #endif
 #ifndef VTMHIP_SMVD_G16
 #define VTMHIP_SMVD_G16 1   // ... of the 16-tile shapes (measured: one wave 2.58 ms for the picture's SMVD stage, group form 2.63, two waves 2.71)
 #endif
-template<int TX, int TY, int NW>
+template<int TX, int TY, int NW, int NSLOT>
 __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
                                                                         vtmhip_smvd_job *__restrict__ jobs, int n, int op )
 {
   // group form: NSLOT candidate slots per PU and pass step; a pass of the search (up to 8 candidates: the diamond's first round, two start vectors x four predictor
   // pairs) runs as ceil( candidates / NSLOT ) steps.  Four slots instead of eight: the passes with <= 4 candidates (predictor pairs, later diamond rounds, cross, final
   // check) no longer carry four idle slots, and a wave holds twice as many PUs.
-  constexpr int  NSLOT = VTMHIP_SMVD_GROUP_SLOTS;
   constexpr int  T = TX * TY, LPP = ( NW ? 8 : NSLOT ) * T, PPW = NW ? 1 : 64 / LPP, NT = NW ? 64 * NW : 64;
   constexpr bool PAIR = TX != TY, GROUP = NW == 0;
   static_assert( NW != 0 || NSLOT * T <= 64, "the group form keeps a PU inside one wave" );
@@ -823,8 +819,22 @@ __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_
 template<int TX, int TY, int NW>
 void launch_tile( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, vtmhip_smvd_job *d_jobs, int n, int op )
 {
-  constexpr int PPW = NW ? 1 : 64 / ( VTMHIP_SMVD_GROUP_SLOTS * TX * TY );
-  hipLaunchKernelGGL( ( smvd_tile_kernel<TX, TY, NW> ), dim3( ( n + PPW - 1 ) / PPW ), dim3( NW ? 64 * NW : 64 ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, op );
+  if constexpr( NW != 0 )
+  {
+    hipLaunchKernelGGL( ( smvd_tile_kernel<TX, TY, NW, 8> ), dim3( n ), dim3( 64 * NW ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, op );
+  }
+  else
+  {
+  // group form: four candidate slots per PU fill the lanes best (the passes of a search hold 3 .. 8 candidates) and are the choice when the batch is larger than
+  // the machine; a batch of at most two waves per SIMD (a rank's share of a picture on eight GPUs) is bound by the latency of ONE wave's
+  // search, and eight slots halve the pass steps of that wave (1/8 share of a 4K picture: 2.60 -> 2.52 ms)
+  constexpr int T = TX * TY, WIDE = 8 * T <= 64 ? 8 : 4, PPW_WIDE = 64 / ( WIDE * T ), PPW4 = 64 / ( 4 * T );
+  const long wavesWide = ( ( long ) n + PPW_WIDE - 1 ) / PPW_WIDE;
+  if( WIDE == 8 && wavesWide <= 2L * 4 * ctx->numCUs )
+    hipLaunchKernelGGL( ( smvd_tile_kernel<TX, TY, 0, WIDE> ), dim3( ( n + PPW_WIDE - 1 ) / PPW_WIDE ), dim3( 64 ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, op );
+  else
+    hipLaunchKernelGGL( ( smvd_tile_kernel<TX, TY, 0, 4> ), dim3( ( n + PPW4 - 1 ) / PPW4 ), dim3( 64 ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, op );
+  }
 }
 
 }   // namespace
