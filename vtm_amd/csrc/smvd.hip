@@ -521,7 +521,7 @@ __device__ __forceinline__ unsigned long long shfl_x64( unsigned long long v, in
 
 enum { PH_INIT = 0, PH_STARTS, PH_DIAMOND, PH_CROSS, PH_FINAL, PH_COST, PH_DONE };
 
-// NW == 0: "group" form for PUs of at most four tiles -- a lane is (PU of the wave, candidate slot, tile), 64 / (8 * tiles) PUs per wave.
+// NW == 0: "group" form for PUs of at most eight tiles -- a lane is (PU of the wave, candidate slot, tile), 64 / (NSLOT * tiles) PUs per wave.
 // NW >= 1: one PU per workgroup of NW waves -- the (slot, tile) items of a pass are dealt to the lanes, the per-slot sums meet in LDS.
 #ifndef VTMHIP_SMVD_G8
 #define VTMHIP_SMVD_G8 0    // waves per PU of the 8-tile shapes (0: group form, two PUs per wave)
