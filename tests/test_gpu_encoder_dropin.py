@@ -138,6 +138,23 @@ def test_reference_encoder_predInterSearch_low_delay(tmp_path, structure):
 
 
 @pytest.mark.skipif(not os.path.exists(enc_dropin.REF_SO), reason="oracle/_ref/libvtmref.so not built (needs /root/reference)")
+def test_reference_encoder_predInterSearch_8bit_internal(tmp_path):
+    """The same hook with InternalBitDepth 8 (the random-access cfg otherwise): the interpolation shifts and offsets, the packed SATD paths and the clipping ranges of
+    8-bit samples inside the real encoder.  Replace mode; bitstream and reconstruction equal the plain run's."""
+    yuv = str(tmp_path / "clip.yuv")
+    enc_dropin.write_clip(yuv, W, H, FRAMES)
+    extra = ("--InternalBitDepth=8",)
+    st0, bits0, rec0 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "plain"), False, 2048 | 8, 1, 0, extra=extra)
+    st2, bits2, rec2 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "rep"), True, 2048 | 128, 1, 0, extra=extra, env={"VTMREF_REPLACE": "1"})
+    print("8-bit plain:", st0["pis"], "replace:", st2["pis"], st2["affine"])
+    assert st0["rc"] == 0 and st2["rc"] == 0 and st2["errors"] == 0, st2
+    assert st2["pis"]["calls"] == st0["pis"]["calls"] and st2["pis"]["device"] >= 5000, st2["pis"]
+    assert st2["pis"]["unsupported"] == 0 and st2["pis"]["mismatch"] == [0] * 6 and st2["pis"]["replayFallback"] == 0, st2["pis"]
+    assert st2["affine"][2] == 0, st2["affine"]
+    assert bits2 == bits0 and rec2 == rec0
+
+
+@pytest.mark.skipif(not os.path.exists(enc_dropin.REF_SO), reason="oracle/_ref/libvtmref.so not built (needs /root/reference)")
 def test_reference_encoder_intra_preselection_batched(tmp_path):
     """SURVEY.md 8(f) row 4, first part: the SATD pre-selection of IntraSearch::estIntraPredLumaQT (IntraSearch.cpp:549-592) as ONE vtmhip_intra_cand_cost_batch_dev call per CU
     inside the real encoder (oracle/ref_shim_intra.hpp): the 35 first-round predictors (formed by the reference's own predIntraAng) against the original block -> 35 SADs + 35
