@@ -340,7 +340,9 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
   PU::spanMotionInfo( pu );                  // (:2330; the member does it again)
   const double   lambda = is->m_pcRdCost->m_motionLambda;
   const Position pos = cu.lumaPos();
-  const uint32_t mbBits[3] = { isB ? 3u : 1u, 3u, 5u };      // xGetBlkBits (:3158-3163)
+  // xGetBlkBits (:3158-3163); with BCW enabled every bi cost carries the bits of the weight index (:2594, 2622, 2780: getWeightIdxBits( bcwIdx )) -- of the default weight here,
+  // other weights are unsupported above -- which is one more constant on the bi mode's bits
+  const uint32_t mbBits[3] = { isB ? 3u : 1u, 3u, 5u + ( isB && sps.getUseBcw() ? is->getWeightIdxBits( BCW_DEFAULT ) : 0u ) };
   const bool     fdm = is->m_pcEncCfg->getFastMEForGenBLowDelayEnabled();
   const bool     biRestricted = PU::isBipredRestriction( pu );
   const bool     hasSmvd = isB && !biRestricted && slice.getBiDirPred() && trySmvd;

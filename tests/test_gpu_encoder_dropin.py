@@ -155,6 +155,25 @@ def test_reference_encoder_predInterSearch_8bit_internal(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(enc_dropin.REF_SO), reason="oracle/_ref/libvtmref.so not built (needs /root/reference)")
+def test_reference_encoder_predInterSearch_with_bcw_enabled(tmp_path):
+    """BCW : 1 as in cfg/encoder_randomaccess_vtm.cfg: the encoder then calls predInterSearch once per CU-level weight.  The calls at the default weight go to the device
+    (their bi costs carry the bits of the weight index, InterSearch.cpp:2594, 2622, 2780); the calls at another weight (buffered uni vectors, weighted targets) are left
+    to the host and counted `unsupported`.  Replace mode; bitstream and reconstruction equal the plain run's."""
+    yuv = str(tmp_path / "clip.yuv")
+    enc_dropin.write_clip(yuv, W, H, FRAMES)
+    extra = ("--BCW=1", "--BcwFast=1")
+    st0, bits0, rec0 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "plain"), False, 2048 | 8, 1, 0, extra=extra)
+    st2, bits2, rec2 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "rep"), True, 2048 | 128, 1, 0, extra=extra, env={"VTMREF_REPLACE": "1"})
+    print("BCW plain:", st0["pis"], "replace:", st2["pis"], st2["affine"])
+    assert st0["rc"] == 0 and st2["rc"] == 0 and st2["errors"] == 0, st2
+    assert st2["pis"]["calls"] == st0["pis"]["calls"] and st2["pis"]["device"] >= 5000 and st2["pis"]["unsupported"] > 0, st2["pis"]
+    assert st2["pis"]["device"] + st2["pis"]["unsupported"] + st2["pis"]["skipped"] == st2["pis"]["calls"], st2["pis"]
+    assert st2["pis"]["mismatch"] == [0] * 6 and st2["pis"]["replayFallback"] == 0, st2["pis"]
+    assert st2["affine"][2] == 0, st2["affine"]
+    assert bits2 == bits0 and rec2 == rec0
+
+
+@pytest.mark.skipif(not os.path.exists(enc_dropin.REF_SO), reason="oracle/_ref/libvtmref.so not built (needs /root/reference)")
 def test_reference_encoder_intra_preselection_batched(tmp_path):
     """SURVEY.md 8(f) row 4, first part: the SATD pre-selection of IntraSearch::estIntraPredLumaQT (IntraSearch.cpp:549-592) as ONE vtmhip_intra_cand_cost_batch_dev call per CU
     inside the real encoder (oracle/ref_shim_intra.hpp): the 35 first-round predictors (formed by the reference's own predIntraAng) against the original block -> 35 SADs + 35
