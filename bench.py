@@ -72,6 +72,7 @@ def parse():
                     "9.83 vs 9.89 ms on one GPU, 2.08 vs 2.09 ms for a rank's share of an 8-GPU run: the step is bound by its dependent chain of kernels, not by launches")
     ap.add_argument("--inflight", type=int, default=1, help="pictures in flight: step k + 1 starts on a second stream set while step k's tail still runs (each has its own tables)")
     ap.add_argument("--serial", action="store_true", help="one stream, no overlap of the levels' chains: clean per-kernel times for profiling")
+    ap.add_argument("--launch-check", action="store_true", help="every rank prints {rank, world} as one JSON line and exits before any GPU work (the CPU test of the --gpus N self-launch)")
     a = ap.parse_args()
     if not a.lite:
         a.smvd, a.affine, a.transform_skip = True, True, True
@@ -102,7 +103,7 @@ def workload_key(a, world):
     src["headers"] = hdr.hexdigest()
     args = dict(width=a.width, height=a.height, config=a.config, dpoc=a.dpoc_list if a.config == "ra" else None, qp=a.qp, ts=bool(a.transform_skip), smvd=bool(a.smvd and a.config == "ra"),
                 affine=bool(a.affine), partition=a.partition, luma_only=bool(a.luma_only), shard=a.shard if world > 1 else None, world=world, lam=a.lambda_motion,
-                sim=int(os.environ.get("VTM_BENCH_SIMULATE_WORLD", "0")))
+                sim=int(os.environ.get("VTM_BENCH_SIMULATE_WORLD", "0")), lambda_bit_depth=10)
     return {"args": args, "src_sha1": src}
 
 
@@ -175,6 +176,23 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: start the N ranks as a CHILD process (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) before this process
+        # imports torch or touches the GPU, relay the ranks' stdout (rank 0's JSON line) and leave with the child's exit code.  No exec: this process stays the parent.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+        for line in child.stdout:
+            os.write(json_fd, line)
+        sys.exit(child.wait())
+    if a.launch_check:
+        os.write(json_fd, (json.dumps({"launch_check": True, "rank": int(os.environ.get("RANK", "0")), "world": int(os.environ.get("WORLD_SIZE", "1")), "gpus": a.gpus}) + "\n").encode())
+        return
     import torch
     import torch.distributed as dist
     from vtm_amd import pipeline, synth
@@ -257,10 +275,13 @@ def main():
     if os.environ.get("VTM_BENCH_MAIN_PRIORITY", "0") != "0":
         torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["VTM_BENCH_MAIN_PRIORITY"])))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    # lambda_motion from the slice QP as the reference derives it for this cfg (LambdaFromQpEnable, DepQuant): lambda = 0.57 * 2^((QP - 12) / 3) * 2^(0.25 / 3)
-    # (EncSlice.cpp:700-786; bitDepthShift = -12 at 10 bits), m_dLambdaMotionSAD = sqrt( lambda ) (RdCost.cpp:79-84): QP 32 -> 7.83, QP 27 -> 4.39, QP 22 -> 2.47
+    # lambda_motion from the slice QP as the reference derives it for this cfg (LambdaFromQpEnable, DepQuant): lambda = 0.57 * 2^((QP + bitDepthShift) / 3) * 2^(0.25 / 3) with
+    # bitDepthShift = 6 * (bitDepth - 8 - DISTORTION_PRECISION_ADJUSTMENT) - 12 = 0 for the 10-bit pictures of this bench (FULL_NBIT: the adjustment is 0; EncSlice.cpp:699-786,
+    # TypeDef.h:228-233), m_dLambdaMotionSAD = sqrt( lambda ) (RdCost.cpp:79-84): QP 32 -> 31.3, QP 27 -> 17.6, QP 22 -> 9.9 (rounds 1-3 used the 8-bit shift of -12: 7.83 at QP 32,
+    # four times too small for a 10-bit picture -- ADVICE r3; the encoder's own records hold 37 .. 117 at QP 30 + the GOP's QP offsets)
     qp = a.qp
-    lam = a.lambda_motion if a.lambda_motion > 0 else (0.57 * 2.0 ** ((qp - 12) / 3.0) * 2.0 ** (0.25 / 3.0)) ** 0.5
+    BIT_DEPTH = 10
+    lam = a.lambda_motion if a.lambda_motion > 0 else (0.57 * 2.0 ** ((qp + 6 * (BIT_DEPTH - 8) - 12) / 3.0) * 2.0 ** (0.25 / 3.0)) ** 0.5
     bands = pipeline.ctu_bands(W, H, world, unit=a.shard)
     ctu_filter = pipeline.band_filter(W, bands[rank]) if world > 1 else None
     sim = int(os.environ.get("VTM_BENCH_SIMULATE_WORLD", "0"))      # one GPU computing rank 0's share of an N-GPU run (no exchange): what a rank's step costs
@@ -394,18 +415,37 @@ def main():
     satd_out = torch.empty(max(1, nb) * 81, dtype=torch.int32, device=dev)
     ref0_ptr = dpb.data_ptr() + 2 * (refs[0][0][0] + r0 * 8 * refs[0][0][1])
     cur_ptr = cur.data_ptr() + 2 * r0 * 8 * W
-    ctx.kernel_timing(True)
-    for _ in range(2):
-        ctx.satd8_grid(cur_ptr, W, ref0_ptr, refs[0][0][1], W, (r1 - r0) * 8, 4, satd_out.data_ptr())
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        ctx.satd8_grid(cur_ptr, W, ref0_ptr, refs[0][0][1], W, (r1 - r0) * 8, 4, satd_out.data_ptr())
-    e1.record()
-    torch.cuda.synchronize()
-    satd_ms = e0.elapsed_time(e1) / 10
-    satd_k_ms, satd_k_n = ctx.kernel_timing_read("satd8_grid_kernel")
-    ctx.kernel_timing(False)
+    # ONE number: 2 warm-up launches, then SATD_REPS launches back to back between two events on the launch stream (torch's current stream IS the context's stream here); the
+    # per-launch event bracket of vtmhip_kernel_timing is NOT used for this kernel (it added ~80 us to a 144 us launch in round 3 and gave the line two different rates)
+    SATD_REPS = 20
+
+    def satd_rate(c_ptr, c_stride, r_ptr, r_stride, w, h, out_ptr):
+        for _ in range(2):
+            ctx.satd8_grid(c_ptr, c_stride, r_ptr, r_stride, w, h, 4, out_ptr)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(SATD_REPS):
+            ctx.satd8_grid(c_ptr, c_stride, r_ptr, r_stride, w, h, 4, out_ptr)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / SATD_REPS
+
+    satd_ms = satd_rate(cur_ptr, W, ref0_ptr, refs[0][0][1], W, (r1 - r0) * 8, satd_out.data_ptr())
+    # the other two picture sizes SURVEY.md 8(d) lists for this micro-benchmark (rank 0, N = 1 only; uniform random 10-bit samples: the kernel's arithmetic path -- packed
+    # 16-bit levels for samples inside [0, 1023] -- is the one the synthetic picture takes)
+    satd_sizes = {}
+    if world == 1 and not a.no_cpu_baseline:
+        for (sw, sh) in ((1920, 1080), (7680, 4320)):
+            if (sw, sh) == (W, H):
+                continue
+            g = torch.Generator(device=dev)
+            g.manual_seed(sw)
+            sc = torch.randint(0, 1024, (sh, sw), dtype=torch.int16, device=dev, generator=g)
+            sr_ = torch.randint(0, 1024, (sh + 16, sw + 16), dtype=torch.int16, device=dev, generator=g)
+            so = torch.empty((sw // 8) * (sh // 8) * 81, dtype=torch.int32, device=dev)
+            ms_ = satd_rate(sc.data_ptr(), sw, sr_.data_ptr() + 2 * (8 * (sw + 16) + 8), sw + 16, sw, (sh // 8) * 8, so.data_ptr())
+            satd_sizes["%dx%d" % (sw, sh)] = {"pairs_per_launch": (sw // 8) * (sh // 8) * 81, "ms_per_launch": ms_, "gblocks_per_s": (sw // 8) * (sh // 8) * 81 / ms_ / 1e6}
+            del sc, sr_, so
     satd_g = torch.tensor([nb * 81 / satd_ms / 1e6], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(satd_g)
@@ -489,10 +529,12 @@ def main():
                 r = issue_roofline(k, kern[k]["ms_per_step"], kern[k]["launches_per_step"])
                 r.pop("note", None)
                 out["roofline_next"].append(r)
-        if satd_k_n:
-            r = issue_roofline("satd8_grid_kernel", satd_k_ms / satd_k_n, 1, in_step=False)
-            r["pairs_per_s_G"] = nb * 81 / (satd_k_ms / satd_k_n) / 1e6
-            out["satd_roofline"] = r
+        r = issue_roofline("satd8_grid_kernel", satd_ms, 1, in_step=False)      # the same 20 back-to-back launches as satd_gblocks_per_s: one rate per line
+        r["pairs_per_s_G"] = nb * 81 / satd_ms / 1e6
+        r["pairs_per_launch"] = nb * 81
+        out["satd_roofline"] = r
+        satd_sizes["%dx%d" % (W, H)] = {"pairs_per_launch": nb * 81, "ms_per_launch": satd_ms, "gblocks_per_s": nb * 81 / satd_ms / 1e6}
+        out["satd_grid_sizes"] = satd_sizes
         if world == 1:
             # what a host encoder would add per picture if the inputs were NOT resident: the original picture and the picture reconstructed last (the other
             # reference pictures are already on the device) from pinned host memory, measured here, not overlapped -- never part of `value`

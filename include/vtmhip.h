@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define VTMHIP_ABI_VERSION 5
+#define VTMHIP_ABI_VERSION 6
 
 enum
 {
@@ -223,6 +223,17 @@ int vtmhip_intra_cand_cost_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase,
 int vtmhip_satd8_grid_dev( vtmhip_ctx *ctx, const int16_t *d_org, int orgStride, const int16_t *d_ref, int refStride, int width, int height,
                            int r, uint32_t *d_dist );
 
+/* ---- reference planes under d_refBase: what must be readable ---------------------------------------------------------
+ * A reference plane handed to any *_dev call is the reconstructed picture WITH its border: at least ctuSize + 16 samples on every side (the reference's own
+ * Picture::margin, 144 for CTU 128: clipMv keeps a block's origin inside [-ctuSize - 7, pic + 7], the 8-tap filter adds 3 / 4 samples, the block its size).
+ * The kernels fetch reference samples in whole 16-byte groups and whole window rows (search windows, the column-walking raster scan), so a fetch may start
+ * before / end after the samples it uses: the library may READ (never write, never use) up to VTMHIP_PLANE_SLACK samples before the first and after the last
+ * sample of a plane (first = row -margin, column -margin; last = the last sample of row height + margin - 1).  Planes that sit inside one allocation (the DPB
+ * layout of DESIGN.md section 2) give each other that slack; the first and the last plane of an allocation need VTMHIP_PLANE_SLACK readable samples in front
+ * of / behind them -- allocate ( samples + 2 * VTMHIP_PLANE_SLACK ) and hand over the pointer VTMHIP_PLANE_SLACK samples in (oracle/ref_shim_enc.cpp:refPlane
+ * does exactly that for the encoder's pictures; tests/pis_golden.py:build_dpb for the recorded planes). */
+#define VTMHIP_PLANE_SLACK 2048
+
 /* ---- integer motion search ----------------------------------------------------------------------------------- */
 typedef struct
 {
@@ -232,7 +243,8 @@ typedef struct
   int32_t wavesPerJob;  /* tuning hint for this batch: 0/1 = one wave per search; 2, 4, 8, 16 = waves that split each candidate list (large PUs) */
   int32_t maxSearchRange; /* tuning hint: the largest searchRange of the batch's TZ jobs (m_aaiAdaptSR: up to 384 with ASR).  The raster scan of xTZSearch (:3888-3899) is run by a
                              column-walking kernel whose per-scan totals live in LDS: 0 (or <= 96) sizes it for the 39 x 39 points of SearchRange 96; a larger value for
-                             ((2 * range) / 5 + 1)^2 points (384: 154 x 154).  A scan that does not fit runs inside the search kernel: same result, much slower. */
+                             ((2 * range) / 5 + 1)^2 points (384: 154 x 154), capped at what one CU's LDS holds (201 x 201 points = range 500).  A scan that does not fit runs
+                             inside the search kernel: same result, much slower.  Any value is accepted (a hint never makes a call fail). */
 } vtmhip_pic_params;
 
 /* One (PU, reference picture) integer search = one call of InterSearch::xTZSearch. */
@@ -345,6 +357,16 @@ typedef struct
 /* uni job: the block-vector cache of the mode control holds an integer vector for this (block, list, refIdx) (CacheBlkInfoCtrl::getMv, InterSearch.cpp:3360-3368):
  * rcMv = mvHor / mvVer (that vector in internal precision) and xTZSearch runs with bFastSettings (:3434-3441) instead of starting at rcMvPred */
 #define VTMHIP_MEJ_CACHED_INT_MV 1u
+/* uni row of vtmhip_predInterSearch_batch_dev that is GIVEN, not searched (InterSearch::xReadBufferedUniMv :7677-7697: a CU-level BCW weight other than the default re-uses the
+ * vectors the default-weight pass left in m_uniMotions): on entry uniOut[row].mvHor / mvVer = the buffered vector and uniOut[row].cost = its distortion WITHOUT any rate; the
+ * row's AMVP estimation runs as usual, its bits become the entry bits + the vector's bits against the chosen predictor (both in the AMVR precision) and its cost
+ * distortion + getCost( bits ); uniOut[row] then holds that result.  The level lists the (list, refIdx) groups whose rows are all given in vtmhip_pis_level::givenRows. */
+#define VTMHIP_MEJ_GIVEN_UNI 2u
+/* bi job: flags bits 8..15 = getBcwWeight( cu.BcwIdx, searched list ) as int8 (0 or 4: the default weight): the search target is removeWeightHighFreq( org, otherPred, w )
+ * = ( org * w0 - otherPred * w1 + 2^15 ) >> 16 (Buffer.h:417-460) instead of 2 * org - otherPred, and the distortion weight of :3483 / xPatternSearchIntRefine is |w| / 8
+ * (xGetMEDistortionWeight :7666-7676) instead of 0.5 */
+#define VTMHIP_MEJ_BCW_WEIGHT( flags ) ( ( int ) ( int8_t ) ( ( ( flags ) >> 8 ) & 0xffu ) )
+#define VTMHIP_MEJ_BCW_FLAGS( weight ) ( ( ( uint32_t ) ( uint8_t ) ( int8_t ) ( weight ) ) << 8 )
 
 typedef struct
 {
@@ -407,7 +429,8 @@ typedef struct
   uint8_t bitDepth, useAltHpelIf, chroma;
   uint8_t route;                /* 0: every call processes the job; a driver that launches BOTH vtmhip_motion_compensation_batch_dev and vtmhip_bdof_batch_dev over
                                    one table marks each job on the device: 1 = BDOF's (the plain call skips it), 2 = the plain call's (BDOF skips it) */
-  int16_t pad1;
+  int16_t bcwWeight;            /* epilogue 2 only: 0 or 4 = out = 2*org - pred; another getBcwWeight( cu.BcwIdx, searched list ) in {-2, 3, 5, 10}: out = removeWeightHighFreq
+                                   = ( org * w0 - pred * w1 + 2^15 ) >> 16 with normalizer = ( 2^16 + |w| / 2 ) / w, w0 = normalizer * 8, w1 = ( 8 - w ) * normalizer (Buffer.h:417-460) */
 } vtmhip_pred_job;
 
 /* d_predBase and d_outBase may each be NULL (that output is skipped); d_orgBase is needed when d_outBase is given. */
@@ -532,7 +555,7 @@ typedef struct
   uint8_t useAltHpelIf;     /* cu.imv == IMV_HPEL */
   uint8_t imvShift;         /* 0: half + quarter refinement; 1 (IMV_HPEL): half only */
   uint8_t bitDepth;
-  int32_t pad;
+  int32_t wideOrg;          /* != 0: the original samples may leave [-3072, 3071] (a BCW-weighted bi-pred target: up to +-5115): the tiled kernel takes its 32-bit SATD path */
 } vtmhip_frac_job;
 
 typedef struct
@@ -672,7 +695,8 @@ typedef struct
   uint8_t  profAllowed;             /* sps.getUsePROF() && !m_skipPROF && !picHeader.getDisProfFlag() */
   uint8_t  profNeedsLargeGrad;      /* m_encOnly && !slice.getCheckLDC() */
   uint8_t  profIsBi;                /* m_isBi */
-  uint8_t  pad0;
+  int8_t   bcwWeight;               /* bi: getBcwWeight( cu.BcwIdx, searched list ); 0 or 4 = default (target 2*org - otherPred, distortion weight 0.5), else the weighted target
+                                       of Buffer.h:417-460 and the distortion weight |w| / 8 */
   int32_t  mvPred[3][2];            /* acMvPred */
   int32_t  mv[3][2];                /* acMv on entry */
   uint32_t bits;                    /* ruiBits on entry */
@@ -693,6 +717,12 @@ typedef struct
 int vtmhip_xAffineMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
                                               const int16_t *d_otherPredBase, const vtmhip_affine_me_job *d_jobs, int n, int maxWidth, int maxHeight,
                                               vtmhip_affine_me_out *d_results );
+/* The same call for a batch that may hold bi jobs under a CU-level BCW weight (vtmhip_affine_me_job::bcwWeight): a weight of -2 makes the search target -4 org + 5 pred, whose
+ * differences leave the packed 16-bit Hadamard levels of the <= 10-bit kernel, so those jobs run in the 32-bit variant, launched beside the packed one (each job belongs to
+ * exactly one of the two).  Results as above. */
+int vtmhip_xAffineMotionEstimation_bcw_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                                  const int16_t *d_otherPredBase, const vtmhip_affine_me_job *d_jobs, int n, int maxWidth, int maxHeight,
+                                                  vtmhip_affine_me_out *d_results );
 /* InterPrediction::xPredAffineBlk, luma, uni-directional (rounded and clipped; PROF as flagged) at the jobs' `mv` models */
 int vtmhip_xPredAffineBlk_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_refBase, int16_t *d_dstBase,
                                      const vtmhip_affine_me_job *d_jobs, int n, int maxWidth, int maxHeight );
@@ -818,9 +848,13 @@ typedef struct
   uint8_t  uniMvInsert;            /* insertUniMvCands runs between the uni loop and the bi stage (:2451-2459: cu.imv == 0, default BCW): the bi searches and the SMVD
                                       start list see the PU's own uni vectors in m_uniMvList */
   uint8_t  uniMvSelfIsNew;         /* with uniMvInsert: the block has no entry yet -- its vectors become the newest entry (of 15 entries the oldest drops out) */
-  uint8_t  pad;
-  int32_t  uniMvSelfPos;           /* with uniMvInsert && !uniMvSelfIsNew: position (newest first) of the block's entry, overwritten in place (InterSearch.h:247-275) */
-} vtmhip_pis_pu_in;
+  int8_t   bcwWeightL1;            /* g_BcwWeights[cu.BcwIdx] = getBcwWeight( cu.BcwIdx, REF_PIC_LIST_1 ) in {-2, 3, 4, 5, 10}; 0 or 4: the default weight.  Another weight (list 0 then
+                                      weighs 8 - w): the bi stage refines the list with the SMALLER |weight| (:2556-2559) against the weighted target, prices with |w| / 8, skips the refined
+                                      list's pictures that have the other list's POC (bcwFastSkipPoc, :2588-2593) and ENFORCES the bi mode (enforceBcwPred :2543, 2843-2847) */
+  int16_t  uniMvSelfPos;           /* with uniMvInsert && !uniMvSelfIsNew: position (newest first, 0 .. 14) of the block's entry, overwritten in place (InterSearch.h:247-275) */
+  uint8_t  bcwIdxBits;             /* getWeightIdxBits( cu.BcwIdx ) when sps.getUseBcw(), else 0: joins every bi row's bits and the SMVD mode bits (:2595, 2781) */
+  uint8_t  bcwFastSkipPoc;         /* m_pcEncCfg->getUseBcwFast() && slice.getTLayer() > 1 (the device adds: weight != default && cu.imv == 0) */
+} vtmhip_pis_pu_in;                /* 8 bytes as in ABI 5 (uniMvSelfPos was an int32 holding 0 .. 14: records of ABI 5 read unchanged, with the BCW fields 0) */
 
 typedef struct
 {
@@ -871,7 +905,7 @@ typedef struct
   int32_t  mvdL1Zero;              /* picHeader.getMvdL1ZeroFlag() (both lists hold the same pictures): the bi mode takes list 1 AT its best AMVP predictor (smallest template cost over
                                       the list-1 rows, :2382-2387, 2477-2522: needs distBiP) and refines list 0 only (:2576-2580) */
   int32_t  fastMEForGenBLowDelay;  /* cfg FDM (:2391-2404): the rows of list-1 pictures that are list-0 pictures too take the list-0 vector and a re-priced cost instead of a search */
-  int32_t  pad2;
+  int32_t  givenRows;              /* bit ( list ? numRef[0] : 0 ) + refIdx: every row of that (list, refIdx) carries VTMHIP_MEJ_GIVEN_UNI -- the group is not searched */
   int32_t  picW, picH, ctuSize;    /* picW != 0: the other list's vector is clipped as motionCompensation does it (clipMv, InterPrediction.cpp:445-470) before the prediction for the bi
                                       refinement is formed -- search results are inside the clip range by construction, an AMVP predictor (MvdL1Zero) need not be */
 } vtmhip_pis_level;
@@ -942,7 +976,11 @@ int vtmhip_pis_run_picture( vtmhip_ctx *ctx, const vtmhip_pis_level_run *levels,
  *   -> the SMVD block (L->pis.smvdJobs) -> uni / bi decision.
  * Results: L->pis.uniRows, L->uniOut (every row's vector / bits / cost BEFORE xCheckBestMVP: what m_uniMotions and the block-vector cache store), L->pis.biRows, L->biOut,
  * L->pis.smvdJobs (with the trace), L->pis.pus.  No prediction, no residual coding (predFinal may be NULL); buf->orgBi: numPU * width * height samples of scratch.
- * Not covered (the caller keeps the reference path): BCW weights, weighted prediction, MvdL1Zero, four bi iterations (FEN off), MCTS, composite references, IBC. */
+ * Covered: P and B slices, cu.imv 0 .. 3, block-vector cache hits, m_uniMvList, FastMEForGenBLowDelay copies, MvdL1Zero pictures (mvdL1Zero, distBiP, mvpIdxL1Zero),
+ * bi-prediction restriction, the SMVD block, BCW (ABI 6): the weight-index bits (puIn.bcwIdxBits) and CU-level weights other than the default (puIn.bcwWeightL1, given uni rows).
+ * Not covered (the caller keeps the reference path): explicit weighted prediction, four bi iterations (FEN off), MCTS, composite references, hash ME, IBC.
+ * Synchronisation: none for the shapes vtmhip_is_uniform_shape() accepts and for every call with fewer than 64 rows (a CU-level hook); a batch of >= 64 rows of another shape
+ * (64x8, 128x64, ...) is bucketed by shape inside vtmhip_xMotionEstimation_batch_dev, which synchronises the stream once to read the class counts (never under stream capture). */
 int vtmhip_predInterSearch_batch_dev( vtmhip_ctx *ctx, const vtmhip_pis_level_run *L, const vtmhip_pis_buffers *buf );
 /* 1 when a batch of width x height blocks may promise cfg.uniformSquare (the tiled kernels know the shape) */
 int vtmhip_is_uniform_shape( int width, int height );

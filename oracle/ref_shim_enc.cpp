@@ -100,7 +100,7 @@ struct Api
   decltype( &vtmhip_xT_batch_dev )                 xT;
   decltype( &vtmhip_tu_ts_chain_batch_dev )        tsChain;
   decltype( &vtmhip_mts_select2 )                  mtsSelect;
-  decltype( &vtmhip_xAffineMotionEstimation_batch_dev ) affineMe;
+  decltype( &vtmhip_xAffineMotionEstimation_batch_dev ) affineMe, affineMeBcw;
   decltype( &vtmhip_lfnst_set_tables )             lfnstTables;
   decltype( &vtmhip_lfnst_tu_batch_dev )           lfnstTu;
   decltype( &vtmhip_xEstimateMvPredAMVP_batch_dev ) amvp;
@@ -475,7 +475,7 @@ inline bool hookSampled( uint64_t &ctr )
 }
 
 struct RefPlane { const Picture *pic; int poc; int16_t *dev, *alloc; size_t samples; int stride, margin; };
-constexpr size_t PLANE_PAD = 2048;   // samples of slack before and after an uploaded plane: the tiled kernels fetch whole 16-byte groups around a search window (include/vtmhip.h)
+constexpr size_t PLANE_PAD = VTMHIP_PLANE_SLACK;   // samples of slack before and after an uploaded plane (include/vtmhip.h: "reference planes under d_refBase: what must be readable")
 std::vector<RefPlane> g_planes;
 int16_t *d_hOrg = nullptr, *d_hOther = nullptr;
 void    *d_hJob = nullptr, *d_hOut = nullptr;
@@ -776,7 +776,15 @@ void affineHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPi
   const Picture *refPic = slice.getRefPic( eRefPicList, iRefIdxPred );
   const int      w = pu.Y().width, h = pu.Y().height;
   const bool     encOpt = is->m_pcEncCfg->getUseAffineAmvrEncOpt();
-  const bool unsupported = pu.cu->BcwIdx != BCW_DEFAULT || is->m_pcEncCfg->getMCTSEncConstraint() || is->m_pcEncCfg->getClipForBiPredMeEnabled() || ( pu.cu->imv == 2 && encOpt )
+  const bool     bcw = pu.cu->cs->sps->getUseBcw() && pu.cu->BcwIdx != BCW_DEFAULT;
+  if( bcw && !bBi && is->m_uniMotions.isReadModeAffine( ( uint32_t ) eRefPicList, ( uint32_t ) iRefIdxPred, pu.cu->affineType ) )
+  {
+    // xReadBufferedAffineUniMv (:5352-5357, 7699-7716): the member only copies the default-weight pass's model out of m_uniMotions and re-prices it -- nothing to search
+    g_st->affineCalls--;
+    vtmref_orig_xAffineMotionEstimation( is, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi );
+    return;
+  }
+  const bool unsupported = is->m_pcEncCfg->getMCTSEncConstraint() || is->m_pcEncCfg->getClipForBiPredMeEnabled() || ( pu.cu->imv == 2 && encOpt )
                         || refPic->isWrapAroundEnabled( pu.cs->pps ) || refPic->isRefScaled( pu.cs->pps ) || w < 16 || h < 16 || w > 128 || h > 128
                         || slice.getSPS()->getBitDepth( CHANNEL_TYPE_LUMA ) > 10 || slice.getPPS()->getUseWP() || slice.getPPS()->getWPBiPred();
   if( unsupported ) g_st->affineUnsupported++;
@@ -804,6 +812,7 @@ void affineHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPi
   j.lowDelayRounds = is->m_pcEncCfg->getIntraPeriod() == -1;
   j.profAllowed = pu.cs->sps->getUsePROF() && !is->m_skipPROF && !pu.cs->picHeader->getDisProfFlag();
   j.profNeedsLargeGrad = is->m_encOnly && !pu.cu->slice->getCheckLDC(); j.profIsBi = is->m_isBi;
+  j.bcwWeight = ( bcw && bBi ) ? getBcwWeight( pu.cu->BcwIdx, eRefPicList ) : 0;      // removeHighFreq( ..., getBcwWeight ) / xGetMEDistortionWeight (:5377-5385)
   for( int i = 0; i < 3; i++ ) { j.mvPred[i][0] = acMvPred[i].hor; j.mvPred[i][1] = acMvPred[i].ver; j.mv[i][0] = acMv[i].hor; j.mv[i][1] = acMv[i].ver; }
   j.bits = ruiBits; j.motionLambda = is->m_pcRdCost->m_motionLambda; j.hevcCost = is->m_hevcCost;
   vtmhip_pic_params pic; memset( &pic, 0, sizeof( pic ) );
@@ -816,7 +825,7 @@ void affineHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPi
   vtmhip_affine_me_out o; memset( &o, 0, sizeof( o ) );
   const bool ok = rp && A.h2d( g_ctx, d_hOrg, blk.data(), blk.size() * 2 ) == VTMHIP_OK && ( !bBi || A.h2d( g_ctx, d_hOther, oth.data(), oth.size() * 2 ) == VTMHIP_OK )
                && A.h2d( g_ctx, d_hJob, &j, sizeof( j ) ) == VTMHIP_OK
-               && A.affineMe( g_ctx, &pic, d_hOrg, rp->dev, d_hOther, ( const vtmhip_affine_me_job * ) d_hJob, 1, w, h, ( vtmhip_affine_me_out * ) d_hOut ) == VTMHIP_OK
+               && ( j.bcwWeight ? A.affineMeBcw : A.affineMe )( g_ctx, &pic, d_hOrg, rp->dev, d_hOther, ( const vtmhip_affine_me_job * ) d_hJob, 1, w, h, ( vtmhip_affine_me_out * ) d_hOut ) == VTMHIP_OK
                && A.d2h( g_ctx, &o, d_hOut, sizeof( o ) ) == VTMHIP_OK;
   g_affineNs[1] += nowNs() - tA;
   if( !ok ) { note_error(); if( replaceOnly ) vtmref_orig_xAffineMotionEstimation( is, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi ); return; }
@@ -1013,7 +1022,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
                  && sym( A.addAvg, "vtmhip_add_avg_batch_dev" ) && sym( A.rhf, "vtmhip_remove_high_freq_batch_dev" )
                  && sym( A.sobel, "vtmhip_affine_sobel_batch_dev" ) && sym( A.eqc, "vtmhip_affine_equal_coeff_batch_dev" )
                  && sym( A.amvp, "vtmhip_xEstimateMvPredAMVP_batch_dev" ) && sym( A.smvd, "vtmhip_smvd_batch_dev" ) && sym( A.me, "vtmhip_xMotionEstimation_batch_dev" ) && sym( A.xT, "vtmhip_xT_batch_dev" ) && sym( A.tsChain, "vtmhip_tu_ts_chain_batch_dev" )
-                 && sym( A.mtsSelect, "vtmhip_mts_select2" ) && sym( A.affineMe, "vtmhip_xAffineMotionEstimation_batch_dev" )
+                 && sym( A.mtsSelect, "vtmhip_mts_select2" ) && sym( A.affineMe, "vtmhip_xAffineMotionEstimation_batch_dev" ) && sym( A.affineMeBcw, "vtmhip_xAffineMotionEstimation_bcw_batch_dev" )
                  && sym( A.lfnstTables, "vtmhip_lfnst_set_tables" ) && sym( A.lfnstTu, "vtmhip_lfnst_tu_batch_dev" );
     if( !ok || !sym( g_apiPis, "vtmhip_predInterSearch_batch_dev" ) || !sym( g_apiUniformShape, "vtmhip_is_uniform_shape" ) || !sym( g_apiHostAlloc, "vtmhip_host_alloc" ) )
     { fprintf( stderr, "ref_encode: libvtmhip.so lacks a pointer-surface symbol\n" ); return -11; }

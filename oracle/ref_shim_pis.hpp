@@ -60,7 +60,12 @@ struct PisHeader    // one dump record: PisHeader, PisSlots (inputs), PisSlots (
   int32_t  rowPlane[PIS_ROWS];   // index of the row's reference plane among the dumped planes (PisPlaneHeader records, in file order)
   int64_t  rowOff[PIS_ROWS];     // sample offset of the PU position (vector 0,0) inside that plane's dump
   int32_t  rowCached[PIS_ROWS], rowCalls[PIS_ROWS];   // block-vector cache hit; the reference searched the row (1) or copied it from list 0 (0)
+  // (appended in round 4; records of round 3 end above and read as zeros here)
+  int32_t  refPoc[2][PIS_MAX_REF], curPoc;            // POCs of the reference pictures and of the current picture (BcwFast's same-POC skip :2588-2593)
+  int32_t  givenRows;                                 // vtmhip_pis_level::givenRows: rows served by xReadBufferedUniMv (a CU-level BCW weight other than the default)
+  int32_t  bcwIdx, bcwNoBi;                           // cu.BcwIdx on entry; the bi stage is switched off by the BcwFast rule of :2462-2464 (folded into biRestricted)
 };
+constexpr uint64_t PIS_COST_UNKNOWN = ~0ull - 1;      // PisFinal::hevcCost when the member did not store its translational cost (:3054-3057: a non-default weight with both affine models buffered)
 struct PisPlaneHeader { uint32_t magic, bytes; int32_t poc, stride, margin, width, height, index; };   // followed by (height + 2 margin) * stride samples
 constexpr uint32_t PIS_MAGIC = 0x50495331, PIS_PLANE_MAGIC = 0x50495332;
 
@@ -70,7 +75,7 @@ struct PisReplay
   PisSlots *s = nullptr;               // the downloaded tables (compare / replace) or the recorded member results (record)
   int       numRef[2] = { 0, 0 }, w = 0, h = 0;
   AMVPInfo  amvp[2][PIS_MAX_REF];
-  bool      cached[PIS_ROWS] = {};
+  bool      cached[PIS_ROWS] = {}, given[PIS_ROWS] = {};
   int       refineList = -1, amvpServed = 0, meServed = 0, smvdCostCalls = 0;
   bool      hasSmvd = false, inMember = false;
   int       row( int list, int ref ) const { return ( list ? numRef[0] : 0 ) + ref; }
@@ -193,7 +198,7 @@ void pisServeMe( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPi
     return;
   }
   rcMv.set( o.mvHor, o.mvVer ); rcMvPred.set( o.mvPredHor, o.mvPredVer ); riMVPIdx = o.mvpIdx; ruiBits = o.bits; ruiCost = o.cost;
-  if( !bBi && !g_rp.cached[row] )      // the member's own side effect (:3449-3456): the integer vector enters the block-vector cache
+  if( !bBi && !g_rp.cached[row] && !g_rp.given[row] )      // the member's own side effect (:3449-3456): the integer vector enters the block-vector cache (a buffered row returns before it)
   {
     auto blkCache = dynamic_cast<CacheBlkInfoCtrl *>( is->m_modeCtrl );
     const Mv intMv( o.intX, o.intY );
@@ -304,7 +309,9 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
   const bool trySmvd  = ( bestCU != nullptr && imv == 2 && checkAffine ) ? ( !bestCU->firstPU->mergeFlag && !bestCU->affine ) : true;
   if( imv == 2 && checkNonAffine && sps.getAffineAmvrEnabledFlag() ) checkNonAffine = is->m_affineMotion.hevcCost[1] < is->m_affineMotion.hevcCost[0] * 1.06f;
   const auto fsm = is->m_pcEncCfg->getFastInterSearchMode();
-  bool unsupported = ( isB ? cu.BcwIdx : BCW_DEFAULT ) != BCW_DEFAULT || slice.getPPS()->getUseWP() || slice.getPPS()->getWPBiPred() || is->m_pcEncCfg->getMCTSEncConstraint()
+  const uint8_t bcwIdx = isB ? cu.BcwIdx : BCW_DEFAULT;      // (:2286)
+  const bool    useBcw = sps.getUseBcw();
+  bool unsupported = slice.getPPS()->getUseWP() || slice.getPPS()->getWPBiPred() || is->m_pcEncCfg->getMCTSEncConstraint()
                   || is->m_useCompositeRef || is->m_pcEncCfg->getUseHashME() || is->m_pcEncCfg->getClipForBiPredMeEnabled()
                   || ( fsm != FASTINTERSEARCH_MODE1 && fsm != FASTINTERSEARCH_MODE2 )
                   || ( is->m_motionEstimationSearchMethod != MESEARCH_DIAMOND && is->m_motionEstimationSearchMethod != MESEARCH_DIAMOND_ENHANCED )
@@ -319,7 +326,7 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
   if( !checkNonAffine ) { g_st->pisSkipped++; vtmref_orig_predInterSearch( is, cu, partitioner ); g_st->pisNs[3] += nowNs() - t0; return; }
   if( unsupported ) g_st->pisUnsupported++;
   if( unsupported && getenv( "VTMREF_PIS_WHY" ) )
-    fprintf( stderr, "PISWHY bcw%d wp%d hash%d clip%d mvdl1z%d fsm%d me%d w%d h%d nr%d,%d bd%d next%d imv%d\n", ( isB ? cu.BcwIdx : BCW_DEFAULT ) != BCW_DEFAULT, slice.getPPS()->getUseWP(),
+    fprintf( stderr, "PISWHY bcw%d wp%d hash%d clip%d mvdl1z%d fsm%d me%d w%d h%d nr%d,%d bd%d next%d imv%d\n", bcwIdx != BCW_DEFAULT, slice.getPPS()->getUseWP(),
              is->m_pcEncCfg->getUseHashME(), is->m_pcEncCfg->getClipForBiPredMeEnabled(), cu.cs->picHeader->getMvdL1ZeroFlag(), ( int ) fsm, ( int ) is->m_motionEstimationSearchMethod, w, h,
              numRef[0], numRef[1], sps.getBitDepth( CHANNEL_TYPE_LUMA ), cu.firstPU->next != nullptr, imv );
   const bool dumping = g_pisDump != nullptr;
@@ -342,9 +349,11 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
   const Position pos = cu.lumaPos();
   // xGetBlkBits (:3158-3163); with BCW enabled every bi cost carries the bits of the weight index (:2594, 2622, 2780: getWeightIdxBits( bcwIdx )) -- of the default weight here,
   // other weights are unsupported above -- which is one more constant on the bi mode's bits
-  const uint32_t mbBits[3] = { isB ? 3u : 1u, 3u, 5u + ( isB && sps.getUseBcw() ? is->getWeightIdxBits( BCW_DEFAULT ) : 0u ) };
+  const uint32_t mbBits[3] = { isB ? 3u : 1u, 3u, 5u };      // (the weight-index bits travel per PU: vtmhip_pis_pu_in::bcwIdxBits)
   const bool     fdm = is->m_pcEncCfg->getFastMEForGenBLowDelayEnabled();
-  const bool     biRestricted = PU::isBipredRestriction( pu );
+  // no bi stage (and no SMVD block, which sits inside it): 8x4 / 4x8 PUs, and -- BcwFast -- a non-default weight after an affine winner of the default pass (:2460-2464)
+  const bool     bcwNoBi = !( slice.getCheckLDC() || bcwIdx == BCW_DEFAULT || !is->m_affineModeSelected || !is->m_pcEncCfg->getUseBcwFast() );
+  const bool     biRestricted = PU::isBipredRestriction( pu ) || bcwNoBi;
   const bool     hasSmvd = isB && !biRestricted && slice.getBiDirPred() && trySmvd;
   const CPelBuf  org = cu.cs->getOrgBuf( pu ).Y();
   for( int y = 0; y < h; y++ ) memcpy( S.org + size_t( y ) * w, org.buf + ptrdiff_t( y ) * org.stride, sizeof( Pel ) * w );
@@ -405,13 +414,28 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
       const int from0 = l == 1 ? slice.getList1IdxToList0Idx( r ) : -1;
       if( l == 1 ) L.list1FromList0[r] = from0 >= 0 ? from0 + 1 : 0;
       hd.rowCalls[row] = !( l == 1 && fdm && from0 >= 0 );
+      L.refPoc[l][r] = hd.refPoc[l][r] = refPic->getPOC();
+      // xReadBufferedUniMv (:3301-3304, 7677-7697): under a CU-level weight other than the default the row is the default-weight pass's vector and distortion (m_uniMotions)
+      if( useBcw && cu.BcwIdx != BCW_DEFAULT && hd.rowCalls[row] && is->m_uniMotions.isReadMode( ( uint32_t ) l, ( uint32_t ) r ) )
+      {
+        Mv mv; Distortion dist = 0;
+        is->m_uniMotions.copyTo( mv, dist, ( uint32_t ) l, ( uint32_t ) r );
+        j.flags |= VTMHIP_MEJ_GIVEN_UNI;
+        S.uniOut[row].mvHor = mv.hor; S.uniOut[row].mvVer = mv.ver; S.uniOut[row].cost = dist;
+        g_rp.given[row] = true; g_rp.cached[row] = false;      // (the member returns before it looks at the block-vector cache)
+        j.flags &= ~VTMHIP_MEJ_CACHED_INT_MV; hd.rowCached[row] = 0;
+        L.givenRows |= 1 << row;
+      }
       CHECK( ry.stride != refStride, "reference planes of one picture size share a stride" );
     }
   if( !ok ) { note_error(); vtmref_orig_predInterSearch( is, cu, partitioner ); return; }
   // m_uniMvList after insertUniMvCands (:2451-2459)
   vtmhip_pis_pu_in &pin = S.puIn[0];
   pin.noSmvd = !trySmvd;
-  pin.uniMvInsert = imv == 0;      // (:2451: cu.imv == 0 and the default BCW weight -- other weights are unsupported above)
+  pin.uniMvInsert = imv == 0 && ( !useBcw || bcwIdx == BCW_DEFAULT );      // (:2451)
+  pin.bcwWeightL1 = bcwIdx != BCW_DEFAULT ? g_BcwWeights[bcwIdx] : 0;
+  pin.bcwIdxBits = ( uint8_t ) ( isB && useBcw ? is->getWeightIdxBits( bcwIdx ) : 0 );
+  pin.bcwFastSkipPoc = is->m_pcEncCfg->getUseBcwFast() && slice.getTLayer() > 1;
   if( pin.uniMvInsert )
   {
     int k = 0;
@@ -426,6 +450,7 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
   for( int i = 0; i < 3; i++ ) L.mbBits[i] = mbBits[i];
   L.candsGiven = 1; L.biRestricted = biRestricted; L.mvdL1Zero = isB && cu.cs->picHeader->getMvdL1ZeroFlag(); L.fastMEForGenBLowDelay = fdm;
   L.picW = cu.cs->pps->getPicWidthInLumaSamples(); L.picH = cu.cs->pps->getPicHeightInLumaSamples(); L.ctuSize = sps.getMaxCUWidth();
+  L.curPoc = hd.curPoc = slice.getPOC(); hd.givenRows = L.givenRows; hd.bcwIdx = bcwIdx; hd.bcwNoBi = bcwNoBi;
   if( hasSmvd ) { L.symRefIdx[0] = slice.getSymRefIdx( 0 ); L.symRefIdx[1] = slice.getSymRefIdx( 1 ); }
   S.pos[0] = ( int64_t ) pu.Y().y * refStride + pu.Y().x;
   vtmhip_pred_job &po = S.predOther[0];
@@ -504,7 +529,8 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
     F.refIdx[l] = pu.refIdx[l]; F.mv[l][0] = pu.mv[l].hor; F.mv[l][1] = pu.mv[l].ver; F.mvd[l][0] = pu.mvd[l].hor; F.mvd[l][1] = pu.mvd[l].ver;
     F.mvpIdx[l] = pu.mvpIdx[l]; F.mvpNum[l] = pu.mvpNum[l]; F.refIdxBi[l] = cu.refIdxBi[l];
   }
-  F.hevcCost = is->m_affineMotion.hevcCost[imv];
+  // (:3054-3057) the member stores its translational cost unless the weight is not the default one and both affine models are buffered
+  F.hevcCost = ( bcwIdx == BCW_DEFAULT || !is->m_affineMotion.affine4ParaAvail || !is->m_affineMotion.affine6ParaAvail ) ? is->m_affineMotion.hevcCost[imv] : PIS_COST_UNKNOWN;
   F.smvdRan = dumping ? g_rp.smvdCostCalls == -1 : hasSmvd;
   if( dumping )
   {
@@ -519,7 +545,7 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
   const vtmhip_pis_pu &P = S.pus[0];
   const bool bi = P.interDir == 3;
   const uint64_t devCost = bi ? P.costBi : P.cost[P.interDir == 2 ? 1 : 0];
-  bool bad = devCost != F.hevcCost;
+  bool bad = F.hevcCost != PIS_COST_UNKNOWN && devCost != F.hevcCost;
   if( !cu.affine )
   {
     bad = bad || P.interDir != F.interDir || ( bi && ( P.smvdMode != 0 ) != ( F.smvdMode != 0 ) );

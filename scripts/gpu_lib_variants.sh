@@ -5,6 +5,7 @@ set -e
 cd $GRAFT_REPO_ROOT
 TESTS=$1; shift
 cp vtm_amd/libvtmhip.so /tmp/libvtmhip_orig.so
+trap 'cp /tmp/libvtmhip_orig.so vtm_amd/libvtmhip.so' EXIT      # whatever happens below (a failing test, a bench timeout, a missing variant): the tree gets its own library back
 for t in "$@"; do
   cp vtm_amd/libvtmhip_$t.so vtm_amd/libvtmhip.so
   timeout -k 10 500 python -m pytest $TESTS -m gpu -x -q > gpurun_out/var_${t}_tests.log 2>&1 || (tail -20 gpurun_out/var_${t}_tests.log; exit 1)
@@ -17,4 +18,3 @@ print("${t}", round(d["ms_per_step"], 3), {k: round(v, 3) for k, v in d["stages_
 print("${t}", {k: round(v["ms_per_step"] if isinstance(v, dict) else v, 3) for k, v in d["kernels"].items()})
 PY
 done
-cp /tmp/libvtmhip_orig.so vtm_amd/libvtmhip.so

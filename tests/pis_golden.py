@@ -36,7 +36,12 @@ class PisHeader(C.Structure):
                 ("symRefIdx", C.c_int32 * 2), ("hasSmvd", C.c_int32), ("biRestricted", C.c_int32), ("mvdL1Zero", C.c_int32), ("fdm", C.c_int32), ("list1FromList0", C.c_int32 * MAX_REF),
                 ("mbBits", C.c_uint32 * 3), ("bipredSearchRange", C.c_int32), ("useHadME", C.c_int32), ("fen13", C.c_int32), ("extendedSettings", C.c_int32),
                 ("firstSearchStop", C.c_int32), ("uniMvListSize", C.c_int32), ("rowPlane", C.c_int32 * ROWS), ("rowOff", C.c_int64 * ROWS), ("rowCached", C.c_int32 * ROWS),
-                ("rowCalls", C.c_int32 * ROWS)]
+                ("rowCalls", C.c_int32 * ROWS),
+                # appended in round 4 (records of round 3 end above: load_npz pads them with zeros)
+                ("refPoc", (C.c_int32 * MAX_REF) * 2), ("curPoc", C.c_int32), ("givenRows", C.c_int32), ("bcwIdx", C.c_int32), ("bcwNoBi", C.c_int32)]
+
+
+COST_UNKNOWN = 2 ** 64 - 2      # PisFinal.hevcCost when the member did not store its translational cost (oracle/ref_shim_pis.hpp: PIS_COST_UNKNOWN)
 
 
 class PlaneHeader(C.Structure):
@@ -86,8 +91,10 @@ def load_npz(path):
     planes = [(PlaneHeader.from_buffer_copy(z["plane_hdr"].tobytes()[i * C.sizeof(PlaneHeader):(i + 1) * C.sizeof(PlaneHeader)]), z["plane%d" % i]) for i in range(m)]
     recs, o = [], 0
     hb, ib, ob, fb, org = z["rec_hdr"].tobytes(), z["rec_in"].tobytes(), z["rec_out"].tobytes(), z["rec_fin"].tobytes(), z["org"]
+    hsz = len(hb) // max(1, n)      # the header grew at its end in round 4: older files hold the shorter form
+    assert hsz <= C.sizeof(PisHeader) and len(ib) == n * C.sizeof(PisSlots), "golden file of another ABI"
     for i in range(n):
-        hd = PisHeader.from_buffer_copy(hb[i * C.sizeof(PisHeader):(i + 1) * C.sizeof(PisHeader)])
+        hd = PisHeader.from_buffer_copy(hb[i * hsz:(i + 1) * hsz].ljust(C.sizeof(PisHeader), b"\0"))
         sin = PisSlots.from_buffer_copy(ib[i * C.sizeof(PisSlots):(i + 1) * C.sizeof(PisSlots)])
         sout = PisSlots.from_buffer_copy(ob[i * C.sizeof(PisSlots):(i + 1) * C.sizeof(PisSlots)])
         fin = PisFinal.from_buffer_copy(fb[i * C.sizeof(PisFinal):(i + 1) * C.sizeof(PisFinal)])
@@ -96,7 +103,7 @@ def load_npz(path):
     return planes, recs
 
 
-PAD = 4096      # samples of slack around every plane of the rebuilt DPB (the tiled kernels fetch whole 16-byte groups around a window)
+PAD = 4096      # samples of slack around every plane of the rebuilt DPB (>= VTMHIP_PLANE_SLACK of include/vtmhip.h: the kernels fetch whole 16-byte groups / window rows)
 
 
 def build_dpb(planes):

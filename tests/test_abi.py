@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for s in syms:
         assert hasattr(L, s), "libvtmhip.so does not export %s" % s
     assert set(syms) == set(lib.exported_symbols()), set(syms) ^ set(lib.exported_symbols())
-    assert L.vtmhip_abi_version() == 5
+    assert L.vtmhip_abi_version() == 6
 
 
 def test_no_device_is_reported_not_crashed():

@@ -156,21 +156,68 @@ def test_reference_encoder_predInterSearch_8bit_internal(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(enc_dropin.REF_SO), reason="oracle/_ref/libvtmref.so not built (needs /root/reference)")
 def test_reference_encoder_predInterSearch_with_bcw_enabled(tmp_path):
-    """BCW : 1 as in cfg/encoder_randomaccess_vtm.cfg: the encoder then calls predInterSearch once per CU-level weight.  The calls at the default weight go to the device
-    (their bi costs carry the bits of the weight index, InterSearch.cpp:2594, 2622, 2780); the calls at another weight (buffered uni vectors, weighted targets) are left
-    to the host and counted `unsupported`.  Replace mode; bitstream and reconstruction equal the plain run's."""
+    """BCW : 1, BcwFast : 1, AffineAmvr : 1 as in cfg/encoder_randomaccess_vtm.cfg: the encoder then calls predInterSearch once per CU-level weight.  Every call goes to the
+    device (round 4): the default-weight calls with the weight-index bits in their bi costs (InterSearch.cpp:2594, 2622, 2780), the calls at another weight with their uni rows
+    GIVEN (xReadBufferedUniMv :7677-7697), the list with the smaller weight refined against the weighted target (removeWeightHighFreq, :2556-2559, 3320-3326), the distortion
+    weight |w| / 8 (:7666-7676), BcwFast's same-POC skip (:2588-2593), the enforced bi mode (:2843-2847) and the weighted SMVD block; xAffineMotionEstimation's bi calls under a
+    weight run on the device too.  Compare mode (every served member also runs the reference's code) and replace mode; bitstream and reconstruction equal the plain run's."""
     yuv = str(tmp_path / "clip.yuv")
     enc_dropin.write_clip(yuv, W, H, FRAMES)
-    extra = ("--BCW=1", "--BcwFast=1")
+    extra = ("--BCW=1", "--BcwFast=1", "--AffineAmvr=1", "--AffineAmvrEncOpt=1")
     st0, bits0, rec0 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "plain"), False, 2048 | 8, 1, 0, extra=extra)
+    st1, bits1, rec1 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "cmp"), True, 2048 | 128, 1, 0, extra=extra)
     st2, bits2, rec2 = enc_dropin.encode(yuv, W, H, FRAMES, QP, str(tmp_path / "rep"), True, 2048 | 128, 1, 0, extra=extra, env={"VTMREF_REPLACE": "1"})
-    print("BCW plain:", st0["pis"], "replace:", st2["pis"], st2["affine"])
-    assert st0["rc"] == 0 and st2["rc"] == 0 and st2["errors"] == 0, st2
-    assert st2["pis"]["calls"] == st0["pis"]["calls"] and st2["pis"]["device"] >= 5000 and st2["pis"]["unsupported"] > 0, st2["pis"]
-    assert st2["pis"]["device"] + st2["pis"]["unsupported"] + st2["pis"]["skipped"] == st2["pis"]["calls"], st2["pis"]
-    assert st2["pis"]["mismatch"] == [0] * 6 and st2["pis"]["replayFallback"] == 0, st2["pis"]
-    assert st2["affine"][2] == 0, st2["affine"]
+    print("BCW plain:", st0["pis"], "compare:", st1["pis"], st1["affine"], "replace:", st2["pis"], st2["affine"])
+    assert st0["rc"] == 0
+    for st in (st1, st2):
+        assert st["rc"] == 0 and st["errors"] == 0, st
+        assert st["pis"]["calls"] == st0["pis"]["calls"] and st["pis"]["device"] >= 5000 and st["pis"]["unsupported"] == 0, st["pis"]
+        assert st["pis"]["device"] + st["pis"]["skipped"] == st["pis"]["calls"], st["pis"]
+        assert st["pis"]["mismatch"] == [0] * 6 and st["pis"]["replayFallback"] == 0, st["pis"]
+        assert st["affine"][2] == 0 and st["affine"][3] == 0, st["affine"]
+    assert bits1 == bits0 and rec1 == rec0
     assert bits2 == bits0 and rec2 == rec0
+    out = os.path.join(enc_dropin.ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        import json
+        json.dump({"clip": "%dx%d, %d pictures, QP %d, tests/data/enc_ra_gop4.cfg + %s" % (W, H, FRAMES, QP, " ".join(extra)), "bitstream_md5": bits0, "identical_bitstream": True,
+                   "plain": st0["pis"], "compare": st1["pis"], "replace": st2["pis"], "affine_compare": st1["affine"], "affine_replace": st2["affine"]},
+                  open(os.path.join(out, "encoder_replace_bcw_192x128.json"), "w"), indent=1)
+
+
+FULL_CFG = os.path.join(enc_dropin.ROOT, "tests", "data", "enc_ra_full.cfg")
+
+
+@pytest.mark.skipif(not os.path.exists(enc_dropin.REF_SO), reason="oracle/_ref/libvtmref.so not built (needs /root/reference)")
+def test_reference_encoder_predInterSearch_full_random_access_cfg(tmp_path):
+    """The hook under the reference's OWN random-access operating point (tests/data/enc_ra_full.cfg = the values of cfg/encoder_randomaccess_vtm.cfg: GOP 16 with its reference
+    lists, SearchRange 384 / MinSearchWindow 96 with ASR, MaxMTTHierarchyDepth 3, BCW + BcwFast, AffineAmvr + AffineAmvrEncOpt, CIIP, LFNST, ISP, MIP, LMCS, JointCbCr, MMVD ... all
+    on): 416x240, 17 pictures (one whole GOP + the intra picture), QP 32, replace mode -- every predInterSearch call with a translational part and every
+    xAffineMotionEstimation call on the MI355X, none left to the host, bitstream and reconstruction equal the plain run's."""
+    import json
+    import time
+    w, h, frames, qp = 416, 240, 17, 32
+    yuv = str(tmp_path / "clip.yuv")
+    enc_dropin.write_clip(yuv, w, h, frames)
+    t0 = time.time()
+    st0, bits0, rec0 = enc_dropin.encode(yuv, w, h, frames, qp, str(tmp_path / "plain"), False, 2048 | 8, 1, 0, cfg=FULL_CFG)
+    t1 = time.time()
+    st2, bits2, rec2 = enc_dropin.encode(yuv, w, h, frames, qp, str(tmp_path / "rep"), True, 2048 | 128, 1, 0, cfg=FULL_CFG, env={"VTMREF_REPLACE": "1"})
+    t2 = time.time()
+    print("full RA cfg plain %.1f s:" % (t1 - t0), st0["pis"], "replace %.1f s:" % (t2 - t1), st2["pis"], st2["affine"])
+    assert st0["rc"] == 0 and st2["rc"] == 0 and st2["errors"] == 0, st2
+    assert st2["pis"]["calls"] == st0["pis"]["calls"] and st2["pis"]["device"] >= 100000, st2["pis"]
+    assert st2["pis"]["unsupported"] == 0 and st2["pis"]["device"] + st2["pis"]["skipped"] == st2["pis"]["calls"], st2["pis"]
+    assert st2["pis"]["mismatch"] == [0] * 6 and st2["pis"]["replayFallback"] == 0, st2["pis"]
+    assert st2["affine"][2] == 0 and st2["affine"][3] == 0 and st2["affine"][1] > 10000, st2["affine"]
+    assert bits2 == bits0 and rec2 == rec0
+    out = os.path.join(enc_dropin.ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        in_member = sum(st0["pis"]["seconds"])
+        json.dump({"clip": "%dx%d, %d pictures, QP %d, tests/data/enc_ra_full.cfg (the values of cfg/encoder_randomaccess_vtm.cfg)" % (w, h, frames, qp), "bitstream_md5": bits0,
+                   "identical_bitstream": True, "plain_s": t1 - t0, "replace_s": t2 - t1, "speedup_replace_vs_plain": (t1 - t0) / (t2 - t1),
+                   "predInterSearch_share_of_plain_run": in_member / (t1 - t0), "plain": st0["pis"], "replace": st2["pis"], "affine_replace": st2["affine"],
+                   "affine_seconds_replace": st2["affineSeconds"]}, open(os.path.join(out, "encoder_replace_full_cfg_416x240.json"), "w"), indent=1)
 
 
 @pytest.mark.skipif(not os.path.exists(enc_dropin.REF_SO), reason="oracle/_ref/libvtmref.so not built (needs /root/reference)")

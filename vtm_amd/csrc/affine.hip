@@ -426,6 +426,11 @@ __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( PACKED
   __shared__ int                sCtl;     // loop control of the gradient iterations: 0 continue, 1 stop
   const vtmhip_affine_me_job &j = jobs[blockIdx.x];
   if( ( j.sixParam != 0 ) != SIX ) return;      // a mixed batch is launched once per model; every job belongs to exactly one of the two launches
+  // A CU-level BCW weight of -2 makes the bi-pred target -4 org + 5 pred: differences up to 6138 leave the packed 16-bit Hadamard levels.  Such jobs belong to the 32-bit
+  // variant (launched beside the packed one by vtmhip_xAffineMotionEstimation_bcw_batch_dev); every other job of a <= 10-bit picture to the packed variant.
+  const int  bcw = ( j.bi && j.bcwWeight != 4 ) ? j.bcwWeight : 0;
+  const bool wideJob = bcw < 0;
+  if( PACKED ? wideJob : ( pic.bitDepth <= 10 && !wideJob ) ) return;
   const int w = j.width, h = j.height;
   int16_t  *sPat = sMem, *sPred = sMem + w * h;
   AffCtx c;
@@ -434,16 +439,17 @@ __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( PACKED
   c.verMax = ( pic.picH + 8 - j.puY - 1 ) << 4; c.verMin = ( -pic.ctuSize - 8 - j.puY + 1 ) << 4;
   c.profAllowed = j.profAllowed != 0; c.profLarge = j.profNeedsLargeGrad != 0; c.profIsBi = j.profIsBi != 0;
   const bool   bi = j.bi != 0, satd = j.useSatd != 0;
-  const double fWeight = bi ? 0.5 : 1.0, lam = j.motionLambda;
+  const double fWeight = bi ? ( bcw ? fabs( ( double ) bcw / 8.0 ) : 0.5 ) : 1.0, lam = j.motionLambda;      // xGetMEDistortionWeight (InterSearch.cpp:7666-7676)
   const int    imv = j.imv, rs = imv == 0 ? 2 : imv == 1 ? 0 : 4;      // (rsTab of the reference: MV_PRECISION of the AMVR mode)
-  // pattern: org, or 2*org - otherPred (removeHighFreq, unclipped)
+  // pattern: org, or 2*org - otherPred (removeHighFreq, unclipped), or the weighted form ( org * w0 - otherPred * w1 + 2^15 ) >> 16 under a CU-level BCW weight (Buffer.h:417-460)
   {
     const int16_t *o = orgBase + j.orgOff, *p = bi ? otherBase + j.otherPredOff : nullptr;
+    const int      nrm = bcw ? ( ( 1 << 16 ) + ( bcw > 0 ? ( bcw >> 1 ) : -( bcw >> 1 ) ) ) / bcw : 0, bw0 = nrm << 3, bw1 = ( 8 - bcw ) * nrm;
     for( int i = threadIdx.x; i < w * h; i += blockDim.x )
     {
       const int y = i / w, x = i - y * w;
       const int v = o[( long ) y * j.orgStride + x];
-      sPat[i] = ( int16_t ) ( bi ? 2 * v - p[( long ) y * j.otherPredStride + x] : v );
+      sPat[i] = ( int16_t ) ( !bi ? v : bcw ? ( v * bw0 - ( int ) p[( long ) y * j.otherPredStride + x] * bw1 + ( 1 << 15 ) ) >> 16 : 2 * v - p[( long ) y * j.otherPredStride + x] );
     }
   }
   int pred[3][2];
@@ -755,12 +761,23 @@ int vtmhip_internal_affine_me_launch( vtmhip_ctx *ctx, const vtmhip_pic_params *
   // one wave per job up to 32x32 (64 4x4 sub-blocks: a lane each), four waves above: the model iterations are a serial chain per job, so small blocks gain
   // from four times as many jobs in flight, not from idle lanes
   const int threads = maxWidth * maxHeight <= 1024 ? 64 : 256;
-  const int sel = models;
+  const int sel = models < 0 ? -1 : ( models & 3 );      // 0: 4-parameter jobs only, 1: 6-parameter only, -1 / 2: both
+  const bool wideToo = models >= 0 && ( models & VTMHIP_AFFINE_LAUNCH_WIDE ) != 0;      // the batch may hold BCW weight -2 jobs: the 32-bit variants run beside the packed ones
   const int16_t *oth = d_otherPredBase ? d_otherPredBase : d_orgBase;
   if( packed )
   {
     if( sel != 1 ) hipLaunchKernelGGL( ( affine_me_kernel<false, true> ), dim3( n ), dim3( threads ), lds, ctx->stream, *pic, d_orgBase, d_refBase, oth, d_jobs, d_results );
     if( sel != 0 ) hipLaunchKernelGGL( ( affine_me_kernel<true, true> ), dim3( n ), dim3( threads ), lds, ctx->stream, *pic, d_orgBase, d_refBase, oth, d_jobs, d_results );
+    if( wideToo )
+    {
+      if( lds > 48 * 1024 )
+      {
+        VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( affine_me_kernel<false, false> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
+        VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( affine_me_kernel<true, false> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
+      }
+      if( sel != 1 ) hipLaunchKernelGGL( ( affine_me_kernel<false, false> ), dim3( n ), dim3( threads ), lds, ctx->stream, *pic, d_orgBase, d_refBase, oth, d_jobs, d_results );
+      if( sel != 0 ) hipLaunchKernelGGL( ( affine_me_kernel<true, false> ), dim3( n ), dim3( threads ), lds, ctx->stream, *pic, d_orgBase, d_refBase, oth, d_jobs, d_results );
+    }
   }
   else
   {
@@ -779,6 +796,13 @@ int vtmhip_xAffineMotionEstimation_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_
                                               vtmhip_affine_me_out *d_results )
 {
   return vtmhip_internal_affine_me_launch( ctx, pic, d_orgBase, d_refBase, d_otherPredBase, d_jobs, n, maxWidth, maxHeight, d_results, -1 );
+}
+
+int vtmhip_xAffineMotionEstimation_bcw_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                                  const int16_t *d_otherPredBase, const vtmhip_affine_me_job *d_jobs, int n, int maxWidth, int maxHeight,
+                                                  vtmhip_affine_me_out *d_results )
+{
+  return vtmhip_internal_affine_me_launch( ctx, pic, d_orgBase, d_refBase, d_otherPredBase, d_jobs, n, maxWidth, maxHeight, d_results, 2 | VTMHIP_AFFINE_LAUNCH_WIDE );
 }
 
 int vtmhip_xPredAffineBlk_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_refBase, int16_t *d_dstBase, const vtmhip_affine_me_job *d_jobs, int n,

@@ -100,6 +100,7 @@ int vtmhip_internal_mc_launch( vtmhip_ctx *ctx, const int16_t *d_orgBase, const 
                                int n, int maxWidth, int maxHeight, unsigned long long *d_sadOut );   // mc.hip: motionCompensation, optionally reduced to the SAD against the original
 int vtmhip_internal_mc_amvp_launch( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_me_job *d_rows, int n,
                                     int maxWidth, int maxHeight, unsigned long long *d_sadOut );   // mc.hip: the AMVP candidates' predictions reduced to their SADs, jobs from the ME rows
+#define VTMHIP_AFFINE_LAUNCH_WIDE 8      // `models` of vtmhip_internal_affine_me_launch: also launch the 32-bit variants (jobs with a BCW weight of -2)
 int vtmhip_internal_affine_me_launch( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, const int16_t *d_otherPredBase,
                                       const vtmhip_affine_me_job *d_jobs, int n, int maxWidth, int maxHeight, vtmhip_affine_me_out *d_results, int models );   // affine.hip
 int vtmhip_internal_workspace( vtmhip_ctx *ctx, size_t bytes, void **out, int slot = 0 ); // the arena (slot) of ctx->stream, grown to `bytes` (device only)

@@ -32,13 +32,16 @@ int run_uni( vtmhip_ctx *ctx, const vtmhip_pis_level_run &L, const vtmhip_pis_bu
   if( st ) return st;
   st = vtmhip_xEstimateMvPredAMVP_batch_dev( ctx, &L.pic, b.org, b.dpb, L.pis.uniJobs, rows, L.width, L.height, 1, 1, L.pis.distBiP );   // (the index bits of the chosen predictor join the row's bits)
   if( st ) return st;
-  // the searched rows: all of list 0, and the list-1 pictures that are not list-0 pictures too (FastMEForGenBLowDelay copies those in stage 1); rows of one
-  // (list, refIdx) are contiguous, so the searched rows are a few contiguous runs
-  int first = 0, count = L.pis.numRef[0];
-  for( int r = 0; r <= L.pis.numRef[1]; r++ )
+  // the searched rows: every (list, refIdx) group but the list-1 pictures that are list-0 pictures too (FastMEForGenBLowDelay copies those in stage 1) and the groups whose rows
+  // are GIVEN (pis.givenRows: buffered uni vectors of a CU-level BCW weight, re-priced in stage 1); rows of one group are contiguous, so the searched rows are a few contiguous runs
+  const int groups = L.pis.numRef[0] + L.pis.numRef[1];
+  int first = 0, count = 0;
+  for( int g = 0; g <= groups; g++ )
   {
-    const bool searched = r < L.pis.numRef[1] && !( L.pis.fastMEForGenBLowDelay && L.pis.list1FromList0[r] > 0 && L.pis.list1FromList0[r] <= L.pis.numRef[0] );
-    if( searched ) { if( !count ) first = L.pis.numRef[0] + r; count++; continue; }
+    const int  r1 = g - L.pis.numRef[0];      // refIdx of a list-1 group
+    const bool copied = g < groups && r1 >= 0 && L.pis.fastMEForGenBLowDelay && L.pis.list1FromList0[r1] > 0 && L.pis.list1FromList0[r1] <= L.pis.numRef[0];
+    const bool searched = g < groups && !copied && !( ( L.pis.givenRows >> g ) & 1 );
+    if( searched ) { if( !count ) first = g; count++; continue; }
     if( count )
     {
       st = vtmhip_xMotionEstimation_batch_dev( ctx, &L.pic, &L.cfgUni, b.org, b.dpb, nullptr, L.pis.uniJobs + ( size_t ) first * n, count * n, L.width, L.height, L.uniOut + ( size_t ) first * n );

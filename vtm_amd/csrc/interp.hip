@@ -412,7 +412,7 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
   }
   for( int i = tid; i < C::JPW * 2; i += C::BLOCK ) sCentre[i >> 1][i & 1] = 0;
   // the packed 16-bit evaluation (phase V) needs every PU of the workgroup to ask for the Hadamard cost at bitDepth <= 10
-  const bool pkAll = !__syncthreads_or( tid < nj && !( jobs[job0 + tid].useHad && jobs[job0 + tid].bitDepth <= 10 ) );
+  const bool pkAll = !__syncthreads_or( tid < nj && !( jobs[job0 + tid].useHad && jobs[job0 + tid].bitDepth <= 10 && !jobs[job0 + tid].wideOrg ) );   // wideOrg: a BCW-weighted target
 
 #pragma unroll 1
   for( int round = 0; round < 2; round++ )

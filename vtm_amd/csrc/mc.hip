@@ -40,12 +40,14 @@ struct Epilogue
 {
   const int16_t *org; int orgStride; int16_t *pred; int predStride; int16_t *out; int outStride; int mode;
   unsigned *sad;   // mode 3: this lane's running SAD of the prediction against the original (the AMVP template cost: nothing is stored)
+  int w0, w1;      // mode 4: removeWeightHighFreq (Buffer.h:417-460): out = ( org * w0 - pred * w1 + 2^15 ) >> 16 -- the bi-pred search target under a CU-level BCW weight
   __device__ __forceinline__ void operator()( int y, int x, int16_t v ) const
   {
     if( pred ) pred[( long ) y * predStride + x] = v;
     if( mode == 1 ) out[( long ) y * outStride + x] = ( int16_t ) ( org[( long ) y * orgStride + x] - v );
     else if( mode == 2 ) out[( long ) y * outStride + x] = ( int16_t ) ( 2 * org[( long ) y * orgStride + x] - v );
     else if( mode == 3 ) *sad += ( unsigned ) abs( ( int ) org[( long ) y * orgStride + x] - ( int ) v );
+    else if( mode == 4 ) out[( long ) y * outStride + x] = ( int16_t ) ( ( ( int ) org[( long ) y * orgStride + x] * w0 - ( int ) v * w1 + ( 1 << 15 ) ) >> 16 );
   }
   __device__ __forceinline__ void vec( int y, int x0, const int v[8] ) const
   {
@@ -64,7 +66,7 @@ struct Epilogue
       int o[8], r[8];
       load8g( org + ( long ) y * orgStride + x0, o );
 #pragma unroll
-      for( int k = 0; k < 8; k++ ) r[k] = ( mode == 1 ? o[k] : 2 * o[k] ) - v[k];
+      for( int k = 0; k < 8; k++ ) r[k] = mode == 4 ? ( int ) ( int16_t ) ( ( o[k] * w0 - v[k] * w1 + ( 1 << 15 ) ) >> 16 ) : ( mode == 1 ? o[k] : 2 * o[k] ) - v[k];
       store8g( out + ( long ) y * outStride + x0, r );
     }
   }
@@ -110,6 +112,12 @@ __device__ __forceinline__ void motion_comp_body( const int16_t *__restrict__ or
   ep.pred = predBase ? predBase + j.predOff : nullptr; ep.predStride = j.predStride;
   ep.out = outBase ? outBase + j.outOff : nullptr; ep.outStride = j.outStride;
   ep.mode = sadOut ? 3 : ( outBase && orgBase ) ? j.epilogue : 0;
+  ep.w0 = ep.w1 = 0;
+  if( ep.mode == 2 && j.bcwWeight != 0 && j.bcwWeight != 4 )
+  {
+    const int bcw = j.bcwWeight, nrm = ( ( 1 << 16 ) + ( bcw > 0 ? ( bcw >> 1 ) : -( bcw >> 1 ) ) ) / bcw;
+    ep.w0 = nrm << 3; ep.w1 = ( 8 - bcw ) * nrm; ep.mode = 4;
+  }
   unsigned sadAcc = 0;
   ep.sad = &sadAcc;
   if( THREADS == 256 && sadOut ) { if( threadIdx.x == 0 ) sSad = 0; __syncthreads(); }
@@ -175,7 +183,7 @@ __global__ __launch_bounds__( THREADS * JPB ) void motion_comp_amvp_kernel( vtmh
     p.orgOff = r.orgOff; p.refOff[0] = r.refOff; p.refOff[1] = r.refOff; p.predOff = 0; p.outOff = 0;
     p.orgStride = r.orgStride; p.refStride[0] = p.refStride[1] = r.refStride; p.predStride = r.width; p.outStride = r.width;
     p.mv[0][0] = th; p.mv[0][1] = tv; p.mv[1][0] = p.mv[1][1] = 0;
-    p.width = r.width; p.height = r.height; p.mode = 0; p.epilogue = 0; p.bitDepth = ( uint8_t ) pic.bitDepth; p.useAltHpelIf = r.imv == 3; p.chroma = 0; p.route = 0; p.pad1 = 0;
+    p.width = r.width; p.height = r.height; p.mode = 0; p.epilogue = 0; p.bitDepth = ( uint8_t ) pic.bitDepth; p.useAltHpelIf = r.imv == 3; p.chroma = 0; p.route = 0; p.bcwWeight = 0;
     return p;
   }, n2, maxW, maxH, sadOut );
 }

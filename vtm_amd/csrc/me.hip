@@ -1421,8 +1421,12 @@ extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_par
   // split search (default; VTMHIP_TZ_SPLIT=0: one launch): the raster scans of the batch run in tz_raster_cols_kernel between two launches of the search kernel
   static const bool split = !( getenv( "VTMHIP_TZ_SPLIT" ) && atoi( getenv( "VTMHIP_TZ_SPLIT" ) ) == 0 );
   // the raster column kernel keeps a scan's totals in LDS: 39 x 39 points (SearchRange 96) by default, ((2 * range) / 5 + 1)^2 for the caller's maxSearchRange hint (384: 154 x 154 = 93 KB)
+  // The hint never makes the call fail: the totals of one scan must fit the CU's LDS beside the kernel's static arrays (160 KB on gfx950: ( 160 KB - 1 KB ) / 4 - 1 = 40 703
+  // points = a 201 x 201 scan = search range 500); scans with more points than totCap are not listed for the column kernel and run inside the search kernel (mode 1 checks totCap).
+  constexpr int RASTER_TOT_MAX = ( 160 * 1024 - 1024 ) / ( int ) sizeof( unsigned ) - 1;
   const int rasterSide = pic->maxSearchRange > 96 ? ( 2 * ( pic->maxSearchRange < 512 ? pic->maxSearchRange : 512 ) ) / 5 + 1 : 0;
-  const int totCap = rasterSide * rasterSide > RASTER_TOT_CAP ? rasterSide * rasterSide : RASTER_TOT_CAP;
+  const int totWant = rasterSide * rasterSide > RASTER_TOT_CAP ? rasterSide * rasterSide : RASTER_TOT_CAP;
+  const int totCap = totWant < RASTER_TOT_MAX ? totWant : RASTER_TOT_MAX;
   TzSaved  *d_saved = nullptr;
   int      *d_list  = nullptr;
   unsigned *d_tot   = nullptr;
@@ -1435,6 +1439,8 @@ extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_par
     if( totCap > RASTER_TOT_CAP && splitScan && n <= 4096 && rasterParts < 4 ) rasterParts = 4;      // big scans (one workgroup per CU by LDS): a few workgroups per scan balance the tail   // aim at the 1280 resident workgroups (5 per CU); twice that measured slower
     const size_t oList = ( ( size_t ) n * sizeof( TzSaved ) + 255 ) & ~( size_t ) 255;
     const size_t oTot  = ( oList + ( ( size_t ) n + 1 ) * sizeof( int ) + 255 ) & ~( size_t ) 255;
+    // global totals of the split scans (rasterParts > 1): n x (totCap + 1) words, zeroed per call -- bounded to 64 MB (big scans of many jobs keep one workgroup per scan)
+    if( rasterParts > 1 && ( size_t ) n * ( totCap + 1 ) * sizeof( unsigned ) > ( ( size_t ) 64 << 20 ) ) rasterParts = 1;
     const size_t totBytes = rasterParts > 1 ? ( size_t ) n * ( totCap + 1 ) * sizeof( unsigned ) : 0;
     void        *arena = nullptr;
     int          st    = vtmhip_internal_workspace( ctx, oTot + totBytes, &arena, 1 );

@@ -43,6 +43,8 @@ __device__ __forceinline__ void clip_mv( const vtmhip_pic_params &pic, const vtm
 }
 __device__ __forceinline__ int sub_shift( const vtmhip_me_cfg &cfg, int w, int h ) { return cfg.fastInterSearchMode13 && h > 8 && w <= 64 ? 1 : 0; }   // RdCost.cpp:289-323, mode 2
 __device__ __forceinline__ unsigned imv_shift( int imv ) { return imv == 3 ? 1u : ( unsigned ) imv << 1; }
+// CU-level BCW weight of the searched list of a bi job (0: the default pair); the default weight (4 of 8) is normalised to 0
+__device__ __forceinline__ int bcw_weight( const vtmhip_me_job &j ) { const int w = j.bi ? VTMHIP_MEJ_BCW_WEIGHT( j.flags ) : 0; return w == 4 ? 0 : w; }
 
 // m_uniMvList entries, newest first, each kept only if no earlier entry equals it (:3391-3403, :3728-3746)
 __device__ __forceinline__ int dedup( const vtmhip_me_job &j, int ex[15][2] )
@@ -90,6 +92,17 @@ __global__ __launch_bounds__( 256 ) void mest_pattern_kernel( const int16_t *__r
   if( j.bi )
   {
     const int16_t *p = otherBase + j.otherPredOff;
+    const int      bcw = bcw_weight( j );
+    if( bcw )      // removeWeightHighFreq (Buffer.h:417-460)
+    {
+      const int nrm = ( ( 1 << 16 ) + ( bcw > 0 ? ( bcw >> 1 ) : -( bcw >> 1 ) ) ) / bcw, w0 = nrm << 3, w1 = ( 8 - bcw ) * nrm;
+      for( int i = threadIdx.x; i < w * h; i += 256 )
+      {
+        const int y = i / w, x = i - y * w;
+        d[i] = ( int16_t ) ( ( ( int ) o[( long ) y * j.orgStride + x] * w0 - ( int ) p[( long ) y * j.otherPredStride + x] * w1 + ( 1 << 15 ) ) >> 16 );
+      }
+    }
+    else
     for( int i = threadIdx.x; i < w * h; i += 256 )
     {
       const int y = i / w, x = i - y * w;
@@ -211,7 +224,7 @@ __global__ __launch_bounds__( 256 ) void mest_mid_kernel( vtmhip_pic_params pic,
     q.orgOff = slot; q.refOff = j.refOff; q.orgStride = sst; q.refStride = j.refStride; q.width = j.width; q.height = j.height;
     q.intX = ( int16_t ) r.mvX; q.intY = ( int16_t ) r.mvY;
     q.predHor = prec_down( j.mvPredHor, 2 ); q.predVer = prec_down( j.mvPredVer, 2 ); q.motionLambda = j.motionLambda;
-    q.useHad = cfg.useHadME; q.useAltHpelIf = j.imv == 3; q.imvShift = j.imv == 3; q.bitDepth = ( uint8_t ) pic.bitDepth; q.pad = 0;
+    q.useHad = cfg.useHadME; q.useAltHpelIf = j.imv == 3; q.imvShift = j.imv == 3; q.bitDepth = ( uint8_t ) pic.bitDepth; q.wideOrg = bcw_weight( j ) != 0;
   }
   else
   {
@@ -233,7 +246,8 @@ __global__ __launch_bounds__( 256 ) void mest_final_kernel( vtmhip_me_cfg cfg, c
   if( i >= n ) return;
   const vtmhip_me_job   &j = jobs[i];
   const vtmhip_me_result r = wk.ires[i];
-  const double           fWeight = j.bi ? 0.5 : 1.0;    // xGetMEDistortionWeight with BCW_DEFAULT (:7666-7676)
+  const int              bcw = bcw_weight( j );
+  const double           fWeight = j.bi ? ( bcw ? fabs( ( double ) bcw / 8.0 ) : 0.5 ) : 1.0;    // xGetMEDistortionWeight (:7666-7676): |getBcwWeight| / g_BcwWeightBase, 0.5 for BCW_DEFAULT
   const double           lam = j.motionLambda;
   vtmhip_me_out o;
   o.intX = r.mvX; o.intY = r.mvY; o.intDist = r.dist;

@@ -114,6 +114,17 @@ __device__ __forceinline__ void uni_mv_list_entry( const vtmhip_pis_level &L, in
   v = self ? selfV : u.extraStart[max( src, 0 )][1];
 }
 
+// CU-level BCW weight of the PU (puIn.bcwWeightL1): list 1's weight of 8, 0 when it is the default pair (4 / 4) or no per-PU record exists
+__device__ __forceinline__ int bcw_weight_l1( const vtmhip_pis_level &L, int pu ) { const int w = L.puIn ? L.puIn[pu].bcwWeightL1 : 0; return w == 4 ? 0 : w; }
+__device__ __forceinline__ unsigned bcw_idx_bits( const vtmhip_pis_level &L, int pu ) { return L.puIn ? L.puIn[pu].bcwIdxBits : 0u; }
+// BcwFast (:2588-2593): under a non-default weight the refined list skips its pictures that carry the POC of the other list's chosen picture (cu.imv 0, temporal layer > 1)
+__device__ __forceinline__ bool bcw_fast_skip( const vtmhip_pis_level &L, int pu, int imv, int rl, int ref, int otherRef )
+{
+  if( !L.puIn || !L.puIn[pu].bcwFastSkipPoc || !bcw_weight_l1( L, pu ) || imv != 0 ) return false;
+  const int a = rl ? L.refPoc[1][ref] : L.refPoc[0][ref], b = rl ? L.refPoc[0][otherRef] : L.refPoc[1][otherRef];
+  return a == b;
+}
+
 __device__ __forceinline__ void final_pred( const vtmhip_pis_level &L, int pu, const vtmhip_pis_pu &P )
 {
   if( !L.predFinal ) return;      // vtmhip_predInterSearch_batch_dev: decisions only
@@ -190,6 +201,20 @@ __global__ __launch_bounds__( 256 ) void pis_uni_select_kernel( vtmhip_pis_level
         c.intX = c.intY = 0; c.intDist = 0;
         const_cast<vtmhip_me_out *>( L.uniOut )[row] = c;
       }
+      else if( j.flags & VTMHIP_MEJ_GIVEN_UNI )
+      {
+        // xReadBufferedUniMv (:7677-7697): vector and distortion of the default-weight pass (m_uniMotions), the rate re-priced against this call's predictor -- both in the
+        // AMVR precision (changeTransPrecInternal2Amvr), cost scale 0
+        const vtmhip_me_out g = L.uniOut[row];
+        const int sh = amvr_shift( j.imv );
+        r.mvHor = g.mvHor; r.mvVer = g.mvVer; r.mvPredHor = j.mvPredHor; r.mvPredVer = j.mvPredVer; r.mvpIdx = j.mvpIdx;
+        r.bits = j.bits + eg_bits( prec_down( r.mvHor, sh ) - prec_down( j.mvPredHor, sh ) ) + eg_bits( prec_down( r.mvVer, sh ) - prec_down( j.mvPredVer, sh ) );
+        r.cost = g.cost + rate( j.motionLambda, r.bits );
+        vtmhip_me_out c;
+        c.mvHor = r.mvHor; c.mvVer = r.mvVer; c.mvPredHor = r.mvPredHor; c.mvPredVer = r.mvPredVer; c.mvpIdx = r.mvpIdx; c.bits = r.bits; c.cost = r.cost;
+        c.intX = c.intY = 0; c.intDist = 0;
+        const_cast<vtmhip_me_out *>( L.uniOut )[row] = c;
+      }
       else
       {
         const vtmhip_me_out o = L.uniOut[row];
@@ -213,10 +238,14 @@ __global__ __launch_bounds__( 256 ) void pis_bi_jobs_kernel( vtmhip_pis_level L 
   const int pu = blockIdx.x * 256 + threadIdx.x;
   if( pu >= L.numPU ) return;
   vtmhip_pis_pu &P = L.pus[pu];
-  const int rl = L.mvdL1Zero ? 0 : ( P.cost[0] <= P.cost[1] ? 1 : 0 ), ot = 1 - rl;   // FASTINTERSEARCH_MODE1: refine the list with the larger cost (:2544-2556); MvdL1Zero: list 0 (:2576-2580)
+  // FASTINTERSEARCH_MODE1: refine the list with the larger cost (:2544-2556); a CU-level BCW weight: the list with the smaller |weight| (:2556-2559); MvdL1Zero: list 0 (:2576-2580)
+  const int wL1 = bcw_weight_l1( L, pu );
+  const int rl = L.mvdL1Zero ? 0 : wL1 ? ( abs( 8 - wL1 ) > abs( wL1 ) ? 1 : 0 ) : ( P.cost[0] <= P.cost[1] ? 1 : 0 ), ot = 1 - rl;
+  const int wRefined = wL1 ? ( rl ? wL1 : 8 - wL1 ) : 0;      // getBcwWeight( bcwIdx, refined list )
   P.refineList = rl;
   vtmhip_pred_job &po = L.predOther[pu];
   po.mode = ( uint8_t ) ot;
+  po.bcwWeight = ( int16_t ) wRefined;      // epilogue 2: the weighted target of removeHighFreq (:3320-3326)
   unsigned motOther;
   if( L.mvdL1Zero )
   {
@@ -258,8 +287,8 @@ __global__ __launch_bounds__( 256 ) void pis_bi_jobs_kernel( vtmhip_pis_level L 
     b.mvHor = r.mvHor; b.mvVer = r.mvVer;                       // cMvTemp[iRefList][iRefIdxTemp]: the uni result is the start of the bi search
     b.amvpCand[0][0] = u.amvpCand[0][0]; b.amvpCand[0][1] = u.amvpCand[0][1]; b.amvpCand[1][0] = u.amvpCand[1][0]; b.amvpCand[1][1] = u.amvpCand[1][1];
     b.mvpIdxBits[0] = u.mvpIdxBits[0]; b.mvpIdxBits[1] = u.mvpIdxBits[1];
-    b.bits = L.mbBits[2] + motOther + ref_idx_bits( L.numRef[rl], ref ) + u.mvpIdxBits[r.mvpIdx & 1] + ( L.smvdBit ? 1u : 0u );   // :2578-2593
-    b.searchRange = u.searchRange; b.motionLambda = u.motionLambda; b.flags = 0;
+    b.bits = L.mbBits[2] + motOther + bcw_idx_bits( L, pu ) + ref_idx_bits( L.numRef[rl], ref ) + u.mvpIdxBits[r.mvpIdx & 1] + ( L.smvdBit ? 1u : 0u );   // :2594-2608
+    b.searchRange = u.searchRange; b.motionLambda = u.motionLambda; b.flags = VTMHIP_MEJ_BCW_FLAGS( wRefined );
     const int nl = uni_mv_list_size( L, pu, u );   // the start candidates of the bi search (:3397-3426): none in the level-order driver
     b.numExtraStart = nl;
     for( int k = 0; k < nl; k++ ) { int eh, ev; uni_mv_list_entry( L, pu, u, r.mvHor, r.mvVer, k, eh, ev ); b.extraStart[k][0] = eh; b.extraStart[k][1] = ev; }
@@ -280,12 +309,21 @@ __global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
   };
   if( !L.mvdL1Zero || rl == 0 ) set_bi( 0, P.mv[0][0], P.mv[0][1], P.refIdx[0] );      // (MvdL1Zero: stage 2 put list 1 at its predictor, and list 0 is the refined list)
   if( !L.mvdL1Zero || rl == 1 ) set_bi( 1, P.mv[1][0], P.mv[1][1], P.refIdx[1] );
+  const int wL1 = bcw_weight_l1( L, pu );
+  const int otherRef = L.mvdL1Zero ? P.refIdxBi[1] : ( rl ? P.refIdx[0] : P.refIdx[1] );      // pu.refIdx[1 - iRefList] during the iteration
+  bool symRowSkipped = false;
   for( int ref = 0; ref < L.numRef[rl]; ref++ )
   {
     const vtmhip_me_job &j = L.biJobs[ref * L.numPU + pu];
     const vtmhip_me_out  o = L.biOut[ref * L.numPU + pu];
     vtmhip_pis_row r;
     r.mvHor = o.mvHor; r.mvVer = o.mvVer; r.mvPredHor = o.mvPredHor; r.mvPredVer = o.mvPredVer; r.mvpIdx = o.mvpIdx; r.bits = o.bits; r.cost = o.cost;
+    if( bcw_fast_skip( L, pu, j.imv, rl, ref, otherRef ) )      // the reference `continue`s before the search (:2588-2593): the row's search result is not used
+    {
+      if( L.biRows ) { r.cost = ~0ull; L.biRows[ref * L.numPU + pu] = r; }
+      if( rl == 0 && ref == L.symRefIdx[0] ) symRowSkipped = true;
+      continue;
+    }
     check_best_mvp( j, r );
     if( L.biRows ) L.biRows[ref * L.numPU + pu] = r;
     if( r.cost < P.costBi ) { P.costBi = r.cost; P.bits[2] = r.bits; set_bi( rl, r.mvHor, r.mvVer, ref ); }
@@ -300,17 +338,17 @@ __global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
     vtmhip_smvd_job &j = L.smvdJobs[pu];   // written in place
     j.orgOff = u0.orgOff; j.refOff[0] = u0.refOff; j.refOff[1] = u1.refOff; j.orgStride = u0.orgStride; j.refStride[0] = u0.refStride; j.refStride[1] = u1.refStride;
     j.puX = u0.puX; j.puY = u0.puY; j.width = u0.width; j.height = u0.height;
-    j.imv = u0.imv; j.useSatd = 1; j.clipBiPred = 0; j.bcwWeightTar = 4;
+    j.imv = u0.imv; j.useSatd = 1; j.clipBiPred = 0; j.bcwWeightTar = ( int8_t ) ( wL1 ? wL1 : 4 );      // the mirrored list is list 1
     j.numCand[0] = u0.numAmvpCand; j.numCand[1] = u1.numAmvpCand; j.skip = 0; j.pad_[0] = j.pad_[1] = j.pad_[2] = 0;
     for( int c = 0; c < 2; c++ )
     {
       j.cand[0][c][0] = u0.amvpCand[c][0]; j.cand[0][c][1] = u0.amvpCand[c][1]; j.cand[1][c][0] = u1.amvpCand[c][0]; j.cand[1][c][1] = u1.amvpCand[c][1];
       j.mvpIdxBits[c] = u0.mvpIdxBits[c];
     }
-    j.modeBits = L.mbBits[2] + 1; j.motionLambda = u0.motionLambda;
+    j.modeBits = L.mbBits[2] + 1 + bcw_idx_bits( L, pu ); j.motionLambda = u0.motionLambda;      // :2779-2782
     int ns = 0;
     j.starts[ns][0] = r0.mvHor; j.starts[ns][1] = r0.mvVer; ns++;
-    if( rl == 0 ) { const vtmhip_me_out o = L.biOut[s0 * L.numPU + pu]; j.starts[ns][0] = o.mvHor; j.starts[ns][1] = o.mvVer; }
+    if( rl == 0 && !symRowSkipped ) { const vtmhip_me_out o = L.biOut[s0 * L.numPU + pu]; j.starts[ns][0] = o.mvHor; j.starts[ns][1] = o.mvVer; }
     else { j.starts[ns][0] = r0.mvHor; j.starts[ns][1] = r0.mvVer; }
     ns++;
     if( P.refIdxBi[0] == s0 ) { j.starts[ns][0] = P.mvBi[0][0]; j.starts[ns][1] = P.mvBi[0][1]; ns++; }
@@ -329,6 +367,7 @@ __global__ __launch_bounds__( 256 ) void pis_final_kernel( vtmhip_pis_level L )
     return;
   }
   take_valid_list1( L, pu, P );
+  if( wL1 ) P.cost[0] = P.cost[1] = 0xffffffffull;      // enforceBcwPred (:2543, 2843-2847): uiCost[0] = uiCost[1] = MAX_UINT
   P.interDir = ( P.costBi <= P.cost[0] && P.costBi <= P.cost[1] ) ? 3 : ( P.cost[0] <= P.cost[1] ? 1 : 2 );   // :2846-2893
   final_pred( L, pu, P );
   L.pus[pu] = P;
@@ -348,6 +387,7 @@ __global__ __launch_bounds__( 256 ) void pis_smvd_merge_kernel( vtmhip_pis_level
     P.mvBi[1][0] = j.mvTar[0]; P.mvBi[1][1] = j.mvTar[1]; P.refIdxBi[1] = L.symRefIdx[1];
   }
   take_valid_list1( L, pu, P );
+  if( bcw_weight_l1( L, pu ) ) P.cost[0] = P.cost[1] = 0xffffffffull;      // enforceBcwPred
   P.interDir = ( P.costBi <= P.cost[0] && P.costBi <= P.cost[1] ) ? 3 : ( P.cost[0] <= P.cost[1] ? 1 : 2 );
   final_pred( L, pu, P );
   L.pus[pu] = P;
@@ -368,7 +408,7 @@ __global__ __launch_bounds__( 256 ) void pis_affine_jobs_kernel( vtmhip_pis_leve
   a.orgStride = u.orgStride; a.refStride = u.refStride; a.otherPredStride = 0; a.predStride = 0;
   a.puX = u.puX; a.puY = u.puY; a.width = u.width; a.height = u.height;
   a.sixParam = 0; a.interDir = ( uint8_t ) ( 1 + list ); a.imv = 0; a.bi = 0; a.useSatd = 1; a.useAffineType = 1; a.amvrEncOpt = 0;
-  a.lowDelayRounds = ( uint8_t ) L.affLowDelay; a.profAllowed = 1; a.profNeedsLargeGrad = ( uint8_t ) !L.affCheckLDC; a.profIsBi = 0; a.pad0 = 0;
+  a.lowDelayRounds = ( uint8_t ) L.affLowDelay; a.profAllowed = 1; a.profNeedsLargeGrad = ( uint8_t ) !L.affCheckLDC; a.profIsBi = 0; a.bcwWeight = 0;
   for( int c = 0; c < 3; c++ )
   {
     a.mvPred[c][0] = r.mvPredHor; a.mvPred[c][1] = r.mvPredVer;

@@ -49,7 +49,7 @@ class FracJob(C.Structure):
     _fields_ = [("orgOff", C.c_int64), ("refOff", C.c_int64), ("orgStride", C.c_int32), ("refStride", C.c_int32),
                 ("width", C.c_int16), ("height", C.c_int16), ("intX", C.c_int16), ("intY", C.c_int16),
                 ("predHor", C.c_int32), ("predVer", C.c_int32), ("motionLambda", C.c_double), ("useHad", C.c_uint8),
-                ("useAltHpelIf", C.c_uint8), ("imvShift", C.c_uint8), ("bitDepth", C.c_uint8), ("pad", C.c_int32)]
+                ("useAltHpelIf", C.c_uint8), ("imvShift", C.c_uint8), ("bitDepth", C.c_uint8), ("wideOrg", C.c_int32)]
 
 
 class FracResult(C.Structure):
@@ -134,7 +134,7 @@ class PredJob(C.Structure):
     _fields_ = [("orgOff", C.c_int64), ("refOff", C.c_int64 * 2), ("predOff", C.c_int64), ("outOff", C.c_int64), ("orgStride", C.c_int32),
                 ("refStride", C.c_int32 * 2), ("predStride", C.c_int32), ("outStride", C.c_int32), ("mv", (C.c_int32 * 2) * 2),
                 ("width", C.c_int16), ("height", C.c_int16), ("mode", C.c_uint8), ("epilogue", C.c_uint8), ("bitDepth", C.c_uint8),
-                ("useAltHpelIf", C.c_uint8), ("chroma", C.c_uint8), ("route", C.c_uint8), ("pad1", C.c_int16)]
+                ("useAltHpelIf", C.c_uint8), ("chroma", C.c_uint8), ("route", C.c_uint8), ("bcwWeight", C.c_int16)]
 
 
 class MaskedSadJob(C.Structure):
@@ -176,7 +176,8 @@ class PisPu(C.Structure):
 
 
 class PisPuIn(C.Structure):
-    _fields_ = [("noSmvd", C.c_uint8), ("uniMvInsert", C.c_uint8), ("uniMvSelfIsNew", C.c_uint8), ("pad", C.c_uint8), ("uniMvSelfPos", C.c_int32)]
+    _fields_ = [("noSmvd", C.c_uint8), ("uniMvInsert", C.c_uint8), ("uniMvSelfIsNew", C.c_uint8), ("bcwWeightL1", C.c_int8), ("uniMvSelfPos", C.c_int16),
+                ("bcwIdxBits", C.c_uint8), ("bcwFastSkipPoc", C.c_uint8)]
 
 
 class PisLevel(C.Structure):
@@ -187,7 +188,7 @@ class PisLevel(C.Structure):
                 ("refPoc", (C.c_int32 * MAX_REF) * 2), ("predFinalC", C.c_void_p), ("posC", C.c_void_p), ("refPlaneOffC", ((C.c_int64 * MAX_REF) * 2) * 2),
                 ("affJobs", C.c_void_p), ("affLowDelay", C.c_int32), ("affCheckLDC", C.c_int32), ("smvdJobs", C.c_void_p), ("symRefIdx", C.c_int32 * 2),
                 ("candsGiven", C.c_int32), ("biRestricted", C.c_int32), ("list1FromList0", C.c_int32 * MAX_REF), ("puIn", C.c_void_p), ("biRows", C.c_void_p),
-                ("distBiP", C.c_void_p), ("mvdL1Zero", C.c_int32), ("fastMEForGenBLowDelay", C.c_int32), ("pad2", C.c_int32), ("picW", C.c_int32), ("picH", C.c_int32), ("ctuSize", C.c_int32)]
+                ("distBiP", C.c_void_p), ("mvdL1Zero", C.c_int32), ("fastMEForGenBLowDelay", C.c_int32), ("givenRows", C.c_int32), ("picW", C.c_int32), ("picH", C.c_int32), ("ctuSize", C.c_int32)]
 
 
 class PisLevelRun(C.Structure):
@@ -207,7 +208,7 @@ class AffineMeJob(C.Structure):
                 ("otherPredStride", C.c_int32), ("predStride", C.c_int32), ("puX", C.c_int16), ("puY", C.c_int16), ("width", C.c_int16), ("height", C.c_int16),
                 ("sixParam", C.c_uint8), ("interDir", C.c_uint8), ("imv", C.c_uint8), ("bi", C.c_uint8), ("useSatd", C.c_uint8), ("useAffineType", C.c_uint8),
                 ("amvrEncOpt", C.c_uint8), ("lowDelayRounds", C.c_uint8), ("profAllowed", C.c_uint8), ("profNeedsLargeGrad", C.c_uint8), ("profIsBi", C.c_uint8),
-                ("pad0", C.c_uint8), ("mvPred", (C.c_int32 * 2) * 3), ("mv", (C.c_int32 * 2) * 3), ("bits", C.c_uint32), ("pad1", C.c_uint32),
+                ("bcwWeight", C.c_int8), ("mvPred", (C.c_int32 * 2) * 3), ("mv", (C.c_int32 * 2) * 3), ("bits", C.c_uint32), ("pad1", C.c_uint32),
                 ("motionLambda", C.c_double), ("hevcCost", C.c_uint64)]
 
 
