@@ -676,8 +676,8 @@ int vtmhip_affine_equal_coeff_batch_dev( vtmhip_ctx *ctx, const int16_t *d_resiB
  * (InterSearch.cpp:5340-5775) = the first prediction at the (clipped, AMVR-rounded) start model, up to 7 gradient iterations (error -> Sobel ->
  * normal equations -> solveEqual :5215-5284 -> control-point update -> InterPrediction::xPredAffineBlk :856-1232 -> SATD / SAD + xCalcAffineMVBits
  * :3067-3085) and the control-point refinement (:5655-5765), one workgroup per job from start to end: the fp64 steps run on the device in IEEE
- * double.  Covered: cu.imv 0 / 1, and 2 without AffineAmvrEncOpt (xDetermineBestMvp stays with the host); default BCW weight; PROF as the
- * caller's flags say.  The predictor acMvPred and the AMVP index do not change in these modes, so the result is the model, its bits and cost. */
+ * double.  Covered: cu.imv 0 / 1 / 2, with AffineAmvrEncOpt too (imv 2: xDetermineBestMvp over the job's AMVP list); BCW weights (bcwWeight); PROF as the
+ * caller's flags say.  Without an AMVP list in the job the predictor acMvPred and the AMVP index do not change, so the result is the model, its bits and cost. */
 typedef struct
 {
   int64_t  orgOff, refOff;          /* PU top-left in the original plane / the same position (MV 0,0) in the reference plane */
@@ -703,6 +703,14 @@ typedef struct
   uint32_t pad1;
   double   motionLambda;
   uint64_t hevcCost;                /* m_hevcCost: the refinement stage runs when the best cost so far <= AFFINE_ME_LIST_MVP_TH * hevcCost */
+  /* cu.imv == 2 with AffineAmvrEncOpt (ABI 6): xDetermineBestMvp (:7766-7785) re-picks the affine AMVP candidate at the start model and at every evaluation of the
+   * gradient stage (:5444-5449, 5629-5634: acMvPred follows the pick even when the evaluation does not improve the cost; the refinement stage prices against the
+   * predictor the LAST gradient evaluation left).  numAmvpCand == 0: no list given, the predictor never changes (every other mode). */
+  int32_t  amvpCand[2][3][2];       /* aamvpi.mvCandLT / mvCandRT / mvCandLB of candidate i */
+  uint32_t mvpIdxBits[2];           /* m_auiMVPIdxCost[i][aamvpi.numCand] */
+  uint8_t  numAmvpCand;             /* aamvpi.numCand (1 or 2), 0: not given */
+  uint8_t  mvpIdx;                  /* mvpIdx on entry: `bits` holds m_auiMVPIdxCost[mvpIdx][numCand] (dirBits = bits - that, :5359) */
+  uint8_t  pad2[6];
 } vtmhip_affine_me_job;
 
 typedef struct
@@ -710,7 +718,7 @@ typedef struct
   int32_t  mv[3][2];                /* acMv */
   uint32_t bits;                    /* ruiBits */
   int32_t  iterations, refinements; /* predictions evaluated in the gradient stage / the refinement stage (statistics) */
-  int32_t  pad;
+  int32_t  mvpIdx;                  /* mvpIdx on return (changes only with an AMVP list in the job; acMvPred = that candidate, :5768-5770) */
   uint64_t cost;                    /* ruiCost */
 } vtmhip_affine_me_out;
 

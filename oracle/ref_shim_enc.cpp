@@ -784,7 +784,8 @@ void affineHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPi
     vtmref_orig_xAffineMotionEstimation( is, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi );
     return;
   }
-  const bool unsupported = is->m_pcEncCfg->getMCTSEncConstraint() || is->m_pcEncCfg->getClipForBiPredMeEnabled() || ( pu.cu->imv == 2 && encOpt )
+  const bool pickMvp = pu.cu->imv == 2 && encOpt;      // xDetermineBestMvp over the affine AMVP list (:5444-5449, 5629-5634): the list travels in the job
+  const bool unsupported = is->m_pcEncCfg->getMCTSEncConstraint() || is->m_pcEncCfg->getClipForBiPredMeEnabled() || ( pickMvp && ( aamvpi.numCand < 1 || aamvpi.numCand > 2 ) )
                         || refPic->isWrapAroundEnabled( pu.cs->pps ) || refPic->isRefScaled( pu.cs->pps ) || w < 16 || h < 16 || w > 128 || h > 128
                         || slice.getSPS()->getBitDepth( CHANNEL_TYPE_LUMA ) > 10 || slice.getPPS()->getUseWP() || slice.getPPS()->getWPBiPred();
   if( unsupported ) g_st->affineUnsupported++;
@@ -815,6 +816,17 @@ void affineHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPi
   j.bcwWeight = ( bcw && bBi ) ? getBcwWeight( pu.cu->BcwIdx, eRefPicList ) : 0;      // removeHighFreq( ..., getBcwWeight ) / xGetMEDistortionWeight (:5377-5385)
   for( int i = 0; i < 3; i++ ) { j.mvPred[i][0] = acMvPred[i].hor; j.mvPred[i][1] = acMvPred[i].ver; j.mv[i][0] = acMv[i].hor; j.mv[i][1] = acMv[i].ver; }
   j.bits = ruiBits; j.motionLambda = is->m_pcRdCost->m_motionLambda; j.hevcCost = is->m_hevcCost;
+  if( pickMvp )
+  {
+    j.numAmvpCand = ( uint8_t ) aamvpi.numCand; j.mvpIdx = ( uint8_t ) mvpIdx;
+    for( int i = 0; i < aamvpi.numCand; i++ )
+    {
+      const Mv cp[3] = { aamvpi.mvCandLT[i], aamvpi.mvCandRT[i], aamvpi.mvCandLB[i] };
+      for( int v = 0; v < 3; v++ ) { j.amvpCand[i][v][0] = cp[v].hor; j.amvpCand[i][v][1] = cp[v].ver; }
+      j.mvpIdxBits[i] = is->m_auiMVPIdxCost[i][aamvpi.numCand];
+    }
+  }
+  const int mvpIdxIn = mvpIdx;
   vtmhip_pic_params pic; memset( &pic, 0, sizeof( pic ) );
   pic.picW = pu.cs->pps->getPicWidthInLumaSamples(); pic.picH = pu.cs->pps->getPicHeightInLumaSamples(); pic.ctuSize = pu.cs->sps->getMaxCUWidth();
   pic.bitDepth = slice.getSPS()->getBitDepth( CHANNEL_TYPE_LUMA );
@@ -831,11 +843,14 @@ void affineHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPi
   if( !ok ) { note_error(); if( replaceOnly ) vtmref_orig_xAffineMotionEstimation( is, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi ); return; }
   g_st->affineDevice++;
   const int mvNum = j.sixParam ? 3 : 2;
-  bool bad = !replaceOnly && ( o.bits != ruiBits || o.cost != ruiCost );
+  bool bad = !replaceOnly && ( o.bits != ruiBits || o.cost != ruiCost || ( pickMvp && o.mvpIdx != mvpIdx ) );
   for( int i = 0; i < mvNum && !replaceOnly; i++ ) bad |= o.mv[i][0] != acMv[i].hor || o.mv[i][1] != acMv[i].ver;
   if( bad ) { if( g_st->affineMismatch++ == 0 && g_st->hookMismatch[0] + g_st->hookMismatch[1] == 0 ) { const int32_t v[8] = { 2, w * 1000 + h, j.sixParam * 100 + j.bi * 10 + j.imv, o.mv[0][0] - acMv[0].hor, o.mv[1][0] - acMv[1].hor, ( int32_t ) ruiCost, ( int32_t ) o.cost, 0 }; memcpy( g_st->hookFirstMismatch, v, sizeof( v ) ); } }
   for( int i = 0; i < mvNum; i++ ) { acMv[i].hor = o.mv[i][0]; acMv[i].ver = o.mv[i][1]; }
   ruiBits = o.bits; ruiCost = o.cost;
+  // the member's last statements (:5768-5770): acMvPred = the AMVP candidate of mvpIdx -- which only moves when xDetermineBestMvp ran
+  mvpIdx = pickMvp ? o.mvpIdx : mvpIdxIn;
+  acMvPred[0] = aamvpi.mvCandLT[mvpIdx]; acMvPred[1] = aamvpi.mvCandRT[mvpIdx]; acMvPred[2] = aamvpi.mvCandLB[mvpIdx];
 }
 
 // what the trampoline of xFwdLfnst / xInvLfnst derives from the TU exactly as the reference does (TrQuant.cpp:346-366): does LFNST apply, and with
@@ -1058,7 +1073,8 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
         if( g_mask & 2048 )
         {
           // VTMREF_PIS_DUMP: record mode (no device); otherwise compare mode, VTMREF_REPLACE=1: replace mode
-          if( getenv( "VTMREF_PIS_DUMP" ) ) { g_pisDump = fopen( getenv( "VTMREF_PIS_DUMP" ), "wb" ); g_pisDumpStride = getenv( "VTMREF_PIS_DUMP_STRIDE" ) ? strtoull( getenv( "VTMREF_PIS_DUMP_STRIDE" ), nullptr, 10 ) : 1; }
+          if( getenv( "VTMREF_PIS_DUMP" ) ) { g_pisDump = fopen( getenv( "VTMREF_PIS_DUMP" ), "wb" ); g_pisDumpStride = getenv( "VTMREF_PIS_DUMP_STRIDE" ) ? strtoull( getenv( "VTMREF_PIS_DUMP_STRIDE" ), nullptr, 10 ) : 1;
+            g_pisDumpBcwStride = getenv( "VTMREF_PIS_DUMP_BCW_STRIDE" ) ? strtoull( getenv( "VTMREF_PIS_DUMP_BCW_STRIDE" ), nullptr, 10 ) : 0; g_pisDumpBcwCtr = 0; }
           g_pisReplace = getenv( "VTMREF_REPLACE" ) && atoi( getenv( "VTMREF_REPLACE" ) ) != 0;
           g_hookPis = g_pisDump != nullptr || g_countOnly || ( g_ctx && pisAlloc() );      // (count-only: the hook only times the member)
         }

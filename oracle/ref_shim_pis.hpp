@@ -85,7 +85,7 @@ PisSlots   *g_pisHost = nullptr, *g_pisRec = nullptr;
 char       *d_pis = nullptr;
 int16_t    *d_pisOrgBi = nullptr;
 bool        g_hookPis = false;
-uint64_t    g_pisCtr = 0, g_pisDumpCtr = 0, g_pisDumpStride = 1;
+uint64_t    g_pisCtr = 0, g_pisDumpCtr = 0, g_pisDumpStride = 1, g_pisDumpBcwCtr = 0, g_pisDumpBcwStride = 0;   // (BcwStride != 0: the calls at a non-default BCW weight are sampled with their own stride)
 FILE       *g_pisDump = nullptr;
 std::vector<std::pair<const Picture *, int>> g_pisDumpedPlanes;   // (picture buffer, POC) in dump order
 decltype( &vtmhip_predInterSearch_batch_dev ) g_apiPis = nullptr;
@@ -330,7 +330,8 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
              is->m_pcEncCfg->getUseHashME(), is->m_pcEncCfg->getClipForBiPredMeEnabled(), cu.cs->picHeader->getMvdL1ZeroFlag(), ( int ) fsm, ( int ) is->m_motionEstimationSearchMethod, w, h,
              numRef[0], numRef[1], sps.getBitDepth( CHANNEL_TYPE_LUMA ), cu.firstPU->next != nullptr, imv );
   const bool dumping = g_pisDump != nullptr;
-  if( unsupported || ( !dumping && !hookSampled( g_pisCtr ) ) || ( dumping && ( g_pisDumpCtr++ % g_pisDumpStride ) != 0 ) )
+  const bool dumpOwn = dumping && bcwIdx != BCW_DEFAULT && g_pisDumpBcwStride != 0;
+  if( unsupported || ( !dumping && !hookSampled( g_pisCtr ) ) || ( dumping && ( dumpOwn ? ( g_pisDumpBcwCtr++ % g_pisDumpBcwStride ) != 0 : ( g_pisDumpCtr++ % g_pisDumpStride ) != 0 ) ) )
   {
     const uint64_t t1 = nowNs();
     vtmref_orig_predInterSearch( is, cu, partitioner );

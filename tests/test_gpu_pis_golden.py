@@ -14,7 +14,11 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # ra: the random-access clip (353 records); ldp / ldb: BASELINE config 2's structures (147 / 148 records: P slices with four references; low-delay B with the same four
 # pictures in both lists -- every list-1 row a FastMEForGenBLowDelay copy, mvd_l1_zero)
-NPZS = {"ra": os.path.join(GOLDEN, "pis_enc.npz"), "ldp": os.path.join(GOLDEN, "pis_enc_ldp.npz"), "ldb": os.path.join(GOLDEN, "pis_enc_ldb.npz")}
+# bcw: the random-access clip with BCW + BcwFast + AffineAmvr (350 records, ~250 of them at a CU-level weight other than the default: given uni rows, weighted bi targets, the
+# distortion weight |w| / 8, BcwFast's same-POC skip, the enforced bi mode, the weighted SMVD block)
+NPZS = {"ra": os.path.join(GOLDEN, "pis_enc.npz"), "ldp": os.path.join(GOLDEN, "pis_enc_ldp.npz"), "ldb": os.path.join(GOLDEN, "pis_enc_ldb.npz"), "bcw": os.path.join(GOLDEN, "pis_enc_bcw.npz")}
+GIVEN_UNI = 2          # VTMHIP_MEJ_GIVEN_UNI
+SKIPPED = 2 ** 64 - 1  # biRows[].cost of a row BcwFast skipped
 
 
 def rate(lam, bits):
@@ -25,7 +29,7 @@ def same(a, b, fields):
     return all(getattr(a, f) == getattr(b, f) for f in fields)
 
 
-@pytest.mark.parametrize("structure", ["ra", "ldp", "ldb"])
+@pytest.mark.parametrize("structure", ["ra", "ldp", "ldb", "bcw"])
 def test_predInterSearch_one_call_per_pu_matches_the_real_encoder(structure):
     from vtm_amd.device import Context
     planes, recs = G.load_npz(NPZS[structure])
@@ -35,7 +39,8 @@ def test_predInterSearch_one_call_per_pu_matches_the_real_encoder(structure):
     d_slots = ctx.alloc(C.sizeof(G.PisSlots) + 128 * 128 * 2)
     d_orgbi = ctx.alloc(128 * 128 * 2)
     off = {f: getattr(G.PisSlots, f).offset for f, _ in G.PisSlots._fields_}
-    stats = dict(recs=0, rows=0, copies=0, cached=0, bi=0, smvd=0, smvd_won=0, mvdl1zero=0, imv=[0, 0, 0, 0], affine_won=0, dirs=[0, 0, 0, 0])
+    stats = dict(recs=0, rows=0, copies=0, cached=0, bi=0, smvd=0, smvd_won=0, mvdl1zero=0, imv=[0, 0, 0, 0], affine_won=0, dirs=[0, 0, 0, 0], given=0, weighted=0, skipped=0,
+                 weighted_bi_won=0, cost_unknown=0, weights={})
     for hd, sin, sout, org, fin in recs:
         w, h, n0, n1 = hd.w, hd.h, hd.numRef[0], hd.numRef[1]
         rows = n0 + n1
@@ -62,6 +67,10 @@ def test_predInterSearch_one_call_per_pu_matches_the_real_encoder(structure):
         for r in range(4):
             L.list1FromList0[r] = hd.list1FromList0[r]
         L.symRefIdx[0], L.symRefIdx[1] = hd.symRefIdx[0], hd.symRefIdx[1]
+        L.givenRows, L.curPoc = hd.givenRows, hd.curPoc
+        for l in (0, 1):
+            for r in range(4):
+                L.refPoc[l][r] = hd.refPoc[l][r]
         L.uniJobs, L.uniOut, L.uniRows, L.distBiP = base + off["uniJobs"], base + off["uniOut"], base + off["uniRows"], base + off["distBiP"]
         L.pus, L.puIn, L.predOther, L.biJobs, L.biOut, L.biRows, L.pos = (base + off[k] for k in ("pus", "puIn", "predOther", "biJobs", "biOut", "biRows", "pos"))
         L.smvdJobs = base + off["smvd"] if hd.hasSmvd else None
@@ -83,8 +92,11 @@ def test_predInterSearch_one_call_per_pu_matches_the_real_encoder(structure):
         for row in range(rows):
             assert same(D.uniJobs[row], E.uniJobs[row], ("mvpIdx", "mvPredHor", "mvPredVer", "bits")) and D.distBiP[row] == E.distBiP[row], ("amvp", tag, row)
             if hd.rowCalls[row]:
+                # (a GIVEN row -- xReadBufferedUniMv under a non-default BCW weight -- went through the member too: it returned the buffered vector, re-priced)
                 assert E.uniOut[row].intDist == 1, ("the reference did not search a row it should have", tag, row)
                 assert same(D.uniOut[row], E.uniOut[row], ("mvHor", "mvVer", "mvPredHor", "mvPredVer", "mvpIdx", "bits", "cost")), ("uni", tag, row, hd.rowCached[row])
+                stats["given"] += int(bool(S.uniJobs[row].flags & GIVEN_UNI))
+                assert bool(S.uniJobs[row].flags & GIVEN_UNI) == bool((hd.givenRows >> row) & 1)
             else:
                 assert E.uniOut[row].intDist == 0
                 stats["copies"] += 1
@@ -95,9 +107,17 @@ def test_predInterSearch_one_call_per_pu_matches_the_real_encoder(structure):
         if fin.biList >= 0:
             assert P.refineList == fin.biList, ("refined list", tag)
             for r in range((n0, n1)[fin.biList]):
+                if E.biOut[r].intDist == 0:      # the reference never searched this row: BcwFast's same-POC skip (InterSearch.cpp:2588-2593)
+                    assert S.puIn[0].bcwWeightL1 not in (0, 4) and D.biRows[r].cost == SKIPPED, ("bi row the reference skipped", tag, r)
+                    stats["skipped"] += 1
+                    continue
+                assert D.biRows[r].cost != SKIPPED, ("bi row the device skipped", tag, r)
                 assert same(D.biJobs[r], E.biJobs[r], ("mvPredHor", "mvPredVer", "mvHor", "mvVer", "mvpIdx", "bits")), ("bi entry", tag, r)
                 assert same(D.biOut[r], E.biOut[r], ("mvHor", "mvVer", "mvPredHor", "mvPredVer", "mvpIdx", "bits", "cost")), ("bi", tag, r)
             stats["bi"] += 1
+        elif S.puIn[0].bcwWeightL1 not in (0, 4) and n1 and not hd.biRestricted:
+            # every row of the refined list skipped: no served bi call told the record mode which list it was
+            assert all(D.biRows[r].cost == SKIPPED for r in range((n0, n1)[P.refineList])), ("bi stage without a searched row", tag)
         # ---- the SMVD block ----
         if fin.smvdRan:
             assert hd.hasSmvd
@@ -112,7 +132,15 @@ def test_predInterSearch_one_call_per_pu_matches_the_real_encoder(structure):
         # ---- what the member left in pu ----
         bi = P.interDir == 3
         dev_cost = P.costBi if bi else P.cost[1 if P.interDir == 2 else 0]
-        assert dev_cost == fin.hevcCost, ("best translational cost", tag, dev_cost, fin.hevcCost)
+        if fin.hevcCost == G.COST_UNKNOWN:      # the member did not store its translational cost (a non-default weight with both affine models buffered, :3054-3057)
+            stats["cost_unknown"] += 1
+        else:
+            assert dev_cost == fin.hevcCost, ("best translational cost", tag, dev_cost, fin.hevcCost)
+        wl1 = int(S.puIn[0].bcwWeightL1)
+        if wl1 not in (0, 4):
+            stats["weighted"] += 1
+            stats["weights"][wl1] = stats["weights"].get(wl1, 0) + 1
+            stats["weighted_bi_won"] += int(bi and not fin.affine)
         if not fin.affine:
             assert P.interDir == fin.interDir and (not bi or bool(P.smvdMode) == bool(fin.smvdMode)), ("decision", tag)
             for l in (0, 1):
@@ -141,6 +169,9 @@ def test_predInterSearch_one_call_per_pu_matches_the_real_encoder(structure):
     if structure == "ra":
         assert stats["recs"] >= 300 and stats["copies"] >= 100 and stats["cached"] >= 100 and stats["bi"] >= 200 and stats["smvd"] >= 30 and stats["mvdl1zero"] >= 100
         assert min(stats["imv"][:3]) >= 20 and stats["dirs"][3] >= 50 and stats["dirs"][1] >= 20
+    elif structure == "bcw":
+        assert stats["recs"] >= 300 and stats["weighted"] >= 200 and stats["given"] >= 300 and stats["skipped"] >= 1 and stats["weighted_bi_won"] >= 50 and len(stats["weights"]) == 4
+        assert stats["smvd"] >= 30 and min(stats["imv"][:3]) >= 10
     elif structure == "ldp":
         assert stats["recs"] >= 100 and stats["bi"] == 0 and stats["dirs"][1] >= 50 and stats["dirs"][2] == 0 and stats["dirs"][3] == 0
     else:
@@ -166,6 +197,10 @@ def _level(ctx, planes, bases, hd, n, base_ptr, off_of):
     for r in range(4):
         L.list1FromList0[r] = hd.list1FromList0[r]
     L.symRefIdx[0], L.symRefIdx[1] = hd.symRefIdx[0], hd.symRefIdx[1]
+    L.givenRows, L.curPoc = hd.givenRows, hd.curPoc
+    for l in (0, 1):
+        for r in range(4):
+            L.refPoc[l][r] = hd.refPoc[l][r]
     for name in ("uniJobs", "uniOut", "uniRows", "distBiP", "pus", "puIn", "predOther", "biJobs", "biOut", "biRows", "pos"):
         setattr(L, name, base_ptr + off_of(name))
     L.smvdJobs = base_ptr + off_of("smvd") if hd.hasSmvd else None
@@ -176,7 +211,7 @@ def _level(ctx, planes, bases, hd, n, base_ptr, off_of):
     return R, stride
 
 
-@pytest.mark.parametrize("structure", ["ra", "ldp", "ldb"])
+@pytest.mark.parametrize("structure", ["ra", "ldp", "ldb", "bcw"])
 def test_predInterSearch_batches_of_several_pus_equal_the_single_calls(structure):
     """The same records in BATCHES: the PUs of one slice, shape and AMVR mode (up to 17 in the golden file) in one vtmhip_predInterSearch_batch_dev call -- tables in
     the level-order layout (rows (list, refIdx)-major, PU-minor), per-PU m_uniMvList state in vtmhip_pis_pu_in -- must give every PU exactly what its own call gives."""
@@ -189,7 +224,9 @@ def test_predInterSearch_batches_of_several_pus_equal_the_single_calls(structure
     groups = {}
     for rec in recs:
         hd, sin = rec[0], rec[1]
-        key = (hd.poc, hd.w, hd.h, hd.imv, hd.hasSmvd, hd.biRestricted, hd.mvdL1Zero, hd.numRef[0], hd.numRef[1], hd.uniMvListSize == 0, int(sin.puIn[0].uniMvInsert))
+        # (one batch = one level record: PUs that share the slice, the shape, the AMVR mode and the level-wide switches -- under BCW also the set of given rows; the CU-level
+        # weight itself is per PU (vtmhip_pis_pu_in), so PUs of different weights may share a batch when their given rows agree)
+        key = (hd.poc, hd.w, hd.h, hd.imv, hd.hasSmvd, hd.biRestricted, hd.mvdL1Zero, hd.numRef[0], hd.numRef[1], hd.givenRows, hd.uniMvListSize == 0, int(sin.puIn[0].uniMvInsert))
         groups.setdefault(key, []).append(rec)
     types = [("uniJobs", MeJob, 8), ("uniOut", MeOut, 8), ("uniRows", PisRow, 8), ("distBiP", C.c_uint64, 8), ("pus", PisPu, 1), ("puIn", PisPuIn, 1), ("predOther", PredJob, 1),
              ("biJobs", MeJob, 4), ("biOut", MeOut, 4), ("biRows", PisRow, 4), ("smvd", SmvdJob, 1), ("pos", C.c_int64, 1)]
@@ -220,6 +257,7 @@ def test_predInterSearch_batches_of_several_pus_equal_the_single_calls(structure
                 j.refOff = bases[hp.rowPlane[row]] + pl.margin * pl.stride + pl.margin + hp.y * pl.stride + hp.x
                 j.orgOff = p * w * h
                 put("uniJobs", MeJob, row * n + p, j)
+                put("uniOut", MeOut, row * n + p, sin.uniOut[row])      # (input of a GIVEN row: the buffered vector and its distortion)
             put("puIn", PisPuIn, p, sin.puIn[0])
             po = PredJob.from_buffer_copy(bytes(sin.predOther[0]))
             po.orgOff = po.predOff = po.outOff = p * w * h

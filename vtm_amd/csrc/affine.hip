@@ -470,6 +470,10 @@ __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( PACKED
   if( !j.useAffineType ) iterTime = bi ? 5 : 7;
   const int maxRound = imv ? 3 : ( ( j.amvrEncOpt && j.lowDelayRounds ) ? 2 : 3 );
   int iterations = 0, refinements = 0;
+  // cu.imv == 2 with AffineAmvrEncOpt: xDetermineBestMvp over the job's AMVP list at the start model and at every gradient evaluation (InterSearch.cpp:5444-5449, 5629-5634)
+  const bool     pickMvp = imv == 2 && j.amvrEncOpt && j.numAmvpCand > 0;
+  const unsigned dirBits = pickMvp ? j.bits - j.mvpIdxBits[j.mvpIdx & 1] : 0u;      // (:5359)
+  int            mvpIdx = j.mvpIdx, bestMvpIdx = j.mvpIdx;
   enum { P_INIT, P_ITER, P_REF_START, P_C1, P_C2, P_C3, P_RND, P_DONE };
   int  phase = P_INIT, iter = 0, k = 0, it = 0, pos = 0, rnd = 0;
   bool modelChange = false, loopChange = false;
@@ -667,10 +671,28 @@ __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( PACKED
     affine_pred( c, cand, sPred );
     __syncthreads();
     unsigned long long cost = uni64( block_dist<PACKED>( sPred, sPat, w, h, satd, sRed ) );
-    const unsigned     bits = j.bits + affine_mv_bits( SIX, imv, cand, pred );
+    unsigned           bits;
+    const bool         picking = pickMvp && ( cur == P_INIT || cur == P_ITER );
+    if( picking )
+    {
+      // xDetermineBestMvp (:7766-7785): the candidate with the fewest bits for this model, first minimum; acMvPred follows it whether or not the model wins
+      unsigned minBits = ~0u;
+      for( int ci = 0; ci < j.numAmvpCand && ci < 2; ci++ )
+      {
+        int pc[3][2];
+#pragma unroll
+        for( int v = 0; v < 3; v++ ) { pc[v][0] = ci ? j.amvpCand[1][v][0] : j.amvpCand[0][v][0]; pc[v][1] = ci ? j.amvpCand[1][v][1] : j.amvpCand[0][v][1]; }
+        const unsigned cb = ( ci ? j.mvpIdxBits[1] : j.mvpIdxBits[0] ) + affine_mv_bits( SIX, imv, cand, pc );
+        if( cb < minBits ) { minBits = cb; bestMvpIdx = ci; }
+      }
+#pragma unroll
+      for( int v = 0; v < 3; v++ ) { pred[v][0] = bestMvpIdx ? j.amvpCand[1][v][0] : j.amvpCand[0][v][0]; pred[v][1] = bestMvpIdx ? j.amvpCand[1][v][1] : j.amvpCand[0][v][1]; }
+      bits = dirBits + minBits;
+    }
+    else bits = j.bits + affine_mv_bits( SIX, imv, cand, pred );
     cost = ( unsigned long long ) ( floor( fWeight * ( double ) cost ) + ( double ) ( unsigned long long ) ( lam * bits ) );
     const bool better = cur == P_INIT || cost < costBest;
-    if( better ) { costBest = cost; bitsBest = bits; best = cand; }
+    if( better ) { costBest = cost; bitsBest = bits; best = cand; if( picking ) mvpIdx = bestMvpIdx; }
     if( cur == P_INIT ) phase = P_ITER;
     else if( cur == P_ITER ) iterations++;
     else
@@ -701,7 +723,7 @@ __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( PACKED
   {
     vtmhip_affine_me_out o;
     for( int i = 0; i < 3; i++ ) { o.mv[i][0] = best.v[i][0]; o.mv[i][1] = best.v[i][1]; }
-    o.bits = bitsBest; o.cost = costBest; o.iterations = iterations; o.refinements = refinements; o.pad = 0;
+    o.bits = bitsBest; o.cost = costBest; o.iterations = iterations; o.refinements = refinements; o.mvpIdx = mvpIdx;
     results[blockIdx.x] = o;
   }
 }

@@ -418,6 +418,7 @@ __global__ __launch_bounds__( 256 ) void pis_affine_jobs_kernel( vtmhip_pis_leve
   unsigned long long hc = P.cost[0] < P.cost[1] ? P.cost[0] : P.cost[1];
   if( L.numRef[1] > 0 && P.costBi < hc ) hc = P.costBi;
   a.hevcCost = hc;
+  a.numAmvpCand = 0; a.mvpIdx = 0;      // no AMVP list: the predictor stays (the other list fields are never read)
   L.affJobs[row] = a;
 }
 

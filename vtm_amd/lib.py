@@ -209,11 +209,12 @@ class AffineMeJob(C.Structure):
                 ("sixParam", C.c_uint8), ("interDir", C.c_uint8), ("imv", C.c_uint8), ("bi", C.c_uint8), ("useSatd", C.c_uint8), ("useAffineType", C.c_uint8),
                 ("amvrEncOpt", C.c_uint8), ("lowDelayRounds", C.c_uint8), ("profAllowed", C.c_uint8), ("profNeedsLargeGrad", C.c_uint8), ("profIsBi", C.c_uint8),
                 ("bcwWeight", C.c_int8), ("mvPred", (C.c_int32 * 2) * 3), ("mv", (C.c_int32 * 2) * 3), ("bits", C.c_uint32), ("pad1", C.c_uint32),
-                ("motionLambda", C.c_double), ("hevcCost", C.c_uint64)]
+                ("motionLambda", C.c_double), ("hevcCost", C.c_uint64), ("amvpCand", ((C.c_int32 * 2) * 3) * 2), ("mvpIdxBits", C.c_uint32 * 2), ("numAmvpCand", C.c_uint8),
+                ("mvpIdx", C.c_uint8), ("pad2", C.c_uint8 * 6)]
 
 
 class AffineMeOut(C.Structure):
-    _fields_ = [("mv", (C.c_int32 * 2) * 3), ("bits", C.c_uint32), ("iterations", C.c_int32), ("refinements", C.c_int32), ("pad", C.c_int32), ("cost", C.c_uint64)]
+    _fields_ = [("mv", (C.c_int32 * 2) * 3), ("bits", C.c_uint32), ("iterations", C.c_int32), ("refinements", C.c_int32), ("mvpIdx", C.c_int32), ("cost", C.c_uint64)]
 
 
 class SmvdTrace(C.Structure):
