@@ -234,9 +234,10 @@ class Context:
     def is_uniform_shape(self, w, h):
         return bool(self.L.vtmhip_is_uniform_shape(w, h))
 
-    def affine_motion_estimation_batch(self, pic, d_org, d_ref, d_other, d_jobs, n, max_w, max_h, d_results):
-        """InterSearch::xAffineMotionEstimation per AffineMeJob (one workgroup per job)"""
-        self._check(self.L.vtmhip_xAffineMotionEstimation_batch_dev(self.h, C.byref(pic), d_org, d_ref, d_other, d_jobs, n, max_w, max_h, d_results))
+    def affine_motion_estimation_batch(self, pic, d_org, d_ref, d_other, d_jobs, n, max_w, max_h, d_results, bcw=False):
+        """InterSearch::xAffineMotionEstimation per AffineMeJob (one workgroup per job); bcw: the batch may hold bi jobs under a CU-level BCW weight of -2 (32-bit variant beside)"""
+        f = self.L.vtmhip_xAffineMotionEstimation_bcw_batch_dev if bcw else self.L.vtmhip_xAffineMotionEstimation_batch_dev
+        self._check(f(self.h, C.byref(pic), d_org, d_ref, d_other, d_jobs, n, max_w, max_h, d_results))
 
     def mts_select_batch(self, d_results, num_tu, cands, w, h, bit_depth, max_cand, d_test):
         """TrQuant::transformNxN( trModes ) pre-selection of every TU of a level from the sum |coef| of its candidates (runs of num_tu results per candidate)"""
