@@ -22,6 +22,7 @@
 #include <chrono>
 #include <utility>
 #include <vector>
+#include <mutex>
 
 #include "EncoderLib/EncLibCommon.h"
 #include "EncApp.h"
@@ -67,6 +68,7 @@ struct RefEncStats
   // [1] batched on the device, [2] (unused), [3] served calls refused because the reference's prediction differed from the batch's
   uint64_t intraBatches[4], intraServed, intraMismatch;
   int32_t  intraFirstMismatch[8];
+  uint64_t hookThreads;         // encoder threads that made CU-level device calls, each through its own vtmhip context (1 unless the split-parallel build runs --NumSplitThreads > 1)
 };
 }
 
@@ -92,6 +94,7 @@ struct Api
   decltype( &vtmhip_dev_free )     dfree;
   decltype( &vtmhip_h2d )          h2d;
   decltype( &vtmhip_d2h )          d2h;
+  decltype( &vtmhip_sync )         sync;
   decltype( &vtmhip_add_avg_batch_dev )            addAvg;
   decltype( &vtmhip_remove_high_freq_batch_dev )   rhf;
   decltype( &vtmhip_affine_sobel_batch_dev )       sobel;
@@ -121,9 +124,12 @@ inline bool sampled( uint64_t &ctr )
   if( g_countOnly ) return false;
   return n < g_head || ( n % g_stride ) == 0;
 }
-inline void note_error()
+// counters the CU-level hooks bump from several encoder threads (ENABLE_SPLIT_PARALLELISM build)
+#define ST_ADD( field, v ) __atomic_fetch_add( &g_st->field, ( uint64_t ) ( v ), __ATOMIC_RELAXED )
+#define ST_INC( field ) ST_ADD( field, 1 )
+inline void note_error( vtmhip_ctx *ctx = nullptr )
 {
-  if( g_st->errors++ == 0 ) { strncpy( g_st->firstError, A.last_error( g_ctx ), sizeof( g_st->firstError ) - 1 ); }
+  if( ST_INC( errors ) == 0 ) { strncpy( g_st->firstError, A.last_error( ctx ? ctx : g_ctx ), sizeof( g_st->firstError ) - 1 ); }
 }
 inline void note_mismatch( int family, int a, int b, int c, int d, long long ref, long long dev )
 {
@@ -469,10 +475,30 @@ inline uint64_t nowNs() { return ( uint64_t ) std::chrono::duration_cast<std::ch
 uint64_t g_hookCtr[2] = { 0, 0 }, g_hookStride = 0;   // VTMREF_HOOK_STRIDE: the hooks' own sampling stride (default: the tables' stride)
 inline bool hookSampled( uint64_t &ctr )
 {
-  const uint64_t n = ctr++;
+  const uint64_t n = __atomic_fetch_add( &ctr, 1, __ATOMIC_RELAXED );
   if( g_countOnly ) return false;
   return n < g_head || ( n % ( g_hookStride ? g_hookStride : g_stride ) ) == 0;
 }
+
+// ---- per-thread state of the CU-level hooks -------------------------------------------------------------------------------------------------
+// The ENABLE_SPLIT_PARALLELISM build (oracle/Makefile.ref SP=1) runs up to six EncCu / InterSearch instances in OpenMP threads (EncCu::xCompressCUParallel): every encoder
+// thread gets its own vtmhip context (own stream, own workspaces: "one context per encoder thread", include/vtmhip.h), its own page-locked slot block and device blocks, so
+// that the threads' CU-level calls are in flight on the device TOGETHER.  The single-threaded build has exactly one.
+struct HookThread
+{
+  vtmhip_ctx *ctx = nullptr;
+  void       *pisHost = nullptr;                 // PisSlots, page-locked (vtmhip_host_alloc)
+  char       *d_pis = nullptr;
+  int16_t    *d_pisOrgBi = nullptr, *d_org = nullptr, *d_other = nullptr;   // affine hook: the original block, the other list's prediction
+  void       *d_job = nullptr, *d_out = nullptr;
+  bool        ok = false, ownsCtx = false;
+  unsigned    gen = 0;
+};
+unsigned                  g_hkGen = 1;
+std::mutex                g_hkMutex;
+std::vector<HookThread *> g_hkAll;
+thread_local HookThread  *t_hk = nullptr;
+HookThread *hookThread();      // (defined behind ref_shim_pis.hpp: it sizes the slot block)
 
 struct RefPlane { const Picture *pic; int poc; int16_t *dev, *alloc; size_t samples; int stride, margin; };
 constexpr size_t PLANE_PAD = VTMHIP_PLANE_SLACK;   // samples of slack before and after an uploaded plane (include/vtmhip.h: "reference planes under d_refBase: what must be readable")
@@ -489,22 +515,27 @@ bool hookAlloc()
       && A.dalloc( g_ctx, 8 * 64 * 64 * 4, (void **) &d_hCoef ) == VTMHIP_OK && A.dalloc( g_ctx, 256, (void **) &d_hSum ) == VTMHIP_OK;
 }
 
-// the reconstructed reference picture, border included, uploaded once per (picture buffer, POC)
-const RefPlane *refPlane( const Picture *pic )
+// the reconstructed reference picture, border included, uploaded once per (picture buffer, POC).  Returns a copy under the table's lock (encoder threads share the table; reference
+// pictures only change between pictures, i.e. outside the parallel regions); ok == false: allocation / upload failed
+struct RefPlaneRef { RefPlane p; bool ok; const RefPlane *operator->() const { return &p; } explicit operator bool() const { return ok; } };
+RefPlaneRef refPlaneOf( vtmhip_ctx *ctx, const Picture *pic )
 {
-  for( const RefPlane &p : g_planes ) if( p.pic == pic && p.poc == pic->getPOC() ) return &p;
+  std::lock_guard<std::mutex> lock( g_hkMutex );
+  for( const RefPlane &p : g_planes ) if( p.pic == pic && p.poc == pic->getPOC() ) return { p, true };
   const CPelBuf y = pic->getRecoBuf( COMPONENT_Y );
   const int     m = pic->margin;
-  RefPlane      r; r.pic = pic; r.poc = pic->getPOC(); r.stride = y.stride; r.margin = m;
+  RefPlane      r; r.pic = pic; r.poc = pic->getPOC(); r.stride = y.stride; r.margin = m; r.dev = r.alloc = nullptr;
   r.samples = size_t( y.height + 2 * m ) * y.stride;
-  for( RefPlane &p : g_planes ) if( p.pic == pic ) { A.dfree( g_ctx, p.alloc ); p = g_planes.back(); g_planes.pop_back(); break; }   // the buffer now holds another picture
-  if( A.dalloc( g_ctx, ( r.samples + 2 * PLANE_PAD ) * 2, (void **) &r.alloc ) != VTMHIP_OK ) return nullptr;
+  for( RefPlane &p : g_planes ) if( p.pic == pic ) { A.dfree( ctx, p.alloc ); p = g_planes.back(); g_planes.pop_back(); break; }   // the buffer now holds another picture
+  if( A.dalloc( ctx, ( r.samples + 2 * PLANE_PAD ) * 2, (void **) &r.alloc ) != VTMHIP_OK ) return { r, false };
   r.dev = r.alloc + PLANE_PAD;
-  // rows -margin .. height + margin - 1 of the plane; the last row is copied only up to its last sample (the allocation ends there)
-  if( A.h2d( g_ctx, r.dev, y.buf - ptrdiff_t( m ) * y.stride - m, ( r.samples - size_t( y.stride - y.width - 2 * m > 0 ? y.stride - y.width - 2 * m : 0 ) ) * 2 ) != VTMHIP_OK ) return nullptr;
+  // rows -margin .. height + margin - 1 of the plane; the last row is copied only up to its last sample (the allocation ends there); complete before any other thread's stream reads it
+  if( A.h2d( ctx, r.dev, y.buf - ptrdiff_t( m ) * y.stride - m, ( r.samples - size_t( y.stride - y.width - 2 * m > 0 ? y.stride - y.width - 2 * m : 0 ) ) * 2 ) != VTMHIP_OK
+      || A.sync( ctx ) != VTMHIP_OK ) return { r, false };
   g_planes.push_back( r );
-  return &g_planes.back();
+  return { r, true };
 }
+inline RefPlaneRef refPlane( const Picture *pic ) { return refPlaneOf( t_hk ? t_hk->ctx : g_ctx, pic ); }
 
 void hookNoteMismatch( int which, int a, int b, int c, int d, long long ref, long long dev )
 {
@@ -540,7 +571,7 @@ void meHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPicLis
   }
   // ---- the job, from the arguments and the members the reference function reads (InterSearch.cpp:3299-3494) ----
   vtmhip_me_job j; memset( &j, 0, sizeof( j ) );
-  const RefPlane *rp = refPlane( refPic );
+  const RefPlaneRef rp = refPlane( refPic );
   const CPelBuf   org = origBuf.Y();
   std::vector<Pel> blk( size_t( w ) * h ), oth( size_t( w ) * h );
   for( int y = 0; y < h; y++ ) memcpy( &blk[size_t( y ) * w], org.buf + ptrdiff_t( y ) * org.stride, sizeof( Pel ) * w );
@@ -607,7 +638,7 @@ void amvpHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPicL
   if( unsupported ) g_st->amvpUnsupported++;
   if( unsupported || !hookSampled( g_amvpCtr ) ) return;
   vtmhip_me_job j; memset( &j, 0, sizeof( j ) );
-  const RefPlane *rp = refPlane( refPic );
+  const RefPlaneRef rp = refPlane( refPic );
   const CPelBuf   org = origBuf.Y();
   std::vector<Pel> blk( size_t( w ) * h );
   for( int y = 0; y < h; y++ ) memcpy( &blk[size_t( y ) * w], org.buf + ptrdiff_t( y ) * org.stride, sizeof( Pel ) * w );
@@ -655,12 +686,9 @@ SmvdCall smvdJob( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefP
   const int      w = pu.Y().width, h = pu.Y().height;
   if( slice.testWeightPred() || slice.testWeightBiPred() || picA->isWrapAroundEnabled( pu.cs->pps ) || picB->isWrapAroundEnabled( pu.cs->pps ) || picA->isRefScaled( pu.cs->pps )
       || picB->isRefScaled( pu.cs->pps ) || is->m_pcEncCfg->getMCTSEncConstraint() || w > 128 || h > 128 || slice.getSPS()->getBitDepth( CHANNEL_TYPE_LUMA ) > 12 ) return c;
-  const RefPlane *pa = refPlane( picA );
-  if( !pa ) return c;
-  const RefPlane a = *pa;                     // the table may move when the second plane is uploaded
-  const RefPlane *pb = refPlane( picB );
-  if( !pb ) return c;
-  const RefPlane b = *pb;
+  const RefPlaneRef pa = refPlane( picA ), pb = refPlane( picB );
+  if( !pa || !pb ) return c;
+  const RefPlane a = pa.p, b = pb.p;
   const Position  pos = pu.cu->lumaPos();
   vtmhip_smvd_job &j = c.j;
   j.orgOff = 0; j.orgStride = w;
@@ -771,7 +799,8 @@ void smvdCheckHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, Mv
 void affineHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPicList eRefPicList, Mv acMvPred[3], int iRefIdxPred, Mv acMv[3], uint32_t &ruiBits, Distortion &ruiCost,
                  int &mvpIdx, const AffineAMVPInfo &aamvpi, bool bBi )
 {
-  g_st->affineCalls++;
+  ST_INC( affineCalls );
+  HookThread *T = hookThread();
   const Slice   &slice  = *pu.cu->slice;
   const Picture *refPic = slice.getRefPic( eRefPicList, iRefIdxPred );
   const int      w = pu.Y().width, h = pu.Y().height;
@@ -780,7 +809,7 @@ void affineHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPi
   if( bcw && !bBi && is->m_uniMotions.isReadModeAffine( ( uint32_t ) eRefPicList, ( uint32_t ) iRefIdxPred, pu.cu->affineType ) )
   {
     // xReadBufferedAffineUniMv (:5352-5357, 7699-7716): the member only copies the default-weight pass's model out of m_uniMotions and re-prices it -- nothing to search
-    g_st->affineCalls--;
+    ST_ADD( affineCalls, -1 );
     vtmref_orig_xAffineMotionEstimation( is, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi );
     return;
   }
@@ -788,14 +817,14 @@ void affineHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPi
   const bool unsupported = is->m_pcEncCfg->getMCTSEncConstraint() || is->m_pcEncCfg->getClipForBiPredMeEnabled() || ( pickMvp && ( aamvpi.numCand < 1 || aamvpi.numCand > 2 ) )
                         || refPic->isWrapAroundEnabled( pu.cs->pps ) || refPic->isRefScaled( pu.cs->pps ) || w < 16 || h < 16 || w > 128 || h > 128
                         || slice.getSPS()->getBitDepth( CHANNEL_TYPE_LUMA ) > 10 || slice.getPPS()->getUseWP() || slice.getPPS()->getWPBiPred();
-  if( unsupported ) g_st->affineUnsupported++;
-  if( unsupported || !hookSampled( g_affineCtr ) )
+  if( unsupported || !T ) ST_INC( affineUnsupported );
+  if( unsupported || !T || !hookSampled( g_affineCtr ) )
   {
     vtmref_orig_xAffineMotionEstimation( is, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi );
     return;
   }
   vtmhip_affine_me_job j; memset( &j, 0, sizeof( j ) );
-  const RefPlane *rp = refPlane( refPic );
+  const RefPlaneRef rp = refPlane( refPic );
   const CPelBuf   org = origBuf.Y();
   std::vector<Pel> blk( size_t( w ) * h ), oth( size_t( w ) * h );
   for( int y = 0; y < h; y++ ) memcpy( &blk[size_t( y ) * w], org.buf + ptrdiff_t( y ) * org.stride, sizeof( Pel ) * w );
@@ -833,19 +862,19 @@ void affineHook( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPi
   const bool replaceOnly = g_pisReplace;      // VTMREF_REPLACE=1: the member's body does not run (its outputs on this path: acMv, ruiBits, ruiCost)
   const uint64_t tA = nowNs();
   if( !replaceOnly ) vtmref_orig_xAffineMotionEstimation( is, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi );
-  g_affineNs[0] += nowNs() - tA;
+  __atomic_fetch_add( &g_affineNs[0], nowNs() - tA, __ATOMIC_RELAXED );
   vtmhip_affine_me_out o; memset( &o, 0, sizeof( o ) );
-  const bool ok = rp && A.h2d( g_ctx, d_hOrg, blk.data(), blk.size() * 2 ) == VTMHIP_OK && ( !bBi || A.h2d( g_ctx, d_hOther, oth.data(), oth.size() * 2 ) == VTMHIP_OK )
-               && A.h2d( g_ctx, d_hJob, &j, sizeof( j ) ) == VTMHIP_OK
-               && ( j.bcwWeight ? A.affineMeBcw : A.affineMe )( g_ctx, &pic, d_hOrg, rp->dev, d_hOther, ( const vtmhip_affine_me_job * ) d_hJob, 1, w, h, ( vtmhip_affine_me_out * ) d_hOut ) == VTMHIP_OK
-               && A.d2h( g_ctx, &o, d_hOut, sizeof( o ) ) == VTMHIP_OK;
-  g_affineNs[1] += nowNs() - tA;
-  if( !ok ) { note_error(); if( replaceOnly ) vtmref_orig_xAffineMotionEstimation( is, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi ); return; }
-  g_st->affineDevice++;
+  const bool ok = rp && A.h2d( T->ctx, T->d_org, blk.data(), blk.size() * 2 ) == VTMHIP_OK && ( !bBi || A.h2d( T->ctx, T->d_other, oth.data(), oth.size() * 2 ) == VTMHIP_OK )
+               && A.h2d( T->ctx, T->d_job, &j, sizeof( j ) ) == VTMHIP_OK
+               && ( j.bcwWeight ? A.affineMeBcw : A.affineMe )( T->ctx, &pic, T->d_org, rp->dev, T->d_other, ( const vtmhip_affine_me_job * ) T->d_job, 1, w, h, ( vtmhip_affine_me_out * ) T->d_out ) == VTMHIP_OK
+               && A.d2h( T->ctx, &o, T->d_out, sizeof( o ) ) == VTMHIP_OK;
+  __atomic_fetch_add( &g_affineNs[1], nowNs() - tA, __ATOMIC_RELAXED );
+  if( !ok ) { note_error( T->ctx ); if( replaceOnly ) vtmref_orig_xAffineMotionEstimation( is, pu, origBuf, eRefPicList, acMvPred, iRefIdxPred, acMv, ruiBits, ruiCost, mvpIdx, aamvpi, bBi ); return; }
+  ST_INC( affineDevice );
   const int mvNum = j.sixParam ? 3 : 2;
   bool bad = !replaceOnly && ( o.bits != ruiBits || o.cost != ruiCost || ( pickMvp && o.mvpIdx != mvpIdx ) );
   for( int i = 0; i < mvNum && !replaceOnly; i++ ) bad |= o.mv[i][0] != acMv[i].hor || o.mv[i][1] != acMv[i].ver;
-  if( bad ) { if( g_st->affineMismatch++ == 0 && g_st->hookMismatch[0] + g_st->hookMismatch[1] == 0 ) { const int32_t v[8] = { 2, w * 1000 + h, j.sixParam * 100 + j.bi * 10 + j.imv, o.mv[0][0] - acMv[0].hor, o.mv[1][0] - acMv[1].hor, ( int32_t ) ruiCost, ( int32_t ) o.cost, 0 }; memcpy( g_st->hookFirstMismatch, v, sizeof( v ) ); } }
+  if( bad ) { if( ST_INC( affineMismatch ) == 0 && g_st->hookMismatch[0] + g_st->hookMismatch[1] == 0 ) { const int32_t v[8] = { 2, w * 1000 + h, j.sixParam * 100 + j.bi * 10 + j.imv, o.mv[0][0] - acMv[0].hor, o.mv[1][0] - acMv[1].hor, ( int32_t ) ruiCost, ( int32_t ) o.cost, 0 }; memcpy( g_st->hookFirstMismatch, v, sizeof( v ) ); } }
   for( int i = 0; i < mvNum; i++ ) { acMv[i].hor = o.mv[i][0]; acMv[i].ver = o.mv[i][1]; }
   ruiBits = o.bits; ruiCost = o.cost;
   // the member's last statements (:5768-5770): acMvPred = the AMVP candidate of mvpIdx -- which only moves when xDetermineBestMvp ran
@@ -1033,7 +1062,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
     const bool ok = sym( A.create, "vtmhip_create" ) && sym( A.destroy, "vtmhip_destroy" ) && sym( A.last_error, "vtmhip_last_error" ) && sym( A.sad, "vtmhip_xGetSAD" )
                  && sym( A.had, "vtmhip_xGetHADs" ) && sym( A.sse, "vtmhip_xGetSSE" ) && sym( A.sadmask, "vtmhip_xGetSADwMask" ) && sym( A.fhor, "vtmhip_filterHor" ) && sym( A.fver, "vtmhip_filterVer" )
                  && sym( A.fcopy, "vtmhip_filterCopy" ) && sym( A.geo, "vtmhip_weightedGeoBlk" ) && sym( A.fwd, "vtmhip_fastFwdTrans" ) && sym( A.inv, "vtmhip_fastInvTrans" )
-                 && sym( A.dalloc, "vtmhip_dev_alloc" ) && sym( A.dfree, "vtmhip_dev_free" ) && sym( A.h2d, "vtmhip_h2d" ) && sym( A.d2h, "vtmhip_d2h" )
+                 && sym( A.dalloc, "vtmhip_dev_alloc" ) && sym( A.dfree, "vtmhip_dev_free" ) && sym( A.h2d, "vtmhip_h2d" ) && sym( A.d2h, "vtmhip_d2h" ) && sym( A.sync, "vtmhip_sync" )
                  && sym( A.addAvg, "vtmhip_add_avg_batch_dev" ) && sym( A.rhf, "vtmhip_remove_high_freq_batch_dev" )
                  && sym( A.sobel, "vtmhip_affine_sobel_batch_dev" ) && sym( A.eqc, "vtmhip_affine_equal_coeff_batch_dev" )
                  && sym( A.amvp, "vtmhip_xEstimateMvPredAMVP_batch_dev" ) && sym( A.smvd, "vtmhip_smvd_batch_dev" ) && sym( A.me, "vtmhip_xMotionEstimation_batch_dev" ) && sym( A.xT, "vtmhip_xT_batch_dev" ) && sym( A.tsChain, "vtmhip_tu_ts_chain_batch_dev" )
@@ -1061,9 +1090,15 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
       if( g_ctx || g_countOnly )
       {
         installDist( std::make_integer_sequence<int, DF_TOTAL_FUNCTIONS>() );
+#if VTMREF_SPLIT_PARALLEL
+        // the split-parallel build holds one InterSearch / TrQuant / ... stack per job (EncLib.h:82-131): only the CU-level hooks (masks 128, 2048), which receive the instance
+        // they were called on, are thread-aware here
+        if( g_mask & ~( 8u | 128u | 2048u ) ) { fprintf( stderr, "ref_encode: the split-parallel build takes the CU-level hooks only (masks 8, 128, 2048)\n" ); rc = 3; }
+#else
         if( g_mask & 2 ) installIf( app->m_cEncLib.m_cInterSearch.m_if );
         if( g_mask & 4 ) installTr();
         if( ( g_mask & 16 ) && ( g_countOnly || auxAlloc() ) ) installAux( (AffineGradientSearch &) app->m_cEncLib.m_cInterSearch );   // private base: C-style cast
+#endif
         g_pisDump = nullptr; g_pisDumpedPlanes.clear(); g_pisCtr = g_pisDumpCtr = 0;
         if( ( g_mask & 4096 ) && g_ctx && !g_countOnly && sym( g_apiIntra, "vtmhip_intra_cand_cost_batch_dev" ) && intraAlloc() )
         {
@@ -1076,7 +1111,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
           if( getenv( "VTMREF_PIS_DUMP" ) ) { g_pisDump = fopen( getenv( "VTMREF_PIS_DUMP" ), "wb" ); g_pisDumpStride = getenv( "VTMREF_PIS_DUMP_STRIDE" ) ? strtoull( getenv( "VTMREF_PIS_DUMP_STRIDE" ), nullptr, 10 ) : 1;
             g_pisDumpBcwStride = getenv( "VTMREF_PIS_DUMP_BCW_STRIDE" ) ? strtoull( getenv( "VTMREF_PIS_DUMP_BCW_STRIDE" ), nullptr, 10 ) : 0; g_pisDumpBcwCtr = 0; }
           g_pisReplace = getenv( "VTMREF_REPLACE" ) && atoi( getenv( "VTMREF_REPLACE" ) ) != 0;
-          g_hookPis = g_pisDump != nullptr || g_countOnly || ( g_ctx && pisAlloc() );      // (count-only: the hook only times the member)
+          g_hookPis = g_pisDump != nullptr || g_countOnly || g_ctx != nullptr;      // (count-only: the hook only times the member; the slots are made per encoder thread: hookThread)
         }
         if( ( g_mask & ( 96 | 128 | 256 | 512 | 1024 ) ) && ( g_countOnly || ( g_ctx && hookAlloc() ) ) ) { g_hookAffine = ( g_mask & 128 ) != 0; g_affineCtr = 0;
           g_hookAmvp = ( g_mask & 512 ) != 0 && !g_countOnly; g_amvpCtr = 0;
@@ -1085,7 +1120,7 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
           g_hookStride = getenv( "VTMREF_HOOK_STRIDE" ) ? strtoull( getenv( "VTMREF_HOOK_STRIDE" ), nullptr, 10 ) : 0; }
       }
       bool eos = false;
-      while( !eos )
+      while( !eos && rc == 0 )
       {
         while( app->encodePrep( eos ) ) {}
         while( app->encode() ) {}
@@ -1098,8 +1133,10 @@ extern "C" int ref_encode( int argc, char **argv, const char *vtmhipPath, unsign
   g_hookMe = g_hookMts = g_hookAffine = g_hookLfnst = g_hookAmvp = g_hookSmvd = g_hookPis = g_hookIntra = g_intraLive = false; g_intra = IntraBatch();
   stats->affineNs[0] = g_affineNs[0]; stats->affineNs[1] = g_affineNs[1]; g_affineNs[0] = g_affineNs[1] = 0;
   if( g_pisDump ) { fclose( g_pisDump ); g_pisDump = nullptr; }
+  stats->hookThreads = ( uint64_t ) hookThreadsCount();
   for( RefPlane &p : g_planes ) A.dfree( g_ctx, p.alloc );
   g_planes.clear();
+  hookThreadsFree();
   if( g_ctx || g_countOnly ) { restoreDist(); restoreTr(); restoreAux(); }
   app->destroy();
   delete app;

@@ -80,10 +80,7 @@ struct PisReplay
   bool      hasSmvd = false, inMember = false;
   int       row( int list, int ref ) const { return ( list ? numRef[0] : 0 ) + ref; }
 };
-PisReplay   g_rp;
-PisSlots   *g_pisHost = nullptr, *g_pisRec = nullptr;
-char       *d_pis = nullptr;
-int16_t    *d_pisOrgBi = nullptr;
+thread_local PisReplay g_rp;      // (one predInterSearch call per encoder thread at a time)
 bool        g_hookPis = false;
 uint64_t    g_pisCtr = 0, g_pisDumpCtr = 0, g_pisDumpStride = 1, g_pisDumpBcwCtr = 0, g_pisDumpBcwStride = 0;   // (BcwStride != 0: the calls at a non-default BCW weight are sampled with their own stride)
 FILE       *g_pisDump = nullptr;
@@ -95,21 +92,52 @@ decltype( &vtmhip_host_alloc )                g_apiHostAlloc = nullptr;
 
 void pisNote( int what, int a, int b, int c, long long ref, long long dev )   // what: 0 final decision, 1 AMVP, 2 uni ME, 3 bi ME, 4 SMVD, 5 replay argument check
 {
-  if( g_st->pisMismatch[what]++ == 0 && g_st->pisFirstMismatch[0] == 0 )
+  if( ST_INC( pisMismatch[what] ) == 0 && g_st->pisFirstMismatch[0] == 0 )
   {
     const int32_t v[8] = { what + 1, a, b, c, ( int32_t ) ref, ( int32_t ) dev, ( int32_t ) ( ref >> 32 ), ( int32_t ) ( dev >> 32 ) };
     memcpy( g_st->pisFirstMismatch, v, sizeof( v ) );
   }
 }
 
-bool pisAlloc()
+// the calling encoder thread's context and slots (created on its first call: the first thread takes the context ref_encode made, every further thread -- the split-parallel
+// build's OpenMP workers -- its own)
+HookThread *hookThread()
 {
-  if( g_countOnly || !g_ctx ) return true;
-  void *h = nullptr;
-  if( !g_apiHostAlloc || g_apiHostAlloc( g_ctx, sizeof( PisSlots ), &h ) != VTMHIP_OK ) return false;
-  g_pisHost = ( PisSlots * ) h;
-  return A.dalloc( g_ctx, sizeof( PisSlots ), ( void ** ) &d_pis ) == VTMHIP_OK && A.dalloc( g_ctx, 128 * 128 * 2, ( void ** ) &d_pisOrgBi ) == VTMHIP_OK;
+  if( t_hk && t_hk->gen == g_hkGen ) return t_hk->ok ? t_hk : nullptr;      // (a record of an earlier ref_encode call of this process is stale)
+  if( g_countOnly || !g_ctx ) return nullptr;
+  HookThread *T = new HookThread();
+  T->gen = g_hkGen;
+  {
+    std::lock_guard<std::mutex> lock( g_hkMutex );
+    if( g_hkAll.empty() ) T->ctx = g_ctx;
+    g_hkAll.push_back( T );
+  }
+  if( !T->ctx ) { T->ownsCtx = A.create( 0, &T->ctx ) == VTMHIP_OK; if( !T->ownsCtx ) T->ctx = nullptr; }
+  t_hk = T;
+  constexpr size_t HK_BLK = 128 * 128 * 2;
+  T->ok = T->ctx && g_apiHostAlloc && g_apiHostAlloc( T->ctx, sizeof( PisSlots ), &T->pisHost ) == VTMHIP_OK
+       && A.dalloc( T->ctx, sizeof( PisSlots ), ( void ** ) &T->d_pis ) == VTMHIP_OK && A.dalloc( T->ctx, HK_BLK, ( void ** ) &T->d_pisOrgBi ) == VTMHIP_OK
+       && A.dalloc( T->ctx, HK_BLK, ( void ** ) &T->d_org ) == VTMHIP_OK && A.dalloc( T->ctx, HK_BLK, ( void ** ) &T->d_other ) == VTMHIP_OK
+       && A.dalloc( T->ctx, 4096, &T->d_job ) == VTMHIP_OK && A.dalloc( T->ctx, 4096, &T->d_out ) == VTMHIP_OK;
+  if( !T->ok ) note_error( T->ctx );
+  return T->ok ? T : nullptr;
 }
+void hookThreadsFree()
+{
+  std::lock_guard<std::mutex> lock( g_hkMutex );
+  for( HookThread *T : g_hkAll )
+  {
+    if( T->ctx )
+    {
+      for( void *d : { ( void * ) T->d_pis, ( void * ) T->d_pisOrgBi, ( void * ) T->d_org, ( void * ) T->d_other, T->d_job, T->d_out } ) if( d ) A.dfree( T->ctx, d );
+      if( T->ownsCtx ) A.destroy( T->ctx );
+    }
+    T->ok = false; T->ctx = nullptr;      // (the records stay allocated: a worker thread of the OpenMP pool may outlive this encode with its t_hk pointer)
+  }
+  g_hkAll.clear();
+  g_hkGen++;
+}
+int hookThreadsCount() { std::lock_guard<std::mutex> lock( g_hkMutex ); int n = 0; for( HookThread *T : g_hkAll ) n += T->ctx != nullptr; return n; }
 
 int pisDumpPlane( const Picture *pic )
 {
@@ -192,7 +220,7 @@ void pisServeMe( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, RefPi
   if( !g_rp.replace || !argsOk )
   {
     vtmref_orig_xMotionEstimation( is, pu, origBuf, eRefPicList, rcMvPred, iRefIdxPred, rcMv, riMVPIdx, ruiBits, ruiCost, amvpInfo, bBi );
-    if( !argsOk ) { g_st->pisReplayFallback++; return; }
+    if( !argsOk ) { ST_INC( pisReplayFallback ); return; }
     if( o.mvHor != rcMv.hor || o.mvVer != rcMv.ver || o.mvPredHor != rcMvPred.hor || o.mvPredVer != rcMvPred.ver || o.mvpIdx != riMVPIdx || o.bits != ruiBits || o.cost != ruiCost )
       pisNote( bBi ? 3 : 2, row * 10 + pu.cu->imv, rcMv.hor - o.mvHor, rcMv.ver - o.mvVer, ( long long ) ruiCost, ( long long ) o.cost );
     return;
@@ -282,7 +310,7 @@ void pisServeSmvdMe( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, M
     g_rp.inMember = true;
     vtmref_orig_xSymmetricMotionEstimation( is, pu, origBuf, predCur, predTar, eCur, cur, tar, cost, bcwIdx );
     g_rp.inMember = false;
-    if( !argsOk ) { g_st->pisReplayFallback++; g_rp.hasSmvd = false; return; }      // the rest of the block runs the reference's code
+    if( !argsOk ) { ST_INC( pisReplayFallback ); g_rp.hasSmvd = false; return; }      // the rest of the block runs the reference's code
     if( cur.mv.hor != j.trace[2].mv[0] || cur.mv.ver != j.trace[2].mv[1] || cost != j.trace[2].cost ) pisNote( 4, 2, cur.mv.hor - j.trace[2].mv[0], cur.mv.ver - j.trace[2].mv[1], ( long long ) cost, ( long long ) j.trace[2].cost );
     return;
   }
@@ -294,7 +322,7 @@ void pisServeSmvdMe( InterSearch *is, PredictionUnit &pu, PelUnitBuf &origBuf, M
 // ---- gather + device + replay --------------------------------------------------------------------------------------------------------------------
 void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
 {
-  g_st->pisCalls++;
+  ST_INC( pisCalls );
   const uint64_t t0 = nowNs();
   PredictionUnit &pu    = *cu.firstPU;
   const Slice    &slice = *cu.cs->slice;
@@ -323,8 +351,8 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
       const Picture *rp = slice.getRefPic( RefPicList( l ), r );
       unsupported = unsupported || rp->isWrapAroundEnabled( cu.cs->pps ) || rp->isRefScaled( cu.cs->pps );
     }
-  if( !checkNonAffine ) { g_st->pisSkipped++; vtmref_orig_predInterSearch( is, cu, partitioner ); g_st->pisNs[3] += nowNs() - t0; return; }
-  if( unsupported ) g_st->pisUnsupported++;
+  if( !checkNonAffine ) { ST_INC( pisSkipped ); vtmref_orig_predInterSearch( is, cu, partitioner ); ST_ADD( pisNs[3], nowNs() - t0 ); return; }
+  if( unsupported ) ST_INC( pisUnsupported );
   if( unsupported && getenv( "VTMREF_PIS_WHY" ) )
     fprintf( stderr, "PISWHY bcw%d wp%d hash%d clip%d mvdl1z%d fsm%d me%d w%d h%d nr%d,%d bd%d next%d imv%d\n", bcwIdx != BCW_DEFAULT, slice.getPPS()->getUseWP(),
              is->m_pcEncCfg->getUseHashME(), is->m_pcEncCfg->getClipForBiPredMeEnabled(), cu.cs->picHeader->getMvdL1ZeroFlag(), ( int ) fsm, ( int ) is->m_motionEstimationSearchMethod, w, h,
@@ -335,13 +363,15 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
   {
     const uint64_t t1 = nowNs();
     vtmref_orig_predInterSearch( is, cu, partitioner );
-    g_st->pisNs[3] += nowNs() - t1;
+    ST_ADD( pisNs[3], nowNs() - t1 );
     return;
   }
 
   // ---- gather ----
   static PisSlots recIn, recOut;
-  PisSlots &S = dumping ? recIn : *g_pisHost;
+  HookThread *T = dumping ? nullptr : hookThread();
+  if( !dumping && !T ) { note_error(); vtmref_orig_predInterSearch( is, cu, partitioner ); return; }
+  PisSlots &S = dumping ? recIn : *( PisSlots * ) T->pisHost;
   memset( &S, 0, offsetof( PisSlots, org ) );
   PisHeader hd; memset( &hd, 0, sizeof( hd ) );
   is->m_pcRdCost->selectMotionLambda();      // (:2357; idempotent)
@@ -366,8 +396,8 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
   g_rp.numRef[0] = numRef[0]; g_rp.numRef[1] = numRef[1]; g_rp.w = w; g_rp.h = h;
   vtmhip_pis_level_run R; memset( &R, 0, sizeof( R ) );
   vtmhip_pis_level &L = R.pis;
-  for( int l = 0; l < 2; l++ )
-    for( int r = 0; r < numRef[l]; r++ )
+  for( int l = 0; l < 2 && ok; l++ )
+    for( int r = 0; r < numRef[l] && ok; r++ )
     {
       const int      row = g_rp.row( l, r );
       const Picture *refPic = slice.getRefPic( RefPicList( l ), r );
@@ -378,7 +408,7 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
       if( dumping ) { hd.rowPlane[row] = pisDumpPlane( refPic ); hd.rowOff[row] = inPlane; j.refOff = inPlane; }
       else
       {
-        const RefPlane *rp = refPlane( refPic );
+        const RefPlaneRef rp = refPlaneOf( T->ctx, refPic );
         if( !rp ) { ok = false; break; }
         if( !devBase ) devBase = rp->dev;
         L.refPlaneOff[l][r] = ( int64_t ) ( rp->dev - devBase ) + ( int64_t ) m * ry.stride + m;      // the plane's sample (0, 0)
@@ -477,7 +507,7 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
   hd.bipredSearchRange = cfg.bipredSearchRange; hd.useHadME = cfg.useHadME; hd.fen13 = cfg.fastInterSearchMode13; hd.extendedSettings = cfg.extendedSettings;
   hd.firstSearchStop = cfg.firstSearchStop; hd.uniMvListSize = is->m_uniMvListSize;
   const uint64_t t1 = nowNs();
-  g_st->pisNs[0] += t1 - t0;
+  ST_ADD( pisNs[0], t1 - t0 );
 
   // ---- device ----
   static const bool trace = getenv( "VTMREF_PIS_TRACE" ) != nullptr;      // one line per device call BEFORE it is issued: the last line names the PU of a faulting launch
@@ -485,7 +515,7 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
                          is->m_uniMvListSize, hasSmvd, biRestricted, L.list1FromList0[0], L.list1FromList0[1], g_rp.cached[0], g_rp.cached[1], g_rp.cached[2], g_rp.cached[3] ); fflush( stderr ); }
   if( !dumping )
   {
-    char *d = d_pis;
+    char *d = T->d_pis;
     auto  dp = [&]( size_t off ) { return ( void * ) ( d + off ); };
     L.uniJobs = ( vtmhip_me_job * ) dp( offsetof( PisSlots, uniJobs ) ); L.uniOut = ( const vtmhip_me_out * ) dp( offsetof( PisSlots, uniOut ) );
     L.uniRows = ( vtmhip_pis_row * ) dp( offsetof( PisSlots, uniRows ) ); L.distBiP = ( uint64_t * ) dp( offsetof( PisSlots, distBiP ) );
@@ -503,14 +533,14 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
     R.cfgUni = cfg; R.cfgUni.uniformSquare = uniformShape; R.cfgUni.uniformBi = 1; R.cfgUni.noUniMvList = is->m_uniMvListSize == 0;
     R.cfgBi = cfg; R.cfgBi.uniformSquare = uniformShape; R.cfgBi.uniformBi = 2; R.cfgBi.noUniMvList = is->m_uniMvListSize == 0 && !pin.uniMvInsert; R.cfgBi.biPatternGiven = 1;
     vtmhip_pis_buffers B; memset( &B, 0, sizeof( B ) );
-    B.org = ( const int16_t * ) dp( offsetof( PisSlots, org ) ); B.dpb = devBase; B.orgBi = d_pisOrgBi;
-    ok = A.h2d( g_ctx, d_pis, &S, offsetof( PisSlots, org ) + size_t( w ) * h * 2 ) == VTMHIP_OK && g_apiPis( g_ctx, &R, &B ) == VTMHIP_OK
-      && A.d2h( g_ctx, &S, d_pis, offsetof( PisSlots, org ) ) == VTMHIP_OK;
-    if( !ok ) { note_error(); vtmref_orig_predInterSearch( is, cu, partitioner ); return; }
-    g_st->pisDevice++;
+    B.org = ( const int16_t * ) dp( offsetof( PisSlots, org ) ); B.dpb = devBase; B.orgBi = T->d_pisOrgBi;
+    ok = A.h2d( T->ctx, T->d_pis, &S, offsetof( PisSlots, org ) + size_t( w ) * h * 2 ) == VTMHIP_OK && g_apiPis( T->ctx, &R, &B ) == VTMHIP_OK
+      && A.d2h( T->ctx, &S, T->d_pis, offsetof( PisSlots, org ) ) == VTMHIP_OK;
+    if( !ok ) { note_error( T->ctx ); vtmref_orig_predInterSearch( is, cu, partitioner ); return; }
+    ST_INC( pisDevice );
   }
   const uint64_t t2 = nowNs();
-  g_st->pisNs[1] += t2 - t1;
+  ST_ADD( pisNs[1], t2 - t1 );
 
   // ---- the reference's own member over the tables ----
   if( dumping ) { recOut = recIn; g_rp.s = &recOut; g_rp.record = true; }
@@ -520,7 +550,7 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
   vtmref_orig_predInterSearch( is, cu, partitioner );
   g_rp.active = false;
   const uint64_t t3 = nowNs();
-  g_st->pisNs[2] += t3 - t2;
+  ST_ADD( pisNs[2], t3 - t2 );
 
   // ---- what the member left behind ----
   PisFinal F; memset( &F, 0, sizeof( F ) );
@@ -538,10 +568,10 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
     hd.bytes = ( uint32_t ) ( sizeof( hd ) + 2 * offsetof( PisSlots, org ) + size_t( w ) * h * 2 + sizeof( F ) );
     fwrite( &hd, sizeof( hd ), 1, g_pisDump ); fwrite( &recIn, offsetof( PisSlots, org ), 1, g_pisDump ); fwrite( &recOut, offsetof( PisSlots, org ), 1, g_pisDump );
     fwrite( recIn.org, 2, size_t( w ) * h, g_pisDump ); fwrite( &F, sizeof( F ), 1, g_pisDump );
-    g_st->pisDevice++;
+    ST_INC( pisDevice );
     return;
   }
-  if( !F.ran ) { g_st->pisSkipped++; return; }
+  if( !F.ran ) { ST_INC( pisSkipped ); return; }
   // the device's own decision record against the member's result
   const vtmhip_pis_pu &P = S.pus[0];
   const bool bi = P.interDir == 3;
@@ -563,5 +593,5 @@ void pisHook( InterSearch *is, CodingUnit &cu, Partitioner &partitioner )
     }
   }
   if( bad ) pisNote( 0, w * 1000 + h, imv * 10 + P.interDir, F.interDir * 10 + cu.affine, ( long long ) F.hevcCost, ( long long ) devCost );
-  g_st->pisNs[0] += nowNs() - t3;
+  ST_ADD( pisNs[0], nowNs() - t3 );
 }

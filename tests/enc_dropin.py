@@ -11,6 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libvtmref.so")
+REF_SP_SO = os.path.join(ROOT, "oracle", "_ref", "libvtmref_sp.so")      # the same sources with ENABLE_SPLIT_PARALLELISM (oracle/Makefile.ref SP=1): takes --NumSplitThreads
 HIP_SO = os.path.join(ROOT, "vtm_amd", "libvtmhip.so")
 CFG = os.path.join(ROOT, "tests", "data", "enc_ra_gop4.cfg")
 
@@ -25,7 +26,7 @@ class Stats(C.Structure):
                 ("smvdCalls", C.c_uint64 * 3), ("smvdDevice", C.c_uint64 * 3), ("smvdMismatch", C.c_uint64 * 3), ("smvdUnsupported", C.c_uint64),
                 ("pisCalls", C.c_uint64), ("pisDevice", C.c_uint64), ("pisUnsupported", C.c_uint64), ("pisSkipped", C.c_uint64), ("pisReplayFallback", C.c_uint64),
                 ("pisMismatch", C.c_uint64 * 6), ("pisFirstMismatch", C.c_int32 * 8), ("pisNs", C.c_uint64 * 4), ("affineNs", C.c_uint64 * 2),
-                ("intraBatches", C.c_uint64 * 4), ("intraServed", C.c_uint64), ("intraMismatch", C.c_uint64), ("intraFirstMismatch", C.c_int32 * 8)]
+                ("intraBatches", C.c_uint64 * 4), ("intraServed", C.c_uint64), ("intraMismatch", C.c_uint64), ("intraFirstMismatch", C.c_int32 * 8), ("hookThreads", C.c_uint64)]
 
 
 def write_clip(path, w, h, frames, seed=77):
@@ -39,7 +40,7 @@ def write_clip(path, w, h, frames, seed=77):
 
 def _child(argv_json):
     a = json.loads(argv_json)
-    lib = C.CDLL(REF_SO)
+    lib = C.CDLL(a.get("ref_so") or REF_SO)
     lib.ref_encode.restype = C.c_int
     lib.ref_encode.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_uint, C.c_uint64, C.c_uint64, C.POINTER(Stats)]
     args = [b"EncoderApp"] + [s.encode() for s in a["args"]]
@@ -56,18 +57,19 @@ def _child(argv_json):
            "pis": {"calls": st.pisCalls, "device": st.pisDevice, "unsupported": st.pisUnsupported, "skipped": st.pisSkipped, "replayFallback": st.pisReplayFallback,
                    "mismatch": list(st.pisMismatch), "firstMismatch": list(st.pisFirstMismatch), "seconds": [v / 1e9 for v in st.pisNs]},
            "affineSeconds": [v / 1e9 for v in st.affineNs],
+           "hookThreads": st.hookThreads,
            "intra": {"batches": list(st.intraBatches), "served": st.intraServed, "mismatch": st.intraMismatch, "firstMismatch": list(st.intraFirstMismatch)}}
     sys.stdout.flush()
     os.write(2, ("\nDROPIN_RESULT " + json.dumps(out) + "\n").encode())
 
 
-def encode(yuv, w, h, frames, qp, out_prefix, hip=False, mask=23, stride=1, head=0, extra=(), timeout=1500, env=None, cfg=None):
+def encode(yuv, w, h, frames, qp, out_prefix, hip=False, mask=23, stride=1, head=0, extra=(), timeout=1500, env=None, cfg=None, ref_so=None):
     """Returns (stats dict, md5 of the bitstream, md5 of the reconstruction).  mask bit 2048: InterSearch::predInterSearch as one device call per CU
     (oracle/ref_shim_pis.hpp; env VTMREF_REPLACE=1: replace mode, VTMREF_PIS_DUMP=<file>: record mode without a device)."""
     bits, rec = out_prefix + ".bin", out_prefix + "_rec.yuv"
     args = ["-c", cfg or CFG, "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-f", str(frames), "-q", str(qp), "-b", bits, "-o", rec,
             "--SEIDecodedPictureHash=1", "--OutputBitDepth=10"] + list(extra)
-    req = json.dumps({"args": args, "hip": HIP_SO if hip else "", "mask": mask, "stride": stride, "head": head})
+    req = json.dumps({"args": args, "hip": HIP_SO if hip else "", "mask": mask, "stride": stride, "head": head, "ref_so": ref_so})
     p = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import enc_dropin; enc_dropin._child(sys.argv[1])"
                         % os.path.dirname(os.path.abspath(__file__)), req], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout,
                        env=dict(os.environ, **(env or {})))

@@ -103,6 +103,20 @@ int vtmhip_internal_mc_amvp_launch( vtmhip_ctx *ctx, const vtmhip_pic_params *pi
 #define VTMHIP_AFFINE_LAUNCH_WIDE 8      // `models` of vtmhip_internal_affine_me_launch: also launch the 32-bit variants (jobs with a BCW weight of -2)
 int vtmhip_internal_affine_me_launch( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, const int16_t *d_otherPredBase,
                                       const vtmhip_affine_me_job *d_jobs, int n, int maxWidth, int maxHeight, vtmhip_affine_me_out *d_results, int models );   // affine.hip
+struct MeFuse;      // mest_glue.hpp
+int vtmhip_internal_tz_search( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_tz_job *d_jobs, int n,
+                               vtmhip_me_result *d_results, const MeFuse *fuse );   // me.hip: vtmhip_tz_search_batch_dev, optionally fused with the row bookkeeping around it
+struct FullFuse;    // mest_glue.hpp
+int vtmhip_internal_full_search( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_full_job *d_jobs, int n,
+                                 int width, int height, vtmhip_me_result *d_results, const FullFuse *fuse );   // me.hip: the exhaustive searches, optionally fused
+int vtmhip_internal_frac_search( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_frac_job *d_jobs, int n, int maxWidth, int maxHeight,
+                                 int uniformSquare, vtmhip_frac_result *d_results, const MeFuse *fuse );   // interp.hip: vtmhip_frac_search_batch_dev, optionally fused
+int vtmhip_internal_amvp_sads( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_me_job *d_jobs, int n,
+                               int maxWidth, int maxHeight, unsigned long long **d_dout );   // pis.hip
+int vtmhip_internal_mest_with_amvp( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg *cfg, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                    vtmhip_me_job *d_jobs, int n, int maxWidth, int maxHeight, vtmhip_me_out *d_results, const unsigned long long *d_amvpDout,
+                                    unsigned long long *d_distBiP, int addIdxBits );   // mest.hip
+int vtmhip_internal_mest_fusable( const vtmhip_me_cfg *cfg );
 int vtmhip_internal_workspace( vtmhip_ctx *ctx, size_t bytes, void **out, int slot = 0 ); // the arena (slot) of ctx->stream, grown to `bytes` (device only)
 
 // ---- device helpers -------------------------------------------------------------------------------------------

@@ -4,6 +4,8 @@
 #include "ctx.hpp"
 
 #include <vector>
+#include <cstring>
+#include <cstdlib>
 
 namespace
 {
@@ -30,6 +32,20 @@ int run_uni( vtmhip_ctx *ctx, const vtmhip_pis_level_run &L, const vtmhip_pis_bu
   const int n = L.pis.numPU, rows = ( L.pis.numRef[0] + L.pis.numRef[1] ) * n;
   int st = L.pis.candsGiven ? VTMHIP_OK : vtmhip_pis_stage( ctx, &L.pis, 0 );   // candsGiven: the rows carry the caller's real AMVP lists
   if( st ) return st;
+  // every row group searched (no FastMEForGenBLowDelay copy, no given row) and every row a fractional-refinement uni search: xEstimateMvPredAMVP's selection rides in the prologue
+  // of the fused integer search (mest.hip), so the level's uni chain is: template SADs -> TZ (-> raster -> resume) -> fractional search + final records -> stage 1
+  bool allSearched = L.pis.givenRows == 0;
+  for( int r = 0; r < L.pis.numRef[1] && allSearched; r++ )
+    allSearched = !( L.pis.fastMEForGenBLowDelay && L.pis.list1FromList0[r] > 0 && L.pis.list1FromList0[r] <= L.pis.numRef[0] );
+  if( allSearched && vtmhip_internal_mest_fusable( &L.cfgUni ) )
+  {
+    unsigned long long *dout = nullptr;
+    st = vtmhip_internal_amvp_sads( ctx, &L.pic, b.org, b.dpb, L.pis.uniJobs, rows, L.width, L.height, &dout );
+    if( st ) return st;
+    st = vtmhip_internal_mest_with_amvp( ctx, &L.pic, &L.cfgUni, b.org, b.dpb, L.pis.uniJobs, rows, L.width, L.height, L.uniOut, dout, ( unsigned long long * ) L.pis.distBiP, 1 );
+    if( st ) return st;
+    return vtmhip_pis_stage( ctx, &L.pis, 1 );
+  }
   st = vtmhip_xEstimateMvPredAMVP_batch_dev( ctx, &L.pic, b.org, b.dpb, L.pis.uniJobs, rows, L.width, L.height, 1, 1, L.pis.distBiP );   // (the index bits of the chosen predictor join the row's bits)
   if( st ) return st;
   // the searched rows: every (list, refIdx) group but the list-1 pictures that are list-0 pictures too (FastMEForGenBLowDelay copies those in stage 1) and the groups whose rows
@@ -165,7 +181,19 @@ extern "C" int vtmhip_pis_run_picture( vtmhip_ctx *ctx, const vtmhip_pis_level_r
   // behind that event, so that the host never holds back the dependent chain while it enqueues a level's ~20 side launches.  Measured neutral on one GPU (whole picture and a
   // 1/8 share alike): the chain's idle time between its 61 launches (profiles/r03_trace_sim8_timeline.txt: busy 1.76 ms of a 2.62 ms span) is dispatch latency of dependent
   // kernels that share the CUs with the side streams' kernels, not host enqueue time.
+  // VTMHIP_ISSUE_ORDER=interleave (round 4 experiment): level i's remaining stages are enqueued right after level i + 1's uni chain instead of after
+  // ALL uni chains, so that a side chain's first launch is in its queue as soon as the event it waits for can fire
+  static const bool interleave = getenv( "VTMHIP_ISSUE_ORDER" ) && !strcmp( getenv( "VTMHIP_ISSUE_ORDER" ), "interleave" );
   std::vector<hipEvent_t> done( ( size_t ) numLevels, nullptr );
+  auto rest = [&]( int i ) -> int
+  {
+    hipStream_t side = ( hipStream_t ) sideStreams[i % numSide];
+    VTMHIP_HIP( ctx, hipStreamWaitEvent( side, done[i], 0 ) );
+    ctx->stream = side;
+    const int r = run_rest( ctx, levels[i], *buf );
+    ctx->stream = main;
+    return r;
+  };
   ctx->stream = main;
   for( int i = 0; i < numLevels && !st; i++ )
   {
@@ -174,14 +202,10 @@ extern "C" int vtmhip_pis_run_picture( vtmhip_ctx *ctx, const vtmhip_pis_level_r
     done[i] = pool.get();
     VTMHIP_REQUIRE( ctx, done[i], "hipEventCreate" );
     VTMHIP_HIP( ctx, hipEventRecord( done[i], main ) );
+    if( interleave && i > 0 ) st = rest( i - 1 );
   }
-  for( int i = 0; i < numLevels && !st; i++ )
-  {
-    hipStream_t side = ( hipStream_t ) sideStreams[i % numSide];
-    VTMHIP_HIP( ctx, hipStreamWaitEvent( side, done[i], 0 ) );
-    ctx->stream = side;
-    st = run_rest( ctx, levels[i], *buf );
-  }
+  if( interleave ) { if( !st && numLevels > 0 ) st = rest( numLevels - 1 ); }
+  else for( int i = 0; i < numLevels && !st; i++ ) st = rest( i );
   ctx->stream = main;
   for( int s = 0; s < numSide && s < numLevels; s++ )   // join
   {

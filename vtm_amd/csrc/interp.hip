@@ -14,6 +14,7 @@
 // through the same FIR with taps {0,0,0,64,0,0,0,0}, which is arithmetically identical to filterCopy.
 // One wave per PU: window -> LDS once, 3 H passes per round (one per horizontal phase), 9 V passes + SATDs.
 #include "ctx.hpp"
+#include "mest_glue.hpp"
 #include "had.hpp"
 
 #include <type_traits>
@@ -298,11 +299,19 @@ __device__ int refine_round( const vtmhip_frac_job &j, const int16_t *org, const
 
 __global__ __launch_bounds__( 64 ) void frac_search_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
                                                            const vtmhip_frac_job *__restrict__ jobs, vtmhip_frac_result *__restrict__ results,
-                                                           int maxW, int maxH )
+                                                           int maxW, int maxH, FracFuse fu )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];
   const int             lane = threadIdx.x;
-  const vtmhip_frac_job j    = jobs[blockIdx.x];
+  vtmhip_frac_job       j;
+  if( fu.me )      // FUSED (mest_glue.hpp): the job from the xMotionEstimation row and its integer result (what mest_mid_kernel would have written)
+  {
+    const vtmhip_me_job   &mj = fu.me[blockIdx.x];
+    const vtmhip_me_result r  = fu.ires[blockIdx.x];
+    if( mj.imv != 0 && mj.imv != 3 ) return;      // an AMVR row of a mixed batch: integer refinement, not this kernel's (the stand-alone chain handles mixed batches)
+    mg::make_frac_job( fu.useHadME, fu.bitDepth, mj, r.mvX, r.mvY, fuse_pat_off( fu, mj ), fuse_pat_stride( fu, mj ), j );
+  }
+  else j = jobs[blockIdx.x];
   const int             w = j.width, h = j.height;
   if( w == 0 ) return;   // empty slot of a multi-stage call
   const int             winLd = w + 8;
@@ -338,7 +347,14 @@ __global__ __launch_bounds__( 64 ) void frac_search_kernel( const int16_t *__res
     res.qterY = c_refineQ[bi][1];
   }
   res.cost = cost;
-  if( lane == 0 ) results[blockIdx.x] = res;
+  if( lane == 0 && results ) results[blockIdx.x] = res;
+  if( lane == 0 && fu.me )      // the row's final record: the rate re-weighting mest_final_kernel would have done
+  {
+    const vtmhip_me_result r = fu.ires[blockIdx.x];
+    vtmhip_me_out          o;
+    mg::make_out_frac( fu.me[blockIdx.x], r.mvX, r.mvY, r.dist, res, o );
+    fu.out[blockIdx.x] = o;
+  }
 }
 
 
@@ -387,7 +403,7 @@ struct FracSq
 template<int W, int H>
 __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) void frac_search_sq_kernel( const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
                                                                             const vtmhip_frac_job *__restrict__ jobs, int numJobs,
-                                                                            vtmhip_frac_result *__restrict__ results )
+                                                                            vtmhip_frac_result *__restrict__ results, FracFuse fu )
 {
   using C = FracSq<W, H>;
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t lds[];
@@ -397,6 +413,21 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
   const int tid = threadIdx.x;
   const int job0 = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x ) * C::JPW;   // neighbouring PUs share most of their windows: keep them on one XCD's L2
   const int nj = min( C::JPW, numJobs - job0 );
+  // FUSED (fu.me != nullptr, mest_glue.hpp): the workgroup's job records from the xMotionEstimation rows and their integer results, into LDS (what mest_mid_kernel wrote to a table)
+  // (the records sit in LDS either way -- copied from the job table when not fused -- so that every later read is an LDS read at a 32-bit address)
+  __shared__ vtmhip_frac_job sFJ[C::JPW];
+  const vtmhip_frac_job     *jb = sFJ;
+  if( tid < nj )
+  {
+    if( fu.me )
+    {
+      const vtmhip_me_job   &mj = fu.me[job0 + tid];
+      const vtmhip_me_result r  = fu.ires[job0 + tid];
+      mg::make_frac_job( fu.useHadME, fu.bitDepth, mj, r.mvX, r.mvY, fuse_pat_off( fu, mj ), fuse_pat_stride( fu, mj ), sFJ[tid] );
+    }
+    else sFJ[tid] = jobs[job0 + tid];
+  }
+  __syncthreads();
 
   // ---- windows: rows -4 .. H+3, columns -4 .. W+3 around the integer vector; 8 samples (16 bytes) per thread and step ----------------------
   {
@@ -404,7 +435,7 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
     for( int i = tid; i < nj * ( H + 8 ) * CH; i += C::BLOCK )
     {
       const int               jl = i / ( ( H + 8 ) * CH ), rem = i - jl * ( H + 8 ) * CH, r = rem / CH, c = ( rem - r * CH ) * 8;
-      const vtmhip_frac_job &j  = jobs[job0 + jl];
+      const vtmhip_frac_job &j  = jb[jl];
       const int16_t         *ref = refBase + j.refOff + ( long ) ( j.intY + r - 4 ) * j.refStride + ( j.intX + c - 4 );
       const Pel8u            v   = *reinterpret_cast<const Pel8u *>( ref );
       *reinterpret_cast<int4 *>( lds + jl * C::PERJOB + r * C::WLD + c ) = make_int4( ( int ) v.v[0], ( int ) v.v[1], ( int ) v.v[2], ( int ) v.v[3] );
@@ -412,13 +443,13 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
   }
   for( int i = tid; i < C::JPW * 2; i += C::BLOCK ) sCentre[i >> 1][i & 1] = 0;
   // the packed 16-bit evaluation (phase V) needs every PU of the workgroup to ask for the Hadamard cost at bitDepth <= 10
-  const bool pkAll = !__syncthreads_or( tid < nj && !( jobs[job0 + tid].useHad && jobs[job0 + tid].bitDepth <= 10 && !jobs[job0 + tid].wideOrg ) );   // wideOrg: a BCW-weighted target
+  const bool pkAll = !__syncthreads_or( tid < nj && !( jb[tid].useHad && jb[tid].bitDepth <= 10 && !jb[tid].wideOrg ) );   // wideOrg: a BCW-weighted target
 
 #pragma unroll 1
   for( int round = 0; round < 2; round++ )
   {
     const int step = round == 0 ? 2 : 1;
-    if( round == 1 && jobs[job0].imvShift != 0 ) break;   // IMV_HPEL: half-sample refinement only (uniform per batch, checked on the host side)
+    if( round == 1 && jb[0].imvShift != 0 ) break;   // IMV_HPEL: half-sample refinement only (uniform per batch, checked on the host side)
     // round 2: candidate 0 is the half-sample winner itself -- the block round 1 already measured -- so only 8 candidates are formed
     for( int i = tid; i < C::JPW * 16; i += C::BLOCK ) sCost[i] = ( round == 1 && ( i & 15 ) == 0 ) ? sKeep[i >> 4] : 0u;
 #pragma unroll 1
@@ -442,7 +473,7 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
         if( jl >= nj ) continue;
         const int p = C::SEQ ? seqPl : round == 0 ? pp : 2 * pp;                                  // dx + 1
         const int ps = C::SEQ ? 0 : plane_slot( round, sCentre[jl][0], p - 1 );                    // the slot the plane is stored in
-        const vtmhip_frac_job &j = jobs[job0 + jl];
+        const vtmhip_frac_job &j = jb[jl];
         const int qx = sCentre[jl][0] + ( p - 1 ) * step, ix = qx >> 2, fx = qx & 3;
         const IfParams pH = if_params( 1, 0, j.bitDepth, 0, ( 1 << j.bitDepth ) - 1, 0 );
         if( fx == 0 )
@@ -528,7 +559,7 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
       const int ci = it / ( C::JPW * C::TILES ), rem = it - ci * C::JPW * C::TILES, jl = rem / C::TILES, tile = rem - jl * C::TILES;
       if( jl >= nj ) continue;
       const int cand = C::SEQ ? ( seqPl == 1 ? ci + seqSkip : 3 + 2 * ci + ( seqPl >> 1 ) ) : ( int ) ( ( ORDER >> ( 4 * ( ci + round ) ) ) & 15 );
-      const vtmhip_frac_job &j = jobs[job0 + jl];
+      const vtmhip_frac_job &j = jb[jl];
       const int8_t( *tab )[2] = round == 0 ? c_refineH : c_refineQ;
       const int dx = tab[cand][0], dy = tab[cand][1];
       const int qy = sCentre[jl][1] + dy * step, iy = qy >> 2, fy = qy & 3;
@@ -704,7 +735,7 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
     // ---- select: first strict minimum of distortion + MV rate in table order ------------------------------------------------
     if( tid < nj )
     {
-      const vtmhip_frac_job &j = jobs[job0 + tid];
+      const vtmhip_frac_job &j = jb[tid];
       const int8_t( *tab )[2] = round == 0 ? c_refineH : c_refineQ;
       const int costScale = round == 0 ? 1 : 0;
       const int bx = round == 0 ? ( j.intX << 1 ) : ( ( ( j.intX << 1 ) + ( sCentre[tid][0] >> 1 ) ) << 1 );
@@ -727,6 +758,16 @@ __global__ __launch_bounds__( ( FracSq<W, H>::BLOCK ), ( FracSq<W, H>::MINW ) ) 
       else
       {
         res->qterX = tab[bi][0]; res->qterY = tab[bi][1]; res->cost = best;
+      }
+      if( fu.me && ( round == 1 || j.imvShift != 0 ) )      // the last round: the row's final record (the rate re-weighting mest_final_kernel would have done)
+      {
+        vtmhip_frac_result f;
+        f.halfX = ( int16_t ) ( round == 0 ? tab[bi][0] : sCentre[tid][0] >> 1 ); f.halfY = ( int16_t ) ( round == 0 ? tab[bi][1] : sCentre[tid][1] >> 1 );
+        f.qterX = ( int16_t ) ( round == 0 ? 0 : tab[bi][0] ); f.qterY = ( int16_t ) ( round == 0 ? 0 : tab[bi][1] ); f.cost = best;
+        const vtmhip_me_result r = fu.ires[job0 + tid];
+        vtmhip_me_out          o;
+        mg::make_out_frac( fu.me[job0 + tid], r.mvX, r.mvY, r.dist, f, o );
+        fu.out[job0 + tid] = o;
       }
     }
     __syncthreads();
@@ -773,14 +814,14 @@ int if_single( vtmhip_ctx *ctx, int vertical, int taps, int isFirst, int isLast,
 }
 
 template<int W, int H>
-int launch_frac_sq( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_frac_job *d_jobs, int n, vtmhip_frac_result *d_results )
+int launch_frac_sq( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_frac_job *d_jobs, int n, vtmhip_frac_result *d_results, const FracFuse &fu )
 {
   using C = FracSq<W, H>;
   if( C::LDS > 64 * 1024 )
     VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( frac_search_sq_kernel<W, H> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) C::LDS ) );
   VTMHIP_TIME_KERNEL( ctx, "frac_search_sq_kernel" );
   hipLaunchKernelGGL( ( frac_search_sq_kernel<W, H> ), dim3( ( n + C::JPW - 1 ) / C::JPW ), dim3( C::BLOCK ), C::LDS, ctx->stream, d_orgBase, d_refBase, d_jobs, n,
-                      d_results );
+                      d_results, fu );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }
@@ -822,15 +863,26 @@ int vtmhip_if_batch_dev( vtmhip_ctx *ctx, const int16_t *d_srcBase, int16_t *d_d
 int vtmhip_frac_search_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_frac_job *d_jobs, int n,
                                   int maxWidth, int maxHeight, int uniformSquare, vtmhip_frac_result *d_results )
 {
+  return vtmhip_internal_frac_search( ctx, d_orgBase, d_refBase, d_jobs, n, maxWidth, maxHeight, uniformSquare, d_results, nullptr );
+}
+
+}   // extern "C"
+
+// fuse != nullptr: the fractional searches of the xMotionEstimation rows fuse->me after their integer stage fuse->ires; the rows' final records go to fuse->out (d_jobs unused)
+int vtmhip_internal_frac_search( vtmhip_ctx *ctx, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_frac_job *d_jobs, int n, int maxWidth, int maxHeight,
+                                 int uniformSquare, vtmhip_frac_result *d_results, const MeFuse *fuse )
+{
   VTMHIP_CHECK_CTX( ctx );
   VTMHIP_REQUIRE( ctx, n >= 0, "n" );
   if( n == 0 ) return VTMHIP_OK;
-  VTMHIP_REQUIRE( ctx, d_orgBase && d_refBase && d_jobs && d_results, "null pointer" );
+  VTMHIP_REQUIRE( ctx, d_orgBase && d_refBase && ( d_jobs || fuse ) && d_results, "null pointer" );
+  FracFuse fu; memset( &fu, 0, sizeof( fu ) );
+  if( fuse ) { fu.me = fuse->me; fu.ires = fuse->ires; fu.out = fuse->out; fu.useHadME = fuse->cfg.useHadME; fu.bitDepth = fuse->bitDepth; fu.patIsOther = fuse->patIsOther; }
   VTMHIP_REQUIRE( ctx, maxWidth >= 4 && maxWidth <= 128 && maxHeight >= 4 && maxHeight <= 128, "maxWidth / maxHeight" );
   if( uniformSquare )
   {
     // caller's promise: every job is exactly maxWidth x maxHeight and all jobs share imvShift -> tiled fast path (squares and the split shapes)
-#define VTMHIP_FRAC_CASE( WW, HH ) case ( WW ) * 256 + ( HH ): return launch_frac_sq<WW, HH>( ctx, d_orgBase, d_refBase, d_jobs, n, d_results );
+#define VTMHIP_FRAC_CASE( WW, HH ) case ( WW ) * 256 + ( HH ): return launch_frac_sq<WW, HH>( ctx, d_orgBase, d_refBase, d_jobs, n, d_results, fu );
     switch( maxWidth * 256 + maxHeight )
     {
       VTMHIP_FRAC_CASE( 8, 8 ) VTMHIP_FRAC_CASE( 16, 16 ) VTMHIP_FRAC_CASE( 32, 32 ) VTMHIP_FRAC_CASE( 64, 64 ) VTMHIP_FRAC_CASE( 128, 128 )
@@ -844,9 +896,7 @@ int vtmhip_frac_search_batch_dev( vtmhip_ctx *ctx, const int16_t *d_orgBase, con
   if( lds > 64 * 1024 )
     VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( frac_search_kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) );
   VTMHIP_TIME_KERNEL( ctx, "frac_search_kernel" );
-  hipLaunchKernelGGL( frac_search_kernel, dim3( n ), dim3( 64 ), lds, ctx->stream, d_orgBase, d_refBase, d_jobs, d_results, maxWidth, maxHeight );
+  hipLaunchKernelGGL( frac_search_kernel, dim3( n ), dim3( 64 ), lds, ctx->stream, d_orgBase, d_refBase, d_jobs, d_results, maxWidth, maxHeight, fu );
   VTMHIP_LAUNCHED( ctx );
   return VTMHIP_OK;
 }
-
-}   // extern "C"

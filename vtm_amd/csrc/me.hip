@@ -12,6 +12,7 @@
 // The sequential dependence that remains is round -> round, which is why a job owns a wave and a launch carries
 // thousands of jobs (all PUs x reference pictures of a picture).
 #include "ctx.hpp"
+#include "mest_glue.hpp"
 
 #include <cstdlib>
 
@@ -925,12 +926,12 @@ __global__ __launch_bounds__( 256 ) void tz_raster_cols_kernel( vtmhip_pic_param
 
 // WPJ = 1: 256 threads = 4 independent jobs.  WPJ > 1: 64 * WPJ threads = 1 job.
 template<int WPJ>
-__global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) __attribute__( ( amdgpu_waves_per_eu( WPJ == 2 || WPJ == 4 ? 4 : 1 ) ) )      // two / four waves per search sat at 129 / 131 VGPRs: one register over the four-waves-per-SIMD budget
+__global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) __attribute__( ( amdgpu_waves_per_eu( WPJ == 2 || WPJ == 4 || WPJ == 8 ? 4 : 1 ) ) )      // two / four / eight waves per search sit at 129 .. 131 VGPRs: a register or two over the four-waves-per-SIMD budget
 void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase,
                                                                                 const int16_t *__restrict__ refBase,
                                                                                 const vtmhip_tz_job *__restrict__ jobs, int numJobs,
                                                                                 vtmhip_me_result *__restrict__ results, int mode, TzSaved *__restrict__ saved,
-                                                                                int *__restrict__ list, int totCap )
+                                                                                int *__restrict__ list, int totCap, MeFuse fu )
 {
   // mode 0: the whole search.  Split launches: mode 1 stops at the raster decision of jobs tz_raster_cols_kernel can take (state -> saved[], job
   // index -> list[]; every other job runs to the end here); mode 2 resumes the listed jobs after the scan.
@@ -948,8 +949,67 @@ void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBas
     jobIdx = uni( list[1 + jobIdx] );
   }
   if( jobIdx >= numJobs ) return;   // WPJ == 1: whole waves leave; WPJ > 1: never true (grid = numJobs)
-  const vtmhip_tz_job *jp  = jobs + jobIdx;
-  if( uni( ( int ) jp->width ) == 0 ) return;   // empty slot of a multi-stage call (job handled by another stage); uniform per wave / per block
+  // The job's scalar fields live in registers (wave-uniform: the scalar unit keeps them), its start-candidate list behind a pointer.
+  // FUSED (fu.me != nullptr, mest_glue.hpp): both are derived from the xMotionEstimation row itself -- xEstimateMvPredAMVP's selection when the template SADs are given, then
+  // what mest_prepare_kernel would have written to a job table; the distinct m_uniMvList entries go to LDS (no job table, no launch in between)
+  __shared__ int sExtra[JOBS_PER_BLOCK][15][2];
+  vtmhip_tz_job  tj;      // (extraStart / numExtraStart of this copy are never touched: `extra` / `numExtra`)
+  const int( *extra )[2];
+  int       numExtra;
+  if( fu.me )
+  {
+    vtmhip_me_job &mj = fu.me[jobIdx];
+    int mvpIdx = mj.mvpIdx, predH = mj.mvPredHor, predV = mj.mvPredVer;
+    unsigned bits = mj.bits;
+    if( fu.amvpDout )      // xEstimateMvPredAMVP (:3088-3128): the first candidate with the smallest template cost; every lane derives it, the job's first lane stores it
+    {
+      const unsigned long long c0 = fu.amvpDout[2 * ( long ) jobIdx] + mg::rate( mj.motionLambda, mj.mvpIdxBits[0] );
+      const unsigned long long c1 = mj.numAmvpCand > 1 ? fu.amvpDout[2 * ( long ) jobIdx + 1] + mg::rate( mj.motionLambda, mj.mvpIdxBits[1] ) : ~0ull;
+      mvpIdx = c0 > c1 ? 1 : 0;
+      predH = mvpIdx ? mj.amvpCand[1][0] : mj.amvpCand[0][0]; predV = mvpIdx ? mj.amvpCand[1][1] : mj.amvpCand[0][1];
+      if( fu.addIdxBits ) bits += mvpIdx ? mj.mvpIdxBits[1] : mj.mvpIdxBits[0];
+      if( lane == 0 && ( WPJ == 1 || wv == 0 ) )
+      {
+        mj.mvPredHor = predH; mj.mvPredVer = predV; mj.mvpIdx = ( uint8_t ) mvpIdx; mj.bits = bits;
+        if( fu.distBiP ) fu.distBiP[jobIdx] = c0 > c1 ? c1 : c0;
+      }
+    }
+    mg::make_tz_job_scalars( fu.cfg, mj, fuse_pat_off( fu, mj ), fuse_pat_stride( fu, mj ), predH, predV, tj );
+    // the distinct m_uniMvList entries, newest first: lane i owns entry i, compares it with every earlier one and the survivors close up
+    const int m = mg::num_extra( mj );
+    int( *se )[2] = sExtra[WPJ == 1 ? wv : 0];
+    unsigned long long keep = 0;
+    if( m > 0 )      // (uniform)
+    {
+      int eh = 0, ev = 0;
+      if( lane < m ) { eh = mj.extraStart[lane][0]; ev = mj.extraStart[lane][1]; }
+      bool first = lane < m;
+#pragma unroll
+      for( int k = 0; k < 14; k++ )
+      {
+        const int oh = __shfl( eh, k, 64 ), ov = __shfl( ev, k, 64 );
+        if( k < lane && oh == eh && ov == ev ) first = false;
+      }
+      keep = __ballot( first );
+      if( first && ( WPJ == 1 || wv == 0 ) ) { const int pos = __popcll( keep & ( ( 1ull << lane ) - 1ull ) ); se[pos][0] = eh; se[pos][1] = ev; }
+      job_sync<WPJ>();
+    }
+    numExtra = __popcll( keep );
+    extra = se;
+  }
+  else
+  {
+    const vtmhip_tz_job *jp = jobs + jobIdx;
+    if( uni( ( int ) jp->width ) == 0 ) return;   // empty slot of a multi-stage call (job handled by another stage); uniform per wave / per block
+    tj.orgOff = jp->orgOff; tj.refOff = jp->refOff; tj.orgStride = jp->orgStride; tj.refStride = jp->refStride; tj.puX = jp->puX; tj.puY = jp->puY;
+    tj.width = jp->width; tj.height = jp->height; tj.subShift = jp->subShift; tj.imvShift = jp->imvShift; tj.signedSamples = jp->signedSamples;
+    tj.predHor = jp->predHor; tj.predVer = jp->predVer; tj.motionLambda = jp->motionLambda; tj.mvHor = jp->mvHor; tj.mvVer = jp->mvVer; tj.searchRange = jp->searchRange;
+    tj.extendedSettings = jp->extendedSettings; tj.fastSettings = jp->fastSettings; tj.firstSearchStop = jp->firstSearchStop; tj.hasIntMv2Nx2NPred = jp->hasIntMv2Nx2NPred;
+    tj.intMv2Nx2NPredHor = jp->intMv2Nx2NPredHor; tj.intMv2Nx2NPredVer = jp->intMv2Nx2NPredVer;
+    numExtra = jp->numExtraStart;
+    extra = jp->extraStart;
+  }
+  const vtmhip_tz_job *jp = &tj;      // (scalar fields only below)
   int4                *pts = sPts[WPJ == 1 ? wv : 0];
   Coop                 co;
   co.lane = lane; co.wave = WPJ == 1 ? 0 : wv; co.wpj = WPJ; co.leader = ( lane == 0 && co.wave == 0 );
@@ -1028,20 +1088,20 @@ void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBas
     int n = 0;
     PUSH( mx, my, 0, 0 );
     if( !fast && ( mx != 0 || my != 0 ) ) PUSH( 0, 0, 0, 0 );
-    const int ne = min( jp->numExtraStart, 14 );
+    const int ne = min( numExtra, 14 );
     for( int i = 0; i < ne; i++ )
     {
-      int ex = jp->extraStart[i][0], ey = jp->extraStart[i][1];
+      int ex = extra[i][0], ey = extra[i][1];
       clip_mv( j, ex, ey );
       PUSH( prec_down( ex, 4 ), prec_down( ey, 4 ), 0, 0 );
     }
     tz_round<WPJ>( j, s, pts, n, co, true );
-    if( jp->numExtraStart > 14 )   // 15th candidate: the list holds 16 points
+    if( numExtra > 14 )   // 15th candidate: the list holds 16 points
     {
       int m = 0;
       {
         int n = 0;
-        int ex = jp->extraStart[14][0], ey = jp->extraStart[14][1];
+        int ex = extra[14][0], ey = extra[14][1];
         clip_mv( j, ex, ey );
         PUSH( prec_down( ex, 4 ), prec_down( ey, 4 ), 0, 0 );
         m = n;
@@ -1074,10 +1134,10 @@ void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBas
     }
     // m_uniMvList start candidates (:3725-3762): one parallel round, same first-strict-minimum semantics
     int       n  = 0;
-    const int ne = min( jp->numExtraStart, 15 );
+    const int ne = min( numExtra, 15 );
     for( int i = 0; i < ne; i++ )
     {
-      int ex = jp->extraStart[i][0], ey = jp->extraStart[i][1];
+      int ex = extra[i][0], ey = extra[i][1];
       clip_mv( j, ex, ey );
       PUSH( prec_down( ex, 4 ), prec_down( ey, 4 ), 0, 0 );
     }
@@ -1128,6 +1188,15 @@ void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBas
         sv.bestRound = s.bestRound; sv.nEval = s.nEval; sv.rasterCost = ~0ull; sv.rasterIdx = 0; sv.pad = 0;
         saved[jobIdx] = sv;
         list[1 + atomicAdd( &list[0], 1 )] = jobIdx;
+      }
+      if( fu.me && co.leader )      // the raster kernel and the resume launch read the record from the job table: store the scalar fields (neither reads the start candidates)
+      {
+        vtmhip_tz_job *g = fu.tzSpill + jobIdx;
+        g->orgOff = tj.orgOff; g->refOff = tj.refOff; g->orgStride = tj.orgStride; g->refStride = tj.refStride; g->puX = tj.puX; g->puY = tj.puY;
+        g->width = tj.width; g->height = tj.height; g->subShift = tj.subShift; g->imvShift = tj.imvShift; g->signedSamples = tj.signedSamples;
+        g->predHor = tj.predHor; g->predVer = tj.predVer; g->motionLambda = tj.motionLambda; g->mvHor = tj.mvHor; g->mvVer = tj.mvVer; g->searchRange = tj.searchRange;
+        g->extendedSettings = tj.extendedSettings; g->fastSettings = tj.fastSettings; g->firstSearchStop = tj.firstSearchStop; g->hasIntMv2Nx2NPred = tj.hasIntMv2Nx2NPred;
+        g->intMv2Nx2NPredHor = tj.intMv2Nx2NPredHor; g->intMv2Nx2NPredVer = tj.intMv2Nx2NPredVer; g->numExtraStart = 0;
       }
       return;   // wave-uniform (WPJ == 1) / block-uniform: the search continues in the mode-2 launch
     }
@@ -1186,17 +1255,28 @@ template<int WPJ>
 __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void full_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase,
                                                                                   const int16_t *__restrict__ refBase,
                                                                                   const vtmhip_full_job *__restrict__ jobs, int numJobs,
-                                                                                  vtmhip_me_result *__restrict__ results )
+                                                                                  vtmhip_me_result *__restrict__ results, FullFuse fu )
 {
+  constexpr int JOBS_PER_BLOCK = WPJ == 1 ? 4 : 1;
   __shared__ unsigned long long sRedCost[WPJ];
   __shared__ unsigned           sRedIdx[WPJ];
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sOrgLds[WPJ >= 4 ? ORG_LDS_CAP : WPJ == 2 ? ORG_LDS_CAP2 : 8];
+  __shared__ int4               sPts[JOBS_PER_BLOCK][16];   // fused: the start candidates (integer positions) ...
+  __shared__ int                sStart[JOBS_PER_BLOCK][16][2];   // ... and the vectors they came from (the winner's UNCLIPPED vector is the search centre)
   const int lane = threadIdx.x & 63, wv = uni( ( int ) ( threadIdx.x >> 6 ) );
   const int blk    = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x );
   const int jobIdx = WPJ == 1 ? blk * 4 + wv : blk;
   if( jobIdx >= numJobs ) return;
-  const vtmhip_full_job *jp = jobs + jobIdx;
-  if( uni( ( int ) jp->width ) == 0 ) return;   // empty slot (see tz_search_kernel)
+  // the job's fields in registers (wave-uniform).  FUSED (fu.me != nullptr, mest_glue.hpp): from the bi row itself -- what mest_prepare_kernel / mest_bi_start_kernel wrote to a table
+  vtmhip_full_job fj;
+  if( fu.me ) mg::make_full_job( fu, fu.me[jobIdx], fu.me[jobIdx].mvHor, fu.me[jobIdx].mvVer, fj );
+  else
+  {
+    const vtmhip_full_job *gp = jobs + jobIdx;
+    if( uni( ( int ) gp->width ) == 0 ) return;   // empty slot (see tz_search_kernel)
+    fj = *gp;
+  }
+  const vtmhip_full_job *jp = &fj;
   Coop                   co;
   co.lane = lane; co.wave = WPJ == 1 ? 0 : wv; co.wpj = WPJ; co.leader = ( lane == 0 && co.wave == 0 ); co.redCost = sRedCost; co.redIdx = sRedIdx;
   MeJob j;
@@ -1241,7 +1321,40 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void full_search_kerne
   }
   stage_org<WPJ, ( WPJ >= 4 ? ORG_LDS_CAP : ORG_LDS_CAP2 )>( j, sOrgLds, ( int ) threadIdx.x );
 
-  const Range sr = search_range( j, jp->centerHor, jp->centerVer, jp->searchRange );
+  int centerHor = jp->centerHor, centerVer = jp->centerVer;
+  if( fu.me && !fu.noStart )
+  {
+    // the best start (:3377-3420): rcMv, then the distinct m_uniMvList entries, newest first -- clipped, at integer precision, SAD + vector rate, first strict minimum.
+    // Lane i owns list entry i - 1 (lane 0: rcMv); the survivors close up in LDS and one candidate round picks the lexicographic (cost, index) minimum
+    const vtmhip_me_job &mj = fu.me[jobIdx];
+    const int m = mg::num_extra( mj );
+    int4 *pts = sPts[WPJ == 1 ? wv : 0];
+    int( *st )[2] = sStart[WPJ == 1 ? wv : 0];
+    int eh = mj.mvHor, ev = mj.mvVer;
+    if( lane >= 1 && lane <= m ) { eh = mj.extraStart[lane - 1][0]; ev = mj.extraStart[lane - 1][1]; }
+    bool first = lane <= m;
+#pragma unroll
+    for( int k = 1; k < 15; k++ )      // (entry k - 1 against the later entries; rcMv itself is always a candidate and never removes one)
+    {
+      const int oh = __shfl( eh, k, 64 ), ov = __shfl( ev, k, 64 );
+      if( k < lane && oh == eh && ov == ev ) first = false;
+    }
+    const unsigned long long keep = __ballot( first );
+    if( first && ( WPJ == 1 || wv == 0 ) )
+    {
+      const int pos = __popcll( keep & ( ( 1ull << lane ) - 1ull ) );
+      int ch = eh, cv = ev;
+      clip_mv( j, ch, cv );
+      pts[pos] = make_int4( mg::prec_down( ch, 4 ), mg::prec_down( cv, 4 ), 0, 0 );
+      st[pos][0] = eh; st[pos][1] = ev;
+    }
+    job_sync<WPJ>();
+    unsigned long long c0;
+    unsigned           i0;
+    eval_candidates<false, WPJ>( j, pts, __popcll( keep ), 0, 0, 1, 1, co, c0, i0 );
+    centerHor = st[i0 & 15][0]; centerVer = st[i0 & 15][1];
+  }
+  const Range sr = search_range( j, centerHor, centerVer, jp->searchRange );
   const int   nx = sr.right >= sr.left ? sr.right - sr.left + 1 : 0, ny = sr.bottom >= sr.top ? sr.bottom - sr.top + 1 : 0;
   unsigned long long cost;
   unsigned           idx;
@@ -1275,9 +1388,10 @@ template<int W, int H> struct FullSq
 
 template<int W, int H>
 __global__ __launch_bounds__( ( FullSq<W, H>::THREADS ) ) void full_search_sq_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
-                                                               const vtmhip_full_job *__restrict__ jobs, int numJobs, vtmhip_me_result *__restrict__ results )
+                                                               const vtmhip_full_job *__restrict__ jobs, int numJobs, vtmhip_me_result *__restrict__ results, FullFuse fu )
 {
   constexpr int JPB = FullSq<W, H>::JPB, THREADS = FullSq<W, H>::THREADS, WLD = W + 8, WLR = H + 8, WD = WLD / 2 + 1, MAXC = 81;
+  __shared__ vtmhip_full_job    sJob[JPB];              // the workgroup's job records: copied from the table, or (FUSED, fu.me != nullptr) built from the bi rows with rcMv as the centre
   __shared__ unsigned           sWin[JPB][WLR][WD];     // reference window, two samples per dword, one spare dword per row
   __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned sOrg[JPB][H][W / 2];
   __shared__ int                sRange[JPB][5];          // left, top, nx, ny, floor((2^32 - 1) / nx)
@@ -1297,7 +1411,9 @@ __global__ __launch_bounds__( ( FullSq<W, H>::THREADS ) ) void full_search_sq_ke
   };
   if( tid < nj )
   {
-    const vtmhip_full_job &q = jobs[job0 + tid];
+    if( fu.me ) mg::make_full_job( fu, fu.me[job0 + tid], fu.me[job0 + tid].mvHor, fu.me[job0 + tid].mvVer, sJob[tid] );
+    else sJob[tid] = jobs[job0 + tid];
+    const vtmhip_full_job &q = sJob[tid];
     view( q );
     const Range sr = search_range( j, q.centerHor, q.centerVer, q.searchRange );
     sRange[tid][0] = sr.left; sRange[tid][1] = sr.top;
@@ -1317,7 +1433,7 @@ __global__ __launch_bounds__( ( FullSq<W, H>::THREADS ) ) void full_search_sq_ke
     unsigned  v = 0;
     if( r < ny + H - 1 && c2 < nx + W - 1 )
     {
-      const vtmhip_full_job &q = jobs[job0 + jl];
+      const vtmhip_full_job &q = sJob[jl];
       const int16_t *p = refBase + q.refOff + ( long ) ( sRange[jl][1] + r ) * q.refStride + ( sRange[jl][0] + c2 );
       const unsigned lo = ( unsigned short ) p[0], hi = c2 + 1 < nx + W - 1 ? ( unsigned short ) p[1] : 0u;
       v = ( lo | ( hi << 16 ) ) ^ ( q.signedSamples ? 0x80008000u : 0u );
@@ -1328,7 +1444,7 @@ __global__ __launch_bounds__( ( FullSq<W, H>::THREADS ) ) void full_search_sq_ke
   for( int i = tid; i < nj * H * ( W / 2 ); i += THREADS )
   {
     const int jl = i / ( H * ( W / 2 ) ), rem = i - jl * ( H * ( W / 2 ) ), r = rem / ( W / 2 ), c2 = ( rem - r * ( W / 2 ) ) * 2;
-    const vtmhip_full_job &q = jobs[job0 + jl];
+    const vtmhip_full_job &q = sJob[jl];
     const int16_t *p = orgBase + q.orgOff + ( long ) r * q.orgStride + c2;
     sOrg[jl][r][c2 >> 1] = ( ( unsigned ) ( unsigned short ) p[0] | ( ( unsigned ) ( unsigned short ) p[1] << 16 ) ) ^ ( q.signedSamples ? 0x80008000u : 0u );
   }
@@ -1348,7 +1464,7 @@ __global__ __launch_bounds__( ( FullSq<W, H>::THREADS ) ) void full_search_sq_ke
       const int nx = sRange[jl][2], ny = sRange[jl][3];
       if( k < nx * ny )
       {
-        const vtmhip_full_job &q = jobs[job0 + jl];
+        const vtmhip_full_job &q = sJob[jl];
         view( q );
         int cy = ( int ) __umulhi( ( unsigned ) k, ( unsigned ) sRange[jl][4] );   // k / nx: the multiply-high is the quotient or one less (k < 81)
         cy += ( cy + 1 ) * nx <= k ? 1 : 0;
@@ -1387,7 +1503,7 @@ __global__ __launch_bounds__( ( FullSq<W, H>::THREADS ) ) void full_search_sq_ke
   __syncthreads();
   if( tid < nj )
   {
-    const vtmhip_full_job &q = jobs[job0 + tid];
+    const vtmhip_full_job &q = sJob[tid];
     view( q );
     const int nx = sRange[tid][2], ny = sRange[tid][3];
     vtmhip_me_result r;
@@ -1409,10 +1525,20 @@ __global__ __launch_bounds__( ( FullSq<W, H>::THREADS ) ) void full_search_sq_ke
 extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
                                            const vtmhip_tz_job *d_jobs, int n, vtmhip_me_result *d_results )
 {
+  return vtmhip_internal_tz_search( ctx, pic, d_orgBase, d_refBase, d_jobs, n, d_results, nullptr );
+}
+
+// fuse != nullptr: the searches of the xMotionEstimation rows fuse->me (job records built in the kernel's prologue, mest_glue.hpp); d_jobs is then the table the searches that
+// go to the raster kernel store their record in (fuse->tzSpill == d_jobs)
+int vtmhip_internal_tz_search( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_tz_job *d_jobs, int n,
+                               vtmhip_me_result *d_results, const MeFuse *fuse )
+{
   VTMHIP_CHECK_CTX( ctx );
   VTMHIP_REQUIRE( ctx, pic && n >= 0, "pic / n" );
   if( n == 0 ) return VTMHIP_OK;
   VTMHIP_REQUIRE( ctx, d_orgBase && d_refBase && d_jobs && d_results, "null pointer" );
+  MeFuse fuNone; memset( &fuNone, 0, sizeof( fuNone ) );
+  const MeFuse fuFirst = fuse ? *fuse : fuNone;      // the first launch (mode 0 / 1) builds the records; the resume launch (mode 2) reads the stored ones
   VTMHIP_REQUIRE( ctx, pic->picW > 0 && pic->picH > 0 && pic->ctuSize > 0, "picture parameters" );
   // wavesPerJob: tuning hint for the whole batch (0 / 1: a wave per search -- small blocks, short candidate lists;
   // 2..16: that many waves split every candidate list -- large blocks, raster scans)
@@ -1452,7 +1578,8 @@ extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_par
     if( totBytes ) VTMHIP_HIP( ctx, hipMemsetAsync( d_tot, 0, totBytes, ctx->stream ) );
   }
 #define VTMHIP_TZ_LAUNCH( W, GRID, MODE ) \
-  hipLaunchKernelGGL( tz_search_kernel<W>, dim3( GRID ), dim3( W == 1 ? 256 : 64 * W ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, d_results, MODE, d_saved, d_list, totCap )
+  hipLaunchKernelGGL( tz_search_kernel<W>, dim3( GRID ), dim3( W == 1 ? 256 : 64 * W ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, d_results, MODE, d_saved, d_list, totCap, \
+                      ( MODE ) == 2 ? fuNone : fuFirst )
 #define VTMHIP_TZ_SWITCH( MODE )                                    \
   switch( wpj )                                                     \
   {                                                                 \
@@ -1484,18 +1611,37 @@ extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_par
 }
 
 
+static int full_search_uniform( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_full_job *d_jobs, int n,
+                                int width, int height, vtmhip_me_result *d_results, const FullFuse &fu );
+
 extern "C" int vtmhip_full_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
                                              const vtmhip_full_job *d_jobs, int n, vtmhip_me_result *d_results )
+{
+  return vtmhip_internal_full_search( ctx, pic, d_orgBase, d_refBase, d_jobs, n, 0, 0, d_results, nullptr );
+}
+
+// fuse != nullptr: the exhaustive searches of the bi rows fuse->me (job records -- and, unless fuse->noStart, the choice of the start vector -- in the kernel's prologue; d_jobs
+// unused).  width / height != 0: the caller's promise of a uniform batch (the lane-per-candidate kernel when the shape has one, the batch has no start candidates to weigh and the
+// range is +-4)
+int vtmhip_internal_full_search( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_full_job *d_jobs, int n,
+                                 int width, int height, vtmhip_me_result *d_results, const FullFuse *fuse )
 {
   VTMHIP_CHECK_CTX( ctx );
   VTMHIP_REQUIRE( ctx, pic && n >= 0, "pic / n" );
   if( n == 0 ) return VTMHIP_OK;
-  VTMHIP_REQUIRE( ctx, d_orgBase && d_refBase && d_jobs && d_results, "null pointer" );
+  VTMHIP_REQUIRE( ctx, d_orgBase && d_refBase && ( d_jobs || fuse ) && d_results, "null pointer" );
+  FullFuse fu; memset( &fu, 0, sizeof( fu ) );
+  if( fuse ) fu = *fuse;
+  if( width && height && ( !fuse || ( fuse->noStart && fuse->bipredSearchRange <= 4 ) ) )
+  {
+    int st = full_search_uniform( ctx, pic, d_orgBase, d_refBase, d_jobs, n, width, height, d_results, fu );
+    if( st != VTMHIP_E_INVALID + 1000 ) return st;      // (no lane-per-candidate kernel for this shape: the cooperative kernel below)
+  }
   VTMHIP_REQUIRE( ctx, pic->picW > 0 && pic->picH > 0 && pic->ctuSize > 0, "picture parameters" );
   const int wpj = pic->wavesPerJob;
   VTMHIP_REQUIRE( ctx, wpj == 0 || wpj == 1 || wpj == 2 || wpj == 4 || wpj == 8 || wpj == 16, "wavesPerJob must be 0, 1, 2, 4, 8 or 16" );
 #define VTMHIP_FS_LAUNCH( W, GRID ) \
-  hipLaunchKernelGGL( full_search_kernel<W>, dim3( GRID ), dim3( W == 1 ? 256 : 64 * W ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, d_results )
+  hipLaunchKernelGGL( full_search_kernel<W>, dim3( GRID ), dim3( W == 1 ? 256 : 64 * W ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, d_results, fu )
   { VTMHIP_TIME_KERNEL( ctx, "full_search_kernel" );
   switch( wpj )
   {
@@ -1515,15 +1661,17 @@ extern "C" int vtmhip_full_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_p
 extern "C" int vtmhip_full_search_uniform_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
                                                      const vtmhip_full_job *d_jobs, int n, int width, int height, vtmhip_me_result *d_results )
 {
-  VTMHIP_CHECK_CTX( ctx );
-  VTMHIP_REQUIRE( ctx, pic && n >= 0, "pic / n" );
-  if( n == 0 ) return VTMHIP_OK;
-  VTMHIP_REQUIRE( ctx, d_orgBase && d_refBase && d_jobs && d_results, "null pointer" );
+  return vtmhip_internal_full_search( ctx, pic, d_orgBase, d_refBase, d_jobs, n, width, height, d_results, nullptr );
+}
+
+static int full_search_uniform( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_full_job *d_jobs, int n,
+                                int width, int height, vtmhip_me_result *d_results, const FullFuse &fu )
+{
   VTMHIP_REQUIRE( ctx, pic->picW > 0 && pic->picH > 0 && pic->ctuSize > 0, "picture parameters" );
 #define VTMHIP_FSQ_LAUNCH( WW, HH )                                                                                                                                     \
   case ( WW ) * 256 + ( HH ):                                                                                                                                           \
     hipLaunchKernelGGL( ( full_search_sq_kernel<WW, HH> ), dim3( ( n + FullSq<WW, HH>::JPB - 1 ) / FullSq<WW, HH>::JPB ), dim3( FullSq<WW, HH>::THREADS ), 0, ctx->stream, \
-                        *pic, d_orgBase, d_refBase, d_jobs, n, d_results );                                                                                             \
+                        *pic, d_orgBase, d_refBase, d_jobs, n, d_results, fu );                                                                                         \
     break;
   {
     VTMHIP_TIME_KERNEL( ctx, "full_search_sq_kernel" );
@@ -1532,7 +1680,7 @@ extern "C" int vtmhip_full_search_uniform_batch_dev( vtmhip_ctx *ctx, const vtmh
       VTMHIP_FSQ_LAUNCH( 8, 8 ) VTMHIP_FSQ_LAUNCH( 16, 16 ) VTMHIP_FSQ_LAUNCH( 32, 32 ) VTMHIP_FSQ_LAUNCH( 64, 64 )
       VTMHIP_FSQ_LAUNCH( 16, 8 ) VTMHIP_FSQ_LAUNCH( 8, 16 ) VTMHIP_FSQ_LAUNCH( 32, 8 ) VTMHIP_FSQ_LAUNCH( 8, 32 ) VTMHIP_FSQ_LAUNCH( 32, 16 ) VTMHIP_FSQ_LAUNCH( 16, 32 )
       VTMHIP_FSQ_LAUNCH( 64, 16 ) VTMHIP_FSQ_LAUNCH( 16, 64 ) VTMHIP_FSQ_LAUNCH( 64, 32 ) VTMHIP_FSQ_LAUNCH( 32, 64 )
-    default: return vtmhip_full_search_batch_dev( ctx, pic, d_orgBase, d_refBase, d_jobs, n, d_results );   // other shapes: the cooperative kernel
+    default: return VTMHIP_E_INVALID + 1000;   // other shapes: the caller takes the cooperative kernel
     }
   }
 #undef VTMHIP_FSQ_LAUNCH

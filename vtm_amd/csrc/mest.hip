@@ -11,6 +11,7 @@
 //   frac / [dist]
 //   final     rate re-weighting (:3478-3484) or the AMVR selection loop (:4208-4262), fp64 exactly as the reference
 #include "ctx.hpp"
+#include "mest_glue.hpp"
 #include "bucket.hpp"
 
 namespace
@@ -18,48 +19,7 @@ namespace
 
 constexpr int REFINE_SLOTS = 18;   // 9 positions x 2 AMVP candidates
 
-__device__ __forceinline__ int floor_log2_u( unsigned v ) { return 31 - __clz( ( int ) v ); }
-// RdCost::xGetExpGolombNumberOfBits (RdCost.h:301-313)
-__device__ __forceinline__ unsigned eg_bits( int v )
-{
-  // xGetExpGolombNumberOfBits (RdCost.h:301-313): its `while( t > 128 ) { len += 14; t >>= 7; }` only splits floorLog2( t ) = 7 + floorLog2( t >> 7 ),
-  // so the length is 1 + 2 * floorLog2( t ) for every t >= 1 -- no loop
-  const unsigned t = ( v <= 0 ) ? ( ( unsigned ) ( -v ) << 1 ) + 1 : ( unsigned ) ( v << 1 );
-  return 1u + ( ( unsigned ) ( 31 - __clz( ( int ) t ) ) << 1 );
-}
-__device__ __forceinline__ unsigned mv_bits( int x, int y, int predHor, int predVer, int costScale, unsigned imvShift )
-{
-  return eg_bits( ( ( x << costScale ) - predHor ) >> imvShift ) + eg_bits( ( ( y << costScale ) - predVer ) >> imvShift );
-}
-__device__ __forceinline__ unsigned long long rate( double lambda, unsigned bits ) { return ( unsigned long long ) ( lambda * bits ); }   // RdCost::getCost
-__device__ __forceinline__ int prec_down( int v, int rs ) { const int o = 1 << ( rs - 1 ); return v >= 0 ? ( v + o - 1 ) >> rs : ( v + o ) >> rs; }   // Mv::changePrecision
-__device__ __forceinline__ int amvr_shift( int imv ) { return imv == 0 ? 2 : imv == 1 ? 4 : imv == 2 ? 6 : 3; }   // Mv::m_amvrPrecision vs INTERNAL
-__device__ __forceinline__ void clip_mv( const vtmhip_pic_params &pic, const vtmhip_me_job &j, int &hor, int &ver )   // clipMvInPic
-{
-  const int horMax = ( pic.picW + 8 - j.puX - 1 ) << 4, horMin = ( -pic.ctuSize - 8 - j.puX + 1 ) << 4;
-  const int verMax = ( pic.picH + 8 - j.puY - 1 ) << 4, verMin = ( -pic.ctuSize - 8 - j.puY + 1 ) << 4;
-  hor = min( horMax, max( horMin, hor ) );
-  ver = min( verMax, max( verMin, ver ) );
-}
-__device__ __forceinline__ int sub_shift( const vtmhip_me_cfg &cfg, int w, int h ) { return cfg.fastInterSearchMode13 && h > 8 && w <= 64 ? 1 : 0; }   // RdCost.cpp:289-323, mode 2
-__device__ __forceinline__ unsigned imv_shift( int imv ) { return imv == 3 ? 1u : ( unsigned ) imv << 1; }
-// CU-level BCW weight of the searched list of a bi job (0: the default pair); the default weight (4 of 8) is normalised to 0
-__device__ __forceinline__ int bcw_weight( const vtmhip_me_job &j ) { const int w = j.bi ? VTMHIP_MEJ_BCW_WEIGHT( j.flags ) : 0; return w == 4 ? 0 : w; }
-
-// m_uniMvList entries, newest first, each kept only if no earlier entry equals it (:3391-3403, :3728-3746)
-__device__ __forceinline__ int dedup( const vtmhip_me_job &j, int ex[15][2] )
-{
-  int n = 0;
-  const int m = min( 15, max( 0, j.numExtraStart ) );
-  for( int i = 0; i < m; i++ )
-  {
-    int k = 0;
-    for( ; k < i; k++ ) if( j.extraStart[k][0] == j.extraStart[i][0] && j.extraStart[k][1] == j.extraStart[i][1] ) break;
-    if( k < i ) continue;
-    ex[n][0] = j.extraStart[i][0]; ex[n][1] = j.extraStart[i][1]; n++;
-  }
-  return n;
-}
+using namespace mg;      // the per-row arithmetic (mest_glue.hpp): shared with the fused prologues / epilogues of the search kernels
 
 struct Work
 {
@@ -134,38 +94,30 @@ __global__ __launch_bounds__( 256 ) void mest_prepare_kernel( vtmhip_pic_params 
   const long     slot = pat_off( wk, j, i );
   const int      sst  = pat_stride( wk, j );
   const int      ss   = sub_shift( cfg, j.width, j.height );
-  const unsigned is   = imv_shift( j.imv );
-  int ex[15][2];
-  const int nex = dedup( j, ex );
-  vtmhip_tz_job   &t = wk.tz[i];
-  vtmhip_full_job &f = wk.full[i];
   vtmhip_dist_job *d = wk.dist + ( long ) i * REFINE_SLOTS;
   if( wk.needDist ) for( int k = 0; k < REFINE_SLOTS; k++ ) d[k].width = 0;
   if( !j.bi )
   {
-    if( wk.hasFull ) f.width = 0;
-    t.orgOff = slot; t.refOff = j.refOff; t.orgStride = sst; t.refStride = j.refStride;
-    t.puX = j.puX; t.puY = j.puY; t.width = j.width; t.height = j.height; t.subShift = ( int16_t ) ss; t.imvShift = ( uint8_t ) is; t.signedSamples = 0;
-    t.predHor = prec_down( j.mvPredHor, 2 ); t.predVer = prec_down( j.mvPredVer, 2 ); t.motionLambda = j.motionLambda;
-    const bool cached = ( j.flags & VTMHIP_MEJ_CACHED_INT_MV ) != 0;   // block-vector cache hit (:3360-3368): rcMv = the cached vector, xTZSearch with bFastSettings (:3434-3441)
-    t.mvHor = cached ? j.mvHor : j.mvPredHor; t.mvVer = cached ? j.mvVer : j.mvPredVer;   // else rcMv = rcMvPred (:3446)
-    t.searchRange = j.searchRange;
-    t.extendedSettings = cfg.extendedSettings; t.fastSettings = cached; t.firstSearchStop = cfg.firstSearchStop; t.hasIntMv2Nx2NPred = 0;
-    t.intMv2Nx2NPredHor = t.intMv2Nx2NPredVer = 0;
-    t.numExtraStart = nex;
-    for( int k = 0; k < nex; k++ ) { t.extraStart[k][0] = ex[k][0]; t.extraStart[k][1] = ex[k][1]; }
+    if( wk.hasFull ) wk.full[i].width = 0;
+    make_tz_job( cfg, j, slot, sst, wk.tz[i] );
   }
   else
   {
-    if( wk.hasTz ) t.width = 0;
-    f.width = 0;   // filled by mest_bi_start_kernel
+    if( wk.hasTz ) wk.tz[i].width = 0;
+    wk.full[i].width = 0;   // filled by mest_bi_start_kernel
     if( wk.needDist )
-      for( int k = 0; k <= nex; k++ )
+    {
+      // start candidates (:3377-3420): rcMv, then the distinct m_uniMvList entries, newest first -- slot k of the row's distortion jobs
+      int k = 0;
+      for( int e = -1; e < num_extra( j ); e++ )
       {
-        int th = k == 0 ? j.mvHor : ex[k - 1][0], tv = k == 0 ? j.mvVer : ex[k - 1][1];
+        if( e >= 0 && !extra_is_first( j, e ) ) continue;
+        int th = e < 0 ? j.mvHor : j.extraStart[e][0], tv = e < 0 ? j.mvVer : j.extraStart[e][1];
         clip_mv( pic, j, th, tv );
         sad_job( d[k], slot, sst, j, prec_down( th, 4 ), prec_down( tv, 4 ), ss, VTMHIP_DIST_SAD );
+        k++;
       }
+    }
   }
 }
 
@@ -177,23 +129,23 @@ __global__ __launch_bounds__( 256 ) void mest_bi_start_kernel( vtmhip_pic_params
   if( !j.bi ) return;
   const unsigned is = imv_shift( j.imv );
   const int      ph = prec_down( j.mvPredHor, 2 ), pv = prec_down( j.mvPredVer, 2 );
-  int ex[15][2];
-  const int nex = dedup( j, ex );
   unsigned long long best = 0;
   int                bestH = j.mvHor, bestV = j.mvVer;
-  for( int k = 0; k <= ( wk.needDist ? nex : -1 ); k++ )   // needDist == 0: the caller promised empty m_uniMvList lists -- rcMv is the only candidate and wins whatever its cost
+  if( wk.needDist )      // needDist == 0: the caller promised empty m_uniMvList lists -- rcMv is the only candidate and wins whatever its cost
   {
-    int th = k == 0 ? j.mvHor : ex[k - 1][0], tv = k == 0 ? j.mvVer : ex[k - 1][1];
-    clip_mv( pic, j, th, tv );
-    th = prec_down( th, 4 ); tv = prec_down( tv, 4 );
-    const unsigned long long c = wk.dout[( long ) i * REFINE_SLOTS + k] + rate( j.motionLambda, mv_bits( th, tv, ph, pv, 2, is ) );
-    if( k == 0 || c < best ) { best = c; if( k ) { bestH = ex[k - 1][0]; bestV = ex[k - 1][1]; } }
+    int k = 0;
+    for( int e = -1; e < num_extra( j ); e++ )
+    {
+      if( e >= 0 && !extra_is_first( j, e ) ) continue;
+      int th = e < 0 ? j.mvHor : j.extraStart[e][0], tv = e < 0 ? j.mvVer : j.extraStart[e][1];
+      clip_mv( pic, j, th, tv );
+      th = prec_down( th, 4 ); tv = prec_down( tv, 4 );
+      const unsigned long long c = wk.dout[( long ) i * REFINE_SLOTS + k] + rate( j.motionLambda, mv_bits( th, tv, ph, pv, 2, is ) );
+      if( k == 0 || c < best ) { best = c; if( e >= 0 ) { bestH = j.extraStart[e][0]; bestV = j.extraStart[e][1]; } }
+      k++;
+    }
   }
-  vtmhip_full_job &f = wk.full[i];
-  f.orgOff = pat_off( wk, j, i ); f.refOff = j.refOff; f.orgStride = pat_stride( wk, j ); f.refStride = j.refStride;
-  f.puX = j.puX; f.puY = j.puY; f.width = j.width; f.height = j.height; f.subShift = ( int16_t ) sub_shift( cfg, j.width, j.height );
-  f.imvShift = ( uint8_t ) is; f.signedSamples = 1;
-  f.predHor = ph; f.predVer = pv; f.motionLambda = j.motionLambda; f.centerHor = bestH; f.centerVer = bestV; f.searchRange = cfg.bipredSearchRange; f.pad = 0;
+  make_full_job( cfg, j, pat_off( wk, j, i ), pat_stride( wk, j ), bestH, bestV, wk.full[i] );
 }
 
 // test vector of the AMVR refinement: position `pos`, AMVP candidate c (:4208-4215)
@@ -219,13 +171,7 @@ __global__ __launch_bounds__( 256 ) void mest_mid_kernel( vtmhip_pic_params pic,
   vtmhip_frac_job       &q = wk.frac[i];
   vtmhip_dist_job       *d = wk.dist + ( long ) i * REFINE_SLOTS;
   if( wk.needDist ) for( int k = 0; k < REFINE_SLOTS; k++ ) d[k].width = 0;
-  if( j.imv == 0 || j.imv == 3 )
-  {
-    q.orgOff = slot; q.refOff = j.refOff; q.orgStride = sst; q.refStride = j.refStride; q.width = j.width; q.height = j.height;
-    q.intX = ( int16_t ) r.mvX; q.intY = ( int16_t ) r.mvY;
-    q.predHor = prec_down( j.mvPredHor, 2 ); q.predVer = prec_down( j.mvPredVer, 2 ); q.motionLambda = j.motionLambda;
-    q.useHad = cfg.useHadME; q.useAltHpelIf = j.imv == 3; q.imvShift = j.imv == 3; q.bitDepth = ( uint8_t ) pic.bitDepth; q.wideOrg = bcw_weight( j ) != 0;
-  }
+  if( j.imv == 0 || j.imv == 3 ) make_frac_job( cfg.useHadME, pic.bitDepth, j, r.mvX, r.mvY, slot, sst, q );
   else
   {
     q.width = 0;
@@ -252,15 +198,7 @@ __global__ __launch_bounds__( 256 ) void mest_final_kernel( vtmhip_me_cfg cfg, c
   vtmhip_me_out o;
   o.intX = r.mvX; o.intY = r.mvY; o.intDist = r.dist;
   unsigned bits = j.bits;
-  if( j.imv == 0 || j.imv == 3 )
-  {
-    const vtmhip_frac_result f = wk.fres[i];
-    const int qx = ( r.mvX << 2 ) + ( f.halfX << 1 ) + f.qterX, qy = ( r.mvY << 2 ) + ( f.halfY << 1 ) + f.qterY;
-    const unsigned mvBits = mv_bits( qx, qy, prec_down( j.mvPredHor, 2 ), prec_down( j.mvPredVer, 2 ), 0, imv_shift( j.imv ) );
-    bits += mvBits;
-    o.cost = ( unsigned long long ) ( floor( fWeight * ( ( double ) f.cost - ( double ) rate( lam, mvBits ) ) ) + ( double ) rate( lam, bits ) );   // :3483
-    o.mvHor = qx << 2; o.mvVer = qy << 2; o.mvPredHor = j.mvPredHor; o.mvPredVer = j.mvPredVer; o.mvpIdx = j.mvpIdx; o.bits = bits;
-  }
+  if( j.imv == 0 || j.imv == 3 ) make_out_frac( j, r.mvX, r.mvY, r.dist, wk.fres[i], o );
   else
   {
     const int sh = amvr_shift( j.imv );
@@ -299,8 +237,10 @@ struct MestClassOf
   __device__ int operator()( const vtmhip_me_job &j ) const { return shape_class( j.width, j.height ); }
 };
 
+// AMVP selection folded into the fused integer search (vtmhip_internal_mest): the template SADs of the rows' candidates, written by the launch before this call
+struct MestAmvp { const unsigned long long *dout; unsigned long long *distBiP; int addIdxBits; };
 int mest_run( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg *cfg, const int16_t *d_orgBase, const int16_t *d_refBase,
-              const int16_t *d_otherPredBase, const vtmhip_me_job *d_jobs, int n, int maxWidth, int maxHeight, vtmhip_me_out *d_results );
+              const int16_t *d_otherPredBase, const vtmhip_me_job *d_jobs, int n, int maxWidth, int maxHeight, vtmhip_me_out *d_results, const MestAmvp *amvp = nullptr );
 
 // a mixed-shape batch: bucket the jobs by shape on the device and run the uniform chain of every non-empty shape class over its slice
 int mest_bucketed( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg *cfg, const int16_t *d_orgBase, const int16_t *d_refBase,
@@ -344,7 +284,7 @@ namespace
 {
 
 int mest_run( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg *cfg, const int16_t *d_orgBase, const int16_t *d_refBase,
-              const int16_t *d_otherPredBase, const vtmhip_me_job *d_jobs, int n, int maxWidth, int maxHeight, vtmhip_me_out *d_results )
+              const int16_t *d_otherPredBase, const vtmhip_me_job *d_jobs, int n, int maxWidth, int maxHeight, vtmhip_me_out *d_results, const MestAmvp *amvp )
 {
   VTMHIP_CHECK_CTX( ctx );
   VTMHIP_REQUIRE( ctx, n >= 0, "n" );
@@ -395,10 +335,32 @@ int mest_run( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg
   }
   const int16_t *patBase = wk.direct ? ( allUni ? d_orgBase : d_otherPredBase ) : wk.pattern;
 
+  // FUSED forms (round 4; VTMHIP_MEST_FUSE=0 keeps the stand-alone glue launches): uniform batches whose pattern is addressed directly and whose rows all take the fractional
+  // refinement -- the integer search builds its job records from the rows in its prologue (with xEstimateMvPredAMVP's selection when `amvp` is given), the fractional search
+  // builds its jobs from the rows + the integer results and writes the rows' final records: no mest_prepare / mest_mid / mest_final launch, no job tables in between
+  static const bool fuseOn = !( getenv( "VTMHIP_MEST_FUSE" ) && atoi( getenv( "VTMHIP_MEST_FUSE" ) ) == 0 );
+  const bool fuseFrac = fuseOn && wk.direct && fracOnly;
+  const bool fuseTz   = fuseFrac && allUni;
+  VTMHIP_REQUIRE( ctx, !amvp || fuseTz, "the folded AMVP selection needs the fused uni chain" );
+  MeFuse fu; memset( &fu, 0, sizeof( fu ) );
+  fu.me = const_cast<vtmhip_me_job *>( d_jobs ); fu.cfg = *cfg; fu.bitDepth = pic->bitDepth; fu.patIsOther = allUni ? 0 : 1;
+  fu.ires = wk.ires; fu.out = d_results; fu.tzSpill = wk.tz;
+  if( amvp ) { fu.amvpDout = amvp->dout; fu.distBiP = amvp->distBiP; fu.addIdxBits = amvp->addIdxBits; }
+
   if( !wk.direct ) hipLaunchKernelGGL( mest_pattern_kernel, dim3( n ), tpb, 0, ctx->stream, d_orgBase, d_otherPredBase ? d_otherPredBase : d_orgBase, d_jobs, wk );
-  hipLaunchKernelGGL( mest_prepare_kernel, perJob, tpb, 0, ctx->stream, *pic, *cfg, d_jobs, n, wk );
-  VTMHIP_LAUNCHED( ctx );
-  if( !allUni )
+  const bool fuseFull = fuseFrac && allBi;      // bi rows whose target the caller made: the start choice and the job record ride in the exhaustive search's prologue
+  if( !fuseTz && !fuseFull )
+  {
+    hipLaunchKernelGGL( mest_prepare_kernel, perJob, tpb, 0, ctx->stream, *pic, *cfg, d_jobs, n, wk );
+    VTMHIP_LAUNCHED( ctx );
+  }
+  if( fuseFull )
+  {
+    FullFuse ff; ff.me = d_jobs; ff.subShiftMode13 = cfg->fastInterSearchMode13; ff.bipredSearchRange = cfg->bipredSearchRange; ff.patIsOther = 1; ff.noStart = noStart;
+    st = vtmhip_internal_full_search( ctx, &pFull, patBase, d_refBase, nullptr, n, cfg->uniformSquare ? maxWidth : 0, cfg->uniformSquare ? maxHeight : 0, wk.ires, &ff );
+    if( st ) return st;
+  }
+  else if( !allUni )
   {
     // bi-pred: start candidates -> best start -> exhaustive search
     if( !noStart )
@@ -419,9 +381,11 @@ int mest_run( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg
   if( !allBi )
   {
     // uni: TZ search
-    st = vtmhip_tz_search_batch_dev( ctx, &pTz, patBase, d_refBase, wk.tz, n, wk.ires );
+    st = vtmhip_internal_tz_search( ctx, &pTz, patBase, d_refBase, wk.tz, n, wk.ires, fuseTz ? &fu : nullptr );
     if( st ) return st;
   }
+  if( fuseFrac )      // integer results -> fractional search -> the rows' final records, in one launch
+    return vtmhip_internal_frac_search( ctx, patBase, d_refBase, nullptr, n, maxWidth, maxHeight, cfg->uniformSquare, wk.fres, &fu );
   hipLaunchKernelGGL( mest_mid_kernel, perJob, tpb, 0, ctx->stream, *pic, *cfg, d_jobs, n, wk );
   VTMHIP_LAUNCHED( ctx );
   if( uimv == -1 || uimv == 0 || uimv == 3 )
@@ -440,3 +404,20 @@ int mest_run( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg
 }
 
 }   // namespace
+
+// vtmhip_xMotionEstimation_batch_dev for the level / CU-level driver (driver.hip): uniform uni rows whose AMVP candidates' template SADs sit in d_amvpDout -- xEstimateMvPredAMVP's
+// selection happens in the prologue of the fused integer search (the rows are written in place).  Falls back to the selection kernel + the ordinary call when the batch does not
+// take the fused chain (AMVR rows, mixed batches, VTMHIP_MEST_FUSE=0).
+int vtmhip_internal_mest_with_amvp( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg *cfg, const int16_t *d_orgBase, const int16_t *d_refBase,
+                                    vtmhip_me_job *d_jobs, int n, int maxWidth, int maxHeight, vtmhip_me_out *d_results, const unsigned long long *d_amvpDout,
+                                    unsigned long long *d_distBiP, int addIdxBits )
+{
+  MestAmvp a = { d_amvpDout, d_distBiP, addIdxBits };
+  return mest_run( ctx, pic, cfg, d_orgBase, d_refBase, nullptr, d_jobs, n, maxWidth, maxHeight, d_results, &a );
+}
+int vtmhip_internal_mest_fusable( const vtmhip_me_cfg *cfg )
+{
+  static const bool fuseOn = !( getenv( "VTMHIP_MEST_FUSE" ) && atoi( getenv( "VTMHIP_MEST_FUSE" ) ) == 0 );
+  return fuseOn && cfg->uniformBi == 1 && ( cfg->uniformImv == 0 || cfg->uniformImv == 3 );
+}
+

@@ -476,6 +476,25 @@ int vtmhip_xEstimateMvPredAMVP_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_para
   return VTMHIP_OK;
 }
 
+}   // extern "C"
+
+// the first half of vtmhip_xEstimateMvPredAMVP_batch_dev: the template SADs of the rows' AMVP candidates ([2 * row + c]) into a workspace of the context's stream (slot 2: it must
+// outlive the start of the fused integer search, whose prologue makes the selection -- mest.hip: vtmhip_internal_mest_with_amvp)
+int vtmhip_internal_amvp_sads( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_me_job *d_jobs, int n,
+                               int maxWidth, int maxHeight, unsigned long long **d_dout )
+{
+  VTMHIP_CHECK_CTX( ctx );
+  VTMHIP_REQUIRE( ctx, n > 0 && pic && d_orgBase && d_refBase && d_jobs && d_dout, "amvp sads: arguments" );
+  void *arena = nullptr;
+  int   st    = vtmhip_internal_workspace( ctx, align_up( 2 * ( size_t ) n * sizeof( unsigned long long ) ), &arena, 2 );
+  if( st ) return st;
+  *d_dout = ( unsigned long long * ) arena;
+  return vtmhip_internal_mc_amvp_launch( ctx, pic, d_orgBase, d_refBase, d_jobs, n, maxWidth, maxHeight, *d_dout );
+}
+
+extern "C"
+{
+
 int vtmhip_merge_cand_satd_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, int16_t *d_predBase,
                                       const vtmhip_pred_job *d_plain, int nPlain, const vtmhip_pred_job *d_bdof, int nBdof, const vtmhip_dmvr_job *d_dmvr, int nDmvr,
                                       int32_t *d_mvd, int maxWidth, int maxHeight, int uniformSize, int useSatd, uint64_t *d_dist )
