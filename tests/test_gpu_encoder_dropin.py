@@ -107,7 +107,9 @@ def test_reference_encoder_predInterSearch_one_call_per_cu(tmp_path):
                    "plain_s": t1 - t0, "compare_s": t2 - t1, "replace_s": t3 - t2, "speedup_replace_vs_plain": (t1 - t0) / (t3 - t2),
                    "predInterSearch_share_of_plain_run": p, "amdahl_bound_if_predInterSearch_were_free": 1.0 / (1.0 - p),
                    "plain": st0["pis"], "compare": st1["pis"], "replace": st2["pis"], "affine_compare": st1["affine"], "affine_replace": st2["affine"],
-                   "affine_seconds_compare": st1["affineSeconds"], "affine_seconds_replace": st2["affineSeconds"]},
+                   "affine_seconds_compare": st1["affineSeconds"], "affine_seconds_replace": st2["affineSeconds"],
+                   "device_us_per_cu_replace": 1e6 * st2["pis"]["seconds"][1] / max(1, st2["pis"]["device"]),
+                   "host_us_per_cu_in_the_plain_run": 1e6 * in_member / max(1, st0["pis"]["calls"])},
                   open(os.path.join(out, "encoder_replace_192x128.json"), "w"), indent=1)
 
 
@@ -217,7 +219,44 @@ def test_reference_encoder_predInterSearch_full_random_access_cfg(tmp_path):
         json.dump({"clip": "%dx%d, %d pictures, QP %d, tests/data/enc_ra_full.cfg (the values of cfg/encoder_randomaccess_vtm.cfg)" % (w, h, frames, qp), "bitstream_md5": bits0,
                    "identical_bitstream": True, "plain_s": t1 - t0, "replace_s": t2 - t1, "speedup_replace_vs_plain": (t1 - t0) / (t2 - t1),
                    "predInterSearch_share_of_plain_run": in_member / (t1 - t0), "plain": st0["pis"], "replace": st2["pis"], "affine_replace": st2["affine"],
-                   "affine_seconds_replace": st2["affineSeconds"]}, open(os.path.join(out, "encoder_replace_full_cfg_416x240.json"), "w"), indent=1)
+                   "affine_seconds_replace": st2["affineSeconds"], "device_us_per_cu_replace": 1e6 * st2["pis"]["seconds"][1] / max(1, st2["pis"]["device"]),
+                   "host_us_per_cu_in_the_plain_run": 1e6 * in_member / max(1, st0["pis"]["calls"])}, open(os.path.join(out, "encoder_replace_full_cfg_416x240.json"), "w"), indent=1)
+
+
+@pytest.mark.skipif(not os.path.exists(enc_dropin.REF_SO), reason="oracle/_ref/libvtmref.so not built (needs /root/reference)")
+def test_reference_encoder_predInterSearch_1080p_replace(tmp_path):
+    """BASELINE metric (1) at the size of configs 2-3: 1920x1080, 3 pictures (I + two B), QP 32, tests/data/enc_ra_gop4.cfg, the hook in replace mode against the plain
+    encoder -- every predInterSearch call and every xAffineMotionEstimation call on the MI355X, identical bitstream and reconstruction; wall times, the per-hook split and the
+    Amdahl bound go to gpurun_out/encoder_replace_1920x1080.json (profiles/r04_encoder_replace_1920x1080.json)."""
+    import json
+    import time
+    w, h, frames, qp = 1920, 1080, 3, 32
+    yuv = str(tmp_path / "clip.yuv")
+    enc_dropin.write_clip(yuv, w, h, frames)
+    t0 = time.time()
+    st0, bits0, rec0 = enc_dropin.encode(yuv, w, h, frames, qp, str(tmp_path / "plain"), False, 2048 | 8, 1, 0, timeout=3000)
+    t1 = time.time()
+    st2, bits2, rec2 = enc_dropin.encode(yuv, w, h, frames, qp, str(tmp_path / "rep"), True, 2048 | 128, 1, 0, env={"VTMREF_REPLACE": "1"}, timeout=3000)
+    t2 = time.time()
+    print("1080p plain %.1f s:" % (t1 - t0), st0["pis"], "replace %.1f s:" % (t2 - t1), st2["pis"], st2["affine"])
+    assert st0["rc"] == 0 and st2["rc"] == 0 and st2["errors"] == 0, st2
+    assert st2["pis"]["calls"] == st0["pis"]["calls"] and st2["pis"]["device"] >= 10000, st2["pis"]
+    assert st2["pis"]["unsupported"] == 0 and st2["pis"]["mismatch"] == [0] * 6 and st2["pis"]["replayFallback"] == 0, st2["pis"]
+    assert st2["affine"][2] == 0 and st2["affine"][3] == 0, st2["affine"]
+    assert bits2 == bits0 and rec2 == rec0
+    out = os.path.join(enc_dropin.ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        in_member = sum(st0["pis"]["seconds"])
+        dev = st2["pis"]["seconds"][1]
+        json.dump({"clip": "%dx%d synthetic (vtm_amd/synth.py), %d pictures, QP %d, tests/data/enc_ra_gop4.cfg" % (w, h, frames, qp), "bitstream_md5": bits0, "identical_bitstream": True,
+                   "plain_s": t1 - t0, "replace_s": t2 - t1, "encoded_fps_plain": frames / (t1 - t0), "encoded_fps_replace": frames / (t2 - t1),
+                   "speedup_replace_vs_plain": (t1 - t0) / (t2 - t1), "predInterSearch_share_of_plain_run": in_member / (t1 - t0),
+                   "amdahl_bound_if_predInterSearch_were_free": 1.0 / (1.0 - in_member / (t1 - t0)), "plain": st0["pis"], "replace": st2["pis"], "affine_replace": st2["affine"],
+                   "per_hook_seconds_replace": {"gather_and_final_compare": st2["pis"]["seconds"][0], "upload_device_download": dev,
+                                                "reference_glue_over_the_tables_incl_affine_search_and_final_mc": st2["pis"]["seconds"][2],
+                                                "xAffineMotionEstimation_device_calls": st2["affineSeconds"][1]},
+                   "device_us_per_cu": 1e6 * dev / max(1, st2["pis"]["device"]), "host_us_per_cu_in_the_plain_run": 1e6 * in_member / max(1, st0["pis"]["calls"])},
+                  open(os.path.join(out, "encoder_replace_1920x1080.json"), "w"), indent=1)
 
 
 @pytest.mark.skipif(not os.path.exists(enc_dropin.REF_SO), reason="oracle/_ref/libvtmref.so not built (needs /root/reference)")

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include "ctx.hpp"
 #include "had.hpp"
+#include "dist_block.hpp"
 
 namespace
 {
@@ -28,91 +29,8 @@ __global__ __launch_bounds__( 256 ) void dist_batch_kernel( const int16_t *__res
   const int16_t        *org = orgBase + j.orgOff;
   const int16_t        *cur = curBase + j.curOff;
   const int             w = j.width, h = j.height, os = j.orgStride, cs = j.curStride;
-  unsigned long long    acc = 0;
   if( w == 0 ) return;   // empty slot of a multi-stage call: nothing read, nothing written
-
-  if( j.kind == VTMHIP_DIST_SAD )
-  {
-    // rows y = 0, step, 2*step ...; work items = (row, 4-sample segment), or single samples for widths like 2 / 6 (chroma)
-    const int ss = j.subShift, rows = ( h + ( 1 << ss ) - 1 ) >> ss, segs = w >> 2;
-    unsigned  s = 0;
-    if( ( w & 3 ) == 0 )
-    {
-      for( int it = lane; it < rows * segs; it += 64 )
-      {
-        const int      r = it / segs, x = ( it - r * segs ) << 2;
-        const int16_t *o = org + ( long ) ( r << ss ) * os + x;
-        const int16_t *c = cur + ( long ) ( r << ss ) * cs + x;
-#pragma unroll
-        for( int k = 0; k < 4; k++ ) s += ( unsigned ) abs( ( int ) o[k] - ( int ) c[k] );
-      }
-    }
-    else
-    {
-      for( int it = lane; it < rows * w; it += 64 )
-      {
-        const int r = it / w, x = it - r * w;
-        s += ( unsigned ) abs( ( int ) org[( long ) ( r << ss ) * os + x] - ( int ) cur[( long ) ( r << ss ) * cs + x] );
-      }
-    }
-    acc = ( unsigned long long ) s << ss;   // per-lane partial (W*H*65535 < 2^32 for W,H <= 128 needs care: 128*128*65535 = 2^30)
-  }
-  else if( j.kind == VTMHIP_DIST_SSE )
-  {
-    const int segs = w >> 2;
-    if( ( w & 3 ) == 0 )
-    {
-      for( int it = lane; it < h * segs; it += 64 )
-      {
-        const int      r = it / segs, x = ( it - r * segs ) << 2;
-        const int16_t *o = org + ( long ) r * os + x;
-        const int16_t *c = cur + ( long ) r * cs + x;
-#pragma unroll
-        for( int k = 0; k < 4; k++ )
-        {
-          const int d = ( int ) o[k] - ( int ) c[k];
-          acc += ( unsigned long long ) ( ( unsigned ) d * ( unsigned ) d );   // per-addend 32-bit product as RdCost.cpp:1783-1814
-        }
-      }
-    }
-    else
-    {
-      for( int it = lane; it < h * w; it += 64 )
-      {
-        const int r = it / w, x = it - r * w;
-        const int d = ( int ) org[( long ) r * os + x] - ( int ) cur[( long ) r * cs + x];
-        acc += ( unsigned long long ) ( ( unsigned ) d * ( unsigned ) d );
-      }
-    }
-  }
-  else   // SATD: tile shape by the rules of xGetHADs (RdCost.cpp:2837-2931); one tile per lane
-  {
-    int tw, th;
-    if( w > h && ( h & 7 ) == 0 && ( w & 15 ) == 0 ) { tw = 16; th = 8; }
-    else if( w < h && ( w & 7 ) == 0 && ( h & 15 ) == 0 ) { tw = 8; th = 16; }
-    else if( w > h && ( h & 3 ) == 0 && ( w & 7 ) == 0 ) { tw = 8; th = 4; }
-    else if( w < h && ( w & 3 ) == 0 && ( h & 7 ) == 0 ) { tw = 4; th = 8; }
-    else if( ( h & 7 ) == 0 && ( w & 7 ) == 0 ) { tw = 8; th = 8; }
-    else if( ( h & 3 ) == 0 && ( w & 3 ) == 0 ) { tw = 4; th = 4; }
-    else { tw = 2; th = 2; }
-    const int tx = w / tw, ty = h / th;
-    for( int it = lane; it < tx * ty; it += 64 )
-    {
-      const int      y = ( it / tx ) * th, x = ( it % tx ) * tw;
-      const int16_t *o = org + ( long ) y * os + x;
-      const int16_t *c = cur + ( long ) y * cs + x;
-      unsigned       v;
-      if( tw == 16 ) v = had_tile<16, 8>( o, os, c, cs );
-      else if( th == 16 ) v = had_tile<8, 16>( o, os, c, cs );
-      else if( tw == 8 && th == 4 ) v = had_tile<8, 4>( o, os, c, cs );
-      else if( tw == 4 && th == 8 ) v = had_tile<4, 8>( o, os, c, cs );
-      else if( tw == 8 ) v = had_tile<8, 8>( o, os, c, cs );
-      else if( tw == 4 ) v = had_tile<4, 4>( o, os, c, cs );
-      else v = had_tile<2, 2>( o, os, c, cs );
-      acc += v;
-    }
-  }
-  acc = wave_reduce_add_u64( acc );
+  const unsigned long long acc = wave_block_dist( j.kind, org, os, cur, cs, w, h, j.subShift, lane );
   if( lane == 0 ) out[job] = acc;
 }
 

@@ -1574,8 +1574,9 @@ int vtmhip_internal_tz_search( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, co
     d_saved = ( TzSaved * ) arena;
     d_list  = ( int * ) ( ( char * ) arena + oList );
     d_tot   = ( unsigned * ) ( ( char * ) arena + oTot );
-    VTMHIP_HIP( ctx, hipMemsetAsync( d_list, 0, sizeof( int ), ctx->stream ) );
-    if( totBytes ) VTMHIP_HIP( ctx, hipMemsetAsync( d_tot, 0, totBytes, ctx->stream ) );
+    // the list counter and (split scans) the global totals in ONE fill: they sit next to each other in the arena (a fill is a launch on the dependent chain of the call)
+    if( totBytes ) VTMHIP_HIP( ctx, hipMemsetAsync( d_list, 0, ( size_t ) ( ( char * ) d_tot - ( char * ) d_list ) + totBytes, ctx->stream ) );
+    else VTMHIP_HIP( ctx, hipMemsetAsync( d_list, 0, sizeof( int ), ctx->stream ) );
   }
 #define VTMHIP_TZ_LAUNCH( W, GRID, MODE ) \
   hipLaunchKernelGGL( tz_search_kernel<W>, dim3( GRID ), dim3( W == 1 ? 256 : 64 * W ), 0, ctx->stream, *pic, d_orgBase, d_refBase, d_jobs, n, d_results, MODE, d_saved, d_list, totCap, \

@@ -12,6 +12,7 @@
 //   final     rate re-weighting (:3478-3484) or the AMVR selection loop (:4208-4262), fp64 exactly as the reference
 #include "ctx.hpp"
 #include "mest_glue.hpp"
+#include "dist_block.hpp"
 #include "bucket.hpp"
 
 namespace
@@ -230,6 +231,79 @@ __global__ __launch_bounds__( 256 ) void mest_final_kernel( vtmhip_me_cfg cfg, c
   out[i] = o;
 }
 
+// FUSED integer refinement of the AMVR modes (xPatternSearchIntRefine :4172-4282; cu.imv 1 / 2): one wave per row forms the nine test vectors per AMVP candidate around the
+// integer result, measures each (SATD or SAD of the pattern against the reference block at the clipped vector; a second candidate whose vector equals the first's re-uses its
+// value, :4226-4239), adds the vector + index rate and keeps the first strict minimum -- what mest_mid_kernel (18 job records) + dist_batch_kernel + mest_final_kernel did in
+// three launches.  The loop IS mest_final_kernel's, with the distortion computed where that kernel read it.
+__global__ __launch_bounds__( 576 ) void mest_amvr_kernel( vtmhip_pic_params pic, vtmhip_me_cfg cfg, const int16_t *__restrict__ patBase, const int16_t *__restrict__ refBase,
+                                                          const vtmhip_me_job *__restrict__ jobs, int n, const vtmhip_me_result *__restrict__ ires, int patIsOther,
+                                                          vtmhip_me_out *__restrict__ out )
+{
+  // one workgroup of nine waves per row: wave `pos` measures the test vectors of refinement position `pos` (both AMVP candidates), then the row's first lane runs the
+  // selection loop over the 18 values in the reference's order
+  __shared__ unsigned long long sDist[18];
+  const int lane = threadIdx.x & 63, pos = ( int ) ( threadIdx.x >> 6 );
+  const int i    = blockIdx.x;
+  const vtmhip_me_job   &j = jobs[i];
+  const vtmhip_me_result r = ires[i];
+  const int16_t *pat = patBase + ( patIsOther ? j.otherPredOff : j.orgOff );
+  const int      ps  = patIsOther ? j.otherPredStride : j.orgStride;
+  const int      kind = cfg.useHadME ? VTMHIP_DIST_SATD : VTMHIP_DIST_SAD;
+  {
+    int t0h = 0, t0v = 0;
+    for( int c = 0; c < j.numAmvpCand && c < 2; c++ )
+    {
+      int th, tv;
+      refine_test_mv( j, r.mvX, r.mvY, pos, c, th, tv );
+      if( c == 0 ) { t0h = th; t0v = tv; }
+      if( c == 0 || th != t0h || tv != t0v )      // (a second candidate with the first one's vector re-uses its value, :4226-4239)
+      {
+        int ch = th, cv = tv;
+        clip_mv( pic, j, ch, cv );
+        const unsigned long long d = wave_block_dist( kind, pat, ps, refBase + j.refOff + ( long ) ( cv >> 4 ) * j.refStride + ( ch >> 4 ), j.refStride, j.width, j.height, 0, lane );
+        if( lane == 0 ) sDist[pos * 2 + c] = d;
+      }
+    }
+  }
+  __syncthreads();
+  if( pos != 0 ) return;
+  // the selection (:4208-4262): lane k = (position k / 2, candidate k & 1) prices its test vector; the first strict minimum in the reference's evaluation order = the
+  // lexicographic minimum of (cost, k)
+  const int      bcw = bcw_weight( j );
+  const double   fWeight = j.bi ? ( bcw ? fabs( ( double ) bcw / 8.0 ) : 0.5 ) : 1.0, lam = j.motionLambda;
+  const int      sh = amvr_shift( j.imv ), nc = min( ( int ) j.numAmvpCand, 2 );
+  const int      p = lane >> 1, c = lane & 1;
+  unsigned long long cost = ~0ull;
+  int                th = 0, tv = 0, mvBits = 0;
+  if( lane < 18 && c < nc )
+  {
+    int t0h, t0v;
+    refine_test_mv( j, r.mvX, r.mvY, p, 0, t0h, t0v );
+    refine_test_mv( j, r.mvX, r.mvY, p, c, th, tv );
+    const bool own = c == 0 || th != t0h || tv != t0v;
+    const unsigned long long d = ( unsigned long long ) ( ( double ) sDist[p * 2 + ( own ? c : 0 )] * fWeight );
+    mvBits = ( int ) j.mvpIdxBits[c] + ( int ) mv_bits( prec_down( th, sh ), prec_down( tv, sh ), prec_down( j.amvpCand[c][0], sh ), prec_down( j.amvpCand[c][1], sh ), 0, 0 );
+    cost = d + rate( lam, ( unsigned ) mvBits );
+  }
+  unsigned long long bc = cost;
+  unsigned           bk = ( unsigned ) lane;
+#pragma unroll
+  for( int o = 16; o > 0; o >>= 1 )      // lanes 0 .. 31 hold the 18 candidates
+  {
+    const unsigned long long oc = __shfl_xor( bc, o, 64 );
+    const unsigned           ok = __shfl_xor( bk, o, 64 );
+    if( oc < bc || ( oc == bc && ok < bk ) ) { bc = oc; bk = ok; }
+  }
+  if( lane >= 32 || ( unsigned ) lane != bk ) return;      // the winner (among the first 32 lanes: the upper half reduced its own idle lanes) writes the row's record
+  vtmhip_me_out o;
+  o.intX = r.mvX; o.intY = r.mvY; o.intDist = r.dist;
+  o.mvHor = th; o.mvVer = tv; o.mvpIdx = c; o.mvPredHor = j.amvpCand[c][0]; o.mvPredVer = j.amvpCand[c][1];
+  const unsigned bits = j.bits - j.mvpIdxBits[j.mvpIdx & 1] + ( unsigned ) mvBits;
+  o.bits = bits;
+  o.cost = cost - rate( lam, ( unsigned ) mvBits ) + rate( lam, bits );
+  out[i] = o;
+}
+
 size_t align_up( size_t v ) { return ( v + 255 ) & ~( size_t ) 255; }
 
 struct MestClassOf
@@ -339,8 +413,10 @@ int mest_run( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg
   // refinement -- the integer search builds its job records from the rows in its prologue (with xEstimateMvPredAMVP's selection when `amvp` is given), the fractional search
   // builds its jobs from the rows + the integer results and writes the rows' final records: no mest_prepare / mest_mid / mest_final launch, no job tables in between
   static const bool fuseOn = !( getenv( "VTMHIP_MEST_FUSE" ) && atoi( getenv( "VTMHIP_MEST_FUSE" ) ) == 0 );
-  const bool fuseFrac = fuseOn && wk.direct && fracOnly;
-  const bool fuseTz   = fuseFrac && allUni;
+  const bool fuseAny  = fuseOn && wk.direct && uimv != -1;      // a uniform AMVR mode: the integer stage fuses either way, then the fractional or the integer refinement
+  const bool fuseFrac = fuseAny && fracOnly;
+  const bool fuseAmvr = fuseAny && !fracOnly;
+  const bool fuseTz   = fuseAny && allUni;
   VTMHIP_REQUIRE( ctx, !amvp || fuseTz, "the folded AMVP selection needs the fused uni chain" );
   MeFuse fu; memset( &fu, 0, sizeof( fu ) );
   fu.me = const_cast<vtmhip_me_job *>( d_jobs ); fu.cfg = *cfg; fu.bitDepth = pic->bitDepth; fu.patIsOther = allUni ? 0 : 1;
@@ -348,7 +424,7 @@ int mest_run( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg
   if( amvp ) { fu.amvpDout = amvp->dout; fu.distBiP = amvp->distBiP; fu.addIdxBits = amvp->addIdxBits; }
 
   if( !wk.direct ) hipLaunchKernelGGL( mest_pattern_kernel, dim3( n ), tpb, 0, ctx->stream, d_orgBase, d_otherPredBase ? d_otherPredBase : d_orgBase, d_jobs, wk );
-  const bool fuseFull = fuseFrac && allBi;      // bi rows whose target the caller made: the start choice and the job record ride in the exhaustive search's prologue
+  const bool fuseFull = fuseAny && allBi;      // bi rows whose target the caller made: the start choice and the job record ride in the exhaustive search's prologue
   if( !fuseTz && !fuseFull )
   {
     hipLaunchKernelGGL( mest_prepare_kernel, perJob, tpb, 0, ctx->stream, *pic, *cfg, d_jobs, n, wk );
@@ -386,6 +462,12 @@ int mest_run( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg
   }
   if( fuseFrac )      // integer results -> fractional search -> the rows' final records, in one launch
     return vtmhip_internal_frac_search( ctx, patBase, d_refBase, nullptr, n, maxWidth, maxHeight, cfg->uniformSquare, wk.fres, &fu );
+  if( fuseAmvr )      // integer results -> the nine-position integer refinement of the AMVR modes -> the rows' final records, in one launch
+  {
+    hipLaunchKernelGGL( mest_amvr_kernel, dim3( n ), dim3( 576 ), 0, ctx->stream, *pic, *cfg, patBase, d_refBase, d_jobs, n, wk.ires, allUni ? 0 : 1, d_results );
+    VTMHIP_LAUNCHED( ctx );
+    return VTMHIP_OK;
+  }
   hipLaunchKernelGGL( mest_mid_kernel, perJob, tpb, 0, ctx->stream, *pic, *cfg, d_jobs, n, wk );
   VTMHIP_LAUNCHED( ctx );
   if( uimv == -1 || uimv == 0 || uimv == 3 )
@@ -418,6 +500,6 @@ int vtmhip_internal_mest_with_amvp( vtmhip_ctx *ctx, const vtmhip_pic_params *pi
 int vtmhip_internal_mest_fusable( const vtmhip_me_cfg *cfg )
 {
   static const bool fuseOn = !( getenv( "VTMHIP_MEST_FUSE" ) && atoi( getenv( "VTMHIP_MEST_FUSE" ) ) == 0 );
-  return fuseOn && cfg->uniformBi == 1 && ( cfg->uniformImv == 0 || cfg->uniformImv == 3 );
+  return fuseOn && cfg->uniformBi == 1 && cfg->uniformImv >= 0 && cfg->uniformImv <= 3;
 }
 

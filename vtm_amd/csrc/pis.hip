@@ -235,47 +235,59 @@ __global__ __launch_bounds__( 256 ) void pis_uni_select_kernel( vtmhip_pis_level
 
 __global__ __launch_bounds__( 256 ) void pis_bi_jobs_kernel( vtmhip_pis_level L )
 {
-  const int pu = blockIdx.x * 256 + threadIdx.x;
+  // VTMHIP_MAX_REF threads per PU: every thread derives the PU's refined list and the other list's bits (a few reads), thread 0 of the PU writes the PU's record and the
+  // other list's prediction job, thread `ref` the bi row of reference picture `ref` (a 232-byte record each: side by side instead of one after the other)
+  const int t = blockIdx.x * 256 + threadIdx.x, pu = t / VTMHIP_MAX_REF, ref = t % VTMHIP_MAX_REF;
   if( pu >= L.numPU ) return;
-  vtmhip_pis_pu &P = L.pus[pu];
+  const bool head = ref == 0;
+  const vtmhip_pis_pu &P = L.pus[pu];
   // FASTINTERSEARCH_MODE1: refine the list with the larger cost (:2544-2556); a CU-level BCW weight: the list with the smaller |weight| (:2556-2559); MvdL1Zero: list 0 (:2576-2580)
   const int wL1 = bcw_weight_l1( L, pu );
   const int rl = L.mvdL1Zero ? 0 : wL1 ? ( abs( 8 - wL1 ) > abs( wL1 ) ? 1 : 0 ) : ( P.cost[0] <= P.cost[1] ? 1 : 0 ), ot = 1 - rl;
   const int wRefined = wL1 ? ( rl ? wL1 : 8 - wL1 ) : 0;      // getBcwWeight( bcwIdx, refined list )
-  P.refineList = rl;
-  vtmhip_pred_job &po = L.predOther[pu];
-  po.mode = ( uint8_t ) ot;
-  po.bcwWeight = ( int16_t ) wRefined;      // epilogue 2: the weighted target of removeHighFreq (:3320-3326)
   unsigned motOther;
+  int      otherRef, otherMvH, otherMvV, mvpL1 = 0;
   if( L.mvdL1Zero )
   {
     // list 1 enters the bi mode AT its best AMVP predictor: the row with the smallest template cost (first minimum, :2382-2387), vector = that predictor, no vector difference
     unsigned long long bestDist = ~0ull;
     int                bestRef = 0, bestMvp = 0;
-    for( int ref = 0; ref < L.numRef[1]; ref++ )
+    for( int r = 0; r < L.numRef[1]; r++ )
     {
-      const int row = uni_row( L, 1, ref, pu );
-      if( L.distBiP[row] < bestDist ) { bestDist = L.distBiP[row]; bestRef = ref; bestMvp = L.uniJobs[row].mvpIdx; }
+      const int row = uni_row( L, 1, r, pu );
+      if( L.distBiP[row] < bestDist ) { bestDist = L.distBiP[row]; bestRef = r; bestMvp = L.uniJobs[row].mvpIdx; }
     }
     const vtmhip_me_job &u1 = L.uniJobs[uni_row( L, 1, bestRef, pu )];
-    P.mvBi[1][0] = u1.amvpCand[bestMvp & 1][0]; P.mvBi[1][1] = u1.amvpCand[bestMvp & 1][1]; P.refIdxBi[1] = bestRef; P.mvpIdxL1Zero = bestMvp;
-    po.refOff[1] = L.refPlaneOff[1][bestRef] + L.pos[pu];
-    po.mv[1][0] = P.mvBi[1][0]; po.mv[1][1] = P.mvBi[1][1];
-    motOther = L.mbBits[1] + ref_idx_bits( L.numRef[1], bestRef ) + u1.mvpIdxBits[bestMvp & 1];      // uiMotBits[1] (:2506-2517)
+    otherRef = bestRef; mvpL1 = bestMvp;
+    otherMvH = bestMvp & 1 ? u1.amvpCand[1][0] : u1.amvpCand[0][0]; otherMvV = bestMvp & 1 ? u1.amvpCand[1][1] : u1.amvpCand[0][1];
+    motOther = L.mbBits[1] + ref_idx_bits( L.numRef[1], bestRef ) + ( bestMvp & 1 ? u1.mvpIdxBits[1] : u1.mvpIdxBits[0] );      // uiMotBits[1] (:2506-2517)
   }
   else
   {
-    po.refOff[ot] = L.refPlaneOff[ot][P.refIdx[ot]] + L.pos[pu];
-    po.mv[ot][0] = P.mv[ot][0]; po.mv[ot][1] = P.mv[ot][1];
-    motOther = P.bits[ot] - L.mbBits[ot];           // uiMotBits[1 - iRefList] (:2525-2527)
+    otherRef = ot ? P.refIdx[1] : P.refIdx[0];
+    otherMvH = ot ? P.mv[1][0] : P.mv[0][0]; otherMvV = ot ? P.mv[1][1] : P.mv[0][1];
+    motOther = ( ot ? P.bits[1] : P.bits[0] ) - ( ot ? L.mbBits[1] : L.mbBits[0] );           // uiMotBits[1 - iRefList] (:2525-2527)
   }
-  if( L.picW )      // clipMv of motionCompensation (the PU's own record keeps the unclipped vector)
+  if( head )
   {
-    const vtmhip_me_job &u0 = L.uniJobs[uni_row( L, 0, 0, pu )];
-    po.mv[ot][0] = min( ( L.picW + 8 - u0.puX - 1 ) << 4, max( ( -L.ctuSize - 8 - u0.puX + 1 ) << 4, po.mv[ot][0] ) );
-    po.mv[ot][1] = min( ( L.picH + 8 - u0.puY - 1 ) << 4, max( ( -L.ctuSize - 8 - u0.puY + 1 ) << 4, po.mv[ot][1] ) );
+    vtmhip_pis_pu   &Pw = L.pus[pu];
+    vtmhip_pred_job &po = L.predOther[pu];
+    Pw.refineList = rl;
+    po.mode = ( uint8_t ) ot;
+    po.bcwWeight = ( int16_t ) wRefined;      // epilogue 2: the weighted target of removeHighFreq (:3320-3326)
+    if( L.mvdL1Zero ) { Pw.mvBi[1][0] = otherMvH; Pw.mvBi[1][1] = otherMvV; Pw.refIdxBi[1] = otherRef; Pw.mvpIdxL1Zero = mvpL1; }
+    int ph = otherMvH, pv = otherMvV;
+    if( L.picW )      // clipMv of motionCompensation (the PU's own record keeps the unclipped vector)
+    {
+      const vtmhip_me_job &u0 = L.uniJobs[uni_row( L, 0, 0, pu )];
+      ph = min( ( L.picW + 8 - u0.puX - 1 ) << 4, max( ( -L.ctuSize - 8 - u0.puX + 1 ) << 4, ph ) );
+      pv = min( ( L.picH + 8 - u0.puY - 1 ) << 4, max( ( -L.ctuSize - 8 - u0.puY + 1 ) << 4, pv ) );
+    }
+    const int64_t off = ( ot ? L.refPlaneOff[1][otherRef] : L.refPlaneOff[0][otherRef] ) + L.pos[pu];
+    if( ot ) { po.refOff[1] = off; po.mv[1][0] = ph; po.mv[1][1] = pv; }
+    else     { po.refOff[0] = off; po.mv[0][0] = ph; po.mv[0][1] = pv; }
   }
-  for( int ref = 0; ref < L.numRef[rl]; ref++ )
+  if( ref < ( rl ? L.numRef[1] : L.numRef[0] ) )
   {
     const int             row = uni_row( L, rl, ref, pu );
     const vtmhip_me_job  &u   = L.uniJobs[row];
@@ -550,7 +562,7 @@ int vtmhip_pis_stage( vtmhip_ctx *ctx, const vtmhip_pis_level *lvl, int stage )
   {
     VTMHIP_REQUIRE( ctx, lvl->numRef[1] >= 1 && lvl->predOther && lvl->biJobs && lvl->biOut, "the bi stages need list 1 and the bi tables" );
     VTMHIP_REQUIRE( ctx, !lvl->mvdL1Zero || ( lvl->distBiP && !lvl->smvdJobs ), "MvdL1Zero needs the template costs (distBiP) and has no SMVD block" );
-    if( stage == 2 ) hipLaunchKernelGGL( pis_bi_jobs_kernel, perPU, tpb, 0, ctx->stream, *lvl );
+    if( stage == 2 ) hipLaunchKernelGGL( pis_bi_jobs_kernel, dim3( ( lvl->numPU * VTMHIP_MAX_REF + 255 ) / 256 ), tpb, 0, ctx->stream, *lvl );
     else hipLaunchKernelGGL( pis_final_kernel, perPU, tpb, 0, ctx->stream, *lvl );
   }
   VTMHIP_LAUNCHED( ctx );
