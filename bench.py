@@ -137,7 +137,7 @@ def cpu_baseline(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, budget_s, pocs=Non
     per_level = budget_s / len(snaps)
     for li, lvl in enumerate(snaps):
         s, npu = lvl["size"], lvl["npu"]
-        parent = snaps[li - 1] if li else None
+        parent = snaps[lvl["parent_level"]] if lvl["parent_level"] >= 0 else None
         t_lvl, n_lvl = 0.0, 0
         for i in rng.permutation(npu):
             i = int(i)

@@ -63,7 +63,7 @@ def check(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, R, per_level=24, min_chec
         cqp = pipeline.chroma_qp(qp) + 12
         chroma = dict(chroma, qp_per=cqp // 6, qp_rem=cqp % 6)
     for li, lvl in enumerate(snaps):
-        parent = snaps[li - 1] if li else None
+        parent = snaps[lvl["parent_level"]] if lvl["parent_level"] >= 0 else None
         s, npu = lvl["size"], lvl["npu"]
         for i in range(0, npu, max(1, npu // per_level)):
             out = cpu_pis.run_pu(cur_np, dpb_np.ctypes.data, refs, sr, W, H, s, int(lvl["xs"][i]), int(lvl["ys"][i]), cpu_pis.cands_of(lvl, nref, i), lam,

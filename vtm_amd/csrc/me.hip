@@ -35,6 +35,7 @@ struct MeJob   // wave-uniform view of one vtmhip_tz_job
   int            seg, segsPerRow, items, lpc;
   int            lpcShift, sprShift;   // log2(lpc); log2(segsPerRow) or -1 when it is not a power of two (widths 12, 24, 48)
   bool           narrow;               // lambda * 126 < 2^31: distortion + MV rate fits 32 bits -> packed (cost, index) keys
+  bool           tiny;                 // distortion + MV rate < 2^26 whatever the candidate: (cost << 6 | index) is ONE 32-bit key for rounds of at most 64 candidates
   unsigned       bias;   // 0x80008000 when samples may be negative (v_sad_u16 is unsigned), else 0
   // items == lpc (blocks up to 32x32 with row sub-sampling): every lane owns ONE segment of the original block for the whole
   // search, so it is loaded once (per-lane data, already XORed with bias) instead of once per candidate
@@ -419,10 +420,21 @@ __device__ __forceinline__ void eval_candidates( const MeJob &j, const int4 *pts
   }
   if( j.narrow )
   {
-    // cost < 2^32: lexicographic minimum of (cost, index) as two 32-bit wave minima -- the cost, then the index among the lanes that hold it
-    const unsigned c32 = bestIdx == 0xffffffffu ? 0xffffffffu : ( unsigned ) bestCost;
-    const unsigned cm  = wave_min_u32( c32 );
-    const unsigned km  = wave_min_u32( c32 == cm ? bestIdx : 0xffffffffu );
+    // cost < 2^32: lexicographic minimum of (cost, index) as two 32-bit wave minima -- the cost, then the index among the lanes that hold it;
+    // cost < 2^26 and at most 64 candidates (every diamond / start round of a block up to 128x128 of 10-bit samples): one minimum over (cost << 6 | index)
+    unsigned cm, km;
+    if( j.tiny && total <= 64 )
+    {
+      const unsigned m = wave_min_u32( bestIdx == 0xffffffffu ? 0xffffffffu : ( ( unsigned ) bestCost << 6 ) | bestIdx );
+      cm = m == 0xffffffffu ? 0xffffffffu : m >> 6;
+      km = m == 0xffffffffu ? 0xffffffffu : m & 63u;
+    }
+    else
+    {
+      const unsigned c32 = bestIdx == 0xffffffffu ? 0xffffffffu : ( unsigned ) bestCost;
+      cm = wave_min_u32( c32 );
+      km = wave_min_u32( c32 == cm ? bestIdx : 0xffffffffu );
+    }
     unsigned long long key = km == 0xffffffffu ? ~0ull : ( ( unsigned long long ) cm << 32 ) | km;
     if( WPJ > 1 )
     {
@@ -856,7 +868,7 @@ __global__ __launch_bounds__( 256 ) void tz_raster_cols_kernel( vtmhip_pic_param
     j.w = jp->width; j.h = jp->height; j.ss = jp->subShift; j.imvShift = ( unsigned ) jp->imvShift;
     j.predHor = jp->predHor; j.predVer = jp->predVer; j.costScale = 2; j.lambda = jp->motionLambda;
     j.bias = jp->signedSamples ? 0x80008000u : 0u;
-    j.narrow = false; j.totCap = totCap;
+    j.narrow = false; j.tiny = false; j.totCap = totCap;
     const Range r = sv.sr;
     const int   nx = ( r.right - r.left ) / 5 + 1, ny = ( r.bottom - r.top ) / 5 + 1, total = nx * ny;
     for( int i = threadIdx.x; i < total; i += 256 ) sTot[i] = 0;
@@ -1041,6 +1053,7 @@ void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBas
   j.lpcShift   = floor_log2_u( ( unsigned ) j.lpc );
   j.sprShift   = ( j.segsPerRow & ( j.segsPerRow - 1 ) ) == 0 ? floor_log2_u( ( unsigned ) j.segsPerRow ) : -1;
   j.narrow     = j.lambda >= 0.0 && j.lambda * 126.0 < 2147483648.0;
+  j.tiny       = j.narrow && ( double ) ( j.w * j.h ) * ( j.bias ? 65535.0 : ( double ) ( ( 1 << pic.bitDepth ) - 1 ) ) + j.lambda * 126.0 < 67108864.0;
 
   j.orgResident = j.items == j.lpc;
   j.resOff      = 0;
@@ -1297,6 +1310,7 @@ __global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) void full_search_kerne
   j.lpcShift   = floor_log2_u( ( unsigned ) j.lpc );
   j.sprShift   = ( j.segsPerRow & ( j.segsPerRow - 1 ) ) == 0 ? floor_log2_u( ( unsigned ) j.segsPerRow ) : -1;
   j.narrow     = j.lambda >= 0.0 && j.lambda * 126.0 < 2147483648.0;
+  j.tiny       = false;
 
   j.orgResident = j.items == j.lpc;
   j.resOff      = 0;
@@ -1407,7 +1421,7 @@ __global__ __launch_bounds__( ( FullSq<W, H>::THREADS ) ) void full_search_sq_ke
     j.ss = q.subShift; j.imvShift = q.imvShift; j.predHor = q.predHor; j.predVer = q.predVer; j.costScale = 2; j.lambda = q.motionLambda;
     j.horMax = ( pic.picW + 8 - q.puX - 1 ) << 4; j.horMin = ( -pic.ctuSize - 8 - q.puX + 1 ) << 4;
     j.verMax = ( pic.picH + 8 - q.puY - 1 ) << 4; j.verMin = ( -pic.ctuSize - 8 - q.puY + 1 ) << 4;
-    j.narrow = j.lambda >= 0.0 && j.lambda * 126.0 < 2147483648.0;
+    j.narrow = j.lambda >= 0.0 && j.lambda * 126.0 < 2147483648.0; j.tiny = false;
   };
   if( tid < nj )
   {

@@ -53,14 +53,17 @@ def band_filter(pic_w, band, ctu=128):
     return lambda cy, cx: (cy * cw + cx >= band[0]) & (cy * cw + cx < band[1])
 
 
-def quadtree_levels(pic_w, pic_h, sizes=(128, 64, 32, 16, 8), row_filter=None, ctu_filter=None):
+def quadtree_levels(pic_w, pic_h, sizes=(128, 64, 32, 16, 8), row_filter=None, ctu_filter=None, split_last=None):
     """PUs of every partition level that lie fully inside the picture.  sizes: one entry per level, coarse to fine, an int (square PUs: the quadtree)
     or (w, h) (the binary / ternary split shapes; a level's blocks nest inside the previous level's).  row_filter(ctu_row_array) -> bool array selects the
     CTU rows (128 luma rows each) this rank owns; ctu_filter(ctu_row_array, ctu_col_array) -> bool array selects single CTUs.
-    Returns [(size as given, xs, ys, parent_index_or_None)], coarse to fine."""
+    split_last = K > 1: the LAST (finest, largest) level comes as K levels over K contiguous raster ranges of its PUs, all children of the level before it -- a level-order
+    driver then runs the remaining stages of the first part beside the searches of the second (its tail after the dependent chain of searches is 1 / K as long).
+    Returns [(size as given, xs, ys, parent_index_or_None)], coarse to fine; with split_last given (1: no split) every entry carries a fifth element, the index of its
+    parent's entry in this list (or -1)."""
     levels = []
     prev = None
-    for s in sizes:
+    for si, s in enumerate(sizes):
         bw, bh = (s, s) if np.isscalar(s) else s
         ys, xs = np.mgrid[0:pic_h - bh + 1:bh, 0:pic_w - bw + 1:bw]
         xs, ys = xs.ravel().astype(np.int64), ys.ravel().astype(np.int64)
@@ -75,7 +78,14 @@ def quadtree_levels(pic_w, pic_h, sizes=(128, 64, 32, 16, 8), row_filter=None, c
             (pw, ph), pxs, pys = prev
             lut = {(int(x), int(y)): i for i, (x, y) in enumerate(zip(pxs, pys))}
             parent = np.array([lut.get((int(x) // pw * pw, int(y) // ph * ph), -1) for x, y in zip(xs, ys)], dtype=np.int64)
-        levels.append((s, xs, ys, parent))
+        pl = len(levels) - 1 if prev is not None else -1
+        if split_last is None:
+            levels.append((s, xs, ys, parent))
+        else:
+            k = split_last if (si == len(sizes) - 1 and split_last > 1 and xs.size >= 64 * split_last) else 1
+            for q in range(k):
+                a, b = xs.size * q // k, xs.size * (q + 1) // k
+                levels.append((s, xs[a:b], ys[a:b], None if parent is None else parent[a:b], pl))
         prev = ((bw, bh), xs, ys)
     return levels
 
@@ -181,7 +191,7 @@ class FrameHotPath:
     between the bi refinement and the uni / bi decision (one vtmhip_smvd_batch_dev search per PU; one more bit on the bi rows, :2590-2593)."""
 
     def __init__(self, ctx, torch, device, pic_w, pic_h, org_stride, refs, search_ranges, motion_lambda=8.0, qp=32, sizes=(128, 64, 32, 16, 8),
-                 ctu_filter=None, transform_skip=False, bit_depth=10, pocs=None, chroma=None, bdof=True, affine=False, low_delay=False, smvd=None):
+                 ctu_filter=None, transform_skip=False, bit_depth=10, pocs=None, chroma=None, bdof=True, affine=False, low_delay=False, smvd=None, split_last=None):
         T, dev = torch, device
         self.ctx, self.torch, self.device = ctx, T, dev
         self.pic_w, self.pic_h, self.org_stride, self.lam = pic_w, pic_h, org_stride, motion_lambda
@@ -209,15 +219,21 @@ class FrameHotPath:
         if chroma is not None:
             cqp = chroma_qp(qp) + 6 * (bit_depth - 8)
             self.cqp_per, self.cqp_rem = cqp // 6, cqp % 6
-        self.levels, prev = [], None
+        self.levels = []
         sb = 0
-        for (s, xs, ys, parent) in quadtree_levels(pic_w, pic_h, sizes, None, ctu_filter):
+        # VTM_AMD_SPLIT_LAST=K (default 1 = off): the finest level as K levels over raster ranges of its PUs -- part 1's remaining stages run beside part 2's searches, and the tail
+        # behind the dependent chain of searches (the last level's bi refinement / SMVD / prediction / TU chains) would be 1 / K as long.  Measured (round 4, profiles/
+        # r04_split_last.txt): 12.12 / 12.22 / 12.29 / 12.50 ms for K = 1 .. 4 -- the picture is bound by the kernels' total time on the machine, not by that tail; off by default
+        split_last = int(os.environ.get("VTM_AMD_SPLIT_LAST", "1")) if split_last is None else int(split_last)
+        built = {}      # index in quadtree_levels' list -> the level record (empty levels are not built)
+        for qi, (s, xs, ys, parent, parent_q) in enumerate(quadtree_levels(pic_w, pic_h, sizes, None, ctu_filter, split_last)):
             n = xs.size
+            prev = built.get(parent_q)
             if n == 0:
-                prev = None
                 continue
             w, h = (s, s) if np.isscalar(s) else s                   # a level of the quadtree, or of a binary / ternary split shape
-            lvl = dict(size=s, w=w, h=h, npu=n, xs=xs, ys=ys, sb=sb)
+            lvl = dict(size=s, w=w, h=h, npu=n, xs=xs, ys=ys, sb=sb, parent_level=next((i for i, l in enumerate(self.levels) if l is prev), -1))
+            built[qi] = lvl
             blk = sb + np.arange(n, dtype=np.int64) * w * h          # compact per-PU slots of the level-wide sample buffers
             sb += n * w * h
             uj = np.zeros(R * n, ME_DT)
@@ -330,7 +346,6 @@ class FrameHotPath:
             lvl.update(ntu=ntu, nc=nc, ts=tw, tw=tw, th=th, cands=cl, tu=_Tab(T, dev, tj), tu_res=T.zeros((ntu * nc, 2), dtype=T.int64, device=dev), mts_test=T.zeros(ntu * nc, dtype=T.uint8, device=dev),
                        qcoef=T.zeros(ntu * nc * tw * th, dtype=T.int32, device=dev))
             self.levels.append(lvl)
-            prev = lvl
         self.NS = sb
         self.NP = sum(l["npu"] for l in self.levels)
         self.n_me_jobs = sum(l["npu"] * (R + (nref[0] if self.is_b else 0)) for l in self.levels)
@@ -489,7 +504,7 @@ class FrameHotPath:
         """numpy copies of every decision, per level (tests/cpu_chain.py, a host encoder, the multi-GPU gather read these)"""
         out = []
         for lvl in self.levels:
-            d = dict(size=lvl["size"], w=lvl["w"], h=lvl["h"], tw=lvl["tw"], th=lvl["th"], npu=lvl["npu"], ntu=lvl["ntu"], nc=lvl["nc"], ts=lvl["ts"], cands=lvl["cands"], xs=lvl["xs"], ys=lvl["ys"],
+            d = dict(size=lvl["size"], parent_level=lvl["parent_level"], w=lvl["w"], h=lvl["h"], tw=lvl["tw"], th=lvl["th"], npu=lvl["npu"], ntu=lvl["ntu"], nc=lvl["nc"], ts=lvl["ts"], cands=lvl["cands"], xs=lvl["xs"], ys=lvl["ys"],
                      uni_jobs=lvl["uni_jobs"].t.cpu().numpy().view(ME_DT).reshape(-1), uni_out=lvl["uni_out"].cpu().numpy().view(MEOUT_DT).reshape(-1),
                      uni_rows=lvl["uni_rows"].cpu().numpy().view(ROW_DT).reshape(-1), pus=lvl["pus"].cpu().numpy().view(PU_DT).reshape(-1),
                      tu_res=lvl["tu_res"].cpu().numpy(), mts_test=lvl["mts_test"].cpu().numpy())
