@@ -319,6 +319,8 @@ extern "C" void ref_motion_estimation( const vo_mest_cfg_t *cfg, const vo_mest_j
   r.pu.chromaFormat = CHROMA_400;
   r.cu.imv    = j->imv;
   r.cu.BcwIdx = BCW_DEFAULT;
+  if( j->bi && j->bcwWeight != 0 && j->bcwWeight != 4 )      // the rig searches list 0: the CU-level index whose list-0 weight is the job's
+    for( int i = 0; i < BCW_NUM; i++ ) if( getBcwWeight( ( uint8_t ) i, REF_PIC_LIST_0 ) == j->bcwWeight ) r.cu.BcwIdx = ( uint8_t ) i;
   r.rd.m_motionLambda = j->motionLambda;
   ClpRng clp; clp.min = 0; clp.max = ( 1 << j->bitDepth ) - 1; clp.bd = j->bitDepth; clp.n = 0;
   r.slice.m_clpRngs.comp[COMPONENT_Y] = clp;

@@ -1635,8 +1635,17 @@ void vo_motion_estimation( const vo_mest_cfg_t *cfg, const vo_mest_job_t *j, vo_
   {
     tmp = ( int16_t * ) malloc( sizeof( int16_t ) * w * h );
     for( int y = 0; y < h; y++ ) memcpy( tmp + y * w, j->org + ( ptrdiff_t ) y * j->orgStride, sizeof( int16_t ) * w );
-    vo_remove_high_freq( tmp, w, j->otherPred, j->otherStride, w, h );
-    pat = tmp; ps = w; fWeight = 0.5;
+    if( j->bcwWeight != 0 && j->bcwWeight != 4 )      /* a CU-level BCW weight (:3320-3328): weighted target, distortion weight |w| / 8 */
+    {
+      vo_remove_weight_high_freq( tmp, w, j->otherPred, j->otherStride, w, h, j->bcwWeight );
+      fWeight = fabs( ( double ) j->bcwWeight / 8.0 );
+    }
+    else
+    {
+      vo_remove_high_freq( tmp, w, j->otherPred, j->otherStride, w, h );
+      fWeight = 0.5;
+    }
+    pat = tmp; ps = w;
   }
   vo_me_ctx_t c;
   memset( &c, 0, sizeof( c ) );

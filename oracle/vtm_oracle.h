@@ -155,6 +155,8 @@ typedef struct
   int extraStart[16][2];                     /* m_uniMvList entries for (list, refIdx), newest first, NOT de-duplicated */
   int cachedIntMv;                           /* uni: the block-vector cache holds a vector for this (block, list, refIdx) (CacheBlkInfoCtrl::getMv, :3360-3368): rcMv = mvHor / mvVer
                                                 (that integer vector in internal precision), xTZSearch with bFastSettings (:3434-3441) */
+  int bcwWeight;                             /* bi: getBcwWeight( cu.BcwIdx, searched list ) in {-2, 3, 5, 10} under a CU-level BCW weight; 0 or 4: the default pair.  The search target is
+                                                then removeWeightHighFreq( org, otherPred, w ) (Buffer.h:417-460) and the distortion weight |w| / 8 (xGetMEDistortionWeight :7666-7676) */
 } vo_mest_job_t;
 
 typedef struct

@@ -183,6 +183,7 @@ def oracle_mest_job(scene, j, keep):
     t.numExtraStart = len(j["extra"])
     for i, (a, b) in enumerate(j["extra"]):
         t.extraStart[i][0], t.extraStart[i][1] = a, b
+    t.bcwWeight = j.get("bcw", 0)      # bi: the searched list's CU-level BCW weight (0: the default pair)
     return t
 
 

@@ -71,7 +71,7 @@ class MestJob(C.Structure):
                 ("picH", C.c_int), ("ctuSize", C.c_int), ("bitDepth", C.c_int), ("bi", C.c_int), ("imv", C.c_int), ("mvpIdx", C.c_int),
                 ("numAmvpCand", C.c_int), ("mvPredHor", C.c_int), ("mvPredVer", C.c_int), ("mvHor", C.c_int), ("mvVer", C.c_int),
                 ("amvpCand", (C.c_int * 2) * 2), ("mvpIdxBits", C.c_uint * 2), ("bits", C.c_uint), ("searchRange", C.c_int),
-                ("motionLambda", C.c_double), ("numExtraStart", C.c_int), ("extraStart", (C.c_int * 2) * 16), ("cachedIntMv", C.c_int)]
+                ("motionLambda", C.c_double), ("numExtraStart", C.c_int), ("extraStart", (C.c_int * 2) * 16), ("cachedIntMv", C.c_int), ("bcwWeight", C.c_int)]
 
 
 class MestResult(C.Structure):

@@ -40,6 +40,7 @@ def hip_jobs(scene, jobs, others):
         t.numExtraStart = len(j["extra"])
         for i, (a, b) in enumerate(j["extra"]):
             t.extraStart[i][0], t.extraStart[i][1] = a, b
+        t.flags = (j.get("bcw", 0) & 0xff) << 8      # VTMHIP_MEJ_BCW_FLAGS: the searched list's CU-level BCW weight of a bi job
     return arr
 
 
@@ -59,6 +60,38 @@ def run_device(ctx, scene, jobs, cfgv, uniform_imv=-1, uniform_square=0, max_wh=
     ctx.motion_estimation_batch(pic, cfg, d_cur.ptr, d_ref.ptr, d_oth.ptr, d_jobs.ptr, len(jobs), max_wh[0], max_wh[1], d_res.ptr)
     res = (MeOut * len(jobs)).from_buffer_copy(d_res.to_host(np.uint8).tobytes())
     return [(r.mvHor, r.mvVer, r.mvPredHor, r.mvPredVer, r.mvpIdx, r.bits, r.cost) for r in res], res
+
+
+@pytest.mark.parametrize("weight,uniform", [(-2, 0), (3, 0), (5, 0), (10, 0), (-2, 1), (3, 1)])
+def test_bi_rows_under_a_bcw_weight(ctx, weight, uniform):
+    """Bi rows under a CU-level BCW weight (flags bits 8..15): the weighted target of removeWeightHighFreq, the distortion weight |w| / 8 -- a mixed batch (pattern copies made
+    by the library) and uniform 16x16 batches through the fused exhaustive / fractional / AMVR kernels (the -2 weight leaves the packed 16-bit Hadamard range: wideOrg)."""
+    L = ol.oracle()
+    scene = me_util.Scene(416, 240, hard=True)
+    sizes = ([16], [16]) if uniform else None
+    jobs = [j for j in me_util.random_mest_jobs(scene, 300, seed=950 + weight + uniform, **({"sizes": sizes} if sizes else {})) if j["bi"]]
+    cfgv = (4, 1, 1, 0, 1)
+    cfg = ol.MestCfg(*cfgv)
+    for imv in ((0, 1, 2, 3) if uniform else (None,)):
+        js = [dict(j) for j in jobs]
+        for j in js:
+            j["bcw"] = weight
+            if imv is not None:
+                j["imv"] = imv
+                j["cands"] = [[me_util._round_amvr(v, imv) for v in c] for c in j["cands"]]
+                j["mvPred"] = tuple(j["cands"][j["mvpIdx"]])
+        exp = []
+        for j in js:
+            keep = []
+            t = me_util.oracle_mest_job(scene, j, keep)
+            r = ol.MestResult()
+            L.vo_motion_estimation(C.byref(cfg), C.byref(t), C.byref(r))
+            exp.append(r.key())
+        if uniform:
+            got, _ = run_device(ctx, scene, js, cfgv, uniform_imv=imv, uniform_square=1, max_wh=(16, 16), uniform_bi=2, pattern_given=0)
+        else:
+            got, _ = run_device(ctx, scene, js, cfgv)
+        assert got == exp, (weight, uniform, imv)
 
 
 def test_matches_golden_from_reference(ctx):

@@ -206,6 +206,26 @@ def test_motion_estimation_equals_reference_xMotionEstimation(oracle, reflib, us
     assert len(seen) == 8   # uni / bi x the four AMVR modes
 
 
+@pytest.mark.parametrize("weight", [-2, 3, 5, 10])
+def test_motion_estimation_bi_under_a_bcw_weight_equals_reference(oracle, reflib, weight):
+    """The bi refinement of xMotionEstimation under a CU-level BCW weight (cu.BcwIdx != BCW_DEFAULT, InterSearch.cpp:3320-3328, 3483, 7666-7676): the search target is
+    removeWeightHighFreq( org, otherPred, w ) and the distortion weight |w| / 8 -- the real member on the rig vs the oracle, the four AMVR modes."""
+    scene = me_util.Scene(416, 240, hard=True)
+    cfg = ol.MestCfg(4, 1, 1, 0, 1)
+    jobs = [j for j in me_util.random_mest_jobs(scene, 420, seed=900 + weight) if j["bi"]]
+    seen = set()
+    for j in jobs:
+        j["bcw"] = weight
+        keep = []
+        t = me_util.oracle_mest_job(scene, j, keep)
+        a, b = ol.MestResult(), ol.MestResult()
+        oracle.vo_motion_estimation(C.byref(cfg), C.byref(t), C.byref(a))
+        reflib.ref_motion_estimation(C.byref(cfg), C.byref(t), C.byref(b))
+        assert a.key() == b.key(), (j, a.key(), b.key())
+        seen.add(j["imv"])
+    assert len(jobs) >= 60 and len(seen) == 4
+
+
 def test_pred_inter_blk_luma_and_chroma(oracle, reflib):
     """InterPrediction::xPredInterBlk on a rig (real member function, Picture aliasing our planes) vs vo_mc_block: luma 8-tap / chroma
     4-tap at 1/32 phase, uni (rounded, clipped) and bi (14-bit intermediates), alternative half-sample filter."""

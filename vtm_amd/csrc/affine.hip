@@ -424,7 +424,10 @@ __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( PACKED
   __shared__ Mv3                sMv;      // the model of the next gradient step (written by thread 0)
   __shared__ Mv3                sPrev[7]; // models of the earlier gradient steps (thread 0; the AMVR encoder option compares against them)
   __shared__ int                sCtl;     // loop control of the gradient iterations: 0 continue, 1 stop
-  const vtmhip_affine_me_job &j = jobs[blockIdx.x];
+  // XCD-aware job order: the hardware deals workgroups round-robin over the 8 XCDs; workgroup b takes the job at position xcd_order( b ), so that the jobs one XCD works on at
+  // any moment are NEIGHBOURS in the table (PUs in raster order: overlapping reference windows) and share that XCD's L2 (the 16x16 level read 628 MB from HBM per launch without)
+  const int jobIdx = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x );
+  const vtmhip_affine_me_job &j = jobs[jobIdx];
   if( ( j.sixParam != 0 ) != SIX ) return;      // a mixed batch is launched once per model; every job belongs to exactly one of the two launches
   // A CU-level BCW weight of -2 makes the bi-pred target -4 org + 5 pred: differences up to 6138 leave the packed 16-bit Hadamard levels.  Such jobs belong to the 32-bit
   // variant (launched beside the packed one by vtmhip_xAffineMotionEstimation_bcw_batch_dev); every other job of a <= 10-bit picture to the packed variant.
@@ -724,7 +727,7 @@ __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( PACKED
     vtmhip_affine_me_out o;
     for( int i = 0; i < 3; i++ ) { o.mv[i][0] = best.v[i][0]; o.mv[i][1] = best.v[i][1]; }
     o.bits = bitsBest; o.cost = costBest; o.iterations = iterations; o.refinements = refinements; o.mvpIdx = mvpIdx;
-    results[blockIdx.x] = o;
+    results[jobIdx] = o;
   }
 }
 

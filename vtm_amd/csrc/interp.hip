@@ -390,7 +390,10 @@ struct FracSq
   static constexpr int ITEMS = 9 * TILES;                       // per PU per round
   static constexpr int BLOCK = TILES == 16 ? 192 : TILES == 256 ? 512 : 256;   // 128x128: 72 KB of LDS = two workgroups per CU, so eight waves each (768 items per plane pass = 1.5 trips): 3.13 -> 3.03 ms per picture; 16 waves 3.09; 64x64 with six waves 3.23
   static constexpr int JPW   = TILES == 16 ? 2 : ITEMS >= BLOCK ? 1 : BLOCK / ITEMS;   // 8x8: 28, 16x8: 14, 16x16 / 32x8: 7, 32x16: 3, larger: 1
-  static constexpr int MINW  = 4;                                // waves per SIMD the register budget is sized for (128 VGPRs; the dot-product V pass fits every size)
+#ifndef VTMHIP_FRAC_RECT_MINW
+#define VTMHIP_FRAC_RECT_MINW 4
+#endif
+  static constexpr int MINW  = ( W != H ) ? VTMHIP_FRAC_RECT_MINW : 4;   // waves per SIMD the register budget is sized for (128 VGPRs; the dot-product V pass fits every square size; the rectangles' Hadamard pairs spill 11 - 21 registers there)
   static constexpr int WLD   = W + 8;                           // window stride
   static constexpr int WIN   = ( H + 8 ) * WLD;                 // window samples per PU
   static constexpr int PLANE = ( H + 8 ) * W;                   // one H-pass plane

@@ -542,9 +542,12 @@ __global__ __launch_bounds__( NW ? 64 * NW : 64 ) void smvd_tile_kernel( vtmhip_
   __shared__ unsigned sDist[8];
   const int lane = threadIdx.x, g = GROUP ? lane / LPP : 0, l = GROUP ? lane - g * LPP : lane, slot = GROUP ? l / T : 0, tile = GROUP ? l - slot * T : 0;
   auto tile_xy = [&]( int tl, int &tx, int &ty ) { if( TX >= TY ) { ty = tl / TX; tx = tl - ty * TX; } else { tx = tl / TY; ty = tl - tx * TY; } };   // pair halves adjacent
-  const int puRaw = blockIdx.x * PPW + g;
+  // XCD-aware order of the WORKGROUPS (the hardware deals them round-robin over the 8 XCDs): workgroup b takes the PPW consecutive PUs of position xcd_order( b ) -- neighbouring
+  // PUs (raster order: overlapping reference windows) then run on one XCD and share its L2.  (Round 3 permuted the PU index instead: with PPW > 1 that scattered a wave's PUs over
+  // eight distant regions of the picture and sent neighbours to different XCDs -- 1.2 GB of HBM-side traffic for the 8x8 launch.)
+  const int puRaw = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x ) * PPW + g;
   const bool live = puRaw < n;
-  vtmhip_smvd_job &j = jobs[live ? xcd_order( puRaw, n ) : 0];
+  vtmhip_smvd_job &j = jobs[live ? puRaw : 0];
 
   TileJob t;
   t.orgStride = j.orgStride; t.strideA = j.refStride[0]; t.strideB = j.refStride[1];
