@@ -450,6 +450,14 @@ def main():
     if use_dist:
         dist.all_reduce(satd_g)
 
+    # SAD candidates of the integer searches (SURVEY.md 8d prices one at 4 * W * H >> subShift algorithmic bytes): counted after the timed region by running the levels' uni
+    # searches once more through the public TZ call (the kernel keeps the count per search) -- rank 0, one GPU
+    sad_cands = None
+    if rank == 0 and world == 1 and sim <= 1:
+        try:
+            sad_cands = fme.sad_candidates(cur.data_ptr(), dpb.data_ptr())
+        except Exception as e:      # a statistic: never fails the line
+            print("sad_candidates:", e, file=sys.stderr)
     if rank == 0:
         wc = fme.work_counts()
         # ---- roofline of the dominant kernel: vector-ALU ISSUE (these kernels are integer / packed-16-bit instruction streams; their HBM traffic is
@@ -521,6 +529,17 @@ def main():
             "satd_gblocks_per_s": float(satd_g.item()),
             "stages_ms": stage_acc, "kernels": kern, "workload_key": wkey,
         }
+        if sad_cands:
+            tz_ms = sum(kern[k]["ms_per_step"] for k in ("tz_search_kernel", "tz_raster_cols_kernel") if k in kern)
+            alg = sum(c * ((4 * w * h) >> ss) for (w, h, ss, n, c) in sad_cands)
+            out["integer_search"] = {"levels": [{"pu": "%dx%d" % (w, h), "subShift": ss, "searches": n, "candidates": c, "candidates_per_search": c / max(1, n),
+                                                 "algorithmic_bytes": c * ((4 * w * h) >> ss)} for (w, h, ss, n, c) in sad_cands],
+                                     "candidates_per_picture": sum(c for (_, _, _, _, c) in sad_cands), "algorithmic_GB_per_picture": alg / 1e9,
+                                     "kernels_ms_per_picture": tz_ms, "algorithmic_GBps": alg / 1e9 / (tz_ms * 1e-3) if tz_ms else None,
+                                     "note": "SURVEY.md 8(d): a SAD candidate = 4 * W * H >> subShift algorithmic bytes (org + reference samples); candidates = sum of the "
+                                             "TZ kernel's per-search count (start points, diamond rounds, raster scan, star refinement) of every uni search of the picture; the "
+                                             "rate is against tz_search_kernel + tz_raster_cols_kernel time.  The samples are re-used out of L1 / L2 (counter traffic: roofline.traffic), "
+                                             "so this is a work rate, not an HBM fraction"}
         if dom:
             out["roofline"] = issue_roofline(dom, kern[dom]["ms_per_step"], kern[dom]["launches_per_step"])
             # the next two kernel families by time, same definition (the three largest are within 6 % of each other at the default operating point)

@@ -533,6 +533,30 @@ class FrameHotPath:
                 out.append(lvl["aff_out"].reshape(-1))
         return out
 
+    def sad_candidates(self, org_ptr, dpb_ptr):
+        """After run(): the integer-search candidates every level's uni searches evaluated (sum of vtmhip_me_result.nEval, the statistic the TZ kernel keeps): the same searches
+        once more through vtmhip_tz_search_batch_dev on job records rebuilt from the rows (predictor as chosen by the AMVP stage, FEN row sub-sampling).  SURVEY.md 8(d) prices a
+        SAD candidate at 4 * W * H >> subShift bytes: bench.py reports sum( candidates * that ) per picture beside the search kernels' time.  -> [(w, h, subShift, searches, candidates)]"""
+        T, out = self.torch, []
+        tz_dt, res_dt = np.dtype(TzJob), np.dtype(MeResult)
+        for lvl in self.levels:
+            uj = lvl["uni_jobs"].t.cpu().numpy().view(ME_DT).reshape(-1)
+            n, w, h = uj.size, lvl["w"], lvl["h"]
+            ss = subshift_mode2(w, h)
+            tj = np.zeros(n, tz_dt)
+            for f in ("orgOff", "refOff", "orgStride", "refStride", "puX", "puY", "width", "height", "motionLambda", "searchRange"):
+                tj[f] = uj[f]
+            down = lambda v: np.where(v >= 0, (v + 1) >> 2, (v + 2) >> 2)      # noqa: E731  Mv::changePrecision( INTERNAL -> QUARTER )
+            tj["subShift"], tj["predHor"], tj["predVer"] = ss, down(uj["mvPredHor"].astype(np.int64)), down(uj["mvPredVer"].astype(np.int64))
+            tj["mvHor"], tj["mvVer"], tj["firstSearchStop"] = uj["mvPredHor"], uj["mvPredVer"], 1
+            d_j = T.from_numpy(tj.view(np.uint8)).to(self.device)
+            d_r = T.zeros(n * res_dt.itemsize, dtype=T.uint8, device=self.device)
+            self.ctx.tz_search_batch(lvl["pic"], org_ptr, dpb_ptr, d_j.data_ptr(), n, d_r.data_ptr())
+            T.cuda.synchronize()
+            r = d_r.cpu().numpy().view(res_dt).reshape(-1)
+            out.append((w, h, ss, n, int(r["nEval"].astype(np.int64).sum())))
+        return out
+
     def work_counts(self):
         R = self.nref[0] + self.nref[1]
         return dict(pus=self.NP, uni_searches=R * self.NP, bi_searches=(self.nref[0] if self.is_b else 0) * self.NP,
