@@ -39,7 +39,7 @@ SIMDS, CLOCK_HZ = 1024, 2.4e9          # 256 CUs x 4 SIMDs, peak shader clock (M
 GUIDE_CYCLES = 2.0                     # MI355X_MICROARCH.md: one wave64 VALU instruction per 2 cycles per SIMD (>= 2 waves) -- the machine's full-rate issue peak
 MIX_CLOCK_HZ = 2.3e9                   # the clock the issue micro-benchmark actually held on mixed streams (implied_MHz 2 280 .. 2 360, profiles/r02_valu_issue.jsonl)
 SALU_CYCLES = 4.03   # measured: cycles per scalar instruction per SIMD (profiles/r02_valu_issue.jsonl, s_add_u32, 1 .. 8 waves)
-KERNELS = ("tz_search_kernel", "tz_raster_cols_kernel", "frac_search_sq_kernel", "full_search_sq_kernel", "full_search_kernel", "motion_comp_kernel", "tu_chain_uni_kernel",
+KERNELS = ("tz_search_kernel", "tz_group_kernel", "tz_raster_cols_kernel", "frac_search_sq_kernel", "full_search_sq_kernel", "full_search_kernel", "motion_comp_kernel", "tu_chain_uni_kernel",
            "dist_uniform_kernel", "tu_ts_kernel", "bdof_kernel", "tu_chain_lane_kernel", "affine_me_kernel", "smvd_tile_kernel", "smvd_kernel")
 
 
@@ -81,7 +81,7 @@ def parse():
     return a
 
 
-KERNEL_SRC = {"tz_search_kernel": "me.hip", "tz_raster_cols_kernel": "me.hip", "full_search_sq_kernel": "me.hip", "full_search_kernel": "me.hip", "frac_search_sq_kernel": "interp.hip",
+KERNEL_SRC = {"tz_search_kernel": "me.hip", "tz_group_kernel": "me.hip", "tz_raster_cols_kernel": "me.hip", "full_search_sq_kernel": "me.hip", "full_search_kernel": "me.hip", "frac_search_sq_kernel": "interp.hip",
               "motion_comp_kernel": "mc.hip", "bdof_kernel": "mc.hip", "tu_chain_uni_kernel": "transform.hip", "tu_ts_kernel": "transform.hip", "tu_chain_lane_kernel": "transform.hip",
               "dist_uniform_kernel": "dist.hip", "satd8_grid_kernel": "dist.hip", "affine_me_kernel": "affine.hip", "smvd_tile_kernel": "smvd.hip", "smvd_kernel": "smvd.hip"}
 
@@ -530,7 +530,7 @@ def main():
             "stages_ms": stage_acc, "kernels": kern, "workload_key": wkey,
         }
         if sad_cands:
-            tz_ms = sum(kern[k]["ms_per_step"] for k in ("tz_search_kernel", "tz_raster_cols_kernel") if k in kern)
+            tz_ms = sum(kern[k]["ms_per_step"] for k in ("tz_search_kernel", "tz_group_kernel", "tz_raster_cols_kernel") if k in kern)
             alg = sum(c * ((4 * w * h) >> ss) for (w, h, ss, n, c) in sad_cands)
             out["integer_search"] = {"levels": [{"pu": "%dx%d" % (w, h), "subShift": ss, "searches": n, "candidates": c, "candidates_per_search": c / max(1, n),
                                                  "algorithmic_bytes": c * ((4 * w * h) >> ss)} for (w, h, ss, n, c) in sad_cands],
@@ -538,7 +538,7 @@ def main():
                                      "kernels_ms_per_picture": tz_ms, "algorithmic_GBps": alg / 1e9 / (tz_ms * 1e-3) if tz_ms else None,
                                      "note": "SURVEY.md 8(d): a SAD candidate = 4 * W * H >> subShift algorithmic bytes (org + reference samples); candidates = sum of the "
                                              "TZ kernel's per-search count (start points, diamond rounds, raster scan, star refinement) of every uni search of the picture; the "
-                                             "rate is against tz_search_kernel + tz_raster_cols_kernel time.  The samples are re-used out of L1 / L2 (counter traffic: roofline.traffic), "
+                                             "rate is against tz_search_kernel + tz_group_kernel + tz_raster_cols_kernel time.  The samples are re-used out of L1 / L2 (counter traffic: roofline.traffic), "
                                              "so this is a work rate, not an HBM fraction"}
         if dom:
             out["roofline"] = issue_roofline(dom, kern[dom]["ms_per_step"], kern[dom]["launches_per_step"])

@@ -105,7 +105,7 @@ int vtmhip_internal_affine_me_launch( vtmhip_ctx *ctx, const vtmhip_pic_params *
                                       const vtmhip_affine_me_job *d_jobs, int n, int maxWidth, int maxHeight, vtmhip_affine_me_out *d_results, int models );   // affine.hip
 struct MeFuse;      // mest_glue.hpp
 int vtmhip_internal_tz_search( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_tz_job *d_jobs, int n,
-                               vtmhip_me_result *d_results, const MeFuse *fuse );   // me.hip: vtmhip_tz_search_batch_dev, optionally fused with the row bookkeeping around it
+                               vtmhip_me_result *d_results, const MeFuse *fuse, int uniformW, int uniformH );   // me.hip: vtmhip_tz_search_batch_dev (uniformW / H != 0: every job has this shape), optionally fused with the row bookkeeping around it
 struct FullFuse;    // mest_glue.hpp
 int vtmhip_internal_full_search( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_full_job *d_jobs, int n,
                                  int width, int height, vtmhip_me_result *d_results, const FullFuse *fuse );   // me.hip: the exhaustive searches, optionally fused

@@ -1262,6 +1262,470 @@ void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBas
 }
 
 
+// ---- small blocks: FOUR searches per wave ---------------------------------------------------------------------------------------------------------
+// tz_group_kernel: a search owns one DPP row (16 lanes) and a lane is one CANDIDATE of the round -- a round of xTZ8PointDiamondSearch has at most 16 points, and lane `slot` takes the
+// slot-th point of the round's list in the reference's evaluation order (:504-705; points outside the search range are skipped there and idle here, which keeps the order).  The lane
+// walks its candidate's whole block (8 .. 64 segments of 8 samples: uniform batches of 8x8 .. 32x32 PUs; the original block sits in LDS, item-major) and the round's first strict
+// minimum is ONE row-wide DPP minimum over (cost << 4 | slot).  No per-candidate cross-lane sum, no candidate list in LDS, no scalar control: the search state is per-lane (equal in
+// the 16 lanes of a row) and the four searches of a wave step through ONE loop -- a state machine (start round, first diamond loop, two-point step, raster decision, star refinement)
+// whose single evaluation site serves whatever phase each row is in, so a wave runs max-over-its-rows rounds.  Against one wave per search (tz_search_kernel<1>: 700 vector + 600 scalar
+// instructions per 8x8 search, vector port 60-78 % busy) a search costs about a third of the instructions.
+// Takes the FUSED uni rows only (job record from the xMotionEstimation row, mest_glue.hpp), modes 0 / 1; the few searches that go to the raster kernel resume in tz_search_kernel<1>.
+#ifndef VTMHIP_TZG_ALIGNED
+#define VTMHIP_TZG_ALIGNED 0
+#endif
+#ifndef VTMHIP_TZG_WAVES
+#define VTMHIP_TZG_WAVES 3
+#endif
+enum { GP_START = 0, GP_START15, GP_DIA1, GP_TWO1, GP_DIA2, GP_TWO2 };
+
+template<int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64( unsigned long long v )
+{
+  return ( ( unsigned long long ) dpp_u32<CTRL>( ( unsigned ) ( v >> 32 ) ) << 32 ) | dpp_u32<CTRL>( ( unsigned ) v );
+}
+__device__ __forceinline__ unsigned row_min_u32( unsigned v )      // minimum over the 16 lanes of a DPP row; every lane of the row gets it
+{
+  v = min( v, dpp_u32<DPP_XOR1>( v ) );
+  v = min( v, dpp_u32<DPP_XOR2>( v ) );
+  v = min( v, dpp_u32<DPP_HALF_MIRROR>( v ) );
+  v = min( v, dpp_u32<DPP_MIRROR>( v ) );
+  return v;
+}
+__device__ __forceinline__ unsigned long long row_min_u64( unsigned long long v )
+{
+  unsigned long long o;
+  o = dpp_u64<DPP_XOR1>( v ); v = o < v ? o : v;
+  o = dpp_u64<DPP_XOR2>( v ); v = o < v ? o : v;
+  o = dpp_u64<DPP_HALF_MIRROR>( v ); v = o < v ? o : v;
+  o = dpp_u64<DPP_MIRROR>( v ); v = o < v ? o : v;
+  return v;
+}
+__device__ __forceinline__ int row_read( int v, int lane, int slot )      // v of lane `slot` of this lane's row
+{
+  return __builtin_amdgcn_ds_bpermute( ( ( lane & 48 ) + slot ) << 2, v );
+}
+
+// SAD of the whole block at candidate (x, y): SPR segments per row, 8 segments (= 8 / SPR rows) per trip with their loads in flight together
+template<int SPR>
+__device__ __forceinline__ unsigned grp_sad( const MeJob &j, const uint4 *so, int x, int y )
+{
+  const int16_t *p  = j.ref + ( long ) y * j.refStride + x;
+  const long     cs = ( long ) j.refStride << j.ss;
+  unsigned       s  = 0;
+  for( int it0 = 0; it0 < j.items; it0 += 8 )
+  {
+    Pel8 b[8];
+#if VTMHIP_TZG_ALIGNED
+    // (a 16-byte load from an address that is only 2-byte aligned runs at 0.28x the rate, see ld8: the dwords below + a funnel shift)
+    {
+      const unsigned  sh = ( ( unsigned ) reinterpret_cast<uintptr_t>( p ) & 2u ) << 3;
+      const int16_t  *pa = reinterpret_cast<const int16_t *>( reinterpret_cast<uintptr_t>( p ) & ~( uintptr_t ) 3 );
+      Dw4      a4[8];
+      unsigned e[8];
+#pragma unroll
+      for( int q = 0; q < 8; q++ )
+      {
+        const unsigned *w = reinterpret_cast<const unsigned *>( pa + ( q / SPR ) * cs + ( q % SPR ) * 8 );
+        a4[q] = *reinterpret_cast<const Dw4 *>( w );
+        e[q]  = w[4];
+      }
+#pragma unroll
+      for( int q = 0; q < 8; q++ )
+      {
+        b[q].v[0] = __builtin_amdgcn_alignbit( a4[q].v[1], a4[q].v[0], sh ); b[q].v[1] = __builtin_amdgcn_alignbit( a4[q].v[2], a4[q].v[1], sh );
+        b[q].v[2] = __builtin_amdgcn_alignbit( a4[q].v[3], a4[q].v[2], sh ); b[q].v[3] = __builtin_amdgcn_alignbit( e[q], a4[q].v[3], sh );
+      }
+    }
+#else
+#pragma unroll
+    for( int q = 0; q < 8; q++ ) b[q] = *reinterpret_cast<const Pel8 *>( p + ( q / SPR ) * cs + ( q % SPR ) * 8 );
+#endif
+#pragma unroll
+    for( int q = 0; q < 8; q++ )
+    {
+      const uint4 a = so[it0 + q];
+      s = sad2( a.x, b[q].v[0], s ); s = sad2( a.y, b[q].v[1], s ); s = sad2( a.z, b[q].v[2], s ); s = sad2( a.w, b[q].v[3], s );
+    }
+    p += ( 8 / SPR ) * cs;
+  }
+  return s;
+}
+
+// The search WINDOW of a row's search in LDS.  Every candidate of the dependent rounds lies within a few samples of the start point, and a candidate reads 16 bytes of each of
+// its rows: through the vector memory path that is one 128-byte cache-line request per (candidate, row) -- 200 - 450 requests per search against the 30 - 50 lines the window has, with
+// 64 searches per CU sharing a 32 KB L1 (measured: the kernel ran at the L2's request rate whatever its occupancy or the alignment of the loads).  After the start round the row's 16
+// lanes copy the (w + 2 R) x (h + 2 R) window around the start point to LDS in aligned 16-byte chunks (each cache line once); a candidate inside reads its segments from there
+// (ds_read_b128 at any 2-byte offset: gfx950 takes unaligned DS addresses), one outside -- the far rounds of a long search -- keeps the global path.
+constexpr int TZG_R = 8;      // the window reaches R samples beyond the block on every side: the rounds at distance 1 .. 8 around the start point
+template<int SPR> struct TzgWin
+{
+  static constexpr int WBYTES = ( SPR * 8 + 2 * TZG_R ) * 2;                                    // the window's samples of one row
+  static constexpr int CH     = ( WBYTES + 14 + 15 ) / 16;                                      // aligned 16-byte chunks that cover them whatever the start address modulo 16
+  static constexpr int PITCH  = ( CH * 16 ) % 64 == 0 ? CH * 16 + 16 : CH * 16;                 // (a pitch that is a multiple of 64 bytes would put every other row on the same banks)
+};
+
+template<int SPR, int SS>
+__device__ __forceinline__ unsigned grp_sad_win( const unsigned char *wp, const uint4 *so, int items )
+{
+  unsigned s = 0;
+  for( int it0 = 0; it0 < items; it0 += 8 )
+  {
+    Pel8 b[8];
+#pragma unroll
+    for( int q = 0; q < 8; q++ ) b[q] = *reinterpret_cast<const Pel8 *>( wp + ( ( q / SPR ) << SS ) * TzgWin<SPR>::PITCH + ( q % SPR ) * 16 );
+#pragma unroll
+    for( int q = 0; q < 8; q++ )
+    {
+      const uint4 a = so[it0 + q];
+      s = sad2( a.x, b[q].v[0], s ); s = sad2( a.y, b[q].v[1], s ); s = sad2( a.z, b[q].v[2], s ); s = sad2( a.w, b[q].v[3], s );
+    }
+    wp += ( ( 8 / SPR ) << SS ) * TzgWin<SPR>::PITCH;
+  }
+  return s;
+}
+
+// first strict minimum of the row's (cost, slot) pairs: cost (~0: no candidate) and the winner's slot
+// (SMALLKEY: keys below 16 -- the slots of a round; the branch must be the same for the 16 lanes of a row, the DPP steps read their neighbours)
+template<bool SMALLKEY>
+__device__ __forceinline__ void row_argmin( const MeJob &j, unsigned long long c, bool valid, unsigned key, unsigned long long &minCost, unsigned &minKey )
+{
+  if( SMALLKEY && j.tiny )      // cost < 2^26 (see MeJob::tiny): one 32-bit key
+  {
+    const unsigned m = row_min_u32( valid ? ( ( unsigned ) c << 4 ) | key : 0xffffffffu );
+    minCost = m == 0xffffffffu ? ~0ull : ( unsigned long long ) ( m >> 4 );
+    minKey  = m & 15u;
+  }
+  else
+  {
+    const unsigned long long cc = valid ? c : ~0ull;
+    minCost = row_min_u64( cc );
+    minKey  = row_min_u32( valid && cc == minCost ? key : 0xffffffffu );
+  }
+}
+
+template<int SPR, int SS>
+__global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( VTMHIP_TZG_WAVES ) ) ) void tz_group_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase, int numJobs,
+                                                         vtmhip_me_result *__restrict__ results, int mode, TzSaved *__restrict__ saved, int *__restrict__ list, int totCap, int itemsMax,
+                                                         int winRows, MeFuse fu )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char sDyn[];      // [16 searches]: itemsMax segments of the original block + winRows rows of the search window
+  const int lane = threadIdx.x & 63, wv = ( int ) ( threadIdx.x >> 6 ), row = lane >> 4, slot = lane & 15;
+  const int blk = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x );
+  const int jobIdx = blk * 16 + wv * 4 + row;
+  if( jobIdx >= numJobs ) return;      // whole rows leave
+  unsigned char *sMine = sDyn + ( size_t ) ( wv * 4 + row ) * ( ( size_t ) itemsMax * 16 + ( size_t ) winRows * TzgWin<SPR>::PITCH );
+  uint4         *so  = reinterpret_cast<uint4 *>( sMine );
+  unsigned char *win = sMine + ( size_t ) itemsMax * 16;
+
+  // the job from the xMotionEstimation row (every lane of the row derives the same record)
+  vtmhip_me_job &mj = fu.me[jobIdx];
+  int mvpIdx = mj.mvpIdx, predH = mj.mvPredHor, predV = mj.mvPredVer;
+  if( fu.amvpDout )      // xEstimateMvPredAMVP (:3088-3128): the first candidate with the smallest template cost
+  {
+    unsigned bits = mj.bits;
+    const unsigned long long c0 = fu.amvpDout[2 * ( long ) jobIdx] + mg::rate( mj.motionLambda, mj.mvpIdxBits[0] );
+    const unsigned long long c1 = mj.numAmvpCand > 1 ? fu.amvpDout[2 * ( long ) jobIdx + 1] + mg::rate( mj.motionLambda, mj.mvpIdxBits[1] ) : ~0ull;
+    mvpIdx = c0 > c1 ? 1 : 0;
+    predH = mvpIdx ? mj.amvpCand[1][0] : mj.amvpCand[0][0]; predV = mvpIdx ? mj.amvpCand[1][1] : mj.amvpCand[0][1];
+    if( fu.addIdxBits ) bits += mvpIdx ? mj.mvpIdxBits[1] : mj.mvpIdxBits[0];
+    // (every lane has read the row's fields above before lane 0 of the row rewrites them: the loads' results are consumed -- c0 / c1 / predH -- before the stores issue in program order)
+    if( slot == 0 )
+    {
+      mj.mvPredHor = predH; mj.mvPredVer = predV; mj.mvpIdx = ( uint8_t ) mvpIdx; mj.bits = bits;
+      if( fu.distBiP ) fu.distBiP[jobIdx] = c0 > c1 ? c1 : c0;
+    }
+  }
+  vtmhip_tz_job tj;
+  mg::make_tz_job_scalars( fu.cfg, mj, fuse_pat_off( fu, mj ), fuse_pat_stride( fu, mj ), predH, predV, tj );
+
+  MeJob j;
+  j.org = orgBase + tj.orgOff; j.ref = refBase + tj.refOff; j.orgStride = tj.orgStride; j.refStride = tj.refStride;
+  j.w = tj.width; j.h = tj.height; j.ss = tj.subShift; j.imvShift = ( unsigned ) tj.imvShift; j.predHor = tj.predHor; j.predVer = tj.predVer; j.costScale = 2; j.lambda = tj.motionLambda;
+  j.horMax = ( pic.picW + 8 - tj.puX - 1 ) << 4; j.horMin = ( -pic.ctuSize - 8 - tj.puX + 1 ) << 4;
+  j.verMax = ( pic.picH + 8 - tj.puY - 1 ) << 4; j.verMin = ( -pic.ctuSize - 8 - tj.puY + 1 ) << 4;
+  j.seg = 8; j.segsPerRow = SPR; j.items = SPR * ( ( j.h + ( 1 << j.ss ) - 1 ) >> j.ss ); j.bias = 0;
+  j.narrow = j.lambda >= 0.0 && j.lambda * 126.0 < 2147483648.0;
+  j.tiny   = j.narrow && ( double ) ( j.w * j.h ) * ( double ) ( ( 1 << pic.bitDepth ) - 1 ) + j.lambda * 126.0 < 67108864.0;
+  if( j.w != SPR * 8 || j.ss != SS || j.items > itemsMax || ( j.items & 7 ) || j.h + 2 * TZG_R > winRows ) return;      // (the caller promised a uniform batch of this shape: never true)
+
+  // original block -> LDS, item-major
+  for( int it = slot; it < j.items; it += 16 )
+  {
+    const Pel8 a = *reinterpret_cast<const Pel8 *>( j.org + ( long ) ( ( it / SPR ) << j.ss ) * j.orgStride + ( it % SPR ) * 8 );
+    so[it] = make_uint4( a.v[0], a.v[1], a.v[2], a.v[3] );
+  }
+
+  const bool fast = tj.fastSettings != 0, firstStop = tj.firstSearchStop != 0;
+  const int  iRaster = fast ? 8 : 5, searchRange = tj.searchRange;
+
+  // start candidates (:3675-3762) in the reference's order: slot 0 rcMv, slot 1 the zero vector (when tested), slots 2 .. 15 the m_uniMvList entries 0 .. 13 (an entry equal to an earlier
+  // one is skipped); entry 14 follows in a round of its own (it is the last of the list either way, and a round's minimum is the first STRICT one, so the split changes nothing)
+  int mx = tj.mvHor, my = tj.mvVer;
+  clip_mv( j, mx, my );
+  mx = div_pow2( prec_down( mx, 2 ), 2 );
+  my = div_pow2( prec_down( my, 2 ), 2 );
+  const int m = mg::num_extra( mj );
+  int  eh = 0, ev = 0;
+  bool efirst = slot < m;
+  if( m > 0 )
+  {
+    if( slot < m ) { eh = mj.extraStart[slot][0]; ev = mj.extraStart[slot][1]; }
+    for( int k = 0; k + 1 < m; k++ )      // (row-uniform trip count)
+    {
+      const int oh = row_read( eh, lane, k ), ov = row_read( ev, lane, k );
+      if( k < slot && oh == eh && ov == ev ) efirst = false;
+    }
+    clip_mv( j, eh, ev );
+    eh = prec_down( eh, 4 ); ev = prec_down( ev, 4 );
+  }
+  // entry 14 (lane 14 of the row) for the second round
+  const int  e15x = m > 14 ? row_read( eh, lane, 14 ) : 0, e15y = m > 14 ? row_read( ev, lane, 14 ) : 0;
+  const bool e15  = m > 14 && row_read( efirst ? 1 : 0, lane, 14 ) != 0;
+  // entries 0 .. 13 move two lanes up
+  const int  sh = row_read( eh, lane, ( slot + 14 ) & 15 ), sv = row_read( ev, lane, ( slot + 14 ) & 15 );
+  const bool sf = row_read( efirst ? 1 : 0, lane, ( slot + 14 ) & 15 ) != 0;
+  int  cx, cy, cnr = 0, cdist = 0;
+  bool cv;
+  if( slot == 0 ) { cx = mx; cy = my; cv = true; }
+  else if( slot == 1 ) { cx = 0; cy = 0; cv = !fast && ( mx != 0 || my != 0 ); }
+  else { cx = sh; cy = sv; cv = sf; }
+
+  job_sync<1>();      // the row's original block is in LDS (DS operations of a wave execute in order)
+
+  TzState s;
+  s.bestSad = ~0ull; s.bestX = 0; s.bestY = 0; s.pointNr = 0; s.bestDist = 0; s.bestRound = 0; s.nEval = 0;
+  s.sr.left = s.sr.right = s.sr.top = s.sr.bottom = 0;
+  int  phase = GP_START, d = 0, startX = 0, startY = 0;
+  bool touch = true, listed = false;
+  int  winX = 0, winY = 0, winSkew = -1;      // the LDS window's first sample / the byte offset of that sample in its row (-1: no window yet)
+
+  for( ;; )
+  {
+    // ---- the round: every lane its candidate, the row's first strict minimum, xTZSearchHelp's accept rule (:397-417)
+    {
+      // idle lanes re-read the start point (in the window) / the best point (a valid address)
+      const int  ex = cv ? cx : ( winSkew >= 0 ? startX : s.bestX ), ey = cv ? cy : ( winSkew >= 0 ? startY : s.bestY );
+      const bool inWin = winSkew >= 0 && ( unsigned ) ( ex - winX ) <= 2u * TZG_R && ( unsigned ) ( ey - winY ) <= 2u * TZG_R;
+      unsigned   sad;
+      if( inWin ) sad = grp_sad_win<SPR, SS>( win + ( ey - winY ) * TzgWin<SPR>::PITCH + winSkew + ( ex - winX ) * 2, so, j.items );
+      else sad = grp_sad<SPR>( j, so, ex, ey );
+      const unsigned long long c   = ( ( unsigned long long ) sad << j.ss ) + mv_cost( j, cx, cy );
+      unsigned long long minCost;
+      unsigned           minKey;
+      row_argmin<true>( j, c, cv, ( unsigned ) slot, minCost, minKey );
+      const unsigned long long vb = __ballot( cv );
+      s.nEval += ( unsigned ) __popc( ( unsigned ) ( vb >> ( lane & 48 ) ) & 0xffffu );
+      const int pxy = row_read( ( cx & 0xffff ) | ( cy << 16 ), lane, ( int ) ( minKey & 15u ) );
+      const int pnd = row_read( cnr | ( cdist << 8 ), lane, ( int ) ( minKey & 15u ) );
+      if( minCost < s.bestSad )      // (minCost == ~0: no candidate in the round)
+      {
+        s.bestSad = minCost;
+        s.bestX   = ( int ) ( short ) ( pxy & 0xffff );
+        s.bestY   = pxy >> 16;
+        if( touch ) { s.bestDist = ( unsigned ) ( pnd >> 8 ); s.bestRound = 0; s.pointNr = pnd & 0xff; }
+      }
+    }
+    // ---- what comes next (xTZSearch :3765-3971 without the extended settings)
+    bool enterDia1 = false, afterLoop1 = false, rasterDecision = false, afterLoop2 = false, enterStar = false, done = false;
+    touch = true;
+    if( phase == GP_START )
+    {
+      if( e15 ) { phase = GP_START15; touch = false; }
+      else enterDia1 = true;
+    }
+    else if( phase == GP_START15 ) enterDia1 = true;
+    else if( phase == GP_DIA1 )
+    {
+      if( ( firstStop && s.bestRound >= 3 ) || 2 * d > searchRange ) afterLoop1 = true;
+      else d *= 2;
+    }
+    else if( phase == GP_TWO1 ) rasterDecision = true;
+    else if( phase == GP_DIA2 )
+    {
+      if( ( fast && s.bestRound >= 2 ) || 2 * d > searchRange ) afterLoop2 = true;
+      else d *= 2;
+    }
+    else enterStar = true;      // GP_TWO2
+    if( enterDia1 )
+    {
+      s.sr   = search_range( j, s.bestX << 4, s.bestY << 4, searchRange >> ( fast ? 1 : 0 ) );
+      startX = s.bestX; startY = s.bestY;
+      d      = 1;
+      phase  = GP_DIA1;
+      if( searchRange < 1 ) afterLoop1 = true;      // (an empty first loop)
+      else if( ( j.refStride & 7 ) == 0 )
+      {
+        // the window around the start point -> LDS: rows winY .. winY + h + 2 R - 1 (clamped to the rows a block may touch: the clipped vectors keep every tested candidate
+        // inside them, and the plane has no samples beyond), CH aligned chunks per row from the 16-byte boundary below the row's first sample (the rows' pitch is a multiple
+        // of 16 bytes, so the offset of that sample in its chunk -- winSkew -- is the same in every row)
+        winX = startX - TZG_R; winY = startY - TZG_R;
+        const int yLo = j.verMin >> 4, yHi = ( j.verMax >> 4 ) + j.h - 1, nrows = j.h + 2 * TZG_R;
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>( j.ref + ( long ) winY * j.refStride + winX );
+        winSkew = ( int ) ( a0 & 15 );
+        for( int idx = slot; idx < nrows * TzgWin<SPR>::CH; idx += 16 )
+        {
+          const int r = idx / TzgWin<SPR>::CH, c = idx - r * TzgWin<SPR>::CH;
+          const int yy = min( max( winY + r, yLo ), yHi );
+          const uintptr_t a = ( reinterpret_cast<uintptr_t>( j.ref + ( long ) yy * j.refStride + winX ) & ~( uintptr_t ) 15 ) + ( uintptr_t ) c * 16;
+          *reinterpret_cast<uint4 *>( win + r * TzgWin<SPR>::PITCH + c * 16 ) = *reinterpret_cast<const uint4 *>( a );
+        }
+        job_sync<1>();      // (the row's lanes read each other's chunks: DS operations of a wave execute in order)
+      }
+    }
+    if( afterLoop1 )
+    {
+      if( s.bestDist == 1 ) { s.bestDist = 0; phase = GP_TWO1; }
+      else rasterDecision = true;
+    }
+    if( rasterDecision )
+    {
+      if( ( int ) s.bestDist >= iRaster )
+      {
+        s.bestDist = ( unsigned ) iRaster;
+        const int nx = s.sr.right >= s.sr.left ? ( s.sr.right - s.sr.left ) / iRaster + 1 : 0, ny = s.sr.bottom >= s.sr.top ? ( s.sr.bottom - s.sr.top ) / iRaster + 1 : 0;
+        if( mode == 1 && iRaster == 5 && j.h <= 128 && nx >= 1 && ny >= 1 && nx * ny <= totCap )
+        {
+          // the scan runs in tz_raster_cols_kernel, the search resumes in tz_search_kernel<1> (mode 2): state and job record as that kernel stores them
+          if( slot == 0 )
+          {
+            TzSaved sv;
+            sv.sr = s.sr; sv.bestSad = s.bestSad; sv.bestX = s.bestX; sv.bestY = s.bestY; sv.pointNr = s.pointNr; sv.bestDist = s.bestDist;
+            sv.bestRound = s.bestRound; sv.nEval = s.nEval; sv.rasterCost = ~0ull; sv.rasterIdx = 0; sv.pad = 0;
+            saved[jobIdx] = sv;
+            list[1 + atomicAdd( &list[0], 1 )] = jobIdx;
+            // (the record again from the row, not kept in registers through the search)
+            vtmhip_tz_job t2;
+            mg::make_tz_job_scalars( fu.cfg, mj, fuse_pat_off( fu, mj ), fuse_pat_stride( fu, mj ), predH, predV, t2 );
+            vtmhip_tz_job *g = fu.tzSpill + jobIdx;
+            g->orgOff = t2.orgOff; g->refOff = t2.refOff; g->orgStride = t2.orgStride; g->refStride = t2.refStride; g->puX = t2.puX; g->puY = t2.puY;
+            g->width = t2.width; g->height = t2.height; g->subShift = t2.subShift; g->imvShift = t2.imvShift; g->signedSamples = t2.signedSamples;
+            g->predHor = t2.predHor; g->predVer = t2.predVer; g->motionLambda = t2.motionLambda; g->mvHor = t2.mvHor; g->mvVer = t2.mvVer; g->searchRange = t2.searchRange;
+            g->extendedSettings = t2.extendedSettings; g->fastSettings = t2.fastSettings; g->firstSearchStop = t2.firstSearchStop; g->hasIntMv2Nx2NPred = t2.hasIntMv2Nx2NPred;
+            g->intMv2Nx2NPredHor = t2.intMv2Nx2NPredHor; g->intMv2Nx2NPredVer = t2.intMv2Nx2NPredVer; g->numExtraStart = 0;
+          }
+          listed = true;
+          done   = true;
+        }
+        else
+        {
+          // the scan here (:3888-3899): lane `slot` takes the candidates slot, slot + 16, ... of the row-major raster; (cost, index) first strict minimum
+          const int          total = nx * ny;
+          unsigned long long bc = ~0ull;
+          unsigned           bk = 0xffffffffu;
+          for( int k = slot; k < total; k += 16 )
+          {
+            const int ry = k / nx, rx = k - ry * nx, x = s.sr.left + rx * iRaster, y = s.sr.top + ry * iRaster;
+            const unsigned long long c = ( ( unsigned long long ) grp_sad<SPR>( j, so, x, y ) << j.ss ) + mv_cost( j, x, y );
+            if( c < bc ) { bc = c; bk = ( unsigned ) k; }
+          }
+          unsigned long long rc;
+          unsigned           rk;
+          row_argmin<false>( j, bc, bk != 0xffffffffu, bk, rc, rk );
+          s.nEval += ( unsigned ) total;
+          if( total > 0 && rc < s.bestSad )
+          {
+            const int ry = ( int ) rk / nx, rx = ( int ) rk - ry * nx;
+            s.bestSad = rc; s.bestX = s.sr.left + rx * iRaster; s.bestY = s.sr.top + ry * iRaster; s.bestDist = ( unsigned ) iRaster; s.bestRound = 0; s.pointNr = 0;
+          }
+          enterStar = true;
+        }
+      }
+      else enterStar = true;
+    }
+    if( afterLoop2 )
+    {
+      if( s.bestDist == 1 )
+      {
+        s.bestDist = 0;
+        if( s.pointNr != 0 ) phase = GP_TWO2;
+        else enterStar = true;
+      }
+      else enterStar = true;
+    }
+    if( enterStar )
+    {
+      if( s.bestDist > 0 )      // star refinement (:3937-3971)
+      {
+        startX = s.bestX; startY = s.bestY;
+        s.bestDist = 0; s.pointNr = 0;
+        d     = 1;
+        phase = GP_DIA2;
+        if( searchRange < 1 ) done = true;      // (an empty loop body: bestDist stays 0)
+      }
+      else done = true;
+    }
+    if( done ) break;
+
+    // ---- the next round's candidate of this lane
+    if( phase == GP_START15 )
+    {
+      cx = e15x; cy = e15y; cnr = 0; cdist = 0; cv = slot == 0;
+    }
+    else if( phase == GP_DIA1 || phase == GP_DIA2 )
+    {
+      // xTZ8PointDiamondSearch (:504-705): offsets of the slot-th point of the round at distance d, its point number and the distance it reports
+      s.bestRound += 1;
+      int dx, dy;
+      cnr = 0; cdist = d;
+      bool on = true;
+      if( d == 1 )
+      {
+        // (left, top) (sx, top) (right, top) (left, sy) (right, sy) (left, bot) (sx, bot) (right, bot); the corners only with the extended settings -- not here
+        dx = slot == 1 || slot == 6 ? 0 : ( slot == 0 || slot == 3 || slot == 5 ? -1 : 1 );
+        dy = slot < 3 ? -1 : slot < 5 ? 0 : 1;
+        cnr = slot + 1;
+        on  = slot < 8 && ( dx == 0 || dy == 0 );
+      }
+      else if( d <= 8 )
+      {
+        // (sx, top, 2) (left2, top2, 1) (right2, top2, 3) (left, sy, 4) (right, sy, 5) (left2, bot2, 6) (right2, bot2, 8) (sx, bot, 7)
+        const int  h2 = d >> 1;
+        const bool half = slot == 1 || slot == 2 || slot == 5 || slot == 6;
+        dx = slot == 0 || slot == 7 ? 0 : ( half ? ( slot & 1 ? -h2 : h2 ) : ( slot == 3 ? -d : d ) );
+        dy = slot == 3 || slot == 4 ? 0 : ( half ? ( slot < 3 ? -h2 : h2 ) : ( slot == 0 ? -d : d ) );
+        cnr   = slot == 0 ? 2 : slot == 1 ? 1 : slot == 2 ? 3 : slot == 3 ? 4 : slot == 4 ? 5 : slot == 5 ? 6 : slot == 6 ? 8 : 7;
+        cdist = half ? h2 : d;
+        on    = slot < 8;
+      }
+      else
+      {
+        // (sx, top) (left, sy) (right, sy) (sx, bot), then for i = 1 .. 3: (xl, yt) (xr, yt) (xl, yb) (xr, yb) with q = d / 4 steps along the diamond's edges
+        const int q = d >> 2, i = ( ( slot - 4 ) >> 2 ) + 1, mm = ( slot - 4 ) & 3;
+        if( slot < 4 ) { dx = slot == 1 ? -d : slot == 2 ? d : 0; dy = slot == 0 ? -d : slot == 3 ? d : 0; }
+        else { dx = ( mm & 1 ) ? q * i : -q * i; dy = ( mm & 2 ) ? d - q * i : -( d - q * i ); }
+      }
+      cx = startX + dx; cy = startY + dy;
+      // a point is tested when it lies inside the search range on the side(s) it moved to (the checks of :510-700, which test exactly those sides)
+      cv = on && ( dx >= 0 || cx >= s.sr.left ) && ( dx <= 0 || cx <= s.sr.right ) && ( dy >= 0 || cy >= s.sr.top ) && ( dy <= 0 || cy <= s.sr.bottom );
+    }
+    else
+    {
+      // xTZ2PointSearch (:426-446): the two untested neighbours of the best point, by the point number of the distance-1 round; 2-bit fields (offset + 1) per point number 0 .. 8
+      constexpr unsigned XO0 = 1u | 0u << 2 | 0u << 4 | 1u << 6 | 0u << 8 | 2u << 10 | 0u << 12 | 0u << 14 | 2u << 16;
+      constexpr unsigned XO1 = 1u | 1u << 2 | 2u << 4 | 2u << 6 | 0u << 8 | 2u << 10 | 1u << 12 | 2u << 14 | 1u << 16;
+      constexpr unsigned YO0 = 1u | 1u << 2 | 0u << 4 | 0u << 6 | 2u << 8 | 0u << 10 | 1u << 12 | 2u << 14 | 1u << 16;
+      constexpr unsigned YO1 = 1u | 0u << 2 | 0u << 4 | 1u << 6 | 0u << 8 | 2u << 10 | 2u << 12 | 2u << 14 | 2u << 16;
+      const int      sh2 = 2 * s.pointNr;
+      const unsigned xo = slot == 0 ? XO0 : XO1, yo = slot == 0 ? YO0 : YO1;
+      cx = s.bestX + ( int ) ( ( xo >> sh2 ) & 3u ) - 1;
+      cy = s.bestY + ( int ) ( ( yo >> sh2 ) & 3u ) - 1;
+      cnr = 0; cdist = 2;
+      cv = slot < 2 && cx >= s.sr.left && cx <= s.sr.right && cy >= s.sr.top && cy <= s.sr.bottom;
+    }
+  }
+
+  if( !listed && slot == 0 )
+  {
+    vtmhip_me_result r;
+    r.mvX = s.bestX; r.mvY = s.bestY; r.nEval = s.nEval; r.reserved = 0;
+    r.cost = s.bestSad;
+    r.dist = s.bestSad - mv_cost( j, s.bestX, s.bestY );
+    results[jobIdx] = r;
+  }
+}
+
+
 // ---- exhaustive search (InterSearch::xPatternSearch :3566-3608 after xSetSearchRange :3496-3563): the bi-predictive
 // refinement of xMotionEstimation (:3385-3440, +-BipredSearchRange around the current vector).  One wave per job.
 template<int WPJ>
@@ -1539,13 +2003,13 @@ __global__ __launch_bounds__( ( FullSq<W, H>::THREADS ) ) void full_search_sq_ke
 extern "C" int vtmhip_tz_search_batch_dev( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase,
                                            const vtmhip_tz_job *d_jobs, int n, vtmhip_me_result *d_results )
 {
-  return vtmhip_internal_tz_search( ctx, pic, d_orgBase, d_refBase, d_jobs, n, d_results, nullptr );
+  return vtmhip_internal_tz_search( ctx, pic, d_orgBase, d_refBase, d_jobs, n, d_results, nullptr, 0, 0 );
 }
 
 // fuse != nullptr: the searches of the xMotionEstimation rows fuse->me (job records built in the kernel's prologue, mest_glue.hpp); d_jobs is then the table the searches that
 // go to the raster kernel store their record in (fuse->tzSpill == d_jobs)
 int vtmhip_internal_tz_search( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const int16_t *d_orgBase, const int16_t *d_refBase, const vtmhip_tz_job *d_jobs, int n,
-                               vtmhip_me_result *d_results, const MeFuse *fuse )
+                               vtmhip_me_result *d_results, const MeFuse *fuse, int uniformW, int uniformH )
 {
   VTMHIP_CHECK_CTX( ctx );
   VTMHIP_REQUIRE( ctx, pic && n >= 0, "pic / n" );
@@ -1604,6 +2068,39 @@ int vtmhip_internal_tz_search( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, co
   case 16: VTMHIP_TZ_LAUNCH( 16, n, MODE ); break;                  \
   default: VTMHIP_TZ_LAUNCH( 1, ( n + 3 ) / 4, MODE ); break;       \
   }
+  // Uniform batches of small blocks (fused uni rows, no extended settings): four searches per wave, a lane per candidate (tz_group_kernel).  VTMHIP_TZ_GROUP=0: off;
+  // VTMHIP_TZ_GROUP_ITEMS: the largest block in 8-sample segments after row sub-sampling (default 16: 8x8 .. 16x16)
+  static const bool groupOn = !( getenv( "VTMHIP_TZ_GROUP" ) && atoi( getenv( "VTMHIP_TZ_GROUP" ) ) == 0 );
+  static const int  groupItems = getenv( "VTMHIP_TZ_GROUP_ITEMS" ) ? atoi( getenv( "VTMHIP_TZ_GROUP_ITEMS" ) ) : 16;
+  int grpItems = 0, grpSs = 0;
+  if( groupOn && fuse && fuse->me && !fuse->cfg.extendedSettings && ( wpj == 0 || wpj == 1 ) && ( uniformW == 8 || uniformW == 16 || uniformW == 32 ) && uniformH >= 8 )
+  {
+    const int ss = fuse->cfg.fastInterSearchMode13 && uniformH > 8 && uniformW <= 64 ? 1 : 0;      // mg::sub_shift
+    const int items = ( uniformW >> 3 ) * ( ( uniformH + ( 1 << ss ) - 1 ) >> ss );
+    if( ( items & 7 ) == 0 && items <= groupItems && items <= 128 ) { grpItems = items; grpSs = ss; }
+  }
+  if( grpItems )
+  {
+    VTMHIP_TIME_KERNEL( ctx, "tz_group_kernel" );
+    const int  spr = uniformW >> 3, winRows = uniformH + 2 * TZG_R;
+    const int  pitch = spr == 1 ? TzgWin<1>::PITCH : spr == 2 ? TzgWin<2>::PITCH : TzgWin<4>::PITCH;
+    const size_t lds = ( size_t ) 16 * ( ( size_t ) grpItems * 16 + ( size_t ) winRows * pitch );
+    const dim3   grid( ( n + 15 ) / 16 );
+    const int    md = split ? 1 : 0;
+#define VTMHIP_TZG_LAUNCH( SPR, SS )                                                                                                                                        \
+  {                                                                                                                                                                         \
+    if( lds > 48 * 1024 ) VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( tz_group_kernel<SPR, SS> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) ); \
+    hipLaunchKernelGGL( ( tz_group_kernel<SPR, SS> ), grid, dim3( 256 ), lds, ctx->stream, *pic, d_orgBase, d_refBase, n, d_results, md, d_saved, d_list, totCap, grpItems, winRows, fuFirst ); \
+  }
+    if( spr == 1 && grpSs == 0 ) VTMHIP_TZG_LAUNCH( 1, 0 )
+    else if( spr == 1 ) VTMHIP_TZG_LAUNCH( 1, 1 )
+    else if( spr == 2 && grpSs == 0 ) VTMHIP_TZG_LAUNCH( 2, 0 )
+    else if( spr == 2 ) VTMHIP_TZG_LAUNCH( 2, 1 )
+    else if( grpSs == 0 ) VTMHIP_TZG_LAUNCH( 4, 0 )
+    else VTMHIP_TZG_LAUNCH( 4, 1 )
+#undef VTMHIP_TZG_LAUNCH
+  }
+  else
   { VTMHIP_TIME_KERNEL( ctx, "tz_search_kernel" );
     VTMHIP_TZ_SWITCH( split ? 1 : 0 )
   }

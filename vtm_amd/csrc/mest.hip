@@ -457,7 +457,7 @@ int mest_run( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, const vtmhip_me_cfg
   if( !allBi )
   {
     // uni: TZ search
-    st = vtmhip_internal_tz_search( ctx, &pTz, patBase, d_refBase, wk.tz, n, wk.ires, fuseTz ? &fu : nullptr );
+    st = vtmhip_internal_tz_search( ctx, &pTz, patBase, d_refBase, wk.tz, n, wk.ires, fuseTz ? &fu : nullptr, cfg->uniformSquare ? maxWidth : 0, cfg->uniformSquare ? maxHeight : 0 );
     if( st ) return st;
   }
   if( fuseFrac )      // integer results -> fractional search -> the rows' final records, in one launch
