@@ -184,6 +184,7 @@ def oracle_mest_job(scene, j, keep):
     for i, (a, b) in enumerate(j["extra"]):
         t.extraStart[i][0], t.extraStart[i][1] = a, b
     t.bcwWeight = j.get("bcw", 0)      # bi: the searched list's CU-level BCW weight (0: the default pair)
+    t.cachedIntMv = j.get("cached", 0)  # uni: rcMv = the block-vector cache's integer vector, xTZSearch with bFastSettings (InterSearch.cpp:3360-3368, :3434-3441)
     return t
 
 

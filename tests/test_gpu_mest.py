@@ -40,7 +40,7 @@ def hip_jobs(scene, jobs, others):
         t.numExtraStart = len(j["extra"])
         for i, (a, b) in enumerate(j["extra"]):
             t.extraStart[i][0], t.extraStart[i][1] = a, b
-        t.flags = (j.get("bcw", 0) & 0xff) << 8      # VTMHIP_MEJ_BCW_FLAGS: the searched list's CU-level BCW weight of a bi job
+        t.flags = ((j.get("bcw", 0) & 0xff) << 8) | (1 if j.get("cached") else 0)      # VTMHIP_MEJ_BCW_FLAGS: the searched list's CU-level BCW weight of a bi job; VTMHIP_MEJ_CACHED_INT_MV
     return arr
 
 
@@ -175,6 +175,59 @@ def test_uniform_bi_fast_paths(ctx, size, bi, opts):
         exp.append(r.key())
     got, _ = run_device(ctx, scene, jobs, cfgv, uniform_imv=0, uniform_square=1, max_wh=(size, size), uniform_bi=1 + bi, **opts)
     assert got == exp
+
+
+@pytest.mark.parametrize("w,h", [(8, 8), (16, 16), (16, 8), (8, 16), (8, 32)])
+def test_four_searches_per_wave_integer_kernel(ctx, w, h):
+    """tz_group_kernel (uniform all-uni batches of blocks up to 16 segments: a DPP row per search, a lane per candidate) on what its state machine has to get right:
+    0 .. 15 m_uniMvList entries with duplicates (the 15th in a round of its own, up to 4 start candidates beside the speculative distance-1 / -2 points, more without them),
+    cached integer vectors (xTZSearch's fast settings: no zero candidate, halved range, raster distance 8, the star loop's early stop), search ranges 1 .. 192 (empty and
+    one-round loops, raster scans listed for the column kernel), predictors far from the true motion (two-point steps and star refinements)."""
+    L = ol.oracle()
+    scene = me_util.Scene(416, 240, hard=True)
+    jobs = me_util.random_mest_jobs(scene, 336, seed=7000 + 64 * w + h, sizes=([w], [h]))
+    rng = np.random.default_rng(9 + w + h)
+    for k, j in enumerate(jobs):
+        j["imv"], j["bi"] = 0, 0
+        j["cands"] = [[me_util._round_amvr(v, 0) for v in c] for c in j["cands"]]
+        j["mvPred"] = tuple(j["cands"][j["mvpIdx"]])
+        j["searchRange"] = [1, 2, 4, 8, 64, 96, 192][k % 7]
+        n = k % 16
+        extra = [(int(rng.integers(-12 * 16, 12 * 16)), int(rng.integers(-12 * 16, 12 * 16))) for _ in range(n)]
+        if n >= 3 and k % 2:
+            extra[n - 1] = extra[0]                    # a duplicate at the end (with 15 entries: no second round)
+        if n >= 4 and k % 3 == 0:
+            extra[2] = extra[1]
+        j["extra"] = extra
+        j["cached"] = int(k % 5 == 0)
+        if k % 4 == 0:                                 # a predictor next to the zero vector: the zero candidate wins or ties the start round
+            j["cands"] = [[0, 0], [16, 0]]
+            j["mvPred"] = tuple(j["cands"][j["mvpIdx"]])
+    cfgv = (4, 1, 1, 0, 1)
+    cfg = ol.MestCfg(*cfgv)
+    exp = []
+    for j in jobs:
+        keep = []
+        t = me_util.oracle_mest_job(scene, j, keep)
+        r = ol.MestResult()
+        L.vo_motion_estimation(C.byref(cfg), C.byref(t), C.byref(r))
+        exp.append(r.key())
+    got, _ = run_device(ctx, scene, jobs, cfgv, uniform_imv=0, uniform_square=1, max_wh=(w, h), uniform_bi=1)
+    bad = [k for k in range(len(jobs)) if got[k] != exp[k]]
+    assert not bad, (bad[:10], [(got[k], exp[k], jobs[k]["searchRange"], len(jobs[k]["extra"]), jobs[k]["cached"]) for k in bad[:3]])
+
+
+def test_integer_search_in_one_launch(ctx):
+    """VTMHIP_TZ_SPLIT=0 (read once per process: a child process): the raster scans run inside the search kernels instead of tz_raster_cols_kernel between two launches --
+    tz_group_kernel's lane-strided scan and tz_search_kernel's -- with the same results."""
+    if os.environ.get("VTMHIP_TEST_CHILD"):
+        pytest.skip("the child itself")
+    import subprocess
+    import sys
+    env = dict(os.environ, VTMHIP_TZ_SPLIT="0", VTMHIP_TEST_CHILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "four_searches_per_wave or uniform_bi_fast_paths"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
 
 
 @pytest.mark.parametrize("w,h", [(16, 8), (8, 16), (32, 8), (8, 32), (32, 16), (16, 32), (64, 16), (16, 64), (64, 32), (32, 64)])

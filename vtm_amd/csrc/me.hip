@@ -1271,11 +1271,11 @@ void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBas
 // whose single evaluation site serves whatever phase each row is in, so a wave runs max-over-its-rows rounds.  Against one wave per search (tz_search_kernel<1>: 700 vector + 600 scalar
 // instructions per 8x8 search, vector port 60-78 % busy) a search costs about a third of the instructions.
 // Takes the FUSED uni rows only (job record from the xMotionEstimation row, mest_glue.hpp), modes 0 / 1; the few searches that go to the raster kernel resume in tz_search_kernel<1>.
-#ifndef VTMHIP_TZG_ALIGNED
-#define VTMHIP_TZG_ALIGNED 0
+#ifndef VTMHIP_TZG_SPEC
+#define VTMHIP_TZG_SPEC 1
 #endif
 #ifndef VTMHIP_TZG_WAVES
-#define VTMHIP_TZG_WAVES 3
+#define VTMHIP_TZG_WAVES 4      // (128 VGPRs with 7 spilled in cold paths: measured faster than 3 waves without spills, 0.68 against 0.73 ms)
 #endif
 enum { GP_START = 0, GP_START15, GP_DIA1, GP_TWO1, GP_DIA2, GP_TWO2 };
 
@@ -1307,40 +1307,17 @@ __device__ __forceinline__ int row_read( int v, int lane, int slot )      // v o
 }
 
 // SAD of the whole block at candidate (x, y): SPR segments per row, 8 segments (= 8 / SPR rows) per trip with their loads in flight together
-template<int SPR>
+template<int SPR, int SS>
 __device__ __forceinline__ unsigned grp_sad( const MeJob &j, const uint4 *so, int x, int y )
 {
   const int16_t *p  = j.ref + ( long ) y * j.refStride + x;
-  const long     cs = ( long ) j.refStride << j.ss;
+  const long     cs = ( long ) j.refStride << SS;
   unsigned       s  = 0;
   for( int it0 = 0; it0 < j.items; it0 += 8 )
   {
     Pel8 b[8];
-#if VTMHIP_TZG_ALIGNED
-    // (a 16-byte load from an address that is only 2-byte aligned runs at 0.28x the rate, see ld8: the dwords below + a funnel shift)
-    {
-      const unsigned  sh = ( ( unsigned ) reinterpret_cast<uintptr_t>( p ) & 2u ) << 3;
-      const int16_t  *pa = reinterpret_cast<const int16_t *>( reinterpret_cast<uintptr_t>( p ) & ~( uintptr_t ) 3 );
-      Dw4      a4[8];
-      unsigned e[8];
-#pragma unroll
-      for( int q = 0; q < 8; q++ )
-      {
-        const unsigned *w = reinterpret_cast<const unsigned *>( pa + ( q / SPR ) * cs + ( q % SPR ) * 8 );
-        a4[q] = *reinterpret_cast<const Dw4 *>( w );
-        e[q]  = w[4];
-      }
-#pragma unroll
-      for( int q = 0; q < 8; q++ )
-      {
-        b[q].v[0] = __builtin_amdgcn_alignbit( a4[q].v[1], a4[q].v[0], sh ); b[q].v[1] = __builtin_amdgcn_alignbit( a4[q].v[2], a4[q].v[1], sh );
-        b[q].v[2] = __builtin_amdgcn_alignbit( a4[q].v[3], a4[q].v[2], sh ); b[q].v[3] = __builtin_amdgcn_alignbit( e[q], a4[q].v[3], sh );
-      }
-    }
-#else
 #pragma unroll
     for( int q = 0; q < 8; q++ ) b[q] = *reinterpret_cast<const Pel8 *>( p + ( q / SPR ) * cs + ( q % SPR ) * 8 );
-#endif
 #pragma unroll
     for( int q = 0; q < 8; q++ )
     {
@@ -1348,39 +1325,6 @@ __device__ __forceinline__ unsigned grp_sad( const MeJob &j, const uint4 *so, in
       s = sad2( a.x, b[q].v[0], s ); s = sad2( a.y, b[q].v[1], s ); s = sad2( a.z, b[q].v[2], s ); s = sad2( a.w, b[q].v[3], s );
     }
     p += ( 8 / SPR ) * cs;
-  }
-  return s;
-}
-
-// The search WINDOW of a row's search in LDS.  Every candidate of the dependent rounds lies within a few samples of the start point, and a candidate reads 16 bytes of each of
-// its rows: through the vector memory path that is one 128-byte cache-line request per (candidate, row) -- 200 - 450 requests per search against the 30 - 50 lines the window has, with
-// 64 searches per CU sharing a 32 KB L1 (measured: the kernel ran at the L2's request rate whatever its occupancy or the alignment of the loads).  After the start round the row's 16
-// lanes copy the (w + 2 R) x (h + 2 R) window around the start point to LDS in aligned 16-byte chunks (each cache line once); a candidate inside reads its segments from there
-// (ds_read_b128 at any 2-byte offset: gfx950 takes unaligned DS addresses), one outside -- the far rounds of a long search -- keeps the global path.
-constexpr int TZG_R = 8;      // the window reaches R samples beyond the block on every side: the rounds at distance 1 .. 8 around the start point
-template<int SPR> struct TzgWin
-{
-  static constexpr int WBYTES = ( SPR * 8 + 2 * TZG_R ) * 2;                                    // the window's samples of one row
-  static constexpr int CH     = ( WBYTES + 14 + 15 ) / 16;                                      // aligned 16-byte chunks that cover them whatever the start address modulo 16
-  static constexpr int PITCH  = ( CH * 16 ) % 64 == 0 ? CH * 16 + 16 : CH * 16;                 // (a pitch that is a multiple of 64 bytes would put every other row on the same banks)
-};
-
-template<int SPR, int SS>
-__device__ __forceinline__ unsigned grp_sad_win( const unsigned char *wp, const uint4 *so, int items )
-{
-  unsigned s = 0;
-  for( int it0 = 0; it0 < items; it0 += 8 )
-  {
-    Pel8 b[8];
-#pragma unroll
-    for( int q = 0; q < 8; q++ ) b[q] = *reinterpret_cast<const Pel8 *>( wp + ( ( q / SPR ) << SS ) * TzgWin<SPR>::PITCH + ( q % SPR ) * 16 );
-#pragma unroll
-    for( int q = 0; q < 8; q++ )
-    {
-      const uint4 a = so[it0 + q];
-      s = sad2( a.x, b[q].v[0], s ); s = sad2( a.y, b[q].v[1], s ); s = sad2( a.z, b[q].v[2], s ); s = sad2( a.w, b[q].v[3], s );
-    }
-    wp += ( ( 8 / SPR ) << SS ) * TzgWin<SPR>::PITCH;
   }
   return s;
 }
@@ -1404,19 +1348,27 @@ __device__ __forceinline__ void row_argmin( const MeJob &j, unsigned long long c
   }
 }
 
+// the idx-th point of a diamond round at distance 2 .. 8 (:537-608), offsets in units of d / 2: (sx, top, 2) (left2, top2, 1) (right2, top2, 3) (left, sy, 4) (right, sy, 5)
+// (left2, bot2, 6) (right2, bot2, 8) (sx, bot, 7); half: the point reports distance d / 2
+__device__ __forceinline__ void tzg_mid_point( int idx, int &ux, int &uy, int &nr, bool &half )
+{
+  half = idx == 1 || idx == 2 || idx == 5 || idx == 6;
+  ux   = idx == 0 || idx == 7 ? 0 : ( half ? ( idx & 1 ? -1 : 1 ) : ( idx == 3 ? -2 : 2 ) );
+  uy   = idx == 3 || idx == 4 ? 0 : ( half ? ( idx < 3 ? -1 : 1 ) : ( idx == 0 ? -2 : 2 ) );
+  nr   = idx == 0 ? 2 : idx == 1 ? 1 : idx == 2 ? 3 : idx == 3 ? 4 : idx == 4 ? 5 : idx == 5 ? 6 : idx == 6 ? 8 : 7;
+}
+
 template<int SPR, int SS>
 __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( VTMHIP_TZG_WAVES ) ) ) void tz_group_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase, int numJobs,
                                                          vtmhip_me_result *__restrict__ results, int mode, TzSaved *__restrict__ saved, int *__restrict__ list, int totCap, int itemsMax,
-                                                         int winRows, MeFuse fu )
+                                                         MeFuse fu )
 {
-  extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char sDyn[];      // [16 searches]: itemsMax segments of the original block + winRows rows of the search window
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char sDyn[];      // [16 searches][itemsMax] segments of the original blocks
   const int lane = threadIdx.x & 63, wv = ( int ) ( threadIdx.x >> 6 ), row = lane >> 4, slot = lane & 15;
   const int blk = xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x );
   const int jobIdx = blk * 16 + wv * 4 + row;
   if( jobIdx >= numJobs ) return;      // whole rows leave
-  unsigned char *sMine = sDyn + ( size_t ) ( wv * 4 + row ) * ( ( size_t ) itemsMax * 16 + ( size_t ) winRows * TzgWin<SPR>::PITCH );
-  uint4         *so  = reinterpret_cast<uint4 *>( sMine );
-  unsigned char *win = sMine + ( size_t ) itemsMax * 16;
+  uint4 *so = reinterpret_cast<uint4 *>( sDyn ) + ( size_t ) ( wv * 4 + row ) * itemsMax;
 
   // the job from the xMotionEstimation row (every lane of the row derives the same record)
   vtmhip_me_job &mj = fu.me[jobIdx];
@@ -1444,15 +1396,15 @@ __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( VTMHIP
   j.w = tj.width; j.h = tj.height; j.ss = tj.subShift; j.imvShift = ( unsigned ) tj.imvShift; j.predHor = tj.predHor; j.predVer = tj.predVer; j.costScale = 2; j.lambda = tj.motionLambda;
   j.horMax = ( pic.picW + 8 - tj.puX - 1 ) << 4; j.horMin = ( -pic.ctuSize - 8 - tj.puX + 1 ) << 4;
   j.verMax = ( pic.picH + 8 - tj.puY - 1 ) << 4; j.verMin = ( -pic.ctuSize - 8 - tj.puY + 1 ) << 4;
-  j.seg = 8; j.segsPerRow = SPR; j.items = SPR * ( ( j.h + ( 1 << j.ss ) - 1 ) >> j.ss ); j.bias = 0;
+  j.seg = 8; j.segsPerRow = SPR; j.items = SPR * ( ( j.h + ( 1 << SS ) - 1 ) >> SS ); j.bias = 0;
   j.narrow = j.lambda >= 0.0 && j.lambda * 126.0 < 2147483648.0;
   j.tiny   = j.narrow && ( double ) ( j.w * j.h ) * ( double ) ( ( 1 << pic.bitDepth ) - 1 ) + j.lambda * 126.0 < 67108864.0;
-  if( j.w != SPR * 8 || j.ss != SS || j.items > itemsMax || ( j.items & 7 ) || j.h + 2 * TZG_R > winRows ) return;      // (the caller promised a uniform batch of this shape: never true)
+  if( j.w != SPR * 8 || j.ss != SS || j.items > itemsMax || ( j.items & 7 ) ) return;      // (the caller promised a uniform batch of this shape: never true)
 
   // original block -> LDS, item-major
   for( int it = slot; it < j.items; it += 16 )
   {
-    const Pel8 a = *reinterpret_cast<const Pel8 *>( j.org + ( long ) ( ( it / SPR ) << j.ss ) * j.orgStride + ( it % SPR ) * 8 );
+    const Pel8 a = *reinterpret_cast<const Pel8 *>( j.org + ( long ) ( ( it / SPR ) << SS ) * j.orgStride + ( it % SPR ) * 8 );
     so[it] = make_uint4( a.v[0], a.v[1], a.v[2], a.v[3] );
   }
 
@@ -1466,10 +1418,13 @@ __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( VTMHIP
   mx = div_pow2( prec_down( mx, 2 ), 2 );
   my = div_pow2( prec_down( my, 2 ), 2 );
   const int m = mg::num_extra( mj );
-  int  eh = 0, ev = 0;
-  bool efirst = slot < m;
-  if( m > 0 )
+  int  cx = slot == 0 ? mx : 0, cy = slot == 0 ? my : 0, cnr = 0, cdist = 0;
+  bool cv = slot == 0 || ( slot == 1 && !fast && ( mx != 0 || my != 0 ) );
+  bool e15 = false;
+  if( m > 0 )      // (row-uniform)
   {
+    int  eh = 0, ev = 0;
+    bool efirst = slot < m;
     if( slot < m ) { eh = mj.extraStart[slot][0]; ev = mj.extraStart[slot][1]; }
     for( int k = 0; k + 1 < m; k++ )      // (row-uniform trip count)
     {
@@ -1478,107 +1433,146 @@ __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( VTMHIP
     }
     clip_mv( j, eh, ev );
     eh = prec_down( eh, 4 ); ev = prec_down( ev, 4 );
+    e15 = m > 14 && row_read( efirst ? 1 : 0, lane, 14 ) != 0;      // entry 14 (lane 14 of the row): the second round
+    // entries 0 .. 13 move two lanes up
+    const int  sh = row_read( eh, lane, ( slot + 14 ) & 15 ), sv = row_read( ev, lane, ( slot + 14 ) & 15 );
+    const bool sf = row_read( efirst ? 1 : 0, lane, ( slot + 14 ) & 15 ) != 0;
+    if( slot >= 2 ) { cx = sh; cy = sv; cv = sf; }
   }
-  // entry 14 (lane 14 of the row) for the second round
-  const int  e15x = m > 14 ? row_read( eh, lane, 14 ) : 0, e15y = m > 14 ? row_read( ev, lane, 14 ) : 0;
-  const bool e15  = m > 14 && row_read( efirst ? 1 : 0, lane, 14 ) != 0;
-  // entries 0 .. 13 move two lanes up
-  const int  sh = row_read( eh, lane, ( slot + 14 ) & 15 ), sv = row_read( ev, lane, ( slot + 14 ) & 15 );
-  const bool sf = row_read( efirst ? 1 : 0, lane, ( slot + 14 ) & 15 ) != 0;
-  int  cx, cy, cnr = 0, cdist = 0;
-  bool cv;
-  if( slot == 0 ) { cx = mx; cy = my; cv = true; }
-  else if( slot == 1 ) { cx = 0; cy = 0; cv = !fast && ( mx != 0 || my != 0 ); }
-  else { cx = sh; cy = sv; cv = sf; }
 
-  job_sync<1>();      // the row's original block is in LDS (DS operations of a wave execute in order)
+  // lane constants of the diamond rounds (xTZ8PointDiamondSearch :504-705): the slot-th point of a round's list, as 4-bit fields
+  //   bits  0 ..  7  distance 1:      (x, y) offsets of (left, top) (sx, top) (right, top) (left, sy) (right, sy) (left, bot) (sx, bot) (right, bot); the corners only with the
+  //                                   extended settings -- never here; point number slot + 1
+  //   bits  8 .. 15  distance 2 .. 8: in units of d / 2: (sx, top, 2) (left2, top2, 1) (right2, top2, 3) (left, sy, 4) (right, sy, 5) (left2, bot2, 6) (right2, bot2, 8) (sx, bot, 7)
+  //   bits 16 .. 23  distance > 8:    in units of d / 4: (sx, top) (left, sy) (right, sy) (sx, bot), then for i = 1 .. 3: (xl, yt) (xr, yt) (xl, yb) (xr, yb) along the diamond's edges
+  //   bits 24 .. 27  point number of the distance 2 .. 8 class; bit 28 / 29: the slot has a point at distance 1 / 2 .. 8; bit 30: that point reports distance d / 2
+  unsigned lc;
+  {
+    const int  u1x = slot == 1 || slot == 6 ? 0 : ( slot == 0 || slot == 3 || slot == 5 ? -1 : 1 ), u1y = slot < 3 ? -1 : slot < 5 ? 0 : 1;
+    int  u2x, u2y, n2;
+    bool half;
+    tzg_mid_point( slot, u2x, u2y, n2, half );
+    const int  i4 = ( ( slot - 4 ) >> 2 ) + 1, m4 = ( slot - 4 ) & 3;
+    const int  u4x = slot < 4 ? ( slot == 1 ? -4 : slot == 2 ? 4 : 0 ) : ( ( m4 & 1 ) ? i4 : -i4 );
+    const int  u4y = slot < 4 ? ( slot == 0 ? -4 : slot == 3 ? 4 : 0 ) : ( ( m4 & 2 ) ? 4 - i4 : -( 4 - i4 ) );
+    lc = ( unsigned ) ( u1x & 15 ) | ( unsigned ) ( u1y & 15 ) << 4 | ( unsigned ) ( u2x & 15 ) << 8 | ( unsigned ) ( u2y & 15 ) << 12 | ( unsigned ) ( u4x & 15 ) << 16 | ( unsigned ) ( u4y & 15 ) << 20
+         | ( unsigned ) n2 << 24 | ( slot < 8 && ( u1x == 0 || u1y == 0 ) ? 1u << 28 : 0u ) | ( slot < 8 ? 1u << 29 : 0u ) | ( half ? 1u << 30 : 0u );
+  }
 
+  // SPECULATIVE first round.  The first diamond loop's rounds at distance 1 and 2 are always evaluated (xTZSearch stops it after three rounds without a new best point at the
+  // earliest) and their points depend only on the start round's winner -- nearly always rcMv, the predictor.  So when the start round has at most four candidates the row's other
+  // twelve lanes evaluate the distance-1 points (lanes 4 .. 7) and the distance-2 points (lanes 8 .. 15) around rcMv in the SAME round; if rcMv wins the start round, the two
+  // diamond rounds are replayed from their minima with the reference's accept rule and the search goes on at distance 4: two dependent round trips less.  Otherwise the
+  // speculative costs are dropped (and not counted) and the search proceeds as usual.
   TzState s;
   s.bestSad = ~0ull; s.bestX = 0; s.bestY = 0; s.pointNr = 0; s.bestDist = 0; s.bestRound = 0; s.nEval = 0;
   s.sr.left = s.sr.right = s.sr.top = s.sr.bottom = 0;
+  bool spec = VTMHIP_TZG_SPEC && m <= 2 && searchRange >= 2 && j.tiny;      // (row-uniform)
+  if( spec )
+  {
+    s.sr = search_range( j, mx << 4, my << 4, searchRange >> ( fast ? 1 : 0 ) );      // what the loop's entry computes when rcMv wins
+    if( slot >= 4 )
+    {
+      int dx, dy;
+      if( slot < 8 )      // (sx, top, 2) (left, sy, 4) (right, sy, 5) (sx, bot, 7)
+      {
+        const int t = slot - 4;
+        dx = t == 1 ? -1 : t == 2 ? 1 : 0; dy = t == 0 ? -1 : t == 3 ? 1 : 0;
+        cnr = t == 0 ? 2 : t == 1 ? 4 : t == 2 ? 5 : 7; cdist = 1;
+      }
+      else
+      {
+        bool half;
+        tzg_mid_point( slot - 8, dx, dy, cnr, half );
+        cdist = half ? 1 : 2;
+      }
+      cx = mx + dx; cy = my + dy;
+      cv = ( dx >= 0 || cx >= s.sr.left ) && ( dx <= 0 || cx <= s.sr.right ) && ( dy >= 0 || cy >= s.sr.top ) && ( dy <= 0 || cy <= s.sr.bottom );
+    }
+  }
+
+  job_sync<1>();      // the row's original block is in LDS (DS operations of a wave execute in order)
+
   int  phase = GP_START, d = 0, startX = 0, startY = 0;
   bool touch = true, listed = false;
-  int  winX = 0, winY = 0, winSkew = -1;      // the LDS window's first sample / the byte offset of that sample in its row (-1: no window yet)
 
   for( ;; )
   {
     // ---- the round: every lane its candidate, the row's first strict minimum, xTZSearchHelp's accept rule (:397-417)
     {
-      // idle lanes re-read the start point (in the window) / the best point (a valid address)
-      const int  ex = cv ? cx : ( winSkew >= 0 ? startX : s.bestX ), ey = cv ? cy : ( winSkew >= 0 ? startY : s.bestY );
-      const bool inWin = winSkew >= 0 && ( unsigned ) ( ex - winX ) <= 2u * TZG_R && ( unsigned ) ( ey - winY ) <= 2u * TZG_R;
-      unsigned   sad;
-      if( inWin ) sad = grp_sad_win<SPR, SS>( win + ( ey - winY ) * TzgWin<SPR>::PITCH + winSkew + ( ex - winX ) * 2, so, j.items );
-      else sad = grp_sad<SPR>( j, so, ex, ey );
-      const unsigned long long c   = ( ( unsigned long long ) sad << j.ss ) + mv_cost( j, cx, cy );
+      const unsigned           sad = grp_sad<SPR, SS>( j, so, cv ? cx : s.bestX, cv ? cy : s.bestY );      // idle lanes re-read the best point (a valid address)
+      const unsigned long long c   = ( ( unsigned long long ) sad << SS ) + mv_cost( j, cx, cy );
+      const unsigned vrow = ( unsigned ) ( __ballot( cv ) >> ( lane & 48 ) ) & 0xffffu;      // the row's lanes with a candidate
+      const int      myXy = ( cx & 0xffff ) | ( cy << 16 ), myNd = cnr | ( cdist << 8 );
+      if( spec )      // (row-uniform; the first round only)
+      {
+        spec = false;
+        unsigned k = cv ? ( ( unsigned ) c << 4 ) | ( unsigned ) slot : 0xffffffffu;      // (j.tiny: cost < 2^26)
+        k = min( k, dpp_u32<DPP_XOR1>( k ) );
+        k = min( k, dpp_u32<DPP_XOR2>( k ) );
+        const unsigned kq = k;                                                              // minimum of the lane's quad
+        const unsigned k8 = min( k, dpp_u32<DPP_HALF_MIRROR>( k ) );                        // ... of its eight lanes
+        const unsigned kS = ( unsigned ) row_read( ( int ) kq, lane, 0 ), k1 = ( unsigned ) row_read( ( int ) kq, lane, 4 ), k2 = ( unsigned ) row_read( ( int ) k8, lane, 8 );
+        const int xyS = row_read( myXy, lane, ( int ) ( kS & 15u ) );
+        const int xy1 = row_read( myXy, lane, ( int ) ( k1 & 15u ) ), nd1 = row_read( myNd, lane, ( int ) ( k1 & 15u ) );
+        const int xy2 = row_read( myXy, lane, ( int ) ( k2 & 15u ) ), nd2 = row_read( myNd, lane, ( int ) ( k2 & 15u ) );
+        // the start round (slot 0 always has a candidate): best = its first strict minimum, distance / point number / round counter 0
+        s.bestSad = kS >> 4; s.bestX = ( int ) ( short ) ( xyS & 0xffff ); s.bestY = xyS >> 16;
+        s.nEval   = ( unsigned ) __popc( vrow & 0xfu );
+        if( ( kS & 15u ) == 0 )
+        {
+          // rcMv won: the rounds at distance 1 and 2 around it, as the loop would have run them (round counter + 1, then the accept rule)
+          startX = s.bestX; startY = s.bestY;
+          s.nEval += ( unsigned ) __popc( vrow & 0xfff0u );
+          s.bestRound = 1;
+          if( k1 != 0xffffffffu && ( unsigned long long ) ( k1 >> 4 ) < s.bestSad )
+          {
+            s.bestSad = k1 >> 4; s.bestX = ( int ) ( short ) ( xy1 & 0xffff ); s.bestY = xy1 >> 16; s.bestDist = ( unsigned ) ( nd1 >> 8 ); s.bestRound = 0; s.pointNr = nd1 & 0xff;
+          }
+          s.bestRound += 1;
+          if( k2 != 0xffffffffu && ( unsigned long long ) ( k2 >> 4 ) < s.bestSad )
+          {
+            s.bestSad = k2 >> 4; s.bestX = ( int ) ( short ) ( xy2 & 0xffff ); s.bestY = xy2 >> 16; s.bestDist = ( unsigned ) ( nd2 >> 8 ); s.bestRound = 0; s.pointNr = nd2 & 0xff;
+          }
+          phase = GP_DIA1; d = 2;      // (the round at distance 2 of the first loop is done)
+        }
+      }
+      else
+      {
       unsigned long long minCost;
       unsigned           minKey;
       row_argmin<true>( j, c, cv, ( unsigned ) slot, minCost, minKey );
-      const unsigned long long vb = __ballot( cv );
-      s.nEval += ( unsigned ) __popc( ( unsigned ) ( vb >> ( lane & 48 ) ) & 0xffffu );
-      const int pxy = row_read( ( cx & 0xffff ) | ( cy << 16 ), lane, ( int ) ( minKey & 15u ) );
-      const int pnd = row_read( cnr | ( cdist << 8 ), lane, ( int ) ( minKey & 15u ) );
-      if( minCost < s.bestSad )      // (minCost == ~0: no candidate in the round)
-      {
-        s.bestSad = minCost;
-        s.bestX   = ( int ) ( short ) ( pxy & 0xffff );
-        s.bestY   = pxy >> 16;
-        if( touch ) { s.bestDist = ( unsigned ) ( pnd >> 8 ); s.bestRound = 0; s.pointNr = pnd & 0xff; }
+      s.nEval += ( unsigned ) __popc( vrow );
+      const int pxy = row_read( myXy, lane, ( int ) ( minKey & 15u ) );
+      const int pnd = row_read( myNd, lane, ( int ) ( minKey & 15u ) );
+      const bool acc = minCost < s.bestSad;      // (minCost == ~0: no candidate in the round)
+      s.bestSad   = acc ? minCost : s.bestSad;
+      s.bestX     = acc ? ( int ) ( short ) ( pxy & 0xffff ) : s.bestX;
+      s.bestY     = acc ? pxy >> 16 : s.bestY;
+      s.bestDist  = acc && touch ? ( unsigned ) ( pnd >> 8 ) : s.bestDist;
+      s.bestRound = acc && touch ? 0u : s.bestRound;
+      s.pointNr   = acc && touch ? ( pnd & 0xff ) : s.pointNr;
       }
     }
-    // ---- what comes next (xTZSearch :3765-3971 without the extended settings)
-    bool enterDia1 = false, afterLoop1 = false, rasterDecision = false, afterLoop2 = false, enterStar = false, done = false;
-    touch = true;
-    if( phase == GP_START )
-    {
-      if( e15 ) { phase = GP_START15; touch = false; }
-      else enterDia1 = true;
-    }
-    else if( phase == GP_START15 ) enterDia1 = true;
-    else if( phase == GP_DIA1 )
-    {
-      if( ( firstStop && s.bestRound >= 3 ) || 2 * d > searchRange ) afterLoop1 = true;
-      else d *= 2;
-    }
-    else if( phase == GP_TWO1 ) rasterDecision = true;
-    else if( phase == GP_DIA2 )
-    {
-      if( ( fast && s.bestRound >= 2 ) || 2 * d > searchRange ) afterLoop2 = true;
-      else d *= 2;
-    }
-    else enterStar = true;      // GP_TWO2
-    if( enterDia1 )
+    // ---- what comes next (xTZSearch :3765-3971 without the extended settings), as conditions rather than branches: the four rows of a wave are in whatever phase each is in
+    const bool isS = phase == GP_START, isS15 = phase == GP_START15, isD1 = phase == GP_DIA1, isT1 = phase == GP_TWO1, isD2 = phase == GP_DIA2, isT2 = phase == GP_TWO2;
+    const bool more   = 2 * d <= searchRange;                                        // the diamond loops' `d *= 2` stays inside the range
+    const bool end1   = isD1 && ( ( firstStop && s.bestRound >= 3 ) || !more );      // first loop (:3765-3772)
+    const bool end2   = isD2 && ( ( fast && s.bestRound >= 2 ) || !more );           // a star refinement's loop (:3944-3951)
+    const bool toS15  = isS && e15;
+    const bool enter1 = ( isS && !e15 ) || isS15;
+    if( enter1 )
     {
       s.sr   = search_range( j, s.bestX << 4, s.bestY << 4, searchRange >> ( fast ? 1 : 0 ) );
       startX = s.bestX; startY = s.bestY;
-      d      = 1;
-      phase  = GP_DIA1;
-      if( searchRange < 1 ) afterLoop1 = true;      // (an empty first loop)
-      else if( ( j.refStride & 7 ) == 0 )
-      {
-        // the window around the start point -> LDS: rows winY .. winY + h + 2 R - 1 (clamped to the rows a block may touch: the clipped vectors keep every tested candidate
-        // inside them, and the plane has no samples beyond), CH aligned chunks per row from the 16-byte boundary below the row's first sample (the rows' pitch is a multiple
-        // of 16 bytes, so the offset of that sample in its chunk -- winSkew -- is the same in every row)
-        winX = startX - TZG_R; winY = startY - TZG_R;
-        const int yLo = j.verMin >> 4, yHi = ( j.verMax >> 4 ) + j.h - 1, nrows = j.h + 2 * TZG_R;
-        const uintptr_t a0 = reinterpret_cast<uintptr_t>( j.ref + ( long ) winY * j.refStride + winX );
-        winSkew = ( int ) ( a0 & 15 );
-        for( int idx = slot; idx < nrows * TzgWin<SPR>::CH; idx += 16 )
-        {
-          const int r = idx / TzgWin<SPR>::CH, c = idx - r * TzgWin<SPR>::CH;
-          const int yy = min( max( winY + r, yLo ), yHi );
-          const uintptr_t a = ( reinterpret_cast<uintptr_t>( j.ref + ( long ) yy * j.refStride + winX ) & ~( uintptr_t ) 15 ) + ( uintptr_t ) c * 16;
-          *reinterpret_cast<uint4 *>( win + r * TzgWin<SPR>::PITCH + c * 16 ) = *reinterpret_cast<const uint4 *>( a );
-        }
-        job_sync<1>();      // (the row's lanes read each other's chunks: DS operations of a wave execute in order)
-      }
     }
-    if( afterLoop1 )
-    {
-      if( s.bestDist == 1 ) { s.bestDist = 0; phase = GP_TWO1; }
-      else rasterDecision = true;
-    }
-    if( rasterDecision )
+    const bool after1 = end1 || ( enter1 && searchRange < 1 );
+    const bool toT1   = after1 && s.bestDist == 1;                                   // :3790-3794
+    const bool rdec   = ( after1 && !toT1 ) || isT1;                                 // the raster decision (:3872)
+    const bool toT2   = end2 && s.bestDist == 1 && s.pointNr != 0;                   // :3953-3960
+    if( toT1 || ( end2 && s.bestDist == 1 ) ) s.bestDist = 0;
+    bool star = ( end2 && !toT2 ) || isT2;                                           // back at the star loop's condition (:3937)
+    if( rdec )
     {
       if( ( int ) s.bestDist >= iRaster )
       {
@@ -1605,7 +1599,6 @@ __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( VTMHIP
             g->intMv2Nx2NPredHor = t2.intMv2Nx2NPredHor; g->intMv2Nx2NPredVer = t2.intMv2Nx2NPredVer; g->numExtraStart = 0;
           }
           listed = true;
-          done   = true;
         }
         else
         {
@@ -1616,7 +1609,7 @@ __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( VTMHIP
           for( int k = slot; k < total; k += 16 )
           {
             const int ry = k / nx, rx = k - ry * nx, x = s.sr.left + rx * iRaster, y = s.sr.top + ry * iRaster;
-            const unsigned long long c = ( ( unsigned long long ) grp_sad<SPR>( j, so, x, y ) << j.ss ) + mv_cost( j, x, y );
+            const unsigned long long c = ( ( unsigned long long ) grp_sad<SPR, SS>( j, so, x, y ) << SS ) + mv_cost( j, x, y );
             if( c < bc ) { bc = c; bk = ( unsigned ) k; }
           }
           unsigned long long rc;
@@ -1628,76 +1621,41 @@ __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( VTMHIP
             const int ry = ( int ) rk / nx, rx = ( int ) rk - ry * nx;
             s.bestSad = rc; s.bestX = s.sr.left + rx * iRaster; s.bestY = s.sr.top + ry * iRaster; s.bestDist = ( unsigned ) iRaster; s.bestRound = 0; s.pointNr = 0;
           }
-          enterStar = true;
         }
       }
-      else enterStar = true;
+      star = true;
     }
-    if( afterLoop2 )
-    {
-      if( s.bestDist == 1 )
-      {
-        s.bestDist = 0;
-        if( s.pointNr != 0 ) phase = GP_TWO2;
-        else enterStar = true;
-      }
-      else enterStar = true;
-    }
-    if( enterStar )
-    {
-      if( s.bestDist > 0 )      // star refinement (:3937-3971)
-      {
-        startX = s.bestX; startY = s.bestY;
-        s.bestDist = 0; s.pointNr = 0;
-        d     = 1;
-        phase = GP_DIA2;
-        if( searchRange < 1 ) done = true;      // (an empty loop body: bestDist stays 0)
-      }
-      else done = true;
-    }
-    if( done ) break;
+    const bool go2 = star && !listed && s.bestDist > 0 && searchRange >= 1;      // another star refinement (:3937-3971)
+    if( listed || ( star && !go2 ) ) break;
+    startX     = go2 ? s.bestX : startX;
+    startY     = go2 ? s.bestY : startY;
+    s.bestDist = go2 ? 0u : s.bestDist;
+    s.pointNr  = go2 ? 0 : s.pointNr;
+    d          = ( enter1 || go2 ) ? 1 : ( ( isD1 && !end1 ) || ( isD2 && !end2 ) ) ? 2 * d : d;
+    phase      = toS15 ? GP_START15 : toT1 ? GP_TWO1 : toT2 ? GP_TWO2 : go2 ? GP_DIA2 : enter1 ? GP_DIA1 : phase;
+    touch      = !toS15;
 
     // ---- the next round's candidate of this lane
-    if( phase == GP_START15 )
+    if( phase == GP_DIA1 || phase == GP_DIA2 )
     {
-      cx = e15x; cy = e15y; cnr = 0; cdist = 0; cv = slot == 0;
-    }
-    else if( phase == GP_DIA1 || phase == GP_DIA2 )
-    {
-      // xTZ8PointDiamondSearch (:504-705): offsets of the slot-th point of the round at distance d, its point number and the distance it reports
       s.bestRound += 1;
-      int dx, dy;
-      cnr = 0; cdist = d;
-      bool on = true;
-      if( d == 1 )
-      {
-        // (left, top) (sx, top) (right, top) (left, sy) (right, sy) (left, bot) (sx, bot) (right, bot); the corners only with the extended settings -- not here
-        dx = slot == 1 || slot == 6 ? 0 : ( slot == 0 || slot == 3 || slot == 5 ? -1 : 1 );
-        dy = slot < 3 ? -1 : slot < 5 ? 0 : 1;
-        cnr = slot + 1;
-        on  = slot < 8 && ( dx == 0 || dy == 0 );
-      }
-      else if( d <= 8 )
-      {
-        // (sx, top, 2) (left2, top2, 1) (right2, top2, 3) (left, sy, 4) (right, sy, 5) (left2, bot2, 6) (right2, bot2, 8) (sx, bot, 7)
-        const int  h2 = d >> 1;
-        const bool half = slot == 1 || slot == 2 || slot == 5 || slot == 6;
-        dx = slot == 0 || slot == 7 ? 0 : ( half ? ( slot & 1 ? -h2 : h2 ) : ( slot == 3 ? -d : d ) );
-        dy = slot == 3 || slot == 4 ? 0 : ( half ? ( slot < 3 ? -h2 : h2 ) : ( slot == 0 ? -d : d ) );
-        cnr   = slot == 0 ? 2 : slot == 1 ? 1 : slot == 2 ? 3 : slot == 3 ? 4 : slot == 4 ? 5 : slot == 5 ? 6 : slot == 6 ? 8 : 7;
-        cdist = half ? h2 : d;
-        on    = slot < 8;
-      }
-      else
-      {
-        // (sx, top) (left, sy) (right, sy) (sx, bot), then for i = 1 .. 3: (xl, yt) (xr, yt) (xl, yb) (xr, yb) with q = d / 4 steps along the diamond's edges
-        const int q = d >> 2, i = ( ( slot - 4 ) >> 2 ) + 1, mm = ( slot - 4 ) & 3;
-        if( slot < 4 ) { dx = slot == 1 ? -d : slot == 2 ? d : 0; dy = slot == 0 ? -d : slot == 3 ? d : 0; }
-        else { dx = ( mm & 1 ) ? q * i : -q * i; dy = ( mm & 2 ) ? d - q * i : -( d - q * i ); }
-      }
-      cx = startX + dx; cy = startY + dy;
+      const int      cls = d == 1 ? 0 : d <= 8 ? 1 : 2;                         // the three forms of the pattern; their offsets count in units of 1, d / 2, d / 4
+      const int      unit = d >> cls;
+      const unsigned f = lc >> ( cls * 8 );
+      const int      dx = ( ( int ) ( f << 28 ) >> 28 ) * unit, dy = ( ( int ) ( f << 24 ) >> 28 ) * unit;
+      cx    = startX + dx; cy = startY + dy;
+      cnr   = cls == 0 ? slot + 1 : cls == 1 ? ( int ) ( ( lc >> 24 ) & 15u ) : 0;
+      cdist = cls == 1 && ( lc & ( 1u << 30 ) ) ? d >> 1 : d;
+      const bool on = cls == 0 ? ( lc & ( 1u << 28 ) ) != 0 : cls == 1 ? ( lc & ( 1u << 29 ) ) != 0 : true;
       // a point is tested when it lies inside the search range on the side(s) it moved to (the checks of :510-700, which test exactly those sides)
       cv = on && ( dx >= 0 || cx >= s.sr.left ) && ( dx <= 0 || cx <= s.sr.right ) && ( dy >= 0 || cy >= s.sr.top ) && ( dy <= 0 || cy <= s.sr.bottom );
+    }
+    else if( phase == GP_START15 )
+    {
+      // m_uniMvList entry 14, on the row's first lane
+      int ex = mj.extraStart[14][0], ey = mj.extraStart[14][1];
+      clip_mv( j, ex, ey );
+      cx = prec_down( ex, 4 ); cy = prec_down( ey, 4 ); cnr = 0; cdist = 0; cv = slot == 0;
     }
     else
     {
@@ -1724,7 +1682,6 @@ __global__ __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( VTMHIP
     results[jobIdx] = r;
   }
 }
-
 
 // ---- exhaustive search (InterSearch::xPatternSearch :3566-3608 after xSetSearchRange :3496-3563): the bi-predictive
 // refinement of xMotionEstimation (:3385-3440, +-BipredSearchRange around the current vector).  One wave per job.
@@ -2082,15 +2039,14 @@ int vtmhip_internal_tz_search( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, co
   if( grpItems )
   {
     VTMHIP_TIME_KERNEL( ctx, "tz_group_kernel" );
-    const int  spr = uniformW >> 3, winRows = uniformH + 2 * TZG_R;
-    const int  pitch = spr == 1 ? TzgWin<1>::PITCH : spr == 2 ? TzgWin<2>::PITCH : TzgWin<4>::PITCH;
-    const size_t lds = ( size_t ) 16 * ( ( size_t ) grpItems * 16 + ( size_t ) winRows * pitch );
+    const int    spr = uniformW >> 3;
+    const size_t lds = ( size_t ) 16 * grpItems * 16;
     const dim3   grid( ( n + 15 ) / 16 );
     const int    md = split ? 1 : 0;
 #define VTMHIP_TZG_LAUNCH( SPR, SS )                                                                                                                                        \
   {                                                                                                                                                                         \
     if( lds > 48 * 1024 ) VTMHIP_HIP( ctx, hipFuncSetAttribute( reinterpret_cast<const void *>( tz_group_kernel<SPR, SS> ), hipFuncAttributeMaxDynamicSharedMemorySize, ( int ) lds ) ); \
-    hipLaunchKernelGGL( ( tz_group_kernel<SPR, SS> ), grid, dim3( 256 ), lds, ctx->stream, *pic, d_orgBase, d_refBase, n, d_results, md, d_saved, d_list, totCap, grpItems, winRows, fuFirst ); \
+    hipLaunchKernelGGL( ( tz_group_kernel<SPR, SS> ), grid, dim3( 256 ), lds, ctx->stream, *pic, d_orgBase, d_refBase, n, d_results, md, d_saved, d_list, totCap, grpItems, fuFirst ); \
   }
     if( spr == 1 && grpSs == 0 ) VTMHIP_TZG_LAUNCH( 1, 0 )
     else if( spr == 1 ) VTMHIP_TZG_LAUNCH( 1, 1 )
