@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--shard", choices=["ctu", "row"], default="ctu", help="--gpus N: raster-scan CTU ranges (balanced) or whole CTU rows")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-encoder-level", action="store_true", help="skip cpu_baseline.encoder_level (the real reference encoder, plain vs predInterSearch on the device, on a small clip: ~40 s)")
     ap.add_argument("--partition", choices=["qt", "btt"], default="qt", help="qt: the five quadtree levels 128 .. 8 (the headline workload); btt: a binary / ternary "
                     "split mix -- 128x128, 64x64, 64x32, 32x32, 32x16, 16x16, 16x8, 8x8 -- through the rectangular fast paths")
     ap.add_argument("--smvd", action="store_true", help="add the symmetric-MVD block of predInterSearch (one search per PU between the bi refinement and the uni / bi decision; ra only)")
@@ -160,6 +161,35 @@ def cpu_baseline(hp, cur_np, dpb_np, refs, sr, W, H, lam, qp, budget_s, pocs=Non
             "sample": "%d PUs (%s) of the same picture through the whole chain, per-level time extrapolated to all %d PUs; %d mismatches vs GPU"
                       % (done, " ".join(detail), sum(l["npu"] for l in snaps), mism),
             "seconds_per_picture": total_s, "mismatches_vs_gpu": mism}
+
+
+def encoder_level():
+    """BASELINE metric (1), encoded frames/s, on a BOUNDED sample: the real VTM 9.3 encoder (oracle/_ref/libvtmref.so, compiled in place from /root/reference; present only when
+    it travelled with the repo) encodes a 192x128 x 5-picture synthetic random-access clip twice in child processes -- plain on one host core, and with
+    InterSearch::predInterSearch routed to the device as one vtmhip_predInterSearch_batch_dev call per CU (+ xAffineMotionEstimation; the reference's own glue replayed over the device
+    tables: oracle/ref_shim_pis.hpp, test infrastructure).  Reported beside the hot-path metric, never part of `value`."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tempfile
+    import enc_dropin
+    if not (os.path.exists(enc_dropin.REF_SO) and os.path.exists(enc_dropin.HIP_SO)):
+        return None
+    W, H, N, qp = 192, 128, 5, 32
+    with tempfile.TemporaryDirectory() as tmp:
+        yuv = os.path.join(tmp, "clip.yuv")
+        enc_dropin.write_clip(yuv, W, H, N)
+        t = time.time()
+        st0, bits0, rec0 = enc_dropin.encode(yuv, W, H, N, qp, os.path.join(tmp, "plain"), False, 2048 | 8, 1, 0, timeout=600)
+        plain_s = time.time() - t
+        t = time.time()
+        st1, bits1, rec1 = enc_dropin.encode(yuv, W, H, N, qp, os.path.join(tmp, "rep"), True, 2048 | 128, 1, 0, env={"VTMREF_REPLACE": "1"}, timeout=600)
+        rep_s = time.time() - t
+    in_member = sum(st0["pis"]["seconds"])
+    return {"metric": "encoded frames/s (BASELINE metric 1), one CU per device call", "clip": "%dx%d synthetic, %d pictures, QP %d, tests/data/enc_ra_gop4.cfg" % (W, H, N, qp),
+            "encoded_fps_plain_1_core": N / plain_s, "encoded_fps_predInterSearch_on_device": N / rep_s, "speedup": plain_s / rep_s,
+            "identical_bitstream_and_reconstruction": bits0 == bits1 and rec0 == rec1, "predInterSearch_calls": st1["pis"]["calls"], "calls_on_device": st1["pis"]["device"],
+            "mismatches": sum(st1["pis"]["mismatch"]), "predInterSearch_share_of_plain_run": in_member / plain_s,
+            "amdahl_bound_if_predInterSearch_were_free": 1.0 / (1.0 - in_member / plain_s),
+            "note": "process start, clip input and the library's start-up are inside both times; profiles/r04_encoder_replace_*.json hold the 416x240 (reference RA cfg) and 1920x1080 runs"}
 
 
 def load_json(name):
@@ -574,6 +604,11 @@ def main():
             del host, stage
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fme, cur_np, dpb_np, refs, sr, W, H, lam, qp, a.cpu_seconds, pocs=poc_arg, chroma=ch_cpu, affine=a.affine, low_delay=a.config == "ldp", smvd=smvd)
+            if not a.no_encoder_level:
+                try:
+                    out["cpu_baseline"]["encoder_level"] = encoder_level()
+                except Exception as e:      # a reported side figure: never fails the line
+                    out["cpu_baseline"]["encoder_level"] = {"error": str(e)[-400:]}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()

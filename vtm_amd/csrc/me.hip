@@ -938,12 +938,9 @@ __global__ __launch_bounds__( 256 ) void tz_raster_cols_kernel( vtmhip_pic_param
 
 // WPJ = 1: 256 threads = 4 independent jobs.  WPJ > 1: 64 * WPJ threads = 1 job.
 template<int WPJ>
-__global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) __attribute__( ( amdgpu_waves_per_eu( WPJ == 2 || WPJ == 4 || WPJ == 8 ? 4 : 1 ) ) )      // two / four / eight waves per search sit at 129 .. 131 VGPRs: a register or two over the four-waves-per-SIMD budget
-void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase,
-                                                                                const int16_t *__restrict__ refBase,
-                                                                                const vtmhip_tz_job *__restrict__ jobs, int numJobs,
-                                                                                vtmhip_me_result *__restrict__ results, int mode, TzSaved *__restrict__ saved,
-                                                                                int *__restrict__ list, int totCap, MeFuse fu )
+__device__ __forceinline__ void tz_search_one( const vtmhip_pic_params &pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase,
+                                               const vtmhip_tz_job *__restrict__ jobs, int numJobs, vtmhip_me_result *__restrict__ results, int mode, TzSaved *__restrict__ saved,
+                                               int *__restrict__ list, int totCap, const MeFuse &fu, int blockIdxX, int gridDimX )
 {
   // mode 0: the whole search.  Split launches: mode 1 stops at the raster decision of jobs tz_raster_cols_kernel can take (state -> saved[], job
   // index -> list[]; every other job runs to the end here); mode 2 resumes the listed jobs after the scan.
@@ -953,7 +950,7 @@ void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBas
   __shared__ unsigned           sRedIdx[WPJ];
   __shared__ __attribute__( ( aligned( 16 ) ) ) int16_t sOrgLds[WPJ >= 4 ? ORG_LDS_CAP : WPJ == 2 ? ORG_LDS_CAP2 : 8];
   const int lane = threadIdx.x & 63, wv = uni( ( int ) ( threadIdx.x >> 6 ) );
-  const int blk    = mode == 2 ? ( int ) blockIdx.x : xcd_order( ( int ) blockIdx.x, ( int ) gridDim.x );
+  const int blk    = mode == 2 ? blockIdxX : xcd_order( blockIdxX, gridDimX );
   int       jobIdx = WPJ == 1 ? blk * 4 + wv : blk;
   if( mode == 2 )
   {
@@ -1259,6 +1256,23 @@ void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBas
     r.dist = s.bestSad - mv_cost( j, s.bestX, s.bestY );
     results[jobIdx] = r;
   }
+}
+
+template<int WPJ>
+__global__ __launch_bounds__( WPJ == 1 ? 256 : 64 * WPJ ) __attribute__( ( amdgpu_waves_per_eu( WPJ == 2 || WPJ == 4 || WPJ == 8 ? 4 : 1 ) ) )      // two / four / eight waves per search sit at 129 .. 131 VGPRs: a register or two over the four-waves-per-SIMD budget
+void tz_search_kernel( vtmhip_pic_params pic, const int16_t *__restrict__ orgBase, const int16_t *__restrict__ refBase, const vtmhip_tz_job *__restrict__ jobs, int numJobs,
+                       vtmhip_me_result *__restrict__ results, int mode, TzSaved *__restrict__ saved, int *__restrict__ list, int totCap, MeFuse fu )
+{
+  if( WPJ == 1 && mode == 2 )
+  {
+    // the resume launch of a level of small blocks: only the listed searches run (a few per cent of the level), and a grid of one workgroup per four searches of the LEVEL would be
+    // 130 000 workgroups that leave at once -- 50 us of a launch for nothing.  A bounded grid walks the list instead (the waves of a workgroup are independent searches here)
+    const int listed = uni( list[0] );
+    for( int b = ( int ) blockIdx.x; b * 4 < listed; b += ( int ) gridDim.x )
+      tz_search_one<WPJ>( pic, orgBase, refBase, jobs, numJobs, results, mode, saved, list, totCap, fu, b, ( int ) gridDim.x );
+    return;
+  }
+  tz_search_one<WPJ>( pic, orgBase, refBase, jobs, numJobs, results, mode, saved, list, totCap, fu, ( int ) blockIdx.x, ( int ) gridDim.x );
 }
 
 
@@ -2023,7 +2037,7 @@ int vtmhip_internal_tz_search( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, co
   case 4: VTMHIP_TZ_LAUNCH( 4, n, MODE ); break;                    \
   case 8: VTMHIP_TZ_LAUNCH( 8, n, MODE ); break;                    \
   case 16: VTMHIP_TZ_LAUNCH( 16, n, MODE ); break;                  \
-  default: VTMHIP_TZ_LAUNCH( 1, ( n + 3 ) / 4, MODE ); break;       \
+  default: VTMHIP_TZ_LAUNCH( 1, ( ( MODE ) == 2 && ( n + 3 ) / 4 > 2048 ? 2048 : ( n + 3 ) / 4 ), MODE ); break; \
   }
   // Uniform batches of small blocks (fused uni rows, no extended settings): four searches per wave, a lane per candidate (tz_group_kernel).  VTMHIP_TZ_GROUP=0: off;
   // VTMHIP_TZ_GROUP_ITEMS: the largest block in 8-sample segments after row sub-sampling (default 16: 8x8 .. 16x16)
