@@ -84,8 +84,10 @@ def main():
         for k, d in shape.items():
             if k.startswith("native"):
                 continue
+            if len(next(iter(d.values()))) < steps:      # not a launch of the step (the bench's one-off statistic passes, e.g. FrameHotPath.sad_candidates' table-driven searches)
+                continue
             e = {cnt: sum(v) / len(v) for cnt, v in d.items()}
-            e["launches_per_step"] = max(1, len(next(iter(d.values()))) // steps)
+            e["launches_per_step"] = len(next(iter(d.values()))) // steps
             if e.get("SQ_WAVES"):
                 e["valu_per_wave"] = e.get("SQ_INSTS_VALU", 0) / e["SQ_WAVES"]
                 e["salu_per_wave"] = e.get("SQ_INSTS_SALU", 0) / e["SQ_WAVES"]

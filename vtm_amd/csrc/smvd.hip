@@ -329,6 +329,9 @@ __global__ __launch_bounds__( THREADS ) void smvd_kernel( vtmhip_pic_params pic,
 // The integer phases run the same two passes with the taps {0,0,0,64,0,0,0,0}: for rounded uni-prediction that is exactly filterCopy / the single-pass forms
 // ((sum >> s) + 2^(h-1)) >> h == (sum + 32) >> 6 for sum = 2^s q + r.
 // =====================================================================================================================================
+#ifndef VTMHIP_SMVD_PREFETCH
+#define VTMHIP_SMVD_PREFETCH 1
+#endif
 struct TileFir { int shH, offH, shV, offV, cmax; };
 
 __device__ __forceinline__ void load_taps( int frac, bool alt, v2s c[4] )
@@ -348,10 +351,20 @@ __device__ __forceinline__ void pred_tile( const int16_t *__restrict__ ref, int 
   const int16_t *src = ref + ( long ) ( ( mvVer >> 4 ) - 3 ) * stride + ( mvHor >> 4 ) - 3;
   int      acc[64];
   unsigned prevH[4] = { 0, 0, 0, 0 };
+#if VTMHIP_SMVD_PREFETCH
+  // the next input row's two loads are issued BEFORE this row's filter work (the scheduling barrier at the end of a row keeps the compiler from hoisting all fifteen rows' loads --
+  // registers -- but it also kept every row's loads behind the previous row's arithmetic: a full memory latency per row at two waves per SIMD)
+  Pel8u na = *reinterpret_cast<const Pel8u *>( src ), nb = *reinterpret_cast<const Pel8u *>( src + 8 );
+#endif
 #pragma unroll
   for( int r = 0; r < 15; r++ )
   {
+#if VTMHIP_SMVD_PREFETCH
+    const Pel8u a = na, b = nb;
+    if( r < 14 ) { na = *reinterpret_cast<const Pel8u *>( src + ( long ) ( r + 1 ) * stride ); nb = *reinterpret_cast<const Pel8u *>( src + ( long ) ( r + 1 ) * stride + 8 ); }
+#else
     const Pel8u a = *reinterpret_cast<const Pel8u *>( src + ( long ) r * stride ), b = *reinterpret_cast<const Pel8u *>( src + ( long ) r * stride + 8 );
+#endif
     const unsigned d[8] = { a.v[0], a.v[1], a.v[2], a.v[3], b.v[0], b.v[1], b.v[2], b.v[3] };   // d[m] = samples (2m, 2m + 1)
     unsigned e[7];                                                                             // e[m] = samples (2m + 1, 2m + 2)
 #pragma unroll
@@ -478,9 +491,17 @@ __device__ __forceinline__ unsigned tile_eval( const TileJob &t, int tx, int ty,
   bx = min( t.horMax, max( t.horMin, bx ) ); by = min( t.verMax, max( t.verMin, by ) );
   const int16_t *org = t.org + ( long ) ( ty * 8 ) * t.orgStride + tx * 8;
   v2s D[8][4];
+#if VTMHIP_SMVD_PREFETCH
+  Pel8u onx = *reinterpret_cast<const Pel8u *>( org );      // the original block's rows arrive one output row ahead, like the reference rows in pred_tile
+#endif
   pred_tile( t.refA + ( long ) ( ty * 8 ) * t.strideA + tx * 8, t.strideA, ax, ay, t.alt, t.f, [&]( int y, const unsigned w[4] )
   {
+#if VTMHIP_SMVD_PREFETCH
+    const Pel8u o = onx;
+    if( y < 7 ) onx = *reinterpret_cast<const Pel8u *>( org + ( long ) ( y + 1 ) * t.orgStride );
+#else
     const Pel8u o = *reinterpret_cast<const Pel8u *>( org + ( long ) y * t.orgStride );
+#endif
 #pragma unroll
     for( int k = 0; k < 4; k++ )
     {
