@@ -177,9 +177,9 @@ def test_uniform_bi_fast_paths(ctx, size, bi, opts):
     assert got == exp
 
 
-@pytest.mark.parametrize("w,h", [(8, 8), (16, 16), (16, 8), (8, 16), (8, 32)])
+@pytest.mark.parametrize("w,h", [(8, 8), (16, 16), (16, 8), (8, 16), (8, 32), (32, 16), (16, 32), (32, 8)])
 def test_four_searches_per_wave_integer_kernel(ctx, w, h):
-    """tz_group_kernel (uniform all-uni batches of blocks up to 16 segments: a DPP row per search, a lane per candidate) on what its state machine has to get right:
+    """tz_group_kernel (uniform all-uni batches of blocks up to 32 segments: a DPP row per search, a lane per candidate) on what its state machine has to get right:
     0 .. 15 m_uniMvList entries with duplicates (the 15th in a round of its own, up to 4 start candidates beside the speculative distance-1 / -2 points, more without them),
     cached integer vectors (xTZSearch's fast settings: no zero candidate, halved range, raster distance 8, the star loop's early stop), search ranges 1 .. 192 (empty and
     one-round loops, raster scans listed for the column kernel), predictors far from the true motion (two-point steps and star refinements)."""

@@ -2040,9 +2040,10 @@ int vtmhip_internal_tz_search( vtmhip_ctx *ctx, const vtmhip_pic_params *pic, co
   default: VTMHIP_TZ_LAUNCH( 1, ( ( MODE ) == 2 && ( n + 3 ) / 4 > 2048 ? 2048 : ( n + 3 ) / 4 ), MODE ); break; \
   }
   // Uniform batches of small blocks (fused uni rows, no extended settings): four searches per wave, a lane per candidate (tz_group_kernel).  VTMHIP_TZ_GROUP=0: off;
-  // VTMHIP_TZ_GROUP_ITEMS: the largest block in 8-sample segments after row sub-sampling (default 16: 8x8 .. 16x16)
+  // VTMHIP_TZ_GROUP_ITEMS: the largest block in 8-sample segments after row sub-sampling (default 32: 8x8 .. 16x16 and the 32x16 / 16x32 split shapes -- `--partition btt` 17.57 -> 17.49 ms;
+  // 32x32, 64 segments, is faster with a wave per search: 0.21 against 0.26 ms)
   static const bool groupOn = !( getenv( "VTMHIP_TZ_GROUP" ) && atoi( getenv( "VTMHIP_TZ_GROUP" ) ) == 0 );
-  static const int  groupItems = getenv( "VTMHIP_TZ_GROUP_ITEMS" ) ? atoi( getenv( "VTMHIP_TZ_GROUP_ITEMS" ) ) : 16;
+  static const int  groupItems = getenv( "VTMHIP_TZ_GROUP_ITEMS" ) ? atoi( getenv( "VTMHIP_TZ_GROUP_ITEMS" ) ) : 32;
   int grpItems = 0, grpSs = 0;
   if( groupOn && fuse && fuse->me && !fuse->cfg.extendedSettings && ( wpj == 0 || wpj == 1 ) && ( uniformW == 8 || uniformW == 16 || uniformW == 32 ) && uniformH >= 8 )
   {
